@@ -1,0 +1,87 @@
+"""In-tree build of libcvhip.so (hipcc, gfx950 only). No torch involvement: the library is a plain
+C-ABI shared object (include/cvhip.h) loaded through ctypes.
+
+    python -m cvpytorch_amd.build [--force]
+"""
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libcvhip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+SOURCES = [
+    "api.hip",
+    "conv_igemm.hip",
+    "conv_wgrad.hip",
+    "bn_act.hip",
+    "pool_resize.hip",
+    "weights_optim.hip",
+    "dwconv.hip",
+    "post.hip",
+    "loss_kernels.hip",
+]
+FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    "-munsafe-fp-atomics",
+    "-Wall",
+    "-Wno-unused-function",
+]
+
+
+def _deps():
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(HERE, "..", "include", "cvhip.h"))
+    return hdrs
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _compile(src):
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    path = os.path.join(CSRC, src)
+    if not _newer(obj, [path] + _deps()):
+        return obj, None
+    cmd = [HIPCC] + FLAGS + ["-c", path, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    return obj, r.stderr
+
+
+def build_lib(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    if force:
+        for s in srcs:
+            o = os.path.join(OBJ, s.replace(".hip", ".o"))
+            if os.path.exists(o):
+                os.remove(o)
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        results = list(ex.map(_compile, srcs))
+    objs = [o for o, _ in results]
+    for (o, warn), s in zip(results, srcs):
+        if warn and verbose:
+            sys.stderr.write("[cvhip build] %s:\n%s\n" % (s, warn))
+    if force or _newer(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv))

@@ -1,0 +1,286 @@
+// api.hip — extern "C" entry points for convolution (+ host planning), error plumbing and the
+// hardware-layout probes. See include/cvhip.h for the contract of every symbol.
+#include <string.h>
+
+#include <string>
+
+#include "common.h"
+#include "conv_plan.h"
+
+namespace cvhip {
+
+static thread_local std::string g_last_error = "";
+
+void set_last_error(const char* what, hipError_t e) {
+  g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_last_error(what, e);
+    return CVHIP_ERR_LAUNCH;
+  }
+  return CVHIP_OK;
+}
+
+int validate_dense_desc(const cvhip_conv_desc* d) {
+  if (!d) return CVHIP_ERR_INVALID;
+  if (d->N <= 0 || d->C <= 0 || d->H <= 0 || d->W <= 0 || d->K <= 0 || d->R <= 0 || d->S <= 0) return CVHIP_ERR_INVALID;
+  if (d->stride_h <= 0 || d->stride_w <= 0 || d->dil_h <= 0 || d->dil_w <= 0 || d->pad_h < 0 || d->pad_w < 0)
+    return CVHIP_ERR_INVALID;
+  if (d->x_ld < d->C || d->y_ld < d->K) return CVHIP_ERR_INVALID;
+  if (d->groups != 1) return CVHIP_ERR_UNSUPPORTED;
+  // 16-byte channel vectors on the gathered operand: input channels and pitches multiple of 8
+  if ((d->C & 7) || (d->x_ld & 7)) return CVHIP_ERR_UNSUPPORTED;
+  if (d->stride_h * d->stride_w > kMaxClasses) return CVHIP_ERR_UNSUPPORTED;
+  const int P = conv_out_dim(d->H, d->pad_h, d->dil_h, d->R, d->stride_h);
+  const int Q = conv_out_dim(d->W, d->pad_w, d->dil_w, d->S, d->stride_w);
+  if (P <= 0 || Q <= 0) return CVHIP_ERR_INVALID;
+  // 32-bit pixel indexing inside the kernels
+  if ((int64_t)d->N * d->H * d->W >= (1ll << 31) || (int64_t)d->N * P * Q >= (1ll << 31)) return CVHIP_ERR_UNSUPPORTED;
+  return CVHIP_OK;
+}
+
+void plan_fprop(const cvhip_conv_desc* d, IgemmParams* p) {
+  memset(p, 0, sizeof(*p));
+  const int P = conv_out_dim(d->H, d->pad_h, d->dil_h, d->R, d->stride_h);
+  const int Q = conv_out_dim(d->W, d->pad_w, d->dil_w, d->S, d->stride_w);
+  p->NB = d->N;
+  p->IH = d->H;
+  p->IW = d->W;
+  p->Cin = d->C;
+  p->x_ld = d->x_ld;
+  p->in_sh = d->stride_h;
+  p->in_sw = d->stride_w;
+  p->Nout = d->K;
+  p->y_ld = d->y_ld;
+  p->OH = P;
+  p->OW = Q;
+  p->out_sh = 1;
+  p->out_sw = 1;
+  p->ncls = 1;
+  IgemmClass& c = p->cls[0];
+  c.TR = d->R;
+  c.TS = d->S;
+  c.dh0 = -d->pad_h;
+  c.dh_step = d->dil_h;
+  c.dw0 = -d->pad_w;
+  c.dw_step = d->dil_w;
+  c.out_oh = 0;
+  c.out_ow = 0;
+  c.OHi = P;
+  c.OWi = Q;
+  c.M = d->N * P * Q;
+  c.w_off = 0;
+  c.r0 = 0;
+  c.r_step = 1;
+  c.s0 = 0;
+  c.s_step = 1;
+}
+
+int plan_dgrad(const cvhip_conv_desc* d, IgemmParams* p) {
+  memset(p, 0, sizeof(*p));
+  const int P = conv_out_dim(d->H, d->pad_h, d->dil_h, d->R, d->stride_h);
+  const int Q = conv_out_dim(d->W, d->pad_w, d->dil_w, d->S, d->stride_w);
+  p->NB = d->N;
+  p->IH = P;  // the gathered operand is dy
+  p->IW = Q;
+  p->Cin = d->K;
+  p->x_ld = d->y_ld;
+  p->in_sh = 1;
+  p->in_sw = 1;
+  p->Nout = d->C;
+  p->y_ld = d->x_ld;
+  p->OH = d->H;
+  p->OW = d->W;
+  p->out_sh = d->stride_h;
+  p->out_sw = d->stride_w;
+  int n = 0;
+  int64_t woff = 0;
+  for (int ph = 0; ph < d->stride_h; ++ph) {
+    for (int pw = 0; pw < d->stride_w; ++pw) {
+      IgemmClass& c = p->cls[n];
+      c.TR = dgrad_taps_1d(ph, d->pad_h, d->dil_h, d->stride_h, d->R, &c.r0, &c.r_step, &c.dh0, &c.dh_step);
+      c.TS = dgrad_taps_1d(pw, d->pad_w, d->dil_w, d->stride_w, d->S, &c.s0, &c.s_step, &c.dw0, &c.dw_step);
+      if (c.TR == 0 || c.TS == 0) {  // no tap reaches this parity: the class just writes zeros
+        c.TR = 0;
+        c.TS = 0;
+      }
+      c.out_oh = ph;
+      c.out_ow = pw;
+      c.OHi = ph < d->H ? (d->H - ph + d->stride_h - 1) / d->stride_h : 0;
+      c.OWi = pw < d->W ? (d->W - pw + d->stride_w - 1) / d->stride_w : 0;
+      c.M = d->N * c.OHi * c.OWi;
+      c.w_off = woff;
+      woff += (int64_t)d->C * c.TR * c.TS * d->K;
+      ++n;
+    }
+  }
+  p->ncls = n;
+  return n;
+}
+
+int pack_weights(const cvhip_conv_desc* d, const float* master, void* w_fprop, void* w_dgrad, hipStream_t stream);
+int launch_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, hipStream_t stream);
+
+// ---- probes ---------------------------------------------------------------------------------------
+__global__ void probe_mfma_kernel(const bf16_t* a, const bf16_t* b, float* d) {
+  // a: [16][32] row-major (i,k); b: [32][16] row-major (k,j). Lane l supplies A[i=l&15][k=8*(l>>4)+e],
+  // B[k=8*(l>>4)+e][j=l&15]; result reg r -> D[row = 4*(l>>4)+r][col = l&15].
+  const int l = threadIdx.x;
+  bf16x8 fa, fb;
+  for (int e = 0; e < 8; ++e) {
+    fa[e] = a[(l & 15) * 32 + 8 * (l >> 4) + e];
+    fb[e] = b[(8 * (l >> 4) + e) * 16 + (l & 15)];
+  }
+  f32x4 c = {0.f, 0.f, 0.f, 0.f};
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, c, 0, 0, 0);
+  for (int r = 0; r < 4; ++r) d[(4 * (l >> 4) + r) * 16 + (l & 15)] = c[r];
+}
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
+__global__ void probe_tr16_kernel(const bf16_t* in, bf16_t* out) {
+  // in: 64 lanes x 4 bf16 written linearly to LDS (lane l at byte l*8); every lane then issues
+  // ds_read_b64_tr_b16 at its own linear address; out[l][0..3] = what lane l received.
+  __shared__ __attribute__((aligned(16))) bf16_t lds[256];
+  const int l = threadIdx.x;
+  for (int e = 0; e < 4; ++e) lds[l * 4 + e] = in[l * 4 + e];
+  __syncthreads();
+  bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(&lds[l * 4]));
+  for (int e = 0; e < 4; ++e) out[l * 4 + e] = v[e];
+}
+
+}  // namespace cvhip
+
+using namespace cvhip;
+
+extern "C" {
+
+int cvhip_version(void) { return CVHIP_VERSION; }
+const char* cvhip_last_error(void) { return g_last_error.c_str(); }
+
+int cvhip_conv2d_out_hw(const cvhip_conv_desc* d, int32_t* P, int32_t* Q) {
+  if (!d || !P || !Q) return CVHIP_ERR_INVALID;
+  *P = conv_out_dim(d->H, d->pad_h, d->dil_h, d->R, d->stride_h);
+  *Q = conv_out_dim(d->W, d->pad_w, d->dil_w, d->S, d->stride_w);
+  return (*P > 0 && *Q > 0) ? CVHIP_OK : CVHIP_ERR_INVALID;
+}
+
+int cvhip_conv2d_fprop_stats_rows(const cvhip_conv_desc* d) {
+  int st = validate_dense_desc(d);
+  if (st) return st;
+  const int P = conv_out_dim(d->H, d->pad_h, d->dil_h, d->R, d->stride_h);
+  const int Q = conv_out_dim(d->W, d->pad_w, d->dil_w, d->S, d->stride_w);
+  return cdiv(d->N * P * Q, igemm_block_m(d->K));
+}
+
+int64_t cvhip_conv2d_dgrad_weight_elems(const cvhip_conv_desc* d) {
+  int st = validate_dense_desc(d);
+  if (st) return st;
+  IgemmParams p;
+  const int n = plan_dgrad(d, &p);
+  int64_t e = 0;
+  for (int i = 0; i < n; ++i) e += (int64_t)d->C * p.cls[i].TR * p.cls[i].TS * d->K;
+  return e;
+}
+
+int cvhip_conv2d_dgrad_plan(const cvhip_conv_desc* d, int32_t* out, int max_classes) {
+  int st = validate_dense_desc(d);
+  if (st) return st;
+  IgemmParams p;
+  const int n = plan_dgrad(d, &p);
+  if (!out || max_classes < n) return CVHIP_ERR_INVALID;
+  for (int i = 0; i < n; ++i) {
+    const IgemmClass& c = p.cls[i];
+    int32_t* o = out + i * CVHIP_DGRAD_CLASS_INTS;
+    o[0] = c.TR;
+    o[1] = c.TS;
+    o[2] = c.r0;
+    o[3] = c.r_step;
+    o[4] = c.dh0;
+    o[5] = c.dh_step;
+    o[6] = c.s0;
+    o[7] = c.s_step;
+    o[8] = c.dw0;
+    o[9] = c.dw_step;
+    o[10] = (int32_t)(c.w_off & 0xffffffffll);
+    o[11] = (int32_t)(c.w_off >> 32);
+  }
+  return n;
+}
+
+int cvhip_conv2d_prep_weights(const cvhip_conv_desc* d, const float* w_master, void* w_fprop, void* w_dgrad, void* stream) {
+  int st = validate_dense_desc(d);
+  if (st) return st;
+  if (!w_master || (!w_fprop && !w_dgrad)) return CVHIP_ERR_INVALID;
+  if ((((uintptr_t)w_master) & 15) || (((uintptr_t)w_fprop) & 15) || (((uintptr_t)w_dgrad) & 15)) return CVHIP_ERR_INVALID;
+  return pack_weights(d, w_master, w_fprop, w_dgrad, (hipStream_t)stream);
+}
+
+int cvhip_conv2d_fprop(const cvhip_conv_desc* d, const void* x, const void* w, const float* bias, void* y,
+                       float* stats_partial, void* stream) {
+  int st = validate_dense_desc(d);
+  if (st) return st;
+  if (!x || !w || !y) return CVHIP_ERR_INVALID;
+  if (stats_partial && bias) return CVHIP_ERR_INVALID;
+  if ((((uintptr_t)x) & 15) || (((uintptr_t)w) & 15)) return CVHIP_ERR_INVALID;
+  IgemmParams p;
+  plan_fprop(d, &p);
+  p.x = (const bf16_t*)x;
+  p.w = (const bf16_t*)w;
+  p.y = (bf16_t*)y;
+  p.bias = bias;
+  p.stats = stats_partial;
+  p.y_vec_ok = ((d->y_ld & 3) == 0) && ((((uintptr_t)y) & 7) == 0);
+  return launch_igemm(p, (hipStream_t)stream);
+}
+
+int cvhip_conv2d_dgrad(const cvhip_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, void* stream) {
+  int st = validate_dense_desc(d);
+  if (st) return st;
+  if (!dy || !w_dgrad || !dx) return CVHIP_ERR_INVALID;
+  // the gathered operand is dy: its channel count / pitch must be 16-byte vectorisable
+  if ((d->K & 7) || (d->y_ld & 7)) return CVHIP_ERR_UNSUPPORTED;
+  if ((((uintptr_t)dy) & 15) || (((uintptr_t)w_dgrad) & 15)) return CVHIP_ERR_INVALID;
+  IgemmParams p;
+  plan_dgrad(d, &p);
+  p.x = (const bf16_t*)dy;
+  p.w = (const bf16_t*)w_dgrad;
+  p.y = (bf16_t*)dx;
+  p.bias = nullptr;
+  p.stats = nullptr;
+  p.y_vec_ok = ((d->x_ld & 3) == 0) && ((((uintptr_t)dx) & 7) == 0);
+  return launch_igemm(p, (hipStream_t)stream);
+}
+
+int cvhip_conv2d_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate, void* stream) {
+  int st = validate_dense_desc(d);
+  if (st) return st;
+  if (!x || !dy || !dw) return CVHIP_ERR_INVALID;
+  if ((d->K & 7) || (d->y_ld & 7)) return CVHIP_ERR_UNSUPPORTED;
+  if ((((uintptr_t)x) & 15) || (((uintptr_t)dy) & 15)) return CVHIP_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->K * d->R * d->S * d->C, s);
+    if (e != hipSuccess) {
+      set_last_error("hipMemsetAsync(dw)", e);
+      return CVHIP_ERR_LAUNCH;
+    }
+  }
+  return launch_wgrad(d, x, dy, dw, s);
+}
+
+int cvhip_probe_mfma_16x16x32(const void* a, const void* b, float* d, void* stream) {
+  if (!a || !b || !d) return CVHIP_ERR_INVALID;
+  hipLaunchKernelGGL(probe_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, d);
+  return check_launch("probe_mfma_kernel");
+}
+
+int cvhip_probe_ds_read_tr16(const void* in, void* out, void* stream) {
+  if (!in || !out) return CVHIP_ERR_INVALID;
+  hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out);
+  return check_launch("probe_tr16_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,449 @@
+// bn_act.hip — training-mode BatchNorm + activation, forward and backward, over NHWC bf16 matrices
+// [M = N*H*W][C] with row pitch ld. All kernels are HBM-bound streaming passes: 16-B vector
+// accesses along the channel axis, fp32 math, two-stage deterministic column reductions.
+//
+// Replaces aten::native_batch_norm(_backward) + aten::silu_/relu_ (+ residual add) reached from
+// reference src/models/bricks/conv_module.py:211-213 and src/models/modules/yolo_modules.py:102.
+#include "common.h"
+
+namespace cvhip {
+
+constexpr int kRedBlocksMax = 1024;
+constexpr int kRedRowsPerBlockMin = 64;
+
+static inline int colreduce_rows_host(int64_t M, int32_t C) {
+  (void)C;
+  int64_t b = cdiv64(M, kRedRowsPerBlockMin);
+  if (b > kRedBlocksMax) b = kRedBlocksMax;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// MODE 0: (sum x, sum x^2)          MODE 1: (sum du, sum du*xhat)       MODE 2: (sum x, -)
+struct RedParams {
+  const bf16_t* a;   // x (mode 0/2) or dz (mode 1)
+  const bf16_t* y;   // conv output (mode 1)
+  int ld_a, ld_y;
+  int64_t M;
+  int C;
+  const float *scale, *shift, *mean, *invstd;
+  int act;
+  float ap;
+  float* partial;  // [gridDim.x][2][C]
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void colreduce_kernel(const RedParams p) {
+  __shared__ float red[256 * 16];
+  const int t = threadIdx.x;
+  const int CV = (p.C + 7) >> 3;  // 16-B column vectors (C % 8 == 0 on the fast path)
+  const bool vec = (p.C & 7) == 0 && (p.ld_a & 7) == 0 && (MODE != 1 || (p.ld_y & 7) == 0) &&
+                   (((uintptr_t)p.a | (uintptr_t)p.y) & 15) == 0;
+  const int cols_per_pass = CV < 256 ? CV : 256;
+  const int rows_per_pass = 256 / cols_per_pass;
+  const int tx = t % cols_per_pass, ty = t / cols_per_pass;
+  const bool active = ty < rows_per_pass;
+  const int64_t rows_per_block = cdiv64(p.M, gridDim.x);
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r_end = r_begin + rows_per_block;
+  if (r_end > p.M) r_end = p.M;
+
+  for (int cv0 = 0; cv0 < CV; cv0 += cols_per_pass) {
+    const int cv = cv0 + tx;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+    float sc[8], sh[8], mu[8], is[8];
+    if (MODE == 1 && active && cv < CV) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = cv * 8 + j;
+        const bool ok = c < p.C;
+        sc[j] = (ok && p.scale) ? p.scale[c] : 1.f;
+        sh[j] = (ok && p.shift) ? p.shift[c] : 0.f;
+        mu[j] = (ok && p.mean) ? p.mean[c] : 0.f;
+        is[j] = (ok && p.invstd) ? p.invstd[c] : 1.f;
+      }
+    }
+    if (active && cv < CV) {
+      for (int64_t r = r_begin + ty; r < r_end; r += rows_per_pass) {
+        f32x8 a, y;
+        if (vec) {
+          a = unpack8(*reinterpret_cast<const uint4*>(p.a + r * p.ld_a + cv * 8));
+          if (MODE == 1) y = unpack8(*reinterpret_cast<const uint4*>(p.y + r * p.ld_y + cv * 8));
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int c = cv * 8 + j;
+            a.v[j] = c < p.C ? (float)p.a[r * p.ld_a + c] : 0.f;
+            if (MODE == 1) y.v[j] = c < p.C ? (float)p.y[r * p.ld_y + c] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (MODE == 0) {
+            s1[j] += a.v[j];
+            s2[j] += a.v[j] * a.v[j];
+          } else if (MODE == 2) {
+            s1[j] += a.v[j];
+          } else {
+            const float u = y.v[j] * sc[j] + sh[j];
+            const float du = a.v[j] * act_bwd(u, p.act, p.ap);
+            const float xh = (y.v[j] - mu[j]) * is[j];
+            s1[j] += du;
+            s2[j] += du * xh;
+          }
+        }
+      }
+    }
+    // reduce over ty through LDS
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[t * 16 + j] = s1[j];
+      red[t * 16 + 8 + j] = s2[j];
+    }
+    __syncthreads();
+    // thread (tx, j16) sums over ty
+    for (int idx = t; idx < cols_per_pass * 16; idx += 256) {
+      const int x = idx >> 4, j = idx & 15;
+      float s = 0.f;
+      for (int yy = 0; yy < rows_per_pass; ++yy) s += red[(yy * cols_per_pass + x) * 16 + j];
+      const int c = (cv0 + x) * 8 + (j & 7);
+      if (cv0 + x < CV && c < p.C) p.partial[((int64_t)blockIdx.x * 2 + (j >> 3)) * p.C + c] = s;
+    }
+  }
+}
+
+// ---- finalize kernels (one thread per channel) -----------------------------------------------------
+__global__ void bn_finalize_kernel(const float* partial, int rows, int C, double count, const float* gamma,
+                                   const float* beta, float* rmean, float* rvar, float momentum, float eps,
+                                   float* mean, float* invstd, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < rows; ++r) {
+    s1 += (double)partial[((int64_t)r * 2 + 0) * C + c];
+    s2 += (double)partial[((int64_t)r * 2 + 1) * C + c];
+  }
+  const double m = s1 / count;
+  double var = s2 / count - m * m;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  if (mean) mean[c] = (float)m;
+  if (invstd) invstd[c] = is;
+  const float sc = g * is;
+  if (scale) scale[c] = sc;
+  if (shift) shift[c] = b - (float)m * sc;
+  if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+  if (rvar) {
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+  }
+}
+
+__global__ void bn_eval_kernel(int C, const float* gamma, const float* beta, const float* rmean, const float* rvar,
+                               float eps, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float is = 1.f / sqrtf(rvar[c] + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  scale[c] = g * is;
+  shift[c] = b - rmean[c] * g * is;
+}
+
+// out0[c] = sum_r partial[r][0][c]; out1[c] = sum_r partial[r][1][c]
+__global__ void sum_partials_kernel(const float* partial, int rows, int C, float* out0, float* out1, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < rows; ++r) {
+    s1 += (double)partial[((int64_t)r * 2 + 0) * C + c];
+    if (out1) s2 += (double)partial[((int64_t)r * 2 + 1) * C + c];
+  }
+  if (out0) out0[c] = accumulate ? out0[c] + (float)s1 : (float)s1;
+  if (out1) out1[c] = accumulate ? out1[c] + (float)s2 : (float)s2;
+}
+
+// ---- elementwise passes -----------------------------------------------------------------------------
+struct EwParams {
+  const bf16_t *a, *y, *res;
+  bf16_t* out;
+  int ld_a, ld_y, ld_res, ld_out;
+  int64_t M;
+  int C;
+  const float *scale, *shift, *mean, *invstd, *dgamma, *dbeta;
+  int act;
+  float ap;
+  float inv_count;
+};
+
+// MODE 0: out = act(a*scale+shift) (+res)         [a = conv output y]
+// MODE 1: out = dy from (a = dz, y)               [BN+act backward apply]
+// MODE 2: out = a (copy)       MODE 3: out = a + res
+template <int MODE>
+__global__ __launch_bounds__(256) void ew_kernel(const EwParams p) {
+  const int CV = (p.C + 7) >> 3;
+  const bool vec = (p.C & 7) == 0 && (p.ld_a & 7) == 0 && (p.ld_out & 7) == 0 &&
+                   (MODE != 1 || (p.ld_y & 7) == 0) && (!p.res || (p.ld_res & 7) == 0) &&
+                   (((uintptr_t)p.a | (uintptr_t)p.y | (uintptr_t)p.res | (uintptr_t)p.out) & 15) == 0;
+  // thread owns one 16-B channel vector (tx) and walks rows: per-channel constants live in registers
+  const int t = threadIdx.x;
+  const int cols_per_pass = CV < 256 ? CV : 256;
+  const int rows_per_pass = 256 / cols_per_pass;
+  const int tx = t % cols_per_pass, ty = t / cols_per_pass;
+  if (ty >= rows_per_pass) return;
+  const int64_t rows_per_block = cdiv64(p.M, gridDim.x);
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r_end = r_begin + rows_per_block;
+  if (r_end > p.M) r_end = p.M;
+
+  for (int cv = tx; cv < CV; cv += cols_per_pass) {
+    const int c = cv * 8;
+    float sc[8], sh[8], mu[8], is[8], k1[8], k2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int cc = (c + j < p.C) ? c + j : p.C - 1;
+      sc[j] = p.scale ? p.scale[cc] : 1.f;
+      sh[j] = p.shift ? p.shift[cc] : 0.f;
+      if (MODE == 1 && p.mean) {
+        mu[j] = p.mean[cc];
+        is[j] = p.invstd[cc];
+        k1[j] = p.dbeta[cc] * p.inv_count;
+        k2[j] = p.dgamma[cc] * p.inv_count;
+      } else {
+        mu[j] = 0.f; is[j] = 1.f; k1[j] = 0.f; k2[j] = 0.f;
+      }
+    }
+    for (int64_t r = r_begin + ty; r < r_end; r += rows_per_pass) {
+      f32x8 a, y, rs, o;
+      if (vec) {
+        a = unpack8(*reinterpret_cast<const uint4*>(p.a + r * p.ld_a + c));
+        if (MODE == 1) y = unpack8(*reinterpret_cast<const uint4*>(p.y + r * p.ld_y + c));
+        if ((MODE == 0 || MODE == 3) && p.res) rs = unpack8(*reinterpret_cast<const uint4*>(p.res + r * p.ld_res + c));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bool ok = c + j < p.C;
+          a.v[j] = ok ? (float)p.a[r * p.ld_a + c + j] : 0.f;
+          if (MODE == 1) y.v[j] = ok ? (float)p.y[r * p.ld_y + c + j] : 0.f;
+          if ((MODE == 0 || MODE == 3) && p.res) rs.v[j] = ok ? (float)p.res[r * p.ld_res + c + j] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (MODE == 0) {
+          float v = act_fwd(a.v[j] * sc[j] + sh[j], p.act, p.ap);
+          if (p.res) v += rs.v[j];
+          o.v[j] = v;
+        } else if (MODE == 1) {
+          const float u = y.v[j] * sc[j] + sh[j];
+          const float du = a.v[j] * act_bwd(u, p.act, p.ap);
+          if (p.mean) {
+            const float xh = (y.v[j] - mu[j]) * is[j];
+            o.v[j] = sc[j] * (du - k1[j] - xh * k2[j]);
+          } else {
+            o.v[j] = sc[j] * du;
+          }
+        } else if (MODE == 2) {
+          o.v[j] = a.v[j];
+        } else {
+          o.v[j] = a.v[j] + rs.v[j];
+        }
+      }
+      if (vec) {
+        *reinterpret_cast<uint4*>(p.out + r * p.ld_out + c) = pack8(o);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (c + j < p.C) p.out[r * p.ld_out + c + j] = (bf16_t)o.v[j];
+      }
+    }
+  }
+}
+
+// blocks are row chunks; a thread moves 16 B per row visit, so ~32 row-visits per thread keeps
+// enough bytes in flight while leaving >> 256 blocks for large activations
+static inline int ew_grid(int64_t M, int C) {
+  const int CV = (C + 7) / 8;
+  const int cols = CV < 256 ? CV : 256;
+  const int rows_per_pass = 256 / cols;
+  int64_t b = cdiv64(M, (int64_t)rows_per_pass * 16);
+  if (b > 256 * 32) b = 256 * 32;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace cvhip
+
+using namespace cvhip;
+
+extern "C" {
+
+int cvhip_colreduce_rows(int64_t M, int32_t C) { return colreduce_rows_host(M, C); }
+
+static int launch_red(int mode, RedParams& p, hipStream_t s) {
+  if (!p.a || !p.partial || p.M < 0 || p.C <= 0) return CVHIP_ERR_INVALID;
+  const int rows = colreduce_rows_host(p.M, p.C);
+  if (mode == 0) hipLaunchKernelGGL(colreduce_kernel<0>, dim3(rows), dim3(256), 0, s, p);
+  else if (mode == 1) hipLaunchKernelGGL(colreduce_kernel<1>, dim3(rows), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(colreduce_kernel<2>, dim3(rows), dim3(256), 0, s, p);
+  return check_launch("colreduce_kernel");
+}
+
+int cvhip_bn_stats_partial(const void* x, int64_t M, int32_t C, int32_t ld, float* partial, void* stream) {
+  RedParams p{};
+  p.a = (const bf16_t*)x;
+  p.ld_a = ld;
+  p.M = M;
+  p.C = C;
+  p.partial = partial;
+  return launch_red(0, p, (hipStream_t)stream);
+}
+
+int cvhip_colsum_partial(const void* x, int64_t M, int32_t C, int32_t ld, float* partial, void* stream) {
+  RedParams p{};
+  p.a = (const bf16_t*)x;
+  p.ld_a = ld;
+  p.M = M;
+  p.C = C;
+  p.partial = partial;
+  return launch_red(2, p, (hipStream_t)stream);
+}
+
+int cvhip_bn_act_bwd_partial(const void* dz, int32_t ld_dz, const void* y, int32_t ld_y, int64_t M, int32_t C,
+                             const float* scale, const float* shift, const float* mean, const float* invstd,
+                             int32_t act, float act_param, float* partial, void* stream) {
+  if (!y) return CVHIP_ERR_INVALID;
+  RedParams p{};
+  p.a = (const bf16_t*)dz;
+  p.y = (const bf16_t*)y;
+  p.ld_a = ld_dz;
+  p.ld_y = ld_y;
+  p.M = M;
+  p.C = C;
+  p.scale = scale;
+  p.shift = shift;
+  p.mean = mean;
+  p.invstd = invstd;
+  p.act = act;
+  p.ap = act_param;
+  p.partial = partial;
+  return launch_red(1, p, (hipStream_t)stream);
+}
+
+int cvhip_bn_finalize(const float* partial, int32_t rows, int32_t C, int64_t count, const float* gamma,
+                      const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                      float* mean, float* invstd, float* scale, float* shift, void* stream) {
+  if (!partial || rows <= 0 || C <= 0 || count <= 0) return CVHIP_ERR_INVALID;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, rows, C,
+                     (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+  return check_launch("bn_finalize_kernel");
+}
+
+int cvhip_bn_eval_scale_shift(int32_t C, const float* gamma, const float* beta, const float* running_mean,
+                              const float* running_var, float eps, float* scale, float* shift, void* stream) {
+  if (C <= 0 || !running_mean || !running_var || !scale || !shift) return CVHIP_ERR_INVALID;
+  hipLaunchKernelGGL(bn_eval_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, C, gamma, beta,
+                     running_mean, running_var, eps, scale, shift);
+  return check_launch("bn_eval_kernel");
+}
+
+int cvhip_bn_bwd_finalize(const float* partial, int32_t rows, int32_t C, float* dgamma, float* dbeta, void* stream) {
+  if (!partial || rows <= 0 || C <= 0) return CVHIP_ERR_INVALID;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, rows, C,
+                     dbeta, dgamma, 0);
+  return check_launch("sum_partials_kernel");
+}
+
+int cvhip_colsum_finalize(const float* partial, int32_t rows, int32_t C, float* out, int accumulate, void* stream) {
+  if (!partial || rows <= 0 || C <= 0 || !out) return CVHIP_ERR_INVALID;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, rows, C,
+                     out, (float*)nullptr, accumulate);
+  return check_launch("sum_partials_kernel");
+}
+
+int cvhip_bn_act_fwd(const void* y, int32_t ld_y, void* z, int32_t ld_z, int64_t M, int32_t C, const float* scale,
+                     const float* shift, int32_t act, float act_param, const void* residual, int32_t ld_res,
+                     void* stream) {
+  if (!y || !z || M < 0 || C <= 0) return CVHIP_ERR_INVALID;
+  if (M == 0) return CVHIP_OK;
+  EwParams p{};
+  p.a = (const bf16_t*)y;
+  p.ld_a = ld_y;
+  p.out = (bf16_t*)z;
+  p.ld_out = ld_z;
+  p.res = (const bf16_t*)residual;
+  p.ld_res = ld_res;
+  p.M = M;
+  p.C = C;
+  p.scale = scale;
+  p.shift = shift;
+  p.act = act;
+  p.ap = act_param;
+  hipLaunchKernelGGL(ew_kernel<0>, dim3(ew_grid(M, C)), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("ew_kernel<0>");
+}
+
+int cvhip_bn_act_bwd_apply(const void* dz, int32_t ld_dz, const void* y, int32_t ld_y, void* dy, int32_t ld_dy,
+                           int64_t M, int32_t C, const float* scale, const float* shift, const float* mean,
+                           const float* invstd, const float* dgamma, const float* dbeta, int32_t act,
+                           float act_param, void* stream) {
+  if (!dz || !y || !dy || M < 0 || C <= 0) return CVHIP_ERR_INVALID;
+  if (mean && (!invstd || !dgamma || !dbeta)) return CVHIP_ERR_INVALID;
+  if (M == 0) return CVHIP_OK;
+  EwParams p{};
+  p.a = (const bf16_t*)dz;
+  p.ld_a = ld_dz;
+  p.y = (const bf16_t*)y;
+  p.ld_y = ld_y;
+  p.out = (bf16_t*)dy;
+  p.ld_out = ld_dy;
+  p.M = M;
+  p.C = C;
+  p.scale = scale;
+  p.shift = shift;
+  p.mean = mean;
+  p.invstd = invstd;
+  p.dgamma = dgamma;
+  p.dbeta = dbeta;
+  p.act = act;
+  p.ap = act_param;
+  p.inv_count = 1.f / (float)M;
+  hipLaunchKernelGGL(ew_kernel<1>, dim3(ew_grid(M, C)), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("ew_kernel<1>");
+}
+
+int cvhip_copy2d(const void* src, int32_t ld_src, void* dst, int32_t ld_dst, int64_t M, int32_t C, void* stream) {
+  if (!src || !dst || M < 0 || C <= 0) return CVHIP_ERR_INVALID;
+  if (M == 0) return CVHIP_OK;
+  EwParams p{};
+  p.a = (const bf16_t*)src;
+  p.ld_a = ld_src;
+  p.out = (bf16_t*)dst;
+  p.ld_out = ld_dst;
+  p.M = M;
+  p.C = C;
+  hipLaunchKernelGGL(ew_kernel<2>, dim3(ew_grid(M, C)), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("ew_kernel<2>");
+}
+
+int cvhip_add2d(const void* a, int32_t ld_a, const void* b, int32_t ld_b, void* dst, int32_t ld_dst, int64_t M,
+                int32_t C, void* stream) {
+  if (!a || !b || !dst || M < 0 || C <= 0) return CVHIP_ERR_INVALID;
+  if (M == 0) return CVHIP_OK;
+  EwParams p{};
+  p.a = (const bf16_t*)a;
+  p.ld_a = ld_a;
+  p.res = (const bf16_t*)b;
+  p.ld_res = ld_b;
+  p.out = (bf16_t*)dst;
+  p.ld_out = ld_dst;
+  p.M = M;
+  p.C = C;
+  hipLaunchKernelGGL(ew_kernel<3>, dim3(ew_grid(M, C)), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("ew_kernel<3>");
+}
+
+}  // extern "C"

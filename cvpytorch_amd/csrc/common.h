@@ -1,0 +1,113 @@
+// common.h — shared device helpers for libcvhip (gfx950 / CDNA4 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cvhip.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace cvhip {
+
+void set_last_error(const char* what, hipError_t e);
+int check_launch(const char* what);
+
+__host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// 8 bf16 <-> 8 fp32
+struct f32x8 {
+  float v[8];
+};
+
+__device__ __forceinline__ f32x8 unpack8(uint4 u) {
+  f32x8 r;
+  // bf16 -> fp32 is a 16-bit left shift
+  r.v[0] = __uint_as_float(u.x << 16);
+  r.v[1] = __uint_as_float(u.x & 0xffff0000u);
+  r.v[2] = __uint_as_float(u.y << 16);
+  r.v[3] = __uint_as_float(u.y & 0xffff0000u);
+  r.v[4] = __uint_as_float(u.z << 16);
+  r.v[5] = __uint_as_float(u.z & 0xffff0000u);
+  r.v[6] = __uint_as_float(u.w << 16);
+  r.v[7] = __uint_as_float(u.w & 0xffff0000u);
+  return r;
+}
+
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  bf16x2 t;
+  t[0] = (bf16_t)lo;  // RNE; lowers to v_cvt_pk_bf16_f32 on gfx950
+  t[1] = (bf16_t)hi;
+  return __builtin_bit_cast(uint32_t, t);
+}
+
+__device__ __forceinline__ uint4 pack8(const f32x8& f) {
+  uint4 u;
+  u.x = pack2(f.v[0], f.v[1]);
+  u.y = pack2(f.v[2], f.v[3]);
+  u.z = pack2(f.v[4], f.v[5]);
+  u.w = pack2(f.v[6], f.v[7]);
+  return u;
+}
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+  bf16_t b = (bf16_t)f;
+  return __builtin_bit_cast(uint16_t, b);
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// activation forward / derivative (as function of the pre-activation u)
+__device__ __forceinline__ float act_fwd(float u, int act, float ap) {
+  switch (act) {
+    case CVHIP_ACT_RELU: return u > 0.f ? u : 0.f;
+    case CVHIP_ACT_SILU: return u * sigmoidf_(u);
+    case CVHIP_ACT_LEAKY: return u > 0.f ? u : u * ap;
+    case CVHIP_ACT_SIGMOID: return sigmoidf_(u);
+    case CVHIP_ACT_HSWISH: {
+      float r = fminf(fmaxf(u + 3.f, 0.f), 6.f);
+      return u * r * (1.f / 6.f);
+    }
+    default: return u;
+  }
+}
+__device__ __forceinline__ float act_bwd(float u, int act, float ap) {
+  switch (act) {
+    case CVHIP_ACT_RELU: return u > 0.f ? 1.f : 0.f;
+    case CVHIP_ACT_SILU: {
+      float s = sigmoidf_(u);
+      return s * (1.f + u * (1.f - s));
+    }
+    case CVHIP_ACT_LEAKY: return u > 0.f ? 1.f : ap;
+    case CVHIP_ACT_SIGMOID: {
+      float s = sigmoidf_(u);
+      return s * (1.f - s);
+    }
+    case CVHIP_ACT_HSWISH: {
+      if (u <= -3.f) return 0.f;
+      if (u >= 3.f) return 1.f;
+      return (2.f * u + 3.f) * (1.f / 6.f);
+    }
+    default: return 1.f;
+  }
+}
+
+// XCD-aware, bijective block-id remap (cdna_hip_programming.md §5 "XCD swizzle must be bijective"):
+// hardware places block b on XCD b%8; give each XCD a contiguous chunk of the logical tile space so
+// neighbouring tiles (shared im2col halos / shared A panels) hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int NX = 8;
+  if (nblk < NX * 2) return bid;
+  int xcd = bid % NX;
+  int q = nblk / NX, r = nblk % NX;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + bid / NX;
+}
+
+}  // namespace cvhip

@@ -1,0 +1,287 @@
+// conv_igemm.hip — implicit-GEMM convolution for gfx950 (CDNA4): fprop and dgrad share one kernel.
+//
+//   Out[m][n] = sum_{t,c} X[pix(m) + tap(t)][c] * Wt[n][t*Cin + c]
+//
+//   m  : output "iteration pixel" (batch, oh, ow) of one stride-parity class
+//   n  : output channel (K for fprop, C for dgrad)
+//   t  : tap (r,s) of the class; input pixel = (oh*in_sh + dh0 + i*dh_step, ow*in_sw + dw0 + j*dw_step)
+//
+// fprop  : one class, in_s = conv stride, out_s = 1.
+// dgrad  : one class per (h % stride_h, w % stride_w) parity; each class only visits the taps that
+//          actually reach it (k3 s2: 1+2+2+4 = 9 taps over the 4 classes — no wasted MFMA work),
+//          in_s = 1, out_s = conv stride, weights pre-packed per class as [C][taps][K].
+//
+// Replaces aten::convolution / convolution_backward(input) reached from
+// reference src/models/bricks/conv_module.py:209 and trainer.py:189 (loss.backward()).
+//
+// Tiling (256 threads = 4 waves of 64): block tile BM x BN x 32, wave tile WM x WN built from
+// v_mfma_f32_16x16x32_bf16 fragments with SWAPPED operands (A-operand = weight rows, B-operand =
+// pixel rows) so every lane ends up holding 4 CONSECUTIVE output channels of one pixel -> 8-byte
+// packed bf16 stores along the NHWC channel axis. Global->register->LDS staging (zero-fill for the
+// conv halo needs the register hop), double-buffered LDS, one barrier per 32-deep K step, next
+// tile's global loads issued before the MFMA block (cdna_hip_programming.md T14). LDS rows are
+// 64 B (32 bf16) with a 16-B-slot XOR swizzle that makes the ds_read_b128 fragment reads
+// conflict-free for the 4x16-lane groups of MI355X_MICROARCH.md §LDS.
+#include "common.h"
+#include "conv_plan.h"
+
+namespace cvhip {
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
+  constexpr int WAVES_N = BN / WN;
+  constexpr int WAVES_M = BM / WM;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+  constexpr int MF = WM / 16, NF = WN / 16;
+  constexpr int A_IT = BM / 64;
+  constexpr int B_IT = (BN + 63) / 64;
+  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_BYTES + 2 * B_BYTES];
+  unsigned char* const sA = smem;
+  unsigned char* const sB = smem + 2 * A_BYTES;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  // ---- which tile ---------------------------------------------------------------------------
+  const int lt = xcd_remap(blockIdx.x, p.total_tiles);
+  int ci = 0;
+#pragma unroll 1
+  for (int i = 1; i < p.ncls; ++i)
+    if (lt >= p.cls[i].tile_begin) ci = i;
+  const IgemmClass& cl = p.cls[ci];
+  const int local = lt - cl.tile_begin;
+  const int mtile = local / p.n_tiles;
+  const int ntile = local - mtile * p.n_tiles;
+  const int m0 = mtile * BM, n0 = ntile * BN;
+  const int TR = cl.TR, TS = cl.TS;
+  const int Cin = p.Cin;
+  const int Ktot = TR * TS * Cin;
+  const int nk = (Ktot + 31) >> 5;
+  const int M = cl.M;
+  const int OWi = cl.OWi, OHWi = cl.OHi * cl.OWi;
+
+  // ---- per-thread A rows: this thread stages rows (t>>2) + 64*i, 16-B slot (t&3) --------------
+  int ih0[A_IT], iw0[A_IT], pbase[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int m = m0 + i * 64 + (t >> 2);
+    if (m < M) {
+      const int n = m / OHWi;
+      const int rem = m - n * OHWi;
+      const int oh = rem / OWi;
+      const int ow = rem - oh * OWi;
+      ih0[i] = oh * p.in_sh + cl.dh0;
+      iw0[i] = ow * p.in_sw + cl.dw0;
+      pbase[i] = n * p.IH * p.IW;
+    } else {
+      ih0[i] = -(1 << 28);
+      iw0[i] = 0;
+      pbase[i] = 0;
+    }
+  }
+  // tap walker for this thread's 16-B slot: element k = kt*32 + (t&3)*8 -> (tr, ts, c0)
+  int c0, ts_, tr_;
+  {
+    const int k = (t & 3) * 8;
+    const int tap = k / Cin;
+    c0 = k - tap * Cin;
+    tr_ = tap / TS;
+    ts_ = tap - tr_ * TS;
+  }
+  const bf16_t* __restrict__ wbase = p.w + cl.w_off;
+
+  // swizzled 16-B slot for the LDS write (thread-constant) and the fragment read (lane-constant)
+  const int swz_w = (t & 3) ^ ((0x78 >> (2 * ((t >> 4) & 3))) & 3);
+  const int swz_r = (lane >> 4) ^ ((0x78 >> (2 * ((lane >> 2) & 3))) & 3);
+
+  uint4 ra[A_IT], rb[B_IT];
+
+  auto load_tile = [&](int kt) {
+    const bool tap_ok = tr_ < TR;
+    const int dh = tr_ * cl.dh_step, dw = ts_ * cl.dw_step;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int ih = ih0[i] + dh, iw = iw0[i] + dw;
+      const bool ok = tap_ok && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ok) {
+        const bf16_t* src = p.x + ((int64_t)(pbase[i] + ih * p.IW + iw) * p.x_ld + c0);
+        v = *reinterpret_cast<const uint4*>(src);
+      }
+      ra[i] = v;
+    }
+    const int k = kt * 32 + (t & 3) * 8;
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int row = i * 64 + (t >> 2);
+      const int n = n0 + row;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (row < BN && n < p.Nout && k < Ktot)
+        v = *reinterpret_cast<const uint4*>(wbase + ((int64_t)n * Ktot + k));
+      rb[i] = v;
+    }
+    // advance the tap walker by one K step (32 elements)
+    c0 += 32;
+    while (c0 >= Cin) {
+      c0 -= Cin;
+      ++ts_;
+    }
+    while (ts_ >= TS) {
+      ts_ -= TS;
+      ++tr_;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i)
+      *reinterpret_cast<uint4*>(sA + buf * A_BYTES + (i * 64 + (t >> 2)) * 64 + swz_w * 16) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int row = i * 64 + (t >> 2);
+      if (row < BN) *reinterpret_cast<uint4*>(sB + buf * B_BYTES + row * 64 + swz_w * 16) = rb[i];
+    }
+  };
+
+  f32x4 acc[NF][MF];
+#pragma unroll
+  for (int a = 0; a < NF; ++a)
+#pragma unroll
+    for (int b = 0; b < MF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  const int a_row = wm * WM + (lane & 15);
+  const int b_row = wn * WN + (lane & 15);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);  // global loads in flight under the MFMA block
+    bf16x8 xa[MF], wb[NF];
+#pragma unroll
+    for (int b = 0; b < MF; ++b)
+      xa[b] = *reinterpret_cast<const bf16x8*>(sA + cur * A_BYTES + (a_row + b * 16) * 64 + swz_r * 16);
+#pragma unroll
+    for (int a = 0; a < NF; ++a)
+      wb[a] = *reinterpret_cast<const bf16x8*>(sB + cur * B_BYTES + (b_row + a * 16) * 64 + swz_r * 16);
+#pragma unroll
+    for (int a = 0; a < NF; ++a)
+#pragma unroll
+      for (int b = 0; b < MF; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[a], xa[b], acc[a][b], 0, 0, 0);
+    if (kt + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds D'[n = 4*(lane>>4)+r][m = lane&15] per fragment --------------------
+  const int nq = (lane >> 4) * 4;
+#pragma unroll
+  for (int b = 0; b < MF; ++b) {
+    const int m = m0 + wm * WM + b * 16 + (lane & 15);
+    if (m >= M) continue;
+    const int n_img = m / OHWi;
+    const int rem = m - n_img * OHWi;
+    const int oh = rem / OWi;
+    const int ow = rem - oh * OWi;
+    const int64_t opix = ((int64_t)n_img * p.OH + (oh * p.out_sh + cl.out_oh)) * p.OW + (ow * p.out_sw + cl.out_ow);
+    bf16_t* yrow = p.y + opix * p.y_ld;
+#pragma unroll
+    for (int a = 0; a < NF; ++a) {
+      const int n = n0 + wn * WN + a * 16 + nq;
+      if (n >= p.Nout) continue;
+      float v0 = acc[a][b][0], v1 = acc[a][b][1], v2 = acc[a][b][2], v3 = acc[a][b][3];
+      if (p.bias) {
+        v0 += p.bias[n];
+        if (n + 1 < p.Nout) v1 += p.bias[n + 1];
+        if (n + 2 < p.Nout) v2 += p.bias[n + 2];
+        if (n + 3 < p.Nout) v3 += p.bias[n + 3];
+      }
+      if (p.y_vec_ok && n + 3 < p.Nout) {
+        uint2 u;
+        u.x = pack2(v0, v1);
+        u.y = pack2(v2, v3);
+        *reinterpret_cast<uint2*>(yrow + n) = u;
+      } else {
+        yrow[n] = (bf16_t)v0;
+        if (n + 1 < p.Nout) yrow[n + 1] = (bf16_t)v1;
+        if (n + 2 < p.Nout) yrow[n + 2] = (bf16_t)v2;
+        if (n + 3 < p.Nout) yrow[n + 3] = (bf16_t)v3;
+      }
+    }
+  }
+
+  // ---- optional BatchNorm statistics (sum, sum^2 of the fp32 accumulators) ----------------------
+  if (p.stats) {
+    float* red = reinterpret_cast<float*>(smem);  // [WAVES_M][BN][2]; tile buffers are dead now
+#pragma unroll
+    for (int a = 0; a < NF; ++a) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int b = 0; b < MF; ++b) {
+          const float v = acc[a][b][r];  // rows m >= M contributed zero A rows -> v == 0
+          s1 += v;
+          s2 += v * v;
+        }
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+          s1 += __shfl_xor(s1, off, 64);
+          s2 += __shfl_xor(s2, off, 64);
+        }
+        if ((lane & 15) == 0) {
+          const int nl = wn * WN + a * 16 + nq + r;
+          red[(wm * BN + nl) * 2 + 0] = s1;
+          red[(wm * BN + nl) * 2 + 1] = s2;
+        }
+      }
+    }
+    __syncthreads();
+    if (t < BN) {
+      const int n = n0 + t;
+      if (n < p.Nout) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES_M; ++w) {
+          s1 += red[(w * BN + t) * 2 + 0];
+          s2 += red[(w * BN + t) * 2 + 1];
+        }
+        float* dst = p.stats + (int64_t)mtile * 2 * p.Nout;
+        dst[n] = s1;
+        dst[p.Nout + n] = s2;
+      }
+    }
+  }
+}
+
+// ---- host side ----------------------------------------------------------------------------------
+
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(IgemmParams& p, hipStream_t stream) {
+  int total = 0;
+  p.n_tiles = cdiv(p.Nout, BN);
+  for (int i = 0; i < p.ncls; ++i) {
+    p.cls[i].tile_begin = total;
+    total += cdiv(p.cls[i].M, BM) * p.n_tiles;
+  }
+  p.total_tiles = total;
+  if (total == 0) return CVHIP_OK;
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), dim3(total), dim3(256), 0, stream, p);
+  return check_launch("igemm_kernel");
+}
+
+int igemm_block_m(int Nout) { return Nout <= 64 ? 256 : 128; }
+
+int launch_igemm(IgemmParams& p, hipStream_t stream) {
+  if (p.Nout <= 32) return launch_cfg<256, 32, 64, 32>(p, stream);
+  if (p.Nout <= 64) return launch_cfg<256, 64, 64, 64>(p, stream);
+  return launch_cfg<128, 128, 64, 64>(p, stream);
+}
+
+}  // namespace cvhip

@@ -1,0 +1,87 @@
+// conv_plan.h — host-side planning for the implicit-GEMM convolution kernels (pure arithmetic; the
+// CPU test-suite checks it against a numpy gather interpreter without needing a GPU).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+
+namespace cvhip {
+
+constexpr int kMaxClasses = 16;  // stride_h * stride_w <= 16
+
+struct IgemmClass {
+  int TR, TS;            // taps visited by this class
+  int dh0, dh_step;      // input row  = oh*in_sh + dh0 + i*dh_step   (i in [0,TR))
+  int dw0, dw_step;      // input col  = ow*in_sw + dw0 + j*dw_step   (j in [0,TS))
+  int out_oh, out_ow;    // output pixel = (oh*out_sh + out_oh, ow*out_sw + out_ow)
+  int OHi, OWi;          // iteration grid of this class
+  int M;                 // NB * OHi * OWi
+  int tile_begin;        // first logical tile of this class (filled by the launcher)
+  int64_t w_off;         // element offset of this class's weight image
+  // provenance of the taps in the original kernel (used by the weight packer)
+  int r0, r_step, s0, s_step;
+};
+
+struct IgemmParams {
+  const bf16_t* x;
+  const bf16_t* w;
+  bf16_t* y;
+  const float* bias;
+  float* stats;
+  int NB, IH, IW, Cin, x_ld;
+  int in_sh, in_sw;
+  int Nout, y_ld, OH, OW, out_sh, out_sw;
+  int n_tiles, total_tiles, ncls;
+  int y_vec_ok;
+  IgemmClass cls[kMaxClasses];
+};
+
+inline int conv_out_dim(int in, int pad, int dil, int k, int stride) {
+  return (in + 2 * pad - dil * (k - 1) - 1) / stride + 1;
+}
+
+inline int gcd_(int a, int b) {
+  while (b) {
+    int t = a % b;
+    a = b;
+    b = t;
+  }
+  return a;
+}
+
+// 1-D tap progression for dgrad parity `ph`: taps r with (ph + pad - r*dil) % stride == 0.
+// Returns count; r = r0 + i*r_step; d(i) = (ph + pad - r*dil)/stride = d0 + i*d_step.
+inline int dgrad_taps_1d(int ph, int pad, int dil, int stride, int R, int* r0, int* r_step, int* d0,
+                         int* d_step) {
+  const int g = gcd_(dil, stride);
+  const int step = stride / g;
+  int first = -1;
+  for (int r = 0; r < R && r < step; ++r) {
+    int v = ph + pad - r * dil;
+    if (((v % stride) + stride) % stride == 0) {
+      first = r;
+      break;
+    }
+  }
+  *r_step = step;
+  *d_step = -(dil / g);
+  if (first < 0) {
+    *r0 = 0;
+    *d0 = 0;
+    return 0;
+  }
+  *r0 = first;
+  // floor division is exact here
+  *d0 = (ph + pad - first * dil) / stride;
+  return (R - 1 - first) / step + 1;
+}
+
+int validate_dense_desc(const cvhip_conv_desc* d);
+void plan_fprop(const cvhip_conv_desc* d, IgemmParams* p);
+// returns number of classes (<= kMaxClasses) or negative status
+int plan_dgrad(const cvhip_conv_desc* d, IgemmParams* p);
+int igemm_block_m(int Nout);
+int launch_igemm(IgemmParams& p, hipStream_t stream);
+
+}  // namespace cvhip

@@ -1,0 +1,252 @@
+// conv_wgrad.hip — weight-gradient implicit GEMM for gfx950 (CDNA4).
+//
+//   dW[n][t*Cin + c] (+)= sum_m dY[m][n] * X[pix(m) + tap(t)][c]         (fp32, KRSC layout)
+//
+// The reduction runs over output pixels m = (batch, p, q): in NHWC that is the SLOW axis of both
+// operands, so the MFMA fragments (8 consecutive reduction elements per lane) are gathered from
+// row-major [pixel][channel] LDS tiles with the gfx950 hardware-transpose read
+// ds_read_b64_tr_b16 (cdna_hip_programming.md T10) — no software transpose, coalesced 16-B global
+// loads along channels. Split-K over pixels (grid.y) with fp32 atomics fills the chip even when
+// the weight tensor is a single tile (128x128 3x3: 9 tiles x splits).
+//
+// Replaces aten::convolution_backward(weight) reached from trainer.py:189 (loss.backward()).
+#include "common.h"
+#include "conv_plan.h"
+
+namespace cvhip {
+
+struct WgradParams {
+  const bf16_t* x;
+  const bf16_t* dy;
+  float* dw;
+  int NB, IH, IW, Cin, x_ld;
+  int OHi, OWi, in_sh, in_sw;
+  int dh0, dh_step, dw0, dw_step, TR, TS;
+  int Nout, dy_ld;
+  int Ktot, M;
+  int n_tiles, k_tiles, m_per_split;
+};
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+__device__ __forceinline__ bf16x8 tr_read8(const unsigned char* p0, const unsigned char* p1) {
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p1));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// TN: out-channel tile (128/64/32); K-column tile is always 128; reduction step 32 pixels.
+template <int TN, int WN, int WK>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
+  constexpr int TK = 128;
+  constexpr int WAVES_K = TK / WK;
+  static_assert((TN / WN) * WAVES_K == 4, "4 waves per block");
+  constexpr int NF = WN / 16, KF = WK / 16;
+  constexpr int DV = TN / 8;             // 16-B vectors per dY row
+  constexpr int D_ROWS = 256 / DV;       // dY rows staged per pass
+  constexpr int D_IT = (32 + D_ROWS - 1) / D_ROWS;
+  constexpr int D_ROWB = TN * 2;         // dY LDS row bytes
+  constexpr int D_SEGM = TN / 16 - 1;    // 32-B segment mask
+  constexpr int X_ROWB = TK * 2;
+  constexpr int D_BYTES = 32 * D_ROWB, X_BYTES = 32 * X_ROWB;
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * D_BYTES + 2 * X_BYTES];
+  unsigned char* const sD = smem;
+  unsigned char* const sX = smem + 2 * D_BYTES;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wn = wave / WAVES_K, wk = wave % WAVES_K;
+
+  const int tile = blockIdx.x;
+  const int ntile = tile / p.k_tiles, ktile = tile - ntile * p.k_tiles;
+  const int n0 = ntile * TN, k0 = ktile * TK;
+  const int m_begin = blockIdx.y * p.m_per_split;
+  const int m_end = min(p.M, m_begin + p.m_per_split);
+  const int nsteps = (m_end - m_begin + 31) >> 5;
+  if (nsteps <= 0) return;
+
+  // ---- X staging: thread owns 16-B column (t&15) of rows (t>>4) and (t>>4)+16 -------------------
+  const int xv = t & 15;
+  const int kcol = k0 + xv * 8;
+  const bool k_ok = kcol < p.Ktot;
+  int c0 = 0, dh = 0, dw = 0;
+  if (k_ok) {
+    const int tap = kcol / p.Cin;
+    c0 = kcol - tap * p.Cin;
+    const int tr = tap / p.TS, ts = tap - tr * p.TS;
+    dh = p.dh0 + tr * p.dh_step;
+    dw = p.dw0 + ts * p.dw_step;
+  }
+  int xn[2], xoh[2], xow[2];
+  const int OHWi = p.OHi * p.OWi;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m_begin + (t >> 4) + 16 * i;
+    const int n = m / OHWi;
+    const int rem = m - n * OHWi;
+    xn[i] = n;
+    xoh[i] = rem / p.OWi;
+    xow[i] = rem - xoh[i] * p.OWi;
+  }
+  // ---- dY staging ---------------------------------------------------------------------------------
+  const int dv = t % DV;
+  const int drow = t / DV;
+  const int dn = n0 + dv * 8;
+  const bool dn_ok = dn < p.Nout;  // Nout % 8 == 0 is required
+
+  uint4 rx[2], rd[D_IT];
+
+  auto load_step = [&](int step) {
+    const int mb = m_begin + step * 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = mb + (t >> 4) + 16 * i;
+      const int ih = xoh[i] * p.in_sh + dh, iw = xow[i] * p.in_sw + dw;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (k_ok && m < m_end && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW)
+        v = *reinterpret_cast<const uint4*>(p.x + ((int64_t)((xn[i] * p.IH + ih) * p.IW + iw) * p.x_ld + c0));
+      rx[i] = v;
+      // advance this pixel by 32 for the next step
+      xow[i] += 32;
+      while (xow[i] >= p.OWi) {
+        xow[i] -= p.OWi;
+        ++xoh[i];
+      }
+      while (xoh[i] >= p.OHi) {
+        xoh[i] -= p.OHi;
+        ++xn[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < D_IT; ++i) {
+      const int row = drow + i * D_ROWS;
+      const int m = mb + row;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (row < 32 && dn_ok && m < m_end)
+        v = *reinterpret_cast<const uint4*>(p.dy + ((int64_t)m * p.dy_ld + dn));
+      rd[i] = v;
+    }
+  };
+  // swizzle: 32-B segment index ^= h(px), h(px) = (px&3) | ((px>>1)&4)
+  auto store_step = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int px = (t >> 4) + 16 * i;
+      const int h = (px & 3) | ((px >> 1) & 4);
+      *reinterpret_cast<uint4*>(sX + buf * X_BYTES + px * X_ROWB + ((((xv >> 1) ^ h) & 7) << 5) + (xv & 1) * 16) = rx[i];
+    }
+#pragma unroll
+    for (int i = 0; i < D_IT; ++i) {
+      const int px = drow + i * D_ROWS;
+      if (px < 32) {
+        const int h = (px & 3) | ((px >> 1) & 4);
+        *reinterpret_cast<uint4*>(sD + buf * D_BYTES + px * D_ROWB + ((((dv >> 1) ^ h) & D_SEGM) << 5) + (dv & 1) * 16) = rd[i];
+      }
+    }
+  };
+
+  f32x4 acc[NF][KF];
+#pragma unroll
+  for (int a = 0; a < NF; ++a)
+#pragma unroll
+    for (int b = 0; b < KF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_step(0);
+  store_step(0);
+  __syncthreads();
+
+  // fragment read geometry (lane-constant): pixel rows 8g+4j+q, 8-B column (lane&3) of the 32-B seg
+  const int g = lane >> 4, q = (lane >> 2) & 3;
+  const int hsw = q | ((g & 1) << 2);
+  const int px0 = 8 * g + q;
+
+  for (int step = 0; step < nsteps; ++step) {
+    const int cur = step & 1;
+    if (step + 1 < nsteps) load_step(step + 1);
+    bf16x8 fd[NF], fx[KF];
+#pragma unroll
+    for (int a = 0; a < NF; ++a) {
+      const int seg = (wn * WN + a * 16) >> 4;
+      const unsigned char* base = sD + cur * D_BYTES + (((seg ^ hsw) & D_SEGM) << 5) + (lane & 3) * 8;
+      fd[a] = tr_read8(base + px0 * D_ROWB, base + (px0 + 4) * D_ROWB);
+    }
+#pragma unroll
+    for (int b = 0; b < KF; ++b) {
+      const int seg = (wk * WK + b * 16) >> 4;
+      const unsigned char* base = sX + cur * X_BYTES + (((seg ^ hsw) & 7) << 5) + (lane & 3) * 8;
+      fx[b] = tr_read8(base + px0 * X_ROWB, base + (px0 + 4) * X_ROWB);
+    }
+#pragma unroll
+    for (int a = 0; a < NF; ++a)
+#pragma unroll
+      for (int b = 0; b < KF; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[a], fx[b], acc[a][b], 0, 0, 0);
+    if (step + 1 < nsteps) store_step(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: lane holds D[n = 4*(lane>>4)+r][kcol = lane&15]
+#pragma unroll
+  for (int a = 0; a < NF; ++a) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wn * WN + a * 16 + 4 * (lane >> 4) + r;
+      if (n >= p.Nout) continue;
+#pragma unroll
+      for (int b = 0; b < KF; ++b) {
+        const int kc = k0 + wk * WK + b * 16 + (lane & 15);
+        if (kc < p.Ktot) unsafeAtomicAdd(p.dw + ((int64_t)n * p.Ktot + kc), acc[a][b][r]);
+      }
+    }
+  }
+}
+
+template <int TN, int WN, int WK>
+static int launch_wg(WgradParams& p, hipStream_t stream) {
+  p.n_tiles = cdiv(p.Nout, TN);
+  p.k_tiles = cdiv(p.Ktot, 128);
+  const int tiles = p.n_tiles * p.k_tiles;
+  // fill ~3 blocks per CU; keep >= 8 reduction steps per split
+  int splits = cdiv(768, tiles);
+  const int max_splits = (p.M + 255) / 256;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int mps = cdiv(p.M, splits);
+  mps = ((mps + 31) / 32) * 32;
+  splits = cdiv(p.M, mps);
+  p.m_per_split = mps;
+  hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK>), dim3(tiles, splits), dim3(256), 0, stream, p);
+  return check_launch("wgrad_kernel");
+}
+
+int launch_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, hipStream_t stream) {
+  WgradParams p;
+  p.x = (const bf16_t*)x;
+  p.dy = (const bf16_t*)dy;
+  p.dw = dw;
+  p.NB = d->N;
+  p.IH = d->H;
+  p.IW = d->W;
+  p.Cin = d->C;
+  p.x_ld = d->x_ld;
+  p.OHi = conv_out_dim(d->H, d->pad_h, d->dil_h, d->R, d->stride_h);
+  p.OWi = conv_out_dim(d->W, d->pad_w, d->dil_w, d->S, d->stride_w);
+  p.in_sh = d->stride_h;
+  p.in_sw = d->stride_w;
+  p.dh0 = -d->pad_h;
+  p.dh_step = d->dil_h;
+  p.dw0 = -d->pad_w;
+  p.dw_step = d->dil_w;
+  p.TR = d->R;
+  p.TS = d->S;
+  p.Nout = d->K;
+  p.dy_ld = d->y_ld;
+  p.Ktot = d->R * d->S * d->C;
+  p.M = d->N * p.OHi * p.OWi;
+  if (p.M <= 0) return CVHIP_OK;
+  if (d->K <= 32) return launch_wg<32, 32, 32>(p, stream);
+  if (d->K <= 64) return launch_wg<64, 32, 64>(p, stream);
+  return launch_wg<128, 64, 64>(p, stream);
+}
+
+}  // namespace cvhip

@@ -1,0 +1,286 @@
+// dwconv.hip — depthwise convolution (groups == C == K), direct form. One multiply-add per tap per
+// channel: arithmetic intensity ~ R*S/2 flop/byte, far below machine balance, so these are plain
+// HBM-bound streaming kernels (16-B channel vectors, fp32 weights held in registers) — no MFMA.
+//
+// Reference: src/models/bricks/depthwise_separable_conv_module.py:76-94 as used by
+// src/models/heads/seg/deeplabv3plus_head.py:18-30,49-54 (3x3, dilation 1/12/24/36).
+#include <string.h>
+#include "common.h"
+#include "conv_plan.h"
+
+namespace cvhip {
+
+struct DwParams {
+  const bf16_t* x;   // fprop: input; dgrad: dy; wgrad: x
+  const bf16_t* dy;  // wgrad only
+  const float* w;    // [C][R][S]
+  const float* bias;
+  bf16_t* y;         // fprop: y; dgrad: dx
+  float* dw;
+  int N, C, H, W, P, Q, R, S, sh, sw, ph, pw, dh, dw_;
+  int x_ld, y_ld;
+};
+
+__device__ __forceinline__ bool dw_vec_ok(const DwParams& p) {
+  return (p.C & 7) == 0 && (p.x_ld & 7) == 0 && (p.y_ld & 7) == 0 && ((((uintptr_t)p.x) | ((uintptr_t)p.y) | ((uintptr_t)p.dy)) & 15) == 0;
+}
+
+__device__ __forceinline__ f32x8 dw_load8(const bf16_t* p, int c, int C, bool vec) {
+  if (vec) return unpack8(*reinterpret_cast<const uint4*>(p + c));
+  f32x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r.v[j] = (c + j < C) ? (float)p[c + j] : 0.f;
+  return r;
+}
+__device__ __forceinline__ void dw_store8(bf16_t* p, int c, int C, bool vec, const f32x8& v) {
+  if (vec) {
+    *reinterpret_cast<uint4*>(p + c) = pack8(v);
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (c + j < C) p[c + j] = (bf16_t)v.v[j];
+}
+
+// y[n,p,q,c] = bias[c] + sum_{r,s} x[n, p*sh-ph+r*dh, q*sw-pw+s*dw, c] * w[c][r][s]
+__global__ __launch_bounds__(256) void dw_fprop_kernel(const DwParams p) {
+  const int CV = (p.C + 7) >> 3;
+  const bool vec = dw_vec_ok(p);
+  const int64_t total = (int64_t)p.N * p.P * p.Q * CV;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    int64_t pix = i / CV;
+    const int q = (int)(pix % p.Q);
+    pix /= p.Q;
+    const int pp = (int)(pix % p.P);
+    const int n = (int)(pix / p.P);
+    const int c = cv * 8;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = (p.bias && c + j < p.C) ? p.bias[c + j] : 0.f;
+    for (int r = 0; r < p.R; ++r) {
+      const int ih = pp * p.sh - p.ph + r * p.dh;
+      if ((unsigned)ih >= (unsigned)p.H) continue;
+      for (int s = 0; s < p.S; ++s) {
+        const int iw = q * p.sw - p.pw + s * p.dw_;
+        if ((unsigned)iw >= (unsigned)p.W) continue;
+        const f32x8 v = dw_load8(p.x + ((int64_t)(n * p.H + ih) * p.W + iw) * p.x_ld, c, p.C, vec);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int cc = c + j < p.C ? c + j : p.C - 1;
+          acc[j] += v.v[j] * p.w[(cc * p.R + r) * p.S + s];
+        }
+      }
+    }
+    f32x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.v[j] = acc[j];
+    dw_store8(p.y + ((int64_t)(n * p.P + pp) * p.Q + q) * p.y_ld, c, p.C, vec, o);
+  }
+}
+
+// dx[n,h,w,c] = sum_{r,s : (h+ph-r*dh) % sh == 0 ...} dy[n,(h+ph-r*dh)/sh,(w+pw-s*dw)/sw,c] * w[c][r][s]
+// here p.x = dy (P x Q, pitch x_ld), p.y = dx (H x W, pitch y_ld)
+__global__ __launch_bounds__(256) void dw_dgrad_kernel(const DwParams p) {
+  const int CV = (p.C + 7) >> 3;
+  const bool vec = dw_vec_ok(p);
+  const int64_t total = (int64_t)p.N * p.H * p.W * CV;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    int64_t pix = i / CV;
+    const int w = (int)(pix % p.W);
+    pix /= p.W;
+    const int h = (int)(pix % p.H);
+    const int n = (int)(pix / p.H);
+    const int c = cv * 8;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int r = 0; r < p.R; ++r) {
+      const int th = h + p.ph - r * p.dh;
+      if (th < 0 || th % p.sh) continue;
+      const int oh = th / p.sh;
+      if (oh >= p.P) continue;
+      for (int s = 0; s < p.S; ++s) {
+        const int tw = w + p.pw - s * p.dw_;
+        if (tw < 0 || tw % p.sw) continue;
+        const int ow = tw / p.sw;
+        if (ow >= p.Q) continue;
+        const f32x8 g = dw_load8(p.x + ((int64_t)(n * p.P + oh) * p.Q + ow) * p.x_ld, c, p.C, vec);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int cc = c + j < p.C ? c + j : p.C - 1;
+          acc[j] += g.v[j] * p.w[(cc * p.R + r) * p.S + s];
+        }
+      }
+    }
+    f32x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.v[j] = acc[j];
+    dw_store8(p.y + ((int64_t)(n * p.H + h) * p.W + w) * p.y_ld, c, p.C, vec, o);
+  }
+}
+
+// dw[c][r][s] += sum_m dy[m][c] * x[pix(m)+tap][c]; block = chunk of output rows, thread = (row lane,
+// channel vector), R*S <= 9 taps accumulated in registers, LDS reduce over row lanes, one fp32
+// atomic per (block, channel, tap).
+constexpr int kDwMaxTaps = 9;
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwParams p, int rows_per_block) {
+  __shared__ float red[256 * 8];
+  const int CV = (p.C + 7) >> 3;
+  const bool vec = dw_vec_ok(p);
+  const int t = threadIdx.x;
+  const int cols = CV < 256 ? CV : 256;
+  const int rpp = 256 / cols;
+  const int tx = t % cols, ty = t / cols;
+  const int64_t M = (int64_t)p.N * p.P * p.Q;
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r_end = r_begin + rows_per_block;
+  if (r_end > M) r_end = M;
+  const int T = p.R * p.S;
+  for (int cv0 = 0; cv0 < CV; cv0 += cols) {
+    const int cv = cv0 + tx;
+    const int c = cv * 8;
+    float acc[kDwMaxTaps][8];
+#pragma unroll
+    for (int a = 0; a < kDwMaxTaps; ++a)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[a][j] = 0.f;
+    if (ty < rpp && cv < CV) {
+      for (int64_t m = r_begin + ty; m < r_end; m += rpp) {
+        const int q = (int)(m % p.Q);
+        const int pp = (int)((m / p.Q) % p.P);
+        const int n = (int)(m / ((int64_t)p.Q * p.P));
+        const f32x8 g = dw_load8(p.dy + m * p.y_ld, c, p.C, vec);
+#pragma unroll
+        for (int a = 0; a < kDwMaxTaps; ++a) {
+          if (a >= T) break;
+          const int r = a / p.S, s = a - r * p.S;
+          const int ih = pp * p.sh - p.ph + r * p.dh, iw = q * p.sw - p.pw + s * p.dw_;
+          if ((unsigned)ih >= (unsigned)p.H || (unsigned)iw >= (unsigned)p.W) continue;
+          const f32x8 v = dw_load8(p.x + ((int64_t)(n * p.H + ih) * p.W + iw) * p.x_ld, c, p.C, vec);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[a][j] += g.v[j] * v.v[j];
+        }
+      }
+    }
+    for (int a = 0; a < T; ++a) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = 0.f;
+#pragma unroll
+        for (int aa = 0; aa < kDwMaxTaps; ++aa)
+          if (aa == a) v = acc[aa][j];
+        red[t * 8 + j] = v;
+      }
+      __syncthreads();
+      for (int idx = t; idx < cols * 8; idx += 256) {
+        const int x = idx >> 3, j = idx & 7;
+        float s = 0.f;
+        for (int yy = 0; yy < rpp; ++yy) s += red[(yy * cols + x) * 8 + j];
+        const int cc = (cv0 + x) * 8 + j;
+        if (cv0 + x < CV && cc < p.C && s != 0.f) unsafeAtomicAdd(p.dw + (int64_t)cc * T + a, s);
+      }
+    }
+  }
+}
+
+static int fill(const cvhip_conv_desc* d, DwParams* p) {
+  if (!d) return CVHIP_ERR_INVALID;
+  if (d->groups != d->C || d->K != d->C) return CVHIP_ERR_UNSUPPORTED;
+  if (d->N <= 0 || d->C <= 0 || d->H <= 0 || d->W <= 0 || d->R <= 0 || d->S <= 0 || d->stride_h <= 0 || d->stride_w <= 0 ||
+      d->dil_h <= 0 || d->dil_w <= 0 || d->pad_h < 0 || d->pad_w < 0 || d->x_ld < d->C || d->y_ld < d->C)
+    return CVHIP_ERR_INVALID;
+  memset(p, 0, sizeof(*p));
+  p->N = d->N;
+  p->C = d->C;
+  p->H = d->H;
+  p->W = d->W;
+  p->R = d->R;
+  p->S = d->S;
+  p->sh = d->stride_h;
+  p->sw = d->stride_w;
+  p->ph = d->pad_h;
+  p->pw = d->pad_w;
+  p->dh = d->dil_h;
+  p->dw_ = d->dil_w;
+  p->P = conv_out_dim(d->H, d->pad_h, d->dil_h, d->R, d->stride_h);
+  p->Q = conv_out_dim(d->W, d->pad_w, d->dil_w, d->S, d->stride_w);
+  if (p->P <= 0 || p->Q <= 0) return CVHIP_ERR_INVALID;
+  return CVHIP_OK;
+}
+
+static inline int grid_for(int64_t total) {
+  int64_t b = cdiv64(total, 256);
+  if (b > 256 * 32) b = 256 * 32;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace cvhip
+
+using namespace cvhip;
+
+extern "C" {
+
+int cvhip_dwconv2d_fprop(const cvhip_conv_desc* d, const void* x, const float* w, const float* bias, void* y, void* stream) {
+  DwParams p;
+  int st = fill(d, &p);
+  if (st) return st;
+  if (!x || !w || !y) return CVHIP_ERR_INVALID;
+  p.x = (const bf16_t*)x;
+  p.w = w;
+  p.bias = bias;
+  p.y = (bf16_t*)y;
+  p.x_ld = d->x_ld;
+  p.y_ld = d->y_ld;
+  hipLaunchKernelGGL(dw_fprop_kernel, dim3(grid_for((int64_t)p.N * p.P * p.Q * ((p.C + 7) / 8))), dim3(256), 0,
+                     (hipStream_t)stream, p);
+  return check_launch("dw_fprop_kernel");
+}
+
+int cvhip_dwconv2d_dgrad(const cvhip_conv_desc* d, const void* dy, const float* w, void* dx, void* stream) {
+  DwParams p;
+  int st = fill(d, &p);
+  if (st) return st;
+  if (!dy || !w || !dx) return CVHIP_ERR_INVALID;
+  p.x = (const bf16_t*)dy;
+  p.w = w;
+  p.y = (bf16_t*)dx;
+  p.x_ld = d->y_ld;  // pitch of dy
+  p.y_ld = d->x_ld;  // pitch of dx
+  hipLaunchKernelGGL(dw_dgrad_kernel, dim3(grid_for((int64_t)p.N * p.H * p.W * ((p.C + 7) / 8))), dim3(256), 0,
+                     (hipStream_t)stream, p);
+  return check_launch("dw_dgrad_kernel");
+}
+
+int cvhip_dwconv2d_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate, void* stream) {
+  DwParams p;
+  int st = fill(d, &p);
+  if (st) return st;
+  if (!x || !dy || !dw) return CVHIP_ERR_INVALID;
+  if (p.R * p.S > kDwMaxTaps) return CVHIP_ERR_UNSUPPORTED;
+  p.x = (const bf16_t*)x;
+  p.dy = (const bf16_t*)dy;
+  p.dw = dw;
+  p.x_ld = d->x_ld;
+  p.y_ld = d->y_ld;
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)p.C * p.R * p.S, s);
+    if (e != hipSuccess) {
+      set_last_error("hipMemsetAsync(dw)", e);
+      return CVHIP_ERR_LAUNCH;
+    }
+  }
+  const int64_t M = (int64_t)p.N * p.P * p.Q;
+  int64_t blocks = cdiv64(M, 256);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  const int rows_per_block = (int)cdiv64(M, blocks);
+  hipLaunchKernelGGL(dw_wgrad_kernel, dim3((int)blocks), dim3(256), 0, s, p, rows_per_block);
+  return check_launch("dw_wgrad_kernel");
+}
+
+}  // extern "C"

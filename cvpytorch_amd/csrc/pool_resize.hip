@@ -1,0 +1,664 @@
+// pool_resize.hip — pooling / resampling / layout glue on NHWC bf16 (HBM-bound streaming kernels,
+// 16-B channel vectors per thread where C % 8 == 0, scalar fallback otherwise).
+//
+// Reference call sites: src/models/modules/yolo_modules.py:147,152 (nearest x2 + cat),
+// :176-192 (SPPF max-pools), src/models/heads/seg/deeplabv3plus_head.py:56-66 and
+// src/models/segmentors/encoder_decoder.py:99 (bilinear), src/models/modules/yolo_modules.py:30-36
+// (Focus space-to-depth).
+#include "common.h"
+
+namespace cvhip {
+
+__device__ __forceinline__ bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// generic 8-wide load/store helpers with scalar tail
+__device__ __forceinline__ f32x8 load8(const bf16_t* p, int c, int C, bool vec) {
+  if (vec) return unpack8(*reinterpret_cast<const uint4*>(p + c));
+  f32x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r.v[j] = (c + j < C) ? (float)p[c + j] : 0.f;
+  return r;
+}
+__device__ __forceinline__ void store8(bf16_t* p, int c, int C, bool vec, const f32x8& v) {
+  if (vec) {
+    *reinterpret_cast<uint4*>(p + c) = pack8(v);
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (c + j < C) p[c + j] = (bf16_t)v.v[j];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// max pool
+// ---------------------------------------------------------------------------------------------------
+struct PoolParams {
+  const bf16_t* x;
+  bf16_t* y;
+  uint8_t* idx;
+  const bf16_t* dy;
+  const uint8_t* cidx;
+  bf16_t* dx;
+  int ld_x, ld_y, ld_dy, ld_dx;
+  int N, C, H, W, OH, OW, k, s, pad;
+  int accumulate;
+};
+
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const PoolParams p) {
+  const int CV = (p.C + 7) >> 3;
+  const bool vec = (p.C & 7) == 0 && (p.ld_x & 7) == 0 && (p.ld_y & 7) == 0 && aligned16(p.x) && aligned16(p.y);
+  const int64_t total = (int64_t)p.N * p.OH * p.OW * CV;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    int64_t pix = i / CV;
+    const int ow = (int)(pix % p.OW);
+    pix /= p.OW;
+    const int oh = (int)(pix % p.OH);
+    const int n = (int)(pix / p.OH);
+    const int c = cv * 8;
+    const int h0 = oh * p.s - p.pad, w0 = ow * p.s - p.pad;
+    float best[8];
+    int bi[8];
+    bool first = true;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      best[j] = -INFINITY;
+      bi[j] = 0;
+    }
+    for (int kh = 0; kh < p.k; ++kh) {
+      const int ih = h0 + kh;
+      if ((unsigned)ih >= (unsigned)p.H) continue;
+      for (int kw = 0; kw < p.k; ++kw) {
+        const int iw = w0 + kw;
+        if ((unsigned)iw >= (unsigned)p.W) continue;
+        const f32x8 v = load8(p.x + ((int64_t)(n * p.H + ih) * p.W + iw) * p.ld_x, c, p.C, vec);
+        const int off = kh * p.k + kw;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          // ATen rule: the first in-bounds tap seeds the index (value stays -inf); a later tap wins
+          // only if strictly greater, or NaN.
+          if (first) bi[j] = off;
+          if (v.v[j] > best[j] || v.v[j] != v.v[j]) {
+            best[j] = v.v[j];
+            bi[j] = off;
+          }
+        }
+        first = false;
+      }
+    }
+    const int64_t opix = ((int64_t)(n * p.OH + oh) * p.OW + ow);
+    f32x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.v[j] = best[j];
+    store8(p.y + opix * p.ld_y, c, p.C, vec, o);
+    if (p.idx) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (c + j < p.C) p.idx[opix * p.C + c + j] = (uint8_t)bi[j];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolParams p) {
+  const int CV = (p.C + 7) >> 3;
+  const bool vec = (p.C & 7) == 0 && (p.ld_dy & 7) == 0 && (p.ld_dx & 7) == 0 && aligned16(p.dy) && aligned16(p.dx);
+  const int64_t total = (int64_t)p.N * p.H * p.W * CV;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    int64_t pix = i / CV;
+    const int iw = (int)(pix % p.W);
+    pix /= p.W;
+    const int ih = (int)(pix % p.H);
+    const int n = (int)(pix / p.H);
+    const int c = cv * 8;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    // outputs whose window covers (ih, iw): oh*s - pad <= ih <= oh*s - pad + k - 1
+    int oh_lo = ih + p.pad - p.k + 1;
+    oh_lo = oh_lo <= 0 ? 0 : (oh_lo + p.s - 1) / p.s;
+    int oh_hi = (ih + p.pad) / p.s;
+    if (oh_hi > p.OH - 1) oh_hi = p.OH - 1;
+    int ow_lo = iw + p.pad - p.k + 1;
+    ow_lo = ow_lo <= 0 ? 0 : (ow_lo + p.s - 1) / p.s;
+    int ow_hi = (iw + p.pad) / p.s;
+    if (ow_hi > p.OW - 1) ow_hi = p.OW - 1;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+      const int kh = ih - (oh * p.s - p.pad);
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        const int kw = iw - (ow * p.s - p.pad);
+        const int off = kh * p.k + kw;
+        const int64_t opix = ((int64_t)(n * p.OH + oh) * p.OW + ow);
+        const f32x8 g = load8(p.dy + opix * p.ld_dy, c, p.C, vec);
+        const uint8_t* ip = p.cidx + opix * p.C + c;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (c + j < p.C && ip[j] == off) acc[j] += g.v[j];
+      }
+    }
+    bf16_t* dst = p.dx + ((int64_t)(n * p.H + ih) * p.W + iw) * p.ld_dx;
+    f32x8 o;
+    if (p.accumulate) {
+      const f32x8 old = load8(dst, c, p.C, vec);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o.v[j] = old.v[j] + acc[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o.v[j] = acc[j];
+    }
+    store8(dst, c, p.C, vec, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// nearest x2 upsample + channel concat
+// ---------------------------------------------------------------------------------------------------
+struct UpParams {
+  const bf16_t *a, *b;
+  bf16_t* out;
+  int ld_a, ld_b, ld_out, Ca, Cb, N, Ha, Wa;
+};
+
+__global__ __launch_bounds__(256) void up2cat_fwd_kernel(const UpParams p) {
+  const int Ct = p.Ca + p.Cb;
+  const int CVa = (p.Ca + 7) >> 3, CVb = (p.Cb + 7) >> 3;
+  const int CV = CVa + CVb;
+  const int OH = p.Ha * 2, OW = p.Wa * 2;
+  const bool vec = (p.Ca & 7) == 0 && (p.Cb & 7) == 0 && (p.ld_a & 7) == 0 && (p.ld_b & 7) == 0 &&
+                   (p.ld_out & 7) == 0 && aligned16(p.a) && aligned16(p.b) && aligned16(p.out);
+  (void)Ct;
+  const int64_t total = (int64_t)p.N * OH * OW * CV;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    int64_t pix = i / CV;
+    const int ow = (int)(pix % OW);
+    pix /= OW;
+    const int oh = (int)(pix % OH);
+    const int n = (int)(pix / OH);
+    bf16_t* orow = p.out + ((int64_t)(n * OH + oh) * OW + ow) * p.ld_out;
+    if (cv < CVa) {
+      const f32x8 v = load8(p.a + ((int64_t)(n * p.Ha + (oh >> 1)) * p.Wa + (ow >> 1)) * p.ld_a, cv * 8, p.Ca, vec);
+      store8(orow, cv * 8, p.Ca, vec, v);
+    } else {
+      const int cb = (cv - CVa) * 8;
+      const f32x8 v = load8(p.b + ((int64_t)(n * OH + oh) * OW + ow) * p.ld_b, cb, p.Cb, vec);
+      store8(orow + p.Ca, cb, p.Cb, vec, v);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void up2_bwd_kernel(const UpParams p) {
+  // p.out = dout (read), p.a = da (write)
+  const int CV = (p.Ca + 7) >> 3;
+  const int OW = p.Wa * 2, OH = p.Ha * 2;
+  const bool vec = (p.Ca & 7) == 0 && (p.ld_a & 7) == 0 && (p.ld_out & 7) == 0 && aligned16(p.a) && aligned16(p.out);
+  const int64_t total = (int64_t)p.N * p.Ha * p.Wa * CV;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    int64_t pix = i / CV;
+    const int w = (int)(pix % p.Wa);
+    pix /= p.Wa;
+    const int h = (int)(pix % p.Ha);
+    const int n = (int)(pix / p.Ha);
+    f32x8 s;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s.v[j] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const f32x8 v = load8(p.out + ((int64_t)(n * OH + 2 * h + dy) * OW + 2 * w + dx) * p.ld_out, cv * 8, p.Ca, vec);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s.v[j] += v.v[j];
+      }
+    store8(const_cast<bf16_t*>(p.a) + ((int64_t)(n * p.Ha + h) * p.Wa + w) * p.ld_a, cv * 8, p.Ca, vec, s);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// bilinear resize (ATen upsample_bilinear2d index rule)
+// ---------------------------------------------------------------------------------------------------
+struct BilParams {
+  const bf16_t* src;
+  bf16_t* dst;
+  int ld_src, ld_dst, N, C, Hi, Wi, Ho, Wo, align;
+  float sh, sw;  // source-index scale
+};
+
+__device__ __forceinline__ void bil_src(int o, float scale, int align, int in, int* i0, int* i1, float* l1) {
+  float s;
+  if (align) s = scale * o;
+  else {
+    s = scale * (o + 0.5f) - 0.5f;
+    if (s < 0.f) s = 0.f;
+  }
+  int a = (int)s;
+  if (a > in - 1) a = in - 1;
+  const int b = a + ((a < in - 1) ? 1 : 0);
+  *i0 = a;
+  *i1 = b;
+  *l1 = s - (float)a;
+}
+
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const BilParams p) {
+  const int CV = (p.C + 7) >> 3;
+  const bool vec = (p.C & 7) == 0 && (p.ld_src & 7) == 0 && (p.ld_dst & 7) == 0 && aligned16(p.src) && aligned16(p.dst);
+  const int64_t total = (int64_t)p.N * p.Ho * p.Wo * CV;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    int64_t pix = i / CV;
+    const int ow = (int)(pix % p.Wo);
+    pix /= p.Wo;
+    const int oh = (int)(pix % p.Ho);
+    const int n = (int)(pix / p.Ho);
+    int h0, h1, w0, w1;
+    float lh, lw;
+    bil_src(oh, p.sh, p.align, p.Hi, &h0, &h1, &lh);
+    bil_src(ow, p.sw, p.align, p.Wi, &w0, &w1, &lw);
+    const bf16_t* base = p.src + (int64_t)n * p.Hi * p.Wi * p.ld_src;
+    const f32x8 v00 = load8(base + ((int64_t)h0 * p.Wi + w0) * p.ld_src, cv * 8, p.C, vec);
+    const f32x8 v01 = load8(base + ((int64_t)h0 * p.Wi + w1) * p.ld_src, cv * 8, p.C, vec);
+    const f32x8 v10 = load8(base + ((int64_t)h1 * p.Wi + w0) * p.ld_src, cv * 8, p.C, vec);
+    const f32x8 v11 = load8(base + ((int64_t)h1 * p.Wi + w1) * p.ld_src, cv * 8, p.C, vec);
+    const float a0 = 1.f - lh, a1 = lh, b0 = 1.f - lw, b1 = lw;
+    f32x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.v[j] = a0 * (b0 * v00.v[j] + b1 * v01.v[j]) + a1 * (b0 * v10.v[j] + b1 * v11.v[j]);
+    store8(p.dst + ((int64_t)(n * p.Ho + oh) * p.Wo + ow) * p.ld_dst, cv * 8, p.C, vec, o);
+  }
+}
+
+// backward as a deterministic gather: each INPUT pixel scans the (small) range of output pixels that
+// can reference it and re-derives their interpolation weights.
+__device__ __forceinline__ void bil_range(int i, float scale, int align, int out, int* lo, int* hi) {
+  // outputs o with floor(src(o)) in {i-1, i}; src is monotone in o. Conservative bounds, then exact test.
+  const float inv = scale > 0.f ? 1.f / scale : 0.f;
+  float a, b;
+  if (align) {
+    a = (i - 1) * inv;
+    b = (i + 1) * inv;
+  } else {
+    a = (i - 1 + 0.5f) * inv - 0.5f;
+    b = (i + 1 + 0.5f) * inv - 0.5f;
+  }
+  int l = (int)floorf(a) - 1, h = (int)ceilf(b) + 1;
+  if (scale <= 0.f) {
+    l = 0;
+    h = out - 1;
+  }
+  if (l < 0) l = 0;
+  if (h > out - 1) h = out - 1;
+  *lo = l;
+  *hi = h;
+}
+
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const BilParams p) {
+  // p.src = dy (Ho x Wo, read), p.dst = dx (Hi x Wi, write)
+  const int CV = (p.C + 7) >> 3;
+  const bool vec = (p.C & 7) == 0 && (p.ld_src & 7) == 0 && (p.ld_dst & 7) == 0 && aligned16(p.src) && aligned16(p.dst);
+  const int64_t total = (int64_t)p.N * p.Hi * p.Wi * CV;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    int64_t pix = i / CV;
+    const int iw = (int)(pix % p.Wi);
+    pix /= p.Wi;
+    const int ih = (int)(pix % p.Hi);
+    const int n = (int)(pix / p.Hi);
+    int oh_lo, oh_hi, ow_lo, ow_hi;
+    bil_range(ih, p.sh, p.align, p.Ho, &oh_lo, &oh_hi);
+    bil_range(iw, p.sw, p.align, p.Wo, &ow_lo, &ow_hi);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    const bf16_t* base = p.src + (int64_t)n * p.Ho * p.Wo * p.ld_src;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+      int h0, h1;
+      float lh;
+      bil_src(oh, p.sh, p.align, p.Hi, &h0, &h1, &lh);
+      float wh = 0.f;
+      if (h0 == ih) wh += 1.f - lh;
+      if (h1 == ih) wh += lh;
+      if (wh == 0.f) continue;
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        int w0, w1;
+        float lw;
+        bil_src(ow, p.sw, p.align, p.Wi, &w0, &w1, &lw);
+        float ww = 0.f;
+        if (w0 == iw) ww += 1.f - lw;
+        if (w1 == iw) ww += lw;
+        if (ww == 0.f) continue;
+        const f32x8 g = load8(base + ((int64_t)oh * p.Wo + ow) * p.ld_src, cv * 8, p.C, vec);
+        const float wgt = wh * ww;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += wgt * g.v[j];
+      }
+    }
+    f32x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.v[j] = acc[j];
+    store8(p.dst + ((int64_t)(n * p.Hi + ih) * p.Wi + iw) * p.ld_dst, cv * 8, p.C, vec, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// global average pool
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const bf16_t* x, int ld_x, bf16_t* y, int N, int C, int HW) {
+  // block = (image n, 32 channels); 256 threads = 8 row-lanes x 32 channels
+  __shared__ float red[8][33];
+  const int n = blockIdx.y, c = blockIdx.x * 32 + (threadIdx.x & 31), ry = threadIdx.x >> 5;
+  float s = 0.f;
+  if (c < C)
+    for (int r = ry; r < HW; r += 8) s += (float)x[((int64_t)n * HW + r) * ld_x + c];
+  red[ry][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x & 31];
+    y[(int64_t)n * C + c] = (bf16_t)(t / (float)HW);
+  }
+}
+
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const bf16_t* dy, bf16_t* dx, int ld_dx, int N, int C, int HW) {
+  const int64_t total = (int64_t)N * HW * C;
+  const float inv = 1.f / (float)HW;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int64_t pix = i / C;
+    const int n = (int)(pix / HW);
+    dx[pix * ld_dx + c] = (bf16_t)((float)dy[(int64_t)n * C + c] * inv);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// layout conversions at the torch boundary
+// ---------------------------------------------------------------------------------------------------
+// mode 0: plain NCHW fp32 -> NHWC bf16 (pitch ld, channels >= C zero-filled up to Cfill)
+// mode 1: Focus space-to-depth: out (N, H/2, W/2, 4C) channel order TL, BL, TR, BR
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, bf16_t* y, int N, int C, int H, int W, int ld,
+                                                           int Cfill, int focus) {
+  const int OH = focus ? H / 2 : H, OW = focus ? W / 2 : W;
+  const int64_t total = (int64_t)N * OH * OW;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ow = (int)(i % OW);
+    const int oh = (int)((i / OW) % OH);
+    const int n = (int)(i / ((int64_t)OW * OH));
+    bf16_t* dst = y + i * ld;
+    const int Cout = focus ? 4 * C : C;
+    for (int c = 0; c < Cout; ++c) {
+      float v;
+      if (focus) {
+        const int patch = c / C, cc = c - patch * C;
+        const int dh = patch & 1, dw = patch >> 1;  // order TL(0,0) BL(1,0) TR(0,1) BR(1,1)
+        v = x[((int64_t)(n * C + cc) * H + (2 * oh + dh)) * W + (2 * ow + dw)];
+      } else {
+        v = x[((int64_t)(n * C + c) * H + oh) * W + ow];
+      }
+      dst[c] = (bf16_t)v;
+    }
+    for (int c = Cout; c < Cfill; ++c) dst[c] = (bf16_t)0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const bf16_t* x, int ld, float* y, int N, int C, int H, int W) {
+  const int64_t HW = (int64_t)H * W;
+  const int64_t total = (int64_t)N * HW;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t n = i / HW, hw = i - n * HW;
+    const bf16_t* src = x + i * ld;
+    for (int c = 0; c < C; ++c) y[(n * C + c) * HW + hw] = (float)src[c];
+  }
+}
+
+
+// YOLO head boundary: bf16 NHWC (N,H,W,ld>=A*NO) <-> fp32 (N,A,H,W,NO) contiguous.
+// Fuses the reference's x.view(bs,na,no,ny,nx).permute(0,1,3,4,2).contiguous() (+ fp32 cast for the
+// loss) — src/models/detects/yolov5_detect.py:43-44.
+__global__ __launch_bounds__(256) void head_permute_fwd_kernel(const bf16_t* x, int ld, float* y, int N, int A, int NO, int H, int W) {
+  const int64_t total = (int64_t)N * A * H * W * NO;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int o = (int)(i % NO);
+    int64_t r = i / NO;
+    const int xw = (int)(r % W);
+    r /= W;
+    const int yh = (int)(r % H);
+    r /= H;
+    const int a = (int)(r % A);
+    const int n = (int)(r / A);
+    y[i] = (float)x[((int64_t)(n * H + yh) * W + xw) * ld + a * NO + o];
+  }
+}
+__global__ __launch_bounds__(256) void head_permute_bwd_kernel(const float* dy, bf16_t* dx, int ld, int N, int A, int NO, int H, int W) {
+  // one thread per (pixel, channel<ld); pad channels >= A*NO are zero-filled
+  const int64_t total = (int64_t)N * H * W * ld;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % ld);
+    int64_t pix = i / ld;
+    float v = 0.f;
+    if (c < A * NO) {
+      const int a = c / NO, o = c - a * NO;
+      const int xw = (int)(pix % W);
+      const int yh = (int)((pix / W) % H);
+      const int n = (int)(pix / ((int64_t)W * H));
+      v = dy[((((int64_t)n * A + a) * H + yh) * W + xw) * NO + o];
+    }
+    dx[i] = (bf16_t)v;
+  }
+}
+
+static inline int grid_for(int64_t total) {
+  int64_t b = cdiv64(total, 256);
+  if (b > 256 * 32) b = 256 * 32;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace cvhip
+
+using namespace cvhip;
+
+extern "C" {
+
+int cvhip_maxpool2d_fwd(const void* x, int32_t ld_x, void* y, int32_t ld_y, uint8_t* argmax, int32_t N, int32_t C,
+                        int32_t H, int32_t W, int32_t k, int32_t stride, int32_t pad, void* stream) {
+  if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0 || stride <= 0 || pad < 0) return CVHIP_ERR_INVALID;
+  if (k * k > 255 || pad * 2 > k) return CVHIP_ERR_UNSUPPORTED;
+  PoolParams p{};
+  p.x = (const bf16_t*)x;
+  p.y = (bf16_t*)y;
+  p.idx = argmax;
+  p.ld_x = ld_x;
+  p.ld_y = ld_y;
+  p.N = N;
+  p.C = C;
+  p.H = H;
+  p.W = W;
+  p.k = k;
+  p.s = stride;
+  p.pad = pad;
+  p.OH = (H + 2 * pad - k) / stride + 1;
+  p.OW = (W + 2 * pad - k) / stride + 1;
+  const int64_t total = (int64_t)N * p.OH * p.OW * ((C + 7) / 8);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("maxpool_fwd_kernel");
+}
+
+int cvhip_maxpool2d_bwd(const void* dy, int32_t ld_dy, const uint8_t* argmax, void* dx, int32_t ld_dx, int32_t N,
+                        int32_t C, int32_t H, int32_t W, int32_t k, int32_t stride, int32_t pad, int accumulate,
+                        void* stream) {
+  if (!dy || !dx || !argmax || N <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0 || stride <= 0 || pad < 0)
+    return CVHIP_ERR_INVALID;
+  PoolParams p{};
+  p.dy = (const bf16_t*)dy;
+  p.cidx = argmax;
+  p.dx = (bf16_t*)dx;
+  p.ld_dy = ld_dy;
+  p.ld_dx = ld_dx;
+  p.N = N;
+  p.C = C;
+  p.H = H;
+  p.W = W;
+  p.k = k;
+  p.s = stride;
+  p.pad = pad;
+  p.OH = (H + 2 * pad - k) / stride + 1;
+  p.OW = (W + 2 * pad - k) / stride + 1;
+  p.accumulate = accumulate;
+  const int64_t total = (int64_t)N * H * W * ((C + 7) / 8);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("maxpool_bwd_kernel");
+}
+
+int cvhip_upsample2x_cat_fwd(const void* a, int32_t ld_a, int32_t Ca, const void* b, int32_t ld_b, int32_t Cb,
+                             void* out, int32_t ld_out, int32_t N, int32_t Ha, int32_t Wa, void* stream) {
+  if (!a || !out || Ca <= 0 || Cb < 0 || (Cb > 0 && !b) || N <= 0 || Ha <= 0 || Wa <= 0) return CVHIP_ERR_INVALID;
+  UpParams p{};
+  p.a = (const bf16_t*)a;
+  p.b = (const bf16_t*)b;
+  p.out = (bf16_t*)out;
+  p.ld_a = ld_a;
+  p.ld_b = ld_b;
+  p.ld_out = ld_out;
+  p.Ca = Ca;
+  p.Cb = Cb;
+  p.N = N;
+  p.Ha = Ha;
+  p.Wa = Wa;
+  const int64_t total = (int64_t)N * Ha * 2 * Wa * 2 * ((Ca + 7) / 8 + (Cb + 7) / 8);
+  hipLaunchKernelGGL(up2cat_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("up2cat_fwd_kernel");
+}
+
+int cvhip_upsample2x_bwd(const void* dout, int32_t ld_dout, void* da, int32_t ld_da, int32_t Ca, int32_t N, int32_t Ha,
+                         int32_t Wa, void* stream) {
+  if (!dout || !da || Ca <= 0 || N <= 0 || Ha <= 0 || Wa <= 0) return CVHIP_ERR_INVALID;
+  UpParams p{};
+  p.out = (bf16_t*)const_cast<void*>(dout);
+  p.a = (const bf16_t*)da;
+  p.ld_out = ld_dout;
+  p.ld_a = ld_da;
+  p.Ca = Ca;
+  p.N = N;
+  p.Ha = Ha;
+  p.Wa = Wa;
+  const int64_t total = (int64_t)N * Ha * Wa * ((Ca + 7) / 8);
+  hipLaunchKernelGGL(up2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("up2_bwd_kernel");
+}
+
+static void bil_scales(int Hi, int Wi, int Ho, int Wo, int align, float* sh, float* sw) {
+  if (align) {
+    *sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
+    *sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+  } else {
+    *sh = (float)Hi / (float)Ho;
+    *sw = (float)Wi / (float)Wo;
+  }
+}
+
+int cvhip_resize_bilinear_fwd(const void* x, int32_t ld_x, void* y, int32_t ld_y, int32_t N, int32_t C, int32_t Hi,
+                              int32_t Wi, int32_t Ho, int32_t Wo, int32_t align_corners, void* stream) {
+  if (!x || !y || N <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return CVHIP_ERR_INVALID;
+  BilParams p{};
+  p.src = (const bf16_t*)x;
+  p.dst = (bf16_t*)y;
+  p.ld_src = ld_x;
+  p.ld_dst = ld_y;
+  p.N = N;
+  p.C = C;
+  p.Hi = Hi;
+  p.Wi = Wi;
+  p.Ho = Ho;
+  p.Wo = Wo;
+  p.align = align_corners;
+  bil_scales(Hi, Wi, Ho, Wo, align_corners, &p.sh, &p.sw);
+  const int64_t total = (int64_t)N * Ho * Wo * ((C + 7) / 8);
+  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("bilinear_fwd_kernel");
+}
+
+int cvhip_resize_bilinear_bwd(const void* dy, int32_t ld_dy, void* dx, int32_t ld_dx, int32_t N, int32_t C, int32_t Hi,
+                              int32_t Wi, int32_t Ho, int32_t Wo, int32_t align_corners, void* stream) {
+  if (!dy || !dx || N <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return CVHIP_ERR_INVALID;
+  BilParams p{};
+  p.src = (const bf16_t*)dy;
+  p.dst = (bf16_t*)dx;
+  p.ld_src = ld_dy;
+  p.ld_dst = ld_dx;
+  p.N = N;
+  p.C = C;
+  p.Hi = Hi;
+  p.Wi = Wi;
+  p.Ho = Ho;
+  p.Wo = Wo;
+  p.align = align_corners;
+  bil_scales(Hi, Wi, Ho, Wo, align_corners, &p.sh, &p.sw);
+  const int64_t total = (int64_t)N * Hi * Wi * ((C + 7) / 8);
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("bilinear_bwd_kernel");
+}
+
+int cvhip_global_avgpool_fwd(const void* x, int32_t ld_x, void* y, int32_t N, int32_t C, int32_t HW, void* stream) {
+  if (!x || !y || N <= 0 || C <= 0 || HW <= 0) return CVHIP_ERR_INVALID;
+  hipLaunchKernelGGL(gap_fwd_kernel, dim3(cdiv(C, 32), N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld_x,
+                     (bf16_t*)y, N, C, HW);
+  return check_launch("gap_fwd_kernel");
+}
+
+int cvhip_global_avgpool_bwd(const void* dy, void* dx, int32_t ld_dx, int32_t N, int32_t C, int32_t HW, void* stream) {
+  if (!dy || !dx || N <= 0 || C <= 0 || HW <= 0) return CVHIP_ERR_INVALID;
+  hipLaunchKernelGGL(gap_bwd_kernel, dim3(grid_for((int64_t)N * HW * C)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dy, (bf16_t*)dx, ld_dx, N, C, HW);
+  return check_launch("gap_bwd_kernel");
+}
+
+int cvhip_nchw_f32_to_nhwc_bf16(const float* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Cpad,
+                                void* stream) {
+  if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || Cpad < C) return CVHIP_ERR_INVALID;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, x,
+                     (bf16_t*)y, N, C, H, W, Cpad, Cpad, 0);
+  return check_launch("nchw_to_nhwc_kernel");
+}
+
+int cvhip_focus_nchw_f32_to_nhwc_bf16(const float* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Cpad,
+                                      void* stream) {
+  if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || Cpad < 4 * C) return CVHIP_ERR_INVALID;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((int64_t)N * H * W / 4)), dim3(256), 0, (hipStream_t)stream, x,
+                     (bf16_t*)y, N, C, H, W, Cpad, Cpad, 1);
+  return check_launch("nchw_to_nhwc_kernel(focus)");
+}
+
+int cvhip_nhwc_bf16_to_nchw_f32(const void* x, int32_t ld, float* y, int32_t N, int32_t C, int32_t H, int32_t W,
+                                void* stream) {
+  if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || ld < C) return CVHIP_ERR_INVALID;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, ld, y, N, C, H, W);
+  return check_launch("nhwc_to_nchw_kernel");
+}
+
+int cvhip_nchw_f32_to_nhwc_bf16_ld(const float* x, void* y, int32_t ld, int32_t N, int32_t C, int32_t H, int32_t W,
+                                   void* stream) {
+  if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || ld < C) return CVHIP_ERR_INVALID;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, x,
+                     (bf16_t*)y, N, C, H, W, ld, C, 0);
+  return check_launch("nchw_to_nhwc_kernel(ld)");
+}
+
+int cvhip_head_permute_fwd(const void* x, int32_t ld, float* y, int32_t N, int32_t A, int32_t NO, int32_t H, int32_t W,
+                           void* stream) {
+  if (!x || !y || N <= 0 || A <= 0 || NO <= 0 || H <= 0 || W <= 0 || ld < A * NO) return CVHIP_ERR_INVALID;
+  hipLaunchKernelGGL(head_permute_fwd_kernel, dim3(grid_for((int64_t)N * A * H * W * NO)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)x, ld, y, N, A, NO, H, W);
+  return check_launch("head_permute_fwd_kernel");
+}
+
+int cvhip_head_permute_bwd(const float* dy, void* dx, int32_t ld, int32_t N, int32_t A, int32_t NO, int32_t H, int32_t W,
+                           void* stream) {
+  if (!dy || !dx || N <= 0 || A <= 0 || NO <= 0 || H <= 0 || W <= 0 || ld < A * NO) return CVHIP_ERR_INVALID;
+  hipLaunchKernelGGL(head_permute_bwd_kernel, dim3(grid_for((int64_t)N * H * W * ld)), dim3(256), 0,
+                     (hipStream_t)stream, dy, (bf16_t*)dx, ld, N, A, NO, H, W);
+  return check_launch("head_permute_bwd_kernel");
+}
+
+}  // extern "C"

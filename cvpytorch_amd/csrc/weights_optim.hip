@@ -1,0 +1,149 @@
+// weights_optim.hip — weight operand packing (fp32 KRSC master -> bf16 fprop / dgrad images) and the
+// fused SGD-nesterov + EMA update over a flat fp32 parameter arena.
+//
+// Reference: autocast's per-forward weight cast (trainer.py:179-184), torch.optim.SGD
+// (src/optimizers/__init__.py:60-68) and ModelEMA.update (src/utils/ema.py:30-39).
+#include "common.h"
+#include "conv_plan.h"
+
+namespace cvhip {
+
+// w_fprop[k][r][s][c] = bf16(master[k][r][s][c])  — same element order, 8 elements per thread
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
+  const int64_t nv = n >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+    const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+    uint4 u;
+    u.x = pack2(a.x, a.y);
+    u.y = pack2(a.z, a.w);
+    u.z = pack2(b.x, b.y);
+    u.w = pack2(b.z, b.w);
+    reinterpret_cast<uint4*>(dst)[i] = u;
+  }
+  // tail
+  for (int64_t i = (nv << 3) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = (bf16_t)src[i];
+}
+
+struct DgradPack {
+  int ncls;
+  int K, R, S, C;
+  IgemmClass cls[kMaxClasses];
+};
+
+// dgrad image of class q: [c][i*TS + j][k] = master[k][r0+i*r_step][s0+j*s_step][c]
+// one thread per output element, k fastest (coalesced writes; reads strided by R*S*C — the weight
+// tensors are small and L2-resident).
+__global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* __restrict__ master, bf16_t* __restrict__ dst, const DgradPack p) {
+  const int q = blockIdx.y;
+  const IgemmClass& cl = p.cls[q];
+  const int T = cl.TR * cl.TS;
+  const int64_t total = (int64_t)p.C * T * p.K;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int k = (int)(idx % p.K);
+    const int64_t ct = idx / p.K;
+    const int tap = (int)(ct % T);
+    const int c = (int)(ct / T);
+    const int i = tap / cl.TS, j = tap - i * cl.TS;
+    const int r = cl.r0 + i * cl.r_step, s = cl.s0 + j * cl.s_step;
+    dst[cl.w_off + idx] = (bf16_t)master[(((int64_t)k * p.R + r) * p.S + s) * p.C + c];
+  }
+}
+
+// ---- fused optimizer ---------------------------------------------------------------------------------
+// torch.optim.SGD step for element i in segment g:
+//   d = grad*grad_scale + wd_g * p
+//   buf = first_step ? d : momentum*buf + d
+//   d = nesterov ? d + momentum*buf : buf
+//   p -= lr_g * d
+//   ema = decay*ema + (1-decay)*p        (if ema != NULL)
+__global__ __launch_bounds__(256) void sgd_ema_kernel(float* __restrict__ param, const float* __restrict__ grad,
+                                                      float* __restrict__ mom, float* __restrict__ ema, int64_t n,
+                                                      const int64_t* __restrict__ seg, const float* __restrict__ seg_lr,
+                                                      const float* __restrict__ seg_wd, int nseg, float momentum,
+                                                      int nesterov, int first, float decay, float gscale) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    // binary search the segment containing i (segments are sorted, disjoint, cover [0,n))
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (i >= seg[2 * mid + 1]) lo = mid + 1;
+      else hi = mid;
+    }
+    const float lr = seg_lr[lo], wd = seg_wd[lo];
+    float pv = param[i];
+    float d = grad[i] * gscale + wd * pv;
+    float b = first ? d : momentum * mom[i] + d;
+    mom[i] = b;
+    d = nesterov ? d + momentum * b : b;
+    pv -= lr * d;
+    param[i] = pv;
+    if (ema) ema[i] = decay * ema[i] + (1.f - decay) * pv;
+  }
+}
+
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ ema, const float* __restrict__ src, int64_t n, float decay) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    ema[i] = decay * ema[i] + (1.f - decay) * src[i];
+}
+
+static inline int grid1d(int64_t n) {
+  int64_t b = cdiv64(n, 256);
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+int pack_weights(const cvhip_conv_desc* d, const float* master, void* w_fprop, void* w_dgrad, hipStream_t stream) {
+  const int64_t n = (int64_t)d->K * d->R * d->S * d->C;
+  if (w_fprop) {
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid1d(n / 8 + 1)), dim3(256), 0, stream, master, (bf16_t*)w_fprop, n);
+    int st = check_launch("cast_f32_bf16_kernel");
+    if (st) return st;
+  }
+  if (w_dgrad) {
+    IgemmParams ip;
+    const int ncls = plan_dgrad(d, &ip);
+    if (ncls < 0) return ncls;
+    DgradPack p;
+    p.ncls = ncls;
+    p.K = d->K;
+    p.R = d->R;
+    p.S = d->S;
+    p.C = d->C;
+    int64_t maxe = 1;
+    for (int i = 0; i < ncls; ++i) {
+      p.cls[i] = ip.cls[i];
+      const int64_t e = (int64_t)d->C * ip.cls[i].TR * ip.cls[i].TS * d->K;
+      if (e > maxe) maxe = e;
+    }
+    hipLaunchKernelGGL(pack_dgrad_kernel, dim3(grid1d(maxe), ncls), dim3(256), 0, stream, master, (bf16_t*)w_dgrad, p);
+    return check_launch("pack_dgrad_kernel");
+  }
+  return CVHIP_OK;
+}
+
+}  // namespace cvhip
+
+using namespace cvhip;
+
+extern "C" {
+
+int cvhip_sgd_nesterov_ema(float* param, const float* grad, float* momentum_buf, float* ema, int64_t n,
+                           const int64_t* seg_bounds, const float* seg_lr, const float* seg_wd, int32_t nseg,
+                           float momentum, int32_t nesterov, int32_t first_step, float ema_decay, float grad_scale,
+                           void* stream) {
+  if (!param || !grad || !momentum_buf || n < 0 || !seg_bounds || !seg_lr || !seg_wd || nseg <= 0) return CVHIP_ERR_INVALID;
+  if (n == 0) return CVHIP_OK;
+  hipLaunchKernelGGL(sgd_ema_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, param, grad, momentum_buf, ema, n,
+                     seg_bounds, seg_lr, seg_wd, nseg, momentum, nesterov, first_step, ema_decay, grad_scale);
+  return check_launch("sgd_ema_kernel");
+}
+
+int cvhip_ema_update(float* ema, const float* src, int64_t n, float decay, void* stream) {
+  if (!ema || !src || n < 0) return CVHIP_ERR_INVALID;
+  if (n == 0) return CVHIP_OK;
+  hipLaunchKernelGGL(ema_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, ema, src, n, decay);
+  return check_launch("ema_kernel");
+}
+
+}  // extern "C"

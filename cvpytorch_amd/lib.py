@@ -1,0 +1,120 @@
+"""ctypes binding of libcvhip.so — the C ABI declared in include/cvhip.h.
+
+The product path has NO fallback: if the shared object is missing, or an entry point refuses a call,
+this module raises. (The pure-torch restatement under /oracle is test infrastructure only and is
+never imported from here.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcvhip.so")
+
+OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -1, -2, -3
+ACT_NONE, ACT_RELU, ACT_SILU, ACT_LEAKY, ACT_SIGMOID, ACT_HSWISH = 0, 1, 2, 3, 4, 5
+DGRAD_CLASS_INTS = 12
+
+
+class CvhipError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    """cvhip_conv_desc (include/cvhip.h)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "N", "C", "H", "W", "K", "R", "S", "stride_h", "stride_w", "pad_h", "pad_w", "dil_h", "dil_w",
+        "groups", "x_ld", "y_ld", "reserved0", "reserved1")]
+
+    def key(self):
+        return tuple(getattr(self, n) for n, _ in self._fields_)
+
+
+_p, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+_dp = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); mirrors include/cvhip.h one-to-one
+SIGNATURES = {
+    "cvhip_version": (_i32, []),
+    "cvhip_last_error": (C.c_char_p, []),
+    "cvhip_conv2d_out_hw": (_i32, [_dp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "cvhip_conv2d_fprop_stats_rows": (_i32, [_dp]),
+    "cvhip_conv2d_dgrad_weight_elems": (_i64, [_dp]),
+    "cvhip_conv2d_dgrad_plan": (_i32, [_dp, C.POINTER(_i32), _i32]),
+    "cvhip_conv2d_prep_weights": (_i32, [_dp, _p, _p, _p, _p]),
+    "cvhip_conv2d_fprop": (_i32, [_dp, _p, _p, _p, _p, _p, _p]),
+    "cvhip_conv2d_dgrad": (_i32, [_dp, _p, _p, _p, _p]),
+    "cvhip_conv2d_wgrad": (_i32, [_dp, _p, _p, _p, _i32, _p]),
+    "cvhip_dwconv2d_fprop": (_i32, [_dp, _p, _p, _p, _p, _p]),
+    "cvhip_dwconv2d_dgrad": (_i32, [_dp, _p, _p, _p, _p]),
+    "cvhip_dwconv2d_wgrad": (_i32, [_dp, _p, _p, _p, _i32, _p]),
+    "cvhip_colreduce_rows": (_i32, [_i64, _i32]),
+    "cvhip_bn_stats_partial": (_i32, [_p, _i64, _i32, _i32, _p, _p]),
+    "cvhip_bn_finalize": (_i32, [_p, _i32, _i32, _i64, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _p]),
+    "cvhip_bn_eval_scale_shift": (_i32, [_i32, _p, _p, _p, _p, _f32, _p, _p, _p]),
+    "cvhip_bn_act_fwd": (_i32, [_p, _i32, _p, _i32, _i64, _i32, _p, _p, _i32, _f32, _p, _i32, _p]),
+    "cvhip_bn_act_bwd_partial": (_i32, [_p, _i32, _p, _i32, _i64, _i32, _p, _p, _p, _p, _i32, _f32, _p, _p]),
+    "cvhip_bn_bwd_finalize": (_i32, [_p, _i32, _i32, _p, _p, _p]),
+    "cvhip_bn_act_bwd_apply": (_i32, [_p, _i32, _p, _i32, _p, _i32, _i64, _i32, _p, _p, _p, _p, _p, _p, _i32, _f32, _p]),
+    "cvhip_colsum_partial": (_i32, [_p, _i64, _i32, _i32, _p, _p]),
+    "cvhip_colsum_finalize": (_i32, [_p, _i32, _i32, _p, _i32, _p]),
+    "cvhip_maxpool2d_fwd": (_i32, [_p, _i32, _p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "cvhip_maxpool2d_bwd": (_i32, [_p, _i32, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "cvhip_upsample2x_cat_fwd": (_i32, [_p, _i32, _i32, _p, _i32, _i32, _p, _i32, _i32, _i32, _i32, _p]),
+    "cvhip_upsample2x_bwd": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    "cvhip_copy2d": (_i32, [_p, _i32, _p, _i32, _i64, _i32, _p]),
+    "cvhip_add2d": (_i32, [_p, _i32, _p, _i32, _p, _i32, _i64, _i32, _p]),
+    "cvhip_resize_bilinear_fwd": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "cvhip_resize_bilinear_bwd": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "cvhip_global_avgpool_fwd": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _p]),
+    "cvhip_global_avgpool_bwd": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _p]),
+    "cvhip_nchw_f32_to_nhwc_bf16": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    "cvhip_focus_nchw_f32_to_nhwc_bf16": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    "cvhip_nhwc_bf16_to_nchw_f32": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _p]),
+    "cvhip_nchw_f32_to_nhwc_bf16_ld": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    "cvhip_head_permute_fwd": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    "cvhip_head_permute_bwd": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "cvhip_yolov5_decode": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _f32, _p, _i64, _i64, _p]),
+    "cvhip_nms_workspace_bytes": (_i64, [_i32]),
+    "cvhip_nms_sorted": (_i32, [_p, _i32, _f32, _p, _p, _p, _p]),
+    "cvhip_box_iou": (_i32, [_p, _i32, _p, _i32, _p, _p]),
+    "cvhip_sgd_nesterov_ema": (_i32, [_p, _p, _p, _p, _i64, _p, _p, _p, _i32, _f32, _i32, _i32, _f32, _f32, _p]),
+    "cvhip_ema_update": (_i32, [_p, _p, _i64, _f32, _p]),
+    "cvhip_probe_mfma_16x16x32": (_i32, [_p, _p, _p, _p]),
+    "cvhip_probe_ds_read_tr16": (_i32, [_p, _p, _p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libcvhip.so (once). Raises CvhipError if it has not been built — there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CvhipError(
+            "libcvhip.so not found at %s — build it with `python -m cvpytorch_amd.build` "
+            "(hipcc --offload-arch=gfx950). The HIP engine has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == ABI drift; let it propagate loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.cvhip_version() < 100:
+        raise CvhipError("libcvhip.so too old")
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != OK:
+        lib = load()
+        msg = {ERR_INVALID: "invalid argument", ERR_UNSUPPORTED: "unsupported shape/feature",
+               ERR_LAUNCH: "HIP launch error: " + (lib.cvhip_last_error() or b"").decode()}.get(status, "status %d" % status)
+        raise CvhipError("%s failed: %s" % (what, msg))
+
+
+def call(name, *args):
+    """Invoke an int-status entry point and raise on failure."""
+    lib = load()
+    check(getattr(lib, name)(*args), name)

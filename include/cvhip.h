@@ -1,0 +1,295 @@
+/*
+ * cvhip.h — C ABI of libcvhip.so, the MI355X (gfx950 / CDNA4) engine for CvPytorch's
+ * data-parallel CNN training hot path.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers + sizes + a `hipStream_t` (as void*),
+ * is NON-ALLOCATING and ASYNCHRONOUS on the caller's stream (so a whole train step can be
+ * captured in a hipGraph), and returns an int status (CVHIP_OK == 0; negative = refused).
+ * No torch types appear here; the host side (cvpytorch_amd python modules, or any other language with an
+ * FFI) owns every buffer.
+ *
+ * The reference (shanglianlm0525/CvPytorch) is pure Python: its hot path bottoms out in
+ * ATen/cuDNN/torchvision/NCCL calls, so there is no reference FFI to mirror symbol-for-symbol.
+ * Each entry point below therefore cites the reference CALL SITE whose native op it replaces
+ * (paths relative to the reference root).
+ *
+ * Layout contract
+ *   activations : NHWC ("channels_last"), bf16, addressed as rows of `ld` elements per pixel so
+ *                 that a channel slice of a wider concat buffer is a first-class operand
+ *                 (ld >= C, base pointer already offset to the slice's first channel).
+ *   weights     : master copy fp32 KRSC (= torch OIHW tensor in channels_last memory format);
+ *                 cvhip_conv2d_prep_weights() derives the bf16 operand images.
+ *   BN stats    : fp32.
+ */
+#ifndef CVHIP_H_
+#define CVHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CVHIP_VERSION 100
+
+/* status codes */
+#define CVHIP_OK 0
+#define CVHIP_ERR_INVALID (-1)     /* bad argument (null pointer, misaligned, negative size) */
+#define CVHIP_ERR_UNSUPPORTED (-2) /* shape/feature not implemented by the HIP path */
+#define CVHIP_ERR_LAUNCH (-3)      /* hipLaunch / runtime error (see cvhip_last_error) */
+
+/* activation ids — src/models/bricks/activation.py:13-30 (ReLU/LeakyReLU/SiLU),
+ * src/models/bricks/swish.py:8-25 (Swish == SiLU arithmetic) */
+#define CVHIP_ACT_NONE 0
+#define CVHIP_ACT_RELU 1
+#define CVHIP_ACT_SILU 2
+#define CVHIP_ACT_LEAKY 3 /* negative slope passed separately */
+#define CVHIP_ACT_SIGMOID 4
+#define CVHIP_ACT_HSWISH 5
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution descriptor (POD). Logical tensor shapes follow nn.Conv2d:
+ *   x (N,C,H,W)  w (K,C/groups,R,S)  y (N,K,P,Q),
+ *   P = (H + 2*pad_h - dil_h*(R-1) - 1)/stride_h + 1, likewise Q.
+ * Replaces aten::convolution / convolution_backward reached from
+ *   src/models/bricks/conv_module.py:209 (ConvModule.forward -> self.conv(x)),
+ *   src/models/bricks/conv.py:8-46 (build_conv_layer -> nn.Conv2d),
+ *   src/models/detects/yolov5_detect.py:25,42, src/models/heads/seg/base_seg_head.py:30.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cvhip_conv_desc {
+  int32_t N, C, H, W;     /* input: batch, channels, height, width                        */
+  int32_t K, R, S;        /* output channels, kernel height, kernel width                  */
+  int32_t stride_h, stride_w;
+  int32_t pad_h, pad_w;
+  int32_t dil_h, dil_w;
+  int32_t groups;         /* 1 (dense, MFMA implicit GEMM) or C==K (depthwise)             */
+  int32_t x_ld;           /* elements between consecutive input pixels  (>= C)             */
+  int32_t y_ld;           /* elements between consecutive output pixels (>= K)             */
+  int32_t reserved0, reserved1;
+} cvhip_conv_desc;
+
+int cvhip_version(void);
+/* last HIP runtime error string seen by the library on this thread (never NULL) */
+const char* cvhip_last_error(void);
+
+/* output spatial size for a descriptor (pure host arithmetic, usable without a GPU) */
+int cvhip_conv2d_out_hw(const cvhip_conv_desc* d, int32_t* P, int32_t* Q);
+
+/* Plan queries (pure host arithmetic, usable without a GPU; exercised by the CPU test-suite).
+ *   cvhip_conv2d_fprop_stats_rows : number of per-M-tile partial rows the fprop epilogue writes
+ *                                   into `stats_partial` ([rows][2][K] fp32) when BN statistics
+ *                                   are requested.
+ *   cvhip_conv2d_dgrad_weight_elems: number of bf16 elements of the dgrad weight image.
+ *   cvhip_conv2d_dgrad_plan       : the stride-parity decomposition used by dgrad. For class
+ *                                   (ph,pw) in [0,stride_h)x[0,stride_w) writes 8 int32:
+ *                                   {TR, TS, r0, r_step, dh0, dh_step(neg), s0/... see DESIGN.md}
+ */
+int cvhip_conv2d_fprop_stats_rows(const cvhip_conv_desc* d);
+int64_t cvhip_conv2d_dgrad_weight_elems(const cvhip_conv_desc* d);
+/* per class: {TR, TS, r0, r_step, dh0, dh_step, s0, s_step, dw0, dw_step, w_offset(elems, 2 x int32 lo/hi)} = 12 int32 */
+#define CVHIP_DGRAD_CLASS_INTS 12
+int cvhip_conv2d_dgrad_plan(const cvhip_conv_desc* d, int32_t* out_classes, int max_classes);
+
+/* Derive the bf16 operand images from the fp32 KRSC master weights.
+ *   w_fprop : bf16 [K][R*S*C]              (also the wgrad output layout)
+ *   w_dgrad : bf16, per stride-parity class [C][taps(class)][K], classes concatenated
+ *             (may be NULL when the layer's input needs no gradient)
+ * Replaces the implicit fp32->half weight cast autocast performs at trainer.py:179-184. */
+int cvhip_conv2d_prep_weights(const cvhip_conv_desc* d, const float* w_master_krsc,
+                              void* w_fprop_bf16, void* w_dgrad_bf16, void* stream);
+
+/* fprop: y = conv(x, w) (+ bias). If stats_partial != NULL the epilogue also emits per-M-tile
+ * partial sums  stats_partial[tile][0][k] = sum_m acc, [tile][1][k] = sum_m acc^2  (fp32
+ * accumulators, before rounding to bf16) for training-mode BatchNorm; `bias` must be NULL then. */
+int cvhip_conv2d_fprop(const cvhip_conv_desc* d, const void* x_bf16, const void* w_fprop_bf16,
+                       const float* bias, void* y_bf16, float* stats_partial, void* stream);
+
+/* dgrad: dx = conv_transpose(dy, w) — implicit GEMM over stride-parity classes (no wasted taps). */
+int cvhip_conv2d_dgrad(const cvhip_conv_desc* d, const void* dy_bf16, const void* w_dgrad_bf16,
+                       void* dx_bf16, void* stream);
+
+/* wgrad: dw[K][R][S][C] (fp32) (+)= sum over pixels dy^T * im2col(x); split-K over pixels with
+ * fp32 atomics. accumulate==0 zero-fills dw first (hipMemsetAsync on `stream`). */
+int cvhip_conv2d_wgrad(const cvhip_conv_desc* d, const void* x_bf16, const void* dy_bf16,
+                       float* dw_krsc_f32, int accumulate, void* stream);
+
+/* depthwise conv (groups == C == K), direct, bandwidth-bound.
+ * src/models/bricks/depthwise_separable_conv_module.py:76-94 (DeepLabv3+ ASPP / fuse convs).
+ * weights: fp32 [C][R][S] master is used directly. */
+int cvhip_dwconv2d_fprop(const cvhip_conv_desc* d, const void* x_bf16, const float* w_crs,
+                         const float* bias, void* y_bf16, void* stream);
+int cvhip_dwconv2d_dgrad(const cvhip_conv_desc* d, const void* dy_bf16, const float* w_crs,
+                         void* dx_bf16, void* stream);
+int cvhip_dwconv2d_wgrad(const cvhip_conv_desc* d, const void* x_bf16, const void* dy_bf16,
+                         float* dw_crs, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Column reductions over a [M][C] bf16 matrix with row pitch ld (NHWC activations, M=N*H*W).
+ * Two-stage and deterministic: stage 1 writes `rows` partial rows, finalize reduces them.
+ * ------------------------------------------------------------------------------------------ */
+/* number of partial rows stage-1 reductions produce for an M-row matrix */
+int cvhip_colreduce_rows(int64_t M, int32_t C);
+
+/* partial[rows][2][C] = per-block (sum x, sum x^2).  aten::native_batch_norm statistics —
+ * src/models/bricks/conv_module.py:211 (self.norm(x)), bricks/norm.py:74-123. */
+int cvhip_bn_stats_partial(const void* x_bf16, int64_t M, int32_t C, int32_t ld,
+                           float* partial, void* stream);
+
+/* Finalize training-mode BN statistics from partial rows:
+ *   mean, invstd = 1/sqrt(var_biased + eps)            (saved for backward)
+ *   scale = gamma*invstd, shift = beta - mean*scale     (consumed by cvhip_bn_act_fwd)
+ *   running_mean/var updated with `momentum` (unbiased variance), as torch.nn.BatchNorm2d.
+ * gamma/beta may be NULL (affine=False); running_* may be NULL (track_running_stats=False). */
+int cvhip_bn_finalize(const float* partial, int32_t rows, int32_t C, int64_t count,
+                      const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, float momentum, float eps, float* mean, float* invstd,
+                      float* scale, float* shift, void* stream);
+
+/* eval-mode BN folded into scale/shift from running statistics */
+int cvhip_bn_eval_scale_shift(int32_t C, const float* gamma, const float* beta,
+                              const float* running_mean, const float* running_var, float eps,
+                              float* scale, float* shift, void* stream);
+
+/* z = act(y*scale + shift) (+ residual).  scale/shift may be NULL (pure activation).
+ * Fuses aten::batch_norm apply + aten::silu_/relu_ (+ DarknetBottleneck shortcut add,
+ * src/models/modules/yolo_modules.py:102) into one pass. */
+int cvhip_bn_act_fwd(const void* y_bf16, int32_t ld_y, void* z_bf16, int32_t ld_z, int64_t M,
+                     int32_t C, const float* scale, const float* shift, int32_t act,
+                     float act_param, const void* residual_bf16, int32_t ld_res, void* stream);
+
+/* backward stage 1: partial[rows][2][C] = (sum du, sum du*xhat),  du = dz*act'(u),
+ * u = y*scale+shift, xhat = (y-mean)*invstd. */
+int cvhip_bn_act_bwd_partial(const void* dz_bf16, int32_t ld_dz, const void* y_bf16, int32_t ld_y,
+                             int64_t M, int32_t C, const float* scale, const float* shift,
+                             const float* mean, const float* invstd, int32_t act,
+                             float act_param, float* partial, void* stream);
+/* backward finalize: dbeta = sum du, dgamma = sum du*xhat  (sums over partial rows) */
+int cvhip_bn_bwd_finalize(const float* partial, int32_t rows, int32_t C, float* dgamma,
+                          float* dbeta, void* stream);
+/* backward stage 2: dy = gamma*invstd*(du - dbeta/M - xhat*dgamma/M)   (training BN)
+ *   if mean==NULL (no BN / eval BN): dy = scale*du (scale may be NULL -> dy = du). */
+int cvhip_bn_act_bwd_apply(const void* dz_bf16, int32_t ld_dz, const void* y_bf16, int32_t ld_y,
+                           void* dy_bf16, int32_t ld_dy, int64_t M, int32_t C, const float* scale,
+                           const float* shift, const float* mean, const float* invstd,
+                           const float* dgamma, const float* dbeta, int32_t act, float act_param,
+                           void* stream);
+
+/* column sum of a bf16 matrix into fp32 (conv bias gradient): out[c] = sum_m x[m][c] */
+int cvhip_colsum_partial(const void* x_bf16, int64_t M, int32_t C, int32_t ld, float* partial,
+                         void* stream);
+int cvhip_colsum_finalize(const float* partial, int32_t rows, int32_t C, float* out, int accumulate,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Pooling / resampling / layout glue (all NHWC bf16 with row pitches)
+ * ------------------------------------------------------------------------------------------ */
+/* max_pool2d forward (+ uint8 argmax window offset for backward). First maximum in row-major
+ * window scan order wins ties (ATen CPU rule).  src/models/modules/yolo_modules.py:176-192
+ * (SPPF), src/models/modules/yolov7_modules.py:39,53,130, src/models/backbones/seg/resnet.py:80 */
+int cvhip_maxpool2d_fwd(const void* x_bf16, int32_t ld_x, void* y_bf16, int32_t ld_y,
+                        uint8_t* argmax, int32_t N, int32_t C, int32_t H, int32_t W, int32_t k,
+                        int32_t stride, int32_t pad, void* stream);
+int cvhip_maxpool2d_bwd(const void* dy_bf16, int32_t ld_dy, const uint8_t* argmax, void* dx_bf16,
+                        int32_t ld_dx, int32_t N, int32_t C, int32_t H, int32_t W, int32_t k,
+                        int32_t stride, int32_t pad, int accumulate, void* stream);
+
+/* out[:, :Ca] = nearest_upsample_x2(a); out[:, Ca:Ca+Cb] = b   — the FPN/PAN "up + cat"
+ * (src/models/modules/yolo_modules.py:147,152 UpsamplingModule). b may be NULL (Cb=0). */
+int cvhip_upsample2x_cat_fwd(const void* a_bf16, int32_t ld_a, int32_t Ca, const void* b_bf16,
+                             int32_t ld_b, int32_t Cb, void* out_bf16, int32_t ld_out, int32_t N,
+                             int32_t Ha, int32_t Wa, void* stream);
+/* da = 2x2 sum-pool of dout[:, :Ca]  (db is the channel slice dout[:, Ca:], a view) */
+int cvhip_upsample2x_bwd(const void* dout_bf16, int32_t ld_dout, void* da_bf16, int32_t ld_da,
+                         int32_t Ca, int32_t N, int32_t Ha, int32_t Wa, void* stream);
+
+/* strided 2-D copy dst[m][0:C] = src[m][0:C] (channel concat / slice materialisation) */
+int cvhip_copy2d(const void* src_bf16, int32_t ld_src, void* dst_bf16, int32_t ld_dst, int64_t M,
+                 int32_t C, void* stream);
+/* dst = a + b  (gradient accumulation at fan-out points, residual adds) */
+int cvhip_add2d(const void* a_bf16, int32_t ld_a, const void* b_bf16, int32_t ld_b, void* dst_bf16,
+                int32_t ld_dst, int64_t M, int32_t C, void* stream);
+
+/* bilinear resize, align_corners = 0/1 (F.interpolate).
+ * src/models/heads/seg/deeplabv3plus_head.py:56-66, segmentors/encoder_decoder.py:99 */
+int cvhip_resize_bilinear_fwd(const void* x_bf16, int32_t ld_x, void* y_bf16, int32_t ld_y,
+                              int32_t N, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
+                              int32_t align_corners, void* stream);
+int cvhip_resize_bilinear_bwd(const void* dy_bf16, int32_t ld_dy, void* dx_bf16, int32_t ld_dx,
+                              int32_t N, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
+                              int32_t align_corners, void* stream);
+
+/* global average pool (AdaptiveAvgPool2d(1)) fwd/bwd: y[n][c] = mean_hw x */
+int cvhip_global_avgpool_fwd(const void* x_bf16, int32_t ld_x, void* y_bf16, int32_t N, int32_t C,
+                             int32_t HW, void* stream);
+int cvhip_global_avgpool_bwd(const void* dy_bf16, void* dx_bf16, int32_t ld_dx, int32_t N,
+                             int32_t C, int32_t HW, void* stream);
+
+/* fp32 NCHW image batch -> bf16 NHWC with channels zero-padded to Cpad (trainer.py:157-175 H2D
+ * boundary + channels_last relayout); and Focus space-to-depth (yolo_modules.py:30-36,
+ * concat order TL, BL, TR, BR) fused with the same relayout. */
+int cvhip_nchw_f32_to_nhwc_bf16(const float* x, void* y_bf16, int32_t N, int32_t C, int32_t H,
+                                int32_t W, int32_t Cpad, void* stream);
+int cvhip_focus_nchw_f32_to_nhwc_bf16(const float* x, void* y_bf16, int32_t N, int32_t C,
+                                      int32_t H, int32_t W, int32_t Cpad, void* stream);
+/* bf16 NHWC (pitch ld) -> fp32 NCHW (logits handed to torch-side losses) and its adjoint */
+int cvhip_nhwc_bf16_to_nchw_f32(const void* x_bf16, int32_t ld, float* y, int32_t N, int32_t C,
+                                int32_t H, int32_t W, void* stream);
+int cvhip_nchw_f32_to_nhwc_bf16_ld(const float* x, void* y_bf16, int32_t ld, int32_t N, int32_t C,
+                                   int32_t H, int32_t W, void* stream);
+
+/* YOLO head boundary: bf16 NHWC (N,H,W,ld >= A*NO) <-> fp32 (N,A,H,W,NO) contiguous; fuses the
+ * reference's view/permute/contiguous (src/models/detects/yolov5_detect.py:43-44) with the fp32 cast
+ * the loss needs. The backward writes all `ld` channels (pad channels zero). */
+int cvhip_head_permute_fwd(const void* x_bf16, int32_t ld, float* y, int32_t N, int32_t A,
+                           int32_t NO, int32_t H, int32_t W, void* stream);
+int cvhip_head_permute_bwd(const float* dy, void* dx_bf16, int32_t ld, int32_t N, int32_t A,
+                           int32_t NO, int32_t H, int32_t W, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Detection post-processing (bit-exact index semantics)
+ * ------------------------------------------------------------------------------------------ */
+/* YOLOv5 eval decode: src/models/detects/yolov5_detect.py:48-55.
+ * p: bf16 NHWC head output (N, H, W, ld>=A*NO) ; out fp32 (N, A*H*W, NO) with the reference's
+ * anchor-major ordering; xy=(sig*2-0.5+grid)*stride, wh=(sig*2)^2*anchor_px, rest=sigmoid. */
+int cvhip_yolov5_decode(const void* p_bf16, int32_t ld, float* out, int32_t N, int32_t A,
+                        int32_t NO, int32_t H, int32_t W, float stride, const float* anchors_px,
+                        int64_t out_image_stride, int64_t out_level_offset, void* stream);
+
+/* Greedy NMS on boxes ALREADY sorted by descending score (stable) — torchvision.ops.nms contract
+ * (models/yolov5.py:137): keep i, suppress later j with IoU(i,j) > thr, IoU=inter/(a_i+a_j-inter),
+ * area=(x2-x1)*(y2-y1). Two kernels: 64x64-tile suppression bitmask (ballot), then a single-wave
+ * sequential scan. mask: uint64 [n][ceil(n/64)] workspace. keep_idx: int32[n], keep_count: int32[1]. */
+int64_t cvhip_nms_workspace_bytes(int32_t n);
+int cvhip_nms_sorted(const float* boxes_xyxy, int32_t n, float iou_thr, void* workspace,
+                     int32_t* keep_idx, int32_t* keep_count, void* stream);
+
+/* pairwise IoU matrix (N x M) fp32 — models/yolov5.py:27-49 box_iou, losses/det/yolox_loss.py:14-31 */
+int cvhip_box_iou(const float* a_xyxy, int32_t n, const float* b_xyxy, int32_t m, float* out,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused optimizer: SGD(momentum, nesterov, weight decay) + EMA over a flat fp32 parameter arena.
+ * torch.optim.SGD semantics (src/optimizers/__init__.py:60-68) + ModelEMA.update
+ * (src/utils/ema.py:30-39). wd/lr are per-element-range via a segment table.
+ *   seg: int64 [nseg][2] = {begin, end} element ranges; seg_lr/seg_wd: float[nseg].
+ * ------------------------------------------------------------------------------------------ */
+int cvhip_sgd_nesterov_ema(float* param, const float* grad, float* momentum_buf, float* ema,
+                           int64_t n, const int64_t* seg_bounds, const float* seg_lr,
+                           const float* seg_wd, int32_t nseg, float momentum, int32_t nesterov,
+                           int32_t first_step, float ema_decay, float grad_scale, void* stream);
+/* ema[i] = d*ema[i] + (1-d)*src[i] over a flat fp32 range (buffers: BN running stats) */
+int cvhip_ema_update(float* ema, const float* src, int64_t n, float decay, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Hardware probes used by the GPU test-suite to pin the MFMA / LDS-transpose lane layouts the
+ * kernels rely on (cdna_hip_programming.md §3, T10). out buffers are small fp32 arrays.
+ * ------------------------------------------------------------------------------------------ */
+int cvhip_probe_mfma_16x16x32(const void* a_bf16_16x32, const void* b_bf16_32x16, float* d_16x16,
+                              void* stream);
+int cvhip_probe_ds_read_tr16(const void* in_bf16_64x4, void* out_bf16_64x4, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CVHIP_H_ */
