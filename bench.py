@@ -1,0 +1,171 @@
+"""bench.py — images/sec of one full YOLOv5-s train step (BASELINE.json metric) on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Step (mirrors trainer_det_yolov5.py:145-207 between timer.tic :379 and timer.toc :382): forward ->
+loss -> backward (+ bucketed RCCL gradient all-reduce) -> SGD(nesterov) -> zero_grad -> EMA, on a
+synthetic COCO-shape batch already resident in HBM (640x640, bf16 activations,
+per-GPU batch 64, weak scaling). One JSON line on rank 0.
+
+Extra objects:
+  roofline     : dominant conv kernel (by summed launch time, HIP events on the launch stream inside the
+                 timed region) against the MI355X roofline that binds it (MI355X_MICROARCH.md: 2.5 PFLOP/s
+                 dense bf16 MFMA, 8 TB/s HBM3E). Algorithmic flops/bytes per launch: DESIGN.md §4.
+  cpu_baseline : the oracle (pure-PyTorch CPU restatement of the reference, fp32) timed on this box's
+                 host cores on a bounded sample (batch 8), rank 0, N == 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_MFMA_TFLOPS = 2500.0  # dense bf16, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (conf/coco_yolov5_s.yml:17)")
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    return ap.parse_args()
+
+
+def cpu_baseline(size, cpu_batch, budget_s=20.0):
+    """Oracle train step on the host cores: bounded sample (SURVEY.md §8d 'CPU baseline')."""
+    from oracle import torch_ref as R
+    torch.manual_seed(1029)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model = R.YOLOv5(80, "s").train()
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4)
+    imgs, targets = R.synthetic_batch(cpu_batch, size, seed=1029)
+
+    def step():
+        loss = model(imgs, targets, "train")["loss"]
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+
+    step()  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 3:
+            break
+    return {"value": round(cpu_batch * n / el, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle YOLOv5-s fp32 train step (fwd+loss+bwd+SGD), batch %d @%dx%d, %d timed steps after 1 warm-up, %.1f s"
+                      % (cpu_batch, size, size, n, el)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from cvpytorch_amd import ops, yolov5
+    from cvpytorch_amd.data import synthetic_detection_batch
+    from cvpytorch_amd.train import GradBucketer, ModelEMA, TrainStep, build_optimizer
+
+    torch.manual_seed(1029)
+    max_boxes = 20
+    model = yolov5.YOLOv5(80, "s", max_targets=a.batch * max_boxes).to(dev).train()
+    if world > 1:  # same initial weights everywhere (DDP broadcasts rank 0's at construction)
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, 0)
+    opt = build_optimizer(model, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4)
+    ema = ModelEMA(model) if rank == 0 else None  # trainer.py:293: EMA on the main process only
+    bucketer = GradBucketer(model) if world > 1 else None
+    step = TrainStep(model, opt, ema, bucketer, sync_buffers=world > 1)
+    imgs, targets = synthetic_detection_batch(a.batch, a.size, seed=1029 + rank, max_boxes=max_boxes, device=dev)
+    gts = yolov5.targets_to_tensor(targets, a.batch * max_boxes, dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step(imgs, gts)
+    ops.TIMER.enabled = (not a.no_kernel_timing) and rank == 0
+    ops.TIMER.reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        losses = step(imgs, gts)
+    barrier()
+    el = time.perf_counter() - t0
+    ops.TIMER.enabled = False
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    loss_val = float(losses["loss"])
+
+    if rank == 0:
+        gb = a.batch * world
+        out = {
+            "metric": "images/sec/node train step, YOLOv5-s@640", "value": round(gb * a.steps / el, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * el / a.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "coco_yolov5_s.yml YOLOv5-s %dx%d bf16 train step (fwd+loss+bwd+SGD-nesterov+EMA), per-GPU batch %d, "
+                                   "synthetic COCO-shape tensors resident in HBM" % (a.size, a.size, a.batch),
+                       "global_batch": gb, "parallelism": "dp%d" % world, "final_loss": round(loss_val, 4)},
+        }
+        summ = ops.TIMER.summary()
+        if summ:
+            dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
+            name, d = dom
+            sec = d["ms"] * 1e-3
+            tflops = d["flops"] / sec / 1e12
+            gbs = d["bytes"] / sec / 1e9
+            ai = d["flops"] / d["bytes"]
+            balance = PEAK_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+            if ai < balance:
+                roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)}
+            else:
+                roof = {"bound": "mfma", "achieved": round(tflops, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tflops / PEAK_MFMA_TFLOPS, 4)}
+            roof.update({"traffic": None, "kernel": name, "launches": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
+                         "arith_intensity_flop_per_byte": round(ai, 1), "mfma_tflops": round(tflops, 1),
+                         "mfma_frac": round(tflops / PEAK_MFMA_TFLOPS, 4), "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4)})
+            out["roofline"] = roof
+            out["kernels"] = {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / a.steps, 3),
+                                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), "alg_gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
+                              for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
+            # whole-step roofline fractions from BASELINE.md §2 (49.30 GFLOP and 366 MB per image, train)
+            ips_gpu = a.batch * a.steps / el
+            out["step_roofline"] = {"mfma_frac": round(ips_gpu * 49.30e9 / (PEAK_MFMA_TFLOPS * 1e12), 4),
+                                    "hbm_frac": round(ips_gpu * 366e6 / (PEAK_HBM_GBS * 1e9), 4)}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.size, a.cpu_batch)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

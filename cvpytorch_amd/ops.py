@@ -1,0 +1,716 @@
+"""torch.autograd.Function wrappers over the libcvhip C ABI (include/cvhip.h).
+
+Tensor convention ("NHWC view"): logical shape (N, C, H, W), dtype bf16, device cuda, element
+(n, c, h, w) at offset ((n*H + h)*W + w)*ld + c with ld >= C. A plain channels_last tensor has
+ld == C; a channel slice of a wider concat buffer has ld == C_total. Every kernel takes the pitch
+explicitly, so slices are first-class operands and `torch.cat` never has to materialise.
+
+There is deliberately no CPU / eager fallback in this module: an op that cannot run on the HIP
+engine raises (lib.CvhipError).
+
+Reference call sites replaced (file:line in the reference tree):
+  conv+BN+act  : src/models/bricks/conv_module.py:201-214
+  max-pool     : src/models/modules/yolo_modules.py:176-192
+  up x2 + cat  : src/models/modules/yolo_modules.py:147,152
+  cat / add    : src/models/modules/yolo_modules.py:102,139,162,190
+  head permute : src/models/detects/yolov5_detect.py:43-44
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+BF16 = torch.bfloat16
+_weights_epoch = 0  # bumped by the fused optimizer (it updates parameters behind torch's back)
+
+
+def bump_weights_epoch():
+    global _weights_epoch
+    _weights_epoch += 1
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class KernelTimer:
+    """Optional per-launch HIP-event timing of the conv kernels (used by bench.py's roofline leg).
+    Events are recorded on torch's current stream — the stream every libcvhip launch goes to."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []  # (kernel name, algorithmic flops, algorithmic bytes, ev0, ev1)
+
+    def reset(self):
+        self.records = []
+
+    def summary(self):
+        out = {}
+        for name, fl, by, e0, e1 in self.records:
+            d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += by
+        return out
+
+
+TIMER = KernelTimer()
+
+
+def _igemm_name(nout):
+    return "igemm_kernel<256,32,64,32>" if nout <= 32 else ("igemm_kernel<256,64,64,64>" if nout <= 64 else "igemm_kernel<128,128,64,64>")
+
+
+def _wgrad_name(k):
+    return "wgrad_kernel<32,32,32>" if k <= 32 else ("wgrad_kernel<64,32,64>" if k <= 64 else "wgrad_kernel<128,64,64>")
+
+
+def _timed_call(kname, geom, fname, *args):
+    """geom = (N, C, H, W, K, R, S, P, Q): algorithmic work of one conv pass = 2*M*K*R*S*C flop and
+    one read of the gathered operand + one write of the result + the weights (bf16)."""
+    if not TIMER.enabled:
+        L.call(fname, *args)
+        return
+    N, Cc, H, W, K, R, S, P, Q = geom
+    flops = 2.0 * N * P * Q * K * R * S * Cc
+    nbytes = 2.0 * (N * H * W * Cc + N * P * Q * K + K * R * S * Cc)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.call(fname, *args)
+    e1.record()
+    TIMER.records.append((kname, flops, nbytes, e0, e1))
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def empty_nhwc(N, Cc, H, W, device, ld=None):
+    """Fresh NHWC-view tensor of logical shape (N,C,H,W); ld > C gives a padded pitch."""
+    if ld is None or ld == Cc:
+        return torch.empty((N, Cc, H, W), dtype=BF16, device=device, memory_format=torch.channels_last)
+    buf = torch.empty((N, H, W, ld), dtype=BF16, device=device)
+    return buf.permute(0, 3, 1, 2)[:, :Cc]
+
+
+def nhwc_ld(t):
+    """Return the pixel pitch of an NHWC-view tensor, or None if `t` is not one."""
+    if t.dim() != 4 or t.dtype != BF16:
+        return None
+    N, Cc, H, W = t.shape
+    sN, sC, sH, sW = t.stride()
+    if Cc > 1 and sC != 1:
+        return None
+    ld = sW if W > 1 else (sH if H > 1 else (sN if N > 1 else max(Cc, 1)))
+    if W > 1 and sW != ld:
+        return None
+    if H > 1 and sH != W * ld:
+        return None
+    if N > 1 and sN != H * W * ld:
+        return None
+    if ld < Cc:
+        return None
+    return ld
+
+
+def as_nhwc(t):
+    """NHWC view of `t` (no copy when it already is one; otherwise one channels_last relayout)."""
+    if not t.is_cuda:
+        raise L.CvhipError("cvpytorch_amd ops need CUDA/HIP tensors (no CPU fallback); got %s" % t.device)
+    if t.dtype != BF16:
+        t = t.to(BF16)
+    ld = nhwc_ld(t)
+    if ld is None:
+        t = t.contiguous(memory_format=torch.channels_last)
+        ld = nhwc_ld(t)
+    return t, ld
+
+
+_desc_cache = {}
+
+
+def conv_desc(N, Cc, H, W, K, R, S, stride, pad, dil, groups, x_ld, y_ld):
+    key = (N, Cc, H, W, K, R, S, stride, pad, dil, groups, x_ld, y_ld)
+    d = _desc_cache.get(key)
+    if d is None:
+        d = L.ConvDesc(N, Cc, H, W, K, R, S, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], groups, x_ld, y_ld, 0, 0)
+        _desc_cache[key] = d
+    return d
+
+
+def conv_out_hw(H, W, R, S, stride, pad, dil):
+    P = (H + 2 * pad[0] - dil[0] * (R - 1) - 1) // stride[0] + 1
+    Q = (W + 2 * pad[1] - dil[1] * (S - 1) - 1) // stride[1] + 1
+    return P, Q
+
+
+def _round8(x):
+    return (x + 7) // 8 * 8
+
+
+class ConvState:
+    """Per-layer cache of the bf16 operand images derived from the fp32 master weight."""
+
+    def __init__(self):
+        self.key = None
+        self.w_fprop = None
+        self.w_dgrad = None
+        self.w_dw = None
+
+    def prepare(self, weight, desc_for_pack, need_dgrad, vkey):
+        """`vkey` identifies the VALUE of the master weight (parameter version + optimizer epoch): the
+        effective weight handed in may be a per-call temporary (channel-padded), so its own
+        data_ptr/_version cannot be trusted."""
+        key = (vkey, _weights_epoch, tuple(weight.shape))
+        if self.key == key and self.w_fprop is not None and (self.w_dgrad is not None or not need_dgrad):
+            return
+        K, Cc, R, S = weight.shape
+        dev = weight.device
+        Kp = _round8(K)
+        # master in KRSC physical order (OIHW tensor, channels_last memory format)
+        w = weight.detach()
+        if w.dtype != torch.float32:
+            w = w.float()
+        wk = w.permute(0, 2, 3, 1)
+        if not wk.is_contiguous():
+            wk = wk.contiguous()
+        if Kp != K:
+            wk = torch.cat([wk, wk.new_zeros((Kp - K, R, S, Cc))], 0)
+        lib = L.load()
+        self.w_fprop = torch.empty((Kp, R, S, Cc), dtype=BF16, device=dev)
+        wd = None
+        if need_dgrad:
+            n = lib.cvhip_conv2d_dgrad_weight_elems(C.byref(desc_for_pack))
+            if n < 0:
+                L.check(int(n), "cvhip_conv2d_dgrad_weight_elems")
+            wd = torch.empty((max(int(n), 8),), dtype=BF16, device=dev)
+        L.call("cvhip_conv2d_prep_weights", C.byref(desc_for_pack), wk.data_ptr(), self.w_fprop.data_ptr(), _ptr(wd), _stream())
+        self.w_dgrad = wd
+        self.key = key
+
+
+class ConvCfg:
+    """Static configuration of one conv(+BN+act) layer (python-side, hashable pieces only)."""
+    __slots__ = ("stride", "pad", "dil", "groups", "act", "act_param", "has_bn", "bn_training", "momentum", "eps",
+                 "state", "track", "vkey")
+
+    def __init__(self, stride, pad, dil, groups=1, act=L.ACT_NONE, act_param=0.0, has_bn=False, bn_training=True,
+                 momentum=0.1, eps=1e-5, state=None, track=True):
+        self.stride, self.pad, self.dil, self.groups = tuple(stride), tuple(pad), tuple(dil), groups
+        self.act, self.act_param = act, float(act_param)
+        self.has_bn, self.bn_training = has_bn, bn_training
+        self.momentum, self.eps = float(momentum), float(eps)
+        self.state = state if state is not None else ConvState()
+        self.track = track
+        self.vkey = None  # set by the calling module each forward: (id(param), param._version)
+
+
+def _colreduce_rows(M, Cc):
+    return L.load().cvhip_colreduce_rows(M, Cc)
+
+
+class ConvBnAct(torch.autograd.Function):
+    """z = act(bn(conv(x, W) + b)) (+ residual)   — any of bn / act / bias / residual optional."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, residual, cfg):
+        lib = L.load()
+        x, x_ld = as_nhwc(x)
+        N, Cc, H, W = x.shape
+        K, Cg, R, S = weight.shape
+        dev = x.device
+        depthwise = cfg.groups != 1
+        if depthwise and not (cfg.groups == Cc == K and Cg == 1):
+            raise L.CvhipError("grouped conv other than depthwise is not supported by the HIP engine")
+        P, Q = conv_out_hw(H, W, R, S, cfg.stride, cfg.pad, cfg.dil)
+        M = N * P * Q
+        Kp = _round8(K)
+        need_dx = ctx.needs_input_grad[0]
+        y = empty_nhwc(N, K, P, Q, dev, ld=Kp)
+        desc = conv_desc(N, Cc, H, W, Kp if not depthwise else K, R, S, cfg.stride, cfg.pad, cfg.dil, cfg.groups, x_ld, Kp)
+        st = _stream()
+        train_bn = cfg.has_bn and cfg.bn_training
+        if cfg.has_bn and bias is not None:
+            raise L.CvhipError("conv bias followed by BatchNorm is not supported (ConvModule never builds it)")
+        stats = None
+        partial = None
+        epilogue_stats = train_bn and not depthwise and Kp == K  # BN sums straight from the MFMA accumulators
+        b = bias.detach().float() if bias is not None else None
+        if b is not None and Kp != K and not depthwise:
+            b = torch.cat([b, b.new_zeros(Kp - K)])  # the kernel reads bias for all Kp (padded) output channels
+        if depthwise:
+            wm = weight.detach().float().reshape(K, R, S).contiguous()
+            L.call("cvhip_dwconv2d_fprop", C.byref(desc), x.data_ptr(), wm.data_ptr(), _ptr(b), y.data_ptr(), st)
+        else:
+            # pack descriptor: contiguous pitches (the packed images do not depend on activation pitches)
+            pdesc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, _round8(Cc), Kp)
+            cfg.state.prepare(weight, pdesc, need_dx, cfg.vkey)
+            if epilogue_stats:
+                rows = lib.cvhip_conv2d_fprop_stats_rows(C.byref(desc))
+                if rows < 0:
+                    L.check(rows, "cvhip_conv2d_fprop_stats_rows")
+                partial = torch.empty((rows, 2, K), dtype=torch.float32, device=dev)
+            _timed_call(_igemm_name(Kp), (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv2d_fprop", C.byref(desc), x.data_ptr(),
+                        cfg.state.w_fprop.data_ptr(), _ptr(b), y.data_ptr(), _ptr(partial), st)
+        if train_bn:
+            if partial is None:
+                rows = _colreduce_rows(M, K)
+                partial = torch.empty((rows, 2, K), dtype=torch.float32, device=dev)
+                L.call("cvhip_bn_stats_partial", y.data_ptr(), M, K, Kp, partial.data_ptr(), st)
+            stats = torch.empty((4, K), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
+            g = gamma.detach().float() if gamma is not None else None
+            bt = beta.detach().float() if beta is not None else None
+            rm = running_mean if cfg.track else None
+            rv = running_var if cfg.track else None
+            L.call("cvhip_bn_finalize", partial.data_ptr(), partial.shape[0], K, M, _ptr(g), _ptr(bt), _ptr(rm), _ptr(rv),
+                   cfg.momentum, cfg.eps, stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), st)
+        elif cfg.has_bn:
+            stats = torch.empty((4, K), dtype=torch.float32, device=dev)
+            L.call("cvhip_bn_eval_scale_shift", K, _ptr(gamma.detach().float() if gamma is not None else None),
+                   _ptr(beta.detach().float() if beta is not None else None), running_mean.data_ptr(), running_var.data_ptr(),
+                   cfg.eps, stats[2].data_ptr(), stats[3].data_ptr(), st)
+        res_ld = 0
+        if residual is not None:
+            residual, res_ld = as_nhwc(residual)
+        if cfg.has_bn or cfg.act != L.ACT_NONE or residual is not None:
+            z = empty_nhwc(N, K, P, Q, dev)
+            L.call("cvhip_bn_act_fwd", y.data_ptr(), Kp, z.data_ptr(), K, M, K,
+                   _ptr(stats[2]) if stats is not None else None, _ptr(stats[3]) if stats is not None else None,
+                   cfg.act, cfg.act_param, _ptr(residual), res_ld, st)
+        else:
+            z = y
+        ctx.cfg = cfg
+        ctx.geom = (N, Cc, H, W, K, R, S, P, Q, Kp, x_ld)
+        ctx.train_bn = train_bn
+        ctx.depthwise = depthwise
+        ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
+        ctx.w_dgrad = cfg.state.w_dgrad if not depthwise else None
+        ctx.save_for_backward(x, y, stats, weight)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, y, stats, weight = ctx.saved_tensors
+        cfg = ctx.cfg
+        N, Cc, H, W, K, R, S, P, Q, Kp, x_ld = ctx.geom
+        dev = x.device
+        M = N * P * Q
+        st = _stream()
+        dz, dz_ld = as_nhwc(dz)
+        need_dx, need_dw, need_db, need_dg, need_dbeta = (ctx.needs_input_grad[i] for i in range(5))
+        dgamma = dbeta = dbias = None
+        pointwise = cfg.has_bn or cfg.act != L.ACT_NONE
+        if pointwise:
+            if Kp != K:  # pad channels must read as zero in dgrad/wgrad
+                dy = torch.zeros((N, P, Q, Kp), dtype=BF16, device=dev).permute(0, 3, 1, 2)[:, :K]
+            else:
+                dy = empty_nhwc(N, K, P, Q, dev)
+            if ctx.train_bn:
+                rows = _colreduce_rows(M, K)
+                partial = torch.empty((rows, 2, K), dtype=torch.float32, device=dev)
+                L.call("cvhip_bn_act_bwd_partial", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, M, K, stats[2].data_ptr(),
+                       stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), cfg.act, cfg.act_param,
+                       partial.data_ptr(), st)
+                dgb = torch.empty((2, K), dtype=torch.float32, device=dev)
+                L.call("cvhip_bn_bwd_finalize", partial.data_ptr(), rows, K, dgb[0].data_ptr(), dgb[1].data_ptr(), st)
+                dgamma, dbeta = dgb[0], dgb[1]
+                L.call("cvhip_bn_act_bwd_apply", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, dy.data_ptr(), Kp, M, K,
+                       stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+                       dgamma.data_ptr(), dbeta.data_ptr(), cfg.act, cfg.act_param, st)
+            else:
+                sc = stats[2].data_ptr() if stats is not None else None
+                sh = stats[3].data_ptr() if stats is not None else None
+                L.call("cvhip_bn_act_bwd_apply", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, dy.data_ptr(), Kp, M, K, sc, sh,
+                       None, None, None, None, cfg.act, cfg.act_param, st)
+            dy_ld = Kp
+        else:
+            dy, dy_ld = dz, dz_ld
+            if dy_ld % 8 != 0 or (Kp != K and dy_ld < Kp):
+                # repack into a 16-byte-vectorisable pitch with zeroed pad channels
+                buf = torch.zeros((N, P, Q, Kp), dtype=BF16, device=dev)
+                L.call("cvhip_copy2d", dy.data_ptr(), dy_ld, buf.data_ptr(), Kp, M, K, st)
+                dy, dy_ld = buf.permute(0, 3, 1, 2)[:, :K], Kp
+        if ctx.has_bias and need_db and not ctx.train_bn:
+            rows = _colreduce_rows(M, K)
+            partial = torch.empty((rows, 2, K), dtype=torch.float32, device=dev)
+            L.call("cvhip_colsum_partial", dy.data_ptr(), M, K, dy_ld, partial.data_ptr(), st)
+            dbias = torch.empty((K,), dtype=torch.float32, device=dev)
+            L.call("cvhip_colsum_finalize", partial.data_ptr(), rows, K, dbias.data_ptr(), 0, st)
+        elif ctx.has_bias and need_db:
+            dbias = torch.zeros((K,), dtype=torch.float32, device=dev)  # bias before train-mode BN has zero gradient
+        dx = dw = None
+        if ctx.depthwise:
+            desc = conv_desc(N, Cc, H, W, K, R, S, cfg.stride, cfg.pad, cfg.dil, cfg.groups, x_ld, dy_ld)
+            wm = weight.detach().float().reshape(K, R, S).contiguous()
+            if need_dw:
+                dwm = torch.empty((K, R, S), dtype=torch.float32, device=dev)
+                L.call("cvhip_dwconv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(), dwm.data_ptr(), 0, st)
+                dw = dwm.reshape(K, 1, R, S)
+            if need_dx:
+                dx = empty_nhwc(N, Cc, H, W, dev)
+                ddesc = conv_desc(N, Cc, H, W, K, R, S, cfg.stride, cfg.pad, cfg.dil, cfg.groups, Cc, dy_ld)
+                L.call("cvhip_dwconv2d_dgrad", C.byref(ddesc), dy.data_ptr(), wm.data_ptr(), dx.data_ptr(), st)
+        else:
+            if need_dw:
+                desc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, x_ld, dy_ld)
+                dwk = torch.empty((Kp, R, S, Cc), dtype=torch.float32, device=dev)
+                _timed_call(_wgrad_name(Kp), (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(),
+                            dy.data_ptr(), dwk.data_ptr(), 0, st)
+                dw = dwk[:K].permute(0, 3, 1, 2)  # logical OIHW, channels_last memory
+            if need_dx:
+                if ctx.w_dgrad is None:
+                    raise L.CvhipError("dgrad weight image missing (input started requiring grad after forward)")
+                dx = empty_nhwc(N, Cc, H, W, dev)
+                ddesc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, Cc, dy_ld)
+                _timed_call(_igemm_name(Cc), (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv2d_dgrad", C.byref(ddesc), dy.data_ptr(),
+                            ctx.w_dgrad.data_ptr(), dx.data_ptr(), st)
+        if dw is not None and dw.dtype != weight.dtype:
+            dw = dw.to(weight.dtype)
+        dres = dz if ctx.has_res else None
+        return dx, dw, dbias, (dgamma if need_dg else None), (dbeta if need_dbeta else None), None, None, dres, None
+
+
+def conv_bn_act(x, weight, bias, gamma, beta, running_mean, running_var, residual, cfg):
+    return ConvBnAct.apply(x, weight, bias, gamma, beta, running_mean, running_var, residual, cfg)
+
+
+class BnAct(torch.autograd.Function):
+    """z = act(bn(y)) (+ residual) for an arbitrary NHWC input (statistics by a separate reduction pass)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, residual, has_bn, training, momentum, eps, act, act_param, track):
+        y, y_ld = as_nhwc(y)
+        N, K, P, Q = y.shape
+        M = N * P * Q
+        dev = y.device
+        st = _stream()
+        stats = None
+        train_bn = has_bn and training
+        if train_bn:
+            rows = _colreduce_rows(M, K)
+            partial = torch.empty((rows, 2, K), dtype=torch.float32, device=dev)
+            L.call("cvhip_bn_stats_partial", y.data_ptr(), M, K, y_ld, partial.data_ptr(), st)
+            stats = torch.empty((4, K), dtype=torch.float32, device=dev)
+            L.call("cvhip_bn_finalize", partial.data_ptr(), rows, K, M, _ptr(gamma.detach().float() if gamma is not None else None),
+                   _ptr(beta.detach().float() if beta is not None else None), _ptr(running_mean if track else None),
+                   _ptr(running_var if track else None), float(momentum), float(eps), stats[0].data_ptr(), stats[1].data_ptr(),
+                   stats[2].data_ptr(), stats[3].data_ptr(), st)
+        elif has_bn:
+            stats = torch.empty((4, K), dtype=torch.float32, device=dev)
+            L.call("cvhip_bn_eval_scale_shift", K, _ptr(gamma.detach().float() if gamma is not None else None),
+                   _ptr(beta.detach().float() if beta is not None else None), running_mean.data_ptr(), running_var.data_ptr(),
+                   float(eps), stats[2].data_ptr(), stats[3].data_ptr(), st)
+        res_ld = 0
+        if residual is not None:
+            residual, res_ld = as_nhwc(residual)
+        z = empty_nhwc(N, K, P, Q, dev)
+        L.call("cvhip_bn_act_fwd", y.data_ptr(), y_ld, z.data_ptr(), K, M, K, _ptr(stats[2]) if stats is not None else None,
+               _ptr(stats[3]) if stats is not None else None, act, float(act_param), _ptr(residual), res_ld, st)
+        ctx.meta = (N, K, P, Q, y_ld, train_bn, act, float(act_param), residual is not None)
+        ctx.save_for_backward(y, stats)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        y, stats = ctx.saved_tensors
+        N, K, P, Q, y_ld, train_bn, act, ap, has_res = ctx.meta
+        M = N * P * Q
+        dev = y.device
+        st = _stream()
+        dz, dz_ld = as_nhwc(dz)
+        dy = empty_nhwc(N, K, P, Q, dev)
+        dgamma = dbeta = None
+        if train_bn:
+            rows = _colreduce_rows(M, K)
+            partial = torch.empty((rows, 2, K), dtype=torch.float32, device=dev)
+            L.call("cvhip_bn_act_bwd_partial", dz.data_ptr(), dz_ld, y.data_ptr(), y_ld, M, K, stats[2].data_ptr(),
+                   stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), act, ap, partial.data_ptr(), st)
+            dgb = torch.empty((2, K), dtype=torch.float32, device=dev)
+            L.call("cvhip_bn_bwd_finalize", partial.data_ptr(), rows, K, dgb[0].data_ptr(), dgb[1].data_ptr(), st)
+            dgamma, dbeta = dgb[0], dgb[1]
+            L.call("cvhip_bn_act_bwd_apply", dz.data_ptr(), dz_ld, y.data_ptr(), y_ld, dy.data_ptr(), K, M, K,
+                   stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), dgamma.data_ptr(),
+                   dbeta.data_ptr(), act, ap, st)
+        else:
+            sc = stats[2].data_ptr() if stats is not None else None
+            sh = stats[3].data_ptr() if stats is not None else None
+            L.call("cvhip_bn_act_bwd_apply", dz.data_ptr(), dz_ld, y.data_ptr(), y_ld, dy.data_ptr(), K, M, K, sc, sh, None, None,
+                   None, None, act, ap, st)
+        return (dy, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None, None, None,
+                dz if has_res else None, None, None, None, None, None, None, None)
+
+
+def bn_act(y, gamma=None, beta=None, running_mean=None, running_var=None, residual=None, has_bn=True, training=True,
+           momentum=0.1, eps=1e-5, act=L.ACT_NONE, act_param=0.0, track=True):
+    return BnAct.apply(y, gamma, beta, running_mean, running_var, residual, has_bn, training, momentum, eps, act, act_param, track)
+
+
+class MaxPool2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, stride, pad):
+        x, ld = as_nhwc(x)
+        N, Cc, H, W = x.shape
+        OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        y = empty_nhwc(N, Cc, OH, OW, x.device)
+        idx = torch.empty((N, OH, OW, Cc), dtype=torch.uint8, device=x.device)
+        L.call("cvhip_maxpool2d_fwd", x.data_ptr(), ld, y.data_ptr(), Cc, idx.data_ptr(), N, Cc, H, W, k, stride, pad, _stream())
+        ctx.meta = (N, Cc, H, W, k, stride, pad)
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        N, Cc, H, W, k, stride, pad = ctx.meta
+        dy, ld = as_nhwc(dy)
+        dx = empty_nhwc(N, Cc, H, W, dy.device)
+        L.call("cvhip_maxpool2d_bwd", dy.data_ptr(), ld, idx.data_ptr(), dx.data_ptr(), Cc, N, Cc, H, W, k, stride, pad, 0, _stream())
+        return dx, None, None, None
+
+
+def max_pool2d(x, k, stride=None, pad=0):
+    return MaxPool2d.apply(x, int(k), int(stride if stride is not None else k), int(pad))
+
+
+class Upsample2xCat(torch.autograd.Function):
+    """cat([nearest_up_x2(a), b], dim=1) in one pass; b optional."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, ld_a = as_nhwc(a)
+        N, Ca, Ha, Wa = a.shape
+        Cb, ld_b = 0, 0
+        if b is not None:
+            b, ld_b = as_nhwc(b)
+            Cb = b.shape[1]
+            if b.shape[0] != N or b.shape[2] != 2 * Ha or b.shape[3] != 2 * Wa:
+                raise L.CvhipError("upsample2x_cat: lateral tensor shape mismatch")
+        out = empty_nhwc(N, Ca + Cb, 2 * Ha, 2 * Wa, a.device)
+        L.call("cvhip_upsample2x_cat_fwd", a.data_ptr(), ld_a, Ca, _ptr(b), ld_b, Cb, out.data_ptr(), Ca + Cb, N, Ha, Wa, _stream())
+        ctx.meta = (N, Ca, Cb, Ha, Wa)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        N, Ca, Cb, Ha, Wa = ctx.meta
+        dout, ld = as_nhwc(dout)
+        da = empty_nhwc(N, Ca, Ha, Wa, dout.device)
+        L.call("cvhip_upsample2x_bwd", dout.data_ptr(), ld, da.data_ptr(), Ca, Ca, N, Ha, Wa, _stream())
+        db = dout[:, Ca:] if Cb else None  # channel-slice view: no copy
+        return da, db
+
+
+def upsample2x_cat(a, b=None):
+    return Upsample2xCat.apply(a, b)
+
+
+class Cat(torch.autograd.Function):
+    """Channel concat: copies each input into its slice of one NHWC buffer; backward hands out slice views."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [as_nhwc(x) for x in xs]
+        N, _, H, W = xs[0][0].shape
+        Ct = sum(x.shape[1] for x, _ in xs)
+        out = empty_nhwc(N, Ct, H, W, xs[0][0].device)
+        st = _stream()
+        off = 0
+        M = N * H * W
+        for x, ld in xs:
+            Cc = x.shape[1]
+            L.call("cvhip_copy2d", x.data_ptr(), ld, out.data_ptr() + 2 * off, Ct, M, Cc, st)
+            off += Cc
+        ctx.sizes = [x.shape[1] for x, _ in xs]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        outs, off = [], 0
+        for c in ctx.sizes:
+            outs.append(dout[:, off:off + c])
+            off += c
+        return tuple(outs)
+
+
+def cat(xs):
+    return Cat.apply(*xs)
+
+
+class Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, la = as_nhwc(a)
+        b, lb = as_nhwc(b)
+        N, Cc, H, W = a.shape
+        out = empty_nhwc(N, Cc, H, W, a.device)
+        L.call("cvhip_add2d", a.data_ptr(), la, b.data_ptr(), lb, out.data_ptr(), Cc, N * H * W, Cc, _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, d
+
+
+def add(a, b):
+    return Add.apply(a, b)
+
+
+class ResizeBilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo, align_corners):
+        x, ld = as_nhwc(x)
+        N, Cc, Hi, Wi = x.shape
+        y = empty_nhwc(N, Cc, Ho, Wo, x.device)
+        L.call("cvhip_resize_bilinear_fwd", x.data_ptr(), ld, y.data_ptr(), Cc, N, Cc, Hi, Wi, Ho, Wo, int(align_corners), _stream())
+        ctx.meta = (N, Cc, Hi, Wi, Ho, Wo, int(align_corners))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, Cc, Hi, Wi, Ho, Wo, ac = ctx.meta
+        dy, ld = as_nhwc(dy)
+        dx = empty_nhwc(N, Cc, Hi, Wi, dy.device)
+        L.call("cvhip_resize_bilinear_bwd", dy.data_ptr(), ld, dx.data_ptr(), Cc, N, Cc, Hi, Wi, Ho, Wo, ac, _stream())
+        return dx, None, None, None
+
+
+def resize_bilinear(x, size, align_corners=False):
+    return ResizeBilinear.apply(x, int(size[0]), int(size[1]), bool(align_corners))
+
+
+class GlobalAvgPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x, ld = as_nhwc(x)
+        N, Cc, H, W = x.shape
+        y = empty_nhwc(N, Cc, 1, 1, x.device)
+        L.call("cvhip_global_avgpool_fwd", x.data_ptr(), ld, y.data_ptr(), N, Cc, H * W, _stream())
+        ctx.meta = (N, Cc, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, Cc, H, W = ctx.meta
+        dy = dy.to(BF16).reshape(N, Cc).contiguous()
+        dx = empty_nhwc(N, Cc, H, W, dy.device)
+        L.call("cvhip_global_avgpool_bwd", dy.data_ptr(), dx.data_ptr(), Cc, N, Cc, H * W, _stream())
+        return dx
+
+
+def global_avg_pool(x):
+    return GlobalAvgPool.apply(x)
+
+
+def images_to_nhwc(x, cpad=8, focus=False):
+    """fp32 NCHW image batch -> bf16 NHWC view with channels zero-padded to `cpad` (no autograd)."""
+    if not x.is_cuda:
+        raise L.CvhipError("cvpytorch_amd ops need CUDA/HIP tensors (no CPU fallback)")
+    x = x.detach().float().contiguous()
+    N, Cc, H, W = x.shape
+    if focus:
+        y = torch.empty((N, cpad, H // 2, W // 2), dtype=BF16, device=x.device, memory_format=torch.channels_last)
+        L.call("cvhip_focus_nchw_f32_to_nhwc_bf16", x.data_ptr(), y.data_ptr(), N, Cc, H, W, cpad, _stream())
+    else:
+        y = torch.empty((N, cpad, H, W), dtype=BF16, device=x.device, memory_format=torch.channels_last)
+        L.call("cvhip_nchw_f32_to_nhwc_bf16", x.data_ptr(), y.data_ptr(), N, Cc, H, W, cpad, _stream())
+    return y
+
+
+class NhwcToNchwF32(torch.autograd.Function):
+    """bf16 NHWC activations -> fp32 NCHW contiguous (what torch-side losses consume) and its adjoint."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x, ld = as_nhwc(x)
+        N, Cc, H, W = x.shape
+        y = torch.empty((N, Cc, H, W), dtype=torch.float32, device=x.device)
+        L.call("cvhip_nhwc_bf16_to_nchw_f32", x.data_ptr(), ld, y.data_ptr(), N, Cc, H, W, _stream())
+        ctx.meta = (N, Cc, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, Cc, H, W = ctx.meta
+        dy = dy.float().contiguous()
+        Cp = _round8(Cc)
+        buf = torch.zeros((N, H, W, Cp), dtype=BF16, device=dy.device) if Cp != Cc else torch.empty((N, H, W, Cp), dtype=BF16, device=dy.device)
+        L.call("cvhip_nchw_f32_to_nhwc_bf16_ld", dy.data_ptr(), buf.data_ptr(), Cp, N, Cc, H, W, _stream())
+        return buf.permute(0, 3, 1, 2)[:, :Cc]
+
+
+def to_nchw_f32(x):
+    return NhwcToNchwF32.apply(x)
+
+
+class HeadPermute(torch.autograd.Function):
+    """(N, A*NO, H, W) bf16 NHWC -> (N, A, H, W, NO) fp32 contiguous."""
+
+    @staticmethod
+    def forward(ctx, x, A, NO):
+        x, ld = as_nhwc(x)
+        N, Cc, H, W = x.shape
+        if Cc != A * NO:
+            raise L.CvhipError("head_permute: channels != A*NO")
+        y = torch.empty((N, A, H, W, NO), dtype=torch.float32, device=x.device)
+        L.call("cvhip_head_permute_fwd", x.data_ptr(), ld, y.data_ptr(), N, A, NO, H, W, _stream())
+        ctx.meta = (N, A, NO, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, A, NO, H, W = ctx.meta
+        dy = dy.float().contiguous()
+        Cp = _round8(A * NO)
+        buf = torch.empty((N, H, W, Cp), dtype=BF16, device=dy.device)
+        L.call("cvhip_head_permute_bwd", dy.data_ptr(), buf.data_ptr(), Cp, N, A, NO, H, W, _stream())
+        return buf.permute(0, 3, 1, 2)[:, :A * NO], None, None
+
+
+def head_permute(x, A, NO):
+    return HeadPermute.apply(x, A, NO)
+
+
+# ---- non-differentiable post-processing ---------------------------------------------------------------
+
+def yolov5_decode(levels, strides, anchors_px, A, NO):
+    """levels: list of (N, A*NO, H, W) head outputs; returns (N, sum(A*H*W), NO) fp32 — detects/yolov5_detect.py:48-57."""
+    N = levels[0].shape[0]
+    tot = sum(A * l.shape[2] * l.shape[3] for l in levels)
+    out = torch.empty((N, tot, NO), dtype=torch.float32, device=levels[0].device)
+    off = 0
+    for l, s, anc in zip(levels, strides, anchors_px):
+        l, ld = as_nhwc(l.detach())
+        H, W = l.shape[2], l.shape[3]
+        anc = anc.to(device=l.device, dtype=torch.float32).contiguous()
+        L.call("cvhip_yolov5_decode", l.data_ptr(), ld, out.data_ptr(), N, A, NO, H, W, float(s), anc.data_ptr(), tot * NO, off, _stream())
+        off += A * H * W
+    return out
+
+
+def nms(boxes, scores, iou_thr):
+    """torchvision.ops.nms contract: returns int64 indices of kept boxes, in decreasing score order."""
+    if boxes.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    if not boxes.is_cuda:
+        raise L.CvhipError("cvpytorch_amd.nms needs CUDA/HIP tensors (no CPU fallback)")
+    order = torch.sort(scores.float(), descending=True, stable=True)[1]
+    b = boxes.float()[order].contiguous()
+    n = b.shape[0]
+    lib = L.load()
+    ws = torch.empty((int(lib.cvhip_nms_workspace_bytes(n)),), dtype=torch.uint8, device=b.device)
+    keep = torch.empty((n,), dtype=torch.int32, device=b.device)
+    cnt = torch.zeros((1,), dtype=torch.int32, device=b.device)
+    L.call("cvhip_nms_sorted", b.data_ptr(), n, float(iou_thr), ws.data_ptr(), keep.data_ptr(), cnt.data_ptr(), _stream())
+    k = int(cnt.item())
+    return order[keep[:k].long()]
+
+
+def box_iou(a, b):
+    a = a.float().contiguous()
+    b = b.float().contiguous()
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    L.call("cvhip_box_iou", a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], out.data_ptr(), _stream())
+    return out

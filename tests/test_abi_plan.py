@@ -1,0 +1,160 @@
+"""CPU-only checks of the C-ABI boundary: libcvhip.so loads without a GPU, exports every symbol that
+include/cvhip.h declares, refuses bad descriptors with the documented status codes, and its HOST-SIDE
+planning (conv output size, BN partial rows, the dgrad stride-parity decomposition + weight-image
+layout) is arithmetically right — verified by interpreting the plan in numpy and comparing with
+torch's own conv backward. No kernel is launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from cvpytorch_amd import lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "cvhip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cvhip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = L.load()
+    assert lib.cvhip_version() >= 100
+    syms = header_symbols()
+    assert len(syms) >= 45
+    raw = C.CDLL(L.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), "libcvhip.so does not export %s" % s
+        assert s in L.SIGNATURES, "cvpytorch_amd.lib has no ctypes signature for %s" % s
+    for s in L.SIGNATURES:
+        assert s in syms, "%s bound in lib.py but not declared in include/cvhip.h" % s
+
+
+def desc(N, Cc, H, W, K, R, S, stride=(1, 1), pad=(0, 0), dil=(1, 1), groups=1, x_ld=None, y_ld=None):
+    return L.ConvDesc(N, Cc, H, W, K, R, S, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], groups,
+                      x_ld or Cc, y_ld or K, 0, 0)
+
+
+@pytest.mark.parametrize("H,W,R,S,s,p,d", [(640, 640, 6, 6, 2, 2, 1), (80, 80, 3, 3, 1, 1, 1), (81, 77, 3, 3, 2, 1, 1),
+                                           (32, 64, 3, 3, 1, 12, 12), (20, 20, 1, 1, 1, 0, 1), (9, 9, 5, 3, 3, 2, 2)])
+def test_out_hw_matches_torch(H, W, R, S, s, p, d):
+    lib = L.load()
+    dd = desc(1, 8, H, W, 8, R, S, (s, s), (p, p), (d, d))
+    P, Q = C.c_int32(), C.c_int32()
+    assert lib.cvhip_conv2d_out_hw(C.byref(dd), C.byref(P), C.byref(Q)) == 0
+    y = F.conv2d(torch.zeros(1, 1, H, W), torch.zeros(1, 1, R, S), stride=s, padding=p, dilation=d)
+    assert (P.value, Q.value) == tuple(y.shape[2:])
+
+
+def test_descriptor_validation_status_codes():
+    lib = L.load()
+    assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(desc(2, 3, 8, 8, 16, 3, 3))) == L.ERR_UNSUPPORTED  # C % 8 != 0
+    assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(desc(2, 16, 8, 8, 16, 3, 3, groups=2))) == L.ERR_UNSUPPORTED
+    assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(desc(0, 16, 8, 8, 16, 3, 3))) == L.ERR_INVALID
+    assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(desc(2, 16, 8, 8, 16, 3, 3, x_ld=8))) == L.ERR_INVALID  # pitch < C
+    assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(desc(1, 16, 2, 2, 16, 5, 5))) == L.ERR_INVALID  # empty output
+    # null pointers are refused before any launch
+    assert lib.cvhip_conv2d_fprop(C.byref(desc(2, 16, 8, 8, 16, 3, 3)), None, None, None, None, None, None) == L.ERR_INVALID
+    assert lib.cvhip_bn_act_fwd(None, 8, None, 8, 4, 8, None, None, 0, 0.0, None, 0, None) == L.ERR_INVALID
+    assert lib.cvhip_nms_sorted(None, 5, 0.5, None, None, None, None) == L.ERR_INVALID
+    with pytest.raises(L.CvhipError):
+        L.call("cvhip_conv2d_fprop", C.byref(desc(2, 16, 8, 8, 16, 3, 3)), None, None, None, None, None, None)
+
+
+def test_stats_rows_tiles():
+    lib = L.load()
+    # block-M is 256 for K <= 64 and 128 otherwise (conv_igemm.hip launch_igemm)
+    assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(desc(64, 8, 640, 640, 32, 6, 6, (2, 2), (2, 2)))) == (64 * 320 * 320 + 255) // 256
+    assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(desc(2, 128, 40, 40, 128, 3, 3, (1, 1), (1, 1)))) == (2 * 1600 + 127) // 128
+    assert lib.cvhip_colreduce_rows(10, 32) == 1
+    assert lib.cvhip_colreduce_rows(10 ** 7, 32) == 1024
+    assert lib.cvhip_nms_workspace_bytes(100) == (100 * 2 + 2) * 8
+
+
+def dgrad_plan(dd):
+    lib = L.load()
+    buf = (C.c_int32 * (16 * L.DGRAD_CLASS_INTS))()
+    n = lib.cvhip_conv2d_dgrad_plan(C.byref(dd), buf, 16)
+    assert n > 0
+    cls = []
+    for i in range(n):
+        v = [buf[i * L.DGRAD_CLASS_INTS + j] for j in range(L.DGRAD_CLASS_INTS)]
+        cls.append(dict(TR=v[0], TS=v[1], r0=v[2], r_step=v[3], dh0=v[4], dh_step=v[5], s0=v[6], s_step=v[7], dw0=v[8],
+                        dw_step=v[9], w_off=(v[10] & 0xffffffff) | (v[11] << 32)))
+    return cls
+
+
+def interpret_dgrad(dd, dy_nhwc, w_krsc):
+    """numpy interpreter of the dgrad plan: exactly the gather the igemm kernel performs per class."""
+    N, Cc, H, W, K = dd.N, dd.C, dd.H, dd.W, dd.K
+    P, Q = dy_nhwc.shape[1:3]
+    sh, sw = dd.stride_h, dd.stride_w
+    classes = dgrad_plan(dd)
+    assert len(classes) == sh * sw
+    total = L.load().cvhip_conv2d_dgrad_weight_elems(C.byref(dd))
+    wimg = np.zeros(total, dtype=np.float64)
+    # weight image: per class [C][taps][K] at w_off
+    for q, cl in enumerate(classes):
+        T_ = cl["TR"] * cl["TS"]
+        for i in range(cl["TR"]):
+            for j in range(cl["TS"]):
+                r, s = cl["r0"] + i * cl["r_step"], cl["s0"] + j * cl["s_step"]
+                blk = w_krsc[:, r, s, :].T  # (C, K)
+                for c in range(Cc):
+                    o = cl["w_off"] + (c * T_ + i * cl["TS"] + j) * K
+                    wimg[o:o + K] = blk[c]
+    assert sum(Cc * cl["TR"] * cl["TS"] * K for cl in classes) == total
+    dx = np.zeros((N, H, W, Cc))
+    qi = 0
+    for ph in range(sh):
+        for pw in range(sw):
+            cl = classes[qi]
+            qi += 1
+            T_ = cl["TR"] * cl["TS"]
+            OHi = (H - ph + sh - 1) // sh if ph < H else 0
+            OWi = (W - pw + sw - 1) // sw if pw < W else 0
+            wq = wimg[cl["w_off"]:cl["w_off"] + Cc * T_ * K].reshape(Cc, T_, K) if T_ else None
+            for hh in range(OHi):
+                for ww in range(OWi):
+                    acc = np.zeros((N, Cc))
+                    for i in range(cl["TR"]):
+                        ih = hh + cl["dh0"] + i * cl["dh_step"]
+                        if not (0 <= ih < P):
+                            continue
+                        for j in range(cl["TS"]):
+                            iw = ww + cl["dw0"] + j * cl["dw_step"]
+                            if not (0 <= iw < Q):
+                                continue
+                            acc += dy_nhwc[:, ih, iw, :] @ wq[:, i * cl["TS"] + j, :].T
+                    dx[:, hh * sh + ph, ww * sw + pw, :] = acc
+    return dx
+
+
+@pytest.mark.parametrize("H,W,R,S,stride,pad,dil", [
+    (8, 10, 3, 3, (1, 1), (1, 1), (1, 1)),
+    (8, 10, 3, 3, (2, 2), (1, 1), (1, 1)),
+    (9, 11, 3, 3, (2, 2), (1, 1), (1, 1)),   # odd sizes: parity classes of unequal extent
+    (12, 12, 6, 6, (2, 2), (2, 2), (1, 1)),  # YOLOv5 stem geometry
+    (8, 8, 1, 1, (2, 2), (0, 0), (1, 1)),    # ResNet downsample: three empty classes must write zeros
+    (10, 10, 3, 3, (1, 1), (2, 2), (2, 2)),  # dilation
+    (11, 9, 3, 5, (2, 1), (1, 2), (1, 1)),   # asymmetric
+    (13, 13, 5, 5, (3, 3), (2, 2), (1, 1)),
+    (12, 12, 3, 3, (2, 2), (2, 2), (2, 2)),  # stride 2 + dilation 2: only one parity per axis has taps
+])
+def test_dgrad_plan_interpreted_matches_torch(H, W, R, S, stride, pad, dil):
+    torch.manual_seed(0)
+    N, Cc, K = 2, 8, 8
+    x = torch.randn(N, Cc, H, W, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(K, Cc, R, S, dtype=torch.float64)
+    y = F.conv2d(x, w, stride=stride, padding=pad, dilation=dil)
+    dy = torch.randn_like(y)
+    (gx,) = torch.autograd.grad(y, x, dy)
+    dd = desc(N, Cc, H, W, K, R, S, stride, pad, dil)
+    got = interpret_dgrad(dd, dy.permute(0, 2, 3, 1).numpy(), w.permute(0, 2, 3, 1).numpy())
+    np.testing.assert_allclose(got, gx.detach().permute(0, 2, 3, 1).numpy(), rtol=1e-10, atol=1e-10)

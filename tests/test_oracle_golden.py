@@ -1,0 +1,196 @@
+"""Pin the oracle (oracle/torch_ref.py) to the reference: replay the golden vectors that
+tools/gen_golden.py captured from the reference's own modules (/root/reference, build container only).
+CPU-only; same torch build => results are required to match to fp32 round-off (rtol 1e-5) and index
+tensors exactly."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref as R
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+    out = {}
+    for k in z.files:
+        parts = k.split("/", 1)
+        if len(parts) == 1:
+            out[k] = z[k]
+        else:
+            out.setdefault(parts[0], {})[parts[1]] = z[k]
+    return out
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(1.0, float(b.abs().max())) if b.numel() else 1.0
+    err = float((a - b).abs().max()) if b.numel() else 0.0
+    assert err <= atol + rtol * scale, "max err %g (scale %g)" % (err, scale)
+
+
+def lst(d):
+    return [T(d[str(i)]) for i in range(len(d))]
+
+
+def load_state(mod, state):
+    sd = {k: T(v) for k, v in state.items()}
+    missing, unexpected = mod.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+
+
+CONV_ACT = {"k1": dict(type="SiLU"), "k3": dict(type="SiLU"), "k3s2": dict(type="Swish"), "k3s2odd": dict(type="SiLU"),
+            "k6s2": dict(type="SiLU"), "k3d2": dict(type="ReLU"), "k1bias": None, "dw3d3": dict(type="ReLU"), "k1s2": None}
+CONV_NORM = {"k3d2": dict(type="BN"), "k1bias": None, "dw3d3": dict(type="BN"), "k1s2": dict(type="BN")}
+BN_YOLO = dict(type="BN", momentum=0.03, eps=0.001)
+
+
+def run(mod, inputs, cots):
+    inputs = [x.clone().requires_grad_(True) for x in inputs]
+    out = mod(*inputs)
+    outs = [o for o in (list(out) if isinstance(out, (tuple, list)) else [out]) if torch.is_tensor(o)]
+    loss = sum((o * c).sum() for o, c in zip(outs, cots))
+    named = [(n, p) for n, p in mod.named_parameters() if p.requires_grad]
+    grads = torch.autograd.grad(loss, inputs + [p for _, p in named], allow_unused=True)
+    gpar = {n: (g if g is not None else torch.zeros_like(p)) for (n, p), g in zip(named, grads[len(inputs):])}
+    return outs, grads[:len(inputs)], gpar
+
+
+@pytest.mark.parametrize("name", sorted(CONV_ACT))
+def test_convmodule(name):
+    g = load("convmodule_" + name)
+    cin, cout, k, s, p, d, grp = [int(v) for v in g["meta"]]
+    m = R.ConvModule(cin, cout, k, stride=s, padding=p, dilation=d, groups=grp, norm_cfg=CONV_NORM.get(name, BN_YOLO), act_cfg=CONV_ACT[name])
+    load_state(m, g["state"])
+    m.train()
+    outs, gx, gpar = run(m, [T(g["x"])], [T(g["cot"])])
+    close(outs[0], g["out"])
+    close(gx[0], g["gx"], rtol=1e-4)
+    for n, v in g["gparam"].items():
+        close(gpar[n], v, rtol=1e-4)
+    for n, v in g.get("state_after", {}).items():
+        close(m.state_dict()[n], v)
+
+
+BLOCKS = {
+    "bottleneck": lambda: R.DarknetBottleneck(16, 16, 1.0, True, norm_cfg=BN_YOLO, act_cfg=dict(type="SiLU")),
+    "csp": lambda: R.CSPLayer(32, 32, n=2, shortcut=True, norm_cfg=BN_YOLO, act_cfg=dict(type="SiLU")),
+    "sppf": lambda: R.SPPF(32, 32, kernel_sizes=5, norm_cfg=BN_YOLO, act_cfg=dict(type="SiLU")),
+    "spp": lambda: R.SPPF(32, 32, kernel_sizes=(5, 9, 13), norm_cfg=BN_YOLO, act_cfg=dict(type="Swish")),
+    "focus": lambda: R.Focus(3, 16, 3, norm_cfg=BN_YOLO, act_cfg=dict(type="Swish")),
+    "up": lambda: R.UpsamplingModule(32, 16, 1, norm_cfg=BN_YOLO, act_cfg=dict(type="SiLU")),
+    "down": lambda: R.DownsamplingModule(16, 32, 1, norm_cfg=BN_YOLO, act_cfg=dict(type="SiLU")),
+}
+
+
+@pytest.mark.parametrize("name", sorted(BLOCKS))
+def test_block(name):
+    g = load("block_" + name)
+    m = BLOCKS[name]()
+    for mm in m.modules():
+        if isinstance(mm, torch.nn.BatchNorm2d):
+            mm.eps, mm.momentum = 1e-3, 0.03
+    load_state(m, g["state"])
+    m.train()
+    outs, gx, gpar = run(m, lst(g["x"]), lst(g["cot"]))
+    for o, e in zip(outs, lst(g["out"])):
+        close(o, e)
+    for a, e in zip(gx, lst(g["gx"])):
+        close(a, e, rtol=1e-4)
+    for n, v in g["gparam"].items():
+        close(gpar[n], v, rtol=2e-4)
+
+
+def test_backbone_v5n_full():
+    g = load("backbone_v5n_full")
+    m = R.YOLOv5CSPDarknet("cspdark_n")
+    load_state(m, g["state"])
+    m.train()
+    outs, _, gpar = run(m, [T(g["x"])], lst(g["cot"]))
+    for o, e in zip(outs, lst(g["out"])):
+        close(o, e, rtol=1e-4)
+    close(gpar["stem.conv.weight"], g["g_stem"], rtol=1e-3)
+    for n, v in g["gparam_norms"].items():
+        assert abs(float(gpar[n].norm()) - float(v)) <= 1e-3 * max(1.0, float(v)), n
+
+
+def test_backbone_v5s_structure():
+    """Same parameter names / count as the reference's YOLOv5CSPDarknet('cspdark_s') and same output shapes."""
+    g = load("backbone_v5s")
+    m = R.YOLOv5CSPDarknet("cspdark_s")
+    assert sorted(m.state_dict().keys()) == [str(k) for k in g["state_keys"]]
+    assert sum(p.numel() for p in m.parameters()) == int(g["n_params"][0])
+    m.train()
+    feats = m(T(g["x"]))
+    for f, e in zip(feats, lst(g["feats"])):
+        assert tuple(f.shape) == tuple(e.shape)
+
+
+def test_detect():
+    g = load("detect_v5")
+    m = R.YOLOv5Detect(80, in_channels=(256, 512, 1024), width_mul=0.125)
+    load_state(m, g["state"])
+    m.train()
+    _, tr = m(lst(g["x"]))
+    for o, e in zip(tr, lst(g["train_out"])):
+        close(o, e)
+    m.eval()
+    z, _ = m(lst(g["x"]))
+    close(z, g["z"])
+
+
+def test_bbox_iou_family():
+    g = load("bbox_iou")
+    b1, b2 = T(g["b1"]), T(g["b2"])
+    close(R.bbox_iou(b1, b2, x1y1x2y2=False), g["iou"])
+    close(R.bbox_iou(b1, b2, x1y1x2y2=False, GIoU=True), g["giou"])
+    close(R.bbox_iou(b1, b2, x1y1x2y2=False, DIoU=True), g["diou"])
+    close(R.bbox_iou(b1, b2, x1y1x2y2=False, CIoU=True), g["ciou"])
+
+
+def test_bbox_overlaps_known_answer():
+    """The one known-answer vector the reference holds for this path: src/losses/det/iou_losses.py:35-52."""
+    g = load("bbox_overlaps_kat")
+    expect = torch.tensor([[0.5, 0.0, 0.0], [0.0, 0.0, 1.0], [0.0, 0.0, 0.0]])
+    close(T(g["iou"]), expect, atol=1e-4)
+    close(R.box_iou(T(g["b1"]), T(g["b2"])), expect, atol=1e-4)
+
+
+def test_box_iou_xywh2xyxy():
+    g = load("box_iou")
+    close(R.box_iou(T(g["a"]), T(g["b"])), g["iou"])
+    close(R.xywh2xyxy(T(g["a"])), g["xyxy"])
+
+
+@pytest.mark.parametrize("trial", [0, 1, 2])
+def test_yolov5_loss(trial):
+    g = load("yolov5_loss_%d" % trial)
+    p = [q.requires_grad_(True) for q in lst(g["p"])]
+    loss = R.YOLOv5Loss(80)
+    total, stats = loss(p, T(g["targets"]))
+    close(total, g["total"])
+    close(stats, g["stats"])
+    grads = torch.autograd.grad(total, p)
+    for a, e in zip(grads, lst(g["grads"])):
+        close(a, e, atol=1e-7)
+    tcls, tbox, indices, anch = loss.build_targets([q.detach() for q in p], T(g["targets"]))
+    for i in range(3):
+        assert torch.equal(indices[i][0], T(g["b"][str(i)]))
+        assert torch.equal(indices[i][1], T(g["a"][str(i)]))
+        assert torch.equal(indices[i][2], T(g["gj"][str(i)]))
+        assert torch.equal(indices[i][3], T(g["gi"][str(i)]))
+        assert torch.equal(tcls[i], T(g["tcls"][str(i)]))
+        close(tbox[i], g["tbox"][str(i)])
+
+
+def test_golden_files_present():
+    assert len(glob.glob(os.path.join(GOLD, "*.npz"))) >= 20
