@@ -155,6 +155,9 @@ class HipConv2d(nn.Conv2d):
         if isinstance(self.padding, str):
             raise L.CvhipError("HipConv2d needs numeric padding")
         self._hip_state = ops.ConvState()
+        # master weights live in KRSC physical order (OIHW shape, channels_last strides): the operand packers
+        # read them without a relayout and wgrad's KRSC output IS the .grad tensor (no clone in AccumulateGrad)
+        self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
 
     def _effective(self, x):
         """Image inputs (fp32, C % 8 != 0) are relaid out to bf16 NHWC with zero-padded channels; the
@@ -584,6 +587,7 @@ def _swap_conv(m):
     new = HipConv2d(m.in_channels, m.out_channels, m.kernel_size, m.stride, m.padding, m.dilation, m.groups,
                     m.bias is not None, m.padding_mode)
     new.weight = m.weight
+    new.weight.data = new.weight.data.contiguous(memory_format=torch.channels_last)
     new.bias = m.bias
     return new
 

@@ -115,6 +115,46 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const RedParams p) {
   }
 }
 
+// ---- partial-row pre-reduction -------------------------------------------------------------------
+// The conv epilogue emits one partial row per M tile (25,600 rows for the YOLOv5-s stem at batch 64) and
+// the streaming reductions up to 1024: reducing those serially in a one-thread-per-channel finalize
+// kernel costs hundreds of microseconds of pure latency. When rows > kStage2Rows a fully parallel
+// pre-pass folds them into kStage2Rows rows first, written to the scratch rows that every partial
+// buffer carries behind its payload (CVHIP_REDUCE_SCRATCH_ROWS). Deterministic (fixed partition).
+constexpr int kStage2Rows = CVHIP_REDUCE_SCRATCH_ROWS;
+
+__global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ in, int rows, int Wd, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int t = threadIdx.x;
+  const int col = blockIdx.x * 64 + (t & 63), lane = t >> 6;
+  const int chunk = (rows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * chunk;
+  const int r1 = min(rows, r0 + chunk);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (col < Wd) {
+    int r = r0 + lane;
+    for (; r + 12 < r1; r += 16) {
+      a0 += in[(int64_t)r * Wd + col];
+      a1 += in[(int64_t)(r + 4) * Wd + col];
+      a2 += in[(int64_t)(r + 8) * Wd + col];
+      a3 += in[(int64_t)(r + 12) * Wd + col];
+    }
+    for (; r < r1; r += 4) a0 += in[(int64_t)r * Wd + col];
+  }
+  red[lane][t & 63] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (lane == 0 && col < Wd) out[(int64_t)blockIdx.y * Wd + col] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+}
+
+// returns the (possibly pre-reduced) partial pointer and updates *rows
+static const float* prereduce(const float* partial, int* rows, int Wd, hipStream_t s) {
+  if (*rows <= kStage2Rows) return partial;
+  float* scratch = const_cast<float*>(partial) + (int64_t)(*rows) * Wd;
+  hipLaunchKernelGGL(rows_reduce_kernel, dim3(cdiv(Wd, 64), kStage2Rows), dim3(256), 0, s, partial, *rows, Wd, scratch);
+  *rows = kStage2Rows;
+  return scratch;
+}
+
 // ---- finalize kernels (one thread per channel) -----------------------------------------------------
 __global__ void bn_finalize_kernel(const float* partial, int rows, int C, double count, const float* gamma,
                                    const float* beta, float* rmean, float* rvar, float momentum, float eps,
@@ -337,6 +377,7 @@ int cvhip_bn_finalize(const float* partial, int32_t rows, int32_t C, int64_t cou
                       const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                       float* mean, float* invstd, float* scale, float* shift, void* stream) {
   if (!partial || rows <= 0 || C <= 0 || count <= 0) return CVHIP_ERR_INVALID;
+  partial = prereduce(partial, &rows, 2 * C, (hipStream_t)stream);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, rows, C,
                      (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
   return check_launch("bn_finalize_kernel");
@@ -352,6 +393,7 @@ int cvhip_bn_eval_scale_shift(int32_t C, const float* gamma, const float* beta, 
 
 int cvhip_bn_bwd_finalize(const float* partial, int32_t rows, int32_t C, float* dgamma, float* dbeta, void* stream) {
   if (!partial || rows <= 0 || C <= 0) return CVHIP_ERR_INVALID;
+  partial = prereduce(partial, &rows, 2 * C, (hipStream_t)stream);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, rows, C,
                      dbeta, dgamma, 0);
   return check_launch("sum_partials_kernel");
@@ -359,6 +401,7 @@ int cvhip_bn_bwd_finalize(const float* partial, int32_t rows, int32_t C, float* 
 
 int cvhip_colsum_finalize(const float* partial, int32_t rows, int32_t C, float* out, int accumulate, void* stream) {
   if (!partial || rows <= 0 || C <= 0 || !out) return CVHIP_ERR_INVALID;
+  partial = prereduce(partial, &rows, 2 * C, (hipStream_t)stream);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, rows, C,
                      out, (float*)nullptr, accumulate);
   return check_launch("sum_partials_kernel");

@@ -7,12 +7,19 @@ never imported from here.)
 import ctypes as C
 import os
 
+# torch must be imported BEFORE libcvhip.so is dlopen'ed: the torch wheel bundles its own HIP runtime
+# (torch/lib/libamdhip64.so, no SONAME) and loads it into the global symbol scope; libcvhip's hip* calls
+# then resolve to that one runtime. Loaded the other way round, libcvhip binds /opt/rocm's copy and the
+# process ends up with two HIP runtimes (second one reports "no ROCm-capable device").
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcvhip.so")
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -1, -2, -3
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_LEAKY, ACT_SIGMOID, ACT_HSWISH = 0, 1, 2, 3, 4, 5
 DGRAD_CLASS_INTS = 12
+REDUCE_SCRATCH_ROWS = 64  # CVHIP_REDUCE_SCRATCH_ROWS
 
 
 class CvhipError(RuntimeError):

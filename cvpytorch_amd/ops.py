@@ -251,20 +251,20 @@ class ConvBnAct(torch.autograd.Function):
                 rows = lib.cvhip_conv2d_fprop_stats_rows(C.byref(desc))
                 if rows < 0:
                     L.check(rows, "cvhip_conv2d_fprop_stats_rows")
-                partial = torch.empty((rows, 2, K), dtype=torch.float32, device=dev)
+                partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
             _timed_call(_igemm_name(Kp), (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv2d_fprop", C.byref(desc), x.data_ptr(),
                         cfg.state.w_fprop.data_ptr(), _ptr(b), y.data_ptr(), _ptr(partial), st)
         if train_bn:
             if partial is None:
                 rows = _colreduce_rows(M, K)
-                partial = torch.empty((rows, 2, K), dtype=torch.float32, device=dev)
+                partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
                 L.call("cvhip_bn_stats_partial", y.data_ptr(), M, K, Kp, partial.data_ptr(), st)
             stats = torch.empty((4, K), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
             g = gamma.detach().float() if gamma is not None else None
             bt = beta.detach().float() if beta is not None else None
             rm = running_mean if cfg.track else None
             rv = running_var if cfg.track else None
-            L.call("cvhip_bn_finalize", partial.data_ptr(), partial.shape[0], K, M, _ptr(g), _ptr(bt), _ptr(rm), _ptr(rv),
+            L.call("cvhip_bn_finalize", partial.data_ptr(), rows, K, M, _ptr(g), _ptr(bt), _ptr(rm), _ptr(rv),
                    cfg.momentum, cfg.eps, stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), st)
         elif cfg.has_bn:
             stats = torch.empty((4, K), dtype=torch.float32, device=dev)
@@ -310,13 +310,13 @@ class ConvBnAct(torch.autograd.Function):
                 dy = empty_nhwc(N, K, P, Q, dev)
             if ctx.train_bn:
                 rows = _colreduce_rows(M, K)
-                partial = torch.empty((rows, 2, K), dtype=torch.float32, device=dev)
+                partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
                 L.call("cvhip_bn_act_bwd_partial", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, M, K, stats[2].data_ptr(),
                        stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), cfg.act, cfg.act_param,
                        partial.data_ptr(), st)
-                dgb = torch.empty((2, K), dtype=torch.float32, device=dev)
-                L.call("cvhip_bn_bwd_finalize", partial.data_ptr(), rows, K, dgb[0].data_ptr(), dgb[1].data_ptr(), st)
-                dgamma, dbeta = dgb[0], dgb[1]
+                dgamma = torch.empty((K,), dtype=torch.float32, device=dev)
+                dbeta = torch.empty((K,), dtype=torch.float32, device=dev)
+                L.call("cvhip_bn_bwd_finalize", partial.data_ptr(), rows, K, dgamma.data_ptr(), dbeta.data_ptr(), st)
                 L.call("cvhip_bn_act_bwd_apply", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, dy.data_ptr(), Kp, M, K,
                        stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
                        dgamma.data_ptr(), dbeta.data_ptr(), cfg.act, cfg.act_param, st)
@@ -335,7 +335,7 @@ class ConvBnAct(torch.autograd.Function):
                 dy, dy_ld = buf.permute(0, 3, 1, 2)[:, :K], Kp
         if ctx.has_bias and need_db and not ctx.train_bn:
             rows = _colreduce_rows(M, K)
-            partial = torch.empty((rows, 2, K), dtype=torch.float32, device=dev)
+            partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
             L.call("cvhip_colsum_partial", dy.data_ptr(), M, K, dy_ld, partial.data_ptr(), st)
             dbias = torch.empty((K,), dtype=torch.float32, device=dev)
             L.call("cvhip_colsum_finalize", partial.data_ptr(), rows, K, dbias.data_ptr(), 0, st)
@@ -356,10 +356,14 @@ class ConvBnAct(torch.autograd.Function):
         else:
             if need_dw:
                 desc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, x_ld, dy_ld)
-                dwk = torch.empty((Kp, R, S, Cc), dtype=torch.float32, device=dev)
+                if Kp == K:  # logical OIHW, KRSC (channels_last) memory: a fresh non-view tensor autograd can adopt as .grad
+                    dw = torch.empty((K, Cc, R, S), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+                    dwp = dw.data_ptr()
+                else:
+                    dwk = torch.empty((Kp, R, S, Cc), dtype=torch.float32, device=dev)
+                    dw, dwp = dwk[:K].permute(0, 3, 1, 2), dwk.data_ptr()
                 _timed_call(_wgrad_name(Kp), (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(),
-                            dy.data_ptr(), dwk.data_ptr(), 0, st)
-                dw = dwk[:K].permute(0, 3, 1, 2)  # logical OIHW, channels_last memory
+                            dy.data_ptr(), dwp, 0, st)
             if need_dx:
                 if ctx.w_dgrad is None:
                     raise L.CvhipError("dgrad weight image missing (input started requiring grad after forward)")
@@ -391,7 +395,7 @@ class BnAct(torch.autograd.Function):
         train_bn = has_bn and training
         if train_bn:
             rows = _colreduce_rows(M, K)
-            partial = torch.empty((rows, 2, K), dtype=torch.float32, device=dev)
+            partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
             L.call("cvhip_bn_stats_partial", y.data_ptr(), M, K, y_ld, partial.data_ptr(), st)
             stats = torch.empty((4, K), dtype=torch.float32, device=dev)
             L.call("cvhip_bn_finalize", partial.data_ptr(), rows, K, M, _ptr(gamma.detach().float() if gamma is not None else None),
@@ -425,12 +429,12 @@ class BnAct(torch.autograd.Function):
         dgamma = dbeta = None
         if train_bn:
             rows = _colreduce_rows(M, K)
-            partial = torch.empty((rows, 2, K), dtype=torch.float32, device=dev)
+            partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
             L.call("cvhip_bn_act_bwd_partial", dz.data_ptr(), dz_ld, y.data_ptr(), y_ld, M, K, stats[2].data_ptr(),
                    stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), act, ap, partial.data_ptr(), st)
-            dgb = torch.empty((2, K), dtype=torch.float32, device=dev)
-            L.call("cvhip_bn_bwd_finalize", partial.data_ptr(), rows, K, dgb[0].data_ptr(), dgb[1].data_ptr(), st)
-            dgamma, dbeta = dgb[0], dgb[1]
+            dgamma = torch.empty((K,), dtype=torch.float32, device=dev)
+            dbeta = torch.empty((K,), dtype=torch.float32, device=dev)
+            L.call("cvhip_bn_bwd_finalize", partial.data_ptr(), rows, K, dgamma.data_ptr(), dbeta.data_ptr(), st)
             L.call("cvhip_bn_act_bwd_apply", dz.data_ptr(), dz_ld, y.data_ptr(), y_ld, dy.data_ptr(), K, M, K,
                    stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), dgamma.data_ptr(),
                    dbeta.data_ptr(), act, ap, st)

@@ -128,6 +128,10 @@ int cvhip_dwconv2d_wgrad(const cvhip_conv_desc* d, const void* x_bf16, const voi
  * Column reductions over a [M][C] bf16 matrix with row pitch ld (NHWC activations, M=N*H*W).
  * Two-stage and deterministic: stage 1 writes `rows` partial rows, finalize reduces them.
  * ------------------------------------------------------------------------------------------ */
+/* Every `partial` buffer ([rows][2][C] fp32) handed to a *_finalize entry point must be allocated with
+ * CVHIP_REDUCE_SCRATCH_ROWS extra rows behind its payload: finalize pre-reduces many-row partials
+ * (one row per conv M-tile: 25,600 for the YOLOv5-s stem at batch 64) into that scratch in parallel. */
+#define CVHIP_REDUCE_SCRATCH_ROWS 64
 /* number of partial rows stage-1 reductions produce for an M-row matrix */
 int cvhip_colreduce_rows(int64_t M, int32_t C);
 

@@ -55,7 +55,8 @@ def test_probe_mfma_layout():
     a = torch.randn(16, 32).to(BF)
     b = torch.randn(32, 16).to(BF)  # asymmetric on purpose (transpose-detecting)
     d = torch.zeros(16, 16, device=dev())
-    L.call("cvhip_probe_mfma_16x16x32", a.to(dev()).data_ptr(), b.to(dev()).data_ptr(), d.data_ptr(), None)
+    ad, bd = a.to(dev()), b.to(dev())  # keep the device copies alive across the launch
+    L.call("cvhip_probe_mfma_16x16x32", ad.data_ptr(), bd.data_ptr(), d.data_ptr(), None)
     torch.cuda.synchronize()
     ref = a.float() @ b.float()
     assert rel_l2(d, ref) < 1e-5
@@ -64,7 +65,8 @@ def test_probe_mfma_layout():
 def test_probe_ds_read_tr16():
     src = torch.arange(256, dtype=torch.float32).to(BF)
     out = torch.zeros(256, dtype=BF, device=dev())
-    L.call("cvhip_probe_ds_read_tr16", src.to(dev()).data_ptr(), out.data_ptr(), None)
+    srcd = src.to(dev())
+    L.call("cvhip_probe_ds_read_tr16", srcd.data_ptr(), out.data_ptr(), None)
     torch.cuda.synchronize()
     got = out.float().cpu().view(64, 4)
     exp = torch.empty(64, 4)
