@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--stock-optimizer", action="store_true", help="torch.optim.SGD + ModelEMA instead of the fused arena step")
     return ap.parse_args()
 
 
@@ -88,6 +89,7 @@ def main():
 
     from cvpytorch_amd import ops, yolov5
     from cvpytorch_amd.data import synthetic_detection_batch
+    from cvpytorch_amd.arena import FlatTrainState, FlatTrainStep
     from cvpytorch_amd.train import GradBucketer, ModelEMA, TrainStep, build_optimizer
 
     torch.manual_seed(1029)
@@ -96,10 +98,14 @@ def main():
     if world > 1:  # same initial weights everywhere (DDP broadcasts rank 0's at construction)
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, 0)
-    opt = build_optimizer(model, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4)
-    ema = ModelEMA(model) if rank == 0 else None  # trainer.py:293: EMA on the main process only
-    bucketer = GradBucketer(model) if world > 1 else None
-    step = TrainStep(model, opt, ema, bucketer, sync_buffers=world > 1)
+    if a.stock_optimizer:  # reference-shaped tail: .grad tensors -> torch.optim.SGD -> ModelEMA (+ GradBucketer)
+        opt = build_optimizer(model, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4)
+        ema = ModelEMA(model) if rank == 0 else None  # trainer.py:293: EMA on the main process only
+        bucketer = GradBucketer(model) if world > 1 else None
+        step = TrainStep(model, opt, ema, bucketer, sync_buffers=world > 1)
+    else:  # flat arenas: direct gradient writes, in-place bucketed all-reduce, ONE fused SGD+EMA kernel
+        state = FlatTrainState(model, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4, use_ema=(rank == 0))
+        step = FlatTrainStep(model, state, sync_buffers=world > 1)
     imgs, targets = synthetic_detection_batch(a.batch, a.size, seed=1029 + rank, max_boxes=max_boxes, device=dev)
     gts = yolov5.targets_to_tensor(targets, a.batch * max_boxes, dev)
 

@@ -1,0 +1,220 @@
+"""Flat parameter / gradient / momentum / EMA arenas and the fused optimizer step.
+
+The reference's step tail is python-loop heavy: torch.optim.SGD over 177 one-parameter groups
+(src/optimizers/__init__.py:36-68), `ModelEMA.update` looping over every state_dict entry
+(src/utils/ema.py:30-39), DDP's bucket copy-in / copy-out (trainer.py:312-313). Here all trainable
+parameters live in ONE fp32 arena (each nn.Parameter is re-pointed at a view of it, shape and strides
+unchanged), their gradients in a second arena of identical layout (`p.grad` is a permanent view), so:
+
+  * backward writes weight / BN gradients straight into the gradient arena (cvhip_conv2d_wgrad with
+    accumulate=1, cvhip_bn_bwd_finalize(accumulate=1)) — no per-parameter .grad tensors, no clones;
+  * gradient all-reduce runs IN PLACE on contiguous arena ranges (buckets in reverse layer order,
+    launched on a side stream as soon as the layers inside have produced their gradients; the 1/world
+    average is folded into the optimizer's grad_scale);
+  * SGD(momentum, nesterov, weight decay) + EMA for all parameters is ONE kernel
+    (cvhip_sgd_nesterov_ema), the EMA of the BN running statistics one more (cvhip_ema_update);
+  * zero_grad is one memset.
+
+Semantics are torch.optim.SGD's and ModelEMA's (checked by tests/test_gpu_arena.py against the stock
+optimizer path).
+"""
+import math
+from copy import deepcopy
+
+import torch
+import torch.distributed as dist
+
+from . import lib as L
+from . import ops
+from .train import build_param_groups
+
+_ALIGN = 8  # floats (32 B): keeps every parameter 16-byte aligned for the vectorised packers
+
+
+def _dense_view(flat, off, like):
+    return flat[off:off + like.numel()].as_strided(like.shape, like.stride())
+
+
+class FlatTrainState:
+    def __init__(self, model, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4, backbone_lr=None, ema_decay=0.9999,
+                 use_ema=True, bucket_bytes=8 << 20, process_group=None):
+        self.model = model
+        self.momentum, self.nesterov = float(momentum), bool(nesterov)
+        groups = build_param_groups(model, lr, backbone_lr, weight_decay)
+        hyper = {id(g["params"][0]): (g["lr"], g["weight_decay"]) for g in groups}
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise L.CvhipError("FlatTrainState needs the model on the GPU (no CPU fallback)")
+        offs, total = [], 0
+        for p in self.params:
+            if not p.is_non_overlapping_and_dense():
+                raise L.CvhipError("parameter is not dense")
+            offs.append(total)
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.offsets, self.total = offs, total
+        self.param = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.mom = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.index = {}
+        for i, (p, off) in enumerate(zip(self.params, offs)):
+            v = _dense_view(self.param, off, p)
+            v.copy_(p.data)
+            p.data = v
+            p.grad = _dense_view(self.grad, off, p)
+            p._hip_grad = p.grad
+            p._hip_arena = (self, i)
+            self.index[id(p)] = i
+        seg = [[off, off + (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN] for p, off in zip(self.params, offs)]
+        self.seg_bounds = torch.tensor(seg, dtype=torch.int64, device=dev)
+        self.base_lr = [hyper[id(p)][0] for p in self.params]
+        self.seg_lr = torch.tensor(self.base_lr, dtype=torch.float32, device=dev)
+        self.seg_wd = torch.tensor([hyper[id(p)][1] for p in self.params], dtype=torch.float32, device=dev)
+        self.steps = 0
+        # floating-point buffers (BN running statistics) in their own arena
+        self.bufs = [b for b in model.buffers() if b.dtype == torch.float32]
+        self.buf = torch.zeros(sum(b.numel() for b in self.bufs), dtype=torch.float32, device=dev)
+        o = 0
+        owners = {}
+        for m in model.modules():
+            for name, b in m._buffers.items():
+                if b is not None and b.dtype == torch.float32:
+                    owners[id(b)] = (m, name)
+        for b in self.bufs:
+            v = self.buf[o:o + b.numel()].view(b.shape)
+            v.copy_(b)
+            m, name = owners[id(b)]
+            m._buffers[name] = v
+            o += b.numel()
+        # EMA (trainer.py:293: rank 0 only — the caller decides via use_ema)
+        self.ema_model = None
+        self.ema_param = self.ema_buf = None
+        self.ema_decay = ema_decay
+        self.ema_updates = 0
+        if use_ema:
+            self.ema_model = deepcopy(model).eval()
+            for p in self.ema_model.parameters():
+                p.requires_grad_(False)
+                p.grad = None
+            self.ema_param = self.param.clone()
+            self.ema_buf = self.buf.clone()
+            eparams = [p for p, q in zip(self.ema_model.parameters(), model.parameters()) if q.requires_grad]
+            for p, off in zip(eparams, offs):
+                p.data = _dense_view(self.ema_param, off, p)
+            o = 0
+            eowners = {}
+            for m in self.ema_model.modules():
+                for name, b in m._buffers.items():
+                    if b is not None and b.dtype == torch.float32:
+                        eowners.setdefault(id(b), (m, name))
+            for b in [b for b in self.ema_model.buffers() if b.dtype == torch.float32]:
+                m, name = eowners[id(b)]
+                m._buffers[name] = self.ema_buf[o:o + b.numel()].view(b.shape)
+                o += b.numel()
+        # gradient buckets: contiguous arena ranges, filled in reverse registration order
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.buckets = []  # [lo, hi, first_param, last_param]
+        cap = max(1, bucket_bytes // 4)
+        hi_i = len(self.params) - 1
+        i = hi_i
+        while i >= 0:
+            lo_i = i
+            while lo_i - 1 >= 0 and (seg[hi_i][1] - seg[lo_i - 1][0]) <= cap:
+                lo_i -= 1
+            self.buckets.append((seg[lo_i][0], seg[hi_i][1], lo_i, hi_i))
+            i = hi_i = lo_i - 1
+        self.bucket_of = {}
+        for bi, (_, _, lo_i, hi_i2) in enumerate(self.buckets):
+            for k in range(lo_i, hi_i2 + 1):
+                self.bucket_of[k] = bi
+        self._pending = None
+        self._works = []
+        self._stream = None
+        if self.world > 1:
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(self._hook)
+        self._reset_buckets()
+
+    # ---- gradient readiness / all-reduce ------------------------------------------------------------------
+    def _reset_buckets(self):
+        self._pending = [hi - lo + 1 for (_, _, lo, hi) in self.buckets]
+        self._seen = set()
+        self._works = []
+
+    def _hook(self, p):
+        self.mark_ready(self.index[id(p)])
+
+    def mark_ready(self, i):
+        """Called when parameter i's gradient for this step is complete in the arena."""
+        if self.world == 1 or i in self._seen:
+            return
+        self._seen.add(i)
+        bi = self.bucket_of[i]
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._launch(bi)
+
+    def _launch(self, bi):
+        lo, hi = self.buckets[bi][0], self.buckets[bi][1]
+        flat = self.grad[lo:hi]
+        if self._stream is None:
+            self._stream = torch.cuda.Stream()
+        self._stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._stream):
+            w = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._works.append(w)
+
+    def finish_allreduce(self):
+        if self.world == 1:
+            return
+        for bi, n in enumerate(self._pending):
+            if n > 0:  # some parameters received no gradient this step (their arena slots are zero)
+                self._pending[bi] = 0
+                self._launch(bi)
+        for w in self._works:
+            w.wait()
+        if self._stream is not None:
+            torch.cuda.current_stream().wait_stream(self._stream)
+
+    # ---- optimizer ------------------------------------------------------------------------------------------
+    def set_lr_scale(self, scale):
+        """lr = base_lr * scale for every parameter (warm-up / scheduler hook: lr_schedulers/__init__.py)."""
+        self.seg_lr.copy_(torch.tensor([b * scale for b in self.base_lr], dtype=torch.float32))
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def step(self):
+        self.finish_allreduce()
+        d = 0.0
+        ema_ptr = None
+        if self.ema_param is not None:
+            self.ema_updates += 1
+            d = self.ema_decay * (1 - math.exp(-self.ema_updates / 2000))
+            ema_ptr = self.ema_param.data_ptr()
+        st = ops._stream()
+        L.call("cvhip_sgd_nesterov_ema", self.param.data_ptr(), self.grad.data_ptr(), self.mom.data_ptr(), ema_ptr, self.total,
+               self.seg_bounds.data_ptr(), self.seg_lr.data_ptr(), self.seg_wd.data_ptr(), len(self.params), self.momentum,
+               int(self.nesterov), int(self.steps == 0), float(d), 1.0 / self.world, st)
+        if self.ema_buf is not None and self.buf.numel():
+            L.call("cvhip_ema_update", self.ema_buf.data_ptr(), self.buf.data_ptr(), self.buf.numel(), float(d), st)
+        self.steps += 1
+        ops.bump_weights_epoch()  # parameters changed behind torch's version counters
+        self.zero_grad()
+        self._reset_buckets()
+
+
+class FlatTrainStep:
+    """forward -> loss -> backward (grads land in the arena, buckets all-reduce as they fill) -> fused SGD+EMA."""
+
+    def __init__(self, model, state, sync_buffers=False):
+        self.model, self.state, self.sync_buffers = model, state, sync_buffers
+
+    def __call__(self, imgs, targets):
+        if self.sync_buffers and self.state.world > 1 and self.state.buf.numel():
+            dist.broadcast(self.state.buf, 0, group=self.state.group)  # DDP broadcast_buffers: ONE collective
+        losses = self.model(imgs, targets, "train")
+        losses["loss"].backward()
+        self.state.step()
+        return losses

@@ -184,6 +184,14 @@ class HipConv2d(nn.Conv2d):
                           eps=(bn.eps if bn is not None else 1e-5), state=self._hip_state,
                           track=(bn.track_running_stats and bn.training) if bn is not None else False)
         cfg.vkey = (id(self.weight), self.weight._version)
+        # flat gradient arena (cvpytorch_amd/arena.py): let backward accumulate straight into the parameters' slots
+        ar = getattr(self.weight, "_hip_arena", None)
+        if ar is not None and torch.is_grad_enabled():
+            cfg.arena = ar[0]
+            cfg.gw, cfg.idx_w = self.weight._hip_grad, ar[1]  # used only when the effective weight IS the parameter
+            if bn is not None and bn.weight is not None and bn.bias is not None and getattr(bn.weight, "_hip_arena", None) is not None:
+                cfg.gg, cfg.gbeta = bn.weight._hip_grad, bn.bias._hip_grad
+                cfg.idx_bn = (bn.weight._hip_arena[1], bn.bias._hip_arena[1])
         return cfg
 
     def forward(self, x):

@@ -156,16 +156,41 @@ static const float* prereduce(const float* partial, int* rows, int Wd, hipStream
 }
 
 // ---- finalize kernels (one thread per channel) -----------------------------------------------------
-__global__ void bn_finalize_kernel(const float* partial, int rows, int C, double count, const float* gamma,
-                                   const float* beta, float* rmean, float* rvar, float momentum, float eps,
-                                   float* mean, float* invstd, float* scale, float* shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < rows; ++r) {
-    s1 += (double)partial[((int64_t)r * 2 + 0) * C + c];
-    s2 += (double)partial[((int64_t)r * 2 + 1) * C + c];
+// 256 threads = 16 channels x 16 row-lanes; rows <= kStage2Rows after the pre-reduction, so every lane
+// sums <= 4 rows and the 16 lanes of a channel are folded through LDS (latency ~ one L2 round trip).
+__device__ __forceinline__ void fold16(const float* partial, int rows, int C, int c, int lane, double* s1, double* s2,
+                                       bool want2, double (*red)[16][17]) {
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (int r = lane; r < rows; r += 16) {
+      a += (double)partial[((int64_t)r * 2 + 0) * C + c];
+      if (want2) b += (double)partial[((int64_t)r * 2 + 1) * C + c];
+    }
+  const int cc = threadIdx.x & 15;
+  red[0][lane][cc] = a;
+  red[1][lane][cc] = b;
+  __syncthreads();
+  a = 0.0;
+  b = 0.0;
+  if (lane == 0) {
+#pragma unroll
+    for (int l = 0; l < 16; ++l) {
+      a += red[0][l][cc];
+      b += red[1][l][cc];
+    }
   }
+  *s1 = a;
+  *s2 = b;
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partial, int rows, int C, double count, const float* gamma,
+                                                          const float* beta, float* rmean, float* rvar, float momentum, float eps,
+                                                          float* mean, float* invstd, float* scale, float* shift) {
+  __shared__ double red[2][16][17];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), lane = threadIdx.x >> 4;
+  double s1, s2;
+  fold16(partial, rows, C, c, lane, &s1, &s2, true, red);
+  if (lane != 0 || c >= C) return;
   const double m = s1 / count;
   double var = s2 / count - m * m;
   if (var < 0.0) var = 0.0;
@@ -193,17 +218,19 @@ __global__ void bn_eval_kernel(int C, const float* gamma, const float* beta, con
   shift[c] = b - rmean[c] * g * is;
 }
 
-// out0[c] = sum_r partial[r][0][c]; out1[c] = sum_r partial[r][1][c]
-__global__ void sum_partials_kernel(const float* partial, int rows, int C, float* out0, float* out1, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < rows; ++r) {
-    s1 += (double)partial[((int64_t)r * 2 + 0) * C + c];
-    if (out1) s2 += (double)partial[((int64_t)r * 2 + 1) * C + c];
-  }
+// out0[c] = sum_r partial[r][0][c]; out1[c] = sum_r partial[r][1][c]; optionally acc0/acc1 += the same sums
+// (accumulate != 0 makes out0/out1 accumulate as well)
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* partial, int rows, int C, float* out0, float* out1, int accumulate,
+                                                           float* acc0, float* acc1) {
+  __shared__ double red[2][16][17];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), lane = threadIdx.x >> 4;
+  double s1, s2;
+  fold16(partial, rows, C, c, lane, &s1, &s2, out1 != nullptr || acc1 != nullptr, red);
+  if (lane != 0 || c >= C) return;
   if (out0) out0[c] = accumulate ? out0[c] + (float)s1 : (float)s1;
   if (out1) out1[c] = accumulate ? out1[c] + (float)s2 : (float)s2;
+  if (acc0) acc0[c] += (float)s1;
+  if (acc1) acc1[c] += (float)s2;
 }
 
 // ---- elementwise passes -----------------------------------------------------------------------------
@@ -378,7 +405,7 @@ int cvhip_bn_finalize(const float* partial, int32_t rows, int32_t C, int64_t cou
                       float* mean, float* invstd, float* scale, float* shift, void* stream) {
   if (!partial || rows <= 0 || C <= 0 || count <= 0) return CVHIP_ERR_INVALID;
   partial = prereduce(partial, &rows, 2 * C, (hipStream_t)stream);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, rows, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, rows, C,
                      (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
   return check_launch("bn_finalize_kernel");
 }
@@ -391,19 +418,20 @@ int cvhip_bn_eval_scale_shift(int32_t C, const float* gamma, const float* beta, 
   return check_launch("bn_eval_kernel");
 }
 
-int cvhip_bn_bwd_finalize(const float* partial, int32_t rows, int32_t C, float* dgamma, float* dbeta, void* stream) {
+int cvhip_bn_bwd_finalize(const float* partial, int32_t rows, int32_t C, float* dgamma, float* dbeta, float* acc_dgamma,
+                          float* acc_dbeta, void* stream) {
   if (!partial || rows <= 0 || C <= 0) return CVHIP_ERR_INVALID;
   partial = prereduce(partial, &rows, 2 * C, (hipStream_t)stream);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, rows, C,
-                     dbeta, dgamma, 0);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, rows, C,
+                     dbeta, dgamma, 0, acc_dbeta, acc_dgamma);
   return check_launch("sum_partials_kernel");
 }
 
 int cvhip_colsum_finalize(const float* partial, int32_t rows, int32_t C, float* out, int accumulate, void* stream) {
   if (!partial || rows <= 0 || C <= 0 || !out) return CVHIP_ERR_INVALID;
   partial = prereduce(partial, &rows, 2 * C, (hipStream_t)stream);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, rows, C,
-                     out, (float*)nullptr, accumulate);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, rows, C,
+                     out, (float*)nullptr, accumulate, (float*)nullptr, (float*)nullptr);
   return check_launch("sum_partials_kernel");
 }
 

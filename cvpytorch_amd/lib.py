@@ -60,7 +60,7 @@ SIGNATURES = {
     "cvhip_bn_eval_scale_shift": (_i32, [_i32, _p, _p, _p, _p, _f32, _p, _p, _p]),
     "cvhip_bn_act_fwd": (_i32, [_p, _i32, _p, _i32, _i64, _i32, _p, _p, _i32, _f32, _p, _i32, _p]),
     "cvhip_bn_act_bwd_partial": (_i32, [_p, _i32, _p, _i32, _i64, _i32, _p, _p, _p, _p, _i32, _f32, _p, _p]),
-    "cvhip_bn_bwd_finalize": (_i32, [_p, _i32, _i32, _p, _p, _p]),
+    "cvhip_bn_bwd_finalize": (_i32, [_p, _i32, _i32, _p, _p, _p, _p, _p]),
     "cvhip_bn_act_bwd_apply": (_i32, [_p, _i32, _p, _i32, _p, _i32, _i64, _i32, _p, _p, _p, _p, _p, _p, _i32, _f32, _p]),
     "cvhip_colsum_partial": (_i32, [_p, _i64, _i32, _i32, _p, _p]),
     "cvhip_colsum_finalize": (_i32, [_p, _i32, _i32, _p, _i32, _p]),

@@ -194,7 +194,7 @@ class ConvState:
 class ConvCfg:
     """Static configuration of one conv(+BN+act) layer (python-side, hashable pieces only)."""
     __slots__ = ("stride", "pad", "dil", "groups", "act", "act_param", "has_bn", "bn_training", "momentum", "eps",
-                 "state", "track", "vkey")
+                 "state", "track", "vkey", "gw", "gg", "gbeta", "arena", "idx_w", "idx_bn")
 
     def __init__(self, stride, pad, dil, groups=1, act=L.ACT_NONE, act_param=0.0, has_bn=False, bn_training=True,
                  momentum=0.1, eps=1e-5, state=None, track=True):
@@ -205,6 +205,9 @@ class ConvCfg:
         self.state = state if state is not None else ConvState()
         self.track = track
         self.vkey = None  # set by the calling module each forward: (id(param), param._version)
+        # flat gradient arena hooks (cvpytorch_amd/arena.py): views to accumulate weight / BN gradients into
+        self.gw = self.gg = self.gbeta = None
+        self.arena, self.idx_w, self.idx_bn = None, None, ()
 
 
 def _colreduce_rows(M, Cc):
@@ -316,7 +319,11 @@ class ConvBnAct(torch.autograd.Function):
                        partial.data_ptr(), st)
                 dgamma = torch.empty((K,), dtype=torch.float32, device=dev)
                 dbeta = torch.empty((K,), dtype=torch.float32, device=dev)
-                L.call("cvhip_bn_bwd_finalize", partial.data_ptr(), rows, K, dgamma.data_ptr(), dbeta.data_ptr(), st)
+                direct_bn = cfg.gg is not None and cfg.gbeta is not None
+                L.call("cvhip_bn_bwd_finalize", partial.data_ptr(), rows, K, dgamma.data_ptr(), dbeta.data_ptr(),
+                       cfg.gg.data_ptr() if direct_bn else None, cfg.gbeta.data_ptr() if direct_bn else None, st)
+                if direct_bn:
+                    need_dg = need_dbeta = False  # already accumulated into the gradient arena
                 L.call("cvhip_bn_act_bwd_apply", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, dy.data_ptr(), Kp, M, K,
                        stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
                        dgamma.data_ptr(), dbeta.data_ptr(), cfg.act, cfg.act_param, st)
@@ -345,7 +352,9 @@ class ConvBnAct(torch.autograd.Function):
         if ctx.depthwise:
             desc = conv_desc(N, Cc, H, W, K, R, S, cfg.stride, cfg.pad, cfg.dil, cfg.groups, x_ld, dy_ld)
             wm = weight.detach().float().reshape(K, R, S).contiguous()
-            if need_dw:
+            if need_dw and cfg.gw is not None:
+                L.call("cvhip_dwconv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(), cfg.gw.data_ptr(), 1, st)
+            elif need_dw:
                 dwm = torch.empty((K, R, S), dtype=torch.float32, device=dev)
                 L.call("cvhip_dwconv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(), dwm.data_ptr(), 0, st)
                 dw = dwm.reshape(K, 1, R, S)
@@ -356,14 +365,17 @@ class ConvBnAct(torch.autograd.Function):
         else:
             if need_dw:
                 desc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, x_ld, dy_ld)
-                if Kp == K:  # logical OIHW, KRSC (channels_last) memory: a fresh non-view tensor autograd can adopt as .grad
+                acc = 0
+                if Kp == K and cfg.gw is not None and tuple(cfg.gw.shape) == (K, Cc, R, S):
+                    dw, dwp, acc = None, cfg.gw.data_ptr(), 1  # accumulate straight into the flat gradient arena (KRSC slot)
+                elif Kp == K:  # logical OIHW, KRSC (channels_last) memory: a fresh non-view tensor autograd can adopt as .grad
                     dw = torch.empty((K, Cc, R, S), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
                     dwp = dw.data_ptr()
                 else:
                     dwk = torch.empty((Kp, R, S, Cc), dtype=torch.float32, device=dev)
                     dw, dwp = dwk[:K].permute(0, 3, 1, 2), dwk.data_ptr()
                 _timed_call(_wgrad_name(Kp), (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(),
-                            dy.data_ptr(), dwp, 0, st)
+                            dy.data_ptr(), dwp, acc, st)
             if need_dx:
                 if ctx.w_dgrad is None:
                     raise L.CvhipError("dgrad weight image missing (input started requiring grad after forward)")
@@ -374,6 +386,12 @@ class ConvBnAct(torch.autograd.Function):
         if dw is not None and dw.dtype != weight.dtype:
             dw = dw.to(weight.dtype)
         dres = dz if ctx.has_res else None
+        if cfg.arena is not None:  # tell the bucketed all-reduce which arena slots are now complete
+            if need_dw and dw is None and cfg.idx_w is not None:
+                cfg.arena.mark_ready(cfg.idx_w)
+            if ctx.train_bn and cfg.gg is not None:
+                for i in cfg.idx_bn:
+                    cfg.arena.mark_ready(i)
         return dx, dw, dbias, (dgamma if need_dg else None), (dbeta if need_dbeta else None), None, None, dres, None
 
 
@@ -434,7 +452,7 @@ class BnAct(torch.autograd.Function):
                    stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), act, ap, partial.data_ptr(), st)
             dgamma = torch.empty((K,), dtype=torch.float32, device=dev)
             dbeta = torch.empty((K,), dtype=torch.float32, device=dev)
-            L.call("cvhip_bn_bwd_finalize", partial.data_ptr(), rows, K, dgamma.data_ptr(), dbeta.data_ptr(), st)
+            L.call("cvhip_bn_bwd_finalize", partial.data_ptr(), rows, K, dgamma.data_ptr(), dbeta.data_ptr(), None, None, st)
             L.call("cvhip_bn_act_bwd_apply", dz.data_ptr(), dz_ld, y.data_ptr(), y_ld, dy.data_ptr(), K, M, K,
                    stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), dgamma.data_ptr(),
                    dbeta.data_ptr(), act, ap, st)

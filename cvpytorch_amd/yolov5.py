@@ -221,7 +221,10 @@ class YOLOv5Loss(nn.Module):
             bs, na, ny, nx, no = pi.shape
             self_f = sel.float()
             n = self_f.sum()
-            ps = pi[b, a, gj, gi]  # (5, na, T, no) dense gather
+            cell = ((b * na + a) * ny + gj) * nx + gi  # flat (image, anchor, row, col) index of every candidate
+            # dense gather of all 5*na*T candidates; index_select's backward is an atomic index_add (the
+            # advanced-indexing form pi[b,a,gj,gi] sorts its indices first: 1.2 ms per level on MI355X)
+            ps = pi.reshape(-1, no).index_select(0, cell.reshape(-1)).view(5, na, -1, no)
             pxy = ps[..., :2].sigmoid() * 2. - 0.5
             pwh = (ps[..., 2:4].sigmoid() * 2) ** 2 * anch
             pbox = torch.cat((pxy, pwh), -1)
@@ -231,7 +234,6 @@ class YOLOv5Loss(nn.Module):
             # objectness target: scatter iou into (bs, na, ny, nx); last candidate (largest ordinal) wins duplicates
             score = iou.detach().clamp(0).to(pi.dtype)
             ncell = bs * na * ny * nx
-            cell = ((b * na + a) * ny + gj) * nx + gi
             ordinal = torch.arange(cell.numel(), device=dev).view_as(cell)
             # invalid candidates go to PRIVATE dump slots behind the grid (a single shared dump slot would
             # serialise ~16k atomic-max operations on one address: 5 ms per level on MI355X)

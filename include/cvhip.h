@@ -168,9 +168,11 @@ int cvhip_bn_act_bwd_partial(const void* dz_bf16, int32_t ld_dz, const void* y_b
                              int64_t M, int32_t C, const float* scale, const float* shift,
                              const float* mean, const float* invstd, int32_t act,
                              float act_param, float* partial, void* stream);
-/* backward finalize: dbeta = sum du, dgamma = sum du*xhat  (sums over partial rows) */
+/* backward finalize: dbeta = sum du, dgamma = sum du*xhat (sums over partial rows), consumed by
+ * cvhip_bn_act_bwd_apply; if acc_dgamma / acc_dbeta are non-NULL the same sums are also ADDED there
+ * (the parameter's slot in a flat gradient arena). */
 int cvhip_bn_bwd_finalize(const float* partial, int32_t rows, int32_t C, float* dgamma,
-                          float* dbeta, void* stream);
+                          float* dbeta, float* acc_dgamma, float* acc_dbeta, void* stream);
 /* backward stage 2: dy = gamma*invstd*(du - dbeta/M - xhat*dgamma/M)   (training BN)
  *   if mean==NULL (no BN / eval BN): dy = scale*du (scale may be NULL -> dy = du). */
 int cvhip_bn_act_bwd_apply(const void* dz_bf16, int32_t ld_dz, const void* y_bf16, int32_t ld_y,
