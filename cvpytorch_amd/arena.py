@@ -48,8 +48,8 @@ class FlatTrainState:
             raise L.CvhipError("FlatTrainState needs the model on the GPU (no CPU fallback)")
         offs, total = [], 0
         for p in self.params:
-            if not p.is_non_overlapping_and_dense():
-                raise L.CvhipError("parameter is not dense")
+            if not (p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))):
+                raise L.CvhipError("parameter is neither contiguous nor channels_last")
             offs.append(total)
             total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         self.offsets, self.total = offs, total
