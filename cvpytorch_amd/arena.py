@@ -71,6 +71,9 @@ class FlatTrainState:
         self.seg_lr = torch.tensor(self.base_lr, dtype=torch.float32, device=dev)
         self.seg_wd = torch.tensor([hyper[id(p)][1] for p in self.params], dtype=torch.float32, device=dev)
         self.steps = 0
+        self.lr_scale = 1.0
+        self.dyn = torch.tensor([0.0, 1.0], dtype=torch.float32, device=dev)  # {ema_decay, lr_scale}, read by the kernels
+        self._dyn_host = torch.zeros((256, 2), dtype=torch.float32).pin_memory()
         # floating-point buffers (BN running statistics) in their own arena
         self.bufs = [b for b in model.buffers() if b.dtype == torch.float32]
         self.buf = torch.zeros(sum(b.numel() for b in self.bufs), dtype=torch.float32, device=dev)
@@ -179,42 +182,103 @@ class FlatTrainState:
 
     # ---- optimizer ------------------------------------------------------------------------------------------
     def set_lr_scale(self, scale):
-        """lr = base_lr * scale for every parameter (warm-up / scheduler hook: lr_schedulers/__init__.py)."""
-        self.seg_lr.copy_(torch.tensor([b * scale for b in self.base_lr], dtype=torch.float32))
+        """lr = base_lr * scale for every parameter (warm-up / scheduler hook: lr_schedulers/__init__.py); takes
+        effect at the next step through device memory, so it also works under hipGraph replay."""
+        self.lr_scale = float(scale)
 
     def zero_grad(self):
         self.grad.zero_()
 
-    def step(self):
-        self.finish_allreduce()
+    def pre_step(self):
+        """Host-side bookkeeping of one optimizer step + upload of the dynamic scalars {ema_decay, lr_scale}
+        to device memory. Runs eagerly (outside any hipGraph) right before the step's kernels."""
         d = 0.0
-        ema_ptr = None
         if self.ema_param is not None:
             self.ema_updates += 1
             d = self.ema_decay * (1 - math.exp(-self.ema_updates / 2000))
-            ema_ptr = self.ema_param.data_ptr()
+        slot = self._dyn_host[self.steps % self._dyn_host.shape[0]]  # ring: the async H2D below may still be pending
+        slot[0], slot[1] = d, self.lr_scale
+        self.dyn.copy_(slot, non_blocking=True)
+
+    def step_kernels(self):
+        """The device work of one step (capturable): wait for the bucketed all-reduce, fused SGD+EMA, EMA of the
+        BN statistics, zero the gradient arena."""
+        self.finish_allreduce()
+        ema_ptr = self.ema_param.data_ptr() if self.ema_param is not None else None
         st = ops._stream()
         L.call("cvhip_sgd_nesterov_ema", self.param.data_ptr(), self.grad.data_ptr(), self.mom.data_ptr(), ema_ptr, self.total,
                self.seg_bounds.data_ptr(), self.seg_lr.data_ptr(), self.seg_wd.data_ptr(), len(self.params), self.momentum,
-               int(self.nesterov), int(self.steps == 0), float(d), 1.0 / self.world, st)
+               int(self.nesterov), 0, 0.0, 1.0 / self.world, self.dyn.data_ptr(), st)
         if self.ema_buf is not None and self.buf.numel():
-            L.call("cvhip_ema_update", self.ema_buf.data_ptr(), self.buf.data_ptr(), self.buf.numel(), float(d), st)
+            L.call("cvhip_ema_update", self.ema_buf.data_ptr(), self.buf.data_ptr(), self.buf.numel(), 0.0, self.dyn.data_ptr(), st)
+        self.zero_grad()
+
+    def post_step(self):
         self.steps += 1
         ops.bump_weights_epoch()  # parameters changed behind torch's version counters
-        self.zero_grad()
         self._reset_buckets()
+
+    def step(self):
+        self.pre_step()
+        self.step_kernels()
+        self.post_step()
 
 
 class FlatTrainStep:
-    """forward -> loss -> backward (grads land in the arena, buckets all-reduce as they fill) -> fused SGD+EMA."""
+    """forward -> loss -> backward (grads land in the arena, buckets all-reduce as they fill) -> fused SGD+EMA.
+
+    `capture(imgs, targets)` records the whole step (forward, loss, backward, optimizer) into ONE hipGraph over static
+    input buffers; afterwards `__call__` copies the batch into those buffers and replays the graph (the ~2000 kernel
+    launches of a YOLOv5-s step cost no host time). Everything underneath is capturable by construction: libcvhip never
+    allocates or synchronises, the loss has static shapes, and the per-step scalars live in device memory.
+    """
 
     def __init__(self, model, state, sync_buffers=False):
         self.model, self.state, self.sync_buffers = model, state, sync_buffers
+        self.graph = None
+        self.static_imgs = self.static_targets = self.static_losses = None
 
-    def __call__(self, imgs, targets):
-        if self.sync_buffers and self.state.world > 1 and self.state.buf.numel():
-            dist.broadcast(self.state.buf, 0, group=self.state.group)  # DDP broadcast_buffers: ONE collective
+    def _body(self, imgs, targets):
         losses = self.model(imgs, targets, "train")
         losses["loss"].backward()
-        self.state.step()
+        self.state.step_kernels()
+        return losses
+
+    def capture(self, imgs, targets, warmup=2):
+        if self.state.world > 1:
+            raise L.CvhipError("hipGraph capture of the multi-GPU step is not enabled (eager mode is used)")
+        if not torch.is_tensor(targets):
+            raise L.CvhipError("capture needs the fixed-shape (T,6) target tensor (yolov5.targets_to_tensor)")
+        self.static_imgs, self.static_targets = imgs.clone(), targets.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self.state.pre_step()
+                self._body(self.static_imgs, self.static_targets)
+                self.state.post_step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.state.pre_step()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.static_losses = self._body(self.static_imgs, self.static_targets)
+        self.state.post_step()
+        self.graph = g
+
+    def __call__(self, imgs, targets):
+        if self.graph is not None:
+            if imgs is not self.static_imgs:
+                self.static_imgs.copy_(imgs, non_blocking=True)
+            if targets is not self.static_targets:
+                self.static_targets.copy_(targets, non_blocking=True)
+            self.state.pre_step()
+            self.graph.replay()
+            self.state.post_step()
+            return self.static_losses
+        if self.sync_buffers and self.state.world > 1 and self.state.buf.numel():
+            dist.broadcast(self.state.buf, 0, group=self.state.group)  # DDP broadcast_buffers: ONE collective
+        self.state.pre_step()
+        losses = self._body(imgs, targets)
+        self.state.post_step()
         return losses

@@ -61,7 +61,9 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
   return __builtin_bit_cast(uint16_t, b);
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division sequence: the BN/act passes are
+// HBM-bound only if the per-element math stays this cheap (8 sigmoids per 16-byte vector)
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // activation forward / derivative (as function of the pre-activation u)
 __device__ __forceinline__ float act_fwd(float u, int act, float ap) {

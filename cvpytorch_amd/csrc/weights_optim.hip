@@ -60,7 +60,13 @@ __global__ __launch_bounds__(256) void sgd_ema_kernel(float* __restrict__ param,
                                                       float* __restrict__ mom, float* __restrict__ ema, int64_t n,
                                                       const int64_t* __restrict__ seg, const float* __restrict__ seg_lr,
                                                       const float* __restrict__ seg_wd, int nseg, float momentum,
-                                                      int nesterov, int first, float decay, float gscale) {
+                                                      int nesterov, int first, float decay, float gscale,
+                                                      const float* __restrict__ dyn) {
+  float lr_scale = 1.f;
+  if (dyn) {  // {ema_decay, lr_scale} read from device memory: values can change between hipGraph replays
+    decay = dyn[0];
+    lr_scale = dyn[1];
+  }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     // binary search the segment containing i (segments are sorted, disjoint, cover [0,n))
     int lo = 0, hi = nseg - 1;
@@ -69,7 +75,7 @@ __global__ __launch_bounds__(256) void sgd_ema_kernel(float* __restrict__ param,
       if (i >= seg[2 * mid + 1]) lo = mid + 1;
       else hi = mid;
     }
-    const float lr = seg_lr[lo], wd = seg_wd[lo];
+    const float lr = seg_lr[lo] * lr_scale, wd = seg_wd[lo];
     float pv = param[i];
     float d = grad[i] * gscale + wd * pv;
     float b = first ? d : momentum * mom[i] + d;
@@ -81,7 +87,9 @@ __global__ __launch_bounds__(256) void sgd_ema_kernel(float* __restrict__ param,
   }
 }
 
-__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ ema, const float* __restrict__ src, int64_t n, float decay) {
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ ema, const float* __restrict__ src, int64_t n, float decay,
+                                                  const float* __restrict__ dyn) {
+  if (dyn) decay = dyn[0];
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
     ema[i] = decay * ema[i] + (1.f - decay) * src[i];
 }
@@ -131,18 +139,18 @@ extern "C" {
 int cvhip_sgd_nesterov_ema(float* param, const float* grad, float* momentum_buf, float* ema, int64_t n,
                            const int64_t* seg_bounds, const float* seg_lr, const float* seg_wd, int32_t nseg,
                            float momentum, int32_t nesterov, int32_t first_step, float ema_decay, float grad_scale,
-                           void* stream) {
+                           const float* dyn_decay_lrscale, void* stream) {
   if (!param || !grad || !momentum_buf || n < 0 || !seg_bounds || !seg_lr || !seg_wd || nseg <= 0) return CVHIP_ERR_INVALID;
   if (n == 0) return CVHIP_OK;
   hipLaunchKernelGGL(sgd_ema_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, param, grad, momentum_buf, ema, n,
-                     seg_bounds, seg_lr, seg_wd, nseg, momentum, nesterov, first_step, ema_decay, grad_scale);
+                     seg_bounds, seg_lr, seg_wd, nseg, momentum, nesterov, first_step, ema_decay, grad_scale, dyn_decay_lrscale);
   return check_launch("sgd_ema_kernel");
 }
 
-int cvhip_ema_update(float* ema, const float* src, int64_t n, float decay, void* stream) {
+int cvhip_ema_update(float* ema, const float* src, int64_t n, float decay, const float* dyn_decay, void* stream) {
   if (!ema || !src || n < 0) return CVHIP_ERR_INVALID;
   if (n == 0) return CVHIP_OK;
-  hipLaunchKernelGGL(ema_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, ema, src, n, decay);
+  hipLaunchKernelGGL(ema_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, ema, src, n, decay, dyn_decay);
   return check_launch("ema_kernel");
 }
 

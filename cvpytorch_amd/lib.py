@@ -84,8 +84,8 @@ SIGNATURES = {
     "cvhip_nms_workspace_bytes": (_i64, [_i32]),
     "cvhip_nms_sorted": (_i32, [_p, _i32, _f32, _p, _p, _p, _p]),
     "cvhip_box_iou": (_i32, [_p, _i32, _p, _i32, _p, _p]),
-    "cvhip_sgd_nesterov_ema": (_i32, [_p, _p, _p, _p, _i64, _p, _p, _p, _i32, _f32, _i32, _i32, _f32, _f32, _p]),
-    "cvhip_ema_update": (_i32, [_p, _p, _i64, _f32, _p]),
+    "cvhip_sgd_nesterov_ema": (_i32, [_p, _p, _p, _p, _i64, _p, _p, _p, _i32, _f32, _i32, _i32, _f32, _f32, _p, _p]),
+    "cvhip_ema_update": (_i32, [_p, _p, _i64, _f32, _p, _p]),
     "cvhip_probe_mfma_16x16x32": (_i32, [_p, _p, _p, _p]),
     "cvhip_probe_ds_read_tr16": (_i32, [_p, _p, _p]),
 }

@@ -173,6 +173,7 @@ class YOLOv5Loss(nn.Module):
         self.balance = {3: [4.0, 1.0, 0.4]}.get(self.num_layers, [4.0, 1.0, 0.25, 0.06, .02])
         self.cp, self.cn = 1.0, 0.0
         self.gr = 1.0
+        self._gain_cache = {}
 
     def build_targets(self, shapes, targets):
         """Returns per level (b, a, gj, gi, tbox, anch, tcls, valid) with leading shape (5, na, T)."""
@@ -185,7 +186,11 @@ class YOLOv5Loss(nn.Module):
         for i in range(self.num_layers):
             anchors = self.anchors[i]
             ny, nx = shapes[i]
-            gain = torch.tensor([1, 1, nx, ny, nx, ny, 1], device=dev, dtype=torch.float32)
+            key = (ny, nx, str(dev))
+            gain = self._gain_cache.get(key)
+            if gain is None:  # built once per (grid, device): a host->device copy here would break hipGraph capture
+                gain = torch.tensor([1, 1, nx, ny, nx, ny, 1], device=dev, dtype=torch.float32)
+                self._gain_cache[key] = gain
             t = t7 * gain
             r = t[:, :, 4:6] / anchors[:, None]
             jm = (torch.max(r, 1. / r).max(2)[0] < self.hyp_anchor_t) & tvalid[None]  # (na, T)

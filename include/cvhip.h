@@ -283,9 +283,14 @@ int cvhip_box_iou(const float* a_xyxy, int32_t n, const float* b_xyxy, int32_t m
 int cvhip_sgd_nesterov_ema(float* param, const float* grad, float* momentum_buf, float* ema,
                            int64_t n, const int64_t* seg_bounds, const float* seg_lr,
                            const float* seg_wd, int32_t nseg, float momentum, int32_t nesterov,
-                           int32_t first_step, float ema_decay, float grad_scale, void* stream);
-/* ema[i] = d*ema[i] + (1-d)*src[i] over a flat fp32 range (buffers: BN running stats) */
-int cvhip_ema_update(float* ema, const float* src, int64_t n, float decay, void* stream);
+                           int32_t first_step, float ema_decay, float grad_scale,
+                           const float* dyn_decay_lrscale, void* stream);
+/* dyn_decay_lrscale: optional DEVICE float[2] = {ema_decay, lr_scale}; when non-NULL it overrides
+ * `ema_decay` and multiplies every segment lr, so the values can change between hipGraph replays. */
+/* ema[i] = d*ema[i] + (1-d)*src[i] over a flat fp32 range (buffers: BN running stats);
+ * dyn_decay: optional DEVICE float[1] overriding `decay`. */
+int cvhip_ema_update(float* ema, const float* src, int64_t n, float decay, const float* dyn_decay,
+                     void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Hardware probes used by the GPU test-suite to pin the MFMA / LDS-transpose lane layouts the

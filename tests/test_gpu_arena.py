@@ -62,3 +62,31 @@ def test_flat_state_matches_stock_optimizer_and_ema():
     with torch.no_grad():
         z, _ = state.ema_model.forward_features(imgs)
     assert torch.isfinite(z).all()
+
+
+def test_hipgraph_replay_matches_eager():
+    """Whole-step hipGraph (forward + loss + backward + fused optimizer) == the same steps run eagerly."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    base = yolov5.YOLOv5(80, "n", max_targets=64).to(dev).train()
+    a, b = copy.deepcopy(base), copy.deepcopy(base)
+    imgs, targets = synthetic_detection_batch(4, 96, seed=7, max_boxes=8, device=dev)
+    gts = yolov5.targets_to_tensor(targets, 64, dev)
+    sa, sb = FlatTrainState(a, use_ema=True), FlatTrainState(b, use_ema=True)
+    ea, eb = FlatTrainStep(a, sa), FlatTrainStep(b, sb)
+    eb.capture(imgs, gts, warmup=2)          # 2 eager warm-up steps + 1 captured (executed) step ...
+    for _ in range(3):
+        ea(imgs, gts)                        # ... == 3 eager steps
+    la = [float(ea(imgs, gts)["loss"]) for _ in range(3)]
+    lb = [float(eb(imgs, gts)["loss"]) for _ in range(3)]
+    torch.cuda.synchronize()
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= 5e-3 * abs(x), (la, lb)
+    assert sa.steps == sb.steps == 6 and sa.ema_updates == sb.ema_updates
+    assert rel(sb.param, sa.param) < 5e-3 and rel(sb.ema_param, sa.ema_param) < 1e-4 and rel(sb.buf, sa.buf) < 5e-3
+    # new batch contents flow through the static buffers
+    imgs2, targets2 = synthetic_detection_batch(4, 96, seed=8, max_boxes=8, device=dev)
+    gts2 = yolov5.targets_to_tensor(targets2, 64, dev)
+    l1 = float(eb(imgs2, gts2)["loss"])
+    l2 = float(ea(imgs2, gts2)["loss"])
+    assert abs(l1 - l2) <= 1e-2 * abs(l2), (l1, l2)
