@@ -195,7 +195,7 @@ class YOLOv5Loss(nn.Module):
             r = t[:, :, 4:6] / anchors[:, None]
             jm = (torch.max(r, 1. / r).max(2)[0] < self.hyp_anchor_t) & tvalid[None]  # (na, T)
             gxy = t[:, :, 2:4]
-            gxi = gain[[2, 3]] - gxy
+            gxi = gain[2:4] - gxy  # (a python-list index would upload an index tensor: not capturable)
             g = 0.5
             jk = ((gxy % 1. < g) & (gxy > 1.))  # (na,T,2): j (x), k (y)
             lm = ((gxi % 1. < g) & (gxi > 1.))
