@@ -24,6 +24,20 @@ int check_launch(const char* what) {
   return CVHIP_OK;
 }
 
+__global__ __launch_bounds__(256) void zero_fill_kernel(uint32_t* p, size_t n_words) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+
+int zero_fill(void* ptr, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return CVHIP_OK;
+  if ((((uintptr_t)ptr) & 3) || (bytes & 3)) return CVHIP_ERR_INVALID;
+  const size_t n = bytes / 4;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (uint32_t*)ptr, n);
+  return check_launch("zero_fill_kernel");
+}
+
 int validate_dense_desc(const cvhip_conv_desc* d) {
   if (!d) return CVHIP_ERR_INVALID;
   if (d->N <= 0 || d->C <= 0 || d->H <= 0 || d->W <= 0 || d->K <= 0 || d->R <= 0 || d->S <= 0) return CVHIP_ERR_INVALID;
@@ -262,11 +276,8 @@ int cvhip_conv2d_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, 
   if ((((uintptr_t)x) & 15) || (((uintptr_t)dy) & 15)) return CVHIP_ERR_INVALID;
   hipStream_t s = (hipStream_t)stream;
   if (!accumulate) {
-    hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->K * d->R * d->S * d->C, s);
-    if (e != hipSuccess) {
-      set_last_error("hipMemsetAsync(dw)", e);
-      return CVHIP_ERR_LAUNCH;
-    }
+    int zs = zero_fill(dw, sizeof(float) * (size_t)d->K * d->R * d->S * d->C, s);
+    if (zs) return zs;
   }
   return launch_wgrad(d, x, dy, dw, s);
 }

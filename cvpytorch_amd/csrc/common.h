@@ -16,6 +16,8 @@ namespace cvhip {
 
 void set_last_error(const char* what, hipError_t e);
 int check_launch(const char* what);
+// zero-fill by a kernel (not hipMemsetAsync: memset nodes proved unreliable under hipGraph replay on this stack)
+int zero_fill(void* ptr, size_t bytes, hipStream_t stream);
 
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

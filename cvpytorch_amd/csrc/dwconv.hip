@@ -268,11 +268,8 @@ int cvhip_dwconv2d_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy
   p.y_ld = d->y_ld;
   hipStream_t s = (hipStream_t)stream;
   if (!accumulate) {
-    hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)p.C * p.R * p.S, s);
-    if (e != hipSuccess) {
-      set_last_error("hipMemsetAsync(dw)", e);
-      return CVHIP_ERR_LAUNCH;
-    }
+    int zs = zero_fill(dw, sizeof(float) * (size_t)p.C * p.R * p.S, s);
+    if (zs) return zs;
   }
   const int64_t M = (int64_t)p.N * p.P * p.Q;
   int64_t blocks = cdiv64(M, 256);

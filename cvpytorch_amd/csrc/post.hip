@@ -144,14 +144,7 @@ int cvhip_nms_sorted(const float* boxes, int32_t n, float iou_thr, void* workspa
                      int32_t* keep_count, void* stream) {
   if (n < 0 || !keep_count || (n > 0 && (!boxes || !workspace || !keep_idx))) return CVHIP_ERR_INVALID;
   hipStream_t s = (hipStream_t)stream;
-  if (n == 0) {
-    hipError_t e = hipMemsetAsync(keep_count, 0, sizeof(int32_t), s);
-    if (e != hipSuccess) {
-      set_last_error("hipMemsetAsync", e);
-      return CVHIP_ERR_LAUNCH;
-    }
-    return CVHIP_OK;
-  }
+  if (n == 0) return zero_fill(keep_count, sizeof(int32_t), s);
   if ((((uintptr_t)boxes) & 15) != 0) return CVHIP_ERR_INVALID;
   const int nblk = (n + 63) / 64;
   if (nblk > 2048) return CVHIP_ERR_UNSUPPORTED;
