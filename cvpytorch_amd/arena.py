@@ -187,7 +187,7 @@ class FlatTrainState:
         self.lr_scale = float(scale)
 
     def zero_grad(self):
-        self.grad.zero_()
+        ops.zero_fill(self.grad)  # a kernel, not a memset node (hipGraph-safe)
 
     def pre_step(self):
         """Host-side bookkeeping of one optimizer step + upload of the dynamic scalars {ema_decay, lr_scale}
@@ -227,18 +227,34 @@ class FlatTrainState:
 class FlatTrainStep:
     """forward -> loss -> backward (grads land in the arena, buckets all-reduce as they fill) -> fused SGD+EMA.
 
-    `capture(imgs, targets)` records the whole step (forward, loss, backward, optimizer) into ONE hipGraph over static
-    input buffers; afterwards `__call__` copies the batch into those buffers and replays the graph (the ~2000 kernel
-    launches of a YOLOv5-s step cost no host time). Everything underneath is capturable by construction: libcvhip never
-    allocates or synchronises, the loss has static shapes, and the per-step scalars live in device memory.
+    `capture(imgs, targets)` records the step into TWO hipGraphs over static buffers:
+        G1 = model.forward_features(imgs)                       (backbone / neck / head: ~700 kernels)
+        -- eager: loss on the head outputs and its gradient w.r.t. them (small torch ops, runs while G1 executes) --
+        G2 = backward from the head outputs + fused optimizer   (~1200 kernels)
+    so the ~2000 launches of a YOLOv5-s step cost no host time. libcvhip never allocates, synchronises or issues
+    memset/memcpy calls, so both graphs contain kernel nodes only (hipMemset nodes proved unreliable under replay on
+    ROCm 7.2, and capturing the torch-op loss backward crashed the runtime — hence the eager island).
+
+    The model must provide `forward_features(imgs) -> (aux, [tensors])` and
+    `loss_from_features([tensors], targets) -> dict with 'loss'`.
     """
 
     def __init__(self, model, state, sync_buffers=False):
         self.model, self.state, self.sync_buffers = model, state, sync_buffers
-        self.graph = None
-        self.static_imgs = self.static_targets = self.static_losses = None
+        self.g1 = self.g2 = None
+        self.static_imgs = self.static_targets = None
+        self.feats = self.g_feats = None
 
-    def _body(self, imgs, targets):
+    @property
+    def graph(self):
+        return self.g1
+
+    @graph.setter
+    def graph(self, v):
+        if v is None:
+            self.g1 = self.g2 = None
+
+    def _eager(self, imgs, targets):
         losses = self.model(imgs, targets, "train")
         losses["loss"].backward()
         self.state.step_kernels()
@@ -248,37 +264,50 @@ class FlatTrainStep:
         if self.state.world > 1:
             raise L.CvhipError("hipGraph capture of the multi-GPU step is not enabled (eager mode is used)")
         if not torch.is_tensor(targets):
-            raise L.CvhipError("capture needs the fixed-shape (T,6) target tensor (yolov5.targets_to_tensor)")
+            raise L.CvhipError("capture needs the fixed-shape target tensor (e.g. yolov5.targets_to_tensor)")
+        m, st = self.model, self.state
         self.static_imgs, self.static_targets = imgs.clone(), targets.clone()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(warmup):
-                self.state.pre_step()
-                self._body(self.static_imgs, self.static_targets)
-                self.state.post_step()
+                st.pre_step()
+                self._eager(self.static_imgs, self.static_targets)
+                st.post_step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        self.state.pre_step()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self.static_losses = self._body(self.static_imgs, self.static_targets)
-        self.state.post_step()
-        self.graph = g
+        pool = torch.cuda.graph_pool_handle()
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1, pool=pool):
+            _, feats = m.forward_features(self.static_imgs)
+        self.feats = list(feats)
+        self.g_feats = [torch.zeros_like(f) for f in self.feats]
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, pool=pool):
+            torch.autograd.backward(self.feats, grad_tensors=self.g_feats)
+            st.step_kernels()
+        self.g1, self.g2 = g1, g2
 
     def __call__(self, imgs, targets):
-        if self.graph is not None:
+        st = self.state
+        if self.g1 is not None:
             if imgs is not self.static_imgs:
                 self.static_imgs.copy_(imgs, non_blocking=True)
             if targets is not self.static_targets:
                 self.static_targets.copy_(targets, non_blocking=True)
-            self.state.pre_step()
-            self.graph.replay()
-            self.state.post_step()
-            return self.static_losses
-        if self.sync_buffers and self.state.world > 1 and self.state.buf.numel():
-            dist.broadcast(self.state.buf, 0, group=self.state.group)  # DDP broadcast_buffers: ONE collective
-        self.state.pre_step()
-        losses = self._body(imgs, targets)
-        self.state.post_step()
+            st.pre_step()
+            self.g1.replay()
+            p = [f.detach().requires_grad_(True) for f in self.feats]
+            losses = self.model.loss_from_features(p, self.static_targets)
+            grads = torch.autograd.grad(losses["loss"], p)
+            for d, g in zip(self.g_feats, grads):
+                d.copy_(g)
+            self.g2.replay()
+            st.post_step()
+            return losses
+        if self.sync_buffers and st.world > 1 and st.buf.numel():
+            dist.broadcast(st.buf, 0, group=st.group)  # DDP broadcast_buffers: ONE collective
+        st.pre_step()
+        losses = self._eager(imgs, targets)
+        st.post_step()
         return losses

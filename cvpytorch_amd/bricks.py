@@ -160,8 +160,8 @@ class HipConv2d(nn.Conv2d):
         self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
 
     def _effective(self, x):
-        """Image inputs (fp32, C % 8 != 0) are relaid out to bf16 NHWC with zero-padded channels; the
-        weight is zero-padded to match (tiny; autograd slices the gradient back)."""
+        """Image inputs (fp32 NCHW, C % 8 != 0) are relaid out to bf16 NHWC with zero-padded channels by one
+        libcvhip kernel; the weight keeps its real shape (the packers pad it: cvhip_conv_desc.c_valid)."""
         w = self.weight
         if x.dim() == 4 and x.shape[1] == self.in_channels and self.in_channels % 8 != 0 and self.groups == 1:
             if x.requires_grad:
@@ -170,11 +170,7 @@ class HipConv2d(nn.Conv2d):
             if x.dtype == torch.float32 and ops.nhwc_ld(x) is None:
                 x = ops.images_to_nhwc(x, cpad=cp)
             else:
-                x = F.pad(x.to(ops.BF16), (0, 0, 0, 0, 0, cp - self.in_channels)).contiguous(memory_format=torch.channels_last)
-        if x.shape[1] != self.in_channels and self.groups == 1:
-            if x.shape[1] != (self.in_channels + 7) // 8 * 8:
-                raise L.CvhipError("HipConv2d: channel mismatch %d vs %d" % (x.shape[1], self.in_channels))
-            w = F.pad(w, (0, 0, 0, 0, 0, x.shape[1] - self.in_channels))
+                x = ops.images_to_nhwc(x.float(), cpad=cp)
         return x, w
 
     def make_cfg(self, act=L.ACT_NONE, act_param=0.0, bn=None):
@@ -188,7 +184,9 @@ class HipConv2d(nn.Conv2d):
         ar = getattr(self.weight, "_hip_arena", None)
         if ar is not None and torch.is_grad_enabled():
             cfg.arena = ar[0]
-            cfg.gw, cfg.idx_w = self.weight._hip_grad, ar[1]  # used only when the effective weight IS the parameter
+            cfg.gw, cfg.idx_w = self.weight._hip_grad, ar[1]
+            if self.bias is not None and getattr(self.bias, "_hip_arena", None) is not None:
+                cfg.gb, cfg.idx_b = self.bias._hip_grad, self.bias._hip_arena[1]
             if bn is not None and bn.weight is not None and bn.bias is not None and getattr(bn.weight, "_hip_arena", None) is not None:
                 cfg.gg, cfg.gbeta = bn.weight._hip_grad, bn.bias._hip_grad
                 cfg.idx_bn = (bn.weight._hip_arena[1], bn.bias._hip_arena[1])

@@ -28,6 +28,14 @@ __global__ __launch_bounds__(256) void zero_fill_kernel(uint32_t* p, size_t n_wo
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (size_t)gridDim.x * 256) p[i] = 0u;
 }
 
+__global__ __launch_bounds__(256) void unpad_add_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n, int C, int Cv) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t kt = i / Cv;
+    const int c = (int)(i - kt * Cv);
+    dst[i] += src[kt * C + c];
+  }
+}
+
 int zero_fill(void* ptr, size_t bytes, hipStream_t stream) {
   if (bytes == 0) return CVHIP_OK;
   if ((((uintptr_t)ptr) & 3) || (bytes & 3)) return CVHIP_ERR_INVALID;
@@ -44,6 +52,7 @@ int validate_dense_desc(const cvhip_conv_desc* d) {
   if (d->stride_h <= 0 || d->stride_w <= 0 || d->dil_h <= 0 || d->dil_w <= 0 || d->pad_h < 0 || d->pad_w < 0)
     return CVHIP_ERR_INVALID;
   if (d->x_ld < d->C || d->y_ld < d->K) return CVHIP_ERR_INVALID;
+  if (d->k_valid < 0 || d->k_valid > d->K || d->c_valid < 0 || d->c_valid > d->C) return CVHIP_ERR_INVALID;
   if (d->groups != 1) return CVHIP_ERR_UNSUPPORTED;
   // 16-byte channel vectors on the gathered operand: input channels and pitches multiple of 8
   if ((d->C & 7) || (d->x_ld & 7)) return CVHIP_ERR_UNSUPPORTED;
@@ -228,7 +237,7 @@ int cvhip_conv2d_prep_weights(const cvhip_conv_desc* d, const float* w_master, v
   int st = validate_dense_desc(d);
   if (st) return st;
   if (!w_master || (!w_fprop && !w_dgrad)) return CVHIP_ERR_INVALID;
-  if ((((uintptr_t)w_master) & 15) || (((uintptr_t)w_fprop) & 15) || (((uintptr_t)w_dgrad) & 15)) return CVHIP_ERR_INVALID;
+  if ((((uintptr_t)w_master) & 3) || (((uintptr_t)w_fprop) & 15) || (((uintptr_t)w_dgrad) & 15)) return CVHIP_ERR_INVALID;
   return pack_weights(d, w_master, w_fprop, w_dgrad, (hipStream_t)stream);
 }
 
@@ -245,6 +254,7 @@ int cvhip_conv2d_fprop(const cvhip_conv_desc* d, const void* x, const void* w, c
   p.w = (const bf16_t*)w;
   p.y = (bf16_t*)y;
   p.bias = bias;
+  p.bias_n = d->k_valid > 0 ? d->k_valid : d->K;
   p.stats = stats_partial;
   p.y_vec_ok = ((d->y_ld & 3) == 0) && ((((uintptr_t)y) & 7) == 0);
   return launch_igemm(p, (hipStream_t)stream);
@@ -280,6 +290,20 @@ int cvhip_conv2d_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, 
     if (zs) return zs;
   }
   return launch_wgrad(d, x, dy, dw, s);
+}
+
+int cvhip_zero_fill(void* ptr, int64_t bytes, void* stream) {
+  if (!ptr || bytes < 0) return CVHIP_ERR_INVALID;
+  return zero_fill(ptr, (size_t)bytes, (hipStream_t)stream);
+}
+
+int cvhip_f32_unpad_add(const float* src, float* dst, int32_t K_valid, int32_t T, int32_t C, int32_t C_valid, void* stream) {
+  if (!src || !dst || K_valid <= 0 || T <= 0 || C <= 0 || C_valid <= 0 || C_valid > C) return CVHIP_ERR_INVALID;
+  const int64_t n = (int64_t)K_valid * T * C_valid;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(unpad_add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, n, C, C_valid);
+  return check_launch("unpad_add_kernel");
 }
 
 int cvhip_probe_mfma_16x16x32(const void* a, const void* b, float* d, void* stream) {

@@ -197,10 +197,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
       if (n >= p.Nout) continue;
       float v0 = acc[a][b][0], v1 = acc[a][b][1], v2 = acc[a][b][2], v3 = acc[a][b][3];
       if (p.bias) {
-        v0 += p.bias[n];
-        if (n + 1 < p.Nout) v1 += p.bias[n + 1];
-        if (n + 2 < p.Nout) v2 += p.bias[n + 2];
-        if (n + 3 < p.Nout) v3 += p.bias[n + 3];
+        if (n < p.bias_n) v0 += p.bias[n];
+        if (n + 1 < p.bias_n) v1 += p.bias[n + 1];
+        if (n + 2 < p.bias_n) v2 += p.bias[n + 2];
+        if (n + 3 < p.bias_n) v3 += p.bias[n + 3];
       }
       if (p.y_vec_ok && n + 3 < p.Nout) {
         uint2 u;

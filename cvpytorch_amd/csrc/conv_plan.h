@@ -28,6 +28,7 @@ struct IgemmParams {
   const bf16_t* w;
   bf16_t* y;
   const float* bias;
+  int bias_n;  // number of valid bias entries (k_valid)
   float* stats;
   int NB, IH, IW, Cin, x_ld;
   int in_sh, in_sw;

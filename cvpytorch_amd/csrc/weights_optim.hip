@@ -8,11 +8,21 @@
 
 namespace cvhip {
 
-// w_fprop[k][r][s][c] = bf16(master[k][r][s][c])  — same element order, 8 elements per thread
+// w_fprop[k][r][s][c] = bf16(master[k][r][s][c]) with zero rows/columns beyond the master's real (Kv, Cv) extent.
+// Fast path (no padding): same element order, 8 elements per thread.
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
   const int64_t nv = n >> 3;
+  const bool al = (((uintptr_t)src) & 15) == 0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
-    const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+    float4 a, b;
+    if (al) {
+      a = reinterpret_cast<const float4*>(src)[2 * i];
+      b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+    } else {
+      const float* q = src + 8 * i;
+      a = make_float4(q[0], q[1], q[2], q[3]);
+      b = make_float4(q[4], q[5], q[6], q[7]);
+    }
     uint4 u;
     u.x = pack2(a.x, a.y);
     u.y = pack2(a.z, a.w);
@@ -20,13 +30,24 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
     u.w = pack2(b.z, b.w);
     reinterpret_cast<uint4*>(dst)[i] = u;
   }
-  // tail
   for (int64_t i = (nv << 3) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = (bf16_t)src[i];
+}
+
+__global__ __launch_bounds__(256) void pack_fprop_padded_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int K, int T, int C,
+                                                                int Kv, int Cv) {
+  const int64_t n = (int64_t)K * T * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int64_t kt = i / C;
+    const int t = (int)(kt % T);
+    const int k = (int)(kt / T);
+    dst[i] = (k < Kv && c < Cv) ? (bf16_t)src[((int64_t)k * T + t) * Cv + c] : (bf16_t)0.f;
+  }
 }
 
 struct DgradPack {
   int ncls;
-  int K, R, S, C;
+  int K, R, S, C, Kv, Cv;
   IgemmClass cls[kMaxClasses];
 };
 
@@ -45,7 +66,7 @@ __global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* __restrict
     const int c = (int)(ct / T);
     const int i = tap / cl.TS, j = tap - i * cl.TS;
     const int r = cl.r0 + i * cl.r_step, s = cl.s0 + j * cl.s_step;
-    dst[cl.w_off + idx] = (bf16_t)master[(((int64_t)k * p.R + r) * p.S + s) * p.C + c];
+    dst[cl.w_off + idx] = (k < p.Kv && c < p.Cv) ? (bf16_t)master[(((int64_t)k * p.R + r) * p.S + s) * p.Cv + c] : (bf16_t)0.f;
   }
 }
 
@@ -103,9 +124,15 @@ static inline int grid1d(int64_t n) {
 
 int pack_weights(const cvhip_conv_desc* d, const float* master, void* w_fprop, void* w_dgrad, hipStream_t stream) {
   const int64_t n = (int64_t)d->K * d->R * d->S * d->C;
+  const int Kv = d->k_valid > 0 ? d->k_valid : d->K, Cv = d->c_valid > 0 ? d->c_valid : d->C;
   if (w_fprop) {
-    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid1d(n / 8 + 1)), dim3(256), 0, stream, master, (bf16_t*)w_fprop, n);
-    int st = check_launch("cast_f32_bf16_kernel");
+    if (Kv == d->K && Cv == d->C) {
+      hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid1d(n / 8 + 1)), dim3(256), 0, stream, master, (bf16_t*)w_fprop, n);
+    } else {
+      hipLaunchKernelGGL(pack_fprop_padded_kernel, dim3(grid1d(n)), dim3(256), 0, stream, master, (bf16_t*)w_fprop, d->K, d->R * d->S,
+                         d->C, Kv, Cv);
+    }
+    int st = check_launch("pack_fprop_kernel");
     if (st) return st;
   }
   if (w_dgrad) {
@@ -118,6 +145,8 @@ int pack_weights(const cvhip_conv_desc* d, const float* master, void* w_fprop, v
     p.R = d->R;
     p.S = d->S;
     p.C = d->C;
+    p.Kv = Kv;
+    p.Cv = Cv;
     int64_t maxe = 1;
     for (int i = 0; i < ncls; ++i) {
       p.cls[i] = ip.cls[i];

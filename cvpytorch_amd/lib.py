@@ -30,7 +30,7 @@ class ConvDesc(C.Structure):
     """cvhip_conv_desc (include/cvhip.h)."""
     _fields_ = [(n, C.c_int32) for n in (
         "N", "C", "H", "W", "K", "R", "S", "stride_h", "stride_w", "pad_h", "pad_w", "dil_h", "dil_w",
-        "groups", "x_ld", "y_ld", "reserved0", "reserved1")]
+        "groups", "x_ld", "y_ld", "k_valid", "c_valid")]
 
     def key(self):
         return tuple(getattr(self, n) for n, _ in self._fields_)
@@ -68,6 +68,8 @@ SIGNATURES = {
     "cvhip_maxpool2d_bwd": (_i32, [_p, _i32, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "cvhip_upsample2x_cat_fwd": (_i32, [_p, _i32, _i32, _p, _i32, _i32, _p, _i32, _i32, _i32, _i32, _p]),
     "cvhip_upsample2x_bwd": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    "cvhip_zero_fill": (_i32, [_p, _i64, _p]),
+    "cvhip_f32_unpad_add": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _p]),
     "cvhip_copy2d": (_i32, [_p, _i32, _p, _i32, _i64, _i32, _p]),
     "cvhip_add2d": (_i32, [_p, _i32, _p, _i32, _p, _i32, _i64, _i32, _p]),
     "cvhip_resize_bilinear_fwd": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),

@@ -131,11 +131,12 @@ def as_nhwc(t):
 _desc_cache = {}
 
 
-def conv_desc(N, Cc, H, W, K, R, S, stride, pad, dil, groups, x_ld, y_ld):
-    key = (N, Cc, H, W, K, R, S, stride, pad, dil, groups, x_ld, y_ld)
+def conv_desc(N, Cc, H, W, K, R, S, stride, pad, dil, groups, x_ld, y_ld, k_valid=0, c_valid=0):
+    key = (N, Cc, H, W, K, R, S, stride, pad, dil, groups, x_ld, y_ld, k_valid, c_valid)
     d = _desc_cache.get(key)
     if d is None:
-        d = L.ConvDesc(N, Cc, H, W, K, R, S, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], groups, x_ld, y_ld, 0, 0)
+        d = L.ConvDesc(N, Cc, H, W, K, R, S, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], groups, x_ld, y_ld,
+                       k_valid, c_valid)
         _desc_cache[key] = d
     return d
 
@@ -150,6 +151,22 @@ def _round8(x):
     return (x + 7) // 8 * 8
 
 
+def zero_fill(t):
+    """Zero a dense tensor with a libcvhip kernel (no hipMemset: see include/cvhip.h cvhip_zero_fill)."""
+    L.call("cvhip_zero_fill", t.data_ptr(), t.numel() * t.element_size(), _stream())
+    return t
+
+
+def _krsc_master(weight):
+    """fp32 master weight in KRSC physical order. HipConv2d keeps its parameter that way (OIHW shape,
+    channels_last strides) so this is normally a no-op view; other layouts cost one relayout kernel."""
+    w = weight.detach()
+    if w.dtype != torch.float32:
+        w = w.float()
+    wk = w.permute(0, 2, 3, 1)
+    return wk if wk.is_contiguous() else wk.contiguous()
+
+
 class ConvState:
     """Per-layer cache of the bf16 operand images derived from the fp32 master weight."""
 
@@ -157,44 +174,34 @@ class ConvState:
         self.key = None
         self.w_fprop = None
         self.w_dgrad = None
-        self.w_dw = None
 
-    def prepare(self, weight, desc_for_pack, need_dgrad, vkey):
-        """`vkey` identifies the VALUE of the master weight (parameter version + optimizer epoch): the
-        effective weight handed in may be a per-call temporary (channel-padded), so its own
-        data_ptr/_version cannot be trusted."""
-        key = (vkey, _weights_epoch, tuple(weight.shape))
+    def prepare(self, weight, pdesc, need_dgrad, vkey):
+        """`vkey` identifies the VALUE of the master weight (parameter identity/version; the optimizer epoch is
+        added here because the fused optimizer updates parameters behind torch's version counters). Channel
+        padding (pdesc.k_valid / c_valid) is applied by the packer kernels: no torch ops are involved."""
+        key = (vkey, _weights_epoch, pdesc.key())
         if self.key == key and self.w_fprop is not None and (self.w_dgrad is not None or not need_dgrad):
             return
-        K, Cc, R, S = weight.shape
         dev = weight.device
-        Kp = _round8(K)
-        # master in KRSC physical order (OIHW tensor, channels_last memory format)
-        w = weight.detach()
-        if w.dtype != torch.float32:
-            w = w.float()
-        wk = w.permute(0, 2, 3, 1)
-        if not wk.is_contiguous():
-            wk = wk.contiguous()
-        if Kp != K:
-            wk = torch.cat([wk, wk.new_zeros((Kp - K, R, S, Cc))], 0)
+        master = _krsc_master(weight)
         lib = L.load()
-        self.w_fprop = torch.empty((Kp, R, S, Cc), dtype=BF16, device=dev)
+        self.w_fprop = torch.empty((pdesc.K, pdesc.R, pdesc.S, pdesc.C), dtype=BF16, device=dev)
         wd = None
         if need_dgrad:
-            n = lib.cvhip_conv2d_dgrad_weight_elems(C.byref(desc_for_pack))
+            n = lib.cvhip_conv2d_dgrad_weight_elems(C.byref(pdesc))
             if n < 0:
                 L.check(int(n), "cvhip_conv2d_dgrad_weight_elems")
             wd = torch.empty((max(int(n), 8),), dtype=BF16, device=dev)
-        L.call("cvhip_conv2d_prep_weights", C.byref(desc_for_pack), wk.data_ptr(), self.w_fprop.data_ptr(), _ptr(wd), _stream())
+        L.call("cvhip_conv2d_prep_weights", C.byref(pdesc), master.data_ptr(), self.w_fprop.data_ptr(), _ptr(wd), _stream())
+        self._master_ref = master  # keep a relayout copy (if any) alive until the kernels have run
         self.w_dgrad = wd
         self.key = key
 
 
 class ConvCfg:
-    """Static configuration of one conv(+BN+act) layer (python-side, hashable pieces only)."""
+    """Static configuration of one conv(+BN+act) layer (python-side)."""
     __slots__ = ("stride", "pad", "dil", "groups", "act", "act_param", "has_bn", "bn_training", "momentum", "eps",
-                 "state", "track", "vkey", "gw", "gg", "gbeta", "arena", "idx_w", "idx_bn")
+                 "state", "track", "vkey", "gw", "gb", "gg", "gbeta", "arena", "idx_w", "idx_b", "idx_bn")
 
     def __init__(self, stride, pad, dil, groups=1, act=L.ACT_NONE, act_param=0.0, has_bn=False, bn_training=True,
                  momentum=0.1, eps=1e-5, state=None, track=True):
@@ -205,9 +212,9 @@ class ConvCfg:
         self.state = state if state is not None else ConvState()
         self.track = track
         self.vkey = None  # set by the calling module each forward: (id(param), param._version)
-        # flat gradient arena hooks (cvpytorch_amd/arena.py): views to accumulate weight / BN gradients into
-        self.gw = self.gg = self.gbeta = None
-        self.arena, self.idx_w, self.idx_bn = None, None, ()
+        # flat gradient arena hooks (cvpytorch_amd/arena.py): views to accumulate weight / bias / BN gradients into
+        self.gw = self.gb = self.gg = self.gbeta = None
+        self.arena, self.idx_w, self.idx_b, self.idx_bn = None, None, None, ()
 
 
 def _colreduce_rows(M, Cc):
@@ -215,7 +222,11 @@ def _colreduce_rows(M, Cc):
 
 
 class ConvBnAct(torch.autograd.Function):
-    """z = act(bn(conv(x, W) + b)) (+ residual)   — any of bn / act / bias / residual optional."""
+    """z = act(bn(conv(x, W) + b)) (+ residual)   — any of bn / act / bias / residual optional.
+
+    Channel counts that are not multiples of 8 are handled by padding INSIDE the engine: x may arrive with its
+    channels zero-padded to 8 (image stem), K is padded to 8 internally (255-channel detect head); the fp32
+    master weight / bias / their gradients keep the layer's real shapes."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, residual, cfg):
@@ -227,28 +238,36 @@ class ConvBnAct(torch.autograd.Function):
         depthwise = cfg.groups != 1
         if depthwise and not (cfg.groups == Cc == K and Cg == 1):
             raise L.CvhipError("grouped conv other than depthwise is not supported by the HIP engine")
+        if not depthwise and Cc != Cg and Cc != _round8(Cg):
+            raise L.CvhipError("conv input has %d channels, weight expects %d" % (Cc, Cg))
         P, Q = conv_out_hw(H, W, R, S, cfg.stride, cfg.pad, cfg.dil)
         M = N * P * Q
         Kp = _round8(K)
+        kv = K if Kp != K else 0
+        cv = Cg if (not depthwise and Cg != Cc) else 0
         need_dx = ctx.needs_input_grad[0]
         y = empty_nhwc(N, K, P, Q, dev, ld=Kp)
-        desc = conv_desc(N, Cc, H, W, Kp if not depthwise else K, R, S, cfg.stride, cfg.pad, cfg.dil, cfg.groups, x_ld, Kp)
         st = _stream()
         train_bn = cfg.has_bn and cfg.bn_training
         if cfg.has_bn and bias is not None:
             raise L.CvhipError("conv bias followed by BatchNorm is not supported (ConvModule never builds it)")
         stats = None
         partial = None
+        rows = 0
         epilogue_stats = train_bn and not depthwise and Kp == K  # BN sums straight from the MFMA accumulators
-        b = bias.detach().float() if bias is not None else None
-        if b is not None and Kp != K and not depthwise:
-            b = torch.cat([b, b.new_zeros(Kp - K)])  # the kernel reads bias for all Kp (padded) output channels
+        b = bias.detach() if bias is not None else None
+        if b is not None and b.dtype != torch.float32:
+            b = b.float()
         if depthwise:
-            wm = weight.detach().float().reshape(K, R, S).contiguous()
+            desc = conv_desc(N, Cc, H, W, K, R, S, cfg.stride, cfg.pad, cfg.dil, cfg.groups, x_ld, Kp)
+            wm = weight.detach()
+            wm = (wm if wm.dtype == torch.float32 else wm.float()).reshape(K, R, S)
+            wm = wm if wm.is_contiguous() else wm.contiguous()
             L.call("cvhip_dwconv2d_fprop", C.byref(desc), x.data_ptr(), wm.data_ptr(), _ptr(b), y.data_ptr(), st)
         else:
+            desc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, x_ld, Kp, kv, cv)
             # pack descriptor: contiguous pitches (the packed images do not depend on activation pitches)
-            pdesc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, _round8(Cc), Kp)
+            pdesc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, Cc, Kp, kv, cv)
             cfg.state.prepare(weight, pdesc, need_dx, cfg.vkey)
             if epilogue_stats:
                 rows = lib.cvhip_conv2d_fprop_stats_rows(C.byref(desc))
@@ -263,16 +282,16 @@ class ConvBnAct(torch.autograd.Function):
                 partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
                 L.call("cvhip_bn_stats_partial", y.data_ptr(), M, K, Kp, partial.data_ptr(), st)
             stats = torch.empty((4, K), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
-            g = gamma.detach().float() if gamma is not None else None
-            bt = beta.detach().float() if beta is not None else None
+            g = gamma.detach() if gamma is not None else None
+            bt = beta.detach() if beta is not None else None
             rm = running_mean if cfg.track else None
             rv = running_var if cfg.track else None
             L.call("cvhip_bn_finalize", partial.data_ptr(), rows, K, M, _ptr(g), _ptr(bt), _ptr(rm), _ptr(rv),
                    cfg.momentum, cfg.eps, stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), st)
         elif cfg.has_bn:
             stats = torch.empty((4, K), dtype=torch.float32, device=dev)
-            L.call("cvhip_bn_eval_scale_shift", K, _ptr(gamma.detach().float() if gamma is not None else None),
-                   _ptr(beta.detach().float() if beta is not None else None), running_mean.data_ptr(), running_var.data_ptr(),
+            L.call("cvhip_bn_eval_scale_shift", K, _ptr(gamma.detach() if gamma is not None else None),
+                   _ptr(beta.detach() if beta is not None else None), running_mean.data_ptr(), running_var.data_ptr(),
                    cfg.eps, stats[2].data_ptr(), stats[3].data_ptr(), st)
         res_ld = 0
         if residual is not None:
@@ -285,7 +304,7 @@ class ConvBnAct(torch.autograd.Function):
         else:
             z = y
         ctx.cfg = cfg
-        ctx.geom = (N, Cc, H, W, K, R, S, P, Q, Kp, x_ld)
+        ctx.geom = (N, Cc, H, W, K, R, S, P, Q, Kp, x_ld, Cg)
         ctx.train_bn = train_bn
         ctx.depthwise = depthwise
         ctx.has_bias = bias is not None
@@ -298,17 +317,20 @@ class ConvBnAct(torch.autograd.Function):
     def backward(ctx, dz):
         x, y, stats, weight = ctx.saved_tensors
         cfg = ctx.cfg
-        N, Cc, H, W, K, R, S, P, Q, Kp, x_ld = ctx.geom
+        N, Cc, H, W, K, R, S, P, Q, Kp, x_ld, Cg = ctx.geom
         dev = x.device
         M = N * P * Q
         st = _stream()
         dz, dz_ld = as_nhwc(dz)
         need_dx, need_dw, need_db, need_dg, need_dbeta = (ctx.needs_input_grad[i] for i in range(5))
         dgamma = dbeta = dbias = None
+        kv = K if Kp != K else 0
+        cv = Cg if (not ctx.depthwise and Cg != Cc) else 0
         pointwise = cfg.has_bn or cfg.act != L.ACT_NONE
+        arena = cfg.arena
         if pointwise:
             if Kp != K:  # pad channels must read as zero in dgrad/wgrad
-                dy = torch.zeros((N, P, Q, Kp), dtype=BF16, device=dev).permute(0, 3, 1, 2)[:, :K]
+                dy = zero_fill(torch.empty((N, P, Q, Kp), dtype=BF16, device=dev)).permute(0, 3, 1, 2)[:, :K]
             else:
                 dy = empty_nhwc(N, K, P, Q, dev)
             if ctx.train_bn:
@@ -319,11 +341,13 @@ class ConvBnAct(torch.autograd.Function):
                        partial.data_ptr(), st)
                 dgamma = torch.empty((K,), dtype=torch.float32, device=dev)
                 dbeta = torch.empty((K,), dtype=torch.float32, device=dev)
-                direct_bn = cfg.gg is not None and cfg.gbeta is not None
+                direct_bn = arena is not None and cfg.gg is not None and cfg.gbeta is not None
                 L.call("cvhip_bn_bwd_finalize", partial.data_ptr(), rows, K, dgamma.data_ptr(), dbeta.data_ptr(),
                        cfg.gg.data_ptr() if direct_bn else None, cfg.gbeta.data_ptr() if direct_bn else None, st)
                 if direct_bn:
                     need_dg = need_dbeta = False  # already accumulated into the gradient arena
+                    for i in cfg.idx_bn:
+                        arena.mark_ready(i)
                 L.call("cvhip_bn_act_bwd_apply", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, dy.data_ptr(), Kp, M, K,
                        stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
                        dgamma.data_ptr(), dbeta.data_ptr(), cfg.act, cfg.act_param, st)
@@ -337,61 +361,76 @@ class ConvBnAct(torch.autograd.Function):
             dy, dy_ld = dz, dz_ld
             if dy_ld % 8 != 0 or (Kp != K and dy_ld < Kp):
                 # repack into a 16-byte-vectorisable pitch with zeroed pad channels
-                buf = torch.zeros((N, P, Q, Kp), dtype=BF16, device=dev)
+                buf = zero_fill(torch.empty((N, P, Q, Kp), dtype=BF16, device=dev))
                 L.call("cvhip_copy2d", dy.data_ptr(), dy_ld, buf.data_ptr(), Kp, M, K, st)
                 dy, dy_ld = buf.permute(0, 3, 1, 2)[:, :K], Kp
         if ctx.has_bias and need_db and not ctx.train_bn:
             rows = _colreduce_rows(M, K)
             partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
             L.call("cvhip_colsum_partial", dy.data_ptr(), M, K, dy_ld, partial.data_ptr(), st)
-            dbias = torch.empty((K,), dtype=torch.float32, device=dev)
-            L.call("cvhip_colsum_finalize", partial.data_ptr(), rows, K, dbias.data_ptr(), 0, st)
+            if arena is not None and cfg.gb is not None:
+                L.call("cvhip_colsum_finalize", partial.data_ptr(), rows, K, cfg.gb.data_ptr(), 1, st)
+                arena.mark_ready(cfg.idx_b)
+            else:
+                dbias = torch.empty((K,), dtype=torch.float32, device=dev)
+                L.call("cvhip_colsum_finalize", partial.data_ptr(), rows, K, dbias.data_ptr(), 0, st)
         elif ctx.has_bias and need_db:
-            dbias = torch.zeros((K,), dtype=torch.float32, device=dev)  # bias before train-mode BN has zero gradient
+            dbias = zero_fill(torch.empty((K,), dtype=torch.float32, device=dev))  # bias before train-mode BN: zero gradient
         dx = dw = None
+        direct_w = arena is not None and cfg.gw is not None and tuple(cfg.gw.shape) == tuple(weight.shape)
         if ctx.depthwise:
             desc = conv_desc(N, Cc, H, W, K, R, S, cfg.stride, cfg.pad, cfg.dil, cfg.groups, x_ld, dy_ld)
-            wm = weight.detach().float().reshape(K, R, S).contiguous()
-            if need_dw and cfg.gw is not None:
+            if need_dw and direct_w:
                 L.call("cvhip_dwconv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(), cfg.gw.data_ptr(), 1, st)
+                arena.mark_ready(cfg.idx_w)
             elif need_dw:
                 dwm = torch.empty((K, R, S), dtype=torch.float32, device=dev)
                 L.call("cvhip_dwconv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(), dwm.data_ptr(), 0, st)
                 dw = dwm.reshape(K, 1, R, S)
             if need_dx:
+                wm = weight.detach()
+                wm = (wm if wm.dtype == torch.float32 else wm.float()).reshape(K, R, S)
+                wm = wm if wm.is_contiguous() else wm.contiguous()
                 dx = empty_nhwc(N, Cc, H, W, dev)
                 ddesc = conv_desc(N, Cc, H, W, K, R, S, cfg.stride, cfg.pad, cfg.dil, cfg.groups, Cc, dy_ld)
                 L.call("cvhip_dwconv2d_dgrad", C.byref(ddesc), dy.data_ptr(), wm.data_ptr(), dx.data_ptr(), st)
         else:
             if need_dw:
-                desc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, x_ld, dy_ld)
-                acc = 0
-                if Kp == K and cfg.gw is not None and tuple(cfg.gw.shape) == (K, Cc, R, S):
-                    dw, dwp, acc = None, cfg.gw.data_ptr(), 1  # accumulate straight into the flat gradient arena (KRSC slot)
-                elif Kp == K:  # logical OIHW, KRSC (channels_last) memory: a fresh non-view tensor autograd can adopt as .grad
+                desc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, x_ld, dy_ld, kv, cv)
+                padded = (Kp != K) or (Cg != Cc)
+                geom = (N, Cc, H, W, K, R, S, P, Q)
+                if not padded and direct_w:
+                    # accumulate straight into the parameter's KRSC slot of the flat gradient arena
+                    _timed_call(_wgrad_name(Kp), geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(),
+                                cfg.gw.data_ptr(), 1, st)
+                elif not padded:
+                    # logical OIHW, KRSC (channels_last) memory: a fresh non-view tensor autograd can adopt as .grad
                     dw = torch.empty((K, Cc, R, S), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
-                    dwp = dw.data_ptr()
+                    _timed_call(_wgrad_name(Kp), geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(),
+                                dw.data_ptr(), 0, st)
                 else:
-                    dwk = torch.empty((Kp, R, S, Cc), dtype=torch.float32, device=dev)
-                    dw, dwp = dwk[:K].permute(0, 3, 1, 2), dwk.data_ptr()
-                _timed_call(_wgrad_name(Kp), (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(),
-                            dy.data_ptr(), dwp, acc, st)
+                    # padded problem: wgrad into a [Kp][R][S][Cc] scratch, then fold the valid block into the real gradient
+                    tmp = torch.empty((Kp, R, S, Cc), dtype=torch.float32, device=dev)
+                    _timed_call(_wgrad_name(Kp), geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(),
+                                tmp.data_ptr(), 0, st)
+                    if direct_w:
+                        dst = cfg.gw
+                    else:
+                        dw = zero_fill(torch.empty((K, Cg, R, S), dtype=torch.float32, device=dev, memory_format=torch.channels_last))
+                        dst = dw
+                    L.call("cvhip_f32_unpad_add", tmp.data_ptr(), dst.data_ptr(), K, R * S, Cc, Cg, st)
+                if direct_w:
+                    arena.mark_ready(cfg.idx_w)
             if need_dx:
                 if ctx.w_dgrad is None:
                     raise L.CvhipError("dgrad weight image missing (input started requiring grad after forward)")
                 dx = empty_nhwc(N, Cc, H, W, dev)
-                ddesc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, Cc, dy_ld)
+                ddesc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, Cc, dy_ld, kv, cv)
                 _timed_call(_igemm_name(Cc), (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv2d_dgrad", C.byref(ddesc), dy.data_ptr(),
                             ctx.w_dgrad.data_ptr(), dx.data_ptr(), st)
         if dw is not None and dw.dtype != weight.dtype:
             dw = dw.to(weight.dtype)
         dres = dz if ctx.has_res else None
-        if cfg.arena is not None:  # tell the bucketed all-reduce which arena slots are now complete
-            if need_dw and dw is None and cfg.idx_w is not None:
-                cfg.arena.mark_ready(cfg.idx_w)
-            if ctx.train_bn and cfg.gg is not None:
-                for i in cfg.idx_bn:
-                    cfg.arena.mark_ready(i)
         return dx, dw, dbias, (dgamma if need_dg else None), (dbeta if need_dbeta else None), None, None, dres, None
 
 
@@ -658,7 +697,9 @@ class NhwcToNchwF32(torch.autograd.Function):
         N, Cc, H, W = ctx.meta
         dy = dy.float().contiguous()
         Cp = _round8(Cc)
-        buf = torch.zeros((N, H, W, Cp), dtype=BF16, device=dy.device) if Cp != Cc else torch.empty((N, H, W, Cp), dtype=BF16, device=dy.device)
+        buf = torch.empty((N, H, W, Cp), dtype=BF16, device=dy.device)
+        if Cp != Cc:
+            zero_fill(buf)
         L.call("cvhip_nchw_f32_to_nhwc_bf16_ld", dy.data_ptr(), buf.data_ptr(), Cp, N, Cc, H, W, _stream())
         return buf.permute(0, 3, 1, 2)[:, :Cc]
 

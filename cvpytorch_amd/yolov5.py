@@ -356,14 +356,18 @@ class YOLOv5(nn.Module):
     def forward_features(self, imgs):
         return self.detect(self.neck(self.backbone(imgs)))
 
+    def loss_from_features(self, train_out, gts):
+        losses = {}
+        losses["loss"], st = self.loss(train_out, gts)
+        losses["box_loss"], losses["obj_loss"], losses["cls_loss"] = st[0], st[1], st[2]
+        return losses
+
     def forward(self, imgs, targets=None, mode="infer", **kwargs):
         if mode == "infer":
             return
         gts = targets if torch.is_tensor(targets) else targets_to_tensor(targets, self.max_targets, imgs.device)
-        losses = {}
         out, train_out = self.forward_features(imgs)
-        losses["loss"], st = self.loss(train_out, gts)
-        losses["box_loss"], losses["obj_loss"], losses["cls_loss"] = st[0], st[1], st[2]
+        losses = self.loss_from_features(train_out, gts)
         if mode == "val":
             outputs = []
             if out is not None:

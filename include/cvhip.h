@@ -66,7 +66,11 @@ typedef struct cvhip_conv_desc {
   int32_t groups;         /* 1 (dense, MFMA implicit GEMM) or C==K (depthwise)             */
   int32_t x_ld;           /* elements between consecutive input pixels  (>= C)             */
   int32_t y_ld;           /* elements between consecutive output pixels (>= K)             */
-  int32_t reserved0, reserved1;
+  /* Channel padding: the engine works on C and K that are multiples of 8 (16-byte vectors). When the
+   * layer's real channel counts are smaller (3-channel image stem, 255-channel detect head) the tensors are
+   * padded and these fields give the REAL counts of the fp32 master weight [k_valid][R][S][c_valid] and of
+   * `bias` (k_valid entries); 0 means "same as K / C". Padded rows/columns of the operand images are zero. */
+  int32_t k_valid, c_valid;
 } cvhip_conv_desc;
 
 int cvhip_version(void);
@@ -208,6 +212,14 @@ int cvhip_upsample2x_cat_fwd(const void* a_bf16, int32_t ld_a, int32_t Ca, const
 /* da = 2x2 sum-pool of dout[:, :Ca]  (db is the channel slice dout[:, Ca:], a view) */
 int cvhip_upsample2x_bwd(const void* dout_bf16, int32_t ld_dout, void* da_bf16, int32_t ld_da,
                          int32_t Ca, int32_t N, int32_t Ha, int32_t Wa, void* stream);
+
+/* zero-fill by a kernel. (hipMemsetAsync nodes proved unreliable under hipGraph replay on ROCm 7.2; the
+ * library never issues memset/memcpy calls, so a captured step contains kernel nodes only.) */
+int cvhip_zero_fill(void* ptr, int64_t bytes, void* stream);
+/* dst[k][t][c] += src[k][t][c] for k < K_valid, c < C_valid; src is [K][T][C] fp32 (padded wgrad result),
+ * dst is [K_valid][T][C_valid] fp32 (the parameter's gradient). */
+int cvhip_f32_unpad_add(const float* src, float* dst, int32_t K_valid, int32_t T, int32_t C,
+                        int32_t C_valid, void* stream);
 
 /* strided 2-D copy dst[m][0:C] = src[m][0:C] (channel concat / slice materialisation) */
 int cvhip_copy2d(const void* src_bf16, int32_t ld_src, void* dst_bf16, int32_t ld_dst, int64_t M,

@@ -110,8 +110,8 @@ def _prep(case, w, need_dgrad=True):
     N, Cc, H, W, K, R, S, s, p, d = case
     Kp = (K + 7) // 8 * 8
     st = ops.ConvState()
-    pdesc = ops.conv_desc(N, Cc, H, W, Kp, R, S, (s, s), (p, p), (d, d), 1, Cc, Kp)
-    st.prepare(w.to(dev()), pdesc, need_dgrad, ("test", id(w)))
+    pdesc = ops.conv_desc(N, Cc, H, W, Kp, R, S, (s, s), (p, p), (d, d), 1, Cc, Kp, K if Kp != K else 0, 0)
+    st.prepare(w.to(dev()).contiguous(memory_format=torch.channels_last), pdesc, need_dgrad, ("test", id(w)))
     return st, Kp
 
 
@@ -125,8 +125,8 @@ def test_conv_fprop(case):
     xd = to_nhwc_dev(x)
     P, Q = ref.shape[2:]
     y = ops.empty_nhwc(N, K, P, Q, dev(), ld=Kp)
-    desc = ops.conv_desc(N, Cc, H, W, Kp, R, S, (s, s), (p, p), (d, d), 1, Cc, Kp)
-    b = torch.cat([bias, torch.zeros(Kp - K)]).to(dev())
+    desc = ops.conv_desc(N, Cc, H, W, Kp, R, S, (s, s), (p, p), (d, d), 1, Cc, Kp, K if Kp != K else 0, 0)
+    b = bias.to(dev())  # K real entries: the kernel guards the padded channels (cvhip_conv_desc.k_valid)
     L.call("cvhip_conv2d_fprop", C.byref(desc), xd.data_ptr(), st.w_fprop.data_ptr(), b.data_ptr(), y.data_ptr(), None, ops._stream())
     torch.cuda.synchronize()
     got = y.float().cpu()
@@ -215,7 +215,7 @@ def test_conv_channel_slice_operands():
     xb = to_nhwc_dev(xbig)
     ybig = torch.zeros((N, 160, H, W), dtype=BF, device=dev()).contiguous(memory_format=torch.channels_last)
     st = ops.ConvState()
-    st.prepare(w.to(dev()), ops.conv_desc(N, Cc, H, W, K, 3, 3, (1, 1), (1, 1), (1, 1), 1, Cc, K), False, ("slice",))
+    st.prepare(w.to(dev()).contiguous(memory_format=torch.channels_last), ops.conv_desc(N, Cc, H, W, K, 3, 3, (1, 1), (1, 1), (1, 1), 1, Cc, K), False, ("slice",))
     desc = ops.conv_desc(N, Cc, H, W, K, 3, 3, (1, 1), (1, 1), (1, 1), 1, 96, 160)
     L.call("cvhip_conv2d_fprop", C.byref(desc), xb.data_ptr() + 2 * 32, st.w_fprop.data_ptr(), None, ybig.data_ptr() + 2 * 64, None, ops._stream())
     torch.cuda.synchronize()
@@ -461,3 +461,34 @@ def test_yolov5_decode():
     got = ops.yolov5_decode(lv, det.stride, [det.anchors[i] * det.stride[i] for i in range(3)], 3, 85).cpu()
     assert got.shape == ref.shape
     assert float((got - ref).abs().max() / ref.abs().max()) < 1e-5
+
+
+def test_padded_channels_in_engine():
+    """3-channel image stem (C padded to 8) and 21-channel output (K padded to 24): master weight, bias and
+    their gradients keep the REAL shapes; padding happens inside libcvhip (cvhip_conv_desc.k_valid / c_valid)."""
+    torch.manual_seed(0)
+    from cvpytorch_amd import bricks
+    m = bricks.HipConv2d(3, 21, 3, stride=2, padding=1).to(dev())
+    x = torch.randn(2, 3, 16, 20)
+    ref = F.conv2d(bf(x), bf(m.weight.detach().cpu()), m.bias.detach().cpu(), stride=2, padding=1)
+    y = m(x.to(dev()))
+    assert tuple(y.shape) == (2, 21, 8, 10)
+    assert rel_l2(y.float().cpu(), ref) < 4e-3
+    g = bf(torch.randn_like(ref))
+    y.backward(g.to(dev()).to(BF))
+    wr = bf(m.weight.detach().cpu()).requires_grad_(True)
+    br = m.bias.detach().cpu().clone().requires_grad_(True)
+    F.conv2d(bf(x), wr, br, stride=2, padding=1).backward(g)
+    assert tuple(m.weight.grad.shape) == (21, 3, 3, 3)
+    assert rel_l2(m.weight.grad.cpu(), wr.grad) < 2e-3
+    assert rel_l2(m.bias.grad.cpu(), br.grad) < 2e-3
+
+
+def test_zero_fill_and_unpad_add():
+    t = torch.full((1000,), 7.0, device=dev())
+    ops.zero_fill(t)
+    assert float(t.abs().max()) == 0.0
+    src = torch.randn(8, 9, 16, device=dev())
+    dst = torch.ones(5, 9, 3, device=dev())
+    L.call("cvhip_f32_unpad_add", src.data_ptr(), dst.data_ptr(), 5, 9, 16, 3, ops._stream())
+    assert torch.allclose(dst, 1 + src[:5, :, :3])
