@@ -244,6 +244,7 @@ struct EwParams {
   int act;
   float ap;
   float inv_count;
+  int res_pre;  // MODE 0: residual is added BEFORE the activation (ResNet bottleneck: relu(bn(y) + identity))
 };
 
 // MODE 0: out = act(a*scale+shift) (+res)         [a = conv output y]
@@ -301,8 +302,13 @@ __global__ __launch_bounds__(256) void ew_kernel(const EwParams p) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         if (MODE == 0) {
-          float v = act_fwd(a.v[j] * sc[j] + sh[j], p.act, p.ap);
-          if (p.res) v += rs.v[j];
+          float v;
+          if (p.res && p.res_pre) {
+            v = act_fwd(a.v[j] * sc[j] + sh[j] + rs.v[j], p.act, p.ap);
+          } else {
+            v = act_fwd(a.v[j] * sc[j] + sh[j], p.act, p.ap);
+            if (p.res) v += rs.v[j];
+          }
           o.v[j] = v;
         } else if (MODE == 1) {
           const float u = y.v[j] * sc[j] + sh[j];
@@ -484,6 +490,26 @@ int cvhip_bn_act_bwd_apply(const void* dz, int32_t ld_dz, const void* y, int32_t
   p.inv_count = 1.f / (float)M;
   hipLaunchKernelGGL(ew_kernel<1>, dim3(ew_grid(M, C)), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("ew_kernel<1>");
+}
+
+int cvhip_add_act_fwd(const void* a, int32_t ld_a, const void* b, int32_t ld_b, void* out, int32_t ld_out, int64_t M, int32_t C,
+                      int32_t act, float act_param, void* stream) {
+  if (!a || !b || !out || M < 0 || C <= 0) return CVHIP_ERR_INVALID;
+  if (M == 0) return CVHIP_OK;
+  EwParams p{};
+  p.a = (const bf16_t*)a;
+  p.ld_a = ld_a;
+  p.res = (const bf16_t*)b;
+  p.ld_res = ld_b;
+  p.out = (bf16_t*)out;
+  p.ld_out = ld_out;
+  p.M = M;
+  p.C = C;
+  p.act = act;
+  p.ap = act_param;
+  p.res_pre = 1;
+  hipLaunchKernelGGL(ew_kernel<0>, dim3(ew_grid(M, C)), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("ew_kernel<0>(add_act)");
 }
 
 int cvhip_copy2d(const void* src, int32_t ld_src, void* dst, int32_t ld_dst, int64_t M, int32_t C, void* stream) {

@@ -1,0 +1,160 @@
+// loss_kernels.hip — loss-side kernels on NHWC bf16 activations.
+//
+//  * per-pixel softmax cross-entropy with ignore_index (nn.CrossEntropyLoss, reduction='mean'):
+//    reference src/losses/seg/cross_entropy_loss.py:32-40 as called from
+//    src/models/segmentors/encoder_decoder.py:93-107 (after the bilinear resize to label size).
+//  * per-(sample, channel) scaling = Dropout2d apply / backward (src/models/heads/seg/base_seg_head.py:32-37).
+#include "common.h"
+
+namespace cvhip {
+
+constexpr int kCeMaxC = 64;
+
+// logits: [M][ld] bf16 (C valid channels), target: int64 [M]; partial: [gridDim.x][2] fp32 = (sum of -log p_t, #valid)
+__global__ __launch_bounds__(256) void seg_ce_fwd_kernel(const bf16_t* __restrict__ logits, int ld, const int64_t* __restrict__ target, int64_t M,
+                                                         int C, int ignore, float* __restrict__ partial) {
+  __shared__ float red[2][256];
+  float loss = 0.f, cnt = 0.f;
+  for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
+    const int64_t t = target[m];
+    if (t == ignore || t < 0 || t >= C) continue;
+    const bf16_t* row = logits + m * ld;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, (float)row[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += __expf((float)row[c] - mx);
+    loss += (mx + __logf(se)) - (float)row[t];
+    cnt += 1.f;
+  }
+  red[0][threadIdx.x] = loss;
+  red[1][threadIdx.x] = cnt;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + s];
+      red[1][threadIdx.x] += red[1][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = red[0][0];
+    partial[2 * blockIdx.x + 1] = red[1][0];
+  }
+}
+
+// out[0] = mean loss (sum/count, 0 if count==0), out[1] = count
+__global__ void seg_ce_finalize_kernel(const float* partial, int rows, float* out) {
+  __shared__ double red[2][256];
+  double a = 0.0, b = 0.0;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    a += (double)partial[2 * r];
+    b += (double)partial[2 * r + 1];
+  }
+  red[0][threadIdx.x] = a;
+  red[1][threadIdx.x] = b;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + s];
+      red[1][threadIdx.x] += red[1][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = red[1][0] > 0.0 ? (float)(red[0][0] / red[1][0]) : 0.f;
+    out[1] = (float)red[1][0];
+  }
+}
+
+// dlogits[m][c] = gscale[0] * (softmax_c - [c==t]) / count  for valid pixels, 0 otherwise; pad channels zero
+__global__ __launch_bounds__(256) void seg_ce_bwd_kernel(const bf16_t* __restrict__ logits, int ld, const int64_t* __restrict__ target, int64_t M,
+                                                         int C, int ignore, const float* __restrict__ stat, const float* __restrict__ gscale,
+                                                         bf16_t* __restrict__ dlogits, int ld_d) {
+  const float cnt = stat[1];
+  const float g = (cnt > 0.f ? 1.f / cnt : 0.f) * (gscale ? gscale[0] : 1.f);
+  for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
+    const int64_t t = target[m];
+    bf16_t* drow = dlogits + m * ld_d;
+    if (t == ignore || t < 0 || t >= C) {
+      for (int c = 0; c < ld_d; ++c) drow[c] = (bf16_t)0.f;
+      continue;
+    }
+    const bf16_t* row = logits + m * ld;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, (float)row[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += __expf((float)row[c] - mx);
+    const float inv = 1.f / se;
+    for (int c = 0; c < C; ++c) {
+      const float p = __expf((float)row[c] - mx) * inv;
+      drow[c] = (bf16_t)(g * (p - (c == (int)t ? 1.f : 0.f)));
+    }
+    for (int c = C; c < ld_d; ++c) drow[c] = (bf16_t)0.f;
+  }
+}
+
+// y[n][hw][c] = x[n][hw][c] * s[n][c]
+__global__ __launch_bounds__(256) void scale_nc_kernel(const bf16_t* __restrict__ x, int ld_x, const float* __restrict__ s, bf16_t* __restrict__ y,
+                                                       int ld_y, int N, int C, int HW) {
+  const int CV = (C + 7) >> 3;
+  const bool vec = (C & 7) == 0 && (ld_x & 7) == 0 && (ld_y & 7) == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
+  const int64_t total = (int64_t)N * HW * CV;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    const int64_t pix = i / CV;
+    const int n = (int)(pix / HW);
+    const int c = cv * 8;
+    if (vec) {
+      f32x8 v = unpack8(*reinterpret_cast<const uint4*>(x + pix * ld_x + c));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v.v[j] *= s[(int64_t)n * C + c + j];
+      *reinterpret_cast<uint4*>(y + pix * ld_y + c) = pack8(v);
+    } else {
+      for (int j = 0; j < 8 && c + j < C; ++j) y[pix * ld_y + c + j] = (bf16_t)((float)x[pix * ld_x + c + j] * s[(int64_t)n * C + c + j]);
+    }
+  }
+}
+
+static inline int grid_for(int64_t total) {
+  int64_t b = cdiv64(total, 256);
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace cvhip
+
+using namespace cvhip;
+
+extern "C" {
+
+int cvhip_seg_ce_rows(int64_t M) { return grid_for(M); }
+
+int cvhip_seg_ce_fwd(const void* logits, int32_t ld, const int64_t* target, int64_t M, int32_t C, int32_t ignore_index, float* partial,
+                     float* out2, void* stream) {
+  if (!logits || !target || !partial || !out2 || M <= 0 || C <= 0 || C > kCeMaxC * 64 || ld < C) return CVHIP_ERR_INVALID;
+  const int rows = grid_for(M);
+  hipLaunchKernelGGL(seg_ce_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, target, M, C, ignore_index,
+                     partial);
+  int st = check_launch("seg_ce_fwd_kernel");
+  if (st) return st;
+  hipLaunchKernelGGL(seg_ce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, rows, out2);
+  return check_launch("seg_ce_finalize_kernel");
+}
+
+int cvhip_seg_ce_bwd(const void* logits, int32_t ld, const int64_t* target, int64_t M, int32_t C, int32_t ignore_index, const float* out2,
+                     const float* grad_scale, void* dlogits, int32_t ld_d, void* stream) {
+  if (!logits || !target || !out2 || !dlogits || M <= 0 || C <= 0 || ld < C || ld_d < C) return CVHIP_ERR_INVALID;
+  hipLaunchKernelGGL(seg_ce_bwd_kernel, dim3(grid_for(M)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, target, M, C,
+                     ignore_index, out2, grad_scale, (bf16_t*)dlogits, ld_d);
+  return check_launch("seg_ce_bwd_kernel");
+}
+
+int cvhip_scale_nc(const void* x, int32_t ld_x, const float* scale_nc, void* y, int32_t ld_y, int32_t N, int32_t C, int32_t HW, void* stream) {
+  if (!x || !scale_nc || !y || N <= 0 || C <= 0 || HW <= 0) return CVHIP_ERR_INVALID;
+  hipLaunchKernelGGL(scale_nc_kernel, dim3(grid_for((int64_t)N * HW * ((C + 7) / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     ld_x, scale_nc, (bf16_t*)y, ld_y, N, C, HW);
+  return check_launch("scale_nc_kernel");
+}
+
+}  // extern "C"

@@ -619,6 +619,104 @@ def add(a, b):
     return Add.apply(a, b)
 
 
+class AddAct(torch.autograd.Function):
+    """out = act(a + b) — ResNet bottleneck tail. Backward recomputes act' from the saved OUTPUT (valid for the
+    activations whose derivative is a function of the output's sign: ReLU / LeakyReLU)."""
+
+    @staticmethod
+    def forward(ctx, a, b, act, act_param):
+        if act not in (L.ACT_RELU, L.ACT_LEAKY, L.ACT_NONE):
+            raise L.CvhipError("add_act supports none / ReLU / LeakyReLU")
+        a, la = as_nhwc(a)
+        b, lb = as_nhwc(b)
+        N, Cc, H, W = a.shape
+        out = empty_nhwc(N, Cc, H, W, a.device)
+        L.call("cvhip_add_act_fwd", a.data_ptr(), la, b.data_ptr(), lb, out.data_ptr(), Cc, N * H * W, Cc, act, float(act_param), _stream())
+        ctx.meta = (N, Cc, H, W, act, float(act_param))
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dz):
+        (out,) = ctx.saved_tensors
+        N, Cc, H, W, act, ap = ctx.meta
+        if act == L.ACT_NONE:
+            return dz, dz, None, None
+        dz, ld = as_nhwc(dz)
+        du = empty_nhwc(N, Cc, H, W, dz.device)
+        L.call("cvhip_bn_act_bwd_apply", dz.data_ptr(), ld, out.data_ptr(), Cc, du.data_ptr(), Cc, N * H * W, Cc, None, None, None, None,
+               None, None, act, ap, _stream())
+        return du, du, None, None
+
+
+def add_act(a, b, act=L.ACT_RELU, act_param=0.0):
+    return AddAct.apply(a, b, act, act_param)
+
+
+class ScaleNC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        x, ld = as_nhwc(x)
+        N, Cc, H, W = x.shape
+        scale = scale.float().contiguous()
+        y = empty_nhwc(N, Cc, H, W, x.device)
+        L.call("cvhip_scale_nc", x.data_ptr(), ld, scale.data_ptr(), y.data_ptr(), Cc, N, Cc, H * W, _stream())
+        ctx.save_for_backward(scale)
+        ctx.meta = (N, Cc, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (scale,) = ctx.saved_tensors
+        N, Cc, H, W = ctx.meta
+        dy, ld = as_nhwc(dy)
+        dx = empty_nhwc(N, Cc, H, W, dy.device)
+        L.call("cvhip_scale_nc", dy.data_ptr(), ld, scale.data_ptr(), dx.data_ptr(), Cc, N, Cc, H * W, _stream())
+        return dx, None
+
+
+def dropout2d(x, p, training=True):
+    """nn.Dropout2d: whole channels of a sample are zeroed with probability p, survivors scaled by 1/(1-p)."""
+    if not training or p <= 0.0:
+        return x
+    N, Cc = x.shape[0], x.shape[1]
+    mask = (torch.rand((N, Cc), device=x.device) >= p).float() * (1.0 / (1.0 - p))
+    return ScaleNC.apply(x, mask)
+
+
+class SegCrossEntropy(torch.autograd.Function):
+    """nn.CrossEntropyLoss(ignore_index, reduction='mean') on NHWC bf16 logits (N,C,H,W) and int64 targets (N,H,W)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        logits, ld = as_nhwc(logits)
+        N, Cc, H, W = logits.shape
+        M = N * H * W
+        target = target.long().contiguous()
+        lib = L.load()
+        partial = torch.empty((2 * lib.cvhip_seg_ce_rows(M),), dtype=torch.float32, device=logits.device)
+        out2 = torch.empty((2,), dtype=torch.float32, device=logits.device)
+        L.call("cvhip_seg_ce_fwd", logits.data_ptr(), ld, target.data_ptr(), M, Cc, int(ignore_index), partial.data_ptr(), out2.data_ptr(), _stream())
+        ctx.meta = (N, Cc, H, W, ld, int(ignore_index))
+        ctx.save_for_backward(logits, target, out2)
+        return out2[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, out2 = ctx.saved_tensors
+        N, Cc, H, W, ld, ign = ctx.meta
+        Cp = _round8(Cc)
+        gs = g.detach().float().reshape(1).contiguous()
+        buf = torch.empty((N, H, W, Cp), dtype=BF16, device=logits.device)
+        L.call("cvhip_seg_ce_bwd", logits.data_ptr(), ld, target.data_ptr(), N * H * W, Cc, ign, out2.data_ptr(), gs.data_ptr(),
+               buf.data_ptr(), Cp, _stream())
+        return buf.permute(0, 3, 1, 2)[:, :Cc], None, None
+
+
+def seg_cross_entropy(logits, target, ignore_index=255):
+    return SegCrossEntropy.apply(logits, target, ignore_index)
+
+
 class ResizeBilinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, Ho, Wo, align_corners):

@@ -228,6 +228,29 @@ int cvhip_copy2d(const void* src_bf16, int32_t ld_src, void* dst_bf16, int32_t l
 int cvhip_add2d(const void* a_bf16, int32_t ld_a, const void* b_bf16, int32_t ld_b, void* dst_bf16,
                 int32_t ld_dst, int64_t M, int32_t C, void* stream);
 
+/* out = act(a + b): the ResNet bottleneck tail relu(bn3(conv3) + identity) (torchvision Bottleneck, used through
+ * src/models/backbones/seg/resnet.py:91-94). Backward: du = dz*act'(out) via cvhip_bn_act_bwd_apply on `out`. */
+int cvhip_add_act_fwd(const void* a_bf16, int32_t ld_a, const void* b_bf16, int32_t ld_b,
+                      void* out_bf16, int32_t ld_out, int64_t M, int32_t C, int32_t act,
+                      float act_param, void* stream);
+
+/* y[n][hw][c] = x[n][hw][c] * scale[n][c] — Dropout2d apply and its backward
+ * (src/models/heads/seg/base_seg_head.py:25-37; the Bernoulli mask/(1-p) is drawn by the host). */
+int cvhip_scale_nc(const void* x_bf16, int32_t ld_x, const float* scale_nc, void* y_bf16,
+                   int32_t ld_y, int32_t N, int32_t C, int32_t HW, void* stream);
+
+/* Per-pixel softmax cross-entropy with ignore_index, reduction 'mean' over non-ignored pixels
+ * (nn.CrossEntropyLoss: src/losses/seg/cross_entropy_loss.py:32-40). logits: [M][ld] bf16 NHWC (M = N*H*W),
+ * target int64 [M]. fwd: partial = float[2*cvhip_seg_ce_rows(M)] scratch, out2 = device float[2] {mean loss,
+ * #valid}. bwd: dlogits = grad_scale[0] * (softmax - onehot)/#valid (zeros for ignored pixels and pad channels);
+ * grad_scale is a DEVICE scalar (the upstream gradient of the loss), NULL = 1. */
+int cvhip_seg_ce_rows(int64_t M);
+int cvhip_seg_ce_fwd(const void* logits_bf16, int32_t ld, const int64_t* target, int64_t M,
+                     int32_t C, int32_t ignore_index, float* partial, float* out2, void* stream);
+int cvhip_seg_ce_bwd(const void* logits_bf16, int32_t ld, const int64_t* target, int64_t M,
+                     int32_t C, int32_t ignore_index, const float* out2, const float* grad_scale,
+                     void* dlogits_bf16, int32_t ld_d, void* stream);
+
 /* bilinear resize, align_corners = 0/1 (F.interpolate).
  * src/models/heads/seg/deeplabv3plus_head.py:56-66, segmentors/encoder_decoder.py:99 */
 int cvhip_resize_bilinear_fwd(const void* x_bf16, int32_t ld_x, void* y_bf16, int32_t ld_y,

@@ -570,3 +570,159 @@ def synthetic_batch(batch, size=640, num_classes=80, seed=1029, max_boxes=20):
         wh = torch.min(wh, 2 * torch.min(cxy, 1 - cxy))
         targets.append({"labels": labels, "boxes": torch.cat([cxy, wh], 1)})
     return imgs, targets
+
+
+# ---- DeepLabv3+ / ResNet-50-v1c (BASELINE config 3) ------------------------------------------------------
+class Bottleneck(nn.Module):
+    """torchvision.models.resnet.Bottleneck (v1.5). THIRD-PARTY: torchvision is neither vendored in the reference nor
+    installed here (README.md:54-55 names 0.7.0), so this block is restated from torchvision's public definition and is
+    PARITY-UNPINNED against a torchvision binary."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        return self.relu(out + identity)
+
+
+class ResNet50(nn.Module):
+    """src/models/backbones/seg/resnet.py:27-154 for subtype resnet50 / resnet50v1c (deep stem :67-80). As written the
+    reference never dilates ResNet-50 (:102-118) => output_stride 32; 8/16 give the intended torchvision dilation."""
+
+    def __init__(self, subtype="resnet50v1c", out_stages=(1, 4), output_stride=32, classifier=False, num_classes=1000):
+        super().__init__()
+        self.out_stages, self.classifier = list(out_stages), classifier
+        if subtype.endswith("c"):
+            self.stem = nn.Sequential(nn.Conv2d(3, 32, 3, 2, 1, bias=False), nn.BatchNorm2d(32), nn.ReLU(inplace=True),
+                                      nn.Conv2d(32, 32, 3, 1, 1, bias=False), nn.BatchNorm2d(32), nn.ReLU(inplace=True),
+                                      nn.Conv2d(32, 64, 3, 1, 1, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True))
+        else:
+            self.stem = nn.Sequential(nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True))
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        dilate3, dilate4 = {32: (False, False), 16: (False, True), 8: (True, True)}[output_stride]
+        self.inplanes, self._dilation = 64, 1
+        self.layer1 = self._make_layer(64, 3, 1, False)
+        self.layer2 = self._make_layer(128, 4, 2, False)
+        self.layer3 = self._make_layer(256, 6, 2, dilate3)
+        self.layer4 = self._make_layer(512, 3, 2, dilate4)
+        if classifier:
+            self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+            self.fc = nn.Linear(2048, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, planes, blocks, stride, dilate):
+        previous_dilation = self._dilation
+        if dilate:
+            self._dilation *= stride
+            stride = 1
+        downsample = None
+        if stride != 1 or self.inplanes != planes * 4:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False), nn.BatchNorm2d(planes * 4))
+        layers = [Bottleneck(self.inplanes, planes, stride, downsample, dilation=previous_dilation)]
+        self.inplanes = planes * 4
+        for _ in range(1, blocks):
+            layers.append(Bottleneck(self.inplanes, planes, dilation=self._dilation))
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        x = self.maxpool(self.stem(x))
+        output = []
+        for i in range(1, 5):
+            x = getattr(self, "layer%d" % i)(x)
+            if i in self.out_stages and not self.classifier:
+                output.append(x)
+        if self.classifier:
+            return self.fc(torch.flatten(self.avgpool(x), 1))
+        return output if len(self.out_stages) > 1 else output[0]
+
+
+class ASPP(nn.ModuleList):
+    """src/models/heads/seg/deeplabv3_head.py:15-48; depthwise-separable branches per deeplabv3plus_head.py:14-30."""
+
+    def __init__(self, dilations, in_channels, channels, norm_cfg, act_cfg, depthwise=True):
+        super().__init__()
+        for d in dilations:
+            if d > 1 and depthwise:
+                self.append(DepthwiseSeparableConvModule(in_channels, channels, 3, dilation=d, padding=d, norm_cfg=norm_cfg, act_cfg=act_cfg))
+            else:
+                self.append(ConvModule(in_channels, channels, 1 if d == 1 else 3, dilation=d, padding=0 if d == 1 else d, norm_cfg=norm_cfg,
+                                       act_cfg=act_cfg))
+
+    def forward(self, x):
+        return [m(x) for m in self]
+
+
+class Deeplabv3PlusHead(nn.Module):
+    """src/models/heads/seg/deeplabv3plus_head.py:33-68 (+ deeplabv3_head.py:50-74, base_seg_head.py:13-37)."""
+
+    def __init__(self, num_classes, in_channels=2048, channels=512, dilations=(1, 12, 24, 36), low_in_channels=256, low_channels=48,
+                 dropout_ratio=0.1, norm_cfg=dict(type="BN", requires_grad=True), act_cfg=dict(type="ReLU")):
+        super().__init__()
+        self.dropout = nn.Dropout2d(dropout_ratio) if dropout_ratio > 0 else None
+        self.cls_seg = nn.Conv2d(channels, num_classes, kernel_size=1)
+        self.proj = nn.Sequential(nn.AdaptiveAvgPool2d(1), ConvModule(in_channels, channels, 1, norm_cfg=norm_cfg, act_cfg=act_cfg))
+        self.aspp = ASPP(dilations, in_channels, channels, norm_cfg, act_cfg, depthwise=True)
+        self.reduce = ConvModule((len(dilations) + 1) * channels, channels, 3, padding=1, norm_cfg=norm_cfg, act_cfg=act_cfg)
+        self.low_proj = ConvModule(low_in_channels, low_channels, 1, norm_cfg=norm_cfg, act_cfg=act_cfg) if low_in_channels > 0 else None
+        self.fuse = nn.Sequential(
+            DepthwiseSeparableConvModule(channels + low_channels, channels, 3, padding=1, norm_cfg=norm_cfg, act_cfg=act_cfg),
+            DepthwiseSeparableConvModule(channels, channels, 3, padding=1, norm_cfg=norm_cfg, act_cfg=act_cfg))
+
+    def forward(self, x):
+        outs = [F.interpolate(self.proj(x[1]), size=x[1].size()[2:], mode="bilinear", align_corners=False)]
+        outs.extend(self.aspp(x[1]))
+        outs = self.reduce(torch.cat(outs, dim=1))
+        if self.low_proj is not None:
+            low = self.low_proj(x[0])
+            outs = torch.cat([F.interpolate(outs, size=low.size()[2:], mode="bilinear", align_corners=False), low], dim=1)
+        outs = self.fuse(outs)
+        if self.dropout is not None:
+            outs = self.dropout(outs)
+        return self.cls_seg(outs)
+
+
+class EncoderDecoder(nn.Module):
+    """src/models/segmentors/encoder_decoder.py:93-150 with CrossEntropyLoss2d (losses/seg/cross_entropy_loss.py:32-40)."""
+
+    def __init__(self, num_classes=19, output_stride=32, dropout_ratio=0.1, ignore_index=255):
+        super().__init__()
+        self.backbone = ResNet50("resnet50v1c", (1, 4), output_stride)
+        self.head = Deeplabv3PlusHead(num_classes, dropout_ratio=dropout_ratio)
+        self.criterion = nn.CrossEntropyLoss(ignore_index=ignore_index)
+
+    def forward(self, imgs, targets=None, mode="train"):
+        preds = self.head(self.backbone(imgs))
+        if mode == "train":
+            preds = F.interpolate(preds, size=targets.shape[-2:], mode="bilinear", align_corners=False)
+            ce = self.criterion(preds, targets.long())
+            return {"ce_loss": ce, "loss": ce}
+        return torch.argmax(F.interpolate(preds, size=targets.shape[-2:], mode="bilinear", align_corners=False), dim=1)
+
+
+def synthetic_seg_batch(batch, size=(512, 1024), num_classes=19, seed=1029, ignore_frac=0.05):
+    """SURVEY.md §8(d) config 3."""
+    g = torch.Generator().manual_seed(seed)
+    imgs = torch.randn(batch, 3, size[0], size[1], generator=g)
+    tgt = torch.randint(0, num_classes, (batch, size[0], size[1]), generator=g)
+    tgt[torch.rand(batch, size[0], size[1], generator=g) < ignore_frac] = 255
+    return imgs, tgt

@@ -119,3 +119,13 @@ def test_ema_matches_reference_formula():
     for k, v in ema.ema.state_dict().items():
         if v.dtype.is_floating_point:
             assert torch.allclose(v, before[k] * d + (1 - d) * m.state_dict()[k])
+
+
+def test_deeplab_state_dict_matches_oracle_layout():
+    from cvpytorch_amd import deeplab
+    ref, hip = R.EncoderDecoder(19), deeplab.EncoderDecoder(19)
+    assert list(ref.state_dict().keys()) == list(hip.state_dict().keys())
+    assert sum(p.numel() for p in hip.parameters()) == 41225187  # 41.23 M
+    hip.load_state_dict(ref.state_dict())
+    r8 = R.EncoderDecoder(19, output_stride=8)
+    assert [tuple(v.shape) for v in r8.state_dict().values()] == [tuple(v.shape) for v in deeplab.EncoderDecoder(19, output_stride=8).state_dict().values()]

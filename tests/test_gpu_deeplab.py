@@ -1,0 +1,158 @@
+"""GPU parity for the DeepLabv3+ / ResNet-50 path (BASELINE config 3): new kernels (add+ReLU, Dropout2d scale,
+softmax cross-entropy with ignore_index), the head against the REFERENCE's golden vectors, and the full
+EncoderDecoder against the oracle. Tolerances as in test_gpu_modules.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from cvpytorch_amd import deeplab, ops
+from cvpytorch_amd import lib as L
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+BF = torch.bfloat16
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / max(float(b.norm()), 1e-12))
+
+
+def cosine(a, b):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return float((a @ b) / (a.norm() * b.norm()).clamp(min=1e-30))
+
+
+def nhwc(x):
+    return x.to(dev()).to(BF).contiguous(memory_format=torch.channels_last)
+
+
+def bf(x):
+    return x.to(BF).float()
+
+
+def test_add_act():
+    torch.manual_seed(0)
+    a, b = bf(torch.randn(2, 24, 5, 7)), bf(torch.randn(2, 24, 5, 7))
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.relu(ar + br)
+    g = bf(torch.randn_like(ref))
+    ref.backward(g)
+    ad, bd = nhwc(a).requires_grad_(True), nhwc(b).requires_grad_(True)
+    out = ops.add_act(ad, bd, L.ACT_RELU)
+    out.backward(nhwc(g))
+    assert torch.equal(out.detach().float().cpu(), bf(ref.detach()))
+    assert torch.equal(ad.grad.float().cpu(), ar.grad) and torch.equal(bd.grad.float().cpu(), br.grad)
+
+
+def test_dropout2d_semantics():
+    torch.manual_seed(0)
+    x = nhwc(torch.ones(8, 64, 4, 4)).requires_grad_(True)
+    y = ops.dropout2d(x, 0.25, True)
+    v = y.detach().float().cpu()
+    per = v.amax((2, 3))
+    assert set(np.round(per.unique().numpy(), 3).tolist()) <= {0.0, round(1 / 0.75, 3)}
+    assert torch.equal(v, per[:, :, None, None].expand_as(v))  # whole channels are dropped
+    assert 0.1 < float((per == 0).float().mean()) < 0.4
+    y.backward(torch.ones_like(y))
+    assert torch.equal(x.grad.float().cpu(), v)
+    assert ops.dropout2d(x, 0.25, False) is x
+
+
+@pytest.mark.parametrize("Cc,H,W", [(19, 9, 11), (8, 4, 4), (21, 16, 16)])
+def test_seg_cross_entropy(Cc, H, W):
+    torch.manual_seed(0)
+    N = 3
+    logits = bf(torch.randn(N, Cc, H, W) * 3)
+    tgt = torch.randint(0, Cc, (N, H, W))
+    tgt[torch.rand(N, H, W) < 0.2] = 255
+    lr = logits.clone().requires_grad_(True)
+    ref = F.cross_entropy(lr, tgt, ignore_index=255)
+    (gref,) = torch.autograd.grad(ref, lr)
+    ld = nhwc(logits).requires_grad_(True)
+    loss = ops.seg_cross_entropy(ld, tgt.to(dev()), 255)
+    (g,) = torch.autograd.grad(loss * 2.0, ld)
+    assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+    assert rel_l2(g.float(), 2.0 * gref) < 4e-3
+    # all pixels ignored -> zero loss and zero gradient (torch returns nan; the reference never hits this)
+    allign = torch.full((N, H, W), 255)
+    l0 = ops.seg_cross_entropy(nhwc(logits).requires_grad_(True), allign.to(dev()), 255)
+    assert float(l0) == 0.0
+
+
+def _load(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    out = {}
+    for k in z.files:
+        parts = k.split("/", 1)
+        if len(parts) == 1:
+            out[k] = z[k]
+        else:
+            out.setdefault(parts[0], {})[parts[1]] = z[k]
+    return out
+
+
+def test_hip_deeplab_head_vs_reference_vectors():
+    g = _load("deeplabv3plus_head")
+    T = lambda a: torch.from_numpy(np.asarray(a))
+    m = deeplab.Deeplabv3PlusHead(19, in_channels=64, channels=32, dilations=(1, 2, 3, 4), low_in_channels=16, low_channels=8, dropout_ratio=0)
+    missing, unexpected = m.load_state_dict({k: T(v) for k, v in g["state"].items()}, strict=True)
+    assert not missing and not unexpected
+    m.to(dev()).train()
+    xs = [nhwc(T(g["x"][str(i)])).requires_grad_(True) for i in range(2)]
+    logits = m(xs)
+    assert rel_l2(logits.float(), T(g["logits"])) < 3e-2, rel_l2(logits.float(), T(g["logits"]))
+    tgt = T(g["target"]).to(dev())
+    loss = ops.seg_cross_entropy(ops.resize_bilinear(logits, tgt.shape[-2:], False), tgt, 255)
+    assert abs(float(loss) - float(g["loss"])) < 2e-2 * float(g["loss"])
+    named = [(n, q) for n, q in m.named_parameters()]
+    grads = torch.autograd.grad(loss, xs + [q for _, q in named])
+    for i in range(2):
+        assert cosine(grads[i].float(), T(g["gx"][str(i)])) > 0.99, (i, cosine(grads[i].float(), T(g["gx"][str(i)])))
+    cs = sorted((cosine(a.float(), T(g["gparam"][n])), n) for (n, _), a in zip(named, grads[2:]) if float(T(g["gparam"][n]).norm()) > 1e-7)
+    assert np.median([c for c, _ in cs]) > 0.99 and cs[0][0] > 0.9, cs[:4]
+
+
+@pytest.mark.parametrize("output_stride", [32, 8])
+def test_deeplab_end_to_end_vs_oracle(output_stride):
+    from oracle import torch_ref as R
+    torch.manual_seed(0)
+    ref = R.EncoderDecoder(19, output_stride=output_stride, dropout_ratio=0)
+    hip = deeplab.EncoderDecoder(19, output_stride=output_stride, dropout_ratio=0)
+    hip.load_state_dict(ref.state_dict())
+    imgs, tgt = R.synthetic_seg_batch(2, (128, 192), seed=3)
+    ref.train()
+    lr = ref(imgs, tgt, "train")["loss"]
+    lr.backward()
+    hip.to(dev()).train()
+    lh = hip(imgs.to(dev()), tgt.to(dev()), "train")["loss"]
+    lh.backward()
+    torch.cuda.synchronize()
+    assert abs(float(lh) - float(lr)) < 3e-2 * abs(float(lr)), (float(lh), float(lr))
+    rp = dict(ref.named_parameters())
+    # noise floor of bf16 storage: the oracle under CPU bf16 autocast
+    ref2 = R.EncoderDecoder(19, output_stride=output_stride, dropout_ratio=0)
+    ref2.load_state_dict(ref.state_dict())
+    ref2.train()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        l2 = ref2(imgs, tgt, "train")["loss"]
+    l2.backward()
+    floor = np.median([cosine(p.grad.float(), rp[n].grad) for n, p in ref2.named_parameters()])
+    got = np.median([cosine(p.grad.float(), rp[n].grad) for n, p in hip.named_parameters()])
+    assert got > floor - 0.05, (got, floor)
+    rb = dict(ref.named_buffers())
+    for n, b in hip.named_buffers():
+        if "running_mean" in n and "layer1.0" in n:
+            assert rel_l2(b.float(), rb[n]) < 5e-2, n
+    hip.eval()
+    with torch.no_grad():
+        pred = hip(imgs.to(dev()), tgt.to(dev()), "val")
+    assert tuple(pred.shape) == (2, 128, 192) and pred.dtype == torch.int64

@@ -194,3 +194,26 @@ def test_yolov5_loss(trial):
 
 def test_golden_files_present():
     assert len(glob.glob(os.path.join(GOLD, "*.npz"))) >= 20
+
+
+def test_deeplabv3plus_head_and_ce():
+    """Reference Deeplabv3PlusHead (heads/seg/deeplabv3plus_head.py) + CrossEntropyLoss2d after the bilinear resize
+    (segmentors/encoder_decoder.py:93-107)."""
+    import torch.nn.functional as F
+    g = load("deeplabv3plus_head")
+    m = R.Deeplabv3PlusHead(19, in_channels=64, channels=32, dilations=(1, 2, 3, 4), low_in_channels=16, low_channels=8, dropout_ratio=0)
+    load_state(m, g["state"])
+    m.train()
+    xs = [x.requires_grad_(True) for x in lst(g["x"])]
+    logits = m(xs)
+    close(logits, g["logits"], rtol=1e-4)
+    tgt = T(g["target"])
+    up = F.interpolate(logits, size=tgt.shape[-2:], mode="bilinear", align_corners=False)
+    loss = torch.nn.CrossEntropyLoss(ignore_index=255)(up, tgt.long())
+    close(loss, g["loss"], rtol=1e-5)
+    named = [(n, q) for n, q in m.named_parameters()]
+    grads = torch.autograd.grad(loss, xs + [q for _, q in named])
+    for a, e in zip(grads[:2], lst(g["gx"])):
+        close(a, e, rtol=1e-3, atol=1e-8)
+    for (n, _), a in zip(named, grads[2:]):
+        close(a, g["gparam"][n], rtol=2e-3, atol=1e-8)

@@ -208,6 +208,31 @@ def main():
     z, _ = det([f.clone() for f in fe])
     save("detect_v5", x=fe, state=det.state_dict(), train_out=tr, z=z)
 
+    # ---- DeepLabv3+ head (reference class, reduced width, dropout disabled for determinism) + CrossEntropyLoss2d --------
+    from src.models.heads.seg.deeplabv3plus_head import Deeplabv3PlusHead
+    from src.losses.seg.cross_entropy_loss import CrossEntropyLoss2d
+    torch.manual_seed(12)
+    head = Deeplabv3PlusHead(low_in_channels=16, low_channels=8, num_classes=19, in_channels=64, channels=32, dilations=(1, 2, 3, 4),
+                             dropout_ratio=0)
+    for mm in head.modules():
+        if isinstance(mm, torch.nn.BatchNorm2d):
+            with torch.no_grad():
+                mm.weight.uniform_(0.5, 1.5)
+                mm.bias.uniform_(-0.3, 0.3)
+    xs = [torch.randn(2, 16, 16, 24), torch.randn(2, 64, 4, 6)]
+    state0 = {k: v.clone() for k, v in head.state_dict().items()}
+    head.train()
+    xin = [x.clone().requires_grad_(True) for x in xs]
+    logits = head(xin)
+    tgt = torch.randint(0, 19, (2, 32, 48))
+    tgt[torch.rand(2, 32, 48) < 0.1] = 255
+    up = torch.nn.functional.interpolate(logits, size=tgt.shape[-2:], mode="bilinear", align_corners=False)
+    loss = CrossEntropyLoss2d()(up, tgt)
+    named = [(n, q) for n, q in head.named_parameters()]
+    grads = torch.autograd.grad(loss, xin + [q for _, q in named])
+    save("deeplabv3plus_head", x=xs, state=state0, logits=logits, target=tgt, loss=loss, gx=grads[:2],
+         gparam={n: g for (n, _), g in zip(named, grads[2:])})
+
     # ---- IoU family + known-answer vector ------------------------------------------------------------------------
     torch.manual_seed(11)
     b1 = torch.rand(4, 50) * torch.tensor([[10.], [10.], [5.], [5.]]) + 0.1
