@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--no-deeplab", action="store_true", help="skip the DeepLabv3+ (config 3) side workload")
     ap.add_argument("--no-graph", action="store_true", help="run the timed steps eagerly instead of replaying a hipGraph")
     ap.add_argument("--stock-optimizer", action="store_true", help="torch.optim.SGD + ModelEMA instead of the fused arena step")
     return ap.parse_args()
@@ -73,6 +74,38 @@ def cpu_baseline(size, cpu_batch, budget_s=20.0):
     return {"value": round(cpu_batch * n / el, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "oracle YOLOv5-s fp32 train step (fwd+loss+bwd+SGD), batch %d @%dx%d, %d timed steps after 1 warm-up, %.1f s"
                       % (cpu_batch, size, size, n, el)}
+
+
+def deeplab_workload(dev, a, batch=16, size=(512, 1024), steps=5, warmup=2):
+    """Second headline workload of BASELINE.json's metric (config 3): DeepLabv3+ ResNet-50-v1c, 1024x512, bf16, batch 16,
+    OS-32 as the reference builds it. Same step definition; reported next to the YOLOv5-s line."""
+    from cvpytorch_amd import deeplab
+    from cvpytorch_amd.arena import FlatTrainState, FlatTrainStep
+    from cvpytorch_amd.data import synthetic_segmentation_batch
+    torch.manual_seed(1029)
+    model = deeplab.EncoderDecoder(19, output_stride=32).to(dev).train()
+    state = FlatTrainState(model, lr=0.01, momentum=0.9, nesterov=True, weight_decay=5e-4, backbone_lr=0.001, use_ema=False)
+    step = FlatTrainStep(model, state)
+    imgs, tgt = synthetic_segmentation_batch(batch, size, device=dev)
+    for _ in range(warmup):
+        step(imgs, tgt)
+    graph = not a.no_graph
+    if graph:
+        step.capture(imgs, tgt)
+        imgs, tgt = step.static_imgs, step.static_targets
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses = step(imgs, tgt)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ips = batch * steps / el
+    # BASELINE.md §2: 434.7 GFLOP and ~2558 MB per image (train, OS-32 as written)
+    return {"value": round(ips, 2), "unit": "images/sec", "ms_per_step": round(1e3 * el / steps, 2), "steps": steps, "warmup": warmup,
+            "workload": "DeepLabv3+ R50-v1c %dx%d bf16 batch %d OS-32 (as written), SGD-nesterov, synthetic" % (size[1], size[0], batch),
+            "launch": "hipGraph replay" if graph else "eager", "final_loss": round(float(losses["loss"]), 4),
+            "step_roofline": {"mfma_frac": round(ips * 434.7e9 / (PEAK_MFMA_TFLOPS * 1e12), 4),
+                              "hbm_frac": round(ips * 2558e6 / (PEAK_HBM_GBS * 1e9), 4)}}
 
 
 def main():
@@ -183,6 +216,11 @@ def main():
             ips_gpu = a.batch * a.steps / el
             out["step_roofline"] = {"mfma_frac": round(ips_gpu * 49.30e9 / (PEAK_MFMA_TFLOPS * 1e12), 4),
                                     "hbm_frac": round(ips_gpu * 366e6 / (PEAK_HBM_GBS * 1e9), 4)}
+        if world == 1 and not a.no_deeplab:
+            try:
+                out["config3_deeplabv3plus_r50"] = deeplab_workload(dev, a)
+            except Exception as e:  # the headline line must still be printed
+                out["config3_deeplabv3plus_r50"] = {"error": repr(e)[:300]}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.size, a.cpu_batch)
         print(json.dumps(out), flush=True)
