@@ -83,66 +83,73 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
       pbase[i] = 0;
     }
   }
-  // tap walker for this thread's 16-B slot: element k = kt*32 + (t&3)*8 -> (tr, ts, c0)
-  int c0, ts_, tr_;
-  {
-    const int k = (t & 3) * 8;
-    const int tap = k / Cin;
-    c0 = k - tap * Cin;
-    tr_ = tap / TS;
-    ts_ = tap - tr_ * TS;
-  }
+  // branch-free tap decode for this thread's 16-B slot: element k -> (tr, ts, c0) by exact magic-number division
+  const unsigned cin_magic = p.cin_magic, ts_magic = cl.ts_magic;
+  auto fdiv = [](unsigned n, unsigned magic) -> unsigned { return magic ? __umulhi(n, magic) : n; };
   const bf16_t* __restrict__ wbase = p.w + cl.w_off;
 
   // swizzled 16-B slot for the LDS write (thread-constant) and the fragment read (lane-constant)
   const int swz_w = (t & 3) ^ ((0x78 >> (2 * ((t >> 4) & 3))) & 3);
   const int swz_r = (lane >> 4) ^ ((0x78 >> (2 * ((lane >> 2) & 3))) & 3);
 
-  uint4 ra[A_IT], rb[B_IT];
+  // Two register stages: while tile kt is consumed from LDS, tiles kt+2 and kt+3 are in flight from L2/HBM
+  // (the kernel is latency x concurrency bound: bytes in flight per CU set its speed).
+  uint4 ra0[A_IT], rb0[B_IT], ra1[A_IT], rb1[B_IT];
 
-  auto load_tile = [&](int kt) {
-    const bool tap_ok = tr_ < TR;
-    const int dh = tr_ * cl.dh_step, dw = ts_ * cl.dw_step;
+  // Loads are UNCONDITIONAL (masked lanes read a safe address and are zeroed when the tile is written to LDS):
+  // a load inside a divergent branch makes hipcc fall back to s_waitcnt vmcnt(0) at every join, which would drain
+  // both register stages each step; branch-free loads let it emit the counted waits the pipeline needs.
+  unsigned msk0 = 0, msk1 = 0;
+  auto load_tile = [&](int kt, uint4(&ra)[A_IT], uint4(&rb)[B_IT], unsigned& msk) {
+    const unsigned k = (unsigned)(kt * 32 + (t & 3) * 8);
+    const unsigned tap = fdiv(k, cin_magic);
+    const int c0 = (int)(k - tap * (unsigned)Cin);
+    const unsigned tr = fdiv(tap, ts_magic);
+    const int ts = (int)(tap - tr * (unsigned)TS);
+    const bool tap_ok = (int)tr < TR;  // also false for every k >= Ktot (tiles past the end are all-zero)
+    const int dh = (int)tr * cl.dh_step, dw = ts * cl.dw_step;
+    unsigned m = 0;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int ih = ih0[i] + dh, iw = iw0[i] + dw;
       const bool ok = tap_ok && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) {
-        const bf16_t* src = p.x + ((int64_t)(pbase[i] + ih * p.IW + iw) * p.x_ld + c0);
-        v = *reinterpret_cast<const uint4*>(src);
-      }
-      ra[i] = v;
+      const int64_t off = ok ? ((int64_t)(pbase[i] + ih * p.IW + iw) * p.x_ld + c0) : 0;
+      ra[i] = *reinterpret_cast<const uint4*>(p.x + off);
+      m |= (ok ? 1u : 0u) << i;
     }
-    const int k = kt * 32 + (t & 3) * 8;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const int row = i * 64 + (t >> 2);
       const int n = n0 + row;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (row < BN && n < p.Nout && k < Ktot)
-        v = *reinterpret_cast<const uint4*>(wbase + ((int64_t)n * Ktot + k));
-      rb[i] = v;
+      const bool ok = row < BN && n < p.Nout && (int)k < Ktot;
+      const int64_t off = ok ? ((int64_t)n * Ktot + k) : 0;
+      rb[i] = *reinterpret_cast<const uint4*>(wbase + off);
+      m |= (ok ? 1u : 0u) << (8 + i);
     }
-    // advance the tap walker by one K step (32 elements)
-    c0 += 32;
-    while (c0 >= Cin) {
-      c0 -= Cin;
-      ++ts_;
-    }
-    while (ts_ >= TS) {
-      ts_ -= TS;
-      ++tr_;
-    }
+    msk = m;
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const uint4(&ra)[A_IT], const uint4(&rb)[B_IT], unsigned msk) {
+    const uint4 z = make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i)
-      *reinterpret_cast<uint4*>(sA + buf * A_BYTES + (i * 64 + (t >> 2)) * 64 + swz_w * 16) = ra[i];
+    for (int i = 0; i < A_IT; ++i) {
+      const bool ok = (msk >> i) & 1u;
+      uint4 v = ra[i];
+      v.x = ok ? v.x : z.x;
+      v.y = ok ? v.y : z.y;
+      v.z = ok ? v.z : z.z;
+      v.w = ok ? v.w : z.w;
+      *reinterpret_cast<uint4*>(sA + buf * A_BYTES + (i * 64 + (t >> 2)) * 64 + swz_w * 16) = v;
+    }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const int row = i * 64 + (t >> 2);
-      if (row < BN) *reinterpret_cast<uint4*>(sB + buf * B_BYTES + row * 64 + swz_w * 16) = rb[i];
+      const bool ok = (msk >> (8 + i)) & 1u;
+      uint4 v = rb[i];
+      v.x = ok ? v.x : z.x;
+      v.y = ok ? v.y : z.y;
+      v.z = ok ? v.z : z.z;
+      v.w = ok ? v.w : z.w;
+      if (BN >= 64 || row < BN) *reinterpret_cast<uint4*>(sB + buf * B_BYTES + row * 64 + swz_w * 16) = v;
     }
   };
 
@@ -152,17 +159,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
     for (int b = 0; b < MF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (nk > 0) {
-    load_tile(0);
-    store_tile(0);
-  }
-  __syncthreads();
-
   const int a_row = wm * WM + (lane & 15);
   const int b_row = wn * WN + (lane & 15);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);  // global loads in flight under the MFMA block
+  auto compute = [&](int cur) {
     bf16x8 xa[MF], wb[NF];
 #pragma unroll
     for (int b = 0; b < MF; ++b)
@@ -175,7 +174,25 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
       for (int b = 0; b < MF; ++b)
         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[a], xa[b], acc[a][b], 0, 0, 0);
-    if (kt + 1 < nk) store_tile(cur ^ 1);
+  };
+
+  // prologue: tiles 0,1 -> registers; tile 0 -> LDS[0]; tile 2 -> registers. Loads/stores are issued
+  // unconditionally (tiles past nk decode to tap_ok == false: masked, zero) so the loop body is straight-line code.
+  load_tile(0, ra0, rb0, msk0);
+  load_tile(1, ra1, rb1, msk1);
+  store_tile(0, ra0, rb0, msk0);
+  load_tile(2, ra0, rb0, msk0);
+  __syncthreads();
+  // step kt: [tile kt+1: registers -> LDS[nxt]] [issue tile kt+3 -> the freed registers] [MFMA on LDS[cur]] barrier
+  for (int kt = 0; kt < nk; kt += 2) {
+    store_tile(1, ra1, rb1, msk1);
+    load_tile(kt + 3, ra1, rb1, msk1);
+    compute(0);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    store_tile(0, ra0, rb0, msk0);
+    load_tile(kt + 4, ra0, rb0, msk0);
+    compute(1);
     __syncthreads();
   }
 
@@ -266,7 +283,10 @@ template <int BM, int BN, int WM, int WN>
 static int launch_cfg(IgemmParams& p, hipStream_t stream) {
   int total = 0;
   p.n_tiles = cdiv(p.Nout, BN);
+  p.cin_magic = div_magic(p.Cin);
   for (int i = 0; i < p.ncls; ++i) {
+    p.cls[i].ts_magic = div_magic(p.cls[i].TS);
+    if ((int64_t)p.cls[i].TR * p.cls[i].TS * p.Cin >= 65536) return CVHIP_ERR_UNSUPPORTED;  // 16-bit exact fast division
     p.cls[i].tile_begin = total;
     total += cdiv(p.cls[i].M, BM) * p.n_tiles;
   }

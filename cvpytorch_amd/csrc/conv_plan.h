@@ -19,6 +19,7 @@ struct IgemmClass {
   int M;                 // NB * OHi * OWi
   int tile_begin;        // first logical tile of this class (filled by the launcher)
   int64_t w_off;         // element offset of this class's weight image
+  unsigned ts_magic;     // ceil(2^32 / TS) for the branch-free tap decode (0 when TS <= 1)
   // provenance of the taps in the original kernel (used by the weight packer)
   int r0, r_step, s0, s_step;
 };
@@ -31,6 +32,7 @@ struct IgemmParams {
   int bias_n;  // number of valid bias entries (k_valid)
   float* stats;
   int NB, IH, IW, Cin, x_ld;
+  unsigned cin_magic;    // ceil(2^32 / Cin)
   int in_sh, in_sw;
   int Nout, y_ld, OH, OW, out_sh, out_sw;
   int n_tiles, total_tiles, ncls;
@@ -41,6 +43,9 @@ struct IgemmParams {
 inline int conv_out_dim(int in, int pad, int dil, int k, int stride) {
   return (in + 2 * pad - dil * (k - 1) - 1) / stride + 1;
 }
+
+// exact n / d for n, d < 2^16 as __umulhi(n, magic), magic = ceil(2^32 / d)  (d == 1 -> magic 0: caller returns n)
+inline unsigned div_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
 
 inline int gcd_(int a, int b) {
   while (b) {
