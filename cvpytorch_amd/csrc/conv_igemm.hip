@@ -22,6 +22,8 @@
 // tile's global loads issued before the MFMA block (cdna_hip_programming.md T14). LDS rows are
 // 64 B (32 bf16) with a 16-B-slot XOR swizzle that makes the ds_read_b128 fragment reads
 // conflict-free for the 4x16-lane groups of MI355X_MICROARCH.md §LDS.
+#include <stdlib.h>
+
 #include "common.h"
 #include "conv_plan.h"
 
@@ -277,7 +279,241 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   }
 }
 
+// =====================================================================================================
+// v2: the same implicit GEMM with LDS-DMA staging (global_load_lds_dwordx4: HBM/L2 -> LDS without a VGPR hop and
+// without ds_write instructions), a 3-deep LDS ring and ONE raw s_barrier per K step with a COUNTED s_waitcnt
+// vmcnt (cdna_hip_programming.md §5 "Pipelining across barriers", T3+T4): while tile kt is consumed, tiles kt+1
+// and kt+2 are in flight. The conv halo / K tail is zero-filled by pointing masked lanes at a 64-byte zero page.
+// The LDS image is lane-linear (DMA destination = wave base + lane*16), so the 16-B-slot XOR swizzle is applied to
+// the SOURCE address (which logical K-slot a lane fetches) and to the fragment reads (rule 21).
+// =====================================================================================================
+__device__ __attribute__((aligned(64))) unsigned int g_zero_page[16];
+
+#define CVHIP_GLDS16(src, dst)                                                                                  \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                       \
+                                   (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) {
+  constexpr int WAVES_N = BN / WN;
+  constexpr int WAVES_M = BM / WM;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+  constexpr int MF = WM / 16, NF = WN / 16;
+  constexpr int A_IT = BM / 64;
+  constexpr int B_ROWS = BN < 64 ? 64 : BN;  // B tile padded to >= 64 rows so all 4 waves issue the same DMA count
+  constexpr int B_IT = B_ROWS / 64;
+  constexpr int A_BYTES = BM * 64, B_BYTES = B_ROWS * 64, ST_BYTES = A_BYTES + B_BYTES;
+  constexpr int NST = 3;
+  constexpr int PER = A_IT + B_IT;  // DMA instructions per stage per wave
+
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  const int lt = xcd_remap(blockIdx.x, p.total_tiles);
+  int ci = 0;
+#pragma unroll 1
+  for (int i = 1; i < p.ncls; ++i)
+    if (lt >= p.cls[i].tile_begin) ci = i;
+  const IgemmClass& cl = p.cls[ci];
+  const int local = lt - cl.tile_begin;
+  const int mtile = local / p.n_tiles;
+  const int ntile = local - mtile * p.n_tiles;
+  const int m0 = mtile * BM, n0 = ntile * BN;
+  const int TR = cl.TR, TS = cl.TS;
+  const int Cin = p.Cin;
+  const int Ktot = TR * TS * Cin;
+  const int nk = (Ktot + 31) >> 5;
+  const int M = cl.M;
+  const int OWi = cl.OWi, OHWi = cl.OHi * cl.OWi;
+
+  int ih0[A_IT], iw0[A_IT], pbase[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int m = m0 + i * 64 + (t >> 2);
+    if (m < M) {
+      const int n = m / OHWi;
+      const int rem = m - n * OHWi;
+      const int oh = rem / OWi;
+      const int ow = rem - oh * OWi;
+      ih0[i] = oh * p.in_sh + cl.dh0;
+      iw0[i] = ow * p.in_sw + cl.dw0;
+      pbase[i] = n * p.IH * p.IW;
+    } else {
+      ih0[i] = -(1 << 28);
+      iw0[i] = 0;
+      pbase[i] = 0;
+    }
+  }
+  const unsigned cin_magic = p.cin_magic, ts_magic = cl.ts_magic;
+  auto fdiv = [](unsigned n, unsigned magic) -> unsigned { return magic ? __umulhi(n, magic) : n; };
+  const bf16_t* __restrict__ wbase = p.w + cl.w_off;
+  const bf16_t* const zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+
+  // physical 16-B slot of this lane inside its 64-B LDS row is (t&3); it must hold LOGICAL K-slot (t&3)^g(row>>2)
+  const int lslot = (t & 3) ^ ((0x78 >> (2 * ((t >> 4) & 3))) & 3);
+  const int swz_r = (lane >> 4) ^ ((0x78 >> (2 * ((lane >> 2) & 3))) & 3);
+
+  auto stage = [&](int kt, int st) {
+    const unsigned k = (unsigned)(kt * 32 + lslot * 8);
+    const unsigned tap = fdiv(k, cin_magic);
+    const int c0 = (int)(k - tap * (unsigned)Cin);
+    const unsigned tr = fdiv(tap, ts_magic);
+    const int ts = (int)(tap - tr * (unsigned)TS);
+    const bool tap_ok = (int)tr < TR;
+    const int dh = (int)tr * cl.dh_step, dw = ts * cl.dw_step;
+    unsigned char* const sA = smem + st * ST_BYTES;
+    unsigned char* const sB = sA + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int ih = ih0[i] + dh, iw = iw0[i] + dw;
+      const bool ok = tap_ok && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+      const bf16_t* src = ok ? (p.x + ((int64_t)(pbase[i] + ih * p.IW + iw) * p.x_ld + c0)) : zero;
+      CVHIP_GLDS16(src, sA + (i * 64 + wave * 16) * 64);
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int row = i * 64 + (t >> 2);
+      const int n = n0 + row;
+      const bool ok = row < BN && n < p.Nout && (int)k < Ktot;
+      const bf16_t* src = ok ? (wbase + ((int64_t)n * Ktot + k)) : zero;
+      CVHIP_GLDS16(src, sB + (i * 64 + wave * 16) * 64);
+    }
+  };
+
+  f32x4 acc[NF][MF];
+#pragma unroll
+  for (int a = 0; a < NF; ++a)
+#pragma unroll
+    for (int b = 0; b < MF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int a_row = wm * WM + (lane & 15);
+  const int b_row = wn * WN + (lane & 15);
+  auto compute = [&](int st) {
+    const unsigned char* const sA = smem + st * ST_BYTES;
+    const unsigned char* const sB = sA + A_BYTES;
+    bf16x8 xa[MF], wb[NF];
+#pragma unroll
+    for (int b = 0; b < MF; ++b) xa[b] = *reinterpret_cast<const bf16x8*>(sA + (a_row + b * 16) * 64 + swz_r * 16);
+#pragma unroll
+    for (int a = 0; a < NF; ++a) wb[a] = *reinterpret_cast<const bf16x8*>(sB + (b_row + a * 16) * 64 + swz_r * 16);
+#pragma unroll
+    for (int a = 0; a < NF; ++a)
+#pragma unroll
+      for (int b = 0; b < MF; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[a], xa[b], acc[a][b], 0, 0, 0);
+  };
+
+  stage(0, 0);
+  stage(1, 1);
+  int st_cur = 0, st_nxt2 = 2;
+  for (int kt = 0; kt < nk; ++kt) {
+    // this wave's DMAs of tile kt have landed when at most PER (= tile kt+1) remain outstanding ...
+    if constexpr (PER == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (PER == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    // ... and after the barrier everybody's have; it also proves all waves finished reading ring slot (kt+2)%3
+    __builtin_amdgcn_s_barrier();
+    stage(kt + 2, st_nxt2);  // past-the-end tiles decode to all-masked lanes (zero page): DMA counts stay uniform
+    compute(st_cur);
+    st_cur = st_cur == NST - 1 ? 0 : st_cur + 1;
+    st_nxt2 = st_nxt2 == NST - 1 ? 0 : st_nxt2 + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (all-zero) DMAs must land before smem is reused
+  __syncthreads();
+
+  const int nq = (lane >> 4) * 4;
+#pragma unroll
+  for (int b = 0; b < MF; ++b) {
+    const int m = m0 + wm * WM + b * 16 + (lane & 15);
+    if (m >= M) continue;
+    const int n_img = m / OHWi;
+    const int rem = m - n_img * OHWi;
+    const int oh = rem / OWi;
+    const int ow = rem - oh * OWi;
+    const int64_t opix = ((int64_t)n_img * p.OH + (oh * p.out_sh + cl.out_oh)) * p.OW + (ow * p.out_sw + cl.out_ow);
+    bf16_t* yrow = p.y + opix * p.y_ld;
+#pragma unroll
+    for (int a = 0; a < NF; ++a) {
+      const int n = n0 + wn * WN + a * 16 + nq;
+      if (n >= p.Nout) continue;
+      float v0 = acc[a][b][0], v1 = acc[a][b][1], v2 = acc[a][b][2], v3 = acc[a][b][3];
+      if (p.bias) {
+        if (n < p.bias_n) v0 += p.bias[n];
+        if (n + 1 < p.bias_n) v1 += p.bias[n + 1];
+        if (n + 2 < p.bias_n) v2 += p.bias[n + 2];
+        if (n + 3 < p.bias_n) v3 += p.bias[n + 3];
+      }
+      if (p.y_vec_ok && n + 3 < p.Nout) {
+        uint2 u;
+        u.x = pack2(v0, v1);
+        u.y = pack2(v2, v3);
+        *reinterpret_cast<uint2*>(yrow + n) = u;
+      } else {
+        yrow[n] = (bf16_t)v0;
+        if (n + 1 < p.Nout) yrow[n + 1] = (bf16_t)v1;
+        if (n + 2 < p.Nout) yrow[n + 2] = (bf16_t)v2;
+        if (n + 3 < p.Nout) yrow[n + 3] = (bf16_t)v3;
+      }
+    }
+  }
+
+  if (p.stats) {
+    float* red = reinterpret_cast<float*>(smem);  // [WAVES_M][BN][2]
+#pragma unroll
+    for (int a = 0; a < NF; ++a) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int b = 0; b < MF; ++b) {
+          const float v = acc[a][b][r];
+          s1 += v;
+          s2 += v * v;
+        }
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+          s1 += __shfl_xor(s1, off, 64);
+          s2 += __shfl_xor(s2, off, 64);
+        }
+        if ((lane & 15) == 0) {
+          const int nl = wn * WN + a * 16 + nq + r;
+          red[(wm * BN + nl) * 2 + 0] = s1;
+          red[(wm * BN + nl) * 2 + 1] = s2;
+        }
+      }
+    }
+    __syncthreads();
+    if (t < BN) {
+      const int n = n0 + t;
+      if (n < p.Nout) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES_M; ++w) {
+          s1 += red[(w * BN + t) * 2 + 0];
+          s2 += red[(w * BN + t) * 2 + 1];
+        }
+        float* dst = p.stats + (int64_t)mtile * 2 * p.Nout;
+        dst[n] = s1;
+        dst[p.Nout + n] = s2;
+      }
+    }
+  }
+}
+
 // ---- host side ----------------------------------------------------------------------------------
+
+static bool use_v1() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CVHIP_IGEMM_V1");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
 
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(IgemmParams& p, hipStream_t stream) {
@@ -292,7 +528,8 @@ static int launch_cfg(IgemmParams& p, hipStream_t stream) {
   }
   p.total_tiles = total;
   if (total == 0) return CVHIP_OK;
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), dim3(total), dim3(256), 0, stream, p);
+  if (use_v1()) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), dim3(total), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN>), dim3(total), dim3(256), 0, stream, p);
   return check_launch("igemm_kernel");
 }
 
