@@ -41,9 +41,11 @@ class KernelTimer:
     def __init__(self):
         self.enabled = False
         self.records = []  # (kernel name, algorithmic flops, algorithmic bytes, ev0, ev1)
+        self.detail = []   # (entry point, geometry) per record
 
     def reset(self):
         self.records = []
+        self.detail = []
 
     def summary(self):
         out = {}
@@ -81,6 +83,7 @@ def _timed_call(kname, geom, fname, *args):
     L.call(fname, *args)
     e1.record()
     TIMER.records.append((kname, flops, nbytes, e0, e1))
+    TIMER.detail.append((fname, geom))
 
 
 def _ptr(t):

@@ -1,0 +1,38 @@
+"""Dev tool: per-shape timing of every conv launch of one YOLOv5-s train step (eager, HIP events)."""
+import sys, os, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cvpytorch_amd import yolov5, ops
+from cvpytorch_amd.arena import FlatTrainState, FlatTrainStep
+from cvpytorch_amd.data import synthetic_detection_batch
+dev = torch.device("cuda:0")
+B = 64
+model = yolov5.YOLOv5(80, "s", max_targets=B * 20).to(dev).train()
+state = FlatTrainState(model, use_ema=False)
+step = FlatTrainStep(model, state)
+imgs, targets = synthetic_detection_batch(B, 640, device=dev)
+gts = yolov5.targets_to_tensor(targets, B * 20, dev)
+for _ in range(3):
+    step(imgs, gts)
+ops.TIMER.enabled = True
+ops.TIMER.reset()
+for _ in range(3):
+    step(imgs, gts)
+torch.cuda.synchronize()
+ops.TIMER.enabled = False
+agg = collections.OrderedDict()
+for (name, fl, by, e0, e1), (fn, geom) in zip(ops.TIMER.records, ops.TIMER.detail):
+    k = (fn.replace("cvhip_conv2d_", ""), geom, name)
+    d = agg.setdefault(k, [0, 0.0, fl, by])
+    d[0] += 1
+    d[1] += e0.elapsed_time(e1)
+rows = []
+for (fn, g, name), (n, ms, fl, by) in agg.items():
+    N, C, H, W, K, R, S, P, Q = g
+    us = 1e3 * ms / n
+    rows.append((ms / 3, fn, "%dx%d %d->%d k%d @%dx%d->%dx%d" % (N, 1, C, K, R, H, W, P, Q), n // 3, us, fl / us / 1e6, by / us / 1e3, name))
+rows.sort(reverse=True)
+tot = sum(r[0] for r in rows)
+print("total conv ms/step %.3f" % tot)
+for r in rows[:45]:
+    print("%6.3f ms/step  %-6s %-34s x%d  %8.1f us  %7.1f TF  %7.1f GB/s  %s" % r)
