@@ -66,19 +66,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const RedParams p) {
       }
     }
     if (active && cv < CV) {
-      for (int64_t r = r_begin + ty; r < r_end; r += rows_per_pass) {
-        f32x8 a, y;
-        if (vec) {
-          a = unpack8(*reinterpret_cast<const uint4*>(p.a + r * p.ld_a + cv * 8));
-          if (MODE == 1) y = unpack8(*reinterpret_cast<const uint4*>(p.y + r * p.ld_y + cv * 8));
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int c = cv * 8 + j;
-            a.v[j] = c < p.C ? (float)p.a[r * p.ld_a + c] : 0.f;
-            if (MODE == 1) y.v[j] = c < p.C ? (float)p.y[r * p.ld_y + c] : 0.f;
-          }
-        }
+      auto accum = [&](const f32x8& a, const f32x8& y) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           if (MODE == 0) {
@@ -94,6 +82,36 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const RedParams p) {
             s2[j] += du * xh;
           }
         }
+      };
+      int64_t r = r_begin + ty;
+      if (vec) {
+        // 4 rows per trip: 4-8 independent 16-B loads in flight per lane before any arithmetic (HBM latency hiding)
+        const int64_t stp = rows_per_pass;
+        for (; r + 3 * stp < r_end; r += 4 * stp) {
+          uint4 ua[4], uy[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            ua[q] = *reinterpret_cast<const uint4*>(p.a + (r + q * stp) * p.ld_a + cv * 8);
+            if (MODE == 1) uy[q] = *reinterpret_cast<const uint4*>(p.y + (r + q * stp) * p.ld_y + cv * 8);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) accum(unpack8(ua[q]), MODE == 1 ? unpack8(uy[q]) : f32x8{});
+        }
+      }
+      for (; r < r_end; r += rows_per_pass) {
+        f32x8 a, y;
+        if (vec) {
+          a = unpack8(*reinterpret_cast<const uint4*>(p.a + r * p.ld_a + cv * 8));
+          if (MODE == 1) y = unpack8(*reinterpret_cast<const uint4*>(p.y + r * p.ld_y + cv * 8));
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int c = cv * 8 + j;
+            a.v[j] = c < p.C ? (float)p.a[r * p.ld_a + c] : 0.f;
+            if (MODE == 1) y.v[j] = c < p.C ? (float)p.y[r * p.ld_y + c] : 0.f;
+          }
+        }
+        accum(a, y);
       }
     }
     // reduce over ty through LDS
@@ -284,21 +302,8 @@ __global__ __launch_bounds__(256) void ew_kernel(const EwParams p) {
         mu[j] = 0.f; is[j] = 1.f; k1[j] = 0.f; k2[j] = 0.f;
       }
     }
-    for (int64_t r = r_begin + ty; r < r_end; r += rows_per_pass) {
-      f32x8 a, y, rs, o;
-      if (vec) {
-        a = unpack8(*reinterpret_cast<const uint4*>(p.a + r * p.ld_a + c));
-        if (MODE == 1) y = unpack8(*reinterpret_cast<const uint4*>(p.y + r * p.ld_y + c));
-        if ((MODE == 0 || MODE == 3) && p.res) rs = unpack8(*reinterpret_cast<const uint4*>(p.res + r * p.ld_res + c));
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const bool ok = c + j < p.C;
-          a.v[j] = ok ? (float)p.a[r * p.ld_a + c + j] : 0.f;
-          if (MODE == 1) y.v[j] = ok ? (float)p.y[r * p.ld_y + c + j] : 0.f;
-          if ((MODE == 0 || MODE == 3) && p.res) rs.v[j] = ok ? (float)p.res[r * p.ld_res + c + j] : 0.f;
-        }
-      }
+    auto math = [&](const f32x8& a, const f32x8& y, const f32x8& rs) -> f32x8 {
+      f32x8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         if (MODE == 0) {
@@ -325,6 +330,44 @@ __global__ __launch_bounds__(256) void ew_kernel(const EwParams p) {
           o.v[j] = a.v[j] + rs.v[j];
         }
       }
+      return o;
+    };
+    int64_t r = r_begin + ty;
+    if (vec) {
+      // 4 rows per trip: all loads of the trip are issued before the arithmetic (bytes in flight per lane x4)
+      const int64_t stp = rows_per_pass;
+      const bool has_res = (MODE == 0 || MODE == 3) && p.res;
+      for (; r + 3 * stp < r_end; r += 4 * stp) {
+        uint4 ua[4], uy[4], ur[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          ua[q] = *reinterpret_cast<const uint4*>(p.a + (r + q * stp) * p.ld_a + c);
+          if (MODE == 1) uy[q] = *reinterpret_cast<const uint4*>(p.y + (r + q * stp) * p.ld_y + c);
+          if (has_res) ur[q] = *reinterpret_cast<const uint4*>(p.res + (r + q * stp) * p.ld_res + c);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x8 o = math(unpack8(ua[q]), MODE == 1 ? unpack8(uy[q]) : f32x8{}, has_res ? unpack8(ur[q]) : f32x8{});
+          *reinterpret_cast<uint4*>(p.out + (r + q * stp) * p.ld_out + c) = pack8(o);
+        }
+      }
+    }
+    for (; r < r_end; r += rows_per_pass) {
+      f32x8 a, y, rs;
+      if (vec) {
+        a = unpack8(*reinterpret_cast<const uint4*>(p.a + r * p.ld_a + c));
+        if (MODE == 1) y = unpack8(*reinterpret_cast<const uint4*>(p.y + r * p.ld_y + c));
+        if ((MODE == 0 || MODE == 3) && p.res) rs = unpack8(*reinterpret_cast<const uint4*>(p.res + r * p.ld_res + c));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bool ok = c + j < p.C;
+          a.v[j] = ok ? (float)p.a[r * p.ld_a + c + j] : 0.f;
+          if (MODE == 1) y.v[j] = ok ? (float)p.y[r * p.ld_y + c + j] : 0.f;
+          if ((MODE == 0 || MODE == 3) && p.res) rs.v[j] = ok ? (float)p.res[r * p.ld_res + c + j] : 0.f;
+        }
+      }
+      const f32x8 o = math(a, y, rs);
       if (vec) {
         *reinterpret_cast<uint4*>(p.out + r * p.ld_out + c) = pack8(o);
       } else {
