@@ -635,3 +635,21 @@ def convert_to_hip(module):
         if new_child is not child:
             out.add_module(name, new_child)
     return out
+
+
+class HipConvBN(nn.Sequential):
+    """`nn.Sequential(Conv2d(bias=False), BatchNorm2d)` (state_dict keys `0.*`, `1.*`) executed as ONE fused op — the shape
+    the reference uses for RepConv branches (yolov7_modules.py:187-195) and STDC's avd/skip layers (stdcnet.py:37-48)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, groups=1, act=L.ACT_NONE):
+        super().__init__(HipConv2d(in_channels, out_channels, kernel_size, stride, padding, groups=groups, bias=False),
+                         HipBN(out_channels))
+        self._act = act
+
+    def forward(self, x, residual=None):
+        conv, bn = self[0], self[1]
+        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        xx, w = conv._effective(x)
+        return ops.conv_bn_act(xx, w, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual,
+                               conv.make_cfg(self._act, 0.0, bn))

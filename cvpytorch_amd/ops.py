@@ -362,8 +362,9 @@ class ConvBnAct(torch.autograd.Function):
             dy_ld = Kp
         else:
             dy, dy_ld = dz, dz_ld
-            if dy_ld % 8 != 0 or (Kp != K and dy_ld < Kp):
-                # repack into a 16-byte-vectorisable pitch with zeroed pad channels
+            if dy_ld % 8 != 0 or dy.data_ptr() % 16 != 0 or (Kp != K and dy_ld < Kp):
+                # repack into a 16-byte-vectorisable pitch / base address (a channel slice of a cat gradient can start at any
+                # element) with zeroed pad channels
                 buf = zero_fill(torch.empty((N, P, Q, Kp), dtype=BF16, device=dev))
                 L.call("cvhip_copy2d", dy.data_ptr(), dy_ld, buf.data_ptr(), Kp, M, K, st)
                 dy, dy_ld = buf.permute(0, 3, 1, 2)[:, :K], Kp

@@ -1,0 +1,281 @@
+"""YOLOv7 on the HIP engine (BASELINE config 5): E-ELAN / DownA-B / SPPCSPC / UpSampling / FeatureFusion /
+RepConv blocks, neck, head, detect and the model wiring, with the reference's module tree and state_dict keys.
+
+  blocks  : src/models/modules/yolov7_modules.py:20-33 (Conv), :36-61 (DownA/DownB), :64-82 (EELAN), :85-95 (UpSampling),
+            :98-120 (FeatureFusion — conv4 applied three times, conv5/conv6 never called), :122-140 (SPPCSPC), :168-213 (RepConv)
+  neck    : src/models/necks/yolov7_neck.py:13-55          head : src/models/heads/yolov7_head.py:12-40
+  detect  : src/models/detects/yolov7_detect.py:71-122     model: src/models/yolov7.py:150-256
+The reference's backbone for this config is a stub (backbones/det/yolov7_csp_vovnet.py:46-56 builds empty stages; the yml
+names a class that does not exist): `YOLOv7Backbone` is the public YOLOv7-l layout built from the reference's blocks, whose
+outputs (512/1024/1024 @ /8,/16,/32) are what the reference neck's in_channels require (conf/coco_yolov7.yml:67).
+Loss for config 5: YOLOv5-style dense loss with YOLOv7 gains/anchors; the OTA loss is a "next" row.
+
+What differs from the reference is only how the glue executes: concats are slice copies into one NHWC buffer (ops.cat),
+UpSampling's nearest-x2 + cat is one kernel, RepConv's three-branch sum + SiLU is two fused passes.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import lib as L
+from . import ops
+from .bricks import HipBN, HipConv2d, HipConvBN, HipConvModule, HipMaxPool2d
+from .yolov5 import YOLOv5Loss, targets_to_tensor, non_max_suppression
+
+ANCHORS = [[[1.50000, 2.00000], [2.37500, 4.50000], [5.00000, 3.50000]],
+           [[2.25000, 4.68750], [4.75000, 3.43750], [4.50000, 9.12500]],
+           [[4.43750, 3.43750], [6.00000, 7.59375], [14.34375, 12.53125]]]
+
+
+def _torch_default_conv_init(conv):
+    conv.reset_parameters()
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+
+
+class Conv(HipConvModule):
+    """yolov7_modules.py:20-33: Conv2d(bias=False, autopad) + BatchNorm2d + SiLU, sub-modules `conv`, `bn`, (`act`)."""
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act=True):
+        super().__init__(c1, c2, k, stride=s, padding=(k // 2 if p is None else p), groups=g, norm_cfg=dict(type="BN"),
+                         act_cfg=dict(type="SiLU") if act is True else None)
+        _torch_default_conv_init(self.conv)
+
+
+class DownA(nn.Module):
+    def __init__(self, c1, c2):
+        super().__init__()
+        self.branch1 = nn.Sequential(HipMaxPool2d(kernel_size=2, stride=2), Conv(c1, c2, 1, 1))
+        self.branch2 = nn.Sequential(Conv(c1, c2, 1, 1), Conv(c2, c2, 3, 2))
+
+    def forward(self, x):
+        return ops.cat([self.branch1(x), self.branch2(x)])
+
+
+class DownB(DownA):
+    def forward(self, x, y):
+        return ops.cat([self.branch1(x), self.branch2(x), y])
+
+
+class EELAN(nn.Module):
+    def __init__(self, c1, c2, c3):
+        super().__init__()
+        self.conv1 = Conv(c1, c2, 1, 1)
+        self.conv2 = Conv(c1, c2, 1, 1)
+        self.conv3 = nn.Sequential(Conv(c2, c2, 3, 1), Conv(c2, c2, 3, 1))
+        self.conv4 = nn.Sequential(Conv(c2, c2, 3, 1), Conv(c2, c2, 3, 1))
+        self.conv5 = Conv(c2 * 4, c3, 1, 1)
+
+    def forward(self, x):
+        x1 = self.conv1(x)
+        x2 = self.conv2(x)
+        x3 = self.conv3(x2)
+        x4 = self.conv4(x3)
+        return self.conv5(ops.cat([x1, x2, x3, x4]))
+
+
+class UpSampling(nn.Module):
+    def __init__(self, c1, c2, c3):
+        super().__init__()
+        self.conv1 = Conv(c1, c3, 1, 1)
+        self.upsampling = nn.UpsamplingNearest2d(scale_factor=2)  # parameter-free; executed by cvhip_upsample2x_cat
+        self.conv2 = Conv(c2, c3, 1, 1)
+
+    def forward(self, x, y):
+        return ops.upsample2x_cat(self.conv1(x), self.conv2(y))
+
+
+class FeatureFusion(nn.Module):
+    def __init__(self, c1, c2):
+        super().__init__()
+        mid = c2 // 2
+        self.conv1 = Conv(c1, c2, 1, 1)
+        self.conv2 = Conv(c1, c2, 1, 1)
+        self.conv3 = Conv(c2, mid, 3, 1)
+        self.conv4 = Conv(mid, mid, 3, 1)
+        self.conv5 = Conv(mid, mid, 3, 1)  # in the state_dict, never called (yolov7_modules.py:113-120)
+        self.conv6 = Conv(mid, mid, 3, 1)
+        self.conv7 = Conv(c2 * 4, c2, 1, 1)
+
+    def forward(self, x):
+        x1 = self.conv1(x)
+        x2 = self.conv2(x)
+        x3 = self.conv3(x2)
+        x4 = self.conv4(x3)
+        x5 = self.conv4(x4)
+        x6 = self.conv4(x5)
+        return self.conv7(ops.cat([x1, x2, x3, x4, x5, x6]))
+
+
+class SPPCSPC(nn.Module):
+    def __init__(self, c1, c2, n=1, shortcut=False, g=1, e=0.5, k=(5, 9, 13)):
+        super().__init__()
+        c_ = int(2 * c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c1, c_, 1, 1)
+        self.cv3 = Conv(c_, c_, 3, 1)
+        self.cv4 = Conv(c_, c_, 1, 1)
+        self.m = nn.ModuleList([HipMaxPool2d(kernel_size=x, stride=1, padding=x // 2) for x in k])
+        self.cv5 = Conv(4 * c_, c_, 1, 1)
+        self.cv6 = Conv(c_, c_, 3, 1)
+        self.cv7 = Conv(2 * c_, c2, 1, 1)
+
+    def forward(self, x):
+        x1 = self.cv4(self.cv3(self.cv1(x)))
+        y1 = self.cv6(self.cv5(ops.cat([x1] + [m(x1) for m in self.m])))
+        return self.cv7(ops.cat([y1, self.cv2(x)]))
+
+
+class RepConv(nn.Module):
+    """Training-time RepConv: SiLU(BN(conv3x3(x)) + BN(conv1x1(x)) [+ BN(x)]) — yolov7_modules.py:168-213."""
+
+    def __init__(self, c1, c2, k=3, s=1, p=None, g=1, act=True, deploy=False):
+        super().__init__()
+        if deploy or k != 3 or g != 1:
+            raise L.CvhipError("RepConv: only the training-time k=3 form is built (re-parameterised deploy form: next row)")
+        self.in_channels, self.out_channels = c1, c2
+        self.act = nn.SiLU() if act is True else nn.Identity()
+        self._act = L.ACT_SILU if act is True else L.ACT_NONE
+        self.rbr_identity = HipBN(c1) if c2 == c1 and s == 1 else None
+        self.rbr_dense = HipConvBN(c1, c2, k, s, 1)
+        self.rbr_1x1 = HipConvBN(c1, c2, 1, s, 0)
+        for m in (self.rbr_dense[0], self.rbr_1x1[0]):
+            _torch_default_conv_init(m)
+
+    def forward(self, x):
+        a = self.rbr_dense(x)
+        b = self.rbr_1x1(x)
+        if self.rbr_identity is not None:
+            a = ops.add(a, self.rbr_identity(x))
+        return ops.add_act(a, b, self._act)
+
+
+def _bn_fix(module):
+    for m in module.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.eps, m.momentum = 1e-3, 0.03
+
+
+class YOLOv7Neck(nn.Module):
+    def __init__(self, in_channels=(512, 1024, 1024), out_channels=(128, 256, 512), depth_mul=1.0, width_mul=1.0):
+        super().__init__()
+        ic = [max(round(x * width_mul), 1) for x in in_channels]
+        oc = [max(round(x * width_mul), 1) for x in out_channels]
+        self.spp = SPPCSPC(ic[2], ic[0])
+        self.up1_1 = UpSampling(ic[0], ic[1], oc[1])
+        self.featurefusion1_1 = FeatureFusion(oc[1] * 2, oc[1])
+        self.up1_2 = UpSampling(oc[1], ic[0], oc[0])
+        self.featurefusion1_2 = FeatureFusion(oc[0] * 2, oc[0])
+        self.down2_1 = DownB(oc[0], oc[0])
+        self.featurefusion2_1 = FeatureFusion(oc[1] * 2, oc[1])
+        self.down2_2 = DownB(oc[1], oc[1])
+        self.featurefusion2_2 = FeatureFusion(oc[2] * 2, oc[2])
+        _bn_fix(self)
+
+    def forward(self, x):
+        x3, x4, x5 = x
+        x5 = self.spp(x5)
+        x4_up = self.featurefusion1_1(self.up1_1(x5, x4))
+        x3_up = self.featurefusion1_2(self.up1_2(x4_up, x3))
+        x4_down = self.featurefusion2_1(self.down2_1(x3_up, x4_up))
+        x5_down = self.featurefusion2_2(self.down2_2(x4_down, x5))
+        return [x3_up, x4_down, x5_down]
+
+
+class YOLOv7Head(nn.Module):
+    def __init__(self, in_channels=(128, 256, 512), out_channels=(256, 512, 1024), depth_mul=1.0, width_mul=1.0):
+        super().__init__()
+        ic = [int(x * width_mul) for x in in_channels]
+        oc = [int(x * width_mul) for x in out_channels]
+        self.conv1, self.conv2, self.conv3 = RepConv(ic[0], oc[0]), RepConv(ic[1], oc[1]), RepConv(ic[2], oc[2])
+        _bn_fix(self)
+
+    def forward(self, x):
+        return [self.conv1(x[0]), self.conv2(x[1]), self.conv3(x[2])]
+
+
+class YOLOv7Detect(nn.Module):
+    """yolov7_detect.py:71-122: same per-pixel 1x1 conv + (N,3,H,W,85) permute + sigmoid/grid/anchor decode as YOLOv5's."""
+
+    def __init__(self, num_classes=80, in_channels=(256, 512, 1024), stride=(8., 16., 32.), anchors=ANCHORS, depth_mul=1.0, width_mul=1.0):
+        super().__init__()
+        ic = [int(x * width_mul) for x in in_channels]
+        self.num_classes, self.num_outputs = num_classes, num_classes + 5
+        self.num_layers, self.num_anchors = len(anchors), len(anchors[0])
+        self.stride = list(stride)
+        a = torch.tensor(anchors).float().view(self.num_layers, -1, 2)
+        self.register_buffer("anchors", a)
+        self.register_buffer("anchor_grid", (a.clone() * torch.tensor(stride).view(-1, 1, 1)).view(self.num_layers, 1, -1, 1, 1, 2))
+        self.m = nn.ModuleList(HipConv2d(x, self.num_outputs * self.num_anchors, 1) for x in ic)
+        for mi, s in zip(self.m, self.stride):
+            b = mi.bias.view(self.num_anchors, -1)
+            b.data[:, 4] += math.log(8 / (640 / s) ** 2)
+            b.data[:, 5:] += math.log(0.6 / (self.num_classes - 0.99))
+            mi.bias = torch.nn.Parameter(b.view(-1), requires_grad=True)
+
+    def forward(self, x):
+        raw = [self.m[i](x[i]) for i in range(self.num_layers)]
+        train_out = [ops.head_permute(r, self.num_anchors, self.num_outputs) for r in raw]
+        if self.training:
+            return None, train_out
+        anchors_px = [self.anchors[i] * self.stride[i] for i in range(self.num_layers)]
+        return ops.yolov5_decode(raw, self.stride, anchors_px, self.num_anchors, self.num_outputs), train_out
+
+
+class YOLOv7Backbone(nn.Module):
+    def __init__(self, width_mul=1.0):
+        super().__init__()
+        w = lambda c: max(int(c * width_mul), 1)  # noqa: E731
+        self.stem = nn.Sequential(Conv(3, w(32), 3, 1), Conv(w(32), w(64), 3, 2), Conv(w(64), w(64), 3, 1))
+        self.stage1 = nn.Sequential(Conv(w(64), w(128), 3, 2), EELAN(w(128), w(64), w(256)))
+        self.stage2 = nn.Sequential(DownA(w(256), w(128)), EELAN(w(256), w(128), w(512)))
+        self.stage3 = nn.Sequential(DownA(w(512), w(256)), EELAN(w(512), w(256), w(1024)))
+        self.stage4 = nn.Sequential(DownA(w(1024), w(512)), EELAN(w(1024), w(256), w(1024)))
+        _bn_fix(self)
+
+    def forward(self, x):
+        x = self.stage1(self.stem(x))
+        p3 = self.stage2(x)
+        p4 = self.stage3(p3)
+        p5 = self.stage4(p4)
+        return [p3, p4, p5]
+
+
+class YOLOv7(nn.Module):
+    """src/models/yolov7.py:150-256. forward(imgs, targets, mode): 'train' -> losses dict; 'val' -> (losses, outputs)."""
+    anchors = ANCHORS
+
+    def __init__(self, num_classes=80, width_mul=1.0, max_targets=None):
+        super().__init__()
+        self.num_classes = num_classes
+        self.backbone = YOLOv7Backbone(width_mul)
+        self.neck = YOLOv7Neck(width_mul=width_mul)
+        self.head = YOLOv7Head(width_mul=width_mul)
+        self.detect = YOLOv7Detect(num_classes, width_mul=width_mul)
+        self.loss = YOLOv5Loss(num_classes, anchors=ANCHORS, hyp_box=0.05, hyp_obj=0.7, hyp_cls=0.3)
+        self.conf_thres, self.iou_thres = 0.001, 0.65
+        self.max_targets = max_targets
+        _bn_fix(self)
+
+    def forward_features(self, imgs):
+        return self.detect(self.head(self.neck(self.backbone(imgs))))
+
+    def loss_from_features(self, train_out, gts):
+        losses = {}
+        losses["loss"], st = self.loss(train_out, gts)
+        losses["box_loss"], losses["obj_loss"], losses["cls_loss"] = st[0], st[1], st[2]
+        return losses
+
+    def forward(self, imgs, targets=None, mode="infer", **kwargs):
+        if mode == "infer":
+            return
+        gts = targets if torch.is_tensor(targets) else targets_to_tensor(targets, self.max_targets, imgs.device)
+        out, train_out = self.forward_features(imgs)
+        losses = self.loss_from_features(train_out, gts)
+        if mode == "val":
+            outputs = []
+            if out is not None:
+                for pred in non_max_suppression(out, self.conf_thres, self.iou_thres, multi_label=True):
+                    outputs.append({"boxes": pred[:, :4], "labels": pred[:, 5], "scores": pred[:, 4]})
+            return losses, outputs
+        return losses

@@ -1,0 +1,109 @@
+"""GPU parity of the YOLOv7 blocks / neck / head / detect (BASELINE config 5) against the reference's golden
+vectors, and of the assembled YOLOv7-l (reduced width) train step against the oracle. Tolerances as tests/test_gpu_modules.py."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cvpytorch_amd import yolov7
+from test_gpu_modules import T, cosine, dev, load, lst, rel_l2
+
+V7_BLOCKS = {
+    "v7_eelan": lambda: yolov7.EELAN(16, 8, 32),
+    "v7_downa": lambda: yolov7.DownA(16, 8),
+    "v7_downb": lambda: yolov7.DownB(16, 16),
+    "v7_sppcspc": lambda: yolov7.SPPCSPC(32, 16),
+    "v7_upsampling": lambda: yolov7.UpSampling(16, 24, 8),
+    "v7_featurefusion": lambda: yolov7.FeatureFusion(16, 8),
+    "v7_repconv_id": lambda: yolov7.RepConv(16, 16),
+    "v7_repconv": lambda: yolov7.RepConv(16, 24),
+    "v7_neck": lambda: yolov7.YOLOv7Neck(width_mul=0.0625),
+    "v7_head": lambda: yolov7.YOLOv7Head(width_mul=0.0625),
+}
+LIST_ARG = {"v7_neck", "v7_head"}
+
+
+@pytest.mark.parametrize("name", sorted(V7_BLOCKS))
+def test_hip_v7_block_vs_reference_vectors(name):
+    g = load(name)
+    m = V7_BLOCKS[name]()
+    yolov7._bn_fix(m)
+    missing, unexpected = m.load_state_dict({kk: T(v) for kk, v in g["state"].items()}, strict=True)
+    assert not missing and not unexpected
+    m.to(dev()).train()
+    xs = [x.to(torch.bfloat16).to(dev()).contiguous(memory_format=torch.channels_last).requires_grad_(True) for x in lst(g["x"])]
+    out = m(xs) if name in LIST_ARG else m(*xs)
+    outs = list(out) if isinstance(out, (list, tuple)) else [out]
+    for o, e in zip(outs, lst(g["out"])):
+        assert tuple(o.shape) == tuple(e.shape)
+        assert rel_l2(o.float(), e) < 2.5e-2, rel_l2(o.float(), e)
+    loss = sum((o.float() * c.to(dev())).sum() for o, c in zip(outs, lst(g["cot"])))
+    named = [(n, p) for n, p in m.named_parameters()]
+    grads = torch.autograd.grad(loss, xs + [p for _, p in named], allow_unused=True)
+    for a, e in zip(grads[:len(xs)], lst(g["gx"])):
+        assert cosine(a.float(), e) > 0.99, cosine(a.float(), e)
+    deep = name in ("v7_neck",)
+    for (n, p), a in zip(named, grads[len(xs):]):
+        e = T(g["gparam"][n])
+        if a is None:  # FeatureFusion.conv5 / conv6 are never called
+            assert float(e.abs().max()) == 0.0, n
+            continue
+        assert cosine(a.float(), e) > (0.9 if deep else 0.98), (n, cosine(a.float(), e))
+
+
+def test_hip_v7_detect_vs_reference_vectors():
+    g = load("v7_detect")
+    m = yolov7.YOLOv7Detect(80, width_mul=0.0625)
+    missing, unexpected = m.load_state_dict({kk: T(v) for kk, v in g["state"].items()}, strict=True)
+    assert not missing and not unexpected
+    m.to(dev()).train()
+    xs = [x.to(torch.bfloat16).to(dev()).contiguous(memory_format=torch.channels_last) for x in lst(g["x"])]
+    _, tr = m(xs)
+    for o, e in zip(tr, lst(g["train_out"])):
+        assert tuple(o.shape) == tuple(e.shape)
+        assert rel_l2(o, e) < 2e-2
+    m.eval()
+    with torch.no_grad():
+        z, _ = m(xs)
+    assert rel_l2(z, T(g["z"])) < 2e-2
+
+
+def test_yolov7_end_to_end_vs_oracle():
+    """YOLOv7-l at quarter width (same topology, 2.4 M params): same weights, same synthetic batch -> loss within 2e-2 of
+    the fp32 oracle; gradients judged against the oracle's own CPU-bf16 run (see test_yolov5s_end_to_end_vs_oracle)."""
+    from oracle import torch_ref as R
+    from oracle import yolov7_ref as R7
+    torch.manual_seed(0)
+    ref = R7.YOLOv7(80, width_mul=0.25)
+    hip = yolov7.YOLOv7(80, width_mul=0.25, max_targets=64)
+    sd = ref.state_dict()
+    missing, unexpected = hip.load_state_dict(sd, strict=False)
+    assert all(k.startswith("loss.") for k in missing), missing
+    assert not unexpected, unexpected
+    imgs, targets = R.synthetic_batch(4, 128, seed=1029, max_boxes=10)
+    ref.train()
+    lr = ref(imgs, targets, "train")
+    lr["loss"].backward()
+    ref_bf = R7.YOLOv7(80, width_mul=0.25)
+    ref_bf.load_state_dict(sd)
+    ref_bf.train()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        lb = ref_bf(imgs, targets, "train")
+    lb["loss"].float().backward()
+    hip.to(dev()).train()
+    tg = [{k: v.to(dev()) for k, v in t.items()} for t in targets]
+    lh = hip(imgs.to(dev()), tg, "train")
+    lh["loss"].backward()
+    torch.cuda.synchronize()
+    for k in ("loss", "box_loss", "obj_loss", "cls_loss"):
+        a, b = float(lh[k]), float(lr[k])
+        assert abs(a - b) <= 2e-2 * abs(b) + 1e-4, (k, a, b)
+    rp = dict(ref.named_parameters())
+    cos = sorted((cosine(p.grad.float(), rp[n].grad), n) for n, p in hip.named_parameters() if p.grad is not None and n in rp and rp[n].grad is not None)
+    floor = sorted(cosine(p.grad.float(), rp[n].grad) for n, p in ref_bf.named_parameters() if p.grad is not None)
+    assert np.median([c for c, _ in cos]) > np.median(floor) - 0.05, (np.median([c for c, _ in cos]), np.median(floor), cos[:5])
+    rb = dict(ref.named_buffers())
+    for n, bf in hip.named_buffers():
+        if "running_var" in n and "conv5" not in n and "conv6" not in n:
+            assert rel_l2(bf.float(), rb[n]) < 3e-2, n

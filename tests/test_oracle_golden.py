@@ -217,3 +217,125 @@ def test_deeplabv3plus_head_and_ce():
         close(a, e, rtol=1e-3, atol=1e-8)
     for (n, _), a in zip(named, grads[2:]):
         close(a, g["gparam"][n], rtol=2e-3, atol=1e-8)
+
+
+# ------------------------------------------------------------------------------------------------------
+# YOLOX — fixtures from tools/gen_golden_more.py
+# ------------------------------------------------------------------------------------------------------
+from oracle import yolox_ref as RX  # noqa: E402
+
+
+class _ListArg(torch.nn.Module):
+    def __init__(self, m):
+        super().__init__()
+        self.m = m
+
+    def forward(self, *xs):
+        return self.m(list(xs))
+
+
+def test_yolox_backbone_n_full():
+    g = load("yolox_backbone_n")
+    m = RX.YOLOXCSPDarknet("cspdark_n")
+    load_state(m, g["state"])
+    m.train()
+    outs, _, gpar = run(m, [T(g["x"])], lst(g["cot"]))
+    for o, e in zip(outs, lst(g["out"])):
+        close(o, e, rtol=1e-4)
+    close(gpar["stem.conv.conv.weight"], g["g_stem"], rtol=1e-3)
+    for n, v in g["gparam_norms"].items():
+        assert abs(float(gpar[n].norm()) - float(v)) <= 1e-3 * max(1.0, float(v)), n
+
+
+def test_yolox_head():
+    g = load("yolox_head_n")
+    m = RX.YOLOXHead("yolox_n", num_classes=80, norm_cfg=BN_YOLO)
+    load_state(m, g["state"])
+    m.train()
+    outs, gx, gpar = run(_ListArg(m), lst(g["x"]), lst(g["cot"]))
+    for o, e in zip(outs, lst(g["out"])):
+        close(o, e, rtol=1e-4)
+    for a, e in zip(gx, lst(g["gx"])):
+        close(a, e, rtol=1e-4)
+    for n, v in g["gparam"].items():
+        close(gpar["m." + n], v, rtol=2e-4)
+
+
+@pytest.mark.parametrize("trial", [0, 1, 2])
+def test_yolox_loss(trial):
+    g = load("yolox_loss_%d" % trial)
+    p = [q.requires_grad_(True) for q in lst(g["p"])]
+    out, assigns = RX.YOLOXLoss(80)(p, T(g["targets"]), return_assign=True)
+    for k in ("loss", "conf_loss", "cls_loss", "iou_loss", "num_fg"):
+        close(out[k], g[k])
+    grads = torch.autograd.grad(out["loss"], p)
+    for a, e in zip(grads, lst(g["grads"])):
+        close(a, e, atol=1e-7)
+    rec = [a for a in assigns if a is not None]
+    assert len(rec) == len(g.get("fg", {}))
+    for i, (fg, mgt, miou) in enumerate(rec):
+        assert torch.equal(fg, T(g["fg"][str(i)]))
+        assert torch.equal(mgt, T(g["matched_gt"][str(i)]))
+        close(miou, g["matched_iou"][str(i)])
+
+
+def test_yolox_neck_shapes():
+    """YOLOXNeck cannot be built in the reference; the restatement is pinned by the shape contract of
+    yolox_neck.py:80-105 — three maps of out_channels at strides 8/16/32."""
+    m = RX.YOLOXNeck("yolox_n")
+    outs = m([torch.randn(1, 64, 8, 8), torch.randn(1, 128, 4, 4), torch.randn(1, 256, 2, 2)])
+    assert [tuple(o.shape) for o in outs] == [(1, 64, 8, 8), (1, 64, 4, 4), (1, 64, 2, 2)]
+
+
+# ------------------------------------------------------------------------------------------------------
+# YOLOv7 blocks (SURVEY §8a row 19)
+# ------------------------------------------------------------------------------------------------------
+from oracle import yolov7_ref as R7  # noqa: E402
+
+V7_BLOCKS = {
+    "v7_eelan": lambda: R7.EELAN(16, 8, 32),
+    "v7_downa": lambda: R7.DownA(16, 8),
+    "v7_downb": lambda: R7.DownB(16, 16),
+    "v7_sppcspc": lambda: R7.SPPCSPC(32, 16),
+    "v7_upsampling": lambda: R7.UpSampling(16, 24, 8),
+    "v7_featurefusion": lambda: R7.FeatureFusion(16, 8),
+    "v7_repconv_id": lambda: R7.RepConv(16, 16),
+    "v7_repconv": lambda: R7.RepConv(16, 24),
+    "v7_neck": lambda: _ListArg(R7.YOLOv7Neck(width_mul=0.0625)),
+    "v7_head": lambda: _ListArg(R7.YOLOv7Head(width_mul=0.0625)),
+}
+
+
+def _load_maybe_wrapped(m, state):
+    target = m.m if isinstance(m, _ListArg) else m
+    load_state(target, state)
+
+
+@pytest.mark.parametrize("name", sorted(V7_BLOCKS))
+def test_v7_block(name):
+    g = load(name)
+    m = V7_BLOCKS[name]()
+    R7._bn_fix(m)
+    _load_maybe_wrapped(m, g["state"])
+    m.train()
+    outs, gx, gpar = run(m, lst(g["x"]), lst(g["cot"]))
+    for o, e in zip(outs, lst(g["out"])):
+        close(o, e, rtol=1e-4)
+    for a, e in zip(gx, lst(g["gx"])):
+        close(a, e, rtol=2e-4)
+    pre = "m." if isinstance(m, _ListArg) else ""
+    for n, v in g["gparam"].items():
+        close(gpar[pre + n], v, rtol=5e-4)
+
+
+def test_v7_detect():
+    g = load("v7_detect")
+    m = R7.YOLOv7Detect(80, width_mul=0.0625)
+    load_state(m, g["state"])
+    m.train()
+    _, tr = m(lst(g["x"]))
+    for o, e in zip(tr, lst(g["train_out"])):
+        close(o, e)
+    m.eval()
+    z, _ = m(lst(g["x"]))
+    close(z, g["z"])
