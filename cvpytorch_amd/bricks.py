@@ -280,6 +280,27 @@ class HipAdaptiveAvgPool1x1(nn.Module):
         return ops.global_avg_pool(x)
 
 
+class HipAvgPool2d(nn.AvgPool2d):
+    """nn.AvgPool2d(k, stride, pad) with count_include_pad=True (torch default) == depthwise conv with constant 1/k^2
+    taps, so it runs on libcvhip's depthwise kernels (cvhip_dwconv2d_fprop / _dgrad). Used by STDC's CatBottleneck skip
+    (src/models/backbones/seg/stdcnet.py:92)."""
+
+    def forward(self, x):
+        k = self.kernel_size if isinstance(self.kernel_size, int) else self.kernel_size[0]
+        s = self.stride if isinstance(self.stride, int) else self.stride[0]
+        p = self.padding if isinstance(self.padding, int) else self.padding[0]
+        if self.ceil_mode or not self.count_include_pad or self.divisor_override is not None:
+            raise L.CvhipError("HipAvgPool2d: only floor mode with count_include_pad=True")
+        Cc = x.shape[1]
+        dw = self.__dict__.get("_dw")
+        if dw is None or dw.in_channels != Cc or dw.weight.device != x.device:
+            dw = HipConv2d(Cc, Cc, k, s, p, groups=Cc, bias=False).to(x.device)
+            dw.weight.data.fill_(1.0 / (k * k))
+            dw.weight.requires_grad_(False)
+            self.__dict__["_dw"] = dw  # not a registered sub-module: state_dict stays parameter-free like nn.AvgPool2d's
+        return dw(x)
+
+
 # ---- registrations: the reference's stock names (bricks/conv.py:8-9, norm.py:12-16, activation.py:13-30,
 # upsample.py:11-12) keep their stock torch classes; the Hip* names select the MI355X engine -------------
 CONV_LAYERS.register_module("Conv1d", module=nn.Conv1d)

@@ -679,6 +679,39 @@ class ScaleNC(torch.autograd.Function):
         return dx, None
 
 
+class ChannelScale(torch.autograd.Function):
+    """y[n,c,h,w] = x[n,c,h,w] * s[n,c]  with gradients to both (SE / attention-refinement gating:
+    src/models/necks/seg/stdc_neck.py:53-58,110-114). ds is a per-(n,c) reduction over the pixels."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        x, ld = as_nhwc(x)
+        N, Cc, H, W = x.shape
+        sf = s.reshape(N, Cc).float().contiguous()
+        y = empty_nhwc(N, Cc, H, W, x.device)
+        L.call("cvhip_scale_nc", x.data_ptr(), ld, sf.data_ptr(), y.data_ptr(), Cc, N, Cc, H * W, _stream())
+        ctx.save_for_backward(x, sf)
+        ctx.s_shape, ctx.s_dtype = tuple(s.shape), s.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, sf = ctx.saved_tensors
+        N, Cc, H, W = x.shape
+        dy, ld = as_nhwc(dy)
+        dx = ds = None
+        if ctx.needs_input_grad[0]:
+            dx = empty_nhwc(N, Cc, H, W, dy.device)
+            L.call("cvhip_scale_nc", dy.data_ptr(), ld, sf.data_ptr(), dx.data_ptr(), Cc, N, Cc, H * W, _stream())
+        if ctx.needs_input_grad[1]:
+            ds = (dy.float() * x.float()).sum(dim=(2, 3)).reshape(ctx.s_shape).to(ctx.s_dtype)
+        return dx, ds
+
+
+def channel_scale(x, s):
+    return ChannelScale.apply(x, s)
+
+
 def dropout2d(x, p, training=True):
     """nn.Dropout2d: whole channels of a sample are zeroed with probability p, survivors scaled by 1/(1-p)."""
     if not training or p <= 0.0:

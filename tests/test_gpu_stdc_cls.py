@@ -1,0 +1,115 @@
+"""GPU parity of the STDC backbone/neck against the reference's golden vectors, and of the
+Classification model (row 20, BASELINE config 1 shape) against the oracle. Tolerances as tests/test_gpu_modules.py."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cvpytorch_amd import classification, stdc
+from test_gpu_modules import T, cosine, dev, load, lst, rel_l2
+
+STDC_BLOCKS = {
+    "stdc_cat_s2": lambda: stdc.CatBottleneck(16, 32, 4, 2),
+    "stdc_cat_s1": lambda: stdc.CatBottleneck(32, 32, 4, 1),
+    "stdc_add_s2": lambda: stdc.AddBottleneck(16, 32, 4, 2),
+    "stdc_arm": lambda: stdc.AttentionRefinementModule(32, 16),
+    "stdc_ffm": lambda: stdc.FeatureFusionModule(48, 32),
+    "stdc_neck": lambda: stdc.STDCNeck(in_channels=[32, 64, 128], out_channels=32, aux_out_channels=16),
+}
+
+
+@pytest.mark.parametrize("name", sorted(STDC_BLOCKS))
+def test_hip_stdc_block_vs_reference_vectors(name):
+    g = load(name)
+    m = STDC_BLOCKS[name]()
+    missing, unexpected = m.load_state_dict({kk: T(v) for kk, v in g["state"].items()}, strict=True)
+    assert not missing and not unexpected
+    m.to(dev()).train()
+    xs = [x.to(torch.bfloat16).to(dev()).contiguous(memory_format=torch.channels_last).requires_grad_(True) for x in lst(g["x"])]
+    if name == "stdc_neck":
+        f, aux = m(xs)
+        outs = [f] + list(aux[1:])
+    else:
+        out = m(*xs)
+        outs = list(out) if isinstance(out, (list, tuple)) else [out]
+    # 1x1-spatial BN over a batch of 2 (ARM / conv_avg) normalises to exactly +-1: bf16 rounding of the inputs can move
+    # the result by more than the usual 2e-2 there, hence the wider output bound for the attention blocks
+    tol = 5e-2 if name in ("stdc_arm", "stdc_ffm", "stdc_neck") else 2.5e-2
+    for o, e in zip(outs, lst(g["out"])):
+        assert tuple(o.shape) == tuple(e.shape)
+        assert rel_l2(o.float(), e) < tol, rel_l2(o.float(), e)
+    loss = sum((o.float() * c.to(dev())).sum() for o, c in zip(outs, lst(g["cot"])))
+    named = [(n, p) for n, p in m.named_parameters()]
+    grads = torch.autograd.grad(loss, xs + [p for _, p in named], allow_unused=True)
+    for a, e in zip(grads[:len(xs)], lst(g["gx"])):
+        assert cosine(a.float(), e) > 0.98, cosine(a.float(), e)
+    cs = [cosine(a.float(), T(g["gparam"][n])) for (n, _), a in zip(named, grads[len(xs):]) if a is not None]
+    assert np.median(cs) > 0.98 and min(cs) > 0.85, (np.median(cs), min(cs))
+
+
+def test_hip_stdcnet_small_vs_reference_vectors():
+    g = load("stdc_net_small")
+    m = stdc.STDCNet("stdc1", out_channels=[8, 16, 64, 128, 256], layers=[2, 2, 2], block_num=4)
+    missing, unexpected = m.load_state_dict({kk: T(v) for kk, v in g["state"].items()}, strict=True)
+    assert not missing and not unexpected
+    m.to(dev()).train()
+    feats = m(T(g["x"]).to(dev()))
+    for f, e in zip(feats, lst(g["out"])):
+        assert tuple(f.shape) == tuple(e.shape)
+        assert rel_l2(f.float(), e) < 4e-2, rel_l2(f.float(), e)
+    loss = sum((f.float() * c.to(dev())).sum() for f, c in zip(feats, lst(g["cot"])))
+    loss.backward()
+    assert cosine(m.stem.conv.weight.grad.float(), T(g["g_stem"])) > 0.9
+    bad = []
+    for n, p in m.named_parameters():
+        ref = float(g["gparam_norms"][n])
+        got = float(p.grad.float().norm())
+        if abs(got - ref) > 0.25 * max(ref, 1e-3):
+            bad.append((n, got, ref))
+    assert len(bad) <= 5, bad[:8]
+
+
+def test_stdc1_full_structure_on_device():
+    s = load("stdc1_structure")
+    m = stdc.STDCNet("stdc1")
+    assert sorted(m.state_dict().keys()) == [str(k) for k in s["state_keys"]]
+    assert sum(p.numel() for p in m.parameters()) == int(s["n_params"][0])
+    m.to(dev()).train()
+    feats = m(torch.randn(1, 3, 64, 128, device=dev()))
+    assert [list(f.shape) for f in feats] == [list(map(int, r)) for r in s["shapes"]]
+
+
+def test_classification_resnet50_step_vs_oracle():
+    """BASELINE config 1 at reduced resolution: ResNet-50 + fc + CE, bs 8, 100 classes."""
+    from oracle import cls_ref as RC
+    torch.manual_seed(0)
+    dictionary = [{"c%d" % i: 1.0} for i in range(100)]
+    ref = RC.Classification(dictionary)
+    hip = classification.Classification(dictionary)
+    sd = {k: v for k, v in ref.state_dict().items() if not k.startswith("criterion.")}
+    missing, unexpected = hip.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    imgs, tg = RC.synthetic_cls_batch(8, 96, 100)
+    ref.train()
+    lr = ref(imgs, tg, "train")
+    lr["loss"].backward()
+    hip.to(dev()).train()
+    lh = hip(imgs.to(dev()), tg.to(dev()), "train")
+    lh["loss"].backward()
+    assert set(lh) == set(lr)
+    assert abs(float(lh["loss"]) - float(lr["loss"])) <= 3e-2 * abs(float(lr["loss"])), (float(lh["loss"]), float(lr["loss"]))
+    rp = dict(ref.named_parameters())
+    cos = sorted(cosine(p.grad.float(), rp[n].grad) for n, p in hip.named_parameters() if p.grad is not None)
+    ref_bf = RC.Classification(dictionary)
+    ref_bf.load_state_dict(ref.state_dict())
+    ref_bf.train()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        lb = ref_bf(imgs, tg, "train")
+    lb["loss"].float().backward()
+    floor = sorted(cosine(p.grad.float(), rp[n].grad) for n, p in ref_bf.named_parameters() if p.grad is not None)
+    assert np.median(cos) > np.median(floor) - 0.05, (np.median(cos), np.median(floor))
+    hip.eval()
+    with torch.no_grad():
+        probs = hip(imgs.to(dev()), None, "infer")
+    assert tuple(probs.shape) == (8, 100) and torch.allclose(probs.sum(1).cpu(), torch.ones(8), atol=1e-3)

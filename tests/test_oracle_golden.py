@@ -339,3 +339,65 @@ def test_v7_detect():
     m.eval()
     z, _ = m(lst(g["x"]))
     close(z, g["z"])
+
+
+# ------------------------------------------------------------------------------------------------------
+# STDC
+# ------------------------------------------------------------------------------------------------------
+from oracle import stdc_ref as RS  # noqa: E402
+
+
+class _FlatNeck(torch.nn.Module):
+    def __init__(self, m):
+        super().__init__()
+        self.m = m
+
+    def forward(self, *xs):
+        f, aux = self.m(list(xs))
+        return [f] + list(aux[1:])
+
+
+STDC_BLOCKS = {
+    "stdc_cat_s2": lambda: RS.CatBottleneck(16, 32, 4, 2),
+    "stdc_cat_s1": lambda: RS.CatBottleneck(32, 32, 4, 1),
+    "stdc_add_s2": lambda: RS.AddBottleneck(16, 32, 4, 2),
+    "stdc_arm": lambda: RS.AttentionRefinementModule(32, 16),
+    "stdc_ffm": lambda: RS.FeatureFusionModule(48, 32),
+    "stdc_neck": lambda: _FlatNeck(RS.STDCNeck(in_channels=[32, 64, 128], out_channels=32, aux_out_channels=16)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(STDC_BLOCKS))
+def test_stdc_block(name):
+    g = load(name)
+    m = STDC_BLOCKS[name]()
+    load_state(m.m if isinstance(m, _FlatNeck) else m, g["state"])
+    m.train()
+    outs, gx, gpar = run(m, lst(g["x"]), lst(g["cot"]))
+    for o, e in zip(outs, lst(g["out"])):
+        close(o, e, rtol=1e-4)
+    for a, e in zip(gx, lst(g["gx"])):
+        close(a, e, rtol=2e-4)
+    pre = "m." if isinstance(m, _FlatNeck) else ""
+    for n, v in g["gparam"].items():
+        close(gpar[pre + n], v, rtol=5e-4)
+
+
+def test_stdc_net_small_and_structure():
+    g = load("stdc_net_small")
+    m = RS.STDCNet("stdc1", out_channels=[8, 16, 64, 128, 256], layers=[2, 2, 2], block_num=4)
+    load_state(m, g["state"])
+    m.train()
+    outs, _, gpar = run(m, [T(g["x"])], lst(g["cot"]))
+    for o, e in zip(outs, lst(g["out"])):
+        close(o, e, rtol=1e-4)
+    close(gpar["stem.conv.weight"], g["g_stem"], rtol=1e-3)
+    for n, v in g["gparam_norms"].items():
+        assert abs(float(gpar[n].norm()) - float(v)) <= 1e-3 * max(1.0, float(v)), n
+    s = load("stdc1_structure")
+    full = RS.STDCNet("stdc1")
+    assert sorted(full.state_dict().keys()) == [str(k) for k in s["state_keys"]]
+    assert sum(p.numel() for p in full.parameters()) == int(s["n_params"][0])
+    full.train()
+    feats = full(torch.randn(1, 3, 64, 128))
+    assert [list(f.shape) for f in feats] == [list(map(int, r)) for r in s["shapes"]]

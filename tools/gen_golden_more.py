@@ -152,6 +152,23 @@ def stdc():
     module_case("stdc_arm", AttentionRefinementModule(32, 16), [torch.randn(2, 32, 6, 7)])
     torch.manual_seed(56)
     module_case("stdc_ffm", FeatureFusionModule(48, 32), [torch.randn(2, 32, 6, 7), torch.randn(2, 16, 6, 7)])
+    from src.models.necks.seg.stdc_neck import STDCNeck
+    torch.manual_seed(58)
+    neck = STDCNeck(in_channels=[32, 64, 128], out_channels=32, aux_out_channels=16)
+
+    class _Flat(torch.nn.Module):  # (feat, [aux...]) -> flat tuple of tensors
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+
+        def forward(self, *xs):
+            f, aux = self.m(list(xs))
+            return [f] + list(aux[1:])
+
+    state0 = {k: v.clone() for k, v in neck.state_dict().items()}
+    xs = [torch.randn(2, 32, 8, 12), torch.randn(2, 64, 4, 6), torch.randn(2, 128, 2, 3)]
+    outs, cots, gin, gpar = run_module(_Flat(neck), xs)
+    save("stdc_neck", x=xs, state=state0, out=outs, cot=cots, gx=gin, gparam={k[2:]: v for k, v in gpar.items()})
     # full-size structure facts for STDC1 (parameter names / count / output shapes)
     torch.manual_seed(57)
     full = STDCNet("stdc1")
