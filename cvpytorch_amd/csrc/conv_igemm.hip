@@ -293,7 +293,8 @@ __device__ __attribute__((aligned(64))) unsigned int g_zero_page[16];
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                       \
                                    (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
-template <int BM, int BN, int WM, int WN>
+// ABL: profiling ablation (CVHIP_IGEMM_ABLATE): 0 = the kernel, 1 = staging only (no LDS reads / MFMA), 2 = compute only
+template <int BM, int BN, int WM, int WN, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) {
   constexpr int WAVES_N = BN / WN;
   constexpr int WAVES_M = BM / WM;
@@ -417,8 +418,8 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) 
     else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     // ... and after the barrier everybody's have; it also proves all waves finished reading ring slot (kt+2)%3
     __builtin_amdgcn_s_barrier();
-    stage(kt + 2, st_nxt2);  // past-the-end tiles decode to all-masked lanes (zero page): DMA counts stay uniform
-    compute(st_cur);
+    if (ABL != 2) stage(kt + 2, st_nxt2);  // past-the-end tiles decode to all-masked lanes (zero page): DMA counts stay uniform
+    if (ABL != 1) compute(st_cur);
     st_cur = st_cur == NST - 1 ? 0 : st_cur + 1;
     st_nxt2 = st_nxt2 == NST - 1 ? 0 : st_nxt2 + 1;
   }
@@ -506,6 +507,15 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) 
 
 // ---- host side ----------------------------------------------------------------------------------
 
+static int ablate_mode() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CVHIP_IGEMM_ABLATE");
+    v = (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0;
+  }
+  return v;
+}
+
 static bool use_v1() {
   static int v = -1;
   if (v < 0) {
@@ -529,6 +539,8 @@ static int launch_cfg(IgemmParams& p, hipStream_t stream) {
   p.total_tiles = total;
   if (total == 0) return CVHIP_OK;
   if (use_v1()) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), dim3(total), dim3(256), 0, stream, p);
+  else if (ablate_mode() == 1) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 1>), dim3(total), dim3(256), 0, stream, p);
+  else if (ablate_mode() == 2) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 2>), dim3(total), dim3(256), 0, stream, p);
   else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN>), dim3(total), dim3(256), 0, stream, p);
   return check_launch("igemm_kernel");
 }

@@ -239,6 +239,16 @@ class ConvBnAct(torch.autograd.Function):
         K, Cg, R, S = weight.shape
         dev = x.device
         depthwise = cfg.groups != 1
+        c_orig = Cc
+        if not depthwise and Cc == Cg and (Cc % 8 != 0 or x_ld % 8 != 0 or x.data_ptr() % 16 != 0):
+            # the MFMA gather reads 16-byte channel vectors: repack odd channel counts / pitches / slice offsets into a
+            # zero-padded [N,H,W,round8(C)] buffer (the packers pad the weight to match: cvhip_conv_desc.c_valid)
+            Cp = _round8(Cc)
+            xp = torch.empty((N, H, W, Cp), dtype=BF16, device=dev)
+            if Cp != Cc:
+                zero_fill(xp)
+            L.call("cvhip_copy2d", x.data_ptr(), x_ld, xp.data_ptr(), Cp, N * H * W, Cc, _stream())
+            x, x_ld, Cc = xp.permute(0, 3, 1, 2), Cp, Cp
         if depthwise and not (cfg.groups == Cc == K and Cg == 1):
             raise L.CvhipError("grouped conv other than depthwise is not supported by the HIP engine")
         if not depthwise and Cc != Cg and Cc != _round8(Cg):
@@ -308,6 +318,7 @@ class ConvBnAct(torch.autograd.Function):
             z = y
         ctx.cfg = cfg
         ctx.geom = (N, Cc, H, W, K, R, S, P, Q, Kp, x_ld, Cg)
+        ctx.c_orig = c_orig
         ctx.train_bn = train_bn
         ctx.depthwise = depthwise
         ctx.has_bias = bias is not None
@@ -435,6 +446,8 @@ class ConvBnAct(torch.autograd.Function):
         if dw is not None and dw.dtype != weight.dtype:
             dw = dw.to(weight.dtype)
         dres = dz if ctx.has_res else None
+        if dx is not None and ctx.c_orig != Cc:
+            dx = dx[:, :ctx.c_orig]  # channel slice of the padded gradient buffer (an NHWC view with ld = round8(C))
         return dx, dw, dbias, (dgamma if need_dg else None), (dbeta if need_dbeta else None), None, None, dres, None
 
 
