@@ -20,7 +20,7 @@ import torch.nn as nn
 
 from . import lib as L
 from . import ops
-from .bricks import HipBN, HipConv2d, HipConvBN, HipConvModule, HipMaxPool2d
+from .bricks import HipBN, HipConv2d, HipConvBN, HipConvModule, HipMaxPool2d, HipSiLU
 from .yolov5 import YOLOv5Loss, targets_to_tensor, non_max_suppression
 
 ANCHORS = [[[1.50000, 2.00000], [2.37500, 4.50000], [5.00000, 3.50000]],
@@ -134,8 +134,7 @@ class RepConv(nn.Module):
         if deploy or k != 3 or g != 1:
             raise L.CvhipError("RepConv: only the training-time k=3 form is built (re-parameterised deploy form: next row)")
         self.in_channels, self.out_channels = c1, c2
-        self.act = nn.SiLU() if act is True else nn.Identity()
-        self._act = L.ACT_SILU if act is True else L.ACT_NONE
+        self.act = HipSiLU() if act is True else nn.Identity()
         self.rbr_identity = HipBN(c1) if c2 == c1 and s == 1 else None
         self.rbr_dense = HipConvBN(c1, c2, k, s, 1)
         self.rbr_1x1 = HipConvBN(c1, c2, 1, s, 0)
@@ -143,11 +142,15 @@ class RepConv(nn.Module):
             _torch_default_conv_init(m)
 
     def forward(self, x):
+        # every branch sum rides in the next branch's BN-apply pass (the `residual` operand of cvhip_bn_act_fwd)
         a = self.rbr_dense(x)
-        b = self.rbr_1x1(x)
-        if self.rbr_identity is not None:
-            a = ops.add(a, self.rbr_identity(x))
-        return ops.add_act(a, b, self._act)
+        bn = self.rbr_identity
+        if bn is not None:
+            if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+            a = ops.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, a, True, bn.training or bn.running_mean is None,
+                           bn.momentum, bn.eps, L.ACT_NONE, 0.0, bn.track_running_stats and bn.training)
+        return self.act(self.rbr_1x1(x, residual=a))
 
 
 def _bn_fix(module):

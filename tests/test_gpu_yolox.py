@@ -88,9 +88,14 @@ def test_dense_simota_on_device_equals_reference_vectors(trial):
 
 
 def test_yolox_s_end_to_end_vs_oracle():
-    """Full YOLOX-s train step on a seeded synthetic batch: loss terms within 2e-2 of the fp32 oracle unless the bf16
-    perturbation of the head maps flips a SimOTA match (then num_fg differs and the criterion is the CPU-bf16 floor);
-    gradients compared with the oracle's own bf16-autocast run as in test_yolov5s_end_to_end_vs_oracle."""
+    """Full YOLOX-s on a seeded synthetic batch, same weights as the oracle. SimOTA on a randomly initialised network is a
+    near-tie contest, so an end-to-end loss/gradient comparison would measure how bf16 noise flips matches, not the engine.
+    The step is therefore checked in three well-conditioned pieces:
+      1. head maps: HIP vs fp32 oracle, rel-L2 within max(5e-2, 1.5 x the oracle's own CPU-bf16 floor);
+      2. loss: the HIP model's loss equals the ORACLE loss evaluated on the HIP model's own head maps (same inputs ->
+         same assignment) to 1e-3;
+      3. gradients: one fixed cotangent (the oracle's dLoss/dmaps) is back-propagated through both networks; per-parameter
+         cosine vs the fp32 oracle judged against the CPU-bf16 floor, as in test_yolov5s_end_to_end_vs_oracle."""
     from oracle import yolox_ref as RX
     torch.manual_seed(0)
     ref = RX.YOLOX(80, "s")
@@ -99,27 +104,37 @@ def test_yolox_s_end_to_end_vs_oracle():
     missing, unexpected = hip.load_state_dict(sd, strict=False)
     assert not missing and not unexpected, (missing, unexpected)
     imgs, targets = RX.synthetic_batch(4, 128, seed=1029, max_boxes=10)
+    gts = RX.targets_to_padded(targets)
     ref.train()
-    lr = ref(imgs, targets, "train")
-    lr["loss"].backward()
+    maps_ref = ref.head(ref.neck(ref.backbone(imgs)))
+    loss_ref = ref.loss(maps_ref, gts)["loss"]
+    cots = torch.autograd.grad(loss_ref, maps_ref, retain_graph=True)
+    torch.autograd.backward(maps_ref, grad_tensors=cots)
     ref_bf = RX.YOLOX(80, "s")
     ref_bf.load_state_dict(sd)
     ref_bf.train()
     with torch.autocast("cpu", dtype=torch.bfloat16):
-        lb = ref_bf(imgs, targets, "train")
-    lb["loss"].float().backward()
+        maps_bf = ref_bf.head(ref_bf.neck(ref_bf.backbone(imgs)))
+    floor_maps = [rel_l2(a.float(), b) for a, b in zip(maps_bf, maps_ref)]
+    torch.autograd.backward([m.float() for m in maps_bf], grad_tensors=cots)
+
     hip.to(dev()).train()
-    tg = [{k: v.to(dev()) for k, v in t.items()} for t in targets]
-    lh = hip(imgs.to(dev()), tg, "train")
-    lh["loss"].backward()
+    _, feats = hip.forward_features(imgs.to(dev()))
+    hw = hip._hw
+    maps_hip = [f.view(f.shape[0], h, w, -1).permute(0, 3, 1, 2) for f, (h, w) in zip(feats, hw)]
+    for a, b, fl in zip(maps_hip, maps_ref, floor_maps):
+        assert rel_l2(a.float(), b) < max(5e-2, 1.5 * fl), (rel_l2(a.float(), b), fl)
+    lh = hip.loss_from_features(feats, gts.to(dev()))
+    lo = RX.YOLOXLoss(80)([m.detach().cpu().contiguous() for m in maps_hip], gts)
+    for k in ("loss", "iou_loss", "conf_loss", "cls_loss"):
+        assert abs(float(lh[k]) - float(lo[k])) <= 1e-3 * abs(float(lo[k])) + 1e-5, (k, float(lh[k]), float(lo[k]))
+    torch.autograd.backward(feats, grad_tensors=[c.permute(0, 2, 3, 1).reshape(f.shape).to(dev()) for c, f in zip(cots, feats)])
     torch.cuda.synchronize()
-    floor_loss = abs(float(lb["loss"]) - float(lr["loss"])) / abs(float(lr["loss"]))
-    a, b = float(lh["loss"]), float(lr["loss"])
-    assert abs(a - b) <= max(2e-2, 2.0 * floor_loss) * abs(b), (a, b, floor_loss)
     rp = dict(ref.named_parameters())
     cos = sorted((cosine(p.grad.float(), rp[n].grad), n) for n, p in hip.named_parameters() if p.grad is not None and n in rp)
     floor = sorted(cosine(p.grad.float(), rp[n].grad) for n, p in ref_bf.named_parameters() if p.grad is not None)
-    assert np.median([c for c, _ in cos]) > np.median(floor) - 0.05, (np.median([c for c, _ in cos]), np.median(floor), cos[:5])
+    assert np.median([c for c, _ in cos]) > np.median(floor) - 0.03, (np.median([c for c, _ in cos]), np.median(floor), cos[:5])
+    assert cos[0][0] > floor[0] - 0.15, (cos[:5], floor[:5])
     rb = dict(ref.named_buffers())
     for n, bf in hip.named_buffers():
         if "running_var" in n:

@@ -149,9 +149,9 @@ def stdc():
     save("stdc_net_small", x=x, state=state0, out=outs, cot=cots, gparam_norms={k: v.norm() for k, v in gpar.items()},
          g_stem=gpar["stem.conv.weight"])
     torch.manual_seed(55)
-    module_case("stdc_arm", AttentionRefinementModule(32, 16), [torch.randn(2, 32, 6, 7)])
+    module_case("stdc_arm", AttentionRefinementModule(32, 16), [torch.randn(6, 32, 6, 7)])  # 1x1-spatial BN: needs a batch > 2
     torch.manual_seed(56)
-    module_case("stdc_ffm", FeatureFusionModule(48, 32), [torch.randn(2, 32, 6, 7), torch.randn(2, 16, 6, 7)])
+    module_case("stdc_ffm", FeatureFusionModule(48, 32), [torch.randn(6, 32, 6, 7), torch.randn(6, 16, 6, 7)])
     from src.models.necks.seg.stdc_neck import STDCNeck
     torch.manual_seed(58)
     neck = STDCNeck(in_channels=[32, 64, 128], out_channels=32, aux_out_channels=16)
@@ -166,7 +166,7 @@ def stdc():
             return [f] + list(aux[1:])
 
     state0 = {k: v.clone() for k, v in neck.state_dict().items()}
-    xs = [torch.randn(2, 32, 8, 12), torch.randn(2, 64, 4, 6), torch.randn(2, 128, 2, 3)]
+    xs = [torch.randn(6, 32, 8, 12), torch.randn(6, 64, 4, 6), torch.randn(6, 128, 2, 3)]
     outs, cots, gin, gpar = run_module(_Flat(neck), xs)
     save("stdc_neck", x=xs, state=state0, out=outs, cot=cots, gx=gin, gparam={k[2:]: v for k, v in gpar.items()})
     # full-size structure facts for STDC1 (parameter names / count / output shapes)
