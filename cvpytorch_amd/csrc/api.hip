@@ -162,6 +162,45 @@ __global__ void probe_mfma_kernel(const bf16_t* a, const bf16_t* b, float* d) {
   for (int r = 0; r < 4; ++r) d[(4 * (l >> 4) + r) * 16 + (l & 15)] = c[r];
 }
 
+// LDS read-bandwidth probe: the igemm main loop's ds_read_b128 pattern without MFMA / staging.
+//   mode 0: the kernel's swizzled fragment reads   mode 1: same rows, no swizzle   mode 2: linear lane*16 (conflict-free by construction)
+//   mode 3: swizzled pattern issued as 2 x ds_read_b64
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void probe_lds_bw_kernel(float* out, int iters) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[49152];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int i = t; i < 49152 / 4; i += 256) reinterpret_cast<unsigned*>(smem)[i] = i * 2654435761u;
+  __syncthreads();
+  const int wm = wave >> 1, wn = wave & 1;
+  const int swz = (MODE == 1) ? (lane >> 4) : ((lane >> 4) ^ ((0x78 >> (2 * ((lane >> 2) & 3))) & 3));
+  const int a_row = wm * 64 + (lane & 15), b_row = wn * 64 + (lane & 15);
+  unsigned acc = 0;
+  for (int it = 0; it < iters; ++it) {
+    const unsigned char* sA = smem + (it % 3) * 16384;
+    const unsigned char* sB = sA + 8192;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (MODE == 2) {
+        const uint4 u = *reinterpret_cast<const uint4*>(sA + j * 1024 + lane * 16 + wave * 4096 % 8192);
+        const uint4 v = *reinterpret_cast<const uint4*>(sB + j * 1024 + lane * 16);
+        acc ^= u.x ^ u.w ^ v.y ^ v.z;
+      } else if (MODE == 3) {
+        const uint2 u0 = *reinterpret_cast<const uint2*>(sA + (a_row + j * 16) * 64 + swz * 16);
+        const uint2 u1 = *reinterpret_cast<const uint2*>(sA + (a_row + j * 16) * 64 + swz * 16 + 8);
+        const uint2 v0 = *reinterpret_cast<const uint2*>(sB + (b_row + j * 16) * 64 + swz * 16);
+        const uint2 v1 = *reinterpret_cast<const uint2*>(sB + (b_row + j * 16) * 64 + swz * 16 + 8);
+        acc ^= u0.x ^ u1.y ^ v0.y ^ v1.x;
+      } else {
+        const uint4 u = *reinterpret_cast<const uint4*>(sA + (a_row + j * 16) * 64 + swz * 16);
+        const uint4 v = *reinterpret_cast<const uint4*>(sB + (b_row + j * 16) * 64 + swz * 16);
+        acc ^= u.x ^ u.w ^ v.y ^ v.z;
+      }
+    }
+  }
+  if (acc == 0x12345678u) out[blockIdx.x] = 1.f;
+}
+
+
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
 __global__ void probe_tr16_kernel(const bf16_t* in, bf16_t* out) {
   // in: 64 lanes x 4 bf16 written linearly to LDS (lane l at byte l*8); every lane then issues
@@ -316,6 +355,19 @@ int cvhip_probe_ds_read_tr16(const void* in, void* out, void* stream) {
   if (!in || !out) return CVHIP_ERR_INVALID;
   hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out);
   return check_launch("probe_tr16_kernel");
+}
+
+int cvhip_probe_lds_read_bw(int32_t mode, int32_t iters, int32_t blocks, float* out, void* stream) {
+  if (!out || iters <= 0 || blocks <= 0) return CVHIP_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  switch (mode) {
+    case 0: hipLaunchKernelGGL(probe_lds_bw_kernel<0>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+    case 1: hipLaunchKernelGGL(probe_lds_bw_kernel<1>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+    case 2: hipLaunchKernelGGL(probe_lds_bw_kernel<2>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+    case 3: hipLaunchKernelGGL(probe_lds_bw_kernel<3>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+    default: return CVHIP_ERR_INVALID;
+  }
+  return check_launch("probe_lds_bw_kernel");
 }
 
 }  // extern "C"

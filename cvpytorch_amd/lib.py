@@ -95,6 +95,7 @@ SIGNATURES = {
     "cvhip_ema_update": (_i32, [_p, _p, _i64, _f32, _p, _p]),
     "cvhip_probe_mfma_16x16x32": (_i32, [_p, _p, _p, _p]),
     "cvhip_probe_ds_read_tr16": (_i32, [_p, _p, _p]),
+    "cvhip_probe_lds_read_bw": (_i32, [_i32, _i32, _i32, _p, _p]),
 }
 
 _lib = None

@@ -334,6 +334,9 @@ int cvhip_ema_update(float* ema, const float* src, int64_t n, float decay, const
 int cvhip_probe_mfma_16x16x32(const void* a_bf16_16x32, const void* b_bf16_32x16, float* d_16x16,
                               void* stream);
 int cvhip_probe_ds_read_tr16(const void* in_bf16_64x4, void* out_bf16_64x4, void* stream);
+/* LDS read-bandwidth probe (dev tool, tools/lds_probe.py): `blocks` x 256 threads issue the implicit-GEMM main loop's
+ * ds_read_b128 fragment pattern `iters` times. mode 0 swizzled, 1 unswizzled, 2 linear, 3 as 2 x ds_read_b64. */
+int cvhip_probe_lds_read_bw(int32_t mode, int32_t iters, int32_t blocks, float* out, void* stream);
 
 #ifdef __cplusplus
 }

