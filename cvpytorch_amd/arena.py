@@ -242,6 +242,7 @@ class FlatTrainStep:
     def __init__(self, model, state, sync_buffers=False):
         self.model, self.state, self.sync_buffers = model, state, sync_buffers
         self.g1 = self.g2 = None
+        self.static_losses = None
         self.static_imgs = self.static_targets = None
         self.feats = self.g_feats = None
 
@@ -277,6 +278,17 @@ class FlatTrainStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         pool = torch.cuda.graph_pool_handle()
+        if getattr(m, "loss_capturable", False):
+            # the loss is libcvhip kernels too (no torch autograd ops): the whole step is ONE graph
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                _, feats = m.forward_features(self.static_imgs)
+                losses = m.loss_from_features(feats, self.static_targets)
+                losses["loss"].backward()
+                st.step_kernels()
+            self.static_losses = losses
+            self.g1, self.g2 = g, None
+            return
         g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1, pool=pool):
             _, feats = m.forward_features(self.static_imgs)
@@ -297,6 +309,9 @@ class FlatTrainStep:
                 self.static_targets.copy_(targets, non_blocking=True)
             st.pre_step()
             self.g1.replay()
+            if self.g2 is None:  # single-graph step
+                st.post_step()
+                return self.static_losses
             p = [f.detach().requires_grad_(True) for f in self.feats]
             losses = self.model.loss_from_features(p, self.static_targets)
             grads = torch.autograd.grad(losses["loss"], p)

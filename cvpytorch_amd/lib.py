@@ -36,8 +36,14 @@ class ConvDesc(C.Structure):
         return tuple(getattr(self, n) for n, _ in self._fields_)
 
 
+class YoloLossDesc(C.Structure):
+    """cvhip_yolo_loss_desc (include/cvhip.h)."""
+    _fields_ = [(n, C.c_int32) for n in ("N", "A", "NO", "H", "W", "ld", "T")] + [("anchor_t", C.c_float), ("anchors", C.c_float * 16)]
+
+
 _p, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _dp = C.POINTER(ConvDesc)
+_ylp = C.POINTER(YoloLossDesc)
 
 # name -> (restype, argtypes); mirrors include/cvhip.h one-to-one
 SIGNATURES = {
@@ -93,6 +99,10 @@ SIGNATURES = {
     "cvhip_box_iou": (_i32, [_p, _i32, _p, _i32, _p, _p]),
     "cvhip_sgd_nesterov_ema": (_i32, [_p, _p, _p, _p, _i64, _p, _p, _p, _i32, _f32, _i32, _i32, _f32, _f32, _p, _p]),
     "cvhip_ema_update": (_i32, [_p, _p, _i64, _f32, _p, _p]),
+    "cvhip_yolov5_loss_workspace_bytes": (_i64, [_ylp]),
+    "cvhip_yolov5_loss_level_fwd": (_i32, [_ylp, _p, _p, _p, _p, _p]),
+    "cvhip_yolov5_loss_finalize": (_i32, [_p, _i32, _p, _p, _f32, _f32, _f32, _i32, _f32, _p, _p, _p]),
+    "cvhip_yolov5_loss_level_bwd": (_i32, [_ylp, _p, _p, _p, _p, _p, _f32, _f32, _f32, _p, _p]),
     "cvhip_probe_mfma_16x16x32": (_i32, [_p, _p, _p, _p]),
     "cvhip_probe_ds_read_tr16": (_i32, [_p, _p, _p]),
     "cvhip_probe_lds_read_bw": (_i32, [_i32, _i32, _i32, _p, _p]),

@@ -884,6 +884,79 @@ def head_permute(x, A, NO):
     return HeadPermute.apply(x, A, NO)
 
 
+class YoloV5LossFused(torch.autograd.Function):
+    """YOLOv5 loss (build_targets + CIoU + class/objectness BCE) straight on the bf16 NHWC head maps — libcvhip
+    cvhip_yolov5_loss_* (src/losses/yolov5_loss.py:173-278). forward(targets, cfg, *raw_maps) -> (total (1,), stats (3,)).
+    cfg: object with num_classes, num_anchors, anchors (L, A, 2) list, anchor_t, hyp_box/obj/cls, balance."""
+
+    @staticmethod
+    def forward(ctx, targets, cfg, *raws):
+        dev = raws[0].device
+        st = _stream()
+        tg = targets.detach()
+        if tg.dtype != torch.float32 or not tg.is_contiguous():
+            tg = tg.float().contiguous()
+        T = tg.shape[0]
+        A, NO = cfg.num_anchors, cfg.num_classes + 5
+        nl = len(raws)
+        sums = torch.empty((nl, 4), dtype=torch.float32, device=dev)
+        descs, wss, maps, ncells = [], [], [], []
+        for i, r in enumerate(raws):
+            r, ld = as_nhwc(r)
+            N, Cc, H, W = r.shape
+            if Cc != A * NO:
+                raise L.CvhipError("yolov5 loss: head map has %d channels, expected %d" % (Cc, A * NO))
+            d = L.YoloLossDesc(N, A, NO, H, W, ld, T, float(cfg.anchor_t))
+            for j, v in enumerate([float(x) for pair in cfg.anchors[i] for x in pair]):
+                d.anchors[j] = v
+            nbytes = L.load().cvhip_yolov5_loss_workspace_bytes(C.byref(d))
+            if nbytes < 0:
+                L.check(int(nbytes), "cvhip_yolov5_loss_workspace_bytes")
+            ws = torch.empty((int(nbytes),), dtype=torch.uint8, device=dev)
+            L.call("cvhip_yolov5_loss_level_fwd", C.byref(d), r.data_ptr(), tg.data_ptr(), ws.data_ptr(), sums[i].data_ptr(), st)
+            descs.append(d)
+            wss.append(ws)
+            maps.append(r)
+            ncells.append(float(N * A * H * W))
+        key = (tuple(ncells), tuple(cfg.balance[:nl]), str(dev))
+        consts = cfg._const_cache.get(key)
+        if consts is None:  # built once per shape/device (a host->device copy here would break hipGraph capture)
+            consts = (torch.tensor(ncells, dtype=torch.float32, device=dev), torch.tensor(list(cfg.balance[:nl]), dtype=torch.float32, device=dev))
+            cfg._const_cache[key] = consts
+        total = torch.empty((1,), dtype=torch.float32, device=dev)
+        stats = torch.empty((3,), dtype=torch.float32, device=dev)
+        bs = float(raws[0].shape[0])
+        L.call("cvhip_yolov5_loss_finalize", sums.data_ptr(), nl, consts[0].data_ptr(), consts[1].data_ptr(), float(cfg.hyp_box),
+               float(cfg.hyp_obj), float(cfg.hyp_cls), cfg.num_classes, bs, total.data_ptr(), stats.data_ptr(), st)
+        ctx.cfg, ctx.descs, ctx.wss, ctx.ncells, ctx.bs = cfg, descs, wss, ncells, bs
+        ctx.save_for_backward(tg, sums, *maps)
+        ctx.mark_non_differentiable(stats)
+        return total, stats
+
+    @staticmethod
+    def backward(ctx, g_total, g_stats):
+        tg, sums, *maps = ctx.saved_tensors
+        cfg = ctx.cfg
+        st = _stream()
+        g = g_total.detach()
+        if g.dtype != torch.float32 or not g.is_contiguous():
+            g = g.float().contiguous()
+        outs = []
+        nc = cfg.num_classes
+        for i, r in enumerate(maps):
+            d = ctx.descs[i]
+            draw = torch.empty((d.N, d.H, d.W, d.ld), dtype=BF16, device=r.device)
+            L.call("cvhip_yolov5_loss_level_bwd", C.byref(d), r.data_ptr(), tg.data_ptr(), ctx.wss[i].data_ptr(), sums[i].data_ptr(),
+                   g.data_ptr(), float(cfg.hyp_box) * ctx.bs, (float(cfg.hyp_cls) * ctx.bs / nc) if nc > 1 else 0.0,
+                   float(cfg.hyp_obj) * float(cfg.balance[i]) * ctx.bs / ctx.ncells[i], draw.data_ptr(), st)
+            outs.append(draw.permute(0, 3, 1, 2)[:, :d.A * d.NO])
+        return (None, None, *outs)
+
+
+def yolov5_loss_fused(raws, targets, cfg):
+    return YoloV5LossFused.apply(targets, cfg, *raws)
+
+
 # ---- non-differentiable post-processing ---------------------------------------------------------------
 
 def yolov5_decode(levels, strides, anchors_px, A, NO):

@@ -117,14 +117,21 @@ class YOLOv5Detect(nn.Module):
             b.data[:, 5:] += math.log(0.6 / (self.num_classes - 0.999999))
             mi.bias = torch.nn.Parameter(b.view(-1), requires_grad=True)
 
+    def forward_raw(self, x):
+        """the per-level 1x1 prediction convs only: [(N, na*no, H, W)] bf16 NHWC (input of the fused loss)"""
+        return [self.m[i](x[i]) for i in range(self.num_layers)]
+
     def forward(self, x):
-        raw = [self.m[i](x[i]) for i in range(self.num_layers)]  # (N, na*no, H, W) NHWC bf16
+        raw = self.forward_raw(x)  # (N, na*no, H, W) NHWC bf16
         train_out = [ops.head_permute(r, self.num_anchors, self.num_outputs) for r in raw]  # (N, na, H, W, no) fp32
         if self.training:
             return None, train_out
+        return self.decode(raw), train_out
+
+    def decode(self, raw):
+        """eval-mode sigmoid + grid/anchor decode of the raw maps -> (N, sum(na*H*W), no) (yolov5_detect.py:48-57)"""
         anchors_px = [self.anchors[i] * self.stride[i] for i in range(self.num_layers)]
-        z = ops.yolov5_decode(raw, self.stride, anchors_px, self.num_anchors, self.num_outputs)
-        return z, train_out
+        return ops.yolov5_decode(raw, self.stride, anchors_px, self.num_anchors, self.num_outputs)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -262,6 +269,27 @@ class YOLOv5Loss(nn.Module):
         return (lbox + lobj + lcls) * bs, torch.cat((lbox, lobj, lcls)).detach()
 
 
+class YOLOv5LossFused(nn.Module):
+    """Same loss, same constructor, computed by libcvhip's fused kernels (cvhip_yolov5_loss_*) directly on the raw bf16 head
+    maps [(N, A*NO, H, W)] instead of the permuted fp32 (N, A, H, W, NO) copies: build_targets, CIoU, BCE and all gradients
+    in 8 launches per level, no torch autograd ops => the whole train step can be captured in ONE hipGraph."""
+
+    def __init__(self, num_classes, stride=(8., 16., 32.), anchors=ANCHORS, hyp_box=0.05, hyp_obj=1.0, hyp_cls=0.5):
+        super().__init__()
+        self.num_classes = num_classes
+        self.num_layers = len(anchors)
+        self.num_anchors = len(anchors[0])
+        self.anchors = [[list(map(float, a)) for a in lvl] for lvl in anchors]
+        self.anchor_t = 4.0
+        self.hyp_box, self.hyp_obj, self.hyp_cls = hyp_box, hyp_obj, hyp_cls
+        self.balance = {3: [4.0, 1.0, 0.4]}.get(self.num_layers, [4.0, 1.0, 0.25, 0.06, .02])
+        self._const_cache = {}
+
+    def forward(self, raws, targets):
+        total, stats = ops.yolov5_loss_fused(list(raws), targets, self)
+        return total, stats
+
+
 def targets_to_tensor(targets, max_targets=None, device=None):
     """list[dict(labels (n,), boxes (n,4) cxcywh)] -> (T,6) [img, cls, cx, cy, w, h], padded with img=-1 rows.
     (trans_specific_format, src/models/yolov5.py:218-244; padding makes the shape static.)"""
@@ -338,15 +366,17 @@ class YOLOv5(nn.Module):
     """src/models/yolov5.py:156-287. forward(imgs, targets, mode): 'train' -> losses dict; 'val' -> (losses, outputs)."""
     anchors = ANCHORS
 
-    def __init__(self, num_classes=80, subtype="s", max_targets=None):
+    def __init__(self, num_classes=80, subtype="s", max_targets=None, fused_loss=False):
         super().__init__()
         self.num_classes = num_classes
+        self.fused_loss = fused_loss
+        self.loss_capturable = fused_loss  # no torch autograd ops in the loss => arena.FlatTrainStep captures one graph
         self.depth_mul, self.width_mul = SCALES[subtype]
         self.backbone = YOLOv5CSPDarknet(subtype="cspdark_" + subtype, out_stages=(2, 3, 4))
         self.neck = YOLOv5Neck(subtype="yolov5_" + subtype, in_channels=(256, 512, 1024), out_channels=(256, 512, 1024), num_blocks=(3, 3, 3, 3))
         self.detect = YOLOv5Detect(num_classes=num_classes, in_channels=(256, 512, 1024), anchors=ANCHORS, depth_mul=self.depth_mul,
                                    width_mul=self.width_mul)
-        self.loss = YOLOv5Loss(num_classes, anchors=ANCHORS)
+        self.loss = (YOLOv5LossFused if fused_loss else YOLOv5Loss)(num_classes, anchors=ANCHORS)
         self.conf_thres, self.iou_thres = 0.001, 0.6
         self.max_targets = max_targets
         for m in self.modules():  # yolov5.py:194-203
@@ -354,7 +384,11 @@ class YOLOv5(nn.Module):
                 m.eps, m.momentum = 1e-3, 0.03
 
     def forward_features(self, imgs):
-        return self.detect(self.neck(self.backbone(imgs)))
+        x = self.neck(self.backbone(imgs))
+        if self.fused_loss:
+            raw = self.detect.forward_raw(x)
+            return (None if self.training else self.detect.decode(raw)), raw
+        return self.detect(x)
 
     def loss_from_features(self, train_out, gts):
         losses = {}

@@ -328,6 +328,33 @@ int cvhip_ema_update(float* ema, const float* src, int64_t n, float decay, const
                      void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * YOLOv5 loss on device, one detection level at a time.
+ * Replaces src/losses/yolov5_loss.py:173-278 (YOLOv5Loss.__call__ + build_targets) and :12-54 (bbox_iou/CIoU): reads the
+ * bf16 NHWC head map (N, H, W, ld) with channel a*NO + o directly (no (N,A,H,W,NO) fp32 copy) and writes its bf16
+ * gradient directly. targets: (T, 6) fp32 [img, cls, cx, cy, w, h] normalised, img < 0 = padding row.
+ *   level_fwd : build_targets + per-candidate CIoU / class BCE (+ their unscaled gradients, kept in `ws`) + objectness BCE
+ *               -> sums4 = {n_matched, sum(1 - ciou), sum(cls bce), sum(obj bce)}  (deterministic reductions)
+ *   finalize  : lbox = hyp_box * sum_l lbox_l / n_l ...; total = (lbox + lobj + lcls) * batch; stats3 = {lbox, lobj, lcls}
+ *   level_bwd : d total / d head map, scaled by the DEVICE scalar gout (NULL = 1):
+ *               k_box = hyp_box*batch, k_cls = hyp_cls*batch/nc, k_obj = hyp_obj*balance_l*batch/(N*A*H*W)
+ * `ws` (cvhip_yolov5_loss_workspace_bytes) must stay untouched between level_fwd and level_bwd.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cvhip_yolo_loss_desc {
+  int32_t N, A, NO, H, W, ld, T;
+  float anchor_t;       /* hyp anchor_t = 4.0 (yolov5_loss.py:247-248) */
+  float anchors[16];    /* A x (w, h) in grid units of this level */
+} cvhip_yolo_loss_desc;
+int64_t cvhip_yolov5_loss_workspace_bytes(const cvhip_yolo_loss_desc* d);
+int cvhip_yolov5_loss_level_fwd(const cvhip_yolo_loss_desc* d, const void* raw_bf16, const float* targets, void* ws,
+                                float* sums4, void* stream);
+int cvhip_yolov5_loss_finalize(const float* sums, int32_t levels, const float* ncell, const float* balance, float hyp_box,
+                               float hyp_obj, float hyp_cls, int32_t nc, float batch, float* total, float* stats3,
+                               void* stream);
+int cvhip_yolov5_loss_level_bwd(const cvhip_yolo_loss_desc* d, const void* raw_bf16, const float* targets, void* ws,
+                                const float* sums4, const float* gout, float k_box, float k_cls, float k_obj,
+                                void* draw_bf16, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Hardware probes used by the GPU test-suite to pin the MFMA / LDS-transpose lane layouts the
  * kernels rely on (cdna_hip_programming.md §3, T10). out buffers are small fp32 arrays.
  * ------------------------------------------------------------------------------------------ */
