@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-deeplab", action="store_true", help="skip the DeepLabv3+ (config 3) side workload")
     ap.add_argument("--no-graph", action="store_true", help="run the timed steps eagerly instead of replaying a hipGraph")
     ap.add_argument("--stock-optimizer", action="store_true", help="torch.optim.SGD + ModelEMA instead of the fused arena step")
+    ap.add_argument("--torch-loss", action="store_true", help="fixed-shape torch-op YOLOv5 loss instead of the fused libcvhip loss kernels")
     return ap.parse_args()
 
 
@@ -128,7 +129,7 @@ def main():
 
     torch.manual_seed(1029)
     max_boxes = 20
-    model = yolov5.YOLOv5(80, "s", max_targets=a.batch * max_boxes).to(dev).train()
+    model = yolov5.YOLOv5(80, "s", max_targets=a.batch * max_boxes, fused_loss=not a.torch_loss).to(dev).train()
     if world > 1:  # same initial weights everywhere (DDP broadcasts rank 0's at construction)
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, 0)

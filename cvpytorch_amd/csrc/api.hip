@@ -24,8 +24,9 @@ int check_launch(const char* what) {
   return CVHIP_OK;
 }
 
-__global__ __launch_bounds__(256) void zero_fill_kernel(uint32_t* p, size_t n_words) {
+__global__ __launch_bounds__(256) void zero_fill_kernel(uint32_t* p, size_t n_words, int tail_half) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (size_t)gridDim.x * 256) p[i] = 0u;
+  if (tail_half && blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<uint16_t*>(p)[n_words * 2] = 0;
 }
 
 __global__ __launch_bounds__(256) void unpad_add_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n, int C, int Cv) {
@@ -38,11 +39,12 @@ __global__ __launch_bounds__(256) void unpad_add_kernel(const float* __restrict_
 
 int zero_fill(void* ptr, size_t bytes, hipStream_t stream) {
   if (bytes == 0) return CVHIP_OK;
-  if ((((uintptr_t)ptr) & 3) || (bytes & 3)) return CVHIP_ERR_INVALID;
+  if ((((uintptr_t)ptr) & 3) || (bytes & 1)) return CVHIP_ERR_INVALID;  // whole 32-bit words (+ one trailing bf16)
   const size_t n = bytes / 4;
   size_t blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (uint32_t*)ptr, n);
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (uint32_t*)ptr, n, (int)((bytes & 2) != 0));
   return check_launch("zero_fill_kernel");
 }
 

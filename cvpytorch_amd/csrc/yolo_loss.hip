@@ -419,7 +419,8 @@ int cvhip_yolov5_loss_level_fwd(const cvhip_yolo_loss_desc* d, const void* raw, 
   if (rc != CVHIP_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   const int64_t ncell = (int64_t)p.N * p.A * p.H * p.W;
-  zero_fill(p.winner, (ncell * 4 + 255) / 256 * 256 * 2, st);  // winner + head are adjacent
+  rc = zero_fill(p.winner, (ncell * 4 + 255) / 256 * 256 * 2, st);  // winner + head are adjacent
+  if (rc != CVHIP_OK) return rc;
   hipLaunchKernelGGL(yolo_cand_kernel, dim3(cdiv(p.ncand, 4)), dim3(256), 0, st, p);
   hipLaunchKernelGGL(yolo_cand_reduce_kernel, dim3(1), dim3(1024), 0, st, p);
   const int nb = (int)(cdiv64(ncell, 256) < 1024 ? cdiv64(ncell, 256) : 1024);
@@ -449,7 +450,8 @@ int cvhip_yolov5_loss_level_bwd(const cvhip_yolo_loss_desc* d, const void* raw, 
   p.k_obj = k_obj;
   hipStream_t st = (hipStream_t)stream;
   const int64_t ncell = (int64_t)p.N * p.A * p.H * p.W;
-  zero_fill(p.draw, (int64_t)p.N * p.H * p.W * p.ld * 2, st);
+  rc = zero_fill(p.draw, (int64_t)p.N * p.H * p.W * p.ld * 2, st);
+  if (rc != CVHIP_OK) return rc;
   const int nb = (int)(cdiv64(ncell, 256) < 8192 ? cdiv64(ncell, 256) : 8192);
   hipLaunchKernelGGL(yolo_obj_kernel<true>, dim3(nb), dim3(256), 0, st, p);
   hipLaunchKernelGGL(yolo_cand_bwd_kernel, dim3(cdiv(p.ncand, 4)), dim3(256), 0, st, p);
