@@ -4,6 +4,7 @@
 //
 // Replaces aten::native_batch_norm(_backward) + aten::silu_/relu_ (+ residual add) reached from
 // reference src/models/bricks/conv_module.py:211-213 and src/models/modules/yolo_modules.py:102.
+#include <stdlib.h>
 #include "common.h"
 
 namespace cvhip {
@@ -32,7 +33,21 @@ struct RedParams {
   float* partial;  // [gridDim.x][2][C]
 };
 
-template <int MODE>
+// 8 per-channel constants for the channel vector starting at c: UNCONDITIONAL clamped loads (a per-element
+// `ok ? p[c] : dflt` compiles to 8 exec-masked blocks with an s_waitcnt vmcnt(0) at every join: 16-48 serialized
+// ~1 us round trips per thread, i.e. a fixed ~17 us per launch — measured, tools/stream_probe.py)
+__device__ __forceinline__ void load8c(const float* __restrict__ p, int c, int C, float (&o)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = p[(c + j < C) ? c + j : C - 1];
+}
+__device__ __forceinline__ void fill8c(float v, float (&o)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = v;
+}
+
+// ACT: compile-time activation id for MODE 1 (a runtime switch inside the element loop compiles to a chain of scalar
+// branches per element)
+template <int MODE, int ACT = 0>
 __global__ __launch_bounds__(256) void colreduce_kernel(const RedParams p) {
   __shared__ float red[256 * 16];
   const int t = threadIdx.x;
@@ -54,15 +69,19 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const RedParams p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
     float sc[8], sh[8], mu[8], is[8];
-    if (MODE == 1 && active && cv < CV) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int c = cv * 8 + j;
-        const bool ok = c < p.C;
-        sc[j] = (ok && p.scale) ? p.scale[c] : 1.f;
-        sh[j] = (ok && p.shift) ? p.shift[c] : 0.f;
-        mu[j] = (ok && p.mean) ? p.mean[c] : 0.f;
-        is[j] = (ok && p.invstd) ? p.invstd[c] : 1.f;
+    fill8c(1.f, sc);
+    fill8c(0.f, sh);
+    fill8c(0.f, mu);
+    fill8c(1.f, is);
+    if (MODE == 1) {
+      const int cc = (cv < CV ? cv : CV - 1) * 8;
+      if (p.scale) {  // uniform: scale/shift come together, mean/invstd come together
+        load8c(p.scale, cc, p.C, sc);
+        load8c(p.shift, cc, p.C, sh);
+      }
+      if (p.mean) {
+        load8c(p.mean, cc, p.C, mu);
+        load8c(p.invstd, cc, p.C, is);
       }
     }
     if (active && cv < CV) {
@@ -76,7 +95,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const RedParams p) {
             s1[j] += a.v[j];
           } else {
             const float u = y.v[j] * sc[j] + sh[j];
-            const float du = a.v[j] * act_bwd(u, p.act, p.ap);
+            const float du = a.v[j] * act_bwd(u, ACT, p.ap);
             const float xh = (y.v[j] - mu[j]) * is[j];
             s1[j] += du;
             s2[j] += du * xh;
@@ -268,7 +287,7 @@ struct EwParams {
 // MODE 0: out = act(a*scale+shift) (+res)         [a = conv output y]
 // MODE 1: out = dy from (a = dz, y)               [BN+act backward apply]
 // MODE 2: out = a (copy)       MODE 3: out = a + res
-template <int MODE>
+template <int MODE, int ACT = 0>
 __global__ __launch_bounds__(256) void ew_kernel(const EwParams p) {
   const int CV = (p.C + 7) >> 3;
   const bool vec = (p.C & 7) == 0 && (p.ld_a & 7) == 0 && (p.ld_out & 7) == 0 &&
@@ -288,18 +307,25 @@ __global__ __launch_bounds__(256) void ew_kernel(const EwParams p) {
   for (int cv = tx; cv < CV; cv += cols_per_pass) {
     const int c = cv * 8;
     float sc[8], sh[8], mu[8], is[8], k1[8], k2[8];
+    fill8c(1.f, sc);
+    fill8c(0.f, sh);
+    fill8c(0.f, mu);
+    fill8c(1.f, is);
+    fill8c(0.f, k1);
+    fill8c(0.f, k2);
+    if (p.scale) {  // uniform branches: (scale, shift) and (mean, invstd, dgamma, dbeta) come as groups
+      load8c(p.scale, c, p.C, sc);
+      load8c(p.shift, c, p.C, sh);
+    }
+    if (MODE == 1 && p.mean) {
+      load8c(p.mean, c, p.C, mu);
+      load8c(p.invstd, c, p.C, is);
+      load8c(p.dbeta, c, p.C, k1);
+      load8c(p.dgamma, c, p.C, k2);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int cc = (c + j < p.C) ? c + j : p.C - 1;
-      sc[j] = p.scale ? p.scale[cc] : 1.f;
-      sh[j] = p.shift ? p.shift[cc] : 0.f;
-      if (MODE == 1 && p.mean) {
-        mu[j] = p.mean[cc];
-        is[j] = p.invstd[cc];
-        k1[j] = p.dbeta[cc] * p.inv_count;
-        k2[j] = p.dgamma[cc] * p.inv_count;
-      } else {
-        mu[j] = 0.f; is[j] = 1.f; k1[j] = 0.f; k2[j] = 0.f;
+      for (int j = 0; j < 8; ++j) {
+        k1[j] *= p.inv_count;
+        k2[j] *= p.inv_count;
       }
     }
     auto math = [&](const f32x8& a, const f32x8& y, const f32x8& rs) -> f32x8 {
@@ -309,15 +335,15 @@ __global__ __launch_bounds__(256) void ew_kernel(const EwParams p) {
         if (MODE == 0) {
           float v;
           if (p.res && p.res_pre) {
-            v = act_fwd(a.v[j] * sc[j] + sh[j] + rs.v[j], p.act, p.ap);
+            v = act_fwd(a.v[j] * sc[j] + sh[j] + rs.v[j], ACT, p.ap);
           } else {
-            v = act_fwd(a.v[j] * sc[j] + sh[j], p.act, p.ap);
+            v = act_fwd(a.v[j] * sc[j] + sh[j], ACT, p.ap);
             if (p.res) v += rs.v[j];
           }
           o.v[j] = v;
         } else if (MODE == 1) {
           const float u = y.v[j] * sc[j] + sh[j];
-          const float du = a.v[j] * act_bwd(u, p.act, p.ap);
+          const float du = a.v[j] * act_bwd(u, ACT, p.ap);
           if (p.mean) {
             const float xh = (y.v[j] - mu[j]) * is[j];
             o.v[j] = sc[j] * (du - k1[j] - xh * k2[j]);
@@ -381,11 +407,32 @@ __global__ __launch_bounds__(256) void ew_kernel(const EwParams p) {
 
 // blocks are row chunks; a thread moves 16 B per row visit, so ~32 row-visits per thread keeps
 // enough bytes in flight while leaving >> 256 blocks for large activations
+// launch KERNEL<MODE, act> for the runtime activation id
+#define CVHIP_LAUNCH_ACT(KERNEL, MODE, ACTV, GRID, STREAM, PARAMS)                                                       \
+  switch (ACTV) {                                                                                                        \
+    case CVHIP_ACT_RELU: hipLaunchKernelGGL((KERNEL<MODE, CVHIP_ACT_RELU>), GRID, dim3(256), 0, STREAM, PARAMS); break;        \
+    case CVHIP_ACT_SILU: hipLaunchKernelGGL((KERNEL<MODE, CVHIP_ACT_SILU>), GRID, dim3(256), 0, STREAM, PARAMS); break;        \
+    case CVHIP_ACT_LEAKY: hipLaunchKernelGGL((KERNEL<MODE, CVHIP_ACT_LEAKY>), GRID, dim3(256), 0, STREAM, PARAMS); break;      \
+    case CVHIP_ACT_SIGMOID: hipLaunchKernelGGL((KERNEL<MODE, CVHIP_ACT_SIGMOID>), GRID, dim3(256), 0, STREAM, PARAMS); break;  \
+    case CVHIP_ACT_HSWISH: hipLaunchKernelGGL((KERNEL<MODE, CVHIP_ACT_HSWISH>), GRID, dim3(256), 0, STREAM, PARAMS); break;    \
+    default: hipLaunchKernelGGL((KERNEL<MODE, CVHIP_ACT_NONE>), GRID, dim3(256), 0, STREAM, PARAMS); break;                   \
+  }
+
+static int ew_rows_per_thread() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CVHIP_EW_ROWS");
+    v = e ? atoi(e) : 16;
+    if (v < 1) v = 16;
+  }
+  return v;
+}
+
 static inline int ew_grid(int64_t M, int C) {
   const int CV = (C + 7) / 8;
   const int cols = CV < 256 ? CV : 256;
   const int rows_per_pass = 256 / cols;
-  int64_t b = cdiv64(M, (int64_t)rows_per_pass * 16);
+  int64_t b = cdiv64(M, (int64_t)rows_per_pass * ew_rows_per_thread());
   if (b > 256 * 32) b = 256 * 32;
   if (b < 1) b = 1;
   return (int)b;
@@ -403,7 +450,9 @@ static int launch_red(int mode, RedParams& p, hipStream_t s) {
   if (!p.a || !p.partial || p.M < 0 || p.C <= 0) return CVHIP_ERR_INVALID;
   const int rows = colreduce_rows_host(p.M, p.C);
   if (mode == 0) hipLaunchKernelGGL(colreduce_kernel<0>, dim3(rows), dim3(256), 0, s, p);
-  else if (mode == 1) hipLaunchKernelGGL(colreduce_kernel<1>, dim3(rows), dim3(256), 0, s, p);
+  else if (mode == 1) {
+    CVHIP_LAUNCH_ACT(colreduce_kernel, 1, p.act, dim3(rows), s, p)
+  }
   else hipLaunchKernelGGL(colreduce_kernel<2>, dim3(rows), dim3(256), 0, s, p);
   return check_launch("colreduce_kernel");
 }
@@ -502,7 +551,7 @@ int cvhip_bn_act_fwd(const void* y, int32_t ld_y, void* z, int32_t ld_z, int64_t
   p.shift = shift;
   p.act = act;
   p.ap = act_param;
-  hipLaunchKernelGGL(ew_kernel<0>, dim3(ew_grid(M, C)), dim3(256), 0, (hipStream_t)stream, p);
+  CVHIP_LAUNCH_ACT(ew_kernel, 0, act, dim3(ew_grid(M, C)), (hipStream_t)stream, p)
   return check_launch("ew_kernel<0>");
 }
 
@@ -531,7 +580,7 @@ int cvhip_bn_act_bwd_apply(const void* dz, int32_t ld_dz, const void* y, int32_t
   p.act = act;
   p.ap = act_param;
   p.inv_count = 1.f / (float)M;
-  hipLaunchKernelGGL(ew_kernel<1>, dim3(ew_grid(M, C)), dim3(256), 0, (hipStream_t)stream, p);
+  CVHIP_LAUNCH_ACT(ew_kernel, 1, act, dim3(ew_grid(M, C)), (hipStream_t)stream, p)
   return check_launch("ew_kernel<1>");
 }
 
@@ -551,7 +600,7 @@ int cvhip_add_act_fwd(const void* a, int32_t ld_a, const void* b, int32_t ld_b, 
   p.act = act;
   p.ap = act_param;
   p.res_pre = 1;
-  hipLaunchKernelGGL(ew_kernel<0>, dim3(ew_grid(M, C)), dim3(256), 0, (hipStream_t)stream, p);
+  CVHIP_LAUNCH_ACT(ew_kernel, 0, act, dim3(ew_grid(M, C)), (hipStream_t)stream, p)
   return check_launch("ew_kernel<0>(add_act)");
 }
 
