@@ -10,6 +10,7 @@
 // the weight tensor is a single tile (128x128 3x3: 9 tiles x splits).
 //
 // Replaces aten::convolution_backward(weight) reached from trainer.py:189 (loss.backward()).
+#include <stdlib.h>
 #include "common.h"
 #include "conv_plan.h"
 
@@ -25,6 +26,7 @@ struct WgradParams {
   int Nout, dy_ld;
   int Ktot, M;
   int n_tiles, k_tiles, m_per_split;
+  int ablate;  // CVHIP_WGRAD_ABLATE: 1 = skip the atomic epilogue (profiling only)
 };
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -57,10 +59,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wn = wave / WAVES_K, wk = wave % WAVES_K;
 
-  const int tile = blockIdx.x;
+  // 1-D grid, XCD-aware: all (n, k) tiles of one pixel split get consecutive logical ids => the same XCD, so the x / dY
+  // slab of the split is fetched into ONE L2 and re-used by the other tiles (PMC: 3.1x over-fetch with the 2-D grid)
+  const int tiles = p.n_tiles * p.k_tiles;
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = lin / tiles;
+  const int tile = lin - split * tiles;
   const int ntile = tile / p.k_tiles, ktile = tile - ntile * p.k_tiles;
   const int n0 = ntile * TN, k0 = ktile * TK;
-  const int m_begin = blockIdx.y * p.m_per_split;
+  const int m_begin = split * p.m_per_split;
   const int m_end = min(p.M, m_begin + p.m_per_split);
   const int nsteps = (m_end - m_begin + 31) >> 5;
   if (nsteps <= 0) return;
@@ -186,6 +193,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   }
 
   // epilogue: lane holds D[n = 4*(lane>>4)+r][kcol = lane&15]
+  if (p.ablate == 1 && acc[0][0][0] != 12345.678f) return;
 #pragma unroll
   for (int a = 0; a < NF; ++a) {
 #pragma unroll
@@ -207,15 +215,30 @@ static int launch_wg(WgradParams& p, hipStream_t stream) {
   p.k_tiles = cdiv(p.Ktot, 128);
   const int tiles = p.n_tiles * p.k_tiles;
   // fill ~3 blocks per CU; keep >= 8 reduction steps per split
-  int splits = cdiv(768, tiles);
-  const int max_splits = (p.M + 255) / 256;
+  static int target = -1, min_rows = -1;
+  if (target < 0) {
+    const char* e = getenv("CVHIP_WGRAD_BLOCKS");
+    target = e ? atoi(e) : 768;
+    const char* f = getenv("CVHIP_WGRAD_MINROWS");
+    min_rows = f ? atoi(f) : 512;
+  }
+  int splits = cdiv(target, tiles);
+  const int max_splits = (p.M + min_rows - 1) / min_rows;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   int mps = cdiv(p.M, splits);
   mps = ((mps + 31) / 32) * 32;
   splits = cdiv(p.M, mps);
   p.m_per_split = mps;
-  hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK>), dim3(tiles, splits), dim3(256), 0, stream, p);
+  {
+    static int abl = -1;
+    if (abl < 0) {
+      const char* e = getenv("CVHIP_WGRAD_ABLATE");
+      abl = e ? atoi(e) : 0;
+    }
+    p.ablate = abl;
+  }
+  hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK>), dim3(tiles * splits), dim3(256), 0, stream, p);
   return check_launch("wgrad_kernel");
 }
 

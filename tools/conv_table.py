@@ -7,7 +7,7 @@ from cvpytorch_amd.arena import FlatTrainState, FlatTrainStep
 from cvpytorch_amd.data import synthetic_detection_batch
 dev = torch.device("cuda:0")
 B = 64
-model = yolov5.YOLOv5(80, "s", max_targets=B * 20).to(dev).train()
+model = yolov5.YOLOv5(80, "s", max_targets=B * 20, fused_loss=True).to(dev).train()
 state = FlatTrainState(model, use_ema=False)
 step = FlatTrainStep(model, state)
 imgs, targets = synthetic_detection_batch(B, 640, device=dev)
@@ -33,6 +33,7 @@ for (fn, g, name), (n, ms, fl, by) in agg.items():
     rows.append((ms / 3, fn, "%dx%d %d->%d k%d @%dx%d->%dx%d" % (N, 1, C, K, R, H, W, P, Q), n // 3, us, fl / us / 1e6, by / us / 1e3, name))
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
-print("total conv ms/step %.3f" % tot)
-for r in rows[:45]:
+print("total conv ms/step %.3f   wgrad %.3f  fprop %.3f  dgrad %.3f" % (tot, sum(r[0] for r in rows if r[1]=="wgrad"), sum(r[0] for r in rows if r[1]=="fprop"), sum(r[0] for r in rows if r[1]=="dgrad")))
+NROWS = int(os.environ.get("TABLE_ROWS", "45"))
+for r in rows[:NROWS]:
     print("%6.3f ms/step  %-6s %-34s x%d  %8.1f us  %7.1f TF  %7.1f GB/s  %s" % r)
