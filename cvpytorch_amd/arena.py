@@ -71,6 +71,12 @@ class FlatTrainState:
         self.seg_lr = torch.tensor(self.base_lr, dtype=torch.float32, device=dev)
         self.seg_wd = torch.tensor([hyper[id(p)][1] for p in self.params], dtype=torch.float32, device=dev)
         self.steps = 0
+        # BatchNorm step counters: one multi-tensor add per step (bricks.bn_tick) instead of one tiny kernel per layer
+        self._nbt = []
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d) and m.track_running_stats and m.num_batches_tracked is not None:
+                m._nbt_deferred = True
+                self._nbt.append(m.num_batches_tracked)
         self.lr_scale = 1.0
         self.dyn = torch.tensor([0.0, 1.0], dtype=torch.float32, device=dev)  # {ema_decay, lr_scale}, read by the kernels
         self._dyn_host = torch.zeros((256, 2), dtype=torch.float32).pin_memory()
@@ -211,6 +217,8 @@ class FlatTrainState:
                int(self.nesterov), 0, 0.0, 1.0 / self.world, self.dyn.data_ptr(), st)
         if self.ema_buf is not None and self.buf.numel():
             L.call("cvhip_ema_update", self.ema_buf.data_ptr(), self.buf.data_ptr(), self.buf.numel(), 0.0, self.dyn.data_ptr(), st)
+        if self._nbt and self.model.training:
+            torch._foreach_add_(self._nbt, 1)
         self.zero_grad()
 
     def post_step(self):

@@ -145,6 +145,14 @@ def _pair(v):
 # ------------------------------------------------------------------------------------------------------
 # Hip layers
 # ------------------------------------------------------------------------------------------------------
+def bn_tick(bn):
+    """BatchNorm's `num_batches_tracked += 1` (torch/nn/modules/batchnorm.py). A train state that owns the step
+    (arena.FlatTrainState) sets `bn._nbt_deferred` and bumps all counters with ONE multi-tensor add per step instead of
+    one 4-us kernel per layer."""
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None and not getattr(bn, "_nbt_deferred", False):
+        bn.num_batches_tracked.add_(1)
+
+
 class HipConv2d(nn.Conv2d):
     """nn.Conv2d whose forward/backward run on libcvhip's MFMA implicit-GEMM kernels."""
 
@@ -201,8 +209,7 @@ class HipBN(nn.BatchNorm2d):
 
     def forward(self, x):
         training = self.training or self.running_mean is None
-        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)
+        bn_tick(self)
         if self.momentum is None:
             raise L.CvhipError("HipBN: cumulative moving average (momentum=None) is not supported")
         return ops.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, None, True, training,
@@ -564,8 +571,7 @@ class HipConvModule(nn.Module):
             x, w = conv._effective(x)
             cfg = conv.make_cfg(aid, ap, bn)
             if bn is not None:
-                if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-                    bn.num_batches_tracked.add_(1)
+                bn_tick(bn)
                 return ops.conv_bn_act(x, w, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, cfg)
             return ops.conv_bn_act(x, w, conv.bias, None, None, None, None, residual, cfg)
         for layer in self.order:
@@ -668,8 +674,7 @@ class HipConvBN(nn.Sequential):
 
     def forward(self, x, residual=None):
         conv, bn = self[0], self[1]
-        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+        bn_tick(bn)
         xx, w = conv._effective(x)
         return ops.conv_bn_act(xx, w, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual,
                                conv.make_cfg(self._act, 0.0, bn))

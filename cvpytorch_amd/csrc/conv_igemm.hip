@@ -413,9 +413,11 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) 
   int st_cur = 0, st_nxt2 = 2;
   for (int kt = 0; kt < nk; ++kt) {
     // this wave's DMAs of tile kt have landed when at most PER (= tile kt+1) remain outstanding ...
+    static_assert(PER >= 3 && PER <= 6, "DMA count per stage");
     if constexpr (PER == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if constexpr (PER == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (PER == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     // ... and after the barrier everybody's have; it also proves all waves finished reading ring slot (kt+2)%3
     __builtin_amdgcn_s_barrier();
     if (ABL != 2) stage(kt + 2, st_nxt2);  // past-the-end tiles decode to all-masked lanes (zero page): DMA counts stay uniform
@@ -538,18 +540,44 @@ static int launch_cfg(IgemmParams& p, hipStream_t stream) {
   }
   p.total_tiles = total;
   if (total == 0) return CVHIP_OK;
-  if (use_v1()) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), dim3(total), dim3(256), 0, stream, p);
-  else if (ablate_mode() == 1) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 1>), dim3(total), dim3(256), 0, stream, p);
+  if constexpr (WM == 64) {
+    if (use_v1()) {
+      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), dim3(total), dim3(256), 0, stream, p);
+      return check_launch("igemm_kernel");
+    }
+  }
+  if (ablate_mode() == 1) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 1>), dim3(total), dim3(256), 0, stream, p);
   else if (ablate_mode() == 2) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 2>), dim3(total), dim3(256), 0, stream, p);
   else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN>), dim3(total), dim3(256), 0, stream, p);
   return check_launch("igemm_kernel");
 }
 
-int igemm_block_m(int Nout) { return Nout <= 64 ? 256 : 128; }
+// Tile choice. Wide outputs (> 64 channels) of large problems use 256x128 block tiles with 128x64 WAVE tiles: LDS fragment
+// reads per MFMA drop by 25 % (12 ds_read_b128 per 32 MFMAs instead of 8 per 16) and global->LDS bytes per flop by 25 %
+// — the two limits profiles/r01_igemm_ablation.log and r01_lds_read_bw_probe.log measure. Small problems keep 128x128
+// so the grid still covers the 256 CUs.
+static bool big_tile_disabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CVHIP_IGEMM_NO256");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+
+int igemm_block_m(int Nout, int64_t M) {
+  if (Nout <= 64) return 256;
+  if (use_v1() || big_tile_disabled()) return 128;
+  const int64_t tiles256 = ((M + 255) / 256) * ((Nout + 127) / 128);
+  return tiles256 >= 384 ? 256 : 128;
+}
 
 int launch_igemm(IgemmParams& p, hipStream_t stream) {
   if (p.Nout <= 32) return launch_cfg<256, 32, 64, 32>(p, stream);
   if (p.Nout <= 64) return launch_cfg<256, 64, 64, 64>(p, stream);
+  int64_t M = 0;
+  for (int i = 0; i < p.ncls; ++i) M += p.cls[i].M;
+  if (igemm_block_m(p.Nout, M) == 256) return launch_cfg<256, 128, 128, 64>(p, stream);
   return launch_cfg<128, 128, 64, 64>(p, stream);
 }
 

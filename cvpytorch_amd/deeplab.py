@@ -15,6 +15,7 @@ import torch.nn as nn
 
 from . import lib as L
 from . import ops
+from .bricks import bn_tick  # noqa: E402
 from .bricks import HipBN, HipConv2d, HipMaxPool2d
 from .bricks import HipConvModule as ConvModule
 from .bricks import HipDepthwiseSeparableConvModule as DepthwiseSeparableConvModule
@@ -23,8 +24,7 @@ from .bricks import HipDepthwiseSeparableConvModule as DepthwiseSeparableConvMod
 def _cba(x, conv, bn, act, residual=None):
     """conv -> bn -> act as ONE fused op (conv and bn are sibling modules, torchvision style)."""
     cfg = conv.make_cfg(act, 0.0, bn)
-    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    bn_tick(bn)
     xx, w = conv._effective(x)
     return ops.conv_bn_act(xx, w, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, cfg)
 

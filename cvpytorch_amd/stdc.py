@@ -15,6 +15,7 @@ import torch.nn.functional as F
 
 from . import lib as L
 from . import ops
+from .bricks import bn_tick  # noqa: E402
 from .bricks import (HipAdaptiveAvgPool1x1, HipAvgPool2d, HipBN, HipConv2d, HipConvBN, HipSigmoid)
 from .bricks import HipConvModule as ConvModule
 
@@ -51,8 +52,7 @@ class _DwPwSkip(nn.Sequential):
 
     def forward(self, x):
         for conv, bn in ((self[0], self[1]), (self[2], self[3])):
-            if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(1)
+            bn_tick(bn)
             xx, w = conv._effective(x)
             x = ops.conv_bn_act(xx, w, None, bn.weight, bn.bias, bn.running_mean, bn.running_var, None, conv.make_cfg(L.ACT_NONE, 0.0, bn))
         return x

@@ -95,6 +95,10 @@ CONV_CASES = [
     (2, 128, 12, 12, 19, 1, 1, 1, 0, 1),
     (1, 40, 9, 9, 24, 3, 3, 1, 1, 1),
     (64, 32, 8, 8, 32, 3, 3, 1, 1, 1),
+    # large enough for the 256x128 block / 128x64 wave-tile configuration (>= 384 tiles), ragged last tile
+    (62, 128, 40, 40, 128, 3, 3, 1, 1, 1),
+    (25, 64, 64, 64, 256, 1, 1, 1, 0, 1),
+    (26, 128, 80, 80, 256, 3, 3, 2, 1, 1),
 ]
 
 
