@@ -236,7 +236,7 @@ int cvhip_conv2d_fprop_stats_rows(const cvhip_conv_desc* d) {
   if (st) return st;
   const int P = conv_out_dim(d->H, d->pad_h, d->dil_h, d->R, d->stride_h);
   const int Q = conv_out_dim(d->W, d->pad_w, d->dil_w, d->S, d->stride_w);
-  return cdiv(d->N * P * Q, igemm_block_m(d->K, (int64_t)d->N * P * Q));
+  return cdiv(d->N * P * Q, igemm_block_m(d->K, (int64_t)d->N * P * Q, d->R * d->S * d->C));
 }
 
 int64_t cvhip_conv2d_dgrad_weight_elems(const cvhip_conv_desc* d) {

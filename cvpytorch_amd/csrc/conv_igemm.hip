@@ -565,9 +565,12 @@ static bool big_tile_disabled() {
   return v == 1;
 }
 
-int igemm_block_m(int Nout, int64_t M) {
+int igemm_block_m(int Nout, int64_t M, int Ktot) {
   if (Nout <= 64) return 256;
   if (use_v1() || big_tile_disabled()) return 128;
+  // shallow reductions (1x1 convs with < 512 input channels) are memory-bound: more, smaller blocks hide latency better
+  // (measured per shape: gpurun conv_table A/B)
+  if (Ktot < 512) return 128;
   const int64_t tiles256 = ((M + 255) / 256) * ((Nout + 127) / 128);
   return tiles256 >= 384 ? 256 : 128;
 }
@@ -576,8 +579,13 @@ int launch_igemm(IgemmParams& p, hipStream_t stream) {
   if (p.Nout <= 32) return launch_cfg<256, 32, 64, 32>(p, stream);
   if (p.Nout <= 64) return launch_cfg<256, 64, 64, 64>(p, stream);
   int64_t M = 0;
-  for (int i = 0; i < p.ncls; ++i) M += p.cls[i].M;
-  if (igemm_block_m(p.Nout, M) == 256) return launch_cfg<256, 128, 128, 64>(p, stream);
+  int ktot = 0;
+  for (int i = 0; i < p.ncls; ++i) {
+    M += p.cls[i].M;
+    const int k = p.cls[i].TR * p.cls[i].TS * p.Cin;
+    ktot = k > ktot ? k : ktot;
+  }
+  if (igemm_block_m(p.Nout, M, ktot) == 256) return launch_cfg<256, 128, 128, 64>(p, stream);
   return launch_cfg<128, 128, 64, 64>(p, stream);
 }
 

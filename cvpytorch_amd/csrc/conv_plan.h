@@ -87,7 +87,7 @@ int validate_dense_desc(const cvhip_conv_desc* d);
 void plan_fprop(const cvhip_conv_desc* d, IgemmParams* p);
 // returns number of classes (<= kMaxClasses) or negative status
 int plan_dgrad(const cvhip_conv_desc* d, IgemmParams* p);
-int igemm_block_m(int Nout, int64_t M);
+int igemm_block_m(int Nout, int64_t M, int Ktot);
 int launch_igemm(IgemmParams& p, hipStream_t stream);
 
 }  // namespace cvhip
