@@ -48,33 +48,42 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(size, cpu_batch, budget_s=20.0):
-    """Oracle train step on the host cores: bounded sample (SURVEY.md §8d 'CPU baseline')."""
+def cpu_baseline(size, cpu_batch, budget_s=20.0, max_threads=32):
+    """Oracle train step on the host cores: bounded sample (SURVEY.md §8d 'CPU baseline').
+    Threads are capped at 32: with all 256 logical cores of the GPU box torch's intra-op pool oversubscribes and one batch-8
+    step took 192 s (0.04 img/s); the sample is sized so that warm-up + timed steps stay within ~30 s."""
     from oracle import torch_ref as R
     torch.manual_seed(1029)
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    threads = max(1, min(max_threads, os.cpu_count() or 1))
+    torch.set_num_threads(threads)
     model = R.YOLOv5(80, "s").train()
     opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4)
     imgs, targets = R.synthetic_batch(cpu_batch, size, seed=1029)
 
-    def step():
-        loss = model(imgs, targets, "train")["loss"]
+    def step(b):
+        loss = model(imgs[:b], targets[:b], "train")["loss"]
         loss.backward()
         opt.step()
         opt.zero_grad(set_to_none=True)
 
-    step()  # warm-up
+    t0 = time.perf_counter()
+    step(1)  # warm-up on one image (allocator, thread pool, lazy inits)
+    warm = time.perf_counter() - t0
+    # size the timed sample from the warm-up: whole batches if they fit the budget, otherwise a smaller batch
+    b = cpu_batch
+    while b > 1 and warm * b > budget_s:
+        b //= 2
     n, t0 = 0, time.perf_counter()
     while True:
-        step()
+        step(b)
         n += 1
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 3:
             break
-    return {"value": round(cpu_batch * n / el, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle YOLOv5-s fp32 train step (fwd+loss+bwd+SGD), batch %d @%dx%d, %d timed steps after 1 warm-up, %.1f s"
-                      % (cpu_batch, size, size, n, el)}
+    return {"value": round(b * n / el, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle (oracle/torch_ref.py) YOLOv5-s fp32 train step (fwd+loss+bwd+SGD-nesterov), batch %d @%dx%d, %d timed step(s) "
+                      "after a 1-image warm-up, %.1f s, %d intra-op threads of %d logical cores"
+                      % (b, size, size, n, el, torch.get_num_threads(), os.cpu_count() or 1)}
 
 
 def deeplab_workload(dev, a, batch=16, size=(512, 1024), steps=5, warmup=2):
