@@ -177,7 +177,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = (not a.no_graph) and (not a.stock_optimizer) and world == 1
+    # at world > 1 the graph holds forward + loss + backward; the gradient all-reduce and the fused optimizer run eagerly after it
+    use_graph = (not a.no_graph) and (not a.stock_optimizer)
     for _ in range(a.warmup):
         step(imgs, gts)
     if use_graph:  # the W warm-up steps above ran eagerly; the K timed steps replay ONE hipGraph of the whole step
@@ -193,10 +194,10 @@ def main():
     el = time.perf_counter() - t0
     ops.TIMER.enabled = False
     timing_source = "HIP events around every conv launch inside the timed region (eager)"
-    if use_graph and not a.no_kernel_timing and rank == 0:
+    if use_graph and not a.no_kernel_timing:  # every rank takes part (the steps contain collectives); only rank 0 records events
         # per-kernel events cannot ride inside a graph replay: time the same K steps once more, eagerly, right after
         step.graph = None
-        ops.TIMER.enabled = True
+        ops.TIMER.enabled = rank == 0
         ops.TIMER.reset()
         for _ in range(a.steps):
             step(imgs, gts)
@@ -218,7 +219,7 @@ def main():
             "config": {"workload": "coco_yolov5_s.yml YOLOv5-s %dx%d bf16 train step (fwd+loss+bwd+SGD-nesterov+EMA), per-GPU batch %d, "
                                    "synthetic COCO-shape tensors resident in HBM" % (a.size, a.size, a.batch),
                        "global_batch": gb, "parallelism": "dp%d" % world, "final_loss": round(loss_val, 4),
-                       "launch": "hipGraph replay of the whole step" if use_graph else "eager"},
+                       "launch": ("hipGraph replay of the whole step" if world == 1 else "hipGraph replay of forward+loss+backward, then RCCL all-reduce of the gradient arena + fused optimizer") if use_graph else "eager"},
         }
         summ = ops.TIMER.summary()
         if summ:

@@ -140,6 +140,9 @@ class FlatTrainState:
         self._pending = None
         self._works = []
         self._stream = None
+        # defer mode (hipGraph replay at world > 1): gradients are NOT reduced while backward runs (collectives are never
+        # captured); finish_allreduce() then reduces the whole gradient arena with ONE in-place collective on the current stream
+        self.defer_allreduce = False
         if self.world > 1:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
@@ -156,7 +159,7 @@ class FlatTrainState:
 
     def mark_ready(self, i):
         """Called when parameter i's gradient for this step is complete in the arena."""
-        if self.world == 1 or i in self._seen:
+        if self.world == 1 or self.defer_allreduce or i in self._seen:
             return
         self._seen.add(i)
         bi = self.bucket_of[i]
@@ -176,6 +179,9 @@ class FlatTrainState:
 
     def finish_allreduce(self):
         if self.world == 1:
+            return
+        if self.defer_allreduce:
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.group)
             return
         for bi, n in enumerate(self._pending):
             if n > 0:  # some parameters received no gradient this step (their arena slots are zero)
@@ -251,6 +257,7 @@ class FlatTrainStep:
         self.model, self.state, self.sync_buffers = model, state, sync_buffers
         self.g1 = self.g2 = None
         self.static_losses = None
+        self.eager_tail = False
         self.static_imgs = self.static_targets = None
         self.feats = self.g_feats = None
 
@@ -262,6 +269,8 @@ class FlatTrainStep:
     def graph(self, v):
         if v is None:
             self.g1 = self.g2 = None
+            self.state.defer_allreduce = False
+            self.eager_tail = False
 
     def _eager(self, imgs, targets):
         losses = self.model(imgs, targets, "train")
@@ -270,8 +279,9 @@ class FlatTrainStep:
         return losses
 
     def capture(self, imgs, targets, warmup=2):
-        if self.state.world > 1:
-            raise L.CvhipError("hipGraph capture of the multi-GPU step is not enabled (eager mode is used)")
+        multi = self.state.world > 1  # collectives stay outside the graph(s): backward is replayed, then all-reduce + optimizer run eagerly
+        self.state.defer_allreduce = multi
+        self.eager_tail = multi
         if not torch.is_tensor(targets):
             raise L.CvhipError("capture needs the fixed-shape target tensor (e.g. yolov5.targets_to_tensor)")
         m, st = self.model, self.state
@@ -293,7 +303,8 @@ class FlatTrainStep:
                 _, feats = m.forward_features(self.static_imgs)
                 losses = m.loss_from_features(feats, self.static_targets)
                 losses["loss"].backward()
-                st.step_kernels()
+                if not multi:
+                    st.step_kernels()
             self.static_losses = losses
             self.g1, self.g2 = g, None
             return
@@ -305,7 +316,8 @@ class FlatTrainStep:
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2, pool=pool):
             torch.autograd.backward(self.feats, grad_tensors=self.g_feats)
-            st.step_kernels()
+            if not multi:
+                st.step_kernels()
         self.g1, self.g2 = g1, g2
 
     def __call__(self, imgs, targets):
@@ -315,9 +327,13 @@ class FlatTrainStep:
                 self.static_imgs.copy_(imgs, non_blocking=True)
             if targets is not self.static_targets:
                 self.static_targets.copy_(targets, non_blocking=True)
+            if self.sync_buffers and st.world > 1 and st.buf.numel():
+                dist.broadcast(st.buf, 0, group=st.group)  # DDP broadcast_buffers: ONE collective
             st.pre_step()
             self.g1.replay()
             if self.g2 is None:  # single-graph step
+                if self.eager_tail:
+                    st.step_kernels()
                 st.post_step()
                 return self.static_losses
             p = [f.detach().requires_grad_(True) for f in self.feats]
@@ -326,6 +342,8 @@ class FlatTrainStep:
             for d, g in zip(self.g_feats, grads):
                 d.copy_(g)
             self.g2.replay()
+            if self.eager_tail:
+                st.step_kernels()
             st.post_step()
             return losses
         if self.sync_buffers and st.world > 1 and st.buf.numel():
