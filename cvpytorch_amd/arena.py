@@ -279,6 +279,9 @@ class FlatTrainStep:
         return losses
 
     def capture(self, imgs, targets, warmup=2):
+        from .bricks import sync_of
+        if any(sync_of(mm) is not None for mm in self.model.modules()):
+            raise L.CvhipError("the step contains active HipSyncBN layers (collectives inside forward/backward): it is not captured; run it eagerly")
         multi = self.state.world > 1  # collectives stay outside the graph(s): backward is replayed, then all-reduce + optimizer run eagerly
         self.state.defer_allreduce = multi
         self.eager_tail = multi

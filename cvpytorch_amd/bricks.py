@@ -187,6 +187,7 @@ class HipConv2d(nn.Conv2d):
                           eps=(bn.eps if bn is not None else 1e-5), state=self._hip_state,
                           track=(bn.track_running_stats and bn.training) if bn is not None else False)
         cfg.vkey = (id(self.weight), self.weight._version)
+        cfg.sync = sync_of(bn) if bn is not None else None
         # flat gradient arena (cvpytorch_amd/arena.py): let backward accumulate straight into the parameters' slots
         ar = getattr(self.weight, "_hip_arena", None)
         if ar is not None and torch.is_grad_enabled():
@@ -213,7 +214,45 @@ class HipBN(nn.BatchNorm2d):
         if self.momentum is None:
             raise L.CvhipError("HipBN: cumulative moving average (momentum=None) is not supported")
         return ops.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, None, True, training,
-                          self.momentum, self.eps, L.ACT_NONE, 0.0, self.track_running_stats and self.training)
+                          self.momentum, self.eps, L.ACT_NONE, 0.0, self.track_running_stats and self.training, sync_of(self))
+
+
+def sync_of(bn):
+    """(process_group, world) when `bn` is a HipSyncBN whose statistics must be shared right now, else None."""
+    if not isinstance(bn, HipSyncBN) or not (bn.training or bn.running_mean is None):
+        return None
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    world = dist.get_world_size(bn.process_group)
+    return (bn.process_group, world) if world > 1 else None
+
+
+class HipSyncBN(HipBN):
+    """nn.SyncBatchNorm semantics (trainer.py:126-127) on the HIP engine: batch statistics are the statistics of the GLOBAL
+    batch — forward all-reduces the per-channel (sum, sum of squares), backward all-reduces (sum dy, sum dy*xhat); 2K floats
+    each, per layer. Equal per-rank batches are assumed (DistributedSampler). Eval mode and single-process runs behave as HipBN.
+    A step containing active HipSyncBN layers holds collectives and is therefore not captured into a hipGraph."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, process_group=None):
+        super().__init__(num_features, eps, momentum, affine, track_running_stats)
+        self.process_group = process_group
+
+
+def convert_sync_batchnorm(module, process_group=None):
+    """torch.nn.SyncBatchNorm.convert_sync_batchnorm for Hip / torch BatchNorm2d layers (parameters and buffers are shared,
+    state_dict keys unchanged)."""
+    out = module
+    if isinstance(module, nn.BatchNorm2d) and not isinstance(module, HipSyncBN):
+        out = HipSyncBN(module.num_features, module.eps, module.momentum, module.affine, module.track_running_stats, process_group)
+        out.weight, out.bias = module.weight, module.bias
+        out.running_mean, out.running_var, out.num_batches_tracked = module.running_mean, module.running_var, module.num_batches_tracked
+        out.training = module.training
+    for name, child in list(module.named_children()):
+        new = convert_sync_batchnorm(child, process_group)
+        if new is not child:
+            setattr(out, name, new)
+    return out
 
 
 class _HipAct:
@@ -315,6 +354,7 @@ CONV_LAYERS.register_module("HipConv2d", module=HipConv2d)
 NORM_LAYERS.register_module("BN", module=nn.BatchNorm2d)
 NORM_LAYERS.register_module("BN2d", module=nn.BatchNorm2d)
 NORM_LAYERS.register_module("SyncBN", module=nn.SyncBatchNorm)
+NORM_LAYERS.register_module("HipSyncBN", module=HipSyncBN)
 NORM_LAYERS.register_module("GN", module=nn.GroupNorm)
 NORM_LAYERS.register_module("HipBN", module=HipBN)
 for _m in (nn.ReLU, nn.LeakyReLU, nn.PReLU, nn.ReLU6, nn.ELU, nn.Sigmoid, nn.Tanh, nn.SiLU, nn.Hardswish):
@@ -453,6 +493,8 @@ def hip_norm(cfg=None):
     c = dict(cfg) if cfg else dict(type="BN")
     if c.get("type") in ("BN", "BN2d"):
         c["type"] = "HipBN"
+    elif c.get("type") == "SyncBN":
+        c["type"] = "HipSyncBN"
     return c
 
 
@@ -625,7 +667,10 @@ def _swap_conv(m):
 
 
 def _swap_bn(m):
-    new = HipBN(m.num_features, m.eps, m.momentum, m.affine, m.track_running_stats)
+    if isinstance(m, nn.SyncBatchNorm):
+        new = HipSyncBN(m.num_features, m.eps, m.momentum, m.affine, m.track_running_stats, m.process_group)
+    else:
+        new = HipBN(m.num_features, m.eps, m.momentum, m.affine, m.track_running_stats)
     new.weight, new.bias = m.weight, m.bias
     new.running_mean, new.running_var, new.num_batches_tracked = m.running_mean, m.running_var, m.num_batches_tracked
     new.training = m.training

@@ -210,7 +210,7 @@ class ConvState:
 class ConvCfg:
     """Static configuration of one conv(+BN+act) layer (python-side)."""
     __slots__ = ("stride", "pad", "dil", "groups", "act", "act_param", "has_bn", "bn_training", "momentum", "eps",
-                 "state", "track", "vkey", "gw", "gb", "gg", "gbeta", "arena", "idx_w", "idx_b", "idx_bn")
+                 "state", "track", "vkey", "gw", "gb", "gg", "gbeta", "arena", "idx_w", "idx_b", "idx_bn", "sync")
 
     def __init__(self, stride, pad, dil, groups=1, act=L.ACT_NONE, act_param=0.0, has_bn=False, bn_training=True,
                  momentum=0.1, eps=1e-5, state=None, track=True):
@@ -224,6 +224,30 @@ class ConvCfg:
         # flat gradient arena hooks (cvpytorch_amd/arena.py): views to accumulate weight / bias / BN gradients into
         self.gw = self.gb = self.gg = self.gbeta = None
         self.arena, self.idx_w, self.idx_b, self.idx_bn = None, None, None, ()
+        self.sync = None  # SyncBN: (process_group or None for the default group, world_size) when statistics are shared across ranks
+
+
+# ---- SyncBatchNorm plumbing (trainer.py:126-127 -> torch.nn.SyncBatchNorm semantics) -------------------------------------
+def _sync_fwd_totals(partial, rows, K, M, sync):
+    """Local partial rows [rows][2][K] -> global (sum, sum of squares) over all ranks as a 1-row partial buffer and the
+    global element count. One all-reduce of 2K floats (equal per-rank batches, as DistributedSampler gives)."""
+    import torch.distributed as dist
+    group, world = sync
+    tot = torch.empty((1 + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=partial.device)
+    L.call("cvhip_bn_bwd_finalize", partial.data_ptr(), rows, K, tot[0, 1].data_ptr(), tot[0, 0].data_ptr(), None, None, _stream())
+    dist.all_reduce(tot[0], op=dist.ReduceOp.SUM, group=group)
+    return tot, 1, M * world
+
+
+def _sync_bwd_sums(dgamma, dbeta, sync):
+    """Global (sum dy*xhat, sum dy) scaled by 1/world: cvhip_bn_act_bwd_apply divides by the LOCAL row count, and
+    global_sum / M_total == (global_sum / world) / M_local. The parameter gradients stay local (DDP averages them later)."""
+    import torch.distributed as dist
+    group, world = sync
+    g = torch.stack([dgamma, dbeta])
+    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+    g = g / world
+    return g[0], g[1]
 
 
 def _colreduce_rows(M, Cc):
@@ -305,7 +329,10 @@ class ConvBnAct(torch.autograd.Function):
             bt = beta.detach() if beta is not None else None
             rm = running_mean if cfg.track else None
             rv = running_var if cfg.track else None
-            L.call("cvhip_bn_finalize", partial.data_ptr(), rows, K, M, _ptr(g), _ptr(bt), _ptr(rm), _ptr(rv),
+            Mstat = M
+            if cfg.sync is not None:
+                partial, rows, Mstat = _sync_fwd_totals(partial, rows, K, M, cfg.sync)
+            L.call("cvhip_bn_finalize", partial.data_ptr(), rows, K, Mstat, _ptr(g), _ptr(bt), _ptr(rm), _ptr(rv),
                    cfg.momentum, cfg.eps, stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), st)
         elif cfg.has_bn:
             stats = torch.empty((4, K), dtype=torch.float32, device=dev)
@@ -368,9 +395,10 @@ class ConvBnAct(torch.autograd.Function):
                     need_dg = need_dbeta = False  # already accumulated into the gradient arena
                     for i in cfg.idx_bn:
                         arena.mark_ready(i)
+                ag, ab = (dgamma, dbeta) if cfg.sync is None else _sync_bwd_sums(dgamma, dbeta, cfg.sync)
                 L.call("cvhip_bn_act_bwd_apply", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, dy.data_ptr(), Kp, M, K,
                        stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
-                       dgamma.data_ptr(), dbeta.data_ptr(), cfg.act, cfg.act_param, st)
+                       ag.data_ptr(), ab.data_ptr(), cfg.act, cfg.act_param, st)
             else:
                 sc = stats[2].data_ptr() if stats is not None else None
                 sh = stats[3].data_ptr() if stats is not None else None
@@ -465,7 +493,7 @@ class BnAct(torch.autograd.Function):
     """z = act(bn(y)) (+ residual) for an arbitrary NHWC input (statistics by a separate reduction pass)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, residual, has_bn, training, momentum, eps, act, act_param, track):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, residual, has_bn, training, momentum, eps, act, act_param, track, sync=None):
         y, y_ld = as_nhwc(y)
         N, K, P, Q = y.shape
         M = N * P * Q
@@ -478,7 +506,10 @@ class BnAct(torch.autograd.Function):
             partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
             L.call("cvhip_bn_stats_partial", y.data_ptr(), M, K, y_ld, partial.data_ptr(), st)
             stats = torch.empty((4, K), dtype=torch.float32, device=dev)
-            L.call("cvhip_bn_finalize", partial.data_ptr(), rows, K, M, _ptr(gamma.detach().float() if gamma is not None else None),
+            Mstat = M
+            if sync is not None:
+                partial, rows, Mstat = _sync_fwd_totals(partial, rows, K, M, sync)
+            L.call("cvhip_bn_finalize", partial.data_ptr(), rows, K, Mstat, _ptr(gamma.detach().float() if gamma is not None else None),
                    _ptr(beta.detach().float() if beta is not None else None), _ptr(running_mean if track else None),
                    _ptr(running_var if track else None), float(momentum), float(eps), stats[0].data_ptr(), stats[1].data_ptr(),
                    stats[2].data_ptr(), stats[3].data_ptr(), st)
@@ -494,6 +525,7 @@ class BnAct(torch.autograd.Function):
         L.call("cvhip_bn_act_fwd", y.data_ptr(), y_ld, z.data_ptr(), K, M, K, _ptr(stats[2]) if stats is not None else None,
                _ptr(stats[3]) if stats is not None else None, act, float(act_param), _ptr(residual), res_ld, st)
         ctx.meta = (N, K, P, Q, y_ld, train_bn, act, float(act_param), residual is not None)
+        ctx.sync = sync if train_bn else None
         ctx.save_for_backward(y, stats)
         return z
 
@@ -515,21 +547,22 @@ class BnAct(torch.autograd.Function):
             dgamma = torch.empty((K,), dtype=torch.float32, device=dev)
             dbeta = torch.empty((K,), dtype=torch.float32, device=dev)
             L.call("cvhip_bn_bwd_finalize", partial.data_ptr(), rows, K, dgamma.data_ptr(), dbeta.data_ptr(), None, None, st)
+            ag, ab = (dgamma, dbeta) if ctx.sync is None else _sync_bwd_sums(dgamma, dbeta, ctx.sync)
             L.call("cvhip_bn_act_bwd_apply", dz.data_ptr(), dz_ld, y.data_ptr(), y_ld, dy.data_ptr(), K, M, K,
-                   stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), dgamma.data_ptr(),
-                   dbeta.data_ptr(), act, ap, st)
+                   stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), ag.data_ptr(),
+                   ab.data_ptr(), act, ap, st)
         else:
             sc = stats[2].data_ptr() if stats is not None else None
             sh = stats[3].data_ptr() if stats is not None else None
             L.call("cvhip_bn_act_bwd_apply", dz.data_ptr(), dz_ld, y.data_ptr(), y_ld, dy.data_ptr(), K, M, K, sc, sh, None, None,
                    None, None, act, ap, st)
         return (dy, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None, None, None,
-                dz if has_res else None, None, None, None, None, None, None, None)
+                dz if has_res else None, None, None, None, None, None, None, None, None)
 
 
 def bn_act(y, gamma=None, beta=None, running_mean=None, running_var=None, residual=None, has_bn=True, training=True,
-           momentum=0.1, eps=1e-5, act=L.ACT_NONE, act_param=0.0, track=True):
-    return BnAct.apply(y, gamma, beta, running_mean, running_var, residual, has_bn, training, momentum, eps, act, act_param, track)
+           momentum=0.1, eps=1e-5, act=L.ACT_NONE, act_param=0.0, track=True, sync=None):
+    return BnAct.apply(y, gamma, beta, running_mean, running_var, residual, has_bn, training, momentum, eps, act, act_param, track, sync)
 
 
 class MaxPool2d(torch.autograd.Function):

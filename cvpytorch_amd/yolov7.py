@@ -20,7 +20,7 @@ import torch.nn as nn
 
 from . import lib as L
 from . import ops
-from .bricks import bn_tick  # noqa: E402
+from .bricks import bn_tick, sync_of  # noqa: E402
 from .bricks import HipBN, HipConv2d, HipConvBN, HipConvModule, HipMaxPool2d, HipSiLU
 from .yolov5 import YOLOv5Loss, targets_to_tensor, non_max_suppression
 
@@ -149,7 +149,7 @@ class RepConv(nn.Module):
         if bn is not None:
             bn_tick(bn)
             a = ops.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, a, True, bn.training or bn.running_mean is None,
-                           bn.momentum, bn.eps, L.ACT_NONE, 0.0, bn.track_running_stats and bn.training)
+                           bn.momentum, bn.eps, L.ACT_NONE, 0.0, bn.track_running_stats and bn.training, sync_of(bn))
         return self.act(self.rbr_1x1(x, residual=a))
 
 

@@ -94,3 +94,72 @@ def test_two_ranks_on_one_gpu(use_graph):
         assert r[3], r                  # parameters identical on both ranks after 3 steps
     assert res[0][4] == res[1][4]
     assert all(r[5] == (4 if use_graph else 3) for r in res), res
+
+
+def _syncbn_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from cvpytorch_amd import bricks, yolo_blocks
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(0)
+        torch.manual_seed(3)
+        net = torch.nn.Sequential(bricks.HipConvModule(16, 32, 3, padding=1, norm_cfg=dict(type="BN"), act_cfg=dict(type="SiLU")),
+                                  yolo_blocks.CSPLayer(32, 32, n=1, norm_cfg=dict(type="BN"), act_cfg=dict(type="SiLU")),
+                                  bricks.HipBN(32))
+        g = torch.Generator().manual_seed(9)
+        xfull = torch.randn(8, 16, 12, 10, generator=g).to(torch.bfloat16)
+        cot = torch.randn(8, 32, 12, 10, generator=g)
+        import copy
+        full = copy.deepcopy(net).to(dev).train()                       # plain BN on the whole batch
+        sync = bricks.convert_sync_batchnorm(copy.deepcopy(net)).to(dev).train()   # SyncBN on this rank's half
+        assert list(sync.state_dict().keys()) == list(full.state_dict().keys())
+        assert sum(isinstance(m, bricks.HipSyncBN) for m in sync.modules()) == sum(isinstance(m, torch.nn.BatchNorm2d) for m in full.modules())
+
+        def run(m, x, c):
+            x = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            z = m(x)
+            (z.float() * c.to(dev)).sum().backward()
+            return z.detach().float(), x.grad.detach().float()
+
+        zf, gxf = run(full, xfull, cot)
+        lo, hi = rank * 4, rank * 4 + 4
+        zs, gxs = run(sync, xfull[lo:hi], cot[lo:hi])
+
+        def rel(a, b):
+            return float((a - b).norm() / b.norm().clamp(min=1e-12))
+
+        out = {"z": rel(zs, zf[lo:hi]), "gx": rel(gxs, gxf[lo:hi])}
+        pf = dict(full.named_parameters())
+        worst = 0.0
+        for n, p in sync.named_parameters():
+            gsum = p.grad.detach().float().clone()
+            dist.all_reduce(gsum)                                     # sum-type loss: full-batch grad == sum of the ranks' grads
+            worst = max(worst, rel(gsum, pf[n].grad.float()))
+        out["gparam"] = worst
+        bf = dict(full.named_buffers())
+        out["running"] = max(rel(b.float(), bf[n].float()) for n, b in sync.named_buffers() if "running" in n)
+        q.put((rank, "ok", out))
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, "error", traceback.format_exc()[-1500:]))
+
+
+def test_syncbn_two_ranks_equals_full_batch_bn():
+    """HipSyncBN over two ranks (half a batch each) == plain BN over the whole batch: outputs, input gradients, parameter
+    gradients (summed over ranks) and running statistics, to bf16 storage accuracy."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
+    for r in res:
+        o = r[2]
+        assert o["z"] < 1e-2 and o["gx"] < 2e-2 and o["gparam"] < 2e-2 and o["running"] < 1e-3, o
