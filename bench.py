@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-deeplab", action="store_true", help="skip the DeepLabv3+ (config 3) side workload")
     ap.add_argument("--no-graph", action="store_true", help="run the timed steps eagerly instead of replaying a hipGraph")
     ap.add_argument("--stock-optimizer", action="store_true", help="torch.optim.SGD + ModelEMA instead of the fused arena step")
+    ap.add_argument("--sync-bn", action="store_true", help="N > 1 only: HipSyncBN (trainer.py:126-127 converts BN to SyncBN under DDP); the step then runs eagerly")
     ap.add_argument("--torch-loss", action="store_true", help="fixed-shape torch-op YOLOv5 loss instead of the fused libcvhip loss kernels")
     return ap.parse_args()
 
@@ -163,6 +164,9 @@ def main():
     torch.manual_seed(1029)
     max_boxes = 20
     model = yolov5.YOLOv5(80, "s", max_targets=a.batch * max_boxes, fused_loss=not a.torch_loss).to(dev).train()
+    if a.sync_bn and world > 1:
+        from cvpytorch_amd.bricks import convert_sync_batchnorm
+        model = convert_sync_batchnorm(model)
     if world > 1:  # same initial weights everywhere (DDP broadcasts rank 0's at construction)
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, 0)
@@ -183,7 +187,7 @@ def main():
         torch.cuda.synchronize()
 
     # at world > 1 the graph holds forward + loss + backward; the gradient all-reduce and the fused optimizer run eagerly after it
-    use_graph = (not a.no_graph) and (not a.stock_optimizer)
+    use_graph = (not a.no_graph) and (not a.stock_optimizer) and not (a.sync_bn and world > 1)
     for _ in range(a.warmup):
         step(imgs, gts)
     if use_graph:  # the W warm-up steps above ran eagerly; the K timed steps replay ONE hipGraph of the whole step
