@@ -22,7 +22,7 @@ from . import lib as L
 from . import ops
 from .bricks import bn_tick, sync_of  # noqa: E402
 from .bricks import HipBN, HipConv2d, HipConvBN, HipConvModule, HipMaxPool2d, HipSiLU
-from .yolov5 import YOLOv5Loss, targets_to_tensor, non_max_suppression
+from .yolov5 import YOLOv5Loss, YOLOv5LossFused, targets_to_tensor, non_max_suppression
 
 ANCHORS = [[[1.50000, 2.00000], [2.37500, 4.50000], [5.00000, 3.50000]],
            [[2.25000, 4.68750], [4.75000, 3.43750], [4.50000, 9.12500]],
@@ -216,13 +216,19 @@ class YOLOv7Detect(nn.Module):
             b.data[:, 5:] += math.log(0.6 / (self.num_classes - 0.99))
             mi.bias = torch.nn.Parameter(b.view(-1), requires_grad=True)
 
+    def forward_raw(self, x):
+        return [self.m[i](x[i]) for i in range(self.num_layers)]
+
+    def decode(self, raw):
+        anchors_px = [self.anchors[i] * self.stride[i] for i in range(self.num_layers)]
+        return ops.yolov5_decode(raw, self.stride, anchors_px, self.num_anchors, self.num_outputs)
+
     def forward(self, x):
-        raw = [self.m[i](x[i]) for i in range(self.num_layers)]
+        raw = self.forward_raw(x)
         train_out = [ops.head_permute(r, self.num_anchors, self.num_outputs) for r in raw]
         if self.training:
             return None, train_out
-        anchors_px = [self.anchors[i] * self.stride[i] for i in range(self.num_layers)]
-        return ops.yolov5_decode(raw, self.stride, anchors_px, self.num_anchors, self.num_outputs), train_out
+        return self.decode(raw), train_out
 
 
 class YOLOv7Backbone(nn.Module):
@@ -248,20 +254,26 @@ class YOLOv7(nn.Module):
     """src/models/yolov7.py:150-256. forward(imgs, targets, mode): 'train' -> losses dict; 'val' -> (losses, outputs)."""
     anchors = ANCHORS
 
-    def __init__(self, num_classes=80, width_mul=1.0, max_targets=None):
+    def __init__(self, num_classes=80, width_mul=1.0, max_targets=None, fused_loss=False):
         super().__init__()
         self.num_classes = num_classes
+        self.fused_loss = fused_loss
+        self.loss_capturable = fused_loss
         self.backbone = YOLOv7Backbone(width_mul)
         self.neck = YOLOv7Neck(width_mul=width_mul)
         self.head = YOLOv7Head(width_mul=width_mul)
         self.detect = YOLOv7Detect(num_classes, width_mul=width_mul)
-        self.loss = YOLOv5Loss(num_classes, anchors=ANCHORS, hyp_box=0.05, hyp_obj=0.7, hyp_cls=0.3)
+        self.loss = (YOLOv5LossFused if fused_loss else YOLOv5Loss)(num_classes, anchors=ANCHORS, hyp_box=0.05, hyp_obj=0.7, hyp_cls=0.3)
         self.conf_thres, self.iou_thres = 0.001, 0.65
         self.max_targets = max_targets
         _bn_fix(self)
 
     def forward_features(self, imgs):
-        return self.detect(self.head(self.neck(self.backbone(imgs))))
+        x = self.head(self.neck(self.backbone(imgs)))
+        if self.fused_loss:
+            raw = self.detect.forward_raw(x)
+            return (None if self.training else self.detect.decode(raw)), raw
+        return self.detect(x)
 
     def loss_from_features(self, train_out, gts):
         losses = {}
