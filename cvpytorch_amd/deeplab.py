@@ -173,6 +173,7 @@ class EncoderDecoder(nn.Module):
     def __init__(self, num_classes=19, output_stride=32, dropout_ratio=0.1, ignore_index=255):
         super().__init__()
         self.num_classes, self.ignore_index = num_classes, ignore_index
+        self.loss_capturable = True  # resize + cross-entropy are libcvhip ops: arena.FlatTrainStep captures ONE graph
         self.backbone = ResNet("resnet50v1c", out_stages=(1, 4), output_stride=output_stride)
         self.head = Deeplabv3PlusHead(num_classes, in_channels=2048, channels=512, dilations=(1, 12, 24, 36), low_in_channels=256,
                                       low_channels=48, dropout_ratio=dropout_ratio)

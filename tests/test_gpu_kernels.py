@@ -231,7 +231,9 @@ def test_conv_channel_slice_operands():
 # ------------------------------------------------------------------------------------------------------
 # depthwise
 # ------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("Cc,H,W,s,p,d", [(32, 12, 14, 1, 1, 1), (64, 10, 10, 1, 3, 3), (48, 11, 9, 2, 1, 1), (20, 8, 8, 1, 1, 1)])
+@pytest.mark.parametrize("Cc,H,W,s,p,d", [(32, 12, 14, 1, 1, 1), (64, 10, 10, 1, 3, 3), (48, 11, 9, 2, 1, 1), (20, 8, 8, 1, 1, 1),
+                                         # 3x3/s1/d1 register-window fast path: several row segments, ragged tails, pad 0 / 2, > 256 channels
+                                         (304, 21, 200, 1, 1, 1), (16, 9, 130, 1, 0, 1), (24, 9, 70, 1, 2, 1), (2304, 5, 7, 1, 1, 1)])
 def test_depthwise(Cc, H, W, s, p, d):
     torch.manual_seed(0)
     N = 2
