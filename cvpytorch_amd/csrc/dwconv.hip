@@ -125,12 +125,15 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const DwParams p) {
 // channel vector), R*S <= 9 taps accumulated in registers, LDS reduce over row lanes, one fp32
 // atomic per (block, channel, tap).
 constexpr int kDwMaxTaps = 9;
+constexpr int kDwWgradCols = 32;
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwParams p, int rows_per_block) {
   __shared__ float red[256 * 8];
   const int CV = (p.C + 7) >> 3;
   const bool vec = dw_vec_ok(p);
   const int t = threadIdx.x;
-  const int cols = CV < 256 ? CV : 256;
+  // blockIdx.y = chunk of <= 32 channel vectors (wide layers on small maps — ASPP: 2048 channels @16x32 — would otherwise
+  // run 32 blocks with one row lane each); 256 / cols row lanes per block
+  const int cols = CV < kDwWgradCols ? CV : kDwWgradCols;
   const int rpp = 256 / cols;
   const int tx = t % cols, ty = t / cols;
   const int64_t M = (int64_t)p.N * p.P * p.Q;
@@ -138,7 +141,8 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwParams p, int row
   int64_t r_end = r_begin + rows_per_block;
   if (r_end > M) r_end = M;
   const int T = p.R * p.S;
-  for (int cv0 = 0; cv0 < CV; cv0 += cols) {
+  {
+    const int cv0 = blockIdx.y * cols;
     const int cv = cv0 + tx;
     const int c = cv * 8;
     float acc[kDwMaxTaps][8];
@@ -458,11 +462,16 @@ int cvhip_dwconv2d_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy
     return check_launch("dw3x3_kernel<1>");
   }
   const int64_t M = (int64_t)p.N * p.P * p.Q;
-  int64_t blocks = cdiv64(M, 256);
-  if (blocks > 1024) blocks = 1024;
+  const int CVh = (p.C + 7) / 8;
+  const int colsh = CVh < kDwWgradCols ? CVh : kDwWgradCols;
+  const int chunks = cdiv(CVh, colsh);
+  const int rpp = 256 / colsh;
+  int64_t blocks = cdiv64(M, (int64_t)rpp * 16);  // >= 16 row visits per thread
+  const int64_t cap = 2048 / chunks > 1 ? 2048 / chunks : 1;
+  if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   const int rows_per_block = (int)cdiv64(M, blocks);
-  hipLaunchKernelGGL(dw_wgrad_kernel, dim3((int)blocks), dim3(256), 0, s, p, rows_per_block);
+  hipLaunchKernelGGL(dw_wgrad_kernel, dim3((int)blocks, chunks), dim3(256), 0, s, p, rows_per_block);
   return check_launch("dw_wgrad_kernel");
 }
 

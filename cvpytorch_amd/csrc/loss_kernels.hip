@@ -66,10 +66,53 @@ __global__ void seg_ce_finalize_kernel(const float* partial, int rows, float* ou
   }
 }
 
-// dlogits[m][c] = gscale[0] * (softmax_c - [c==t]) / count  for valid pixels, 0 otherwise; pad channels zero
+// dlogits[m][c] = gscale[0] * (softmax_c - [c==t]) / count  for valid pixels, 0 otherwise; pad channels zero.
+// A block owns 256 consecutive pixels = one contiguous run of 256*ld elements in both tensors: rows are staged through LDS
+// so global loads / stores are coalesced whatever the (odd) class count — a thread-per-pixel walk of 38-byte rows ran at
+// 0.3 TB/s (1.27 ms for 16x512x1024x19).
+constexpr int kCeMaxLd = 32;
 __global__ __launch_bounds__(256) void seg_ce_bwd_kernel(const bf16_t* __restrict__ logits, int ld, const int64_t* __restrict__ target, int64_t M,
                                                          int C, int ignore, const float* __restrict__ stat, const float* __restrict__ gscale,
                                                          bf16_t* __restrict__ dlogits, int ld_d) {
+  __shared__ float tile[256 * kCeMaxLd];
+  __shared__ bf16_t tout[256 * kCeMaxLd];
+  const float cnt = stat[1];
+  const float g = (cnt > 0.f ? 1.f / cnt : 0.f) * (gscale ? gscale[0] : 1.f);
+  const int t = threadIdx.x;
+  for (int64_t m0 = (int64_t)blockIdx.x * 256; m0 < M; m0 += (int64_t)gridDim.x * 256) {
+    const int rows = (int)(M - m0 < 256 ? M - m0 : 256);
+    const int n_in = rows * ld;
+    const bf16_t* src = logits + m0 * ld;
+    for (int i = t; i < n_in; i += 256) tile[i] = (float)src[i];
+    __syncthreads();
+    if (t < rows) {
+      const int64_t tt = target[m0 + t];
+      const float* row = tile + t * ld;
+      bf16_t* orow = tout + t * ld_d;
+      if (tt == ignore || tt < 0 || tt >= C) {
+        for (int c = 0; c < ld_d; ++c) orow[c] = (bf16_t)0.f;
+      } else {
+        float mx = -INFINITY;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, row[c]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += __expf(row[c] - mx);
+        const float inv = 1.f / se;
+        for (int c = 0; c < C; ++c) orow[c] = (bf16_t)(g * (__expf(row[c] - mx) * inv - (c == (int)tt ? 1.f : 0.f)));
+        for (int c = C; c < ld_d; ++c) orow[c] = (bf16_t)0.f;
+      }
+    }
+    __syncthreads();
+    const int n_out = rows * ld_d;
+    bf16_t* dst = dlogits + m0 * ld_d;
+    for (int i = t; i < n_out; i += 256) dst[i] = tout[i];
+    __syncthreads();
+  }
+}
+
+// generic fallback (pitches above kCeMaxLd)
+__global__ __launch_bounds__(256) void seg_ce_bwd_rows_kernel(const bf16_t* __restrict__ logits, int ld, const int64_t* __restrict__ target, int64_t M,
+                                                              int C, int ignore, const float* __restrict__ stat, const float* __restrict__ gscale,
+                                                              bf16_t* __restrict__ dlogits, int ld_d) {
   const float cnt = stat[1];
   const float g = (cnt > 0.f ? 1.f / cnt : 0.f) * (gscale ? gscale[0] : 1.f);
   for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
@@ -145,8 +188,15 @@ int cvhip_seg_ce_fwd(const void* logits, int32_t ld, const int64_t* target, int6
 int cvhip_seg_ce_bwd(const void* logits, int32_t ld, const int64_t* target, int64_t M, int32_t C, int32_t ignore_index, const float* out2,
                      const float* grad_scale, void* dlogits, int32_t ld_d, void* stream) {
   if (!logits || !target || !out2 || !dlogits || M <= 0 || C <= 0 || ld < C || ld_d < C) return CVHIP_ERR_INVALID;
-  hipLaunchKernelGGL(seg_ce_bwd_kernel, dim3(grid_for(M)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, target, M, C,
-                     ignore_index, out2, grad_scale, (bf16_t*)dlogits, ld_d);
+  if (ld <= kCeMaxLd && ld_d <= kCeMaxLd) {
+    int64_t blocks = (M + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(seg_ce_bwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, target, M, C,
+                       ignore_index, out2, grad_scale, (bf16_t*)dlogits, ld_d);
+  } else {
+    hipLaunchKernelGGL(seg_ce_bwd_rows_kernel, dim3(grid_for(M)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, target, M, C,
+                       ignore_index, out2, grad_scale, (bf16_t*)dlogits, ld_d);
+  }
   return check_launch("seg_ce_bwd_kernel");
 }
 
