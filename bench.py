@@ -49,7 +49,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(size, cpu_batch, budget_s=20.0, max_threads=32):
+def cpu_baseline(size, cpu_batch, budget_s=12.0, max_threads=32):
     """Oracle train step on the host cores: bounded sample (SURVEY.md §8d 'CPU baseline').
     Threads are capped at 32: with all 256 logical cores of the GPU box torch's intra-op pool oversubscribes and one batch-8
     step took 192 s (0.04 img/s); the sample is sized so that warm-up + timed steps stay within ~30 s."""
@@ -79,7 +79,7 @@ def cpu_baseline(size, cpu_batch, budget_s=20.0, max_threads=32):
         step(b)
         n += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or n >= 3:
+        if el >= budget_s or n >= 40:
             break
     return {"value": round(b * n / el, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "oracle (oracle/torch_ref.py) YOLOv5-s fp32 train step (fwd+loss+bwd+SGD-nesterov), batch %d @%dx%d, %d timed step(s) "
