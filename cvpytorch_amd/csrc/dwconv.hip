@@ -274,9 +274,24 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const Dw3Params p) {
         win[r][0] = dw3_load(rp[r], rok[r], q0 - p.pw, p.IW, p.in_ld, c);
         win[r][1] = dw3_load(rp[r], rok[r], q0 - p.pw + 1, p.IW, p.in_ld, c);
       }
+      // software pipeline: the raw 16-B loads of the NEXT pixel's new window column (and dy) are in flight while this
+      // pixel's 72 FMAs run (the window dependency would otherwise expose one memory round trip per pixel)
+      uint4 nraw[3], ndy;
+      auto issue = [&](int q) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const int iw = q - p.pw + 2;
+          const bool ok = rok[r] && (unsigned)iw < (unsigned)p.IW;
+          nraw[r] = ok ? *reinterpret_cast<const uint4*>(rp[r] + (int64_t)iw * p.in_ld + c) : uint4{0u, 0u, 0u, 0u};
+        }
+        if (MODE == 1) ndy = *reinterpret_cast<const uint4*>(p.dy + ((int64_t)row * p.OW + q) * p.dy_ld + c);
+      };
+      issue(q0);
       for (int q = q0; q < q1; ++q) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) win[r][2] = dw3_load(rp[r], rok[r], q - p.pw + 2, p.IW, p.in_ld, c);
+        for (int r = 0; r < 3; ++r) win[r][2] = unpack8(nraw[r]);
+        const uint4 cdy = ndy;
+        if (q + 1 < q1) issue(q + 1);
         if (MODE == 0) {
           f32x8 o;
 #pragma unroll
@@ -290,7 +305,7 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const Dw3Params p) {
           }
           *reinterpret_cast<uint4*>(p.out + ((int64_t)row * p.OW + q) * p.out_ld + c) = pack8(o);
         } else {
-          const f32x8 g = unpack8(*reinterpret_cast<const uint4*>(p.dy + ((int64_t)row * p.OW + q) * p.dy_ld + c));
+          const f32x8 g = unpack8(cdy);
 #pragma unroll
           for (int r = 0; r < 3; ++r)
 #pragma unroll
