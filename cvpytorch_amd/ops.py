@@ -811,8 +811,9 @@ class ResizeBilinear(torch.autograd.Function):
     def forward(ctx, x, Ho, Wo, align_corners):
         x, ld = as_nhwc(x)
         N, Cc, Hi, Wi = x.shape
-        y = empty_nhwc(N, Cc, Ho, Wo, x.device)
-        L.call("cvhip_resize_bilinear_fwd", x.data_ptr(), ld, y.data_ptr(), Cc, N, Cc, Hi, Wi, Ho, Wo, int(align_corners), _stream())
+        yld = _round8(Cc)  # padded pitch: odd channel counts (19-class logits) keep the 16-byte vector path
+        y = empty_nhwc(N, Cc, Ho, Wo, x.device, ld=yld)
+        L.call("cvhip_resize_bilinear_fwd", x.data_ptr(), ld, y.data_ptr(), yld, N, Cc, Hi, Wi, Ho, Wo, int(align_corners), _stream())
         ctx.meta = (N, Cc, Hi, Wi, Ho, Wo, int(align_corners))
         return y
 
@@ -820,8 +821,9 @@ class ResizeBilinear(torch.autograd.Function):
     def backward(ctx, dy):
         N, Cc, Hi, Wi, Ho, Wo, ac = ctx.meta
         dy, ld = as_nhwc(dy)
-        dx = empty_nhwc(N, Cc, Hi, Wi, dy.device)
-        L.call("cvhip_resize_bilinear_bwd", dy.data_ptr(), ld, dx.data_ptr(), Cc, N, Cc, Hi, Wi, Ho, Wo, ac, _stream())
+        xld = _round8(Cc)
+        dx = empty_nhwc(N, Cc, Hi, Wi, dy.device, ld=xld)
+        L.call("cvhip_resize_bilinear_bwd", dy.data_ptr(), ld, dx.data_ptr(), xld, N, Cc, Hi, Wi, Ho, Wo, ac, _stream())
         return dx, None, None, None
 
 
