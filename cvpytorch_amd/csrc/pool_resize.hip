@@ -346,6 +346,32 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const BilParams p) {
   }
 }
 
+// uint8 NHWC image batch -> normalised bf16 NHWC with channels zero-padded to ld: y = x * scale[c] + shift[c]
+// (scale = 1 / (255 * std), shift = -mean / std: ToTensor + Normalize of the reference's CPU transforms fused with the
+// relayout the stem conv wants). One thread per pixel: C (<= 8) byte loads, one 16-byte store per 8 output channels.
+__global__ __launch_bounds__(256) void u8_norm_kernel(const unsigned char* __restrict__ x, bf16_t* __restrict__ y, int64_t npix, int C, int ld,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift) {
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = j < C ? scale[j] : 0.f;
+    sh[j] = j < C ? shift[j] : 0.f;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+    const unsigned char* px = x + i * C;
+    f32x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.v[j] = j < C ? (float)px[j] * sc[j] + sh[j] : 0.f;
+    bf16_t* dst = y + i * ld;
+    if ((ld & 7) == 0 && aligned16(y)) {
+      *reinterpret_cast<uint4*>(dst) = pack8(o);
+      for (int c = 8; c < ld; ++c) dst[c] = (bf16_t)0.f;
+    } else {
+      for (int c = 0; c < ld; ++c) dst[c] = (bf16_t)(c < 8 ? o.v[c] : 0.f);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // global average pool
 // ---------------------------------------------------------------------------------------------------
@@ -649,6 +675,14 @@ int cvhip_nchw_f32_to_nhwc_bf16_ld(const float* x, void* y, int32_t ld, int32_t 
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, x,
                      (bf16_t*)y, N, C, H, W, ld, C, 0);
   return check_launch("nchw_to_nhwc_kernel(ld)");
+}
+
+int cvhip_u8_nhwc_to_bf16_norm(const void* x_u8, int64_t npix, int32_t C, void* y_bf16, int32_t ld, const float* scale, const float* shift,
+                               void* stream) {
+  if (!x_u8 || !y_bf16 || !scale || !shift || npix <= 0 || C <= 0 || C > 8 || ld < C) return CVHIP_ERR_INVALID;
+  hipLaunchKernelGGL(u8_norm_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)x_u8, (bf16_t*)y_bf16,
+                     npix, C, ld, scale, shift);
+  return check_launch("u8_norm_kernel");
 }
 
 int cvhip_head_permute_fwd(const void* x, int32_t ld, float* y, int32_t N, int32_t A, int32_t NO, int32_t H, int32_t W,

@@ -99,6 +99,7 @@ SIGNATURES = {
     "cvhip_box_iou": (_i32, [_p, _i32, _p, _i32, _p, _p]),
     "cvhip_sgd_nesterov_ema": (_i32, [_p, _p, _p, _p, _i64, _p, _p, _p, _i32, _f32, _i32, _i32, _f32, _f32, _p, _p]),
     "cvhip_ema_update": (_i32, [_p, _p, _i64, _f32, _p, _p]),
+    "cvhip_u8_nhwc_to_bf16_norm": (_i32, [_p, _i64, _i32, _p, _i32, _p, _p, _p]),
     "cvhip_yolov5_loss_workspace_bytes": (_i64, [_ylp]),
     "cvhip_yolov5_loss_level_fwd": (_i32, [_ylp, _p, _p, _p, _p, _p]),
     "cvhip_yolov5_loss_finalize": (_i32, [_p, _i32, _p, _p, _f32, _f32, _f32, _i32, _f32, _p, _p, _p]),

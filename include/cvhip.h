@@ -266,6 +266,11 @@ int cvhip_global_avgpool_fwd(const void* x_bf16, int32_t ld_x, void* y_bf16, int
 int cvhip_global_avgpool_bwd(const void* dy_bf16, void* dx_bf16, int32_t ld_dx, int32_t N,
                              int32_t C, int32_t HW, void* stream);
 
+/* uint8 NHWC images (as the CPU loader produces them before ToTensor) -> normalised bf16 NHWC, channels zero-padded to ld:
+ * y = x * scale[c] + shift[c] with scale = 1/(255*std), shift = -mean/std == ToTensor + Normalize
+ * (src/data/transforms/det_transforms.py:102-109, conf/coco_yolov5_s.yml:36-37) fused with the stem's layout. C <= 8. */
+int cvhip_u8_nhwc_to_bf16_norm(const void* x_u8, int64_t npix, int32_t C, void* y_bf16, int32_t ld, const float* scale,
+                               const float* shift, void* stream);
 /* fp32 NCHW image batch -> bf16 NHWC with channels zero-padded to Cpad (trainer.py:157-175 H2D
  * boundary + channels_last relayout); and Focus space-to-depth (yolo_modules.py:30-36,
  * concat order TL, BL, TR, BR) fused with the same relayout. */
