@@ -38,8 +38,12 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* p0, const unsign
 }
 
 // TN: out-channel tile (128/64/32); K-column tile is always 128; reduction step 32 pixels.
+// A block is TWO 4-wave groups working on the two halves of the block's pixel range with private LDS rings; their
+// accumulators are folded through LDS before the epilogue, which halves the fp32 atomics per MFMA (the atomic epilogue was
+// 28 % of wgrad time: profiles/README.md) at unchanged occupancy (1 x 8 waves instead of 2 x 4 per CU).
+constexpr int kWgGroups = 2;
 template <int TN, int WN, int WK>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
+__global__ __launch_bounds__(256 * kWgGroups, 1) void wgrad_kernel(const WgradParams p) {
   constexpr int TK = 128;
   constexpr int WAVES_K = TK / WK;
   static_assert((TN / WN) * WAVES_K == 4, "4 waves per block");
@@ -52,11 +56,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   constexpr int X_ROWB = TK * 2;
   constexpr int D_BYTES = 32 * D_ROWB, X_BYTES = 32 * X_ROWB;
 
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * D_BYTES + 2 * X_BYTES];
-  unsigned char* const sD = smem;
-  unsigned char* const sX = smem + 2 * D_BYTES;
+  constexpr int GROUP_BYTES = 2 * D_BYTES + 2 * X_BYTES;
+  static_assert(kWgGroups * GROUP_BYTES >= 4 * NF * KF * 4 * 64 * 4, "LDS must hold one group's accumulators for the fold");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kWgGroups * GROUP_BYTES];
+  const int grp = threadIdx.x >> 8;
+  unsigned char* const sD = smem + grp * GROUP_BYTES;
+  unsigned char* const sX = sD + 2 * D_BYTES;
 
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x & 255, lane = t & 63, wave = t >> 6;
   const int wn = wave / WAVES_K, wk = wave % WAVES_K;
 
   // 1-D grid, XCD-aware: all (n, k) tiles of one pixel split get consecutive logical ids => the same XCD, so the x / dY
@@ -67,10 +74,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   const int tile = lin - split * tiles;
   const int ntile = tile / p.k_tiles, ktile = tile - ntile * p.k_tiles;
   const int n0 = ntile * TN, k0 = ktile * TK;
-  const int m_begin = split * p.m_per_split;
-  const int m_end = min(p.M, m_begin + p.m_per_split);
-  const int nsteps = (m_end - m_begin + 31) >> 5;
-  if (nsteps <= 0) return;
+  const int blk_begin = split * p.m_per_split;
+  const int blk_end = min(p.M, blk_begin + p.m_per_split);
+  if (blk_end <= blk_begin) return;
+  // group g takes rows [blk_begin + g*half, +half); both groups run the same number of steps (block-wide barriers), the
+  // shorter one sees masked rows
+  const int half = (((blk_end - blk_begin + kWgGroups - 1) / kWgGroups + 31) >> 5) << 5;
+  const int m_begin = blk_begin + grp * half;
+  const int m_end = min(blk_end, m_begin + half);
+  const int nsteps = half >> 5;
 
   // ---- X staging: thread owns 16-B column (t&15) of rows (t>>4) and (t>>4)+16 -------------------
   const int xv = t & 15;
@@ -192,6 +204,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     __syncthreads();
   }
 
+  // fold group 1 into group 0 through LDS (the staging rings are dead after the final barrier of the loop)
+  {
+    float* fold = reinterpret_cast<float*>(smem);
+    if (grp == 1) {
+#pragma unroll
+      for (int a = 0; a < NF; ++a)
+#pragma unroll
+        for (int b = 0; b < KF; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) fold[((wave * NF * KF + a * KF + b) * 4 + r) * 64 + lane] = acc[a][b][r];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int a = 0; a < NF; ++a)
+#pragma unroll
+      for (int b = 0; b < KF; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[a][b][r] += fold[((wave * NF * KF + a * KF + b) * 4 + r) * 64 + lane];
+  }
   // epilogue: lane holds D[n = 4*(lane>>4)+r][kcol = lane&15]
   if (p.ablate == 1 && acc[0][0][0] != 12345.678f) return;
 #pragma unroll
@@ -218,16 +250,16 @@ static int launch_wg(WgradParams& p, hipStream_t stream) {
   static int target = -1, min_rows = -1;
   if (target < 0) {
     const char* e = getenv("CVHIP_WGRAD_BLOCKS");
-    target = e ? atoi(e) : 768;
+    target = e ? atoi(e) : 768;  // blocks of 2 x 4 waves (sweep: profiles/README.md)
     const char* f = getenv("CVHIP_WGRAD_MINROWS");
-    min_rows = f ? atoi(f) : 512;
+    min_rows = f ? atoi(f) : 1024;  // >= 512 rows per group
   }
   int splits = cdiv(target, tiles);
   const int max_splits = (p.M + min_rows - 1) / min_rows;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   int mps = cdiv(p.M, splits);
-  mps = ((mps + 31) / 32) * 32;
+  mps = ((mps + 63) / 64) * 64;
   splits = cdiv(p.M, mps);
   p.m_per_split = mps;
   {
@@ -238,7 +270,7 @@ static int launch_wg(WgradParams& p, hipStream_t stream) {
     }
     p.ablate = abl;
   }
-  hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK>), dim3(tiles * splits), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK>), dim3(tiles * splits), dim3(256 * kWgGroups), 0, stream, p);
   return check_launch("wgrad_kernel");
 }
 
