@@ -31,6 +31,9 @@ struct WgradParams {
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
+// M * tiles threshold below which a block runs two 4-wave groups (per-shape A/B on YOLOv5-s and DeepLabv3+ layers)
+constexpr int64_t kWgTwoGroupWork = 600000;
+
 __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* p0, const unsigned char* p1) {
   bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0));
   bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p1));
@@ -41,9 +44,8 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* p0, const unsign
 // A block is TWO 4-wave groups working on the two halves of the block's pixel range with private LDS rings; their
 // accumulators are folded through LDS before the epilogue, which halves the fp32 atomics per MFMA (the atomic epilogue was
 // 28 % of wgrad time: profiles/README.md) at unchanged occupancy (1 x 8 waves instead of 2 x 4 per CU).
-constexpr int kWgGroups = 2;
-template <int TN, int WN, int WK>
-__global__ __launch_bounds__(256 * kWgGroups, 1) void wgrad_kernel(const WgradParams p) {
+template <int TN, int WN, int WK, int kWgGroups>
+__global__ __launch_bounds__(256 * kWgGroups, kWgGroups == 1 ? 2 : 1) void wgrad_kernel(const WgradParams p) {
   constexpr int TK = 128;
   constexpr int WAVES_K = TK / WK;
   static_assert((TN / WN) * WAVES_K == 4, "4 waves per block");
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256 * kWgGroups, 1) void wgrad_kernel(const WgradPa
   constexpr int D_BYTES = 32 * D_ROWB, X_BYTES = 32 * X_ROWB;
 
   constexpr int GROUP_BYTES = 2 * D_BYTES + 2 * X_BYTES;
-  static_assert(kWgGroups * GROUP_BYTES >= 4 * NF * KF * 4 * 64 * 4, "LDS must hold one group's accumulators for the fold");
+  static_assert(kWgGroups == 1 || kWgGroups * GROUP_BYTES >= 4 * NF * KF * 4 * 64 * 4, "LDS must hold one group's accumulators for the fold");
   __shared__ __attribute__((aligned(16))) unsigned char smem[kWgGroups * GROUP_BYTES];
   const int grp = threadIdx.x >> 8;
   unsigned char* const sD = smem + grp * GROUP_BYTES;
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(256 * kWgGroups, 1) void wgrad_kernel(const WgradPa
   }
 
   // fold group 1 into group 0 through LDS (the staging rings are dead after the final barrier of the loop)
-  {
+  if constexpr (kWgGroups == 2) {
     float* fold = reinterpret_cast<float*>(smem);
     if (grp == 1) {
 #pragma unroll
@@ -246,31 +248,33 @@ static int launch_wg(WgradParams& p, hipStream_t stream) {
   p.n_tiles = cdiv(p.Nout, TN);
   p.k_tiles = cdiv(p.Ktot, 128);
   const int tiles = p.n_tiles * p.k_tiles;
-  // fill ~3 blocks per CU; keep >= 8 reduction steps per split
-  static int target = -1, min_rows = -1;
+  static int target = -1, min_rows = -1, force_groups = -1, abl = -1;
   if (target < 0) {
     const char* e = getenv("CVHIP_WGRAD_BLOCKS");
-    target = e ? atoi(e) : 768;  // blocks of 2 x 4 waves (sweep: profiles/README.md)
+    target = e ? atoi(e) : 768;
     const char* f = getenv("CVHIP_WGRAD_MINROWS");
-    min_rows = f ? atoi(f) : 1024;  // >= 512 rows per group
+    min_rows = f ? atoi(f) : 512;  // per 4-wave group
+    const char* g = getenv("CVHIP_WGRAD_GROUPS");
+    force_groups = g ? atoi(g) : 0;
+    const char* a = getenv("CVHIP_WGRAD_ABLATE");
+    abl = a ? atoi(a) : 0;
   }
+  p.ablate = abl;
+  // Two 4-wave groups per block (accumulators folded through LDS, half the atomics) when the atomic epilogue is a large
+  // share of the block's work: few pixel rows per (n,k) tile. Otherwise 4-wave blocks (more resident blocks per CU).
+  // (the 32-wide output tile always gains: its blocks have the least MFMA work per atomic)
+  int groups = force_groups ? force_groups : ((TN == 32 || (int64_t)p.M * tiles <= kWgTwoGroupWork) ? 2 : 1);
+  const int rows_min = min_rows * groups;
   int splits = cdiv(target, tiles);
-  const int max_splits = (p.M + min_rows - 1) / min_rows;
+  const int max_splits = (p.M + rows_min - 1) / rows_min;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   int mps = cdiv(p.M, splits);
   mps = ((mps + 63) / 64) * 64;
   splits = cdiv(p.M, mps);
   p.m_per_split = mps;
-  {
-    static int abl = -1;
-    if (abl < 0) {
-      const char* e = getenv("CVHIP_WGRAD_ABLATE");
-      abl = e ? atoi(e) : 0;
-    }
-    p.ablate = abl;
-  }
-  hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK>), dim3(tiles * splits), dim3(256 * kWgGroups), 0, stream, p);
+  if (groups == 2) hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 2>), dim3(tiles * splits), dim3(512), 0, stream, p);
+  else hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 1>), dim3(tiles * splits), dim3(256), 0, stream, p);
   return check_launch("wgrad_kernel");
 }
 
