@@ -294,7 +294,7 @@ __device__ __attribute__((aligned(64))) unsigned int g_zero_page[16];
                                    (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
 // ABL: profiling ablation (CVHIP_IGEMM_ABLATE): 0 = the kernel, 1 = staging only (no LDS reads / MFMA), 2 = compute only
-template <int BM, int BN, int WM, int WN, int ABL = 0>
+template <int BM, int BN, int WM, int WN, int ABL = 0, int NST = 3>
 __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) {
   constexpr int WAVES_N = BN / WN;
   constexpr int WAVES_M = BM / WM;
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) 
   constexpr int B_ROWS = BN < 64 ? 64 : BN;  // B tile padded to >= 64 rows so all 4 waves issue the same DMA count
   constexpr int B_IT = B_ROWS / 64;
   constexpr int A_BYTES = BM * 64, B_BYTES = B_ROWS * 64, ST_BYTES = A_BYTES + B_BYTES;
-  constexpr int NST = 3;
+  static_assert(NST == 2 || NST == 3, "LDS ring depth");
   constexpr int PER = A_IT + B_IT;  // DMA instructions per stage per wave
 
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES];
@@ -408,22 +408,33 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) 
         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[a], xa[b], acc[a][b], 0, 0, 0);
   };
 
-  stage(0, 0);
-  stage(1, 1);
-  int st_cur = 0, st_nxt2 = 2;
-  for (int kt = 0; kt < nk; ++kt) {
-    // this wave's DMAs of tile kt have landed when at most PER (= tile kt+1) remain outstanding ...
-    static_assert(PER >= 3 && PER <= 6, "DMA count per stage");
-    if constexpr (PER == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if constexpr (PER == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (PER == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    // ... and after the barrier everybody's have; it also proves all waves finished reading ring slot (kt+2)%3
-    __builtin_amdgcn_s_barrier();
-    if (ABL != 2) stage(kt + 2, st_nxt2);  // past-the-end tiles decode to all-masked lanes (zero page): DMA counts stay uniform
-    if (ABL != 1) compute(st_cur);
-    st_cur = st_cur == NST - 1 ? 0 : st_cur + 1;
-    st_nxt2 = st_nxt2 == NST - 1 ? 0 : st_nxt2 + 1;
+  if constexpr (NST == 3) {
+    stage(0, 0);
+    stage(1, 1);
+    int st_cur = 0, st_nxt2 = 2;
+    for (int kt = 0; kt < nk; ++kt) {
+      // this wave's DMAs of tile kt have landed when at most PER (= tile kt+1) remain outstanding ...
+      static_assert(PER >= 3 && PER <= 6, "DMA count per stage");
+      if constexpr (PER == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if constexpr (PER == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if constexpr (PER == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      // ... and after the barrier everybody's have; it also proves all waves finished reading ring slot (kt+2)%3
+      __builtin_amdgcn_s_barrier();
+      if (ABL != 2) stage(kt + 2, st_nxt2);  // past-the-end tiles decode to all-masked lanes (zero page): DMA counts stay uniform
+      if (ABL != 1) compute(st_cur);
+      st_cur = st_cur == NST - 1 ? 0 : st_cur + 1;
+      st_nxt2 = st_nxt2 == NST - 1 ? 0 : st_nxt2 + 1;
+    }
+  } else {
+    // 2-deep ring (40 % less LDS => twice the resident blocks for the narrow-output, bandwidth-bound configurations)
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // tile kt landed everywhere; everybody finished reading slot (kt+1)&1 (= tile kt-1)
+      if (ABL != 2) stage(kt + 1, (kt + 1) & 1);
+      if (ABL != 1) compute(kt & 1);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (all-zero) DMAs must land before smem is reused
   __syncthreads();
@@ -518,6 +529,18 @@ static int ablate_mode() {
   return v;
 }
 
+// LDS ring depth policy (CVHIP_IGEMM_NST2): 0 = 3-deep everywhere, 1 = 2-deep for the narrow-output configurations (default:
+// measured -0.6 ms/step on YOLOv5-s, they are bandwidth/latency-bound and gain from twice the resident blocks), 2 = also the
+// 128x128 configuration, 3 = all configurations
+static int nst2_level() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CVHIP_IGEMM_NST2");
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+
 static bool use_v1() {
   static int v = -1;
   if (v < 0) {
@@ -540,7 +563,7 @@ static int launch_cfg(IgemmParams& p, hipStream_t stream) {
   }
   p.total_tiles = total;
   if (total == 0) return CVHIP_OK;
-  if constexpr (WM == 64) {
+  if constexpr (WM == 64 && BM >= 128 && (BM != 128 || BN == 128)) {
     if (use_v1()) {
       hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), dim3(total), dim3(256), 0, stream, p);
       return check_launch("igemm_kernel");
@@ -548,6 +571,7 @@ static int launch_cfg(IgemmParams& p, hipStream_t stream) {
   }
   if (ablate_mode() == 1) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 1>), dim3(total), dim3(256), 0, stream, p);
   else if (ablate_mode() == 2) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 2>), dim3(total), dim3(256), 0, stream, p);
+  else if ((BN <= 64 && nst2_level() >= 1) || (BM == 128 && nst2_level() >= 2) || nst2_level() >= 3) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 2>), dim3(total), dim3(256), 0, stream, p);
   else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN>), dim3(total), dim3(256), 0, stream, p);
   return check_launch("igemm_kernel");
 }
@@ -565,8 +589,17 @@ static bool big_tile_disabled() {
   return v == 1;
 }
 
+static bool narrow128() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CVHIP_IGEMM_NARROW128");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+
 int igemm_block_m(int Nout, int64_t M, int Ktot) {
-  if (Nout <= 64) return 256;
+  if (Nout <= 64) return (narrow128() && !use_v1()) ? 128 : 256;
   if (use_v1() || big_tile_disabled()) return 128;
   // shallow reductions (1x1 convs with < 512 input channels) are memory-bound: more, smaller blocks hide latency better
   // (measured per shape: gpurun conv_table A/B)
@@ -576,6 +609,10 @@ int igemm_block_m(int Nout, int64_t M, int Ktot) {
 }
 
 int launch_igemm(IgemmParams& p, hipStream_t stream) {
+  if (narrow128() && !use_v1()) {
+    if (p.Nout <= 32) return launch_cfg<128, 32, 32, 32>(p, stream);
+    if (p.Nout <= 64) return launch_cfg<128, 64, 32, 64>(p, stream);
+  }
   if (p.Nout <= 32) return launch_cfg<256, 32, 64, 32>(p, stream);
   if (p.Nout <= 64) return launch_cfg<256, 64, 64, 64>(p, stream);
   int64_t M = 0;
