@@ -184,8 +184,18 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restric
 }
 
 // returns the (possibly pre-reduced) partial pointer and updates *rows
+static int direct_rows() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CVHIP_FINALIZE_DIRECT_ROWS");
+    v = e ? atoi(e) : kStage2Rows;
+    if (v < kStage2Rows) v = kStage2Rows;
+  }
+  return v;
+}
+
 static const float* prereduce(const float* partial, int* rows, int Wd, hipStream_t s) {
-  if (*rows <= kStage2Rows) return partial;
+  if (*rows <= direct_rows()) return partial;  // few enough rows for the 16-lane finalize kernels (4 independent chains per lane)
   float* scratch = const_cast<float*>(partial) + (int64_t)(*rows) * Wd;
   hipLaunchKernelGGL(rows_reduce_kernel, dim3(cdiv(Wd, 64), kStage2Rows), dim3(256), 0, s, partial, *rows, Wd, scratch);
   *rows = kStage2Rows;
@@ -198,11 +208,29 @@ static const float* prereduce(const float* partial, int* rows, int Wd, hipStream
 __device__ __forceinline__ void fold16(const float* partial, int rows, int C, int c, int lane, double* s1, double* s2,
                                        bool want2, double (*red)[16][17]) {
   double a = 0.0, b = 0.0;
-  if (c < C)
-    for (int r = lane; r < rows; r += 16) {
+  if (c < C) {
+    // 4 independent accumulation chains: the loads of a lane are independent, only the adds chain
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+    int r = lane;
+    for (; r + 48 < rows; r += 64) {
+      a += (double)partial[((int64_t)r * 2 + 0) * C + c];
+      a1 += (double)partial[((int64_t)(r + 16) * 2 + 0) * C + c];
+      a2 += (double)partial[((int64_t)(r + 32) * 2 + 0) * C + c];
+      a3 += (double)partial[((int64_t)(r + 48) * 2 + 0) * C + c];
+      if (want2) {
+        b += (double)partial[((int64_t)r * 2 + 1) * C + c];
+        b1 += (double)partial[((int64_t)(r + 16) * 2 + 1) * C + c];
+        b2 += (double)partial[((int64_t)(r + 32) * 2 + 1) * C + c];
+        b3 += (double)partial[((int64_t)(r + 48) * 2 + 1) * C + c];
+      }
+    }
+    for (; r < rows; r += 16) {
       a += (double)partial[((int64_t)r * 2 + 0) * C + c];
       if (want2) b += (double)partial[((int64_t)r * 2 + 1) * C + c];
     }
+    a = (a + a1) + (a2 + a3);
+    b = (b + b1) + (b2 + b3);
+  }
   const int cc = threadIdx.x & 15;
   red[0][lane][cc] = a;
   red[1][lane][cc] = b;
