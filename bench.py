@@ -133,10 +133,12 @@ def pmc_traffic(kernel_label):
         return None
     tile = kernel_label[kernel_label.index("<") + 1:kernel_label.index(">")].replace(",", ", ")
     base = "igemm" if kernel_label.startswith("igemm") else "wgrad_kernel"
-    for k, v in raw.items():
+    n = tot = 0.0
+    for k, v in raw.items():  # a tile configuration may exist in several template variants (ring depth, group count): launch-weighted mean
         if base in k and ("<" + tile) in k and v.get("fetch_size_raw_kb_per_launch") is not None and v.get("write_size_raw_kb_per_launch") is not None:
-            return round((2.0 * v["fetch_size_raw_kb_per_launch"] + v["write_size_raw_kb_per_launch"]) * 1024.0)
-    return None
+            n += v["launches"]
+            tot += v["launches"] * (2.0 * v["fetch_size_raw_kb_per_launch"] + v["write_size_raw_kb_per_launch"]) * 1024.0
+    return round(tot / n) if n else None
 
 def main():
     a = parse()
