@@ -13,6 +13,7 @@
 // contraction is disabled for this translation unit.
 #pragma clang fp contract(off)
 #include "common.h"
+#include "dual4.h"
 
 namespace cvhip {
 
@@ -41,64 +42,6 @@ struct YoloLossParams {
   float k_box, k_cls, k_obj;  // hyp_box*bs, hyp_cls*bs/nc, hyp_obj*balance*bs/ncell
 };
 
-// ---- forward-mode duals over the 4 box inputs ---------------------------------------------------
-struct D4 {
-  float v, d[4];
-};
-__device__ __forceinline__ D4 cst(float c) { return D4{c, {0.f, 0.f, 0.f, 0.f}}; }
-__device__ __forceinline__ D4 var(float v, int i) {
-  D4 r = cst(v);
-  r.d[i] = 1.f;
-  return r;
-}
-__device__ __forceinline__ D4 operator+(D4 a, D4 b) {
-  D4 r;
-  r.v = a.v + b.v;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] + b.d[i];
-  return r;
-}
-__device__ __forceinline__ D4 operator-(D4 a, D4 b) {
-  D4 r;
-  r.v = a.v - b.v;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] - b.d[i];
-  return r;
-}
-__device__ __forceinline__ D4 operator*(D4 a, D4 b) {
-  D4 r;
-  r.v = a.v * b.v;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
-  return r;
-}
-__device__ __forceinline__ D4 operator/(D4 a, D4 b) {
-  D4 r;
-  r.v = a.v / b.v;
-  const float inv = 1.f / b.v;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
-  return r;
-}
-__device__ __forceinline__ D4 scale(D4 a, float s) {
-  D4 r;
-  r.v = a.v * s;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] * s;
-  return r;
-}
-__device__ __forceinline__ D4 dmin(D4 a, D4 b) { return a.v <= b.v ? a : b; }
-__device__ __forceinline__ D4 dmax(D4 a, D4 b) { return a.v >= b.v ? a : b; }
-__device__ __forceinline__ D4 clamp0(D4 a) { return a.v >= 0.f ? a : cst(0.f); }
-__device__ __forceinline__ D4 datan(D4 a) {
-  D4 r;
-  r.v = atanf(a.v);
-  const float g = 1.f / (1.f + a.v * a.v);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] * g;
-  return r;
-}
-
 // CIoU of box1 = (x, y, w, h) [differentiated] and box2 = t (xywh); yolov5_loss.py:12-54 (x1y1x2y2=False, CIoU=True)
 __device__ __forceinline__ D4 ciou_xywh(float x, float y, float w, float h, float tx, float ty, float tw, float th) {
   const float eps = 1e-7f;
@@ -123,13 +66,6 @@ __device__ __forceinline__ D4 ciou_xywh(float x, float y, float w, float h, floa
   const D4 v = scale(da * da, 0.40528473456935108578f);  // 4 / pi^2
   const float alpha = v.v / (v.v - iou.v + (1.f + eps));
   return iou - (rho2 / c2 + scale(v, alpha));
-}
-
-__device__ __forceinline__ float sigmoid_ref(float x) { return 1.f / (1.f + expf(-x)); }
-__device__ __forceinline__ float bce_logits(float x, float t) {
-  // aten::binary_cross_entropy_with_logits: (1 - t) * x + max(-x, 0) + log(exp(-max) + exp(-x - max))
-  const float m = fmaxf(-x, 0.f);
-  return (1.f - t) * x + m + logf(expf(-m) + expf(-x - m));
 }
 
 // ---- stage A: one wave per candidate ------------------------------------------------------------------

@@ -41,9 +41,17 @@ class YoloLossDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("N", "A", "NO", "H", "W", "ld", "T")] + [("anchor_t", C.c_float), ("anchors", C.c_float * 16)]
 
 
+class SimotaDesc(C.Structure):
+    """cvhip_simota_desc (include/cvhip.h)."""
+    _fields_ = [(n, C.c_int32) for n in ("L", "B", "A", "G", "nc")] + [("H", C.c_int32 * 4), ("W", C.c_int32 * 4), ("ld", C.c_int32 * 4),
+                                                                       ("stride", C.c_float * 4)]
+
+
 _p, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _dp = C.POINTER(ConvDesc)
 _ylp = C.POINTER(YoloLossDesc)
+_smp = C.POINTER(SimotaDesc)
+_pp = C.POINTER(C.c_void_p)
 
 # name -> (restype, argtypes); mirrors include/cvhip.h one-to-one
 SIGNATURES = {
@@ -104,6 +112,10 @@ SIGNATURES = {
     "cvhip_yolov5_loss_level_fwd": (_i32, [_ylp, _p, _p, _p, _p, _p]),
     "cvhip_yolov5_loss_finalize": (_i32, [_p, _i32, _p, _p, _f32, _f32, _f32, _i32, _f32, _p, _p, _p]),
     "cvhip_yolov5_loss_level_bwd": (_i32, [_ylp, _p, _p, _p, _p, _p, _f32, _f32, _f32, _p, _p]),
+    "cvhip_simota_workspace_bytes": (_i64, [_smp]),
+    "cvhip_simota_loss_fwd": (_i32, [_smp, _pp, _p, _p, _p, _p]),
+    "cvhip_simota_loss_bwd": (_i32, [_smp, _pp, _p, _p, _p, _pp, _p]),
+    "cvhip_simota_read_assignment": (_i32, [_smp, _p, _p, _p, _p]),
     "cvhip_probe_mfma_16x16x32": (_i32, [_p, _p, _p, _p]),
     "cvhip_probe_ds_read_tr16": (_i32, [_p, _p, _p]),
     "cvhip_probe_lds_read_bw": (_i32, [_i32, _i32, _i32, _p, _p]),

@@ -998,6 +998,69 @@ def yolov5_loss_fused(raws, targets, cfg):
     return YoloV5LossFused.apply(targets, cfg, *raws)
 
 
+class SimotaLossFused(torch.autograd.Function):
+    """YOLOX loss (SimOTA assignment + 5*IoU^2 + obj + cls BCE) straight on the bf16 NHWC head maps — libcvhip
+    cvhip_simota_loss_* (src/losses/det/yolox_loss.py:73-435). forward(targets (B,G,5) pixels, cfg, *raw_maps) -> out5 =
+    [loss, conf_loss, cls_loss, 5*iou_loss, num_fg/num_gts]; only out5[0] is differentiable."""
+
+    @staticmethod
+    def forward(ctx, targets, cfg, *raws):
+        dev = raws[0].device
+        st = _stream()
+        tg = targets.detach()
+        if tg.dtype != torch.float32 or not tg.is_contiguous():
+            tg = tg.float().contiguous()
+        B, G = int(tg.shape[0]), int(tg.shape[1])
+        nc = cfg.num_classes
+        maps = []
+        d = L.SimotaDesc()
+        d.L, d.B, d.G, d.nc = len(raws), B, G, nc
+        A = 0
+        for i, r in enumerate(raws):
+            r, ld = as_nhwc(r)
+            N, Cc, H, W = r.shape
+            if Cc != nc + 5 or N != B:
+                raise L.CvhipError("simota loss: head map %d has shape %s, expected (%d, %d, H, W)" % (i, tuple(r.shape), B, nc + 5))
+            d.H[i], d.W[i], d.ld[i], d.stride[i] = H, W, ld, float(cfg.strides[i])
+            A += H * W
+            maps.append(r)
+        d.A = A
+        nbytes = L.load().cvhip_simota_workspace_bytes(C.byref(d))
+        if nbytes < 0:
+            L.check(int(nbytes), "cvhip_simota_workspace_bytes")
+        ws = torch.empty((int(nbytes),), dtype=torch.uint8, device=dev)
+        ptrs = (C.c_void_p * len(maps))(*[m.data_ptr() for m in maps])
+        out5 = torch.empty((5,), dtype=torch.float32, device=dev)
+        L.call("cvhip_simota_loss_fwd", C.byref(d), ptrs, tg.data_ptr(), ws.data_ptr(), out5.data_ptr(), st)
+        ctx.desc, ctx.ws = d, ws
+        ctx.save_for_backward(tg, *maps)
+        return out5
+
+    @staticmethod
+    def backward(ctx, g5):
+        tg, *maps = ctx.saved_tensors
+        d = ctx.desc
+        g = g5.detach().float()[0:1].contiguous()  # d total / d out5[0]; the other entries are reporting-only
+        draws = [torch.empty((d.B, d.H[i], d.W[i], d.ld[i]), dtype=BF16, device=maps[i].device) for i in range(d.L)]
+        ptrs = (C.c_void_p * d.L)(*[m.data_ptr() for m in maps])
+        dptrs = (C.c_void_p * d.L)(*[t.data_ptr() for t in draws])
+        L.call("cvhip_simota_loss_bwd", C.byref(d), ptrs, tg.data_ptr(), ctx.ws.data_ptr(), g.data_ptr(), dptrs, _stream())
+        return (None, None, *[t.permute(0, 3, 1, 2)[:, :d.nc + 5] for t in draws])
+
+
+def simota_loss_fused(raws, targets, cfg):
+    return SimotaLossFused.apply(targets, cfg, *raws)
+
+
+def simota_read_assignment(fn_ctx_desc, ws):
+    """(matched gt (B, A) int32 with -1 = background, matched IoU (B, A)) of a finished cvhip_simota_loss_fwd — tests."""
+    d = fn_ctx_desc
+    m = torch.empty((d.B, d.A), dtype=torch.int32, device=ws.device)
+    u = torch.empty((d.B, d.A), dtype=torch.float32, device=ws.device)
+    L.call("cvhip_simota_read_assignment", C.byref(d), ws.data_ptr(), m.data_ptr(), u.data_ptr(), _stream())
+    return m, u
+
+
 # ---- non-differentiable post-processing ---------------------------------------------------------------
 
 def yolov5_decode(levels, strides, anchors_px, A, NO):

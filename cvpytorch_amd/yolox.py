@@ -266,6 +266,26 @@ class YOLOXLoss(nn.Module):
         return (res, (fg, matched, m_iou)) if return_assign else res
 
 
+class YOLOXLossFused(nn.Module):
+    """Same loss computed by libcvhip's SimOTA kernels (cvhip_simota_loss_*) directly on the raw bf16 head maps
+    [(B, 5+nc, H, W)]: no (B, G, A) tensors, ~9 launches, no torch autograd ops => the whole YOLOX step is ONE hipGraph."""
+
+    def __init__(self, num_classes, strides=(8, 16, 32)):
+        super().__init__()
+        self.num_classes = num_classes
+        self.strides = list(strides)
+
+    def forward(self, raws, targets, hw=None, return_assign=False):
+        out5 = ops.simota_loss_fused(list(raws), targets, self)
+        res = {"loss": out5[0], "conf_loss": out5[1].detach(), "cls_loss": out5[2].detach(), "iou_loss": out5[3].detach(),
+               "num_fg": out5[4].detach()}
+        if return_assign:
+            fn = out5.grad_fn
+            m, u = ops.simota_read_assignment(fn.desc, fn.ws)
+            return res, (m >= 0, m.clamp(min=0).long(), u)
+        return res
+
+
 def targets_to_padded(targets, max_labels=None, device=None):
     """src/models/yolox.py:112-139: list of {'labels','boxes' (pixel cxcywh)} -> (B, max_labels, 5). A fixed `max_labels`
     keeps the shape static (hipGraph replay)."""
@@ -285,14 +305,16 @@ def targets_to_padded(targets, max_labels=None, device=None):
 class YOLOX(nn.Module):
     """src/models/yolox.py:71-188."""
 
-    def __init__(self, num_classes=80, subtype="s", max_labels=None):
+    def __init__(self, num_classes=80, subtype="s", max_labels=None, fused_loss=False):
         super().__init__()
         self.num_classes = num_classes
+        self.fused_loss = fused_loss
+        self.loss_capturable = fused_loss
         self.depth_mul, self.width_mul = SCALES[subtype]
         self.backbone = YOLOXCSPDarknet("cspdark_" + subtype)
         self.neck = YOLOXNeck("yolox_" + subtype)
         self.head = YOLOXHead("yolox_" + subtype, num_classes=num_classes, norm_cfg=BN)
-        self.loss = YOLOXLoss(num_classes)
+        self.loss = (YOLOXLossFused if fused_loss else YOLOXLoss)(num_classes)
         self.stride = [8, 16, 32]
         self.conf_thr, self.nms_thr = 0.01, 0.65
         self.max_labels = max_labels
@@ -302,6 +324,8 @@ class YOLOX(nn.Module):
         """-> (None, [(B, HW_l, 5+nc) fp32 per level]); the NHWC head maps already are the (B, HW, C) layout the loss reads."""
         raw = self.head(self.neck(self.backbone(imgs)))
         self._hw = [(int(r.shape[2]), int(r.shape[3])) for r in raw]
+        if self.fused_loss:
+            return None, list(raw)  # the fused loss reads the bf16 NHWC maps as they are
         c = self.num_classes + 5
         return None, [ops.head_permute(r, 1, c).view(r.shape[0], -1, c) for r in raw]
 
@@ -315,6 +339,9 @@ class YOLOX(nn.Module):
         _, feats = self.forward_features(imgs)
         losses = self.loss_from_features(feats, gts)
         if mode == "val":
+            if self.fused_loss:
+                c = self.num_classes + 5
+                feats = [ops.head_permute(r.detach(), 1, c).view(r.shape[0], -1, c) for r in feats]
             return losses, decode_and_nms([f.detach() for f in feats], self._hw, self.stride, self.num_classes, self.conf_thr, self.nms_thr)
         return losses
 

@@ -360,6 +360,26 @@ int cvhip_yolov5_loss_level_bwd(const cvhip_yolo_loss_desc* d, const void* raw_b
                                 void* draw_bf16, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * YOLOX loss on device: SimOTA assignment + 5*IoU^2 + objectness + class BCE, all levels at once.
+ * Replaces src/losses/det/yolox_loss.py:73-435 (per-image python loop, per-gt `.item()` top-k loop). raws[l]: bf16 NHWC head
+ * map of level l, (B, H_l, W_l, ld_l) with channels [reg 4, obj 1, cls nc] (heads/det/yolox_head.py:94); targets: (B, G, 5) fp32
+ * [cls, cx, cy, w, h] in pixels, all-zero rows = padding (models/yolox.py:112-139). A = sum_l H_l*W_l anchors.
+ *   loss_fwd : out5 = {loss, conf_loss, cls_loss, 5*iou_loss, num_fg/num_gts}; assignment + intermediates stay in `ws`
+ *   loss_bwd : draws[l] (same shape/pitch as raws[l]) = d loss / d raws[l], scaled by the DEVICE scalar gout (NULL = 1)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cvhip_simota_desc {
+  int32_t L, B, A, G, nc;
+  int32_t H[4], W[4], ld[4];
+  float stride[4];
+} cvhip_simota_desc;
+int64_t cvhip_simota_workspace_bytes(const cvhip_simota_desc* d);
+int cvhip_simota_loss_fwd(const cvhip_simota_desc* d, const void* const* raws, const float* targets, void* ws, float* out5,
+                          void* stream);
+int cvhip_simota_loss_bwd(const cvhip_simota_desc* d, const void* const* raws, const float* targets, void* ws,
+                          const float* gout, void* const* draws, void* stream);
+int cvhip_simota_read_assignment(const cvhip_simota_desc* d, void* ws, int32_t* matched_out, float* miou_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Hardware probes used by the GPU test-suite to pin the MFMA / LDS-transpose lane layouts the
  * kernels rely on (cdna_hip_programming.md §3, T10). out buffers are small fp32 arrays.
  * ------------------------------------------------------------------------------------------ */

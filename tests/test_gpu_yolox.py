@@ -164,3 +164,86 @@ def test_yolox_val_mode_post_process():
         assert u.shape == v.shape
         assert torch.equal(u[:, 6].cpu(), v[:, 6])
         assert torch.allclose(u.cpu(), v, rtol=1e-5, atol=1e-5)
+
+
+# ---- fused SimOTA loss kernels (cvhip_simota_loss_*) -----------------------------------------------------------------------
+def _raws_from(p_nchw):
+    return [q.to(torch.bfloat16).to(dev()).contiguous(memory_format=torch.channels_last) for q in p_nchw]
+
+
+def _dense_on(raws, targets):
+    """the dense torch formulation (equal to the reference on its vectors) evaluated on the SAME bf16-rounded maps"""
+    hw = [(int(r.shape[2]), int(r.shape[3])) for r in raws]
+    leaves = [r.float().detach().requires_grad_(True) for r in raws]
+    feats = [l.permute(0, 2, 3, 1).reshape(l.shape[0], -1, l.shape[1]) for l in leaves]
+    out, (fg, matched, miou) = yolox.YOLOXLoss(80).to(dev())(feats, targets, hw=hw, return_assign=True)
+    grads = torch.autograd.grad(out["loss"], leaves)
+    return out, fg, matched, miou, grads
+
+
+def _check_fused_simota(p_nchw, targets):
+    raws = _raws_from(p_nchw)
+    targets = targets.to(dev())
+    out_d, fg_d, m_d, u_d, g_d = _dense_on(raws, targets)
+    rr = [r.clone().requires_grad_(True) for r in raws]
+    out_f, (fg_f, m_f, u_f) = yolox.YOLOXLossFused(80)(rr, targets, return_assign=True)
+    g_f = torch.autograd.grad(out_f["loss"], rr)
+    # assignment: identical foreground set and matched gts (costs are fp32 on both sides; summation order of the class cost differs,
+    # so an exact tie could flip — none does on these inputs)
+    assert torch.equal(fg_f, fg_d), (int(fg_f.sum()), int(fg_d.sum()), int((fg_f != fg_d).sum()))
+    assert torch.equal(m_f[fg_d], m_d[fg_d])
+    assert torch.allclose(u_f[fg_d], u_d[fg_d], rtol=1e-5, atol=1e-6)
+    for k in ("loss", "conf_loss", "cls_loss", "iou_loss", "num_fg"):
+        assert torch.allclose(out_f[k].float(), out_d[k].float(), rtol=2e-5, atol=1e-6), (k, float(out_f[k]), float(out_d[k]))
+    for a, b in zip(g_f, g_d):
+        a = a.float()
+        tol = b.abs() * 2.0 ** -8 + 1e-6 * float(b.abs().max()) + 1e-12
+        bad = (a - b).abs() > tol
+        assert not bool(bad.any()), (int(bad.sum()), float((a - b).abs().max()), float(b.abs().max()))
+
+
+@pytest.mark.parametrize("trial", [0, 1, 2])
+def test_fused_simota_equals_dense_on_reference_vectors(trial):
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "yolox_loss_%d.npz" % trial))
+    p = [torch.from_numpy(z["p/%d" % i]) for i in range(3)]
+    _check_fused_simota(p, torch.from_numpy(z["targets"]))
+
+
+@pytest.mark.parametrize("seed,bs,size,nmax", [(0, 2, 64, 6), (1, 4, 96, 20), (2, 8, 160, 20)])
+def test_fused_simota_equals_dense_seeded(seed, bs, size, nmax):
+    from oracle import yolox_ref as RX
+    g = torch.Generator().manual_seed(seed)
+    p = [torch.randn(bs, 85, size // s, size // s, generator=g) * 0.6 for s in (8, 16, 32)]
+    for q in p:
+        q[:, 4:] -= 1.5
+    _, tg = RX.synthetic_batch(bs, size, seed=seed, max_boxes=nmax)
+    targets = RX.targets_to_padded(tg)
+    targets = torch.cat([targets, torch.zeros(bs, 3, 5)], 1)
+    _check_fused_simota(p, targets)
+
+
+def test_yolox_fused_model_one_graph():
+    from cvpytorch_amd.arena import FlatTrainState, FlatTrainStep
+    from oracle import yolox_ref as RX
+    torch.manual_seed(0)
+    a = yolox.YOLOX(80, "s", max_labels=12).to(dev()).train()
+    b = yolox.YOLOX(80, "s", max_labels=12, fused_loss=True).to(dev()).train()
+    b.load_state_dict(a.state_dict())
+    imgs, targets = RX.synthetic_batch(4, 128, seed=1029, max_boxes=10)
+    gts = yolox.targets_to_padded(targets, 12, dev())
+    la = a(imgs.to(dev()), gts, "train")
+    lb = b(imgs.to(dev()), gts, "train")
+    for k in ("loss", "conf_loss", "cls_loss", "iou_loss"):
+        assert abs(float(la[k]) - float(lb[k])) <= 2e-3 * abs(float(la[k])) + 1e-5, (k, float(la[k]), float(lb[k]))
+    b.eval()
+    with torch.no_grad():
+        losses, dets = b(imgs.to(dev()), gts, "val")
+    assert len(dets) == 4
+    b.train()
+    st = FlatTrainState(b)
+    step = FlatTrainStep(b, st)
+    step.capture(imgs.to(dev()), gts, warmup=1)
+    assert step.g1 is not None and step.g2 is None
+    l0 = float(step(imgs.to(dev()), gts)["loss"])
+    l1 = float(step(imgs.to(dev()), gts)["loss"])
+    assert np.isfinite(l0) and np.isfinite(l1)
