@@ -37,7 +37,7 @@ def run(name, model, imgs, gts, flops_per_img, bytes_per_img):
 if "yolox" in which:
     torch.manual_seed(1029)
     B = 64
-    m = yolox.YOLOX(80, "s", max_labels=20).to(dev).train()
+    m = yolox.YOLOX(80, "s", max_labels=20, fused_loss="--torch-loss" not in sys.argv).to(dev).train()
     imgs, targets = synthetic_detection_batch(B, 640, device=dev)
     for t in targets:  # YOLOX targets are pixel-unit cxcywh (models/yolox.py:112-139)
         t["boxes"] = t["boxes"] * 640.0
