@@ -193,8 +193,21 @@ def main():
     for _ in range(a.warmup):
         step(imgs, gts)
     if use_graph:  # the W warm-up steps above ran eagerly; the K timed steps replay ONE hipGraph of the whole step
-        step.capture(imgs, gts)
-        imgs, gts = step.static_imgs, step.static_targets
+        ok = 1
+        try:
+            step.capture(imgs, gts)
+        except Exception as e:  # never lose the bench line to a capture problem: fall back to eager steps
+            ok = 0
+            sys.stderr.write("[bench] hipGraph capture failed on rank %d (%r): running eagerly\n" % (rank, e))
+        if world > 1:  # every rank must run the same mode (the modes issue different collectives)
+            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if ok:
+            imgs, gts = step.static_imgs, step.static_targets
+        else:
+            step.graph = None
+            use_graph = False
     ops.TIMER.enabled = (not a.no_kernel_timing) and rank == 0 and not use_graph
     ops.TIMER.reset()
     barrier()

@@ -302,7 +302,7 @@ class FlatTrainStep:
         if getattr(m, "loss_capturable", False):
             # the loss is libcvhip kernels too (no torch autograd ops): the whole step is ONE graph
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                 _, feats = m.forward_features(self.static_imgs)
                 losses = m.loss_from_features(feats, self.static_targets)
                 losses["loss"].backward()
@@ -312,12 +312,12 @@ class FlatTrainStep:
             self.g1, self.g2 = g, None
             return
         g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1, pool=pool):
+        with torch.cuda.graph(g1, pool=pool, capture_error_mode="thread_local"):
             _, feats = m.forward_features(self.static_imgs)
         self.feats = list(feats)
         self.g_feats = [torch.zeros_like(f) for f in self.feats]
         g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g2, pool=pool):
+        with torch.cuda.graph(g2, pool=pool, capture_error_mode="thread_local"):
             torch.autograd.backward(self.feats, grad_tensors=self.g_feats)
             if not multi:
                 st.step_kernels()
