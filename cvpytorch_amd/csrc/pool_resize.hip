@@ -131,9 +131,18 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolParams p) {
         const int64_t opix = ((int64_t)(n * p.OH + oh) * p.OW + ow);
         const f32x8 g = load8(p.dy + opix * p.ld_dy, c, p.C, vec);
         const uint8_t* ip = p.cidx + opix * p.C + c;
+        if (vec) {  // the 8 arg-max bytes of this channel vector in ONE 8-byte load (they were 8 byte loads per window)
+          const uint2 iv = *reinterpret_cast<const uint2*>(ip);
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (c + j < p.C && ip[j] == off) acc[j] += g.v[j];
+          for (int j = 0; j < 8; ++j) {
+            const unsigned b = ((j < 4 ? iv.x : iv.y) >> (8 * (j & 3))) & 0xffu;
+            if ((int)b == off) acc[j] += g.v[j];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (c + j < p.C && ip[j] == off) acc[j] += g.v[j];
+        }
       }
     }
     bf16_t* dst = p.dx + ((int64_t)(n * p.H + ih) * p.W + iw) * p.ld_dx;
