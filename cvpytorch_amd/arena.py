@@ -71,6 +71,9 @@ class FlatTrainState:
         self.seg_lr = torch.tensor(self.base_lr, dtype=torch.float32, device=dev)
         self.seg_wd = torch.tensor([hyper[id(p)][1] for p in self.params], dtype=torch.float32, device=dev)
         self.steps = 0
+        # wgrad kernels on a side stream (ops._Side); CVHIP_ASYNC_WGRAD=0 keeps everything on one stream
+        import os
+        ops.enable_async_wgrad(os.environ.get("CVHIP_ASYNC_WGRAD", "1") != "0")
         # BatchNorm step counters: one multi-tensor add per step (bricks.bn_tick) instead of one tiny kernel per layer
         self._nbt = []
         for m in model.modules():
@@ -215,6 +218,7 @@ class FlatTrainState:
     def step_kernels(self):
         """The device work of one step (capturable): wait for the bucketed all-reduce, fused SGD+EMA, EMA of the
         BN statistics, zero the gradient arena."""
+        ops.join_side()  # side-stream wgrad kernels (ops._Side) must have landed in the gradient arena
         self.finish_allreduce()
         ema_ptr = self.ema_param.data_ptr() if self.ema_param is not None else None
         st = ops._stream()
@@ -306,6 +310,7 @@ class FlatTrainStep:
                 _, feats = m.forward_features(self.static_imgs)
                 losses = m.loss_from_features(feats, self.static_targets)
                 losses["loss"].backward()
+                ops.join_side()
                 if not multi:
                     st.step_kernels()
             self.static_losses = losses
@@ -319,6 +324,7 @@ class FlatTrainStep:
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2, pool=pool, capture_error_mode="thread_local"):
             torch.autograd.backward(self.feats, grad_tensors=self.g_feats)
+            ops.join_side()
             if not multi:
                 st.step_kernels()
         self.g1, self.g2 = g1, g2

@@ -176,6 +176,41 @@ def _krsc_master(weight):
     return wk if wk.is_contiguous() else wk.contiguous()
 
 
+# ---- weight-gradient kernels on a side stream -------------------------------------------------------------------------------
+# wgrad of a layer depends only on (x, dy) of that layer and nothing downstream depends on it until the optimizer, while the
+# dgrad -> BN-backward chain is the critical path of backward. Issuing wgrad on a second stream lets it fill the CUs the
+# critical path leaves idle (tile-quantisation tails, low-occupancy small layers). Enabled by arena.FlatTrainState (the
+# gradients land in the arena, nothing on the main stream consumes them before `join_side()`); operands are kept alive until
+# the join so the caching allocator cannot hand their memory to a later main-stream kernel. Under hipGraph capture the
+# fork/join become parallel branches of the graph.
+class _Side:
+    enabled = False
+    stream = None
+    keep = []
+    dirty = False
+
+
+def enable_async_wgrad(flag=True):
+    _Side.enabled = bool(flag)
+
+
+def _side_begin():
+    if _Side.stream is None:
+        _Side.stream = torch.cuda.Stream()
+    _Side.stream.wait_stream(torch.cuda.current_stream())
+    _Side.dirty = True
+    return _Side.stream
+
+
+def join_side():
+    """Make the current stream wait for every side-stream wgrad issued so far and release their operands."""
+    if _Side.dirty:
+        torch.cuda.current_stream().wait_stream(_Side.stream)
+        _Side.dirty = False
+    _Side.keep = []
+
+
+
 class ConvState:
     """Per-layer cache of the bf16 operand images derived from the fp32 master weight."""
 
@@ -448,7 +483,13 @@ class ConvBnAct(torch.autograd.Function):
                 desc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, x_ld, dy_ld, kv, cv)
                 padded = (Kp != K) or (Cg != Cc)
                 geom = (N, Cc, H, W, K, R, S, P, Q)
-                if not padded and direct_w:
+                if not padded and direct_w and _Side.enabled and not TIMER.enabled and (arena.world == 1 or arena.defer_allreduce):
+                    # same, on the side stream (see _Side): runs concurrently with the dgrad / BN-backward chain
+                    side = _side_begin()
+                    with torch.cuda.stream(side):
+                        L.call("cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(), cfg.gw.data_ptr(), 1, side.cuda_stream)
+                    _Side.keep.append((x, dy))
+                elif not padded and direct_w:
                     # accumulate straight into the parameter's KRSC slot of the flat gradient arena
                     _timed_call(_wgrad_name(Kp), geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(),
                                 cfg.gw.data_ptr(), 1, st)
