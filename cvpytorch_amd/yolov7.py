@@ -256,21 +256,29 @@ class YOLOv7(nn.Module):
     """src/models/yolov7.py:150-256. forward(imgs, targets, mode): 'train' -> losses dict; 'val' -> (losses, outputs)."""
     anchors = ANCHORS
 
-    def __init__(self, num_classes=80, width_mul=1.0, max_targets=None, fused_loss=False):
+    def __init__(self, num_classes=80, width_mul=1.0, max_targets=None, fused_loss=False, loss="v5", max_per_image=32):
+        """loss="v5": the YOLOv5-style assignment (fused_loss=True -> libcvhip kernels, graph-capturable);
+        loss="ota": the reference's YOLOv7Loss (find_3_positive + OTA matching) in fixed-shape torch ops (YOLOv7OTALoss)."""
         super().__init__()
+        assert loss in ("v5", "ota") and not (loss == "ota" and fused_loss)
         self.num_classes = num_classes
         self.fused_loss = fused_loss
+        self.loss_kind = loss
         self.loss_capturable = fused_loss
         self.backbone = YOLOv7Backbone(width_mul)
         self.neck = YOLOv7Neck(width_mul=width_mul)
         self.head = YOLOv7Head(width_mul=width_mul)
         self.detect = YOLOv7Detect(num_classes, width_mul=width_mul)
-        self.loss = (YOLOv5LossFused if fused_loss else YOLOv5Loss)(num_classes, anchors=ANCHORS, hyp_box=0.05, hyp_obj=0.7, hyp_cls=0.3)
+        if loss == "ota":
+            self.loss = YOLOv7OTALoss(num_classes, anchors=ANCHORS, max_per_image=max_per_image)
+        else:
+            self.loss = (YOLOv5LossFused if fused_loss else YOLOv5Loss)(num_classes, anchors=ANCHORS, hyp_box=0.05, hyp_obj=0.7, hyp_cls=0.3)
         self.conf_thres, self.iou_thres = 0.001, 0.65
         self.max_targets = max_targets
         _bn_fix(self)
 
     def forward_features(self, imgs):
+        self._img_h = int(imgs.shape[2])                      # the reference's OTA matching scales boxes by imgs[b].shape[1]
         x = self.head(self.neck(self.backbone(imgs)))
         if self.fused_loss:
             raw = self.detect.forward_raw(x)
@@ -279,7 +287,10 @@ class YOLOv7(nn.Module):
 
     def loss_from_features(self, train_out, gts):
         losses = {}
-        losses["loss"], st = self.loss(train_out, gts)
+        if self.loss_kind == "ota":
+            losses["loss"], st = self.loss([t.float() for t in train_out], gts, self._img_h)
+        else:
+            losses["loss"], st = self.loss(train_out, gts)
         losses["box_loss"], losses["obj_loss"], losses["cls_loss"] = st[0], st[1], st[2]
         return losses
 
@@ -296,3 +307,163 @@ class YOLOv7(nn.Module):
                     outputs.append({"boxes": pred[:, :4], "labels": pred[:, 5], "scores": pred[:, 4]})
             return losses, outputs
         return losses
+
+
+# ------------------------------------------------------------------------------------------------------
+# OTA loss (the reference's YOLOv7Loss) in fixed-shape form
+# ------------------------------------------------------------------------------------------------------
+import torch.nn.functional as F  # noqa: E402
+
+from .yolov5 import bbox_ciou_xywh  # noqa: E402
+
+
+def flat_to_padded(targets, batch, max_per_image):
+    """(T, 6) [img, cls, cx, cy, w, h] in image order, img < 0 = padding  ->  (B, G, 6) per-image padded + valid mask (B, G).
+    No host sync: the rank of a target inside its image comes from a bincount / cumsum."""
+    T = targets.shape[0]
+    dev = targets.device
+    img = targets[:, 0].long()
+    valid = img >= 0
+    imc = img.clamp(0, batch - 1)
+    counts = torch.zeros(batch + 1, dtype=torch.long, device=dev).index_add_(
+        0, torch.where(valid, imc, torch.full_like(imc, batch)), torch.ones_like(imc))[:batch]       # bincount() would sync
+    first = torch.cumsum(counts, 0) - counts
+    rank = torch.arange(T, device=dev) - first[imc]
+    ok = valid & (rank < max_per_image) & (rank >= 0)
+    slot = torch.where(ok, imc * max_per_image + rank, torch.full_like(imc, batch * max_per_image))
+    out = torch.zeros((batch * max_per_image + 1, 6), device=dev, dtype=targets.dtype)
+    out[:, 0] = -1
+    out = out.index_copy(0, slot, torch.where(ok[:, None], targets, out[-1:].expand(T, 6)))
+    out = out[:-1].view(batch, max_per_image, 6)
+    return out, out[..., 0] >= 0
+
+
+class YOLOv7OTALoss(nn.Module):
+    """src/losses/yolov7_loss.py:129-420 (find_3_positive + per-image OTA matching + CIoU/obj/cls) with FIXED shapes: the
+    per-image python loop, boolean-mask compaction and per-gt `.item()` top-k become dense (B, G, Nc = L*5*na*G) tensors with
+    masks — no host sync. p: list of (B, na, H, W, 5+nc) fp32; targets (T, 6) flat (image order, img < 0 padding);
+    img_size = the reference's `imgs[b].shape[1]`. Equal to the reference on its golden vectors (tests/test_yolov7_ota.py)."""
+
+    def __init__(self, num_classes, stride=(8., 16., 32.), anchors=ANCHORS, max_per_image=32):
+        super().__init__()
+        self.num_classes = num_classes
+        self.num_layers, self.num_anchors = len(anchors), len(anchors[0])
+        self.stride = [float(s) for s in stride]
+        self.register_buffer("anchors", torch.tensor(anchors).float())
+        self.register_buffer("off", torch.tensor([[0, 0], [1, 0], [0, 1], [-1, 0], [0, -1]]).float() * 0.5)
+        self.hyp_anchor_t, self.hyp_box, self.hyp_obj, self.hyp_cls = 4.0, 0.05, 0.7, 0.3
+        self.balance = [4.0, 1.0, 0.4]
+        self.max_per_image = max_per_image
+
+    def _candidates(self, tg, valid, i, ny, nx):
+        """level i: (B, Ncl = 5*na*G) candidate attributes in the reference's (offset, anchor, target) order."""
+        B, G, _ = tg.shape
+        na = self.num_anchors
+        anchors = self.anchors[i]
+        gx, gy, gw, gh = tg[..., 2] * nx, tg[..., 3] * ny, tg[..., 4] * nx, tg[..., 5] * ny          # (B,G)
+        r = torch.stack((gw, gh), -1)[:, None] / anchors[None, :, None, :]                              # (B,na,G,2)
+        jm = (torch.max(r, 1. / r).max(-1)[0] < self.hyp_anchor_t) & valid[:, None, :]                   # (B,na,G)
+        gxy = torch.stack((gx, gy), -1)                                                                  # (B,G,2)
+        gxi = torch.stack((nx - gx, ny - gy), -1)
+        jk = (gxy % 1. < 0.5) & (gxy > 1.)
+        lm = (gxi % 1. < 0.5) & (gxi > 1.)
+        rule = torch.stack((torch.ones_like(jk[..., 0]), jk[..., 0], jk[..., 1], lm[..., 0], lm[..., 1]), 1)  # (B,5,G)
+        sel = rule[:, :, None, :] & jm[:, None]                                                          # (B,5,na,G)
+        gij = (gxy[:, None] - self.off[None, :, None, :]).long()                                         # (B,5,G,2)
+        gi = gij[..., 0].clamp(0, nx - 1)[:, :, None, :].expand(B, 5, na, G)
+        gj = gij[..., 1].clamp(0, ny - 1)[:, :, None, :].expand(B, 5, na, G)
+        a = torch.arange(na, device=tg.device)[None, None, :, None].expand(B, 5, na, G)
+        g = torch.arange(G, device=tg.device)[None, None, None, :].expand(B, 5, na, G)
+        flat = lambda t: t.reshape(B, -1)  # noqa: E731
+        return flat(sel), flat(a), flat(gj), flat(gi), flat(g)
+
+    def forward(self, p, targets, img_size):
+        dev = targets.device
+        B = p[0].shape[0]
+        nc, na = self.num_classes, self.num_anchors
+        tg, valid = flat_to_padded(targets, B, self.max_per_image)
+        G = tg.shape[1]
+        tcls = tg[..., 1].long().clamp(0, nc - 1)
+        txy = tg[..., 2:6] * float(img_size)
+        txyxy = torch.cat((txy[..., :2] - txy[..., 2:] / 2, txy[..., :2] + txy[..., 2:] / 2), -1)       # (B,G,4)
+        lv = []
+        with torch.no_grad():
+            boxes, objs, clss, sels = [], [], [], []
+            for i, pi in enumerate(p):
+                _, _, ny, nx, no = pi.shape
+                sel, a, gj, gi, g = self._candidates(tg, valid, i, ny, nx)
+                cell = (a * ny + gj) * nx + gi
+                ps = torch.gather(pi.detach().reshape(B, na * ny * nx, no), 1, cell[..., None].expand(-1, -1, no))
+                anch = self.anchors[i][a]
+                grid = torch.stack((gi, gj), -1).float()
+                pxy = (ps[..., :2].sigmoid() * 2. - 0.5 + grid) * self.stride[i]
+                pwh = (ps[..., 2:4].sigmoid() * 2) ** 2 * anch * self.stride[i]
+                boxes.append(torch.cat((pxy - pwh / 2, pxy + pwh / 2), -1))
+                objs.append(ps[..., 4])
+                clss.append(ps[..., 5:])
+                sels.append(sel)
+                lv.append((sel, a, gj, gi, g, cell))
+            box = torch.cat(boxes, 1)                                                                    # (B,Nc,4)
+            obj, cls, csel = torch.cat(objs, 1), torch.cat(clss, 1), torch.cat(sels, 1)
+            Nc = box.shape[1]
+            usable = csel[:, None, :] & valid[..., None]                                                 # (B,G,Nc)
+            a1 = ((txyxy[..., 2] - txyxy[..., 0]) * (txyxy[..., 3] - txyxy[..., 1]))[..., None]
+            a2 = ((box[..., 2] - box[..., 0]) * (box[..., 3] - box[..., 1]))[:, None, :]
+            inter = (torch.min(txyxy[:, :, None, 2:], box[:, None, :, 2:]) - torch.max(txyxy[:, :, None, :2], box[:, None, :, :2])).clamp(0).prod(-1)
+            iou = inter / (a1 + a2 - inter)
+            iou = torch.where(usable, iou, torch.zeros((), device=dev))
+            kk = min(20, Nc)
+            dyn_k = torch.clamp(torch.topk(iou, kk, dim=2)[0].sum(2).int(), min=1)
+            y = (cls.float().sigmoid() * obj.float().sigmoid()[..., None]).sqrt()
+            z = torch.log(y / (1 - y))
+            base = F.binary_cross_entropy_with_logits(z, torch.zeros_like(z), reduction="none").sum(-1)  # (B,Nc)
+            corr = -z.transpose(1, 2)                                                                    # bce(z,1) - bce(z,0) = -z
+            cls_cost = base[:, None, :] + torch.gather(corr, 1, tcls[..., None].expand(B, G, Nc))
+            cost = cls_cost + 3.0 * (-torch.log(iou + 1e-8))
+            cost = torch.where(usable, cost, torch.full((), float("inf"), device=dev))
+            cvals, cidx = torch.topk(cost, kk, dim=2, largest=False)
+            pick = (torch.arange(kk, device=dev)[None, None, :] < dyn_k[..., None]) & torch.isfinite(cvals)
+            matching = torch.zeros(B, G, Nc, device=dev).scatter_(2, cidx, pick.float())
+            multi = matching.sum(1) > 1
+            onehot = F.one_hot(torch.argmin(cost, dim=1), G).permute(0, 2, 1).to(matching.dtype)
+            matching = torch.where(multi[:, None, :], onehot, matching)
+            fg = matching.sum(1) > 0                                                                     # (B,Nc)
+            mgt = matching.argmax(1)
+        lcls = torch.zeros(1, device=dev)
+        lbox = torch.zeros(1, device=dev)
+        lobj = torch.zeros(1, device=dev)
+        o = 0
+        for i, pi in enumerate(p):
+            _, _, ny, nx, no = pi.shape
+            sel, a, gj, gi, g, cell = lv[i]
+            Ncl = sel.shape[1]
+            f = fg[:, o:o + Ncl]
+            m = mgt[:, o:o + Ncl]
+            o += Ncl
+            ff = f.float()
+            n = ff.sum()
+            denom = n.clamp(min=1.0)
+            ps = torch.gather(pi.reshape(B, na * ny * nx, no), 1, cell[..., None].expand(-1, -1, no))
+            pxy = ps[..., :2].sigmoid() * 2. - 0.5
+            pwh = (ps[..., 2:4].sigmoid() * 2) ** 2 * self.anchors[i][a]
+            t = torch.gather(tg, 1, m[..., None].expand(-1, -1, 6))
+            tbox = torch.stack((t[..., 2] * nx - gi, t[..., 3] * ny - gj, t[..., 4] * nx, t[..., 5] * ny), -1)
+            iou = bbox_ciou_xywh(torch.cat((pxy, pwh), -1), tbox)
+            lbox = lbox + (torch.where(f, 1.0 - iou, torch.zeros((), device=dev)).sum() / denom) * (n > 0)
+            # objectness target: last fg candidate of a cell wins (image-major, candidate order) -> largest candidate index
+            score = iou.detach().clamp(0).to(pi.dtype)
+            ncell = B * na * ny * nx
+            flatcell = torch.arange(B, device=dev)[:, None] * (na * ny * nx) + cell
+            ordinal = torch.arange(B * Ncl, device=dev).view(B, Ncl)
+            flatcell = torch.where(f, flatcell, ncell + ordinal)
+            winner = torch.full((ncell + B * Ncl,), -1, dtype=torch.long, device=dev)
+            winner = winner.scatter_reduce(0, flatcell.reshape(-1), ordinal.reshape(-1), reduce="amax", include_self=True)[:ncell]
+            tobj = torch.where(winner >= 0, score.reshape(-1)[winner.clamp(min=0)], torch.zeros((), device=dev, dtype=pi.dtype))
+            if nc > 1:
+                tc = F.one_hot(t[..., 1].long().clamp(0, nc - 1), nc).to(ps.dtype)
+                bce = F.binary_cross_entropy_with_logits(ps[..., 5:], tc, reduction="none")
+                lcls = lcls + (torch.where(f[..., None], bce, torch.zeros((), device=dev)).sum() / (denom * nc)) * (n > 0)
+            lobj = lobj + F.binary_cross_entropy_with_logits(pi[..., 4].reshape(-1), tobj) * self.balance[i]
+        lbox, lobj, lcls = lbox * self.hyp_box, lobj * self.hyp_obj, lcls * self.hyp_cls
+        loss = lbox + lobj + lcls
+        return loss * B, torch.cat((lbox, lobj, lcls, loss)).detach()

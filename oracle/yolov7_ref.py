@@ -258,3 +258,165 @@ class YOLOv7(nn.Module):
         losses["loss"], st = self.loss(train_out, gts)
         losses["box_loss"], losses["obj_loss"], losses["cls_loss"] = st[0], st[1], st[2]
         return losses
+
+
+# ------------------------------------------------------------------------------------------------------
+# OTA loss (src/losses/yolov7_loss.py:129-420) — pinned by tests/golden/v7_ota_loss_*.npz (tools/gen_golden_more.py)
+# ------------------------------------------------------------------------------------------------------
+import torch.nn.functional as F  # noqa: E402
+
+from .torch_ref import bbox_iou  # noqa: E402
+
+
+def _xywh2xyxy(x):
+    y = x.clone()
+    y[:, 0] = x[:, 0] - x[:, 2] / 2
+    y[:, 1] = x[:, 1] - x[:, 3] / 2
+    y[:, 2] = x[:, 0] + x[:, 2] / 2
+    y[:, 3] = x[:, 1] + x[:, 3] / 2
+    return y
+
+
+def _box_iou_xyxy(b1, b2):
+    a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+    a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+    inter = (torch.min(b1[:, None, 2:], b2[:, 2:]) - torch.max(b1[:, None, :2], b2[:, :2])).clamp(0).prod(2)
+    return inter / (a1[:, None] + a2 - inter)
+
+
+class YOLOv7OTALoss:
+    """YOLOv7Loss (:129-215) with build_targets = find_3_positive (:365-420) + per-image SimOTA-style matching (:217-363)."""
+
+    def __init__(self, num_classes, stride=(8., 16., 32.), anchors=ANCHORS):
+        self.num_classes = num_classes
+        self.num_layers, self.num_anchors = len(anchors), len(anchors[0])
+        self.stride = [float(s) for s in stride]
+        self.anchors = torch.tensor(anchors).float()
+        self.hyp_anchor_t, self.hyp_box, self.hyp_obj, self.hyp_cls = 4.0, 0.05, 0.7, 0.3
+        self.balance = [4.0, 1.0, 0.4]
+        self.gr = 1.0
+
+    def find_3_positive(self, p, targets):
+        na, nt = self.num_anchors, targets.shape[0]
+        indices, anch = [], []
+        gain = torch.ones(7)
+        ai = torch.arange(na).float().view(na, 1).repeat(1, nt)
+        targets = torch.cat((targets.repeat(na, 1, 1), ai[:, :, None]), 2)
+        g = 0.5
+        off = torch.tensor([[0, 0], [1, 0], [0, 1], [-1, 0], [0, -1]]).float() * g
+        for i in range(self.num_layers):
+            anchors = self.anchors[i]
+            gain[2:6] = torch.tensor(p[i].shape)[[3, 2, 3, 2]]
+            t = targets * gain
+            if nt:
+                r = t[:, :, 4:6] / anchors[:, None]
+                j = torch.max(r, 1. / r).max(2)[0] < self.hyp_anchor_t
+                t = t[j]
+                gxy = t[:, 2:4]
+                gxi = gain[[2, 3]] - gxy
+                j, k = ((gxy % 1. < g) & (gxy > 1.)).T
+                l, m = ((gxi % 1. < g) & (gxi > 1.)).T
+                j = torch.stack((torch.ones_like(j), j, k, l, m))
+                t = t.repeat((5, 1, 1))[j]
+                offsets = (torch.zeros_like(gxy)[None] + off[:, None])[j]
+            else:
+                t = targets[0]
+                offsets = 0
+            b, c = t[:, :2].long().T
+            gxy = t[:, 2:4]
+            gij = (gxy - offsets).long()
+            gi, gj = gij.T
+            a = t[:, 6].long()
+            indices.append((b, a, gj.clamp_(0, int(gain[3]) - 1), gi.clamp_(0, int(gain[2]) - 1)))
+            anch.append(anchors[a])
+        return indices, anch
+
+    def build_targets(self, p, targets, imgs):
+        indices, anch = self.find_3_positive(p, targets)
+        nl = len(p)
+        out = [[[] for _ in range(nl)] for _ in range(6)]
+        for bi in range(p[0].shape[0]):
+            this_target = targets[targets[:, 0] == bi]
+            if this_target.shape[0] == 0:
+                continue
+            txyxy = _xywh2xyxy(this_target[:, 2:6] * imgs[bi].shape[1])
+            pxyxys, p_cls, p_obj, fwl, ab, aa, agj, agi, aan = [], [], [], [], [], [], [], [], []
+            for i, pi in enumerate(p):
+                b, a, gj, gi = indices[i]
+                idx = b == bi
+                b, a, gj, gi = b[idx], a[idx], gj[idx], gi[idx]
+                ab.append(b); aa.append(a); agj.append(gj); agi.append(gi); aan.append(anch[i][idx])
+                fwl.append(torch.ones(len(b)) * i)
+                fg = pi[b, a, gj, gi]
+                p_obj.append(fg[:, 4:5])
+                p_cls.append(fg[:, 5:])
+                grid = torch.stack([gi, gj], dim=1)
+                pxy = (fg[:, :2].sigmoid() * 2. - 0.5 + grid) * self.stride[i]
+                pwh = (fg[:, 2:4].sigmoid() * 2) ** 2 * anch[i][idx] * self.stride[i]
+                pxyxys.append(_xywh2xyxy(torch.cat([pxy, pwh], dim=-1)))
+            pxyxys = torch.cat(pxyxys, 0)
+            if pxyxys.shape[0] == 0:
+                continue
+            p_obj, p_cls, fwl = torch.cat(p_obj, 0), torch.cat(p_cls, 0), torch.cat(fwl, 0)
+            ab, aa, agj, agi, aan = torch.cat(ab), torch.cat(aa), torch.cat(agj), torch.cat(agi), torch.cat(aan)
+            iou = _box_iou_xyxy(txyxy, pxyxys)
+            iou_loss = -torch.log(iou + 1e-8)
+            top_k, _ = torch.topk(iou, min(20, iou.shape[1]), dim=1)
+            dynamic_ks = torch.clamp(top_k.sum(1).int(), min=1)
+            num_gt = this_target.shape[0]
+            onehot = F.one_hot(this_target[:, 1].to(torch.int64), self.num_classes).float().unsqueeze(1).repeat(1, pxyxys.shape[0], 1)
+            y = (p_cls.float().unsqueeze(0).repeat(num_gt, 1, 1).sigmoid() * p_obj.unsqueeze(0).repeat(num_gt, 1, 1).sigmoid()).sqrt()
+            cls_loss = F.binary_cross_entropy_with_logits(torch.log(y / (1 - y)), onehot, reduction="none").sum(-1)
+            cost = cls_loss + 3.0 * iou_loss
+            matching = torch.zeros_like(cost)
+            for g in range(num_gt):
+                _, pos = torch.topk(cost[g], k=int(dynamic_ks[g]), largest=False)
+                matching[g][pos] = 1.0
+            multi = matching.sum(0) > 1
+            if multi.sum() > 0:
+                _, amin = torch.min(cost[:, multi], dim=0)
+                matching[:, multi] *= 0.0
+                matching[amin, multi] = 1.0
+            fgm = matching.sum(0) > 0.0
+            mgt = matching[:, fgm].argmax(0)
+            fwl, ab, aa, agj, agi, aan = fwl[fgm], ab[fgm], aa[fgm], agj[fgm], agi[fgm], aan[fgm]
+            tt = this_target[mgt]
+            for i in range(nl):
+                li = fwl == i
+                for k, v in enumerate((ab[li], aa[li], agj[li], agi[li], tt[li], aan[li])):
+                    out[k][i].append(v)
+        res = []
+        for k in range(6):
+            res.append([torch.cat(out[k][i], 0) if out[k][i] else (torch.zeros(0, 6) if k == 4 else (torch.zeros(0, 2) if k == 5 else torch.zeros(0, dtype=torch.long)))
+                        for i in range(nl)])
+        return res
+
+    def __call__(self, p, targets, imgs, return_assign=False):
+        lcls, lbox, lobj = torch.zeros(1), torch.zeros(1), torch.zeros(1)
+        bs, as_, gjs, gis, tg, anchors = self.build_targets([q.detach() for q in p], targets, imgs)
+        for i, pi in enumerate(p):
+            b, a, gj, gi = bs[i], as_[i], gjs[i], gis[i]
+            tobj = torch.zeros_like(pi[..., 0])
+            n = b.shape[0]
+            if n:
+                ps = pi[b, a, gj, gi]
+                grid = torch.stack([gi, gj], dim=1)
+                pxy = ps[:, :2].sigmoid() * 2. - 0.5
+                pwh = (ps[:, 2:4].sigmoid() * 2) ** 2 * anchors[i]
+                pbox = torch.cat((pxy, pwh), 1)
+                gain = torch.tensor(pi.shape)[[3, 2, 3, 2]]
+                tbox = tg[i][:, 2:6] * gain
+                tbox = torch.cat([tbox[:, :2] - grid, tbox[:, 2:]], 1)
+                iou = bbox_iou(pbox.T, tbox, x1y1x2y2=False, CIoU=True)
+                lbox = lbox + (1.0 - iou).mean()
+                tobj[b, a, gj, gi] = (1.0 - self.gr) + self.gr * iou.detach().clamp(0).type(tobj.dtype)
+                if self.num_classes > 1:
+                    t = torch.zeros_like(ps[:, 5:])
+                    t[range(n), tg[i][:, 1].long()] = 1.0
+                    lcls = lcls + F.binary_cross_entropy_with_logits(ps[:, 5:], t)
+            lobj = lobj + F.binary_cross_entropy_with_logits(pi[..., 4], tobj) * self.balance[i]
+        lbox, lobj, lcls = lbox * self.hyp_box, lobj * self.hyp_obj, lcls * self.hyp_cls
+        bsz = p[0].shape[0]
+        loss = lbox + lobj + lcls
+        out = (loss * bsz, torch.cat((lbox, lobj, lcls, loss)).detach())
+        return (out, (bs, as_, gjs, gis, tg)) if return_assign else out

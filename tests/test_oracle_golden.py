@@ -401,3 +401,26 @@ def test_stdc_net_small_and_structure():
     full.train()
     feats = full(torch.randn(1, 3, 64, 128))
     assert [list(f.shape) for f in feats] == [list(map(int, r)) for r in s["shapes"]]
+
+
+@pytest.mark.parametrize("trial", [0, 1])
+def test_v7_ota_loss(trial):
+    """YOLOv7Loss with OTA assignment (src/losses/yolov7_loss.py:129-420): totals, gradients and the per-level matched lists
+    (image, anchor, gj, gi, class, box) must equal the reference's."""
+    g = load("v7_ota_loss_%d" % trial)
+    p = [q.requires_grad_(True) for q in lst(g["p"])]
+    size = int(g["size"][0])
+    imgs = torch.zeros(p[0].shape[0], 3, size, size)
+    (total, stats), (bs, as_, gjs, gis, tg) = R7.YOLOv7OTALoss(80)(p, T(g["targets"]), imgs, return_assign=True)
+    close(total, g["total"])
+    close(stats, g["stats"])
+    grads = torch.autograd.grad(total, p)
+    for a, e in zip(grads, lst(g["grads"])):
+        close(a, e, atol=1e-7)
+    for i in range(3):
+        assert torch.equal(bs[i], T(g["b"][str(i)]))
+        assert torch.equal(as_[i], T(g["a"][str(i)]))
+        assert torch.equal(gjs[i], T(g["gj"][str(i)]))
+        assert torch.equal(gis[i], T(g["gi"][str(i)]))
+        assert torch.equal(tg[i][:, 1], T(g["tcls"][str(i)]))
+        close(tg[i][:, 2:6], g["tbox"][str(i)])

@@ -131,6 +131,36 @@ def yolov7():
     save("v7_detect", x=fe, state=det.state_dict(), train_out=tr, z=z)
 
 
+def v7_ota():
+    from src.losses.yolov7_loss import YOLOv7Loss
+    import src.models.yolov7 as ref_v7
+    for trial, (bs, size, nmax) in enumerate([(2, 64, 5), (3, 96, 8), (2, 64, 0)]):
+        g = torch.Generator().manual_seed(90 + trial)
+        p = [torch.randn(bs, 3, size // s, size // s, 85, generator=g) for s in (8, 16, 32)]
+        rows = []
+        for i in range(bs):
+            n = int(torch.randint(1, nmax + 1, (1,), generator=g)) if nmax else 0
+            if trial == 1 and i == 1:
+                n = 0
+            t = torch.zeros(n, 6)
+            t[:, 0] = i
+            t[:, 1] = torch.randint(0, 80, (n,), generator=g).float()
+            t[:, 2:4] = torch.rand(n, 2, generator=g) * 0.8 + 0.1
+            t[:, 4:6] = torch.rand(n, 2, generator=g) * 0.4 + 0.05
+            rows.append(t)
+        targets = torch.cat(rows, 0) if rows else torch.zeros(0, 6)
+        imgs = torch.zeros(bs, 3, size, size)
+        loss = YOLOv7Loss(80, anchors=ref_v7.YOLOv7.anchors, device="cpu")
+        pr = [q.clone().requires_grad_(True) for q in p]
+        if targets.shape[0] == 0:
+            continue  # the reference crashes on a batch without any label (torch.cat of empty lists): not a fixture
+        total, stats = loss(pr, targets, imgs)
+        grads = torch.autograd.grad(total, pr)
+        bs_, as_, gjs, gis, tg, anch = loss.build_targets(p, targets, imgs)
+        save("v7_ota_loss_%d" % trial, p=p, targets=targets, size=np.array([size]), total=total, stats=stats, grads=grads,
+             b=bs_, a=as_, gj=gjs, gi=gis, tcls=[t[:, 1] for t in tg], tbox=[t[:, 2:6] for t in tg])
+
+
 def stdc():
     from src.models.backbones.seg.stdcnet import STDCNet, CatBottleneck, AddBottleneck
     from src.models.necks.seg.stdc_neck import AttentionRefinementModule, FeatureFusionModule
@@ -181,7 +211,7 @@ def stdc():
 
 def main():
     install()
-    which = sys.argv[1:] or ["yolox", "yolov7", "stdc"]
+    which = sys.argv[1:] or ["yolox", "yolov7", "stdc", "v7_ota"]
     bn = dict(type="BN", momentum=0.03, eps=0.001)
     if "yolox" in which:
         yolox(bn)
@@ -189,6 +219,8 @@ def main():
         yolov7()
     if "stdc" in which:
         stdc()
+    if "v7_ota" in which:
+        v7_ota()
 
 
 if __name__ == "__main__":
