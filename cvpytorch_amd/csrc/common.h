@@ -102,6 +102,16 @@ __device__ __forceinline__ float act_bwd(float u, int act, float ap) {
   }
 }
 
+// sum over the 16 lanes of a DPP row (= the 16 pixel rows of an MFMA fragment), result in every lane: 4 VALU DPP steps
+// (quad swaps, then half-row and row mirrors) instead of 4 ds_bpermute round trips through the LDS
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+
 // XCD-aware, bijective block-id remap (cdna_hip_programming.md §5 "XCD swizzle must be bijective"):
 // hardware places block b on XCD b%8; give each XCD a contiguous chunk of the logical tile space so
 // neighbouring tiles (shared im2col halos / shared A panels) hit the same L2.

@@ -1,0 +1,310 @@
+// conv1x1_stream.hip — streaming 1x1 / stride-1 convolution (fprop and dgrad) for gfx950.
+//
+//   Out[m][n] = sum_c X[m][c] * Wt[n][c]            (m = pixel row, NHWC; dgrad: X = dy, Wt = W^T image)
+//
+// The 1x1 layers of the detectors are HBM-bound (arithmetic intensity C*K/(C+K) flop/B << the MFMA ridge): the general
+// implicit-GEMM kernel stages A through LDS in 32-deep steps with a barrier each and starts a new block per 128/256 rows —
+// prologue/epilogue latency, not bandwidth, sets its time (2-3 TB/s measured, gpurun conv_table). This kernel is built as a
+// stream instead:
+//   * the whole weight tile (BN x Cin, <= 72 KB) is staged into LDS ONCE per block; blocks are persistent (<= 2 per CU) and
+//     walk the pixel rows with a grid stride, so there is no per-tile barrier at all;
+//   * A fragments go global -> VGPR directly (a 1x1 conv needs no gather: lane (r, g) of v_mfma_f32_16x16x32_bf16 wants 8
+//     consecutive channels of pixel row r = one 16-byte load; 16 rows x 64 contiguous bytes per instruction), register
+//     double-buffered one pipeline stage (tile, 128-channel chunk) ahead of the MFMAs;
+//   * the LDS weight rows are PERMUTED so that the two fragments of a pair leave every lane with 8 consecutive output channels
+//     of its pixel -> one 16-byte store (64 contiguous bytes per pixel row per instruction);
+//   * BatchNorm partial sums stay in registers across all tiles of the block and are written once (one partial row per
+//     block: <= 512 rows for rows_reduce instead of M/256).
+// Replaces the same aten::convolution / convolution_backward(input) calls as conv_igemm.hip (reference
+// src/models/bricks/conv_module.py:209) for kernel_size 1, stride 1, padding 0, groups 1.
+#include <stdlib.h>
+
+#include "common.h"
+#include "conv_plan.h"
+
+namespace cvhip {
+
+constexpr int kS1MaxLds = 72 * 1024;   // weight tile incl. row padding (+ 1 KB bias); two blocks per CU fit the 160 KB LDS
+constexpr int kS1MaxBlocks = 512;      // persistent grid: 2 blocks per CU
+constexpr int kS1MinTiles = 192;       // below this the grid cannot cover the chip: the general kernel's smaller tiles win
+
+template <int NF, int MF, bool STATS>
+__global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmParams p, int ntiles, int vec16) {
+  constexpr int BN = NF * 16;
+  constexpr int RT = 64 * MF;   // pixel rows per block tile: 4 waves x MF fragments x 16
+  constexpr int KC = 256 / MF;  // channels per pipeline stage (register budget: MF * KC/32 * 4 VGPRs per buffer)
+  constexpr int KS = KC / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int Cin = p.Cin;
+  const int M = p.cls[0].M;
+  const int cin_pad = (Cin + 31) & ~31;
+  const int brow = cin_pad * 2 + 16;  // bytes per LDS weight row; (cin_pad/2 + 4) banks = 4 * odd -> 16 rows hit 64 distinct banks
+  const int nkc = (cin_pad + KC - 1) / KC;
+  const int n0 = blockIdx.y * BN;
+
+  const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = my_tiles * nkc;
+
+  bf16x8 buf0[MF][KS], buf1[MF][KS];
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  // pipeline position of the NEXT load
+  int ld_tile = blockIdx.x, ld_kc = 0;
+  auto load = [&](bf16x8 (&dst)[MF][KS]) {
+    const int row0 = ld_tile * RT + wave * (MF * 16) + r;
+    const int kbase = ld_kc * KC + g * 8;
+#pragma unroll
+    for (int b = 0; b < MF; ++b) {
+      const int m = row0 + b * 16;
+      const bf16_t* src = p.x + (int64_t)m * p.x_ld + kbase;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bool ok = m < M && kbase + ks * 32 < Cin;
+        dst[b][ks] = ok ? *reinterpret_cast<const bf16x8*>(src + ks * 32) : zero8;
+      }
+    }
+    if (++ld_kc == nkc) {
+      ld_kc = 0;
+      ld_tile += gridDim.x;
+    }
+  };
+
+  if (total > 0) load(buf0);
+
+  // ---- weight tile -> LDS, rows permuted: LDS row a*16 + i holds channel n0 + (a>>1)*32 + (i>>2)*8 + (a&1)*4 + (i&3)
+  {
+    const int cpr = cin_pad >> 3;  // 16-byte chunks per row
+    const int nchunks = BN * cpr;
+    constexpr int U = 8;  // loads in flight per thread (the tile is up to 72 KB = 18 chunks per thread)
+    for (int q0 = t; q0 < nchunks; q0 += 256 * U) {
+      uint4 v[U];
+      int dst[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int q = q0 + u * 256;
+        const int L = q / cpr;
+        const int kq = q - L * cpr;
+        const int a = L >> 4, i = L & 15;
+        const int ch = n0 + (a >> 1) * 32 + (i >> 2) * 8 + (a & 1) * 4 + (i & 3);
+        dst[u] = q < nchunks ? L * brow + kq * 16 : -1;
+        v[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (q < nchunks && ch < p.Nout && kq * 8 < Cin) v[u] = *reinterpret_cast<const uint4*>(p.w + (int64_t)ch * Cin + kq * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (dst[u] >= 0) *reinterpret_cast<uint4*>(smem + dst[u]) = v[u];
+    }
+  }
+  float* const sbias = reinterpret_cast<float*>(smem + BN * brow);  // [BN] fp32 behind the weight tile
+  if (p.bias && t < BN) sbias[t] = (n0 + t < p.bias_n) ? p.bias[n0 + t] : 0.f;
+  __syncthreads();
+
+  f32x4 acc[NF][MF];
+#pragma unroll
+  for (int a = 0; a < NF; ++a)
+#pragma unroll
+    for (int b = 0; b < MF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float s1[STATS ? NF : 1][4], s2[STATS ? NF : 1][4];
+  if constexpr (STATS) {
+#pragma unroll
+    for (int a = 0; a < NF; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s1[a][q] = s2[a][q] = 0.f;
+  }
+
+  const unsigned char* const wlane = smem + r * brow + g * 16;
+  int cp_tile = blockIdx.x, cp_kc = 0;  // pipeline position of the NEXT compute
+  auto compute = [&](const bf16x8 (&src)[MF][KS]) {
+    const unsigned char* wk = wlane + cp_kc * (KC * 2);
+    const int ksn = min(KS, (cin_pad - cp_kc * KC) >> 5);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks < ksn) {
+#pragma unroll
+        for (int a = 0; a < NF; ++a) {
+          const bf16x8 wb = *reinterpret_cast<const bf16x8*>(wk + a * 16 * brow + ks * 64);
+#pragma unroll
+          for (int b = 0; b < MF; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, src[b][ks], acc[a][b], 0, 0, 0);
+        }
+      }
+    }
+    if (++cp_kc < nkc) return;
+    // ---- tile finished: store, fold into the BN sums, reset
+    const int row0 = cp_tile * RT + wave * (MF * 16) + r;
+#pragma unroll
+    for (int b = 0; b < MF; ++b) {
+      const int m = row0 + b * 16;
+      bf16_t* yrow = p.y + (int64_t)m * p.y_ld;
+#pragma unroll
+      for (int j = 0; j < NF / 2; ++j) {
+        const int ch0 = n0 + j * 32 + g * 8;
+        f32x8 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v.v[q] = acc[2 * j][b][q];
+          v.v[4 + q] = acc[2 * j + 1][b][q];
+        }
+        if constexpr (STATS) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            s1[2 * j][q] += v.v[q];
+            s2[2 * j][q] += v.v[q] * v.v[q];
+            s1[2 * j + 1][q] += v.v[4 + q];
+            s2[2 * j + 1][q] += v.v[4 + q] * v.v[4 + q];
+          }
+        }
+        if (p.bias) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(sbias + j * 32 + g * 8);
+          const f32x4 b1 = *reinterpret_cast<const f32x4*>(sbias + j * 32 + g * 8 + 4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            v.v[q] += b0[q];
+            v.v[4 + q] += b1[q];
+          }
+        }
+        if (m < M) {
+          if (vec16 && ch0 + 7 < p.Nout) {
+            *reinterpret_cast<uint4*>(yrow + ch0) = pack8(v);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+              if (ch0 + q < p.Nout) yrow[ch0 + q] = (bf16_t)v.v[q];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < NF; ++a)
+#pragma unroll
+      for (int b = 0; b < MF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    cp_kc = 0;
+    cp_tile += gridDim.x;
+  };
+
+  for (int it = 0; it < total; it += 2) {
+    if (it + 1 < total) load(buf1);
+    compute(buf0);
+    if (it + 1 < total) {
+      if (it + 2 < total) load(buf0);
+      compute(buf1);
+    }
+  }
+
+  if constexpr (STATS) {
+    if (p.stats) {
+      __syncthreads();  // every wave is done with the weight tile
+      float* red = reinterpret_cast<float*>(smem);  // [4 waves][BN][2]
+#pragma unroll
+      for (int a = 0; a < NF; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float u1 = row16_sum(s1[a][q]), u2 = row16_sum(s2[a][q]);
+          if (r == 0) {
+            const int lc = (a >> 1) * 32 + g * 8 + (a & 1) * 4 + q;
+            red[(wave * BN + lc) * 2 + 0] = u1;
+            red[(wave * BN + lc) * 2 + 1] = u2;
+          }
+        }
+      __syncthreads();
+      if (t < BN && n0 + t < p.Nout) {
+        float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          u1 += red[(w * BN + t) * 2 + 0];
+          u2 += red[(w * BN + t) * 2 + 1];
+        }
+        float* dst = p.stats + (int64_t)blockIdx.x * 2 * p.Nout;
+        dst[n0 + t] = u1;
+        dst[p.Nout + n0 + t] = u2;
+      }
+    }
+  }
+}
+
+// ---- host side ----------------------------------------------------------------------------------
+
+static int s1x1_mode() {  // CVHIP_S1X1: 0 = never, 1 = when profitable (default), 2 = whenever structurally possible (tests)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CVHIP_S1X1");
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+
+// fragments across the output channels: 32/64/128-wide tiles; 256-wide (detection-head convs: 255 channels, bias, no BN sums ->
+// the registers the sums would take hold the second half of the accumulators) when the weight tile still fits
+static int s1x1_nf(int Nout, int Cin, bool stats) {
+  if (Nout <= 32) return 2;
+  if (Nout <= 64) return 4;
+  if (Nout > 128 && Nout <= 256 && !stats && 256 * (((Cin + 31) & ~31) * 2 + 16) <= kS1MaxLds) return 16;
+  return 8;
+}
+
+// grid.x of the streaming kernel for this problem, 0 when the general kernel should run
+int stream1x1_blocks(int Nout, int Cin, int64_t M, bool stats) {
+  const int mode = s1x1_mode();
+  if (mode == 0 || (Cin & 7) || M <= 0 || M >= (1ll << 31)) return 0;
+  const int bn = s1x1_nf(Nout, Cin, stats) * 16;
+  const int cin_pad = (Cin + 31) & ~31;
+  if (bn * (cin_pad * 2 + 16) > kS1MaxLds) return 0;
+  const int ntiles = (int)((M + 127) / 128);
+  if (mode == 1 && (ntiles < kS1MinTiles || Nout > bn)) return 0;
+  const int rounds = cdiv(ntiles, kS1MaxBlocks);
+  return cdiv(ntiles, rounds);  // balanced: every block walks `rounds` (or rounds-1) tiles
+}
+
+static bool s1x1_structural(const IgemmParams& p) {
+  if (p.ncls != 1) return false;
+  const IgemmClass& c = p.cls[0];
+  return c.TR == 1 && c.TS == 1 && p.in_sh == 1 && p.in_sw == 1 && p.out_sh == 1 && p.out_sw == 1 && c.dh0 == 0 && c.dw0 == 0 &&
+         c.out_oh == 0 && c.out_ow == 0 && c.OHi == p.OH && c.OWi == p.OW && p.IH == p.OH && p.IW == p.OW && (p.x_ld & 7) == 0;
+}
+
+template <int NF, bool STATS>
+static int launch_s1(const IgemmParams& p, int blocks, int ntiles, hipStream_t stream) {
+  constexpr int MF = 2;
+  const int bn = NF * 16;
+  const int cin_pad = (p.Cin + 31) & ~31;
+  int lds = bn * (cin_pad * 2 + 16) + bn * (int)sizeof(float);  // weight tile + bias
+  if (lds < 4 * bn * 2 * (int)sizeof(float)) lds = 4 * bn * 2 * (int)sizeof(float);
+  auto kern = conv1x1_stream_kernel<NF, MF, STATS>;
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kS1MaxLds + 1024);
+    if (e != hipSuccess) {
+      set_last_error("hipFuncSetAttribute(conv1x1_stream_kernel)", e);
+      return CVHIP_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  const int vec16 = ((p.y_ld & 7) == 0) && ((((uintptr_t)p.y) & 15) == 0);
+  hipLaunchKernelGGL(kern, dim3(blocks, cdiv(p.Nout, bn)), dim3(256), lds, stream, p, ntiles, vec16);
+  return check_launch("conv1x1_stream_kernel");
+}
+
+// returns -1 when the problem is not taken (caller falls through to the general kernel)
+int try_launch_stream1x1(const IgemmParams& p, hipStream_t stream) {
+  if (!s1x1_structural(p)) return -1;
+  const int64_t M = p.cls[0].M;
+  const int blocks = stream1x1_blocks(p.Nout, p.Cin, M, p.stats != nullptr);
+  if (blocks <= 0) return -1;
+  const int ntiles = (int)((M + 127) / 128);
+  const int nf = s1x1_nf(p.Nout, p.Cin, p.stats != nullptr);
+  if (p.stats) {
+    if (nf == 2) return launch_s1<2, true>(p, blocks, ntiles, stream);
+    if (nf == 4) return launch_s1<4, true>(p, blocks, ntiles, stream);
+    return launch_s1<8, true>(p, blocks, ntiles, stream);
+  }
+  if (nf == 2) return launch_s1<2, false>(p, blocks, ntiles, stream);
+  if (nf == 4) return launch_s1<4, false>(p, blocks, ntiles, stream);
+  if (nf == 16) return launch_s1<16, false>(p, blocks, ntiles, stream);
+  return launch_s1<8, false>(p, blocks, ntiles, stream);
+}
+
+}  // namespace cvhip

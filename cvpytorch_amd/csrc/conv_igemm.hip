@@ -439,6 +439,13 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (all-zero) DMAs must land before smem is reused
   __syncthreads();
 
+  // bias through the LDS: per-element global loads in the epilogue doubled the time of memory-bound layers (tools/s1x1_bench.py)
+  const float* const sbias = reinterpret_cast<const float*>(smem);
+  if (p.bias) {
+    if (t < BN) reinterpret_cast<float*>(smem)[t] = (n0 + t < p.bias_n) ? p.bias[n0 + t] : 0.f;
+    __syncthreads();
+  }
+
   const int nq = (lane >> 4) * 4;
 #pragma unroll
   for (int b = 0; b < MF; ++b) {
@@ -456,10 +463,11 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) 
       if (n >= p.Nout) continue;
       float v0 = acc[a][b][0], v1 = acc[a][b][1], v2 = acc[a][b][2], v3 = acc[a][b][3];
       if (p.bias) {
-        if (n < p.bias_n) v0 += p.bias[n];
-        if (n + 1 < p.bias_n) v1 += p.bias[n + 1];
-        if (n + 2 < p.bias_n) v2 += p.bias[n + 2];
-        if (n + 3 < p.bias_n) v3 += p.bias[n + 3];
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + wn * WN + a * 16 + nq);
+        v0 += bv[0];
+        v1 += bv[1];
+        v2 += bv[2];
+        v3 += bv[3];
       }
       if (p.y_vec_ok && n + 3 < p.Nout) {
         uint2 u;
@@ -488,11 +496,8 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) 
           s1 += v;
           s2 += v * v;
         }
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {
-          s1 += __shfl_xor(s1, off, 64);
-          s2 += __shfl_xor(s2, off, 64);
-        }
+        s1 = row16_sum(s1);
+        s2 = row16_sum(s2);
         if ((lane & 15) == 0) {
           const int nl = wn * WN + a * 16 + nq + r;
           red[(wm * BN + nl) * 2 + 0] = s1;
@@ -609,6 +614,8 @@ int igemm_block_m(int Nout, int64_t M, int Ktot) {
 }
 
 int launch_igemm(IgemmParams& p, hipStream_t stream) {
+  const int s1 = try_launch_stream1x1(p, stream);  // 1x1 / stride 1: persistent streaming kernel (conv1x1_stream.hip)
+  if (s1 >= 0) return s1;
   if (narrow128() && !use_v1()) {
     if (p.Nout <= 32) return launch_cfg<128, 32, 32, 32>(p, stream);
     if (p.Nout <= 64) return launch_cfg<128, 64, 32, 64>(p, stream);

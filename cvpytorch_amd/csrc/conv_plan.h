@@ -89,5 +89,8 @@ void plan_fprop(const cvhip_conv_desc* d, IgemmParams* p);
 int plan_dgrad(const cvhip_conv_desc* d, IgemmParams* p);
 int igemm_block_m(int Nout, int64_t M, int Ktot);
 int launch_igemm(IgemmParams& p, hipStream_t stream);
+// conv1x1_stream.hip: grid size of the streaming 1x1 kernel (0 = the general kernel runs) and its launcher (-1 = not taken)
+int stream1x1_blocks(int Nout, int Cin, int64_t M, bool stats);
+int try_launch_stream1x1(const IgemmParams& p, hipStream_t stream);
 
 }  // namespace cvhip

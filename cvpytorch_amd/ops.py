@@ -61,14 +61,21 @@ class KernelTimer:
 TIMER = KernelTimer()
 
 
-def _igemm_name(nout, m=0, ktot=0):
-    """label of the tile configuration launch_igemm picks (conv_igemm.hip: igemm_block_m) for `nout` output channels, m rows"""
+def _igemm_name(nout, m=0, ktot=0, pointwise=False, ld=0, stats=False):
+    """label of the kernel / tile configuration launch_igemm picks (conv_igemm.hip: igemm_block_m; conv1x1_stream.hip for
+    1x1 stride-1 unpadded passes) for `nout` output channels, m rows"""
+    if pointwise and ld % 8 == 0 and L.load().cvhip_conv1x1_stream_blocks(nout, ktot, m, int(stats)) > 0:
+        return "conv1x1_stream_kernel<%d>" % (32 if nout <= 32 else 64 if nout <= 64 else 128 if nout <= 128 or stats else 256)
     if nout <= 32:
         return "igemm_kernel<256,32,64,32>"
     if nout <= 64:
         return "igemm_kernel<256,64,64,64>"
     big = ktot >= 512 and ((m + 255) // 256) * ((nout + 127) // 128) >= 384
     return "igemm_kernel<256,128,128,64>" if big else "igemm_kernel<128,128,64,64>"
+
+
+def _pointwise(R, S, cfg):
+    return R == 1 and S == 1 and tuple(cfg.stride) == (1, 1) and tuple(cfg.pad) == (0, 0)
 
 
 def _wgrad_name(k):
@@ -352,7 +359,7 @@ class ConvBnAct(torch.autograd.Function):
                 if rows < 0:
                     L.check(rows, "cvhip_conv2d_fprop_stats_rows")
                 partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
-            _timed_call(_igemm_name(Kp, N * P * Q, R * S * Cc), (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv2d_fprop", C.byref(desc), x.data_ptr(),
+            _timed_call(_igemm_name(Kp, N * P * Q, R * S * Cc, _pointwise(R, S, cfg), x_ld, partial is not None), (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv2d_fprop", C.byref(desc), x.data_ptr(),
                         cfg.state.w_fprop.data_ptr(), _ptr(b), y.data_ptr(), _ptr(partial), st)
         if train_bn:
             if partial is None:
@@ -516,7 +523,7 @@ class ConvBnAct(torch.autograd.Function):
                     raise L.CvhipError("dgrad weight image missing (input started requiring grad after forward)")
                 dx = empty_nhwc(N, Cc, H, W, dev)
                 ddesc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, Cc, dy_ld, kv, cv)
-                _timed_call(_igemm_name(Cc, N * H * W, -(-R // cfg.stride[0]) * -(-S // cfg.stride[1]) * Kp), (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv2d_dgrad", C.byref(ddesc), dy.data_ptr(),
+                _timed_call(_igemm_name(Cc, N * H * W, -(-R // cfg.stride[0]) * -(-S // cfg.stride[1]) * Kp, _pointwise(R, S, cfg), dy_ld), (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv2d_dgrad", C.byref(ddesc), dy.data_ptr(),
                             ctx.w_dgrad.data_ptr(), dx.data_ptr(), st)
         if dw is not None and dw.dtype != weight.dtype:
             dw = dw.to(weight.dtype)

@@ -90,6 +90,10 @@ int cvhip_conv2d_out_hw(const cvhip_conv_desc* d, int32_t* P, int32_t* Q);
  *                                   {TR, TS, r0, r_step, dh0, dh_step(neg), s0/... see DESIGN.md}
  */
 int cvhip_conv2d_fprop_stats_rows(const cvhip_conv_desc* d);
+/* grid size of the persistent streaming kernel (conv1x1_stream.hip) that cvhip_conv2d_fprop / _dgrad pick for a 1x1, stride-1,
+ * unpadded pass with `nout` result channels, `cin` reduced channels and `m` pixel rows (`with_stats`: the pass also writes
+ * BatchNorm partial sums); 0 = the general implicit-GEMM kernel runs (profiling labels / tests; pure host arithmetic). */
+int cvhip_conv1x1_stream_blocks(int nout, int cin, int64_t m, int with_stats);
 int64_t cvhip_conv2d_dgrad_weight_elems(const cvhip_conv_desc* d);
 /* per class: {TR, TS, r0, r_step, dh0, dh_step, s0, s_step, dw0, dw_step, w_offset(elems, 2 x int32 lo/hi)} = 12 int32 */
 #define CVHIP_DGRAD_CLASS_INTS 12

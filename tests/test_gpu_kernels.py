@@ -99,7 +99,28 @@ CONV_CASES = [
     (62, 128, 40, 40, 128, 3, 3, 1, 1, 1),
     (25, 64, 64, 64, 256, 1, 1, 1, 0, 1),
     (26, 128, 80, 80, 256, 3, 3, 2, 1, 1),
+    # 1x1 / stride 1 with >= 192 row tiles: the persistent streaming kernel (conv1x1_stream.hip) — ragged last tile, reduced
+    # channels not a multiple of 32, two 128-channel pipeline chunks, 32/64/128/256-wide output tiles (fprop and dgrad roles)
+    (7, 64, 60, 60, 32, 1, 1, 1, 0, 1),
+    (7, 40, 60, 60, 128, 1, 1, 1, 0, 1),
+    (7, 128, 60, 60, 255, 1, 1, 1, 0, 1),
+    (7, 24, 60, 60, 64, 1, 1, 1, 0, 1),
+    (4, 256, 80, 80, 128, 1, 1, 1, 0, 1),
 ]
+STREAM_CASES = CONV_CASES[-5:]
+
+
+def test_stream1x1_cases_take_the_streaming_kernel():
+    lib = L.load()
+    for N, Cc, H, W, K, R, S, s, p, d in STREAM_CASES:
+        Kp = (K + 7) // 8 * 8
+        assert lib.cvhip_conv1x1_stream_blocks(Kp, Cc, N * H * W, 0) > 0, (K, Cc)        # fprop + bias
+        assert lib.cvhip_conv1x1_stream_blocks(Cc, Kp, N * H * W, 0) > 0, (K, Cc)        # dgrad
+        if K % 8 == 0:
+            desc = ops.conv_desc(N, Cc, H, W, K, R, S, (s, s), (p, p), (d, d), 1, Cc, K)
+            assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(desc)) == lib.cvhip_conv1x1_stream_blocks(K, Cc, N * H * W, 1) > 0
+    assert lib.cvhip_conv1x1_stream_blocks(128, 512, 1 << 20, 1) == 0      # weight tile does not fit the LDS budget
+    assert lib.cvhip_conv1x1_stream_blocks(64, 64, 4096, 1) == 0            # too few row tiles to cover the chip
 
 
 def _mk(case, seed=0):
