@@ -42,7 +42,36 @@ class FlatTrainState:
         self.momentum, self.nesterov = float(momentum), bool(nesterov)
         groups = build_param_groups(model, lr, backbone_lr, weight_decay)
         hyper = {id(g["params"][0]): (g["lr"], g["weight_decay"]) for g in groups}
-        self.params = [p for p in model.parameters() if p.requires_grad]
+        # sibling layers that train as one convolution (ops.ConvBnActPair) need their tensors back to back: reorder so that the
+        # second layer's weight / BN weight / BN bias / running statistics directly follow the first layer's
+        follow = {}
+        for m in model.modules():
+            if hasattr(m, "hip_sibling_pairs"):
+                for a, b in m.hip_sibling_pairs():
+                    na, nb = getattr(a, "norm", None), getattr(b, "norm", None)
+                    follow[id(a.conv.weight)] = b.conv.weight
+                    if na is not None and nb is not None:
+                        for name in ("weight", "bias", "running_mean", "running_var"):
+                            ta, tb = getattr(na, name, None), getattr(nb, name, None)
+                            if ta is not None and tb is not None:
+                                follow[id(ta)] = tb
+
+        def paired_order(items):
+            present = {id(t) for t in items}
+            out, placed = [], set()
+            for t in items:
+                if id(t) in placed:
+                    continue
+                out.append(t)
+                placed.add(id(t))
+                nxt = follow.get(id(t))
+                if nxt is not None and id(nxt) in present and id(nxt) not in placed:
+                    out.append(nxt)
+                    placed.add(id(nxt))
+            pos = {id(t): i for i, t in enumerate(items)}
+            return out, [pos[id(t)] for t in out]
+
+        self.params, perm_p = paired_order([p for p in model.parameters() if p.requires_grad])
         dev = self.params[0].device
         if dev.type != "cuda":
             raise L.CvhipError("FlatTrainState needs the model on the GPU (no CPU fallback)")
@@ -85,7 +114,7 @@ class FlatTrainState:
         self.dyn = torch.tensor([0.0, 1.0], dtype=torch.float32, device=dev)  # {ema_decay, lr_scale}, read by the kernels
         self._dyn_host = torch.zeros((256, 2), dtype=torch.float32).pin_memory()
         # floating-point buffers (BN running statistics) in their own arena
-        self.bufs = [b for b in model.buffers() if b.dtype == torch.float32]
+        self.bufs, perm_b = paired_order([b for b in model.buffers() if b.dtype == torch.float32])
         self.buf = torch.zeros(sum(b.numel() for b in self.bufs), dtype=torch.float32, device=dev)
         o = 0
         owners = {}
@@ -112,6 +141,7 @@ class FlatTrainState:
             self.ema_param = self.param.clone()
             self.ema_buf = self.buf.clone()
             eparams = [p for p, q in zip(self.ema_model.parameters(), model.parameters()) if q.requires_grad]
+            eparams = [eparams[i] for i in perm_p]  # same arena order as the live parameters
             for p, off in zip(eparams, offs):
                 p.data = _dense_view(self.ema_param, off, p)
             o = 0
@@ -120,7 +150,8 @@ class FlatTrainState:
                 for name, b in m._buffers.items():
                     if b is not None and b.dtype == torch.float32:
                         eowners.setdefault(id(b), (m, name))
-            for b in [b for b in self.ema_model.buffers() if b.dtype == torch.float32]:
+            ebufs = [b for b in self.ema_model.buffers() if b.dtype == torch.float32]
+            for b in [ebufs[i] for i in perm_b]:
                 m, name = eowners[id(b)]
                 m._buffers[name] = self.ema_buf[o:o + b.numel()].view(b.shape)
                 o += b.numel()

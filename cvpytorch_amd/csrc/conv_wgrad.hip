@@ -303,8 +303,13 @@ int launch_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float*
   p.Ktot = d->R * d->S * d->C;
   p.M = d->N * p.OHi * p.OWi;
   if (p.M <= 0) return CVHIP_OK;
-  if (d->K <= 32) return launch_wg<32, 32, 32>(p, stream);
-  if (d->K <= 64) return launch_wg<64, 32, 64>(p, stream);
+  static int tn_max = -1;
+  if (tn_max < 0) {
+    const char* e = getenv("CVHIP_WGRAD_TNMAX");
+    tn_max = e ? atoi(e) : 128;
+  }
+  if (d->K <= 32 || tn_max <= 32) return launch_wg<32, 32, 32>(p, stream);
+  if (d->K <= 64 || tn_max <= 64) return launch_wg<64, 32, 64>(p, stream);
   return launch_wg<128, 64, 64>(p, stream);
 }
 

@@ -296,6 +296,98 @@ def _colreduce_rows(M, Cc):
     return L.load().cvhip_colreduce_rows(M, Cc)
 
 
+def _mark(arena, idx):
+    for i in (idx if isinstance(idx, tuple) else (idx,)):
+        arena.mark_ready(i)
+
+
+def _conv_grads(ctx, x, weight, dy, dy_ld, need_dx, need_dw, need_db):
+    """bias / weight / input gradients of the convolution itself from dy (the gradient at the conv output, NHWC bf16 with pitch
+    dy_ld): shared by ConvBnAct.backward and ConvBnActPair.backward."""
+    cfg = ctx.cfg
+    N, Cc, H, W, K, R, S, P, Q, Kp, x_ld, Cg = ctx.geom
+    dev = x.device
+    M = N * P * Q
+    st = _stream()
+    kv = K if Kp != K else 0
+    cv = Cg if (not ctx.depthwise and Cg != Cc) else 0
+    arena = cfg.arena
+    dbias = None
+    if ctx.has_bias and need_db and not ctx.train_bn:
+        rows = _colreduce_rows(M, K)
+        partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
+        L.call("cvhip_colsum_partial", dy.data_ptr(), M, K, dy_ld, partial.data_ptr(), st)
+        if arena is not None and cfg.gb is not None:
+            L.call("cvhip_colsum_finalize", partial.data_ptr(), rows, K, cfg.gb.data_ptr(), 1, st)
+            arena.mark_ready(cfg.idx_b)
+        else:
+            dbias = torch.empty((K,), dtype=torch.float32, device=dev)
+            L.call("cvhip_colsum_finalize", partial.data_ptr(), rows, K, dbias.data_ptr(), 0, st)
+    elif ctx.has_bias and need_db:
+        dbias = zero_fill(torch.empty((K,), dtype=torch.float32, device=dev))  # bias before train-mode BN: zero gradient
+    dx = dw = None
+    direct_w = arena is not None and cfg.gw is not None and tuple(cfg.gw.shape) == tuple(weight.shape)
+    if ctx.depthwise:
+        desc = conv_desc(N, Cc, H, W, K, R, S, cfg.stride, cfg.pad, cfg.dil, cfg.groups, x_ld, dy_ld)
+        if need_dw and direct_w:
+            L.call("cvhip_dwconv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(), cfg.gw.data_ptr(), 1, st)
+            _mark(arena, cfg.idx_w)
+        elif need_dw:
+            dwm = torch.empty((K, R, S), dtype=torch.float32, device=dev)
+            L.call("cvhip_dwconv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(), dwm.data_ptr(), 0, st)
+            dw = dwm.reshape(K, 1, R, S)
+        if need_dx:
+            wm = weight.detach()
+            wm = (wm if wm.dtype == torch.float32 else wm.float()).reshape(K, R, S)
+            wm = wm if wm.is_contiguous() else wm.contiguous()
+            dx = empty_nhwc(N, Cc, H, W, dev)
+            ddesc = conv_desc(N, Cc, H, W, K, R, S, cfg.stride, cfg.pad, cfg.dil, cfg.groups, Cc, dy_ld)
+            L.call("cvhip_dwconv2d_dgrad", C.byref(ddesc), dy.data_ptr(), wm.data_ptr(), dx.data_ptr(), st)
+    else:
+        if need_dw:
+            desc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, x_ld, dy_ld, kv, cv)
+            padded = (Kp != K) or (Cg != Cc)
+            geom = (N, Cc, H, W, K, R, S, P, Q)
+            if not padded and direct_w and _Side.enabled and not TIMER.enabled and (arena.world == 1 or arena.defer_allreduce):
+                # same, on the side stream (see _Side): runs concurrently with the dgrad / BN-backward chain
+                side = _side_begin()
+                with torch.cuda.stream(side):
+                    L.call("cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(), cfg.gw.data_ptr(), 1, side.cuda_stream)
+                _Side.keep.append((x, dy))
+            elif not padded and direct_w:
+                # accumulate straight into the parameter's KRSC slot of the flat gradient arena
+                _timed_call(_wgrad_name(Kp), geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(),
+                            cfg.gw.data_ptr(), 1, st)
+            elif not padded:
+                # logical OIHW, KRSC (channels_last) memory: a fresh non-view tensor autograd can adopt as .grad
+                dw = torch.empty((K, Cc, R, S), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+                _timed_call(_wgrad_name(Kp), geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(),
+                            dw.data_ptr(), 0, st)
+            else:
+                # padded problem: wgrad into a [Kp][R][S][Cc] scratch, then fold the valid block into the real gradient
+                tmp = torch.empty((Kp, R, S, Cc), dtype=torch.float32, device=dev)
+                _timed_call(_wgrad_name(Kp), geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(),
+                            tmp.data_ptr(), 0, st)
+                if direct_w:
+                    dst = cfg.gw
+                else:
+                    dw = zero_fill(torch.empty((K, Cg, R, S), dtype=torch.float32, device=dev, memory_format=torch.channels_last))
+                    dst = dw
+                L.call("cvhip_f32_unpad_add", tmp.data_ptr(), dst.data_ptr(), K, R * S, Cc, Cg, st)
+            if direct_w:
+                _mark(arena, cfg.idx_w)
+        if need_dx:
+            if ctx.w_dgrad is None:
+                raise L.CvhipError("dgrad weight image missing (input started requiring grad after forward)")
+            dx = empty_nhwc(N, Cc, H, W, dev)
+            ddesc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, Cc, dy_ld, kv, cv)
+            _timed_call(_igemm_name(Cc, N * H * W, -(-R // cfg.stride[0]) * -(-S // cfg.stride[1]) * Kp, _pointwise(R, S, cfg), dy_ld), (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv2d_dgrad", C.byref(ddesc), dy.data_ptr(),
+                        ctx.w_dgrad.data_ptr(), dx.data_ptr(), st)
+    if dw is not None and dw.dtype != weight.dtype:
+        dw = dw.to(weight.dtype)
+    return dx, dw, dbias
+
+
 class ConvBnAct(torch.autograd.Function):
     """z = act(bn(conv(x, W) + b)) (+ residual)   — any of bn / act / bias / residual optional.
 
@@ -455,78 +547,7 @@ class ConvBnAct(torch.autograd.Function):
                 buf = zero_fill(torch.empty((N, P, Q, Kp), dtype=BF16, device=dev))
                 L.call("cvhip_copy2d", dy.data_ptr(), dy_ld, buf.data_ptr(), Kp, M, K, st)
                 dy, dy_ld = buf.permute(0, 3, 1, 2)[:, :K], Kp
-        if ctx.has_bias and need_db and not ctx.train_bn:
-            rows = _colreduce_rows(M, K)
-            partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
-            L.call("cvhip_colsum_partial", dy.data_ptr(), M, K, dy_ld, partial.data_ptr(), st)
-            if arena is not None and cfg.gb is not None:
-                L.call("cvhip_colsum_finalize", partial.data_ptr(), rows, K, cfg.gb.data_ptr(), 1, st)
-                arena.mark_ready(cfg.idx_b)
-            else:
-                dbias = torch.empty((K,), dtype=torch.float32, device=dev)
-                L.call("cvhip_colsum_finalize", partial.data_ptr(), rows, K, dbias.data_ptr(), 0, st)
-        elif ctx.has_bias and need_db:
-            dbias = zero_fill(torch.empty((K,), dtype=torch.float32, device=dev))  # bias before train-mode BN: zero gradient
-        dx = dw = None
-        direct_w = arena is not None and cfg.gw is not None and tuple(cfg.gw.shape) == tuple(weight.shape)
-        if ctx.depthwise:
-            desc = conv_desc(N, Cc, H, W, K, R, S, cfg.stride, cfg.pad, cfg.dil, cfg.groups, x_ld, dy_ld)
-            if need_dw and direct_w:
-                L.call("cvhip_dwconv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(), cfg.gw.data_ptr(), 1, st)
-                arena.mark_ready(cfg.idx_w)
-            elif need_dw:
-                dwm = torch.empty((K, R, S), dtype=torch.float32, device=dev)
-                L.call("cvhip_dwconv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(), dwm.data_ptr(), 0, st)
-                dw = dwm.reshape(K, 1, R, S)
-            if need_dx:
-                wm = weight.detach()
-                wm = (wm if wm.dtype == torch.float32 else wm.float()).reshape(K, R, S)
-                wm = wm if wm.is_contiguous() else wm.contiguous()
-                dx = empty_nhwc(N, Cc, H, W, dev)
-                ddesc = conv_desc(N, Cc, H, W, K, R, S, cfg.stride, cfg.pad, cfg.dil, cfg.groups, Cc, dy_ld)
-                L.call("cvhip_dwconv2d_dgrad", C.byref(ddesc), dy.data_ptr(), wm.data_ptr(), dx.data_ptr(), st)
-        else:
-            if need_dw:
-                desc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, x_ld, dy_ld, kv, cv)
-                padded = (Kp != K) or (Cg != Cc)
-                geom = (N, Cc, H, W, K, R, S, P, Q)
-                if not padded and direct_w and _Side.enabled and not TIMER.enabled and (arena.world == 1 or arena.defer_allreduce):
-                    # same, on the side stream (see _Side): runs concurrently with the dgrad / BN-backward chain
-                    side = _side_begin()
-                    with torch.cuda.stream(side):
-                        L.call("cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(), cfg.gw.data_ptr(), 1, side.cuda_stream)
-                    _Side.keep.append((x, dy))
-                elif not padded and direct_w:
-                    # accumulate straight into the parameter's KRSC slot of the flat gradient arena
-                    _timed_call(_wgrad_name(Kp), geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(),
-                                cfg.gw.data_ptr(), 1, st)
-                elif not padded:
-                    # logical OIHW, KRSC (channels_last) memory: a fresh non-view tensor autograd can adopt as .grad
-                    dw = torch.empty((K, Cc, R, S), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
-                    _timed_call(_wgrad_name(Kp), geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(),
-                                dw.data_ptr(), 0, st)
-                else:
-                    # padded problem: wgrad into a [Kp][R][S][Cc] scratch, then fold the valid block into the real gradient
-                    tmp = torch.empty((Kp, R, S, Cc), dtype=torch.float32, device=dev)
-                    _timed_call(_wgrad_name(Kp), geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(),
-                                tmp.data_ptr(), 0, st)
-                    if direct_w:
-                        dst = cfg.gw
-                    else:
-                        dw = zero_fill(torch.empty((K, Cg, R, S), dtype=torch.float32, device=dev, memory_format=torch.channels_last))
-                        dst = dw
-                    L.call("cvhip_f32_unpad_add", tmp.data_ptr(), dst.data_ptr(), K, R * S, Cc, Cg, st)
-                if direct_w:
-                    arena.mark_ready(cfg.idx_w)
-            if need_dx:
-                if ctx.w_dgrad is None:
-                    raise L.CvhipError("dgrad weight image missing (input started requiring grad after forward)")
-                dx = empty_nhwc(N, Cc, H, W, dev)
-                ddesc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, Cc, dy_ld, kv, cv)
-                _timed_call(_igemm_name(Cc, N * H * W, -(-R // cfg.stride[0]) * -(-S // cfg.stride[1]) * Kp, _pointwise(R, S, cfg), dy_ld), (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv2d_dgrad", C.byref(ddesc), dy.data_ptr(),
-                            ctx.w_dgrad.data_ptr(), dx.data_ptr(), st)
-        if dw is not None and dw.dtype != weight.dtype:
-            dw = dw.to(weight.dtype)
+        dx, dw, dbias = _conv_grads(ctx, x, weight, dy, dy_ld, need_dx, need_dw, need_db)
         dres = dz if ctx.has_res else None
         if dx is not None and ctx.c_orig != Cc:
             dx = dx[:, :ctx.c_orig]  # channel slice of the padded gradient buffer (an NHWC view with ld = round8(C))
@@ -535,6 +556,98 @@ class ConvBnAct(torch.autograd.Function):
 
 def conv_bn_act(x, weight, bias, gamma, beta, running_mean, running_var, residual, cfg):
     return ConvBnAct.apply(x, weight, bias, gamma, beta, running_mean, running_var, residual, cfg)
+
+
+class ConvBnActPair(torch.autograd.Function):
+    """Two sibling 1x1 Conv-BN-act layers on the SAME input (CSP conv1 / conv2: yolo_modules.py:131-139) as ONE convolution with
+    K1 + K2 output channels: x is read once by fprop and once by wgrad, dgrad produces the complete input gradient (no
+    gradient-accumulation add), the BN+act pass covers both halves. Needs the two layers' parameters / running statistics /
+    gradient slots ADJACENT in the flat arenas (arena.FlatTrainState places `hip_sibling_pairs()` that way); `pair_operands`
+    returns None otherwise and the caller runs the two layers separately. Outputs are the two channel slices of one buffer;
+    backward takes the two slice gradients from wherever they are (no re-assembly copy)."""
+
+    @staticmethod
+    def forward(ctx, x, wf, gf, bf, rmf, rvf, cfg, k1):
+        z = ConvBnAct.forward(ctx, x, wf, None, gf, bf, rmf, rvf, None, cfg)
+        ctx.k1 = k1
+        return z[:, :k1], z[:, k1:]
+
+    @staticmethod
+    def backward(ctx, d1, d2):
+        x, y, stats, weight = ctx.saved_tensors
+        cfg = ctx.cfg
+        N, Cc, H, W, K, R, S, P, Q, Kp, x_ld, Cg = ctx.geom
+        dev = x.device
+        M = N * P * Q
+        st = _stream()
+        dy = empty_nhwc(N, K, P, Q, dev)
+        off = 0
+        for d, kh in ((d1, ctx.k1), (d2, K - ctx.k1)):
+            if d is None:
+                d = zero_fill(empty_nhwc(N, kh, P, Q, dev))
+            d, d_ld = as_nhwc(d)
+            rows = _colreduce_rows(M, kh)
+            partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, kh), dtype=torch.float32, device=dev)
+            sc, sh, mean, invstd = (stats[i].data_ptr() + 4 * off for i in (2, 3, 0, 1))
+            L.call("cvhip_bn_act_bwd_partial", d.data_ptr(), d_ld, y.data_ptr() + 2 * off, Kp, M, kh, sc, sh, mean, invstd,
+                   cfg.act, cfg.act_param, partial.data_ptr(), st)
+            dgamma = torch.empty((kh,), dtype=torch.float32, device=dev)
+            dbeta = torch.empty((kh,), dtype=torch.float32, device=dev)
+            L.call("cvhip_bn_bwd_finalize", partial.data_ptr(), rows, kh, dgamma.data_ptr(), dbeta.data_ptr(),
+                   cfg.gg.data_ptr() + 4 * off, cfg.gbeta.data_ptr() + 4 * off, st)
+            L.call("cvhip_bn_act_bwd_apply", d.data_ptr(), d_ld, y.data_ptr() + 2 * off, Kp, dy.data_ptr() + 2 * off, Kp, M, kh,
+                   sc, sh, mean, invstd, dgamma.data_ptr(), dbeta.data_ptr(), cfg.act, cfg.act_param, st)
+            off += kh
+        for i in cfg.idx_bn:
+            cfg.arena.mark_ready(i)
+        dx, _, _ = _conv_grads(ctx, x, weight, dy, Kp, ctx.needs_input_grad[0], True, False)
+        return dx, None, None, None, None, None, None, None
+
+
+def _adjacent(a, b):
+    return (a is not None and b is not None and a.dtype == b.dtype and a.is_contiguous() and b.is_contiguous()
+            and b.data_ptr() == a.data_ptr() + a.numel() * a.element_size())
+
+
+def pair_operands(conv1, bn1, conv2, bn2):
+    """Fused (weight, gamma, beta, running_mean, running_var, grad views, arena indices) of two sibling 1x1 layers whose tensors
+    sit back to back in the flat arenas, or None."""
+    w1, w2 = conv1.weight, conv2.weight
+    ar = getattr(w1, "_hip_arena", None)
+    if ar is None or getattr(w2, "_hip_arena", None) is None or not torch.is_grad_enabled():
+        return None
+    if not (bn1.training and bn2.training and bn1.track_running_stats and bn2.track_running_stats):
+        return None
+    if bn1.momentum is None or bn1.momentum != bn2.momentum or bn1.eps != bn2.eps:
+        return None
+    k1, k2, cin = w1.shape[0], w2.shape[0], w1.shape[1]
+    if k1 % 8 or k2 % 8 or cin % 8 or w2.shape[1] != cin or tuple(w1.shape[2:]) != (1, 1) or tuple(w2.shape[2:]) != (1, 1):
+        return None
+    flat = lambda t: t.detach().reshape(-1) if t.is_contiguous() else t.detach().permute(0, 2, 3, 1).reshape(-1)  # noqa: E731
+    pairs = [(flat(w1), flat(w2)), (flat(w1._hip_grad), flat(w2._hip_grad))]
+    for name in ("weight", "bias"):
+        a, b = getattr(bn1, name), getattr(bn2, name)
+        if a is None or b is None or getattr(a, "_hip_arena", None) is None or getattr(b, "_hip_arena", None) is None:
+            return None
+        pairs += [(a.detach(), b.detach()), (a._hip_grad, b._hip_grad)]
+    pairs += [(bn1.running_mean, bn2.running_mean), (bn1.running_var, bn2.running_var)]
+    if not all(_adjacent(a, b) for a, b in pairs):
+        return None
+    cat = lambda a, b: a.as_strided((a.numel() + b.numel(),), (1,))  # noqa: E731  (b follows a in the same storage)
+    wf = cat(*pairs[0]).view(k1 + k2, 1, 1, cin).permute(0, 3, 1, 2).requires_grad_(True)   # OIHW shape, KRSC memory
+    gw = cat(*pairs[1]).view(k1 + k2, 1, 1, cin).permute(0, 3, 1, 2)
+    gf, gg = cat(*pairs[2]).requires_grad_(True), cat(*pairs[3])
+    bf, gb = cat(*pairs[4]).requires_grad_(True), cat(*pairs[5])
+    rmf, rvf = cat(*pairs[6]), cat(*pairs[7])
+    idx_w = (w1._hip_arena[1], w2._hip_arena[1])
+    idx_bn = (bn1.weight._hip_arena[1], bn1.bias._hip_arena[1], bn2.weight._hip_arena[1], bn2.bias._hip_arena[1])
+    return wf, gf, bf, rmf, rvf, gw, gg, gb, ar[0], idx_w, idx_bn, k1
+
+
+def conv_bn_act_pair(x, operands, cfg):
+    wf, gf, bf, rmf, rvf, gw, gg, gb, arena, idx_w, idx_bn, k1 = operands
+    cfg.arena, cfg.gw, cfg.gg, cfg.gbeta, cfg.idx_w, cfg.idx_bn = arena, gw, gg, gb, idx_w, idx_bn
+    return ConvBnActPair.apply(x, wf, gf, bf, rmf, rvf, cfg, k1)
 
 
 class BnAct(torch.autograd.Function):

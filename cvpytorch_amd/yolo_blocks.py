@@ -7,12 +7,46 @@ What differs from the reference is only *how* the glue ops execute:
   * CSP / SPPF / Downsampling concats are slice copies into one NHWC buffer whose backward hands out
     channel-slice views (yolo_modules.py:139,162,190)
 """
+import os
+
 import torch.nn as nn
 
 from . import ops
 from .bricks import HipConvModule as ConvModule
 from .bricks import HipDepthwiseSeparableConvModule as DepthwiseSeparableConvModule
-from .bricks import HipMaxPool2d, HipUpsampleNearest2x
+from .bricks import HipMaxPool2d, HipUpsampleNearest2x, bn_tick, sync_of
+
+_PAIR_ENABLED = os.environ.get("CVHIP_PAIR", "1") != "0"
+
+
+def sibling_pair_forward(m1, m2, x, owner):
+    """Run two 1x1 Conv-BN-act modules that share the input `x` as ONE fused convolution (ops.ConvBnActPair) when their
+    tensors are adjacent in the flat training arenas; None -> the caller runs them one by one (eval mode, no arena, SyncBN,
+    odd channel counts, CVHIP_PAIR=0)."""
+    if not _PAIR_ENABLED:
+        return None
+    f1, f2 = m1._fusable(True, True), m2._fusable(True, True)
+    if f1 is None or f2 is None or f1[0] is None or f2[0] is None or f1[1] != f2[1]:
+        return None
+    c1, c2 = m1.conv, m2.conv
+    if (c1.stride, c1.padding, c1.dilation, c1.groups) != ((1, 1), (0, 0), (1, 1), 1) or c1.bias is not None or c2.bias is not None:
+        return None
+    if (c2.stride, c2.padding, c2.dilation, c2.groups) != ((1, 1), (0, 0), (1, 1), 1):
+        return None
+    bn1, bn2 = f1[0], f2[0]
+    if sync_of(bn1) is not None or sync_of(bn2) is not None:
+        return None
+    operands = ops.pair_operands(c1, bn1, c2, bn2)
+    if operands is None:
+        return None
+    state = owner.__dict__.setdefault("_hip_pair_state", ops.ConvState())
+    aid, ap = f1[1]
+    cfg = ops.ConvCfg(c1.stride, c1.padding, c1.dilation, 1, aid, ap, has_bn=True, bn_training=True, momentum=bn1.momentum,
+                      eps=bn1.eps, state=state, track=True)
+    cfg.vkey = (id(c1.weight), c1.weight._version, id(c2.weight), c2.weight._version)
+    bn_tick(bn1)
+    bn_tick(bn2)
+    return ops.conv_bn_act_pair(x, operands, cfg)
 
 
 class Focus(nn.Module):
@@ -71,9 +105,18 @@ class CSPLayer(nn.Module):
             DarknetBottleneck(hidden_channels, hidden_channels, 1.0, shortcut, depthwise, conv_cfg=conv_cfg, norm_cfg=norm_cfg,
                               act_cfg=act_cfg) for _ in range(n)])
 
+    def hip_sibling_pairs(self):
+        """conv1 / conv2 read the same tensor: arena.FlatTrainState lays their parameters out back to back so that training
+        can run them as one convolution (ops.ConvBnActPair)."""
+        return [(self.conv1, self.conv2)]
+
     def forward(self, x):
-        x_1 = self.conv1(x)
-        x_2 = self.conv2(x)
+        pair = sibling_pair_forward(self.conv1, self.conv2, x, self) if self.training else None
+        if pair is not None:
+            x_1, x_2 = pair
+        else:
+            x_1 = self.conv1(x)
+            x_2 = self.conv2(x)
         x_1 = self.m(x_1)
         return self.conv3(ops.cat([x_1, x_2]))
 

@@ -34,11 +34,16 @@ def test_flat_state_matches_stock_optimizer_and_ema():
     state = FlatTrainState(flat, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4, use_ema=True)
     s2 = FlatTrainStep(flat, state)
     assert state.total >= sum(p.numel() for p in flat.parameters())
-    for it in range(3):
-        l1 = s1(imgs, gts)
-        l2 = s2(imgs, gts)
-        torch.cuda.synchronize()
-        assert abs(float(l1["loss"]) - float(l2["loss"])) <= 2e-3 * abs(float(l1["loss"])), (it, float(l1["loss"]), float(l2["loss"]))
+    from cvpytorch_amd import yolo_blocks
+    yolo_blocks._PAIR_ENABLED = False   # same kernels on both sides: this test is about optimizer / EMA semantics (the fused
+    try:                                # sibling-conv path is compared with the separate layers in its own test below)
+        for it in range(3):
+            l1 = s1(imgs, gts)
+            l2 = s2(imgs, gts)
+            torch.cuda.synchronize()
+            assert abs(float(l1["loss"]) - float(l2["loss"])) <= 2e-3 * abs(float(l1["loss"])), (it, float(l1["loss"]), float(l2["loss"]))
+    finally:
+        yolo_blocks._PAIR_ENABLED = True
     sp, fp = dict(stock.named_parameters()), dict(flat.named_parameters())
     worst = max((rel(fp[n], sp[n]), n) for n in sp)
     assert worst[0] < 2e-3, worst
@@ -99,3 +104,74 @@ def test_hipgraph_replay_matches_eager():
     l1 = float(eb(imgs2, gts2)["loss"])
     l2 = float(ea(imgs2, gts2)["loss"])
     assert abs(l1 - l2) <= 2e-2 * abs(l2), (l1, l2)
+
+
+def test_csp_sibling_pair_equals_separate_layers():
+    """CSP conv1 / conv2 trained as ONE convolution (ops.ConvBnActPair, parameters adjacent in the flat arenas) must give the
+    results of the two separate layers: outputs, input gradient, every parameter gradient, BN running statistics."""
+    from cvpytorch_amd import ops, yolo_blocks
+    DEV = torch.device("cuda:0")
+    res = {}
+    for paired in (True, False):
+        torch.manual_seed(3)
+        m = yolo_blocks.CSPLayer(64, 64, n=1, act_cfg=dict(type="SiLU")).to(DEV).train()
+        state = FlatTrainState(m, use_ema=paired)          # the EMA copy must follow the paired arena order too
+        state.zero_grad()
+        yolo_blocks._PAIR_ENABLED = paired
+        try:
+            x = torch.randn(4, 64, 24, 20, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            calls = []
+            orig = ops.conv_bn_act_pair
+            ops.conv_bn_act_pair = lambda *a: (calls.append(1), orig(*a))[1]
+            try:
+                out = m(x)
+            finally:
+                ops.conv_bn_act_pair = orig
+            assert len(calls) == (1 if paired else 0)
+            cot = torch.randn(out.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5)).to(out.dtype)
+            (out.float() * cot.float()).sum().backward()
+            torch.cuda.synchronize()
+        finally:
+            yolo_blocks._PAIR_ENABLED = True
+        res[paired] = (out.float().cpu(), x.grad.float().cpu(), {n: p.grad.float().cpu().clone() for n, p in m.named_parameters()},
+                       {n: b.float().cpu().clone() for n, b in m.named_buffers() if b.dtype == torch.float32})
+        if paired:
+            for n, p in m.named_parameters():     # EMA views line up with the live parameters
+                assert torch.equal(dict(state.ema_model.named_parameters())[n].float().cpu(), p.detach().float().cpu()), n
+    a, b = res[True], res[False]
+    assert rel(a[0], b[0]) < 2e-3
+    assert rel(a[1], b[1]) < 1e-2
+    for n in a[2]:
+        assert rel(a[2][n], b[2][n]) < 1e-2, n
+    for n in a[3]:
+        assert rel(a[3][n], b[3][n]) < 1e-3, n
+
+
+def test_yolov5_step_with_sibling_pairs_matches_unpaired():
+    """whole model, one training step from identical weights: loss and the gradient arena of the paired run agree with the
+    unpaired run (bf16 noise only: the fused convolution sums the BN statistics and split-K partials in a different order)."""
+    from cvpytorch_amd import yolo_blocks
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    base = yolov5.YOLOv5(80, "s", max_targets=64, fused_loss=True).to(dev).train()
+    imgs, targets = synthetic_detection_batch(4, 128, seed=9, max_boxes=8, device=dev)
+    gts = yolov5.targets_to_tensor(targets, 64, dev)
+    out = {}
+    for paired in (True, False):
+        m = copy.deepcopy(base)
+        state = FlatTrainState(m, use_ema=False)
+        state.zero_grad()
+        yolo_blocks._PAIR_ENABLED = paired
+        try:
+            losses = m(imgs, gts, "train")
+            losses["loss"].backward()
+            torch.cuda.synchronize()
+        finally:
+            yolo_blocks._PAIR_ENABLED = True
+        grads = {n: p.grad.detach().float().reshape(-1).clone() for n, p in m.named_parameters()}
+        out[paired] = (float(losses["loss"]), grads)
+    assert abs(out[True][0] - out[False][0]) <= 2e-3 * abs(out[False][0]), (out[True][0], out[False][0])
+    a = torch.cat([out[True][1][n] for n in sorted(out[True][1])]).double()
+    b = torch.cat([out[False][1][n] for n in sorted(out[False][1])]).double()
+    cos = float((a * b).sum() / (a.norm() * b.norm()))
+    assert cos > 0.98, cos
