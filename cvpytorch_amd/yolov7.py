@@ -22,6 +22,7 @@ from . import lib as L
 from . import ops
 from .bricks import bn_tick, sync_of  # noqa: E402
 from .bricks import HipBN, HipConv2d, HipConvBN, HipConvModule, HipMaxPool2d, HipSiLU
+from .yolo_blocks import sibling_pair_forward
 from .yolov5 import YOLOv5Loss, YOLOv5LossFused, targets_to_tensor, non_max_suppression
 
 ANCHORS = [[[1.50000, 2.00000], [2.37500, 4.50000], [5.00000, 3.50000]],
@@ -32,6 +33,13 @@ ANCHORS = [[[1.50000, 2.00000], [2.37500, 4.50000], [5.00000, 3.50000]],
 def _torch_default_conv_init(conv):
     conv.reset_parameters()
     conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+
+
+def _siblings(m1, m2, x, owner):
+    """two 1x1 Conv modules on the same input: one fused convolution while training on the flat arenas (yolo_blocks.
+    sibling_pair_forward), the two modules one after the other otherwise"""
+    pair = sibling_pair_forward(m1, m2, x, owner) if owner.training else None
+    return pair if pair is not None else (m1(x), m2(x))
 
 
 class Conv(HipConvModule):
@@ -67,9 +75,11 @@ class EELAN(nn.Module):
         self.conv4 = nn.Sequential(Conv(c2, c2, 3, 1), Conv(c2, c2, 3, 1))
         self.conv5 = Conv(c2 * 4, c3, 1, 1)
 
+    def hip_sibling_pairs(self):
+        return [(self.conv1, self.conv2)]
+
     def forward(self, x):
-        x1 = self.conv1(x)
-        x2 = self.conv2(x)
+        x1, x2 = _siblings(self.conv1, self.conv2, x, self)
         x3 = self.conv3(x2)
         x4 = self.conv4(x3)
         return self.conv5(ops.cat([x1, x2, x3, x4]))
@@ -98,9 +108,11 @@ class FeatureFusion(nn.Module):
         self.conv6 = Conv(mid, mid, 3, 1)
         self.conv7 = Conv(c2 * 4, c2, 1, 1)
 
+    def hip_sibling_pairs(self):
+        return [(self.conv1, self.conv2)]
+
     def forward(self, x):
-        x1 = self.conv1(x)
-        x2 = self.conv2(x)
+        x1, x2 = _siblings(self.conv1, self.conv2, x, self)
         x3 = self.conv3(x2)
         x4 = self.conv4(x3)
         x5 = self.conv4(x4)
@@ -121,10 +133,14 @@ class SPPCSPC(nn.Module):
         self.cv6 = Conv(c_, c_, 3, 1)
         self.cv7 = Conv(2 * c_, c2, 1, 1)
 
+    def hip_sibling_pairs(self):
+        return [(self.cv1, self.cv2)]
+
     def forward(self, x):
-        x1 = self.cv4(self.cv3(self.cv1(x)))
+        a, b = _siblings(self.cv1, self.cv2, x, self)
+        x1 = self.cv4(self.cv3(a))
         y1 = self.cv6(self.cv5(ops.cat([x1] + [m(x1) for m in self.m])))
-        return self.cv7(ops.cat([y1, self.cv2(x)]))
+        return self.cv7(ops.cat([y1, b]))
 
 
 class RepConv(nn.Module):
