@@ -28,6 +28,7 @@ from . import lib as L
 from . import ops
 from .train import build_param_groups
 
+_PREP_PLAN = __import__("os").environ.get("CVHIP_PREP_PLAN", "1") != "0"
 _ALIGN = 8  # floats (32 B): keeps every parameter 16-byte aligned for the vectorised packers
 
 
@@ -110,6 +111,7 @@ class FlatTrainState:
             if isinstance(m, torch.nn.BatchNorm2d) and m.track_running_stats and m.num_batches_tracked is not None:
                 m._nbt_deferred = True
                 self._nbt.append(m.num_batches_tracked)
+        self.prep_plan = None
         self.lr_scale = 1.0
         self.dyn = torch.tensor([0.0, 1.0], dtype=torch.float32, device=dev)  # {ema_decay, lr_scale}, read by the kernels
         self._dyn_host = torch.zeros((256, 2), dtype=torch.float32).pin_memory()
@@ -263,6 +265,22 @@ class FlatTrainState:
             torch._foreach_add_(self._nbt, 1)
         self.zero_grad()
 
+    def prepare_weights(self):
+        """Batched re-pack of every conv layer's bf16 operand images (ops.PrepPlan: one launch instead of ~2 per layer). The plan
+        is built once the layers have been through one ordinary step (their image buffers exist at fixed addresses); weights
+        whose version counter moved (load_state_dict, manual edits) simply fall back to the per-layer path."""
+        if not _PREP_PLAN:
+            return
+        plan = self.prep_plan
+        if plan is None or not plan.valid():
+            states = [s for s in ops.conv_states_of(self.model) if s.w_fprop is not None and s.rec is not None]
+            if not states:
+                return  # first step: nothing prepared yet (layers that never ran keep the per-layer path)
+            if torch.cuda.is_current_stream_capturing():
+                return  # never build (host->device copy) inside a capture
+            plan = self.prep_plan = ops.PrepPlan(states)
+        plan.run()
+
     def post_step(self):
         self.steps += 1
         ops.bump_weights_epoch()  # parameters changed behind torch's version counters
@@ -309,6 +327,7 @@ class FlatTrainStep:
             self.eager_tail = False
 
     def _eager(self, imgs, targets):
+        self.state.prepare_weights()
         losses = self.model(imgs, targets, "train")
         losses["loss"].backward()
         self.state.step_kernels()
@@ -339,6 +358,7 @@ class FlatTrainStep:
             # the loss is libcvhip kernels too (no torch autograd ops): the whole step is ONE graph
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                st.prepare_weights()
                 _, feats = m.forward_features(self.static_imgs)
                 losses = m.loss_from_features(feats, self.static_targets)
                 losses["loss"].backward()
@@ -350,6 +370,7 @@ class FlatTrainStep:
             return
         g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1, pool=pool, capture_error_mode="thread_local"):
+            st.prepare_weights()
             _, feats = m.forward_features(self.static_imgs)
         self.feats = list(feats)
         self.g_feats = [torch.zeros_like(f) for f in self.feats]

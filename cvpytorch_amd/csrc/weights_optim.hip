@@ -3,6 +3,8 @@
 //
 // Reference: autocast's per-forward weight cast (trainer.py:179-184), torch.optim.SGD
 // (src/optimizers/__init__.py:60-68) and ModelEMA.update (src/utils/ema.py:30-39).
+#include <string.h>
+
 #include "common.h"
 #include "conv_plan.h"
 
@@ -67,6 +69,82 @@ __global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* __restrict
     const int i = tap / cl.TS, j = tap - i * cl.TS;
     const int r = cl.r0 + i * cl.r_step, s = cl.s0 + j * cl.s_step;
     dst[cl.w_off + idx] = (k < p.Kv && c < p.Cv) ? (bf16_t)master[(((int64_t)k * p.R + r) * p.S + s) * p.Cv + c] : (bf16_t)0.f;
+  }
+}
+
+// ---- batched operand preparation ------------------------------------------------------------------------
+// One launch packs the bf16 fprop AND dgrad images of every conv layer of a model (a training step otherwise pays one cast
+// and one pack launch per layer: ~115 sub-5-us kernels on the step's critical path for YOLOv5-s). The table lives in device
+// memory (built once by cvhip_prep_plan_build from the layers' descriptors and fixed operand addresses); block -> item by
+// binary search over the items' first-block indices.
+struct PrepClass {
+  int TR, TS, r0, r_step, s0, s_step;
+  int64_t w_off, w_end;
+};
+struct PrepItem {
+  const float* master;
+  bf16_t* wf;
+  bf16_t* wd;
+  int K, R, S, C, Kv, Cv;
+  int ncls, blk_begin, nblk_f, nblk_d;
+  PrepClass cls[kMaxClasses];
+};
+constexpr int kPrepFpropPerBlock = 2048, kPrepDgradPerBlock = 1024;
+
+__global__ __launch_bounds__(256) void prep_all_kernel(const PrepItem* __restrict__ items, int n_items) {
+  int lo = 0, hi = n_items - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)blockIdx.x >= items[mid].blk_begin) lo = mid;
+    else hi = mid - 1;
+  }
+  const PrepItem& it = items[lo];
+  int b = blockIdx.x - it.blk_begin;
+  const int K = it.K, C = it.C, T = it.R * it.S, Kv = it.Kv, Cv = it.Cv;
+  const int64_t n = (int64_t)K * T * C;
+  const float* __restrict__ src = it.master;
+  if (b < it.nblk_f) {
+    bf16_t* __restrict__ dst = it.wf;
+    const int64_t e0 = (int64_t)b * kPrepFpropPerBlock + threadIdx.x * 8;
+    if (e0 >= n) return;
+    if (Kv == K && Cv == C && e0 + 8 <= n && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0) {
+      const float4 a = reinterpret_cast<const float4*>(src + e0)[0];
+      const float4 c = reinterpret_cast<const float4*>(src + e0)[1];
+      uint4 u;
+      u.x = pack2(a.x, a.y);
+      u.y = pack2(a.z, a.w);
+      u.z = pack2(c.x, c.y);
+      u.w = pack2(c.z, c.w);
+      *reinterpret_cast<uint4*>(dst + e0) = u;
+    } else {
+      for (int64_t i = e0; i < e0 + 8 && i < n; ++i) {
+        const int c = (int)(i % C);
+        const int64_t kt = i / C;
+        const int t = (int)(kt % T);
+        const int k = (int)(kt / T);
+        dst[i] = (k < Kv && c < Cv) ? (bf16_t)src[((int64_t)k * T + t) * Cv + c] : (bf16_t)0.f;
+      }
+    }
+    return;
+  }
+  b -= it.nblk_f;
+  bf16_t* __restrict__ dst = it.wd;
+#pragma unroll
+  for (int j = 0; j < kPrepDgradPerBlock / 256; ++j) {
+    const int64_t g = (int64_t)b * kPrepDgradPerBlock + j * 256 + threadIdx.x;  // element of the concatenated class images
+    if (g >= n) break;
+    int q = 0;
+    while (q + 1 < it.ncls && g >= it.cls[q].w_end) ++q;
+    const PrepClass& cl = it.cls[q];
+    const int64_t idx = g - cl.w_off;
+    const int Tq = cl.TR * cl.TS;
+    const int k = (int)(idx % K);
+    const int64_t ct = idx / K;
+    const int tap = (int)(ct % Tq);
+    const int c = (int)(ct / Tq);
+    const int i = tap / cl.TS, jj = tap - i * cl.TS;
+    const int r = cl.r0 + i * cl.r_step, s2 = cl.s0 + jj * cl.s_step;
+    dst[g] = (k < Kv && c < Cv) ? (bf16_t)src[(((int64_t)k * it.R + r) * it.S + s2) * Cv + c] : (bf16_t)0.f;
   }
 }
 
@@ -174,6 +252,63 @@ int cvhip_sgd_nesterov_ema(float* param, const float* grad, float* momentum_buf,
   hipLaunchKernelGGL(sgd_ema_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, param, grad, momentum_buf, ema, n,
                      seg_bounds, seg_lr, seg_wd, nseg, momentum, nesterov, first_step, ema_decay, grad_scale, dyn_decay_lrscale);
   return check_launch("sgd_ema_kernel");
+}
+
+int cvhip_prep_plan_item_bytes(void) { return (int)sizeof(PrepItem); }
+
+int cvhip_prep_plan_build(const cvhip_prep_entry* entries, int32_t n, void* table_host, int32_t* total_blocks) {
+  if (!entries || n <= 0 || !table_host || !total_blocks) return CVHIP_ERR_INVALID;
+  PrepItem* out = reinterpret_cast<PrepItem*>(table_host);
+  int blk = 0;
+  for (int e = 0; e < n; ++e) {
+    const cvhip_conv_desc* d = &entries[e].desc;
+    int st = validate_dense_desc(d);
+    if (st) return st;
+    if (!entries[e].master || !entries[e].w_fprop) return CVHIP_ERR_INVALID;
+    if ((((uintptr_t)entries[e].w_fprop) & 15) || (((uintptr_t)entries[e].w_dgrad) & 15)) return CVHIP_ERR_INVALID;
+    PrepItem& it = out[e];
+    memset(&it, 0, sizeof(it));
+    it.master = entries[e].master;
+    it.wf = (bf16_t*)entries[e].w_fprop;
+    it.wd = (bf16_t*)entries[e].w_dgrad;
+    it.K = d->K;
+    it.R = d->R;
+    it.S = d->S;
+    it.C = d->C;
+    it.Kv = d->k_valid > 0 ? d->k_valid : d->K;
+    it.Cv = d->c_valid > 0 ? d->c_valid : d->C;
+    const int64_t nel = (int64_t)d->K * d->R * d->S * d->C;
+    it.blk_begin = blk;
+    it.nblk_f = (int)cdiv64(nel, kPrepFpropPerBlock);
+    it.nblk_d = 0;
+    if (it.wd) {
+      IgemmParams ip;
+      const int ncls = plan_dgrad(d, &ip);
+      if (ncls < 0) return ncls;
+      it.ncls = ncls;
+      int64_t end = 0;
+      for (int q = 0; q < ncls; ++q) {
+        const IgemmClass& c = ip.cls[q];
+        PrepClass& pc = it.cls[q];
+        pc.TR = c.TR; pc.TS = c.TS; pc.r0 = c.r0; pc.r_step = c.r_step; pc.s0 = c.s0; pc.s_step = c.s_step;
+        pc.w_off = c.w_off;
+        pc.w_end = c.w_off + (int64_t)d->C * c.TR * c.TS * d->K;
+        if (pc.w_off != end) return CVHIP_ERR_UNSUPPORTED;  // the class images must tile [0, K*R*S*C) in order
+        end = pc.w_end;
+      }
+      if (end != nel) return CVHIP_ERR_UNSUPPORTED;
+      it.nblk_d = (int)cdiv64(nel, kPrepDgradPerBlock);
+    }
+    blk += it.nblk_f + it.nblk_d;
+  }
+  *total_blocks = blk;
+  return CVHIP_OK;
+}
+
+int cvhip_prep_plan_run(const void* table_device, int32_t n, int32_t total_blocks, void* stream) {
+  if (!table_device || n <= 0 || total_blocks <= 0) return CVHIP_ERR_INVALID;
+  hipLaunchKernelGGL(prep_all_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const PrepItem*)table_device, n);
+  return check_launch("prep_all_kernel");
 }
 
 int cvhip_ema_update(float* ema, const float* src, int64_t n, float decay, const float* dyn_decay, void* stream) {

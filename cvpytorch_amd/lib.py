@@ -36,6 +36,11 @@ class ConvDesc(C.Structure):
         return tuple(getattr(self, n) for n, _ in self._fields_)
 
 
+class PrepEntry(C.Structure):
+    """cvhip_prep_entry (include/cvhip.h): one layer of a batched operand-preparation plan."""
+    _fields_ = [("desc", ConvDesc), ("master", C.c_void_p), ("w_fprop", C.c_void_p), ("w_dgrad", C.c_void_p)]
+
+
 class YoloLossDesc(C.Structure):
     """cvhip_yolo_loss_desc (include/cvhip.h)."""
     _fields_ = [(n, C.c_int32) for n in ("N", "A", "NO", "H", "W", "ld", "T")] + [("anchor_t", C.c_float), ("anchors", C.c_float * 16)]
@@ -63,6 +68,9 @@ SIGNATURES = {
     "cvhip_conv2d_dgrad_weight_elems": (_i64, [_dp]),
     "cvhip_conv2d_dgrad_plan": (_i32, [_dp, C.POINTER(_i32), _i32]),
     "cvhip_conv2d_prep_weights": (_i32, [_dp, _p, _p, _p, _p]),
+    "cvhip_prep_plan_item_bytes": (_i32, []),
+    "cvhip_prep_plan_build": (_i32, [_p, _i32, _p, C.POINTER(_i32)]),
+    "cvhip_prep_plan_run": (_i32, [_p, _i32, _i32, _p]),
     "cvhip_conv2d_fprop": (_i32, [_dp, _p, _p, _p, _p, _p, _p]),
     "cvhip_conv2d_dgrad": (_i32, [_dp, _p, _p, _p, _p]),
     "cvhip_conv2d_wgrad": (_i32, [_dp, _p, _p, _p, _i32, _p]),

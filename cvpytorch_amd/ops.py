@@ -225,28 +225,87 @@ class ConvState:
         self.key = None
         self.w_fprop = None
         self.w_dgrad = None
+        self.rec = None
 
     def prepare(self, weight, pdesc, need_dgrad, vkey):
         """`vkey` identifies the VALUE of the master weight (parameter identity/version; the optimizer epoch is
         added here because the fused optimizer updates parameters behind torch's version counters). Channel
-        padding (pdesc.k_valid / c_valid) is applied by the packer kernels: no torch ops are involved."""
+        padding (pdesc.k_valid / c_valid) is applied by the packer kernels: no torch ops are involved.
+        The image buffers are allocated once and re-used (fixed addresses: PrepPlan re-packs them in one batched launch)."""
         key = (vkey, _weights_epoch, pdesc.key())
         if self.key == key and self.w_fprop is not None and (self.w_dgrad is not None or not need_dgrad):
             return
         dev = weight.device
         master = _krsc_master(weight)
         lib = L.load()
-        self.w_fprop = torch.empty((pdesc.K, pdesc.R, pdesc.S, pdesc.C), dtype=BF16, device=dev)
+        shape = (pdesc.K, pdesc.R, pdesc.S, pdesc.C)
+        if self.w_fprop is None or tuple(self.w_fprop.shape) != shape or self.w_fprop.device != dev:
+            self.w_fprop = torch.empty(shape, dtype=BF16, device=dev)
+            self.w_dgrad = None
         wd = None
         if need_dgrad:
             n = lib.cvhip_conv2d_dgrad_weight_elems(C.byref(pdesc))
             if n < 0:
                 L.check(int(n), "cvhip_conv2d_dgrad_weight_elems")
-            wd = torch.empty((max(int(n), 8),), dtype=BF16, device=dev)
+            n = max(int(n), 8)
+            wd = self.w_dgrad if (self.w_dgrad is not None and self.w_dgrad.numel() == n) else torch.empty((n,), dtype=BF16, device=dev)
         L.call("cvhip_conv2d_prep_weights", C.byref(pdesc), master.data_ptr(), self.w_fprop.data_ptr(), _ptr(wd), _stream())
         self._master_ref = master  # keep a relayout copy (if any) alive until the kernels have run
-        self.w_dgrad = wd
+        if wd is not None:
+            self.w_dgrad = wd
         self.key = key
+        # what PrepPlan needs to redo this preparation: only when the master is the parameter's own memory (no relayout copy)
+        self.rec = (master.data_ptr(), pdesc, vkey) if master.data_ptr() == weight.data_ptr() else None
+
+
+class PrepPlan:
+    """ONE launch (cvhip_prep_plan_run) re-packs the bf16 operand images of every ConvState in `states` from the fp32 masters —
+    instead of one cast + one pack launch per layer per step. Built after the states have been prepared once the ordinary way;
+    `run()` marks them fresh for the current optimizer epoch so the per-layer `prepare` calls become no-ops."""
+
+    def __init__(self, states):
+        lib = L.load()
+        self.states = [s for s in states if s.rec is not None and s.w_fprop is not None]
+        n = len(self.states)
+        self.n = n
+        if n == 0:
+            return
+        entries = (L.PrepEntry * n)()
+        self.ptrs = []
+        for e, s in zip(entries, self.states):
+            master, pdesc, _ = s.rec
+            C.memmove(C.byref(e.desc), C.byref(pdesc), C.sizeof(L.ConvDesc))
+            e.master, e.w_fprop = master, s.w_fprop.data_ptr()
+            e.w_dgrad = s.w_dgrad.data_ptr() if s.w_dgrad is not None else None
+            self.ptrs.append((master, e.w_fprop, e.w_dgrad))
+        item = lib.cvhip_prep_plan_item_bytes()
+        host = torch.zeros((n * item,), dtype=torch.uint8)
+        blocks = C.c_int32(0)
+        L.call("cvhip_prep_plan_build", C.cast(entries, C.c_void_p), n, host.data_ptr(), C.byref(blocks))
+        self.blocks = int(blocks.value)
+        self.table = host.to(self.states[0].w_fprop.device)
+
+    def valid(self):
+        return all(s.rec is not None and s.w_fprop is not None and (s.rec[0], s.w_fprop.data_ptr(), s.w_dgrad.data_ptr() if s.w_dgrad is not None else None) == p
+                   for s, p in zip(self.states, self.ptrs))
+
+    def run(self):
+        if self.n == 0:
+            return
+        L.call("cvhip_prep_plan_run", self.table.data_ptr(), self.n, self.blocks, _stream())
+        for s in self.states:
+            s.key = (s.rec[2], _weights_epoch, s.rec[1].key())
+
+
+def conv_states_of(model):
+    """every ConvState a model's layers own (HipConv2d._hip_state, the fused sibling-pair states)"""
+    out = []
+    for m in model.modules():
+        for name in ("_hip_state", "_hip_pair_state"):
+            s = m.__dict__.get(name)
+            if isinstance(s, ConvState):
+                out.append(s)
+    return out
 
 
 class ConvCfg:

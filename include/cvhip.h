@@ -107,6 +107,21 @@ int cvhip_conv2d_dgrad_plan(const cvhip_conv_desc* d, int32_t* out_classes, int 
 int cvhip_conv2d_prep_weights(const cvhip_conv_desc* d, const float* w_master_krsc,
                               void* w_fprop_bf16, void* w_dgrad_bf16, void* stream);
 
+/* Batched operand preparation (weights_optim.hip): ONE launch re-packs the bf16 fprop and dgrad images of many layers from
+ * their fp32 masters — what cvhip_conv2d_prep_weights does per layer (autocast's per-forward weight casts in the reference,
+ * trainer.py:179-184). `cvhip_prep_plan_build` fills a host table of `n` x cvhip_prep_plan_item_bytes() bytes from the entries
+ * (descriptors + fixed operand addresses; w_dgrad may be NULL) and returns the grid size; the caller copies the table to the
+ * device once and calls `cvhip_prep_plan_run` after every optimizer step. */
+typedef struct cvhip_prep_entry {
+  cvhip_conv_desc desc;
+  const float* master;
+  void* w_fprop;
+  void* w_dgrad;
+} cvhip_prep_entry;
+int cvhip_prep_plan_item_bytes(void);
+int cvhip_prep_plan_build(const cvhip_prep_entry* entries, int32_t n, void* table_host, int32_t* total_blocks);
+int cvhip_prep_plan_run(const void* table_device, int32_t n, int32_t total_blocks, void* stream);
+
 /* fprop: y = conv(x, w) (+ bias). If stats_partial != NULL the epilogue also emits per-M-tile
  * partial sums  stats_partial[tile][0][k] = sum_m acc, [tile][1][k] = sum_m acc^2  (fp32
  * accumulators, before rounding to bf16) for training-mode BatchNorm; `bias` must be NULL then. */

@@ -175,3 +175,42 @@ def test_yolov5_step_with_sibling_pairs_matches_unpaired():
     b = torch.cat([out[False][1][n] for n in sorted(out[False][1])]).double()
     cos = float((a * b).sum() / (a.norm() * b.norm()))
     assert cos > 0.98, cos
+
+
+def test_prep_plan_equals_per_layer_preparation():
+    """ops.PrepPlan (one batched launch) must write exactly the bf16 fprop / dgrad operand images the per-layer packers write:
+    stem with padded input channels, stride-2 3x3 (4 parity classes), 255-channel head (padded K), fused sibling pairs."""
+    from cvpytorch_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    m = yolov5.YOLOv5(80, "n", max_targets=64, fused_loss=True).to(dev).train()
+    imgs, targets = synthetic_detection_batch(2, 64, seed=3, max_boxes=4, device=dev)
+    gts = yolov5.targets_to_tensor(targets, 64, dev)
+    state = FlatTrainState(m, use_ema=False)
+    step = FlatTrainStep(m, state)
+    import cvpytorch_amd.arena as arena_mod
+    arena_mod._PREP_PLAN = False
+    try:
+        step(imgs, gts)                      # per-layer preparation; the optimizer then changes every weight
+        m(imgs, gts, "train")                # per-layer preparation of the NEW weights (epoch moved)
+        torch.cuda.synchronize()
+    finally:
+        arena_mod._PREP_PLAN = True
+    states = [s for s in ops.conv_states_of(m) if s.w_fprop is not None]   # (the paired layers' own states never ran)
+    assert len(states) >= 50 and any(s.w_dgrad is None for s in states) and any("_hip_pair_state" in mm.__dict__ for mm in m.modules())
+    want = [(s.w_fprop.view(torch.int16).clone(), None if s.w_dgrad is None else s.w_dgrad.view(torch.int16).clone()) for s in states]
+    for s in states:
+        s.w_fprop.view(torch.int16).fill_(0x7fc0)
+        if s.w_dgrad is not None:
+            s.w_dgrad.view(torch.int16).fill_(0x7fc0)
+    plan = ops.PrepPlan(states)
+    assert plan.n == len(states) and plan.valid()
+    plan.run()
+    torch.cuda.synchronize()
+    for s, (wf, wd) in zip(states, want):
+        assert torch.equal(s.w_fprop.view(torch.int16), wf), tuple(s.w_fprop.shape)
+        if wd is not None:
+            assert torch.equal(s.w_dgrad.view(torch.int16)[:wd.numel()], wd), tuple(s.w_fprop.shape)
+    # and the training step uses it: no per-layer packer runs once the plan exists (keys are fresh after run())
+    state.prepare_weights()
+    assert state.prep_plan is not None and all(s.key[1] == ops._weights_epoch for s in states)
