@@ -236,11 +236,23 @@ int cvhip_conv2d_fprop_stats_rows(const cvhip_conv_desc* d) {
   if (st) return st;
   const int P = conv_out_dim(d->H, d->pad_h, d->dil_h, d->R, d->stride_h);
   const int Q = conv_out_dim(d->W, d->pad_w, d->dil_w, d->S, d->stride_w);
+  {
+    const int blocks = stem_blocks(d->C, d->x_ld, d->K, d->R, d->S, d->stride_h, d->stride_w, d->dil_h, d->dil_w, d->N, P, Q);
+    if (blocks > 0) return blocks;  // same decision as launch_igemm
+  }
   if (d->R == 1 && d->S == 1 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 0 && d->pad_w == 0 && (d->x_ld & 7) == 0) {
     const int blocks = stream1x1_blocks(d->K, d->C, (int64_t)d->N * P * Q, true);  // same decision as launch_igemm
     if (blocks > 0) return blocks;
   }
   return cdiv(d->N * P * Q, igemm_block_m(d->K, (int64_t)d->N * P * Q, d->R * d->S * d->C));
+}
+
+int cvhip_conv_stem_blocks(const cvhip_conv_desc* d) {
+  int st = validate_dense_desc(d);
+  if (st) return st;
+  const int P = conv_out_dim(d->H, d->pad_h, d->dil_h, d->R, d->stride_h);
+  const int Q = conv_out_dim(d->W, d->pad_w, d->dil_w, d->S, d->stride_w);
+  return stem_blocks(d->C, d->x_ld, d->K, d->R, d->S, d->stride_h, d->stride_w, d->dil_h, d->dil_w, d->N, P, Q);
 }
 
 int cvhip_conv1x1_stream_blocks(int nout, int cin, int64_t m, int with_stats) { return stream1x1_blocks(nout, cin, m, with_stats != 0); }

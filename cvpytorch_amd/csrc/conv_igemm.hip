@@ -614,6 +614,8 @@ int igemm_block_m(int Nout, int64_t M, int Ktot) {
 }
 
 int launch_igemm(IgemmParams& p, hipStream_t stream) {
+  const int s0 = try_launch_stem(p, stream);  // 8-channel image stem: direct convolution from an LDS patch (conv_stem.hip)
+  if (s0 >= 0) return s0;
   const int s1 = try_launch_stream1x1(p, stream);  // 1x1 / stride 1: persistent streaming kernel (conv1x1_stream.hip)
   if (s1 >= 0) return s1;
   if (narrow128() && !use_v1()) {

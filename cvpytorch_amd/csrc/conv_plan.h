@@ -92,5 +92,8 @@ int launch_igemm(IgemmParams& p, hipStream_t stream);
 // conv1x1_stream.hip: grid size of the streaming 1x1 kernel (0 = the general kernel runs) and its launcher (-1 = not taken)
 int stream1x1_blocks(int Nout, int Cin, int64_t M, bool stats);
 int try_launch_stream1x1(const IgemmParams& p, hipStream_t stream);
+// conv_stem.hip: direct convolution for 8-channel image stems (grid size, 0 = not taken; launcher, -1 = not taken)
+int stem_blocks(int C, int x_ld, int K, int R, int S, int sh, int sw, int dh, int dw, int N, int OH, int OW);
+int try_launch_stem(const IgemmParams& p, hipStream_t stream);
 
 }  // namespace cvhip

@@ -1,0 +1,299 @@
+// conv_stem.hip — direct convolution for image stems on gfx950: 8 (zero-padded 3) input channels, <= 32 output channels.
+//
+//   Y[n][oy][ox][k] = sum_{r,s,c} X[n][oy*st - pad + r][ox*st - pad + s][c] * W[k][r][s][c]
+//
+// The implicit-GEMM kernel materialises the im2col rows in LDS: for the YOLOv5 stem (k6 s2, 640x640, batch 64) that is 9x the
+// input (3.8 GB of global->LDS traffic per launch; the kernel runs at 1.4 TB/s of algorithmic traffic, 3.4x off the HBM
+// bound). With 8 channels one tap of one pixel is exactly one 16-byte vector = one lane's 8 reduction elements of a
+// v_mfma_f32_16x16x32_bf16 fragment, so the MFMA A fragments can be read STRAIGHT from an input patch held in LDS:
+//   * block = 4 waves; tile = 4 output rows x 64 output columns x all K; the (3*st+R) x (63*st+S) input patch is loaded once
+//     with coalesced 16-byte loads (zero outside the image), register-prefetched one tile ahead, LDS double-buffered: one
+//     barrier per tile, blocks are persistent;
+//   * lane (r, g) of k-step j reads tap 4j+g of output pixel ox = 16b + r: one ds_read_b128; stride-2 columns are stored
+//     de-interleaved (even columns, then odd) so the 16 lanes of a fragment hit consecutive 16-byte slots (no bank conflicts);
+//   * the whole weight tensor (<= 32 x 49 x 8) sits in registers as B fragments, rows permuted so that a lane ends up with 8
+//     consecutive output channels of its pixel (one 16-byte store); BatchNorm partial sums stay in registers across tiles.
+// Replaces aten::convolution for the first layer (reference src/models/backbones/yolov5_csp_darknet.py:83-91 stem,
+// yolov7 backbone stem) — same C-ABI entry (cvhip_conv2d_fprop), picked by launch_igemm.
+#include <stdlib.h>
+
+#include "common.h"
+#include "conv_plan.h"
+
+namespace cvhip {
+
+constexpr int kStemTH = 4, kStemTW = 64;
+constexpr int kStemMaxPH = 3 * 2 + 7, kStemMaxPW = 63 * 2 + 7 + 1;  // R, S <= 7, stride <= 2 (PW rounded up to even)
+constexpr int kStemPatchBytes = kStemMaxPH * kStemMaxPW * 16;
+constexpr int kStemMaxSteps = 13;  // ceil(49 / 4)
+constexpr int kStemBlocks = 768;   // persistent grid (3 blocks per CU by LDS)
+
+struct StemParams {
+  const bf16_t* x;
+  const bf16_t* w;  // [K][R*S*8] bf16
+  bf16_t* y;
+  const float* bias;
+  float* stats;
+  int bias_n;
+  int NB, IH, IW, OH, OW, K, y_ld, R, S, pad_h, pad_w;
+  int tiles_x, tiles_y, ntiles;
+};
+
+template <int ST, int NSTEP, bool STATS>
+__global__ __launch_bounds__(256, 2) void stem_fprop_kernel(const StemParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kStemPatchBytes];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int R = p.R, S = p.S, taps = R * S;
+  const int PH = (kStemTH - 1) * ST + R;
+  const int PW = ((kStemTW - 1) * ST + S + 1) & ~1;  // even, so the de-interleaved halves are equal
+  const int HALF = PW >> 1;
+  const int nchunk = PH * PW;
+
+  // ---- B fragments (weights) in registers: LDS-free, loaded once. Row i of fragment a <-> channel (i>>2)*8 + a*4 + (i&3)
+  bf16x8 wb[2][NSTEP];
+  int aoff[NSTEP];
+  {
+    const int i = lane & 15;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int ch = (i >> 2) * 8 + a * 4 + (i & 3);
+#pragma unroll
+      for (int j = 0; j < NSTEP; ++j) {
+        const int tap = j * 4 + g;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ch < p.K && tap < taps) v = *reinterpret_cast<const bf16x8*>(p.w + ((int64_t)ch * taps + tap) * 8);
+        wb[a][j] = v;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NSTEP; ++j) {
+      int tap = j * 4 + g;
+      if (tap >= taps) tap = taps - 1;  // weight fragment is zero there; any finite operand will do
+      const int tr = tap / S, ts = tap - tr * S;
+      // patch slot of column c: ST == 2: (c & 1) * HALF + (c >> 1); ST == 1: c.   column of (ox, ts) = ox * ST + ts
+      aoff[j] = (tr * PW + (ST == 2 ? (ts & 1) * HALF + (ts >> 1) : ts)) * 16;
+    }
+  }
+
+  // ---- patch loader: thread owns chunks t, t+256, ... of the PH x PW patch (row-major, 16 B per pixel); their patch
+  // coordinates and LDS slots do not depend on the tile
+  constexpr int LD_IT = (kStemMaxPH * kStemMaxPW + 255) / 256;
+  uint4 pre[LD_IT];
+  int pk[LD_IT], loff[LD_IT];
+#pragma unroll
+  for (int i = 0; i < LD_IT; ++i) {
+    const int q = t + i * 256;
+    const int pr = q / PW, pc = q - pr * PW;
+    pk[i] = q < nchunk ? ((pr << 16) | pc) : -1;
+    loff[i] = (pr * PW + (ST == 2 ? (pc & 1) * HALF + (pc >> 1) : pc)) * 16;
+  }
+  auto tile_origin = [&](int tile, int& n, int& oy0, int& ox0) {
+    const int tx = tile % p.tiles_x;
+    const int rest = tile / p.tiles_x;
+    const int ty = rest % p.tiles_y;
+    n = rest / p.tiles_y;
+    oy0 = ty * kStemTH;
+    ox0 = tx * kStemTW;
+  };
+  auto gload = [&](int tile) {
+    int n, oy0, ox0;
+    tile_origin(tile, n, oy0, ox0);
+    const int iy0 = oy0 * ST - p.pad_h, ix0 = ox0 * ST - p.pad_w;
+    const bf16_t* img = p.x + (int64_t)n * p.IH * p.IW * 8;
+#pragma unroll
+    for (int i = 0; i < LD_IT; ++i) {
+      const int iy = iy0 + (pk[i] >> 16), ix = ix0 + (pk[i] & 0xffff);
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (pk[i] >= 0 && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW)
+        v = *reinterpret_cast<const uint4*>(img + (int64_t)(iy * p.IW + ix) * 8);
+      pre[i] = v;
+    }
+  };
+  auto lstore = [&](int buf) {
+    unsigned char* dst = smem + buf * kStemPatchBytes;
+#pragma unroll
+    for (int i = 0; i < LD_IT; ++i)
+      if (pk[i] >= 0) *reinterpret_cast<uint4*>(dst + loff[i]) = pre[i];
+  };
+
+  float s1[2][4], s2[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s1[a][q] = s2[a][q] = 0.f;
+
+  int tile = blockIdx.x;
+  if (tile < p.ntiles) {
+    gload(tile);
+    lstore(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (; tile < p.ntiles; tile += gridDim.x) {
+    const int nxt = tile + gridDim.x;
+    if (nxt < p.ntiles) gload(nxt);
+
+    // ---- compute: wave = output row of the tile, 4 fragments of 16 output columns
+    const unsigned char* base = smem + cur * kStemPatchBytes + ((wave * ST) * PW + r) * 16;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NSTEP; ++j) {
+      bf16x8 xa[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) xa[b] = *reinterpret_cast<const bf16x8*>(base + aoff[j] + b * 16 * 16);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[a][j], xa[b], acc[a][b], 0, 0, 0);
+    }
+
+    // ---- epilogue: lane (r, g) holds channels g*8 .. g*8+7 of pixel (oy, ox0 + 16 b + r)
+    int n, oy0, ox0;
+    tile_origin(tile, n, oy0, ox0);
+    const int oy = oy0 + wave;
+    const int ch0 = g * 8;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int ox = ox0 + b * 16 + r;
+      const bool ok = oy < p.OH && ox < p.OW;
+      f32x8 v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v.v[q] = ok ? acc[0][b][q] : 0.f;
+        v.v[4 + q] = ok ? acc[1][b][q] : 0.f;
+      }
+      if constexpr (STATS) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          s1[0][q] += v.v[q];
+          s2[0][q] += v.v[q] * v.v[q];
+          s1[1][q] += v.v[4 + q];
+          s2[1][q] += v.v[4 + q] * v.v[4 + q];
+        }
+      }
+      if (ok && ch0 < p.K) {
+        if (p.bias) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (ch0 + q < p.bias_n) v.v[q] += p.bias[ch0 + q];
+        }
+        bf16_t* yrow = p.y + ((int64_t)(n * p.OH + oy) * p.OW + ox) * p.y_ld + ch0;
+        if (ch0 + 7 < p.K && (p.y_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0)) {
+          *reinterpret_cast<uint4*>(yrow) = pack8(v);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (ch0 + q < p.K) yrow[q] = (bf16_t)v.v[q];
+        }
+      }
+    }
+    if (nxt < p.ntiles) lstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  if constexpr (STATS) {
+    if (p.stats) {
+      float* red = reinterpret_cast<float*>(smem);  // [4 waves][32][2]; every wave passed the loop's final barrier
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float u1 = row16_sum(s1[a][q]), u2 = row16_sum(s2[a][q]);
+          if (r == 0) {
+            const int lc = g * 8 + a * 4 + q;
+            red[(wave * 32 + lc) * 2 + 0] = u1;
+            red[(wave * 32 + lc) * 2 + 1] = u2;
+          }
+        }
+      __syncthreads();
+      if (t < p.K) {
+        float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          u1 += red[(w * 32 + t) * 2 + 0];
+          u2 += red[(w * 32 + t) * 2 + 1];
+        }
+        float* dst = p.stats + (int64_t)blockIdx.x * 2 * p.K;
+        dst[t] = u1;
+        dst[p.K + t] = u2;
+      }
+    }
+  }
+}
+
+// ---- host side ----------------------------------------------------------------------------------
+
+static int stem_mode() {  // CVHIP_STEM: 0 = never, 1 = default
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CVHIP_STEM");
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+
+// grid size of the stem kernel for a descriptor-level problem, 0 = not taken. Pure arithmetic (also sizes the BN partial rows).
+int stem_blocks(int C, int x_ld, int K, int R, int S, int sh, int sw, int dh, int dw, int N, int OH, int OW) {
+  if (stem_mode() == 0) return 0;
+  if (C != 8 || x_ld != 8 || K > 32 || (K & 7) || R > 7 || S > 7 || sh != sw || (sh != 1 && sh != 2) || dh != 1 || dw != 1) return 0;
+  const int nstep = (R * S + 3) / 4;
+  if (nstep != 1 && nstep != 2 && nstep != 3 && nstep != 7 && nstep != 9 && nstep != 13) return 0;  // instantiated step counts
+  const int64_t tiles = (int64_t)N * cdiv(OH, kStemTH) * cdiv(OW, kStemTW);
+  if (tiles < 512 || tiles >= (1ll << 31)) return 0;  // small problems: the general kernel (and its tests) stay in charge
+  return (int)(tiles < kStemBlocks ? tiles : kStemBlocks);
+}
+
+template <int ST, bool STATS>
+static int launch_stem_steps(const StemParams& sp, int blocks, int nstep, hipStream_t stream) {
+#define CVHIP_STEM_CASE(NS)                                                                                        \
+  case NS:                                                                                                         \
+    hipLaunchKernelGGL((stem_fprop_kernel<ST, NS, STATS>), dim3(blocks), dim3(256), 0, stream, sp);                \
+    break;
+  switch (nstep) {
+    CVHIP_STEM_CASE(1)
+    CVHIP_STEM_CASE(2)
+    CVHIP_STEM_CASE(3)   // 3x3
+    CVHIP_STEM_CASE(7)   // 5x5
+    CVHIP_STEM_CASE(9)   // 6x6
+    CVHIP_STEM_CASE(13)  // 7x7
+    default: return -1;
+  }
+#undef CVHIP_STEM_CASE
+  return check_launch("stem_fprop_kernel");
+}
+
+// returns -1 when the problem is not taken (caller falls through to the general kernel)
+int try_launch_stem(const IgemmParams& p, hipStream_t stream) {
+  if (p.ncls != 1 || p.out_sh != 1 || p.out_sw != 1) return -1;
+  const IgemmClass& c = p.cls[0];
+  if (c.out_oh != 0 || c.out_ow != 0 || c.OHi != p.OH || c.OWi != p.OW || c.dh0 > 0 || c.dw0 > 0) return -1;
+  const int blocks = stem_blocks(p.Cin, p.x_ld, p.Nout, c.TR, c.TS, p.in_sh, p.in_sw, c.dh_step, c.dw_step, p.NB, p.OH, p.OW);
+  if (blocks <= 0 || (((uintptr_t)p.x) & 15) || (((uintptr_t)p.w) & 15)) return -1;
+  const int nstep = (c.TR * c.TS + 3) / 4;
+  StemParams sp;
+  sp.x = p.x;
+  sp.w = p.w;
+  sp.y = p.y;
+  sp.bias = p.bias;
+  sp.bias_n = p.bias_n;
+  sp.stats = p.stats;
+  sp.NB = p.NB; sp.IH = p.IH; sp.IW = p.IW; sp.OH = p.OH; sp.OW = p.OW;
+  sp.K = p.Nout; sp.y_ld = p.y_ld; sp.R = c.TR; sp.S = c.TS;
+  sp.pad_h = -c.dh0; sp.pad_w = -c.dw0;
+  sp.tiles_x = cdiv(p.OW, kStemTW);
+  sp.tiles_y = cdiv(p.OH, kStemTH);
+  sp.ntiles = p.NB * sp.tiles_x * sp.tiles_y;
+  int rc;
+  if (p.in_sh == 2) rc = p.stats ? launch_stem_steps<2, true>(sp, blocks, nstep, stream) : launch_stem_steps<2, false>(sp, blocks, nstep, stream);
+  else rc = p.stats ? launch_stem_steps<1, true>(sp, blocks, nstep, stream) : launch_stem_steps<1, false>(sp, blocks, nstep, stream);
+  return rc;
+}
+
+}  // namespace cvhip

@@ -510,7 +510,8 @@ class ConvBnAct(torch.autograd.Function):
                 if rows < 0:
                     L.check(rows, "cvhip_conv2d_fprop_stats_rows")
                 partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
-            _timed_call(_igemm_name(Kp, N * P * Q, R * S * Cc, _pointwise(R, S, cfg), x_ld, partial is not None), (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv2d_fprop", C.byref(desc), x.data_ptr(),
+            kname = "stem_fprop_kernel" if lib.cvhip_conv_stem_blocks(C.byref(desc)) > 0 else _igemm_name(Kp, N * P * Q, R * S * Cc, _pointwise(R, S, cfg), x_ld, partial is not None)
+            _timed_call(kname, (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv2d_fprop", C.byref(desc), x.data_ptr(),
                         cfg.state.w_fprop.data_ptr(), _ptr(b), y.data_ptr(), _ptr(partial), st)
         if train_bn:
             if partial is None:

@@ -94,6 +94,9 @@ int cvhip_conv2d_fprop_stats_rows(const cvhip_conv_desc* d);
  * unpadded pass with `nout` result channels, `cin` reduced channels and `m` pixel rows (`with_stats`: the pass also writes
  * BatchNorm partial sums); 0 = the general implicit-GEMM kernel runs (profiling labels / tests; pure host arithmetic). */
 int cvhip_conv1x1_stream_blocks(int nout, int cin, int64_t m, int with_stats);
+/* grid size of the direct stem kernel (conv_stem.hip: 8 input channels, <= 32 output channels, kernel <= 7x7, stride 1 or 2) that
+ * cvhip_conv2d_fprop picks for this descriptor; 0 = another kernel runs. */
+int cvhip_conv_stem_blocks(const cvhip_conv_desc* d);
 int64_t cvhip_conv2d_dgrad_weight_elems(const cvhip_conv_desc* d);
 /* per class: {TR, TS, r0, r_step, dh0, dh_step, s0, s_step, dw0, dw_step, w_offset(elems, 2 x int32 lo/hi)} = 12 int32 */
 #define CVHIP_DGRAD_CLASS_INTS 12

@@ -106,8 +106,24 @@ CONV_CASES = [
     (7, 128, 60, 60, 255, 1, 1, 1, 0, 1),
     (7, 24, 60, 60, 64, 1, 1, 1, 0, 1),
     (4, 256, 80, 80, 128, 1, 1, 1, 0, 1),
+    # 8-channel image stems with >= 512 4x64 output tiles: the direct patch kernel (conv_stem.hip) — k6 s2 (YOLOv5), k3 s1
+    # (YOLOv7), k7 s2 with 24 output channels; ragged tiles in both directions
+    (8, 8, 250, 250, 32, 6, 6, 2, 2, 1),
+    (5, 8, 150, 150, 32, 3, 3, 1, 1, 1),
+    (8, 8, 250, 250, 24, 7, 7, 2, 3, 1),
 ]
-STREAM_CASES = CONV_CASES[-5:]
+STREAM_CASES = CONV_CASES[-8:-3]
+STEM_CASES = CONV_CASES[-3:]
+
+
+def test_stem_cases_take_the_stem_kernel():
+    lib = L.load()
+    for N, Cc, H, W, K, R, S, s, p, d in STEM_CASES:
+        desc = ops.conv_desc(N, Cc, H, W, K, R, S, (s, s), (p, p), (d, d), 1, Cc, K)
+        assert lib.cvhip_conv_stem_blocks(C.byref(desc)) > 0
+        assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(desc)) == lib.cvhip_conv_stem_blocks(C.byref(desc))
+    small = ops.conv_desc(2, 8, 64, 64, 32, 6, 6, (2, 2), (2, 2), (1, 1), 1, 8, 32)
+    assert lib.cvhip_conv_stem_blocks(C.byref(small)) == 0
 
 
 def test_stream1x1_cases_take_the_streaming_kernel():
