@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const RedParams p) {
 // pre-pass folds them into kStage2Rows rows first, written to the scratch rows that every partial
 // buffer carries behind its payload (CVHIP_REDUCE_SCRATCH_ROWS). Deterministic (fixed partition).
 constexpr int kStage2Rows = CVHIP_REDUCE_SCRATCH_ROWS;
+constexpr int kDirectRows = 1024;  // up to here the 64-lane finalize kernels read the partial rows themselves
 
 __global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ in, int rows, int Wd, float* __restrict__ out) {
   __shared__ float red[4][64];
@@ -188,7 +189,7 @@ static int direct_rows() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("CVHIP_FINALIZE_DIRECT_ROWS");
-    v = e ? atoi(e) : kStage2Rows;
+    v = e ? atoi(e) : kDirectRows;
     if (v < kStage2Rows) v = kStage2Rows;
   }
   return v;
@@ -203,43 +204,46 @@ static const float* prereduce(const float* partial, int* rows, int Wd, hipStream
 }
 
 // ---- finalize kernels (one thread per channel) -----------------------------------------------------
-// 256 threads = 16 channels x 16 row-lanes; rows <= kStage2Rows after the pre-reduction, so every lane
-// sums <= 4 rows and the 16 lanes of a channel are folded through LDS (latency ~ one L2 round trip).
-__device__ __forceinline__ void fold16(const float* partial, int rows, int C, int c, int lane, double* s1, double* s2,
-                                       bool want2, double (*red)[16][17]) {
+// 256 threads = CPB channels x LPC row-lanes (LPC = 16: CPB = 16, for <= 64 partial rows; LPC = 64: CPB = 4, for up to
+// kDirectRows rows — every lane then sums <= 16 rows with independent loads, i.e. ~2 L2 round trips instead of a
+// rows_reduce_kernel launch + a finalize launch). The lanes of a channel are folded through LDS.
+template <int LPC>
+__device__ __forceinline__ void foldN(const float* partial, int rows, int C, int c, int lane, double* s1, double* s2, bool want2,
+                                      double (*red)[LPC][256 / LPC + 1]) {
   double a = 0.0, b = 0.0;
   if (c < C) {
     // 4 independent accumulation chains: the loads of a lane are independent, only the adds chain
     double a1 = 0.0, a2 = 0.0, a3 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
     int r = lane;
-    for (; r + 48 < rows; r += 64) {
+    for (; r + 3 * LPC < rows; r += 4 * LPC) {
       a += (double)partial[((int64_t)r * 2 + 0) * C + c];
-      a1 += (double)partial[((int64_t)(r + 16) * 2 + 0) * C + c];
-      a2 += (double)partial[((int64_t)(r + 32) * 2 + 0) * C + c];
-      a3 += (double)partial[((int64_t)(r + 48) * 2 + 0) * C + c];
+      a1 += (double)partial[((int64_t)(r + LPC) * 2 + 0) * C + c];
+      a2 += (double)partial[((int64_t)(r + 2 * LPC) * 2 + 0) * C + c];
+      a3 += (double)partial[((int64_t)(r + 3 * LPC) * 2 + 0) * C + c];
       if (want2) {
         b += (double)partial[((int64_t)r * 2 + 1) * C + c];
-        b1 += (double)partial[((int64_t)(r + 16) * 2 + 1) * C + c];
-        b2 += (double)partial[((int64_t)(r + 32) * 2 + 1) * C + c];
-        b3 += (double)partial[((int64_t)(r + 48) * 2 + 1) * C + c];
+        b1 += (double)partial[((int64_t)(r + LPC) * 2 + 1) * C + c];
+        b2 += (double)partial[((int64_t)(r + 2 * LPC) * 2 + 1) * C + c];
+        b3 += (double)partial[((int64_t)(r + 3 * LPC) * 2 + 1) * C + c];
       }
     }
-    for (; r < rows; r += 16) {
+    for (; r < rows; r += LPC) {
       a += (double)partial[((int64_t)r * 2 + 0) * C + c];
       if (want2) b += (double)partial[((int64_t)r * 2 + 1) * C + c];
     }
     a = (a + a1) + (a2 + a3);
     b = (b + b1) + (b2 + b3);
   }
-  const int cc = threadIdx.x & 15;
+  constexpr int CPB = 256 / LPC;
+  const int cc = threadIdx.x % CPB;
   red[0][lane][cc] = a;
   red[1][lane][cc] = b;
   __syncthreads();
   a = 0.0;
   b = 0.0;
   if (lane == 0) {
-#pragma unroll
-    for (int l = 0; l < 16; ++l) {
+#pragma unroll 16
+    for (int l = 0; l < LPC; ++l) {
       a += red[0][l][cc];
       b += red[1][l][cc];
     }
@@ -248,13 +252,15 @@ __device__ __forceinline__ void fold16(const float* partial, int rows, int C, in
   *s2 = b;
 }
 
+template <int LPC>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partial, int rows, int C, double count, const float* gamma,
                                                           const float* beta, float* rmean, float* rvar, float momentum, float eps,
                                                           float* mean, float* invstd, float* scale, float* shift) {
-  __shared__ double red[2][16][17];
-  const int c = blockIdx.x * 16 + (threadIdx.x & 15), lane = threadIdx.x >> 4;
+  constexpr int CPB = 256 / LPC;
+  __shared__ double red[2][LPC][CPB + 1];
+  const int c = blockIdx.x * CPB + (threadIdx.x % CPB), lane = threadIdx.x / CPB;
   double s1, s2;
-  fold16(partial, rows, C, c, lane, &s1, &s2, true, red);
+  foldN<LPC>(partial, rows, C, c, lane, &s1, &s2, true, red);
   if (lane != 0 || c >= C) return;
   const double m = s1 / count;
   double var = s2 / count - m * m;
@@ -285,12 +291,14 @@ __global__ void bn_eval_kernel(int C, const float* gamma, const float* beta, con
 
 // out0[c] = sum_r partial[r][0][c]; out1[c] = sum_r partial[r][1][c]; optionally acc0/acc1 += the same sums
 // (accumulate != 0 makes out0/out1 accumulate as well)
+template <int LPC>
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* partial, int rows, int C, float* out0, float* out1, int accumulate,
                                                            float* acc0, float* acc1) {
-  __shared__ double red[2][16][17];
-  const int c = blockIdx.x * 16 + (threadIdx.x & 15), lane = threadIdx.x >> 4;
+  constexpr int CPB = 256 / LPC;
+  __shared__ double red[2][LPC][CPB + 1];
+  const int c = blockIdx.x * CPB + (threadIdx.x % CPB), lane = threadIdx.x / CPB;
   double s1, s2;
-  fold16(partial, rows, C, c, lane, &s1, &s2, out1 != nullptr || acc1 != nullptr, red);
+  foldN<LPC>(partial, rows, C, c, lane, &s1, &s2, out1 != nullptr || acc1 != nullptr, red);
   if (lane != 0 || c >= C) return;
   if (out0) out0[c] = accumulate ? out0[c] + (float)s1 : (float)s1;
   if (out1) out1[c] = accumulate ? out1[c] + (float)s2 : (float)s2;
@@ -298,7 +306,6 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* partial,
   if (acc1) acc1[c] += (float)s2;
 }
 
-// ---- fused pre-reduction + finalize (rows > kStage2Rows) ------------------------------------------------------------------
 // One launch instead of rows_reduce_kernel + a finalize kernel (2 x ~4.7 us of dependent launch latency per BN layer and
 // pass: ~230 such pairs per YOLOv5-s step). Grid = (32-channel chunks, kStage2Rows row groups); every block folds its row
 // group of its chunk's 64 columns (32 sums + 32 second sums) into the scratch rows, and the LAST block of a chunk to
@@ -660,8 +667,12 @@ int cvhip_bn_finalize(const float* partial, int32_t rows, int32_t C, int64_t cou
     if (launch_fused_finalize(partial, rows, C, fp, (hipStream_t)stream)) return check_launch("rows_reduce_fin_kernel");
   }
   partial = prereduce(partial, &rows, 2 * C, (hipStream_t)stream);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, rows, C,
-                     (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+  if (rows > kStage2Rows)
+    hipLaunchKernelGGL(bn_finalize_kernel<64>, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partial, rows, C,
+                       (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+  else
+    hipLaunchKernelGGL(bn_finalize_kernel<16>, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, rows, C,
+                       (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
   return check_launch("bn_finalize_kernel");
 }
 
@@ -683,16 +694,24 @@ int cvhip_bn_bwd_finalize(const float* partial, int32_t rows, int32_t C, float* 
     if (launch_fused_finalize(partial, rows, C, fp, (hipStream_t)stream)) return check_launch("rows_reduce_fin_kernel");
   }
   partial = prereduce(partial, &rows, 2 * C, (hipStream_t)stream);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, rows, C,
-                     dbeta, dgamma, 0, acc_dbeta, acc_dgamma);
+  if (rows > kStage2Rows)
+    hipLaunchKernelGGL(sum_partials_kernel<64>, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partial, rows, C,
+                       dbeta, dgamma, 0, acc_dbeta, acc_dgamma);
+  else
+    hipLaunchKernelGGL(sum_partials_kernel<16>, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, rows, C,
+                       dbeta, dgamma, 0, acc_dbeta, acc_dgamma);
   return check_launch("sum_partials_kernel");
 }
 
 int cvhip_colsum_finalize(const float* partial, int32_t rows, int32_t C, float* out, int accumulate, void* stream) {
   if (!partial || rows <= 0 || C <= 0 || !out) return CVHIP_ERR_INVALID;
   partial = prereduce(partial, &rows, 2 * C, (hipStream_t)stream);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, rows, C,
-                     out, (float*)nullptr, accumulate, (float*)nullptr, (float*)nullptr);
+  if (rows > kStage2Rows)
+    hipLaunchKernelGGL(sum_partials_kernel<64>, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partial, rows, C,
+                       out, (float*)nullptr, accumulate, (float*)nullptr, (float*)nullptr);
+  else
+    hipLaunchKernelGGL(sum_partials_kernel<16>, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, rows, C,
+                       out, (float*)nullptr, accumulate, (float*)nullptr, (float*)nullptr);
   return check_launch("sum_partials_kernel");
 }
 

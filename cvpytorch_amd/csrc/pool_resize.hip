@@ -421,6 +421,19 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, bf16_
                                                            int Cfill, int focus) {
   const int OH = focus ? H / 2 : H, OW = focus ? W / 2 : W;
   const int64_t total = (int64_t)N * OH * OW;
+  if (!focus && C <= 8 && Cfill == 8 && ld == 8 && ((((uintptr_t)y) & 15) == 0)) {
+    // image stem: one pixel per thread — C coalesced plane reads, ONE 16-byte store (pad channels zero)
+    const int64_t HW = (int64_t)H * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+      const int64_t n = i / HW, hw = i - n * HW;
+      const float* src = x + n * C * HW + hw;
+      f32x8 v;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v.v[c] = c < C ? src[c * HW] : 0.f;
+      reinterpret_cast<uint4*>(y)[i] = pack8(v);
+    }
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int ow = (int)(i % OW);
     const int oh = (int)((i / OW) % OH);
