@@ -306,10 +306,23 @@ int launch_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float*
   static int tn_max = -1;
   if (tn_max < 0) {
     const char* e = getenv("CVHIP_WGRAD_TNMAX");
-    tn_max = e ? atoi(e) : 128;
+    tn_max = e ? atoi(e) : 0;
   }
-  if (d->K <= 32 || tn_max <= 32) return launch_wg<32, 32, 32>(p, stream);
-  if (d->K <= 64 || tn_max <= 64) return launch_wg<64, 32, 64>(p, stream);
+  // Out-channel tile. The fp32 atomic epilogue is 20-45 % of a launch for the small-M layers (gpurun conv_table with
+  // CVHIP_WGRAD_ABLATE=1): narrower tiles mean more (n, k) tiles, hence fewer pixel splits and fewer atomics per MFMA, at
+  // the price of more LDS fragment reads per MFMA. Per-shape A/B on the YOLOv5-s layers (CVHIP_WGRAD_TNMAX=32/64/128):
+  // and DeepLabv3+ R50 layers: memory-bound 1x1 layers of modest size (M*K*C <= 7.5e9: the 20x20..80x80 YOLO layers) want
+  // the 32-wide tile — the large ResNet 1x1 layers lose up to 2x with it; 3x3 layers with >= 256 outputs the 64-wide one.
+  int tn = d->K <= 32 ? 32 : d->K <= 64 ? 64 : 128;
+  if (tn_max > 0) {
+    if (tn > tn_max) tn = tn_max;
+  } else if (d->R == 1 && d->S == 1) {
+    if ((double)p.M * d->K * d->C <= 7.5e9) tn = 32;
+  } else if (d->K >= 256 && d->C <= 1024) {
+    tn = 64;
+  }
+  if (tn == 32) return launch_wg<32, 32, 32>(p, stream);
+  if (tn == 64) return launch_wg<64, 32, 64>(p, stream);
   return launch_wg<128, 64, 64>(p, stream);
 }
 

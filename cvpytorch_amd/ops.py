@@ -78,8 +78,15 @@ def _pointwise(R, S, cfg):
     return R == 1 and S == 1 and tuple(cfg.stride) == (1, 1) and tuple(cfg.pad) == (0, 0)
 
 
-def _wgrad_name(k):
-    return "wgrad_kernel<32,32,32>" if k <= 32 else ("wgrad_kernel<64,32,64>" if k <= 64 else "wgrad_kernel<128,64,64>")
+def _wgrad_name(k, r=3, s=3, c=0, m=0):
+    """label of the tile configuration launch_wgrad picks (conv_wgrad.hip)"""
+    tn = 32 if k <= 32 else 64 if k <= 64 else 128
+    if r == 1 and s == 1:
+        if float(m) * k * c <= 7.5e9:
+            tn = 32
+    elif k >= 256 and c <= 1024:
+        tn = 64
+    return {32: "wgrad_kernel<32,32,32>", 64: "wgrad_kernel<64,32,64>", 128: "wgrad_kernel<128,64,64>"}[tn]
 
 
 def _timed_call(kname, geom, fname, *args):
@@ -415,17 +422,17 @@ def _conv_grads(ctx, x, weight, dy, dy_ld, need_dx, need_dw, need_db):
                 _Side.keep.append((x, dy))
             elif not padded and direct_w:
                 # accumulate straight into the parameter's KRSC slot of the flat gradient arena
-                _timed_call(_wgrad_name(Kp), geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(),
+                _timed_call(_wgrad_name(Kp, R, S, Cc, N * P * Q), geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(),
                             cfg.gw.data_ptr(), 1, st)
             elif not padded:
                 # logical OIHW, KRSC (channels_last) memory: a fresh non-view tensor autograd can adopt as .grad
                 dw = torch.empty((K, Cc, R, S), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
-                _timed_call(_wgrad_name(Kp), geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(),
+                _timed_call(_wgrad_name(Kp, R, S, Cc, N * P * Q), geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(),
                             dw.data_ptr(), 0, st)
             else:
                 # padded problem: wgrad into a [Kp][R][S][Cc] scratch, then fold the valid block into the real gradient
                 tmp = torch.empty((Kp, R, S, Cc), dtype=torch.float32, device=dev)
-                _timed_call(_wgrad_name(Kp), geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(),
+                _timed_call(_wgrad_name(Kp, R, S, Cc, N * P * Q), geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(),
                             tmp.data_ptr(), 0, st)
                 if direct_w:
                     dst = cfg.gw

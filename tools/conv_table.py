@@ -1,4 +1,5 @@
-"""Dev tool: per-shape timing of every conv launch of one YOLOv5-s train step (eager, HIP events)."""
+"""Dev tool: per-shape timing of every conv launch of one train step (eager, HIP events): YOLOv5-s 640x640 bs64, or with
+MODEL=deeplab DeepLabv3+ R50 1024x512 bs16."""
 import sys, os, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -6,12 +7,21 @@ from cvpytorch_amd import yolov5, ops
 from cvpytorch_amd.arena import FlatTrainState, FlatTrainStep
 from cvpytorch_amd.data import synthetic_detection_batch
 dev = torch.device("cuda:0")
-B = 64
-model = yolov5.YOLOv5(80, "s", max_targets=B * 20, fused_loss=True).to(dev).train()
-state = FlatTrainState(model, use_ema=False)
-step = FlatTrainStep(model, state)
-imgs, targets = synthetic_detection_batch(B, 640, device=dev)
-gts = yolov5.targets_to_tensor(targets, B * 20, dev)
+if os.environ.get("MODEL") == "deeplab":
+    from cvpytorch_amd import deeplab
+    from cvpytorch_amd.data import synthetic_segmentation_batch
+    B = 16
+    model = deeplab.EncoderDecoder(19, output_stride=32).to(dev).train()
+    state = FlatTrainState(model, lr=0.01, momentum=0.9, nesterov=True, weight_decay=5e-4, backbone_lr=0.001, use_ema=False)
+    step = FlatTrainStep(model, state)
+    imgs, gts = synthetic_segmentation_batch(B, (512, 1024), device=dev)
+else:
+    B = 64
+    model = yolov5.YOLOv5(80, "s", max_targets=B * 20, fused_loss=True).to(dev).train()
+    state = FlatTrainState(model, use_ema=False)
+    step = FlatTrainStep(model, state)
+    imgs, targets = synthetic_detection_batch(B, 640, device=dev)
+    gts = yolov5.targets_to_tensor(targets, B * 20, dev)
 for _ in range(3):
     step(imgs, gts)
 ops.TIMER.enabled = True
