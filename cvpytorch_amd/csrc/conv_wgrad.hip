@@ -26,7 +26,9 @@ struct WgradParams {
   int Nout, dy_ld;
   int Ktot, M;
   int n_tiles, k_tiles, m_per_split;
-  int ablate;  // CVHIP_WGRAD_ABLATE: 1 = skip the atomic epilogue (profiling only)
+  int ablate;  // CVHIP_WGRAD_ABLATE: 1 = skip the atomic epilogue, 2 = atomics into per-split scratch, 3 = plain stores into it (profiling only)
+  float* scratch;
+  int64_t split_stride;
 };
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256 * kWgGroups, kWgGroups == 1 ? 2 : 1) void wgrad
   constexpr int D_BYTES = 32 * D_ROWB, X_BYTES = 32 * X_ROWB;
 
   constexpr int GROUP_BYTES = 2 * D_BYTES + 2 * X_BYTES;
-  static_assert(kWgGroups == 1 || kWgGroups * GROUP_BYTES >= 4 * NF * KF * 4 * 64 * 4, "LDS must hold one group's accumulators for the fold");
+  static_assert(kWgGroups == 1 || kWgGroups * GROUP_BYTES >= (kWgGroups / 2) * 4 * NF * KF * 4 * 64 * 4, "LDS must hold half the groups' accumulators for the fold");
   __shared__ __attribute__((aligned(16))) unsigned char smem[kWgGroups * GROUP_BYTES];
   const int grp = threadIdx.x >> 8;
   unsigned char* const sD = smem + grp * GROUP_BYTES;
@@ -206,28 +208,40 @@ __global__ __launch_bounds__(256 * kWgGroups, kWgGroups == 1 ? 2 : 1) void wgrad
     __syncthreads();
   }
 
-  // fold group 1 into group 0 through LDS (the staging rings are dead after the final barrier of the loop)
-  if constexpr (kWgGroups == 2) {
+  // fold the other groups into group 0 through LDS (the staging rings are dead after the final barrier of the loop): a
+  // binary tree, each round the upper half of the live groups parks its accumulators and the lower half adds them
+  if constexpr (kWgGroups >= 2) {
     float* fold = reinterpret_cast<float*>(smem);
-    if (grp == 1) {
+    constexpr int ACC_FLOATS = 4 * NF * KF * 4 * 64;  // one group's accumulators
 #pragma unroll
-      for (int a = 0; a < NF; ++a)
+    for (int live = kWgGroups; live > 1; live >>= 1) {
+      const int hl = live >> 1;
+      if (grp >= hl && grp < live) {
+        float* dst = fold + (grp - hl) * ACC_FLOATS;
 #pragma unroll
-        for (int b = 0; b < KF; ++b)
+        for (int a = 0; a < NF; ++a)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) fold[((wave * NF * KF + a * KF + b) * 4 + r) * 64 + lane] = acc[a][b][r];
+          for (int b = 0; b < KF; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[((wave * NF * KF + a * KF + b) * 4 + r) * 64 + lane] = acc[a][b][r];
+      }
+      __syncthreads();
+      if (grp < hl) {
+        const float* src = fold + grp * ACC_FLOATS;
+#pragma unroll
+        for (int a = 0; a < NF; ++a)
+#pragma unroll
+          for (int b = 0; b < KF; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][b][r] += src[((wave * NF * KF + a * KF + b) * 4 + r) * 64 + lane];
+      }
+      if (live > 2) __syncthreads();  // the next round overwrites the parking area
     }
-    __syncthreads();
-    if (grp == 1) return;
-#pragma unroll
-    for (int a = 0; a < NF; ++a)
-#pragma unroll
-      for (int b = 0; b < KF; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[a][b][r] += fold[((wave * NF * KF + a * KF + b) * 4 + r) * 64 + lane];
+    if (grp != 0) return;
   }
   // epilogue: lane holds D[n = 4*(lane>>4)+r][kcol = lane&15]
   if (p.ablate == 1 && acc[0][0][0] != 12345.678f) return;
+  float* const dwp = p.ablate >= 2 ? p.scratch + (int64_t)split * p.split_stride : p.dw;
 #pragma unroll
   for (int a = 0; a < NF; ++a) {
 #pragma unroll
@@ -237,7 +251,10 @@ __global__ __launch_bounds__(256 * kWgGroups, kWgGroups == 1 ? 2 : 1) void wgrad
 #pragma unroll
       for (int b = 0; b < KF; ++b) {
         const int kc = k0 + wk * WK + b * 16 + (lane & 15);
-        if (kc < p.Ktot) unsafeAtomicAdd(p.dw + ((int64_t)n * p.Ktot + kc), acc[a][b][r]);
+        if (kc < p.Ktot) {
+          if (p.ablate == 3) dwp[(int64_t)n * p.Ktot + kc] = acc[a][b][r];
+          else unsafeAtomicAdd(dwp + ((int64_t)n * p.Ktot + kc), acc[a][b][r]);
+        }
       }
     }
   }
@@ -260,6 +277,14 @@ static int launch_wg(WgradParams& p, hipStream_t stream) {
     abl = a ? atoi(a) : 0;
   }
   p.ablate = abl;
+  p.scratch = nullptr;
+  p.split_stride = 0;
+  if (abl >= 2) {  // profiling only: 512 MB of scratch, one region per pixel split
+    static float* scratch = nullptr;
+    if (!scratch && hipMalloc(&scratch, 512ull << 20) != hipSuccess) return CVHIP_ERR_LAUNCH;
+    p.scratch = scratch;
+    p.split_stride = (int64_t)p.Nout * p.Ktot;
+  }
   // Two 4-wave groups per block (accumulators folded through LDS, half the atomics) when the atomic epilogue is a large
   // share of the block's work: few pixel rows per (n,k) tile. Otherwise 4-wave blocks (more resident blocks per CU).
   // (the 32-wide output tile always gains: its blocks have the least MFMA work per atomic)
@@ -273,7 +298,8 @@ static int launch_wg(WgradParams& p, hipStream_t stream) {
   mps = ((mps + 63) / 64) * 64;
   splits = cdiv(p.M, mps);
   p.m_per_split = mps;
-  if (groups == 2) hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 2>), dim3(tiles * splits), dim3(512), 0, stream, p);
+  // (four groups per block were measured too: 1024-thread blocks in lockstep lose 10-50 % on every YOLOv5-s layer)
+  if (groups >= 2) hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 2>), dim3(tiles * splits), dim3(512), 0, stream, p);
   else hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 1>), dim3(tiles * splits), dim3(256), 0, stream, p);
   return check_launch("wgrad_kernel");
 }
