@@ -131,8 +131,13 @@ def pmc_traffic(kernel_label):
         raw = json.load(open(path))
     except Exception:
         return None
-    tile = kernel_label[kernel_label.index("<") + 1:kernel_label.index(">")].replace(",", ", ")
-    base = "igemm" if kernel_label.startswith("igemm") else "wgrad_kernel"
+    if kernel_label.startswith("stem"):
+        base, tile = "stem_fprop_kernel", ""
+    elif kernel_label.startswith("conv1x1_stream"):  # label carries the output-tile width, the template its fragment count
+        base, tile = "conv1x1_stream_kernel", "%d, " % (int(kernel_label[kernel_label.index("<") + 1:kernel_label.index(">")]) // 16)
+    else:
+        tile = kernel_label[kernel_label.index("<") + 1:kernel_label.index(">")].replace(",", ", ")
+        base = "igemm" if kernel_label.startswith("igemm") else "wgrad_kernel"
     n = tot = 0.0
     for k, v in raw.items():  # a tile configuration may exist in several template variants (ring depth, group count): launch-weighted mean
         if base in k and ("<" + tile) in k and v.get("fetch_size_raw_kb_per_launch") is not None and v.get("write_size_raw_kb_per_launch") is not None:
