@@ -605,13 +605,16 @@ class HipConvModule(nn.Module):
             return None
         return bn, aid
 
-    def forward(self, x, activate=True, norm=True, residual=None):
+    def forward(self, x, activate=True, norm=True, residual=None, out=None):
+        """`out`: optional NHWC channel-slice view that receives the result (concat elimination: the caller hands every
+        producer its slice of the concat buffer, ops.cat then has nothing to copy). Ignored on the unfused fallback path."""
         fus = self._fusable(activate, norm)
         if fus is not None:
             bn, (aid, ap) = fus
             conv = self.conv
             x, w = conv._effective(x)
             cfg = conv.make_cfg(aid, ap, bn)
+            cfg.out = out
             if bn is not None:
                 bn_tick(bn)
                 return ops.conv_bn_act(x, w, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, cfg)

@@ -318,7 +318,7 @@ def conv_states_of(model):
 class ConvCfg:
     """Static configuration of one conv(+BN+act) layer (python-side)."""
     __slots__ = ("stride", "pad", "dil", "groups", "act", "act_param", "has_bn", "bn_training", "momentum", "eps",
-                 "state", "track", "vkey", "gw", "gb", "gg", "gbeta", "arena", "idx_w", "idx_b", "idx_bn", "sync")
+                 "state", "track", "vkey", "gw", "gb", "gg", "gbeta", "arena", "idx_w", "idx_b", "idx_bn", "sync", "out", "out_split")
 
     def __init__(self, stride, pad, dil, groups=1, act=L.ACT_NONE, act_param=0.0, has_bn=False, bn_training=True,
                  momentum=0.1, eps=1e-5, state=None, track=True):
@@ -333,6 +333,10 @@ class ConvCfg:
         self.gw = self.gb = self.gg = self.gbeta = None
         self.arena, self.idx_w, self.idx_b, self.idx_bn = None, None, None, ()
         self.sync = None  # SyncBN: (process_group or None for the default group, world_size) when statistics are shared across ranks
+        # concat elimination: `out` = channel-slice view (of a larger NHWC buffer) that receives the layer's result instead of a
+        # fresh tensor; `out_split` = (k1, view): channels [k1, K) go to `view`, channels [0, k1) to a fresh tensor (sibling pairs)
+        self.out = None
+        self.out_split = None
 
 
 # ---- SyncBatchNorm plumbing (trainer.py:126-127 -> torch.nn.SyncBatchNorm semantics) -------------------------------------
@@ -360,6 +364,16 @@ def _sync_bwd_sums(dgamma, dbeta, sync):
 
 def _colreduce_rows(M, Cc):
     return L.load().cvhip_colreduce_rows(M, Cc)
+
+
+def _check_out(out, N, K, P, Q):
+    """`out=` destination of a layer: an NHWC bf16 (channel-slice) view of the right logical shape"""
+    if tuple(out.shape) != (N, K, P, Q) or out.dtype != BF16:
+        raise L.CvhipError("out= has shape %s / %s, the layer produces %s bf16" % (tuple(out.shape), out.dtype, (N, K, P, Q)))
+    ld = nhwc_ld(out)
+    if ld is None:
+        raise L.CvhipError("out= must be an NHWC (channels_last) tensor or a channel slice of one")
+    return out, ld
 
 
 def _mark(arena, idx):
@@ -543,9 +557,21 @@ class ConvBnAct(torch.autograd.Function):
         res_ld = 0
         if residual is not None:
             residual, res_ld = as_nhwc(residual)
-        if cfg.has_bn or cfg.act != L.ACT_NONE or residual is not None:
-            z = empty_nhwc(N, K, P, Q, dev)
-            L.call("cvhip_bn_act_fwd", y.data_ptr(), Kp, z.data_ptr(), K, M, K,
+        if cfg.out_split is not None and cfg.has_bn and residual is None:
+            # two destinations: channels [0, k1) -> a fresh tensor, [k1, K) -> the caller's slice of a concat buffer
+            k1, z2 = cfg.out_split
+            z2, z2_ld = _check_out(z2, N, K - k1, P, Q)
+            z1 = empty_nhwc(N, k1, P, Q, dev)
+            for off, kh, zz, zld in ((0, k1, z1, k1), (k1, K - k1, z2, z2_ld)):
+                L.call("cvhip_bn_act_fwd", y.data_ptr() + 2 * off, Kp, zz.data_ptr(), zld, M, kh, stats[2].data_ptr() + 4 * off,
+                       stats[3].data_ptr() + 4 * off, cfg.act, cfg.act_param, None, 0, st)
+            z = (z1, z2)
+        elif cfg.has_bn or cfg.act != L.ACT_NONE or residual is not None:
+            if cfg.out is not None:
+                z, z_ld = _check_out(cfg.out, N, K, P, Q)
+            else:
+                z, z_ld = empty_nhwc(N, K, P, Q, dev), K
+            L.call("cvhip_bn_act_fwd", y.data_ptr(), Kp, z.data_ptr(), z_ld, M, K,
                    _ptr(stats[2]) if stats is not None else None, _ptr(stats[3]) if stats is not None else None,
                    cfg.act, cfg.act_param, _ptr(residual), res_ld, st)
         else:
@@ -637,6 +663,8 @@ class ConvBnActPair(torch.autograd.Function):
     def forward(ctx, x, wf, gf, bf, rmf, rvf, cfg, k1):
         z = ConvBnAct.forward(ctx, x, wf, None, gf, bf, rmf, rvf, None, cfg)
         ctx.k1 = k1
+        if isinstance(z, tuple):  # cfg.out_split: the second half went straight into the caller's concat buffer
+            return z
         return z[:, :k1], z[:, k1:]
 
     @staticmethod
@@ -711,8 +739,9 @@ def pair_operands(conv1, bn1, conv2, bn2):
     return wf, gf, bf, rmf, rvf, gw, gg, gb, ar[0], idx_w, idx_bn, k1
 
 
-def conv_bn_act_pair(x, operands, cfg):
+def conv_bn_act_pair(x, operands, cfg, out2=None):
     wf, gf, bf, rmf, rvf, gw, gg, gb, arena, idx_w, idx_bn, k1 = operands
+    cfg.out_split = (k1, out2) if out2 is not None else None
     cfg.arena, cfg.gw, cfg.gg, cfg.gbeta, cfg.idx_w, cfg.idx_bn = arena, gw, gg, gb, idx_w, idx_bn
     return ConvBnActPair.apply(x, wf, gf, bf, rmf, rvf, cfg, k1)
 
@@ -860,6 +889,10 @@ class Cat(torch.autograd.Function):
         xs = [as_nhwc(x) for x in xs]
         N, _, H, W = xs[0][0].shape
         Ct = sum(x.shape[1] for x, _ in xs)
+        ctx.sizes = [x.shape[1] for x, _ in xs]
+        # producers that wrote their results straight into consecutive channel slices of one buffer (`out=`): nothing to copy
+        if all(ld == Ct for _, ld in xs) and all(b[0].data_ptr() == a[0].data_ptr() + 2 * a[0].shape[1] for a, b in zip(xs, xs[1:])):
+            return xs[0][0].as_strided((N, Ct, H, W), (H * W * Ct, 1, W * Ct, Ct))
         out = empty_nhwc(N, Ct, H, W, xs[0][0].device)
         st = _stream()
         off = 0

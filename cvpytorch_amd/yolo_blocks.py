@@ -17,9 +17,10 @@ from .bricks import HipDepthwiseSeparableConvModule as DepthwiseSeparableConvMod
 from .bricks import HipMaxPool2d, HipUpsampleNearest2x, bn_tick, sync_of
 
 _PAIR_ENABLED = os.environ.get("CVHIP_PAIR", "1") != "0"
+_CAT_INPLACE = os.environ.get("CVHIP_CAT_INPLACE", "1") != "0"
 
 
-def sibling_pair_forward(m1, m2, x, owner):
+def sibling_pair_forward(m1, m2, x, owner, out2=None):
     """Run two 1x1 Conv-BN-act modules that share the input `x` as ONE fused convolution (ops.ConvBnActPair) when their
     tensors are adjacent in the flat training arenas; None -> the caller runs them one by one (eval mode, no arena, SyncBN,
     odd channel counts, CVHIP_PAIR=0)."""
@@ -46,7 +47,7 @@ def sibling_pair_forward(m1, m2, x, owner):
     cfg.vkey = (id(c1.weight), c1.weight._version, id(c2.weight), c2.weight._version)
     bn_tick(bn1)
     bn_tick(bn2)
-    return ops.conv_bn_act_pair(x, operands, cfg)
+    return ops.conv_bn_act_pair(x, operands, cfg, out2)
 
 
 class Focus(nn.Module):
@@ -83,12 +84,15 @@ class DarknetBottleneck(nn.Module):
         self.shortcut = shortcut and in_channels == out_channels
         self.depthwise = depthwise
 
-    def forward(self, x):
-        out = self.conv1(x)
+    def forward(self, x, out=None):
+        """`out`: optional channel slice of a concat buffer for the block's result (see HipConvModule.forward)"""
+        h = self.conv1(x)
         if self.shortcut and not self.depthwise:
-            return self.conv2(out, residual=x)  # add fused into conv2's BN+act pass
-        out = self.conv2(out)
-        return ops.add(out, x) if self.shortcut else out
+            return self.conv2(h, residual=x, out=out)  # add fused into conv2's BN+act pass
+        if self.depthwise or self.shortcut:
+            h = self.conv2(h)
+            return ops.add(h, x) if self.shortcut else h
+        return self.conv2(h, out=out)
 
 
 class CSPLayer(nn.Module):
@@ -111,13 +115,22 @@ class CSPLayer(nn.Module):
         return [(self.conv1, self.conv2)]
 
     def forward(self, x):
-        pair = sibling_pair_forward(self.conv1, self.conv2, x, self) if self.training else None
+        # concat elimination: conv2's result and the last bottleneck's result are written straight into the two halves of the
+        # buffer conv3 reads (ops.cat then finds adjacent slices and copies nothing)
+        N, _, H, W = x.shape
+        hid = self.conv1.out_channels
+        buf = None
+        if _CAT_INPLACE and x.is_cuda and len(self.m) > 0 and not self.m[-1].depthwise and hid % 8 == 0:
+            buf = ops.empty_nhwc(N, 2 * hid, H, W, x.device)
+        out2 = buf[:, hid:] if buf is not None else None
+        pair = sibling_pair_forward(self.conv1, self.conv2, x, self, out2) if self.training else None
         if pair is not None:
             x_1, x_2 = pair
         else:
             x_1 = self.conv1(x)
-            x_2 = self.conv2(x)
-        x_1 = self.m(x_1)
+            x_2 = self.conv2(x, out=out2)
+        for i, blk in enumerate(self.m):
+            x_1 = blk(x_1, out=buf[:, :hid]) if (buf is not None and i == len(self.m) - 1) else blk(x_1)
         return self.conv3(ops.cat([x_1, x_2]))
 
 

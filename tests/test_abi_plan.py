@@ -69,8 +69,14 @@ def test_descriptor_validation_status_codes():
 
 def test_stats_rows_tiles():
     lib = L.load()
-    # block-M is 256 for K <= 64 and 128 otherwise (conv_igemm.hip launch_igemm)
-    assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(desc(64, 8, 640, 640, 32, 6, 6, (2, 2), (2, 2)))) == (64 * 320 * 320 + 255) // 256
+    # the 8-channel image stem runs on the persistent direct kernel (conv_stem.hip): one partial row per block
+    stem = desc(64, 8, 640, 640, 32, 6, 6, (2, 2), (2, 2))
+    assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(stem)) == lib.cvhip_conv_stem_blocks(C.byref(stem)) == 768
+    # implicit GEMM: block-M is 256 for K <= 64 and 128 otherwise (conv_igemm.hip launch_igemm)
+    assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(desc(64, 32, 160, 160, 32, 3, 3, (1, 1), (1, 1)))) == (64 * 160 * 160 + 255) // 256
+    # 1x1 stride 1 with enough rows: the persistent streaming kernel (conv1x1_stream.hip), balanced grid <= 512
+    pw = desc(64, 64, 160, 160, 32, 1, 1)
+    assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(pw)) == lib.cvhip_conv1x1_stream_blocks(32, 64, 64 * 160 * 160, 1) == 512
     assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(desc(2, 128, 40, 40, 128, 3, 3, (1, 1), (1, 1)))) == (2 * 1600 + 127) // 128
     assert lib.cvhip_colreduce_rows(10, 32) == 1
     assert lib.cvhip_colreduce_rows(10 ** 7, 32) == 1024
