@@ -882,26 +882,34 @@ def upsample2x_cat(a, b=None):
 
 
 class Cat(torch.autograd.Function):
-    """Channel concat: copies each input into its slice of one NHWC buffer; backward hands out slice views."""
+    """Channel concat: copies each input into its slice of one NHWC buffer; backward hands out slice views. Inputs that
+    already ARE their slice of the destination (producers called with `out=`) are not copied; `into` names the destination
+    when only some inputs were produced in place."""
 
     @staticmethod
-    def forward(ctx, *xs):
+    def forward(ctx, into, *xs):
         xs = [as_nhwc(x) for x in xs]
         N, _, H, W = xs[0][0].shape
         Ct = sum(x.shape[1] for x, _ in xs)
         ctx.sizes = [x.shape[1] for x, _ in xs]
-        # producers that wrote their results straight into consecutive channel slices of one buffer (`out=`): nothing to copy
-        if all(ld == Ct for _, ld in xs) and all(b[0].data_ptr() == a[0].data_ptr() + 2 * a[0].shape[1] for a, b in zip(xs, xs[1:])):
+        if into is None and all(ld == Ct for _, ld in xs) and all(b[0].data_ptr() == a[0].data_ptr() + 2 * a[0].shape[1] for a, b in zip(xs, xs[1:])):
+            # every producer wrote straight into consecutive channel slices of one buffer: nothing to copy
             return xs[0][0].as_strided((N, Ct, H, W), (H * W * Ct, 1, W * Ct, Ct))
-        out = empty_nhwc(N, Ct, H, W, xs[0][0].device)
+        if into is not None:
+            out, ld_o = _check_out(into, N, Ct, H, W)
+            if ld_o != Ct:
+                raise L.CvhipError("cat(into=): destination must be a dense NHWC buffer")
+            out = out.as_strided((N, Ct, H, W), (H * W * Ct, 1, W * Ct, Ct))  # fresh alias (the result must not BE an argument)
+        else:
+            out = empty_nhwc(N, Ct, H, W, xs[0][0].device)
         st = _stream()
         off = 0
         M = N * H * W
         for x, ld in xs:
             Cc = x.shape[1]
-            L.call("cvhip_copy2d", x.data_ptr(), ld, out.data_ptr() + 2 * off, Ct, M, Cc, st)
+            if not (ld == Ct and x.data_ptr() == out.data_ptr() + 2 * off):
+                L.call("cvhip_copy2d", x.data_ptr(), ld, out.data_ptr() + 2 * off, Ct, M, Cc, st)
             off += Cc
-        ctx.sizes = [x.shape[1] for x, _ in xs]
         return out
 
     @staticmethod
@@ -910,11 +918,11 @@ class Cat(torch.autograd.Function):
         for c in ctx.sizes:
             outs.append(dout[:, off:off + c])
             off += c
-        return tuple(outs)
+        return (None,) + tuple(outs)
 
 
-def cat(xs):
-    return Cat.apply(*xs)
+def cat(xs, into=None):
+    return Cat.apply(into, *xs)
 
 
 class Add(torch.autograd.Function):

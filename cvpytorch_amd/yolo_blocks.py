@@ -20,7 +20,7 @@ _PAIR_ENABLED = os.environ.get("CVHIP_PAIR", "1") != "0"
 _CAT_INPLACE = os.environ.get("CVHIP_CAT_INPLACE", "1") != "0"
 
 
-def sibling_pair_forward(m1, m2, x, owner, out2=None):
+def sibling_pair_forward(m1, m2, x, owner, out2=None, out=None):
     """Run two 1x1 Conv-BN-act modules that share the input `x` as ONE fused convolution (ops.ConvBnActPair) when their
     tensors are adjacent in the flat training arenas; None -> the caller runs them one by one (eval mode, no arena, SyncBN,
     odd channel counts, CVHIP_PAIR=0)."""
@@ -47,6 +47,7 @@ def sibling_pair_forward(m1, m2, x, owner, out2=None):
     cfg.vkey = (id(c1.weight), c1.weight._version, id(c2.weight), c2.weight._version)
     bn_tick(bn1)
     bn_tick(bn2)
+    cfg.out = out   # both halves side by side into one slice of a concat buffer (or None)
     return ops.conv_bn_act_pair(x, operands, cfg, out2)
 
 
@@ -157,6 +158,10 @@ class DownsamplingModule(nn.Module):
         self.fuse = CSPLayer(c1 * 2, c2, n=layer, shortcut=False, norm_cfg=norm_cfg, act_cfg=act_cfg)
 
     def forward(self, x, y):
+        if _CAT_INPLACE and x.is_cuda and y.dim() == 4:
+            c1 = self.down.out_channels
+            buf = ops.empty_nhwc(y.shape[0], c1 + y.shape[1], y.shape[2], y.shape[3], y.device)
+            return self.fuse(ops.cat([self.down(x, out=buf[:, :c1]), y], into=buf))   # only y is copied
         return self.fuse(ops.cat([self.down(x), y]))
 
 

@@ -35,11 +35,15 @@ def _torch_default_conv_init(conv):
     conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
 
 
-def _siblings(m1, m2, x, owner):
+def _siblings(m1, m2, x, owner, out=None):
     """two 1x1 Conv modules on the same input: one fused convolution while training on the flat arenas (yolo_blocks.
-    sibling_pair_forward), the two modules one after the other otherwise"""
-    pair = sibling_pair_forward(m1, m2, x, owner) if owner.training else None
-    return pair if pair is not None else (m1(x), m2(x))
+    sibling_pair_forward), the two modules one after the other otherwise. `out`: channel slice (of a concat buffer) that
+    receives both results side by side."""
+    pair = sibling_pair_forward(m1, m2, x, owner, out=out) if owner.training else None
+    if pair is not None:
+        return pair
+    k1 = m1.out_channels
+    return (m1(x), m2(x)) if out is None else (m1(x, out=out[:, :k1]), m2(x, out=out[:, k1:]))
 
 
 class Conv(HipConvModule):
@@ -79,9 +83,16 @@ class EELAN(nn.Module):
         return [(self.conv1, self.conv2)]
 
     def forward(self, x):
-        x1, x2 = _siblings(self.conv1, self.conv2, x, self)
-        x3 = self.conv3(x2)
-        x4 = self.conv4(x3)
+        # concat elimination: all four producers write into their slice of the buffer conv5 reads
+        c2 = self.conv1.out_channels
+        buf = ops.empty_nhwc(x.shape[0], 4 * c2, x.shape[2], x.shape[3], x.device) if (x.is_cuda and c2 % 8 == 0) else None
+        x1, x2 = _siblings(self.conv1, self.conv2, x, self, out=None if buf is None else buf[:, :2 * c2])
+        if buf is None:
+            x3 = self.conv3(x2)
+            x4 = self.conv4(x3)
+        else:
+            x3 = self.conv3[1](self.conv3[0](x2), out=buf[:, 2 * c2:3 * c2])
+            x4 = self.conv4[1](self.conv4[0](x3), out=buf[:, 3 * c2:])
         return self.conv5(ops.cat([x1, x2, x3, x4]))
 
 
