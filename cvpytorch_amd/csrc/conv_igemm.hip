@@ -315,12 +315,19 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) 
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
   const int lt = xcd_remap(blockIdx.x, p.total_tiles);
-  int ci = 0;
+  int ci = 0, local;
+  if (p.interleave) {
+    // dgrad parity classes with equal tile counts: the classes of one spatial tile run back to back on the same XCD, so the
+    // stride-2-interleaved pixels they write (half cache lines each) meet in that L2 before they are written back
+    ci = lt % p.ncls;
+    local = lt / p.ncls;
+  } else {
 #pragma unroll 1
-  for (int i = 1; i < p.ncls; ++i)
-    if (lt >= p.cls[i].tile_begin) ci = i;
+    for (int i = 1; i < p.ncls; ++i)
+      if (lt >= p.cls[i].tile_begin) ci = i;
+    local = lt - p.cls[ci].tile_begin;
+  }
   const IgemmClass& cl = p.cls[ci];
-  const int local = lt - cl.tile_begin;
   const int mtile = local / p.n_tiles;
   const int ntile = local - mtile * p.n_tiles;
   const int m0 = mtile * BM, n0 = ntile * BN;
@@ -555,6 +562,15 @@ static bool use_v1() {
   return v == 1;
 }
 
+static bool interleave_classes() {  // CVHIP_IGEMM_INTERLEAVE=0 restores class-major tile order
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CVHIP_IGEMM_INTERLEAVE");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v == 1;
+}
+
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(IgemmParams& p, hipStream_t stream) {
   int total = 0;
@@ -568,6 +584,12 @@ static int launch_cfg(IgemmParams& p, hipStream_t stream) {
   }
   p.total_tiles = total;
   if (total == 0) return CVHIP_OK;
+  p.interleave = 0;
+  if (p.ncls > 1 && interleave_classes() && !use_v1()) {
+    bool same = true;
+    for (int i = 1; i < p.ncls; ++i) same = same && cdiv(p.cls[i].M, BM) == cdiv(p.cls[0].M, BM);
+    p.interleave = same ? 1 : 0;
+  }
   if constexpr (WM == 64 && BM >= 128 && (BM != 128 || BN == 128)) {
     if (use_v1()) {
       hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), dim3(total), dim3(256), 0, stream, p);

@@ -37,6 +37,7 @@ struct IgemmParams {
   int Nout, y_ld, OH, OW, out_sh, out_sw;
   int n_tiles, total_tiles, ncls;
   int y_vec_ok;
+  int interleave;  // 1: logical tile id = spatial tile * ncls + class (classes with equal tile counts: stride-parity dgrad)
   IgemmClass cls[kMaxClasses];
 };
 
