@@ -96,5 +96,6 @@ int try_launch_stream1x1(const IgemmParams& p, hipStream_t stream);
 // conv_stem.hip: direct convolution for 8-channel image stems (grid size, 0 = not taken; launcher, -1 = not taken)
 int stem_blocks(int C, int x_ld, int K, int R, int S, int sh, int sw, int dh, int dw, int N, int OH, int OW);
 int try_launch_stem(const IgemmParams& p, hipStream_t stream);
+int try_launch_stem_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, hipStream_t stream);
 
 }  // namespace cvhip

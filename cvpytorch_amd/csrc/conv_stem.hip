@@ -228,6 +228,165 @@ __global__ __launch_bounds__(256, 2) void stem_fprop_kernel(const StemParams p) 
   }
 }
 
+// ---- weight gradient -----------------------------------------------------------------------------
+//   dW[k][tap][c] += sum over output pixels dY[pix][k] * X[pix*st - pad + tap][c]        (fp32 atomics, [K][R*S][8])
+// Same tiles and the same LDS patch as the forward kernel; the reduction runs over pixels, so both MFMA operands are
+// gathered with the gfx950 LDS transpose read (ds_read_b64_tr_b16): A = dY^T from a row-major [pixel][32 ch] tile (layout and
+// swizzle of conv_wgrad.hip), B = X^T straight from the patch — 16 B columns of a fragment are the 8 channels of TWO taps,
+// lanes with (lane & 2) point at the second tap's pixel; rows are 8 consecutive output columns = 8 consecutive 16-byte patch
+// slots. A wave owns every 4th column fragment (<= NFW of them) and keeps its slice of dW in registers across all tiles of
+// the (persistent) block: one atomic epilogue per block. The general wgrad kernel re-gathers x per tap and re-reads dY per
+// 128-column tile (450 us for the YOLOv5-s stem; HBM bound ~170 us).
+typedef __attribute__((address_space(3))) bf16x4 stem_lds_bf16x4;
+__device__ __forceinline__ bf16x8 stem_tr_read8(const unsigned char* p0, const unsigned char* p1) {
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((stem_lds_bf16x4*)(p0));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((stem_lds_bf16x4*)(p1));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+struct StemWgradParams {
+  const bf16_t* x;
+  const bf16_t* dy;
+  float* dw;  // [K][R*S][8] fp32, accumulated with atomics
+  int NB, IH, IW, OH, OW, K, dy_ld, R, S, pad_h, pad_w;
+  int tiles_x, tiles_y, ntiles;
+};
+
+template <int ST, int NFW>
+__global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const StemWgradParams p) {
+  constexpr int DY_BYTES = kStemTH * kStemTW * 64;  // [256 pixels][32 channels] bf16
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kStemPatchBytes + DY_BYTES];
+  unsigned char* const sP = smem;
+  unsigned char* const sD = smem + kStemPatchBytes;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int g = lane >> 4, q = (lane >> 2) & 3;
+  const int R = p.R, S = p.S, taps = R * S;
+  const int nfrag = (taps + 1) >> 1;  // 16-column fragments: two taps x 8 channels
+  const int PH = (kStemTH - 1) * ST + R;
+  const int PW = ((kStemTW - 1) * ST + S + 1) & ~1;
+  const int HALF = PW >> 1;
+  const int nchunk = PH * PW;
+
+  // ---- loaders (patch: as in stem_fprop_kernel; dY: thread owns 16-byte chunk (t & 3) of pixels (t >> 2) + 64 i)
+  constexpr int LD_IT = (kStemMaxPH * kStemMaxPW + 255) / 256;
+  uint4 pre[LD_IT], pred[4];
+  int pk[LD_IT], loff[LD_IT];
+#pragma unroll
+  for (int i = 0; i < LD_IT; ++i) {
+    const int qq = t + i * 256;
+    const int pr = qq / PW, pc = qq - pr * PW;
+    pk[i] = qq < nchunk ? ((pr << 16) | pc) : -1;
+    loff[i] = (pr * PW + (ST == 2 ? (pc & 1) * HALF + (pc >> 1) : pc)) * 16;
+  }
+  auto tile_origin = [&](int tile, int& n, int& oy0, int& ox0) {
+    const int tx = tile % p.tiles_x;
+    const int rest = tile / p.tiles_x;
+    const int ty = rest % p.tiles_y;
+    n = rest / p.tiles_y;
+    oy0 = ty * kStemTH;
+    ox0 = tx * kStemTW;
+  };
+  const int dchunk = t & 3;
+  auto gload = [&](int tile) {
+    int n, oy0, ox0;
+    tile_origin(tile, n, oy0, ox0);
+    const int iy0 = oy0 * ST - p.pad_h, ix0 = ox0 * ST - p.pad_w;
+    const bf16_t* img = p.x + (int64_t)n * p.IH * p.IW * 8;
+#pragma unroll
+    for (int i = 0; i < LD_IT; ++i) {
+      const int iy = iy0 + (pk[i] >> 16), ix = ix0 + (pk[i] & 0xffff);
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (pk[i] >= 0 && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW)
+        v = *reinterpret_cast<const uint4*>(img + (int64_t)(iy * p.IW + ix) * 8);
+      pre[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int px = (t >> 2) + 64 * i;  // tile pixel: row px / 64, column px % 64
+      const int oy = oy0 + (px >> 6), ox = ox0 + (px & 63);
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (oy < p.OH && ox < p.OW && dchunk * 8 < p.K)
+        v = *reinterpret_cast<const uint4*>(p.dy + ((int64_t)(n * p.OH + oy) * p.OW + ox) * p.dy_ld + dchunk * 8);
+      pred[i] = v;
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < LD_IT; ++i)
+      if (pk[i] >= 0) *reinterpret_cast<uint4*>(sP + loff[i]) = pre[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int px = (t >> 2) + 64 * i;
+      const int h = (px & 3) | ((px >> 1) & 4);  // 32-byte-segment swizzle of conv_wgrad.hip (2 segments per 64-byte row)
+      *reinterpret_cast<uint4*>(sD + px * 64 + ((((dchunk >> 1) ^ h) & 1) << 5) + (dchunk & 1) * 16) = pred[i];
+    }
+  };
+
+  // ---- fragment geometry (lane constants)
+  const int hsw = q | ((g & 1) << 2);
+  const int px0 = 8 * g + q;                 // pixel row of this lane's first transposed read inside a 32-pixel step
+  const int tapsel = (lane >> 1) & 1;        // which of the fragment's two taps this lane's 8-byte piece belongs to
+  int boff[NFW];                             // patch byte offset of (tap of fragment f, this lane's piece), without pixel / row terms
+#pragma unroll
+  for (int j = 0; j < NFW; ++j) {
+    const int f = wave + 4 * j;
+    int tap = 2 * f + tapsel;
+    if (tap >= taps) tap = taps - 1;  // odd tap count / fragments past the end: columns never stored
+    const int tr = tap / S, ts = tap - tr * S;
+    boff[j] = (tr * PW + (ST == 2 ? (ts & 1) * HALF + (ts >> 1) : ts)) * 16 + (lane & 1) * 8;
+  }
+  f32x4 acc[2][NFW];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int j = 0; j < NFW; ++j) acc[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int tile = blockIdx.x;
+  if (tile < p.ntiles) gload(tile);
+  for (; tile < p.ntiles; tile += gridDim.x) {
+    lstore();
+    __syncthreads();
+    const int nxt = tile + gridDim.x;
+    if (nxt < p.ntiles) gload(nxt);
+#pragma unroll 2
+    for (int step = 0; step < (kStemTH * kStemTW) / 32; ++step) {
+      const int ty = step >> 1, xh = step & 1;
+      bf16x8 fd[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const unsigned char* base = sD + step * 32 * 64 + (((a ^ hsw) & 1) << 5) + (lane & 3) * 8;
+        fd[a] = stem_tr_read8(base + px0 * 64, base + (px0 + 4) * 64);
+      }
+      const unsigned char* prow = sP + ((ty * ST) * PW + xh * 32 + px0) * 16;
+#pragma unroll
+      for (int j = 0; j < NFW; ++j) {
+        if (wave + 4 * j < nfrag) {
+          const bf16x8 fx = stem_tr_read8(prow + boff[j], prow + boff[j] + 4 * 16);
+#pragma unroll
+          for (int a = 0; a < 2; ++a) acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[a], fx, acc[a][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();  // everybody is done reading before the next tile's data is stored
+  }
+
+  // ---- epilogue: lane holds D[k = a*16 + 4*(lane>>4) + r][column = f*16 + (lane & 15)]; column -> (tap, channel)
+  const int Ktot = taps * 8;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = a * 16 + 4 * g + r;
+      if (k >= p.K) continue;
+#pragma unroll
+      for (int j = 0; j < NFW; ++j) {
+        const int col = (wave + 4 * j) * 16 + (lane & 15);
+        if (col < Ktot) unsafeAtomicAdd(p.dw + (int64_t)k * Ktot + col, acc[a][j][r]);
+      }
+    }
+}
+
 // ---- host side ----------------------------------------------------------------------------------
 
 static int stem_mode() {  // CVHIP_STEM: 0 = never, 1 = default
@@ -294,6 +453,47 @@ int try_launch_stem(const IgemmParams& p, hipStream_t stream) {
   if (p.in_sh == 2) rc = p.stats ? launch_stem_steps<2, true>(sp, blocks, nstep, stream) : launch_stem_steps<2, false>(sp, blocks, nstep, stream);
   else rc = p.stats ? launch_stem_steps<1, true>(sp, blocks, nstep, stream) : launch_stem_steps<1, false>(sp, blocks, nstep, stream);
   return rc;
+}
+
+// wgrad twin of try_launch_stem: same eligibility (descriptor level), dw = [K][R*S][8] fp32 (already zeroed / holding the sum)
+int try_launch_stem_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, hipStream_t stream) {
+  const int OH = conv_out_dim(d->H, d->pad_h, d->dil_h, d->R, d->stride_h);
+  const int OW = conv_out_dim(d->W, d->pad_w, d->dil_w, d->S, d->stride_w);
+  const int blocks = stem_blocks(d->C, d->x_ld, d->K, d->R, d->S, d->stride_h, d->stride_w, d->dil_h, d->dil_w, d->N, OH, OW);
+  if (blocks <= 0 || (d->y_ld & 7) || (((uintptr_t)x) & 15) || (((uintptr_t)dy) & 15)) return -1;
+  static int off = -1;
+  if (off < 0) {
+    const char* e = getenv("CVHIP_STEM_WGRAD");
+    off = (e && e[0] == '0') ? 1 : 0;
+  }
+  if (off) return -1;
+  StemWgradParams sp;
+  sp.x = (const bf16_t*)x;
+  sp.dy = (const bf16_t*)dy;
+  sp.dw = dw;
+  sp.NB = d->N; sp.IH = d->H; sp.IW = d->W; sp.OH = OH; sp.OW = OW;
+  sp.K = d->K; sp.dy_ld = d->y_ld; sp.R = d->R; sp.S = d->S; sp.pad_h = d->pad_h; sp.pad_w = d->pad_w;
+  sp.tiles_x = cdiv(OW, kStemTW);
+  sp.tiles_y = cdiv(OH, kStemTH);
+  sp.ntiles = d->N * sp.tiles_x * sp.tiles_y;
+  const int nfrag = (d->R * d->S + 1) / 2;
+  const int nfw = cdiv(nfrag, 4);
+  const bool s2 = d->stride_h == 2;
+#define CVHIP_STEMW_CASE(NF)                                                                                          \
+  case NF:                                                                                                            \
+    if (s2) hipLaunchKernelGGL((stem_wgrad_kernel<2, NF>), dim3(blocks), dim3(256), 0, stream, sp);                   \
+    else hipLaunchKernelGGL((stem_wgrad_kernel<1, NF>), dim3(blocks), dim3(256), 0, stream, sp);                      \
+    break;
+  switch (nfw) {
+    CVHIP_STEMW_CASE(1)
+    CVHIP_STEMW_CASE(2)  // 3x3: 5 fragments
+    CVHIP_STEMW_CASE(4)  // 5x5: 13
+    CVHIP_STEMW_CASE(5)  // 6x6: 18
+    CVHIP_STEMW_CASE(7)  // 7x7: 25
+    default: return -1;
+  }
+#undef CVHIP_STEMW_CASE
+  return check_launch("stem_wgrad_kernel");
 }
 
 }  // namespace cvhip

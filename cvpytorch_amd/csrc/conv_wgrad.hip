@@ -305,6 +305,8 @@ static int launch_wg(WgradParams& p, hipStream_t stream) {
 }
 
 int launch_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, hipStream_t stream) {
+  const int stem = try_launch_stem_wgrad(d, x, dy, dw, stream);  // 8-channel image stem: patch kernel (conv_stem.hip)
+  if (stem >= 0) return stem;
   WgradParams p;
   p.x = (const bf16_t*)x;
   p.dy = (const bf16_t*)dy;

@@ -78,8 +78,10 @@ def _pointwise(R, S, cfg):
     return R == 1 and S == 1 and tuple(cfg.stride) == (1, 1) and tuple(cfg.pad) == (0, 0)
 
 
-def _wgrad_name(k, r=3, s=3, c=0, m=0):
-    """label of the tile configuration launch_wgrad picks (conv_wgrad.hip)"""
+def _wgrad_name(k, r=3, s=3, c=0, m=0, desc=None):
+    """label of the kernel / tile configuration launch_wgrad picks (conv_wgrad.hip; conv_stem.hip for image stems)"""
+    if desc is not None and L.load().cvhip_conv_stem_blocks(C.byref(desc)) > 0 and desc.y_ld % 8 == 0:
+        return "stem_wgrad_kernel"
     tn = 32 if k <= 32 else 64 if k <= 64 else 128
     if r == 1 and s == 1:
         if float(m) * k * c <= 7.5e9:
@@ -436,17 +438,17 @@ def _conv_grads(ctx, x, weight, dy, dy_ld, need_dx, need_dw, need_db):
                 _Side.keep.append((x, dy))
             elif not padded and direct_w:
                 # accumulate straight into the parameter's KRSC slot of the flat gradient arena
-                _timed_call(_wgrad_name(Kp, R, S, Cc, N * P * Q), geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(),
+                _timed_call(_wgrad_name(Kp, R, S, Cc, N * P * Q, desc), geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(),
                             cfg.gw.data_ptr(), 1, st)
             elif not padded:
                 # logical OIHW, KRSC (channels_last) memory: a fresh non-view tensor autograd can adopt as .grad
                 dw = torch.empty((K, Cc, R, S), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
-                _timed_call(_wgrad_name(Kp, R, S, Cc, N * P * Q), geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(),
+                _timed_call(_wgrad_name(Kp, R, S, Cc, N * P * Q, desc), geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(),
                             dw.data_ptr(), 0, st)
             else:
                 # padded problem: wgrad into a [Kp][R][S][Cc] scratch, then fold the valid block into the real gradient
                 tmp = torch.empty((Kp, R, S, Cc), dtype=torch.float32, device=dev)
-                _timed_call(_wgrad_name(Kp, R, S, Cc, N * P * Q), geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(),
+                _timed_call(_wgrad_name(Kp, R, S, Cc, N * P * Q, desc), geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(),
                             tmp.data_ptr(), 0, st)
                 if direct_w:
                     dst = cfg.gw
