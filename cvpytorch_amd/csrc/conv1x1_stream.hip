@@ -254,7 +254,13 @@ int stream1x1_blocks(int Nout, int Cin, int64_t M, bool stats) {
   const int cin_pad = (Cin + 31) & ~31;
   if (bn * (cin_pad * 2 + 16) > kS1MaxLds) return 0;
   const int ntiles = (int)((M + 127) / 128);
-  if (mode == 1 && (ntiles < kS1MinTiles || Nout > bn)) return 0;
+  if (mode == 1) {
+    if (ntiles < kS1MinTiles) return 0;
+    // wider outputs run as several 128-wide column tiles (grid.y) that re-read the pixel rows: only worth it while those rows
+    // stay in the Infinity Cache (<= 64 MB) and there are no BN sums (tools/s1x1_bench.py: -12..-29 % on the 40x40 YOLO
+    // layers; with larger operands DeepLabv3+ lost 7 % end to end)
+    if (Nout > bn && (Nout > 4 * bn || stats || (double)M * Cin * 2.0 > 64e6)) return 0;
+  }
   const int rounds = cdiv(ntiles, kS1MaxBlocks);
   return cdiv(ntiles, rounds);  // balanced: every block walks `rounds` (or rounds-1) tiles
 }

@@ -65,7 +65,8 @@ def _igemm_name(nout, m=0, ktot=0, pointwise=False, ld=0, stats=False):
     """label of the kernel / tile configuration launch_igemm picks (conv_igemm.hip: igemm_block_m; conv1x1_stream.hip for
     1x1 stride-1 unpadded passes) for `nout` output channels, m rows"""
     if pointwise and ld % 8 == 0 and L.load().cvhip_conv1x1_stream_blocks(nout, ktot, m, int(stats)) > 0:
-        return "conv1x1_stream_kernel<%d>" % (32 if nout <= 32 else 64 if nout <= 64 else 128 if nout <= 128 or stats else 256)
+        wide = nout > 128 and not stats and 256 * (((ktot + 31) // 32 * 32) * 2 + 16) <= 72 * 1024 and nout <= 256
+        return "conv1x1_stream_kernel<%d>" % (32 if nout <= 32 else 64 if nout <= 64 else 256 if wide else 128)
     if nout <= 32:
         return "igemm_kernel<256,32,64,32>"
     if nout <= 64:
