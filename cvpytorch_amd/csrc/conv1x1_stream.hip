@@ -29,7 +29,7 @@ constexpr int kS1MaxBlocks = 512;      // persistent grid: 2 blocks per CU
 constexpr int kS1MinTiles = 192;       // below this the grid cannot cover the chip: the general kernel's smaller tiles win
 
 template <int NF, int MF, bool STATS>
-__global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmParams p, int ntiles, int vec16) {
+__global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernArgs p, int ntiles, int vec16) {
   constexpr int BN = NF * 16;
   constexpr int RT = 64 * MF;   // pixel rows per block tile: 4 waves x MF fragments x 16
   constexpr int KC = 256 / MF;  // channels per pipeline stage (register budget: MF * KC/32 * 4 VGPRs per buffer)
@@ -290,7 +290,8 @@ static int launch_s1(const IgemmParams& p, int blocks, int ntiles, hipStream_t s
     attr_set = true;
   }
   const int vec16 = ((p.y_ld & 7) == 0) && ((((uintptr_t)p.y) & 15) == 0);
-  hipLaunchKernelGGL(kern, dim3(blocks, cdiv(p.Nout, bn)), dim3(256), lds, stream, p, ntiles, vec16);
+  const IgemmKernArgs k = narrow_plan(p, 0, 1);
+  hipLaunchKernelGGL(kern, dim3(blocks, cdiv(p.Nout, bn)), dim3(256), lds, stream, k, ntiles, vec16);
   return check_launch("conv1x1_stream_kernel");
 }
 

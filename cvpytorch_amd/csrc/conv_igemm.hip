@@ -30,7 +30,7 @@
 namespace cvhip {
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKernArgs p) {
   constexpr int WAVES_N = BN / WN;
   constexpr int WAVES_M = BM / WM;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
@@ -295,7 +295,7 @@ __device__ __attribute__((aligned(64))) unsigned int g_zero_page[16];
 
 // ABL: profiling ablation (CVHIP_IGEMM_ABLATE): 0 = the kernel, 1 = staging only (no LDS reads / MFMA), 2 = compute only
 template <int BM, int BN, int WM, int WN, int ABL = 0, int NST = 3>
-__global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmKernArgs p) {
   constexpr int WAVES_N = BN / WN;
   constexpr int WAVES_M = BM / WM;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
@@ -572,13 +572,9 @@ static bool interleave_classes() {  // CVHIP_IGEMM_INTERLEAVE=0 restores class-m
 }
 
 template <int BM, int BN, int WM, int WN>
-static int launch_cfg(IgemmParams& p, hipStream_t stream) {
+static int launch_group(IgemmKernArgs& p, hipStream_t stream) {
   int total = 0;
-  p.n_tiles = cdiv(p.Nout, BN);
-  p.cin_magic = div_magic(p.Cin);
   for (int i = 0; i < p.ncls; ++i) {
-    p.cls[i].ts_magic = div_magic(p.cls[i].TS);
-    if ((int64_t)p.cls[i].TR * p.cls[i].TS * p.Cin >= 65536) return CVHIP_ERR_UNSUPPORTED;  // 16-bit exact fast division
     p.cls[i].tile_begin = total;
     total += cdiv(p.cls[i].M, BM) * p.n_tiles;
   }
@@ -601,6 +597,24 @@ static int launch_cfg(IgemmParams& p, hipStream_t stream) {
   else if ((BN <= 64 && nst2_level() >= 1) || (BM == 128 && nst2_level() >= 2) || nst2_level() >= 3) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 2>), dim3(total), dim3(256), 0, stream, p);
   else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN>), dim3(total), dim3(256), 0, stream, p);
   return check_launch("igemm_kernel");
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(IgemmParams& p, hipStream_t stream) {
+  p.n_tiles = cdiv(p.Nout, BN);
+  p.cin_magic = div_magic(p.Cin);
+  for (int i = 0; i < p.ncls; ++i) {
+    p.cls[i].ts_magic = div_magic(p.cls[i].TS);
+    if ((int64_t)p.cls[i].TR * p.cls[i].TS * p.Cin >= 65536) return CVHIP_ERR_UNSUPPORTED;  // 16-bit exact fast division
+  }
+  // the kernels take kKernelClasses classes by value (small argument block); plans with more (stride > 2) launch in groups
+  for (int first = 0; first < p.ncls; first += kKernelClasses) {
+    const int count = p.ncls - first < kKernelClasses ? p.ncls - first : kKernelClasses;
+    IgemmKernArgs k = narrow_plan(p, first, count);
+    const int st = launch_group<BM, BN, WM, WN>(k, stream);
+    if (st) return st;
+  }
+  return CVHIP_OK;
 }
 
 // Tile choice. Wide outputs (> 64 channels) of large problems use 256x128 block tiles with 128x64 WAVE tiles: LDS fragment

@@ -24,7 +24,10 @@ struct IgemmClass {
   int r0, r_step, s0, s_step;
 };
 
-struct IgemmParams {
+// scalar part of the kernel arguments, shared by the host-side plan (up to kMaxClasses classes) and the device-side argument
+// struct (kKernelClasses classes: a by-value argument of ~1.4 KB made every launch drag a __amd_rocclr_copyBuffer node along
+// under hipGraph replay — ~100 extra 2.4-us nodes per YOLOv5-s step; 4 classes cover stride <= 2, more classes launch in groups)
+struct IgemmCommon {
   const bf16_t* x;
   const bf16_t* w;
   bf16_t* y;
@@ -38,8 +41,25 @@ struct IgemmParams {
   int n_tiles, total_tiles, ncls;
   int y_vec_ok;
   int interleave;  // 1: logical tile id = spatial tile * ncls + class (classes with equal tile counts: stride-parity dgrad)
-  IgemmClass cls[kMaxClasses];
 };
+
+constexpr int kKernelClasses = 4;
+
+template <int NC>
+struct IgemmParamsT : IgemmCommon {
+  IgemmClass cls[NC];
+};
+typedef IgemmParamsT<kMaxClasses> IgemmParams;      // host-side plan
+typedef IgemmParamsT<kKernelClasses> IgemmKernArgs;  // what the kernels take by value
+
+// kernel arguments for classes [first, first + count) of a plan (tile ranges re-based to the group)
+inline IgemmKernArgs narrow_plan(const IgemmParams& p, int first, int count) {
+  IgemmKernArgs k;
+  static_cast<IgemmCommon&>(k) = static_cast<const IgemmCommon&>(p);
+  k.ncls = count;
+  for (int i = 0; i < kKernelClasses; ++i) k.cls[i] = p.cls[first + (i < count ? i : 0)];
+  return k;
+}
 
 inline int conv_out_dim(int in, int pad, int dil, int k, int stride) {
   return (in + 2 * pad - dil * (k - 1) - 1) / stride + 1;

@@ -19,6 +19,14 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     step(imgs, gts)
     torch.cuda.synchronize()
+import collections
+small = collections.Counter()
+for ev in prof.events():
+    if ev.name in ("aten::copy_", "aten::fill_", "aten::zero_", "aten::clone", "aten::contiguous", "aten::to", "aten::_to_copy") and ev.device_time_total <= 8:
+        stack = [s for s in ev.stack if "cvpytorch_amd" in s][:2]
+        small[(ev.name, str(ev.input_shapes)[:60], " <- ".join(stack))] += 1
+for k, v in small.most_common(25):
+    print("%4d x %s %s\n        %s" % ((v,) + k))
 rows = []
 for ev in prof.events():
     if ev.name in ("aten::copy_", "aten::add", "aten::add_", "aten::contiguous", "aten::clone") and ev.device_time_total > 8:
