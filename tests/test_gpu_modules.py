@@ -262,3 +262,40 @@ def test_hip_ops_refuse_cpu_tensors():
     from cvpytorch_amd import lib as L
     with pytest.raises(L.CvhipError):
         ops.max_pool2d(torch.zeros(1, 8, 4, 4, dtype=torch.bfloat16), 2)
+
+
+def test_out_slices_and_copy_free_cat():
+    """Concat elimination: a ConvModule writing into its channel slice of a concat buffer (`out=`) gives bit-identical results to the
+    module writing a fresh tensor, `ops.cat` of in-place slices aliases the buffer (no copy), `cat(into=)` copies only what is not
+    already in place, and gradients flow as with the copying concat."""
+    from cvpytorch_amd import bricks, ops
+    torch.manual_seed(11)
+    m1 = bricks.HipConvModule(32, 24, 3, padding=1, norm_cfg=dict(type="BN"), act_cfg=dict(type="SiLU")).to(dev()).train()
+    m2 = bricks.HipConvModule(32, 40, 1, norm_cfg=dict(type="BN"), act_cfg=dict(type="SiLU")).to(dev()).train()
+    x = torch.randn(3, 32, 18, 14, device=dev()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ref = ops.cat([m1(xa), m2(xa)])
+    buf = ops.empty_nhwc(3, 64, 18, 14, dev())
+    a, b = m1(xb, out=buf[:, :24]), m2(xb, out=buf[:, 24:])
+    got = ops.cat([a, b])
+    assert got.data_ptr() == buf.data_ptr() and tuple(got.shape) == (3, 64, 18, 14)
+    assert torch.equal(got.float(), ref.float())
+    cot = torch.randn(ref.shape, device=dev()).to(ref.dtype)
+    (ref.float() * cot.float()).sum().backward()
+    g_ref = [p.grad.clone() for p in list(m1.parameters()) + list(m2.parameters())]
+    for p in list(m1.parameters()) + list(m2.parameters()):
+        p.grad = None
+    (got.float() * cot.float()).sum().backward()
+    assert torch.equal(xa.grad.float(), xb.grad.float())
+    for p, g in zip(list(m1.parameters()) + list(m2.parameters()), g_ref):
+        assert rel_l2(p.grad, g) < 1e-5          # wgrad atomics: order-dependent rounding only
+    # partial in-place: first input produced in place, second copied
+    buf2 = ops.empty_nhwc(3, 64, 18, 14, dev())
+    with torch.no_grad():
+        a2 = m1(x, out=buf2[:, :24])
+        other = m2(x)
+        got2 = ops.cat([a2, other], into=buf2)
+        ref2 = ops.cat([m1(x), m2(x)])
+    assert got2.data_ptr() == buf2.data_ptr() and torch.equal(got2.float(), ref2.float())
+    with pytest.raises(Exception):
+        m1(x, out=buf2[:, :16])               # wrong slice width
