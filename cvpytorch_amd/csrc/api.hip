@@ -215,6 +215,44 @@ __global__ void probe_tr16_kernel(const bf16_t* in, bf16_t* out) {
   for (int e = 0; e < 4; ++e) out[l * 4 + e] = v[e];
 }
 
+// Grid-barrier probe (tools/barrier_probe.py): is a device-wide barrier inside a persistent kernel cheap enough on MI355X (8 XCDs,
+// non-coherent L2s) to fuse reduce-then-apply passes? mode 0: partials by plain stores + __threadfence() both sides;
+// mode 1: partials by agent-scope atomic stores / loads (cache-bypassing), no fence. The counter self-resets (generation = target).
+__global__ __launch_bounds__(256) void probe_grid_barrier_kernel(int mode, int iters, float* scratch, unsigned* counter, float* out) {
+  const int t = threadIdx.x;
+  float acc = 0.f;
+  for (int it = 0; it < iters; ++it) {
+    float* part = scratch + (size_t)(it & 1) * gridDim.x;
+    const float mine = (float)(blockIdx.x + 1 + it);
+    if (t == 0) {
+      if (mode == 0) {
+        part[blockIdx.x] = mine;
+        __threadfence();
+      } else {
+        __hip_atomic_store(&part[blockIdx.x], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      const unsigned target = (unsigned)(it + 1) * gridDim.x;
+      __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+      if (mode == 0) __threadfence();
+    }
+    __syncthreads();
+    float s = 0.f;
+    for (int i = t; i < (int)gridDim.x; i += 256)
+      s += mode == 0 ? part[i] : __hip_atomic_load(&part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    acc += s;
+    __syncthreads();
+  }
+  __shared__ float red[256];
+  red[t] = acc;
+  __syncthreads();
+  if (t == 0) {
+    float s = 0.f;
+    for (int i = 0; i < 256; ++i) s += red[i];
+    out[blockIdx.x] = s;
+  }
+}
+
 }  // namespace cvhip
 
 using namespace cvhip;
@@ -375,6 +413,12 @@ int cvhip_probe_ds_read_tr16(const void* in, void* out, void* stream) {
   if (!in || !out) return CVHIP_ERR_INVALID;
   hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out);
   return check_launch("probe_tr16_kernel");
+}
+
+int cvhip_probe_grid_barrier(int32_t mode, int32_t iters, int32_t blocks, float* scratch, uint32_t* counter_zeroed, float* out, void* stream) {
+  if (!scratch || !counter_zeroed || !out || iters <= 0 || blocks <= 0 || blocks > 1024) return CVHIP_ERR_INVALID;
+  hipLaunchKernelGGL(probe_grid_barrier_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mode, iters, scratch, counter_zeroed, out);
+  return check_launch("probe_grid_barrier_kernel");
 }
 
 int cvhip_probe_lds_read_bw(int32_t mode, int32_t iters, int32_t blocks, float* out, void* stream) {

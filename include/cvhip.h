@@ -410,6 +410,10 @@ int cvhip_probe_mfma_16x16x32(const void* a_bf16_16x32, const void* b_bf16_32x16
 int cvhip_probe_ds_read_tr16(const void* in_bf16_64x4, void* out_bf16_64x4, void* stream);
 /* LDS read-bandwidth probe (dev tool, tools/lds_probe.py): `blocks` x 256 threads issue the implicit-GEMM main loop's
  * ds_read_b128 fragment pattern `iters` times. mode 0 swizzled, 1 unswizzled, 2 linear, 3 as 2 x ds_read_b64. */
+/* probe: `iters` device-wide barriers inside one persistent launch of `blocks` (<= resident capacity) blocks; every block then
+ * sums the other blocks' per-iteration values (checks visibility across the 8 non-coherent L2s). mode 0 = plain stores +
+ * __threadfence, 1 = agent-scope atomic stores/loads without fences. `counter_zeroed`: one zeroed uint32; `scratch`: 2*blocks floats. */
+int cvhip_probe_grid_barrier(int32_t mode, int32_t iters, int32_t blocks, float* scratch, uint32_t* counter_zeroed, float* out, void* stream);
 int cvhip_probe_lds_read_bw(int32_t mode, int32_t iters, int32_t blocks, float* out, void* stream);
 
 #ifdef __cplusplus
