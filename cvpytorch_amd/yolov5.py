@@ -315,6 +315,20 @@ def targets_to_tensor(targets, max_targets=None, device=None):
 # ------------------------------------------------------------------------------------------------------
 # post-process
 # ------------------------------------------------------------------------------------------------------
+def unletterbox_boxes(boxes, pad, scale, width, height):
+    """src/models/yolov5.py:269-284 without the device -> host -> numpy -> device round trip per image: remove the letterbox
+    padding (pad = (pad_h, pad_w)), undo the resize (scale = (scale_h, scale_w)), clip to the original (width, height). Same fp32
+    operations in the same order, so the result equals the reference's numpy code bit for bit. boxes (n, 4) xyxy."""
+    dev, dt = boxes.device, boxes.dtype
+    as_t = lambda v: torch.as_tensor(v, device=dev).to(dt).reshape(-1)  # noqa: E731
+    pad, scale, width, height = as_t(pad), as_t(scale), as_t(width), as_t(height)
+    sub = torch.stack((pad[1], pad[0], pad[1], pad[0]))
+    div = torch.stack((scale[1], scale[0], scale[1], scale[0]))
+    hi = torch.stack((width[0], height[0], width[0], height[0]))
+    out = (boxes - sub) / div
+    return torch.minimum(torch.maximum(out, torch.zeros((), device=dev, dtype=dt)), hi)
+
+
 def xywh2xyxy(x):
     y = x.clone()
     y[:, 0] = x[:, 0] - x[:, 2] / 2
@@ -396,7 +410,10 @@ class YOLOv5(nn.Module):
         losses["box_loss"], losses["obj_loss"], losses["cls_loss"] = st[0], st[1], st[2]
         return losses
 
-    def forward(self, imgs, targets=None, mode="infer", **kwargs):
+    def forward(self, imgs, targets=None, mode="infer", meta=None, **kwargs):
+        """`meta` (val mode, optional): dict with per-image 'width', 'height', 'scales' (scale_h, scale_w), 'pads' (pad_h, pad_w) as
+        the reference's collate delivers them in `targets` (models/yolov5.py:266-267): boxes are then mapped back to the original
+        images ON THE DEVICE (unletterbox_boxes) instead of through numpy on the host."""
         if mode == "infer":
             return
         gts = targets if torch.is_tensor(targets) else targets_to_tensor(targets, self.max_targets, imgs.device)
@@ -406,7 +423,10 @@ class YOLOv5(nn.Module):
             outputs = []
             if out is not None:
                 preds = non_max_suppression(out, self.conf_thres, self.iou_thres, multi_label=True)
-                for pred in preds:
-                    outputs.append({"boxes": pred[:, :4], "labels": pred[:, 5], "scores": pred[:, 4]})
+                for i, pred in enumerate(preds):
+                    boxes = pred[:, :4]
+                    if meta is not None:
+                        boxes = unletterbox_boxes(boxes, meta["pads"][i], meta["scales"][i], meta["width"][i], meta["height"][i])
+                    outputs.append({"boxes": boxes, "labels": pred[:, 5], "scores": pred[:, 4]})
             return losses, outputs
         return losses

@@ -556,6 +556,24 @@ class YOLOv5(nn.Module):
         return losses
 
 
+def unpad_scale_clip_numpy(pred, pad, scale, width, height):
+    """src/models/yolov5.py:269-284, verbatim order of operations in numpy: letterbox padding removed, resize scale undone,
+    boxes clipped to the original image. pred (n, 6) [x1, y1, x2, y2, score, label]; pad = (pad_h, pad_w), scale = (scale_h, scale_w)."""
+    import numpy as np
+    scale = np.asarray(scale.cpu().numpy() if torch.is_tensor(scale) else scale)
+    pad = np.asarray(pad.cpu().numpy() if torch.is_tensor(pad) else pad)
+    width = np.asarray(width.cpu().numpy() if torch.is_tensor(width) else width)
+    height = np.asarray(height.cpu().numpy() if torch.is_tensor(height) else height)
+    b = pred.clone()[:, :4].cpu().numpy()
+    b[:, [0, 2]] -= pad[1]
+    b[:, [1, 3]] -= pad[0]
+    b[:, [0, 2]] /= scale[1]
+    b[:, [1, 3]] /= scale[0]
+    b[:, [0, 2]] = b[:, [0, 2]].clip(0, width)
+    b[:, [1, 3]] = b[:, [1, 3]].clip(0, height)
+    return {"boxes": torch.tensor(b), "labels": pred[:, 5], "scores": pred[:, 4]}
+
+
 def synthetic_batch(batch, size=640, num_classes=80, seed=1029, max_boxes=20):
     """randn images; per image U{1..max_boxes} boxes, labels U{0..nc-1},
     cx,cy ~ U(.1,.9), w,h ~ U(.02,.5) clipped to the image; seed 1029 (trainer.py:55)."""

@@ -1,0 +1,26 @@
+"""Val post-process on the device: cvpytorch_amd.yolov5.unletterbox_boxes must equal the reference's numpy
+sequence (src/models/yolov5.py:269-284, restated in oracle/torch_ref.py) bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+from cvpytorch_amd import yolov5
+from oracle import torch_ref as R
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_unletterbox_equals_reference_numpy(seed):
+    g = torch.Generator().manual_seed(seed)
+    n = int(torch.randint(0, 200, (1,), generator=g)) if seed else 0      # seed 0: empty prediction list
+    xy = torch.rand(n, 2, generator=g) * 700 - 30
+    wh = torch.rand(n, 2, generator=g) * 300
+    pred = torch.cat([xy, xy + wh, torch.rand(n, 1, generator=g), torch.randint(0, 80, (n, 1), generator=g).float()], 1)
+    pad = torch.tensor([float(torch.randint(0, 60, (1,), generator=g)), float(torch.randint(0, 60, (1,), generator=g))])
+    scale = torch.rand(2, generator=g) * 1.5 + 0.3
+    width, height = torch.tensor(float(torch.randint(100, 900, (1,), generator=g))), torch.tensor(float(torch.randint(100, 900, (1,), generator=g)))
+    want = R.unpad_scale_clip_numpy(pred, pad, scale, width, height)["boxes"]
+    got = yolov5.unletterbox_boxes(pred[:, :4], pad, scale, width, height)
+    assert got.shape == want.shape and torch.equal(got, want)
+    # python scalars / numpy inputs are accepted too
+    got2 = yolov5.unletterbox_boxes(pred[:, :4], pad.numpy(), scale.tolist(), float(width), np.float32(height))
+    assert torch.equal(got2, want)
