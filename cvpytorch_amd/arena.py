@@ -36,6 +36,26 @@ def _dense_view(flat, off, like):
     return flat[off:off + like.numel()].as_strided(like.shape, like.stride())
 
 
+def paired_arena_order(items, follow):
+    """Arena order of `items` (tensors, in registration order) such that `follow[id(a)]` — the sibling tensor that must sit
+    directly behind `a` (ops.ConvBnActPair views the two as one tensor) — comes right after `a`. Returns (ordered items,
+    permutation: ordered[i] = items[perm[i]]). Tensors without a partner keep their relative order; a partner that is not in
+    `items` (frozen parameter) or was already placed is left where it is (the pair then simply runs unfused)."""
+    present = {id(t) for t in items}
+    out, placed = [], set()
+    for t in items:
+        if id(t) in placed:
+            continue
+        out.append(t)
+        placed.add(id(t))
+        nxt = follow.get(id(t))
+        if nxt is not None and id(nxt) in present and id(nxt) not in placed:
+            out.append(nxt)
+            placed.add(id(nxt))
+    pos = {id(t): i for i, t in enumerate(items)}
+    return out, [pos[id(t)] for t in out]
+
+
 class FlatTrainState:
     def __init__(self, model, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4, backbone_lr=None, ema_decay=0.9999,
                  use_ema=True, bucket_bytes=8 << 20, process_group=None):
@@ -58,19 +78,7 @@ class FlatTrainState:
                                 follow[id(ta)] = tb
 
         def paired_order(items):
-            present = {id(t) for t in items}
-            out, placed = [], set()
-            for t in items:
-                if id(t) in placed:
-                    continue
-                out.append(t)
-                placed.add(id(t))
-                nxt = follow.get(id(t))
-                if nxt is not None and id(nxt) in present and id(nxt) not in placed:
-                    out.append(nxt)
-                    placed.add(id(nxt))
-            pos = {id(t): i for i, t in enumerate(items)}
-            return out, [pos[id(t)] for t in out]
+            return paired_arena_order(items, follow)
 
         self.params, perm_p = paired_order([p for p in model.parameters() if p.requires_grad])
         dev = self.params[0].device
