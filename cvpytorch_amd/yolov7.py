@@ -61,13 +61,26 @@ class DownA(nn.Module):
         self.branch1 = nn.Sequential(HipMaxPool2d(kernel_size=2, stride=2), Conv(c1, c2, 1, 1))
         self.branch2 = nn.Sequential(Conv(c1, c2, 1, 1), Conv(c2, c2, 3, 2))
 
+    def _branches(self, x, extra=0):
+        """both branch results written straight into one concat buffer (plus `extra` trailing channels for DownB's y)"""
+        c2 = self.branch1[1].out_channels
+        a = self.branch1[0](x)
+        if not (x.is_cuda and c2 % 8 == 0 and extra % 8 == 0):
+            return None, self.branch1[1](a), self.branch2(x)
+        buf = ops.empty_nhwc(a.shape[0], 2 * c2 + extra, a.shape[2], a.shape[3], x.device)
+        b1 = self.branch1[1](a, out=buf[:, :c2])
+        b2 = self.branch2[1](self.branch2[0](x), out=buf[:, c2:2 * c2])
+        return buf, b1, b2
+
     def forward(self, x):
-        return ops.cat([self.branch1(x), self.branch2(x)])
+        _, b1, b2 = self._branches(x)
+        return ops.cat([b1, b2])
 
 
 class DownB(DownA):
     def forward(self, x, y):
-        return ops.cat([self.branch1(x), self.branch2(x), y])
+        buf, b1, b2 = self._branches(x, extra=y.shape[1])
+        return ops.cat([b1, b2, y], into=buf)   # only y is copied
 
 
 class EELAN(nn.Module):
@@ -123,11 +136,21 @@ class FeatureFusion(nn.Module):
         return [(self.conv1, self.conv2)]
 
     def forward(self, x):
-        x1, x2 = _siblings(self.conv1, self.conv2, x, self)
-        x3 = self.conv3(x2)
-        x4 = self.conv4(x3)
-        x5 = self.conv4(x4)
-        x6 = self.conv4(x5)
+        c2, mid = self.conv1.out_channels, self.conv3.out_channels
+        if x.is_cuda and c2 % 8 == 0 and mid % 8 == 0:   # all six producers write into their slice of the buffer conv7 reads
+            buf = ops.empty_nhwc(x.shape[0], 2 * c2 + 4 * mid, x.shape[2], x.shape[3], x.device)
+            o = 2 * c2
+            x1, x2 = _siblings(self.conv1, self.conv2, x, self, out=buf[:, :o])
+            x3 = self.conv3(x2, out=buf[:, o:o + mid])
+            x4 = self.conv4(x3, out=buf[:, o + mid:o + 2 * mid])
+            x5 = self.conv4(x4, out=buf[:, o + 2 * mid:o + 3 * mid])
+            x6 = self.conv4(x5, out=buf[:, o + 3 * mid:])
+        else:
+            x1, x2 = _siblings(self.conv1, self.conv2, x, self)
+            x3 = self.conv3(x2)
+            x4 = self.conv4(x3)
+            x5 = self.conv4(x4)
+            x6 = self.conv4(x5)
         return self.conv7(ops.cat([x1, x2, x3, x4, x5, x6]))
 
 
@@ -148,7 +171,16 @@ class SPPCSPC(nn.Module):
         return [(self.cv1, self.cv2)]
 
     def forward(self, x):
+        c_ = self.cv1.out_channels
+        inplace = x.is_cuda and c_ % 8 == 0
         a, b = _siblings(self.cv1, self.cv2, x, self)
+        if inplace:
+            pool_buf = ops.empty_nhwc(x.shape[0], 4 * c_, x.shape[2], x.shape[3], x.device)
+            x1 = self.cv4(self.cv3(a), out=pool_buf[:, :c_])
+            pooled = ops.cat([x1] + [m(x1) for m in self.m], into=pool_buf)      # the pools are copied, x1 is in place
+            out_buf = ops.empty_nhwc(x.shape[0], 2 * c_, x.shape[2], x.shape[3], x.device)
+            y1 = self.cv6(self.cv5(pooled), out=out_buf[:, :c_])
+            return self.cv7(ops.cat([y1, b], into=out_buf))
         x1 = self.cv4(self.cv3(a))
         y1 = self.cv6(self.cv5(ops.cat([x1] + [m(x1) for m in self.m])))
         return self.cv7(ops.cat([y1, b]))
