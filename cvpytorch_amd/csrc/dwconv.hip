@@ -5,6 +5,8 @@
 // Reference: src/models/bricks/depthwise_separable_conv_module.py:76-94 as used by
 // src/models/heads/seg/deeplabv3plus_head.py:18-30,49-54 (3x3, dilation 1/12/24/36).
 #include <string.h>
+#include <stdlib.h>
+
 #include "common.h"
 #include "conv_plan.h"
 
@@ -274,24 +276,34 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const Dw3Params p) {
         win[r][0] = dw3_load(rp[r], rok[r], q0 - p.pw, p.IW, p.in_ld, c);
         win[r][1] = dw3_load(rp[r], rok[r], q0 - p.pw + 1, p.IW, p.in_ld, c);
       }
-      // software pipeline: the raw 16-B loads of the NEXT pixel's new window column (and dy) are in flight while this
-      // pixel's 72 FMAs run (the window dependency would otherwise expose one memory round trip per pixel)
-      uint4 nraw[3], ndy;
-      auto issue = [&](int q) {
+      // software pipeline: the raw 16-B loads of the new window columns (and dy) of the NEXT kDw3Ahead pixels are in flight
+      // while this pixel's 72 FMAs run. With weights + window in registers only 2 waves fit a SIMD, so one pixel of lookahead
+      // left the walk latency-bound (3 x 16 B per lane per ~2 us round trip: 1.3 TB/s algorithmic on the 319 MB DeepLabv3+
+      // decoder tensors); three pixels ahead triple the bytes in flight.
+      constexpr int kDw3Ahead = 3;
+      uint4 nraw[kDw3Ahead][3], ndy[kDw3Ahead];
+      auto issue = [&](int q, uint4 (&raw)[3], uint4& dyv) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
           const int iw = q - p.pw + 2;
-          const bool ok = rok[r] && (unsigned)iw < (unsigned)p.IW;
-          nraw[r] = ok ? *reinterpret_cast<const uint4*>(rp[r] + (int64_t)iw * p.in_ld + c) : uint4{0u, 0u, 0u, 0u};
+          const bool ok = q < q1 && rok[r] && (unsigned)iw < (unsigned)p.IW;
+          raw[r] = ok ? *reinterpret_cast<const uint4*>(rp[r] + (int64_t)iw * p.in_ld + c) : uint4{0u, 0u, 0u, 0u};
         }
-        if (MODE == 1) ndy = *reinterpret_cast<const uint4*>(p.dy + ((int64_t)row * p.OW + q) * p.dy_ld + c);
+        if (MODE == 1) dyv = q < q1 ? *reinterpret_cast<const uint4*>(p.dy + ((int64_t)row * p.OW + q) * p.dy_ld + c) : uint4{0u, 0u, 0u, 0u};
       };
-      issue(q0);
+#pragma unroll
+      for (int a = 0; a < kDw3Ahead; ++a) issue(q0 + a, nraw[a], ndy[a]);
       for (int q = q0; q < q1; ++q) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) win[r][2] = unpack8(nraw[r]);
-        const uint4 cdy = ndy;
-        if (q + 1 < q1) issue(q + 1);
+        for (int r = 0; r < 3; ++r) win[r][2] = unpack8(nraw[0][r]);
+        const uint4 cdy = ndy[0];
+#pragma unroll
+        for (int a = 0; a + 1 < kDw3Ahead; ++a) {  // rotate the ring (register moves: cheap next to 72 FMAs)
+#pragma unroll
+          for (int r = 0; r < 3; ++r) nraw[a][r] = nraw[a + 1][r];
+          ndy[a] = ndy[a + 1];
+        }
+        issue(q + kDw3Ahead, nraw[kDw3Ahead - 1], ndy[kDw3Ahead - 1]);
         if (MODE == 0) {
           f32x8 o;
 #pragma unroll
@@ -345,17 +357,28 @@ static bool dw3_applicable(const DwParams& p, const void* a, const void* b2, con
          (p.y_ld & 7) == 0 && p.ph <= 2 && p.pw <= 2 && ((((uintptr_t)a) | ((uintptr_t)b2) | ((uintptr_t)c2)) & 15) == 0;
 }
 
-static void dw3_launch_geom(Dw3Params& q, int* grid) {
+static void dw3_launch_geom(Dw3Params& q, int* grid, bool wgrad = false) {
   const int CV = q.C >> 3;
   const int cols = CV < 256 ? CV : 256;
   const int rpp = 256 / cols;
-  q.seg_len = q.OW <= 96 ? q.OW : 64;
+  static int seg_env = -1, rpt_env = -1;
+  if (seg_env < 0) {
+    const char* e = getenv("CVHIP_DW3_SEG");
+    seg_env = e ? atoi(e) : 0;
+    const char* f = getenv("CVHIP_DW3_RPT");
+    rpt_env = f ? atoi(f) : 0;
+  }
+  // row segment one thread walks: 64 columns for fprop / dgrad; the weight-gradient walk keeps 9 x 8 sums in registers and
+  // pays an LDS fold + atomics per block, so it takes whole rows up to 256 columns (tools/dw_bench.py: 397 -> 262 us on the
+  // DeepLabv3+ decoder's 304-channel tensor)
+  q.seg_len = seg_env > 0 ? seg_env : (wgrad ? (q.OW <= 256 ? q.OW : 128) : (q.OW <= 96 ? q.OW : 64));
   const int nseg = (q.OW + q.seg_len - 1) / q.seg_len;
   const int ncv = (CV + cols - 1) / cols;
   const int64_t rows = (int64_t)q.N * q.OH;
   // enough blocks to fill the chip (>= ~2048), at most 4 image rows per thread
   int rpt = 4;
   while (rpt > 1 && cdiv64(rows, (int64_t)rpp * rpt) * nseg * ncv < 2048) rpt >>= 1;
+  if (rpt_env > 0) rpt = rpt_env;
   q.rows_per_thread = rpt;
   *grid = (int)(cdiv64(rows, (int64_t)rpp * rpt) * nseg * ncv);
 }
@@ -472,7 +495,7 @@ int cvhip_dwconv2d_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy
     q.N = p.N; q.C = p.C; q.IH = p.H; q.IW = p.W; q.OH = p.P; q.OW = p.Q; q.ph = p.ph; q.pw = p.pw;
     q.in_ld = p.x_ld; q.dy_ld = p.y_ld;
     int grid;
-    dw3_launch_geom(q, &grid);
+    dw3_launch_geom(q, &grid, true);
     hipLaunchKernelGGL(dw3x3_kernel<1>, dim3(grid), dim3(256), 0, s, q);
     return check_launch("dw3x3_kernel<1>");
   }
