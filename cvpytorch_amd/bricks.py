@@ -605,7 +605,7 @@ class HipConvModule(nn.Module):
             return None
         return bn, aid
 
-    def forward(self, x, activate=True, norm=True, residual=None, out=None):
+    def forward(self, x, activate=True, norm=True, residual=None, out=None, dx_link=None, res_link=None):
         """`out`: optional NHWC channel-slice view that receives the result (concat elimination: the caller hands every
         producer its slice of the concat buffer, ops.cat then has nothing to copy). Ignored on the unfused fallback path."""
         fus = self._fusable(activate, norm)
@@ -615,6 +615,7 @@ class HipConvModule(nn.Module):
             x, w = conv._effective(x)
             cfg = conv.make_cfg(aid, ap, bn)
             cfg.out = out
+            cfg.dx_link, cfg.res_link = dx_link, (res_link if residual is not None else None)
             if bn is not None:
                 bn_tick(bn)
                 return ops.conv_bn_act(x, w, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, cfg)

@@ -357,13 +357,14 @@ int cvhip_conv2d_fprop(const cvhip_conv_desc* d, const void* x, const void* w, c
   return launch_igemm(p, (hipStream_t)stream);
 }
 
-int cvhip_conv2d_dgrad(const cvhip_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, void* stream) {
+static int dgrad_impl(const cvhip_conv_desc* d, const void* dy, const void* w_dgrad, const void* addend, int addend_ld, void* dx, void* stream) {
   int st = validate_dense_desc(d);
   if (st) return st;
   if (!dy || !w_dgrad || !dx) return CVHIP_ERR_INVALID;
   // the gathered operand is dy: its channel count / pitch must be 16-byte vectorisable
   if ((d->K & 7) || (d->y_ld & 7)) return CVHIP_ERR_UNSUPPORTED;
   if ((((uintptr_t)dy) & 15) || (((uintptr_t)w_dgrad) & 15)) return CVHIP_ERR_INVALID;
+  if (addend && addend_ld < d->C) return CVHIP_ERR_INVALID;
   IgemmParams p;
   plan_dgrad(d, &p);
   p.x = (const bf16_t*)dy;
@@ -371,8 +372,20 @@ int cvhip_conv2d_dgrad(const cvhip_conv_desc* d, const void* dy, const void* w_d
   p.y = (bf16_t*)dx;
   p.bias = nullptr;
   p.stats = nullptr;
+  p.res = (const bf16_t*)addend;
+  p.res_ld = addend_ld;
   p.y_vec_ok = ((d->x_ld & 3) == 0) && ((((uintptr_t)dx) & 7) == 0);
   return launch_igemm(p, (hipStream_t)stream);
+}
+
+int cvhip_conv2d_dgrad(const cvhip_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, void* stream) {
+  return dgrad_impl(d, dy, w_dgrad, nullptr, 0, dx, stream);
+}
+
+int cvhip_conv2d_dgrad_add(const cvhip_conv_desc* d, const void* dy, const void* w_dgrad, const void* addend, int32_t addend_ld, void* dx,
+                           void* stream) {
+  if (!addend) return CVHIP_ERR_INVALID;
+  return dgrad_impl(d, dy, w_dgrad, addend, addend_ld, dx, stream);
 }
 
 int cvhip_conv2d_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate, void* stream) {

@@ -167,6 +167,18 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernA
             v.v[4 + q] += b1[q];
           }
         }
+        if (p.res && m < M) {  // skip-connection gradient folded into the epilogue
+          const bf16_t* rrow = p.res + (int64_t)m * p.res_ld + ch0;
+          if (ch0 + 7 < p.Nout && (p.res_ld & 7) == 0 && ((((uintptr_t)p.res) & 15) == 0)) {
+            const f32x8 rv = unpack8(*reinterpret_cast<const uint4*>(rrow));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v.v[q] += rv.v[q];
+          } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+              if (ch0 + q < p.Nout) v.v[q] += (float)rrow[q];
+          }
+        }
         if (m < M) {
           if (vec16 && ch0 + 7 < p.Nout) {
             *reinterpret_cast<uint4*>(yrow + ch0) = pack8(v);

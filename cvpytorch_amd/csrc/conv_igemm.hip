@@ -476,6 +476,21 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmKernArgs p
         v2 += bv[2];
         v3 += bv[3];
       }
+      if (p.res) {  // skip-connection gradient folded into dgrad's epilogue (replaces autograd's accumulation add)
+        const bf16_t* rrow = p.res + opix * p.res_ld + n;
+        if (n + 3 < p.Nout && (p.res_ld & 3) == 0 && ((((uintptr_t)p.res) & 7) == 0)) {
+          const uint2 u = *reinterpret_cast<const uint2*>(rrow);   // 4 consecutive channels, like the store below
+          v0 += __uint_as_float(u.x << 16);
+          v1 += __uint_as_float(u.x & 0xffff0000u);
+          v2 += __uint_as_float(u.y << 16);
+          v3 += __uint_as_float(u.y & 0xffff0000u);
+        } else {
+          if (n < p.Nout) v0 += (float)rrow[0];
+          if (n + 1 < p.Nout) v1 += (float)rrow[1];
+          if (n + 2 < p.Nout) v2 += (float)rrow[2];
+          if (n + 3 < p.Nout) v3 += (float)rrow[3];
+        }
+      }
       if (p.y_vec_ok && n + 3 < p.Nout) {
         uint2 u;
         u.x = pack2(v0, v1);
@@ -588,6 +603,7 @@ static int launch_group(IgemmKernArgs& p, hipStream_t stream) {
   }
   if constexpr (WM == 64 && BM >= 128 && (BM != 128 || BN == 128)) {
     if (use_v1()) {
+      if (p.res) return CVHIP_ERR_UNSUPPORTED;
       hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), dim3(total), dim3(256), 0, stream, p);
       return check_launch("igemm_kernel");
     }

@@ -41,6 +41,8 @@ struct IgemmCommon {
   int n_tiles, total_tiles, ncls;
   int y_vec_ok;
   int interleave;  // 1: logical tile id = spatial tile * ncls + class (classes with equal tile counts: stride-parity dgrad)
+  const bf16_t* res;  // optional addend, same pixel grid and channel count as y (dgrad: the gradient arriving over a skip connection)
+  int res_ld;
 };
 
 constexpr int kKernelClasses = 4;

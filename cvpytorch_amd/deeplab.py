@@ -21,9 +21,13 @@ from .bricks import HipConvModule as ConvModule
 from .bricks import HipDepthwiseSeparableConvModule as DepthwiseSeparableConvModule
 
 
-def _cba(x, conv, bn, act, residual=None):
+_GRAD_LINK = __import__("os").environ.get("CVHIP_GRAD_LINK", "1") != "0"
+
+
+def _cba(x, conv, bn, act, residual=None, dx_link=None):
     """conv -> bn -> act as ONE fused op (conv and bn are sibling modules, torchvision style)."""
     cfg = conv.make_cfg(act, 0.0, bn)
+    cfg.dx_link = dx_link
     bn_tick(bn)
     xx, w = conv._effective(x)
     return ops.conv_bn_act(xx, w, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, cfg)
@@ -46,11 +50,13 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = _cba(x, self.conv1, self.bn1, L.ACT_RELU)
+        # identity blocks: the skip connection's gradient is added in conv1's dgrad epilogue (ops.GradLink), not by autograd
+        link = ops.GradLink() if (_GRAD_LINK and self.downsample is None and x.requires_grad and torch.is_grad_enabled()) else None
+        out = _cba(x, self.conv1, self.bn1, L.ACT_RELU, dx_link=link)
         out = _cba(out, self.conv2, self.bn2, L.ACT_RELU)
         out = _cba(out, self.conv3, self.bn3, L.ACT_NONE)
         identity = x if self.downsample is None else _cba(x, self.downsample[0], self.downsample[1], L.ACT_NONE)
-        return ops.add_act(out, identity, L.ACT_RELU)
+        return ops.add_act(out, identity, L.ACT_RELU, link=link)
 
 
 class ResNet(nn.Module):

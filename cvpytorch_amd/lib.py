@@ -75,6 +75,7 @@ SIGNATURES = {
     "cvhip_prep_plan_run": (_i32, [_p, _i32, _i32, _p]),
     "cvhip_conv2d_fprop": (_i32, [_dp, _p, _p, _p, _p, _p, _p]),
     "cvhip_conv2d_dgrad": (_i32, [_dp, _p, _p, _p, _p]),
+    "cvhip_conv2d_dgrad_add": (_i32, [_dp, _p, _p, _p, _i32, _p, _p]),
     "cvhip_conv2d_wgrad": (_i32, [_dp, _p, _p, _p, _i32, _p]),
     "cvhip_dwconv2d_fprop": (_i32, [_dp, _p, _p, _p, _p, _p]),
     "cvhip_dwconv2d_dgrad": (_i32, [_dp, _p, _p, _p, _p]),

@@ -321,7 +321,7 @@ def conv_states_of(model):
 class ConvCfg:
     """Static configuration of one conv(+BN+act) layer (python-side)."""
     __slots__ = ("stride", "pad", "dil", "groups", "act", "act_param", "has_bn", "bn_training", "momentum", "eps",
-                 "state", "track", "vkey", "gw", "gb", "gg", "gbeta", "arena", "idx_w", "idx_b", "idx_bn", "sync", "out", "out_split")
+                 "state", "track", "vkey", "gw", "gb", "gg", "gbeta", "arena", "idx_w", "idx_b", "idx_bn", "sync", "out", "out_split", "dx_link", "res_link")
 
     def __init__(self, stride, pad, dil, groups=1, act=L.ACT_NONE, act_param=0.0, has_bn=False, bn_training=True,
                  momentum=0.1, eps=1e-5, state=None, track=True):
@@ -340,6 +340,11 @@ class ConvCfg:
         # fresh tensor; `out_split` = (k1, view): channels [k1, K) go to `view`, channels [0, k1) to a fresh tensor (sibling pairs)
         self.out = None
         self.out_split = None
+        # skip-connection gradient fusion (GradLink): `res_link` on the layer whose BN+act pass adds the residual parks that
+        # branch's gradient in the link instead of returning it; `dx_link` on the layer that consumes the same tensor folds it
+        # into its dgrad epilogue (cvhip_conv2d_dgrad_add)
+        self.dx_link = None
+        self.res_link = None
 
 
 # ---- SyncBatchNorm plumbing (trainer.py:126-127 -> torch.nn.SyncBatchNorm semantics) -------------------------------------
@@ -367,6 +372,17 @@ def _sync_bwd_sums(dgamma, dbeta, sync):
 
 def _colreduce_rows(M, Cc):
     return L.load().cvhip_colreduce_rows(M, Cc)
+
+
+class GradLink:
+    """One skip connection x -> (conv_a -> ... -> + x): carries the gradient of the identity branch from the op that performs the
+    add (which returns None for that input, so autograd has nothing to accumulate) to conv_a's backward, whose dgrad kernel adds
+    it in its epilogue. Created per forward call by the block that owns the skip connection; only when x requires grad."""
+    __slots__ = ("g", "ok")
+
+    def __init__(self):
+        self.g = None
+        self.ok = False   # set by the consuming layer's forward once it is certain to run a dense dgrad on the unpadded input
 
 
 def _check_out(out, N, K, P, Q):
@@ -464,6 +480,15 @@ def _conv_grads(ctx, x, weight, dy, dy_ld, need_dx, need_dw, need_db):
                 raise L.CvhipError("dgrad weight image missing (input started requiring grad after forward)")
             dx = empty_nhwc(N, Cc, H, W, dev)
             ddesc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, Cc, dy_ld, kv, cv)
+            link = cfg.dx_link
+            if link is not None and link.g is not None and ctx.c_orig == Cc:
+                g, g_ld = as_nhwc(link.g)
+                link.g = None
+                if tuple(g.shape) != (N, Cc, H, W):
+                    raise L.CvhipError("GradLink: skip-connection gradient %s does not match the layer input %s" % (tuple(g.shape), (N, Cc, H, W)))
+                _timed_call(_igemm_name(Cc, N * H * W, -(-R // cfg.stride[0]) * -(-S // cfg.stride[1]) * Kp, _pointwise(R, S, cfg), dy_ld), (N, Cc, H, W, K, R, S, P, Q),
+                            "cvhip_conv2d_dgrad_add", C.byref(ddesc), dy.data_ptr(), ctx.w_dgrad.data_ptr(), g.data_ptr(), g_ld, dx.data_ptr(), st)
+                return dx, dw, dbias
             _timed_call(_igemm_name(Cc, N * H * W, -(-R // cfg.stride[0]) * -(-S // cfg.stride[1]) * Kp, _pointwise(R, S, cfg), dy_ld), (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv2d_dgrad", C.byref(ddesc), dy.data_ptr(),
                         ctx.w_dgrad.data_ptr(), dx.data_ptr(), st)
     if dw is not None and dw.dtype != weight.dtype:
@@ -506,6 +531,8 @@ class ConvBnAct(torch.autograd.Function):
         kv = K if Kp != K else 0
         cv = Cg if (not depthwise and Cg != Cc) else 0
         need_dx = ctx.needs_input_grad[0]
+        if cfg.dx_link is not None:
+            cfg.dx_link.ok = bool(need_dx and not depthwise and c_orig == Cc)   # (grad mode is checked where the link is created)
         y = empty_nhwc(N, K, P, Q, dev, ld=Kp)
         st = _stream()
         train_bn = cfg.has_bn and cfg.bn_training
@@ -645,6 +672,9 @@ class ConvBnAct(torch.autograd.Function):
                 dy, dy_ld = buf.permute(0, 3, 1, 2)[:, :K], Kp
         dx, dw, dbias = _conv_grads(ctx, x, weight, dy, dy_ld, need_dx, need_dw, need_db)
         dres = dz if ctx.has_res else None
+        if dres is not None and cfg.res_link is not None and cfg.res_link.ok:
+            cfg.res_link.g = dres   # handed to the skip connection's first layer (GradLink); nothing for autograd to add
+            dres = None
         if dx is not None and ctx.c_orig != Cc:
             dx = dx[:, :ctx.c_orig]  # channel slice of the padded gradient buffer (an NHWC view with ld = round8(C))
         return dx, dw, dbias, (dgamma if need_dg else None), (dbeta if need_dbeta else None), None, None, dres, None
@@ -952,7 +982,8 @@ class AddAct(torch.autograd.Function):
     activations whose derivative is a function of the output's sign: ReLU / LeakyReLU)."""
 
     @staticmethod
-    def forward(ctx, a, b, act, act_param):
+    def forward(ctx, a, b, act, act_param, link=None):
+        ctx.link = link
         if act not in (L.ACT_RELU, L.ACT_LEAKY, L.ACT_NONE):
             raise L.CvhipError("add_act supports none / ReLU / LeakyReLU")
         a, la = as_nhwc(a)
@@ -969,16 +1000,20 @@ class AddAct(torch.autograd.Function):
         (out,) = ctx.saved_tensors
         N, Cc, H, W, act, ap = ctx.meta
         if act == L.ACT_NONE:
-            return dz, dz, None, None
-        dz, ld = as_nhwc(dz)
-        du = empty_nhwc(N, Cc, H, W, dz.device)
-        L.call("cvhip_bn_act_bwd_apply", dz.data_ptr(), ld, out.data_ptr(), Cc, du.data_ptr(), Cc, N * H * W, Cc, None, None, None, None,
-               None, None, act, ap, _stream())
-        return du, du, None, None
+            du = dz
+        else:
+            dz, ld = as_nhwc(dz)
+            du = empty_nhwc(N, Cc, H, W, dz.device)
+            L.call("cvhip_bn_act_bwd_apply", dz.data_ptr(), ld, out.data_ptr(), Cc, du.data_ptr(), Cc, N * H * W, Cc, None, None, None, None,
+                   None, None, act, ap, _stream())
+        if ctx.link is not None and ctx.link.ok and ctx.needs_input_grad[1]:
+            ctx.link.g = du      # the identity branch's gradient travels through the GradLink (no accumulation add)
+            return du, None, None, None, None
+        return du, du, None, None, None
 
 
-def add_act(a, b, act=L.ACT_RELU, act_param=0.0):
-    return AddAct.apply(a, b, act, act_param)
+def add_act(a, b, act=L.ACT_RELU, act_param=0.0, link=None):
+    return AddAct.apply(a, b, act, act_param, link)
 
 
 class ScaleNC(torch.autograd.Function):

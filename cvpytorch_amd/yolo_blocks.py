@@ -9,6 +9,7 @@ What differs from the reference is only *how* the glue ops execute:
 """
 import os
 
+import torch
 import torch.nn as nn
 
 from . import ops
@@ -18,6 +19,7 @@ from .bricks import HipMaxPool2d, HipUpsampleNearest2x, bn_tick, sync_of
 
 _PAIR_ENABLED = os.environ.get("CVHIP_PAIR", "1") != "0"
 _CAT_INPLACE = os.environ.get("CVHIP_CAT_INPLACE", "1") != "0"
+_GRAD_LINK = os.environ.get("CVHIP_GRAD_LINK", "1") != "0"
 
 
 def sibling_pair_forward(m1, m2, x, owner, out2=None, out=None):
@@ -87,9 +89,12 @@ class DarknetBottleneck(nn.Module):
 
     def forward(self, x, out=None):
         """`out`: optional channel slice of a concat buffer for the block's result (see HipConvModule.forward)"""
-        h = self.conv1(x)
         if self.shortcut and not self.depthwise:
-            return self.conv2(h, residual=x, out=out)  # add fused into conv2's BN+act pass
+            # the shortcut's gradient rides into conv1's dgrad epilogue (ops.GradLink) instead of an autograd accumulation add
+            link = ops.GradLink() if (_GRAD_LINK and x.requires_grad and torch.is_grad_enabled()) else None
+            h = self.conv1(x, dx_link=link)
+            return self.conv2(h, residual=x, out=out, res_link=link)  # add fused into conv2's BN+act pass
+        h = self.conv1(x)
         if self.depthwise or self.shortcut:
             h = self.conv2(h)
             return ops.add(h, x) if self.shortcut else h

@@ -134,6 +134,11 @@ int cvhip_conv2d_fprop(const cvhip_conv_desc* d, const void* x_bf16, const void*
 /* dgrad: dx = conv_transpose(dy, w) — implicit GEMM over stride-parity classes (no wasted taps). */
 int cvhip_conv2d_dgrad(const cvhip_conv_desc* d, const void* dy_bf16, const void* w_dgrad_bf16,
                        void* dx_bf16, void* stream);
+/* dx = dgrad(dy) + addend: `addend` is a bf16 NHWC tensor on dx's pixel grid with d->C channels and pitch addend_ld — the gradient
+ * arriving over a skip connection (x feeds both this convolution and a residual add: yolo_modules.py:102, torchvision Bottleneck).
+ * Folding it into the epilogue replaces autograd's gradient-accumulation add (one read of dx + addend and one write less). */
+int cvhip_conv2d_dgrad_add(const cvhip_conv_desc* d, const void* dy_bf16, const void* w_dgrad_bf16, const void* addend_bf16,
+                           int32_t addend_ld, void* dx_bf16, void* stream);
 
 /* wgrad: dw[K][R][S][C] (fp32) (+)= sum over pixels dy^T * im2col(x); split-K over pixels with
  * fp32 atomics. accumulate==0 zero-fills dw first (hipMemsetAsync on `stream`). */

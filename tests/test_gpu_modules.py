@@ -299,3 +299,42 @@ def test_out_slices_and_copy_free_cat():
     assert got2.data_ptr() == buf2.data_ptr() and torch.equal(got2.float(), ref2.float())
     with pytest.raises(Exception):
         m1(x, out=buf2[:, :16])               # wrong slice width
+
+
+@pytest.mark.parametrize("kind", ["darknet", "resnet"])
+def test_grad_link_equals_autograd_accumulation(kind):
+    """Skip-connection gradient folded into conv1's dgrad epilogue (ops.GradLink / cvhip_conv2d_dgrad_add) == the gradient autograd
+    accumulates with a separate add (only the rounding point moves: the sum is formed in fp32 before the bf16 store)."""
+    from cvpytorch_amd import deeplab, ops, yolo_blocks
+    from cvpytorch_amd import lib as L
+    res = {}
+    for link in (True, False):
+        torch.manual_seed(5)
+        if kind == "darknet":
+            m = yolo_blocks.DarknetBottleneck(64, 64, 1.0, True, act_cfg=dict(type="SiLU")).to(dev()).train()
+            shape = (4, 64, 40, 36)
+        else:
+            m = deeplab.Bottleneck(256, 64).to(dev()).train()
+            shape = (2, 256, 33, 65)
+        yolo_blocks._GRAD_LINK = deeplab._GRAD_LINK = link
+        calls = []
+        orig = L.call
+        try:
+            L.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+            ops.L.call = L.call
+            x = torch.randn(shape, generator=torch.Generator().manual_seed(6)).to(dev()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            pre = ops.add(x, x)                  # non-leaf input, as inside a network
+            out = m(pre)
+            cot = torch.randn(out.shape, generator=torch.Generator().manual_seed(7)).to(dev()).to(out.dtype)
+            (out.float() * cot.float()).sum().backward()
+            torch.cuda.synchronize()
+        finally:
+            L.call = orig
+            ops.L.call = orig
+            yolo_blocks._GRAD_LINK = deeplab._GRAD_LINK = True
+        assert ("cvhip_conv2d_dgrad_add" in calls) == link
+        res[link] = (out.float().cpu(), x.grad.float().cpu(), [p.grad.float().cpu().clone() for p in m.parameters()])
+    assert torch.equal(res[True][0], res[False][0])
+    assert rel_l2(res[True][1], res[False][1]) < 5e-3
+    for a, b in zip(res[True][2], res[False][2]):
+        assert rel_l2(a, b) < 5e-3
