@@ -326,6 +326,25 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const BilParams p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
     const bf16_t* base = p.src + (int64_t)n * p.Ho * p.Wo * p.ld_src;
+    // column weights depend on ow only: computed once per thread (<= kBilCols columns: x4 upsampling visits 9), not per row
+    constexpr int kBilCols = 12;
+    float wcol[kBilCols];
+    const int ncol = ow_hi - ow_lo + 1;
+    const bool hoisted = ncol <= kBilCols;
+    if (hoisted) {
+#pragma unroll
+      for (int c = 0; c < kBilCols; ++c) {
+        float ww = 0.f;
+        if (c < ncol) {
+          int w0, w1;
+          float lw;
+          bil_src(ow_lo + c, p.sw, p.align, p.Wi, &w0, &w1, &lw);
+          if (w0 == iw) ww += 1.f - lw;
+          if (w1 == iw) ww += lw;
+        }
+        wcol[c] = ww;
+      }
+    }
     for (int oh = oh_lo; oh <= oh_hi; ++oh) {
       int h0, h1;
       float lh;
@@ -334,6 +353,18 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const BilParams p) {
       if (h0 == ih) wh += 1.f - lh;
       if (h1 == ih) wh += lh;
       if (wh == 0.f) continue;
+      if (hoisted) {
+#pragma unroll
+        for (int c = 0; c < kBilCols; ++c) {
+          if (c < ncol && wcol[c] != 0.f) {
+            const f32x8 g = load8(base + ((int64_t)oh * p.Wo + ow_lo + c) * p.ld_src, cv * 8, p.C, vec);
+            const float wgt = wh * wcol[c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += wgt * g.v[j];
+          }
+        }
+        continue;
+      }
       for (int ow = ow_lo; ow <= ow_hi; ++ow) {
         int w0, w1;
         float lw;
