@@ -743,6 +743,28 @@ int cvhip_bn_act_fwd(const void* y, int32_t ld_y, void* z, int32_t ld_z, int64_t
   return check_launch("ew_kernel<0>");
 }
 
+int cvhip_bn_add_act_fwd(const void* y, int32_t ld_y, void* z, int32_t ld_z, int64_t M, int32_t C, const float* scale,
+                         const float* shift, int32_t act, float act_param, const void* residual, int32_t ld_res, void* stream) {
+  if (!y || !z || !residual || M < 0 || C <= 0) return CVHIP_ERR_INVALID;
+  if (M == 0) return CVHIP_OK;
+  EwParams p{};
+  p.a = (const bf16_t*)y;
+  p.ld_a = ld_y;
+  p.out = (bf16_t*)z;
+  p.ld_out = ld_z;
+  p.res = (const bf16_t*)residual;
+  p.ld_res = ld_res;
+  p.M = M;
+  p.C = C;
+  p.scale = scale;
+  p.shift = shift;
+  p.act = act;
+  p.ap = act_param;
+  p.res_pre = 1;  // the residual joins BEFORE the activation
+  CVHIP_LAUNCH_ACT(ew_kernel, 0, act, dim3(ew_grid(M, C)), (hipStream_t)stream, p)
+  return check_launch("ew_kernel<0>(bn_add_act)");
+}
+
 int cvhip_bn_act_bwd_apply(const void* dz, int32_t ld_dz, const void* y, int32_t ld_y, void* dy, int32_t ld_dy,
                            int64_t M, int32_t C, const float* scale, const float* shift, const float* mean,
                            const float* invstd, const float* dgamma, const float* dbeta, int32_t act,

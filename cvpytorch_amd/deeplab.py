@@ -22,12 +22,16 @@ from .bricks import HipDepthwiseSeparableConvModule as DepthwiseSeparableConvMod
 
 
 _GRAD_LINK = __import__("os").environ.get("CVHIP_GRAD_LINK", "1") != "0"
+_FUSE_TAIL = __import__("os").environ.get("CVHIP_FUSE_TAIL", "1") != "0"
 
 
-def _cba(x, conv, bn, act, residual=None, dx_link=None):
-    """conv -> bn -> act as ONE fused op (conv and bn are sibling modules, torchvision style)."""
+def _cba(x, conv, bn, act, residual=None, dx_link=None, res_pre=False, res_link=None):
+    """conv -> bn -> act as ONE fused op (conv and bn are sibling modules, torchvision style); `res_pre`: the residual joins
+    before the activation (bottleneck tail)."""
     cfg = conv.make_cfg(act, 0.0, bn)
     cfg.dx_link = dx_link
+    cfg.res_pre = res_pre
+    cfg.res_link = res_link if residual is not None else None
     bn_tick(bn)
     xx, w = conv._effective(x)
     return ops.conv_bn_act(xx, w, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, cfg)
@@ -54,8 +58,10 @@ class Bottleneck(nn.Module):
         link = ops.GradLink() if (_GRAD_LINK and self.downsample is None and x.requires_grad and torch.is_grad_enabled()) else None
         out = _cba(x, self.conv1, self.bn1, L.ACT_RELU, dx_link=link)
         out = _cba(out, self.conv2, self.bn2, L.ACT_RELU)
-        out = _cba(out, self.conv3, self.bn3, L.ACT_NONE)
         identity = x if self.downsample is None else _cba(x, self.downsample[0], self.downsample[1], L.ACT_NONE)
+        if _FUSE_TAIL:   # relu(bn3(conv3(out)) + identity) in conv3's own BN pass (one pass over the 4x-wide tensor less)
+            return _cba(out, self.conv3, self.bn3, L.ACT_RELU, residual=identity, res_pre=True, res_link=link)
+        out = _cba(out, self.conv3, self.bn3, L.ACT_NONE)
         return ops.add_act(out, identity, L.ACT_RELU, link=link)
 
 

@@ -85,6 +85,7 @@ SIGNATURES = {
     "cvhip_bn_finalize": (_i32, [_p, _i32, _i32, _i64, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _p]),
     "cvhip_bn_eval_scale_shift": (_i32, [_i32, _p, _p, _p, _p, _f32, _p, _p, _p]),
     "cvhip_bn_act_fwd": (_i32, [_p, _i32, _p, _i32, _i64, _i32, _p, _p, _i32, _f32, _p, _i32, _p]),
+    "cvhip_bn_add_act_fwd": (_i32, [_p, _i32, _p, _i32, _i64, _i32, _p, _p, _i32, _f32, _p, _i32, _p]),
     "cvhip_bn_act_bwd_partial": (_i32, [_p, _i32, _p, _i32, _i64, _i32, _p, _p, _p, _p, _i32, _f32, _p, _p]),
     "cvhip_bn_bwd_finalize": (_i32, [_p, _i32, _i32, _p, _p, _p, _p, _p]),
     "cvhip_bn_act_bwd_apply": (_i32, [_p, _i32, _p, _i32, _p, _i32, _i64, _i32, _p, _p, _p, _p, _p, _p, _i32, _f32, _p]),

@@ -321,7 +321,7 @@ def conv_states_of(model):
 class ConvCfg:
     """Static configuration of one conv(+BN+act) layer (python-side)."""
     __slots__ = ("stride", "pad", "dil", "groups", "act", "act_param", "has_bn", "bn_training", "momentum", "eps",
-                 "state", "track", "vkey", "gw", "gb", "gg", "gbeta", "arena", "idx_w", "idx_b", "idx_bn", "sync", "out", "out_split", "dx_link", "res_link")
+                 "state", "track", "vkey", "gw", "gb", "gg", "gbeta", "arena", "idx_w", "idx_b", "idx_bn", "sync", "out", "out_split", "dx_link", "res_link", "res_pre")
 
     def __init__(self, stride, pad, dil, groups=1, act=L.ACT_NONE, act_param=0.0, has_bn=False, bn_training=True,
                  momentum=0.1, eps=1e-5, state=None, track=True):
@@ -345,6 +345,8 @@ class ConvCfg:
         # into its dgrad epilogue (cvhip_conv2d_dgrad_add)
         self.dx_link = None
         self.res_link = None
+        # residual joins BEFORE the activation: z = act(bn(conv(x)) + residual) (ResNet bottleneck tail) instead of after it
+        self.res_pre = False
 
 
 # ---- SyncBatchNorm plumbing (trainer.py:126-127 -> torch.nn.SyncBatchNorm semantics) -------------------------------------
@@ -601,7 +603,10 @@ class ConvBnAct(torch.autograd.Function):
                 z, z_ld = _check_out(cfg.out, N, K, P, Q)
             else:
                 z, z_ld = empty_nhwc(N, K, P, Q, dev), K
-            L.call("cvhip_bn_act_fwd", y.data_ptr(), Kp, z.data_ptr(), z_ld, M, K,
+            res_pre = bool(cfg.res_pre and residual is not None)
+            if res_pre and (cfg.act not in (L.ACT_NONE, L.ACT_RELU, L.ACT_LEAKY) or Kp != K):
+                raise L.CvhipError("res_pre needs none / ReLU / LeakyReLU and an unpadded channel count")
+            L.call("cvhip_bn_add_act_fwd" if res_pre else "cvhip_bn_act_fwd", y.data_ptr(), Kp, z.data_ptr(), z_ld, M, K,
                    _ptr(stats[2]) if stats is not None else None, _ptr(stats[3]) if stats is not None else None,
                    cfg.act, cfg.act_param, _ptr(residual), res_ld, st)
         else:
@@ -614,23 +619,38 @@ class ConvBnAct(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
         ctx.w_dgrad = cfg.state.w_dgrad if not depthwise else None
-        ctx.save_for_backward(x, y, stats, weight)
+        ctx.res_pre = bool(cfg.res_pre and residual is not None and not isinstance(z, tuple))
+        if ctx.res_pre:
+            ctx.save_for_backward(x, y, stats, weight, z)   # the activation's derivative is taken from the OUTPUT's sign
+        else:
+            ctx.save_for_backward(x, y, stats, weight)
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        x, y, stats, weight = ctx.saved_tensors
         cfg = ctx.cfg
         N, Cc, H, W, K, R, S, P, Q, Kp, x_ld, Cg = ctx.geom
-        dev = x.device
         M = N * P * Q
         st = _stream()
         dz, dz_ld = as_nhwc(dz)
+        act, act_param = cfg.act, cfg.act_param
+        if ctx.res_pre:
+            # z = act(bn(y) + r): first du = dz * act'(z) from the saved output (shared by the BN branch and the residual),
+            # then the BN backward below sees a layer WITHOUT activation
+            x, y, stats, weight, zout = ctx.saved_tensors
+            zout, z_ld = as_nhwc(zout)
+            du = empty_nhwc(N, K, P, Q, x.device)
+            L.call("cvhip_bn_act_bwd_apply", dz.data_ptr(), dz_ld, zout.data_ptr(), z_ld, du.data_ptr(), K, M, K, None, None, None, None,
+                   None, None, act, act_param, st)
+            dz, dz_ld, act = du, K, L.ACT_NONE
+        else:
+            x, y, stats, weight = ctx.saved_tensors
+        dev = x.device
         need_dx, need_dw, need_db, need_dg, need_dbeta = (ctx.needs_input_grad[i] for i in range(5))
         dgamma = dbeta = dbias = None
         kv = K if Kp != K else 0
         cv = Cg if (not ctx.depthwise and Cg != Cc) else 0
-        pointwise = cfg.has_bn or cfg.act != L.ACT_NONE
+        pointwise = cfg.has_bn or act != L.ACT_NONE
         arena = cfg.arena
         if pointwise:
             if Kp != K:  # pad channels must read as zero in dgrad/wgrad
@@ -641,7 +661,7 @@ class ConvBnAct(torch.autograd.Function):
                 rows = _colreduce_rows(M, K)
                 partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
                 L.call("cvhip_bn_act_bwd_partial", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, M, K, stats[2].data_ptr(),
-                       stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), cfg.act, cfg.act_param,
+                       stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), act, act_param,
                        partial.data_ptr(), st)
                 dgamma = torch.empty((K,), dtype=torch.float32, device=dev)
                 dbeta = torch.empty((K,), dtype=torch.float32, device=dev)
@@ -655,12 +675,12 @@ class ConvBnAct(torch.autograd.Function):
                 ag, ab = (dgamma, dbeta) if cfg.sync is None else _sync_bwd_sums(dgamma, dbeta, cfg.sync)
                 L.call("cvhip_bn_act_bwd_apply", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, dy.data_ptr(), Kp, M, K,
                        stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
-                       ag.data_ptr(), ab.data_ptr(), cfg.act, cfg.act_param, st)
+                       ag.data_ptr(), ab.data_ptr(), act, act_param, st)
             else:
                 sc = stats[2].data_ptr() if stats is not None else None
                 sh = stats[3].data_ptr() if stats is not None else None
                 L.call("cvhip_bn_act_bwd_apply", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, dy.data_ptr(), Kp, M, K, sc, sh,
-                       None, None, None, None, cfg.act, cfg.act_param, st)
+                       None, None, None, None, act, act_param, st)
             dy_ld = Kp
         else:
             dy, dy_ld = dz, dz_ld

@@ -193,6 +193,12 @@ int cvhip_bn_act_fwd(const void* y_bf16, int32_t ld_y, void* z_bf16, int32_t ld_
                      int32_t C, const float* scale, const float* shift, int32_t act,
                      float act_param, const void* residual_bf16, int32_t ld_res, void* stream);
 
+/* z = act(y*scale + shift + residual): BatchNorm apply, skip-connection add and activation of a ResNet bottleneck tail
+ * (torchvision resnet.Bottleneck.forward: `out += identity; out = self.relu(out)`) in one pass. */
+int cvhip_bn_add_act_fwd(const void* y_bf16, int32_t ld_y, void* z_bf16, int32_t ld_z, int64_t M,
+                         int32_t C, const float* scale, const float* shift, int32_t act,
+                         float act_param, const void* residual_bf16, int32_t ld_res, void* stream);
+
 /* backward stage 1: partial[rows][2][C] = (sum du, sum du*xhat),  du = dz*act'(u),
  * u = y*scale+shift, xhat = (y-mean)*invstd. */
 int cvhip_bn_act_bwd_partial(const void* dz_bf16, int32_t ld_dz, const void* y_bf16, int32_t ld_y,

@@ -338,3 +338,32 @@ def test_grad_link_equals_autograd_accumulation(kind):
     assert rel_l2(res[True][1], res[False][1]) < 5e-3
     for a, b in zip(res[True][2], res[False][2]):
         assert rel_l2(a, b) < 5e-3
+
+
+def test_resnet_tail_fused_into_bn_pass_equals_separate_add():
+    """relu(bn3(conv3(x)) + identity) inside conv3's BN pass (cfg.res_pre / cvhip_bn_add_act_fwd) vs the separate add_act pass:
+    same values up to one bf16 rounding of the intermediate, same gradients (identity branch through the GradLink in both)."""
+    from cvpytorch_amd import deeplab
+    res = {}
+    for fused in (True, False):
+        torch.manual_seed(8)
+        m = deeplab.Bottleneck(256, 64).to(dev()).train()
+        deeplab._FUSE_TAIL = fused
+        try:
+            x = torch.randn((2, 256, 33, 65), generator=torch.Generator().manual_seed(9)).to(dev()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            out = m(ops.add(x, x))
+            cot = torch.randn(out.shape, generator=torch.Generator().manual_seed(10)).to(dev()).to(out.dtype)
+            (out.float() * cot.float()).sum().backward()
+            torch.cuda.synchronize()
+        finally:
+            deeplab._FUSE_TAIL = True
+        res[fused] = (out.float().cpu(), x.grad.float().cpu(), [p.grad.float().cpu().clone() for p in m.parameters()],
+                      [b.float().cpu().clone() for b in m.buffers() if b.dtype == torch.float32])
+    assert rel_l2(res[True][0], res[False][0]) < 5e-3
+    assert float(((res[True][0] > 0) != (res[False][0] > 0)).float().mean()) < 2e-3      # the ReLU mask moves only at rounding ties
+    # a fraction f of flipped ReLU-mask elements moves the gradient by ~sqrt(f) in relative L2 (f < 2e-3 => < 4.5e-2)
+    assert rel_l2(res[True][1], res[False][1]) < 6e-2
+    for a, b in zip(res[True][2], res[False][2]):
+        assert rel_l2(a, b) < 6e-2
+    for a, b in zip(res[True][3], res[False][3]):
+        assert torch.equal(a, b)          # BN statistics come from the conv epilogue: identical
