@@ -33,24 +33,6 @@ struct RedParams {
   float* partial;  // [gridDim.x][2][C]
 };
 
-// 8 per-channel constants for the channel vector starting at c: UNCONDITIONAL clamped loads (a per-element
-// `ok ? p[c] : dflt` compiles to 8 exec-masked blocks with an s_waitcnt vmcnt(0) at every join: 16-48 serialized
-// ~1 us round trips per thread, i.e. a fixed ~17 us per launch — measured, tools/stream_probe.py)
-__device__ __forceinline__ void load8c(const float* __restrict__ p, int c, int C, float (&o)[8]) {
-  if (c + 8 <= C && ((((uintptr_t)p) | (uintptr_t)(c * 4)) & 15) == 0) {  // wave-uniform in the vector paths (C % 8 == 0)
-    const float4 a = *reinterpret_cast<const float4*>(p + c), b = *reinterpret_cast<const float4*>(p + c + 4);
-    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
-    o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
-    return;
-  }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = p[(c + j < C) ? c + j : C - 1];
-}
-__device__ __forceinline__ void fill8c(float v, float (&o)[8]) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = v;
-}
-
 // ACT: compile-time activation id for MODE 1 (a runtime switch inside the element loop compiles to a chain of scalar
 // branches per element)
 template <int MODE, int ACT = 0>

@@ -1,0 +1,420 @@
+// conv1x1_bwd.hip — fused backward of a 1x1 / stride-1 Conv-BN-act layer for gfx950: ONE streaming kernel does what
+// cvhip_bn_act_bwd_apply + cvhip_conv2d_dgrad + cvhip_conv2d_wgrad do in three passes.
+//
+//   dy[m][k]  = sc[k] * (dz[m][k] * act'(sc[k]*y[m][k] + sh[k])) + b1[k]*y[m][k] + c1[k]      (BN + activation backward,
+//                                                                                               applied ON LOAD: dy never
+//                                                                                               exists in HBM)
+//   dx[m][c]  = sum_k dy[m][k] * W[k][c]        (+ addend[m][c]: gradient arriving over a skip connection)
+//   dW[k][c] += sum_m dy[m][k] * x[m][c]        (fp32)
+//
+// The 1x1 layers of the detectors are HBM-bound; per layer the three-pass form moves (R dz, R y, W dy) + (R dy, W dx) +
+// (R x, R dy) = 7 activation-sized tensors, this kernel moves (R dz, R y, R x, W dx) = 4. Structure (256 threads, persistent
+// blocks, 64 pixel rows per trip):
+//   * the dgrad weight image W^T [C][K] is staged into LDS once per block (rows permuted so that a lane ends up with 8
+//     consecutive dx channels -> 16-byte stores, as in conv1x1_stream.hip);
+//   * dz / y / x rows go global -> VGPR (16-byte vectors, next trip's loads in flight during this trip's MFMAs), the
+//     BN/act derivative is evaluated in fp32 with per-thread channel constants, dy and x are written to row-major LDS tiles
+//     with the 32-byte-segment XOR swizzle of conv_wgrad.hip;
+//   * dgrad reads dy fragments with ds_read_b128 (pixel rows = MFMA B operand), wgrad reads dy^T and x^T fragments with the
+//     hardware transpose read ds_read_b64_tr_b16; the dW accumulators stay in registers across ALL trips of the block and
+//     are flushed once with fp32 atomics (K*C per block instead of K*C per 512..2048 rows).
+// K (output channels of the layer = reduction of dgrad) is 32 / 64 / 128 per block; wider inputs C run as 128-wide column
+// slices (grid.y), which re-read dz / y.
+//
+// Replaces aten::native_batch_norm_backward + silu_backward + convolution_backward reached from trainer.py:189
+// (loss.backward()) for reference src/models/bricks/conv_module.py:201-214 layers with kernel_size 1.
+#include <stdlib.h>
+
+#include "common.h"
+#include "conv_plan.h"
+
+namespace cvhip {
+
+struct Bwd1x1Params {
+  const bf16_t* dz0;  // gradient at the layer output, channels [0, k_split)
+  const bf16_t* dz1;  // channels [k_split, K) (sibling pairs deliver two tensors); unused when k_split == K
+  int dz0_ld, dz1_ld, k_split;
+  const bf16_t* y;    // raw convolution output (pre-BN)
+  int y_ld;
+  const bf16_t* x;    // layer input
+  int x_ld;
+  const bf16_t* w;    // dgrad image [C][K]
+  const bf16_t* res;  // optional addend for dx
+  int res_ld;
+  bf16_t* dx;
+  int dx_ld;
+  float* dw;          // [K][C] fp32, accumulated
+  const float *scale, *shift, *mean, *invstd, *dgamma, *dbeta;
+  float inv_count;
+  int act;
+  float ap;
+  int M, K, C, ntiles;
+};
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_b;
+
+__device__ __forceinline__ bf16x8 tr_read8_b(const unsigned char* p0, const unsigned char* p1) {
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_b*)(p0));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_b*)(p1));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// byte offset of 16-B vector v of pixel row px inside a row-major tile whose 32-B segments are XOR-swizzled by the row
+// (conv_wgrad.hip's layout: conflict-free for ds_read_b64_tr_b16 fragment gathers and for row-wise ds_read_b128)
+template <int SEGM>
+__device__ __forceinline__ int swz_off(int px, int v) {
+  const int h = (px & 3) | ((px >> 1) & 4);
+  return ((((v >> 1) ^ h) & SEGM) << 5) + (v & 1) * 16;
+}
+
+template <int ACT>
+__device__ __forceinline__ f32x8 bnact_bwd8(const f32x8& dz, const f32x8& y, const float (&sc)[8], const float (&sh)[8],
+                                            const float (&b1)[8], const float (&c1)[8], float ap) {
+  f32x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float u = y.v[j] * sc[j] + sh[j];
+    const float du = dz.v[j] * act_bwd(u, ACT, ap);
+    o.v[j] = sc[j] * du + (b1[j] * y.v[j] + c1[j]);
+  }
+  return o;
+}
+
+template <int KB, int CB>
+__global__ __launch_bounds__(256, 2) void bwd1x1_kernel(const Bwd1x1Params p) {
+  constexpr int RT = 64;
+  constexpr int KV = KB / 8, CV = CB / 8;
+  constexpr int D_PASS = 256 / KV, D_IT = RT / D_PASS;
+  constexpr int X_PASS = 256 / CV, X_IT = RT / X_PASS;
+  constexpr int D_ROWB = KB * 2, X_ROWB = CB * 2;
+  constexpr int D_SEGM = KB / 16 - 1, X_SEGM = CB / 16 - 1;
+  constexpr int W_ROWB = KB * 2 + 16;  // (KB/2 + 4) banks = 4 * odd: 16 weight rows hit 64 distinct banks
+  constexpr int W_BYTES = CB * W_ROWB, D_BYTES = RT * D_ROWB, X_BYTES = RT * X_ROWB;
+  constexpr int NF = CB / 16;   // dx fragments across the input channels (per wave: 16 pixel rows x CB)
+  constexpr int KS = KB / 32;   // dgrad reduction steps
+  constexpr int KF = KB / 32;   // dW fragments of a wave along K (wave owns K/2 x C/2)
+  constexpr int CF = CB / 32;
+  static_assert(D_IT >= 1 && X_IT >= 1, "tile too narrow for 256 threads");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // W_BYTES + D_BYTES + X_BYTES (up to 66 KB: dynamic)
+  unsigned char* const sW = smem;
+  unsigned char* const sD = smem + W_BYTES;
+  unsigned char* const sX = sD + D_BYTES;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int c0 = blockIdx.y * CB;
+  const int M = p.M;
+
+  // ---- staging geometry (thread-constant channel vectors) -----------------------------------------------------------------
+  const int kv = t % KV, drow = t / KV;
+  const int xv = t % CV, xrow = t / CV;
+  const bool seg1 = kv * 8 >= p.k_split;
+  const bf16_t* const dzp = seg1 ? p.dz1 + (kv * 8 - p.k_split) : p.dz0 + kv * 8;
+  const int dz_ld = seg1 ? p.dz1_ld : p.dz0_ld;
+  const bf16_t* const yp = p.y + kv * 8;
+  const bf16_t* const xp = p.x + c0 + xv * 8;
+
+  // per-channel constants of this thread's 8 channels: u = sc*y + sh; dy = sc*du + b1*y + c1
+  float sc[8], sh[8], b1[8], c1[8];
+  fill8c(1.f, sc);
+  fill8c(0.f, sh);
+  fill8c(0.f, b1);
+  fill8c(0.f, c1);
+  if (p.scale) {
+    load8c(p.scale, kv * 8, p.K, sc);
+    load8c(p.shift, kv * 8, p.K, sh);
+  }
+  if (p.mean) {
+    float mu[8], is[8], k1[8], k2[8];
+    load8c(p.mean, kv * 8, p.K, mu);
+    load8c(p.invstd, kv * 8, p.K, is);
+    load8c(p.dbeta, kv * 8, p.K, k1);
+    load8c(p.dgamma, kv * 8, p.K, k2);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float q2 = sc[j] * is[j] * (k2[j] * p.inv_count);
+      b1[j] = -q2;
+      c1[j] = q2 * mu[j] - sc[j] * (k1[j] * p.inv_count);
+    }
+  }
+
+  uint4 rd[D_IT], ry[D_IT], rx[X_IT];
+  // loads are unconditional (rows past M read row 0 and are zeroed when the tile is written): no load sits in a branch
+  auto load_tile = [&](int tile) {
+    const int m0 = tile * RT;
+#pragma unroll
+    for (int i = 0; i < D_IT; ++i) {
+      int m = m0 + i * D_PASS + drow;
+      m = m < M ? m : 0;
+      rd[i] = *reinterpret_cast<const uint4*>(dzp + (int64_t)m * dz_ld);
+      ry[i] = *reinterpret_cast<const uint4*>(yp + (int64_t)m * p.y_ld);
+    }
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) {
+      int m = m0 + i * X_PASS + xrow;
+      m = m < M ? m : 0;
+      rx[i] = *reinterpret_cast<const uint4*>(xp + (int64_t)m * p.x_ld);
+    }
+  };
+  auto store_tile = [&](int tile) {
+    const int m0 = tile * RT;
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int i = 0; i < D_IT; ++i) {
+      const int px = i * D_PASS + drow;
+      const f32x8 dzv = unpack8(rd[i]), yv = unpack8(ry[i]);
+      f32x8 o;
+      switch (p.act) {  // block-uniform; hoisted out of the element loop
+        case CVHIP_ACT_SILU: o = bnact_bwd8<CVHIP_ACT_SILU>(dzv, yv, sc, sh, b1, c1, p.ap); break;
+        case CVHIP_ACT_RELU: o = bnact_bwd8<CVHIP_ACT_RELU>(dzv, yv, sc, sh, b1, c1, p.ap); break;
+        case CVHIP_ACT_LEAKY: o = bnact_bwd8<CVHIP_ACT_LEAKY>(dzv, yv, sc, sh, b1, c1, p.ap); break;
+        case CVHIP_ACT_SIGMOID: o = bnact_bwd8<CVHIP_ACT_SIGMOID>(dzv, yv, sc, sh, b1, c1, p.ap); break;
+        case CVHIP_ACT_HSWISH: o = bnact_bwd8<CVHIP_ACT_HSWISH>(dzv, yv, sc, sh, b1, c1, p.ap); break;
+        default: o = bnact_bwd8<CVHIP_ACT_NONE>(dzv, yv, sc, sh, b1, c1, p.ap); break;
+      }
+      uint4 v = pack8(o);
+      if (m0 + px >= M) v = z;
+      *reinterpret_cast<uint4*>(sD + px * D_ROWB + swz_off<D_SEGM>(px & 31, kv)) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) {
+      const int px = i * X_PASS + xrow;
+      uint4 v = rx[i];
+      if (m0 + px >= M) v = z;
+      *reinterpret_cast<uint4*>(sX + px * X_ROWB + swz_off<X_SEGM>(px & 31, xv)) = v;
+    }
+  };
+
+  int tile = blockIdx.x;
+  load_tile(tile);
+
+  // ---- dgrad weight tile -> LDS once: LDS row a*16 + i holds input channel c0 + (a>>1)*32 + (i>>2)*8 + (a&1)*4 + (i&3) -------
+  {
+    constexpr int NCH = CB * KV;  // 16-byte chunks
+    for (int q = t; q < NCH; q += 256) {
+      const int L = q / KV, kq = q - L * KV;
+      const int a = L >> 4, i = L & 15;
+      const int ch = c0 + (a >> 1) * 32 + (i >> 2) * 8 + (a & 1) * 4 + (i & 3);
+      *reinterpret_cast<uint4*>(sW + L * W_ROWB + kq * 16) = *reinterpret_cast<const uint4*>(p.w + (int64_t)ch * p.K + kq * 8);
+    }
+  }
+
+  f32x4 accw[KF][CF];
+#pragma unroll
+  for (int a = 0; a < KF; ++a)
+#pragma unroll
+    for (int b = 0; b < CF; ++b) accw[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int wk2 = wave >> 1, wc2 = wave & 1;
+  // transpose-read geometry (conv_wgrad.hip): lane reads pixel rows 8g+q (+4), 8-byte column (lane&3) of the 32-B segment
+  const int q4 = (lane >> 2) & 3;
+  const int hsw = q4 | ((g & 1) << 2);
+  const int px0 = 8 * g + q4;
+  const int prow = wave * 16 + r;  // this lane's pixel row of the trip (dgrad B operand / dx row)
+  const unsigned char* const wlane = sW + r * W_ROWB + g * 16;
+
+  for (; tile < p.ntiles; tile += gridDim.x) {
+    store_tile(tile);
+    load_tile(tile + gridDim.x);  // next trip (past the end: clamped rows, never used)
+    __syncthreads();
+
+    // ---- dgrad: dx[16 rows of this wave][CB] -------------------------------------------------------------------------------
+    f32x4 accx[NF];
+#pragma unroll
+    for (int a = 0; a < NF; ++a) accx[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sD + prow * D_ROWB + swz_off<D_SEGM>(prow & 31, 4 * ks + g));
+#pragma unroll
+      for (int a = 0; a < NF; ++a) {
+        const bf16x8 wa = *reinterpret_cast<const bf16x8*>(wlane + a * 16 * W_ROWB + ks * 64);
+        accx[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, fb, accx[a], 0, 0, 0);
+      }
+    }
+    {
+      const int m = tile * RT + prow;
+      if (m < M) {
+        bf16_t* const drow_p = p.dx + (int64_t)m * p.dx_ld + c0 + g * 8;
+#pragma unroll
+        for (int j = 0; j < NF / 2; ++j) {
+          f32x8 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v.v[e] = accx[2 * j][e];
+            v.v[4 + e] = accx[2 * j + 1][e];
+          }
+          if (p.res) {
+            const f32x8 rv = unpack8(*reinterpret_cast<const uint4*>(p.res + (int64_t)m * p.res_ld + c0 + j * 32 + g * 8));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v.v[e] += rv.v[e];
+          }
+          *reinterpret_cast<uint4*>(drow_p + j * 32) = pack8(v);
+        }
+      }
+    }
+
+    // ---- wgrad: dW[K/2 of this wave][C/2 of this wave] += dy^T x over the trip's 64 pixel rows -------------------------------
+#pragma unroll
+    for (int sub = 0; sub < RT / 32; ++sub) {
+      bf16x8 fd[KF], fx[CF];
+#pragma unroll
+      for (int a = 0; a < KF; ++a) {
+        const int seg = (wk2 * (KB / 2) + a * 16) >> 4;
+        const unsigned char* base = sD + sub * 32 * D_ROWB + (((seg ^ hsw) & D_SEGM) << 5) + (lane & 3) * 8;
+        fd[a] = tr_read8_b(base + px0 * D_ROWB, base + (px0 + 4) * D_ROWB);
+      }
+#pragma unroll
+      for (int b = 0; b < CF; ++b) {
+        const int seg = (wc2 * (CB / 2) + b * 16) >> 4;
+        const unsigned char* base = sX + sub * 32 * X_ROWB + (((seg ^ hsw) & X_SEGM) << 5) + (lane & 3) * 8;
+        fx[b] = tr_read8_b(base + px0 * X_ROWB, base + (px0 + 4) * X_ROWB);
+      }
+#pragma unroll
+      for (int a = 0; a < KF; ++a)
+#pragma unroll
+        for (int b = 0; b < CF; ++b) accw[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[a], fx[b], accw[a][b], 0, 0, 0);
+    }
+    __syncthreads();  // everybody is done with the tiles before the next trip overwrites them
+  }
+
+  // ---- flush dW: lane holds D[k = 4g + e][c = lane & 15] per fragment -----------------------------------------------------------
+#pragma unroll
+  for (int a = 0; a < KF; ++a)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = wk2 * (KB / 2) + a * 16 + 4 * g + e;
+#pragma unroll
+      for (int b = 0; b < CF; ++b) {
+        const int c = c0 + wc2 * (CB / 2) + b * 16 + r;
+        unsafeAtomicAdd(p.dw + ((int64_t)k * p.C + c), accw[a][b][e]);
+      }
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------------
+static int bwd1x1_mode() {  // CVHIP_BWD1X1: 0 = never (three-pass backward), 1 = when the geometry fits (default)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CVHIP_BWD1X1");
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+
+static int bwd1x1_cb(int C) { return (C % 128 == 0) ? 128 : (C % 64 == 0) ? 64 : (C % 32 == 0) ? 32 : 0; }
+
+// 1 when the fused kernel takes this layer geometry
+int bwd1x1_fits(const cvhip_conv_desc* d) {
+  if (bwd1x1_mode() == 0) return 0;
+  if (d->groups != 1 || d->R != 1 || d->S != 1 || d->stride_h != 1 || d->stride_w != 1 || d->pad_h != 0 || d->pad_w != 0) return 0;
+  if (d->K != 32 && d->K != 64 && d->K != 128) return 0;
+  if (d->k_valid || d->c_valid) return 0;
+  if (bwd1x1_cb(d->C) == 0 || d->C > 1024) return 0;
+  if ((d->x_ld & 7) || (d->y_ld & 7)) return 0;
+  const int64_t M = (int64_t)d->N * d->H * d->W;
+  if (M < 64 * 64 || M >= (1ll << 31) - 64 * 1024) return 0;  // tiny layers: the general kernels' split-K covers the chip better
+  return 1;
+}
+
+template <int KB, int CB>
+static int launch_b1(const Bwd1x1Params& p, int blocks, hipStream_t s) {
+  constexpr int LDS = CB * (KB * 2 + 16) + 64 * KB * 2 + 64 * CB * 2;
+  auto kern = bwd1x1_kernel<KB, CB>;
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      set_last_error("hipFuncSetAttribute(bwd1x1_kernel)", e);
+      return CVHIP_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(blocks, p.C / CB), dim3(256), LDS, s, p);
+  return check_launch("bwd1x1_kernel");
+}
+
+int launch_bwd1x1(Bwd1x1Params& p, hipStream_t s) {
+  p.ntiles = (p.M + 63) / 64;
+  // persistent grid: <= 2 blocks per CU, >= 8 trips per block (the dW flush costs K*C atomics per block)
+  static int max_blocks = -1, min_trips = -1;
+  if (max_blocks < 0) {
+    const char* e = getenv("CVHIP_BWD1X1_BLOCKS");
+    max_blocks = e ? atoi(e) : 512;
+    const char* f = getenv("CVHIP_BWD1X1_MINTRIPS");
+    min_trips = f ? atoi(f) : 8;
+  }
+  const int cb = bwd1x1_cb(p.C);
+  const int slices = p.C / cb;
+  int cap = max_blocks / slices;
+  if (cap < 64) cap = 64;
+  int blocks = p.ntiles / min_trips;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  const int rounds = cdiv(p.ntiles, blocks);
+  blocks = cdiv(p.ntiles, rounds);
+#define CVHIP_B1(KBV)                                        \
+  if (cb == 128) return launch_b1<KBV, 128>(p, blocks, s);   \
+  if (cb == 64) return launch_b1<KBV, 64>(p, blocks, s);     \
+  return launch_b1<KBV, 32>(p, blocks, s);
+  if (p.K == 128) { CVHIP_B1(128) }
+  if (p.K == 64) { CVHIP_B1(64) }
+  CVHIP_B1(32)
+#undef CVHIP_B1
+}
+
+}  // namespace cvhip
+
+using namespace cvhip;
+
+extern "C" {
+
+int cvhip_conv1x1_bwd_fused_ok(const cvhip_conv_desc* d) { return d ? bwd1x1_fits(d) : 0; }
+
+int cvhip_conv1x1_bwd_fused(const cvhip_conv_desc* d, const void* dz0, int32_t dz0_ld, const void* dz1, int32_t dz1_ld, int32_t k_split,
+                            const void* y, const void* x, const void* w_dgrad, const float* scale, const float* shift, const float* mean,
+                            const float* invstd, const float* dgamma, const float* dbeta, int32_t act, float act_param,
+                            const void* addend, int32_t addend_ld, void* dx, int32_t dx_ld, float* dw, void* stream) {
+  if (!d || !dz0 || !y || !x || !w_dgrad || !dx || !dw) return CVHIP_ERR_INVALID;
+  if (!bwd1x1_fits(d)) return CVHIP_ERR_UNSUPPORTED;
+  if (k_split <= 0 || k_split > d->K || (k_split & 7)) return CVHIP_ERR_INVALID;
+  if (k_split < d->K && (!dz1 || (dz1_ld & 7) || (((uintptr_t)dz1) & 15))) return CVHIP_ERR_INVALID;
+  if ((dz0_ld & 7) || (dx_ld & 7) || dx_ld < d->C) return CVHIP_ERR_INVALID;
+  if ((((uintptr_t)dz0) | ((uintptr_t)y) | ((uintptr_t)x) | ((uintptr_t)w_dgrad) | ((uintptr_t)dx)) & 15) return CVHIP_ERR_INVALID;
+  if (addend && ((addend_ld & 7) || addend_ld < d->C || (((uintptr_t)addend) & 15))) return CVHIP_ERR_INVALID;
+  if ((scale == nullptr) != (shift == nullptr)) return CVHIP_ERR_INVALID;
+  if (mean && (!invstd || !dgamma || !dbeta || !scale)) return CVHIP_ERR_INVALID;
+  Bwd1x1Params p{};
+  p.dz0 = (const bf16_t*)dz0;
+  p.dz1 = (const bf16_t*)(k_split < d->K ? dz1 : dz0);
+  p.dz0_ld = dz0_ld;
+  p.dz1_ld = k_split < d->K ? dz1_ld : dz0_ld;
+  p.k_split = k_split;
+  p.y = (const bf16_t*)y;
+  p.y_ld = d->y_ld;
+  p.x = (const bf16_t*)x;
+  p.x_ld = d->x_ld;
+  p.w = (const bf16_t*)w_dgrad;
+  p.res = (const bf16_t*)addend;
+  p.res_ld = addend_ld;
+  p.dx = (bf16_t*)dx;
+  p.dx_ld = dx_ld;
+  p.dw = dw;
+  p.scale = scale;
+  p.shift = shift;
+  p.mean = mean;
+  p.invstd = invstd;
+  p.dgamma = dgamma;
+  p.dbeta = dbeta;
+  p.M = d->N * d->H * d->W;
+  p.K = d->K;
+  p.C = d->C;
+  p.inv_count = 1.f / (float)p.M;
+  p.act = act;
+  p.ap = act_param;
+  return launch_bwd1x1(p, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -293,17 +293,45 @@ __device__ __attribute__((aligned(64))) unsigned int g_zero_page[16];
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                       \
                                    (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
+// counted s_waitcnt vmcnt(N) for a compile-time N (the immediate must be a literal)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 12, "vmcnt literal table");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+
 // ABL: profiling ablation (CVHIP_IGEMM_ABLATE): 0 = the kernel, 1 = staging only (no LDS reads / MFMA), 2 = compute only
-template <int BM, int BN, int WM, int WN, int ABL = 0, int NST = 3>
-__global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmKernArgs p) {
+// BK : reduction depth per ring slot / barrier. 32: LDS rows of 64 B, a DMA instruction covers 16 rows x 64 B (half cache lines).
+//      64: LDS rows of 128 B, a DMA instruction covers 8 rows x 128 B = FULL 128-byte lines of the NHWC channel axis (when
+//      Cin >= 64), half the barriers / tap decodes / counted waits per MFMA (cdna_hip_programming.md §5: "x through LDS in
+//      full 128-B lines", BK 32 -> 64). The 16-B slots of a 128-B row are XOR-swizzled by (row >> 1) & 7 — conflict-free for
+//      the 16-lane groups of ds_read_b128 — on the DMA SOURCE side and on the fragment reads (rule 21).
+template <int BM, int BN, int WM, int WN, int ABL = 0, int NST = 3, int BK = 32>
+__global__ __launch_bounds__(256, (NST * (BM + (BN < BK ? BK : BN)) * BK * 2 > 80 * 1024) ? 1 : 2) void igemm_dma_kernel(const IgemmKernArgs p) {
   constexpr int WAVES_N = BN / WN;
   constexpr int WAVES_M = BM / WM;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+  static_assert(BK == 32 || BK == 64, "reduction depth per stage");
   constexpr int MF = WM / 16, NF = WN / 16;
-  constexpr int A_IT = BM / 64;
-  constexpr int B_ROWS = BN < 64 ? 64 : BN;  // B tile padded to >= 64 rows so all 4 waves issue the same DMA count
-  constexpr int B_IT = B_ROWS / 64;
-  constexpr int A_BYTES = BM * 64, B_BYTES = B_ROWS * 64, ST_BYTES = A_BYTES + B_BYTES;
+  constexpr int RPI = 1024 / (BK * 2);  // rows per DMA instruction (1 KiB): 16 (BK 32) / 8 (BK 64)
+  constexpr int RPT = 4 * RPI;          // rows per pass of the 4 waves: 64 / 32
+  constexpr int ROWB = BK * 2;          // LDS row bytes
+  constexpr int A_IT = BM / RPT;
+  constexpr int B_ROWS = BN < RPT ? RPT : BN;  // B tile padded so all 4 waves issue the same DMA count
+  constexpr int B_IT = B_ROWS / RPT;
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = B_ROWS * ROWB, ST_BYTES = A_BYTES + B_BYTES;
   static_assert(NST == 2 || NST == 3, "LDS ring depth");
   constexpr int PER = A_IT + B_IT;  // DMA instructions per stage per wave
 
@@ -334,14 +362,16 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmKernArgs p
   const int TR = cl.TR, TS = cl.TS;
   const int Cin = p.Cin;
   const int Ktot = TR * TS * Cin;
-  const int nk = (Ktot + 31) >> 5;
+  const int nk = (Ktot + BK - 1) / BK;
   const int M = cl.M;
   const int OWi = cl.OWi, OHWi = cl.OHi * cl.OWi;
 
+  // staging geometry: this thread's row inside a 4-wave pass and its physical 16-B slot inside the LDS row
+  const int srow = BK == 32 ? (t >> 2) : (wave * 8 + (lane >> 3));
   int ih0[A_IT], iw0[A_IT], pbase[A_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
-    const int m = m0 + i * 64 + (t >> 2);
+    const int m = m0 + i * RPT + srow;
     if (m < M) {
       const int n = m / OHWi;
       const int rem = m - n * OHWi;
@@ -361,12 +391,14 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmKernArgs p
   const bf16_t* __restrict__ wbase = p.w + cl.w_off;
   const bf16_t* const zero = reinterpret_cast<const bf16_t*>(g_zero_page);
 
-  // physical 16-B slot of this lane inside its 64-B LDS row is (t&3); it must hold LOGICAL K-slot (t&3)^g(row>>2)
-  const int lslot = (t & 3) ^ ((0x78 >> (2 * ((t >> 4) & 3))) & 3);
-  const int swz_r = (lane >> 4) ^ ((0x78 >> (2 * ((lane >> 2) & 3))) & 3);
+  // BK 32: physical slot (t&3) of a 64-B row must hold LOGICAL K-slot (t&3)^g(row>>2)
+  // BK 64: physical slot (lane&7) of a 128-B row must hold LOGICAL K-slot (lane&7) ^ ((row>>1)&7), row = i*32 + wave*8 + (lane>>3)
+  const int lslot = BK == 32 ? ((t & 3) ^ ((0x78 >> (2 * ((t >> 4) & 3))) & 3)) : ((lane & 7) ^ (((wave & 1) << 2) | (lane >> 4)));
+  // fragment reads: lane (r = lane&15, g = lane>>4) reads logical slot 4*ks + g of row base + r
+  const int swz_r = BK == 32 ? ((lane >> 4) ^ ((0x78 >> (2 * ((lane >> 2) & 3))) & 3)) : ((lane >> 1) & 7);
 
   auto stage = [&](int kt, int st) {
-    const unsigned k = (unsigned)(kt * 32 + lslot * 8);
+    const unsigned k = (unsigned)(kt * BK + lslot * 8);
     const unsigned tap = fdiv(k, cin_magic);
     const int c0 = (int)(k - tap * (unsigned)Cin);
     const unsigned tr = fdiv(tap, ts_magic);
@@ -380,15 +412,15 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmKernArgs p
       const int ih = ih0[i] + dh, iw = iw0[i] + dw;
       const bool ok = tap_ok && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
       const bf16_t* src = ok ? (p.x + ((int64_t)(pbase[i] + ih * p.IW + iw) * p.x_ld + c0)) : zero;
-      CVHIP_GLDS16(src, sA + (i * 64 + wave * 16) * 64);
+      CVHIP_GLDS16(src, sA + (i * RPT + wave * RPI) * ROWB);
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-      const int row = i * 64 + (t >> 2);
+      const int row = i * RPT + srow;
       const int n = n0 + row;
       const bool ok = row < BN && n < p.Nout && (int)k < Ktot;
       const bf16_t* src = ok ? (wbase + ((int64_t)n * Ktot + k)) : zero;
-      CVHIP_GLDS16(src, sB + (i * 64 + wave * 16) * 64);
+      CVHIP_GLDS16(src, sB + (i * RPT + wave * RPI) * ROWB);
     }
   };
 
@@ -403,16 +435,20 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmKernArgs p
   auto compute = [&](int st) {
     const unsigned char* const sA = smem + st * ST_BYTES;
     const unsigned char* const sB = sA + A_BYTES;
-    bf16x8 xa[MF], wb[NF];
 #pragma unroll
-    for (int b = 0; b < MF; ++b) xa[b] = *reinterpret_cast<const bf16x8*>(sA + (a_row + b * 16) * 64 + swz_r * 16);
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      const int slot = BK == 32 ? swz_r : ((4 * ks + (lane >> 4)) ^ swz_r);
+      bf16x8 xa[MF], wb[NF];
 #pragma unroll
-    for (int a = 0; a < NF; ++a) wb[a] = *reinterpret_cast<const bf16x8*>(sB + (b_row + a * 16) * 64 + swz_r * 16);
+      for (int b = 0; b < MF; ++b) xa[b] = *reinterpret_cast<const bf16x8*>(sA + (a_row + b * 16) * ROWB + slot * 16);
 #pragma unroll
-    for (int a = 0; a < NF; ++a)
+      for (int a = 0; a < NF; ++a) wb[a] = *reinterpret_cast<const bf16x8*>(sB + (b_row + a * 16) * ROWB + slot * 16);
 #pragma unroll
-      for (int b = 0; b < MF; ++b)
-        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[a], xa[b], acc[a][b], 0, 0, 0);
+      for (int a = 0; a < NF; ++a)
+#pragma unroll
+        for (int b = 0; b < MF; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[a], xa[b], acc[a][b], 0, 0, 0);
+    }
   };
 
   if constexpr (NST == 3) {
@@ -421,11 +457,7 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const IgemmKernArgs p
     int st_cur = 0, st_nxt2 = 2;
     for (int kt = 0; kt < nk; ++kt) {
       // this wave's DMAs of tile kt have landed when at most PER (= tile kt+1) remain outstanding ...
-      static_assert(PER >= 3 && PER <= 6, "DMA count per stage");
-      if constexpr (PER == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      else if constexpr (PER == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if constexpr (PER == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      wait_vmcnt<PER>();
       // ... and after the barrier everybody's have; it also proves all waves finished reading ring slot (kt+2)%3
       __builtin_amdgcn_s_barrier();
       if (ABL != 2) stage(kt + 2, st_nxt2);  // past-the-end tiles decode to all-masked lanes (zero page): DMA counts stay uniform
@@ -568,6 +600,16 @@ static int nst2_level() {
   return v;
 }
 
+// CVHIP_IGEMM_BK64: 0 = 32-deep ring slots, 1 = 64-deep slots with a 2-deep ring, 2 = 64-deep slots with a 3-deep ring
+static int bk64_level() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CVHIP_IGEMM_BK64");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
 static bool use_v1() {
   static int v = -1;
   if (v < 0) {
@@ -607,6 +649,12 @@ static int launch_group(IgemmKernArgs& p, hipStream_t stream) {
       hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), dim3(total), dim3(256), 0, stream, p);
       return check_launch("igemm_kernel");
     }
+  }
+  if (bk64_level() > 0 && ablate_mode() == 0) {
+    // BK = 64 ring slots (full 128-byte lines per DMA row): level 1 = 2-deep ring, 2 = 3-deep ring
+    if (bk64_level() >= 2) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 3, 64>), dim3(total), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 2, 64>), dim3(total), dim3(256), 0, stream, p);
+    return check_launch("igemm_kernel(bk64)");
   }
   if (ablate_mode() == 1) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 1>), dim3(total), dim3(256), 0, stream, p);
   else if (ablate_mode() == 2) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 2>), dim3(total), dim3(256), 0, stream, p);

@@ -92,15 +92,17 @@ def _wgrad_name(k, r=3, s=3, c=0, m=0, desc=None):
     return {32: "wgrad_kernel<32,32,32>", 64: "wgrad_kernel<64,32,64>", 128: "wgrad_kernel<128,64,64>"}[tn]
 
 
-def _timed_call(kname, geom, fname, *args):
+def _timed_call(kname, geom, fname, *args, passes=1, nbytes=None):
     """geom = (N, C, H, W, K, R, S, P, Q): algorithmic work of one conv pass = 2*M*K*R*S*C flop and
-    one read of the gathered operand + one write of the result + the weights (bf16)."""
+    one read of the gathered operand + one write of the result + the weights (bf16). `passes` > 1 / `nbytes`: fused kernels
+    that do several passes' work in one launch state their own algorithmic totals."""
     if not TIMER.enabled:
         L.call(fname, *args)
         return
     N, Cc, H, W, K, R, S, P, Q = geom
-    flops = 2.0 * N * P * Q * K * R * S * Cc
-    nbytes = 2.0 * (N * H * W * Cc + N * P * Q * K + K * R * S * Cc)
+    flops = 2.0 * N * P * Q * K * R * S * Cc * passes
+    if nbytes is None:
+        nbytes = 2.0 * (N * H * W * Cc + N * P * Q * K + K * R * S * Cc)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     L.call(fname, *args)
@@ -498,6 +500,65 @@ def _conv_grads(ctx, x, weight, dy, dy_ld, need_dx, need_dw, need_db):
     return dx, dw, dbias
 
 
+def _bwd1x1_ok(ctx, cfg, x, need_dx, need_dw, need_db, segs):
+    """True when the fused 1x1 backward kernel (conv1x1_bwd.hip: BN/act backward on load + dgrad + wgrad in one pass) takes
+    this layer: dense 1x1 stride-1, K in {32, 64, 128}, unpadded channels, both gradients wanted, 16-byte aligned operands."""
+    N, Cc, H, W, K, R, S, P, Q, Kp, x_ld, Cg = ctx.geom
+    if ctx.depthwise or R != 1 or S != 1 or Kp != K or Cg != Cc or ctx.c_orig != Cc or not (need_dx and need_dw):
+        return False
+    if (ctx.has_bias and need_db) or ctx.w_dgrad is None or x.data_ptr() % 16 or x_ld % 8:
+        return False
+    for d, d_ld in segs:
+        if d_ld % 8 or d.data_ptr() % 16:
+            return False
+    desc = conv_desc(N, Cc, H, W, K, R, S, cfg.stride, cfg.pad, cfg.dil, 1, x_ld, Kp)
+    return bool(L.load().cvhip_conv1x1_bwd_fused_ok(C.byref(desc)))
+
+
+def _bwd1x1(ctx, cfg, x, y, weight, segs, k_split, stats, with_mean, ag, ab, act, act_param):
+    """dx, dw of a 1x1 Conv-BN-act layer from the gradient(s) at its OUTPUT in one launch (`segs`: one (tensor, pitch), or two
+    for sibling pairs; `stats` rows: mean, invstd, scale, shift; ag / ab: sum du*xhat / sum du)."""
+    N, Cc, H, W, K, R, S, P, Q, Kp, x_ld, Cg = ctx.geom
+    dev = x.device
+    st = _stream()
+    arena = cfg.arena
+    direct_w = arena is not None and cfg.gw is not None and tuple(cfg.gw.shape) == tuple(weight.shape)
+    dw = None
+    if direct_w:
+        dst = cfg.gw
+    else:
+        dw = zero_fill(torch.empty((K, Cc, 1, 1), dtype=torch.float32, device=dev, memory_format=torch.channels_last))
+        dst = dw
+    dx = empty_nhwc(N, Cc, H, W, dev)
+    g, g_ld = None, 0
+    link = cfg.dx_link
+    if link is not None and link.g is not None:
+        g, g_ld = as_nhwc(link.g)
+        link.g = None
+        if tuple(g.shape) != (N, Cc, H, W):
+            raise L.CvhipError("GradLink: skip-connection gradient %s does not match the layer input %s" % (tuple(g.shape), (N, Cc, H, W)))
+        if g_ld % 8 or g.data_ptr() % 16:
+            g = g.contiguous(memory_format=torch.channels_last)
+            g_ld = Cc
+    desc = conv_desc(N, Cc, H, W, K, R, S, cfg.stride, cfg.pad, cfg.dil, 1, x_ld, Kp)
+    (d0, d0_ld) = segs[0]
+    (d1, d1_ld) = segs[1] if len(segs) > 1 else (None, 0)
+    sc = stats[2].data_ptr() if stats is not None else None
+    sh = stats[3].data_ptr() if stats is not None else None
+    mu = stats[0].data_ptr() if with_mean else None
+    isd = stats[1].data_ptr() if with_mean else None
+    M = N * H * W
+    _timed_call("bwd1x1_kernel", (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv1x1_bwd_fused", C.byref(desc), d0.data_ptr(), d0_ld,
+                _ptr(d1), d1_ld, k_split, y.data_ptr(), x.data_ptr(), ctx.w_dgrad.data_ptr(), sc, sh, mu, isd,
+                ag.data_ptr() if with_mean else None, ab.data_ptr() if with_mean else None, act, act_param, _ptr(g), g_ld,
+                dx.data_ptr(), Cc, dst.data_ptr(), st, passes=2, nbytes=2.0 * M * (2 * K + 2 * Cc))
+    if direct_w:
+        _mark(arena, cfg.idx_w)
+    if dw is not None and dw.dtype != weight.dtype:
+        dw = dw.to(weight.dtype)
+    return dx, dw
+
+
 class ConvBnAct(torch.autograd.Function):
     """z = act(bn(conv(x, W) + b)) (+ residual)   — any of bn / act / bias / residual optional.
 
@@ -652,6 +713,32 @@ class ConvBnAct(torch.autograd.Function):
         cv = Cg if (not ctx.depthwise and Cg != Cc) else 0
         pointwise = cfg.has_bn or act != L.ACT_NONE
         arena = cfg.arena
+        fused = pointwise and _bwd1x1_ok(ctx, cfg, x, need_dx, need_dw, need_db, ((dz, dz_ld),))
+        if fused:
+            # 1x1 layer: BN/activation backward applied on load inside ONE dgrad + wgrad kernel (no dy tensor, no separate passes)
+            ag = ab = None
+            if ctx.train_bn:
+                rows = _colreduce_rows(M, K)
+                partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
+                L.call("cvhip_bn_act_bwd_partial", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, M, K, stats[2].data_ptr(),
+                       stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), act, act_param,
+                       partial.data_ptr(), st)
+                dgamma = torch.empty((K,), dtype=torch.float32, device=dev)
+                dbeta = torch.empty((K,), dtype=torch.float32, device=dev)
+                direct_bn = arena is not None and cfg.gg is not None and cfg.gbeta is not None
+                L.call("cvhip_bn_bwd_finalize", partial.data_ptr(), rows, K, dgamma.data_ptr(), dbeta.data_ptr(),
+                       cfg.gg.data_ptr() if direct_bn else None, cfg.gbeta.data_ptr() if direct_bn else None, st)
+                if direct_bn:
+                    need_dg = need_dbeta = False
+                    for i in cfg.idx_bn:
+                        arena.mark_ready(i)
+                ag, ab = (dgamma, dbeta) if cfg.sync is None else _sync_bwd_sums(dgamma, dbeta, cfg.sync)
+            dx, dw = _bwd1x1(ctx, cfg, x, y, weight, ((dz, dz_ld),), K, stats, ctx.train_bn, ag, ab, act, act_param)
+            dres = dz if ctx.has_res else None
+            if dres is not None and cfg.res_link is not None and cfg.res_link.ok:
+                cfg.res_link.g = dres
+                dres = None
+            return dx, dw, None, (dgamma if need_dg else None), (dbeta if need_dbeta else None), None, None, dres, None
         if pointwise:
             if Kp != K:  # pad channels must read as zero in dgrad/wgrad
                 dy = zero_fill(torch.empty((N, P, Q, Kp), dtype=BF16, device=dev)).permute(0, 3, 1, 2)[:, :K]
@@ -728,12 +815,32 @@ class ConvBnActPair(torch.autograd.Function):
         dev = x.device
         M = N * P * Q
         st = _stream()
-        dy = empty_nhwc(N, K, P, Q, dev)
-        off = 0
+        segs = []
         for d, kh in ((d1, ctx.k1), (d2, K - ctx.k1)):
             if d is None:
                 d = zero_fill(empty_nhwc(N, kh, P, Q, dev))
-            d, d_ld = as_nhwc(d)
+            segs.append(as_nhwc(d))
+        if ctx.train_bn and cfg.sync is None and _bwd1x1_ok(ctx, cfg, x, ctx.needs_input_grad[0], True, False, segs):
+            # fused form: per-half BN sums, then ONE kernel for BN/act backward + dgrad + wgrad of both siblings
+            dgamma = torch.empty((K,), dtype=torch.float32, device=dev)
+            dbeta = torch.empty((K,), dtype=torch.float32, device=dev)
+            off = 0
+            for (d, d_ld), kh in zip(segs, (ctx.k1, K - ctx.k1)):
+                rows = _colreduce_rows(M, kh)
+                partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, kh), dtype=torch.float32, device=dev)
+                sc, sh, mean, invstd = (stats[i].data_ptr() + 4 * off for i in (2, 3, 0, 1))
+                L.call("cvhip_bn_act_bwd_partial", d.data_ptr(), d_ld, y.data_ptr() + 2 * off, Kp, M, kh, sc, sh, mean, invstd,
+                       cfg.act, cfg.act_param, partial.data_ptr(), st)
+                L.call("cvhip_bn_bwd_finalize", partial.data_ptr(), rows, kh, dgamma.data_ptr() + 4 * off, dbeta.data_ptr() + 4 * off,
+                       cfg.gg.data_ptr() + 4 * off, cfg.gbeta.data_ptr() + 4 * off, st)
+                off += kh
+            for i in cfg.idx_bn:
+                cfg.arena.mark_ready(i)
+            dx, _ = _bwd1x1(ctx, cfg, x, y, weight, segs, ctx.k1, stats, True, dgamma, dbeta, cfg.act, cfg.act_param)
+            return dx, None, None, None, None, None, None, None
+        dy = empty_nhwc(N, K, P, Q, dev)
+        off = 0
+        for (d, d_ld), kh in zip(segs, (ctx.k1, K - ctx.k1)):
             rows = _colreduce_rows(M, kh)
             partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, kh), dtype=torch.float32, device=dev)
             sc, sh, mean, invstd = (stats[i].data_ptr() + 4 * off for i in (2, 3, 0, 1))

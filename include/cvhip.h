@@ -140,6 +140,25 @@ int cvhip_conv2d_dgrad(const cvhip_conv_desc* d, const void* dy_bf16, const void
 int cvhip_conv2d_dgrad_add(const cvhip_conv_desc* d, const void* dy_bf16, const void* w_dgrad_bf16, const void* addend_bf16,
                            int32_t addend_ld, void* dx_bf16, void* stream);
 
+/* Fused backward of a 1x1 / stride-1 / unpadded Conv-BN-act layer (conv1x1_bwd.hip): ONE streaming launch replaces
+ * cvhip_bn_act_bwd_apply + cvhip_conv2d_dgrad(_add) + cvhip_conv2d_wgrad — aten::native_batch_norm_backward +
+ * silu_backward + convolution_backward reached from trainer.py:189 (loss.backward()) for the kernel_size-1 layers of
+ * src/models/bricks/conv_module.py:201-214. The BN/activation derivative is applied while the gradient is loaded, so the
+ * gradient at the convolution output never exists in memory:
+ *   dy = scale * (dz * act'(scale*y + shift) - dbeta/M - xhat * dgamma/M),  xhat = (y - mean) * invstd     (M = N*H*W)
+ *   dx = dy . W (+ addend)            dw += dy^T . x      (fp32, KRSC == [K][C]; ACCUMULATED: zero it first when needed)
+ * dz arrives as one tensor (k_split == K) or as two channel ranges [0,k_split) / [k_split,K) with their own pitches (sibling
+ * pairs); y has pitch d->y_ld, x pitch d->x_ld. scale/shift NULL = no BatchNorm (activation only); mean/invstd/dgamma/dbeta
+ * NULL = BatchNorm in eval mode. `cvhip_conv1x1_bwd_fused_ok` tells (pure host arithmetic) whether the kernel takes the
+ * geometry: K in {32,64,128}, C % 32 == 0, pitches % 8 == 0, N*H*W >= 4096; otherwise the call returns
+ * CVHIP_ERR_UNSUPPORTED and the three-pass form applies. All tensor pointers must be 16-byte aligned. */
+int cvhip_conv1x1_bwd_fused_ok(const cvhip_conv_desc* d);
+int cvhip_conv1x1_bwd_fused(const cvhip_conv_desc* d, const void* dz0_bf16, int32_t dz0_ld, const void* dz1_bf16, int32_t dz1_ld,
+                            int32_t k_split, const void* y_bf16, const void* x_bf16, const void* w_dgrad_bf16, const float* scale,
+                            const float* shift, const float* mean, const float* invstd, const float* dgamma, const float* dbeta,
+                            int32_t act, float act_param, const void* addend_bf16, int32_t addend_ld, void* dx_bf16, int32_t dx_ld,
+                            float* dw, void* stream);
+
 /* wgrad: dw[K][R][S][C] (fp32) (+)= sum over pixels dy^T * im2col(x); split-K over pixels with
  * fp32 atomics. accumulate==0 zero-fills dw first (hipMemsetAsync on `stream`). */
 int cvhip_conv2d_wgrad(const cvhip_conv_desc* d, const void* x_bf16, const void* dy_bf16,
