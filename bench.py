@@ -8,11 +8,17 @@ synthetic COCO-shape batch already resident in HBM (640
 per-GPU batch 64, weak scaling). One JSON line on rank 0.
 
 Extra objects:
-  roofline     : dominant conv kernel (by summed launch time, HIP events on the launch stream inside the
-                 timed region) against the MI355X roofline that binds it (MI355X_MICROARCH.md: 2.5 PFLOP/s
-                 dense bf16 MFMA, 8 TB/s HBM3E). Algorithmic flops/bytes per launch: DESIGN.md §4.
+  roofline     : the dominant kernel of the step (by summed launch time; HIP events on the launch stream around EVERY conv,
+                 fused-backward and BN/activation launch) against the MI355X roofline that binds it (MI355X_MICROARCH.md:
+                 2.5 PFLOP/s dense bf16 MFMA, 8 TB/s HBM3E), `conv_roofline` the same for the dominant MFMA conv kernel.
+                 Algorithmic flops/bytes per launch: DESIGN.md §4. `peaks_measured`: what a plain device copy and a bare
+                 MFMA loop reach on THIS box (the attainable ceilings beside the nominal ones).
+  with_h2d     : the same K steps fed through the on-device input pipeline (cvpytorch_amd.data.GraphFeed: pinned uint8 NHWC
+                 host batch -> copy stream -> fused normalise kernel -> the graph's static input): SURVEY.md §8(d)'s step,
+                 H2D inside the timed region and overlapped with the previous step. `value` stays the HBM-resident rate.
+  config3_deeplabv3plus_r50 : the metric's second workload (DeepLabv3+ R50 1024x512 bs16), K timed steps as well.
   cpu_baseline : the oracle (pure-PyTorch CPU restatement of the reference, fp32) timed on this box's
-                 host cores on a bounded sample (batch 8), rank 0, N == 1 only.
+                 host cores on a bounded sample, 32 threads and 1 thread, rank 0, N == 1 only.
 """
 import argparse
 import json
@@ -41,7 +47,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
-    ap.add_argument("--no-deeplab", action="store_true", help="skip the DeepLabv3+ (config 3) side workload")
+    ap.add_argument("--no-deeplab", action="store_true", help="skip the DeepLabv3+ (config 3) workload")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the host-fed leg (H2D inside the timed region)")
     ap.add_argument("--no-graph", action="store_true", help="run the timed steps eagerly instead of replaying a hipGraph")
     ap.add_argument("--stock-optimizer", action="store_true", help="torch.optim.SGD + ModelEMA instead of the fused arena step")
     ap.add_argument("--sync-bn", action="store_true", help="N > 1 only: HipSyncBN (trainer.py:126-127 converts BN to SyncBN under DDP); the step then runs eagerly")
@@ -49,13 +56,19 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(size, cpu_batch, budget_s=12.0, max_threads=32):
-    """Oracle train step on the host cores: bounded sample (SURVEY.md §8d 'CPU baseline').
-    Threads are capped at 32: with all 256 logical cores of the GPU box torch's intra-op pool oversubscribes and one batch-8
-    step took 192 s (0.04 img/s); the sample is sized so that warm-up + timed steps stay within ~30 s."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def _cpu_sample(size, cpu_batch, budget_s, threads):
     from oracle import torch_ref as R
     torch.manual_seed(1029)
-    threads = max(1, min(max_threads, os.cpu_count() or 1))
     torch.set_num_threads(threads)
     model = R.YOLOv5(80, "s").train()
     opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4)
@@ -81,13 +94,26 @@ def cpu_baseline(size, cpu_batch, budget_s=12.0, max_threads=32):
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 40:
             break
-    return {"value": round(b * n / el, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle (oracle/torch_ref.py) YOLOv5-s fp32 train step (fwd+loss+bwd+SGD-nesterov), batch %d @%dx%d, %d timed step(s) "
-                      "after a 1-image warm-up, %.1f s, %d intra-op threads of %d logical cores"
-                      % (b, size, size, n, el, torch.get_num_threads(), os.cpu_count() or 1)}
+    return b * n / el, b, n, el
 
 
-def deeplab_workload(dev, a, batch=16, size=(512, 1024), steps=5, warmup=2):
+def cpu_baseline(size, cpu_batch, budget_s=12.0, max_threads=32):
+    """Oracle train step on the host cores: bounded samples (SURVEY.md §8d 'CPU baseline') with `max_threads` intra-op threads
+    and with ONE thread. Threads are capped at 32: with all 256 logical cores of the GPU box torch's intra-op pool
+    oversubscribes and one batch-8 step took 192 s (0.04 img/s); the samples are sized so that warm-up + timed steps stay
+    within ~30 s together."""
+    threads = max(1, min(max_threads, os.cpu_count() or 1))
+    v, b, n, el = _cpu_sample(size, cpu_batch, budget_s, threads)
+    v1, b1, n1, el1 = _cpu_sample(size, 1, min(8.0, budget_s), 1)
+    return {"value": round(v, 3), "unit": "images/sec", "cores": threads, "kind": "port",
+            "value_1_thread": round(v1, 3), "cpu_model": _cpu_model(), "logical_cores": os.cpu_count() or 1,
+            "torch": torch.__version__,
+            "sample": "oracle (oracle/torch_ref.py) YOLOv5-s fp32 train step (fwd+loss+bwd+SGD-nesterov) @%dx%d: batch %d, %d timed step(s) after a "
+                      "1-image warm-up, %.1f s, %d intra-op threads of %d logical cores; 1-thread figure: batch %d, %d step(s), %.1f s"
+                      % (size, size, b, n, el, threads, os.cpu_count() or 1, b1, n1, el1)}
+
+
+def deeplab_workload(dev, a, batch=16, size=(512, 1024), steps=20, warmup=3):
     """Second headline workload of BASELINE.json's metric (config 3): DeepLabv3+ ResNet-50-v1c, 1024x512, bf16, batch 16,
     OS-32 as the reference builds it. Same step definition; reported next to the YOLOv5-s line."""
     from cvpytorch_amd import deeplab
@@ -145,6 +171,91 @@ def pmc_traffic(kernel_label):
             tot += v["launches"] * (2.0 * v["fetch_size_raw_kb_per_launch"] + v["write_size_raw_kb_per_launch"]) * 1024.0
     return round(tot / n) if n else None
 
+def measured_peaks(dev):
+    """What THIS box attains: a plain device copy (cvhip_copy2d over 512 MiB: bytes read + written per second) and a bare MFMA loop
+    (cvhip_probe_mfma_peak: 8 independent v_mfma_f32_32x32x16_bf16 per round, operands in registers). The nominal peaks
+    (8 TB/s, 2.5 PFLOP/s dense bf16) stay the denominators of `frac`; these are printed beside them."""
+    from cvpytorch_amd import lib as L
+    out = {}
+    M, C = 1 << 18, 1024                       # 256 Ki rows x 1024 bf16 = 512 MiB
+    a = torch.empty((M, C), dtype=torch.bfloat16, device=dev).normal_()
+    b = torch.empty_like(a)
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):
+        L.call("cvhip_copy2d", a.data_ptr(), C, b.data_ptr(), C, M, C, st)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    reps = 5
+    for _ in range(reps):
+        L.call("cvhip_copy2d", a.data_ptr(), C, b.data_ptr(), C, M, C, st)
+    e1.record()
+    torch.cuda.synchronize()
+    out["hbm_copy_gbs"] = round(reps * 2.0 * M * C * 2 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+    del a, b
+    blocks, iters = 256 * 4, 4096
+    scratch = torch.zeros(blocks, dtype=torch.float32, device=dev)
+    L.call("cvhip_probe_mfma_peak", 64, blocks, scratch.data_ptr(), st)
+    e0.record()
+    L.call("cvhip_probe_mfma_peak", iters, blocks, scratch.data_ptr(), st)
+    e1.record()
+    torch.cuda.synchronize()
+    out["mfma_bf16_tflops"] = round(blocks * 4.0 * iters * 8 * 2 * 32 * 32 * 16 / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
+    out["how"] = "device copy of 512 MiB bf16 (read+write bytes / time); 1024 blocks x 4 waves x 4096 rounds of 8 independent v_mfma_f32_32x32x16_bf16"
+    return out
+
+
+def _roof(name, d, timing_source):
+    sec = d["ms"] * 1e-3
+    tflops = d["flops"] / sec / 1e12
+    gbs = d["bytes"] / sec / 1e9
+    ai = d["flops"] / d["bytes"] if d["bytes"] else 0.0
+    balance = PEAK_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+    if ai < balance:
+        roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)}
+    else:
+        roof = {"bound": "mfma", "achieved": round(tflops, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tflops / PEAK_MFMA_TFLOPS, 4)}
+    roof.update({"traffic": pmc_traffic(name), "timing_source": timing_source, "kernel": name, "launches": d["launches"],
+                 "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2), "arith_intensity_flop_per_byte": round(ai, 1),
+                 "mfma_tflops": round(tflops, 1), "mfma_frac": round(tflops / PEAK_MFMA_TFLOPS, 4), "hbm_gbs": round(gbs, 1),
+                 "hbm_frac": round(gbs / PEAK_HBM_GBS, 4)})
+    return roof
+
+
+def h2d_leg(model, state, a, dev, imgs_f32, gts, steps):
+    """SURVEY.md §8(d)'s step: the batch starts on the HOST (pinned uint8 NHWC, what the CPU augmentation pipeline hands over)
+    and crosses PCIe inside the timed region, overlapped with the previous step (data.GraphFeed). Returns the extra JSON object."""
+    from cvpytorch_amd.arena import FlatTrainStep
+    from cvpytorch_amd.data import GraphFeed
+    from cvpytorch_amd import ops
+    B = imgs_f32.shape[0]
+    x0 = ops.images_to_nhwc(imgs_f32, cpad=8)                      # (B, 8, H, W) bf16 NHWC view: the format the feed produces
+    step = FlatTrainStep(model, state)
+    step.capture(x0, gts)
+    feed = GraphFeed(step.static_imgs, step.static_targets)
+    g = torch.Generator().manual_seed(1029)
+    host = [torch.randint(0, 256, (B, a.size, a.size, 3), generator=g, dtype=torch.uint8).pin_memory() for _ in range(2)]
+    tgt_host = gts.detach().cpu().pin_memory()
+    feed.stage(host[0], tgt_host)
+    for i in range(3):                                             # warm the pipeline
+        feed.commit()
+        feed.stage(host[(i + 1) & 1], tgt_host)
+        step(step.static_imgs, step.static_targets)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        feed.commit()
+        feed.stage(host[i & 1], tgt_host)
+        losses = step(step.static_imgs, step.static_targets)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"value": round(B * steps / el, 2), "unit": "images/sec", "ms_per_step": round(1e3 * el / steps, 3), "steps": steps,
+            "host_batch": "pinned uint8 NHWC %dx%dx%dx3 (%.1f MB) + pinned fp32 target tensor per step" % (B, a.size, a.size, B * a.size * a.size * 3 / 1e6),
+            "pipeline": "copy stream H2D into one of two device staging buffers, overlapped with the previous step's replay; main stream: "
+                        "cvhip_u8_nhwc_to_bf16_norm into the graph's static input, then the hipGraph replay",
+            "final_loss": round(float(losses["loss"]), 4)}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -152,16 +263,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP engine has no CPU fallback)")
-    backend = os.environ.get("CVHIP_DIST_BACKEND", "nccl")  # "gloo" lets N ranks share one GPU (control-flow smoke test only)
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    # transport: the RCCL communicator behind the C ABI (cvpytorch_amd/comm.py -> csrc/comm.hip); no torch process group is
+    # created. CVHIP_DIST_BACKEND=gloo is a control-flow smoke test only (N ranks sharing one GPU over torch.distributed/gloo).
+    backend = os.environ.get("CVHIP_DIST_BACKEND", "rccl")
+    dev_index = local_rank if backend == "rccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    from cvpytorch_amd import comm as CM
+    comm = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+        if backend == "rccl":
+            comm = CM.init_from_env(dev)
         else:
             dist.init_process_group(backend)
+            comm = CM.TorchDistComm()
+        CM.set_default(comm)
 
     from cvpytorch_amd import ops, yolov5
     from cvpytorch_amd.data import synthetic_detection_batch
@@ -176,25 +293,27 @@ def main():
         model = convert_sync_batchnorm(model)
     if world > 1:  # same initial weights everywhere (DDP broadcasts rank 0's at construction)
         for t in list(model.parameters()) + list(model.buffers()):
-            dist.broadcast(t.data, 0)
+            if t.is_floating_point():
+                comm.broadcast_(t.data, 0)
     if a.stock_optimizer:  # reference-shaped tail: .grad tensors -> torch.optim.SGD -> ModelEMA (+ GradBucketer)
         opt = build_optimizer(model, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4)
         ema = ModelEMA(model) if rank == 0 else None  # trainer.py:293: EMA on the main process only
-        bucketer = GradBucketer(model) if world > 1 else None
+        bucketer = GradBucketer(model, comm=comm) if world > 1 else None
         step = TrainStep(model, opt, ema, bucketer, sync_buffers=world > 1)
     else:  # flat arenas: direct gradient writes, in-place bucketed all-reduce, ONE fused SGD+EMA kernel
-        state = FlatTrainState(model, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4, use_ema=(rank == 0))
+        state = FlatTrainState(model, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4, use_ema=(rank == 0), comm=comm)
         step = FlatTrainStep(model, state, sync_buffers=world > 1)
     imgs, targets = synthetic_detection_batch(a.batch, a.size, seed=1029 + rank, max_boxes=max_boxes, device=dev)
     gts = yolov5.targets_to_tensor(targets, a.batch * max_boxes, dev)
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            comm.barrier()
         torch.cuda.synchronize()
 
-    # at world > 1 the graph holds forward + loss + backward; the gradient all-reduce and the fused optimizer run eagerly after it
-    use_graph = (not a.no_graph) and (not a.stock_optimizer) and not (a.sync_bn and world > 1)
+    # at world > 1 the bucketed RCCL all-reduces (and SyncBN's exchanges) are captured INSIDE the graph, on a forked stream that
+    # runs beside the rest of backward
+    use_graph = (not a.no_graph) and (not a.stock_optimizer) and not (a.sync_bn and world > 1 and not comm.capturable)
     for _ in range(a.warmup):
         step(imgs, gts)
     if use_graph:  # the W warm-up steps above ran eagerly; the K timed steps replay ONE hipGraph of the whole step
@@ -206,7 +325,8 @@ def main():
             sys.stderr.write("[bench] hipGraph capture failed on rank %d (%r): running eagerly\n" % (rank, e))
         if world > 1:  # every rank must run the same mode (the modes issue different collectives)
             flag = torch.tensor([ok], device=dev, dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            comm.allreduce_(flag, "min")
+            comm.wait()
             ok = int(flag.item())
         if ok:
             imgs, gts = step.static_imgs, step.static_targets
@@ -235,39 +355,32 @@ def main():
         timing_source = "HIP events around every conv launch in an eager re-run of the same K steps right after the timed region (the timed region replays a hipGraph)"
     if world > 1:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        comm.allreduce_(t, "max")
+        comm.wait()
         el = float(t.item())
     loss_val = float(losses["loss"])
 
     if rank == 0:
         gb = a.batch * world
         out = {
-            "metric": "images/sec/node train step, YOLOv5-s@640", "value": round(gb * a.steps / el, 2), "unit": "images/sec",
+            "metric": "images/sec/node train step, YOLOv5-s@640 (value) & DeepLabv3+R50@1024x512 (config3_deeplabv3plus_r50.value)", "value": round(gb * a.steps / el, 2), "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * el / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "coco_yolov5_s.yml YOLOv5-s %dx%d bf16 train step (fwd+loss+bwd+SGD-nesterov+EMA), per-GPU batch %d, "
                                    "synthetic COCO-shape tensors resident in HBM" % (a.size, a.size, a.batch),
                        "global_batch": gb, "parallelism": "dp%d" % world, "final_loss": round(loss_val, 4),
-                       "launch": ("hipGraph replay of the whole step" if world == 1 else "hipGraph replay of forward+loss+backward, then RCCL all-reduce of the gradient arena + fused optimizer") if use_graph else "eager"},
+                       "launch": ("hipGraph replay of the whole step" if world == 1 else ("hipGraph replay of the whole step incl. bucketed RCCL all-reduces (cvhip_allreduce_bucket) on a forked stream beside backward" if not step.eager_tail else "hipGraph replay of forward+loss+backward, then one all-reduce of the gradient arena + fused optimizer")) if use_graph else "eager"},
         }
         summ = ops.TIMER.summary()
         if summ:
-            dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
-            name, d = dom
-            sec = d["ms"] * 1e-3
-            tflops = d["flops"] / sec / 1e12
-            gbs = d["bytes"] / sec / 1e9
-            ai = d["flops"] / d["bytes"]
-            balance = PEAK_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
-            if ai < balance:
-                roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)}
-            else:
-                roof = {"bound": "mfma", "achieved": round(tflops, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(tflops / PEAK_MFMA_TFLOPS, 4)}
-            roof.update({"traffic": pmc_traffic(name), "timing_source": timing_source, "kernel": name, "launches": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
-                         "arith_intensity_flop_per_byte": round(ai, 1), "mfma_tflops": round(tflops, 1),
-                         "mfma_frac": round(tflops / PEAK_MFMA_TFLOPS, 4), "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4)})
-            out["roofline"] = roof
+            # the step's dominant kernel over EVERYTHING that was timed (convs, the fused 1x1 backward, BN/activation passes) ...
+            name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
+            out["roofline"] = _roof(name, d, timing_source)
+            # ... and the dominant MFMA convolution kernel (the north_star's "fraction of conv-MFMA roofline")
+            convs = {k: v for k, v in summ.items() if v["flops"] > 0 and not k.startswith("bwd1x1")}
+            if convs:
+                cname, cd = max(convs.items(), key=lambda kv: kv[1]["ms"])
+                out["conv_roofline"] = _roof(cname, cd, timing_source)
             out["kernels"] = {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / a.steps, 3),
                                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), "alg_gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
                               for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
@@ -275,16 +388,29 @@ def main():
             ips_gpu = a.batch * a.steps / el
             out["step_roofline"] = {"mfma_frac": round(ips_gpu * 49.30e9 / (PEAK_MFMA_TFLOPS * 1e12), 4),
                                     "hbm_frac": round(ips_gpu * 366e6 / (PEAK_HBM_GBS * 1e9), 4)}
+        if world == 1 and not a.no_kernel_timing:
+            try:
+                out["peaks_measured"] = measured_peaks(dev)
+            except Exception as e:
+                out["peaks_measured"] = {"error": repr(e)[:200]}
+        if world == 1 and not a.no_h2d and not a.stock_optimizer and not a.no_graph:
+            try:
+                out["with_h2d"] = h2d_leg(model, state, a, dev, imgs, gts, a.steps)
+            except Exception as e:  # the headline line must still be printed
+                out["with_h2d"] = {"error": repr(e)[:300]}
         if world == 1 and not a.no_deeplab:
             try:
-                out["config3_deeplabv3plus_r50"] = deeplab_workload(dev, a)
+                out["config3_deeplabv3plus_r50"] = deeplab_workload(dev, a, steps=max(a.steps, 20), warmup=max(a.warmup, 3))
             except Exception as e:  # the headline line must still be printed
                 out["config3_deeplabv3plus_r50"] = {"error": repr(e)[:300]}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.size, a.cpu_batch)
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.destroy_process_group()
+        comm.barrier()
+        comm.close()
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

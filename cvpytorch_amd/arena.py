@@ -22,8 +22,8 @@ import math
 from copy import deepcopy
 
 import torch
-import torch.distributed as dist
 
+from . import comm as CM
 from . import lib as L
 from . import ops
 from .train import build_param_groups
@@ -58,7 +58,7 @@ def paired_arena_order(items, follow):
 
 class FlatTrainState:
     def __init__(self, model, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4, backbone_lr=None, ema_decay=0.9999,
-                 use_ema=True, bucket_bytes=8 << 20, process_group=None):
+                 use_ema=True, bucket_bytes=8 << 20, process_group=None, comm=None, force_collectives=False):
         self.model = model
         self.momentum, self.nesterov = float(momentum), bool(nesterov)
         groups = build_param_groups(model, lr, backbone_lr, weight_decay)
@@ -166,8 +166,13 @@ class FlatTrainState:
                 m._buffers[name] = self.ema_buf[o:o + b.numel()].view(b.shape)
                 o += b.numel()
         # gradient buckets: contiguous arena ranges, filled in reverse registration order
-        self.group = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # transport: the RCCL communicator behind the C ABI (comm.RcclComm) in production; a torch.distributed (gloo) group
+        # only as the test transport for the multi-rank bookkeeping (comm.TorchDistComm)
+        self.comm = comm if comm is not None else CM.default_comm(process_group)
+        self.world = self.comm.world if self.comm is not None else 1
+        # `multi`: the collective machinery is live. force_collectives runs it over a 1-rank communicator too (every collective is
+        # then the identity): how the captured-RCCL path is exercised on a single GPU (tests/test_gpu_comm.py)
+        self.multi = self.world > 1 or (self.comm is not None and force_collectives)
         self.buckets = []  # [lo, hi, first_param, last_param]
         cap = max(1, bucket_bytes // 4)
         hi_i = len(self.params) - 1
@@ -183,12 +188,13 @@ class FlatTrainState:
             for k in range(lo_i, hi_i2 + 1):
                 self.bucket_of[k] = bi
         self._pending = None
-        self._works = []
         self._stream = None
-        # defer mode (hipGraph replay at world > 1): gradients are NOT reduced while backward runs (collectives are never
-        # captured); finish_allreduce() then reduces the whole gradient arena with ONE in-place collective on the current stream
+        self._uses = {}
+        # defer mode (hipGraph replay at world > 1 over a transport that cannot be captured): gradients are NOT reduced while
+        # backward runs; finish_allreduce() then reduces the whole gradient arena with ONE in-place collective on the current
+        # stream. With the RCCL communicator the bucket collectives are captured INSIDE the graph (side-stream branch) instead.
         self.defer_allreduce = False
-        if self.world > 1:
+        if self.multi:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
         self._reset_buckets()
@@ -197,20 +203,37 @@ class FlatTrainState:
     def _reset_buckets(self):
         self._pending = [hi - lo + 1 for (_, _, lo, hi) in self.buckets]
         self._seen = set()
-        self._works = []
+        self._uses = {}
+        self._next_bucket = 0
 
     def _hook(self, p):
         self.mark_ready(self.index[id(p)])
 
+    def note_use(self, i):
+        """Forward-side count of the ops that will accumulate into parameter i's gradient slot this step: a layer applied twice
+        must not release its bucket after the FIRST backward use (the second one is still accumulating into the same slot)."""
+        if self.multi:
+            for k in (i if isinstance(i, tuple) else (i,)):
+                if k is not None:
+                    self._uses[k] = self._uses.get(k, 0) + 1
+
     def mark_ready(self, i):
-        """Called when parameter i's gradient for this step is complete in the arena."""
-        if self.world == 1 or self.defer_allreduce or i in self._seen:
+        """Called when an op has finished writing its contribution to parameter i's gradient in the arena; the parameter is
+        complete once every forward use (note_use) has reported."""
+        if not self.multi or self.defer_allreduce or i in self._seen:
+            return
+        left = self._uses.get(i, 0)
+        if left > 1:
+            self._uses[i] = left - 1
             return
         self._seen.add(i)
         bi = self.bucket_of[i]
         self._pending[bi] -= 1
-        if self._pending[bi] == 0:
-            self._launch(bi)
+        # buckets go out in INDEX order only (as DDP's reducer does): the collective sequence is identical on every rank
+        # whatever order gradients complete in
+        while self._next_bucket < len(self.buckets) and self._pending[self._next_bucket] == 0:
+            self._launch(self._next_bucket)
+            self._next_bucket += 1
 
     def _launch(self, bi):
         lo, hi = self.buckets[bi][0], self.buckets[bi][1]
@@ -218,22 +241,20 @@ class FlatTrainState:
         if self._stream is None:
             self._stream = torch.cuda.Stream()
         self._stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self._stream):
-            w = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._works.append(w)
+        self.comm.allreduce_(flat, stream=self._stream)   # cvhip_allreduce_bucket on the side stream (a graph branch under capture)
 
     def finish_allreduce(self):
-        if self.world == 1:
+        if not self.multi:
             return
         if self.defer_allreduce:
-            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.group)
+            self.comm.allreduce_(self.grad)
+            self.comm.wait()
             return
-        for bi, n in enumerate(self._pending):
-            if n > 0:  # some parameters received no gradient this step (their arena slots are zero)
-                self._pending[bi] = 0
-                self._launch(bi)
-        for w in self._works:
-            w.wait()
+        for bi in range(self._next_bucket, len(self.buckets)):  # parameters without a gradient this step: their slots are zero
+            self._pending[bi] = 0
+            self._launch(bi)
+        self._next_bucket = len(self.buckets)
+        self.comm.wait()
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
 
@@ -343,11 +364,15 @@ class FlatTrainStep:
 
     def capture(self, imgs, targets, warmup=2):
         from .bricks import sync_of
-        if any(sync_of(mm) is not None for mm in self.model.modules()):
-            raise L.CvhipError("the step contains active HipSyncBN layers (collectives inside forward/backward): it is not captured; run it eagerly")
-        multi = self.state.world > 1  # collectives stay outside the graph(s): backward is replayed, then all-reduce + optimizer run eagerly
-        self.state.defer_allreduce = multi
-        self.eager_tail = multi
+        multi = self.state.multi
+        # RCCL collectives are captured with the kernels (bucket all-reduces become a parallel branch of the graph, SyncBN
+        # exchanges nodes of the main chain); over the test transport they stay outside: backward is replayed, then ONE
+        # all-reduce of the arena + the optimizer run eagerly
+        capturable = multi and self.state.comm.capturable
+        if not capturable and any(sync_of(mm) is not None for mm in self.model.modules()):
+            raise L.CvhipError("the step contains active HipSyncBN layers over a transport that cannot be captured: run it eagerly")
+        self.state.defer_allreduce = multi and not capturable
+        self.eager_tail = multi and not capturable
         if not torch.is_tensor(targets):
             raise L.CvhipError("capture needs the fixed-shape target tensor (e.g. yolov5.targets_to_tensor)")
         m, st = self.model, self.state
@@ -371,7 +396,7 @@ class FlatTrainStep:
                 losses = m.loss_from_features(feats, self.static_targets)
                 losses["loss"].backward()
                 ops.join_side()
-                if not multi:
+                if not self.eager_tail:
                     st.step_kernels()
             self.static_losses = losses
             self.g1, self.g2 = g, None
@@ -386,7 +411,7 @@ class FlatTrainStep:
         with torch.cuda.graph(g2, pool=pool, capture_error_mode="thread_local"):
             torch.autograd.backward(self.feats, grad_tensors=self.g_feats)
             ops.join_side()
-            if not multi:
+            if not self.eager_tail:
                 st.step_kernels()
         self.g1, self.g2 = g1, g2
 
@@ -397,8 +422,8 @@ class FlatTrainStep:
                 self.static_imgs.copy_(imgs, non_blocking=True)
             if targets is not self.static_targets:
                 self.static_targets.copy_(targets, non_blocking=True)
-            if self.sync_buffers and st.world > 1 and st.buf.numel():
-                dist.broadcast(st.buf, 0, group=st.group)  # DDP broadcast_buffers: ONE collective
+            if self.sync_buffers and st.multi and st.buf.numel():
+                st.comm.broadcast_(st.buf, 0)  # DDP broadcast_buffers: ONE collective
             st.pre_step()
             self.g1.replay()
             if self.g2 is None:  # single-graph step
@@ -416,8 +441,8 @@ class FlatTrainStep:
                 st.step_kernels()
             st.post_step()
             return losses
-        if self.sync_buffers and st.world > 1 and st.buf.numel():
-            dist.broadcast(st.buf, 0, group=st.group)  # DDP broadcast_buffers: ONE collective
+        if self.sync_buffers and st.multi and st.buf.numel():
+            st.comm.broadcast_(st.buf, 0)  # DDP broadcast_buffers: ONE collective
         st.pre_step()
         losses = self._eager(imgs, targets)
         st.post_step()

@@ -218,25 +218,31 @@ class HipBN(nn.BatchNorm2d):
 
 
 def sync_of(bn):
-    """(process_group, world) when `bn` is a HipSyncBN whose statistics must be shared right now, else None."""
+    """(comm, world) when `bn` is a HipSyncBN whose statistics must be shared right now, else None. The transport is the
+    layer's own `comm`, else the process-wide RCCL communicator (comm.set_default), else — test transport — the layer's
+    torch.distributed process group."""
     if not isinstance(bn, HipSyncBN) or not (bn.training or bn.running_mean is None):
         return None
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):
+    from . import comm as CM
+    c = bn.comm if bn.comm is not None else CM.default_comm(bn.process_group)
+    if c is None or c.world <= 1:
         return None
-    world = dist.get_world_size(bn.process_group)
-    return (bn.process_group, world) if world > 1 else None
+    if bn.comm is None:
+        bn.comm = c   # one transport object per layer (keeps async work handles of the test transport together)
+    return (c, c.world)
 
 
 class HipSyncBN(HipBN):
     """nn.SyncBatchNorm semantics (trainer.py:126-127) on the HIP engine: batch statistics are the statistics of the GLOBAL
     batch — forward all-reduces the per-channel (sum, sum of squares), backward all-reduces (sum dy, sum dy*xhat); 2K floats
     each, per layer. Equal per-rank batches are assumed (DistributedSampler). Eval mode and single-process runs behave as HipBN.
-    A step containing active HipSyncBN layers holds collectives and is therefore not captured into a hipGraph."""
+    Over the RCCL communicator (cvhip_comm_allreduce on the caller's stream) the exchanges are captured into the step's hipGraph
+    like any kernel; over the gloo test transport the step runs eagerly."""
 
-    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, process_group=None):
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, process_group=None, comm=None):
         super().__init__(num_features, eps, momentum, affine, track_running_stats)
         self.process_group = process_group
+        self.comm = comm
 
 
 def convert_sync_batchnorm(module, process_group=None):

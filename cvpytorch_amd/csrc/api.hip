@@ -203,6 +203,31 @@ __global__ __launch_bounds__(256, 2) void probe_lds_bw_kernel(float* out, int it
 }
 
 
+
+// MFMA issue-rate probe (bench.py "attainable peak"): every wave runs `iters` rounds of 8 INDEPENDENT v_mfma_f32_32x32x16_bf16
+// (8 accumulator sets: no dependent-accumulator stalls), operands in registers, nothing else. 4 waves per block, one per SIMD.
+// flops per launch = blocks * 4 waves * iters * 8 * (2*32*32*16).
+typedef __bf16 probe_bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void probe_mfma_peak_kernel(float* out, int iters) {
+  const int l = threadIdx.x;
+  probe_bf16x8 a, b;
+  for (int e = 0; e < 8; ++e) {
+    a[e] = (bf16_t)(0.001f * (float)((l * 7 + e * 3) % 17 - 8));
+    b[e] = (bf16_t)(0.002f * (float)((l * 5 + e) % 13 - 6));
+  }
+  f32x16 c[8];
+  for (int j = 0; j < 8; ++j)
+    for (int e = 0; e < 16; ++e) c[j][e] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c[j], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int j = 0; j < 8; ++j)
+    for (int e = 0; e < 16; ++e) s += c[j][e];
+  if (s == 123456.789f) out[blockIdx.x] = s;  // keeps the MFMAs live without a store on the normal path
+}
+
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
 __global__ void probe_tr16_kernel(const bf16_t* in, bf16_t* out) {
   // in: 64 lanes x 4 bf16 written linearly to LDS (lane l at byte l*8); every lane then issues
@@ -432,6 +457,12 @@ int cvhip_probe_grid_barrier(int32_t mode, int32_t iters, int32_t blocks, float*
   if (!scratch || !counter_zeroed || !out || iters <= 0 || blocks <= 0 || blocks > 1024) return CVHIP_ERR_INVALID;
   hipLaunchKernelGGL(probe_grid_barrier_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mode, iters, scratch, counter_zeroed, out);
   return check_launch("probe_grid_barrier_kernel");
+}
+
+int cvhip_probe_mfma_peak(int32_t iters, int32_t blocks, float* out, void* stream) {
+  if (!out || iters <= 0 || blocks <= 0) return CVHIP_ERR_INVALID;
+  hipLaunchKernelGGL(probe_mfma_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, iters);
+  return check_launch("probe_mfma_peak_kernel");
 }
 
 int cvhip_probe_lds_read_bw(int32_t mode, int32_t iters, int32_t blocks, float* out, void* stream) {

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void bwd1x1_kernel(const Bwd1x1Params p) {
   constexpr int D_ROWB = KB * 2, X_ROWB = CB * 2;
   constexpr int D_SEGM = KB / 16 - 1, X_SEGM = CB / 16 - 1;
   constexpr int W_ROWB = KB * 2 + 16;  // (KB/2 + 4) banks = 4 * odd: 16 weight rows hit 64 distinct banks
-  constexpr int W_BYTES = CB * W_ROWB, D_BYTES = RT * D_ROWB, X_BYTES = RT * X_ROWB;
+  constexpr int W_BYTES = CB * W_ROWB, D_BYTES = RT * D_ROWB;  // + RT * X_ROWB for the x tile
   constexpr int NF = CB / 16;   // dx fragments across the input channels (per wave: 16 pixel rows x CB)
   constexpr int KS = KB / 32;   // dgrad reduction steps
   constexpr int KF = KB / 32;   // dW fragments of a wave along K (wave owns K/2 x C/2)
@@ -306,17 +306,27 @@ static int bwd1x1_mode() {  // CVHIP_BWD1X1: 0 = never (three-pass backward), 1 
 
 static int bwd1x1_cb(int C) { return (C % 128 == 0) ? 128 : (C % 64 == 0) ? 64 : (C % 32 == 0) ? 32 : 0; }
 
-// 1 when the fused kernel takes this layer geometry
-int bwd1x1_fits(const cvhip_conv_desc* d) {
-  if (bwd1x1_mode() == 0) return 0;
+// structural fit: the kernel can run this layer geometry at all
+static int bwd1x1_structural(const cvhip_conv_desc* d) {
   if (d->groups != 1 || d->R != 1 || d->S != 1 || d->stride_h != 1 || d->stride_w != 1 || d->pad_h != 0 || d->pad_w != 0) return 0;
   if (d->K != 32 && d->K != 64 && d->K != 128) return 0;
   if (d->k_valid || d->c_valid) return 0;
   if (bwd1x1_cb(d->C) == 0 || d->C > 1024) return 0;
   if ((d->x_ld & 7) || (d->y_ld & 7)) return 0;
   const int64_t M = (int64_t)d->N * d->H * d->W;
-  if (M < 64 * 64 || M >= (1ll << 31) - 64 * 1024) return 0;  // tiny layers: the general kernels' split-K covers the chip better
+  if (M < 1 || M >= (1ll << 31) - 64 * 1024) return 0;
   return 1;
+}
+
+// policy: 1 when the fused kernel is also the faster form. Small layers (few 64-row trips per persistent block) expose the
+// per-trip load -> LDS -> MFMA latency and the K*C-atomics flush of every block: measured on YOLOv5-s (gpurun conv_table,
+// profiles/r02_*): 128->128 @40x40 (1600 trips) 65.8 us fused vs 60.6 us three-pass, everything from 3200 trips up wins 1.2-2x.
+int bwd1x1_fits(const cvhip_conv_desc* d) {
+  if (bwd1x1_mode() == 0 || !bwd1x1_structural(d)) return 0;
+  if (bwd1x1_mode() >= 2) return 1;  // CVHIP_BWD1X1=2: whenever structurally possible (tests)
+  const int64_t M = (int64_t)d->N * d->H * d->W;
+  const int64_t trips = ((M + 63) / 64) * (d->C / bwd1x1_cb(d->C));
+  return trips >= 2400 ? 1 : 0;
 }
 
 template <int KB, int CB>
@@ -338,13 +348,14 @@ static int launch_b1(const Bwd1x1Params& p, int blocks, hipStream_t s) {
 
 int launch_bwd1x1(Bwd1x1Params& p, hipStream_t s) {
   p.ntiles = (p.M + 63) / 64;
-  // persistent grid: <= 2 blocks per CU, >= 8 trips per block (the dW flush costs K*C atomics per block)
+  // persistent grid: <= 2 blocks per CU, >= 16 trips per block (the dW flush costs K*C atomics per block; A/B on the 80x80
+  // layers: 16 trips 101 us, 8 trips 110 us, <= 256 blocks 122 us)
   static int max_blocks = -1, min_trips = -1;
   if (max_blocks < 0) {
     const char* e = getenv("CVHIP_BWD1X1_BLOCKS");
     max_blocks = e ? atoi(e) : 512;
     const char* f = getenv("CVHIP_BWD1X1_MINTRIPS");
-    min_trips = f ? atoi(f) : 8;
+    min_trips = f ? atoi(f) : 16;
   }
   const int cb = bwd1x1_cb(p.C);
   const int slices = p.C / cb;
@@ -378,7 +389,7 @@ int cvhip_conv1x1_bwd_fused(const cvhip_conv_desc* d, const void* dz0, int32_t d
                             const float* invstd, const float* dgamma, const float* dbeta, int32_t act, float act_param,
                             const void* addend, int32_t addend_ld, void* dx, int32_t dx_ld, float* dw, void* stream) {
   if (!d || !dz0 || !y || !x || !w_dgrad || !dx || !dw) return CVHIP_ERR_INVALID;
-  if (!bwd1x1_fits(d)) return CVHIP_ERR_UNSUPPORTED;
+  if (!bwd1x1_structural(d)) return CVHIP_ERR_UNSUPPORTED;
   if (k_split <= 0 || k_split > d->K || (k_split & 7)) return CVHIP_ERR_INVALID;
   if (k_split < d->K && (!dz1 || (dz1_ld & 7) || (((uintptr_t)dz1) & 15))) return CVHIP_ERR_INVALID;
   if ((dz0_ld & 7) || (dx_ld & 7) || dx_ld < d->C) return CVHIP_ERR_INVALID;

@@ -18,6 +18,8 @@ LIB_PATH = os.path.join(_HERE, "libcvhip.so")
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -1, -2, -3
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_LEAKY, ACT_SIGMOID, ACT_HSWISH = 0, 1, 2, 3, 4, 5
+DTYPE_F32, DTYPE_F64, DTYPE_I32, DTYPE_BF16, DTYPE_U8 = 0, 1, 2, 3, 4
+RED_SUM, RED_MAX, RED_MIN = 0, 1, 2
 DGRAD_CLASS_INTS = 12
 REDUCE_SCRATCH_ROWS = 64  # CVHIP_REDUCE_SCRATCH_ROWS
 
@@ -132,9 +134,23 @@ SIGNATURES = {
     "cvhip_simota_loss_fwd": (_i32, [_smp, _pp, _p, _p, _p, _p]),
     "cvhip_simota_loss_bwd": (_i32, [_smp, _pp, _p, _p, _p, _pp, _p]),
     "cvhip_simota_read_assignment": (_i32, [_smp, _p, _p, _p, _p]),
+    "cvhip_comm_available": (_i32, []),
+    "cvhip_comm_rccl_version": (_i32, []),
+    "cvhip_comm_unique_id_bytes": (_i32, []),
+    "cvhip_comm_get_unique_id": (_i32, [_p]),
+    "cvhip_comm_init_rank": (_i32, [_pp, _i32, _i32, _p]),
+    "cvhip_comm_destroy": (_i32, [_p]),
+    "cvhip_comm_world": (_i32, [_p]),
+    "cvhip_comm_rank": (_i32, [_p]),
+    "cvhip_allreduce_bucket": (_i32, [_p, _p, _i64, _p]),
+    "cvhip_comm_allreduce": (_i32, [_p, _p, _i64, _i32, _i32, _p]),
+    "cvhip_comm_broadcast": (_i32, [_p, _p, _i64, _i32, _p]),
+    "cvhip_comm_reduce_scatter_f32": (_i32, [_p, _p, _i64, _p]),
+    "cvhip_comm_all_gather_f32": (_i32, [_p, _p, _i64, _p]),
     "cvhip_probe_mfma_16x16x32": (_i32, [_p, _p, _p, _p]),
     "cvhip_probe_ds_read_tr16": (_i32, [_p, _p, _p]),
     "cvhip_probe_lds_read_bw": (_i32, [_i32, _i32, _i32, _p, _p]),
+    "cvhip_probe_mfma_peak": (_i32, [_i32, _i32, _p, _p]),
 }
 
 _lib = None

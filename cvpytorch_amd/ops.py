@@ -111,6 +111,21 @@ def _timed_call(kname, geom, fname, *args, passes=1, nbytes=None):
     TIMER.detail.append((fname, geom))
 
 
+
+def _timed_ew(kname, nbytes, fname, *args):
+    """Elementwise / reduction passes (BN + activation forward, BN-backward sums, BN-backward apply) under the same HIP-event
+    timing as the conv launches: algorithmic bytes = every operand read or written once (bf16), no flops credited."""
+    if not TIMER.enabled:
+        L.call(fname, *args)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.call(fname, *args)
+    e1.record()
+    TIMER.records.append((kname, 0.0, float(nbytes), e0, e1))
+    TIMER.detail.append((fname, None))
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -355,21 +370,19 @@ class ConvCfg:
 def _sync_fwd_totals(partial, rows, K, M, sync):
     """Local partial rows [rows][2][K] -> global (sum, sum of squares) over all ranks as a 1-row partial buffer and the
     global element count. One all-reduce of 2K floats (equal per-rank batches, as DistributedSampler gives)."""
-    import torch.distributed as dist
-    group, world = sync
+    comm, world = sync
     tot = torch.empty((1 + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=partial.device)
     L.call("cvhip_bn_bwd_finalize", partial.data_ptr(), rows, K, tot[0, 1].data_ptr(), tot[0, 0].data_ptr(), None, None, _stream())
-    dist.all_reduce(tot[0], op=dist.ReduceOp.SUM, group=group)
+    comm.allreduce_(tot[0])   # RCCL through the C ABI on the current stream (capturable); gloo only as the test transport
     return tot, 1, M * world
 
 
 def _sync_bwd_sums(dgamma, dbeta, sync):
     """Global (sum dy*xhat, sum dy) scaled by 1/world: cvhip_bn_act_bwd_apply divides by the LOCAL row count, and
     global_sum / M_total == (global_sum / world) / M_local. The parameter gradients stay local (DDP averages them later)."""
-    import torch.distributed as dist
-    group, world = sync
+    comm, world = sync
     g = torch.stack([dgamma, dbeta])
-    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+    comm.allreduce_(g)
     g = g / world
     return g[0], g[1]
 
@@ -451,7 +464,7 @@ def _conv_grads(ctx, x, weight, dy, dy_ld, need_dx, need_dw, need_db):
             desc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, x_ld, dy_ld, kv, cv)
             padded = (Kp != K) or (Cg != Cc)
             geom = (N, Cc, H, W, K, R, S, P, Q)
-            if not padded and direct_w and _Side.enabled and not TIMER.enabled and (arena.world == 1 or arena.defer_allreduce):
+            if not padded and direct_w and _Side.enabled and not TIMER.enabled and (not arena.multi or arena.defer_allreduce):
                 # same, on the side stream (see _Side): runs concurrently with the dgrad / BN-backward chain
                 side = _side_begin()
                 with torch.cuda.stream(side):
@@ -656,7 +669,7 @@ class ConvBnAct(torch.autograd.Function):
             z2, z2_ld = _check_out(z2, N, K - k1, P, Q)
             z1 = empty_nhwc(N, k1, P, Q, dev)
             for off, kh, zz, zld in ((0, k1, z1, k1), (k1, K - k1, z2, z2_ld)):
-                L.call("cvhip_bn_act_fwd", y.data_ptr() + 2 * off, Kp, zz.data_ptr(), zld, M, kh, stats[2].data_ptr() + 4 * off,
+                _timed_ew("bn_act_fwd(ew_kernel<0>)", 4.0 * M * kh, "cvhip_bn_act_fwd", y.data_ptr() + 2 * off, Kp, zz.data_ptr(), zld, M, kh, stats[2].data_ptr() + 4 * off,
                        stats[3].data_ptr() + 4 * off, cfg.act, cfg.act_param, None, 0, st)
             z = (z1, z2)
         elif cfg.has_bn or cfg.act != L.ACT_NONE or residual is not None:
@@ -667,12 +680,18 @@ class ConvBnAct(torch.autograd.Function):
             res_pre = bool(cfg.res_pre and residual is not None)
             if res_pre and (cfg.act not in (L.ACT_NONE, L.ACT_RELU, L.ACT_LEAKY) or Kp != K):
                 raise L.CvhipError("res_pre needs none / ReLU / LeakyReLU and an unpadded channel count")
-            L.call("cvhip_bn_add_act_fwd" if res_pre else "cvhip_bn_act_fwd", y.data_ptr(), Kp, z.data_ptr(), z_ld, M, K,
+            _timed_ew("bn_act_fwd(ew_kernel<0>)", 2.0 * M * K * (3 if residual is not None else 2),
+                      "cvhip_bn_add_act_fwd" if res_pre else "cvhip_bn_act_fwd", y.data_ptr(), Kp, z.data_ptr(), z_ld, M, K,
                    _ptr(stats[2]) if stats is not None else None, _ptr(stats[3]) if stats is not None else None,
                    cfg.act, cfg.act_param, _ptr(residual), res_ld, st)
         else:
             z = y
         ctx.cfg = cfg
+        if cfg.arena is not None and ctx.needs_input_grad[1]:
+            # bucketed all-reduce: a parameter's bucket may only go once EVERY op that accumulates into its slot has run backward
+            cfg.arena.note_use(cfg.idx_w)
+            cfg.arena.note_use(cfg.idx_b)
+            cfg.arena.note_use(tuple(cfg.idx_bn))
         ctx.geom = (N, Cc, H, W, K, R, S, P, Q, Kp, x_ld, Cg)
         ctx.c_orig = c_orig
         ctx.train_bn = train_bn
@@ -720,7 +739,7 @@ class ConvBnAct(torch.autograd.Function):
             if ctx.train_bn:
                 rows = _colreduce_rows(M, K)
                 partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
-                L.call("cvhip_bn_act_bwd_partial", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, M, K, stats[2].data_ptr(),
+                _timed_ew("bn_act_bwd_sums(colreduce_kernel<1>)", 4.0 * M * K, "cvhip_bn_act_bwd_partial", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, M, K, stats[2].data_ptr(),
                        stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), act, act_param,
                        partial.data_ptr(), st)
                 dgamma = torch.empty((K,), dtype=torch.float32, device=dev)
@@ -747,7 +766,7 @@ class ConvBnAct(torch.autograd.Function):
             if ctx.train_bn:
                 rows = _colreduce_rows(M, K)
                 partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
-                L.call("cvhip_bn_act_bwd_partial", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, M, K, stats[2].data_ptr(),
+                _timed_ew("bn_act_bwd_sums(colreduce_kernel<1>)", 4.0 * M * K, "cvhip_bn_act_bwd_partial", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, M, K, stats[2].data_ptr(),
                        stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), act, act_param,
                        partial.data_ptr(), st)
                 dgamma = torch.empty((K,), dtype=torch.float32, device=dev)
@@ -760,8 +779,8 @@ class ConvBnAct(torch.autograd.Function):
                     for i in cfg.idx_bn:
                         arena.mark_ready(i)
                 ag, ab = (dgamma, dbeta) if cfg.sync is None else _sync_bwd_sums(dgamma, dbeta, cfg.sync)
-                L.call("cvhip_bn_act_bwd_apply", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, dy.data_ptr(), Kp, M, K,
-                       stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+                _timed_ew("bn_act_bwd_apply(ew_kernel<1>)", 6.0 * M * K, "cvhip_bn_act_bwd_apply", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, dy.data_ptr(), Kp, M, K,
+                          stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
                        ag.data_ptr(), ab.data_ptr(), act, act_param, st)
             else:
                 sc = stats[2].data_ptr() if stats is not None else None
@@ -829,7 +848,7 @@ class ConvBnActPair(torch.autograd.Function):
                 rows = _colreduce_rows(M, kh)
                 partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, kh), dtype=torch.float32, device=dev)
                 sc, sh, mean, invstd = (stats[i].data_ptr() + 4 * off for i in (2, 3, 0, 1))
-                L.call("cvhip_bn_act_bwd_partial", d.data_ptr(), d_ld, y.data_ptr() + 2 * off, Kp, M, kh, sc, sh, mean, invstd,
+                _timed_ew("bn_act_bwd_sums(colreduce_kernel<1>)", 4.0 * M * kh, "cvhip_bn_act_bwd_partial", d.data_ptr(), d_ld, y.data_ptr() + 2 * off, Kp, M, kh, sc, sh, mean, invstd,
                        cfg.act, cfg.act_param, partial.data_ptr(), st)
                 L.call("cvhip_bn_bwd_finalize", partial.data_ptr(), rows, kh, dgamma.data_ptr() + 4 * off, dbeta.data_ptr() + 4 * off,
                        cfg.gg.data_ptr() + 4 * off, cfg.gbeta.data_ptr() + 4 * off, st)
@@ -844,13 +863,13 @@ class ConvBnActPair(torch.autograd.Function):
             rows = _colreduce_rows(M, kh)
             partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, kh), dtype=torch.float32, device=dev)
             sc, sh, mean, invstd = (stats[i].data_ptr() + 4 * off for i in (2, 3, 0, 1))
-            L.call("cvhip_bn_act_bwd_partial", d.data_ptr(), d_ld, y.data_ptr() + 2 * off, Kp, M, kh, sc, sh, mean, invstd,
+            _timed_ew("bn_act_bwd_sums(colreduce_kernel<1>)", 4.0 * M * kh, "cvhip_bn_act_bwd_partial", d.data_ptr(), d_ld, y.data_ptr() + 2 * off, Kp, M, kh, sc, sh, mean, invstd,
                    cfg.act, cfg.act_param, partial.data_ptr(), st)
             dgamma = torch.empty((kh,), dtype=torch.float32, device=dev)
             dbeta = torch.empty((kh,), dtype=torch.float32, device=dev)
             L.call("cvhip_bn_bwd_finalize", partial.data_ptr(), rows, kh, dgamma.data_ptr(), dbeta.data_ptr(),
                    cfg.gg.data_ptr() + 4 * off, cfg.gbeta.data_ptr() + 4 * off, st)
-            L.call("cvhip_bn_act_bwd_apply", d.data_ptr(), d_ld, y.data_ptr() + 2 * off, Kp, dy.data_ptr() + 2 * off, Kp, M, kh,
+            _timed_ew("bn_act_bwd_apply(ew_kernel<1>)", 6.0 * M * kh, "cvhip_bn_act_bwd_apply", d.data_ptr(), d_ld, y.data_ptr() + 2 * off, Kp, dy.data_ptr() + 2 * off, Kp, M, kh,
                    sc, sh, mean, invstd, dgamma.data_ptr(), dbeta.data_ptr(), cfg.act, cfg.act_param, st)
             off += kh
         for i in cfg.idx_bn:

@@ -89,9 +89,10 @@ class GradBucketer:
     small enough to start while most of backward is still running.
     """
 
-    def __init__(self, model, bucket_bytes=8 << 20, process_group=None):
-        self.group = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+    def __init__(self, model, bucket_bytes=8 << 20, process_group=None, comm=None):
+        from . import comm as CM
+        self.comm = comm if comm is not None else CM.default_comm(process_group)
+        self.world = self.comm.world if self.comm is not None else 1
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.buckets = []  # (flat tensor, [(param, offset, numel)])
         self._slot = {}
@@ -106,7 +107,7 @@ class GradBucketer:
         if cur:
             self._close(cur, cur_n)
         self._pending = [0] * len(self.buckets)
-        self._works = []
+        self._launched = []
         self._stream = None
         self._hooks = []
         if self.world > 1:
@@ -124,61 +125,75 @@ class GradBucketer:
 
     def reset(self):
         self._pending = [len(items) for _, items in self.buckets]
-        self._works = []
+        self._launched = [False] * len(self.buckets)
+        self._got = set()
+        self._next = 0
 
     def _on_grad(self, p):
         bi, off, ne = self._slot[p]
         flat = self.buckets[bi][0]
         flat[off:off + ne].copy_(p.grad.reshape(-1))
+        self._got.add(p)
         self._pending[bi] -= 1
-        if self._pending[bi] == 0:
-            self._launch(bi)
+        self._launch_in_order()
+
+    def _launch_in_order(self):
+        """Buckets go out in INDEX order only (as DDP's reducer does): a full bucket waits until all lower-numbered ones have
+        been launched, so the collective sequence is the same on every rank whatever order gradients arrive in."""
+        while self._next < len(self.buckets) and self._pending[self._next] == 0:
+            self._launch(self._next)
+            self._next += 1
 
     def _launch(self, bi):
         flat = self.buckets[bi][0]
+        self._launched[bi] = True
         if flat.is_cuda:
             if self._stream is None:
                 self._stream = torch.cuda.Stream()
             self._stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self._stream):
-                w = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.comm.allreduce_(flat, stream=self._stream)
         else:
-            w = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._works.append((bi, w))
+            self.comm.allreduce_(flat)
 
     def finish(self):
-        """Wait for all buckets, average, write back into .grad. Call after backward()."""
+        """Wait for all buckets, average, write back into .grad. Call after backward().
+        EVERY bucket is reduced on every rank, the ones backward did not complete in fixed index order with zero-filled slots for
+        the parameters that got no gradient on this rank (data-dependent branches): the collective sequence never depends on
+        which gradients a rank happened to produce, and a rank without a local gradient still receives the average."""
         if self.world == 1:
             return
-        for bi, n in enumerate(self._pending):  # params that produced no grad this step
-            if n != 0 and n != len(self.buckets[bi][1]):
-                for p, off, ne in self.buckets[bi][1]:
-                    if p.grad is None:
-                        self.buckets[bi][0][off:off + ne].zero_()
-                self._launch(bi)
-        for bi, w in self._works:
-            w.wait()
+        for bi in range(self._next, len(self.buckets)):
+            flat, items = self.buckets[bi]
+            for p, off, ne in items:
+                if p not in self._got:
+                    flat[off:off + ne].zero_()
+            self._launch(bi)
+        self._next = len(self.buckets)
+        self.comm.wait()
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
         inv = 1.0 / self.world
-        for bi, _ in self._works:
-            flat, items = self.buckets[bi]
+        for flat, items in self.buckets:
             flat.mul_(inv)
             for p, off, ne in items:
-                if p.grad is not None:
+                if p.grad is None:
+                    p.grad = flat[off:off + ne].view_as(p).clone()
+                else:
                     p.grad.copy_(flat[off:off + ne].view_as(p.grad))
         self.reset()
 
 
-def broadcast_buffers(model, src=0):
+def broadcast_buffers(model, src=0, comm=None):
     """DDP(broadcast_buffers=True): BN running stats follow rank 0 every iteration."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    from . import comm as CM
+    comm = comm if comm is not None else CM.default_comm()
+    if comm is None or comm.world == 1:
         return
     bufs = [b for b in model.buffers() if b.dtype.is_floating_point]
     if not bufs:
         return
     flat = torch.cat([b.reshape(-1) for b in bufs])
-    dist.broadcast(flat, src)
+    comm.broadcast_(flat, src)
     off = 0
     for b in bufs:
         b.copy_(flat[off:off + b.numel()].view_as(b))

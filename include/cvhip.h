@@ -149,9 +149,10 @@ int cvhip_conv2d_dgrad_add(const cvhip_conv_desc* d, const void* dy_bf16, const 
  *   dx = dy . W (+ addend)            dw += dy^T . x      (fp32, KRSC == [K][C]; ACCUMULATED: zero it first when needed)
  * dz arrives as one tensor (k_split == K) or as two channel ranges [0,k_split) / [k_split,K) with their own pitches (sibling
  * pairs); y has pitch d->y_ld, x pitch d->x_ld. scale/shift NULL = no BatchNorm (activation only); mean/invstd/dgamma/dbeta
- * NULL = BatchNorm in eval mode. `cvhip_conv1x1_bwd_fused_ok` tells (pure host arithmetic) whether the kernel takes the
- * geometry: K in {32,64,128}, C % 32 == 0, pitches % 8 == 0, N*H*W >= 4096; otherwise the call returns
- * CVHIP_ERR_UNSUPPORTED and the three-pass form applies. All tensor pointers must be 16-byte aligned. */
+ * NULL = BatchNorm in eval mode. The kernel takes K in {32,64,128}, C % 32 == 0 (<= 1024), pitches % 8 == 0 (otherwise
+ * CVHIP_ERR_UNSUPPORTED: the three-pass form applies); `cvhip_conv1x1_bwd_fused_ok` is the POLICY query (pure host arithmetic):
+ * 1 when the geometry fits and the layer is large enough for the fused form to be the faster one (>= 2400 64-row trips;
+ * CVHIP_BWD1X1=0 never, =2 whenever it fits). All tensor pointers must be 16-byte aligned. */
 int cvhip_conv1x1_bwd_fused_ok(const cvhip_conv_desc* d);
 int cvhip_conv1x1_bwd_fused(const cvhip_conv_desc* d, const void* dz0_bf16, int32_t dz0_ld, const void* dz1_bf16, int32_t dz1_ld,
                             int32_t k_split, const void* y_bf16, const void* x_bf16, const void* w_dgrad_bf16, const float* scale,
@@ -432,6 +433,45 @@ int cvhip_simota_loss_bwd(const cvhip_simota_desc* d, const void* const* raws, c
 int cvhip_simota_read_assignment(const cvhip_simota_desc* d, void* ws, int32_t* matched_out, float* miou_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Data-parallel collectives (comm.hip): an RCCL communicator behind the C ABI, one process per GPU over xGMI.
+ * Replaces torch.nn.parallel.DistributedDataParallel's reducer + ProcessGroupNCCL reached from trainer.py:312-313 (DDP wrap:
+ * bucketed gradient all-reduce overlapped with backward, buffer broadcast) and src/utils/distributed.py:82-98
+ * (init_process_group('nccl')); SyncBatchNorm's statistics exchange (trainer.py:126-127) uses cvhip_comm_allreduce too.
+ * librccl is bound at run time (dlopen; the copy already mapped into the process wins, then $CVHIP_RCCL_PATH, librccl.so,
+ * librccl.so.1). Rendezvous is the host's business: rank 0 calls cvhip_comm_get_unique_id and hands the
+ * cvhip_comm_unique_id_bytes() opaque bytes to the other ranks over any channel; every rank then calls
+ * cvhip_comm_init_rank with ITS HIP device current. All collectives are in place, asynchronous on `stream`, non-allocating
+ * and capturable in a hipGraph.
+ * ------------------------------------------------------------------------------------------ */
+#define CVHIP_DTYPE_F32 0
+#define CVHIP_DTYPE_F64 1
+#define CVHIP_DTYPE_I32 2
+#define CVHIP_DTYPE_BF16 3
+#define CVHIP_DTYPE_U8 4
+#define CVHIP_RED_SUM 0
+#define CVHIP_RED_MAX 1
+#define CVHIP_RED_MIN 2
+int cvhip_comm_available(void);     /* 1 when librccl could be bound in this process */
+int cvhip_comm_rccl_version(void);  /* ncclGetVersion code, 0 when unavailable */
+int cvhip_comm_unique_id_bytes(void);
+int cvhip_comm_get_unique_id(void* id_out);
+int cvhip_comm_init_rank(void** comm_out, int32_t world, int32_t rank, const void* unique_id);
+int cvhip_comm_destroy(void* comm);
+int cvhip_comm_world(void* comm);
+int cvhip_comm_rank(void* comm);
+/* gradient bucket: in-place SUM all-reduce of `count` fp32 values of the gradient arena (the 1/world average is folded into
+ * the optimizer kernel's grad_scale) */
+int cvhip_allreduce_bucket(void* comm, void* buf_f32, int64_t count, void* stream);
+int cvhip_comm_allreduce(void* comm, void* buf, int64_t count, int32_t dtype, int32_t op, void* stream);
+/* DDP broadcast_buffers / initial parameter broadcast: `bytes` raw bytes from rank `root` */
+int cvhip_comm_broadcast(void* comm, void* buf, int64_t bytes, int32_t root, void* stream);
+/* the all-reduce split in its two ring phases (count % world == 0): after reduce_scatter rank r owns the complete sum of
+ * chunk r; all_gather then publishes every chunk. Equivalent to cvhip_allreduce_bucket; lets the host overlap the
+ * all-gather with the next forward or shard the optimizer between the phases. */
+int cvhip_comm_reduce_scatter_f32(void* comm, void* buf_f32, int64_t count, void* stream);
+int cvhip_comm_all_gather_f32(void* comm, void* buf_f32, int64_t count, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Hardware probes used by the GPU test-suite to pin the MFMA / LDS-transpose lane layouts the
  * kernels rely on (cdna_hip_programming.md §3, T10). out buffers are small fp32 arrays.
  * ------------------------------------------------------------------------------------------ */
@@ -445,6 +485,9 @@ int cvhip_probe_ds_read_tr16(const void* in_bf16_64x4, void* out_bf16_64x4, void
  * __threadfence, 1 = agent-scope atomic stores/loads without fences. `counter_zeroed`: one zeroed uint32; `scratch`: 2*blocks floats. */
 int cvhip_probe_grid_barrier(int32_t mode, int32_t iters, int32_t blocks, float* scratch, uint32_t* counter_zeroed, float* out, void* stream);
 int cvhip_probe_lds_read_bw(int32_t mode, int32_t iters, int32_t blocks, float* out, void* stream);
+/* MFMA issue-rate probe (bench.py's measured attainable peak beside the nominal 2.5 PFLOP/s): `blocks` x 4 waves run `iters`
+ * rounds of 8 independent v_mfma_f32_32x32x16_bf16 on register operands; flops = blocks*4*iters*8*32768. `out`: >= blocks floats. */
+int cvhip_probe_mfma_peak(int32_t iters, int32_t blocks, float* out, void* stream);
 
 #ifdef __cplusplus
 }

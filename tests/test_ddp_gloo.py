@@ -76,3 +76,45 @@ def test_grad_bucketer_single_process_is_noop():
     g = m.weight.grad.clone()
     b.finish()
     assert torch.equal(m.weight.grad, g)
+
+
+def _worker_uneven(rank, world, port, q):
+    """Rank 1 never touches the second branch: rank 0 has a gradient for it, rank 1 has none. Every rank must still issue the
+    same collectives (no hang) and END with the same averaged gradient — including rank 1, whose .grad was None."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cvpytorch_amd.train import GradBucketer
+    torch.manual_seed(0)
+    a, b = nn.Linear(6, 6), nn.Linear(6, 6)
+    model = nn.ModuleList([a, b])
+    bucketer = GradBucketer(model, bucket_bytes=64)   # one parameter per bucket
+    x = torch.ones(2, 6) * (rank + 1)
+    out = a(x).sum()
+    if rank == 0:
+        out = out + b(x).sum()   # data-dependent branch
+    out.backward()
+    local_b = b.weight.grad.clone() if b.weight.grad is not None else torch.zeros_like(b.weight)
+    bucketer.finish()
+    exp = local_b.clone()
+    dist.all_reduce(exp)
+    ok = b.weight.grad is not None and torch.allclose(b.weight.grad, exp / world)
+    g = b.weight.grad.clone()
+    dist.broadcast(g, 0)
+    ok = ok and torch.equal(g, b.weight.grad)   # replicas agree
+    q.put((rank, [bool(ok)]))
+    dist.destroy_process_group()
+
+
+def test_grad_bucketer_ranks_with_different_gradient_sets():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_uneven, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res in out:
+        assert all(res), (rank, res)

@@ -85,7 +85,6 @@ def test_bwd1x1_fused_vs_cpu(case):
     dw_ref = dyb.t() @ x.float()
     d = dev()
     desc = L.ConvDesc(N, Cc, H, W, K, 1, 1, 1, 1, 0, 0, 1, 1, 1, Cc, K, 0, 0)
-    assert L.load().cvhip_conv1x1_bwd_fused_ok(C.byref(desc)) == 1
     xd, yd, wd = x.to(d), y.to(d), w.t().contiguous().to(d)   # dgrad image [C][K]
     if ks < K:
         # two separately allocated gradient tensors with different pitches (a channel slice of a wider buffer for the second)
@@ -114,13 +113,23 @@ def test_bwd1x1_fused_vs_cpu(case):
     assert e_dw <= 2e-3, ("dw", case, e_dw)
 
 
-def test_bwd1x1_refuses_unsupported_geometry():
+def test_bwd1x1_policy_and_refusals():
     lib = L.load()
-    for (Cc, K, R, s) in [(64, 256, 1, 1), (64, 64, 3, 1), (64, 64, 1, 2), (20, 64, 1, 1), (64, 48, 1, 1)]:
-        desc = L.ConvDesc(2, Cc, 64, 64, K, R, R, s, s, R // 2, R // 2, 1, 1, 1, Cc, K, 0, 0)
+    d = dev()
+    buf = torch.zeros(1 << 20, dtype=BF, device=d)
+    f32 = torch.zeros(1 << 18, dtype=torch.float32, device=d)
+    for (Cc, K, R, s) in [(64, 256, 1, 1), (64, 64, 3, 1), (64, 64, 1, 2), (24, 64, 1, 1), (64, 48, 1, 1)]:
+        desc = L.ConvDesc(2, Cc, 16, 16, K, R, R, s, s, R // 2, R // 2, 1, 1, 1, Cc, K, 0, 0)
         assert lib.cvhip_conv1x1_bwd_fused_ok(C.byref(desc)) == 0
-    desc = L.ConvDesc(1, 64, 16, 16, 64, 1, 1, 1, 1, 0, 0, 1, 1, 1, 64, 64, 0, 0)   # M = 256 rows: too small
-    assert lib.cvhip_conv1x1_bwd_fused_ok(C.byref(desc)) == 0
+        st = lib.cvhip_conv1x1_bwd_fused(C.byref(desc), buf.data_ptr(), K, None, 0, K, buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), None, None,
+                                         None, None, None, None, 0, 0.0, None, 0, buf.data_ptr(), Cc, f32.data_ptr(), None)
+        assert st == L.ERR_UNSUPPORTED, (Cc, K, R, s, st)
+    small = L.ConvDesc(1, 64, 16, 16, 64, 1, 1, 1, 1, 0, 0, 1, 1, 1, 64, 64, 0, 0)      # fits, but 4 trips: the policy says three-pass
+    big = L.ConvDesc(64, 64, 80, 80, 64, 1, 1, 1, 1, 0, 0, 1, 1, 1, 64, 64, 0, 0)       # 6400 trips
+    import os
+    if os.environ.get("CVHIP_BWD1X1", "1") == "1":
+        assert lib.cvhip_conv1x1_bwd_fused_ok(C.byref(small)) == 0
+        assert lib.cvhip_conv1x1_bwd_fused_ok(C.byref(big)) == 1
 
 
 @pytest.mark.parametrize("Cc,K,res", [(64, 64, False), (32, 32, True), (128, 64, False)])
@@ -130,8 +139,8 @@ def test_conv_module_backward_takes_fused_path_and_matches_three_pass(Cc, K, res
     torch.manual_seed(3)
     d = dev()
     m = bricks.HipConvModule(Cc, K, 1, norm_cfg=dict(type="HipBN"), act_cfg=dict(type="HipSiLU")).to(d).train()
-    x0 = torch.randn(2, Cc, 48, 48, device=d).to(BF).contiguous(memory_format=torch.channels_last)
-    gout = (torch.randn(2, K, 48, 48, device=d) * 0.1).to(BF).contiguous(memory_format=torch.channels_last)
+    x0 = torch.randn(8, Cc, 160, 160, device=d).to(BF).contiguous(memory_format=torch.channels_last)   # 3200 64-row trips
+    gout = (torch.randn(8, K, 160, 160, device=d) * 0.1).to(BF).contiguous(memory_format=torch.channels_last)
 
     calls = []
     real_call = L.call

@@ -31,7 +31,14 @@ for _ in range(3):
 torch.cuda.synchronize()
 ops.TIMER.enabled = False
 agg = collections.OrderedDict()
+ew = collections.OrderedDict()
 for (name, fl, by, e0, e1), (fn, geom) in zip(ops.TIMER.records, ops.TIMER.detail):
+    if geom is None:  # BN / activation passes: aggregated per kernel
+        d = ew.setdefault(name, [0, 0.0, 0.0])
+        d[0] += 1
+        d[1] += e0.elapsed_time(e1)
+        d[2] += by
+        continue
     k = (fn.replace("cvhip_conv2d_", ""), geom, name)
     d = agg.setdefault(k, [0, 0.0, fl, by])
     d[0] += 1
@@ -44,6 +51,8 @@ for (fn, g, name), (n, ms, fl, by) in agg.items():
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print("total conv ms/step %.3f   wgrad %.3f  fprop %.3f  dgrad %.3f" % (tot, sum(r[0] for r in rows if r[1]=="wgrad"), sum(r[0] for r in rows if r[1]=="fprop"), sum(r[0] for r in rows if r[1]=="dgrad")))
+for name, (n, ms, by) in ew.items():
+    print("%6.3f ms/step  %-44s x%d  %8.1f us avg  %7.1f GB/s algorithmic" % (ms / 3, name, n // 3, 1e3 * ms / n, by / ms / 1e6))
 NROWS = int(os.environ.get("TABLE_ROWS", "45"))
 for r in rows[:NROWS]:
     print("%6.3f ms/step  %-6s %-34s x%d  %8.1f us  %7.1f TF  %7.1f GB/s  %s" % r)
