@@ -58,7 +58,8 @@ def paired_arena_order(items, follow):
 
 class FlatTrainState:
     def __init__(self, model, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4, backbone_lr=None, ema_decay=0.9999,
-                 use_ema=True, bucket_bytes=8 << 20, process_group=None, comm=None, force_collectives=False):
+                 use_ema=True, bucket_bytes=8 << 20, process_group=None, comm=None, force_collectives=False, loss_scaling=None,
+                 init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
         self.model = model
         self.momentum, self.nesterov = float(momentum), bool(nesterov)
         groups = build_param_groups(model, lr, backbone_lr, weight_decay)
@@ -119,6 +120,13 @@ class FlatTrainState:
             if isinstance(m, torch.nn.BatchNorm2d) and m.track_running_stats and m.num_batches_tracked is not None:
                 m._nbt_deferred = True
                 self._nbt.append(m.num_batches_tracked)
+        # dynamic loss scaling (torch.cuda.amp.GradScaler, trainer.py:189-201) — on by default exactly when the engine stores
+        # activations in fp16 (ops.set_precision("fp16")), as the reference pairs autocast(fp16) with GradScaler(enabled=AMP).
+        # State lives on the device: {scale, growth_tracker, found_inf, skipped_steps}; ls_dyn = {1/scale or 0, skip}
+        self.loss_scaling = (ops.precision() == "fp16") if loss_scaling is None else bool(loss_scaling)
+        self.ls_state = torch.tensor([float(init_scale), 0.0, 0.0, 0.0], dtype=torch.float32, device=dev)
+        self.ls_dyn = torch.tensor([1.0 / float(init_scale), 0.0], dtype=torch.float32, device=dev)
+        self.ls_hyper = (float(growth_factor), float(backoff_factor), int(growth_interval))
         self.prep_plan = None
         self.lr_scale = 1.0
         self.dyn = torch.tensor([0.0, 1.0], dtype=torch.float32, device=dev)  # {ema_decay, lr_scale}, read by the kernels
@@ -267,6 +275,16 @@ class FlatTrainState:
     def zero_grad(self):
         ops.zero_fill(self.grad)  # a kernel, not a memset node (hipGraph-safe)
 
+    def scale_loss(self, loss):
+        """scaler.scale(loss): the backward pass is seeded with the CURRENT loss scale, read from device memory (so a replayed
+        hipGraph follows the scale as it grows / backs off). Identity when loss scaling is off."""
+        return loss * self.ls_state[0] if self.loss_scaling else loss
+
+    def loss_scale(self):
+        """(scale, skipped steps so far) — host copies (synchronises; diagnostics only)."""
+        v = self.ls_state.tolist()
+        return v[0], int(v[3])
+
     def pre_step(self):
         """Host-side bookkeeping of one optimizer step + upload of the dynamic scalars {ema_decay, lr_scale}
         to device memory. Runs eagerly (outside any hipGraph) right before the step's kernels."""
@@ -285,9 +303,19 @@ class FlatTrainState:
         self.finish_allreduce()
         ema_ptr = self.ema_param.data_ptr() if self.ema_param is not None else None
         st = ops._stream()
-        L.call("cvhip_sgd_nesterov_ema", self.param.data_ptr(), self.grad.data_ptr(), self.mom.data_ptr(), ema_ptr, self.total,
-               self.seg_bounds.data_ptr(), self.seg_lr.data_ptr(), self.seg_wd.data_ptr(), len(self.params), self.momentum,
-               int(self.nesterov), 0, 0.0, 1.0 / self.world, self.dyn.data_ptr(), st)
+        if self.loss_scaling:
+            # scaler.step(optimizer) + scaler.update(): inf/NaN check of the (all-reduced) gradient arena, scale update and the
+            # unscale-or-skip decision, all on the device (three launches, capturable)
+            g, b, iv = self.ls_hyper
+            L.call("cvhip_loss_scale_check", self.grad.data_ptr(), self.total, self.ls_state.data_ptr(), st)
+            L.call("cvhip_loss_scale_update", self.ls_state.data_ptr(), self.ls_dyn.data_ptr(), g, b, iv, st)
+            L.call("cvhip_sgd_nesterov_ema_scaled", self.param.data_ptr(), self.grad.data_ptr(), self.mom.data_ptr(), ema_ptr, self.total,
+                   self.seg_bounds.data_ptr(), self.seg_lr.data_ptr(), self.seg_wd.data_ptr(), len(self.params), self.momentum,
+                   int(self.nesterov), 0, 0.0, 1.0 / self.world, self.dyn.data_ptr(), self.ls_dyn.data_ptr(), st)
+        else:
+            L.call("cvhip_sgd_nesterov_ema", self.param.data_ptr(), self.grad.data_ptr(), self.mom.data_ptr(), ema_ptr, self.total,
+                   self.seg_bounds.data_ptr(), self.seg_lr.data_ptr(), self.seg_wd.data_ptr(), len(self.params), self.momentum,
+                   int(self.nesterov), 0, 0.0, 1.0 / self.world, self.dyn.data_ptr(), st)
         if self.ema_buf is not None and self.buf.numel():
             L.call("cvhip_ema_update", self.ema_buf.data_ptr(), self.buf.data_ptr(), self.buf.numel(), 0.0, self.dyn.data_ptr(), st)
         if self._nbt and self.model.training:
@@ -358,7 +386,7 @@ class FlatTrainStep:
     def _eager(self, imgs, targets):
         self.state.prepare_weights()
         losses = self.model(imgs, targets, "train")
-        losses["loss"].backward()
+        self.state.scale_loss(losses["loss"]).backward()
         self.state.step_kernels()
         return losses
 
@@ -394,7 +422,7 @@ class FlatTrainStep:
                 st.prepare_weights()
                 _, feats = m.forward_features(self.static_imgs)
                 losses = m.loss_from_features(feats, self.static_targets)
-                losses["loss"].backward()
+                st.scale_loss(losses["loss"]).backward()
                 ops.join_side()
                 if not self.eager_tail:
                     st.step_kernels()
@@ -433,7 +461,7 @@ class FlatTrainStep:
                 return self.static_losses
             p = [f.detach().requires_grad_(True) for f in self.feats]
             losses = self.model.loss_from_features(p, self.static_targets)
-            grads = torch.autograd.grad(losses["loss"], p)
+            grads = torch.autograd.grad(st.scale_loss(losses["loss"]), p)
             for d, g in zip(self.g_feats, grads):
                 d.copy_(g)
             self.g2.replay()

@@ -172,7 +172,7 @@ class HipConv2d(nn.Conv2d):
         libcvhip kernel; the weight keeps its real shape (the packers pad it: cvhip_conv_desc.c_valid)."""
         w = self.weight
         if (x.dim() == 4 and x.shape[1] == self.in_channels and self.in_channels % 8 != 0 and self.groups == 1
-                and not x.requires_grad and x.dtype != ops.BF16):
+                and not x.requires_grad and x.dtype != ops.ACT_DTYPE):
             cp = (self.in_channels + 7) // 8 * 8
             if x.dtype == torch.float32 and ops.nhwc_ld(x) is None:
                 x = ops.images_to_nhwc(x, cpad=cp)

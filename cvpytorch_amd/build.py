@@ -49,12 +49,18 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def _compile(src):
-    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+# sources without 16-bit operands are compiled once; every other source a second time with -DCVHIP_F16 (fp16 storage,
+# entry points suffixed _f16: csrc/common.h, csrc/f16_names.h)
+SINGLE_PRECISION = ("comm.hip",)
+
+
+def _compile(job):
+    src, f16 = job
+    obj = os.path.join(OBJ, src.replace(".hip", ".f16.o" if f16 else ".o"))
     path = os.path.join(CSRC, src)
     if not _newer(obj, [path] + _deps()):
         return obj, None
-    cmd = [HIPCC] + FLAGS + ["-c", path, "-o", obj]
+    cmd = [HIPCC] + FLAGS + (["-DCVHIP_F16=1"] if f16 else []) + ["-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
@@ -64,15 +70,16 @@ def _compile(src):
 def build_lib(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    jobs = [(s, False) for s in srcs] + [(s, True) for s in srcs if s not in SINGLE_PRECISION]
     if force:
-        for s in srcs:
-            o = os.path.join(OBJ, s.replace(".hip", ".o"))
+        for s, f16 in jobs:
+            o = os.path.join(OBJ, s.replace(".hip", ".f16.o" if f16 else ".o"))
             if os.path.exists(o):
                 os.remove(o)
-    with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        results = list(ex.map(_compile, srcs))
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+        results = list(ex.map(_compile, jobs))
     objs = [o for o, _ in results]
-    for (o, warn), s in zip(results, srcs):
+    for (o, warn), (s, _f) in zip(results, jobs):
         if warn and verbose:
             sys.stderr.write("[cvhip build] %s:\n%s\n" % (s, warn))
     if force or _newer(LIB, objs):

@@ -150,17 +150,17 @@ int pack_weights(const cvhip_conv_desc* d, const float* master, void* w_fprop, v
 int launch_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, hipStream_t stream);
 
 // ---- probes ---------------------------------------------------------------------------------------
-__global__ void probe_mfma_kernel(const bf16_t* a, const bf16_t* b, float* d) {
+__global__ void probe_mfma_kernel(const h16_t* a, const h16_t* b, float* d) {
   // a: [16][32] row-major (i,k); b: [32][16] row-major (k,j). Lane l supplies A[i=l&15][k=8*(l>>4)+e],
   // B[k=8*(l>>4)+e][j=l&15]; result reg r -> D[row = 4*(l>>4)+r][col = l&15].
   const int l = threadIdx.x;
-  bf16x8 fa, fb;
+  h16x8 fa, fb;
   for (int e = 0; e < 8; ++e) {
     fa[e] = a[(l & 15) * 32 + 8 * (l >> 4) + e];
     fb[e] = b[(8 * (l >> 4) + e) * 16 + (l & 15)];
   }
   f32x4 c = {0.f, 0.f, 0.f, 0.f};
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, c, 0, 0, 0);
+  c = CVHIP_MFMA_16X16X32(fa, fb, c, 0, 0, 0);
   for (int r = 0; r < 4; ++r) d[(4 * (l >> 4) + r) * 16 + (l & 15)] = c[r];
 }
 
@@ -207,20 +207,19 @@ __global__ __launch_bounds__(256, 2) void probe_lds_bw_kernel(float* out, int it
 // MFMA issue-rate probe (bench.py "attainable peak"): every wave runs `iters` rounds of 8 INDEPENDENT v_mfma_f32_32x32x16_bf16
 // (8 accumulator sets: no dependent-accumulator stalls), operands in registers, nothing else. 4 waves per block, one per SIMD.
 // flops per launch = blocks * 4 waves * iters * 8 * (2*32*32*16).
-typedef __bf16 probe_bf16x8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void probe_mfma_peak_kernel(float* out, int iters) {
   const int l = threadIdx.x;
-  probe_bf16x8 a, b;
+  h16x8 a, b;
   for (int e = 0; e < 8; ++e) {
-    a[e] = (bf16_t)(0.001f * (float)((l * 7 + e * 3) % 17 - 8));
-    b[e] = (bf16_t)(0.002f * (float)((l * 5 + e) % 13 - 6));
+    a[e] = (h16_t)(0.001f * (float)((l * 7 + e * 3) % 17 - 8));
+    b[e] = (h16_t)(0.002f * (float)((l * 5 + e) % 13 - 6));
   }
   f32x16 c[8];
   for (int j = 0; j < 8; ++j)
     for (int e = 0; e < 16; ++e) c[j][e] = 0.f;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) c[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c[j], 0, 0, 0);
+    for (int j = 0; j < 8; ++j) c[j] = CVHIP_MFMA_32X32X16(a, b, c[j], 0, 0, 0);
   }
   float s = 0.f;
   for (int j = 0; j < 8; ++j)
@@ -228,15 +227,15 @@ __global__ __launch_bounds__(256) void probe_mfma_peak_kernel(float* out, int it
   if (s == 123456.789f) out[blockIdx.x] = s;  // keeps the MFMAs live without a store on the normal path
 }
 
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
-__global__ void probe_tr16_kernel(const bf16_t* in, bf16_t* out) {
+typedef __attribute__((address_space(3))) h16x4 lds_h16x4_t;
+__global__ void probe_tr16_kernel(const h16_t* in, h16_t* out) {
   // in: 64 lanes x 4 bf16 written linearly to LDS (lane l at byte l*8); every lane then issues
   // ds_read_b64_tr_b16 at its own linear address; out[l][0..3] = what lane l received.
-  __shared__ __attribute__((aligned(16))) bf16_t lds[256];
+  __shared__ __attribute__((aligned(16))) h16_t lds[256];
   const int l = threadIdx.x;
   for (int e = 0; e < 4; ++e) lds[l * 4 + e] = in[l * 4 + e];
   __syncthreads();
-  bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(&lds[l * 4]));
+  h16x4 v = CVHIP_DS_READ_TR16_B64((lds_h16x4_t*)(&lds[l * 4]));
   for (int e = 0; e < 4; ++e) out[l * 4 + e] = v[e];
 }
 
@@ -372,9 +371,9 @@ int cvhip_conv2d_fprop(const cvhip_conv_desc* d, const void* x, const void* w, c
   if ((((uintptr_t)x) & 15) || (((uintptr_t)w) & 15)) return CVHIP_ERR_INVALID;
   IgemmParams p;
   plan_fprop(d, &p);
-  p.x = (const bf16_t*)x;
-  p.w = (const bf16_t*)w;
-  p.y = (bf16_t*)y;
+  p.x = (const h16_t*)x;
+  p.w = (const h16_t*)w;
+  p.y = (h16_t*)y;
   p.bias = bias;
   p.bias_n = d->k_valid > 0 ? d->k_valid : d->K;
   p.stats = stats_partial;
@@ -392,12 +391,12 @@ static int dgrad_impl(const cvhip_conv_desc* d, const void* dy, const void* w_dg
   if (addend && addend_ld < d->C) return CVHIP_ERR_INVALID;
   IgemmParams p;
   plan_dgrad(d, &p);
-  p.x = (const bf16_t*)dy;
-  p.w = (const bf16_t*)w_dgrad;
-  p.y = (bf16_t*)dx;
+  p.x = (const h16_t*)dy;
+  p.w = (const h16_t*)w_dgrad;
+  p.y = (h16_t*)dx;
   p.bias = nullptr;
   p.stats = nullptr;
-  p.res = (const bf16_t*)addend;
+  p.res = (const h16_t*)addend;
   p.res_ld = addend_ld;
   p.y_vec_ok = ((d->x_ld & 3) == 0) && ((((uintptr_t)dx) & 7) == 0);
   return launch_igemm(p, (hipStream_t)stream);
@@ -443,13 +442,13 @@ int cvhip_f32_unpad_add(const float* src, float* dst, int32_t K_valid, int32_t T
 
 int cvhip_probe_mfma_16x16x32(const void* a, const void* b, float* d, void* stream) {
   if (!a || !b || !d) return CVHIP_ERR_INVALID;
-  hipLaunchKernelGGL(probe_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, d);
+  hipLaunchKernelGGL(probe_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const h16_t*)a, (const h16_t*)b, d);
   return check_launch("probe_mfma_kernel");
 }
 
 int cvhip_probe_ds_read_tr16(const void* in, void* out, void* stream) {
   if (!in || !out) return CVHIP_ERR_INVALID;
-  hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out);
+  hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const h16_t*)in, (h16_t*)out);
   return check_launch("probe_tr16_kernel");
 }
 

@@ -22,8 +22,8 @@ static inline int colreduce_rows_host(int64_t M, int32_t C) {
 
 // MODE 0: (sum x, sum x^2)          MODE 1: (sum du, sum du*xhat)       MODE 2: (sum x, -)
 struct RedParams {
-  const bf16_t* a;   // x (mode 0/2) or dz (mode 1)
-  const bf16_t* y;   // conv output (mode 1)
+  const h16_t* a;   // x (mode 0/2) or dz (mode 1)
+  const h16_t* y;   // conv output (mode 1)
   int ld_a, ld_y;
   int64_t M;
   int C;
@@ -415,8 +415,8 @@ static bool launch_fused_finalize(const float* partial, int rows, int C, const F
 
 // ---- elementwise passes -----------------------------------------------------------------------------
 struct EwParams {
-  const bf16_t *a, *y, *res;
-  bf16_t* out;
+  const h16_t *a, *y, *res;
+  h16_t* out;
   int ld_a, ld_y, ld_res, ld_out;
   int64_t M;
   int C;
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void ew_kernel(const EwParams p) {
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          if (c + j < p.C) p.out[r * p.ld_out + c + j] = (bf16_t)o.v[j];
+          if (c + j < p.C) p.out[r * p.ld_out + c + j] = (h16_t)o.v[j];
       }
     }
   }
@@ -602,7 +602,7 @@ static int launch_red(int mode, RedParams& p, hipStream_t s) {
 
 int cvhip_bn_stats_partial(const void* x, int64_t M, int32_t C, int32_t ld, float* partial, void* stream) {
   RedParams p{};
-  p.a = (const bf16_t*)x;
+  p.a = (const h16_t*)x;
   p.ld_a = ld;
   p.M = M;
   p.C = C;
@@ -612,7 +612,7 @@ int cvhip_bn_stats_partial(const void* x, int64_t M, int32_t C, int32_t ld, floa
 
 int cvhip_colsum_partial(const void* x, int64_t M, int32_t C, int32_t ld, float* partial, void* stream) {
   RedParams p{};
-  p.a = (const bf16_t*)x;
+  p.a = (const h16_t*)x;
   p.ld_a = ld;
   p.M = M;
   p.C = C;
@@ -625,8 +625,8 @@ int cvhip_bn_act_bwd_partial(const void* dz, int32_t ld_dz, const void* y, int32
                              int32_t act, float act_param, float* partial, void* stream) {
   if (!y) return CVHIP_ERR_INVALID;
   RedParams p{};
-  p.a = (const bf16_t*)dz;
-  p.y = (const bf16_t*)y;
+  p.a = (const h16_t*)dz;
+  p.y = (const h16_t*)y;
   p.ld_a = ld_dz;
   p.ld_y = ld_y;
   p.M = M;
@@ -709,11 +709,11 @@ int cvhip_bn_act_fwd(const void* y, int32_t ld_y, void* z, int32_t ld_z, int64_t
   if (!y || !z || M < 0 || C <= 0) return CVHIP_ERR_INVALID;
   if (M == 0) return CVHIP_OK;
   EwParams p{};
-  p.a = (const bf16_t*)y;
+  p.a = (const h16_t*)y;
   p.ld_a = ld_y;
-  p.out = (bf16_t*)z;
+  p.out = (h16_t*)z;
   p.ld_out = ld_z;
-  p.res = (const bf16_t*)residual;
+  p.res = (const h16_t*)residual;
   p.ld_res = ld_res;
   p.M = M;
   p.C = C;
@@ -730,11 +730,11 @@ int cvhip_bn_add_act_fwd(const void* y, int32_t ld_y, void* z, int32_t ld_z, int
   if (!y || !z || !residual || M < 0 || C <= 0) return CVHIP_ERR_INVALID;
   if (M == 0) return CVHIP_OK;
   EwParams p{};
-  p.a = (const bf16_t*)y;
+  p.a = (const h16_t*)y;
   p.ld_a = ld_y;
-  p.out = (bf16_t*)z;
+  p.out = (h16_t*)z;
   p.ld_out = ld_z;
-  p.res = (const bf16_t*)residual;
+  p.res = (const h16_t*)residual;
   p.ld_res = ld_res;
   p.M = M;
   p.C = C;
@@ -755,11 +755,11 @@ int cvhip_bn_act_bwd_apply(const void* dz, int32_t ld_dz, const void* y, int32_t
   if (mean && (!invstd || !dgamma || !dbeta)) return CVHIP_ERR_INVALID;
   if (M == 0) return CVHIP_OK;
   EwParams p{};
-  p.a = (const bf16_t*)dz;
+  p.a = (const h16_t*)dz;
   p.ld_a = ld_dz;
-  p.y = (const bf16_t*)y;
+  p.y = (const h16_t*)y;
   p.ld_y = ld_y;
-  p.out = (bf16_t*)dy;
+  p.out = (h16_t*)dy;
   p.ld_out = ld_dy;
   p.M = M;
   p.C = C;
@@ -781,11 +781,11 @@ int cvhip_add_act_fwd(const void* a, int32_t ld_a, const void* b, int32_t ld_b, 
   if (!a || !b || !out || M < 0 || C <= 0) return CVHIP_ERR_INVALID;
   if (M == 0) return CVHIP_OK;
   EwParams p{};
-  p.a = (const bf16_t*)a;
+  p.a = (const h16_t*)a;
   p.ld_a = ld_a;
-  p.res = (const bf16_t*)b;
+  p.res = (const h16_t*)b;
   p.ld_res = ld_b;
-  p.out = (bf16_t*)out;
+  p.out = (h16_t*)out;
   p.ld_out = ld_out;
   p.M = M;
   p.C = C;
@@ -800,9 +800,9 @@ int cvhip_copy2d(const void* src, int32_t ld_src, void* dst, int32_t ld_dst, int
   if (!src || !dst || M < 0 || C <= 0) return CVHIP_ERR_INVALID;
   if (M == 0) return CVHIP_OK;
   EwParams p{};
-  p.a = (const bf16_t*)src;
+  p.a = (const h16_t*)src;
   p.ld_a = ld_src;
-  p.out = (bf16_t*)dst;
+  p.out = (h16_t*)dst;
   p.ld_out = ld_dst;
   p.M = M;
   p.C = C;
@@ -815,11 +815,11 @@ int cvhip_add2d(const void* a, int32_t ld_a, const void* b, int32_t ld_b, void* 
   if (!a || !b || !dst || M < 0 || C <= 0) return CVHIP_ERR_INVALID;
   if (M == 0) return CVHIP_OK;
   EwParams p{};
-  p.a = (const bf16_t*)a;
+  p.a = (const h16_t*)a;
   p.ld_a = ld_a;
-  p.res = (const bf16_t*)b;
+  p.res = (const h16_t*)b;
   p.ld_res = ld_b;
-  p.out = (bf16_t*)dst;
+  p.out = (h16_t*)dst;
   p.ld_out = ld_dst;
   p.M = M;
   p.C = C;

@@ -1,14 +1,41 @@
 // common.h — shared device helpers for libcvhip (gfx950 / CDNA4 only; wave = 64 lanes).
+//
+// STORAGE PRECISION. Activations, operand images and activation gradients are 16-bit floats (`h16_t`), accumulation is fp32.
+// Every source that touches them is compiled TWICE into the same library:
+//   default      : h16_t = bf16  (v_mfma_f32_16x16x32_bf16)   entry points cvhip_xxx           namespace cvhip
+//   -DCVHIP_F16  : h16_t = fp16  (v_mfma_f32_16x16x32_f16)    entry points cvhip_xxx_f16       namespace cvhip_f16
+// (reference: torch.cuda.amp.autocast fp16 + GradScaler, trainer.py:179-201; BASELINE config 5 "fp16"). The kernels are written
+// once against h16_t / h16x8 / pack8 / unpack8 / CVHIP_MFMA_*; the renaming of the exported symbols happens in f16_names.h
+// (generated from the sources by tools/gen_f16_names.py, checked by tests/test_abi_plan.py).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifdef CVHIP_F16
+#include "f16_names.h"
+#endif
 #include "../../include/cvhip.h"
 
-typedef __bf16 bf16_t;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#ifdef CVHIP_F16
+typedef _Float16 h16_t;
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+#define CVHIP_MFMA_16X16X32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define CVHIP_MFMA_32X32X16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+typedef __fp16 cvhip_fp16x4_raw __attribute__((ext_vector_type(4)));  // the builtin's element type is __fp16, not _Float16
+#define CVHIP_DS_READ_TR16_B64(ptr) \
+  __builtin_bit_cast(h16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) cvhip_fp16x4_raw*)(ptr)))
+#define cvhip cvhip_f16  /* the C++ namespace of this translation unit */
+#else
+typedef __bf16 h16_t;
+typedef __bf16 h16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 h16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 h16x2 __attribute__((ext_vector_type(2)));
+#define CVHIP_MFMA_16X16X32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define CVHIP_MFMA_32X32X16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define CVHIP_DS_READ_TR16_B64 __builtin_amdgcn_ds_read_tr16_b64_v4bf16
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -27,24 +54,33 @@ struct f32x8 {
   float v[8];
 };
 
+#ifdef CVHIP_F16
+__device__ __forceinline__ void unpack2(uint32_t w, float& lo, float& hi) {
+  const h16x2 t = __builtin_bit_cast(h16x2, w);
+  lo = (float)t[0];  // v_cvt_f32_f16 (the high half through SDWA)
+  hi = (float)t[1];
+}
+#else
+__device__ __forceinline__ void unpack2(uint32_t w, float& lo, float& hi) {
+  // bf16 -> fp32 is a 16-bit left shift
+  lo = __uint_as_float(w << 16);
+  hi = __uint_as_float(w & 0xffff0000u);
+}
+#endif
+
 __device__ __forceinline__ f32x8 unpack8(uint4 u) {
   f32x8 r;
-  // bf16 -> fp32 is a 16-bit left shift
-  r.v[0] = __uint_as_float(u.x << 16);
-  r.v[1] = __uint_as_float(u.x & 0xffff0000u);
-  r.v[2] = __uint_as_float(u.y << 16);
-  r.v[3] = __uint_as_float(u.y & 0xffff0000u);
-  r.v[4] = __uint_as_float(u.z << 16);
-  r.v[5] = __uint_as_float(u.z & 0xffff0000u);
-  r.v[6] = __uint_as_float(u.w << 16);
-  r.v[7] = __uint_as_float(u.w & 0xffff0000u);
+  unpack2(u.x, r.v[0], r.v[1]);
+  unpack2(u.y, r.v[2], r.v[3]);
+  unpack2(u.z, r.v[4], r.v[5]);
+  unpack2(u.w, r.v[6], r.v[7]);
   return r;
 }
 
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-  bf16x2 t;
-  t[0] = (bf16_t)lo;  // RNE; lowers to v_cvt_pk_bf16_f32 on gfx950
-  t[1] = (bf16_t)hi;
+  h16x2 t;
+  t[0] = (h16_t)lo;  // RNE; lowers to v_cvt_pk_bf16_f32 / v_cvt_f16_f32 on gfx950
+  t[1] = (h16_t)hi;
   return __builtin_bit_cast(uint32_t, t);
 }
 
@@ -57,9 +93,9 @@ __device__ __forceinline__ uint4 pack8(const f32x8& f) {
   return u;
 }
 
-__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return (float)__builtin_bit_cast(h16_t, h); }
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
-  bf16_t b = (bf16_t)f;
+  h16_t b = (h16_t)f;
   return __builtin_bit_cast(uint16_t, b);
 }
 

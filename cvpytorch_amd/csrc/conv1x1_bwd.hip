@@ -31,17 +31,17 @@
 namespace cvhip {
 
 struct Bwd1x1Params {
-  const bf16_t* dz0;  // gradient at the layer output, channels [0, k_split)
-  const bf16_t* dz1;  // channels [k_split, K) (sibling pairs deliver two tensors); unused when k_split == K
+  const h16_t* dz0;  // gradient at the layer output, channels [0, k_split)
+  const h16_t* dz1;  // channels [k_split, K) (sibling pairs deliver two tensors); unused when k_split == K
   int dz0_ld, dz1_ld, k_split;
-  const bf16_t* y;    // raw convolution output (pre-BN)
+  const h16_t* y;    // raw convolution output (pre-BN)
   int y_ld;
-  const bf16_t* x;    // layer input
+  const h16_t* x;    // layer input
   int x_ld;
-  const bf16_t* w;    // dgrad image [C][K]
-  const bf16_t* res;  // optional addend for dx
+  const h16_t* w;    // dgrad image [C][K]
+  const h16_t* res;  // optional addend for dx
   int res_ld;
-  bf16_t* dx;
+  h16_t* dx;
   int dx_ld;
   float* dw;          // [K][C] fp32, accumulated
   const float *scale, *shift, *mean, *invstd, *dgamma, *dbeta;
@@ -51,11 +51,11 @@ struct Bwd1x1Params {
   int M, K, C, ntiles;
 };
 
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_b;
+typedef __attribute__((address_space(3))) h16x4 lds_h16x4_b;
 
-__device__ __forceinline__ bf16x8 tr_read8_b(const unsigned char* p0, const unsigned char* p1) {
-  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_b*)(p0));
-  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_b*)(p1));
+__device__ __forceinline__ h16x8 tr_read8_b(const unsigned char* p0, const unsigned char* p1) {
+  h16x4 lo = CVHIP_DS_READ_TR16_B64((lds_h16x4_b*)(p0));
+  h16x4 hi = CVHIP_DS_READ_TR16_B64((lds_h16x4_b*)(p1));
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
@@ -112,10 +112,10 @@ __global__ __launch_bounds__(256, 2) void bwd1x1_kernel(const Bwd1x1Params p) {
   const int kv = t % KV, drow = t / KV;
   const int xv = t % CV, xrow = t / CV;
   const bool seg1 = kv * 8 >= p.k_split;
-  const bf16_t* const dzp = seg1 ? p.dz1 + (kv * 8 - p.k_split) : p.dz0 + kv * 8;
+  const h16_t* const dzp = seg1 ? p.dz1 + (kv * 8 - p.k_split) : p.dz0 + kv * 8;
   const int dz_ld = seg1 ? p.dz1_ld : p.dz0_ld;
-  const bf16_t* const yp = p.y + kv * 8;
-  const bf16_t* const xp = p.x + c0 + xv * 8;
+  const h16_t* const yp = p.y + kv * 8;
+  const h16_t* const xp = p.x + c0 + xv * 8;
 
   // per-channel constants of this thread's 8 channels: u = sc*y + sh; dy = sc*du + b1*y + c1
   float sc[8], sh[8], b1[8], c1[8];
@@ -227,17 +227,17 @@ __global__ __launch_bounds__(256, 2) void bwd1x1_kernel(const Bwd1x1Params p) {
     for (int a = 0; a < NF; ++a) accx[a] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sD + prow * D_ROWB + swz_off<D_SEGM>(prow & 31, 4 * ks + g));
+      const h16x8 fb = *reinterpret_cast<const h16x8*>(sD + prow * D_ROWB + swz_off<D_SEGM>(prow & 31, 4 * ks + g));
 #pragma unroll
       for (int a = 0; a < NF; ++a) {
-        const bf16x8 wa = *reinterpret_cast<const bf16x8*>(wlane + a * 16 * W_ROWB + ks * 64);
-        accx[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, fb, accx[a], 0, 0, 0);
+        const h16x8 wa = *reinterpret_cast<const h16x8*>(wlane + a * 16 * W_ROWB + ks * 64);
+        accx[a] = CVHIP_MFMA_16X16X32(wa, fb, accx[a], 0, 0, 0);
       }
     }
     {
       const int m = tile * RT + prow;
       if (m < M) {
-        bf16_t* const drow_p = p.dx + (int64_t)m * p.dx_ld + c0 + g * 8;
+        h16_t* const drow_p = p.dx + (int64_t)m * p.dx_ld + c0 + g * 8;
 #pragma unroll
         for (int j = 0; j < NF / 2; ++j) {
           f32x8 v;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void bwd1x1_kernel(const Bwd1x1Params p) {
     // ---- wgrad: dW[K/2 of this wave][C/2 of this wave] += dy^T x over the trip's 64 pixel rows -------------------------------
 #pragma unroll
     for (int sub = 0; sub < RT / 32; ++sub) {
-      bf16x8 fd[KF], fx[CF];
+      h16x8 fd[KF], fx[CF];
 #pragma unroll
       for (int a = 0; a < KF; ++a) {
         const int seg = (wk2 * (KB / 2) + a * 16) >> 4;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void bwd1x1_kernel(const Bwd1x1Params p) {
 #pragma unroll
       for (int a = 0; a < KF; ++a)
 #pragma unroll
-        for (int b = 0; b < CF; ++b) accw[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[a], fx[b], accw[a][b], 0, 0, 0);
+        for (int b = 0; b < CF; ++b) accw[a][b] = CVHIP_MFMA_16X16X32(fd[a], fx[b], accw[a][b], 0, 0, 0);
     }
     __syncthreads();  // everybody is done with the tiles before the next trip overwrites them
   }
@@ -398,19 +398,19 @@ int cvhip_conv1x1_bwd_fused(const cvhip_conv_desc* d, const void* dz0, int32_t d
   if ((scale == nullptr) != (shift == nullptr)) return CVHIP_ERR_INVALID;
   if (mean && (!invstd || !dgamma || !dbeta || !scale)) return CVHIP_ERR_INVALID;
   Bwd1x1Params p{};
-  p.dz0 = (const bf16_t*)dz0;
-  p.dz1 = (const bf16_t*)(k_split < d->K ? dz1 : dz0);
+  p.dz0 = (const h16_t*)dz0;
+  p.dz1 = (const h16_t*)(k_split < d->K ? dz1 : dz0);
   p.dz0_ld = dz0_ld;
   p.dz1_ld = k_split < d->K ? dz1_ld : dz0_ld;
   p.k_split = k_split;
-  p.y = (const bf16_t*)y;
+  p.y = (const h16_t*)y;
   p.y_ld = d->y_ld;
-  p.x = (const bf16_t*)x;
+  p.x = (const h16_t*)x;
   p.x_ld = d->x_ld;
-  p.w = (const bf16_t*)w_dgrad;
-  p.res = (const bf16_t*)addend;
+  p.w = (const h16_t*)w_dgrad;
+  p.res = (const h16_t*)addend;
   p.res_ld = addend_ld;
-  p.dx = (bf16_t*)dx;
+  p.dx = (h16_t*)dx;
   p.dx_ld = dx_ld;
   p.dw = dw;
   p.scale = scale;

@@ -50,22 +50,22 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernA
   const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int total = my_tiles * nkc;
 
-  bf16x8 buf0[MF][KS], buf1[MF][KS];
-  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  h16x8 buf0[MF][KS], buf1[MF][KS];
+  const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
   // pipeline position of the NEXT load
   int ld_tile = blockIdx.x, ld_kc = 0;
-  auto load = [&](bf16x8 (&dst)[MF][KS]) {
+  auto load = [&](h16x8 (&dst)[MF][KS]) {
     const int row0 = ld_tile * RT + wave * (MF * 16) + r;
     const int kbase = ld_kc * KC + g * 8;
 #pragma unroll
     for (int b = 0; b < MF; ++b) {
       const int m = row0 + b * 16;
-      const bf16_t* src = p.x + (int64_t)m * p.x_ld + kbase;
+      const h16_t* src = p.x + (int64_t)m * p.x_ld + kbase;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const bool ok = m < M && kbase + ks * 32 < Cin;
-        dst[b][ks] = ok ? *reinterpret_cast<const bf16x8*>(src + ks * 32) : zero8;
+        dst[b][ks] = ok ? *reinterpret_cast<const h16x8*>(src + ks * 32) : zero8;
       }
     }
     if (++ld_kc == nkc) {
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernA
 
   const unsigned char* const wlane = smem + r * brow + g * 16;
   int cp_tile = blockIdx.x, cp_kc = 0;  // pipeline position of the NEXT compute
-  auto compute = [&](const bf16x8 (&src)[MF][KS]) {
+  auto compute = [&](const h16x8 (&src)[MF][KS]) {
     const unsigned char* wk = wlane + cp_kc * (KC * 2);
     const int ksn = min(KS, (cin_pad - cp_kc * KC) >> 5);
 #pragma unroll
@@ -127,9 +127,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernA
       if (ks < ksn) {
 #pragma unroll
         for (int a = 0; a < NF; ++a) {
-          const bf16x8 wb = *reinterpret_cast<const bf16x8*>(wk + a * 16 * brow + ks * 64);
+          const h16x8 wb = *reinterpret_cast<const h16x8*>(wk + a * 16 * brow + ks * 64);
 #pragma unroll
-          for (int b = 0; b < MF; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, src[b][ks], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < MF; ++b) acc[a][b] = CVHIP_MFMA_16X16X32(wb, src[b][ks], acc[a][b], 0, 0, 0);
         }
       }
     }
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernA
 #pragma unroll
     for (int b = 0; b < MF; ++b) {
       const int m = row0 + b * 16;
-      bf16_t* yrow = p.y + (int64_t)m * p.y_ld;
+      h16_t* yrow = p.y + (int64_t)m * p.y_ld;
 #pragma unroll
       for (int j = 0; j < NF / 2; ++j) {
         const int ch0 = n0 + j * 32 + g * 8;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernA
           }
         }
         if (p.res && m < M) {  // skip-connection gradient folded into the epilogue
-          const bf16_t* rrow = p.res + (int64_t)m * p.res_ld + ch0;
+          const h16_t* rrow = p.res + (int64_t)m * p.res_ld + ch0;
           if (ch0 + 7 < p.Nout && (p.res_ld & 7) == 0 && ((((uintptr_t)p.res) & 15) == 0)) {
             const f32x8 rv = unpack8(*reinterpret_cast<const uint4*>(rrow));
 #pragma unroll
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernA
           } else {
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-              if (ch0 + q < p.Nout) yrow[ch0 + q] = (bf16_t)v.v[q];
+              if (ch0 + q < p.Nout) yrow[ch0 + q] = (h16_t)v.v[q];
           }
         }
       }

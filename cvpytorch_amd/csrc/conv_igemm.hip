@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKernArgs p) {
   // branch-free tap decode for this thread's 16-B slot: element k -> (tr, ts, c0) by exact magic-number division
   const unsigned cin_magic = p.cin_magic, ts_magic = cl.ts_magic;
   auto fdiv = [](unsigned n, unsigned magic) -> unsigned { return magic ? __umulhi(n, magic) : n; };
-  const bf16_t* __restrict__ wbase = p.w + cl.w_off;
+  const h16_t* __restrict__ wbase = p.w + cl.w_off;
 
   // swizzled 16-B slot for the LDS write (thread-constant) and the fragment read (lane-constant)
   const int swz_w = (t & 3) ^ ((0x78 >> (2 * ((t >> 4) & 3))) & 3);
@@ -164,18 +164,18 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKernArgs p) {
   const int a_row = wm * WM + (lane & 15);
   const int b_row = wn * WN + (lane & 15);
   auto compute = [&](int cur) {
-    bf16x8 xa[MF], wb[NF];
+    h16x8 xa[MF], wb[NF];
 #pragma unroll
     for (int b = 0; b < MF; ++b)
-      xa[b] = *reinterpret_cast<const bf16x8*>(sA + cur * A_BYTES + (a_row + b * 16) * 64 + swz_r * 16);
+      xa[b] = *reinterpret_cast<const h16x8*>(sA + cur * A_BYTES + (a_row + b * 16) * 64 + swz_r * 16);
 #pragma unroll
     for (int a = 0; a < NF; ++a)
-      wb[a] = *reinterpret_cast<const bf16x8*>(sB + cur * B_BYTES + (b_row + a * 16) * 64 + swz_r * 16);
+      wb[a] = *reinterpret_cast<const h16x8*>(sB + cur * B_BYTES + (b_row + a * 16) * 64 + swz_r * 16);
 #pragma unroll
     for (int a = 0; a < NF; ++a)
 #pragma unroll
       for (int b = 0; b < MF; ++b)
-        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[a], xa[b], acc[a][b], 0, 0, 0);
+        acc[a][b] = CVHIP_MFMA_16X16X32(wb[a], xa[b], acc[a][b], 0, 0, 0);
   };
 
   // prologue: tiles 0,1 -> registers; tile 0 -> LDS[0]; tile 2 -> registers. Loads/stores are issued
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKernArgs p) {
     const int oh = rem / OWi;
     const int ow = rem - oh * OWi;
     const int64_t opix = ((int64_t)n_img * p.OH + (oh * p.out_sh + cl.out_oh)) * p.OW + (ow * p.out_sw + cl.out_ow);
-    bf16_t* yrow = p.y + opix * p.y_ld;
+    h16_t* yrow = p.y + opix * p.y_ld;
 #pragma unroll
     for (int a = 0; a < NF; ++a) {
       const int n = n0 + wn * WN + a * 16 + nq;
@@ -227,10 +227,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKernArgs p) {
         u.y = pack2(v2, v3);
         *reinterpret_cast<uint2*>(yrow + n) = u;
       } else {
-        yrow[n] = (bf16_t)v0;
-        if (n + 1 < p.Nout) yrow[n + 1] = (bf16_t)v1;
-        if (n + 2 < p.Nout) yrow[n + 2] = (bf16_t)v2;
-        if (n + 3 < p.Nout) yrow[n + 3] = (bf16_t)v3;
+        yrow[n] = (h16_t)v0;
+        if (n + 1 < p.Nout) yrow[n + 1] = (h16_t)v1;
+        if (n + 2 < p.Nout) yrow[n + 2] = (h16_t)v2;
+        if (n + 3 < p.Nout) yrow[n + 3] = (h16_t)v3;
       }
     }
   }
@@ -388,8 +388,8 @@ __global__ __launch_bounds__(256, (NST * (BM + (BN < BK ? BK : BN)) * BK * 2 > 8
   }
   const unsigned cin_magic = p.cin_magic, ts_magic = cl.ts_magic;
   auto fdiv = [](unsigned n, unsigned magic) -> unsigned { return magic ? __umulhi(n, magic) : n; };
-  const bf16_t* __restrict__ wbase = p.w + cl.w_off;
-  const bf16_t* const zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+  const h16_t* __restrict__ wbase = p.w + cl.w_off;
+  const h16_t* const zero = reinterpret_cast<const h16_t*>(g_zero_page);
 
   // BK 32: physical slot (t&3) of a 64-B row must hold LOGICAL K-slot (t&3)^g(row>>2)
   // BK 64: physical slot (lane&7) of a 128-B row must hold LOGICAL K-slot (lane&7) ^ ((row>>1)&7), row = i*32 + wave*8 + (lane>>3)
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256, (NST * (BM + (BN < BK ? BK : BN)) * BK * 2 > 8
     for (int i = 0; i < A_IT; ++i) {
       const int ih = ih0[i] + dh, iw = iw0[i] + dw;
       const bool ok = tap_ok && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
-      const bf16_t* src = ok ? (p.x + ((int64_t)(pbase[i] + ih * p.IW + iw) * p.x_ld + c0)) : zero;
+      const h16_t* src = ok ? (p.x + ((int64_t)(pbase[i] + ih * p.IW + iw) * p.x_ld + c0)) : zero;
       CVHIP_GLDS16(src, sA + (i * RPT + wave * RPI) * ROWB);
     }
 #pragma unroll
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256, (NST * (BM + (BN < BK ? BK : BN)) * BK * 2 > 8
       const int row = i * RPT + srow;
       const int n = n0 + row;
       const bool ok = row < BN && n < p.Nout && (int)k < Ktot;
-      const bf16_t* src = ok ? (wbase + ((int64_t)n * Ktot + k)) : zero;
+      const h16_t* src = ok ? (wbase + ((int64_t)n * Ktot + k)) : zero;
       CVHIP_GLDS16(src, sB + (i * RPT + wave * RPI) * ROWB);
     }
   };
@@ -438,16 +438,16 @@ __global__ __launch_bounds__(256, (NST * (BM + (BN < BK ? BK : BN)) * BK * 2 > 8
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
       const int slot = BK == 32 ? swz_r : ((4 * ks + (lane >> 4)) ^ swz_r);
-      bf16x8 xa[MF], wb[NF];
+      h16x8 xa[MF], wb[NF];
 #pragma unroll
-      for (int b = 0; b < MF; ++b) xa[b] = *reinterpret_cast<const bf16x8*>(sA + (a_row + b * 16) * ROWB + slot * 16);
+      for (int b = 0; b < MF; ++b) xa[b] = *reinterpret_cast<const h16x8*>(sA + (a_row + b * 16) * ROWB + slot * 16);
 #pragma unroll
-      for (int a = 0; a < NF; ++a) wb[a] = *reinterpret_cast<const bf16x8*>(sB + (b_row + a * 16) * ROWB + slot * 16);
+      for (int a = 0; a < NF; ++a) wb[a] = *reinterpret_cast<const h16x8*>(sB + (b_row + a * 16) * ROWB + slot * 16);
 #pragma unroll
       for (int a = 0; a < NF; ++a)
 #pragma unroll
         for (int b = 0; b < MF; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[a], xa[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = CVHIP_MFMA_16X16X32(wb[a], xa[b], acc[a][b], 0, 0, 0);
     }
   };
 
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256, (NST * (BM + (BN < BK ? BK : BN)) * BK * 2 > 8
     const int oh = rem / OWi;
     const int ow = rem - oh * OWi;
     const int64_t opix = ((int64_t)n_img * p.OH + (oh * p.out_sh + cl.out_oh)) * p.OW + (ow * p.out_sw + cl.out_ow);
-    bf16_t* yrow = p.y + opix * p.y_ld;
+    h16_t* yrow = p.y + opix * p.y_ld;
 #pragma unroll
     for (int a = 0; a < NF; ++a) {
       const int n = n0 + wn * WN + a * 16 + nq;
@@ -509,13 +509,16 @@ __global__ __launch_bounds__(256, (NST * (BM + (BN < BK ? BK : BN)) * BK * 2 > 8
         v3 += bv[3];
       }
       if (p.res) {  // skip-connection gradient folded into dgrad's epilogue (replaces autograd's accumulation add)
-        const bf16_t* rrow = p.res + opix * p.res_ld + n;
+        const h16_t* rrow = p.res + opix * p.res_ld + n;
         if (n + 3 < p.Nout && (p.res_ld & 3) == 0 && ((((uintptr_t)p.res) & 7) == 0)) {
           const uint2 u = *reinterpret_cast<const uint2*>(rrow);   // 4 consecutive channels, like the store below
-          v0 += __uint_as_float(u.x << 16);
-          v1 += __uint_as_float(u.x & 0xffff0000u);
-          v2 += __uint_as_float(u.y << 16);
-          v3 += __uint_as_float(u.y & 0xffff0000u);
+          float r0, r1, r2, r3;
+          unpack2(u.x, r0, r1);
+          unpack2(u.y, r2, r3);
+          v0 += r0;
+          v1 += r1;
+          v2 += r2;
+          v3 += r3;
         } else {
           if (n < p.Nout) v0 += (float)rrow[0];
           if (n + 1 < p.Nout) v1 += (float)rrow[1];
@@ -529,10 +532,10 @@ __global__ __launch_bounds__(256, (NST * (BM + (BN < BK ? BK : BN)) * BK * 2 > 8
         u.y = pack2(v2, v3);
         *reinterpret_cast<uint2*>(yrow + n) = u;
       } else {
-        yrow[n] = (bf16_t)v0;
-        if (n + 1 < p.Nout) yrow[n + 1] = (bf16_t)v1;
-        if (n + 2 < p.Nout) yrow[n + 2] = (bf16_t)v2;
-        if (n + 3 < p.Nout) yrow[n + 3] = (bf16_t)v3;
+        yrow[n] = (h16_t)v0;
+        if (n + 1 < p.Nout) yrow[n + 1] = (h16_t)v1;
+        if (n + 2 < p.Nout) yrow[n + 2] = (h16_t)v2;
+        if (n + 3 < p.Nout) yrow[n + 3] = (h16_t)v3;
       }
     }
   }

@@ -28,9 +28,9 @@ struct IgemmClass {
 // struct (kKernelClasses classes: a by-value argument of ~1.4 KB made every launch drag a __amd_rocclr_copyBuffer node along
 // under hipGraph replay — ~100 extra 2.4-us nodes per YOLOv5-s step; 4 classes cover stride <= 2, more classes launch in groups)
 struct IgemmCommon {
-  const bf16_t* x;
-  const bf16_t* w;
-  bf16_t* y;
+  const h16_t* x;
+  const h16_t* w;
+  h16_t* y;
   const float* bias;
   int bias_n;  // number of valid bias entries (k_valid)
   float* stats;
@@ -41,7 +41,7 @@ struct IgemmCommon {
   int n_tiles, total_tiles, ncls;
   int y_vec_ok;
   int interleave;  // 1: logical tile id = spatial tile * ncls + class (classes with equal tile counts: stride-parity dgrad)
-  const bf16_t* res;  // optional addend, same pixel grid and channel count as y (dgrad: the gradient arriving over a skip connection)
+  const h16_t* res;  // optional addend, same pixel grid and channel count as y (dgrad: the gradient arriving over a skip connection)
   int res_ld;
 };
 

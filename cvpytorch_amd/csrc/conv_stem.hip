@@ -29,9 +29,9 @@ constexpr int kStemMaxSteps = 13;  // ceil(49 / 4)
 constexpr int kStemBlocks = 768;   // persistent grid (3 blocks per CU by LDS)
 
 struct StemParams {
-  const bf16_t* x;
-  const bf16_t* w;  // [K][R*S*8] bf16
-  bf16_t* y;
+  const h16_t* x;
+  const h16_t* w;  // [K][R*S*8] bf16
+  h16_t* y;
   const float* bias;
   float* stats;
   int bias_n;
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256, 2) void stem_fprop_kernel(const StemParams p) 
   const int nchunk = PH * PW;
 
   // ---- B fragments (weights) in registers: LDS-free, loaded once. Row i of fragment a <-> channel (i>>2)*8 + a*4 + (i&3)
-  bf16x8 wb[2][NSTEP];
+  h16x8 wb[2][NSTEP];
   int aoff[NSTEP];
   {
     const int i = lane & 15;
@@ -62,8 +62,8 @@ __global__ __launch_bounds__(256, 2) void stem_fprop_kernel(const StemParams p) 
 #pragma unroll
       for (int j = 0; j < NSTEP; ++j) {
         const int tap = j * 4 + g;
-        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (ch < p.K && tap < taps) v = *reinterpret_cast<const bf16x8*>(p.w + ((int64_t)ch * taps + tap) * 8);
+        h16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ch < p.K && tap < taps) v = *reinterpret_cast<const h16x8*>(p.w + ((int64_t)ch * taps + tap) * 8);
         wb[a][j] = v;
       }
     }
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void stem_fprop_kernel(const StemParams p) 
     int n, oy0, ox0;
     tile_origin(tile, n, oy0, ox0);
     const int iy0 = oy0 * ST - p.pad_h, ix0 = ox0 * ST - p.pad_w;
-    const bf16_t* img = p.x + (int64_t)n * p.IH * p.IW * 8;
+    const h16_t* img = p.x + (int64_t)n * p.IH * p.IW * 8;
 #pragma unroll
     for (int i = 0; i < LD_IT; ++i) {
       const int iy = iy0 + (pk[i] >> 16), ix = ix0 + (pk[i] & 0xffff);
@@ -144,13 +144,13 @@ __global__ __launch_bounds__(256, 2) void stem_fprop_kernel(const StemParams p) 
       for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < NSTEP; ++j) {
-      bf16x8 xa[4];
+      h16x8 xa[4];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) xa[b] = *reinterpret_cast<const bf16x8*>(base + aoff[j] + b * 16 * 16);
+      for (int b = 0; b < 4; ++b) xa[b] = *reinterpret_cast<const h16x8*>(base + aoff[j] + b * 16 * 16);
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[a][j], xa[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < 4; ++b) acc[a][b] = CVHIP_MFMA_16X16X32(wb[a][j], xa[b], acc[a][b], 0, 0, 0);
     }
 
     // ---- epilogue: lane (r, g) holds channels g*8 .. g*8+7 of pixel (oy, ox0 + 16 b + r)
@@ -183,13 +183,13 @@ __global__ __launch_bounds__(256, 2) void stem_fprop_kernel(const StemParams p) 
           for (int q = 0; q < 8; ++q)
             if (ch0 + q < p.bias_n) v.v[q] += p.bias[ch0 + q];
         }
-        bf16_t* yrow = p.y + ((int64_t)(n * p.OH + oy) * p.OW + ox) * p.y_ld + ch0;
+        h16_t* yrow = p.y + ((int64_t)(n * p.OH + oy) * p.OW + ox) * p.y_ld + ch0;
         if (ch0 + 7 < p.K && (p.y_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0)) {
           *reinterpret_cast<uint4*>(yrow) = pack8(v);
         } else {
 #pragma unroll
           for (int q = 0; q < 8; ++q)
-            if (ch0 + q < p.K) yrow[q] = (bf16_t)v.v[q];
+            if (ch0 + q < p.K) yrow[q] = (h16_t)v.v[q];
         }
       }
     }
@@ -237,16 +237,16 @@ __global__ __launch_bounds__(256, 2) void stem_fprop_kernel(const StemParams p) 
 // slots. A wave owns every 4th column fragment (<= NFW of them) and keeps its slice of dW in registers across all tiles of
 // the (persistent) block: one atomic epilogue per block. The general wgrad kernel re-gathers x per tap and re-reads dY per
 // 128-column tile (450 us for the YOLOv5-s stem; HBM bound ~170 us).
-typedef __attribute__((address_space(3))) bf16x4 stem_lds_bf16x4;
-__device__ __forceinline__ bf16x8 stem_tr_read8(const unsigned char* p0, const unsigned char* p1) {
-  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((stem_lds_bf16x4*)(p0));
-  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((stem_lds_bf16x4*)(p1));
+typedef __attribute__((address_space(3))) h16x4 stem_lds_h16x4;
+__device__ __forceinline__ h16x8 stem_tr_read8(const unsigned char* p0, const unsigned char* p1) {
+  h16x4 lo = CVHIP_DS_READ_TR16_B64((stem_lds_h16x4*)(p0));
+  h16x4 hi = CVHIP_DS_READ_TR16_B64((stem_lds_h16x4*)(p1));
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 struct StemWgradParams {
-  const bf16_t* x;
-  const bf16_t* dy;
+  const h16_t* x;
+  const h16_t* dy;
   float* dw;  // [K][R*S][8] fp32, accumulated with atomics
   int NB, IH, IW, OH, OW, K, dy_ld, R, S, pad_h, pad_w;
   int tiles_x, tiles_y, ntiles;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const StemWgradParam
     int n, oy0, ox0;
     tile_origin(tile, n, oy0, ox0);
     const int iy0 = oy0 * ST - p.pad_h, ix0 = ox0 * ST - p.pad_w;
-    const bf16_t* img = p.x + (int64_t)n * p.IH * p.IW * 8;
+    const h16_t* img = p.x + (int64_t)n * p.IH * p.IW * 8;
 #pragma unroll
     for (int i = 0; i < LD_IT; ++i) {
       const int iy = iy0 + (pk[i] >> 16), ix = ix0 + (pk[i] & 0xffff);
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const StemWgradParam
 #pragma unroll 2
     for (int step = 0; step < (kStemTH * kStemTW) / 32; ++step) {
       const int ty = step >> 1, xh = step & 1;
-      bf16x8 fd[2];
+      h16x8 fd[2];
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         const unsigned char* base = sD + step * 32 * 64 + (((a ^ hsw) & 1) << 5) + (lane & 3) * 8;
@@ -362,9 +362,9 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const StemWgradParam
 #pragma unroll
       for (int j = 0; j < NFW; ++j) {
         if (wave + 4 * j < nfrag) {
-          const bf16x8 fx = stem_tr_read8(prow + boff[j], prow + boff[j] + 4 * 16);
+          const h16x8 fx = stem_tr_read8(prow + boff[j], prow + boff[j] + 4 * 16);
 #pragma unroll
-          for (int a = 0; a < 2; ++a) acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[a], fx, acc[a][j], 0, 0, 0);
+          for (int a = 0; a < 2; ++a) acc[a][j] = CVHIP_MFMA_16X16X32(fd[a], fx, acc[a][j], 0, 0, 0);
         }
       }
     }
@@ -468,8 +468,8 @@ int try_launch_stem_wgrad(const cvhip_conv_desc* d, const void* x, const void* d
   }
   if (off) return -1;
   StemWgradParams sp;
-  sp.x = (const bf16_t*)x;
-  sp.dy = (const bf16_t*)dy;
+  sp.x = (const h16_t*)x;
+  sp.dy = (const h16_t*)dy;
   sp.dw = dw;
   sp.NB = d->N; sp.IH = d->H; sp.IW = d->W; sp.OH = OH; sp.OW = OW;
   sp.K = d->K; sp.dy_ld = d->y_ld; sp.R = d->R; sp.S = d->S; sp.pad_h = d->pad_h; sp.pad_w = d->pad_w;

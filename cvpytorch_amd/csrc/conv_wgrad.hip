@@ -17,8 +17,8 @@
 namespace cvhip {
 
 struct WgradParams {
-  const bf16_t* x;
-  const bf16_t* dy;
+  const h16_t* x;
+  const h16_t* dy;
   float* dw;
   int NB, IH, IW, Cin, x_ld;
   int OHi, OWi, in_sh, in_sw;
@@ -31,14 +31,14 @@ struct WgradParams {
   int64_t split_stride;
 };
 
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+typedef __attribute__((address_space(3))) h16x4 lds_h16x4;
 
 // M * tiles threshold below which a block runs two 4-wave groups (per-shape A/B on YOLOv5-s and DeepLabv3+ layers)
 constexpr int64_t kWgTwoGroupWork = 600000;
 
-__device__ __forceinline__ bf16x8 tr_read8(const unsigned char* p0, const unsigned char* p1) {
-  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0));
-  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p1));
+__device__ __forceinline__ h16x8 tr_read8(const unsigned char* p0, const unsigned char* p1) {
+  h16x4 lo = CVHIP_DS_READ_TR16_B64((lds_h16x4*)(p0));
+  h16x4 hi = CVHIP_DS_READ_TR16_B64((lds_h16x4*)(p1));
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256 * kWgGroups, kWgGroups == 1 ? 2 : 1) void wgrad
   for (int step = 0; step < nsteps; ++step) {
     const int cur = step & 1;
     if (step + 1 < nsteps) load_step(step + 1);
-    bf16x8 fd[NF], fx[KF];
+    h16x8 fd[NF], fx[KF];
 #pragma unroll
     for (int a = 0; a < NF; ++a) {
       const int seg = (wn * WN + a * 16) >> 4;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256 * kWgGroups, kWgGroups == 1 ? 2 : 1) void wgrad
     for (int a = 0; a < NF; ++a)
 #pragma unroll
       for (int b = 0; b < KF; ++b)
-        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[a], fx[b], acc[a][b], 0, 0, 0);
+        acc[a][b] = CVHIP_MFMA_16X16X32(fd[a], fx[b], acc[a][b], 0, 0, 0);
     if (step + 1 < nsteps) store_step(cur ^ 1);
     __syncthreads();
   }
@@ -308,8 +308,8 @@ int launch_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float*
   const int stem = try_launch_stem_wgrad(d, x, dy, dw, stream);  // 8-channel image stem: patch kernel (conv_stem.hip)
   if (stem >= 0) return stem;
   WgradParams p;
-  p.x = (const bf16_t*)x;
-  p.dy = (const bf16_t*)dy;
+  p.x = (const h16_t*)x;
+  p.dy = (const h16_t*)dy;
   p.dw = dw;
   p.NB = d->N;
   p.IH = d->H;

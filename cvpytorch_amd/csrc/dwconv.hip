@@ -13,11 +13,11 @@
 namespace cvhip {
 
 struct DwParams {
-  const bf16_t* x;   // fprop: input; dgrad: dy; wgrad: x
-  const bf16_t* dy;  // wgrad only
+  const h16_t* x;   // fprop: input; dgrad: dy; wgrad: x
+  const h16_t* dy;  // wgrad only
   const float* w;    // [C][R][S]
   const float* bias;
-  bf16_t* y;         // fprop: y; dgrad: dx
+  h16_t* y;         // fprop: y; dgrad: dx
   float* dw;
   int N, C, H, W, P, Q, R, S, sh, sw, ph, pw, dh, dw_;
   int x_ld, y_ld;
@@ -27,21 +27,21 @@ __device__ __forceinline__ bool dw_vec_ok(const DwParams& p) {
   return (p.C & 7) == 0 && (p.x_ld & 7) == 0 && (p.y_ld & 7) == 0 && ((((uintptr_t)p.x) | ((uintptr_t)p.y) | ((uintptr_t)p.dy)) & 15) == 0;
 }
 
-__device__ __forceinline__ f32x8 dw_load8(const bf16_t* p, int c, int C, bool vec) {
+__device__ __forceinline__ f32x8 dw_load8(const h16_t* p, int c, int C, bool vec) {
   if (vec) return unpack8(*reinterpret_cast<const uint4*>(p + c));
   f32x8 r;
 #pragma unroll
   for (int j = 0; j < 8; ++j) r.v[j] = (c + j < C) ? (float)p[c + j] : 0.f;
   return r;
 }
-__device__ __forceinline__ void dw_store8(bf16_t* p, int c, int C, bool vec, const f32x8& v) {
+__device__ __forceinline__ void dw_store8(h16_t* p, int c, int C, bool vec, const f32x8& v) {
   if (vec) {
     *reinterpret_cast<uint4*>(p + c) = pack8(v);
     return;
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j)
-    if (c + j < C) p[c + j] = (bf16_t)v.v[j];
+    if (c + j < C) p[c + j] = (h16_t)v.v[j];
 }
 
 // y[n,p,q,c] = bias[c] + sum_{r,s} x[n, p*sh-ph+r*dh, q*sw-pw+s*dw, c] * w[c][r][s]
@@ -199,16 +199,16 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwParams p, int row
 // WALKS an image row with a 3x3 register window: 3 new 16-B loads per pixel instead of 9; neighbouring row lanes of a block
 // take neighbouring image rows, so the halo rows are shared through L1/L2.
 struct Dw3Params {
-  const bf16_t* in;   // fprop: x; dgrad: dy; wgrad: x
-  const bf16_t* dy;   // wgrad only
+  const h16_t* in;   // fprop: x; dgrad: dy; wgrad: x
+  const h16_t* dy;   // wgrad only
   const float* w;     // [C][3][3]
   const float* bias;  // fprop only (may be null)
-  bf16_t* out;
+  h16_t* out;
   float* dw;
   int N, C, IH, IW, OH, OW, ph, pw, in_ld, out_ld, dy_ld, flip, seg_len, rows_per_thread;
 };
 
-__device__ __forceinline__ f32x8 dw3_load(const bf16_t* row, bool row_ok, int iw, int IW, int in_ld, int c) {
+__device__ __forceinline__ f32x8 dw3_load(const h16_t* row, bool row_ok, int iw, int IW, int in_ld, int c) {
   if (row_ok && (unsigned)iw < (unsigned)IW) return unpack8(*reinterpret_cast<const uint4*>(row + (int64_t)iw * in_ld + c));
   f32x8 z;
 #pragma unroll
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const Dw3Params p) {
       const int row = (rowblk * p.rows_per_thread + it) * rpp + ty;
       if (row >= total_rows) break;
       const int n = row / p.OH, oh = row - n * p.OH;
-      const bf16_t* rp[3];
+      const h16_t* rp[3];
       bool rok[3];
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
@@ -426,10 +426,10 @@ int cvhip_dwconv2d_fprop(const cvhip_conv_desc* d, const void* x, const float* w
   int st = fill(d, &p);
   if (st) return st;
   if (!x || !w || !y) return CVHIP_ERR_INVALID;
-  p.x = (const bf16_t*)x;
+  p.x = (const h16_t*)x;
   p.w = w;
   p.bias = bias;
-  p.y = (bf16_t*)y;
+  p.y = (h16_t*)y;
   p.x_ld = d->x_ld;
   p.y_ld = d->y_ld;
   if (dw3_applicable(p, x, y, nullptr)) {
@@ -452,9 +452,9 @@ int cvhip_dwconv2d_dgrad(const cvhip_conv_desc* d, const void* dy, const float* 
   int st = fill(d, &p);
   if (st) return st;
   if (!dy || !w || !dx) return CVHIP_ERR_INVALID;
-  p.x = (const bf16_t*)dy;
+  p.x = (const h16_t*)dy;
   p.w = w;
-  p.y = (bf16_t*)dx;
+  p.y = (h16_t*)dx;
   p.x_ld = d->y_ld;  // pitch of dy
   p.y_ld = d->x_ld;  // pitch of dx
   if (dw3_applicable(p, dy, dx, nullptr)) {
@@ -479,8 +479,8 @@ int cvhip_dwconv2d_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy
   if (st) return st;
   if (!x || !dy || !dw) return CVHIP_ERR_INVALID;
   if (p.R * p.S > kDwMaxTaps) return CVHIP_ERR_UNSUPPORTED;
-  p.x = (const bf16_t*)x;
-  p.dy = (const bf16_t*)dy;
+  p.x = (const h16_t*)x;
+  p.dy = (const h16_t*)dy;
   p.dw = dw;
   p.x_ld = d->x_ld;
   p.y_ld = d->y_ld;

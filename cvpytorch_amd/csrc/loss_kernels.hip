@@ -11,14 +11,14 @@ namespace cvhip {
 constexpr int kCeMaxC = 64;
 
 // logits: [M][ld] bf16 (C valid channels), target: int64 [M]; partial: [gridDim.x][2] fp32 = (sum of -log p_t, #valid)
-__global__ __launch_bounds__(256) void seg_ce_fwd_kernel(const bf16_t* __restrict__ logits, int ld, const int64_t* __restrict__ target, int64_t M,
+__global__ __launch_bounds__(256) void seg_ce_fwd_kernel(const h16_t* __restrict__ logits, int ld, const int64_t* __restrict__ target, int64_t M,
                                                          int C, int ignore, float* __restrict__ partial) {
   __shared__ float red[2][256];
   float loss = 0.f, cnt = 0.f;
   for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
     const int64_t t = target[m];
     if (t == ignore || t < 0 || t >= C) continue;
-    const bf16_t* row = logits + m * ld;
+    const h16_t* row = logits + m * ld;
     float mx = -INFINITY;
     for (int c = 0; c < C; ++c) mx = fmaxf(mx, (float)row[c]);
     float se = 0.f;
@@ -71,58 +71,58 @@ __global__ void seg_ce_finalize_kernel(const float* partial, int rows, float* ou
 // so global loads / stores are coalesced whatever the (odd) class count — a thread-per-pixel walk of 38-byte rows ran at
 // 0.3 TB/s (1.27 ms for 16x512x1024x19).
 constexpr int kCeMaxLd = 32;
-__global__ __launch_bounds__(256) void seg_ce_bwd_kernel(const bf16_t* __restrict__ logits, int ld, const int64_t* __restrict__ target, int64_t M,
+__global__ __launch_bounds__(256) void seg_ce_bwd_kernel(const h16_t* __restrict__ logits, int ld, const int64_t* __restrict__ target, int64_t M,
                                                          int C, int ignore, const float* __restrict__ stat, const float* __restrict__ gscale,
-                                                         bf16_t* __restrict__ dlogits, int ld_d) {
+                                                         h16_t* __restrict__ dlogits, int ld_d) {
   __shared__ float tile[256 * kCeMaxLd];
-  __shared__ bf16_t tout[256 * kCeMaxLd];
+  __shared__ h16_t tout[256 * kCeMaxLd];
   const float cnt = stat[1];
   const float g = (cnt > 0.f ? 1.f / cnt : 0.f) * (gscale ? gscale[0] : 1.f);
   const int t = threadIdx.x;
   for (int64_t m0 = (int64_t)blockIdx.x * 256; m0 < M; m0 += (int64_t)gridDim.x * 256) {
     const int rows = (int)(M - m0 < 256 ? M - m0 : 256);
     const int n_in = rows * ld;
-    const bf16_t* src = logits + m0 * ld;
+    const h16_t* src = logits + m0 * ld;
     for (int i = t; i < n_in; i += 256) tile[i] = (float)src[i];
     __syncthreads();
     if (t < rows) {
       const int64_t tt = target[m0 + t];
       const float* row = tile + t * ld;
-      bf16_t* orow = tout + t * ld_d;
+      h16_t* orow = tout + t * ld_d;
       if (tt == ignore || tt < 0 || tt >= C) {
-        for (int c = 0; c < ld_d; ++c) orow[c] = (bf16_t)0.f;
+        for (int c = 0; c < ld_d; ++c) orow[c] = (h16_t)0.f;
       } else {
         float mx = -INFINITY;
         for (int c = 0; c < C; ++c) mx = fmaxf(mx, row[c]);
         float se = 0.f;
         for (int c = 0; c < C; ++c) se += __expf(row[c] - mx);
         const float inv = 1.f / se;
-        for (int c = 0; c < C; ++c) orow[c] = (bf16_t)(g * (__expf(row[c] - mx) * inv - (c == (int)tt ? 1.f : 0.f)));
-        for (int c = C; c < ld_d; ++c) orow[c] = (bf16_t)0.f;
+        for (int c = 0; c < C; ++c) orow[c] = (h16_t)(g * (__expf(row[c] - mx) * inv - (c == (int)tt ? 1.f : 0.f)));
+        for (int c = C; c < ld_d; ++c) orow[c] = (h16_t)0.f;
       }
     }
     __syncthreads();
     const int n_out = rows * ld_d;
-    bf16_t* dst = dlogits + m0 * ld_d;
+    h16_t* dst = dlogits + m0 * ld_d;
     for (int i = t; i < n_out; i += 256) dst[i] = tout[i];
     __syncthreads();
   }
 }
 
 // generic fallback (pitches above kCeMaxLd)
-__global__ __launch_bounds__(256) void seg_ce_bwd_rows_kernel(const bf16_t* __restrict__ logits, int ld, const int64_t* __restrict__ target, int64_t M,
+__global__ __launch_bounds__(256) void seg_ce_bwd_rows_kernel(const h16_t* __restrict__ logits, int ld, const int64_t* __restrict__ target, int64_t M,
                                                               int C, int ignore, const float* __restrict__ stat, const float* __restrict__ gscale,
-                                                              bf16_t* __restrict__ dlogits, int ld_d) {
+                                                              h16_t* __restrict__ dlogits, int ld_d) {
   const float cnt = stat[1];
   const float g = (cnt > 0.f ? 1.f / cnt : 0.f) * (gscale ? gscale[0] : 1.f);
   for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
     const int64_t t = target[m];
-    bf16_t* drow = dlogits + m * ld_d;
+    h16_t* drow = dlogits + m * ld_d;
     if (t == ignore || t < 0 || t >= C) {
-      for (int c = 0; c < ld_d; ++c) drow[c] = (bf16_t)0.f;
+      for (int c = 0; c < ld_d; ++c) drow[c] = (h16_t)0.f;
       continue;
     }
-    const bf16_t* row = logits + m * ld;
+    const h16_t* row = logits + m * ld;
     float mx = -INFINITY;
     for (int c = 0; c < C; ++c) mx = fmaxf(mx, (float)row[c]);
     float se = 0.f;
@@ -130,14 +130,14 @@ __global__ __launch_bounds__(256) void seg_ce_bwd_rows_kernel(const bf16_t* __re
     const float inv = 1.f / se;
     for (int c = 0; c < C; ++c) {
       const float p = __expf((float)row[c] - mx) * inv;
-      drow[c] = (bf16_t)(g * (p - (c == (int)t ? 1.f : 0.f)));
+      drow[c] = (h16_t)(g * (p - (c == (int)t ? 1.f : 0.f)));
     }
-    for (int c = C; c < ld_d; ++c) drow[c] = (bf16_t)0.f;
+    for (int c = C; c < ld_d; ++c) drow[c] = (h16_t)0.f;
   }
 }
 
 // y[n][hw][c] = x[n][hw][c] * s[n][c]
-__global__ __launch_bounds__(256) void scale_nc_kernel(const bf16_t* __restrict__ x, int ld_x, const float* __restrict__ s, bf16_t* __restrict__ y,
+__global__ __launch_bounds__(256) void scale_nc_kernel(const h16_t* __restrict__ x, int ld_x, const float* __restrict__ s, h16_t* __restrict__ y,
                                                        int ld_y, int N, int C, int HW) {
   const int CV = (C + 7) >> 3;
   const bool vec = (C & 7) == 0 && (ld_x & 7) == 0 && (ld_y & 7) == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void scale_nc_kernel(const bf16_t* __restrict_
       for (int j = 0; j < 8; ++j) v.v[j] *= s[(int64_t)n * C + c + j];
       *reinterpret_cast<uint4*>(y + pix * ld_y + c) = pack8(v);
     } else {
-      for (int j = 0; j < 8 && c + j < C; ++j) y[pix * ld_y + c + j] = (bf16_t)((float)x[pix * ld_x + c + j] * s[(int64_t)n * C + c + j]);
+      for (int j = 0; j < 8 && c + j < C; ++j) y[pix * ld_y + c + j] = (h16_t)((float)x[pix * ld_x + c + j] * s[(int64_t)n * C + c + j]);
     }
   }
 }
@@ -177,7 +177,7 @@ int cvhip_seg_ce_fwd(const void* logits, int32_t ld, const int64_t* target, int6
                      float* out2, void* stream) {
   if (!logits || !target || !partial || !out2 || M <= 0 || C <= 0 || C > kCeMaxC * 64 || ld < C) return CVHIP_ERR_INVALID;
   const int rows = grid_for(M);
-  hipLaunchKernelGGL(seg_ce_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, target, M, C, ignore_index,
+  hipLaunchKernelGGL(seg_ce_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const h16_t*)logits, ld, target, M, C, ignore_index,
                      partial);
   int st = check_launch("seg_ce_fwd_kernel");
   if (st) return st;
@@ -191,19 +191,19 @@ int cvhip_seg_ce_bwd(const void* logits, int32_t ld, const int64_t* target, int6
   if (ld <= kCeMaxLd && ld_d <= kCeMaxLd) {
     int64_t blocks = (M + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(seg_ce_bwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, target, M, C,
-                       ignore_index, out2, grad_scale, (bf16_t*)dlogits, ld_d);
+    hipLaunchKernelGGL(seg_ce_bwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const h16_t*)logits, ld, target, M, C,
+                       ignore_index, out2, grad_scale, (h16_t*)dlogits, ld_d);
   } else {
-    hipLaunchKernelGGL(seg_ce_bwd_rows_kernel, dim3(grid_for(M)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, target, M, C,
-                       ignore_index, out2, grad_scale, (bf16_t*)dlogits, ld_d);
+    hipLaunchKernelGGL(seg_ce_bwd_rows_kernel, dim3(grid_for(M)), dim3(256), 0, (hipStream_t)stream, (const h16_t*)logits, ld, target, M, C,
+                       ignore_index, out2, grad_scale, (h16_t*)dlogits, ld_d);
   }
   return check_launch("seg_ce_bwd_kernel");
 }
 
 int cvhip_scale_nc(const void* x, int32_t ld_x, const float* scale_nc, void* y, int32_t ld_y, int32_t N, int32_t C, int32_t HW, void* stream) {
   if (!x || !scale_nc || !y || N <= 0 || C <= 0 || HW <= 0) return CVHIP_ERR_INVALID;
-  hipLaunchKernelGGL(scale_nc_kernel, dim3(grid_for((int64_t)N * HW * ((C + 7) / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
-                     ld_x, scale_nc, (bf16_t*)y, ld_y, N, C, HW);
+  hipLaunchKernelGGL(scale_nc_kernel, dim3(grid_for((int64_t)N * HW * ((C + 7) / 8))), dim3(256), 0, (hipStream_t)stream, (const h16_t*)x,
+                     ld_x, scale_nc, (h16_t*)y, ld_y, N, C, HW);
   return check_launch("scale_nc_kernel");
 }
 

@@ -12,33 +12,33 @@ namespace cvhip {
 __device__ __forceinline__ bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // generic 8-wide load/store helpers with scalar tail
-__device__ __forceinline__ f32x8 load8(const bf16_t* p, int c, int C, bool vec) {
+__device__ __forceinline__ f32x8 load8(const h16_t* p, int c, int C, bool vec) {
   if (vec) return unpack8(*reinterpret_cast<const uint4*>(p + c));
   f32x8 r;
 #pragma unroll
   for (int j = 0; j < 8; ++j) r.v[j] = (c + j < C) ? (float)p[c + j] : 0.f;
   return r;
 }
-__device__ __forceinline__ void store8(bf16_t* p, int c, int C, bool vec, const f32x8& v) {
+__device__ __forceinline__ void store8(h16_t* p, int c, int C, bool vec, const f32x8& v) {
   if (vec) {
     *reinterpret_cast<uint4*>(p + c) = pack8(v);
     return;
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j)
-    if (c + j < C) p[c + j] = (bf16_t)v.v[j];
+    if (c + j < C) p[c + j] = (h16_t)v.v[j];
 }
 
 // ---------------------------------------------------------------------------------------------------
 // max pool
 // ---------------------------------------------------------------------------------------------------
 struct PoolParams {
-  const bf16_t* x;
-  bf16_t* y;
+  const h16_t* x;
+  h16_t* y;
   uint8_t* idx;
-  const bf16_t* dy;
+  const h16_t* dy;
   const uint8_t* cidx;
-  bf16_t* dx;
+  h16_t* dx;
   int ld_x, ld_y, ld_dy, ld_dx;
   int N, C, H, W, OH, OW, k, s, pad;
   int accumulate;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolParams p) {
         }
       }
     }
-    bf16_t* dst = p.dx + ((int64_t)(n * p.H + ih) * p.W + iw) * p.ld_dx;
+    h16_t* dst = p.dx + ((int64_t)(n * p.H + ih) * p.W + iw) * p.ld_dx;
     f32x8 o;
     if (p.accumulate) {
       const f32x8 old = load8(dst, c, p.C, vec);
@@ -163,8 +163,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolParams p) {
 // nearest x2 upsample + channel concat
 // ---------------------------------------------------------------------------------------------------
 struct UpParams {
-  const bf16_t *a, *b;
-  bf16_t* out;
+  const h16_t *a, *b;
+  h16_t* out;
   int ld_a, ld_b, ld_out, Ca, Cb, N, Ha, Wa;
 };
 
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void up2cat_fwd_kernel(const UpParams p) {
     pix /= OW;
     const int oh = (int)(pix % OH);
     const int n = (int)(pix / OH);
-    bf16_t* orow = p.out + ((int64_t)(n * OH + oh) * OW + ow) * p.ld_out;
+    h16_t* orow = p.out + ((int64_t)(n * OH + oh) * OW + ow) * p.ld_out;
     if (cv < CVa) {
       const f32x8 v = load8(p.a + ((int64_t)(n * p.Ha + (oh >> 1)) * p.Wa + (ow >> 1)) * p.ld_a, cv * 8, p.Ca, vec);
       store8(orow, cv * 8, p.Ca, vec, v);
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void up2_bwd_kernel(const UpParams p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) s.v[j] += v.v[j];
       }
-    store8(const_cast<bf16_t*>(p.a) + ((int64_t)(n * p.Ha + h) * p.Wa + w) * p.ld_a, cv * 8, p.Ca, vec, s);
+    store8(const_cast<h16_t*>(p.a) + ((int64_t)(n * p.Ha + h) * p.Wa + w) * p.ld_a, cv * 8, p.Ca, vec, s);
   }
 }
 
@@ -228,8 +228,8 @@ __global__ __launch_bounds__(256) void up2_bwd_kernel(const UpParams p) {
 // bilinear resize (ATen upsample_bilinear2d index rule)
 // ---------------------------------------------------------------------------------------------------
 struct BilParams {
-  const bf16_t* src;
-  bf16_t* dst;
+  const h16_t* src;
+  h16_t* dst;
   int ld_src, ld_dst, N, C, Hi, Wi, Ho, Wo, align;
   float sh, sw;  // source-index scale
 };
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const BilParams p) {
     float lh, lw;
     bil_src(oh, p.sh, p.align, p.Hi, &h0, &h1, &lh);
     bil_src(ow, p.sw, p.align, p.Wi, &w0, &w1, &lw);
-    const bf16_t* base = p.src + (int64_t)n * p.Hi * p.Wi * p.ld_src;
+    const h16_t* base = p.src + (int64_t)n * p.Hi * p.Wi * p.ld_src;
     const f32x8 v00 = load8(base + ((int64_t)h0 * p.Wi + w0) * p.ld_src, cv * 8, p.C, vec);
     const f32x8 v01 = load8(base + ((int64_t)h0 * p.Wi + w1) * p.ld_src, cv * 8, p.C, vec);
     const f32x8 v10 = load8(base + ((int64_t)h1 * p.Wi + w0) * p.ld_src, cv * 8, p.C, vec);
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const BilParams p) {
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    const bf16_t* base = p.src + (int64_t)n * p.Ho * p.Wo * p.ld_src;
+    const h16_t* base = p.src + (int64_t)n * p.Ho * p.Wo * p.ld_src;
     // column weights depend on ow only: computed once per thread (<= kBilCols columns: x4 upsampling visits 9), not per row
     constexpr int kBilCols = 12;
     float wcol[kBilCols];
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const BilParams p) {
 // uint8 NHWC image batch -> normalised bf16 NHWC with channels zero-padded to ld: y = x * scale[c] + shift[c]
 // (scale = 1 / (255 * std), shift = -mean / std: ToTensor + Normalize of the reference's CPU transforms fused with the
 // relayout the stem conv wants). One thread per pixel: C (<= 8) byte loads, one 16-byte store per 8 output channels.
-__global__ __launch_bounds__(256) void u8_norm_kernel(const unsigned char* __restrict__ x, bf16_t* __restrict__ y, int64_t npix, int C, int ld,
+__global__ __launch_bounds__(256) void u8_norm_kernel(const unsigned char* __restrict__ x, h16_t* __restrict__ y, int64_t npix, int C, int ld,
                                                       const float* __restrict__ scale, const float* __restrict__ shift) {
   float sc[8], sh[8];
 #pragma unroll
@@ -402,12 +402,12 @@ __global__ __launch_bounds__(256) void u8_norm_kernel(const unsigned char* __res
     f32x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o.v[j] = j < C ? (float)px[j] * sc[j] + sh[j] : 0.f;
-    bf16_t* dst = y + i * ld;
+    h16_t* dst = y + i * ld;
     if ((ld & 7) == 0 && aligned16(y)) {
       *reinterpret_cast<uint4*>(dst) = pack8(o);
-      for (int c = 8; c < ld; ++c) dst[c] = (bf16_t)0.f;
+      for (int c = 8; c < ld; ++c) dst[c] = (h16_t)0.f;
     } else {
-      for (int c = 0; c < ld; ++c) dst[c] = (bf16_t)(c < 8 ? o.v[c] : 0.f);
+      for (int c = 0; c < ld; ++c) dst[c] = (h16_t)(c < 8 ? o.v[c] : 0.f);
     }
   }
 }
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void u8_norm_kernel(const unsigned char* __res
 // ---------------------------------------------------------------------------------------------------
 // global average pool
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gap_fwd_kernel(const bf16_t* x, int ld_x, bf16_t* y, int N, int C, int HW) {
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const h16_t* x, int ld_x, h16_t* y, int N, int C, int HW) {
   // block = (image n, 32 channels); 256 threads = 8 row-lanes x 32 channels
   __shared__ float red[8][33];
   const int n = blockIdx.y, c = blockIdx.x * 32 + (threadIdx.x & 31), ry = threadIdx.x >> 5;
@@ -428,18 +428,18 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const bf16_t* x, int ld_x,
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x & 31];
-    y[(int64_t)n * C + c] = (bf16_t)(t / (float)HW);
+    y[(int64_t)n * C + c] = (h16_t)(t / (float)HW);
   }
 }
 
-__global__ __launch_bounds__(256) void gap_bwd_kernel(const bf16_t* dy, bf16_t* dx, int ld_dx, int N, int C, int HW) {
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const h16_t* dy, h16_t* dx, int ld_dx, int N, int C, int HW) {
   const int64_t total = (int64_t)N * HW * C;
   const float inv = 1.f / (float)HW;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int c = (int)(i % C);
     const int64_t pix = i / C;
     const int n = (int)(pix / HW);
-    dx[pix * ld_dx + c] = (bf16_t)((float)dy[(int64_t)n * C + c] * inv);
+    dx[pix * ld_dx + c] = (h16_t)((float)dy[(int64_t)n * C + c] * inv);
   }
 }
 
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const bf16_t* dy, bf16_t* 
 // ---------------------------------------------------------------------------------------------------
 // mode 0: plain NCHW fp32 -> NHWC bf16 (pitch ld, channels >= C zero-filled up to Cfill)
 // mode 1: Focus space-to-depth: out (N, H/2, W/2, 4C) channel order TL, BL, TR, BR
-__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, bf16_t* y, int N, int C, int H, int W, int ld,
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, h16_t* y, int N, int C, int H, int W, int ld,
                                                            int Cfill, int focus) {
   const int OH = focus ? H / 2 : H, OW = focus ? W / 2 : W;
   const int64_t total = (int64_t)N * OH * OW;
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, bf16_
     const int ow = (int)(i % OW);
     const int oh = (int)((i / OW) % OH);
     const int n = (int)(i / ((int64_t)OW * OH));
-    bf16_t* dst = y + i * ld;
+    h16_t* dst = y + i * ld;
     const int Cout = focus ? 4 * C : C;
     for (int c = 0; c < Cout; ++c) {
       float v;
@@ -480,18 +480,18 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, bf16_
       } else {
         v = x[((int64_t)(n * C + c) * H + oh) * W + ow];
       }
-      dst[c] = (bf16_t)v;
+      dst[c] = (h16_t)v;
     }
-    for (int c = Cout; c < Cfill; ++c) dst[c] = (bf16_t)0.f;
+    for (int c = Cout; c < Cfill; ++c) dst[c] = (h16_t)0.f;
   }
 }
 
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const bf16_t* x, int ld, float* y, int N, int C, int H, int W) {
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const h16_t* x, int ld, float* y, int N, int C, int H, int W) {
   const int64_t HW = (int64_t)H * W;
   const int64_t total = (int64_t)N * HW;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t n = i / HW, hw = i - n * HW;
-    const bf16_t* src = x + i * ld;
+    const h16_t* src = x + i * ld;
     for (int c = 0; c < C; ++c) y[(n * C + c) * HW + hw] = (float)src[c];
   }
 }
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const bf16_t* x, int 
 // YOLO head boundary: bf16 NHWC (N,H,W,ld>=A*NO) <-> fp32 (N,A,H,W,NO) contiguous.
 // Fuses the reference's x.view(bs,na,no,ny,nx).permute(0,1,3,4,2).contiguous() (+ fp32 cast for the
 // loss) — src/models/detects/yolov5_detect.py:43-44.
-__global__ __launch_bounds__(256) void head_permute_fwd_kernel(const bf16_t* x, int ld, float* y, int N, int A, int NO, int H, int W) {
+__global__ __launch_bounds__(256) void head_permute_fwd_kernel(const h16_t* x, int ld, float* y, int N, int A, int NO, int H, int W) {
   const int64_t total = (int64_t)N * A * H * W * NO;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int o = (int)(i % NO);
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(256) void head_permute_fwd_kernel(const bf16_t* x, 
     y[i] = (float)x[((int64_t)(n * H + yh) * W + xw) * ld + a * NO + o];
   }
 }
-__global__ __launch_bounds__(256) void head_permute_bwd_kernel(const float* dy, bf16_t* dx, int ld, int N, int A, int NO, int H, int W) {
+__global__ __launch_bounds__(256) void head_permute_bwd_kernel(const float* dy, h16_t* dx, int ld, int N, int A, int NO, int H, int W) {
   // one thread per (pixel, channel<ld); pad channels >= A*NO are zero-filled
   const int64_t total = (int64_t)N * H * W * ld;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256) void head_permute_bwd_kernel(const float* dy, 
       const int n = (int)(pix / ((int64_t)W * H));
       v = dy[((((int64_t)n * A + a) * H + yh) * W + xw) * NO + o];
     }
-    dx[i] = (bf16_t)v;
+    dx[i] = (h16_t)v;
   }
 }
 
@@ -550,8 +550,8 @@ int cvhip_maxpool2d_fwd(const void* x, int32_t ld_x, void* y, int32_t ld_y, uint
   if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0 || stride <= 0 || pad < 0) return CVHIP_ERR_INVALID;
   if (k * k > 255 || pad * 2 > k) return CVHIP_ERR_UNSUPPORTED;
   PoolParams p{};
-  p.x = (const bf16_t*)x;
-  p.y = (bf16_t*)y;
+  p.x = (const h16_t*)x;
+  p.y = (h16_t*)y;
   p.idx = argmax;
   p.ld_x = ld_x;
   p.ld_y = ld_y;
@@ -575,9 +575,9 @@ int cvhip_maxpool2d_bwd(const void* dy, int32_t ld_dy, const uint8_t* argmax, vo
   if (!dy || !dx || !argmax || N <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0 || stride <= 0 || pad < 0)
     return CVHIP_ERR_INVALID;
   PoolParams p{};
-  p.dy = (const bf16_t*)dy;
+  p.dy = (const h16_t*)dy;
   p.cidx = argmax;
-  p.dx = (bf16_t*)dx;
+  p.dx = (h16_t*)dx;
   p.ld_dy = ld_dy;
   p.ld_dx = ld_dx;
   p.N = N;
@@ -599,9 +599,9 @@ int cvhip_upsample2x_cat_fwd(const void* a, int32_t ld_a, int32_t Ca, const void
                              void* out, int32_t ld_out, int32_t N, int32_t Ha, int32_t Wa, void* stream) {
   if (!a || !out || Ca <= 0 || Cb < 0 || (Cb > 0 && !b) || N <= 0 || Ha <= 0 || Wa <= 0) return CVHIP_ERR_INVALID;
   UpParams p{};
-  p.a = (const bf16_t*)a;
-  p.b = (const bf16_t*)b;
-  p.out = (bf16_t*)out;
+  p.a = (const h16_t*)a;
+  p.b = (const h16_t*)b;
+  p.out = (h16_t*)out;
   p.ld_a = ld_a;
   p.ld_b = ld_b;
   p.ld_out = ld_out;
@@ -619,8 +619,8 @@ int cvhip_upsample2x_bwd(const void* dout, int32_t ld_dout, void* da, int32_t ld
                          int32_t Wa, void* stream) {
   if (!dout || !da || Ca <= 0 || N <= 0 || Ha <= 0 || Wa <= 0) return CVHIP_ERR_INVALID;
   UpParams p{};
-  p.out = (bf16_t*)const_cast<void*>(dout);
-  p.a = (const bf16_t*)da;
+  p.out = (h16_t*)const_cast<void*>(dout);
+  p.a = (const h16_t*)da;
   p.ld_out = ld_dout;
   p.ld_a = ld_da;
   p.Ca = Ca;
@@ -646,8 +646,8 @@ int cvhip_resize_bilinear_fwd(const void* x, int32_t ld_x, void* y, int32_t ld_y
                               int32_t Wi, int32_t Ho, int32_t Wo, int32_t align_corners, void* stream) {
   if (!x || !y || N <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return CVHIP_ERR_INVALID;
   BilParams p{};
-  p.src = (const bf16_t*)x;
-  p.dst = (bf16_t*)y;
+  p.src = (const h16_t*)x;
+  p.dst = (h16_t*)y;
   p.ld_src = ld_x;
   p.ld_dst = ld_y;
   p.N = N;
@@ -667,8 +667,8 @@ int cvhip_resize_bilinear_bwd(const void* dy, int32_t ld_dy, void* dx, int32_t l
                               int32_t Wi, int32_t Ho, int32_t Wo, int32_t align_corners, void* stream) {
   if (!dy || !dx || N <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return CVHIP_ERR_INVALID;
   BilParams p{};
-  p.src = (const bf16_t*)dy;
-  p.dst = (bf16_t*)dx;
+  p.src = (const h16_t*)dy;
+  p.dst = (h16_t*)dx;
   p.ld_src = ld_dy;
   p.ld_dst = ld_dx;
   p.N = N;
@@ -686,15 +686,15 @@ int cvhip_resize_bilinear_bwd(const void* dy, int32_t ld_dy, void* dx, int32_t l
 
 int cvhip_global_avgpool_fwd(const void* x, int32_t ld_x, void* y, int32_t N, int32_t C, int32_t HW, void* stream) {
   if (!x || !y || N <= 0 || C <= 0 || HW <= 0) return CVHIP_ERR_INVALID;
-  hipLaunchKernelGGL(gap_fwd_kernel, dim3(cdiv(C, 32), N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld_x,
-                     (bf16_t*)y, N, C, HW);
+  hipLaunchKernelGGL(gap_fwd_kernel, dim3(cdiv(C, 32), N), dim3(256), 0, (hipStream_t)stream, (const h16_t*)x, ld_x,
+                     (h16_t*)y, N, C, HW);
   return check_launch("gap_fwd_kernel");
 }
 
 int cvhip_global_avgpool_bwd(const void* dy, void* dx, int32_t ld_dx, int32_t N, int32_t C, int32_t HW, void* stream) {
   if (!dy || !dx || N <= 0 || C <= 0 || HW <= 0) return CVHIP_ERR_INVALID;
   hipLaunchKernelGGL(gap_bwd_kernel, dim3(grid_for((int64_t)N * HW * C)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)dy, (bf16_t*)dx, ld_dx, N, C, HW);
+                     (const h16_t*)dy, (h16_t*)dx, ld_dx, N, C, HW);
   return check_launch("gap_bwd_kernel");
 }
 
@@ -702,7 +702,7 @@ int cvhip_nchw_f32_to_nhwc_bf16(const float* x, void* y, int32_t N, int32_t C, i
                                 void* stream) {
   if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || Cpad < C) return CVHIP_ERR_INVALID;
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, x,
-                     (bf16_t*)y, N, C, H, W, Cpad, Cpad, 0);
+                     (h16_t*)y, N, C, H, W, Cpad, Cpad, 0);
   return check_launch("nchw_to_nhwc_kernel");
 }
 
@@ -710,7 +710,7 @@ int cvhip_focus_nchw_f32_to_nhwc_bf16(const float* x, void* y, int32_t N, int32_
                                       void* stream) {
   if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || Cpad < 4 * C) return CVHIP_ERR_INVALID;
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((int64_t)N * H * W / 4)), dim3(256), 0, (hipStream_t)stream, x,
-                     (bf16_t*)y, N, C, H, W, Cpad, Cpad, 1);
+                     (h16_t*)y, N, C, H, W, Cpad, Cpad, 1);
   return check_launch("nchw_to_nhwc_kernel(focus)");
 }
 
@@ -718,7 +718,7 @@ int cvhip_nhwc_bf16_to_nchw_f32(const void* x, int32_t ld, float* y, int32_t N, 
                                 void* stream) {
   if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || ld < C) return CVHIP_ERR_INVALID;
   hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)x, ld, y, N, C, H, W);
+                     (const h16_t*)x, ld, y, N, C, H, W);
   return check_launch("nhwc_to_nchw_kernel");
 }
 
@@ -726,14 +726,14 @@ int cvhip_nchw_f32_to_nhwc_bf16_ld(const float* x, void* y, int32_t ld, int32_t 
                                    void* stream) {
   if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || ld < C) return CVHIP_ERR_INVALID;
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, x,
-                     (bf16_t*)y, N, C, H, W, ld, C, 0);
+                     (h16_t*)y, N, C, H, W, ld, C, 0);
   return check_launch("nchw_to_nhwc_kernel(ld)");
 }
 
 int cvhip_u8_nhwc_to_bf16_norm(const void* x_u8, int64_t npix, int32_t C, void* y_bf16, int32_t ld, const float* scale, const float* shift,
                                void* stream) {
   if (!x_u8 || !y_bf16 || !scale || !shift || npix <= 0 || C <= 0 || C > 8 || ld < C) return CVHIP_ERR_INVALID;
-  hipLaunchKernelGGL(u8_norm_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)x_u8, (bf16_t*)y_bf16,
+  hipLaunchKernelGGL(u8_norm_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)x_u8, (h16_t*)y_bf16,
                      npix, C, ld, scale, shift);
   return check_launch("u8_norm_kernel");
 }
@@ -742,7 +742,7 @@ int cvhip_head_permute_fwd(const void* x, int32_t ld, float* y, int32_t N, int32
                            void* stream) {
   if (!x || !y || N <= 0 || A <= 0 || NO <= 0 || H <= 0 || W <= 0 || ld < A * NO) return CVHIP_ERR_INVALID;
   hipLaunchKernelGGL(head_permute_fwd_kernel, dim3(grid_for((int64_t)N * A * H * W * NO)), dim3(256), 0,
-                     (hipStream_t)stream, (const bf16_t*)x, ld, y, N, A, NO, H, W);
+                     (hipStream_t)stream, (const h16_t*)x, ld, y, N, A, NO, H, W);
   return check_launch("head_permute_fwd_kernel");
 }
 
@@ -750,7 +750,7 @@ int cvhip_head_permute_bwd(const float* dy, void* dx, int32_t ld, int32_t N, int
                            void* stream) {
   if (!dy || !dx || N <= 0 || A <= 0 || NO <= 0 || H <= 0 || W <= 0 || ld < A * NO) return CVHIP_ERR_INVALID;
   hipLaunchKernelGGL(head_permute_bwd_kernel, dim3(grid_for((int64_t)N * H * W * ld)), dim3(256), 0,
-                     (hipStream_t)stream, dy, (bf16_t*)dx, ld, N, A, NO, H, W);
+                     (hipStream_t)stream, dy, (h16_t*)dx, ld, N, A, NO, H, W);
   return check_launch("head_permute_bwd_kernel");
 }
 

@@ -13,7 +13,7 @@
 
 namespace cvhip {
 
-__global__ __launch_bounds__(256) void yolov5_decode_kernel(const bf16_t* __restrict__ p, int ld, float* __restrict__ out, int N,
+__global__ __launch_bounds__(256) void yolov5_decode_kernel(const h16_t* __restrict__ p, int ld, float* __restrict__ out, int N,
                                                             int A, int NO, int H, int W, float stride,
                                                             const float* __restrict__ anchors_px, int64_t img_stride,
                                                             int64_t lvl_off) {
@@ -129,7 +129,7 @@ int cvhip_yolov5_decode(const void* p, int32_t ld, float* out, int32_t N, int32_
   const int64_t total = (int64_t)N * A * H * W * NO;
   int64_t b = cdiv64(total, 256);
   if (b > 256 * 32) b = 256 * 32;
-  hipLaunchKernelGGL(yolov5_decode_kernel, dim3((int)b), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)p, ld, out, N, A,
+  hipLaunchKernelGGL(yolov5_decode_kernel, dim3((int)b), dim3(256), 0, (hipStream_t)stream, (const h16_t*)p, ld, out, N, A,
                      NO, H, W, stride, anchors_px, out_image_stride, out_level_offset);
   return check_launch("yolov5_decode_kernel");
 }

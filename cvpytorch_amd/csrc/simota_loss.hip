@@ -19,8 +19,8 @@ namespace cvhip {
 constexpr int kSimMaxLevels = 4;
 
 struct SimotaParams {
-  const bf16_t* raw[kSimMaxLevels];
-  bf16_t* draw[kSimMaxLevels];
+  const h16_t* raw[kSimMaxLevels];
+  h16_t* draw[kSimMaxLevels];
   int ld[kSimMaxLevels], H[kSimMaxLevels], W[kSimMaxLevels], off[kSimMaxLevels + 1];
   float stride[kSimMaxLevels];
   int L, B, A, G, nc;
@@ -52,7 +52,7 @@ __device__ __forceinline__ void sim_locate(const SimotaParams& p, int a, int* l,
   *x = r - (*y) * p.W[lv];
 }
 
-__device__ __forceinline__ const bf16_t* sim_ptr(const SimotaParams& p, int b, int l, int y, int x) {
+__device__ __forceinline__ const h16_t* sim_ptr(const SimotaParams& p, int b, int l, int y, int x) {
   return p.raw[l] + ((int64_t)(b * p.H[l] + y) * p.W[l] + x) * p.ld[l];
 }
 
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void sim_prep_kernel(const SimotaParams p) {
   const int b = i / p.A, a = i - b * p.A;
   int l, y, x;
   sim_locate(p, a, &l, &y, &x);
-  const bf16_t* px = sim_ptr(p, b, l, y, x);
+  const h16_t* px = sim_ptr(p, b, l, y, x);
   const float s = p.stride[l];
   const float bx = ((float)px[0] + (float)x) * s, by = ((float)px[1] + (float)y) * s;
   const float bw = expf((float)px[2]) * s, bh = expf((float)px[3]) * s;
@@ -136,7 +136,7 @@ __device__ __forceinline__ float sim_cost(const SimotaParams& p, int b, int a, c
   const float xc = (float)x * s + 0.5f * s, yc = (float)y * s + 0.5f * s;
   bool ib, ic;
   in_flags(xc, yc, s, t[1], t[2], t[3], t[4], &ib, &ic);
-  const bf16_t* px = sim_ptr(p, b, l, y, x);
+  const h16_t* px = sim_ptr(p, b, l, y, x);
   const float pc = sqrtf(sigmoid_ref((float)px[5 + gcls]) * p.sobj[i]);
   const float cls_cost = p.base[i] + (clog(1.f - pc) - clog(pc));
   return (cls_cost + 3.0f * (-logf(iou + 1e-8f))) + 100000.0f * ((ib && ic) ? 0.f : 1.f);
@@ -305,14 +305,14 @@ __global__ __launch_bounds__(256) void sim_loss_kernel(const SimotaParams p) {
     const int b = i / p.A, a = i - b * p.A;
     int l, y, x;
     sim_locate(p, a, &l, &y, &x);
-    const bf16_t* px = sim_ptr(p, b, l, y, x);
+    const h16_t* px = sim_ptr(p, b, l, y, x);
     const int m = p.matched[i];
     const float fgt = m >= 0 ? 1.f : 0.f;
     const float nf = fmaxf((float)p.numfg[0], 1.f);
     const float go = BWD ? (p.gout ? p.gout[0] : 1.f) / nf : 0.f;
-    bf16_t* dx = BWD ? p.draw[l] + ((int64_t)(b * p.H[l] + y) * p.W[l] + x) * p.ld[l] : nullptr;
+    h16_t* dx = BWD ? p.draw[l] + ((int64_t)(b * p.H[l] + y) * p.W[l] + x) * p.ld[l] : nullptr;
     const float xo = (float)px[4];
-    if (BWD) dx[4] = (bf16_t)((sigmoid_ref(xo) - fgt) * go);
+    if (BWD) dx[4] = (h16_t)((sigmoid_ref(xo) - fgt) * go);
     else l_obj = bce_logits(xo, fgt);
     if (m >= 0) {
       const float* t = p.targets + ((int64_t)b * p.G + m) * 5;
@@ -324,11 +324,11 @@ __global__ __launch_bounds__(256) void sim_loss_kernel(const SimotaParams p) {
       if (BWD) {
         const float s = p.stride[l];
         const float k = -2.f * iou.v * 5.0f * go;  // d(5 * (1 - iou^2))
-        dx[0] = (bf16_t)(k * iou.d[0] * s);
-        dx[1] = (bf16_t)(k * iou.d[1] * s);
-        dx[2] = (bf16_t)(k * iou.d[2] * bo[2]);
-        dx[3] = (bf16_t)(k * iou.d[3] * bo[3]);
-        for (int c = 0; c < p.nc; ++c) dx[5 + c] = (bf16_t)((sigmoid_ref((float)px[5 + c]) - (c == tcls ? mi : 0.f)) * go);
+        dx[0] = (h16_t)(k * iou.d[0] * s);
+        dx[1] = (h16_t)(k * iou.d[1] * s);
+        dx[2] = (h16_t)(k * iou.d[2] * bo[2]);
+        dx[3] = (h16_t)(k * iou.d[3] * bo[3]);
+        for (int c = 0; c < p.nc; ++c) dx[5 + c] = (h16_t)((sigmoid_ref((float)px[5 + c]) - (c == tcls ? mi : 0.f)) * go);
       } else {
         l_iou = 1.f - iou.v * iou.v;
         for (int c = 0; c < p.nc; ++c) l_cls += bce_logits((float)px[5 + c], c == tcls ? mi : 0.f);
@@ -431,7 +431,7 @@ static int sim_fill(SimotaParams& p, const cvhip_simota_desc* d, const void* con
   int off = 0;
   for (int i = 0; i < d->L; ++i) {
     if (!raws[i] || d->H[i] <= 0 || d->W[i] <= 0 || d->ld[i] < 5 + d->nc) return CVHIP_ERR_INVALID;
-    p.raw[i] = (const bf16_t*)raws[i];
+    p.raw[i] = (const h16_t*)raws[i];
     p.ld[i] = d->ld[i];
     p.H[i] = d->H[i];
     p.W[i] = d->W[i];
@@ -489,7 +489,7 @@ int cvhip_simota_loss_bwd(const cvhip_simota_desc* d, const void* const* raws, c
   hipStream_t st = (hipStream_t)stream;
   for (int i = 0; i < p.L; ++i) {
     if (!draws[i]) return CVHIP_ERR_INVALID;
-    p.draw[i] = (bf16_t*)draws[i];
+    p.draw[i] = (h16_t*)draws[i];
     rc = zero_fill(p.draw[i], (int64_t)p.B * p.H[i] * p.W[i] * p.ld[i] * 2, st);
     if (rc != CVHIP_OK) return rc;
   }

@@ -12,7 +12,7 @@ namespace cvhip {
 
 // w_fprop[k][r][s][c] = bf16(master[k][r][s][c]) with zero rows/columns beyond the master's real (Kv, Cv) extent.
 // Fast path (no padding): same element order, 8 elements per thread.
-__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, h16_t* __restrict__ dst, int64_t n) {
   const int64_t nv = n >> 3;
   const bool al = (((uintptr_t)src) & 15) == 0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
@@ -32,10 +32,10 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
     u.w = pack2(b.z, b.w);
     reinterpret_cast<uint4*>(dst)[i] = u;
   }
-  for (int64_t i = (nv << 3) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = (bf16_t)src[i];
+  for (int64_t i = (nv << 3) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = (h16_t)src[i];
 }
 
-__global__ __launch_bounds__(256) void pack_fprop_padded_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int K, int T, int C,
+__global__ __launch_bounds__(256) void pack_fprop_padded_kernel(const float* __restrict__ src, h16_t* __restrict__ dst, int K, int T, int C,
                                                                 int Kv, int Cv) {
   const int64_t n = (int64_t)K * T * C;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void pack_fprop_padded_kernel(const float* __r
     const int64_t kt = i / C;
     const int t = (int)(kt % T);
     const int k = (int)(kt / T);
-    dst[i] = (k < Kv && c < Cv) ? (bf16_t)src[((int64_t)k * T + t) * Cv + c] : (bf16_t)0.f;
+    dst[i] = (k < Kv && c < Cv) ? (h16_t)src[((int64_t)k * T + t) * Cv + c] : (h16_t)0.f;
   }
 }
 
@@ -56,7 +56,7 @@ struct DgradPack {
 // dgrad image of class q: [c][i*TS + j][k] = master[k][r0+i*r_step][s0+j*s_step][c]
 // one thread per output element, k fastest (coalesced writes; reads strided by R*S*C — the weight
 // tensors are small and L2-resident).
-__global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* __restrict__ master, bf16_t* __restrict__ dst, const DgradPack p) {
+__global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* __restrict__ master, h16_t* __restrict__ dst, const DgradPack p) {
   const int q = blockIdx.y;
   const IgemmClass& cl = p.cls[q];
   const int T = cl.TR * cl.TS;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* __restrict
     const int c = (int)(ct / T);
     const int i = tap / cl.TS, j = tap - i * cl.TS;
     const int r = cl.r0 + i * cl.r_step, s = cl.s0 + j * cl.s_step;
-    dst[cl.w_off + idx] = (k < p.Kv && c < p.Cv) ? (bf16_t)master[(((int64_t)k * p.R + r) * p.S + s) * p.Cv + c] : (bf16_t)0.f;
+    dst[cl.w_off + idx] = (k < p.Kv && c < p.Cv) ? (h16_t)master[(((int64_t)k * p.R + r) * p.S + s) * p.Cv + c] : (h16_t)0.f;
   }
 }
 
@@ -84,8 +84,8 @@ struct PrepClass {
 };
 struct PrepItem {
   const float* master;
-  bf16_t* wf;
-  bf16_t* wd;
+  h16_t* wf;
+  h16_t* wd;
   int K, R, S, C, Kv, Cv;
   int ncls, blk_begin, nblk_f, nblk_d;
   int ktiles, ctiles;  // dgrad image: one block per (tap, 64 x 64 tile of the [K][C] slice of that tap)
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void prep_all_kernel(const PrepItem* __restric
   const int64_t n = (int64_t)K * T * C;
   const float* __restrict__ src = it.master;
   if (b < it.nblk_f) {
-    bf16_t* __restrict__ dst = it.wf;
+    h16_t* __restrict__ dst = it.wf;
     const int64_t e0 = (int64_t)b * kPrepFpropPerBlock + threadIdx.x * 8;
     if (e0 >= n) return;
     if (Kv == K && Cv == C && e0 + 8 <= n && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0) {
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void prep_all_kernel(const PrepItem* __restric
         const int64_t kt = i / C;
         const int t = (int)(kt % T);
         const int k = (int)(kt / T);
-        dst[i] = (k < Kv && c < Cv) ? (bf16_t)src[((int64_t)k * T + t) * Cv + c] : (bf16_t)0.f;
+        dst[i] = (k < Kv && c < Cv) ? (h16_t)src[((int64_t)k * T + t) * Cv + c] : (h16_t)0.f;
       }
     }
     return;
@@ -153,11 +153,11 @@ __global__ __launch_bounds__(256) void prep_all_kernel(const PrepItem* __restric
     tile[y][tx] = (k < Kv && c < Cv) ? src[(((int64_t)k * it.R + r) * it.S + s2) * Cv + c] : 0.f;
   }
   __syncthreads();
-  bf16_t* __restrict__ dst = it.wd + cl.w_off;
+  h16_t* __restrict__ dst = it.wd + cl.w_off;
 #pragma unroll
   for (int y = ty; y < kPrepTile; y += 4) {
     const int c = c0 + y, k = k0 + tx;
-    if (c < C && k < K) dst[((int64_t)c * Tq + tap) * K + k] = (bf16_t)tile[tx][y];
+    if (c < C && k < K) dst[((int64_t)c * Tq + tap) * K + k] = (h16_t)tile[tx][y];
   }
 }
 
@@ -173,11 +173,22 @@ __global__ __launch_bounds__(256) void sgd_ema_kernel(float* __restrict__ param,
                                                       const int64_t* __restrict__ seg, const float* __restrict__ seg_lr,
                                                       const float* __restrict__ seg_wd, int nseg, float momentum,
                                                       int nesterov, int first, float decay, float gscale,
-                                                      const float* __restrict__ dyn) {
+                                                      const float* __restrict__ dyn, const float* __restrict__ scaler) {
   float lr_scale = 1.f;
   if (dyn) {  // {ema_decay, lr_scale} read from device memory: values can change between hipGraph replays
     decay = dyn[0];
     lr_scale = dyn[1];
+  }
+  if (scaler) {  // dynamic loss scaling: {1/scale, skip} written by loss_scale_update_kernel for THIS step
+    gscale *= scaler[0];
+    if (scaler[1] != 0.f) {
+      // non-finite gradients: GradScaler.step() skips optimizer.step() — parameters and momentum stay; ModelEMA.update still
+      // runs in the reference (trainer.py:206), on the unchanged parameters
+      if (ema)
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+          ema[i] = decay * ema[i] + (1.f - decay) * param[i];
+      return;
+    }
   }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     // binary search the segment containing i (segments are sorted, disjoint, cover [0,n))
@@ -206,6 +217,47 @@ __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ ema, const
     ema[i] = decay * ema[i] + (1.f - decay) * src[i];
 }
 
+// ---- dynamic loss scaling (fp16 storage): torch.cuda.amp.GradScaler's rule on device, no host round trip -------------------
+// state = {scale, growth_tracker, found_inf, skipped_steps}
+__global__ __launch_bounds__(256) void loss_scale_check_kernel(const float* __restrict__ grad, int64_t n, float* __restrict__ state) {
+  bool bad = false;
+  const int64_t n4 = n >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(grad);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = g4[i];
+    // x - x is 0 for finite x and NaN for +-inf / NaN
+    const float t = (v.x - v.x) + (v.y - v.y) + (v.z - v.z) + (v.w - v.w);
+    bad = bad || !(t == 0.f);
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float x = grad[i];
+    bad = bad || !((x - x) == 0.f);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) state[2] = 1.f;  // benign race: every writer stores the same value
+}
+
+__global__ void loss_scale_update_kernel(float* __restrict__ state, float* __restrict__ scaler, float growth, float backoff, int interval) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float scale = state[0];
+  const bool inf = state[2] != 0.f;
+  scaler[0] = inf ? 0.f : 1.f / scale;   // the gradients of THIS step were produced under `scale`
+  scaler[1] = inf ? 1.f : 0.f;
+  if (inf) {
+    state[0] = fmaxf(scale * backoff, 1.f / 65536.f);
+    state[1] = 0.f;
+    state[3] += 1.f;
+  } else {
+    const float t = state[1] + 1.f;
+    if (t >= (float)interval) {
+      state[0] = fminf(scale * growth, 3.0e38f);
+      state[1] = 0.f;
+    } else {
+      state[1] = t;
+    }
+  }
+  state[2] = 0.f;
+}
+
 static inline int grid1d(int64_t n) {
   int64_t b = cdiv64(n, 256);
   if (b > 256 * 16) b = 256 * 16;
@@ -218,9 +270,9 @@ int pack_weights(const cvhip_conv_desc* d, const float* master, void* w_fprop, v
   const int Kv = d->k_valid > 0 ? d->k_valid : d->K, Cv = d->c_valid > 0 ? d->c_valid : d->C;
   if (w_fprop) {
     if (Kv == d->K && Cv == d->C) {
-      hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid1d(n / 8 + 1)), dim3(256), 0, stream, master, (bf16_t*)w_fprop, n);
+      hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid1d(n / 8 + 1)), dim3(256), 0, stream, master, (h16_t*)w_fprop, n);
     } else {
-      hipLaunchKernelGGL(pack_fprop_padded_kernel, dim3(grid1d(n)), dim3(256), 0, stream, master, (bf16_t*)w_fprop, d->K, d->R * d->S,
+      hipLaunchKernelGGL(pack_fprop_padded_kernel, dim3(grid1d(n)), dim3(256), 0, stream, master, (h16_t*)w_fprop, d->K, d->R * d->S,
                          d->C, Kv, Cv);
     }
     int st = check_launch("pack_fprop_kernel");
@@ -244,7 +296,7 @@ int pack_weights(const cvhip_conv_desc* d, const float* master, void* w_fprop, v
       const int64_t e = (int64_t)d->C * ip.cls[i].TR * ip.cls[i].TS * d->K;
       if (e > maxe) maxe = e;
     }
-    hipLaunchKernelGGL(pack_dgrad_kernel, dim3(grid1d(maxe), ncls), dim3(256), 0, stream, master, (bf16_t*)w_dgrad, p);
+    hipLaunchKernelGGL(pack_dgrad_kernel, dim3(grid1d(maxe), ncls), dim3(256), 0, stream, master, (h16_t*)w_dgrad, p);
     return check_launch("pack_dgrad_kernel");
   }
   return CVHIP_OK;
@@ -263,8 +315,35 @@ int cvhip_sgd_nesterov_ema(float* param, const float* grad, float* momentum_buf,
   if (!param || !grad || !momentum_buf || n < 0 || !seg_bounds || !seg_lr || !seg_wd || nseg <= 0) return CVHIP_ERR_INVALID;
   if (n == 0) return CVHIP_OK;
   hipLaunchKernelGGL(sgd_ema_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, param, grad, momentum_buf, ema, n,
-                     seg_bounds, seg_lr, seg_wd, nseg, momentum, nesterov, first_step, ema_decay, grad_scale, dyn_decay_lrscale);
+                     seg_bounds, seg_lr, seg_wd, nseg, momentum, nesterov, first_step, ema_decay, grad_scale, dyn_decay_lrscale,
+                     (const float*)nullptr);
   return check_launch("sgd_ema_kernel");
+}
+
+int cvhip_sgd_nesterov_ema_scaled(float* param, const float* grad, float* momentum_buf, float* ema, int64_t n,
+                                  const int64_t* seg_bounds, const float* seg_lr, const float* seg_wd, int32_t nseg,
+                                  float momentum, int32_t nesterov, int32_t first_step, float ema_decay, float grad_scale,
+                                  const float* dyn_decay_lrscale, const float* scaler2, void* stream) {
+  if (!param || !grad || !momentum_buf || n < 0 || !seg_bounds || !seg_lr || !seg_wd || nseg <= 0 || !scaler2) return CVHIP_ERR_INVALID;
+  if (n == 0) return CVHIP_OK;
+  hipLaunchKernelGGL(sgd_ema_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, param, grad, momentum_buf, ema, n,
+                     seg_bounds, seg_lr, seg_wd, nseg, momentum, nesterov, first_step, ema_decay, grad_scale, dyn_decay_lrscale,
+                     scaler2);
+  return check_launch("sgd_ema_kernel(scaled)");
+}
+
+int cvhip_loss_scale_check(const float* grad, int64_t n, float* state4, void* stream) {
+  if (!grad || !state4 || n < 0 || (((uintptr_t)grad) & 15)) return CVHIP_ERR_INVALID;
+  if (n == 0) return CVHIP_OK;
+  hipLaunchKernelGGL(loss_scale_check_kernel, dim3(grid1d(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, grad, n, state4);
+  return check_launch("loss_scale_check_kernel");
+}
+
+int cvhip_loss_scale_update(float* state4, float* scaler2, float growth_factor, float backoff_factor, int32_t growth_interval, void* stream) {
+  if (!state4 || !scaler2 || growth_factor < 1.f || backoff_factor <= 0.f || backoff_factor > 1.f || growth_interval < 1) return CVHIP_ERR_INVALID;
+  hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state4, scaler2, growth_factor, backoff_factor,
+                     growth_interval);
+  return check_launch("loss_scale_update_kernel");
 }
 
 int cvhip_prep_plan_item_bytes(void) { return (int)sizeof(PrepItem); }
@@ -282,8 +361,8 @@ int cvhip_prep_plan_build(const cvhip_prep_entry* entries, int32_t n, void* tabl
     PrepItem& it = out[e];
     memset(&it, 0, sizeof(it));
     it.master = entries[e].master;
-    it.wf = (bf16_t*)entries[e].w_fprop;
-    it.wd = (bf16_t*)entries[e].w_dgrad;
+    it.wf = (h16_t*)entries[e].w_fprop;
+    it.wd = (h16_t*)entries[e].w_dgrad;
     it.K = d->K;
     it.R = d->R;
     it.S = d->S;

@@ -21,8 +21,8 @@ constexpr int kLossMaxA = 8;
 constexpr int kCandStride = 4;  // floats of per-candidate scalars: iou, lbox, lcls, (unused)
 
 struct YoloLossParams {
-  const bf16_t* raw;
-  bf16_t* draw;
+  const h16_t* raw;
+  h16_t* draw;
   const float* targets;  // (T, 6) [img, cls, cx, cy, w, h] normalised; img < 0 = padding row
   int ld, N, A, NO, H, W, T, nc, ncand;
   float anchor_t;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void yolo_cand_kernel(const YoloLossParams p) 
     atomicMax(p.winner + cell, c + 1);
     p.next[c] = atomicExch(p.head + cell, c + 1);
   }
-  const bf16_t* px = p.raw + ((int64_t)(b * p.H + gj) * p.W + gi) * p.ld + a * p.NO;
+  const h16_t* px = p.raw + ((int64_t)(b * p.H + gj) * p.W + gi) * p.ld + a * p.NO;
   // box (all lanes redundantly: 4 broadcast loads)
   const float r0 = (float)px[0], r1 = (float)px[1], r2 = (float)px[2], r3 = (float)px[3];
   const float s0 = sigmoid_ref(r0), s1 = sigmoid_ref(r1), s2 = sigmoid_ref(r2), s3 = sigmoid_ref(r3);
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void yolo_obj_kernel(const YoloLossParams p) {
     const float x = (float)p.raw[o];
     const int w = p.winner[i];
     const float tt = w > 0 ? fmaxf(p.cand[(int64_t)(w - 1) * kCandStride], 0.f) : 0.f;
-    if (BWD) p.draw[o] = (bf16_t)((sigmoid_ref(x) - tt) * go);
+    if (BWD) p.draw[o] = (h16_t)((sigmoid_ref(x) - tt) * go);
     else acc += bce_logits(x, tt);
   }
   if (!BWD) {
@@ -265,9 +265,9 @@ __global__ __launch_bounds__(256) void yolo_cand_bwd_kernel(const YoloLossParams
   r /= p.H;
   const int a = r % p.A;
   const int b = r / p.A;
-  bf16_t* dst = p.draw + ((int64_t)(b * p.H + gj) * p.W + gi) * p.ld + a * p.NO;
-  if (ch0 < p.NO && ch0 != 4) dst[ch0] = (bf16_t)(acc0 * (ch0 < 4 ? kb : kc));
-  if (ch1 < p.NO) dst[ch1] = (bf16_t)(acc1 * kc);
+  h16_t* dst = p.draw + ((int64_t)(b * p.H + gj) * p.W + gi) * p.ld + a * p.NO;
+  if (ch0 < p.NO && ch0 != 4) dst[ch0] = (h16_t)(acc0 * (ch0 < 4 ? kb : kc));
+  if (ch1 < p.NO) dst[ch1] = (h16_t)(acc1 * kc);
 }
 
 // ---- final scalars ----------------------------------------------------------------------------------------
@@ -299,7 +299,7 @@ static int fill(YoloLossParams& p, const cvhip_yolo_loss_desc* d, const void* ra
   const int64_t ncell = (int64_t)d->N * d->A * d->H * d->W;
   const int64_t ncand = (int64_t)5 * d->A * d->T;
   if (ncell >= (1ll << 31) || ncand >= (1ll << 30)) return CVHIP_ERR_UNSUPPORTED;
-  p.raw = (const bf16_t*)raw;
+  p.raw = (const h16_t*)raw;
   p.draw = nullptr;
   p.targets = targets;
   p.ld = d->ld;
@@ -379,7 +379,7 @@ int cvhip_yolov5_loss_level_bwd(const cvhip_yolo_loss_desc* d, const void* raw, 
   int rc = fill(p, d, raw, targets, ws, const_cast<float*>(sums4));
   if (rc != CVHIP_OK) return rc;
   if (!draw) return CVHIP_ERR_INVALID;
-  p.draw = (bf16_t*)draw;
+  p.draw = (h16_t*)draw;
   p.gout = gout;
   p.k_box = k_box;
   p.k_cls = k_cls;

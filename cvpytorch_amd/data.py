@@ -76,7 +76,8 @@ class DevicePrefetcher:
             ev.record(self.stream)
             self._events[slot] = ev
             cp = (Cc + 7) // 8 * 8
-            out = torch.empty((N, H, W, cp), dtype=torch.bfloat16, device=self.device)
+            from . import ops
+            out = torch.empty((N, H, W, cp), dtype=ops.ACT_DTYPE, device=self.device)
             L.call("cvhip_u8_nhwc_to_bf16_norm", dev_u8.data_ptr(), N * H * W, Cc, out.data_ptr(), cp, self.scale.data_ptr(),
                    self.shift.data_ptr(), self.stream.cuda_stream)
             tgt = target.to(self.device, non_blocking=True) if torch.is_tensor(target) else target
@@ -123,8 +124,9 @@ class GraphFeed:
     def __init__(self, static_imgs, static_targets, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0)):
         from . import lib as L
         from .ops import nhwc_ld
-        if static_imgs.dtype != torch.bfloat16 or nhwc_ld(static_imgs) is None or nhwc_ld(static_imgs) % 8:
-            raise L.CvhipError("GraphFeed: the static image tensor must be the bf16 NHWC (channels padded to 8) tensor the stem consumes")
+        from . import ops
+        if static_imgs.dtype != ops.ACT_DTYPE or nhwc_ld(static_imgs) is None or nhwc_ld(static_imgs) % 8:
+            raise L.CvhipError("GraphFeed: the static image tensor must be the 16-bit NHWC (channels padded to 8) tensor the stem consumes")
         self.imgs, self.targets = static_imgs, static_targets
         self.device = static_imgs.device
         self.ld = nhwc_ld(static_imgs)

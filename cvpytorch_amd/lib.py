@@ -124,6 +124,9 @@ SIGNATURES = {
     "cvhip_nms_sorted": (_i32, [_p, _i32, _f32, _p, _p, _p, _p]),
     "cvhip_box_iou": (_i32, [_p, _i32, _p, _i32, _p, _p]),
     "cvhip_sgd_nesterov_ema": (_i32, [_p, _p, _p, _p, _i64, _p, _p, _p, _i32, _f32, _i32, _i32, _f32, _f32, _p, _p]),
+    "cvhip_sgd_nesterov_ema_scaled": (_i32, [_p, _p, _p, _p, _i64, _p, _p, _p, _i32, _f32, _i32, _i32, _f32, _f32, _p, _p, _p]),
+    "cvhip_loss_scale_check": (_i32, [_p, _i64, _p, _p]),
+    "cvhip_loss_scale_update": (_i32, [_p, _p, _f32, _f32, _i32, _p]),
     "cvhip_ema_update": (_i32, [_p, _p, _i64, _f32, _p, _p]),
     "cvhip_u8_nhwc_to_bf16_norm": (_i32, [_p, _i64, _i32, _p, _i32, _p, _p, _p]),
     "cvhip_yolov5_loss_workspace_bytes": (_i64, [_ylp]),
@@ -154,6 +157,18 @@ SIGNATURES = {
 }
 
 _lib = None
+_F16 = set()        # entry points that exist a second time with the suffix _f16 (fp16 storage: csrc/common.h)
+PRECISION = "bf16"  # storage precision the engine currently runs in: `call` routes to the _f16 symbols when "fp16"
+
+
+def set_precision(p):
+    """Select the storage precision of activations / operand images / activation gradients: "bf16" (default) or "fp16"
+    (reference: autocast fp16, trainer.py:179). Process-wide, like the reference's autocast context."""
+    global PRECISION
+    if p not in ("bf16", "fp16"):
+        raise CvhipError("precision must be 'bf16' or 'fp16'")
+    load()
+    PRECISION = p
 
 
 def load():
@@ -170,6 +185,13 @@ def load():
         fn = getattr(lib, name)  # AttributeError here == ABI drift; let it propagate loudly
         fn.restype = res
         fn.argtypes = args
+        try:
+            f16 = getattr(lib, name + "_f16")
+        except AttributeError:
+            continue
+        f16.restype = res
+        f16.argtypes = args
+        _F16.add(name)
     if lib.cvhip_version() < 100:
         raise CvhipError("libcvhip.so too old")
     _lib = lib
@@ -180,11 +202,18 @@ def check(status, what):
     if status != OK:
         lib = load()
         msg = {ERR_INVALID: "invalid argument", ERR_UNSUPPORTED: "unsupported shape/feature",
-               ERR_LAUNCH: "HIP launch error: " + (lib.cvhip_last_error() or b"").decode()}.get(status, "status %d" % status)
+               ERR_LAUNCH: "HIP launch error: " + (fn("cvhip_last_error")() or b"").decode()}.get(status, "status %d" % status)
         raise CvhipError("%s failed: %s" % (what, msg))
 
 
-def call(name, *args):
-    """Invoke an int-status entry point and raise on failure."""
+def fn(name):
+    """The entry point `name` of the active precision."""
     lib = load()
-    check(getattr(lib, name)(*args), name)
+    if PRECISION == "fp16" and name in _F16:
+        name += "_f16"
+    return getattr(lib, name)
+
+
+def call(name, *args):
+    """Invoke an int-status entry point (of the active precision) and raise on failure."""
+    check(fn(name)(*args), name)

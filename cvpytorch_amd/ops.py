@@ -21,8 +21,23 @@ import torch
 
 from . import lib as L
 
-BF16 = torch.bfloat16
+ACT_DTYPE = torch.bfloat16  # storage dtype of activations / operand images / activation gradients (set_precision)
 _weights_epoch = 0  # bumped by the fused optimizer (it updates parameters behind torch's back)
+
+
+def set_precision(p):
+    """Storage precision of the engine: "bf16" (default) or "fp16" (reference: torch.cuda.amp.autocast fp16, trainer.py:179; pair it
+    with the dynamic loss scaling of arena.FlatTrainState(loss_scaling=True) as the reference pairs autocast with GradScaler).
+    Process-wide; cached operand images are dropped (they are re-packed in the new precision on the next forward)."""
+    global ACT_DTYPE
+    L.set_precision(p)
+    ACT_DTYPE = torch.float16 if p == "fp16" else torch.bfloat16
+    bump_weights_epoch()
+    _desc_cache.clear()
+
+
+def precision():
+    return L.PRECISION
 
 
 def bump_weights_epoch():
@@ -133,14 +148,14 @@ def _ptr(t):
 def empty_nhwc(N, Cc, H, W, device, ld=None):
     """Fresh NHWC-view tensor of logical shape (N,C,H,W); ld > C gives a padded pitch."""
     if ld is None or ld == Cc:
-        return torch.empty((N, Cc, H, W), dtype=BF16, device=device, memory_format=torch.channels_last)
-    buf = torch.empty((N, H, W, ld), dtype=BF16, device=device)
+        return torch.empty((N, Cc, H, W), dtype=ACT_DTYPE, device=device, memory_format=torch.channels_last)
+    buf = torch.empty((N, H, W, ld), dtype=ACT_DTYPE, device=device)
     return buf.permute(0, 3, 1, 2)[:, :Cc]
 
 
 def nhwc_ld(t):
     """Return the pixel pitch of an NHWC-view tensor, or None if `t` is not one."""
-    if t.dim() != 4 or t.dtype != BF16:
+    if t.dim() != 4 or t.dtype != ACT_DTYPE:
         return None
     N, Cc, H, W = t.shape
     sN, sC, sH, sW = t.stride()
@@ -162,8 +177,8 @@ def as_nhwc(t):
     """NHWC view of `t` (no copy when it already is one; otherwise one channels_last relayout)."""
     if not t.is_cuda:
         raise L.CvhipError("cvpytorch_amd ops need CUDA/HIP tensors (no CPU fallback); got %s" % t.device)
-    if t.dtype != BF16:
-        t = t.to(BF16)
+    if t.dtype != ACT_DTYPE:
+        t = t.to(ACT_DTYPE)
     ld = nhwc_ld(t)
     if ld is None:
         t = t.contiguous(memory_format=torch.channels_last)
@@ -259,15 +274,15 @@ class ConvState:
         added here because the fused optimizer updates parameters behind torch's version counters). Channel
         padding (pdesc.k_valid / c_valid) is applied by the packer kernels: no torch ops are involved.
         The image buffers are allocated once and re-used (fixed addresses: PrepPlan re-packs them in one batched launch)."""
-        key = (vkey, _weights_epoch, pdesc.key())
+        key = (vkey, _weights_epoch, pdesc.key(), L.PRECISION)
         if self.key == key and self.w_fprop is not None and (self.w_dgrad is not None or not need_dgrad):
             return
         dev = weight.device
         master = _krsc_master(weight)
         lib = L.load()
         shape = (pdesc.K, pdesc.R, pdesc.S, pdesc.C)
-        if self.w_fprop is None or tuple(self.w_fprop.shape) != shape or self.w_fprop.device != dev:
-            self.w_fprop = torch.empty(shape, dtype=BF16, device=dev)
+        if self.w_fprop is None or tuple(self.w_fprop.shape) != shape or self.w_fprop.device != dev or self.w_fprop.dtype != ACT_DTYPE:
+            self.w_fprop = torch.empty(shape, dtype=ACT_DTYPE, device=dev)
             self.w_dgrad = None
         wd = None
         if need_dgrad:
@@ -275,7 +290,7 @@ class ConvState:
             if n < 0:
                 L.check(int(n), "cvhip_conv2d_dgrad_weight_elems")
             n = max(int(n), 8)
-            wd = self.w_dgrad if (self.w_dgrad is not None and self.w_dgrad.numel() == n) else torch.empty((n,), dtype=BF16, device=dev)
+            wd = self.w_dgrad if (self.w_dgrad is not None and self.w_dgrad.numel() == n) else torch.empty((n,), dtype=ACT_DTYPE, device=dev)
         L.call("cvhip_conv2d_prep_weights", C.byref(pdesc), master.data_ptr(), self.w_fprop.data_ptr(), _ptr(wd), _stream())
         self._master_ref = master  # keep a relayout copy (if any) alive until the kernels have run
         if wd is not None:
@@ -321,7 +336,7 @@ class PrepPlan:
             return
         L.call("cvhip_prep_plan_run", self.table.data_ptr(), self.n, self.blocks, _stream())
         for s in self.states:
-            s.key = (s.rec[2], _weights_epoch, s.rec[1].key())
+            s.key = (s.rec[2], _weights_epoch, s.rec[1].key(), L.PRECISION)
 
 
 def conv_states_of(model):
@@ -404,7 +419,7 @@ class GradLink:
 
 def _check_out(out, N, K, P, Q):
     """`out=` destination of a layer: an NHWC bf16 (channel-slice) view of the right logical shape"""
-    if tuple(out.shape) != (N, K, P, Q) or out.dtype != BF16:
+    if tuple(out.shape) != (N, K, P, Q) or out.dtype != ACT_DTYPE:
         raise L.CvhipError("out= has shape %s / %s, the layer produces %s bf16" % (tuple(out.shape), out.dtype, (N, K, P, Q)))
     ld = nhwc_ld(out)
     if ld is None:
@@ -592,7 +607,7 @@ class ConvBnAct(torch.autograd.Function):
             # the MFMA gather reads 16-byte channel vectors: repack odd channel counts / pitches / slice offsets into a
             # zero-padded [N,H,W,round8(C)] buffer (the packers pad the weight to match: cvhip_conv_desc.c_valid)
             Cp = _round8(Cc)
-            xp = torch.empty((N, H, W, Cp), dtype=BF16, device=dev)
+            xp = torch.empty((N, H, W, Cp), dtype=ACT_DTYPE, device=dev)
             if Cp != Cc:
                 zero_fill(xp)
             L.call("cvhip_copy2d", x.data_ptr(), x_ld, xp.data_ptr(), Cp, N * H * W, Cc, _stream())
@@ -760,7 +775,7 @@ class ConvBnAct(torch.autograd.Function):
             return dx, dw, None, (dgamma if need_dg else None), (dbeta if need_dbeta else None), None, None, dres, None
         if pointwise:
             if Kp != K:  # pad channels must read as zero in dgrad/wgrad
-                dy = zero_fill(torch.empty((N, P, Q, Kp), dtype=BF16, device=dev)).permute(0, 3, 1, 2)[:, :K]
+                dy = zero_fill(torch.empty((N, P, Q, Kp), dtype=ACT_DTYPE, device=dev)).permute(0, 3, 1, 2)[:, :K]
             else:
                 dy = empty_nhwc(N, K, P, Q, dev)
             if ctx.train_bn:
@@ -793,7 +808,7 @@ class ConvBnAct(torch.autograd.Function):
             if dy_ld % 8 != 0 or dy.data_ptr() % 16 != 0 or (Kp != K and dy_ld < Kp):
                 # repack into a 16-byte-vectorisable pitch / base address (a channel slice of a cat gradient can start at any
                 # element) with zeroed pad channels
-                buf = zero_fill(torch.empty((N, P, Q, Kp), dtype=BF16, device=dev))
+                buf = zero_fill(torch.empty((N, P, Q, Kp), dtype=ACT_DTYPE, device=dev))
                 L.call("cvhip_copy2d", dy.data_ptr(), dy_ld, buf.data_ptr(), Kp, M, K, st)
                 dy, dy_ld = buf.permute(0, 3, 1, 2)[:, :K], Kp
         dx, dw, dbias = _conv_grads(ctx, x, weight, dy, dy_ld, need_dx, need_dw, need_db)
@@ -1249,7 +1264,7 @@ class SegCrossEntropy(torch.autograd.Function):
         N, Cc, H, W, ld, ign = ctx.meta
         Cp = _round8(Cc)
         gs = g.detach().float().reshape(1).contiguous()
-        buf = torch.empty((N, H, W, Cp), dtype=BF16, device=logits.device)
+        buf = torch.empty((N, H, W, Cp), dtype=ACT_DTYPE, device=logits.device)
         L.call("cvhip_seg_ce_bwd", logits.data_ptr(), ld, target.data_ptr(), N * H * W, Cc, ign, out2.data_ptr(), gs.data_ptr(),
                buf.data_ptr(), Cp, _stream())
         return buf.permute(0, 3, 1, 2)[:, :Cc], None, None
@@ -1297,7 +1312,7 @@ class GlobalAvgPool(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         N, Cc, H, W = ctx.meta
-        dy = dy.to(BF16).reshape(N, Cc).contiguous()
+        dy = dy.to(ACT_DTYPE).reshape(N, Cc).contiguous()
         dx = empty_nhwc(N, Cc, H, W, dy.device)
         L.call("cvhip_global_avgpool_bwd", dy.data_ptr(), dx.data_ptr(), Cc, N, Cc, H * W, _stream())
         return dx
@@ -1314,10 +1329,10 @@ def images_to_nhwc(x, cpad=8, focus=False):
     x = x.detach().float().contiguous()
     N, Cc, H, W = x.shape
     if focus:
-        y = torch.empty((N, cpad, H // 2, W // 2), dtype=BF16, device=x.device, memory_format=torch.channels_last)
+        y = torch.empty((N, cpad, H // 2, W // 2), dtype=ACT_DTYPE, device=x.device, memory_format=torch.channels_last)
         L.call("cvhip_focus_nchw_f32_to_nhwc_bf16", x.data_ptr(), y.data_ptr(), N, Cc, H, W, cpad, _stream())
     else:
-        y = torch.empty((N, cpad, H, W), dtype=BF16, device=x.device, memory_format=torch.channels_last)
+        y = torch.empty((N, cpad, H, W), dtype=ACT_DTYPE, device=x.device, memory_format=torch.channels_last)
         L.call("cvhip_nchw_f32_to_nhwc_bf16", x.data_ptr(), y.data_ptr(), N, Cc, H, W, cpad, _stream())
     return y
 
@@ -1339,7 +1354,7 @@ class NhwcToNchwF32(torch.autograd.Function):
         N, Cc, H, W = ctx.meta
         dy = dy.float().contiguous()
         Cp = _round8(Cc)
-        buf = torch.empty((N, H, W, Cp), dtype=BF16, device=dy.device)
+        buf = torch.empty((N, H, W, Cp), dtype=ACT_DTYPE, device=dy.device)
         if Cp != Cc:
             zero_fill(buf)
         L.call("cvhip_nchw_f32_to_nhwc_bf16_ld", dy.data_ptr(), buf.data_ptr(), Cp, N, Cc, H, W, _stream())
@@ -1369,7 +1384,7 @@ class HeadPermute(torch.autograd.Function):
         N, A, NO, H, W = ctx.meta
         dy = dy.float().contiguous()
         Cp = _round8(A * NO)
-        buf = torch.empty((N, H, W, Cp), dtype=BF16, device=dy.device)
+        buf = torch.empty((N, H, W, Cp), dtype=ACT_DTYPE, device=dy.device)
         L.call("cvhip_head_permute_bwd", dy.data_ptr(), buf.data_ptr(), Cp, N, A, NO, H, W, _stream())
         return buf.permute(0, 3, 1, 2)[:, :A * NO], None, None
 
@@ -1439,7 +1454,7 @@ class YoloV5LossFused(torch.autograd.Function):
         nc = cfg.num_classes
         for i, r in enumerate(maps):
             d = ctx.descs[i]
-            draw = torch.empty((d.N, d.H, d.W, d.ld), dtype=BF16, device=r.device)
+            draw = torch.empty((d.N, d.H, d.W, d.ld), dtype=ACT_DTYPE, device=r.device)
             L.call("cvhip_yolov5_loss_level_bwd", C.byref(d), r.data_ptr(), tg.data_ptr(), ctx.wss[i].data_ptr(), sums[i].data_ptr(),
                    g.data_ptr(), float(cfg.hyp_box) * ctx.bs, (float(cfg.hyp_cls) * ctx.bs / nc) if nc > 1 else 0.0,
                    float(cfg.hyp_obj) * float(cfg.balance[i]) * ctx.bs / ctx.ncells[i], draw.data_ptr(), st)
@@ -1494,7 +1509,7 @@ class SimotaLossFused(torch.autograd.Function):
         tg, *maps = ctx.saved_tensors
         d = ctx.desc
         g = g5.detach().float()[0:1].contiguous()  # d total / d out5[0]; the other entries are reporting-only
-        draws = [torch.empty((d.B, d.H[i], d.W[i], d.ld[i]), dtype=BF16, device=maps[i].device) for i in range(d.L)]
+        draws = [torch.empty((d.B, d.H[i], d.W[i], d.ld[i]), dtype=ACT_DTYPE, device=maps[i].device) for i in range(d.L)]
         ptrs = (C.c_void_p * d.L)(*[m.data_ptr() for m in maps])
         dptrs = (C.c_void_p * d.L)(*[t.data_ptr() for t in draws])
         L.call("cvhip_simota_loss_bwd", C.byref(d), ptrs, tg.data_ptr(), ctx.ws.data_ptr(), g.data_ptr(), dptrs, _stream())

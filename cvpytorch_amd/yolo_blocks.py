@@ -65,7 +65,7 @@ class Focus(nn.Module):
 
     def forward(self, x):
         c4 = x.shape[1] * 4
-        if x.dtype.is_floating_point and x.dtype != ops.BF16 and not x.requires_grad:
+        if x.dtype.is_floating_point and x.dtype != ops.ACT_DTYPE and not x.requires_grad:
             xs = ops.images_to_nhwc(x, cpad=(c4 + 7) // 8 * 8, focus=True)
             return self.conv(xs)
         tl, tr = x[..., ::2, ::2], x[..., ::2, 1::2]

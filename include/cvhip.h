@@ -21,8 +21,11 @@
  *                 cvhip_conv2d_prep_weights() derives the bf16 operand images.
  *   BN stats    : fp32.
  */
+/* (cvhip_f16.h includes this file a second time with CVHIP_REDECLARE_F16 defined: only the prototypes are seen again then) */
+#if !defined(CVHIP_H_) || defined(CVHIP_REDECLARE_F16)
 #ifndef CVHIP_H_
 #define CVHIP_H_
+#endif
 
 #include <stddef.h>
 #include <stdint.h>
@@ -57,6 +60,7 @@ extern "C" {
  *   src/models/bricks/conv.py:8-46 (build_conv_layer -> nn.Conv2d),
  *   src/models/detects/yolov5_detect.py:25,42, src/models/heads/seg/base_seg_head.py:30.
  * ------------------------------------------------------------------------------------------ */
+#ifndef CVHIP_REDECLARE_F16
 typedef struct cvhip_conv_desc {
   int32_t N, C, H, W;     /* input: batch, channels, height, width                        */
   int32_t K, R, S;        /* output channels, kernel height, kernel width                  */
@@ -72,6 +76,7 @@ typedef struct cvhip_conv_desc {
    * `bias` (k_valid entries); 0 means "same as K / C". Padded rows/columns of the operand images are zero. */
   int32_t k_valid, c_valid;
 } cvhip_conv_desc;
+#endif
 
 int cvhip_version(void);
 /* last HIP runtime error string seen by the library on this thread (never NULL) */
@@ -115,12 +120,14 @@ int cvhip_conv2d_prep_weights(const cvhip_conv_desc* d, const float* w_master_kr
  * trainer.py:179-184). `cvhip_prep_plan_build` fills a host table of `n` x cvhip_prep_plan_item_bytes() bytes from the entries
  * (descriptors + fixed operand addresses; w_dgrad may be NULL) and returns the grid size; the caller copies the table to the
  * device once and calls `cvhip_prep_plan_run` after every optimizer step. */
+#ifndef CVHIP_REDECLARE_F16
 typedef struct cvhip_prep_entry {
   cvhip_conv_desc desc;
   const float* master;
   void* w_fprop;
   void* w_dgrad;
 } cvhip_prep_entry;
+#endif
 int cvhip_prep_plan_item_bytes(void);
 int cvhip_prep_plan_build(const cvhip_prep_entry* entries, int32_t n, void* table_host, int32_t* total_blocks);
 int cvhip_prep_plan_run(const void* table_device, int32_t n, int32_t total_blocks, void* stream);
@@ -378,6 +385,23 @@ int cvhip_sgd_nesterov_ema(float* param, const float* grad, float* momentum_buf,
                            const float* seg_wd, int32_t nseg, float momentum, int32_t nesterov,
                            int32_t first_step, float ema_decay, float grad_scale,
                            const float* dyn_decay_lrscale, void* stream);
+
+/* Dynamic loss scaling for fp16 storage — torch.cuda.amp.GradScaler on device (trainer.py:189-201: scaler.scale(loss).backward(),
+ * scaler.step(optimizer), scaler.update(); defaults init 65536, growth 2, backoff 0.5, interval 2000). No host round trip: the
+ * whole step, scaler included, stays one hipGraph.
+ *   state4  : fp32 {scale, growth_tracker, found_inf, skipped_steps}; the loss gradient is seeded with state4[0]
+ *   check   : found_inf = 1 when any of the n gradient-arena values is inf / NaN (run after the gradient all-reduce)
+ *   update  : scaler2 = {found_inf ? 0 : 1/scale, found_inf}; scale *= backoff on overflow, *= growth after `growth_interval`
+ *             clean steps in a row; found_inf cleared
+ *   cvhip_sgd_nesterov_ema_scaled : the fused optimizer with scaler2: gradients are multiplied by scaler2[0]; when scaler2[1] != 0
+ *             parameters and momentum are left untouched (the step is skipped), the EMA still follows the parameters. */
+int cvhip_loss_scale_check(const float* grad_arena, int64_t n, float* state4, void* stream);
+int cvhip_loss_scale_update(float* state4, float* scaler2, float growth_factor, float backoff_factor, int32_t growth_interval,
+                            void* stream);
+int cvhip_sgd_nesterov_ema_scaled(float* param, const float* grad, float* momentum_buf, float* ema, int64_t n,
+                                  const int64_t* seg_bounds, const float* seg_lr, const float* seg_wd, int32_t nseg,
+                                  float momentum, int32_t nesterov, int32_t first_step, float ema_decay, float grad_scale,
+                                  const float* dyn_decay_lrscale, const float* scaler2, void* stream);
 /* dyn_decay_lrscale: optional DEVICE float[2] = {ema_decay, lr_scale}; when non-NULL it overrides
  * `ema_decay` and multiplies every segment lr, so the values can change between hipGraph replays. */
 /* ema[i] = d*ema[i] + (1-d)*src[i] over a flat fp32 range (buffers: BN running stats);
@@ -397,11 +421,13 @@ int cvhip_ema_update(float* ema, const float* src, int64_t n, float decay, const
  *               k_box = hyp_box*batch, k_cls = hyp_cls*batch/nc, k_obj = hyp_obj*balance_l*batch/(N*A*H*W)
  * `ws` (cvhip_yolov5_loss_workspace_bytes) must stay untouched between level_fwd and level_bwd.
  * ------------------------------------------------------------------------------------------ */
+#ifndef CVHIP_REDECLARE_F16
 typedef struct cvhip_yolo_loss_desc {
   int32_t N, A, NO, H, W, ld, T;
   float anchor_t;       /* hyp anchor_t = 4.0 (yolov5_loss.py:247-248) */
   float anchors[16];    /* A x (w, h) in grid units of this level */
 } cvhip_yolo_loss_desc;
+#endif
 int64_t cvhip_yolov5_loss_workspace_bytes(const cvhip_yolo_loss_desc* d);
 int cvhip_yolov5_loss_level_fwd(const cvhip_yolo_loss_desc* d, const void* raw_bf16, const float* targets, void* ws,
                                 float* sums4, void* stream);
@@ -420,11 +446,13 @@ int cvhip_yolov5_loss_level_bwd(const cvhip_yolo_loss_desc* d, const void* raw_b
  *   loss_fwd : out5 = {loss, conf_loss, cls_loss, 5*iou_loss, num_fg/num_gts}; assignment + intermediates stay in `ws`
  *   loss_bwd : draws[l] (same shape/pitch as raws[l]) = d loss / d raws[l], scaled by the DEVICE scalar gout (NULL = 1)
  * ------------------------------------------------------------------------------------------ */
+#ifndef CVHIP_REDECLARE_F16
 typedef struct cvhip_simota_desc {
   int32_t L, B, A, G, nc;
   int32_t H[4], W[4], ld[4];
   float stride[4];
 } cvhip_simota_desc;
+#endif
 int64_t cvhip_simota_workspace_bytes(const cvhip_simota_desc* d);
 int cvhip_simota_loss_fwd(const cvhip_simota_desc* d, const void* const* raws, const float* targets, void* ws, float* out5,
                           void* stream);

@@ -36,6 +36,24 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert s in syms, "%s bound in lib.py but not declared in include/cvhip.h" % s
 
 
+def test_fp16_abi_is_generated_in_sync_and_exported():
+    """csrc/f16_names.h and include/cvhip_f16.h are what tools/gen_f16_names.py produces from the current sources, and the
+    library exports every renamed entry point (the fp16-storage build of each 16-bit kernel)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_f16_names", os.path.join(ROOT, "tools", "gen_f16_names.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    a, b, names = gen.render()
+    assert open(os.path.join(ROOT, "cvpytorch_amd", "csrc", "f16_names.h")).read() == a
+    assert open(os.path.join(ROOT, "include", "cvhip_f16.h")).read() == b
+    assert len(names) >= 70 and "cvhip_conv2d_fprop" in names and "cvhip_comm_init_rank" not in names
+    raw = C.CDLL(L.LIB_PATH)
+    L.load()
+    for n in names:
+        assert hasattr(raw, n + "_f16"), n
+        assert n in L._F16
+
+
 def desc(N, Cc, H, W, K, R, S, stride=(1, 1), pad=(0, 0), dil=(1, 1), groups=1, x_ld=None, y_ld=None):
     return L.ConvDesc(N, Cc, H, W, K, R, S, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], groups,
                       x_ld or Cc, y_ld or K, 0, 0)
