@@ -67,8 +67,25 @@ def _compile(job):
     return obj, r.stderr
 
 
+def _sync_f16_names():
+    """Regenerate csrc/f16_names.h and include/cvhip_f16.h (tools/gen_f16_names.py) when an entry point was added or removed:
+    the fp16 build renames every typed entry point, a stale list would define the new ones twice."""
+    import importlib.util
+    path = os.path.join(HERE, "..", "tools", "gen_f16_names.py")
+    if not os.path.exists(path):
+        return
+    spec = importlib.util.spec_from_file_location("gen_f16_names", path)
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    a, b, _ = gen.render()
+    for target, text in ((os.path.join(CSRC, "f16_names.h"), a), (os.path.join(HERE, "..", "include", "cvhip_f16.h"), b)):
+        if not os.path.exists(target) or open(target).read() != text:
+            open(target, "w").write(text)
+
+
 def build_lib(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
+    _sync_f16_names()
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     jobs = [(s, False) for s in srcs] + [(s, True) for s in srcs if s not in SINGLE_PRECISION]
     if force:

@@ -280,6 +280,71 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const BilParams p) {
   }
 }
 
+// ---- nearest-neighbour resize to an arbitrary size (F.interpolate(mode="nearest"): STDC neck stdcnet.py / ffm paths) -----------
+// torch's rule: src = min(floor(dst * scale), in - 1), scale = (float)in / out. Forward is an exact copy; backward is a
+// deterministic gather: every INPUT pixel sums the (contiguous) run of output pixels that map to it.
+__device__ __forceinline__ int nn_src(int dst, float scale, int in) {
+  const int s = (int)floorf((float)dst * scale);
+  return s < in - 1 ? s : in - 1;
+}
+
+__global__ __launch_bounds__(256) void nearest_fwd_kernel(const BilParams p) {
+  const int CV = (p.C + 7) >> 3;
+  const bool vec = (p.ld_src & 7) == 0 && (p.ld_dst & 7) == 0 && p.ld_src >= ((p.C + 7) & ~7) && p.ld_dst >= ((p.C + 7) & ~7) &&
+                   aligned16(p.src) && aligned16(p.dst);
+  const int64_t total = (int64_t)p.N * p.Ho * p.Wo * CV;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    int64_t pix = i / CV;
+    const int ow = (int)(pix % p.Wo);
+    pix /= p.Wo;
+    const int oh = (int)(pix % p.Ho);
+    const int n = (int)(pix / p.Ho);
+    const int ih = nn_src(oh, p.sh, p.Hi), iw = nn_src(ow, p.sw, p.Wi);
+    const f32x8 v = load8(p.src + ((int64_t)(n * p.Hi + ih) * p.Wi + iw) * p.ld_src, cv * 8, p.C, vec);
+    store8(p.dst + ((int64_t)(n * p.Ho + oh) * p.Wo + ow) * p.ld_dst, cv * 8, p.C, vec, v);
+  }
+}
+
+// [lo, hi) = outputs o with nn_src(o) == i (monotone in o): start below the analytic position, walk to the exact ends
+__device__ __forceinline__ void nn_range(int i, float scale, int in, int out, int* lo, int* hi) {
+  int o = (int)floorf((float)i / scale) - 2;
+  if (o < 0) o = 0;
+  while (o < out && nn_src(o, scale, in) < i) ++o;
+  *lo = o;
+  while (o < out && nn_src(o, scale, in) == i) ++o;
+  *hi = o;
+}
+
+// here src = the gradient at the OUTPUT (Ho x Wo), dst = the gradient at the input (Hi x Wi)
+__global__ __launch_bounds__(256) void nearest_bwd_kernel(const BilParams p) {
+  const int CV = (p.C + 7) >> 3;
+  const bool vec = (p.ld_src & 7) == 0 && (p.ld_dst & 7) == 0 && p.ld_src >= ((p.C + 7) & ~7) && p.ld_dst >= ((p.C + 7) & ~7) &&
+                   aligned16(p.src) && aligned16(p.dst);
+  const int64_t total = (int64_t)p.N * p.Hi * p.Wi * CV;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    int64_t pix = i / CV;
+    const int iw = (int)(pix % p.Wi);
+    pix /= p.Wi;
+    const int ih = (int)(pix % p.Hi);
+    const int n = (int)(pix / p.Hi);
+    int h0, h1, w0, w1;
+    nn_range(ih, p.sh, p.Hi, p.Ho, &h0, &h1);
+    nn_range(iw, p.sw, p.Wi, p.Wo, &w0, &w1);
+    f32x8 acc;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc.v[j] = 0.f;
+    for (int oh = h0; oh < h1; ++oh)
+      for (int ow = w0; ow < w1; ++ow) {
+        const f32x8 v = load8(p.src + ((int64_t)(n * p.Ho + oh) * p.Wo + ow) * p.ld_src, cv * 8, p.C, vec);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc.v[j] += v.v[j];
+      }
+    store8(p.dst + ((int64_t)(n * p.Hi + ih) * p.Wi + iw) * p.ld_dst, cv * 8, p.C, vec, acc);
+  }
+}
+
 // backward as a deterministic gather: each INPUT pixel scans the (small) range of output pixels that
 // can reference it and re-derives their interpolation weights.
 __device__ __forceinline__ void bil_range(int i, float scale, int align, int out, int* lo, int* hi) {
@@ -640,6 +705,48 @@ static void bil_scales(int Hi, int Wi, int Ho, int Wo, int align, float* sh, flo
     *sh = (float)Hi / (float)Ho;
     *sw = (float)Wi / (float)Wo;
   }
+}
+
+int cvhip_resize_nearest_fwd(const void* x, int32_t ld_x, void* y, int32_t ld_y, int32_t N, int32_t C, int32_t Hi, int32_t Wi,
+                             int32_t Ho, int32_t Wo, void* stream) {
+  if (!x || !y || N <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return CVHIP_ERR_INVALID;
+  BilParams p{};
+  p.src = (const h16_t*)x;
+  p.dst = (h16_t*)y;
+  p.ld_src = ld_x;
+  p.ld_dst = ld_y;
+  p.N = N;
+  p.C = C;
+  p.Hi = Hi;
+  p.Wi = Wi;
+  p.Ho = Ho;
+  p.Wo = Wo;
+  p.sh = (float)Hi / (float)Ho;
+  p.sw = (float)Wi / (float)Wo;
+  const int64_t total = (int64_t)N * Ho * Wo * ((C + 7) / 8);
+  hipLaunchKernelGGL(nearest_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("nearest_fwd_kernel");
+}
+
+int cvhip_resize_nearest_bwd(const void* dy, int32_t ld_dy, void* dx, int32_t ld_dx, int32_t N, int32_t C, int32_t Hi, int32_t Wi,
+                             int32_t Ho, int32_t Wo, void* stream) {
+  if (!dy || !dx || N <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return CVHIP_ERR_INVALID;
+  BilParams p{};
+  p.src = (const h16_t*)dy;
+  p.dst = (h16_t*)dx;
+  p.ld_src = ld_dy;
+  p.ld_dst = ld_dx;
+  p.N = N;
+  p.C = C;
+  p.Hi = Hi;
+  p.Wi = Wi;
+  p.Ho = Ho;
+  p.Wo = Wo;
+  p.sh = (float)Hi / (float)Ho;
+  p.sw = (float)Wi / (float)Wo;
+  const int64_t total = (int64_t)N * Hi * Wi * ((C + 7) / 8);
+  hipLaunchKernelGGL(nearest_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("nearest_bwd_kernel");
 }
 
 int cvhip_resize_bilinear_fwd(const void* x, int32_t ld_x, void* y, int32_t ld_y, int32_t N, int32_t C, int32_t Hi,

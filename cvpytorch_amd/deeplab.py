@@ -28,12 +28,15 @@ _FUSE_TAIL = __import__("os").environ.get("CVHIP_FUSE_TAIL", "1") != "0"
 def _cba(x, conv, bn, act, residual=None, dx_link=None, res_pre=False, res_link=None):
     """conv -> bn -> act as ONE fused op (conv and bn are sibling modules, torchvision style); `res_pre`: the residual joins
     before the activation (bottleneck tail)."""
-    cfg = conv.make_cfg(act, 0.0, bn)
+    folded = not isinstance(bn, nn.BatchNorm2d)   # deploy.fuse_model folded the BN into conv.weight / conv.bias (nn.Identity left)
+    cfg = conv.make_cfg(act, 0.0, None if folded else bn)
     cfg.dx_link = dx_link
     cfg.res_pre = res_pre
     cfg.res_link = res_link if residual is not None else None
-    bn_tick(bn)
     xx, w = conv._effective(x)
+    if folded:
+        return ops.conv_bn_act(xx, w, conv.bias, None, None, None, None, residual, cfg)
+    bn_tick(bn)
     return ops.conv_bn_act(xx, w, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, cfg)
 
 

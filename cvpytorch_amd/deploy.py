@@ -49,6 +49,9 @@ def fuse_model(model):
             m[1] = nn.Identity()
             m.forward = _fused_seq_forward.__get__(m)
         elif isinstance(m, nn.Sequential) and not isinstance(m, HipConvBN):
+            # (conv, bn) neighbours of a Sequential: the BN slot becomes nn.Identity so that index-based forwards keep their
+            # positions (deeplab.ResNet.stem / Bottleneck.downsample, stdc._DwPwSkip read [i], [i+1] and run the folded pair as
+            # conv + bias when they find the Identity)
             i = 0
             while i + 1 < len(m):
                 if isinstance(m[i], nn.Conv2d) and _is_bn(m[i + 1]):
@@ -57,6 +60,14 @@ def fuse_model(model):
                     i += 2
                 else:
                     i += 1
+        else:
+            # torchvision-style sibling attributes convN / bnN (ResNet Bottleneck: conv1/bn1 .. conv3/bn3)
+            for name, child in list(m._modules.items()):
+                if name.startswith("conv") and name[4:].isdigit() and isinstance(child, nn.Conv2d):
+                    bn = m._modules.get("bn" + name[4:])
+                    if _is_bn(bn):
+                        setattr(m, name, fuse_conv_and_bn(child, bn))
+                        setattr(m, "bn" + name[4:], nn.Identity())
     return model
 
 

@@ -1299,6 +1299,34 @@ def resize_bilinear(x, size, align_corners=False):
     return ResizeBilinear.apply(x, int(size[0]), int(size[1]), bool(align_corners))
 
 
+class ResizeNearest(torch.autograd.Function):
+    """F.interpolate(x, size, mode="nearest") for arbitrary sizes (cvhip_resize_nearest_fwd / _bwd: exact copy forward,
+    deterministic gather-sum backward)."""
+
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        x, ld = as_nhwc(x)
+        N, Cc, Hi, Wi = x.shape
+        yld = _round8(Cc)
+        y = empty_nhwc(N, Cc, Ho, Wo, x.device, ld=yld)
+        L.call("cvhip_resize_nearest_fwd", x.data_ptr(), ld, y.data_ptr(), yld, N, Cc, Hi, Wi, Ho, Wo, _stream())
+        ctx.meta = (N, Cc, Hi, Wi, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, Cc, Hi, Wi, Ho, Wo = ctx.meta
+        dy, ld = as_nhwc(dy)
+        xld = _round8(Cc)
+        dx = empty_nhwc(N, Cc, Hi, Wi, dy.device, ld=xld)
+        L.call("cvhip_resize_nearest_bwd", dy.data_ptr(), ld, dx.data_ptr(), xld, N, Cc, Hi, Wi, Ho, Wo, _stream())
+        return dx, None, None
+
+
+def resize_nearest(x, size):
+    return ResizeNearest.apply(x, int(size[0]), int(size[1]))
+
+
 class GlobalAvgPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

@@ -52,8 +52,11 @@ class _DwPwSkip(nn.Sequential):
 
     def forward(self, x):
         for conv, bn in ((self[0], self[1]), (self[2], self[3])):
-            bn_tick(bn)
             xx, w = conv._effective(x)
+            if not isinstance(bn, nn.BatchNorm2d):   # deploy.fuse_model folded the BN into the conv (bias) and left nn.Identity
+                x = ops.conv_bn_act(xx, w, conv.bias, None, None, None, None, None, conv.make_cfg(L.ACT_NONE, 0.0, None))
+                continue
+            bn_tick(bn)
             x = ops.conv_bn_act(xx, w, None, bn.weight, bn.bias, bn.running_mean, bn.running_var, None, conv.make_cfg(L.ACT_NONE, 0.0, bn))
         return x
 
@@ -173,7 +176,8 @@ class FeatureFusionModule(nn.Module):
 
 
 def _nearest_to(x, size):
-    """F.interpolate(x, size, mode='nearest') for the two cases the neck produces: 1x1 -> HxW broadcast and exact x2."""
+    """F.interpolate(x, size, mode='nearest'): 1x1 -> HxW broadcast and exact x2 take their dedicated paths, every other size the
+    general nearest-resize kernel (ops.resize_nearest) — nothing leaves the engine."""
     h, w = int(size[0]), int(size[1])
     if x.shape[2] == h and x.shape[3] == w:
         return x
@@ -181,7 +185,7 @@ def _nearest_to(x, size):
         return ops.upsample2x_cat(x, None)
     if x.shape[2] == 1 and x.shape[3] == 1:
         return x.expand(x.shape[0], x.shape[1], h, w)
-    return F.interpolate(x, (h, w), mode="nearest")
+    return ops.resize_nearest(x, (h, w))
 
 
 class STDCNeck(nn.Module):

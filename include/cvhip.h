@@ -311,6 +311,14 @@ int cvhip_seg_ce_bwd(const void* logits_bf16, int32_t ld, const int64_t* target,
                      int32_t C, int32_t ignore_index, const float* out2, const float* grad_scale,
                      void* dlogits_bf16, int32_t ld_d, void* stream);
 
+/* nearest-neighbour resize to an arbitrary size: F.interpolate(x, size, mode="nearest") of the STDC neck (src/models/necks/seg:
+ * stdc neck `F.interpolate(..., mode='nearest')` calls; torch's index rule src = min(floor(dst * in/out), in-1)). Forward is an
+ * exact copy (bit-exact); backward a deterministic gather-sum over the output pixels of each input pixel. */
+int cvhip_resize_nearest_fwd(const void* x, int32_t ld_x, void* y, int32_t ld_y, int32_t N, int32_t C, int32_t Hi, int32_t Wi,
+                             int32_t Ho, int32_t Wo, void* stream);
+int cvhip_resize_nearest_bwd(const void* dy, int32_t ld_dy, void* dx, int32_t ld_dx, int32_t N, int32_t C, int32_t Hi, int32_t Wi,
+                             int32_t Ho, int32_t Wo, void* stream);
+
 /* bilinear resize, align_corners = 0/1 (F.interpolate).
  * src/models/heads/seg/deeplabv3plus_head.py:56-66, segmentors/encoder_decoder.py:99 */
 int cvhip_resize_bilinear_fwd(const void* x_bf16, int32_t ld_x, void* y_bf16, int32_t ld_y,

@@ -82,3 +82,58 @@ def test_reparam_repconv_eval_forward_matches():
         got = [o.float() for o in head(xs)]
     for a, b in zip(got, ref):
         assert rel_l2(a, b) < 2e-2, rel_l2(a, b)
+
+
+def _randomise_bn(model, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    for mm in model.modules():
+        if isinstance(mm, torch.nn.BatchNorm2d):
+            mm.running_mean.copy_(torch.randn(mm.num_features, generator=g).to(dev()) * 0.2)
+            mm.running_var.copy_((torch.rand(mm.num_features, generator=g) + 0.5).to(dev()))
+            mm.weight.data.copy_((torch.rand(mm.num_features, generator=g) + 0.5).to(dev()))
+            mm.bias.data.copy_(torch.randn(mm.num_features, generator=g).to(dev()) * 0.2)
+
+
+def test_fuse_model_on_index_based_forwards_deeplab_and_stdc():
+    """models whose forward indexes (conv, bn) children directly (deeplab.ResNet stem / Bottleneck downsample and
+    sibling convN/bnN, stdc._DwPwSkip) must still run after fuse_model and give the un-fused eval result; every BN is folded."""
+    from cvpytorch_amd import deeplab, stdc
+    torch.manual_seed(0)
+    for build, shape in ((lambda: deeplab.EncoderDecoder(19, output_stride=32), (2, 3, 64, 96)),
+                         (lambda: stdc.STDCNet("stdc1"), (2, 3, 64, 64))):
+        m = build().to(dev())
+        _randomise_bn(m)
+        m.eval()
+        x = torch.randn(*shape).to(dev())
+        with torch.no_grad():
+            ref = m.backbone(x) if hasattr(m, "backbone") else m(x)
+            if hasattr(m, "backbone"):
+                ref = m.head(ref)
+        deploy.fuse_model(m)
+        assert not any(isinstance(mm, torch.nn.BatchNorm2d) for mm in m.modules()), "a BatchNorm survived the folding"
+        with torch.no_grad():
+            out = m.head(m.backbone(x)) if hasattr(m, "backbone") else m(x)
+        ref = ref if isinstance(ref, (list, tuple)) else [ref]
+        out = out if isinstance(out, (list, tuple)) else [out]
+        assert len(ref) == len(out)
+        for a, b in zip(out, ref):
+            assert rel_l2(a.float(), b.float()) < 3e-2, rel_l2(a.float(), b.float())
+
+
+@pytest.mark.parametrize("Cc,Hi,Wi,Ho,Wo", [(32, 8, 16, 20, 33), (19, 7, 5, 7, 5), (64, 16, 16, 8, 8), (40, 1, 1, 9, 11), (24, 9, 12, 27, 24)])
+def test_nearest_resize_matches_torch_exactly(Cc, Hi, Wi, Ho, Wo):
+    """cvhip_resize_nearest_fwd / _bwd vs F.interpolate(mode='nearest'): forward is a copy -> bit-exact; backward sums gradient
+    runs in fp32 and rounds once."""
+    from cvpytorch_amd import ops
+    torch.manual_seed(Ho)
+    x = torch.randn(3, Cc, Hi, Wi).to(torch.bfloat16)
+    xd = x.to(dev()).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = ops.resize_nearest(xd, (Ho, Wo))
+    xr = x.float().requires_grad_(True)
+    yr = torch.nn.functional.interpolate(xr, (Ho, Wo), mode="nearest")
+    assert torch.equal(y.detach().float().cpu(), yr.detach())
+    g = torch.randn(3, Cc, Ho, Wo).to(torch.bfloat16)
+    y.backward(g.to(dev()).contiguous(memory_format=torch.channels_last))
+    yr.backward(g.float())
+    torch.cuda.synchronize()
+    assert rel_l2(xd.grad.float().cpu(), xr.grad) < 4e-3
