@@ -124,6 +124,10 @@ SIGNATURES = {
     "cvhip_yolov5_decode": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _f32, _p, _i64, _i64, _p]),
     "cvhip_nms_workspace_bytes": (_i64, [_i32]),
     "cvhip_nms_sorted": (_i32, [_p, _i32, _f32, _p, _p, _p, _p]),
+    "cvhip_detect_postprocess_workspace_bytes": (_i64, [_i32, _i32, _i32]),
+    "cvhip_detect_postprocess": (_i32, [_p, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
+    "cvhip_sort_workspace_bytes": (_i64, [_i64]),
+    "cvhip_argsort_desc_f32": (_i32, [_p, _i64, _p, _p, _p]),
     "cvhip_box_iou": (_i32, [_p, _i32, _p, _i32, _p, _p]),
     "cvhip_sgd_nesterov_ema": (_i32, [_p, _p, _p, _p, _i64, _p, _p, _p, _i32, _f32, _i32, _i32, _f32, _f32, _p, _p]),
     "cvhip_sgd_nesterov_ema_scaled": (_i32, [_p, _p, _p, _p, _i64, _p, _p, _p, _i32, _f32, _i32, _i32, _f32, _f32, _p, _p, _p]),

@@ -340,7 +340,12 @@ def xywh2xyxy(x):
 
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300,
                         nms_fn=None):
-    """src/models/yolov5.py:62-153 with torchvision.ops.nms replaced by the ballot/scan HIP kernels (ops.nms)."""
+    """src/models/yolov5.py:62-153. Device tensors take the batched path (nms.non_max_suppression: every image in ONE launch set —
+    filter, device sort, class offsets, ballot/scan NMS, fixed-capacity outputs); the per-image loop below remains for the
+    `classes=` filter, a custom `nms_fn`, and more candidates per image than the batched kernels' capacity allows."""
+    if prediction.is_cuda and classes is None and nms_fn is None:
+        from . import nms as NMS
+        return NMS.non_max_suppression(prediction, conf_thres, iou_thres, None, agnostic, multi_label, max_det)
     nms_fn = nms_fn or ops.nms
     nc = prediction.shape[2] - 5
     xc = prediction[..., 4] > conf_thres

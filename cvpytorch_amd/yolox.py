@@ -362,16 +362,7 @@ def decode_and_nms(feats, hw, strides, num_classes, conf_thre, nms_thre):
     xy = (out[..., 0:2] + grid) * ss
     wh = torch.exp(out[..., 2:4]) * ss
     sc = torch.sigmoid(out[..., 4:5 + num_classes])
-    res = []
-    for i in range(out.shape[0]):
-        box = torch.cat([xy[i] - wh[i] / 2, xy[i] + wh[i] / 2], 1)
-        conf, pred = torch.max(sc[i, :, 1:], 1, keepdim=True)
-        keep = sc[i, :, 0] * conf.squeeze(1) >= conf_thre
-        det = torch.cat((box, sc[i, :, 0:1], conf, pred.float()), 1)[keep]
-        if not det.size(0):
-            res.append(None)
-            continue
-        offs = det[:, 6:7] * (det[:, :4].max() + 1)
-        idx = ops.nms(det[:, :4] + offs, det[:, 4] * det[:, 5], nms_thre)
-        res.append(det[idx])
-    return res
+    # every image at once on the device (nms.yolox_post_process -> cvhip_detect_postprocess mode 1): confidence filter, device
+    # sort, class offsets of (max coordinate + 1), greedy NMS
+    from . import nms as NMS
+    return NMS.yolox_post_process(torch.cat((xy, wh, sc), -1), num_classes, conf_thre, nms_thre)

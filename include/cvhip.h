@@ -378,6 +378,31 @@ int64_t cvhip_nms_workspace_bytes(int32_t n);
 int cvhip_nms_sorted(const float* boxes_xyxy, int32_t n, float iou_thr, void* workspace,
                      int32_t* keep_idx, int32_t* keep_count, void* stream);
 
+/* Batched detection post-processing (post_batch.hip): confidence filter -> top-`cap` selection by score (descending, ties by
+ * ascending row = a stable sort) -> class-offset boxes -> greedy NMS -> fixed-capacity outputs, for ALL images of a batch in one
+ * launch set with no host round trip. Replaces the per-image python loops (boolean-mask indexing, torch.sort, torchvision.ops.nms)
+ * of src/models/yolov5.py:62-153 non_max_suppression (mode 0: best-class path, class offset `class_offset` = max_wh 4096, or 0
+ * for agnostic) and src/models/yolox.py:48-68 yolox_post_process (mode 1: torchvision.ops.batched_nms, offset = idx * (max box
+ * coordinate of the image + 1)).
+ *   pred     : fp32 [B][n][no] decoded rows {cx, cy, w, h, obj, cls[nc], ...}
+ *   multi_label (mode 0): every (row, class) with obj*cls > conf_thres is a detection of its own (yolov5.py:106-108, the val
+ *              path); `cand_cap` = per-image size of the candidate buffer in the workspace (>= n; n*nc bounds the multi_label case —
+ *              candidates beyond it are dropped and flagged in `overflow`)
+ *   dets     : fp32 [B][max_det][6] {x1,y1,x2,y2,conf,cls} (mode 0) / [B][max_det][7] {x1,y1,x2,y2,obj,class_conf,cls} (mode 1);
+ *              rows >= counts[b] are zero
+ *   overflow : 1 when an image had more than `cap` candidates (the `cap` best were kept: the reference's rule with
+ *              max_nms := cap; the reference's own max_nms is 30000). cap: a power of two in [64, 8192].
+ * Arithmetic (xywh->xyxy, offsets, IoU predicate) is the reference's fp32 arithmetic: results are bit-exact. */
+int64_t cvhip_detect_postprocess_workspace_bytes(int32_t B, int32_t cand_cap, int32_t cap);
+int cvhip_detect_postprocess(const float* pred, int32_t B, int32_t n, int32_t no, int32_t nc, float conf_thres, float iou_thres,
+                             float class_offset, int32_t mode, int32_t multi_label, int32_t cand_cap, int32_t cap, int32_t max_det,
+                             void* workspace, float* dets, int32_t* counts, int32_t* overflow, void* stream);
+/* device argsort, descending by score, ties by ascending index (stable): order[i] = index of the i-th best. Any n <= 2^29
+ * (LDS bitonic blocks + global merge steps). The sort behind batched_nms / multiclass_nms (src/models/modules/nms.py:5-132)
+ * instead of torch.sort. workspace: cvhip_sort_workspace_bytes(n). */
+int64_t cvhip_sort_workspace_bytes(int64_t n);
+int cvhip_argsort_desc_f32(const float* scores, int64_t n, void* workspace, int64_t* order, void* stream);
+
 /* pairwise IoU matrix (N x M) fp32 — models/yolov5.py:27-49 box_iou, losses/det/yolox_loss.py:14-31 */
 int cvhip_box_iou(const float* a_xyxy, int32_t n, const float* b_xyxy, int32_t m, float* out,
                   void* stream);

@@ -1,0 +1,150 @@
+"""Batched on-device post-processing (csrc/post_batch.hip, cvpytorch_amd/nms.py) against the oracle's per-image restatement of the
+reference loops, and the NMS kernels against the hand-derived torchvision known-answer vectors. Boxes, scores, classes and
+their order are BIT-EXACT (integer / index work and fp32 arithmetic replayed in the reference's order)."""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cvpytorch_amd import nms as NMS
+from cvpytorch_amd import ops
+from oracle import torch_ref as R
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def test_nms_kernels_against_hand_derived_known_answers(golden_dir):
+    kat = json.load(open(os.path.join(golden_dir, "nms_kat.json")))
+    for c in kat["cases"]:
+        boxes = torch.tensor(c["boxes"], dtype=torch.float32).reshape(-1, 4).to(dev())
+        scores = torch.tensor(c["scores"], dtype=torch.float32).to(dev())
+        for fn in (ops.nms, NMS.nms):
+            got = fn(boxes, scores, c["iou_threshold"]).tolist()
+            assert got == c["keep"] or got in c["keep_alternatives"], (c["name"], fn.__module__, got, c["keep"])
+
+
+def _synthetic_pred(B, n, nc, seed, hot=0.06, clusters=40):
+    """decoded YOLOv5-style rows: boxes clustered around `clusters` centres (so NMS has work), obj mostly low with `hot` share high."""
+    g = torch.Generator().manual_seed(seed)
+    ctr = torch.rand(B, clusters, 2, generator=g) * 600 + 20
+    which = torch.randint(0, clusters, (B, n), generator=g)
+    cxy = torch.gather(ctr, 1, which[..., None].expand(B, n, 2)) + torch.randn(B, n, 2, generator=g) * 6
+    wh = torch.rand(B, n, 2, generator=g) * 80 + 10
+    obj = torch.rand(B, n, 1, generator=g) * 0.2
+    hotm = torch.rand(B, n, 1, generator=g) < hot
+    obj = torch.where(hotm, 0.3 + 0.7 * torch.rand(B, n, 1, generator=g), obj)
+    cls = torch.rand(B, n, nc, generator=g) ** 3
+    # ties on purpose: quantise part of the scores so equal confidences occur
+    obj[:, ::7] = (obj[:, ::7] * 16).round() / 16
+    return torch.cat([cxy, wh, obj, cls], -1)
+
+
+@pytest.mark.parametrize("multi_label,agnostic", [(False, False), (True, False), (False, True)])
+def test_batched_nms_equals_reference_loop(multi_label, agnostic):
+    B, n, nc = 5, 3000, 12
+    pred = _synthetic_pred(B, n, nc, seed=3 + int(multi_label))
+    pred[2, :, 4] = 0.0                                   # an image without any candidate
+    ref = R.non_max_suppression(pred.clone(), 0.25, 0.45, None, agnostic, multi_label, 300)
+    dets, counts, overflow = NMS.detect_postprocess(pred.to(dev()), 0.25, 0.45, 0, multi_label, agnostic, 300, cap=4096)
+    torch.cuda.synchronize()
+    assert overflow.tolist() == [0] * B
+    assert counts.tolist() == [r.shape[0] for r in ref]
+    assert counts[2].item() == 0
+    for b in range(B):
+        k = ref[b].shape[0]
+        assert torch.equal(dets[b, :k].cpu(), ref[b]), b            # boxes, confidences, classes, order: bit-exact
+        assert float(dets[b, k:].abs().max()) == 0.0 if k < 300 else True
+    # the reference-shaped adapter and the model-level entry point route here
+    from cvpytorch_amd import yolov5
+    lst = yolov5.non_max_suppression(pred.to(dev()), 0.25, 0.45, agnostic=agnostic, multi_label=multi_label)
+    for a, r in zip(lst, ref):
+        assert torch.equal(a.cpu(), r)
+
+
+def test_batched_nms_capacity_is_the_references_max_nms():
+    """More candidates than `cap`: the `cap` best by score go to NMS (the reference's own rule with max_nms := cap) and the image is
+    flagged; max_det truncation as in the reference."""
+    B, n, nc = 2, 4000, 4
+    pred = _synthetic_pred(B, n, nc, seed=9, hot=0.5, clusters=400)
+    dets, counts, overflow = NMS.detect_postprocess(pred.to(dev()), 0.25, 0.6, 0, False, False, 50, cap=256)
+    torch.cuda.synchronize()
+    assert overflow.tolist() == [1, 1]
+    for b in range(B):
+        x = pred[b].clone()
+        x = x[x[:, 4] > 0.25]
+        x[:, 5:] *= x[:, 4:5]
+        conf, j = x[:, 5:].max(1, keepdim=True)
+        box = R.xywh2xyxy(x[:, :4])
+        x = torch.cat((box, conf, j.float()), 1)[conf.view(-1) > 0.25]
+        assert x.shape[0] > 256
+        x = x[torch.sort(x[:, 4], descending=True, stable=True)[1][:256]]
+        i = R.nms(x[:, :4] + x[:, 5:6] * 4096, x[:, 4], 0.6)[:50]
+        assert counts[b].item() == i.shape[0]
+        assert torch.equal(dets[b, :i.shape[0]].cpu(), x[i])
+
+
+def test_yolox_post_process_equals_reference_loop():
+    from oracle import yolox_ref as RX
+    B, nc = 3, 6
+    g = torch.Generator().manual_seed(5)
+    hw, strides = [(16, 16), (8, 8), (4, 4)], (8, 16, 32)
+    feats = [torch.randn(B, 5 + nc, h, w, generator=g) for h, w in hw]
+    for f in feats:
+        f[:, 4] += 0.5
+    feats[0][1, 4] = -20.0
+    feats[1][1, 4] = -20.0
+    feats[2][1, 4] = -20.0                                 # image 1: nothing passes -> None
+    ref = RX.yolox_post_process([f.clone() for f in feats], strides, nc, 0.3, 0.5)
+    from cvpytorch_amd import yolox
+    got = yolox.decode_and_nms([f.flatten(2).permute(0, 2, 1).contiguous().to(dev()) for f in feats], hw, strides, nc, 0.3, 0.5)
+    assert len(got) == B and got[1] is None and ref[1] is None
+    for a, r in zip(got, ref):
+        if r is None:
+            assert a is None
+            continue
+        assert a.shape == r.shape
+        # rows and order are decided by integer / comparison work on fp32 values computed by the same formulas: identical
+        assert torch.allclose(a.cpu(), r, rtol=1e-5, atol=1e-5)
+        assert torch.equal(a[:, 6].cpu(), r[:, 6])
+
+
+@pytest.mark.parametrize("n", [1, 2, 100, 4096, 5000, 70000])
+def test_device_argsort_is_a_stable_descending_sort(n):
+    g = torch.Generator().manual_seed(n)
+    s = (torch.rand(n, generator=g) * 50).round() / 50      # many ties
+    s[::11] = -s[::11]                                      # negative values too
+    ref = torch.sort(s, descending=True, stable=True)[1]
+    got = NMS.argsort_desc(s.to(dev())).cpu()
+    assert torch.equal(got, ref)
+
+
+def test_batched_nms_and_multiclass_nms_mirror_the_reference_module():
+    """src/models/modules/nms.py semantics, restated inline with the oracle's nms (torchvision is absent)."""
+    g = torch.Generator().manual_seed(0)
+    n, ncls = 600, 5
+    ctr = torch.rand(n, 2, generator=g) * 200
+    wh = torch.rand(n, 2, generator=g) * 40 + 5
+    boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], 1)
+    scores = torch.rand(n, generator=g)
+    idxs = torch.randint(0, ncls, (n,), generator=g)
+    # reference batched_nms (class offsets), both branches (n < split_thr and per-class split)
+    offs = idxs.to(boxes) * (boxes.max() + 1)
+    keep_ref = R.nms(boxes + offs[:, None], scores, 0.5)
+    for split in (10000, 100):
+        dets, keep = NMS.batched_nms(boxes.to(dev()), scores.to(dev()), idxs.to(dev()), dict(type="nms", iou_threshold=0.5, split_thr=split))
+        assert torch.equal(keep.cpu(), keep_ref), split
+        assert torch.equal(dets.cpu(), torch.cat([boxes[keep_ref], scores[keep_ref][:, None]], 1))
+    ms = torch.rand(n, ncls + 1, generator=g)
+    valid = ms[:, :-1] > 0.6
+    bb = boxes[:, None].expand(n, ncls, 4)[valid]
+    sc = ms[:, :-1][valid]
+    lab = valid.nonzero()[:, 1]
+    kr = R.nms(bb + (lab.to(bb) * (bb.max() + 1))[:, None], sc, 0.45)[:50]
+    dets, labels = NMS.multiclass_nms(boxes.to(dev()), ms.to(dev()), 0.6, dict(type="nms", iou_threshold=0.45), max_num=50)
+    assert torch.equal(labels.cpu(), lab[kr])
+    assert torch.equal(dets.cpu(), torch.cat([bb[kr], sc[kr][:, None]], 1))
