@@ -2,7 +2,8 @@
 // single-wave scan) and pairwise IoU.
 //
 // Reference: src/models/detects/yolov5_detect.py:48-55 (decode), src/models/yolov5.py:62-153
-// (non_max_suppression -> torchvision.ops.nms, third-party, semantics restated in oracle/nms.py),
+// (non_max_suppression -> torchvision.ops.nms, third-party; semantics restated in oracle/torch_ref.py `nms`, pinned by the
+// hand-derived known-answer vectors tests/golden/nms_kat.json),
 // src/models/yolov5.py:27-49 (box_iou).
 //
 // Bit-exactness: the IoU predicate must round exactly like the fp32 CPU arithmetic

@@ -22,7 +22,7 @@ import torch.nn.functional as F
 from . import ops
 from .bricks import HipConv2d
 from .bricks import HipConvModule as ConvModule
-from .yolo_blocks import CSPLayer, Focus, SPPF
+from .yolo_blocks import CSPLayer, DepthwiseSeparableConvModule, Focus, SPPF
 from .yolov5 import SCALES
 
 BN = dict(type="BN", momentum=0.03, eps=0.001)
@@ -65,6 +65,52 @@ class YOLOXCSPDarknet(nn.Module):
             if i in self.out_stages:
                 out.append(x)
         return out if len(self.out_stages) > 1 else out[0]
+
+
+class CSPDarknet(nn.Module):
+    """The generic CSPDarknet backbone of src/models/backbones/det/csp_darknet.py:25-103 (YOLOv4 / YOLOX / AIRDet family) on the HIP
+    engine: same constructor arguments, sub-module names (stem, stage1..stage4), `out_channels` attribute and state_dict keys, so
+    reference checkpoints load. `depthwise=True` swaps the stride-2 stage convs and the bottlenecks' 3x3 for
+    DepthwiseSeparableConvModule (dwconv.hip kernels)."""
+    cfg = {"n": [0.33, 0.25], "t": [0.33, 0.375], "s": [0.33, 0.5], "m": [0.67, 0.75], "l": [1.0, 1.0], "x": [1.33, 1.25]}
+
+    def __init__(self, subtype="cspdark_s", out_channels=(64, 128, 256, 512, 1024), layers=(3, 9, 9, 3), spp_ksizes=(5, 9, 13),
+                 depthwise=False, conv_cfg=None, norm_cfg=dict(type="BN", momentum=0.03, eps=0.001), act_cfg=dict(type="Swish"),
+                 out_stages=(2, 3, 4), output_stride=32, backbone_path=None, pretrained=False, frozen_stages=-1, norm_eval=False):
+        super().__init__()
+        self.subtype, self.out_stages, self.output_stride = subtype, list(out_stages), output_stride
+        self.backbone_path, self.pretrained, self.frozen_stages, self.norm_eval = backbone_path, pretrained, frozen_stages, norm_eval
+        conv = DepthwiseSeparableConvModule if depthwise else ConvModule
+        depth_mul, width_mul = self.cfg[subtype.split("_")[1]]
+        ch = [int(x * width_mul) for x in out_channels]
+        nb = [max(round(x * depth_mul), 1) for x in layers]
+        self.layers = nb
+        self.stem = Focus(3, ch[0], kernel_sizes=3, conv_cfg=conv_cfg, norm_cfg=norm_cfg, act_cfg=act_cfg)
+        for idx in range(4):
+            stage = [conv(ch[idx], ch[idx + 1], 3, 2, padding=1, conv_cfg=conv_cfg, norm_cfg=norm_cfg, act_cfg=act_cfg)]
+            if idx == 3:
+                stage.append(SPPF(ch[idx + 1], ch[idx + 1], kernel_sizes=spp_ksizes, conv_cfg=conv_cfg, norm_cfg=norm_cfg, act_cfg=act_cfg))
+            stage.append(CSPLayer(ch[idx + 1], ch[idx + 1], n=nb[idx], shortcut=(idx != 3), depthwise=depthwise, conv_cfg=conv_cfg,
+                                  norm_cfg=norm_cfg, act_cfg=act_cfg))
+            self.add_module("stage%d" % (idx + 1), nn.Sequential(*stage))
+        self.out_channels = ch[self.out_stages[0]:self.out_stages[-1] + 1]
+        self.init_weights()
+
+    def init_weights(self):
+        for m in self.modules():   # csp_darknet.py:96-103
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight, a=math.sqrt(5))
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    def forward(self, x):
+        x = self.stem(x)
+        output = []
+        for i in range(1, 5):
+            x = getattr(self, "stage%d" % i)(x)
+            if i in self.out_stages:
+                output.append(x)
+        return output if len(self.out_stages) > 1 else output[0]
 
 
 class YOLOXNeck(nn.Module):

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .torch_ref import ConvModule, CSPLayer, Focus, SPPF, nms
+from .torch_ref import ConvModule, CSPLayer, DepthwiseSeparableConvModule, Focus, SPPF, nms
 
 SCALES = {"n": (0.33, 0.25), "nano": (0.33, 0.25), "t": (0.33, 0.375), "tiny": (0.33, 0.375), "s": (0.33, 0.5),
           "m": (0.67, 0.75), "l": (1.0, 1.0), "x": (1.33, 1.25)}
@@ -60,6 +60,44 @@ class YOLOXCSPDarknet(nn.Module):
             if i in self.out_stages:
                 out.append(x)
         return out
+
+
+class CSPDarknet(nn.Module):
+    """src/models/backbones/det/csp_darknet.py:25-103 — the generic CSPDarknet (YOLOv4 / YOLOX / AIRDet family): Focus stem, four
+    stride-2 stages of conv (or depthwise-separable conv) + CSPLayer, SPPF before the last CSPLayer, `depthwise` threaded into
+    the bottlenecks; widths int(c * width_mul), depths max(round(n * depth_mul), 1) (:50-52); kaiming-uniform init (:96-103)."""
+    cfg = {"n": [0.33, 0.25], "t": [0.33, 0.375], "s": [0.33, 0.5], "m": [0.67, 0.75], "l": [1.0, 1.0], "x": [1.33, 1.25]}
+
+    def __init__(self, subtype="cspdark_s", out_channels=(64, 128, 256, 512, 1024), layers=(3, 9, 9, 3), spp_ksizes=(5, 9, 13),
+                 depthwise=False, norm_cfg=BN, act_cfg=dict(type="Swish"), out_stages=(2, 3, 4)):
+        super().__init__()
+        depth_mul, width_mul = self.cfg[subtype.split("_")[1]]
+        ch = [int(x * width_mul) for x in out_channels]
+        nb = [max(round(x * depth_mul), 1) for x in layers]
+        self.out_stages = list(out_stages)
+        conv = DepthwiseSeparableConvModule if depthwise else ConvModule
+        self.stem = Focus(3, ch[0], kernel_sizes=3, norm_cfg=norm_cfg, act_cfg=act_cfg)
+        for idx in range(4):
+            stage = [conv(ch[idx], ch[idx + 1], 3, 2, padding=1, norm_cfg=norm_cfg, act_cfg=act_cfg)]
+            if idx == 3:
+                stage.append(SPPF(ch[idx + 1], ch[idx + 1], kernel_sizes=spp_ksizes, norm_cfg=norm_cfg, act_cfg=act_cfg))
+            stage.append(CSPLayer(ch[idx + 1], ch[idx + 1], n=nb[idx], shortcut=(idx != 3), depthwise=depthwise, norm_cfg=norm_cfg, act_cfg=act_cfg))
+            self.add_module("stage%d" % (idx + 1), nn.Sequential(*stage))
+        self.out_channels = ch[self.out_stages[0]:self.out_stages[-1] + 1]
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight, a=math.sqrt(5))
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    def forward(self, x):
+        x = self.stem(x)
+        out = []
+        for i in range(1, 5):
+            x = getattr(self, "stage%d" % i)(x)
+            if i in self.out_stages:
+                out.append(x)
+        return out if len(self.out_stages) > 1 else out[0]
 
 
 class YOLOXNeck(nn.Module):

@@ -247,3 +247,36 @@ def test_yolox_fused_model_one_graph():
     l0 = float(step(imgs.to(dev()), gts)["loss"])
     l1 = float(step(imgs.to(dev()), gts)["loss"])
     assert np.isfinite(l0) and np.isfinite(l1)
+
+
+@pytest.mark.parametrize("name,kw", [("cspdarknet_n", dict(subtype="cspdark_n")), ("cspdarknet_n_dw", dict(subtype="cspdark_n", depthwise=True))])
+def test_hip_generic_cspdarknet_vs_reference_vectors(name, kw):
+    """The generic CSPDarknet (src/models/backbones/det/csp_darknet.py:25-103), plain and depthwise: the reference's state_dict
+    loads strictly, features match the reference's vectors within the bf16 floor of the oracle, gradients flow to every parameter."""
+    g = load(name)
+    m = yolox.CSPDarknet(**kw)
+    missing, unexpected = m.load_state_dict({kk: T(v) for kk, v in g["state"].items()}, strict=True)
+    assert not missing and not unexpected
+    assert list(m.out_channels) == [int(v) for v in g["out_channels"]]
+    from oracle import yolox_ref as RX
+    om = RX.CSPDarknet(**kw)
+    om.load_state_dict({kk: T(v) for kk, v in g["state"].items()}, strict=True)
+    om.train()
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        floor = [rel_l2(f.float(), e) for f, e in zip(om(T(g["x"])), lst(g["out"]))]
+    m.to(dev()).train()
+    feats = m(T(g["x"]).to(dev()))
+    for f, e, fl in zip(feats, lst(g["out"]), floor):
+        assert tuple(f.shape) == tuple(e.shape)
+        assert rel_l2(f.float(), e) < max(3e-2, 1.5 * fl), (rel_l2(f.float(), e), fl)
+    loss = sum((f.float() * c.to(dev())).sum() for f, c in zip(feats, lst(g["cot"])))
+    loss.backward()
+    assert cosine(m.stem.conv.conv.weight.grad.float(), T(g["g_stem"])) > 0.9
+    bad = []
+    for n, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+        ref = float(g["gparam_norms"][n])
+        got = float(p.grad.float().norm())
+        if abs(got - ref) > 0.25 * max(ref, 1e-3):
+            bad.append((n, got, ref))
+    assert len(bad) <= 5, bad[:8]

@@ -424,3 +424,21 @@ def test_v7_ota_loss(trial):
         assert torch.equal(gis[i], T(g["gi"][str(i)]))
         assert torch.equal(tg[i][:, 1], T(g["tcls"][str(i)]))
         close(tg[i][:, 2:6], g["tbox"][str(i)])
+
+
+@pytest.mark.parametrize("name,kw", [("cspdarknet_n", dict(subtype="cspdark_n")), ("cspdarknet_n_dw", dict(subtype="cspdark_n", depthwise=True))])
+def test_generic_cspdarknet(name, kw):
+    """oracle restatement of src/models/backbones/det/csp_darknet.py:25-103 == the reference's own class (outputs, stem gradient,
+    per-parameter gradient norms), plain and depthwise."""
+    g = load(name)
+    m = RX.CSPDarknet(**kw)
+    load_state(m, g["state"])
+    assert list(m.out_channels) == [int(v) for v in g["out_channels"]]
+    m.train()
+    outs, _, gpar = run(m, [T(g["x"])], lst(g["cot"]))
+    for o, e in zip(outs, lst(g["out"])):
+        close(o, e, rtol=1e-4)
+    close(gpar["stem.conv.conv.weight"], g["g_stem"], rtol=1e-3)
+    for n, v in g["gparam_norms"].items():
+        assert abs(float(gpar[n].norm()) - float(v)) <= 1e-3 * max(1.0, float(v)), n
+    assert RX.CSPDarknet("cspdark_t").out_channels == [96, 192, 384]   # the 0.375-width 't' variant only this class has
