@@ -23,7 +23,7 @@ SOURCES = [
     "weights_optim.hip",
     "dwconv.hip",
     "post.hip",
-    "loss_kernels.hip", "yolo_loss.hip", "simota_loss.hip", "conv1x1_stream.hip", "conv_stem.hip", "conv1x1_bwd.hip", "comm.hip", "post_batch.hip",
+    "loss_kernels.hip", "yolo_loss.hip", "simota_loss.hip", "conv1x1_stream.hip", "conv_stem.hip", "conv1x1_bwd.hip", "comm.hip", "post_batch.hip", "ota_assign.hip",
 ]
 FLAGS = [
     "--offload-arch=gfx950",

@@ -19,6 +19,7 @@ constexpr int kPostMaxCap = 8192;  // 64 KB of 64-bit keys in LDS
 
 // orderable key: ascending key order == descending score, ties ascending row
 __device__ __forceinline__ unsigned long long post_key(float score, unsigned row) {
+  if (score == 0.f) score = 0.f;  // -0.0 compares EQUAL to +0.0 in the reference's sort: one key for both (ties then go by row)
   unsigned u = __float_as_uint(score);
   u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone in the float order
   return ((unsigned long long)(0xFFFFFFFFu - u) << 32) | row;

@@ -24,6 +24,8 @@ struct YoloLossParams {
   const h16_t* raw;
   h16_t* draw;
   const float* targets;  // (T, 6) [img, cls, cx, cy, w, h] normalised; img < 0 = padding row
+  const int* assign;     // optional [ncand]: externally decided positives (OTA, ota_assign.hip): matched target row or -1;
+                         // the candidate keeps ITS cell (from its generating target) and takes box / class from the matched row
   int ld, N, A, NO, H, W, T, nc, ncand;
   float anchor_t;
   float anchors[kLossMaxA * 2];
@@ -92,6 +94,12 @@ __global__ __launch_bounds__(256) void yolo_cand_kernel(const YoloLossParams p) 
   else if (off == 3) sel = sel && ((gxi - floorf(gxi)) < g) && (gxi > 1.f);
   else if (off == 4) sel = sel && ((gyi - floorf(gyi)) < g) && (gyi > 1.f);
   float* cs = p.cand + (int64_t)c * kCandStride;
+  const float* tm = tg;  // row that supplies the regression / class target
+  if (p.assign) {
+    const int m = p.assign[c];
+    sel = m >= 0;
+    if (sel) tm = p.targets + (int64_t)m * 6;
+  }
   if (!sel) {
     if (lane == 0) {
       p.cell[c] = -1;
@@ -118,7 +126,8 @@ __global__ __launch_bounds__(256) void yolo_cand_kernel(const YoloLossParams p) 
   const float s0 = sigmoid_ref(r0), s1 = sigmoid_ref(r1), s2 = sigmoid_ref(r2), s3 = sigmoid_ref(r3);
   const float bx = s0 * 2.f - 0.5f, by = s1 * 2.f - 0.5f;
   const float bw = (s2 * 2.f) * (s2 * 2.f) * aw, bh = (s3 * 2.f) * (s3 * 2.f) * ah;
-  const D4 ci = ciou_xywh(bx, by, bw, bh, gx - (float)gi, gy - (float)gj, gw, gh);
+  const float mx = tm[2] * nx, my = tm[3] * ny, mw = tm[4] * nx, mh = tm[5] * ny;  // == gx, gy, gw, gh without an assignment
+  const D4 ci = ciou_xywh(bx, by, bw, bh, mx - (float)gi, my - (float)gj, mw, mh);
   float* gr = p.cgrad + (int64_t)c * p.gstride;
   if (lane == 0) {
     cs[0] = ci.v;
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(256) void yolo_cand_kernel(const YoloLossParams p) 
     gr[4] = 0.f;
   }
   // classes
-  int cls = (int)tg[1];
+  int cls = (int)tm[1];
   cls = min(max(cls, 0), p.nc - 1);
   float lsum = 0.f;
   for (int k = lane; k < p.nc; k += 64) {
@@ -302,6 +311,7 @@ static int fill(YoloLossParams& p, const cvhip_yolo_loss_desc* d, const void* ra
   p.raw = (const h16_t*)raw;
   p.draw = nullptr;
   p.targets = targets;
+  p.assign = nullptr;
   p.ld = d->ld;
   p.N = d->N;
   p.A = d->A;
@@ -348,11 +358,26 @@ int64_t cvhip_yolov5_loss_workspace_bytes(const cvhip_yolo_loss_desc* d) {
   return r(ncell * 4) * 2 + r(ncand * 4) * 2 + r(ncand * kCandStride * 4) + r(ncand * gs * 4) + r(1024 * 4);
 }
 
+static int level_fwd(const cvhip_yolo_loss_desc* d, const void* raw, const float* targets, const int32_t* assign, void* ws, float* sums4,
+                     void* stream);
+
 int cvhip_yolov5_loss_level_fwd(const cvhip_yolo_loss_desc* d, const void* raw, const float* targets, void* ws, float* sums4,
                                 void* stream) {
+  return level_fwd(d, raw, targets, nullptr, ws, sums4, stream);
+}
+
+int cvhip_yolov5_loss_level_fwd_assigned(const cvhip_yolo_loss_desc* d, const void* raw, const float* targets, const int32_t* assign,
+                                         void* ws, float* sums4, void* stream) {
+  if (!assign) return CVHIP_ERR_INVALID;
+  return level_fwd(d, raw, targets, assign, ws, sums4, stream);
+}
+
+static int level_fwd(const cvhip_yolo_loss_desc* d, const void* raw, const float* targets, const int32_t* assign, void* ws, float* sums4,
+                     void* stream) {
   YoloLossParams p;
   int rc = fill(p, d, raw, targets, ws, sums4);
   if (rc != CVHIP_OK) return rc;
+  p.assign = assign;
   hipStream_t st = (hipStream_t)stream;
   const int64_t ncell = (int64_t)p.N * p.A * p.H * p.W;
   rc = zero_fill(p.winner, (ncell * 4 + 255) / 256 * 256 * 2, st);  // winner + head are adjacent

@@ -48,6 +48,13 @@ class YoloLossDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("N", "A", "NO", "H", "W", "ld", "T")] + [("anchor_t", C.c_float), ("anchors", C.c_float * 16)]
 
 
+class OtaDesc(C.Structure):
+    """cvhip_ota_desc (include/cvhip.h)."""
+    _fields_ = [(n, C.c_int32) for n in ("L", "N", "A", "NO", "T", "G")] + [("H", C.c_int32 * 4), ("W", C.c_int32 * 4), ("ld", C.c_int32 * 4),
+                                                                            ("stride", C.c_float * 4), ("anchors", (C.c_float * 16) * 4),
+                                                                            ("anchor_t", C.c_float), ("img_size", C.c_float)]
+
+
 class SimotaDesc(C.Structure):
     """cvhip_simota_desc (include/cvhip.h)."""
     _fields_ = [(n, C.c_int32) for n in ("L", "B", "A", "G", "nc")] + [("H", C.c_int32 * 4), ("W", C.c_int32 * 4), ("ld", C.c_int32 * 4),
@@ -58,6 +65,7 @@ _p, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _dp = C.POINTER(ConvDesc)
 _ylp = C.POINTER(YoloLossDesc)
 _smp = C.POINTER(SimotaDesc)
+_otp = C.POINTER(OtaDesc)
 _pp = C.POINTER(C.c_void_p)
 
 # name -> (restype, argtypes); mirrors include/cvhip.h one-to-one
@@ -139,6 +147,10 @@ SIGNATURES = {
     "cvhip_yolov5_loss_level_fwd": (_i32, [_ylp, _p, _p, _p, _p, _p]),
     "cvhip_yolov5_loss_finalize": (_i32, [_p, _i32, _p, _p, _f32, _f32, _f32, _i32, _f32, _p, _p, _p]),
     "cvhip_yolov5_loss_level_bwd": (_i32, [_ylp, _p, _p, _p, _p, _p, _f32, _f32, _f32, _p, _p]),
+    "cvhip_ota_workspace_bytes": (_i64, [_otp]),
+    "cvhip_ota_assign": (_i32, [_otp, _pp, _p, _p, _p, _p]),
+    "cvhip_ota_read_overflow": (_i32, [_otp, _p, _p, _p]),
+    "cvhip_yolov5_loss_level_fwd_assigned": (_i32, [_ylp, _p, _p, _p, _p, _p, _p]),
     "cvhip_simota_workspace_bytes": (_i64, [_smp]),
     "cvhip_simota_loss_fwd": (_i32, [_smp, _pp, _p, _p, _p, _p]),
     "cvhip_simota_loss_bwd": (_i32, [_smp, _pp, _p, _p, _p, _pp, _p]),

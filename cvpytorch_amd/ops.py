@@ -1438,8 +1438,30 @@ class YoloV5LossFused(torch.autograd.Function):
         nl = len(raws)
         sums = torch.empty((nl, 4), dtype=torch.float32, device=dev)
         descs, wss, maps, ncells = [], [], [], []
-        for i, r in enumerate(raws):
-            r, ld = as_nhwc(r)
+        raws = [as_nhwc(r) for r in raws]
+        assign = None
+        ota = getattr(cfg, "ota", None)
+        if ota is not None:
+            # YOLOv7 OTA: the positives are decided on the device first (cvhip_ota_assign: find_3_positive candidates pooled per image,
+            # dynamic-k matching, conflict resolution); the per-level kernels below then take them from `assign`
+            N = raws[0][0].shape[0]
+            od = L.OtaDesc()
+            od.L, od.N, od.A, od.NO, od.T, od.G = nl, N, A, NO, T, int(ota["G"])
+            od.anchor_t, od.img_size = float(cfg.anchor_t), float(ota["img_size"])
+            for i, (r, ld) in enumerate(raws):
+                od.H[i], od.W[i], od.ld[i], od.stride[i] = r.shape[2], r.shape[3], ld, float(ota["stride"][i])
+                for j, v in enumerate([float(x) for pair in cfg.anchors[i] for x in pair]):
+                    od.anchors[i][j] = v
+            nb = L.load().cvhip_ota_workspace_bytes(C.byref(od))
+            if nb < 0:
+                L.check(int(nb), "cvhip_ota_workspace_bytes")
+            ota_ws = torch.empty((int(nb),), dtype=torch.uint8, device=dev)
+            assign = torch.empty((nl, 5 * A * T), dtype=torch.int32, device=dev)
+            ptrs = (C.c_void_p * nl)(*[r.data_ptr() for r, _ in raws])
+            L.call("cvhip_ota_assign", C.byref(od), ptrs, tg.data_ptr(), ota_ws.data_ptr(), assign.data_ptr(), st)
+            ctx.ota_keep = (ota_ws, od)
+            cfg.last_assign = assign   # diagnostics / tests
+        for i, (r, ld) in enumerate(raws):
             N, Cc, H, W = r.shape
             if Cc != A * NO:
                 raise L.CvhipError("yolov5 loss: head map has %d channels, expected %d" % (Cc, A * NO))
@@ -1450,7 +1472,11 @@ class YoloV5LossFused(torch.autograd.Function):
             if nbytes < 0:
                 L.check(int(nbytes), "cvhip_yolov5_loss_workspace_bytes")
             ws = torch.empty((int(nbytes),), dtype=torch.uint8, device=dev)
-            L.call("cvhip_yolov5_loss_level_fwd", C.byref(d), r.data_ptr(), tg.data_ptr(), ws.data_ptr(), sums[i].data_ptr(), st)
+            if assign is not None:
+                L.call("cvhip_yolov5_loss_level_fwd_assigned", C.byref(d), r.data_ptr(), tg.data_ptr(), assign[i].data_ptr(), ws.data_ptr(),
+                       sums[i].data_ptr(), st)
+            else:
+                L.call("cvhip_yolov5_loss_level_fwd", C.byref(d), r.data_ptr(), tg.data_ptr(), ws.data_ptr(), sums[i].data_ptr(), st)
             descs.append(d)
             wss.append(ws)
             maps.append(r)

@@ -317,9 +317,11 @@ class YOLOv7(nn.Module):
 
     def __init__(self, num_classes=80, width_mul=1.0, max_targets=None, fused_loss=False, loss="v5", max_per_image=32):
         """loss="v5": the YOLOv5-style assignment (fused_loss=True -> libcvhip kernels, graph-capturable);
-        loss="ota": the reference's YOLOv7Loss (find_3_positive + OTA matching) in fixed-shape torch ops (YOLOv7OTALoss)."""
+        loss="ota": the reference's YOLOv7Loss (find_3_positive + OTA matching): fused_loss=True -> libcvhip kernels on the raw head maps
+        (cvhip_ota_assign + cvhip_yolov5_loss_level_fwd_assigned: the whole step is ONE hipGraph), fused_loss=False -> the fixed-shape
+        torch-op restatement (YOLOv7OTALoss)."""
         super().__init__()
-        assert loss in ("v5", "ota") and not (loss == "ota" and fused_loss)
+        assert loss in ("v5", "ota")
         self.num_classes = num_classes
         self.fused_loss = fused_loss
         self.loss_kind = loss
@@ -328,7 +330,9 @@ class YOLOv7(nn.Module):
         self.neck = YOLOv7Neck(width_mul=width_mul)
         self.head = YOLOv7Head(width_mul=width_mul)
         self.detect = YOLOv7Detect(num_classes, width_mul=width_mul)
-        if loss == "ota":
+        if loss == "ota" and fused_loss:
+            self.loss = YOLOv7OTALossFused(num_classes, anchors=ANCHORS, max_per_image=max_per_image)
+        elif loss == "ota":
             self.loss = YOLOv7OTALoss(num_classes, anchors=ANCHORS, max_per_image=max_per_image)
         else:
             self.loss = (YOLOv5LossFused if fused_loss else YOLOv5Loss)(num_classes, anchors=ANCHORS, hyp_box=0.05, hyp_obj=0.7, hyp_cls=0.3)
@@ -346,7 +350,9 @@ class YOLOv7(nn.Module):
 
     def loss_from_features(self, train_out, gts):
         losses = {}
-        if self.loss_kind == "ota":
+        if self.loss_kind == "ota" and self.fused_loss:
+            losses["loss"], st = self.loss(train_out, gts, self._img_h)
+        elif self.loss_kind == "ota":
             losses["loss"], st = self.loss([t.float() for t in train_out], gts, self._img_h)
         else:
             losses["loss"], st = self.loss(train_out, gts)
@@ -395,6 +401,32 @@ def flat_to_padded(targets, batch, max_per_image):
     out = out.index_copy(0, slot, torch.where(ok[:, None], targets, out[-1:].expand(T, 6)))
     out = out[:-1].view(batch, max_per_image, 6)
     return out, out[..., 0] >= 0
+
+
+class YOLOv7OTALossFused(nn.Module):
+    """The reference's YOLOv7Loss (src/losses/yolov7_loss.py:129-420) on libcvhip kernels, straight on the raw 16-bit NHWC head maps
+    [(N, A*NO, H, W)]: cvhip_ota_assign (find_3_positive candidates pooled per image, IoU + cost per gt, dynamic-k, conflict
+    resolution — one wave per gt) decides the positives, the YOLOv5-form loss kernels evaluate CIoU / class / objectness and their
+    gradients on that assignment. No torch autograd ops and no host sync: YOLOv7(loss="ota", fused_loss=True) captures as one graph.
+    targets: (T, 6) flat rows [img, cls, cx, cy, w, h], rows of an image contiguous, img < 0 = padding."""
+
+    def __init__(self, num_classes, stride=(8., 16., 32.), anchors=ANCHORS, max_per_image=32):
+        super().__init__()
+        self.num_classes = num_classes
+        self.num_layers, self.num_anchors = len(anchors), len(anchors[0])
+        self.anchors = [[list(map(float, a)) for a in lvl] for lvl in anchors]
+        self.stride = [float(s) for s in stride]
+        self.anchor_t, self.hyp_box, self.hyp_obj, self.hyp_cls = 4.0, 0.05, 0.7, 0.3
+        self.balance = [4.0, 1.0, 0.4]
+        self.max_per_image = int(max_per_image)
+        self._const_cache = {}
+        self.ota = None
+        self.last_assign = None
+
+    def forward(self, raws, targets, img_size):
+        self.ota = dict(G=self.max_per_image, img_size=float(img_size), stride=self.stride)
+        total, stats3 = ops.yolov5_loss_fused(list(raws), targets, self)
+        return total, torch.cat((stats3, stats3.sum().reshape(1)))
 
 
 class YOLOv7OTALoss(nn.Module):

@@ -472,6 +472,34 @@ int cvhip_yolov5_loss_level_bwd(const cvhip_yolo_loss_desc* d, const void* raw_b
                                 void* draw_bf16, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * YOLOv7 OTA label assignment on device (ota_assign.hip) + the loss on that assignment.
+ * Replaces src/losses/yolov7_loss.py:217-365 (build_targets: per-image python loop, boolean-mask compaction, torch.topk, per-gt
+ * `.item()` loops over the find_3_positive candidates :367-420). raws[l]: 16-bit NHWC head map of level l (N, H_l, W_l, ld_l) with
+ * channel a*NO + o; targets (T, 6) fp32 [img, cls, cx, cy, w, h] normalised, rows of one image contiguous, img < 0 = padding.
+ *   cvhip_ota_assign : assign[l][c], c = (offset*A + anchor)*T + target (the candidate ordinal of the YOLOv5 loss kernels) =
+ *                      matched flat target row, or -1. G = capacity of targets per image (images with more: the extra targets get
+ *                      no candidates, flagged via cvhip_ota_read_overflow); L*5*A*G <= 4096.
+ *   cvhip_yolov5_loss_level_fwd_assigned : cvhip_yolov5_loss_level_fwd with the positives taken from `assign` (one level's slice):
+ *                      the candidate keeps its cell, box / class targets come from the matched row. finalize / level_bwd unchanged
+ *                      (hyp 0.05 / 0.7 / 0.3, balance 4 / 1 / 0.4: yolov7_loss.py:129-215).
+ * ------------------------------------------------------------------------------------------ */
+#ifndef CVHIP_REDECLARE_F16
+typedef struct cvhip_ota_desc {
+  int32_t L, N, A, NO, T, G;
+  int32_t H[4], W[4], ld[4];
+  float stride[4];
+  float anchors[4][16]; /* per level: A x (w, h) in grid units */
+  float anchor_t;       /* 4.0 */
+  float img_size;       /* the reference's imgs[b].shape[1] */
+} cvhip_ota_desc;
+#endif
+int64_t cvhip_ota_workspace_bytes(const cvhip_ota_desc* d);
+int cvhip_ota_assign(const cvhip_ota_desc* d, const void* const* raws, const float* targets, void* ws, int32_t* assign, void* stream);
+int cvhip_ota_read_overflow(const cvhip_ota_desc* d, const void* ws, int32_t* out_device, void* stream);
+int cvhip_yolov5_loss_level_fwd_assigned(const cvhip_yolo_loss_desc* d, const void* raw_bf16, const float* targets, const int32_t* assign,
+                                         void* ws, float* sums4, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * YOLOX loss on device: SimOTA assignment + 5*IoU^2 + objectness + class BCE, all levels at once.
  * Replaces src/losses/det/yolox_loss.py:73-435 (per-image python loop, per-gt `.item()` top-k loop). raws[l]: bf16 NHWC head
  * map of level l, (B, H_l, W_l, ld_l) with channels [reg 4, obj 1, cls nc] (heads/det/yolox_head.py:94); targets: (B, G, 5) fp32

@@ -209,18 +209,32 @@ def test_yolov5s_fp16_train_step_vs_oracle(capture):
     if capture:
         assert float(state.mom.abs().max()) > 0.0     # the replayed graph produced (unscaled, finite) gradients
         return
-    upd16 = (state.param - p0).float()
-    # the same step in bf16
+    # gradient quality: the first-step momentum buffer is g + wd*p per parameter. Against the fp32 oracle's gradient the fp16 engine
+    # must be at least as good as the bf16 engine on the same weights and batch (fp16 stores 3 more mantissa bits)
+    from cvpytorch_amd.arena import _dense_view
+    ref.zero_grad()
+    ref(imgs, targets, "train")["loss"].backward()
+    rg = {n: p.grad for n, p in ref.named_parameters() if p.grad is not None}
+
+    def grad_cos(model, st):
+        a, b = [], []
+        for n, p in model.named_parameters():
+            if n in rg and id(p) in st.index:
+                off = st.offsets[st.index[id(p)]]
+                a.append(_dense_view(st.mom, off, p).float().cpu().reshape(-1))
+                b.append(rg[n].reshape(-1))
+        a, b = torch.cat(a), torch.cat(b)
+        return float((a * b).sum() / (a.norm() * b.norm()))
+
+    c16 = grad_cos(hip, state)
     ops.set_precision("bf16")
     ref2, hip2, imgs2, targets2, gts2, _, _ = _v5("s")
     st2 = FlatTrainState(hip2, use_ema=False)
     assert not st2.loss_scaling
-    p1 = st2.param.clone()
     FlatTrainStep(hip2, st2)(imgs2.to(d), gts2)
     torch.cuda.synchronize()
-    updbf = (st2.param - p1).float()
-    cos = float((upd16 * updbf).sum() / (upd16.norm() * updbf.norm()))
-    assert cos > 0.9, cos
+    cbf = grad_cos(hip2, st2)
+    assert c16 > 0.8 and c16 >= cbf - 0.02, (c16, cbf)
 
 
 def test_yolov7l_full_width_fp16_end_to_end_vs_oracle():
