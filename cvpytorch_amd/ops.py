@@ -1488,7 +1488,7 @@ class YoloV5LossFused(torch.autograd.Function):
             cfg._const_cache[key] = consts
         total = torch.empty((1,), dtype=torch.float32, device=dev)
         stats = torch.empty((3,), dtype=torch.float32, device=dev)
-        bs = float(raws[0].shape[0])
+        bs = float(maps[0].shape[0])
         L.call("cvhip_yolov5_loss_finalize", sums.data_ptr(), nl, consts[0].data_ptr(), consts[1].data_ptr(), float(cfg.hyp_box),
                float(cfg.hyp_obj), float(cfg.hyp_cls), cfg.num_classes, bs, total.data_ptr(), stats.data_ptr(), st)
         ctx.cfg, ctx.descs, ctx.wss, ctx.ncells, ctx.bs = cfg, descs, wss, ncells, bs
