@@ -147,29 +147,46 @@ def deeplab_workload(dev, a, batch=16, size=(512, 1024), steps=20, warmup=3):
 
 
 def pmc_traffic(kernel_label):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic_raw.json,
-    collected by `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` over tools/pmc_workload.py = the same eager train step).
-    Corrections per MI355X_MICROARCH.md (HBM section): the counters are KiB; on gfx950 FETCH_SIZE tallies 128-B read requests
-    at 64 B => x2 (confirmed in the same pass on a kernel with a known byte count: fp32->bf16 cast of 209.7 M elements reads
-    838.9 MB, FETCH_SIZE says 409,625 KiB; its 419.4 MB of writes read 409,600 KiB => WRITE_SIZE x1). null if the file is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic_raw.json")
-    try:
-        raw = json.load(open(path))
-    except Exception:
+    """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic_raw.json, falling back to
+    r01's; collected by `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and, separately, `--pmc WRITE_SIZE --kernel-trace` over
+    tools/pmc_workload.py = the same eager train step). Corrections per MI355X_MICROARCH.md (HBM section): the counters are KiB;
+    on gfx950 FETCH_SIZE tallies 128-B read requests at 64 B => x2 (confirmed in the same pass on a kernel with a known byte count:
+    a 419.4 MB bf16 copy reads FETCH_SIZE 204,8xx KiB; its 419.4 MB of writes read WRITE_SIZE 409,600 KiB => WRITE_SIZE x1).
+    null if no file / no matching kernel."""
+    raw = None
+    for name in ("r02_pmc_traffic_raw.json", "r01_pmc_traffic_raw.json"):
+        try:
+            raw = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)))
+            break
+        except Exception:
+            continue
+    if raw is None:
         return None
-    if kernel_label.startswith("stem"):
-        base, tile = "stem_fprop_kernel", ""
+    # bench label -> substrings the demangled kernel name must contain
+    if kernel_label.startswith("bn_act_bwd_sums"):
+        need = ["colreduce_kernel<1,"]
+    elif kernel_label.startswith("bn_act_fwd"):
+        need = ["ew_kernel<0,"]
+    elif kernel_label.startswith("bn_act_bwd_apply"):
+        need = ["ew_kernel<1,"]
+    elif kernel_label.startswith("bwd1x1"):
+        need = ["bwd1x1_kernel"]
+    elif kernel_label.startswith("stem_wgrad"):
+        need = ["stem_wgrad_kernel"]
+    elif kernel_label.startswith("stem"):
+        need = ["stem_fprop_kernel"]
     elif kernel_label.startswith("conv1x1_stream"):  # label carries the output-tile width, the template its fragment count
-        base, tile = "conv1x1_stream_kernel", "%d, " % (int(kernel_label[kernel_label.index("<") + 1:kernel_label.index(">")]) // 16)
+        need = ["conv1x1_stream_kernel<%d, " % (int(kernel_label[kernel_label.index("<") + 1:kernel_label.index(">")]) // 16)]
     else:
         tile = kernel_label[kernel_label.index("<") + 1:kernel_label.index(">")].replace(",", ", ")
-        base = "igemm" if kernel_label.startswith("igemm") else "wgrad_kernel"
+        need = [("igemm_dma_kernel<" if kernel_label.startswith("igemm") else "wgrad_kernel<") + tile]
     n = tot = 0.0
-    for k, v in raw.items():  # a tile configuration may exist in several template variants (ring depth, group count): launch-weighted mean
-        if base in k and ("<" + tile) in k and v.get("fetch_size_raw_kb_per_launch") is not None and v.get("write_size_raw_kb_per_launch") is not None:
+    for k, v in raw.items():  # a configuration may exist in several template variants (ring depth, group count): launch-weighted mean
+        if all(x in k for x in need) and v.get("fetch_size_raw_kb_per_launch") is not None and v.get("write_size_raw_kb_per_launch") is not None:
             n += v["launches"]
             tot += v["launches"] * (2.0 * v["fetch_size_raw_kb_per_launch"] + v["write_size_raw_kb_per_launch"]) * 1024.0
     return round(tot / n) if n else None
+
 
 def measured_peaks(dev):
     """What THIS box attains: a plain device copy (cvhip_copy2d over 512 MiB: bytes read + written per second) and a bare MFMA loop
