@@ -24,6 +24,9 @@
 // conflict-free for the 4x16-lane groups of MI355X_MICROARCH.md §LDS.
 #include <stdlib.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 #include "conv_plan.h"
 
@@ -287,7 +290,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKernArgs p) {
 // The LDS image is lane-linear (DMA destination = wave base + lane*16), so the 16-B-slot XOR swizzle is applied to
 // the SOURCE address (which logical K-slot a lane fetches) and to the fragment reads (rule 21).
 // =====================================================================================================
-__device__ __attribute__((aligned(64))) unsigned int g_zero_page[16];
+// Masked DMA lanes read zeros from here. FAST staging walks a masked row's pointer along with the live ones (Cin * 2 bytes per tap),
+// so the page covers kFastMaxCin channels plus one 64-byte row.
+constexpr int kFastMaxCin = 4096;
+__device__ __attribute__((aligned(64))) unsigned int g_zero_page[kFastMaxCin / 2 + 16];
 
 #define CVHIP_GLDS16(src, dst)                                                                                  \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                       \
@@ -318,7 +324,16 @@ __device__ __forceinline__ void wait_vmcnt() {
 //      Cin >= 64), half the barriers / tap decodes / counted waits per MFMA (cdna_hip_programming.md §5: "x through LDS in
 //      full 128-B lines", BK 32 -> 64). The 16-B slots of a 128-B row are XOR-swizzled by (row >> 1) & 7 — conflict-free for
 //      the 16-lane groups of ds_read_b128 — on the DMA SOURCE side and on the fragment reads (rule 21).
-template <int BM, int BN, int WM, int WN, int ABL = 0, int NST = 3, int BK = 32>
+// FAST: Cin % BK == 0, so a K step lies inside ONE tap and its channel offset advances by BK: the per-row source pointers are
+//      kept in registers, bumped by one 64-bit add per K step and re-derived (halo test, pixel address) only when the tap changes —
+//      every Cin / BK steps, under a wave-uniform branch. The general path re-decodes (tap, channel) and re-tests the halo for every
+//      row at every K step: ~110 VALU instructions and four divergent branches per step, which made ADDRESS GENERATION, not the
+//      DMA rate, the cost of staging (profiles/r01_igemm_ablation.log: staging-only 146 us vs 48 us of pure MFMA; halving the
+//      steps with BK 64 doubled the rows per step and changed nothing: profiles/r02_ab_bwd1x1_bk64.log).
+// A register-double-buffered variant (fragments of tile kt+1 read while tile kt is multiplied, asm-issued ds_read_b128 with one
+// explicit lgkmcnt wait per step) was built and measured in round 2: 8-13 % SLOWER per kernel (profiles/r02_igemm_ablation.log) and
+// removed — the step is not bound by the latency of its own fragment reads.
+template <int BM, int BN, int WM, int WN, int ABL = 0, int NST = 3, int BK = 32, bool FAST = false>
 __global__ __launch_bounds__(256, (NST * (BM + (BN < BK ? BK : BN)) * BK * 2 > 80 * 1024) ? 1 : 2) void igemm_dma_kernel(const IgemmKernArgs p) {
   constexpr int WAVES_N = BN / WN;
   constexpr int WAVES_M = BM / WM;
@@ -373,9 +388,9 @@ __global__ __launch_bounds__(256, (NST * (BM + (BN < BK ? BK : BN)) * BK * 2 > 8
   for (int i = 0; i < A_IT; ++i) {
     const int m = m0 + i * RPT + srow;
     if (m < M) {
-      const int n = m / OHWi;
+      const int n = (int)fast_div31((unsigned)m, cl.ohw_mul, cl.ohw_sh);
       const int rem = m - n * OHWi;
-      const int oh = rem / OWi;
+      const int oh = (int)fast_div31((unsigned)rem, cl.ow_mul, cl.ow_sh);
       const int ow = rem - oh * OWi;
       ih0[i] = oh * p.in_sh + cl.dh0;
       iw0[i] = ow * p.in_sw + cl.dw0;
@@ -424,6 +439,57 @@ __global__ __launch_bounds__(256, (NST * (BM + (BN < BK ? BK : BN)) * BK * 2 > 8
     }
   };
 
+  // ---- FAST staging: running source pointers -----------------------------------------------------------------
+  const h16_t* aptr[A_IT];
+  const h16_t* bptr[B_IT];
+  int f_c = 0, f_tr = 0, f_ts = 0;  // wave-uniform: channel offset inside the current tap, tap coordinates of the NEXT stage
+  if constexpr (FAST) {
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      int n = n0 + i * RPT + srow;  // rows past the tile / past Nout fetch a valid row: their columns are never stored or summed
+      n = n < p.Nout ? n : p.Nout - 1;
+      bptr[i] = wbase + ((int64_t)n * Ktot + lslot * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) aptr[i] = zero;
+  }
+  auto stage_fast = [&](int st) {
+    if (f_c == 0) {  // first K step of a tap: halo test + pixel address, once per Cin / BK steps
+      const int dh = f_tr * cl.dh_step, dw = f_ts * cl.dw_step;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const int ih = ih0[i] + dh, iw = iw0[i] + dw;
+        const bool ok = (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+        const int64_t off = (int64_t)(pbase[i] + ih * p.IW + iw) * p.x_ld;
+        aptr[i] = (ok ? p.x + off : zero) + lslot * 8;
+      }
+    }
+    unsigned char* const sA = smem + st * ST_BYTES;
+    unsigned char* const sB = sA + A_BYTES;
+    // ABL 3 (experiment, wrong results): pixel rows are fetched for 2 of 9 taps only — the DMA volume a patch-in-LDS layout with
+    // tap reuse would have; measures how much of the kernel's time is the issue cost of the A-tile DMA pieces
+    const bool a_live = ABL != 3 || ((f_tr * TS + f_ts) % 6 == 0);
+    if (a_live) {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) CVHIP_GLDS16(aptr[i], sA + (i * RPT + wave * RPI) * ROWB);
+    }
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) aptr[i] += BK;
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      CVHIP_GLDS16(bptr[i], sB + (i * RPT + wave * RPI) * ROWB);
+      bptr[i] += BK;
+    }
+    f_c += BK;
+    if (f_c == Cin) {
+      f_c = 0;
+      if (++f_ts == TS) {
+        f_ts = 0;
+        ++f_tr;
+      }
+    }
+  };
+
   f32x4 acc[NF][MF];
 #pragma unroll
   for (int a = 0; a < NF; ++a)
@@ -451,7 +517,30 @@ __global__ __launch_bounds__(256, (NST * (BM + (BN < BK ? BK : BN)) * BK * 2 > 8
     }
   };
 
-  if constexpr (NST == 3) {
+  if constexpr (FAST && NST == 3) {
+    // no DMA is issued past the last tile (the running weight pointers would leave the array), so the last step waits for
+    // everything instead of "all but the next tile"
+    stage_fast(0);
+    if (nk > 1) stage_fast(1);
+    int st_cur = 0, st_nxt2 = 2;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) wait_vmcnt<PER>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (kt + 2 < nk) stage_fast(st_nxt2);
+      compute(st_cur);
+      st_cur = st_cur == NST - 1 ? 0 : st_cur + 1;
+      st_nxt2 = st_nxt2 == NST - 1 ? 0 : st_nxt2 + 1;
+    }
+  } else if constexpr (FAST) {
+    stage_fast(0);
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 1 < nk) stage_fast((kt + 1) & 1);
+      compute(kt & 1);
+    }
+  } else if constexpr (NST == 3) {
     stage(0, 0);
     stage(1, 1);
     int st_cur = 0, st_nxt2 = 2;
@@ -486,59 +575,68 @@ __global__ __launch_bounds__(256, (NST * (BM + (BN < BK ? BK : BN)) * BK * 2 > 8
   }
 
   const int nq = (lane >> 4) * 4;
+  // Nout % 4 == 0 makes every lane's 4-channel group all-valid or all-invalid, so the packed path has no lane-divergent branch
+  const bool vec4 = p.y_vec_ok && (p.Nout & 3) == 0;
+  const bool rvec = p.res && vec4 && (p.res_ld & 3) == 0 && ((((uintptr_t)p.res) & 7) == 0);
+  auto epilogue = [&](auto vec_c) {
+    constexpr bool VEC = decltype(vec_c)::value;
 #pragma unroll
-  for (int b = 0; b < MF; ++b) {
-    const int m = m0 + wm * WM + b * 16 + (lane & 15);
-    if (m >= M) continue;
-    const int n_img = m / OHWi;
-    const int rem = m - n_img * OHWi;
-    const int oh = rem / OWi;
-    const int ow = rem - oh * OWi;
-    const int64_t opix = ((int64_t)n_img * p.OH + (oh * p.out_sh + cl.out_oh)) * p.OW + (ow * p.out_sw + cl.out_ow);
-    h16_t* yrow = p.y + opix * p.y_ld;
+    for (int b = 0; b < MF; ++b) {
+      const int m = m0 + wm * WM + b * 16 + (lane & 15);
+      if (m >= M) continue;
+      const int n_img = (int)fast_div31((unsigned)m, cl.ohw_mul, cl.ohw_sh);
+      const int rem = m - n_img * OHWi;
+      const int oh = (int)fast_div31((unsigned)rem, cl.ow_mul, cl.ow_sh);
+      const int ow = rem - oh * OWi;
+      const int64_t opix = ((int64_t)n_img * p.OH + (oh * p.out_sh + cl.out_oh)) * p.OW + (ow * p.out_sw + cl.out_ow);
+      h16_t* yrow = p.y + opix * p.y_ld;
+      const h16_t* rbase = p.res ? p.res + opix * p.res_ld : nullptr;
 #pragma unroll
-    for (int a = 0; a < NF; ++a) {
-      const int n = n0 + wn * WN + a * 16 + nq;
-      if (n >= p.Nout) continue;
-      float v0 = acc[a][b][0], v1 = acc[a][b][1], v2 = acc[a][b][2], v3 = acc[a][b][3];
-      if (p.bias) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + wn * WN + a * 16 + nq);
-        v0 += bv[0];
-        v1 += bv[1];
-        v2 += bv[2];
-        v3 += bv[3];
-      }
-      if (p.res) {  // skip-connection gradient folded into dgrad's epilogue (replaces autograd's accumulation add)
-        const h16_t* rrow = p.res + opix * p.res_ld + n;
-        if (n + 3 < p.Nout && (p.res_ld & 3) == 0 && ((((uintptr_t)p.res) & 7) == 0)) {
-          const uint2 u = *reinterpret_cast<const uint2*>(rrow);   // 4 consecutive channels, like the store below
-          float r0, r1, r2, r3;
-          unpack2(u.x, r0, r1);
-          unpack2(u.y, r2, r3);
-          v0 += r0;
-          v1 += r1;
-          v2 += r2;
-          v3 += r3;
+      for (int a = 0; a < NF; ++a) {
+        const int n = n0 + wn * WN + a * 16 + nq;
+        if (n >= p.Nout) continue;
+        float v0 = acc[a][b][0], v1 = acc[a][b][1], v2 = acc[a][b][2], v3 = acc[a][b][3];
+        if (p.bias) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + wn * WN + a * 16 + nq);
+          v0 += bv[0];
+          v1 += bv[1];
+          v2 += bv[2];
+          v3 += bv[3];
+        }
+        if (p.res) {  // skip-connection gradient folded into dgrad's epilogue (replaces autograd's accumulation add)
+          const h16_t* rrow = rbase + n;
+          if (VEC && rvec) {
+            const uint2 u = *reinterpret_cast<const uint2*>(rrow);  // 4 consecutive channels, like the store below
+            float r0, r1, r2, r3;
+            unpack2(u.x, r0, r1);
+            unpack2(u.y, r2, r3);
+            v0 += r0;
+            v1 += r1;
+            v2 += r2;
+            v3 += r3;
+          } else {
+            v0 += (float)rrow[0];
+            if (n + 1 < p.Nout) v1 += (float)rrow[1];
+            if (n + 2 < p.Nout) v2 += (float)rrow[2];
+            if (n + 3 < p.Nout) v3 += (float)rrow[3];
+          }
+        }
+        if (VEC) {
+          uint2 u;
+          u.x = pack2(v0, v1);
+          u.y = pack2(v2, v3);
+          *reinterpret_cast<uint2*>(yrow + n) = u;
         } else {
-          if (n < p.Nout) v0 += (float)rrow[0];
-          if (n + 1 < p.Nout) v1 += (float)rrow[1];
-          if (n + 2 < p.Nout) v2 += (float)rrow[2];
-          if (n + 3 < p.Nout) v3 += (float)rrow[3];
+          yrow[n] = (h16_t)v0;
+          if (n + 1 < p.Nout) yrow[n + 1] = (h16_t)v1;
+          if (n + 2 < p.Nout) yrow[n + 2] = (h16_t)v2;
+          if (n + 3 < p.Nout) yrow[n + 3] = (h16_t)v3;
         }
       }
-      if (p.y_vec_ok && n + 3 < p.Nout) {
-        uint2 u;
-        u.x = pack2(v0, v1);
-        u.y = pack2(v2, v3);
-        *reinterpret_cast<uint2*>(yrow + n) = u;
-      } else {
-        yrow[n] = (h16_t)v0;
-        if (n + 1 < p.Nout) yrow[n + 1] = (h16_t)v1;
-        if (n + 2 < p.Nout) yrow[n + 2] = (h16_t)v2;
-        if (n + 3 < p.Nout) yrow[n + 3] = (h16_t)v3;
-      }
     }
-  }
+  };
+  if (vec4) epilogue(std::true_type{});
+  else epilogue(std::false_type{});
 
   if (p.stats) {
     float* red = reinterpret_cast<float*>(smem);  // [WAVES_M][BN][2]
@@ -586,7 +684,7 @@ static int ablate_mode() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("CVHIP_IGEMM_ABLATE");
-    v = (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0;
+    v = (e && (e[0] == '1' || e[0] == '2' || e[0] == '3')) ? e[0] - '0' : 0;
   }
   return v;
 }
@@ -611,6 +709,16 @@ static int bk64_level() {
     v = e ? atoi(e) : 0;
   }
   return v;
+}
+
+// CVHIP_IGEMM_FAST=0 restores per-step tap decoding for every shape (A/B switch; default on)
+static bool fast_staging() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CVHIP_IGEMM_FAST");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v == 1;
 }
 
 static bool use_v1() {
@@ -659,9 +767,20 @@ static int launch_group(IgemmKernArgs& p, hipStream_t stream) {
     else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 2, 64>), dim3(total), dim3(256), 0, stream, p);
     return check_launch("igemm_kernel(bk64)");
   }
+  const bool nst2 = (BN <= 64 && nst2_level() >= 1) || (BM == 128 && nst2_level() >= 2) || nst2_level() >= 3;
+  if (ablate_mode() == 3) {
+    if (p.Cin % 32 != 0 || p.Cin > kFastMaxCin) return CVHIP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 3, 2, 32, true>), dim3(total), dim3(256), 0, stream, p);
+    return check_launch("igemm_kernel(abl3)");
+  }
+  if (ablate_mode() == 0 && fast_staging() && p.Cin % 32 == 0 && p.Cin <= kFastMaxCin) {
+    if (nst2) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 2, 32, true>), dim3(total), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 3, 32, true>), dim3(total), dim3(256), 0, stream, p);
+    return check_launch("igemm_kernel(fast)");
+  }
   if (ablate_mode() == 1) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 1>), dim3(total), dim3(256), 0, stream, p);
   else if (ablate_mode() == 2) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 2>), dim3(total), dim3(256), 0, stream, p);
-  else if ((BN <= 64 && nst2_level() >= 1) || (BM == 128 && nst2_level() >= 2) || nst2_level() >= 3) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 2>), dim3(total), dim3(256), 0, stream, p);
+  else if (nst2) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 2>), dim3(total), dim3(256), 0, stream, p);
   else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN>), dim3(total), dim3(256), 0, stream, p);
   return check_launch("igemm_kernel");
 }
@@ -672,6 +791,8 @@ static int launch_cfg(IgemmParams& p, hipStream_t stream) {
   p.cin_magic = div_magic(p.Cin);
   for (int i = 0; i < p.ncls; ++i) {
     p.cls[i].ts_magic = div_magic(p.cls[i].TS);
+    div31_consts(p.cls[i].OHi * p.cls[i].OWi, &p.cls[i].ohw_mul, &p.cls[i].ohw_sh);
+    div31_consts(p.cls[i].OWi, &p.cls[i].ow_mul, &p.cls[i].ow_sh);
     if ((int64_t)p.cls[i].TR * p.cls[i].TS * p.Cin >= 65536) return CVHIP_ERR_UNSUPPORTED;  // 16-bit exact fast division
   }
   // the kernels take kKernelClasses classes by value (small argument block); plans with more (stride > 2) launch in groups

@@ -20,6 +20,7 @@ struct IgemmClass {
   int tile_begin;        // first logical tile of this class (filled by the launcher)
   int64_t w_off;         // element offset of this class's weight image
   unsigned ts_magic;     // ceil(2^32 / TS) for the branch-free tap decode (0 when TS <= 1)
+  unsigned ohw_mul, ohw_sh, ow_mul, ow_sh;  // fast_div31 constants of OHi*OWi and OWi (pixel index -> image, row, column)
   // provenance of the taps in the original kernel (used by the weight packer)
   int r0, r_step, s0, s_step;
 };
@@ -69,6 +70,29 @@ inline int conv_out_dim(int in, int pad, int dil, int k, int stride) {
 
 // exact n / d for n, d < 2^16 as __umulhi(n, magic), magic = ceil(2^32 / d)  (d == 1 -> magic 0: caller returns n)
 inline unsigned div_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
+
+// exact n / d for 0 <= n < 2^31 and any d >= 1:  q = umulhi(n, mul) >> sh  (d == 1: mul = 0, the caller returns n).
+// mul = ceil(2^(31 + L) / d), sh = L - 1 with L = ceil(log2 d): the classic round-up multiplier, 32 bits wide because d > 2^(L-1).
+inline void div31_consts(int d, unsigned* mul, unsigned* sh) {
+  if (d <= 1) {
+    *mul = 0;
+    *sh = 0;
+    return;
+  }
+  int L = 0;
+  while ((1ll << L) < d) ++L;
+  const int pw = 31 + L;
+  *mul = (unsigned)(((1ull << pw) + (unsigned long long)d - 1) / (unsigned long long)d);
+  *sh = (unsigned)(L - 1);
+}
+__host__ __device__ __forceinline__ unsigned fast_div31(unsigned n, unsigned mul, unsigned sh) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned q = __umulhi(n, mul) >> sh;
+#else
+  const unsigned q = (unsigned)(((unsigned long long)n * mul) >> 32) >> sh;
+#endif
+  return mul ? q : n;
+}
 
 inline int gcd_(int a, int b) {
   while (b) {
