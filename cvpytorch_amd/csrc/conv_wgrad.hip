@@ -11,6 +11,8 @@
 //
 // Replaces aten::convolution_backward(weight) reached from trainer.py:189 (loss.backward()).
 #include <stdlib.h>
+
+#include <type_traits>
 #include "common.h"
 #include "conv_plan.h"
 
@@ -26,12 +28,34 @@ struct WgradParams {
   int Nout, dy_ld;
   int Ktot, M;
   int n_tiles, k_tiles, m_per_split;
+  unsigned ohw_mul, ohw_sh, ow_mul, ow_sh;  // fast_div31 constants of OHi*OWi and OWi
   int ablate;  // CVHIP_WGRAD_ABLATE: 1 = skip the atomic epilogue, 2 = atomics into per-split scratch, 3 = plain stores into it (profiling only)
   float* scratch;
   int64_t split_stride;
 };
 
 typedef __attribute__((address_space(3))) h16x4 lds_h16x4;
+
+// Operand loads issued through inline asm: hipcc's waitcnt pass does not see them, so it cannot drain them (it put s_waitcnt
+// vmcnt(0) at the header of the pipelined loop); wgrad_wait_vm<N> is the only vmcnt wait of the loop and the empty asm statements
+// after it name the registers as in/out operands, so no use of a loaded value can be scheduled above the wait.
+typedef unsigned __attribute__((ext_vector_type(4))) u32x4;  // a native vector: asm register operands cannot be HIP's uint4 struct
+__device__ __forceinline__ void gload16_async(u32x4& dst, const void* ptr) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wgrad_wait_vm() {
+  static_assert(N >= 0 && N <= 8, "vmcnt literal table");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
 
 // M * tiles threshold below which a block runs two 4-wave groups (per-shape A/B on YOLOv5-s and DeepLabv3+ layers)
 constexpr int64_t kWgTwoGroupWork = 600000;
@@ -46,7 +70,12 @@ __device__ __forceinline__ h16x8 tr_read8(const unsigned char* p0, const unsigne
 // A block is TWO 4-wave groups working on the two halves of the block's pixel range with private LDS rings; their
 // accumulators are folded through LDS before the epilogue, which halves the fp32 atomics per MFMA (the atomic epilogue was
 // 28 % of wgrad time: profiles/README.md) at unchanged occupancy (1 x 8 waves instead of 2 x 4 per CU).
-template <int TN, int WN, int WK, int kWgGroups>
+// PD: prefetch depth in 32-pixel steps. The operands of steps s+1 .. s+PD are in flight (global -> registers) while step s is
+// multiplied from the LDS. PD 1 left one step (12-16 KB per block) in flight for ~300 cycles of fragment reads + 8-16 MFMAs, far
+// less than the load latency under load: the waves sat in s_waitcnt for 41-59 % of their cycles (profiles/r02_sq_step_summary.txt).
+// Loads are unconditional (masked lanes read the tensor's first bytes and are zeroed on the way into the LDS), so hipcc emits
+// counted vmcnt waits and the younger steps stay in flight across the store of the oldest one.
+template <int TN, int WN, int WK, int kWgGroups, int PD = 3>
 __global__ __launch_bounds__(256 * kWgGroups, kWgGroups == 1 ? 2 : 1) void wgrad_kernel(const WgradParams p) {
   constexpr int TK = 128;
   constexpr int WAVES_K = TK / WK;
@@ -100,70 +129,80 @@ __global__ __launch_bounds__(256 * kWgGroups, kWgGroups == 1 ? 2 : 1) void wgrad
     dh = p.dh0 + tr * p.dh_step;
     dw = p.dw0 + ts * p.dw_step;
   }
-  int xn[2], xoh[2], xow[2];
   const int OHWi = p.OHi * p.OWi;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m_begin + (t >> 4) + 16 * i;
-    const int n = m / OHWi;
-    const int rem = m - n * OHWi;
-    xn[i] = n;
-    xoh[i] = rem / p.OWi;
-    xow[i] = rem - xoh[i] * p.OWi;
-  }
   // ---- dY staging ---------------------------------------------------------------------------------
   const int dv = t % DV;
   const int drow = t / DV;
   const int dn = n0 + dv * 8;
   const bool dn_ok = dn < p.Nout;  // Nout % 8 == 0 is required
 
-  uint4 rx[2], rd[D_IT];
+  u32x4 rx[PD][2], rd[PD][D_IT];
+  unsigned live[PD];  // bit i: rx[i] is a real element; bit 8+i: rd[i] is
 
-  auto load_step = [&](int step) {
+  auto load_step = [&](int step, auto setc) {
+    constexpr int S = decltype(setc)::value;
     const int mb = m_begin + step * 32;
+    unsigned lv = 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      // pixel -> (image, row, column) by exact multiply-shift division: no data-dependent loop in the pipelined body (a
+      // carry loop here made hipcc drain vmcnt to 0 at the loop header)
       const int m = mb + (t >> 4) + 16 * i;
-      const int ih = xoh[i] * p.in_sh + dh, iw = xow[i] * p.in_sw + dw;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (k_ok && m < m_end && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW)
-        v = *reinterpret_cast<const uint4*>(p.x + ((int64_t)((xn[i] * p.IH + ih) * p.IW + iw) * p.x_ld + c0));
-      rx[i] = v;
-      // advance this pixel by 32 for the next step
-      xow[i] += 32;
-      while (xow[i] >= p.OWi) {
-        xow[i] -= p.OWi;
-        ++xoh[i];
-      }
-      while (xoh[i] >= p.OHi) {
-        xoh[i] -= p.OHi;
-        ++xn[i];
-      }
+      const int n = (int)fast_div31((unsigned)m, p.ohw_mul, p.ohw_sh);
+      const int rem = m - n * OHWi;
+      const int oh = (int)fast_div31((unsigned)rem, p.ow_mul, p.ow_sh);
+      const int ow = rem - oh * p.OWi;
+      const int ih = oh * p.in_sh + dh, iw = ow * p.in_sw + dw;
+      const bool ok = k_ok && m < m_end && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+      const int64_t off = ok ? ((int64_t)((n * p.IH + ih) * p.IW + iw) * p.x_ld + c0) : 0;
+      gload16_async(rx[S][i], p.x + off);
+      lv |= (ok ? 1u : 0u) << i;
     }
 #pragma unroll
     for (int i = 0; i < D_IT; ++i) {
       const int row = drow + i * D_ROWS;
       const int m = mb + row;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (row < 32 && dn_ok && m < m_end)
-        v = *reinterpret_cast<const uint4*>(p.dy + ((int64_t)m * p.dy_ld + dn));
-      rd[i] = v;
+      const bool ok = row < 32 && dn_ok && m < m_end;
+      const int64_t off = ok ? ((int64_t)m * p.dy_ld + dn) : 0;
+      gload16_async(rd[S][i], p.dy + off);
+      lv |= (ok ? 1u : 0u) << (8 + i);
     }
+    live[S] = lv;
   };
   // swizzle: 32-B segment index ^= h(px), h(px) = (px&3) | ((px>>1)&4)
-  auto store_step = [&](int buf) {
+  auto store_step = [&](int buf, auto setc) {
+    constexpr int S = decltype(setc)::value;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    // the oldest step in flight has landed when only the PD-1 younger ones are outstanding (2 + D_IT loads per step, every lane)
+    wgrad_wait_vm<(PD - 1) * (2 + D_IT)>();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(rx[S][i]));
+#pragma unroll
+    for (int i = 0; i < D_IT; ++i) asm volatile("" : "+v"(rd[S][i]));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int px = (t >> 4) + 16 * i;
       const int h = (px & 3) | ((px >> 1) & 4);
-      *reinterpret_cast<uint4*>(sX + buf * X_BYTES + px * X_ROWB + ((((xv >> 1) ^ h) & 7) << 5) + (xv & 1) * 16) = rx[i];
+      const bool ok = (live[S] >> i) & 1u;
+      uint4 v;
+      v.x = ok ? rx[S][i][0] : z.x;
+      v.y = ok ? rx[S][i][1] : z.y;
+      v.z = ok ? rx[S][i][2] : z.z;
+      v.w = ok ? rx[S][i][3] : z.w;
+      *reinterpret_cast<uint4*>(sX + buf * X_BYTES + px * X_ROWB + ((((xv >> 1) ^ h) & 7) << 5) + (xv & 1) * 16) = v;
     }
 #pragma unroll
     for (int i = 0; i < D_IT; ++i) {
       const int px = drow + i * D_ROWS;
       if (px < 32) {
         const int h = (px & 3) | ((px >> 1) & 4);
-        *reinterpret_cast<uint4*>(sD + buf * D_BYTES + px * D_ROWB + ((((dv >> 1) ^ h) & D_SEGM) << 5) + (dv & 1) * 16) = rd[i];
+        const bool ok = (live[S] >> (8 + i)) & 1u;
+        uint4 v;
+        v.x = ok ? rd[S][i][0] : z.x;
+        v.y = ok ? rd[S][i][1] : z.y;
+        v.z = ok ? rd[S][i][2] : z.z;
+        v.w = ok ? rd[S][i][3] : z.w;
+        *reinterpret_cast<uint4*>(sD + buf * D_BYTES + px * D_ROWB + ((((dv >> 1) ^ h) & D_SEGM) << 5) + (dv & 1) * 16) = v;
       }
     }
   };
@@ -174,18 +213,11 @@ __global__ __launch_bounds__(256 * kWgGroups, kWgGroups == 1 ? 2 : 1) void wgrad
 #pragma unroll
     for (int b = 0; b < KF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  load_step(0);
-  store_step(0);
-  __syncthreads();
-
   // fragment read geometry (lane-constant): pixel rows 8g+4j+q, 8-B column (lane&3) of the 32-B seg
   const int g = lane >> 4, q = (lane >> 2) & 3;
   const int hsw = q | ((g & 1) << 2);
   const int px0 = 8 * g + q;
-
-  for (int step = 0; step < nsteps; ++step) {
-    const int cur = step & 1;
-    if (step + 1 < nsteps) load_step(step + 1);
+  auto compute = [&](int cur) {
     h16x8 fd[NF], fx[KF];
 #pragma unroll
     for (int a = 0; a < NF; ++a) {
@@ -204,9 +236,43 @@ __global__ __launch_bounds__(256 * kWgGroups, kWgGroups == 1 ? 2 : 1) void wgrad
 #pragma unroll
       for (int b = 0; b < KF; ++b)
         acc[a][b] = CVHIP_MFMA_16X16X32(fd[a], fx[b], acc[a][b], 0, 0, 0);
-    if (step + 1 < nsteps) store_step(cur ^ 1);
+  };
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1 % PD>;
+  using I2 = std::integral_constant<int, 2 % PD>;
+  if constexpr (PD == 3) {
+    // register sets rotate with the step: step s lives in set s % 3; the LDS ring stays two deep
+    load_step(0, I0{});
+    load_step(1, I1{});
+    load_step(2, I2{});
+    store_step(0, I0{});
     __syncthreads();
+    auto body = [&](int step, auto mine, auto next) {
+      load_step(step + 3, mine);  // this step's set was emptied into the LDS one step ago; steps past the end are all-masked
+      compute(step & 1);
+      if (step + 1 < nsteps) store_step((step + 1) & 1, next);
+      __syncthreads();
+    };
+    for (int step = 0; step < nsteps; step += 3) {
+      body(step, I0{}, I1{});
+      if (step + 1 < nsteps) body(step + 1, I1{}, I2{});
+      if (step + 2 < nsteps) body(step + 2, I2{}, I0{});
+    }
+  } else {
+    load_step(0, I0{});
+    store_step(0, I0{});
+    __syncthreads();
+    for (int step = 0; step < nsteps; ++step) {
+      const int cur = step & 1;
+      if (step + 1 < nsteps) load_step(step + 1, I0{});
+      compute(cur);
+      if (step + 1 < nsteps) store_step(cur ^ 1, I0{});
+      __syncthreads();
+    }
   }
+
+  wgrad_wait_vm<0>();  // the all-masked loads issued past the last step must not land in registers the epilogue re-uses
 
   // fold the other groups into group 0 through LDS (the staging rings are dead after the final barrier of the loop): a
   // binary tree, each round the upper half of the live groups parks its accumulators and the lower half adds them
@@ -299,8 +365,19 @@ static int launch_wg(WgradParams& p, hipStream_t stream) {
   splits = cdiv(p.M, mps);
   p.m_per_split = mps;
   // (four groups per block were measured too: 1024-thread blocks in lockstep lose 10-50 % on every YOLOv5-s layer)
-  if (groups >= 2) hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 2>), dim3(tiles * splits), dim3(512), 0, stream, p);
-  else hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 1>), dim3(tiles * splits), dim3(256), 0, stream, p);
+  // Prefetch depth (CVHIP_WGRAD_PD=1/3 forces one): three steps in flight pay for the 64-wide tile (-10...-17 % per launch) but
+  // cost the 128-wide tile a resident block (178 VGPRs: +10 %) and do nothing for the 32-wide one (profiles/r02_wgrad_pd.log)
+  static int pd_force = -1;
+  if (pd_force < 0) {
+    const char* e = getenv("CVHIP_WGRAD_PD");
+    pd_force = e ? atoi(e) : 0;
+  }
+  const int pd = pd_force == 1 || pd_force == 3 ? pd_force : (TN == 64 ? 3 : 1);
+  if (pd == 1) {
+    if (groups >= 2) hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 2, 1>), dim3(tiles * splits), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 1, 1>), dim3(tiles * splits), dim3(256), 0, stream, p);
+  } else if (groups >= 2) hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 2, 3>), dim3(tiles * splits), dim3(512), 0, stream, p);
+  else hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 1, 3>), dim3(tiles * splits), dim3(256), 0, stream, p);
   return check_launch("wgrad_kernel");
 }
 
@@ -331,6 +408,8 @@ int launch_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float*
   p.Ktot = d->R * d->S * d->C;
   p.M = d->N * p.OHi * p.OWi;
   if (p.M <= 0) return CVHIP_OK;
+  div31_consts(p.OHi * p.OWi, &p.ohw_mul, &p.ohw_sh);
+  div31_consts(p.OWi, &p.ow_mul, &p.ow_sh);
   static int tn_max = -1;
   if (tn_max < 0) {
     const char* e = getenv("CVHIP_WGRAD_TNMAX");
