@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-fed leg (H2D inside the timed region)")
     ap.add_argument("--no-graph", action="store_true", help="run the timed steps eagerly instead of replaying a hipGraph")
     ap.add_argument("--stock-optimizer", action="store_true", help="torch.optim.SGD + ModelEMA instead of the fused arena step")
-    ap.add_argument("--sync-bn", action="store_true", help="N > 1 only: HipSyncBN (trainer.py:126-127 converts BN to SyncBN under DDP); the step then runs eagerly")
+    ap.add_argument("--sync-bn", action="store_true", help="N > 1 only: HipSyncBN (trainer.py:126-127 converts BN to SyncBN under DDP); its statistics exchange is captured with the native RCCL transport")
     ap.add_argument("--torch-loss", action="store_true", help="fixed-shape torch-op YOLOv5 loss instead of the fused libcvhip loss kernels")
     return ap.parse_args()
 
@@ -291,7 +291,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "rccl":
-            comm = CM.init_from_env(dev)
+            try:
+                comm = CM.init_from_env(dev)
+            except Exception as e:  # never lose the scaling line to the transport: torch's process group carries the same bucket protocol
+                sys.stderr.write("[bench] native RCCL communicator failed on rank %d (%r): falling back to torch.distributed\n" % (rank, e))
+                dist.init_process_group("nccl")
+                comm = CM.TorchDistComm()
         else:
             dist.init_process_group(backend)
             comm = CM.TorchDistComm()

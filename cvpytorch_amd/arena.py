@@ -113,7 +113,7 @@ class FlatTrainState:
         # wgrad kernels on a side stream (ops._Side): measured no gain on MI355X (YOLOv5-s 3220 -> 3134 img/s, DeepLabv3+ 394 -> 392:
         # every kernel already fills the chip), so it is opt-in: CVHIP_ASYNC_WGRAD=1
         import os
-        ops.enable_async_wgrad(os.environ.get("CVHIP_ASYNC_WGRAD", "0") == "1")
+        ops.enable_async_wgrad(os.environ.get("CVHIP_ASYNC_WGRAD", "0") in ("1", "2"), after_dgrad=os.environ.get("CVHIP_ASYNC_WGRAD", "0") == "2")
         # BatchNorm step counters: one multi-tensor add per step (bricks.bn_tick) instead of one tiny kernel per layer
         self._nbt = []
         for m in model.modules():

@@ -520,7 +520,8 @@ __global__ __launch_bounds__(256, (NST * (BM + (BN < BK ? BK : BN)) * BK * 2 > 8
   if constexpr (FAST && NST == 3) {
     // no DMA is issued past the last tile (the running weight pointers would leave the array), so the last step waits for
     // everything instead of "all but the next tile"
-    stage_fast(0);
+    // a class without taps (1x1 stride-2 dgrad: three of the four pixel parities) has nk == 0: nothing to stage, zeros are stored
+    if (nk > 0) stage_fast(0);
     if (nk > 1) stage_fast(1);
     int st_cur = 0, st_nxt2 = 2;
     for (int kt = 0; kt < nk; ++kt) {
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(256, (NST * (BM + (BN < BK ? BK : BN)) * BK * 2 > 8
       st_nxt2 = st_nxt2 == NST - 1 ? 0 : st_nxt2 + 1;
     }
   } else if constexpr (FAST) {
-    stage_fast(0);
+    if (nk > 0) stage_fast(0);
     for (int kt = 0; kt < nk; ++kt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();

@@ -234,13 +234,15 @@ def _krsc_master(weight):
 # fork/join become parallel branches of the graph.
 class _Side:
     enabled = False
+    after_dgrad = False
     stream = None
     keep = []
     dirty = False
 
 
-def enable_async_wgrad(flag=True):
+def enable_async_wgrad(flag=True, after_dgrad=False):
     _Side.enabled = bool(flag)
+    _Side.after_dgrad = bool(after_dgrad)
 
 
 def _side_begin():
@@ -457,6 +459,7 @@ def _conv_grads(ctx, x, weight, dy, dy_ld, need_dx, need_dw, need_db):
     elif ctx.has_bias and need_db:
         dbias = zero_fill(torch.empty((K,), dtype=torch.float32, device=dev))  # bias before train-mode BN: zero gradient
     dx = dw = None
+    pending_side = None
     direct_w = arena is not None and cfg.gw is not None and tuple(cfg.gw.shape) == tuple(weight.shape)
     if ctx.depthwise:
         desc = conv_desc(N, Cc, H, W, K, R, S, cfg.stride, cfg.pad, cfg.dil, cfg.groups, x_ld, dy_ld)
@@ -480,11 +483,18 @@ def _conv_grads(ctx, x, weight, dy, dy_ld, need_dx, need_dw, need_db):
             padded = (Kp != K) or (Cg != Cc)
             geom = (N, Cc, H, W, K, R, S, P, Q)
             if not padded and direct_w and _Side.enabled and not TIMER.enabled and (not arena.multi or arena.defer_allreduce):
-                # same, on the side stream (see _Side): runs concurrently with the dgrad / BN-backward chain
-                side = _side_begin()
-                with torch.cuda.stream(side):
-                    L.call("cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(), cfg.gw.data_ptr(), 1, side.cuda_stream)
-                _Side.keep.append((x, dy))
+                # same, on the side stream (see _Side): runs concurrently with the BN-backward chain of the layers below. With
+                # _Side.after_dgrad the fork is taken AFTER this layer's dgrad launch, so wgrad (MFMA / LDS bound) shares the chip
+                # with the HBM-bound BN passes that follow instead of with the dgrad kernel (same resources: both slowed down)
+                def side_wgrad(desc=desc):
+                    side = _side_begin()
+                    with torch.cuda.stream(side):
+                        L.call("cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(), cfg.gw.data_ptr(), 1, side.cuda_stream)
+                    _Side.keep.append((x, dy))
+                if _Side.after_dgrad and need_dx:
+                    pending_side = side_wgrad
+                else:
+                    side_wgrad()
             elif not padded and direct_w:
                 # accumulate straight into the parameter's KRSC slot of the flat gradient arena
                 _timed_call(_wgrad_name(Kp, R, S, Cc, N * P * Q, desc), geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(),
@@ -520,9 +530,13 @@ def _conv_grads(ctx, x, weight, dy, dy_ld, need_dx, need_dw, need_db):
                     raise L.CvhipError("GradLink: skip-connection gradient %s does not match the layer input %s" % (tuple(g.shape), (N, Cc, H, W)))
                 _timed_call(_igemm_name(Cc, N * H * W, -(-R // cfg.stride[0]) * -(-S // cfg.stride[1]) * Kp, _pointwise(R, S, cfg), dy_ld), (N, Cc, H, W, K, R, S, P, Q),
                             "cvhip_conv2d_dgrad_add", C.byref(ddesc), dy.data_ptr(), ctx.w_dgrad.data_ptr(), g.data_ptr(), g_ld, dx.data_ptr(), st)
+                if pending_side is not None:
+                    pending_side()
                 return dx, dw, dbias
             _timed_call(_igemm_name(Cc, N * H * W, -(-R // cfg.stride[0]) * -(-S // cfg.stride[1]) * Kp, _pointwise(R, S, cfg), dy_ld), (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv2d_dgrad", C.byref(ddesc), dy.data_ptr(),
                         ctx.w_dgrad.data_ptr(), dx.data_ptr(), st)
+            if pending_side is not None:
+                pending_side()
     if dw is not None and dw.dtype != weight.dtype:
         dw = dw.to(weight.dtype)
     return dx, dw, dbias
