@@ -160,15 +160,26 @@ def test_hip_backbone_v5n_vs_reference_vectors():
         assert rel_l2(f.float(), e) < max(3e-2, 1.5 * fl), (rel_l2(f.float(), e), fl)
     loss = sum((f.float() * c.to(dev())).sum() for f, c in zip(feats, lst(g["cot"])))
     loss.backward()
+    # gradient criteria against the STORAGE EMULATOR (tests/storage_emulator.py: the oracle with the engine's bf16 rounding points
+    # and nothing else; test_gpu_storage_emulator.py shows the engine reproduces it block by block): the engine may be as far from
+    # the fp32 reference vectors as 16-bit storage alone puts the emulator, plus a small margin for rounding-flip divergence
+    import storage_emulator as E
+    em = R.YOLOv5CSPDarknet("cspdark_n")
+    em.load_state_dict({kk: T(v) for kk, v in g["state"].items()}, strict=True)
+    em.train()
+    E.emulate_storage(em, torch.bfloat16)
+    sum((f * c).sum() for f, c in zip(em(T(g["x"])), lst(g["cot"]))).backward()
     gs = m.stem.conv.weight.grad
-    assert cosine(gs.float(), T(g["g_stem"])) > 0.9, cosine(gs.float(), T(g["g_stem"]))
-    bad = []
-    for n, p in m.named_parameters():
+    floor_stem = cosine(em.stem.conv.weight.grad, T(g["g_stem"]))
+    assert cosine(gs.float(), T(g["g_stem"])) > floor_stem - 0.05, (cosine(gs.float(), T(g["g_stem"])), floor_stem)
+    ep = dict(em.named_parameters())
+
+    def off(grad, n):
         ref = float(g["gparam_norms"][n])
-        got = float(p.grad.float().norm())
-        if abs(got - ref) > 0.25 * max(ref, 1e-3):
-            bad.append((n, got, ref))
-    assert len(bad) <= 5, bad[:8]
+        return abs(float(grad.float().norm()) - ref) > 0.25 * max(ref, 1e-3)
+    bad = [n for n, p in m.named_parameters() if off(p.grad, n)]
+    bad_emulator = [n for n in ep if off(ep[n].grad, n)]
+    assert len(bad) <= len(bad_emulator) + 3, (bad[:8], bad_emulator[:8])
 
 
 def test_convert_to_hip_keeps_state_dict_and_matches():
@@ -190,11 +201,9 @@ def test_convert_to_hip_keeps_state_dict_and_matches():
 
 def test_yolov5s_end_to_end_vs_oracle():
     """Full YOLOv5-s: same weights, same synthetic batch (SURVEY §8d config 2 at reduced size) ->
-    loss within 2e-2 relative. End-to-end gradients of a randomly initialised 60-conv network are
-    noise-limited at bf16 storage precision (the oracle itself, run under CPU bf16 autocast, only reaches a
-    median per-parameter cosine of ~0.86 against its own fp32 gradients), so the gradient criterion is
-    stated against that measured floor: the HIP path must be at least as close to fp32 as the CPU-bf16
-    run of the reference arithmetic (minus a 0.03 margin)."""
+    loss and its three terms within 1e-2 relative. End-to-end gradients of a randomly initialised 60-conv network are
+    noise-limited at bf16 storage precision; the gradient criterion is stated against the storage emulator (see below and
+    tests/test_gpu_storage_emulator.py, which proves block by block that the engine computes exactly that rounding model)."""
     from oracle import torch_ref as R
     torch.manual_seed(0)
     ref = R.YOLOv5(80, "s")
@@ -214,7 +223,7 @@ def test_yolov5s_end_to_end_vs_oracle():
     torch.cuda.synchronize()
     for k in ("loss", "box_loss", "obj_loss", "cls_loss"):
         a, b = float(lh[k]), float(lr[k])
-        assert abs(a - b) <= 2e-2 * abs(b) + 1e-4, (k, a, b)
+        assert abs(a - b) <= 1e-2 * abs(b) + 1e-4, (k, a, b)
     rp = dict(ref.named_parameters())
     cos = []
     for n, p in hip.named_parameters():
@@ -222,16 +231,17 @@ def test_yolov5s_end_to_end_vs_oracle():
             continue
         cos.append((cosine(p.grad.float(), rp[n].grad), n))
     cos.sort()
-    import copy
-    ref_bf = R.YOLOv5(80, "s")
-    ref_bf.load_state_dict(sd)
-    ref_bf.train()
-    with torch.autocast("cpu", dtype=torch.bfloat16):
-        lb = ref_bf(imgs, targets, "train")
-    lb["loss"].backward()
-    floor = sorted(cosine(p.grad.float(), rp[n].grad) for n, p in ref_bf.named_parameters())
-    assert np.median([c for c, _ in cos]) > np.median(floor) - 0.03, (np.median([c for c, _ in cos]), np.median(floor), cos[:5])
-    assert cos[0][0] > floor[0] - 0.1, (cos[:5], floor[:5])
+    # the floor is the storage emulator (the oracle + the engine's bf16 rounding points): storage rounding alone puts it at ~0.91
+    # median cosine against fp32; the engine must be within 0.02 of that and its worst parameter within 0.06 of the emulator's worst
+    import storage_emulator as E
+    emu = R.YOLOv5(80, "s")
+    emu.load_state_dict(sd)
+    emu.train()
+    E.emulate_storage(emu, torch.bfloat16)
+    emu(imgs, targets, "train")["loss"].backward()
+    floor = sorted(cosine(p.grad.float(), rp[n].grad) for n, p in emu.named_parameters())
+    assert np.median([c for c, _ in cos]) > np.median(floor) - 0.02, (np.median([c for c, _ in cos]), np.median(floor), cos[:5])
+    assert cos[0][0] > floor[0] - 0.06, (cos[:5], floor[:5])
     # running statistics followed the reference's BatchNorm update
     rb = dict(ref.named_buffers())
     for n, b in hip.named_buffers():
