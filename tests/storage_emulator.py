@@ -213,3 +213,48 @@ def emulate_storage(model, dt=torch.bfloat16, fuse_pairs=True, acc64=False):
             m._emu_dt = dt
             m.forward = types.MethodType(_detect_forward, m)
     return model
+
+
+class _Round16(torch.autograd.Function):
+    """Straight-through 16-bit storage: the value is rounded going forward, the gradient is rounded going backward."""
+
+    @staticmethod
+    def forward(ctx, x, dt):
+        ctx.dt = dt
+        y = x.to(dt).float()
+        return y.clone() if y.data_ptr() == x.data_ptr() else y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dt).float(), None
+
+
+def emulate_storage_generic(model, dt=torch.bfloat16):
+    """A module-type-agnostic approximation for models whose blocks are not ConvModules (ResNet bottlenecks, heads built from plain
+    nn.Conv2d / nn.BatchNorm2d): every convolution, normalisation, activation, pooling and linear module rounds its output (and the
+    gradient arriving at it) to 16 bits. This rounds in a few more places than the engine does (the engine keeps BN + activation in
+    one pass), so it is a slightly PESSIMISTIC estimate of what 16-bit storage alone does to the gradients: good for a floor, not
+    for the block-by-block equality that emulate_storage supports. Weights are rounded through the same op. Returns the model."""
+    kinds = (nn.Conv2d, nn.BatchNorm2d, nn.ReLU, nn.SiLU, nn.LeakyReLU, nn.Sigmoid, nn.Hardswish, nn.MaxPool2d, nn.AvgPool2d,
+             nn.AdaptiveAvgPool2d, nn.Linear, nn.Upsample, nn.UpsamplingNearest2d, R.Swish)
+    def round_out(mod, inp, out, dt=dt):
+        return _Round16.apply(out, dt)
+
+    def round_w(mod, inp, dt=dt):      # the engine multiplies 16-bit weight images; the fp32 master keeps receiving the gradient
+        mod._w_saved = mod.weight.data.clone()
+        mod.weight.data.copy_(mod.weight.data.to(dt).float())
+        return None
+
+    def restore_w(mod, inp, out):
+        mod.weight.data.copy_(mod._w_saved)
+        return None
+
+    for m in model.modules():
+        if isinstance(m, kinds):
+            if getattr(m, "inplace", False):
+                m.inplace = False
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                m.register_forward_pre_hook(round_w)
+                m.register_forward_hook(restore_w)
+            m.register_forward_hook(round_out)
+    return model
