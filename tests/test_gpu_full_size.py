@@ -146,3 +146,67 @@ def test_deeplabv3plus_512x1024_bottlenecks_teacher_forced_vs_oracle():
         if row["out_rel"] > 2e-2 or row["dx_cos"] < 0.99 or row["param_cos_min"] < 0.98:
             bad.append(row)
     assert not bad, bad
+
+
+def test_yolox_s_640_head_maps_and_loss_vs_oracle():
+    """config 4 (coco_yolox_s.yml) at 640x640, batch 4: head maps against the fp32 oracle, and the fused SimOTA loss against the ORACLE's
+    loss evaluated on the engine's own head maps (same inputs -> same assignment: the well-conditioned comparison, see
+    test_gpu_yolox.py)."""
+    from cvpytorch_amd import yolox
+    from oracle import yolox_ref as RX
+    torch.manual_seed(0)
+    ref = RX.YOLOX(80, "s").train()
+    hip = yolox.YOLOX(80, "s", max_labels=20)
+    missing, unexpected = hip.load_state_dict(ref.state_dict(), strict=False)
+    assert not missing and not unexpected
+    imgs, targets = RX.synthetic_batch(4, 640, seed=1029, max_boxes=20)
+    gts = RX.targets_to_padded(targets)
+    with torch.no_grad():
+        maps_ref = ref.head(ref.neck(ref.backbone(imgs)))
+    hip.to(dev()).train()
+    _, feats = hip.forward_features(imgs.to(dev()))
+    maps_hip = [f.view(f.shape[0], h, w, -1).permute(0, 3, 1, 2) for f, (h, w) in zip(feats, hip._hw)]
+    for a, b in zip(maps_hip, maps_ref):
+        assert tuple(a.shape) == tuple(b.shape)
+        assert rel_l2(a.float(), b) < 5e-2, rel_l2(a.float(), b)
+    lh = hip.loss_from_features(feats, gts.to(dev()))
+    lo = RX.YOLOXLoss(80)([m.detach().float().cpu().contiguous() for m in maps_hip], gts)
+    for k in ("loss", "iou_loss", "conf_loss", "cls_loss"):
+        assert abs(float(lh[k]) - float(lo[k])) <= 1e-3 * abs(float(lo[k])) + 1e-5, (k, float(lh[k]), float(lo[k]))
+    lh["loss"].backward()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p.grad).all() for p in hip.parameters() if p.grad is not None)
+
+
+def test_yolov7l_1280_fp16_step_vs_oracle_loss():
+    """config 5 (coco_yolov7.yml): YOLOv7-l, 1280x1280, fp16 storage with a loss scale, batch 2: loss terms against the fp32 oracle's
+    forward, finite scaled gradients for every parameter."""
+    from cvpytorch_amd import ops, yolov7
+    from oracle import torch_ref as R
+    from oracle import yolov7_ref as R7
+    torch.manual_seed(0)
+    ref = R7.YOLOv7(80, width_mul=1.0).train()
+    imgs, targets = R.synthetic_batch(2, 1280, seed=1029, max_boxes=20)
+    with torch.no_grad():
+        lr = ref(imgs, targets, "train")
+    ops.set_precision("fp16")
+    try:
+        hip = yolov7.YOLOv7(80, width_mul=1.0, max_targets=2 * 20)
+        missing, unexpected = hip.load_state_dict(ref.state_dict(), strict=False)
+        assert all(k.startswith("loss.") for k in missing) and not unexpected
+        hip.to(dev()).train()
+        tg = [{k: v.to(dev()) for k, v in t.items()} for t in targets]
+        lh = hip(imgs.to(dev()), tg, "train")
+        (lh["loss"] * 1024.0).backward()
+        torch.cuda.synchronize()
+        for k in ("loss", "box_loss", "obj_loss", "cls_loss"):
+            a, b = float(lh[k]), float(lr[k])
+            assert abs(a - b) <= 2e-2 * abs(b) + 1e-4, (k, a, b)
+        n_grad = 0
+        for n, p in hip.named_parameters():
+            if p.grad is not None:
+                assert torch.isfinite(p.grad).all(), n
+                n_grad += 1
+        assert n_grad > 200
+    finally:
+        ops.set_precision("bf16")
