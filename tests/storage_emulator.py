@@ -193,14 +193,25 @@ def _detect_forward(self, x):
     return None, x
 
 
+def _v7conv_forward(self, x):
+    # oracle/yolov7_ref.py Conv: conv -> bn -> SiLU | Identity
+    kind = "silu" if isinstance(self.act, nn.SiLU) else "none"
+    meta = _meta(self.conv, self.bn, kind, 0.0, self._emu_dt, acc64=self._emu_acc64)
+    return QConvBnAct.apply(x, self.conv.weight, None, self.bn.weight, self.bn.bias, None, meta)
+
+
 def emulate_storage(model, dt=torch.bfloat16, fuse_pairs=True, acc64=False):
     """Patch an ORACLE model (oracle/torch_ref.py classes) in place so that its training forward/backward rounds where the engine
     rounds. Returns the model. acc64=True keeps every rounding point but evaluates the convolution sums in fp64 (then fp32): a second
     REALISATION of the same storage format whose pre-rounding values differ from the default one by fp32 summation order only —
     the experiment that measures how far two exact implementations of the same rounding points can agree at all."""
+    from oracle import yolov7_ref as R7
     for m in model.modules():
         m._emu_acc64 = acc64
-        if isinstance(m, R.ConvModule):
+        if isinstance(m, R7.Conv):
+            m._emu_dt = dt
+            m.forward = types.MethodType(_v7conv_forward, m)
+        elif isinstance(m, R.ConvModule):
             assert m.order == ("conv", "norm", "act")
             m._emu_dt = dt
             m.forward = types.MethodType(_convmodule_forward, m)

@@ -1,4 +1,3 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 900 python tools/emu_blocks.py > gpurun_out/h_blocks.log 2>&1
-grep -v Warning gpurun_out/h_blocks.log | tail -80
+timeout 1200 python -m pytest tests/test_gpu_storage_emulator.py -m gpu -q -k yolov7l 2>&1 | grep -E "^E  |assert" | cut -c1-900 | head
