@@ -216,7 +216,7 @@ def test_every_block_teacher_forced_matches_the_emulator(precision, kind, min_bl
     for r in rows:
         single = r["kind"] in ("ConvModule", "Conv")      # one layer: only its own output rounding can flip; a block chains up to 9 layers
         cos_min = 0.99999 if single else 0.9995
-        if (r["out_rel"] > (0.1 if single else 4.0) * ulp or r["param_cos_min"] < cos_min or (r["dx_cos"] is not None and r["dx_cos"] < cos_min)):
+        if (r["out_rel"] > (0.3 if single else 4.0) * ulp or r["param_cos_min"] < cos_min or (r["dx_cos"] is not None and r["dx_cos"] < cos_min)):
             bad.append(r)
     assert not bad, bad
 
