@@ -290,6 +290,9 @@ def main():
     comm = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ.get("LOCAL_WORLD_SIZE", str(world)) == str(world):
+            # one node: RCCL's bootstrap sockets on loopback (the container's hostname / outward interface may not be usable)
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         if backend == "rccl":
             try:
                 comm = CM.init_from_env(dev)
