@@ -329,6 +329,12 @@ int64_t cvhip_conv2d_dgrad_weight_elems(const cvhip_conv_desc* d) {
   return e;
 }
 
+int cvhip_div31_consts(int32_t d, uint32_t* mul, uint32_t* shift) {
+  if (d < 1 || !mul || !shift) return CVHIP_ERR_INVALID;
+  div31_consts(d, mul, shift);
+  return CVHIP_OK;
+}
+
 int cvhip_conv2d_dgrad_plan(const cvhip_conv_desc* d, int32_t* out, int max_classes) {
   int st = validate_dense_desc(d);
   if (st) return st;

@@ -79,6 +79,7 @@ SIGNATURES = {
     "cvhip_probe_grid_barrier": (_i32, [_i32, _i32, _i32, _p, _p, _p, _p]),
     "cvhip_conv2d_dgrad_weight_elems": (_i64, [_dp]),
     "cvhip_conv2d_dgrad_plan": (_i32, [_dp, C.POINTER(_i32), _i32]),
+    "cvhip_div31_consts": (_i32, [_i32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "cvhip_conv2d_prep_weights": (_i32, [_dp, _p, _p, _p, _p]),
     "cvhip_prep_plan_item_bytes": (_i32, []),
     "cvhip_prep_plan_build": (_i32, [_p, _i32, _p, C.POINTER(_i32)]),

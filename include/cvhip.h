@@ -106,6 +106,9 @@ int64_t cvhip_conv2d_dgrad_weight_elems(const cvhip_conv_desc* d);
 /* per class: {TR, TS, r0, r_step, dh0, dh_step, s0, s_step, dw0, dw_step, w_offset(elems, 2 x int32 lo/hi)} = 12 int32 */
 #define CVHIP_DGRAD_CLASS_INTS 12
 int cvhip_conv2d_dgrad_plan(const cvhip_conv_desc* d, int32_t* out_classes, int max_classes);
+/* The multiply-shift constants the conv kernels use to split a pixel index into (image, row, column) without integer division:
+ * for 0 <= n < 2^31,  n / d == (mul ? umulhi(n, mul) >> shift : n)  exactly (d == 1 -> mul = 0). */
+int cvhip_div31_consts(int32_t d, uint32_t* mul, uint32_t* shift);
 
 /* Derive the bf16 operand images from the fp32 KRSC master weights.
  *   w_fprop : bf16 [K][R*S*C]              (also the wgrad output layout)

@@ -182,3 +182,25 @@ def test_dgrad_plan_interpreted_matches_torch(H, W, R, S, stride, pad, dil):
     dd = desc(N, Cc, H, W, K, R, S, stride, pad, dil)
     got = interpret_dgrad(dd, dy.permute(0, 2, 3, 1).numpy(), w.permute(0, 2, 3, 1).numpy())
     np.testing.assert_allclose(got, gx.detach().permute(0, 2, 3, 1).numpy(), rtol=1e-10, atol=1e-10)
+
+
+def test_div31_constants_divide_exactly():
+    """conv_plan.h div31_consts / fast_div31: q = umulhi(n, mul) >> shift must equal n // d for every 0 <= n < 2^31 the kernels
+    can meet (pixel indices) — checked at the edges of every quotient step near 2^31, at small n, and on random draws."""
+    import random
+    lib = L.load()
+    rng = random.Random(1029)
+    ds = [1, 2, 3, 5, 7, 20, 25, 40, 80, 160, 320, 400, 1600, 6400, 25600, 102400, 409600, 1 << 16, (1 << 16) + 1, 999983, (1 << 30) - 1, 1 << 30, (1 << 31) - 1]
+    ds += [rng.randrange(1, 1 << 22) for _ in range(200)]
+    for d in ds:
+        mul, sh = C.c_uint32(), C.c_uint32()
+        assert lib.cvhip_div31_consts(d, C.byref(mul), C.byref(sh)) == 0
+        m, s = mul.value, sh.value
+        assert (m == 0) == (d == 1)
+        top = (1 << 31) - 1
+        ns = [0, 1, d - 1, d, d + 1, top, top - 1, (top // d) * d, max((top // d) * d - 1, 0)]
+        ns += [rng.randrange(0, 1 << 31) for _ in range(300)] + [k * d + o for k in (1, 2, 1000, top // d - 1) for o in (-1, 0, 1) if 0 <= k * d + o <= top]
+        for n in ns:
+            q = n if m == 0 else ((n * m) >> 32) >> s
+            assert q == n // d, (d, n, q, n // d, m, s)
+    assert lib.cvhip_div31_consts(0, C.byref(mul), C.byref(sh)) == L.ERR_INVALID
