@@ -14,7 +14,13 @@ constexpr int kRedRowsPerBlockMin = 64;
 
 static inline int colreduce_rows_host(int64_t M, int32_t C) {
   (void)C;
-  int64_t b = cdiv64(M, kRedRowsPerBlockMin);
+  static int min_rows = -1;
+  if (min_rows < 0) {
+    const char* e = getenv("CVHIP_RED_MINROWS");  // rows per block of the streaming reductions (A/B switch)
+    min_rows = e ? atoi(e) : kRedRowsPerBlockMin;
+    if (min_rows < 1) min_rows = kRedRowsPerBlockMin;
+  }
+  int64_t b = cdiv64(M, min_rows);
   if (b > kRedBlocksMax) b = kRedBlocksMax;
   if (b < 1) b = 1;
   return (int)b;
