@@ -23,7 +23,7 @@ SOURCES = [
     "weights_optim.hip",
     "dwconv.hip",
     "post.hip",
-    "loss_kernels.hip", "yolo_loss.hip", "simota_loss.hip", "conv1x1_stream.hip", "conv_stem.hip", "conv1x1_bwd.hip", "comm.hip", "post_batch.hip", "ota_assign.hip",
+    "loss_kernels.hip", "yolo_loss.hip", "simota_loss.hip", "conv1x1_stream.hip", "conv_stem.hip", "conv1x1_bwd.hip", "comm.hip", "post_batch.hip", "ota_assign.hip", "probes.hip",
 ]
 FLAGS = [
     "--offload-arch=gfx950",
@@ -51,7 +51,7 @@ def _newer(target, deps):
 
 # sources without 16-bit operands are compiled once; every other source a second time with -DCVHIP_F16 (fp16 storage,
 # entry points suffixed _f16: csrc/common.h, csrc/f16_names.h)
-SINGLE_PRECISION = ("comm.hip", "post_batch.hip")
+SINGLE_PRECISION = ("comm.hip", "post_batch.hip", "probes.hip")
 
 
 def _compile(job):

@@ -1,0 +1,219 @@
+// probes.hip — machine-ceiling micro-benchmarks for gfx950 (dev tools; tools/ceilings_probe.py prints the table kept in
+// profiles/). They answer ONE question each, with the issue pattern MI355X_MICROARCH.md prescribes, so that design arguments in
+// DESIGN.md rest on what the box delivers and not on what an earlier kernel happened to reach:
+//   lds_read2   : ds_read_b128 / ds_read_b64 rate with >= 16 DS operations per s_waitcnt lgkmcnt(0), 4..16 waves per CU
+//   mfma_peak2  : back-to-back MFMA issue (32x32x16 or 16x16x32), 1 or 2 waves per SIMD, zero / small / random operands (DVFS)
+//   load_path   : bytes per clock per CU delivered by (0) global_load_lds_dwordx4, (1) global_load_dwordx4 -> VGPR,
+//                 (2) global_load_dwordx4 -> VGPR -> ds_write_b128, from an L2-resident or an HBM-sized source
+//   atomic_f64  : cost of per-block fp64 atomics into sharded per-channel accumulators (BN statistics without finalize launches)
+// Compiled once (no 16-bit typed entry points: listed in build.py SINGLE_PRECISION / tools/gen_f16_names.py SINGLE).
+#include "common.h"
+
+namespace cvhip {
+
+// ---- LDS read rate ------------------------------------------------------------------------------------------------------
+// MODE 0: 16 x ds_read_b128, lane-linear (conflict-free by construction)      -> 16 KiB per wave per trip
+// MODE 1: 16 x ds_read_b128 in the implicit GEMM's fragment pattern (64-B rows, row = lane & 15, XOR-swizzled 16-B slot)
+// MODE 2: 16 x ds_read_b64, lane-linear                                       ->  8 KiB per wave per trip
+template <int MODE>
+__global__ __launch_bounds__(1024) void probe_lds2_kernel(float* out, int iters) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[32768];
+  const int t = threadIdx.x, lane = t & 63;
+  for (int i = t; i < 32768 / 4; i += blockDim.x) reinterpret_cast<unsigned*>(smem)[i] = i * 2654435761u;
+  __syncthreads();
+  unsigned addr;
+  if (MODE == 1) {
+    const int swz = (lane >> 4) ^ ((0x78 >> (2 * ((lane >> 2) & 3))) & 3);
+    addr = (unsigned)(uintptr_t)smem + (lane & 15) * 64 + swz * 16;  // + j * 1024 (16 rows of 64 B) per read
+  } else if (MODE == 2) {
+    addr = (unsigned)(uintptr_t)smem + lane * 8;
+  } else {
+    addr = (unsigned)(uintptr_t)smem + lane * 16;
+  }
+  unsigned acc = 0;
+  for (int it = 0; it < iters; ++it) {
+    if (MODE == 2) {
+      uint2 r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, ra, rb, rc, rd, re, rf;
+      asm volatile(
+          "ds_read_b64 %0, %16\n ds_read_b64 %1, %16 offset:512\n ds_read_b64 %2, %16 offset:1024\n ds_read_b64 %3, %16 offset:1536\n"
+          "ds_read_b64 %4, %16 offset:2048\n ds_read_b64 %5, %16 offset:2560\n ds_read_b64 %6, %16 offset:3072\n ds_read_b64 %7, %16 offset:3584\n"
+          "ds_read_b64 %8, %16 offset:4096\n ds_read_b64 %9, %16 offset:4608\n ds_read_b64 %10, %16 offset:5120\n ds_read_b64 %11, %16 offset:5632\n"
+          "ds_read_b64 %12, %16 offset:6144\n ds_read_b64 %13, %16 offset:6656\n ds_read_b64 %14, %16 offset:7168\n ds_read_b64 %15, %16 offset:7680\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7), "=&v"(r8), "=&v"(r9), "=&v"(ra),
+            "=&v"(rb), "=&v"(rc), "=&v"(rd), "=&v"(re), "=&v"(rf)
+          : "v"(addr)
+          : "memory");
+      acc ^= r0.x ^ r5.y ^ rf.x;
+    } else {
+      uint4 r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, ra, rb, rc, rd, re, rf;
+      asm volatile(
+          "ds_read_b128 %0, %16\n ds_read_b128 %1, %16 offset:1024\n ds_read_b128 %2, %16 offset:2048\n ds_read_b128 %3, %16 offset:3072\n"
+          "ds_read_b128 %4, %16 offset:4096\n ds_read_b128 %5, %16 offset:5120\n ds_read_b128 %6, %16 offset:6144\n ds_read_b128 %7, %16 offset:7168\n"
+          "ds_read_b128 %8, %16 offset:8192\n ds_read_b128 %9, %16 offset:9216\n ds_read_b128 %10, %16 offset:10240\n ds_read_b128 %11, %16 offset:11264\n"
+          "ds_read_b128 %12, %16 offset:12288\n ds_read_b128 %13, %16 offset:13312\n ds_read_b128 %14, %16 offset:14336\n ds_read_b128 %15, %16 offset:15360\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7), "=&v"(r8), "=&v"(r9), "=&v"(ra),
+            "=&v"(rb), "=&v"(rc), "=&v"(rd), "=&v"(re), "=&v"(rf)
+          : "v"(addr)
+          : "memory");
+      acc ^= r0.x ^ r5.y ^ rf.w;
+    }
+  }
+  if (acc == 0x12345678u) out[blockIdx.x] = 1.f;
+}
+
+// ---- MFMA issue rate ----------------------------------------------------------------------------------------------------
+// SHAPE 0: v_mfma_f32_32x32x16 (8 independent accumulators)   SHAPE 1: v_mfma_f32_16x16x32 (16 independent accumulators)
+// data: 0 = zero operands, 1 = small integers, 2 = hashed full-range values in [-1, 1) (what a real kernel's clock sees)
+template <int SHAPE>
+__global__ __launch_bounds__(512) void probe_mfma2_kernel(float* out, int iters, int data) {
+  const int l = threadIdx.x + blockIdx.x * 977;
+  h16x8 a, b;
+  for (int e = 0; e < 8; ++e) {
+    float fa = 0.f, fb = 0.f;
+    if (data == 1) {
+      fa = (float)((l * 7 + e * 3) % 17 - 8);
+      fb = (float)((l * 5 + e) % 13 - 6);
+    } else if (data == 2) {
+      const unsigned ha = (unsigned)(l * 8 + e) * 2654435761u, hb = (unsigned)(l * 8 + e + 77) * 2246822519u;
+      fa = (float)(int)(ha >> 8) * (1.f / 8388608.f) - 1.f;
+      fb = (float)(int)(hb >> 8) * (1.f / 8388608.f) - 1.f;
+    }
+    a[e] = (h16_t)fa;
+    b[e] = (h16_t)fb;
+  }
+  float s = 0.f;
+  if (SHAPE == 0) {
+    f32x16 c[8];
+    for (int j = 0; j < 8; ++j)
+      for (int e = 0; e < 16; ++e) c[j][e] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) c[j] = CVHIP_MFMA_32X32X16(a, b, c[j], 0, 0, 0);
+    }
+    for (int j = 0; j < 8; ++j)
+      for (int e = 0; e < 16; ++e) s += c[j][e];
+  } else {
+    f32x4 c[16];
+    for (int j = 0; j < 16; ++j) c[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) c[j] = CVHIP_MFMA_16X16X32(a, b, c[j], 0, 0, 0);
+    }
+    for (int j = 0; j < 16; ++j) s += c[j][0] + c[j][1] + c[j][2] + c[j][3];
+  }
+  if (s == 123456.789f) out[blockIdx.x] = s;
+}
+
+// ---- global -> on-chip load path ------------------------------------------------------------------------------------------
+// Every wave moves `iters` batches of D x 1 KiB (64 lanes x 16 B, full 128-byte lines) and waits for the batch; with 4-16 waves per
+// CU the batches of different waves overlap, which is how the implicit GEMM's ring behaves. `span` (bytes, power of two): the
+// region a block walks — small (<= 1 MiB, shared by all blocks) = L2-resident after the first touch, large = HBM streaming.
+template <int MODE, int D>
+__global__ __launch_bounds__(1024) void probe_load_kernel(const unsigned char* __restrict__ src, size_t span, size_t block_stride,
+                                                          int iters, float* out) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[65536];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int nw = blockDim.x >> 6;
+  const unsigned char* base = src + (size_t)blockIdx.x * block_stride;
+  unsigned char* my = smem + ((wave * D * 1024) & 65535);
+  unsigned acc = 0;
+  size_t off = (size_t)wave * D * 1024;
+  for (int it = 0; it < iters; ++it) {
+    if (MODE == 0) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const unsigned char* g = base + ((off + d * 1024 + lane * 16) & (span - 1));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(my + d * 1024), 16, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      uint4 v[D];
+#pragma unroll
+      for (int d = 0; d < D; ++d) v[d] = *reinterpret_cast<const uint4*>(base + ((off + d * 1024 + lane * 16) & (span - 1)));
+      if (MODE == 2) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) *reinterpret_cast<uint4*>(my + d * 1024 + lane * 16) = v[d];
+      } else {
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc ^= v[d].x ^ v[d].w;
+      }
+    }
+    off += (size_t)nw * D * 1024;
+  }
+  if (MODE == 2) {
+    __syncthreads();
+    acc ^= reinterpret_cast<const unsigned*>(smem)[t];
+  }
+  if (acc == 0x12345678u) out[blockIdx.x] = 1.f;
+}
+
+// ---- fp64 atomics into sharded accumulators --------------------------------------------------------------------------------
+// block b adds `n` values (n <= 256: threads t < n) into acc[(b % shards) * n + t]: the traffic of a conv epilogue that folds its
+// tile's BatchNorm sums (2 x K values) straight into per-layer accumulators. F32 != 0: the same with fp32 atomics.
+template <int F32>
+__global__ __launch_bounds__(256) void probe_atomic_kernel(void* acc, int shards, int n) {
+  const int t = threadIdx.x;
+  if (t >= n) return;
+  const size_t i = (size_t)(blockIdx.x % shards) * n + t;
+  if (F32) unsafeAtomicAdd(reinterpret_cast<float*>(acc) + i, 1.0f + (float)t);
+  else unsafeAtomicAdd(reinterpret_cast<double*>(acc) + i, 1.0 + (double)t);
+}
+
+}  // namespace cvhip
+
+using namespace cvhip;
+
+extern "C" {
+
+int cvhip_probe_lds_read2(int32_t mode, int32_t iters, int32_t blocks, int32_t threads, float* out, void* stream) {
+  if (!out || iters <= 0 || blocks <= 0 || threads < 64 || threads > 1024 || threads % 64) return CVHIP_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  switch (mode) {
+    case 0: hipLaunchKernelGGL(probe_lds2_kernel<0>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
+    case 1: hipLaunchKernelGGL(probe_lds2_kernel<1>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
+    case 2: hipLaunchKernelGGL(probe_lds2_kernel<2>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
+    default: return CVHIP_ERR_INVALID;
+  }
+  return check_launch("probe_lds2_kernel");
+}
+
+int cvhip_probe_mfma_peak2(int32_t shape, int32_t data, int32_t iters, int32_t blocks, int32_t threads, float* out, void* stream) {
+  if (!out || iters <= 0 || blocks <= 0 || threads < 64 || threads > 512 || threads % 64 || data < 0 || data > 2) return CVHIP_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  if (shape == 0) hipLaunchKernelGGL(probe_mfma2_kernel<0>, dim3(blocks), dim3(threads), 0, st, out, iters, data);
+  else if (shape == 1) hipLaunchKernelGGL(probe_mfma2_kernel<1>, dim3(blocks), dim3(threads), 0, st, out, iters, data);
+  else return CVHIP_ERR_INVALID;
+  return check_launch("probe_mfma2_kernel");
+}
+
+int cvhip_probe_load_path(int32_t mode, int32_t depth, const void* src, int64_t span, int64_t block_stride, int32_t iters, int32_t blocks,
+                          int32_t threads, float* out, void* stream) {
+  if (!src || !out || iters <= 0 || blocks <= 0 || threads < 64 || threads > 1024 || threads % 64) return CVHIP_ERR_INVALID;
+  if (span < 65536 || (span & (span - 1)) || block_stride < 0) return CVHIP_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned char* s = (const unsigned char*)src;
+#define CVHIP_PL(M, D) hipLaunchKernelGGL((probe_load_kernel<M, D>), dim3(blocks), dim3(threads), 0, st, s, (size_t)span, (size_t)block_stride, iters, out)
+  if (depth == 4) {
+    if (mode == 0) CVHIP_PL(0, 4); else if (mode == 1) CVHIP_PL(1, 4); else if (mode == 2) CVHIP_PL(2, 4); else return CVHIP_ERR_INVALID;
+  } else if (depth == 8) {
+    if (mode == 0) CVHIP_PL(0, 8); else if (mode == 1) CVHIP_PL(1, 8); else if (mode == 2) CVHIP_PL(2, 8); else return CVHIP_ERR_INVALID;
+  } else {
+    return CVHIP_ERR_INVALID;
+  }
+#undef CVHIP_PL
+  return check_launch("probe_load_kernel");
+}
+
+int cvhip_probe_atomic_add(int32_t f32, void* acc_zeroed, int32_t shards, int32_t n, int32_t blocks, void* stream) {
+  if (!acc_zeroed || shards <= 0 || n <= 0 || n > 256 || blocks <= 0) return CVHIP_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  if (f32) hipLaunchKernelGGL(probe_atomic_kernel<1>, dim3(blocks), dim3(256), 0, st, acc_zeroed, shards, n);
+  else hipLaunchKernelGGL(probe_atomic_kernel<0>, dim3(blocks), dim3(256), 0, st, acc_zeroed, shards, n);
+  return check_launch("probe_atomic_kernel");
+}
+
+}  // extern "C"

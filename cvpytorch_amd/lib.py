@@ -173,6 +173,10 @@ SIGNATURES = {
     "cvhip_probe_ds_read_tr16": (_i32, [_p, _p, _p]),
     "cvhip_probe_lds_read_bw": (_i32, [_i32, _i32, _i32, _p, _p]),
     "cvhip_probe_mfma_peak": (_i32, [_i32, _i32, _p, _p]),
+    "cvhip_probe_lds_read2": (_i32, [_i32, _i32, _i32, _i32, _p, _p]),
+    "cvhip_probe_mfma_peak2": (_i32, [_i32, _i32, _i32, _i32, _i32, _p, _p]),
+    "cvhip_probe_load_path": (_i32, [_i32, _i32, _p, _i64, _i64, _i32, _i32, _i32, _p, _p]),
+    "cvhip_probe_atomic_add": (_i32, [_i32, _p, _i32, _i32, _i32, _p]),
 }
 
 _lib = None

@@ -580,6 +580,19 @@ int cvhip_probe_lds_read_bw(int32_t mode, int32_t iters, int32_t blocks, float* 
 /* MFMA issue-rate probe (bench.py's measured attainable peak beside the nominal 2.5 PFLOP/s): `blocks` x 4 waves run `iters`
  * rounds of 8 independent v_mfma_f32_32x32x16_bf16 on register operands; flops = blocks*4*iters*8*32768. `out`: >= blocks floats. */
 int cvhip_probe_mfma_peak(int32_t iters, int32_t blocks, float* out, void* stream);
+/* Machine-ceiling probes (csrc/probes.hip, tools/ceilings_probe.py -> profiles/r03_ceilings_probe.log). `out`: >= blocks floats.
+ * lds_read2 : mode 0 = 16 lane-linear ds_read_b128 per s_waitcnt lgkmcnt(0), 1 = the implicit GEMM's swizzled fragment pattern,
+ *             2 = 16 lane-linear ds_read_b64; bytes per launch = blocks * (threads / 64) * iters * 16 KiB (8 KiB for mode 2).
+ * mfma_peak2: shape 0 = v_mfma_f32_32x32x16 x 8 accumulators, 1 = v_mfma_f32_16x16x32 x 16 accumulators per round; data 0 zero /
+ *             1 small integers / 2 full-range values; flops = blocks * (threads / 64) * iters * 8 * 32768 (16 * 16384 for shape 1).
+ * load_path : mode 0 global_load_lds_dwordx4, 1 global_load_dwordx4 -> VGPR, 2 the same + ds_write_b128; every wave moves `iters`
+ *             batches of `depth` (4 | 8) KiB from the `span`-byte (power of two) window at src + block * block_stride.
+ * atomic_add: `blocks` blocks each add n (<= 256) values into acc[(block % shards) * n ...] with fp64 (f32 = 0) or fp32 atomics. */
+int cvhip_probe_lds_read2(int32_t mode, int32_t iters, int32_t blocks, int32_t threads, float* out, void* stream);
+int cvhip_probe_mfma_peak2(int32_t shape, int32_t data, int32_t iters, int32_t blocks, int32_t threads, float* out, void* stream);
+int cvhip_probe_load_path(int32_t mode, int32_t depth, const void* src, int64_t span, int64_t block_stride, int32_t iters, int32_t blocks,
+                          int32_t threads, float* out, void* stream);
+int cvhip_probe_atomic_add(int32_t f32, void* acc_zeroed, int32_t shards, int32_t n, int32_t blocks, void* stream);
 
 #ifdef __cplusplus
 }
