@@ -1,6 +1,12 @@
 """bench.py — images/sec of one full YOLOv5-s train step (BASELINE.json metric) on N MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: either torch.distributed.run starts the N ranks (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment: the driver's
+form, reference README.md:127 `python -m torch.distributed.launch --nproc_per_node=N trainer.py`), or — when WORLD_SIZE is not
+set — bench.py starts them itself (one child process per GPU, same arguments, loopback rendezvous). Rank 0 prints the line.
+`--dry-launch` stops after the rendezvous: every rank joins, the world size is agreed through one all-reduce, rank 0 prints
+{"dry_launch": true, "world": N, ...}; with CVHIP_DIST_BACKEND=gloo it needs no GPU (tests/test_bench_launch.py).
 
 Step (mirrors trainer_det_yolov5.py:145-207 between timer.tic :379 and timer.toc :382): forward ->
 loss -> backward (+ bucketed RCCL gradient all-reduce) -> SGD(nesterov) -> zero_grad -> EMA, on a
@@ -23,6 +29,9 @@ Extra objects:
 import argparse
 import json
 import os
+import signal
+import socket
+import subprocess
 import sys
 import time
 
@@ -53,7 +62,84 @@ def parse():
     ap.add_argument("--stock-optimizer", action="store_true", help="torch.optim.SGD + ModelEMA instead of the fused arena step")
     ap.add_argument("--sync-bn", action="store_true", help="N > 1 only: HipSyncBN (trainer.py:126-127 converts BN to SyncBN under DDP); its statistics exchange is captured with the native RCCL transport")
     ap.add_argument("--torch-loss", action="store_true", help="fixed-shape torch-op YOLOv5 loss instead of the fused libcvhip loss kernels")
+    ap.add_argument("--dry-launch", action="store_true", help="start the ranks, agree on the world size, print it, exit (no workload)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the side workloads (BASELINE configs 4 and 5 at N = 1, DeepLabv3+ OS-8)")
+    ap.add_argument("--no-sync-bn-leg", action="store_true", help="N > 1: skip the extra K steps with SyncBN on (trainer.py:126-127)")
+    ap.add_argument("--allow-torch-dist", action="store_true", help="N > 1: if the native RCCL communicator cannot start, run over torch.distributed "
+                    "(hipified ProcessGroupNCCL) and SAY SO in config.transport instead of failing")
     return ap.parse_args()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (what `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N` would do), forward rank 0's line, fail if any rank fails."""
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("MASTER_PORT", str(_free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(a.gpus)
+    procs = []
+    for r in range(a.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    deadline = time.time() + float(os.environ.get("CVHIP_BENCH_LAUNCH_TIMEOUT", "1800"))
+    try:
+        while procs and time.time() < deadline:
+            for pr in list(procs):
+                code = pr.poll()
+                if code is None:
+                    continue
+                procs.remove(pr)
+                if code != 0:       # one rank died: the others would wait in a collective forever
+                    rc = rc or code
+                    for q in procs:
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for q in procs:
+            q.kill()
+            rc = rc or 124
+    raise SystemExit(rc)
+
+
+def dry_launch(world, rank, backend):
+    """Rendezvous only: proves that N ranks start, find each other and agree on the world size."""
+    info = {"dry_launch": True, "backend": backend}
+    if backend == "rccl":
+        from cvpytorch_amd import comm as CM
+        from cvpytorch_amd import lib as L
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(dev)
+        comm = CM.init_from_env(dev)
+        t = torch.ones(1, device=dev)
+        comm.allreduce_(t)
+        torch.cuda.synchronize()
+        seen = int(t.item())
+        info.update(world=comm.world, rccl_version=int(L.load().cvhip_comm_rccl_version()), transport="rccl-native (cvhip_comm_*)")
+        comm.close()
+    else:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend)
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        info.update(world=dist.get_world_size(), transport="torch.distributed/%s (test transport)" % backend)
+        dist.destroy_process_group()
+    info["ranks_seen"] = seen
+    if seen != world:
+        raise SystemExit("dry launch: %d ranks answered, WORLD_SIZE is %d" % (seen, world))
+    if rank == 0:
+        print(json.dumps(info), flush=True)
 
 
 def _cpu_model():
@@ -113,37 +199,115 @@ def cpu_baseline(size, cpu_batch, budget_s=12.0, max_threads=32):
                       % (size, size, b, n, el, threads, os.cpu_count() or 1, b1, n1, el1)}
 
 
-def deeplab_workload(dev, a, batch=16, size=(512, 1024), steps=20, warmup=3):
+def _median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+
+
+def timed_steps(step, imgs, gts, steps, barrier=None):
+    """Time EXACTLY `steps` steps between barrier + torch.cuda.synchronize() on both sides (wall clock: the contract's `value`), and
+    every step on its own with HIP events recorded on the launch stream between the steps (no host synchronisation inside the
+    region): SURVEY.md §8(d) asks for the MEDIAN over the timed iterations (trainer.py:379-392 times each iteration)."""
+    sync = barrier if barrier is not None else torch.cuda.synchronize
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    sync()
+    t0 = time.perf_counter()
+    evs[0].record()
+    for i in range(steps):
+        losses = step(imgs, gts)
+        evs[i + 1].record()
+    sync()
+    el = time.perf_counter() - t0
+    per = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+    return el, losses, _median(per), per
+
+
+def _graph_step(step, imgs, gts, warmup, graph=True):
+    for _ in range(warmup):
+        step(imgs, gts)
+    if graph:
+        step.capture(imgs, gts)
+        imgs, gts = step.static_imgs, step.static_targets
+        for _ in range(2):
+            step(imgs, gts)
+    return imgs, gts
+
+
+def _side_result(name, batch, steps, warmup, el, med, losses, flops_img, bytes_img, graph, extra=None):
+    ips = batch * steps / el
+    out = {"value": round(ips, 2), "unit": "images/sec", "ms_per_step": round(1e3 * el / steps, 3), "ms_per_step_median": round(med, 3),
+           "value_median": round(batch / (med * 1e-3), 2), "steps": steps, "warmup": warmup, "workload": name,
+           "launch": "hipGraph replay" if graph else "eager", "final_loss": round(float(losses["loss"]), 4),
+           "step_roofline": {"mfma_frac": round(ips * flops_img / (PEAK_MFMA_TFLOPS * 1e12), 4),
+                             "hbm_frac": round(ips * bytes_img / (PEAK_HBM_GBS * 1e9), 4)}}
+    if extra:
+        out.update(extra)
+    return out
+
+
+def deeplab_workload(dev, a, batch=16, size=(512, 1024), steps=20, warmup=3, output_stride=32):
     """Second headline workload of BASELINE.json's metric (config 3): DeepLabv3+ ResNet-50-v1c, 1024x512, bf16, batch 16,
-    OS-32 as the reference builds it. Same step definition; reported next to the YOLOv5-s line."""
+    OS-32 as the reference builds it (the dilation rewrite of backbones/seg/resnet.py:102-118 never fires) —
+    `output_stride=8` is the variant the yml intends, reported separately."""
     from cvpytorch_amd import deeplab
     from cvpytorch_amd.arena import FlatTrainState, FlatTrainStep
     from cvpytorch_amd.data import synthetic_segmentation_batch
     torch.manual_seed(1029)
-    model = deeplab.EncoderDecoder(19, output_stride=32).to(dev).train()
+    model = deeplab.EncoderDecoder(19, output_stride=output_stride).to(dev).train()
     state = FlatTrainState(model, lr=0.01, momentum=0.9, nesterov=True, weight_decay=5e-4, backbone_lr=0.001, use_ema=False)
     step = FlatTrainStep(model, state)
     imgs, tgt = synthetic_segmentation_batch(batch, size, device=dev)
-    for _ in range(warmup):
-        step(imgs, tgt)
     graph = not a.no_graph
-    if graph:
-        step.capture(imgs, tgt)
-        imgs, tgt = step.static_imgs, step.static_targets
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        losses = step(imgs, tgt)
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    ips = batch * steps / el
-    # BASELINE.md §2: 434.7 GFLOP and ~2558 MB per image (train, OS-32 as written)
-    return {"value": round(ips, 2), "unit": "images/sec", "ms_per_step": round(1e3 * el / steps, 2), "steps": steps, "warmup": warmup,
-            "workload": "DeepLabv3+ R50-v1c %dx%d bf16 batch %d OS-32 (as written), SGD-nesterov, synthetic" % (size[1], size[0], batch),
-            "launch": "hipGraph replay" if graph else "eager", "final_loss": round(float(losses["loss"]), 4),
-            "step_roofline": {"mfma_frac": round(ips * 434.7e9 / (PEAK_MFMA_TFLOPS * 1e12), 4),
-                              "hbm_frac": round(ips * 2558e6 / (PEAK_HBM_GBS * 1e9), 4)}}
+    imgs, tgt = _graph_step(step, imgs, tgt, warmup, graph)
+    el, losses, med, _ = timed_steps(step, imgs, tgt, steps)
+    # BASELINE.md §2 / SURVEY.md §8(d): OS-32 as written 434.7 GFLOP and ~2558 MB per image (train); OS-8 2113.9 GFLOP, ~5313 MB
+    fl, by = (434.7e9, 2558e6) if output_stride == 32 else (2113.9e9, 5313e6)
+    return _side_result("DeepLabv3+ R50-v1c %dx%d bf16 batch %d OS-%d (%s), SGD-nesterov, synthetic"
+                        % (size[1], size[0], batch, output_stride, "as written" if output_stride == 32 else "as the yml intends"),
+                        batch, steps, warmup, el, med, losses, fl, by, graph)
 
+
+def yolox_workload(dev, a, steps, warmup, batch=64):
+    """BASELINE config 4 at N = 1: YOLOX-s 640x640 bf16, per-GPU batch 64 (conf/coco_yolox_s.yml:17), fused SimOTA loss kernels."""
+    from cvpytorch_amd import yolox
+    from cvpytorch_amd.arena import FlatTrainState, FlatTrainStep
+    from cvpytorch_amd.data import synthetic_detection_batch
+    torch.manual_seed(1029)
+    m = yolox.YOLOX(80, "s", max_labels=20, fused_loss=True).to(dev).train()
+    imgs, targets = synthetic_detection_batch(batch, 640, device=dev)
+    for t in targets:  # YOLOX targets are pixel-unit cxcywh (models/yolox.py:112-139)
+        t["boxes"] = t["boxes"] * 640.0
+    gts = yolox.targets_to_padded(targets, 20, dev)
+    state = FlatTrainState(m, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4, use_ema=True)
+    step = FlatTrainStep(m, state)
+    imgs, gts = _graph_step(step, imgs, gts, warmup, not a.no_graph)
+    el, losses, med, _ = timed_steps(step, imgs, gts, steps)
+    return _side_result("coco_yolox_s.yml YOLOX-s 640x640 bf16 batch %d (BASELINE config 4 at N = 1), SGD-nesterov + EMA, synthetic" % batch,
+                        batch, steps, warmup, el, med, losses, 80.06e9, 444e6, not a.no_graph, {"dtype": "bf16"})
+
+
+def yolov7_workload(dev, a, steps, warmup, batch=16, size=1280):
+    """BASELINE config 5 at N = 1: YOLOv7-l 1280x1280, fp16 storage + dynamic loss scaling (trainer.py:189-201), batch 16."""
+    from cvpytorch_amd import ops, yolov5, yolov7
+    from cvpytorch_amd.arena import FlatTrainState, FlatTrainStep
+    from cvpytorch_amd.data import synthetic_detection_batch
+    torch.manual_seed(1029)
+    ops.set_precision("fp16")
+    try:
+        m = yolov7.YOLOv7(80, 1.0, max_targets=batch * 20, fused_loss=True).to(dev).train()
+        imgs, targets = synthetic_detection_batch(batch, size, device=dev)
+        gts = yolov5.targets_to_tensor(targets, batch * 20, dev)
+        state = FlatTrainState(m, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4, use_ema=True)
+        step = FlatTrainStep(m, state)
+        imgs, gts = _graph_step(step, imgs, gts, warmup, not a.no_graph)
+        el, losses, med, _ = timed_steps(step, imgs, gts, steps)
+        sc = state.loss_scale()
+        return _side_result("coco_yolov7.yml YOLOv7-l %dx%d fp16 batch %d (BASELINE config 5 at N = 1; YOLOv5-style loss, dynamic loss scaling), "
+                            "SGD-nesterov + EMA, synthetic" % (size, size, batch), batch, steps, warmup, el, med, losses, 1269.2e9, 5037e6,
+                            not a.no_graph, {"dtype": "fp16", "loss_scale": sc[0], "skipped_steps": sc[1]})
+    finally:
+        ops.set_precision("bf16")
 
 
 def pmc_traffic(kernel_label):
@@ -273,36 +437,73 @@ def h2d_leg(model, state, a, dev, imgs_f32, gts, steps):
             "final_loss": round(float(losses["loss"]), 4)}
 
 
+class _Watchdog:
+    """Never lose the headline line to a side leg that hangs (a collective one rank never joins, a wedged kernel): if `budget_s`
+    pass before `done()`, rank 0 prints what it has — with the unfinished legs marked — and every rank exits."""
+
+    def __init__(self, out, rank, budget_s):
+        import threading
+        self.out, self.rank = out, rank
+        self.t = threading.Timer(budget_s, self._fire)
+        self.t.daemon = True
+        self.t.start()
+
+    def _fire(self):
+        if self.rank == 0 and self.out is not None:
+            self.out["watchdog"] = "side legs exceeded their time budget; unfinished legs are missing from this line"
+            print(json.dumps(self.out), flush=True)
+        os._exit(0)
+
+    def done(self):
+        self.t.cancel()
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (the HIP engine has no CPU fallback)")
+    if world != a.gpus and rank == 0:
+        sys.stderr.write("[bench] --gpus %d but the launcher started WORLD_SIZE=%d ranks: running %d\n" % (a.gpus, world, world))
     # transport: the RCCL communicator behind the C ABI (cvpytorch_amd/comm.py -> csrc/comm.hip); no torch process group is
     # created. CVHIP_DIST_BACKEND=gloo is a control-flow smoke test only (N ranks sharing one GPU over torch.distributed/gloo).
     backend = os.environ.get("CVHIP_DIST_BACKEND", "rccl")
-    dev_index = local_rank if backend == "rccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    from cvpytorch_amd import comm as CM
-    comm = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if os.environ.get("LOCAL_WORLD_SIZE", str(world)) == str(world):
             # one node: RCCL's bootstrap sockets on loopback (the container's hostname / outward interface may not be usable)
             os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    if a.dry_launch:
+        dry_launch(world, rank, backend)
+        return
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP engine has no CPU fallback)")
+    dev_index = local_rank if backend == "rccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    from cvpytorch_amd import comm as CM
+    from cvpytorch_amd import lib as L
+    comm = None
+    transport = "none (single process)"
+    if world > 1:
         if backend == "rccl":
             try:
                 comm = CM.init_from_env(dev)
-            except Exception as e:  # never lose the scaling line to the transport: torch's process group carries the same bucket protocol
-                sys.stderr.write("[bench] native RCCL communicator failed on rank %d (%r): falling back to torch.distributed\n" % (rank, e))
+                transport = "rccl-native: cvhip_comm_* / cvhip_allreduce_bucket over librccl %d, %d ranks" % (int(L.load().cvhip_comm_rccl_version()), comm.world)
+            except Exception as e:
+                if not a.allow_torch_dist:   # a line that names the native transport must have been measured on it
+                    raise SystemExit("[bench] native RCCL communicator failed on rank %d: %r (pass --allow-torch-dist to run over torch.distributed instead; "
+                                     "the line then says so in config.transport)" % (rank, e))
+                sys.stderr.write("[bench] native RCCL communicator failed on rank %d (%r): torch.distributed fallback\n" % (rank, e))
                 dist.init_process_group("nccl")
                 comm = CM.TorchDistComm()
+                transport = "torch-nccl-fallback: torch.distributed ProcessGroupNCCL (the native communicator failed: %s)" % repr(e)[:120]
         else:
             dist.init_process_group(backend)
             comm = CM.TorchDistComm()
+            transport = "torch.distributed/%s (control-flow test transport, not a measurement)" % backend
         CM.set_default(comm)
 
     from cvpytorch_amd import ops, yolov5
@@ -310,24 +511,31 @@ def main():
     from cvpytorch_amd.arena import FlatTrainState, FlatTrainStep
     from cvpytorch_amd.train import GradBucketer, ModelEMA, TrainStep, build_optimizer
 
-    torch.manual_seed(1029)
     max_boxes = 20
-    model = yolov5.YOLOv5(80, "s", max_targets=a.batch * max_boxes, fused_loss=not a.torch_loss).to(dev).train()
-    if a.sync_bn and world > 1:
-        from cvpytorch_amd.bricks import convert_sync_batchnorm
-        model = convert_sync_batchnorm(model)
-    if world > 1:  # same initial weights everywhere (DDP broadcasts rank 0's at construction)
-        for t in list(model.parameters()) + list(model.buffers()):
-            if t.is_floating_point():
-                comm.broadcast_(t.data, 0)
-    if a.stock_optimizer:  # reference-shaped tail: .grad tensors -> torch.optim.SGD -> ModelEMA (+ GradBucketer)
-        opt = build_optimizer(model, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4)
-        ema = ModelEMA(model) if rank == 0 else None  # trainer.py:293: EMA on the main process only
-        bucketer = GradBucketer(model, comm=comm) if world > 1 else None
-        step = TrainStep(model, opt, ema, bucketer, sync_buffers=world > 1)
-    else:  # flat arenas: direct gradient writes, in-place bucketed all-reduce, ONE fused SGD+EMA kernel
-        state = FlatTrainState(model, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4, use_ema=(rank == 0), comm=comm)
-        step = FlatTrainStep(model, state, sync_buffers=world > 1)
+
+    def build_step(sync_bn):
+        torch.manual_seed(1029)
+        model = yolov5.YOLOv5(80, "s", max_targets=a.batch * max_boxes, fused_loss=not a.torch_loss).to(dev).train()
+        if sync_bn and world > 1:
+            from cvpytorch_amd.bricks import convert_sync_batchnorm
+            model = convert_sync_batchnorm(model)
+        state = None
+        if a.stock_optimizer:  # reference-shaped tail: .grad tensors -> torch.optim.SGD -> ModelEMA (+ GradBucketer)
+            if world > 1:  # same initial weights everywhere (DDP broadcasts rank 0's at construction)
+                for t in list(model.parameters()) + list(model.buffers()):
+                    if t.is_floating_point():
+                        comm.broadcast_(t.data.contiguous() if not t.data.is_contiguous() else t.data, 0)
+            opt = build_optimizer(model, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4)
+            ema = ModelEMA(model) if rank == 0 else None  # trainer.py:293: EMA on the main process only
+            bucketer = GradBucketer(model, comm=comm) if world > 1 else None
+            step = TrainStep(model, opt, ema, bucketer, sync_buffers=world > 1)
+        else:  # flat arenas: direct gradient writes, in-place bucketed all-reduce, ONE fused SGD+EMA kernel
+            # (FlatTrainState broadcasts rank 0's parameters / momentum / buffers at construction, as DDP does)
+            state = FlatTrainState(model, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4, use_ema=(rank == 0), comm=comm)
+            step = FlatTrainStep(model, state, sync_buffers=world > 1)
+        return model, state, step
+
+    model, state, step = build_step(a.sync_bn)
     imgs, targets = synthetic_detection_batch(a.batch, a.size, seed=1029 + rank, max_boxes=max_boxes, device=dev)
     gts = yolov5.targets_to_tensor(targets, a.batch * max_boxes, dev)
 
@@ -336,36 +544,39 @@ def main():
             comm.barrier()
         torch.cuda.synchronize()
 
-    # at world > 1 the bucketed RCCL all-reduces (and SyncBN's exchanges) are captured INSIDE the graph, on a forked stream that
-    # runs beside the rest of backward
-    use_graph = (not a.no_graph) and (not a.stock_optimizer) and not (a.sync_bn and world > 1 and not comm.capturable)
-    for _ in range(a.warmup):
-        step(imgs, gts)
-    if use_graph:  # the W warm-up steps above ran eagerly; the K timed steps replay ONE hipGraph of the whole step
-        ok = 1
-        try:
-            step.capture(imgs, gts)
-        except Exception as e:  # never lose the bench line to a capture problem: fall back to eager steps
-            ok = 0
-            sys.stderr.write("[bench] hipGraph capture failed on rank %d (%r): running eagerly\n" % (rank, e))
-        if world > 1:  # every rank must run the same mode (the modes issue different collectives)
+    def agree(ok):
+        """every rank must run the same mode (the modes issue different collectives)"""
+        if world > 1:
             flag = torch.tensor([ok], device=dev, dtype=torch.int32)
             comm.allreduce_(flag, "min")
             comm.wait()
             ok = int(flag.item())
-        if ok:
-            imgs, gts = step.static_imgs, step.static_targets
-        else:
-            step.graph = None
-            use_graph = False
+        return ok
+
+    def warm_and_capture(step, imgs, gts, sync_bn):
+        # at world > 1 the bucketed RCCL all-reduces (and SyncBN's exchanges) are captured INSIDE the graph, on a forked stream
+        # that runs beside the rest of backward
+        use_graph = (not a.no_graph) and (not a.stock_optimizer) and not (sync_bn and world > 1 and not comm.capturable)
+        for _ in range(a.warmup):
+            step(imgs, gts)
+        if use_graph:  # the W warm-up steps above ran eagerly; the K timed steps replay ONE hipGraph of the whole step
+            ok = 1
+            try:
+                step.capture(imgs, gts)
+            except Exception as e:  # never lose the bench line to a capture problem: fall back to eager steps
+                ok = 0
+                sys.stderr.write("[bench] hipGraph capture failed on rank %d (%r): running eagerly\n" % (rank, e))
+            if agree(ok):
+                imgs, gts = step.static_imgs, step.static_targets
+            else:
+                step.graph = None
+                use_graph = False
+        return use_graph, imgs, gts
+
+    use_graph, imgs, gts = warm_and_capture(step, imgs, gts, a.sync_bn)
     ops.TIMER.enabled = (not a.no_kernel_timing) and rank == 0 and not use_graph
     ops.TIMER.reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        losses = step(imgs, gts)
-    barrier()
-    el = time.perf_counter() - t0
+    el, losses, med, per = timed_steps(step, imgs, gts, a.steps, barrier)
     ops.TIMER.enabled = False
     timing_source = "HIP events around every conv launch inside the timed region (eager)"
     if use_graph and not a.no_kernel_timing:  # every rank takes part (the steps contain collectives); only rank 0 records events
@@ -379,22 +590,35 @@ def main():
         ops.TIMER.enabled = False
         timing_source = "HIP events around every conv launch in an eager re-run of the same K steps right after the timed region (the timed region replays a hipGraph)"
     if world > 1:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        t = torch.tensor([el, med], device=dev, dtype=torch.float64)
         comm.allreduce_(t, "max")
         comm.wait()
-        el = float(t.item())
+        el, med = float(t[0].item()), float(t[1].item())
     loss_val = float(losses["loss"])
 
+    out = None
     if rank == 0:
         gb = a.batch * world
+        launch = "eager"
+        if use_graph:
+            launch = "hipGraph replay of the whole step"
+            if world > 1:
+                launch = ("hipGraph replay of the whole step incl. the bucketed all-reduces on a forked stream beside backward" if not step.eager_tail
+                          else "hipGraph replay of forward+loss+backward, then one all-reduce of the gradient arena + fused optimizer")
         out = {
-            "metric": "images/sec/node train step, YOLOv5-s@640 (value) & DeepLabv3+R50@1024x512 (config3_deeplabv3plus_r50.value)", "value": round(gb * a.steps / el, 2), "unit": "images/sec",
+            "metric": "images/sec/node train step, YOLOv5-s@640 (value: batch resident in HBM when the timed region starts; with_h2d.value: the same "
+                      "step fed from pinned host memory inside the region) & DeepLabv3+R50@1024x512 (config3_deeplabv3plus_r50.value)",
+            "value": round(gb * a.steps / el, 2), "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * el / a.steps, 3),
+            "ms_per_step_median": round(med, 3), "value_median": round(gb / (med * 1e-3), 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "coco_yolov5_s.yml YOLOv5-s %dx%d bf16 train step (fwd+loss+bwd+SGD-nesterov+EMA), per-GPU batch %d, "
                                    "synthetic COCO-shape tensors resident in HBM" % (a.size, a.size, a.batch),
-                       "global_batch": gb, "parallelism": "dp%d" % world, "final_loss": round(loss_val, 4),
-                       "launch": ("hipGraph replay of the whole step" if world == 1 else ("hipGraph replay of the whole step incl. bucketed RCCL all-reduces (cvhip_allreduce_bucket) on a forked stream beside backward" if not step.eager_tail else "hipGraph replay of forward+loss+backward, then one all-reduce of the gradient arena + fused optimizer")) if use_graph else "eager"},
+                       "global_batch": gb, "parallelism": "dp%d" % world, "final_loss": round(loss_val, 4), "launch": launch,
+                       "world": comm.world if comm is not None else 1, "transport": transport,
+                       "grad_buckets": (len(state.buckets) if (state is not None and world > 1) else 0),
+                       "sync_bn": bool(a.sync_bn and world > 1),
+                       "statistic": "value = global_batch * K / wall time of the K timed steps (max over ranks); *_median from per-step HIP events"},
         }
         summ = ops.TIMER.summary()
         if summ:
@@ -413,23 +637,60 @@ def main():
             ips_gpu = a.batch * a.steps / el
             out["step_roofline"] = {"mfma_frac": round(ips_gpu * 49.30e9 / (PEAK_MFMA_TFLOPS * 1e12), 4),
                                     "hbm_frac": round(ips_gpu * 366e6 / (PEAK_HBM_GBS * 1e9), 4)}
-        if world == 1 and not a.no_kernel_timing:
+
+    # ---- side legs: everything below is extra keys of the same line; a leg that fails or hangs must not cost the headline ----
+    dog = _Watchdog(out, rank, float(os.environ.get("CVHIP_BENCH_SIDE_BUDGET", "900")))
+    if world > 1 and not a.no_sync_bn_leg and not a.sync_bn and not a.stock_optimizer:
+        # the reference forces SyncBN under DDP (trainer.py:126-127); SURVEY.md §8(d) config 4: report both
+        try:
+            del step
+            m2, st2, step2 = build_step(True)
+            i2, t2 = synthetic_detection_batch(a.batch, a.size, seed=1029 + rank, max_boxes=max_boxes, device=dev)
+            g2 = yolov5.targets_to_tensor(t2, a.batch * max_boxes, dev)
+            ug, i2, g2 = warm_and_capture(step2, i2, g2, True)
+            el2, l2, med2, _ = timed_steps(step2, i2, g2, a.steps, barrier)
+            t = torch.tensor([el2, med2], device=dev, dtype=torch.float64)
+            comm.allreduce_(t, "max")
+            comm.wait()
+            if rank == 0:
+                gb = a.batch * world
+                out["with_sync_bn"] = {"value": round(gb * a.steps / float(t[0].item()), 2), "unit": "images/sec", "ms_per_step": round(1e3 * float(t[0].item()) / a.steps, 3),
+                                       "ms_per_step_median": round(float(t[1].item()), 3), "launch": "hipGraph replay" if ug else "eager",
+                                       "final_loss": round(float(l2["loss"]), 4),
+                                       "what": "the same K steps with every BatchNorm converted to HipSyncBN (statistics exchanged through the same communicator)"}
+        except Exception as e:
+            if rank == 0:
+                out["with_sync_bn"] = {"error": repr(e)[:300]}
+    if rank == 0 and world == 1:
+        if not a.no_kernel_timing:
             try:
                 out["peaks_measured"] = measured_peaks(dev)
             except Exception as e:
                 out["peaks_measured"] = {"error": repr(e)[:200]}
-        if world == 1 and not a.no_h2d and not a.stock_optimizer and not a.no_graph:
+        if not a.no_h2d and not a.stock_optimizer and not a.no_graph:
             try:
                 out["with_h2d"] = h2d_leg(model, state, a, dev, imgs, gts, a.steps)
             except Exception as e:  # the headline line must still be printed
                 out["with_h2d"] = {"error": repr(e)[:300]}
-        if world == 1 and not a.no_deeplab:
+        side_steps, side_warm = max(a.steps, 20), max(a.warmup, 3)
+        if not a.no_deeplab:
             try:
-                out["config3_deeplabv3plus_r50"] = deeplab_workload(dev, a, steps=max(a.steps, 20), warmup=max(a.warmup, 3))
-            except Exception as e:  # the headline line must still be printed
+                out["config3_deeplabv3plus_r50"] = deeplab_workload(dev, a, steps=side_steps, warmup=side_warm)
+            except Exception as e:
                 out["config3_deeplabv3plus_r50"] = {"error": repr(e)[:300]}
-        if world == 1 and not a.no_cpu_baseline:
+        if not a.no_extra:
+            for key, fn in (("config3_os8", lambda: deeplab_workload(dev, a, steps=10, warmup=2, output_stride=8)),
+                            ("config4_yolox_s", lambda: yolox_workload(dev, a, side_steps, side_warm)),
+                            ("config5_yolov7l_fp16", lambda: yolov7_workload(dev, a, max(10, a.steps // 2), 2))):
+                try:
+                    out[key] = fn()
+                except Exception as e:
+                    out[key] = {"error": repr(e)[:300]}
+                torch.cuda.empty_cache()
+        if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.size, a.cpu_batch)
+    dog.done()
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         comm.barrier()

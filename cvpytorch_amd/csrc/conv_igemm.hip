@@ -333,15 +333,19 @@ __device__ __forceinline__ void wait_vmcnt() {
 // A register-double-buffered variant (fragments of tile kt+1 read while tile kt is multiplied, asm-issued ds_read_b128 with one
 // explicit lgkmcnt wait per step) was built and measured in round 2: 8-13 % SLOWER per kernel (profiles/r02_igemm_ablation.log) and
 // removed — the step is not bound by the latency of its own fragment reads.
-template <int BM, int BN, int WM, int WN, int ABL = 0, int NST = 3, int BK = 32, bool FAST = false>
-__global__ __launch_bounds__(256, (NST * (BM + (BN < BK ? BK : BN)) * BK * 2 > 80 * 1024) ? 1 : 2) void igemm_dma_kernel(const IgemmKernArgs p) {
+// NW : waves per block. 4: one wave per SIMD and block; 8 (512 threads): two — the same block tile with HALF the wave tile, so a block
+//      alone on its CU still has a second wave per SIMD to issue MFMAs while the first one sits in its DMA-issue / fragment-read /
+//      barrier phase (profiles/r03_ceilings_probe.log: neither the LDS read rate nor the L2->LDS path is the limit of the 4-wave
+//      form; its in-order waves are).
+template <int BM, int BN, int WM, int WN, int ABL = 0, int NST = 3, int BK = 32, bool FAST = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64, ((NST * (BM + (BN < BK ? BK : BN)) * BK * 2 > 80 * 1024) ? 1 : 2) * (NW / 4)) void igemm_dma_kernel(const IgemmKernArgs p) {
   constexpr int WAVES_N = BN / WN;
   constexpr int WAVES_M = BM / WM;
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+  static_assert(WAVES_M * WAVES_N == NW, "NW waves per block");
   static_assert(BK == 32 || BK == 64, "reduction depth per stage");
   constexpr int MF = WM / 16, NF = WN / 16;
   constexpr int RPI = 1024 / (BK * 2);  // rows per DMA instruction (1 KiB): 16 (BK 32) / 8 (BK 64)
-  constexpr int RPT = 4 * RPI;          // rows per pass of the 4 waves: 64 / 32
+  constexpr int RPT = NW * RPI;         // rows per pass of the block's waves: 64 / 32 (4 waves)
   constexpr int ROWB = BK * 2;          // LDS row bytes
   constexpr int A_IT = BM / RPT;
   constexpr int B_ROWS = BN < RPT ? RPT : BN;  // B tile padded so all 4 waves issue the same DMA count
@@ -722,6 +726,15 @@ static bool fast_staging() {
   return v == 1;
 }
 
+static int w8_level() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CVHIP_IGEMM_W8");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
 static bool use_v1() {
   static int v = -1;
   if (v < 0) {
@@ -762,7 +775,7 @@ static int launch_group(IgemmKernArgs& p, hipStream_t stream) {
       return check_launch("igemm_kernel");
     }
   }
-  if (bk64_level() > 0 && ablate_mode() == 0) {
+  if (bk64_level() > 0 && ablate_mode() == 0 && !(fast_staging() && p.Cin % 64 == 0 && p.Cin <= kFastMaxCin)) {
     // BK = 64 ring slots (full 128-byte lines per DMA row): level 1 = 2-deep ring, 2 = 3-deep ring
     if (bk64_level() >= 2) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 3, 64>), dim3(total), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 2, 64>), dim3(total), dim3(256), 0, stream, p);
@@ -775,8 +788,33 @@ static int launch_group(IgemmKernArgs& p, hipStream_t stream) {
     return check_launch("igemm_kernel(abl3)");
   }
   if (ablate_mode() == 0 && fast_staging() && p.Cin % 32 == 0 && p.Cin <= kFastMaxCin) {
-    if (nst2) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 2, 32, true>), dim3(total), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 3, 32, true>), dim3(total), dim3(256), 0, stream, p);
+    // FAST staging. Ring slot depth: 32 (64-byte LDS rows: a DMA instruction fetches 16 HALF cache lines) or, when Cin % 64 == 0
+    // and CVHIP_IGEMM_BK64 asks for it, 64 (8 FULL lines per instruction: profiles/r03_ceilings_probe.log measures the
+    // L2 -> LDS path at 28-35 B/clk/CU for half-line rows against 47-55 for full lines). 8-wave blocks: CVHIP_IGEMM_W8.
+    const bool bk64 = bk64_level() > 0 && p.Cin % 64 == 0;
+    const bool three = bk64 ? bk64_level() >= 2 : !nst2;
+    bool w8 = false;
+    if constexpr (BM == 256 && BN >= 64 && WM >= 64) w8 = w8_level() >= (BN == 128 ? 1 : 2);
+    if constexpr (BM == 256 && BN >= 64 && WM >= 64) {
+      constexpr int WM8 = WM == 128 ? 64 : 32;  // 256x128: 4(M) x 2(N) waves of 64x64; 256x64: 8(M) x 1(N) waves of 32x64
+      if (w8) {
+        if (bk64) {
+          if (three) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM8, WN, 0, 3, 64, true, 8>), dim3(total), dim3(512), 0, stream, p);
+          else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM8, WN, 0, 2, 64, true, 8>), dim3(total), dim3(512), 0, stream, p);
+        } else {
+          if (three) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM8, WN, 0, 3, 32, true, 8>), dim3(total), dim3(512), 0, stream, p);
+          else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM8, WN, 0, 2, 32, true, 8>), dim3(total), dim3(512), 0, stream, p);
+        }
+        return check_launch("igemm_kernel(fast, 8 waves)");
+      }
+    }
+    if (bk64) {
+      if (three) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 3, 64, true>), dim3(total), dim3(256), 0, stream, p);
+      else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 2, 64, true>), dim3(total), dim3(256), 0, stream, p);
+    } else {
+      if (three) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 3, 32, true>), dim3(total), dim3(256), 0, stream, p);
+      else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 2, 32, true>), dim3(total), dim3(256), 0, stream, p);
+    }
     return check_launch("igemm_kernel(fast)");
   }
   if (ablate_mode() == 1) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 1>), dim3(total), dim3(256), 0, stream, p);

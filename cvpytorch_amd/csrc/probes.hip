@@ -151,6 +151,40 @@ __global__ __launch_bounds__(1024) void probe_load_kernel(const unsigned char* _
   if (acc == 0x12345678u) out[blockIdx.x] = 1.f;
 }
 
+// ---- the implicit GEMM's A-tile staging pattern in isolation ---------------------------------------------------------------
+// A block owns 256 pixel rows (row pitch `row_stride` bytes = channels x 2) and sweeps their channels in K steps of ROWB bytes
+// (64 = BK 32: a DMA instruction covers 16 rows x 64 B, i.e. HALF cache lines; 128 = BK 64: 8 rows x FULL lines); per K step the
+// block's waves fetch the whole 256 x ROWB tile into LDS with global_load_lds_dwordx4, `depth` K steps in flight per wave.
+// Isolates what the access pattern alone costs on the L2 -> LDS path (the contiguous form of probe_load_kernel reaches
+// 50+ B/clk/CU; the implicit GEMM's staging-only ablation ~16).
+template <int ROWB>
+__global__ __launch_bounds__(512) void probe_gather_kernel(const unsigned char* __restrict__ src, size_t span, int row_stride, int k_bytes,
+                                                           int iters, int depth, float* out) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[65536];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int nw = blockDim.x >> 6;
+  constexpr int RPI = 1024 / ROWB;             // rows per DMA instruction
+  constexpr int LPR = ROWB / 16;               // lanes per row
+  const int pieces = 256 / RPI / nw;           // DMA instructions per wave per K step
+  const size_t tile0 = (size_t)blockIdx.x * 256 * (size_t)row_stride;
+  int koff = 0;
+  for (int it = 0; it < iters; ++it) {
+    for (int pc = 0; pc < pieces; ++pc) {
+      const int row = (pc * nw + wave) * RPI + lane / LPR;
+      const unsigned char* g = src + ((tile0 + (size_t)row * row_stride + koff + (lane % LPR) * 16) & (span - 1));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(smem + (((it * pieces + pc) * nw + wave) & 63) * 1024), 16, 0, 0);
+    }
+    koff += ROWB;
+    if (koff >= k_bytes) koff = 0;
+    if ((it + 1) % depth == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (reinterpret_cast<const unsigned*>(smem)[t] == 0x12345678u) out[blockIdx.x] = 1.f;
+}
+
 // ---- fp64 atomics into sharded accumulators --------------------------------------------------------------------------------
 // block b adds `n` values (n <= 256: threads t < n) into acc[(b % shards) * n + t]: the traffic of a conv epilogue that folds its
 // tile's BatchNorm sums (2 x K values) straight into per-layer accumulators. F32 != 0: the same with fp32 atomics.
@@ -214,6 +248,18 @@ int cvhip_probe_atomic_add(int32_t f32, void* acc_zeroed, int32_t shards, int32_
   if (f32) hipLaunchKernelGGL(probe_atomic_kernel<1>, dim3(blocks), dim3(256), 0, st, acc_zeroed, shards, n);
   else hipLaunchKernelGGL(probe_atomic_kernel<0>, dim3(blocks), dim3(256), 0, st, acc_zeroed, shards, n);
   return check_launch("probe_atomic_kernel");
+}
+
+int cvhip_probe_gather(int32_t row_bytes, const void* src, int64_t span, int32_t row_stride, int32_t k_bytes, int32_t iters, int32_t depth,
+                       int32_t blocks, int32_t threads, float* out, void* stream) {
+  if (!src || !out || iters <= 0 || depth <= 0 || blocks <= 0 || (threads != 256 && threads != 512)) return CVHIP_ERR_INVALID;
+  if (span < 65536 || (span & (span - 1)) || row_stride < row_bytes || k_bytes < row_bytes || k_bytes > row_stride) return CVHIP_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned char* s = (const unsigned char*)src;
+  if (row_bytes == 64) hipLaunchKernelGGL(probe_gather_kernel<64>, dim3(blocks), dim3(threads), 0, st, s, (size_t)span, row_stride, k_bytes, iters, depth, out);
+  else if (row_bytes == 128) hipLaunchKernelGGL(probe_gather_kernel<128>, dim3(blocks), dim3(threads), 0, st, s, (size_t)span, row_stride, k_bytes, iters, depth, out);
+  else return CVHIP_ERR_INVALID;
+  return check_launch("probe_gather_kernel");
 }
 
 }  // extern "C"

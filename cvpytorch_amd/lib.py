@@ -177,6 +177,7 @@ SIGNATURES = {
     "cvhip_probe_mfma_peak2": (_i32, [_i32, _i32, _i32, _i32, _i32, _p, _p]),
     "cvhip_probe_load_path": (_i32, [_i32, _i32, _p, _i64, _i64, _i32, _i32, _i32, _p, _p]),
     "cvhip_probe_atomic_add": (_i32, [_i32, _p, _i32, _i32, _i32, _p]),
+    "cvhip_probe_gather": (_i32, [_i32, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
 }
 
 _lib = None

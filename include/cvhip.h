@@ -593,6 +593,10 @@ int cvhip_probe_mfma_peak2(int32_t shape, int32_t data, int32_t iters, int32_t b
 int cvhip_probe_load_path(int32_t mode, int32_t depth, const void* src, int64_t span, int64_t block_stride, int32_t iters, int32_t blocks,
                           int32_t threads, float* out, void* stream);
 int cvhip_probe_atomic_add(int32_t f32, void* acc_zeroed, int32_t shards, int32_t n, int32_t blocks, void* stream);
+/* the implicit GEMM's A-tile staging pattern alone: every block fetches its 256 rows (pitch row_stride bytes) in K steps of row_bytes
+ * (64 | 128) bytes per row, sweeping k_bytes per row, `depth` K steps in flight per wave; bytes = blocks * iters * 256 * row_bytes */
+int cvhip_probe_gather(int32_t row_bytes, const void* src, int64_t span, int32_t row_stride, int32_t k_bytes, int32_t iters, int32_t depth,
+                       int32_t blocks, int32_t threads, float* out, void* stream);
 
 #ifdef __cplusplus
 }

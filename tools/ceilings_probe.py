@@ -76,6 +76,24 @@ def load():
                         names[mode], depth, threads, blocks, blocks * threads // 64 // CUS, ms, nbytes / ms / 1e9, nbytes / CUS / (ms * 1e-3) / (GHZ * 1e9)))
 
 
+def gather():
+    print("== the implicit GEMM's A-tile staging pattern alone (global_load_lds_dwordx4; 256 rows per block per K step) ==")
+    big = torch.empty((1 << 30,), dtype=torch.uint8, device=dev)
+    big.random_(0, 255)
+    for span_name, span in (("32 MiB tensor (26 MB activations of a 40x40x128 layer at batch 64)", 1 << 25), ("1 GiB", 1 << 30)):
+        print(" source span: %s" % span_name)
+        for rowb in (64, 128):
+            for stride, kb in ((128, 128), (256, 256), (512, 512), (1024, 1024), (256, 128), (272, 256)):
+                if kb < rowb:
+                    continue
+                for threads, blocks, depth in ((256, 512, 2), (256, 512, 4), (512, 512, 2), (256, 1024, 2)):
+                    iters = 288
+                    ms = timed(lambda: L.call("cvhip_probe_gather", rowb, big.data_ptr(), span, stride, kb, iters, depth, blocks, threads, out.data_ptr(), st))
+                    nbytes = blocks * iters * 256.0 * rowb
+                    print("  rows of %3d B, pitch %4d B, sweep %4d B  %3d thr x %4d blocks, %d K steps in flight: %7.3f ms  %6.2f TB/s  %5.1f B/clk/CU" % (
+                        rowb, stride, kb, threads, blocks, depth, ms, nbytes / ms / 1e9, nbytes / CUS / (ms * 1e-3) / (GHZ * 1e9)))
+
+
 def atomic():
     print("== per-block atomics into sharded accumulators: `blocks` blocks x n adds (a conv epilogue folding 2 x K BatchNorm sums) ==")
     acc = torch.zeros((64 * 256,), dtype=torch.float64, device=dev)
@@ -97,7 +115,7 @@ def atomic():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["lds", "mfma", "load", "atomic"]
+    which = sys.argv[1:] or ["lds", "mfma", "load", "gather", "atomic"]
     print("device:", torch.cuda.get_device_name(0))
     for w in which:
-        {"lds": lds, "mfma": mfma, "load": load, "atomic": atomic}[w]()
+        {"lds": lds, "mfma": mfma, "load": load, "gather": gather, "atomic": atomic}[w]()
