@@ -521,10 +521,7 @@ def main():
             model = convert_sync_batchnorm(model)
         state = None
         if a.stock_optimizer:  # reference-shaped tail: .grad tensors -> torch.optim.SGD -> ModelEMA (+ GradBucketer)
-            if world > 1:  # same initial weights everywhere (DDP broadcasts rank 0's at construction)
-                for t in list(model.parameters()) + list(model.buffers()):
-                    if t.is_floating_point():
-                        comm.broadcast_(t.data.contiguous() if not t.data.is_contiguous() else t.data, 0)
+            # (GradBucketer broadcasts rank 0's parameters and buffers at construction, as DDP does)
             opt = build_optimizer(model, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4)
             ema = ModelEMA(model) if rank == 0 else None  # trainer.py:293: EMA on the main process only
             bucketer = GradBucketer(model, comm=comm) if world > 1 else None

@@ -206,6 +206,16 @@ class FlatTrainState:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
         self._reset_buckets()
+        if self.world > 1:
+            # DistributedDataParallel broadcasts rank 0's parameters and buffers when it wraps the model (trainer.py:312-313):
+            # replicas that start from different weights would train apart silently, because only gradients are averaged
+            for t in (self.param, self.mom, self.buf):
+                if t.numel():
+                    self.comm.broadcast_(t, 0)
+            self.comm.wait()
+            if self.ema_param is not None:
+                self.ema_param.copy_(self.param)
+                self.ema_buf.copy_(self.buf)
 
     # ---- gradient readiness / all-reduce ------------------------------------------------------------------
     def _reset_buckets(self):

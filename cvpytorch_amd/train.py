@@ -106,6 +106,19 @@ class GradBucketer:
             cur_n += p.numel()
         if cur:
             self._close(cur, cur_n)
+        if self.world > 1:
+            # DDP's construction-time broadcast of rank 0's parameters and buffers (trainer.py:312-313); tensors that are not
+            # contiguous (channels_last weights) travel through a contiguous copy
+            with torch.no_grad():
+                for t in list(model.parameters()) + [b for b in model.buffers() if b.is_floating_point()]:
+                    d = t.data
+                    if d.is_contiguous():
+                        self.comm.broadcast_(d, 0)
+                    else:
+                        tmp = d.contiguous()
+                        self.comm.broadcast_(tmp, 0)
+                        d.copy_(tmp)
+            self.comm.wait()
         self._pending = [0] * len(self.buckets)
         self._launched = []
         self._stream = None

@@ -22,14 +22,22 @@ def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from cvpytorch_amd.train import GradBucketer, broadcast_buffers
-    torch.manual_seed(0)
+    torch.manual_seed(rank)   # DIFFERENT initial weights per rank: the bucketer must broadcast rank 0's, as DDP does at construction
     model = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(), nn.Conv2d(8, 16, 3, padding=1), nn.BatchNorm2d(16),
                           nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(16, 4))
+    model[0].weight.data = model[0].weight.data.contiguous(memory_format=torch.channels_last)   # a non-contiguous parameter
     frozen = model[3].bias
     frozen.requires_grad_(False)
     bucketer = GradBucketer(model, bucket_bytes=2048)  # tiny buckets => several collectives in flight
     assert len(bucketer.buckets) >= 3
     res = []
+    same = True
+    for t in list(model.parameters()) + list(model.buffers()):
+        if t.is_floating_point():
+            ref = t.detach().clone().contiguous()
+            dist.broadcast(ref, 0)
+            same = same and torch.equal(ref, t.detach().contiguous())
+    res.append(same)
     for it in range(2):
         g = torch.Generator().manual_seed(100 * it + rank)
         x = torch.randn(4, 3, 8, 8, generator=g)
