@@ -206,6 +206,23 @@ class FlatTrainState:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
         self._reset_buckets()
+        # BatchNorm statistic accumulators (ops._layer_acc): fp64 [2 (forward, backward)][shards][2][K] per BN layer and one more of
+        # K1 + K2 channels per sibling pair, in ONE buffer that step_kernels() zero-fills with a single launch
+        want = []
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                want.append((m, "_hip_acc", m.num_features))
+            if hasattr(m, "hip_sibling_pairs"):
+                for a, b in m.hip_sibling_pairs():
+                    na, nb = getattr(a, "norm", None), getattr(b, "norm", None)
+                    if isinstance(na, torch.nn.BatchNorm2d) and isinstance(nb, torch.nn.BatchNorm2d):
+                        want.append((na, "_hip_acc_pair", na.num_features + nb.num_features))
+        per = 2 * L.BN_ACC_SHARDS * 2
+        self.stat_acc = torch.zeros(sum(k for _, _, k in want) * per, dtype=torch.float64, device=dev)
+        o = 0
+        for m, attr, k in want:
+            m.__dict__[attr] = [self.stat_acc[o:o + per * k].view(2, L.BN_ACC_SHARDS, 2, k), -1]
+            o += per * k
         if self.world > 1:
             # DistributedDataParallel broadcasts rank 0's parameters and buffers when it wraps the model (trainer.py:312-313):
             # replicas that start from different weights would train apart silently, because only gradients are averaged
@@ -285,6 +302,12 @@ class FlatTrainState:
     def zero_grad(self):
         ops.zero_fill(self.grad)  # a kernel, not a memset node (hipGraph-safe)
 
+    def zero_stats(self):
+        """one launch zeroes every layer's BatchNorm statistic accumulators for the next step"""
+        if self.stat_acc.numel():
+            ops.zero_fill(self.stat_acc)
+        ops.bump_acc_epoch()
+
     def scale_loss(self, loss):
         """scaler.scale(loss): the backward pass is seeded with the CURRENT loss scale, read from device memory (so a replayed
         hipGraph follows the scale as it grows / backs off). Identity when loss scaling is off."""
@@ -331,6 +354,7 @@ class FlatTrainState:
         if self._nbt and self.model.training:
             torch._foreach_add_(self._nbt, 1)
         self.zero_grad()
+        self.zero_stats()
 
     def prepare_weights(self):
         """Batched re-pack of every conv layer's bf16 operand images (ops.PrepPlan: one launch instead of ~2 per layer). The plan

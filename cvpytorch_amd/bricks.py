@@ -188,6 +188,7 @@ class HipConv2d(nn.Conv2d):
                           track=(bn.track_running_stats and bn.training) if bn is not None else False)
         cfg.vkey = (id(self.weight), self.weight._version)
         cfg.sync = sync_of(bn) if bn is not None else None
+        cfg.acc_owner = bn   # the layer's persistent statistic accumulators (arena.FlatTrainState) hang on the BatchNorm module
         # flat gradient arena (cvpytorch_amd/arena.py): let backward accumulate straight into the parameters' slots
         ar = getattr(self.weight, "_hip_arena", None)
         if ar is not None and torch.is_grad_enabled():

@@ -383,6 +383,25 @@ int cvhip_conv2d_fprop(const cvhip_conv_desc* d, const void* x, const void* w, c
   p.bias = bias;
   p.bias_n = d->k_valid > 0 ? d->k_valid : d->K;
   p.stats = stats_partial;
+  p.stats_acc = 0;
+  p.y_vec_ok = ((d->y_ld & 3) == 0) && ((((uintptr_t)y) & 7) == 0);
+  return launch_igemm(p, (hipStream_t)stream);
+}
+
+int cvhip_conv2d_fprop_acc(const cvhip_conv_desc* d, const void* x, const void* w, void* y, double* bn_acc, void* stream) {
+  int st = validate_dense_desc(d);
+  if (st) return st;
+  if (!x || !w || !y || !bn_acc) return CVHIP_ERR_INVALID;
+  if ((((uintptr_t)x) & 15) || (((uintptr_t)w) & 15) || (((uintptr_t)bn_acc) & 7)) return CVHIP_ERR_INVALID;
+  IgemmParams p;
+  plan_fprop(d, &p);
+  p.x = (const h16_t*)x;
+  p.w = (const h16_t*)w;
+  p.y = (h16_t*)y;
+  p.bias = nullptr;
+  p.bias_n = d->k_valid > 0 ? d->k_valid : d->K;
+  p.stats = reinterpret_cast<float*>(bn_acc);
+  p.stats_acc = 1;
   p.y_vec_ok = ((d->y_ld & 3) == 0) && ((((uintptr_t)y) & 7) == 0);
   return launch_igemm(p, (hipStream_t)stream);
 }
@@ -402,6 +421,7 @@ static int dgrad_impl(const cvhip_conv_desc* d, const void* dy, const void* w_dg
   p.y = (h16_t*)dx;
   p.bias = nullptr;
   p.stats = nullptr;
+  p.stats_acc = 0;
   p.res = (const h16_t*)addend;
   p.res_ld = addend_ld;
   p.y_vec_ok = ((d->x_ld & 3) == 0) && ((((uintptr_t)dx) & 7) == 0);

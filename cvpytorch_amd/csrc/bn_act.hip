@@ -37,6 +37,8 @@ struct RedParams {
   int act;
   float ap;
   float* partial;  // [gridDim.x][2][C]
+  double* acc;     // or: fp64 accumulator [kAccShards][2][acc_ld] (atomics; common.h acc_add2) — no partial rows, no finalize launch
+  int acc_ld;
 };
 
 // ACT: compile-time activation id for MODE 1 (a runtime switch inside the element loop compiles to a chain of scalar
@@ -141,7 +143,10 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const RedParams p) {
       float s = 0.f;
       for (int yy = 0; yy < rows_per_pass; ++yy) s += red[(yy * cols_per_pass + x) * 16 + j];
       const int c = (cv0 + x) * 8 + (j & 7);
-      if (cv0 + x < CV && c < p.C) p.partial[((int64_t)blockIdx.x * 2 + (j >> 3)) * p.C + c] = s;
+      if (cv0 + x < CV && c < p.C) {
+        if (p.acc) unsafeAtomicAdd(p.acc + ((size_t)((blockIdx.x & (kAccShards - 1)) * 2 + (j >> 3))) * p.acc_ld + c, (double)s);
+        else p.partial[((int64_t)blockIdx.x * 2 + (j >> 3)) * p.C + c] = s;
+      }
     }
   }
 }
@@ -431,13 +436,61 @@ struct EwParams {
   float ap;
   float inv_count;
   int res_pre;  // MODE 0: residual is added BEFORE the activation (ResNet bottleneck: relu(bn(y) + identity))
+  // ACC variants: the per-channel constants are derived in the block's prologue from an fp64 accumulator (common.h acc_fold2)
+  // instead of being read from arrays a finalize launch prepared
+  const double* acc;   // [kAccShards][2][acc_ld]: MODE 0 (sum y, sum y^2); MODE 1 (sum du, sum du*xhat)
+  int acc_ld;
+  double count;        // MODE 0: elements per channel
+  const float *gamma, *beta;
+  float *rmean, *rvar;
+  float momentum, eps;
+  float *o_mean, *o_invstd, *o_scale, *o_shift;   // MODE 0: block 0 stores the layer's statistics for backward
+  float *o_dgamma, *o_dbeta;                       // MODE 1: block 0 stores (accumulate != 0: adds) the parameter gradients
+  int accumulate;
 };
+constexpr int kEwAccMaxC = 2048;
 
 // MODE 0: out = act(a*scale+shift) (+res)         [a = conv output y]
 // MODE 1: out = dy from (a = dz, y)               [BN+act backward apply]
 // MODE 2: out = a (copy)       MODE 3: out = a + res
-template <int MODE, int ACT = 0>
+template <int MODE, int ACT = 0, bool ACC = false>
 __global__ __launch_bounds__(256) void ew_kernel(const EwParams p) {
+  __shared__ float cst[ACC ? 2 * kEwAccMaxC : 1];  // ACC: MODE 0 scale | shift; MODE 1 dbeta/M | dgamma/M
+  if constexpr (ACC) {
+    for (int c = threadIdx.x; c < p.C; c += 256) {
+      double s1, s2;
+      acc_fold2(p.acc, p.acc_ld, c, s1, s2);
+      if (MODE == 0) {
+        const double m = s1 / p.count;
+        double var = s2 / p.count - m * m;
+        if (var < 0.0) var = 0.0;
+        const float is = (float)(1.0 / sqrt(var + (double)p.eps));
+        const float g = p.gamma ? p.gamma[c] : 1.f, b = p.beta ? p.beta[c] : 0.f;
+        const float sc = g * is, sh = b - (float)m * sc;
+        cst[c] = sc;
+        cst[kEwAccMaxC + c] = sh;
+        if (blockIdx.x == 0) {  // the same arithmetic as bn_finalize_kernel
+          p.o_mean[c] = (float)m;
+          p.o_invstd[c] = is;
+          p.o_scale[c] = sc;
+          p.o_shift[c] = sh;
+          if (p.rmean) p.rmean[c] = (1.f - p.momentum) * p.rmean[c] + p.momentum * (float)m;
+          if (p.rvar) {
+            const double unb = p.count > 1.0 ? var * p.count / (p.count - 1.0) : var;
+            p.rvar[c] = (1.f - p.momentum) * p.rvar[c] + p.momentum * (float)unb;
+          }
+        }
+      } else {
+        cst[c] = (float)s1 * p.inv_count;                 // dbeta / M
+        cst[kEwAccMaxC + c] = (float)s2 * p.inv_count;    // dgamma / M
+        if (blockIdx.x == 0) {
+          if (p.o_dbeta) p.o_dbeta[c] = p.accumulate ? p.o_dbeta[c] + (float)s1 : (float)s1;
+          if (p.o_dgamma) p.o_dgamma[c] = p.accumulate ? p.o_dgamma[c] + (float)s2 : (float)s2;
+        }
+      }
+    }
+    __syncthreads();
+  }
   const int CV = (p.C + 7) >> 3;
   const bool vec = (p.C & 7) == 0 && (p.ld_a & 7) == 0 && (p.ld_out & 7) == 0 &&
                    (MODE != 1 || (p.ld_y & 7) == 0) && (!p.res || (p.ld_res & 7) == 0) &&
@@ -462,19 +515,35 @@ __global__ __launch_bounds__(256) void ew_kernel(const EwParams p) {
     fill8c(1.f, is);
     fill8c(0.f, k1);
     fill8c(0.f, k2);
-    if (p.scale) {  // uniform branches: (scale, shift) and (mean, invstd, dgamma, dbeta) come as groups
+    if (ACC && MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int cc = c + j < p.C ? c + j : p.C - 1;
+        sc[j] = cst[cc];
+        sh[j] = cst[kEwAccMaxC + cc];
+      }
+    } else if (p.scale) {  // uniform branches: (scale, shift) and (mean, invstd, dgamma, dbeta) come as groups
       load8c(p.scale, c, p.C, sc);
       load8c(p.shift, c, p.C, sh);
     }
     if (MODE == 1 && p.mean) {
       load8c(p.mean, c, p.C, mu);
       load8c(p.invstd, c, p.C, is);
-      load8c(p.dbeta, c, p.C, k1);
-      load8c(p.dgamma, c, p.C, k2);
+      if (ACC) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        k1[j] *= p.inv_count;
-        k2[j] *= p.inv_count;
+        for (int j = 0; j < 8; ++j) {
+          const int cc = c + j < p.C ? c + j : p.C - 1;
+          k1[j] = cst[cc];
+          k2[j] = cst[kEwAccMaxC + cc];
+        }
+      } else {
+        load8c(p.dbeta, c, p.C, k1);
+        load8c(p.dgamma, c, p.C, k2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          k1[j] *= p.inv_count;
+          k2[j] *= p.inv_count;
+        }
       }
     }
     auto math = [&](const f32x8& a, const f32x8& y, const f32x8& rs) -> f32x8 {
@@ -557,6 +626,16 @@ __global__ __launch_bounds__(256) void ew_kernel(const EwParams p) {
 // blocks are row chunks; a thread moves 16 B per row visit, so ~32 row-visits per thread keeps
 // enough bytes in flight while leaving >> 256 blocks for large activations
 // launch KERNEL<MODE, act> for the runtime activation id
+#define CVHIP_LAUNCH_ACT_ACC(KERNEL, MODE, ACTV, GRID, STREAM, PARAMS)                                                         \
+  switch (ACTV) {                                                                                                              \
+    case CVHIP_ACT_RELU: hipLaunchKernelGGL((KERNEL<MODE, CVHIP_ACT_RELU, true>), GRID, dim3(256), 0, STREAM, PARAMS); break;        \
+    case CVHIP_ACT_SILU: hipLaunchKernelGGL((KERNEL<MODE, CVHIP_ACT_SILU, true>), GRID, dim3(256), 0, STREAM, PARAMS); break;        \
+    case CVHIP_ACT_LEAKY: hipLaunchKernelGGL((KERNEL<MODE, CVHIP_ACT_LEAKY, true>), GRID, dim3(256), 0, STREAM, PARAMS); break;      \
+    case CVHIP_ACT_SIGMOID: hipLaunchKernelGGL((KERNEL<MODE, CVHIP_ACT_SIGMOID, true>), GRID, dim3(256), 0, STREAM, PARAMS); break;  \
+    case CVHIP_ACT_HSWISH: hipLaunchKernelGGL((KERNEL<MODE, CVHIP_ACT_HSWISH, true>), GRID, dim3(256), 0, STREAM, PARAMS); break;    \
+    default: hipLaunchKernelGGL((KERNEL<MODE, CVHIP_ACT_NONE, true>), GRID, dim3(256), 0, STREAM, PARAMS); break;                   \
+  }
+
 #define CVHIP_LAUNCH_ACT(KERNEL, MODE, ACTV, GRID, STREAM, PARAMS)                                                       \
   switch (ACTV) {                                                                                                        \
     case CVHIP_ACT_RELU: hipLaunchKernelGGL((KERNEL<MODE, CVHIP_ACT_RELU>), GRID, dim3(256), 0, STREAM, PARAMS); break;        \
@@ -831,6 +910,98 @@ int cvhip_add2d(const void* a, int32_t ld_a, const void* b, int32_t ld_b, void* 
   p.C = C;
   hipLaunchKernelGGL(ew_kernel<3>, dim3(ew_grid(M, C)), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("ew_kernel<3>");
+}
+
+int cvhip_bn_acc_shards(void) { return kAccShards; }
+
+int cvhip_bn_act_bwd_sums_acc(const void* dz, int32_t ld_dz, const void* y, int32_t ld_y, int64_t M, int32_t C, const float* scale,
+                              const float* shift, const float* mean, const float* invstd, int32_t act, float act_param, double* acc,
+                              int32_t acc_ld, void* stream) {
+  if (!dz || !y || !acc || M < 0 || C <= 0 || acc_ld < C) return CVHIP_ERR_INVALID;
+  if (M == 0) return CVHIP_OK;
+  RedParams p{};
+  p.a = (const h16_t*)dz;
+  p.y = (const h16_t*)y;
+  p.ld_a = ld_dz;
+  p.ld_y = ld_y;
+  p.M = M;
+  p.C = C;
+  p.scale = scale;
+  p.shift = shift;
+  p.mean = mean;
+  p.invstd = invstd;
+  p.act = act;
+  p.ap = act_param;
+  p.acc = acc;
+  p.acc_ld = acc_ld;
+  const int rows = colreduce_rows_host(M, C);
+  CVHIP_LAUNCH_ACT(colreduce_kernel, 1, act, dim3(rows), (hipStream_t)stream, p)
+  return check_launch("colreduce_kernel(acc)");
+}
+
+int cvhip_bn_act_fwd_acc(const void* y, int32_t ld_y, void* z, int32_t ld_z, int64_t M, int32_t C, const double* acc, int32_t acc_ld,
+                         int64_t count, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                         float eps, float* mean, float* invstd, float* scale, float* shift, int32_t act, float act_param,
+                         const void* residual, int32_t ld_res, int32_t res_pre, void* stream) {
+  if (!y || !z || !acc || !mean || !invstd || !scale || !shift || M <= 0 || C <= 0 || count <= 0 || acc_ld < C) return CVHIP_ERR_INVALID;
+  if (C > kEwAccMaxC) return CVHIP_ERR_UNSUPPORTED;
+  EwParams p{};
+  p.a = (const h16_t*)y;
+  p.ld_a = ld_y;
+  p.out = (h16_t*)z;
+  p.ld_out = ld_z;
+  p.res = (const h16_t*)residual;
+  p.ld_res = ld_res;
+  p.res_pre = residual ? res_pre : 0;
+  p.M = M;
+  p.C = C;
+  p.act = act;
+  p.ap = act_param;
+  p.acc = acc;
+  p.acc_ld = acc_ld;
+  p.count = (double)count;
+  p.gamma = gamma;
+  p.beta = beta;
+  p.rmean = running_mean;
+  p.rvar = running_var;
+  p.momentum = momentum;
+  p.eps = eps;
+  p.o_mean = mean;
+  p.o_invstd = invstd;
+  p.o_scale = scale;
+  p.o_shift = shift;
+  CVHIP_LAUNCH_ACT_ACC(ew_kernel, 0, act, dim3(ew_grid(M, C)), (hipStream_t)stream, p)
+  return check_launch("ew_kernel<0,acc>");
+}
+
+int cvhip_bn_act_bwd_apply_acc(const void* dz, int32_t ld_dz, const void* y, int32_t ld_y, void* dy, int32_t ld_dy, int64_t M, int32_t C,
+                               const float* scale, const float* shift, const float* mean, const float* invstd, const double* acc,
+                               int32_t acc_ld, float* dgamma, float* dbeta, int32_t accumulate, int32_t act, float act_param, void* stream) {
+  if (!dz || !y || !dy || !scale || !shift || !mean || !invstd || !acc || M <= 0 || C <= 0 || acc_ld < C) return CVHIP_ERR_INVALID;
+  if (C > kEwAccMaxC) return CVHIP_ERR_UNSUPPORTED;
+  EwParams p{};
+  p.a = (const h16_t*)dz;
+  p.ld_a = ld_dz;
+  p.y = (const h16_t*)y;
+  p.ld_y = ld_y;
+  p.out = (h16_t*)dy;
+  p.ld_out = ld_dy;
+  p.M = M;
+  p.C = C;
+  p.scale = scale;
+  p.shift = shift;
+  p.mean = mean;
+  p.invstd = invstd;
+  p.act = act;
+  p.ap = act_param;
+  p.inv_count = 1.f / (float)M;
+  p.acc = acc;
+  p.acc_ld = acc_ld;
+  p.o_dgamma = dgamma;
+  p.o_dbeta = dbeta;
+  p.accumulate = accumulate;
+  CVHIP_LAUNCH_ACT_ACC(ew_kernel, 1, act, dim3(ew_grid(M, C)), (hipStream_t)stream, p)
+  return check_launch("ew_kernel<1,acc>");
 }
 
 }  // extern "C"

@@ -166,6 +166,30 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// ---- BatchNorm statistic accumulators (fp64, sharded) ---------------------------------------------------------------------------
+// Producers (conv epilogues, the BN-backward reduction, dgrad epilogues) fold their per-tile column sums straight into a per-layer
+// accumulator acc[kAccShards][2][C] with fp64 atomics instead of writing one partial row per tile for a finalize launch to reduce;
+// consumers (the BN+activation apply passes, the fused 1x1 backward) fold the shards in their prologue. fp64 makes the result
+// independent of the arrival order to ~1e-16 relative (fp32 tile sums of similar magnitude add EXACTLY in fp64), i.e. the fp32
+// statistics derived from it are run-to-run identical for all practical purposes. 16 shards keep the same-address chain short
+// (profiles/r03_ceilings_probe.log: 6400 tiles x 128 adds cost 12 us spread over the producing kernel's lifetime).
+constexpr int kAccShards = CVHIP_BN_ACC_SHARDS;
+__device__ __forceinline__ void acc_add2(double* acc, int shard, int C, int c, float s1, float s2) {
+  double* a = acc + (size_t)(shard & (kAccShards - 1)) * 2 * C;
+  unsafeAtomicAdd(a + c, (double)s1);
+  unsafeAtomicAdd(a + C + c, (double)s2);
+}
+__device__ __forceinline__ void acc_fold2(const double* acc, int C, int c, double& s1, double& s2) {
+  double a = 0.0, b = 0.0;
+#pragma unroll
+  for (int sh = 0; sh < kAccShards; ++sh) {
+    a += acc[(size_t)sh * 2 * C + c];
+    b += acc[(size_t)sh * 2 * C + C + c];
+  }
+  s1 = a;
+  s2 = b;
+}
+
 // XCD-aware, bijective block-id remap (cdna_hip_programming.md §5 "XCD swizzle must be bijective"):
 // hardware places block b on XCD b%8; give each XCD a contiguous chunk of the logical tile space so
 // neighbouring tiles (shared im2col halos / shared A panels) hit the same L2.

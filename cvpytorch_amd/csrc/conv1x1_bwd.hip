@@ -49,6 +49,12 @@ struct Bwd1x1Params {
   int act;
   float ap;
   int M, K, C, ntiles;
+  // accumulator form: (sum du, sum du*xhat) arrive as an fp64 accumulator [kAccShards][2][acc_ld] that every block folds in its
+  // prologue (common.h acc_fold2) instead of as arrays prepared by a finalize launch; block (0, 0) stores the parameter gradients
+  const double* acc;
+  int acc_ld;
+  float *o_dgamma, *o_dbeta;
+  int accumulate;
 };
 
 typedef __attribute__((address_space(3))) h16x4 lds_h16x4_b;
@@ -127,12 +133,35 @@ __global__ __launch_bounds__(256, 2) void bwd1x1_kernel(const Bwd1x1Params p) {
     load8c(p.scale, kv * 8, p.K, sc);
     load8c(p.shift, kv * 8, p.K, sh);
   }
+  if (p.acc) {  // block-uniform
+    float* const kst = reinterpret_cast<float*>(sD);  // [2][KB]: the tile buffers are not in use yet
+    if (t < p.K) {
+      double s1, s2;
+      acc_fold2(p.acc, p.acc_ld, t, s1, s2);
+      kst[t] = (float)s1;
+      kst[KB + t] = (float)s2;
+      if (blockIdx.x == 0 && blockIdx.y == 0) {
+        if (p.o_dbeta) p.o_dbeta[t] = p.accumulate ? p.o_dbeta[t] + (float)s1 : (float)s1;
+        if (p.o_dgamma) p.o_dgamma[t] = p.accumulate ? p.o_dgamma[t] + (float)s2 : (float)s2;
+      }
+    }
+    __syncthreads();
+  }
   if (p.mean) {
     float mu[8], is[8], k1[8], k2[8];
     load8c(p.mean, kv * 8, p.K, mu);
     load8c(p.invstd, kv * 8, p.K, is);
-    load8c(p.dbeta, kv * 8, p.K, k1);
-    load8c(p.dgamma, kv * 8, p.K, k2);
+    if (p.acc) {
+      const float* const kst = reinterpret_cast<const float*>(sD);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        k1[j] = kst[kv * 8 + j];
+        k2[j] = kst[KB + kv * 8 + j];
+      }
+    } else {
+      load8c(p.dbeta, kv * 8, p.K, k1);
+      load8c(p.dgamma, kv * 8, p.K, k2);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float q2 = sc[j] * is[j] * (k2[j] * p.inv_count);
@@ -140,6 +169,8 @@ __global__ __launch_bounds__(256, 2) void bwd1x1_kernel(const Bwd1x1Params p) {
       c1[j] = q2 * mu[j] - sc[j] * (k1[j] * p.inv_count);
     }
   }
+
+  if (p.acc) __syncthreads();  // everybody has its constants before the first store_tile overwrites the scratch
 
   uint4 rd[D_IT], ry[D_IT], rx[X_IT];
   // loads are unconditional (rows past M read row 0 and are zeroed when the tile is written): no load sits in a branch
@@ -384,10 +415,11 @@ extern "C" {
 
 int cvhip_conv1x1_bwd_fused_ok(const cvhip_conv_desc* d) { return d ? bwd1x1_fits(d) : 0; }
 
-int cvhip_conv1x1_bwd_fused(const cvhip_conv_desc* d, const void* dz0, int32_t dz0_ld, const void* dz1, int32_t dz1_ld, int32_t k_split,
-                            const void* y, const void* x, const void* w_dgrad, const float* scale, const float* shift, const float* mean,
-                            const float* invstd, const float* dgamma, const float* dbeta, int32_t act, float act_param,
-                            const void* addend, int32_t addend_ld, void* dx, int32_t dx_ld, float* dw, void* stream) {
+static int bwd1x1_impl(const cvhip_conv_desc* d, const void* dz0, int32_t dz0_ld, const void* dz1, int32_t dz1_ld, int32_t k_split,
+                       const void* y, const void* x, const void* w_dgrad, const float* scale, const float* shift, const float* mean,
+                       const float* invstd, const float* dgamma, const float* dbeta, const double* acc, int32_t acc_ld, float* o_dgamma,
+                       float* o_dbeta, int32_t accumulate, int32_t act, float act_param, const void* addend, int32_t addend_ld, void* dx,
+                       int32_t dx_ld, float* dw, void* stream) {
   if (!d || !dz0 || !y || !x || !w_dgrad || !dx || !dw) return CVHIP_ERR_INVALID;
   if (!bwd1x1_structural(d)) return CVHIP_ERR_UNSUPPORTED;
   if (k_split <= 0 || k_split > d->K || (k_split & 7)) return CVHIP_ERR_INVALID;
@@ -396,7 +428,8 @@ int cvhip_conv1x1_bwd_fused(const cvhip_conv_desc* d, const void* dz0, int32_t d
   if ((((uintptr_t)dz0) | ((uintptr_t)y) | ((uintptr_t)x) | ((uintptr_t)w_dgrad) | ((uintptr_t)dx)) & 15) return CVHIP_ERR_INVALID;
   if (addend && ((addend_ld & 7) || addend_ld < d->C || (((uintptr_t)addend) & 15))) return CVHIP_ERR_INVALID;
   if ((scale == nullptr) != (shift == nullptr)) return CVHIP_ERR_INVALID;
-  if (mean && (!invstd || !dgamma || !dbeta || !scale)) return CVHIP_ERR_INVALID;
+  if (mean && (!invstd || !scale || (!acc && (!dgamma || !dbeta)))) return CVHIP_ERR_INVALID;
+  if (acc && (!mean || acc_ld < d->K)) return CVHIP_ERR_INVALID;
   Bwd1x1Params p{};
   p.dz0 = (const h16_t*)dz0;
   p.dz1 = (const h16_t*)(k_split < d->K ? dz1 : dz0);
@@ -425,7 +458,30 @@ int cvhip_conv1x1_bwd_fused(const cvhip_conv_desc* d, const void* dz0, int32_t d
   p.inv_count = 1.f / (float)p.M;
   p.act = act;
   p.ap = act_param;
+  p.acc = acc;
+  p.acc_ld = acc_ld;
+  p.o_dgamma = o_dgamma;
+  p.o_dbeta = o_dbeta;
+  p.accumulate = accumulate;
   return launch_bwd1x1(p, (hipStream_t)stream);
+}
+
+int cvhip_conv1x1_bwd_fused(const cvhip_conv_desc* d, const void* dz0, int32_t dz0_ld, const void* dz1, int32_t dz1_ld, int32_t k_split,
+                            const void* y, const void* x, const void* w_dgrad, const float* scale, const float* shift, const float* mean,
+                            const float* invstd, const float* dgamma, const float* dbeta, int32_t act, float act_param,
+                            const void* addend, int32_t addend_ld, void* dx, int32_t dx_ld, float* dw, void* stream) {
+  return bwd1x1_impl(d, dz0, dz0_ld, dz1, dz1_ld, k_split, y, x, w_dgrad, scale, shift, mean, invstd, dgamma, dbeta, nullptr, 0, nullptr,
+                     nullptr, 0, act, act_param, addend, addend_ld, dx, dx_ld, dw, stream);
+}
+
+int cvhip_conv1x1_bwd_fused_acc(const cvhip_conv_desc* d, const void* dz0, int32_t dz0_ld, const void* dz1, int32_t dz1_ld, int32_t k_split,
+                                const void* y, const void* x, const void* w_dgrad, const float* scale, const float* shift, const float* mean,
+                                const float* invstd, const double* acc, int32_t acc_ld, float* dgamma_out, float* dbeta_out, int32_t accumulate,
+                                int32_t act, float act_param, const void* addend, int32_t addend_ld, void* dx, int32_t dx_ld, float* dw,
+                                void* stream) {
+  if (!acc) return CVHIP_ERR_INVALID;
+  return bwd1x1_impl(d, dz0, dz0_ld, dz1, dz1_ld, k_split, y, x, w_dgrad, scale, shift, mean, invstd, nullptr, nullptr, acc, acc_ld, dgamma_out,
+                     dbeta_out, accumulate, act, act_param, addend, addend_ld, dx, dx_ld, dw, stream);
 }
 
 }  // extern "C"

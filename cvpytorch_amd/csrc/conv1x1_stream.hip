@@ -230,9 +230,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernA
           u1 += red[(w * BN + t) * 2 + 0];
           u2 += red[(w * BN + t) * 2 + 1];
         }
-        float* dst = p.stats + (int64_t)blockIdx.x * 2 * p.Nout;
-        dst[n0 + t] = u1;
-        dst[p.Nout + n0 + t] = u2;
+        if (p.stats_acc) {
+          acc_add2(reinterpret_cast<double*>(p.stats), blockIdx.x, p.Nout, n0 + t, u1, u2);
+        } else {
+          float* dst = p.stats + (int64_t)blockIdx.x * 2 * p.Nout;
+          dst[n0 + t] = u1;
+          dst[p.Nout + n0 + t] = u2;
+        }
       }
     }
   }

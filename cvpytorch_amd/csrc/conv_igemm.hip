@@ -274,9 +274,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKernArgs p) {
           s1 += red[(w * BN + t) * 2 + 0];
           s2 += red[(w * BN + t) * 2 + 1];
         }
-        float* dst = p.stats + (int64_t)mtile * 2 * p.Nout;
-        dst[n] = s1;
-        dst[p.Nout + n] = s2;
+        if (p.stats_acc) {
+          acc_add2(reinterpret_cast<double*>(p.stats), mtile, p.Nout, n, s1, s2);
+        } else {
+          float* dst = p.stats + (int64_t)mtile * 2 * p.Nout;
+          dst[n] = s1;
+          dst[p.Nout + n] = s2;
+        }
       }
     }
   }
@@ -675,9 +679,13 @@ __global__ __launch_bounds__(NW * 64, ((NST * (BM + (BN < BK ? BK : BN)) * BK * 
           s1 += red[(w * BN + t) * 2 + 0];
           s2 += red[(w * BN + t) * 2 + 1];
         }
-        float* dst = p.stats + (int64_t)mtile * 2 * p.Nout;
-        dst[n] = s1;
-        dst[p.Nout + n] = s2;
+        if (p.stats_acc) {
+          acc_add2(reinterpret_cast<double*>(p.stats), mtile, p.Nout, n, s1, s2);
+        } else {
+          float* dst = p.stats + (int64_t)mtile * 2 * p.Nout;
+          dst[n] = s1;
+          dst[p.Nout + n] = s2;
+        }
       }
     }
   }

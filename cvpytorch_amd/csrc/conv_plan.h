@@ -35,6 +35,7 @@ struct IgemmCommon {
   const float* bias;
   int bias_n;  // number of valid bias entries (k_valid)
   float* stats;
+  int stats_acc;  // 0: `stats` = fp32 partial rows [tile][2][Nout]; 1: `stats` is a double* accumulator [kAccShards][2][Nout] (atomics)
   int NB, IH, IW, Cin, x_ld;
   unsigned cin_magic;    // ceil(2^32 / Cin)
   int in_sh, in_sw;

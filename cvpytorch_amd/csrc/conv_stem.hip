@@ -34,6 +34,7 @@ struct StemParams {
   h16_t* y;
   const float* bias;
   float* stats;
+  int stats_acc;
   int bias_n;
   int NB, IH, IW, OH, OW, K, y_ld, R, S, pad_h, pad_w;
   int tiles_x, tiles_y, ntiles;
@@ -220,9 +221,13 @@ __global__ __launch_bounds__(256, 2) void stem_fprop_kernel(const StemParams p) 
           u1 += red[(w * 32 + t) * 2 + 0];
           u2 += red[(w * 32 + t) * 2 + 1];
         }
-        float* dst = p.stats + (int64_t)blockIdx.x * 2 * p.K;
-        dst[t] = u1;
-        dst[p.K + t] = u2;
+        if (p.stats_acc) {
+          acc_add2(reinterpret_cast<double*>(p.stats), blockIdx.x, p.K, t, u1, u2);
+        } else {
+          float* dst = p.stats + (int64_t)blockIdx.x * 2 * p.K;
+          dst[t] = u1;
+          dst[p.K + t] = u2;
+        }
       }
     }
   }
@@ -443,6 +448,7 @@ int try_launch_stem(const IgemmParams& p, hipStream_t stream) {
   sp.bias = p.bias;
   sp.bias_n = p.bias_n;
   sp.stats = p.stats;
+  sp.stats_acc = p.stats_acc;
   sp.NB = p.NB; sp.IH = p.IH; sp.IW = p.IW; sp.OH = p.OH; sp.OW = p.OW;
   sp.K = p.Nout; sp.y_ld = p.y_ld; sp.R = c.TR; sp.S = c.TS;
   sp.pad_h = -c.dh0; sp.pad_w = -c.dw0;

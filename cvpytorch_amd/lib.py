@@ -22,6 +22,7 @@ DTYPE_F32, DTYPE_F64, DTYPE_I32, DTYPE_BF16, DTYPE_U8 = 0, 1, 2, 3, 4
 RED_SUM, RED_MAX, RED_MIN = 0, 1, 2
 DGRAD_CLASS_INTS = 12
 REDUCE_SCRATCH_ROWS = 64  # CVHIP_REDUCE_SCRATCH_ROWS
+BN_ACC_SHARDS = 16  # CVHIP_BN_ACC_SHARDS
 
 
 class CvhipError(RuntimeError):
@@ -103,6 +104,14 @@ SIGNATURES = {
     "cvhip_bn_act_bwd_partial": (_i32, [_p, _i32, _p, _i32, _i64, _i32, _p, _p, _p, _p, _i32, _f32, _p, _p]),
     "cvhip_bn_bwd_finalize": (_i32, [_p, _i32, _i32, _p, _p, _p, _p, _p]),
     "cvhip_bn_act_bwd_apply": (_i32, [_p, _i32, _p, _i32, _p, _i32, _i64, _i32, _p, _p, _p, _p, _p, _p, _i32, _f32, _p]),
+    "cvhip_bn_acc_shards": (_i32, []),
+    "cvhip_conv2d_fprop_acc": (_i32, [_dp, _p, _p, _p, _p, _p]),
+    "cvhip_bn_act_fwd_acc": (_i32, [_p, _i32, _p, _i32, _i64, _i32, _p, _i32, _i64, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _i32, _f32, _p, _i32,
+                             _i32, _p]),
+    "cvhip_bn_act_bwd_sums_acc": (_i32, [_p, _i32, _p, _i32, _i64, _i32, _p, _p, _p, _p, _i32, _f32, _p, _i32, _p]),
+    "cvhip_bn_act_bwd_apply_acc": (_i32, [_p, _i32, _p, _i32, _p, _i32, _i64, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _i32, _f32, _p]),
+    "cvhip_conv1x1_bwd_fused_acc": (_i32, [_dp, _p, _i32, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _i32, _f32, _p, _i32,
+                                    _p, _i32, _p, _p]),
     "cvhip_colsum_partial": (_i32, [_p, _i64, _i32, _i32, _p, _p]),
     "cvhip_colsum_finalize": (_i32, [_p, _i32, _i32, _p, _i32, _p]),
     "cvhip_maxpool2d_fwd": (_i32, [_p, _i32, _p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),

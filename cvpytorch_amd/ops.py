@@ -45,6 +45,35 @@ def bump_weights_epoch():
     _weights_epoch += 1
 
 
+# ---- BatchNorm statistic accumulators (include/cvhip.h CVHIP_BN_ACC_SHARDS) -------------------------------------------------------
+# Training-mode BN layers fold their batch sums into an fp64 accumulator with atomics (conv epilogue / backward reduction) and the
+# consuming pass derives the per-channel constants in its prologue: no partial rows, no finalize launches (~115 five-microsecond
+# kernels per YOLOv5-s step). A layer's accumulator pair [2 (forward, backward)][shards][2][K] lives in the flat training state
+# (arena.FlatTrainState: ONE zero-fill per step for all layers); without it — or when a layer runs a second time inside one step
+# (yolov7 FeatureFusion.conv4) — a scratch accumulator is zero-filled per call. CVHIP_BN_ACC=0 restores the partial-row path.
+_BN_ACC = __import__("os").environ.get("CVHIP_BN_ACC", "1") != "0"
+_BN_ACC_MAX_C = 2048
+_acc_epoch = 0
+
+
+def bump_acc_epoch():
+    """called by whoever has just zeroed the persistent accumulators (arena.FlatTrainState.zero_stats)"""
+    global _acc_epoch
+    _acc_epoch += 1
+
+
+def _layer_acc(cfg, K, dev):
+    """(forward, backward) accumulators [shards][2][K] fp64, zeroed, for ONE application of the layer behind `cfg`"""
+    owner = cfg.acc_owner
+    if owner is not None:
+        ent = owner.__dict__.get(cfg.acc_attr)   # [tensor (2, shards, 2, K), epoch of its last use]
+        if ent is not None and ent[1] != _acc_epoch and ent[0].shape[-1] == K and ent[0].device == dev:
+            ent[1] = _acc_epoch
+            return ent[0][0], ent[0][1]
+    t = zero_fill(torch.empty((2, L.BN_ACC_SHARDS, 2, K), dtype=torch.float64, device=dev))
+    return t[0], t[1]
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -355,7 +384,8 @@ def conv_states_of(model):
 class ConvCfg:
     """Static configuration of one conv(+BN+act) layer (python-side)."""
     __slots__ = ("stride", "pad", "dil", "groups", "act", "act_param", "has_bn", "bn_training", "momentum", "eps",
-                 "state", "track", "vkey", "gw", "gb", "gg", "gbeta", "arena", "idx_w", "idx_b", "idx_bn", "sync", "out", "out_split", "dx_link", "res_link", "res_pre")
+                 "state", "track", "vkey", "gw", "gb", "gg", "gbeta", "arena", "idx_w", "idx_b", "idx_bn", "sync", "out", "out_split", "dx_link", "res_link", "res_pre",
+                 "acc_owner", "acc_attr")
 
     def __init__(self, stride, pad, dil, groups=1, act=L.ACT_NONE, act_param=0.0, has_bn=False, bn_training=True,
                  momentum=0.1, eps=1e-5, state=None, track=True):
@@ -381,6 +411,9 @@ class ConvCfg:
         self.res_link = None
         # residual joins BEFORE the activation: z = act(bn(conv(x)) + residual) (ResNet bottleneck tail) instead of after it
         self.res_pre = False
+        # module (the BatchNorm layer) that may carry this layer's persistent statistic accumulators, and under which attribute
+        self.acc_owner = None
+        self.acc_attr = "_hip_acc"
 
 
 # ---- SyncBatchNorm plumbing (trainer.py:126-127 -> torch.nn.SyncBatchNorm semantics) -------------------------------------
@@ -557,9 +590,10 @@ def _bwd1x1_ok(ctx, cfg, x, need_dx, need_dw, need_db, segs):
     return bool(L.load().cvhip_conv1x1_bwd_fused_ok(C.byref(desc)))
 
 
-def _bwd1x1(ctx, cfg, x, y, weight, segs, k_split, stats, with_mean, ag, ab, act, act_param):
+def _bwd1x1(ctx, cfg, x, y, weight, segs, k_split, stats, with_mean, ag, ab, act, act_param, acc=None, g_out=None, b_out=None, accumulate=0):
     """dx, dw of a 1x1 Conv-BN-act layer from the gradient(s) at its OUTPUT in one launch (`segs`: one (tensor, pitch), or two
-    for sibling pairs; `stats` rows: mean, invstd, scale, shift; ag / ab: sum du*xhat / sum du)."""
+    for sibling pairs; `stats` rows: mean, invstd, scale, shift; ag / ab: sum du*xhat / sum du — or `acc`: the layer's backward
+    accumulator, folded by the kernel itself, which then also stores dgamma / dbeta into g_out / b_out)."""
     N, Cc, H, W, K, R, S, P, Q, Kp, x_ld, Cg = ctx.geom
     dev = x.device
     st = _stream()
@@ -590,15 +624,37 @@ def _bwd1x1(ctx, cfg, x, y, weight, segs, k_split, stats, with_mean, ag, ab, act
     mu = stats[0].data_ptr() if with_mean else None
     isd = stats[1].data_ptr() if with_mean else None
     M = N * H * W
-    _timed_call("bwd1x1_kernel", (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv1x1_bwd_fused", C.byref(desc), d0.data_ptr(), d0_ld,
-                _ptr(d1), d1_ld, k_split, y.data_ptr(), x.data_ptr(), ctx.w_dgrad.data_ptr(), sc, sh, mu, isd,
-                ag.data_ptr() if with_mean else None, ab.data_ptr() if with_mean else None, act, act_param, _ptr(g), g_ld,
-                dx.data_ptr(), Cc, dst.data_ptr(), st, passes=2, nbytes=2.0 * M * (2 * K + 2 * Cc))
+    if acc is not None:
+        _timed_call("bwd1x1_kernel", (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv1x1_bwd_fused_acc", C.byref(desc), d0.data_ptr(), d0_ld,
+                    _ptr(d1), d1_ld, k_split, y.data_ptr(), x.data_ptr(), ctx.w_dgrad.data_ptr(), sc, sh, mu, isd,
+                    acc.data_ptr(), K, _ptr(g_out), _ptr(b_out), int(accumulate), act, act_param, _ptr(g), g_ld,
+                    dx.data_ptr(), Cc, dst.data_ptr(), st, passes=2, nbytes=2.0 * M * (2 * K + 2 * Cc))
+    else:
+        _timed_call("bwd1x1_kernel", (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv1x1_bwd_fused", C.byref(desc), d0.data_ptr(), d0_ld,
+                    _ptr(d1), d1_ld, k_split, y.data_ptr(), x.data_ptr(), ctx.w_dgrad.data_ptr(), sc, sh, mu, isd,
+                    ag.data_ptr() if with_mean else None, ab.data_ptr() if with_mean else None, act, act_param, _ptr(g), g_ld,
+                    dx.data_ptr(), Cc, dst.data_ptr(), st, passes=2, nbytes=2.0 * M * (2 * K + 2 * Cc))
     if direct_w:
         _mark(arena, cfg.idx_w)
     if dw is not None and dw.dtype != weight.dtype:
         dw = dw.to(weight.dtype)
     return dx, dw
+
+
+def _bn_fwd_acc(y, y_ld, z, z_ld, M, kh, off, K, acc_f, gamma, beta, running_mean, running_var, cfg, stats, residual, res_ld, res_pre, st):
+    """BN + activation apply for channels [off, off + kh) of a K-channel layer whose (sum, sum of squares) sit in `acc_f`: the pass
+    derives scale / shift itself, stores the layer's statistics for backward and updates the running statistics (block 0)."""
+    o4, o8 = 4 * off, 8 * off
+    rm = running_mean if cfg.track else None
+    rv = running_var if cfg.track else None
+    g = gamma.detach() if gamma is not None else None
+    bt = beta.detach() if beta is not None else None
+    _timed_ew("bn_act_fwd(ew_kernel<0>)", 2.0 * M * kh * (3 if residual is not None else 2), "cvhip_bn_act_fwd_acc",
+              y.data_ptr() + 2 * off, y_ld, z.data_ptr(), z_ld, M, kh, acc_f.data_ptr() + o8, K, M,
+              (g.data_ptr() + o4) if g is not None else None, (bt.data_ptr() + o4) if bt is not None else None,
+              (rm.data_ptr() + o4) if rm is not None else None, (rv.data_ptr() + o4) if rv is not None else None,
+              cfg.momentum, cfg.eps, stats[0].data_ptr() + o4, stats[1].data_ptr() + o4, stats[2].data_ptr() + o4, stats[3].data_ptr() + o4,
+              cfg.act, cfg.act_param, _ptr(residual), res_ld, int(bool(res_pre)), st)
 
 
 class ConvBnAct(torch.autograd.Function):
@@ -646,6 +702,8 @@ class ConvBnAct(torch.autograd.Function):
         stats = None
         partial = None
         rows = 0
+        use_acc = False
+        acc_f = acc_b = None
         epilogue_stats = train_bn and not depthwise and Kp == K  # BN sums straight from the MFMA accumulators
         b = bias.detach() if bias is not None else None
         if b is not None and b.dtype != torch.float32:
@@ -661,15 +719,24 @@ class ConvBnAct(torch.autograd.Function):
             # pack descriptor: contiguous pitches (the packed images do not depend on activation pitches)
             pdesc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, Cc, Kp, kv, cv)
             cfg.state.prepare(weight, pdesc, need_dx, cfg.vkey)
-            if epilogue_stats:
+            use_acc = _BN_ACC and epilogue_stats and cfg.sync is None and K <= _BN_ACC_MAX_C
+            if use_acc:
+                acc_f, acc_b = _layer_acc(cfg, K, dev)
+            elif epilogue_stats:
                 rows = lib.cvhip_conv2d_fprop_stats_rows(C.byref(desc))
                 if rows < 0:
                     L.check(rows, "cvhip_conv2d_fprop_stats_rows")
                 partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
-            kname = "stem_fprop_kernel" if lib.cvhip_conv_stem_blocks(C.byref(desc)) > 0 else _igemm_name(Kp, N * P * Q, R * S * Cc, _pointwise(R, S, cfg), x_ld, partial is not None)
-            _timed_call(kname, (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv2d_fprop", C.byref(desc), x.data_ptr(),
-                        cfg.state.w_fprop.data_ptr(), _ptr(b), y.data_ptr(), _ptr(partial), st)
-        if train_bn:
+            kname = "stem_fprop_kernel" if lib.cvhip_conv_stem_blocks(C.byref(desc)) > 0 else _igemm_name(Kp, N * P * Q, R * S * Cc, _pointwise(R, S, cfg), x_ld, epilogue_stats)
+            if use_acc:
+                _timed_call(kname, (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv2d_fprop_acc", C.byref(desc), x.data_ptr(),
+                            cfg.state.w_fprop.data_ptr(), y.data_ptr(), acc_f.data_ptr(), st)
+            else:
+                _timed_call(kname, (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv2d_fprop", C.byref(desc), x.data_ptr(),
+                            cfg.state.w_fprop.data_ptr(), _ptr(b), y.data_ptr(), _ptr(partial), st)
+        if train_bn and use_acc:
+            stats = torch.empty((4, K), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift: written by the apply pass
+        elif train_bn:
             if partial is None:
                 rows = _colreduce_rows(M, K)
                 partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
@@ -698,8 +765,11 @@ class ConvBnAct(torch.autograd.Function):
             z2, z2_ld = _check_out(z2, N, K - k1, P, Q)
             z1 = empty_nhwc(N, k1, P, Q, dev)
             for off, kh, zz, zld in ((0, k1, z1, k1), (k1, K - k1, z2, z2_ld)):
-                _timed_ew("bn_act_fwd(ew_kernel<0>)", 4.0 * M * kh, "cvhip_bn_act_fwd", y.data_ptr() + 2 * off, Kp, zz.data_ptr(), zld, M, kh, stats[2].data_ptr() + 4 * off,
-                       stats[3].data_ptr() + 4 * off, cfg.act, cfg.act_param, None, 0, st)
+                if use_acc:
+                    _bn_fwd_acc(y, Kp, zz, zld, M, kh, off, K, acc_f, gamma, beta, running_mean, running_var, cfg, stats, None, 0, False, st)
+                else:
+                    _timed_ew("bn_act_fwd(ew_kernel<0>)", 4.0 * M * kh, "cvhip_bn_act_fwd", y.data_ptr() + 2 * off, Kp, zz.data_ptr(), zld, M, kh, stats[2].data_ptr() + 4 * off,
+                           stats[3].data_ptr() + 4 * off, cfg.act, cfg.act_param, None, 0, st)
             z = (z1, z2)
         elif cfg.has_bn or cfg.act != L.ACT_NONE or residual is not None:
             if cfg.out is not None:
@@ -709,10 +779,13 @@ class ConvBnAct(torch.autograd.Function):
             res_pre = bool(cfg.res_pre and residual is not None)
             if res_pre and (cfg.act not in (L.ACT_NONE, L.ACT_RELU, L.ACT_LEAKY) or Kp != K):
                 raise L.CvhipError("res_pre needs none / ReLU / LeakyReLU and an unpadded channel count")
-            _timed_ew("bn_act_fwd(ew_kernel<0>)", 2.0 * M * K * (3 if residual is not None else 2),
-                      "cvhip_bn_add_act_fwd" if res_pre else "cvhip_bn_act_fwd", y.data_ptr(), Kp, z.data_ptr(), z_ld, M, K,
-                   _ptr(stats[2]) if stats is not None else None, _ptr(stats[3]) if stats is not None else None,
-                   cfg.act, cfg.act_param, _ptr(residual), res_ld, st)
+            if use_acc:
+                _bn_fwd_acc(y, Kp, z, z_ld, M, K, 0, K, acc_f, gamma, beta, running_mean, running_var, cfg, stats, residual, res_ld, res_pre, st)
+            else:
+                _timed_ew("bn_act_fwd(ew_kernel<0>)", 2.0 * M * K * (3 if residual is not None else 2),
+                          "cvhip_bn_add_act_fwd" if res_pre else "cvhip_bn_act_fwd", y.data_ptr(), Kp, z.data_ptr(), z_ld, M, K,
+                       _ptr(stats[2]) if stats is not None else None, _ptr(stats[3]) if stats is not None else None,
+                       cfg.act, cfg.act_param, _ptr(residual), res_ld, st)
         else:
             z = y
         ctx.cfg = cfg
@@ -728,6 +801,7 @@ class ConvBnAct(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
         ctx.w_dgrad = cfg.state.w_dgrad if not depthwise else None
+        ctx.acc_b = acc_b if use_acc else None   # this application's backward accumulator (sum du, sum du*xhat), zeroed
         ctx.res_pre = bool(cfg.res_pre and residual is not None and not isinstance(z, tuple))
         if ctx.res_pre:
             ctx.save_for_backward(x, y, stats, weight, z)   # the activation's derivative is taken from the OUTPUT's sign
@@ -762,6 +836,29 @@ class ConvBnAct(torch.autograd.Function):
         pointwise = cfg.has_bn or act != L.ACT_NONE
         arena = cfg.arena
         fused = pointwise and _bwd1x1_ok(ctx, cfg, x, need_dx, need_dw, need_db, ((dz, dz_ld),))
+        acc_b = ctx.acc_b if ctx.train_bn else None
+        direct_bn = arena is not None and cfg.gg is not None and cfg.gbeta is not None
+        if acc_b is not None:
+            # (sum du, sum du*xhat) into the layer's accumulator; the consumer below folds it and stores dgamma / dbeta
+            _timed_ew("bn_act_bwd_sums(colreduce_kernel<1>)", 4.0 * M * K, "cvhip_bn_act_bwd_sums_acc", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, M, K,
+                      stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), act, act_param, acc_b.data_ptr(), K, st)
+            if direct_bn:
+                g_out, b_out, accum = cfg.gg, cfg.gbeta, 1
+            else:
+                g_out = dgamma = torch.empty((K,), dtype=torch.float32, device=dev)
+                b_out = dbeta = torch.empty((K,), dtype=torch.float32, device=dev)
+                accum = 0
+        if fused and acc_b is not None:
+            dx, dw = _bwd1x1(ctx, cfg, x, y, weight, ((dz, dz_ld),), K, stats, True, None, None, act, act_param, acc_b, g_out, b_out, accum)
+            if direct_bn:
+                need_dg = need_dbeta = False
+                for i in cfg.idx_bn:
+                    arena.mark_ready(i)
+            dres = dz if ctx.has_res else None
+            if dres is not None and cfg.res_link is not None and cfg.res_link.ok:
+                cfg.res_link.g = dres
+                dres = None
+            return dx, dw, None, (dgamma if need_dg else None), (dbeta if need_dbeta else None), None, None, dres, None
         if fused:
             # 1x1 layer: BN/activation backward applied on load inside ONE dgrad + wgrad kernel (no dy tensor, no separate passes)
             ag = ab = None
@@ -792,7 +889,15 @@ class ConvBnAct(torch.autograd.Function):
                 dy = zero_fill(torch.empty((N, P, Q, Kp), dtype=ACT_DTYPE, device=dev)).permute(0, 3, 1, 2)[:, :K]
             else:
                 dy = empty_nhwc(N, K, P, Q, dev)
-            if ctx.train_bn:
+            if acc_b is not None:
+                _timed_ew("bn_act_bwd_apply(ew_kernel<1>)", 6.0 * M * K, "cvhip_bn_act_bwd_apply_acc", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, dy.data_ptr(), Kp, M, K,
+                          stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), acc_b.data_ptr(), K,
+                          g_out.data_ptr(), b_out.data_ptr(), accum, act, act_param, st)
+                if direct_bn:
+                    need_dg = need_dbeta = False
+                    for i in cfg.idx_bn:
+                        arena.mark_ready(i)
+            elif ctx.train_bn:
                 rows = _colreduce_rows(M, K)
                 partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
                 _timed_ew("bn_act_bwd_sums(colreduce_kernel<1>)", 4.0 * M * K, "cvhip_bn_act_bwd_partial", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, M, K, stats[2].data_ptr(),
@@ -800,7 +905,6 @@ class ConvBnAct(torch.autograd.Function):
                        partial.data_ptr(), st)
                 dgamma = torch.empty((K,), dtype=torch.float32, device=dev)
                 dbeta = torch.empty((K,), dtype=torch.float32, device=dev)
-                direct_bn = arena is not None and cfg.gg is not None and cfg.gbeta is not None
                 L.call("cvhip_bn_bwd_finalize", partial.data_ptr(), rows, K, dgamma.data_ptr(), dbeta.data_ptr(),
                        cfg.gg.data_ptr() if direct_bn else None, cfg.gbeta.data_ptr() if direct_bn else None, st)
                 if direct_bn:
@@ -868,6 +972,27 @@ class ConvBnActPair(torch.autograd.Function):
             if d is None:
                 d = zero_fill(empty_nhwc(N, kh, P, Q, dev))
             segs.append(as_nhwc(d))
+        acc_b = ctx.acc_b if ctx.train_bn else None
+        if acc_b is not None:
+            # per-half sums into the pair's accumulator, then either ONE fused kernel or per-half apply passes that fold it themselves
+            halves = list(zip(segs, (ctx.k1, K - ctx.k1), (0, ctx.k1)))
+            for (d, d_ld), kh, off in halves:
+                sc, sh, mean, invstd = (stats[i].data_ptr() + 4 * off for i in (2, 3, 0, 1))
+                _timed_ew("bn_act_bwd_sums(colreduce_kernel<1>)", 4.0 * M * kh, "cvhip_bn_act_bwd_sums_acc", d.data_ptr(), d_ld, y.data_ptr() + 2 * off, Kp, M, kh,
+                          sc, sh, mean, invstd, cfg.act, cfg.act_param, acc_b.data_ptr() + 8 * off, K, st)
+            if _bwd1x1_ok(ctx, cfg, x, ctx.needs_input_grad[0], True, False, segs):
+                dx, _ = _bwd1x1(ctx, cfg, x, y, weight, segs, ctx.k1, stats, True, None, None, cfg.act, cfg.act_param, acc_b, cfg.gg, cfg.gbeta, 1)
+            else:
+                dy = empty_nhwc(N, K, P, Q, dev)
+                for (d, d_ld), kh, off in halves:
+                    sc, sh, mean, invstd = (stats[i].data_ptr() + 4 * off for i in (2, 3, 0, 1))
+                    _timed_ew("bn_act_bwd_apply(ew_kernel<1>)", 6.0 * M * kh, "cvhip_bn_act_bwd_apply_acc", d.data_ptr(), d_ld, y.data_ptr() + 2 * off, Kp,
+                              dy.data_ptr() + 2 * off, Kp, M, kh, sc, sh, mean, invstd, acc_b.data_ptr() + 8 * off, K,
+                              cfg.gg.data_ptr() + 4 * off, cfg.gbeta.data_ptr() + 4 * off, 1, cfg.act, cfg.act_param, st)
+                dx, _, _ = _conv_grads(ctx, x, weight, dy, Kp, ctx.needs_input_grad[0], True, False)
+            for i in cfg.idx_bn:
+                cfg.arena.mark_ready(i)
+            return dx, None, None, None, None, None, None, None
         if ctx.train_bn and cfg.sync is None and _bwd1x1_ok(ctx, cfg, x, ctx.needs_input_grad[0], True, False, segs):
             # fused form: per-half BN sums, then ONE kernel for BN/act backward + dgrad + wgrad of both siblings
             dgamma = torch.empty((K,), dtype=torch.float32, device=dev)

@@ -50,6 +50,7 @@ def sibling_pair_forward(m1, m2, x, owner, out2=None, out=None):
     bn_tick(bn1)
     bn_tick(bn2)
     cfg.out = out   # both halves side by side into one slice of a concat buffer (or None)
+    cfg.acc_owner, cfg.acc_attr = bn1, "_hip_acc_pair"   # the pair's statistic accumulators (K1 + K2 channels) hang on the first layer
     return ops.conv_bn_act_pair(x, operands, cfg, out2)
 
 

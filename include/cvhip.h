@@ -193,6 +193,11 @@ int cvhip_dwconv2d_wgrad(const cvhip_conv_desc* d, const void* x_bf16, const voi
  * CVHIP_REDUCE_SCRATCH_ROWS extra rows behind its payload: finalize pre-reduces many-row partials
  * (one row per conv M-tile: 25,600 for the YOLOv5-s stem at batch 64) into that scratch in parallel. */
 #define CVHIP_REDUCE_SCRATCH_ROWS 64
+/* BatchNorm statistic ACCUMULATORS (round 3): instead of one partial row per tile + a finalize launch, producers add their tile sums
+ * with fp64 atomics into acc[CVHIP_BN_ACC_SHARDS][2][ld] (zeroed by the caller once per step) and consumers fold the shards in their
+ * prologue — entry points with the suffix _acc. Arrival order changes the fp64 sum by <= ~1e-16 relative, so the fp32 statistics
+ * derived from it are run-to-run identical for practical purposes. */
+#define CVHIP_BN_ACC_SHARDS 16
 /* number of partial rows stage-1 reductions produce for an M-row matrix */
 int cvhip_colreduce_rows(int64_t M, int32_t C);
 
@@ -562,6 +567,35 @@ int cvhip_comm_broadcast(void* comm, void* buf, int64_t bytes, int32_t root, voi
  * all-gather with the next forward or shard the optimizer between the phases. */
 int cvhip_comm_reduce_scatter_f32(void* comm, void* buf_f32, int64_t count, void* stream);
 int cvhip_comm_all_gather_f32(void* comm, void* buf_f32, int64_t count, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm through statistic accumulators (no partial rows, no finalize launches); see CVHIP_BN_ACC_SHARDS.
+ * Replaces the same reference calls as the partial-row forms (bricks/conv_module.py:209-213, native_batch_norm(_backward)).
+ * ------------------------------------------------------------------------------------------ */
+int cvhip_bn_acc_shards(void);
+/* convolution (no bias) whose epilogue adds (sum y, sum y^2) of the fp32 accumulators into bn_acc[shards][2][K] */
+int cvhip_conv2d_fprop_acc(const cvhip_conv_desc* d, const void* x, const void* w, void* y, double* bn_acc, void* stream);
+/* z = act(bn(y)) (+ residual; res_pre: before the activation). Every block derives scale / shift of its channels from `acc`
+ * (element count `count` per channel); block 0 stores mean | invstd | scale | shift (4 arrays of C floats) for backward and updates
+ * the running statistics exactly as cvhip_bn_finalize does. C <= 2048. */
+int cvhip_bn_act_fwd_acc(const void* y, int32_t ld_y, void* z, int32_t ld_z, int64_t M, int32_t C, const double* acc, int32_t acc_ld,
+                         int64_t count, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                         float eps, float* mean, float* invstd, float* scale, float* shift, int32_t act, float act_param,
+                         const void* residual, int32_t ld_res, int32_t res_pre, void* stream);
+/* (sum du, sum du*xhat) of the BN+activation backward into acc[shards][2][acc_ld] (du = dz * act'(scale*y + shift)) */
+int cvhip_bn_act_bwd_sums_acc(const void* dz, int32_t ld_dz, const void* y, int32_t ld_y, int64_t M, int32_t C, const float* scale,
+                              const float* shift, const float* mean, const float* invstd, int32_t act, float act_param, double* acc,
+                              int32_t acc_ld, void* stream);
+/* dy from (dz, y) with the two sums taken from `acc`; block 0 stores (accumulate != 0: adds) dgamma / dbeta (either may be NULL) */
+int cvhip_bn_act_bwd_apply_acc(const void* dz, int32_t ld_dz, const void* y, int32_t ld_y, void* dy, int32_t ld_dy, int64_t M, int32_t C,
+                               const float* scale, const float* shift, const float* mean, const float* invstd, const double* acc,
+                               int32_t acc_ld, float* dgamma, float* dbeta, int32_t accumulate, int32_t act, float act_param, void* stream);
+/* cvhip_conv1x1_bwd_fused with the two sums taken from `acc` (K = k_split .. both siblings' channels) */
+int cvhip_conv1x1_bwd_fused_acc(const cvhip_conv_desc* d, const void* dz0, int32_t dz0_ld, const void* dz1, int32_t dz1_ld, int32_t k_split,
+                                const void* y, const void* x, const void* w_dgrad, const float* scale, const float* shift, const float* mean,
+                                const float* invstd, const double* acc, int32_t acc_ld, float* dgamma_out, float* dbeta_out, int32_t accumulate,
+                                int32_t act, float act_param, const void* addend, int32_t addend_ld, void* dx, int32_t dx_ld, float* dw,
+                                void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Hardware probes used by the GPU test-suite to pin the MFMA / LDS-transpose lane layouts the
