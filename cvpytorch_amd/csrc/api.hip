@@ -384,6 +384,8 @@ int cvhip_conv2d_fprop(const cvhip_conv_desc* d, const void* x, const void* w, c
   p.bias_n = d->k_valid > 0 ? d->k_valid : d->K;
   p.stats = stats_partial;
   p.stats_acc = 0;
+  p.stats_ld = d->K;
+  p.tail_y = nullptr;
   p.y_vec_ok = ((d->y_ld & 3) == 0) && ((((uintptr_t)y) & 7) == 0);
   return launch_igemm(p, (hipStream_t)stream);
 }
@@ -402,11 +404,14 @@ int cvhip_conv2d_fprop_acc(const cvhip_conv_desc* d, const void* x, const void* 
   p.bias_n = d->k_valid > 0 ? d->k_valid : d->K;
   p.stats = reinterpret_cast<float*>(bn_acc);
   p.stats_acc = 1;
+  p.stats_ld = d->K;
+  p.tail_y = nullptr;
   p.y_vec_ok = ((d->y_ld & 3) == 0) && ((((uintptr_t)y) & 7) == 0);
   return launch_igemm(p, (hipStream_t)stream);
 }
 
-static int dgrad_impl(const cvhip_conv_desc* d, const void* dy, const void* w_dgrad, const void* addend, int addend_ld, void* dx, void* stream) {
+static int dgrad_impl(const cvhip_conv_desc* d, const void* dy, const void* w_dgrad, const void* addend, int addend_ld, void* dx, void* stream,
+                      const cvhip_bn_tail* tail = nullptr) {
   int st = validate_dense_desc(d);
   if (st) return st;
   if (!dy || !w_dgrad || !dx) return CVHIP_ERR_INVALID;
@@ -422,10 +427,35 @@ static int dgrad_impl(const cvhip_conv_desc* d, const void* dy, const void* w_dg
   p.bias = nullptr;
   p.stats = nullptr;
   p.stats_acc = 0;
+  p.stats_ld = d->C;
   p.res = (const h16_t*)addend;
   p.res_ld = addend_ld;
   p.y_vec_ok = ((d->x_ld & 3) == 0) && ((((uintptr_t)dx) & 7) == 0);
+  p.tail_y = nullptr;
+  if (tail) {
+    if (!tail->y || !tail->scale || !tail->shift || !tail->mean || !tail->invstd || !tail->acc || tail->acc_ld < d->C) return CVHIP_ERR_INVALID;
+    // every kernel's tail code sits on its packed-store path: 8-channel groups, 16-byte aligned rows of dx and y
+    if ((d->C & 7) || (d->x_ld & 7) || (tail->y_ld & 7) || (((uintptr_t)dx) & 15) || (((uintptr_t)tail->y) & 15)) return CVHIP_ERR_UNSUPPORTED;
+    if (tail->act != CVHIP_ACT_NONE && tail->act != CVHIP_ACT_RELU && tail->act != CVHIP_ACT_LEAKY && tail->act != CVHIP_ACT_SILU) return CVHIP_ERR_UNSUPPORTED;
+    p.tail_y = (const h16_t*)tail->y;
+    p.tail_y_ld = tail->y_ld;
+    p.tail_scale = tail->scale;
+    p.tail_shift = tail->shift;
+    p.tail_mean = tail->mean;
+    p.tail_invstd = tail->invstd;
+    p.tail_act = tail->act;
+    p.tail_ap = tail->act_param;
+    p.stats = reinterpret_cast<float*>(tail->acc);
+    p.stats_acc = 1;
+    p.stats_ld = tail->acc_ld;
+  }
   return launch_igemm(p, (hipStream_t)stream);
+}
+
+int cvhip_conv2d_dgrad_tail(const cvhip_conv_desc* d, const void* dy, const void* w_dgrad, const void* addend, int32_t addend_ld, void* dx,
+                            const cvhip_bn_tail* tail, void* stream) {
+  if (!tail) return CVHIP_ERR_INVALID;
+  return dgrad_impl(d, dy, w_dgrad, addend, addend_ld, dx, stream, tail);
 }
 
 int cvhip_conv2d_dgrad(const cvhip_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, void* stream) {

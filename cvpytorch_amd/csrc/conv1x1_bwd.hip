@@ -55,6 +55,15 @@ struct Bwd1x1Params {
   int acc_ld;
   float *o_dgamma, *o_dbeta;
   int accumulate;
+  // "tail" (conv_plan.h IgemmCommon::tail_y): dx is the output gradient of the Conv-BN-act layer that produced x; fold that
+  // layer's BatchNorm-backward sums into ITS accumulator from the stored dx rows and its y / statistics
+  const h16_t* tail_y;
+  int tail_y_ld;
+  const float *tail_scale, *tail_shift, *tail_mean, *tail_invstd;
+  int tail_act;
+  float tail_ap;
+  double* tail_acc;
+  int tail_acc_ld;
 };
 
 typedef __attribute__((address_space(3))) h16x4 lds_h16x4_b;
@@ -106,6 +115,7 @@ __global__ __launch_bounds__(256, 2) void bwd1x1_kernel(const Bwd1x1Params p) {
   unsigned char* const sW = smem;
   unsigned char* const sD = smem + W_BYTES;
   unsigned char* const sX = sD + D_BYTES;
+  float* const sT = reinterpret_cast<float*>(sX + RT * X_ROWB);  // tail: [4][CB] scale | shift | mean | invstd of channels c0 ..
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -219,6 +229,19 @@ __global__ __launch_bounds__(256, 2) void bwd1x1_kernel(const Bwd1x1Params p) {
     }
   };
 
+  const bool tail = p.tail_y != nullptr;  // block-uniform
+  if (tail && t < CB) {
+    sT[t] = p.tail_scale[c0 + t];
+    sT[CB + t] = p.tail_shift[c0 + t];
+    sT[2 * CB + t] = p.tail_mean[c0 + t];
+    sT[3 * CB + t] = p.tail_invstd[c0 + t];
+  }
+  float ts1[NF / 2][8], ts2[NF / 2][8];  // this lane's share of the tail sums for channels c0 + j*32 + g*8 + e
+#pragma unroll
+  for (int j = 0; j < NF / 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ts1[j][e] = ts2[j][e] = 0.f;
+
   int tile = blockIdx.x;
   load_tile(tile);
 
@@ -282,7 +305,19 @@ __global__ __launch_bounds__(256, 2) void bwd1x1_kernel(const Bwd1x1Params p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v.v[e] += rv.v[e];
           }
-          *reinterpret_cast<uint4*>(drow_p + j * 32) = pack8(v);
+          const uint4 packed = pack8(v);
+          *reinterpret_cast<uint4*>(drow_p + j * 32) = packed;
+          if (tail) {  // sums over the ROUNDED gradient, i.e. over what the tail layer's backward reads
+            const f32x8 dzr = unpack8(packed);
+            const f32x8 yv = unpack8(*reinterpret_cast<const uint4*>(p.tail_y + (int64_t)m * p.tail_y_ld + c0 + j * 32 + g * 8));
+            const float* const k = sT + j * 32 + g * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float du = dzr.v[e] * act_bwd(yv.v[e] * k[e] + k[CB + e], p.tail_act, p.tail_ap);
+              ts1[j][e] += du;
+              ts2[j][e] += du * ((yv.v[e] - k[2 * CB + e]) * k[3 * CB + e]);
+            }
+          }
         }
       }
     }
@@ -309,6 +344,32 @@ __global__ __launch_bounds__(256, 2) void bwd1x1_kernel(const Bwd1x1Params p) {
         for (int b = 0; b < CF; ++b) accw[a][b] = CVHIP_MFMA_16X16X32(fd[a], fx[b], accw[a][b], 0, 0, 0);
     }
     __syncthreads();  // everybody is done with the tiles before the next trip overwrites them
+  }
+
+  // ---- tail sums: channel c0 + j*32 + g*8 + e is shared by the 16 lanes of a DPP row and by the 4 waves ----------------------------
+  if (tail) {
+    float* const red = reinterpret_cast<float*>(sD);  // [4 waves][CB][2]; the loop's last barrier freed the tiles
+#pragma unroll
+    for (int j = 0; j < NF / 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float u1 = row16_sum(ts1[j][e]), u2 = row16_sum(ts2[j][e]);
+        if (r == 0) {
+          const int lc = j * 32 + g * 8 + e;
+          red[(wave * CB + lc) * 2 + 0] = u1;
+          red[(wave * CB + lc) * 2 + 1] = u2;
+        }
+      }
+    __syncthreads();
+    if (t < CB) {
+      float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        u1 += red[(w * CB + t) * 2 + 0];
+        u2 += red[(w * CB + t) * 2 + 1];
+      }
+      acc_add2(p.tail_acc, blockIdx.x, p.tail_acc_ld, c0 + t, u1, u2);
+    }
   }
 
   // ---- flush dW: lane holds D[k = 4g + e][c = lane & 15] per fragment -----------------------------------------------------------
@@ -362,7 +423,7 @@ int bwd1x1_fits(const cvhip_conv_desc* d) {
 
 template <int KB, int CB>
 static int launch_b1(const Bwd1x1Params& p, int blocks, hipStream_t s) {
-  constexpr int LDS = CB * (KB * 2 + 16) + 64 * KB * 2 + 64 * CB * 2;
+  constexpr int LDS = CB * (KB * 2 + 16) + 64 * KB * 2 + 64 * CB * 2 + 4 * CB * (int)sizeof(float);
   auto kern = bwd1x1_kernel<KB, CB>;
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {
@@ -419,7 +480,7 @@ static int bwd1x1_impl(const cvhip_conv_desc* d, const void* dz0, int32_t dz0_ld
                        const void* y, const void* x, const void* w_dgrad, const float* scale, const float* shift, const float* mean,
                        const float* invstd, const float* dgamma, const float* dbeta, const double* acc, int32_t acc_ld, float* o_dgamma,
                        float* o_dbeta, int32_t accumulate, int32_t act, float act_param, const void* addend, int32_t addend_ld, void* dx,
-                       int32_t dx_ld, float* dw, void* stream) {
+                       int32_t dx_ld, float* dw, void* stream, const cvhip_bn_tail* tail = nullptr) {
   if (!d || !dz0 || !y || !x || !w_dgrad || !dx || !dw) return CVHIP_ERR_INVALID;
   if (!bwd1x1_structural(d)) return CVHIP_ERR_UNSUPPORTED;
   if (k_split <= 0 || k_split > d->K || (k_split & 7)) return CVHIP_ERR_INVALID;
@@ -463,6 +524,22 @@ static int bwd1x1_impl(const cvhip_conv_desc* d, const void* dz0, int32_t dz0_ld
   p.o_dgamma = o_dgamma;
   p.o_dbeta = o_dbeta;
   p.accumulate = accumulate;
+  p.tail_y = nullptr;
+  if (tail) {
+    if (!tail->y || !tail->scale || !tail->shift || !tail->mean || !tail->invstd || !tail->acc || tail->acc_ld < d->C) return CVHIP_ERR_INVALID;
+    if ((tail->y_ld & 7) || (((uintptr_t)tail->y) & 15)) return CVHIP_ERR_UNSUPPORTED;
+    if (tail->act != CVHIP_ACT_NONE && tail->act != CVHIP_ACT_RELU && tail->act != CVHIP_ACT_LEAKY && tail->act != CVHIP_ACT_SILU) return CVHIP_ERR_UNSUPPORTED;
+    p.tail_y = (const h16_t*)tail->y;
+    p.tail_y_ld = tail->y_ld;
+    p.tail_scale = tail->scale;
+    p.tail_shift = tail->shift;
+    p.tail_mean = tail->mean;
+    p.tail_invstd = tail->invstd;
+    p.tail_act = tail->act;
+    p.tail_ap = tail->act_param;
+    p.tail_acc = tail->acc;
+    p.tail_acc_ld = tail->acc_ld;
+  }
   return launch_bwd1x1(p, (hipStream_t)stream);
 }
 
@@ -478,10 +555,10 @@ int cvhip_conv1x1_bwd_fused_acc(const cvhip_conv_desc* d, const void* dz0, int32
                                 const void* y, const void* x, const void* w_dgrad, const float* scale, const float* shift, const float* mean,
                                 const float* invstd, const double* acc, int32_t acc_ld, float* dgamma_out, float* dbeta_out, int32_t accumulate,
                                 int32_t act, float act_param, const void* addend, int32_t addend_ld, void* dx, int32_t dx_ld, float* dw,
-                                void* stream) {
-  if (!acc) return CVHIP_ERR_INVALID;
+                                const cvhip_bn_tail* tail, void* stream) {
+  if (!acc && mean) return CVHIP_ERR_INVALID;
   return bwd1x1_impl(d, dz0, dz0_ld, dz1, dz1_ld, k_split, y, x, w_dgrad, scale, shift, mean, invstd, nullptr, nullptr, acc, acc_ld, dgamma_out,
-                     dbeta_out, accumulate, act, act_param, addend, addend_ld, dx, dx_ld, dw, stream);
+                     dbeta_out, accumulate, act, act_param, addend, addend_ld, dx, dx_ld, dw, stream, tail);
 }
 
 }  // extern "C"

@@ -28,7 +28,9 @@ constexpr int kS1MaxLds = 72 * 1024;   // weight tile incl. row padding (+ 1 KB 
 constexpr int kS1MaxBlocks = 512;      // persistent grid: 2 blocks per CU
 constexpr int kS1MinTiles = 192;       // below this the grid cannot cover the chip: the general kernel's smaller tiles win
 
-template <int NF, int MF, bool STATS>
+// STATS: 0 = none, 1 = BatchNorm sums of the outputs (fprop), 2 = "tail" (dgrad; conv_plan.h IgemmCommon::tail_y): BatchNorm-BACKWARD
+// sums of the layer whose output gradient this launch produces, from the stored dz and that layer's y / statistics
+template <int NF, int MF, int STATS>
 __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernArgs p, int ntiles, int vec16) {
   constexpr int BN = NF * 16;
   constexpr int RT = 64 * MF;   // pixel rows per block tile: 4 waves x MF fragments x 16
@@ -101,7 +103,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernA
     }
   }
   float* const sbias = reinterpret_cast<float*>(smem + BN * brow);  // [BN] fp32 behind the weight tile
+  const float* const stail = sbias + BN;                            // [4][BN]: scale | shift | mean | invstd of the tail layer
   if (p.bias && t < BN) sbias[t] = (n0 + t < p.bias_n) ? p.bias[n0 + t] : 0.f;
+  if (STATS == 2 && t < BN) {
+    const int n = n0 + t < p.Nout ? n0 + t : p.Nout - 1;
+    sbias[BN + t] = p.tail_scale[n];
+    sbias[2 * BN + t] = p.tail_shift[n];
+    sbias[3 * BN + t] = p.tail_mean[n];
+    sbias[4 * BN + t] = p.tail_invstd[n];
+  }
   __syncthreads();
 
   f32x4 acc[NF][MF];
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernA
           v.v[q] = acc[2 * j][b][q];
           v.v[4 + q] = acc[2 * j + 1][b][q];
         }
-        if constexpr (STATS) {
+        if constexpr (STATS == 1) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             s1[2 * j][q] += v.v[q];
@@ -177,6 +187,27 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernA
 #pragma unroll
             for (int q = 0; q < 8; ++q)
               if (ch0 + q < p.Nout) v.v[q] += (float)rrow[q];
+          }
+        }
+        if constexpr (STATS == 2) {
+          if (m < M) {  // tail sums over the ROUNDED dz (what the tail layer's backward reads); the host guarantees the vector path
+            const uint4 packed = pack8(v);
+            const f32x8 dzr = unpack8(packed);
+            const f32x8 yv = unpack8(*reinterpret_cast<const uint4*>(p.tail_y + (int64_t)m * p.tail_y_ld + ch0));
+            const int cl8 = j * 32 + g * 8;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const float sc = stail[cl8 + q], sh = stail[BN + cl8 + q], mu = stail[2 * BN + cl8 + q], is = stail[3 * BN + cl8 + q];
+              const float du = dzr.v[q] * act_bwd(yv.v[q] * sc + sh, p.tail_act, p.tail_ap);
+              const float dx = du * ((yv.v[q] - mu) * is);
+              if (q < 4) {
+                s1[2 * j][q] += du;
+                s2[2 * j][q] += dx;
+              } else {
+                s1[2 * j + 1][q - 4] += du;
+                s2[2 * j + 1][q - 4] += dx;
+              }
+            }
           }
         }
         if (m < M) {
@@ -231,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernA
           u2 += red[(w * BN + t) * 2 + 1];
         }
         if (p.stats_acc) {
-          acc_add2(reinterpret_cast<double*>(p.stats), blockIdx.x, p.Nout, n0 + t, u1, u2);
+          acc_add2(reinterpret_cast<double*>(p.stats), blockIdx.x, p.stats_ld, n0 + t, u1, u2);
         } else {
           float* dst = p.stats + (int64_t)blockIdx.x * 2 * p.Nout;
           dst[n0 + t] = u1;
@@ -288,17 +319,17 @@ static bool s1x1_structural(const IgemmParams& p) {
          c.out_oh == 0 && c.out_ow == 0 && c.OHi == p.OH && c.OWi == p.OW && p.IH == p.OH && p.IW == p.OW && (p.x_ld & 7) == 0;
 }
 
-template <int NF, bool STATS>
+template <int NF, int STATS>
 static int launch_s1(const IgemmParams& p, int blocks, int ntiles, hipStream_t stream) {
   constexpr int MF = 2;
   const int bn = NF * 16;
   const int cin_pad = (p.Cin + 31) & ~31;
-  int lds = bn * (cin_pad * 2 + 16) + bn * (int)sizeof(float);  // weight tile + bias
+  int lds = bn * (cin_pad * 2 + 16) + 5 * bn * (int)sizeof(float);  // weight tile + bias + the tail layer's 4 constant rows
   if (lds < 4 * bn * 2 * (int)sizeof(float)) lds = 4 * bn * 2 * (int)sizeof(float);
   auto kern = conv1x1_stream_kernel<NF, MF, STATS>;
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kS1MaxLds + 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kS1MaxLds + 4096);
     if (e != hipSuccess) {
       set_last_error("hipFuncSetAttribute(conv1x1_stream_kernel)", e);
       return CVHIP_ERR_LAUNCH;
@@ -319,15 +350,20 @@ int try_launch_stream1x1(const IgemmParams& p, hipStream_t stream) {
   if (blocks <= 0) return -1;
   const int ntiles = (int)((M + 127) / 128);
   const int nf = s1x1_nf(p.Nout, p.Cin, p.stats != nullptr);
-  if (p.stats) {
-    if (nf == 2) return launch_s1<2, true>(p, blocks, ntiles, stream);
-    if (nf == 4) return launch_s1<4, true>(p, blocks, ntiles, stream);
-    return launch_s1<8, true>(p, blocks, ntiles, stream);
+  if (p.stats && p.tail_y) {
+    if (nf == 2) return launch_s1<2, 2>(p, blocks, ntiles, stream);
+    if (nf == 4) return launch_s1<4, 2>(p, blocks, ntiles, stream);
+    return launch_s1<8, 2>(p, blocks, ntiles, stream);
   }
-  if (nf == 2) return launch_s1<2, false>(p, blocks, ntiles, stream);
-  if (nf == 4) return launch_s1<4, false>(p, blocks, ntiles, stream);
-  if (nf == 16) return launch_s1<16, false>(p, blocks, ntiles, stream);
-  return launch_s1<8, false>(p, blocks, ntiles, stream);
+  if (p.stats) {
+    if (nf == 2) return launch_s1<2, 1>(p, blocks, ntiles, stream);
+    if (nf == 4) return launch_s1<4, 1>(p, blocks, ntiles, stream);
+    return launch_s1<8, 1>(p, blocks, ntiles, stream);
+  }
+  if (nf == 2) return launch_s1<2, 0>(p, blocks, ntiles, stream);
+  if (nf == 4) return launch_s1<4, 0>(p, blocks, ntiles, stream);
+  if (nf == 16) return launch_s1<16, 0>(p, blocks, ntiles, stream);
+  return launch_s1<8, 0>(p, blocks, ntiles, stream);
 }
 
 }  // namespace cvhip

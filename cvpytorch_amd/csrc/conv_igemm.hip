@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKernArgs p) {
           s2 += red[(w * BN + t) * 2 + 1];
         }
         if (p.stats_acc) {
-          acc_add2(reinterpret_cast<double*>(p.stats), mtile, p.Nout, n, s1, s2);
+          acc_add2(reinterpret_cast<double*>(p.stats), mtile, p.stats_ld, n, s1, s2);
         } else {
           float* dst = p.stats + (int64_t)mtile * 2 * p.Nout;
           dst[n] = s1;
@@ -341,15 +341,42 @@ __device__ __forceinline__ void wait_vmcnt() {
 //      alone on its CU still has a second wave per SIMD to issue MFMAs while the first one sits in its DMA-issue / fragment-read /
 //      barrier phase (profiles/r03_ceilings_probe.log: neither the LDS read rate nor the L2->LDS path is the limit of the 4-wave
 //      form; its in-order waves are).
-template <int BM, int BN, int WM, int WN, int ABL = 0, int NST = 3, int BK = 32, bool FAST = false, int NW = 4>
-__global__ __launch_bounds__(NW * 64, ((NST * (BM + (BN < BK ? BK : BN)) * BK * 2 > 80 * 1024) ? 1 : 2) * (NW / 4)) void igemm_dma_kernel(const IgemmKernArgs p) {
+// (occupancy bound = the blocks per CU the LDS ring allows, at most 4: keeps the register allocation from dropping a resident block —
+// the 256x64 two-slot configuration sits exactly on the 128-VGPR step)
+constexpr int igemm_lds_bytes(int BM, int BN, int BK, int NST, int LW) {
+  const int rpt = LW * (1024 / (BK * 2));
+  return NST * (BM + (BN < rpt ? rpt : BN)) * BK * 2;
+}
+constexpr int igemm_min_waves(int BM, int BN, int BK, int NST, int NW, int LW, int acc_regs) {
+  const int blocks = (160 * 1024) / igemm_lds_bytes(BM, BN, BK, NST, LW);
+  const int cap = acc_regs >= 128 ? 2 : 4;  // a 128-register accumulator tile leaves room for two waves per SIMD at most
+  return (blocks < 1 ? 1 : blocks > cap ? cap : blocks) * (NW / 4);
+}
+// WS : wave specialisation (NW = 8, FAST, 3-deep ring). Waves 0-3 are CONSUMERS: fragment reads + MFMA only, one per SIMD, the whole
+//      block tile between them (128x64 each for 256x128); waves 4-7 are LOADERS: they issue every LDS DMA of the ring and wait for
+//      it, nothing else. Wave w and wave w + 4 share a SIMD (workgroup waves are dealt to the SIMDs cyclically), so every SIMD runs
+//      one MFMA stream that never stops to compute addresses / issue DMAs / wait for its own loads, beside one VMEM stream that never
+//      competes for the matrix pipe. One s_barrier per ring slot couples the two roles (loaders arrive once the next slot has
+//      landed, consumers once they are done with the current one). Why: profiles/r03_igemm_ablation.log — in the symmetric form
+//      staging-only takes 126 us, fragment reads + MFMA only 115 us, both together 181 us: the two halves barely overlap because
+//      the same in-order waves do both and the blocks of a CU fall into step.
+// ORD: K-step order of FAST staging. 0: tap-major (all channel chunks of a tap, then the next tap) — a pixel row's cache lines are
+//      touched again only Cin / BK steps later, by the next tap. 1: CHUNK-major (all taps of a channel chunk, then the next chunk):
+//      consecutive steps read the same BK-channel segment of (almost) the same pixel rows, shifted by one tap, so the re-reads hit
+//      in L2 instead of going back to the Infinity Cache (profiles/r03_igemm_ablation.log: the pixel-tile DMA alone ran at the
+//      fabric's ~10 TB/s, 17 B/clk/CU, against 30-50 B/clk/CU for the same pattern from an L2-resident window).
+template <int BM, int BN, int WM, int WN, int ABL = 0, int NST = 3, int BK = 32, bool FAST = false, int NW = 4, bool WS = false, int ORD = 0>
+__global__ __launch_bounds__(NW * 64, WS ? 2 : igemm_min_waves(BM, BN, BK, NST, NW, NW, WM * WN / 64)) void igemm_dma_kernel(const IgemmKernArgs p) {
   constexpr int WAVES_N = BN / WN;
   constexpr int WAVES_M = BM / WM;
-  static_assert(WAVES_M * WAVES_N == NW, "NW waves per block");
+  constexpr int CW = WS ? 4 : NW;       // waves that compute
+  constexpr int LW = WS ? NW - 4 : NW;  // waves that stage
+  static_assert(!WS || (NW == 8 && FAST && NST == 3), "wave specialisation: 4 consumers + 4 loaders on the FAST 3-deep ring");
+  static_assert(WAVES_M * WAVES_N == CW, "one wave tile per computing wave");
   static_assert(BK == 32 || BK == 64, "reduction depth per stage");
   constexpr int MF = WM / 16, NF = WN / 16;
   constexpr int RPI = 1024 / (BK * 2);  // rows per DMA instruction (1 KiB): 16 (BK 32) / 8 (BK 64)
-  constexpr int RPT = NW * RPI;         // rows per pass of the block's waves: 64 / 32 (4 waves)
+  constexpr int RPT = LW * RPI;         // rows per pass of the staging waves: 64 / 32 (4 waves)
   constexpr int ROWB = BK * 2;          // LDS row bytes
   constexpr int A_IT = BM / RPT;
   constexpr int B_ROWS = BN < RPT ? RPT : BN;  // B tile padded so all 4 waves issue the same DMA count
@@ -363,7 +390,11 @@ __global__ __launch_bounds__(NW * 64, ((NST * (BM + (BN < BK ? BK : BN)) * BK * 
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const bool consumer = !WS || wave < 4;           // wave-uniform roles
+  const int cwave = WS ? (wave & 3) : wave;        // index among the computing waves (loaders: unused)
+  const int swave = WS ? (wave & 3) : wave;        // index among the staging waves (consumers: unused)
+  const int st_t = WS ? (t & 255) : t;             // thread index among the staging threads
+  const int wm = cwave / WAVES_N, wn = cwave % WAVES_N;
 
   const int lt = xcd_remap(blockIdx.x, p.total_tiles);
   int ci = 0, local;
@@ -373,12 +404,22 @@ __global__ __launch_bounds__(NW * 64, ((NST * (BM + (BN < BK ? BK : BN)) * BK * 
     ci = lt % p.ncls;
     local = lt / p.ncls;
   } else {
-#pragma unroll 1
-    for (int i = 1; i < p.ncls; ++i)
-      if (lt >= p.cls[i].tile_begin) ci = i;
-    local = lt - p.cls[ci].tile_begin;
+    int tb = 0;
+#pragma unroll
+    for (int i = 1; i < kKernelClasses; ++i)
+      if (i < p.ncls && lt >= p.cls[i].tile_begin) {
+        ci = i;
+        tb = p.cls[i].tile_begin;
+      }
+    local = lt - tb;
   }
-  const IgemmClass& cl = p.cls[ci];
+  // the class record BY VALUE, picked with compile-time indices: a run-time index into the by-value argument block makes the compiler
+  // keep the whole block (600 bytes) in scratch memory as soon as anything stops it from folding the access (measured: the step
+  // 30 % slower)
+  IgemmClass cl = p.cls[0];
+#pragma unroll
+  for (int i = 1; i < kKernelClasses; ++i)
+    if (ci == i) cl = p.cls[i];
   const int mtile = local / p.n_tiles;
   const int ntile = local - mtile * p.n_tiles;
   const int m0 = mtile * BM, n0 = ntile * BN;
@@ -390,7 +431,7 @@ __global__ __launch_bounds__(NW * 64, ((NST * (BM + (BN < BK ? BK : BN)) * BK * 
   const int OWi = cl.OWi, OHWi = cl.OHi * cl.OWi;
 
   // staging geometry: this thread's row inside a 4-wave pass and its physical 16-B slot inside the LDS row
-  const int srow = BK == 32 ? (t >> 2) : (wave * 8 + (lane >> 3));
+  const int srow = BK == 32 ? (st_t >> 2) : (swave * 8 + (lane >> 3));
   int ih0[A_IT], iw0[A_IT], pbase[A_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
@@ -416,7 +457,7 @@ __global__ __launch_bounds__(NW * 64, ((NST * (BM + (BN < BK ? BK : BN)) * BK * 
 
   // BK 32: physical slot (t&3) of a 64-B row must hold LOGICAL K-slot (t&3)^g(row>>2)
   // BK 64: physical slot (lane&7) of a 128-B row must hold LOGICAL K-slot (lane&7) ^ ((row>>1)&7), row = i*32 + wave*8 + (lane>>3)
-  const int lslot = BK == 32 ? ((t & 3) ^ ((0x78 >> (2 * ((t >> 4) & 3))) & 3)) : ((lane & 7) ^ (((wave & 1) << 2) | (lane >> 4)));
+  const int lslot = BK == 32 ? ((st_t & 3) ^ ((0x78 >> (2 * ((st_t >> 4) & 3))) & 3)) : ((lane & 7) ^ (((swave & 1) << 2) | (lane >> 4)));
   // fragment reads: lane (r = lane&15, g = lane>>4) reads logical slot 4*ks + g of row base + r
   const int swz_r = BK == 32 ? ((lane >> 4) ^ ((0x78 >> (2 * ((lane >> 2) & 3))) & 3)) : ((lane >> 1) & 7);
 
@@ -435,7 +476,7 @@ __global__ __launch_bounds__(NW * 64, ((NST * (BM + (BN < BK ? BK : BN)) * BK * 
       const int ih = ih0[i] + dh, iw = iw0[i] + dw;
       const bool ok = tap_ok && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
       const h16_t* src = ok ? (p.x + ((int64_t)(pbase[i] + ih * p.IW + iw) * p.x_ld + c0)) : zero;
-      CVHIP_GLDS16(src, sA + (i * RPT + wave * RPI) * ROWB);
+      CVHIP_GLDS16(src, sA + (i * RPT + swave * RPI) * ROWB);
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
@@ -443,7 +484,7 @@ __global__ __launch_bounds__(NW * 64, ((NST * (BM + (BN < BK ? BK : BN)) * BK * 
       const int n = n0 + row;
       const bool ok = row < BN && n < p.Nout && (int)k < Ktot;
       const h16_t* src = ok ? (wbase + ((int64_t)n * Ktot + k)) : zero;
-      CVHIP_GLDS16(src, sB + (i * RPT + wave * RPI) * ROWB);
+      CVHIP_GLDS16(src, sB + (i * RPT + swave * RPI) * ROWB);
     }
   };
 
@@ -461,7 +502,55 @@ __global__ __launch_bounds__(NW * 64, ((NST * (BM + (BN < BK ? BK : BN)) * BK * 
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) aptr[i] = zero;
   }
+  // chunk-major order (ORD 1): per staged row the address of its tap-(0,0) pixel and one validity bit per tap; a step's source is
+  // base + (wave-uniform tap offset + chunk offset) or the zero page
+  unsigned amask[A_IT];
+  int o_t = 0, o_c = 0;
+  const int ntaps = TR * TS;
+  if constexpr (FAST && ORD == 1) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      unsigned mk = 0;
+      for (int tr = 0, b = 0; tr < TR; ++tr)
+        for (int ts = 0; ts < TS; ++ts, ++b) {
+          const int ih = ih0[i] + tr * cl.dh_step, iw = iw0[i] + ts * cl.dw_step;
+          mk |= (((unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW) ? 1u : 0u) << b;
+        }
+      amask[i] = mk;
+      // (rows past M carry ih0 = -2^28: no valid tap, the base below is never dereferenced)
+      aptr[i] = p.x + ((int64_t)(pbase[i] + ih0[i] * p.IW + iw0[i]) * p.x_ld + lslot * 8);
+    }
+  }
   auto stage_fast = [&](int st) {
+    if constexpr (ORD == 1) {
+      const int64_t toff = ((int64_t)(f_tr * cl.dh_step) * p.IW + f_ts * cl.dw_step) * p.x_ld + o_c;  // wave-uniform
+      const unsigned bit = 1u << o_t;
+      unsigned char* const sA1 = smem + st * ST_BYTES;
+      unsigned char* const sB1 = sA1 + A_BYTES;
+      if (ABL != 5) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+          const h16_t* src = (amask[i] & bit) ? aptr[i] + toff : zero + lslot * 8;
+          CVHIP_GLDS16(src, sA1 + (i * RPT + swave * RPI) * ROWB);
+        }
+      }
+      const int boff = o_t * Cin + o_c;  // weight column of (tap, chunk)
+      if (ABL != 4) {
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) CVHIP_GLDS16(bptr[i] + boff, sB1 + (i * RPT + swave * RPI) * ROWB);
+      }
+      ++o_t;
+      if (++f_ts == TS) {
+        f_ts = 0;
+        ++f_tr;
+      }
+      if (o_t == ntaps) {
+        o_t = 0;
+        f_tr = f_ts = 0;
+        o_c += BK;
+      }
+      return;
+    }
     if (f_c == 0) {  // first K step of a tap: halo test + pixel address, once per Cin / BK steps
       const int dh = f_tr * cl.dh_step, dw = f_ts * cl.dw_step;
 #pragma unroll
@@ -476,16 +565,16 @@ __global__ __launch_bounds__(NW * 64, ((NST * (BM + (BN < BK ? BK : BN)) * BK * 
     unsigned char* const sB = sA + A_BYTES;
     // ABL 3 (experiment, wrong results): pixel rows are fetched for 2 of 9 taps only — the DMA volume a patch-in-LDS layout with
     // tap reuse would have; measures how much of the kernel's time is the issue cost of the A-tile DMA pieces
-    const bool a_live = ABL != 3 || ((f_tr * TS + f_ts) % 6 == 0);
+    const bool a_live = (ABL != 3 || ((f_tr * TS + f_ts) % 6 == 0)) && ABL != 5;  // ABL 5: weight tile only
     if (a_live) {
 #pragma unroll
-      for (int i = 0; i < A_IT; ++i) CVHIP_GLDS16(aptr[i], sA + (i * RPT + wave * RPI) * ROWB);
+      for (int i = 0; i < A_IT; ++i) CVHIP_GLDS16(aptr[i], sA + (i * RPT + swave * RPI) * ROWB);
     }
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) aptr[i] += BK;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-      CVHIP_GLDS16(bptr[i], sB + (i * RPT + wave * RPI) * ROWB);
+      if (ABL != 4) CVHIP_GLDS16(bptr[i], sB + (i * RPT + swave * RPI) * ROWB);  // ABL 4: pixel tile only
       bptr[i] += BK;
     }
     f_c += BK;
@@ -506,9 +595,30 @@ __global__ __launch_bounds__(NW * 64, ((NST * (BM + (BN < BK ? BK : BN)) * BK * 
 
   const int a_row = wm * WM + (lane & 15);
   const int b_row = wn * WN + (lane & 15);
-  auto compute = [&](int st) {
+  auto compute = [&](int st) __attribute__((always_inline)) {
     const unsigned char* const sA = smem + st * ST_BYTES;
     const unsigned char* const sB = sA + A_BYTES;
+    if constexpr (WS && BK == 64) {
+      // all fragment reads of the slot first: the second half's reads complete behind the first half's MFMAs (a consumer wave is
+      // alone on its SIMD's matrix pipe: nobody else hides its read latency)
+      h16x8 xa[2][MF], wb[2][NF];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int slot = (4 * ks + (lane >> 4)) ^ swz_r;
+#pragma unroll
+        for (int a = 0; a < NF; ++a) wb[ks][a] = *reinterpret_cast<const h16x8*>(sB + (b_row + a * 16) * ROWB + slot * 16);
+#pragma unroll
+        for (int b = 0; b < MF; ++b) xa[ks][b] = *reinterpret_cast<const h16x8*>(sA + (a_row + b * 16) * ROWB + slot * 16);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int a = 0; a < NF; ++a)
+#pragma unroll
+          for (int b = 0; b < MF; ++b)
+            acc[a][b] = CVHIP_MFMA_16X16X32(wb[ks][a], xa[ks][b], acc[a][b], 0, 0, 0);
+      return;
+    }
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
       const int slot = BK == 32 ? swz_r : ((4 * ks + (lane >> 4)) ^ swz_r);
@@ -525,19 +635,54 @@ __global__ __launch_bounds__(NW * 64, ((NST * (BM + (BN < BK ? BK : BN)) * BK * 
     }
   };
 
-  if constexpr (FAST && NST == 3) {
+  if constexpr (WS) {
+    if (!consumer) {
+      // LOADER: keeps two ring slots in flight; arrives at barrier #kt once slot kt has landed, then refills the slot the
+      // consumers finished with before they arrived there (slot kt - 1 = kt + 2 mod 3)
+      if (ABL != 2) {
+        if (nk > 0) stage_fast(0);
+        if (nk > 1) stage_fast(1);
+      }
+      int st_nxt2 = 2;
+      for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) wait_vmcnt<PER>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (ABL != 2 && kt + 2 < nk) stage_fast(st_nxt2);
+        st_nxt2 = st_nxt2 == NST - 1 ? 0 : st_nxt2 + 1;
+      }
+    } else {
+      // CONSUMER: one barrier per ring slot, then nothing but fragment reads and MFMAs
+      int st_cur = 0;
+      for (int kt = 0; kt < nk; ++kt) {
+        __builtin_amdgcn_s_barrier();
+        if (ABL != 1) compute(st_cur);
+        st_cur = st_cur == NST - 1 ? 0 : st_cur + 1;
+      }
+    }
+  } else if constexpr (FAST && NST == 3) {
     // no DMA is issued past the last tile (the running weight pointers would leave the array), so the last step waits for
     // everything instead of "all but the next tile"
     // a class without taps (1x1 stride-2 dgrad: three of the four pixel parities) has nk == 0: nothing to stage, zeros are stored
-    if (nk > 0) stage_fast(0);
-    if (nk > 1) stage_fast(1);
+    if (ABL != 2) {
+      if (nk > 0) stage_fast(0);
+      if (nk > 1) stage_fast(1);
+    }
     int st_cur = 0, st_nxt2 = 2;
     for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) wait_vmcnt<PER>();
-      else wait_vmcnt<0>();
+      if (ABL == 4) {
+        if (kt + 1 < nk) wait_vmcnt<A_IT>();
+        else wait_vmcnt<0>();
+      } else if (ABL == 5) {
+        if (kt + 1 < nk) wait_vmcnt<B_IT>();
+        else wait_vmcnt<0>();
+      } else {
+        if (kt + 1 < nk) wait_vmcnt<PER>();
+        else wait_vmcnt<0>();
+      }
       __builtin_amdgcn_s_barrier();
-      if (kt + 2 < nk) stage_fast(st_nxt2);
-      compute(st_cur);
+      if (ABL != 2 && kt + 2 < nk) stage_fast(st_nxt2);
+      if (ABL != 1 && ABL != 4 && ABL != 5) compute(st_cur);
       st_cur = st_cur == NST - 1 ? 0 : st_cur + 1;
       st_nxt2 = st_nxt2 == NST - 1 ? 0 : st_nxt2 + 1;
     }
@@ -576,10 +721,23 @@ __global__ __launch_bounds__(NW * 64, ((NST * (BM + (BN < BK ? BK : BN)) * BK * 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (all-zero) DMAs must land before smem is reused
   __syncthreads();
 
-  // bias through the LDS: per-element global loads in the epilogue doubled the time of memory-bound layers (tools/s1x1_bench.py)
+  // bias (and the tail layer's BN constants) through the LDS: per-element global loads in the epilogue doubled the time of
+  // memory-bound layers (tools/s1x1_bench.py)
   const float* const sbias = reinterpret_cast<const float*>(smem);
-  if (p.bias) {
-    if (t < BN) reinterpret_cast<float*>(smem)[t] = (n0 + t < p.bias_n) ? p.bias[n0 + t] : 0.f;
+  const float* const stail = sbias + BN;  // [4][BN]: scale | shift | mean | invstd of the tail layer's channels n0 .. n0 + BN
+  const bool tail = p.tail_y != nullptr;
+  if (p.bias || tail) {
+    if (t < BN) {
+      float* const w = reinterpret_cast<float*>(smem);
+      if (p.bias) w[t] = (n0 + t < p.bias_n) ? p.bias[n0 + t] : 0.f;
+      if (tail) {
+        const int n = n0 + t < p.Nout ? n0 + t : p.Nout - 1;
+        w[BN + t] = p.tail_scale[n];
+        w[2 * BN + t] = p.tail_shift[n];
+        w[3 * BN + t] = p.tail_mean[n];
+        w[4 * BN + t] = p.tail_invstd[n];
+      }
+    }
     __syncthreads();
   }
 
@@ -587,7 +745,16 @@ __global__ __launch_bounds__(NW * 64, ((NST * (BM + (BN < BK ? BK : BN)) * BK * 
   // Nout % 4 == 0 makes every lane's 4-channel group all-valid or all-invalid, so the packed path has no lane-divergent branch
   const bool vec4 = p.y_vec_ok && (p.Nout & 3) == 0;
   const bool rvec = p.res && vec4 && (p.res_ld & 3) == 0 && ((((uintptr_t)p.res) & 7) == 0);
-  auto epilogue = [&](auto vec_c) {
+  const int tact = p.tail_act;
+  const float tap = p.tail_ap;
+  float ts1[NF][4], ts2[NF][4];  // tail: this lane's share of (sum du, sum du * xhat) per channel
+#pragma unroll
+  for (int a = 0; a < NF; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ts1[a][r] = ts2[a][r] = 0.f;
+  // always_inline: an out-of-line instance would take `p` and the accumulators by address — the whole argument block and the
+  // accumulator tile then live in scratch memory (measured: 600 B of scratch per lane, the step 30 % slower)
+  auto epilogue = [&](auto vec_c) __attribute__((always_inline)) {
     constexpr bool VEC = decltype(vec_c)::value;
 #pragma unroll
     for (int b = 0; b < MF; ++b) {
@@ -635,6 +802,24 @@ __global__ __launch_bounds__(NW * 64, ((NST * (BM + (BN < BK ? BK : BN)) * BK * 
           u.x = pack2(v0, v1);
           u.y = pack2(v2, v3);
           *reinterpret_cast<uint2*>(yrow + n) = u;
+          if (tail) {  // block-uniform
+            // the sums are taken over the values the tail layer's backward will read: the ROUNDED dz just stored
+            float d[4], yv[4];
+            unpack2(u.x, d[0], d[1]);
+            unpack2(u.y, d[2], d[3]);
+            const uint2 uy = *reinterpret_cast<const uint2*>(p.tail_y + opix * p.tail_y_ld + n);
+            unpack2(uy.x, yv[0], yv[1]);
+            unpack2(uy.y, yv[2], yv[3]);
+            const int cl4 = wn * WN + a * 16 + nq;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(stail + cl4), sh = *reinterpret_cast<const f32x4*>(stail + BN + cl4);
+            const f32x4 mu = *reinterpret_cast<const f32x4*>(stail + 2 * BN + cl4), is = *reinterpret_cast<const f32x4*>(stail + 3 * BN + cl4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float du = d[r] * act_bwd(yv[r] * sc[r] + sh[r], tact, tap);
+              ts1[a][r] += du;
+              ts2[a][r] += du * ((yv[r] - mu[r]) * is[r]);
+            }
+          }
         } else {
           yrow[n] = (h16_t)v0;
           if (n + 1 < p.Nout) yrow[n + 1] = (h16_t)v1;
@@ -644,25 +829,115 @@ __global__ __launch_bounds__(NW * 64, ((NST * (BM + (BN < BK ? BK : BN)) * BK * 
       }
     }
   };
-  if (vec4) epilogue(std::true_type{});
-  else epilogue(std::false_type{});
+  // ---- staged epilogue: the output tile goes through the LDS and leaves as 16-byte stores, 16 consecutive lanes per pixel row -----
+  // The direct form below stores 8 bytes per lane in the MFMA fragment layout: 32 bytes contiguous per pixel row and instruction,
+  // 32 store instructions per lane for a 128x64 wave tile — store-ISSUE bound (profiles/r03_igemm_ablation.log: the kernel without
+  // its stores is 17-19 % faster). Here every lane writes its 4-channel groups into a [BM][BN] bf16 tile in the (now idle) ring
+  // memory (row pitch BN*2 + 16 bytes: the 16 pixel rows of a fragment land on 16 different 4-bank groups), and after one barrier
+  // the tile leaves row by row: one 16-byte store per lane, whole pixel rows contiguous. Same values, same rounding.
+  constexpr int EP_PITCH = BN * 2 + 16;
+  constexpr int EP_BASE = 5 * BN * (int)sizeof(float);  // behind the bias / tail constants
+  constexpr bool CAN_STAGE = EP_BASE + BM * EP_PITCH <= NST * ST_BYTES;
+  const bool staged = CAN_STAGE && ABL == 0 && !tail && p.staged_epilogue && (p.Nout & 7) == 0 && (p.y_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0);
+  if (staged) {
+    unsigned char* const tile = smem + EP_BASE;
+    if (consumer) {
+#pragma unroll
+      for (int b = 0; b < MF; ++b) {
+        const int row = wm * WM + b * 16 + (lane & 15);
+        const int m = m0 + row;
+        const h16_t* rbase = nullptr;
+        if (p.res && m < M) {
+          const int n_img = (int)fast_div31((unsigned)m, cl.ohw_mul, cl.ohw_sh);
+          const int rem = m - n_img * OHWi;
+          const int oh = (int)fast_div31((unsigned)rem, cl.ow_mul, cl.ow_sh);
+          const int ow = rem - oh * OWi;
+          const int64_t opix = ((int64_t)n_img * p.OH + (oh * p.out_sh + cl.out_oh)) * p.OW + (ow * p.out_sw + cl.out_ow);
+          rbase = p.res + opix * p.res_ld;
+        }
+#pragma unroll
+        for (int a = 0; a < NF; ++a) {
+          const int nl = wn * WN + a * 16 + nq;
+          float v0 = acc[a][b][0], v1 = acc[a][b][1], v2 = acc[a][b][2], v3 = acc[a][b][3];
+          if (p.bias) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + nl);
+            v0 += bv[0];
+            v1 += bv[1];
+            v2 += bv[2];
+            v3 += bv[3];
+          }
+          if (rbase && n0 + nl < p.Nout) {
+            const h16_t* rrow = rbase + n0 + nl;
+            if (rvec) {
+              const uint2 u = *reinterpret_cast<const uint2*>(rrow);
+              float r0, r1, r2, r3;
+              unpack2(u.x, r0, r1);
+              unpack2(u.y, r2, r3);
+              v0 += r0;
+              v1 += r1;
+              v2 += r2;
+              v3 += r3;
+            } else {
+              v0 += (float)rrow[0];
+              v1 += (float)rrow[1];
+              v2 += (float)rrow[2];
+              v3 += (float)rrow[3];
+            }
+          }
+          uint2 u;
+          u.x = pack2(v0, v1);
+          u.y = pack2(v2, v3);
+          *reinterpret_cast<uint2*>(tile + row * EP_PITCH + nl * 2) = u;
+        }
+      }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;  // 16-byte chunks per tile row
+    for (int idx = t; idx < BM * CPR; idx += NW * 64) {
+      const int row = idx / CPR, ch = idx - row * CPR;
+      const int m = m0 + row;
+      if (m >= M || n0 + ch * 8 >= p.Nout) continue;
+      const int n_img = (int)fast_div31((unsigned)m, cl.ohw_mul, cl.ohw_sh);
+      const int rem = m - n_img * OHWi;
+      const int oh = (int)fast_div31((unsigned)rem, cl.ow_mul, cl.ow_sh);
+      const int ow = rem - oh * OWi;
+      const int64_t opix = ((int64_t)n_img * p.OH + (oh * p.out_sh + cl.out_oh)) * p.OW + (ow * p.out_sw + cl.out_ow);
+      *reinterpret_cast<uint4*>(p.y + opix * p.y_ld + n0 + ch * 8) = *reinterpret_cast<const uint4*>(tile + row * EP_PITCH + ch * 16);
+    }
+  } else if (ABL == 6) {  // ablation: no output stores (what the epilogue costs); one store keeps the accumulators alive
+    float sacc = 0.f;
+#pragma unroll
+    for (int a = 0; a < NF; ++a)
+#pragma unroll
+      for (int b = 0; b < MF; ++b) sacc += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+    if (sacc == 123.456f) p.y[0] = (h16_t)sacc;
+  } else if (consumer) {  // (loaders hold no accumulators; they only take part in the barriers below)
+    if (vec4) epilogue(std::true_type{});  // (the host only sets a tail when the packed path applies)
+    else epilogue(std::false_type{});
+  }
 
   if (p.stats) {
+    if (p.bias || tail || staged) __syncthreads();  // the constants / the output tile staged above are dead now
     float* red = reinterpret_cast<float*>(smem);  // [WAVES_M][BN][2]
 #pragma unroll
     for (int a = 0; a < NF; ++a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float s1 = 0.f, s2 = 0.f;
+        if (tail) {
+          s1 = ts1[a][r];
+          s2 = ts2[a][r];
+        } else {
 #pragma unroll
-        for (int b = 0; b < MF; ++b) {
-          const float v = acc[a][b][r];
-          s1 += v;
-          s2 += v * v;
+          for (int b = 0; b < MF; ++b) {
+            const float v = acc[a][b][r];
+            s1 += v;
+            s2 += v * v;
+          }
         }
         s1 = row16_sum(s1);
         s2 = row16_sum(s2);
-        if ((lane & 15) == 0) {
+        if (consumer && (lane & 15) == 0) {
           const int nl = wn * WN + a * 16 + nq + r;
           red[(wm * BN + nl) * 2 + 0] = s1;
           red[(wm * BN + nl) * 2 + 1] = s2;
@@ -680,7 +955,7 @@ __global__ __launch_bounds__(NW * 64, ((NST * (BM + (BN < BK ? BK : BN)) * BK * 
           s2 += red[(w * BN + t) * 2 + 1];
         }
         if (p.stats_acc) {
-          acc_add2(reinterpret_cast<double*>(p.stats), mtile, p.Nout, n, s1, s2);
+          acc_add2(reinterpret_cast<double*>(p.stats), mtile, p.stats_ld, n, s1, s2);
         } else {
           float* dst = p.stats + (int64_t)mtile * 2 * p.Nout;
           dst[n] = s1;
@@ -697,7 +972,7 @@ static int ablate_mode() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("CVHIP_IGEMM_ABLATE");
-    v = (e && (e[0] == '1' || e[0] == '2' || e[0] == '3')) ? e[0] - '0' : 0;
+    v = (e && e[0] >= '1' && e[0] <= '6') ? e[0] - '0' : 0;
   }
   return v;
 }
@@ -743,6 +1018,33 @@ static int w8_level() {
   return v;
 }
 
+static int staged_epilogue() {  // CVHIP_IGEMM_STAGED=0 restores the direct fragment-layout stores
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CVHIP_IGEMM_STAGED");
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+
+static int ord_level() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CVHIP_IGEMM_ORD");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
+static int ws_level() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CVHIP_IGEMM_WS");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
 static bool use_v1() {
   static int v = -1;
   if (v < 0) {
@@ -770,6 +1072,7 @@ static int launch_group(IgemmKernArgs& p, hipStream_t stream) {
   }
   p.total_tiles = total;
   if (total == 0) return CVHIP_OK;
+  p.staged_epilogue = staged_epilogue();
   p.interleave = 0;
   if (p.ncls > 1 && interleave_classes() && !use_v1()) {
     bool same = true;
@@ -778,7 +1081,7 @@ static int launch_group(IgemmKernArgs& p, hipStream_t stream) {
   }
   if constexpr (WM == 64 && BM >= 128 && (BM != 128 || BN == 128)) {
     if (use_v1()) {
-      if (p.res) return CVHIP_ERR_UNSUPPORTED;
+      if (p.res || p.tail_y) return CVHIP_ERR_UNSUPPORTED;
       hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), dim3(total), dim3(256), 0, stream, p);
       return check_launch("igemm_kernel");
     }
@@ -795,12 +1098,31 @@ static int launch_group(IgemmKernArgs& p, hipStream_t stream) {
     hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 3, 2, 32, true>), dim3(total), dim3(256), 0, stream, p);
     return check_launch("igemm_kernel(abl3)");
   }
-  if (ablate_mode() == 0 && fast_staging() && p.Cin % 32 == 0 && p.Cin <= kFastMaxCin) {
+  if ((ablate_mode() == 0 || (ws_level() >= 1 && ablate_mode() <= 2)) && fast_staging() && p.Cin % 32 == 0 && p.Cin <= kFastMaxCin) {
     // FAST staging. Ring slot depth: 32 (64-byte LDS rows: a DMA instruction fetches 16 HALF cache lines) or, when Cin % 64 == 0
     // and CVHIP_IGEMM_BK64 asks for it, 64 (8 FULL lines per instruction: profiles/r03_ceilings_probe.log measures the
     // L2 -> LDS path at 28-35 B/clk/CU for half-line rows against 47-55 for full lines). 8-wave blocks: CVHIP_IGEMM_W8.
     const bool bk64 = bk64_level() > 0 && p.Cin % 64 == 0;
     const bool three = bk64 ? bk64_level() >= 2 : !nst2;
+    if constexpr (BM == 256 && BN == 128 && WM == 128) {
+      // wave-specialised form of the 256x128 tile (CVHIP_IGEMM_WS: 1 = 64-deep slots when Cin % 64 == 0, 2 = also 32-deep slots)
+      if (ws_level() >= 1 && p.Cin % 64 == 0 && ablate_mode() == 1) {
+        hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 1, 3, 64, true, 8, true>), dim3(total), dim3(512), 0, stream, p);
+        return check_launch("igemm_kernel(ws abl1)");
+      }
+      if (ws_level() >= 1 && p.Cin % 64 == 0 && ablate_mode() == 2) {
+        hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 2, 3, 64, true, 8, true>), dim3(total), dim3(512), 0, stream, p);
+        return check_launch("igemm_kernel(ws abl2)");
+      }
+      if (ws_level() >= 1 && p.Cin % 64 == 0) {
+        hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 3, 64, true, 8, true>), dim3(total), dim3(512), 0, stream, p);
+        return check_launch("igemm_kernel(wave-specialised, 64-deep)");
+      }
+      if (ws_level() >= 2) {
+        hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 3, 32, true, 8, true>), dim3(total), dim3(512), 0, stream, p);
+        return check_launch("igemm_kernel(wave-specialised, 32-deep)");
+      }
+    }
     bool w8 = false;
     if constexpr (BM == 256 && BN >= 64 && WM >= 64) w8 = w8_level() >= (BN == 128 ? 1 : 2);
     if constexpr (BM == 256 && BN >= 64 && WM >= 64) {
@@ -816,6 +1138,18 @@ static int launch_group(IgemmKernArgs& p, hipStream_t stream) {
         return check_launch("igemm_kernel(fast, 8 waves)");
       }
     }
+    bool taps32 = true;
+    for (int i = 0; i < p.ncls; ++i) taps32 = taps32 && p.cls[i].TR * p.cls[i].TS <= 32;
+    if (ord_level() >= 1 && taps32 && !bk64) {  // chunk-major K order (CVHIP_IGEMM_ORD)
+      if (three) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 3, 32, true, 4, false, 1>), dim3(total), dim3(256), 0, stream, p);
+      else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 2, 32, true, 4, false, 1>), dim3(total), dim3(256), 0, stream, p);
+      return check_launch("igemm_kernel(fast, chunk-major)");
+    }
+    if (ord_level() >= 1 && taps32 && bk64) {
+      if (three) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 3, 64, true, 4, false, 1>), dim3(total), dim3(256), 0, stream, p);
+      else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 2, 64, true, 4, false, 1>), dim3(total), dim3(256), 0, stream, p);
+      return check_launch("igemm_kernel(fast, chunk-major, 64-deep)");
+    }
     if (bk64) {
       if (three) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 3, 64, true>), dim3(total), dim3(256), 0, stream, p);
       else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 2, 64, true>), dim3(total), dim3(256), 0, stream, p);
@@ -824,6 +1158,15 @@ static int launch_group(IgemmKernArgs& p, hipStream_t stream) {
       else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 2, 32, true>), dim3(total), dim3(256), 0, stream, p);
     }
     return check_launch("igemm_kernel(fast)");
+  }
+  if ((ablate_mode() == 1 || ablate_mode() == 2 || ablate_mode() >= 4) && fast_staging() && p.Cin % 32 == 0 && p.Cin <= kFastMaxCin && !nst2) {
+    // the ablations of the FAST 3-deep-ring form (what the large layers run): 1 = staging only, 2 = fragment reads + MFMA only
+    if (ablate_mode() == 1) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 1, 3, 32, true>), dim3(total), dim3(256), 0, stream, p);
+    else if (ablate_mode() == 4) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 4, 3, 32, true>), dim3(total), dim3(256), 0, stream, p);
+    else if (ablate_mode() == 5) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 5, 3, 32, true>), dim3(total), dim3(256), 0, stream, p);
+    else if (ablate_mode() == 6) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 6, 3, 32, true>), dim3(total), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 2, 3, 32, true>), dim3(total), dim3(256), 0, stream, p);
+    return check_launch("igemm_kernel(fast ablation)");
   }
   if (ablate_mode() == 1) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 1>), dim3(total), dim3(256), 0, stream, p);
   else if (ablate_mode() == 2) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 2>), dim3(total), dim3(256), 0, stream, p);

@@ -35,6 +35,7 @@ struct IgemmCommon {
   const float* bias;
   int bias_n;  // number of valid bias entries (k_valid)
   float* stats;
+  int stats_ld;   // accumulator pitch (stats_acc = 1): channels per accumulator row (>= Nout; a sibling pair's accumulator is wider)
   int stats_acc;  // 0: `stats` = fp32 partial rows [tile][2][Nout]; 1: `stats` is a double* accumulator [kAccShards][2][Nout] (atomics)
   int NB, IH, IW, Cin, x_ld;
   unsigned cin_magic;    // ceil(2^32 / Cin)
@@ -42,9 +43,19 @@ struct IgemmCommon {
   int Nout, y_ld, OH, OW, out_sh, out_sw;
   int n_tiles, total_tiles, ncls;
   int y_vec_ok;
+  int staged_epilogue;  // 1: the implicit GEMM stores its output tile through the LDS (16-byte rows) when the geometry allows
   int interleave;  // 1: logical tile id = spatial tile * ncls + class (classes with equal tile counts: stride-parity dgrad)
   const h16_t* res;  // optional addend, same pixel grid and channel count as y (dgrad: the gradient arriving over a skip connection)
   int res_ld;
+  // "tail" (dgrad only): this launch produces dz, the gradient at the OUTPUT of a Conv-BN-act layer P (the layer whose activations
+  // were this convolution's input). Its epilogue then also folds P's BatchNorm-backward sums (sum du, sum du * xhat with
+  // du = dz * act'(scale * y + shift), xhat = (y - mean) * invstd) into P's accumulator (`stats` with stats_acc = 1), so that P's
+  // backward needs no reduction pass over (dz, y). tail_y: P's raw convolution output, same pixel grid / channel count as `y` here.
+  const h16_t* tail_y;
+  int tail_y_ld;
+  const float *tail_scale, *tail_shift, *tail_mean, *tail_invstd;
+  int tail_act;
+  float tail_ap;
 };
 
 constexpr int kKernelClasses = 4;

@@ -439,7 +439,7 @@ int try_launch_stem(const IgemmParams& p, hipStream_t stream) {
   const IgemmClass& c = p.cls[0];
   if (c.out_oh != 0 || c.out_ow != 0 || c.OHi != p.OH || c.OWi != p.OW || c.dh0 > 0 || c.dw0 > 0) return -1;
   const int blocks = stem_blocks(p.Cin, p.x_ld, p.Nout, c.TR, c.TS, p.in_sh, p.in_sw, c.dh_step, c.dw_step, p.NB, p.OH, p.OW);
-  if (blocks <= 0 || p.res || (((uintptr_t)p.x) & 15) || (((uintptr_t)p.w) & 15)) return -1;
+  if (blocks <= 0 || p.res || p.tail_y || (((uintptr_t)p.x) & 15) || (((uintptr_t)p.w) & 15)) return -1;
   const int nstep = (c.TR * c.TS + 3) / 4;
   StemParams sp;
   sp.x = p.x;

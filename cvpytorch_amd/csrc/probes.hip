@@ -185,6 +185,71 @@ __global__ __launch_bounds__(512) void probe_gather_kernel(const unsigned char* 
   if (reinterpret_cast<const unsigned*>(smem)[t] == 0x12345678u) out[blockIdx.x] = 1.f;
 }
 
+// ---- the implicit GEMM's staging STRUCTURE in isolation ------------------------------------------------------------------------
+// probe_gather_kernel plus, one flag at a time, what the real kernel does around the same loads: flags bit 0 = one s_barrier per K
+// step (after the wait), bit 1 = ring with counted waits (two K steps stay in flight, vmcnt(PER)) instead of batch + drain,
+// bit 2 = a weight tile as well (128 rows x 64 B per K step from ONE 128 x k_bytes*9 matrix shared by every block, pitch 2304 B
+// for k_bytes 256), bit 3 = the pixel rows shift by a tap offset every k_bytes / 64 steps (-41 .. +41 rows, as a 3x3 kernel on a
+// 40-wide map does). 256 threads, 64-B rows (BK 32): 4 pixel-tile pieces (+ 2 weight pieces) per wave per K step.
+__global__ __launch_bounds__(256, 2) void probe_stage_kernel(const unsigned char* __restrict__ src, size_t span, const unsigned char* __restrict__ wsrc,
+                                                             int row_stride, int k_bytes, int iters, int flags, float* out) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * 24576];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool bar = flags & 1, ring = flags & 2, wt = flags & 4, taps = flags & 8;
+  const size_t tile0 = (size_t)blockIdx.x * 256 * (size_t)row_stride;
+  const int steps_per_tap = k_bytes / 64;
+  const int wpitch = steps_per_tap * 64 * 9;
+  int koff = 0, tap = 0, kstep = 0;
+  auto issue = [&](int it) {
+    const int shift = taps ? ((tap / 3 - 1) * 40 + (tap % 3 - 1)) : 0;
+    unsigned char* const st = smem + (it % 3) * 24576;
+#pragma unroll
+    for (int pc = 0; pc < 4; ++pc) {
+      const int row = (pc * 4 + wave) * 16 + (lane >> 2) + shift + 41;
+      const unsigned char* g = src + ((tile0 + (size_t)row * row_stride + koff + (lane & 3) * 16) & (span - 1));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(st + (pc * 4 + wave) * 1024), 16, 0, 0);
+    }
+    if (wt) {
+#pragma unroll
+      for (int pc = 0; pc < 2; ++pc) {
+        const int row = (pc * 4 + wave) * 16 + (lane >> 2);
+        const unsigned char* g = wsrc + (size_t)row * wpitch + (size_t)(tap * steps_per_tap + kstep) * 64 + (lane & 3) * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(st + 16384 + (pc * 4 + wave) * 1024), 16, 0, 0);
+      }
+    }
+    koff += 64;
+    if (++kstep == steps_per_tap) {
+      kstep = 0;
+      koff = 0;
+      if (++tap == 9) tap = 0;
+    }
+  };
+  if (ring) {
+    issue(0);
+    issue(1);
+    for (int it = 0; it < iters; ++it) {
+      if (wt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (bar) __builtin_amdgcn_s_barrier();
+      issue(it + 2);
+    }
+  } else {
+    for (int it = 0; it < iters; ++it) {
+      issue(it);
+      if (it & 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (bar) __builtin_amdgcn_s_barrier();
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (reinterpret_cast<const unsigned*>(smem)[t] == 0x12345678u) out[blockIdx.x] = 1.f;
+}
+
 // ---- fp64 atomics into sharded accumulators --------------------------------------------------------------------------------
 // block b adds `n` values (n <= 256: threads t < n) into acc[(b % shards) * n + t]: the traffic of a conv epilogue that folds its
 // tile's BatchNorm sums (2 x K values) straight into per-layer accumulators. F32 != 0: the same with fp32 atomics.
@@ -260,6 +325,15 @@ int cvhip_probe_gather(int32_t row_bytes, const void* src, int64_t span, int32_t
   else if (row_bytes == 128) hipLaunchKernelGGL(probe_gather_kernel<128>, dim3(blocks), dim3(threads), 0, st, s, (size_t)span, row_stride, k_bytes, iters, depth, out);
   else return CVHIP_ERR_INVALID;
   return check_launch("probe_gather_kernel");
+}
+
+int cvhip_probe_stage(int32_t flags, const void* src, int64_t span, const void* weights, int32_t row_stride, int32_t k_bytes, int32_t iters,
+                      int32_t blocks, float* out, void* stream) {
+  if (!src || !weights || !out || iters <= 0 || blocks <= 0 || span < 65536 || (span & (span - 1)) || k_bytes < 64 || k_bytes % 64 || k_bytes > row_stride)
+    return CVHIP_ERR_INVALID;
+  hipLaunchKernelGGL(probe_stage_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)src, (size_t)span,
+                     (const unsigned char*)weights, row_stride, k_bytes, iters, flags, out);
+  return check_launch("probe_stage_kernel");
 }
 
 }  // extern "C"

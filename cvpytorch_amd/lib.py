@@ -39,6 +39,12 @@ class ConvDesc(C.Structure):
         return tuple(getattr(self, n) for n, _ in self._fields_)
 
 
+class BnTail(C.Structure):
+    """cvhip_bn_tail (include/cvhip.h)."""
+    _fields_ = [("y", C.c_void_p), ("y_ld", C.c_int32), ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p),
+                ("invstd", C.c_void_p), ("act", C.c_int32), ("act_param", C.c_float), ("acc", C.c_void_p), ("acc_ld", C.c_int32)]
+
+
 class PrepEntry(C.Structure):
     """cvhip_prep_entry (include/cvhip.h): one layer of a batched operand-preparation plan."""
     _fields_ = [("desc", ConvDesc), ("master", C.c_void_p), ("w_fprop", C.c_void_p), ("w_dgrad", C.c_void_p)]
@@ -111,7 +117,8 @@ SIGNATURES = {
     "cvhip_bn_act_bwd_sums_acc": (_i32, [_p, _i32, _p, _i32, _i64, _i32, _p, _p, _p, _p, _i32, _f32, _p, _i32, _p]),
     "cvhip_bn_act_bwd_apply_acc": (_i32, [_p, _i32, _p, _i32, _p, _i32, _i64, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _i32, _f32, _p]),
     "cvhip_conv1x1_bwd_fused_acc": (_i32, [_dp, _p, _i32, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _i32, _f32, _p, _i32,
-                                    _p, _i32, _p, _p]),
+                                    _p, _i32, _p, _p, _p]),
+    "cvhip_conv2d_dgrad_tail": (_i32, [_dp, _p, _p, _p, _i32, _p, _p, _p]),
     "cvhip_colsum_partial": (_i32, [_p, _i64, _i32, _i32, _p, _p]),
     "cvhip_colsum_finalize": (_i32, [_p, _i32, _i32, _p, _i32, _p]),
     "cvhip_maxpool2d_fwd": (_i32, [_p, _i32, _p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
@@ -186,6 +193,7 @@ SIGNATURES = {
     "cvhip_probe_mfma_peak2": (_i32, [_i32, _i32, _i32, _i32, _i32, _p, _p]),
     "cvhip_probe_load_path": (_i32, [_i32, _i32, _p, _i64, _i64, _i32, _i32, _i32, _p, _p]),
     "cvhip_probe_atomic_add": (_i32, [_i32, _p, _i32, _i32, _i32, _p]),
+    "cvhip_probe_stage": (_i32, [_i32, _p, _i64, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "cvhip_probe_gather": (_i32, [_i32, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
 }
 

@@ -78,6 +78,74 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- producer records: BN-backward sums from the kernel that writes the gradient ------------------------------------------------------
+# The gradient dz at the output of a Conv-BN-act layer P is, for most layers, written by exactly one kernel: the dgrad (or fused
+# 1x1 backward) of the layer that consumed P's output. That kernel can fold P's BatchNorm-backward sums (sum du, sum du*xhat) into
+# P's accumulator in its epilogue (include/cvhip.h cvhip_bn_tail) — P's backward then skips its reduction pass over (dz, y).
+# Plumbing: P's forward hangs a ProdInfo on its output tensor; the consuming op picks it up in its forward, hands the tail to its
+# dgrad in backward and remembers WHICH tensor the sums were taken over; P's backward uses them only if the gradient it receives is
+# that very tensor (autograd summed nothing else into it) — otherwise it clears the accumulator and reduces as before.
+# MEASURED AND LEFT OFF (CVHIP_BN_TAIL, default 0; profiles/r03_bn_tail_ab.log): every form is a net loss on YOLOv5-s — implicit-GEMM
+# dgrad tail +0.2 ms/step, fused 1x1 backward tail +0.28, streaming dgrad tail +0.03 (32 reduction launches deleted, but the epilogues'
+# extra y read in fragment layout and a second SiLU' per element cost more than the 25-30 us reductions they replace).
+_BN_TAIL_MASK = int(__import__("os").environ.get("CVHIP_BN_TAIL", "0"))   # bit 0: implicit-GEMM dgrad, 1: streaming 1x1 dgrad, 2: fused 1x1 backward
+_BN_TAIL = _BN_TAIL_MASK != 0
+_TAIL_ACTS = (L.ACT_NONE, L.ACT_RELU, L.ACT_LEAKY, L.ACT_SILU)
+
+
+class ProdInfo:
+    __slots__ = ("y", "y_ld", "stats", "act", "ap", "acc", "acc_ld", "c_off", "kh", "shape", "consumers", "fused_dx", "done", "parent", "halves")
+
+    def __init__(self, y, y_ld, stats, act, ap, acc, acc_ld, c_off, kh, shape, parent=None):
+        self.y, self.y_ld, self.stats, self.act, self.ap, self.acc, self.acc_ld = y, y_ld, stats, act, ap, acc, acc_ld
+        self.c_off, self.kh, self.shape = c_off, kh, tuple(shape)
+        self.consumers = 0      # Hip conv ops that took the tensor as their input in forward
+        self.fused_dx = None    # the gradient tensor whose rows the sums were taken over (kept alive until P's backward compares)
+        self.done = False
+        self.parent = parent
+        self.halves = None      # sibling pairs: the records of the two output tensors
+
+    def half(self, off, kh):
+        return ProdInfo(self.y, self.y_ld, self.stats, self.act, self.ap, self.acc, self.acc_ld, self.c_off + off, kh,
+                        (self.shape[0], kh, self.shape[2], self.shape[3]), parent=self)
+
+    def tail(self):
+        o4 = 4 * self.c_off
+        st = self.stats
+        return L.BnTail(self.y.data_ptr() + 2 * self.c_off, self.y_ld, st[2].data_ptr() + o4, st[3].data_ptr() + o4, st[0].data_ptr() + o4,
+                        st[1].data_ptr() + o4, self.act, self.ap, self.acc.data_ptr() + 8 * self.c_off, self.acc_ld)
+
+
+def _take_prod(x):
+    """the producer record of an op's input tensor (None unless a training-mode Conv-BN-act layer of this engine made it)"""
+    if not _BN_TAIL or not torch.is_grad_enabled():
+        return None
+    pi = getattr(x, "_hip_prod", None)
+    if pi is not None:
+        pi.consumers += 1
+    return pi
+
+
+def _tail_for(pi, N, Cc, H, W):
+    """cvhip_bn_tail for the dgrad that is about to write dx (N, Cc, H, W dense) of a tensor made by `pi`, or None"""
+    if pi is None or pi.done or pi.consumers != 1 or pi.kh != Cc or pi.shape != (N, Cc, H, W):
+        return None
+    if Cc % 8 or pi.c_off % 8 or pi.y_ld % 8 or (pi.y.data_ptr() + 2 * pi.c_off) % 16:
+        return None
+    return pi.tail()
+
+
+def _sums_already_done(pi, dz):
+    """True when the BN-backward sums of this layer (half) were folded by the kernel that wrote `dz`; if sums were folded for some
+    OTHER tensor (autograd accumulated several gradients) the caller must clear the accumulator and reduce itself -> 'dirty'"""
+    if pi is None or not pi.done:
+        return False
+    fd, pi.fused_dx = pi.fused_dx, None
+    if fd is not None and fd.data_ptr() == dz.data_ptr() and tuple(fd.shape) == tuple(dz.shape) and fd.stride() == dz.stride():
+        return True
+    return "dirty"
+
+
 class KernelTimer:
     """Optional per-launch HIP-event timing of the conv kernels (used by bench.py's roofline leg).
     Events are recorded on torch's current stream — the stream every libcvhip launch goes to."""
@@ -385,7 +453,7 @@ class ConvCfg:
     """Static configuration of one conv(+BN+act) layer (python-side)."""
     __slots__ = ("stride", "pad", "dil", "groups", "act", "act_param", "has_bn", "bn_training", "momentum", "eps",
                  "state", "track", "vkey", "gw", "gb", "gg", "gbeta", "arena", "idx_w", "idx_b", "idx_bn", "sync", "out", "out_split", "dx_link", "res_link", "res_pre",
-                 "acc_owner", "acc_attr")
+                 "acc_owner", "acc_attr", "prod", "in_prod")
 
     def __init__(self, stride, pad, dil, groups=1, act=L.ACT_NONE, act_param=0.0, has_bn=False, bn_training=True,
                  momentum=0.1, eps=1e-5, state=None, track=True):
@@ -414,6 +482,9 @@ class ConvCfg:
         # module (the BatchNorm layer) that may carry this layer's persistent statistic accumulators, and under which attribute
         self.acc_owner = None
         self.acc_attr = "_hip_acc"
+        # producer records (ProdInfo): `prod` = what this layer's forward made for its output, `in_prod` = its input's record
+        self.prod = None
+        self.in_prod = None
 
 
 # ---- SyncBatchNorm plumbing (trainer.py:126-127 -> torch.nn.SyncBatchNorm semantics) -------------------------------------
@@ -556,6 +627,26 @@ def _conv_grads(ctx, x, weight, dy, dy_ld, need_dx, need_dw, need_db):
             dx = empty_nhwc(N, Cc, H, W, dev)
             ddesc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, Cc, dy_ld, kv, cv)
             link = cfg.dx_link
+            pin = getattr(ctx, "in_prod", None)
+            tail = _tail_for(pin, N, Cc, H, W) if ctx.c_orig == Cc else None
+            if tail is not None:
+                tname = _igemm_name(Cc, N * H * W, -(-R // cfg.stride[0]) * -(-S // cfg.stride[1]) * Kp, _pointwise(R, S, cfg), dy_ld, True)
+                if not (_BN_TAIL_MASK & (2 if tname.startswith("conv1x1_stream") else 1)):
+                    tail = None
+            if tail is not None:
+                # dx is the output gradient of the layer that made x: its BN-backward sums come out of this dgrad's epilogue
+                g, g_ld = None, 0
+                if link is not None and link.g is not None:
+                    g, g_ld = as_nhwc(link.g)
+                    link.g = None
+                    if tuple(g.shape) != (N, Cc, H, W):
+                        raise L.CvhipError("GradLink: skip-connection gradient %s does not match the layer input %s" % (tuple(g.shape), (N, Cc, H, W)))
+                _timed_call(_igemm_name(Cc, N * H * W, -(-R // cfg.stride[0]) * -(-S // cfg.stride[1]) * Kp, _pointwise(R, S, cfg), dy_ld, True), (N, Cc, H, W, K, R, S, P, Q),
+                            "cvhip_conv2d_dgrad_tail", C.byref(ddesc), dy.data_ptr(), ctx.w_dgrad.data_ptr(), _ptr(g), g_ld, dx.data_ptr(), C.byref(tail), st)
+                pin.fused_dx, pin.done = dx, True
+                if pending_side is not None:
+                    pending_side()
+                return dx, dw, dbias
             if link is not None and link.g is not None and ctx.c_orig == Cc:
                 g, g_ld = as_nhwc(link.g)
                 link.g = None
@@ -625,10 +716,15 @@ def _bwd1x1(ctx, cfg, x, y, weight, segs, k_split, stats, with_mean, ag, ab, act
     isd = stats[1].data_ptr() if with_mean else None
     M = N * H * W
     if acc is not None:
+        pin = getattr(ctx, "in_prod", None)
+        tail = _tail_for(pin, N, Cc, H, W) if (_BN_TAIL_MASK & 4) else None
         _timed_call("bwd1x1_kernel", (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv1x1_bwd_fused_acc", C.byref(desc), d0.data_ptr(), d0_ld,
                     _ptr(d1), d1_ld, k_split, y.data_ptr(), x.data_ptr(), ctx.w_dgrad.data_ptr(), sc, sh, mu, isd,
                     acc.data_ptr(), K, _ptr(g_out), _ptr(b_out), int(accumulate), act, act_param, _ptr(g), g_ld,
-                    dx.data_ptr(), Cc, dst.data_ptr(), st, passes=2, nbytes=2.0 * M * (2 * K + 2 * Cc))
+                    dx.data_ptr(), Cc, dst.data_ptr(), C.byref(tail) if tail is not None else None, st, passes=2,
+                    nbytes=2.0 * M * (2 * K + 2 * Cc + (Cc if tail is not None else 0)))
+        if tail is not None:
+            pin.fused_dx, pin.done = dx, True
     else:
         _timed_call("bwd1x1_kernel", (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv1x1_bwd_fused", C.byref(desc), d0.data_ptr(), d0_ld,
                     _ptr(d1), d1_ld, k_split, y.data_ptr(), x.data_ptr(), ctx.w_dgrad.data_ptr(), sc, sh, mu, isd,
@@ -802,6 +898,10 @@ class ConvBnAct(torch.autograd.Function):
         ctx.has_res = residual is not None
         ctx.w_dgrad = cfg.state.w_dgrad if not depthwise else None
         ctx.acc_b = acc_b if use_acc else None   # this application's backward accumulator (sum du, sum du*xhat), zeroed
+        ctx.in_prod = cfg.in_prod if (need_dx and not depthwise and c_orig == Cc) else None
+        cfg.prod = ctx.prod = None
+        if use_acc and _BN_TAIL and cfg.act in _TAIL_ACTS and not (cfg.res_pre and residual is not None) and any(ctx.needs_input_grad):  # (grad mode is off inside forward)
+            cfg.prod = ctx.prod = ProdInfo(y, Kp, stats, cfg.act, cfg.act_param, acc_b, K, 0, K, (N, K, P, Q))
         ctx.res_pre = bool(cfg.res_pre and residual is not None and not isinstance(z, tuple))
         if ctx.res_pre:
             ctx.save_for_backward(x, y, stats, weight, z)   # the activation's derivative is taken from the OUTPUT's sign
@@ -839,9 +939,15 @@ class ConvBnAct(torch.autograd.Function):
         acc_b = ctx.acc_b if ctx.train_bn else None
         direct_bn = arena is not None and cfg.gg is not None and cfg.gbeta is not None
         if acc_b is not None:
-            # (sum du, sum du*xhat) into the layer's accumulator; the consumer below folds it and stores dgamma / dbeta
-            _timed_ew("bn_act_bwd_sums(colreduce_kernel<1>)", 4.0 * M * K, "cvhip_bn_act_bwd_sums_acc", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, M, K,
-                      stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), act, act_param, acc_b.data_ptr(), K, st)
+            # (sum du, sum du*xhat) into the layer's accumulator — unless the kernel that wrote dz already folded them in
+            # (ProdInfo); the consumer below folds the accumulator and stores dgamma / dbeta
+            have = _sums_already_done(getattr(ctx, "prod", None), dz)
+            if have == "dirty":
+                zero_fill(acc_b)
+                have = False
+            if not have:
+                _timed_ew("bn_act_bwd_sums(colreduce_kernel<1>)", 4.0 * M * K, "cvhip_bn_act_bwd_sums_acc", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, M, K,
+                          stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), act, act_param, acc_b.data_ptr(), K, st)
             if direct_bn:
                 g_out, b_out, accum = cfg.gg, cfg.gbeta, 1
             else:
@@ -940,7 +1046,11 @@ class ConvBnAct(torch.autograd.Function):
 
 
 def conv_bn_act(x, weight, bias, gamma, beta, running_mean, running_var, residual, cfg):
-    return ConvBnAct.apply(x, weight, bias, gamma, beta, running_mean, running_var, residual, cfg)
+    cfg.in_prod = _take_prod(x)
+    z = ConvBnAct.apply(x, weight, bias, gamma, beta, running_mean, running_var, residual, cfg)
+    if cfg.prod is not None and torch.is_tensor(z):
+        z._hip_prod = cfg.prod
+    return z
 
 
 class ConvBnActPair(torch.autograd.Function):
@@ -976,7 +1086,15 @@ class ConvBnActPair(torch.autograd.Function):
         if acc_b is not None:
             # per-half sums into the pair's accumulator, then either ONE fused kernel or per-half apply passes that fold it themselves
             halves = list(zip(segs, (ctx.k1, K - ctx.k1), (0, ctx.k1)))
-            for (d, d_ld), kh, off in halves:
+            pi = getattr(ctx, "prod", None)
+            have = [(_sums_already_done(h, d) if pi is not None and pi.halves is not None else False)
+                    for h, ((d, _), _, _) in zip(pi.halves if (pi is not None and pi.halves is not None) else (None, None), halves)]
+            if "dirty" in have:   # sums were folded over a tensor that is not the gradient we received: start over
+                zero_fill(acc_b)
+                have = [False, False]
+            for ((d, d_ld), kh, off), hv in zip(halves, have):
+                if hv:
+                    continue
                 sc, sh, mean, invstd = (stats[i].data_ptr() + 4 * off for i in (2, 3, 0, 1))
                 _timed_ew("bn_act_bwd_sums(colreduce_kernel<1>)", 4.0 * M * kh, "cvhip_bn_act_bwd_sums_acc", d.data_ptr(), d_ld, y.data_ptr() + 2 * off, Kp, M, kh,
                           sc, sh, mean, invstd, cfg.act, cfg.act_param, acc_b.data_ptr() + 8 * off, K, st)
@@ -1076,7 +1194,13 @@ def conv_bn_act_pair(x, operands, cfg, out2=None):
     wf, gf, bf, rmf, rvf, gw, gg, gb, arena, idx_w, idx_bn, k1 = operands
     cfg.out_split = (k1, out2) if out2 is not None else None
     cfg.arena, cfg.gw, cfg.gg, cfg.gbeta, cfg.idx_w, cfg.idx_bn = arena, gw, gg, gb, idx_w, idx_bn
-    return ConvBnActPair.apply(x, wf, gf, bf, rmf, rvf, cfg, k1)
+    cfg.in_prod = _take_prod(x)
+    z1, z2 = ConvBnActPair.apply(x, wf, gf, bf, rmf, rvf, cfg, k1)
+    if cfg.prod is not None:
+        kt = cfg.prod.kh
+        cfg.prod.halves = (cfg.prod.half(0, k1), cfg.prod.half(k1, kt - k1))
+        z1._hip_prod, z2._hip_prod = cfg.prod.halves
+    return z1, z2
 
 
 class BnAct(torch.autograd.Function):

@@ -573,6 +573,25 @@ int cvhip_comm_all_gather_f32(void* comm, void* buf_f32, int64_t count, void* st
  * Replaces the same reference calls as the partial-row forms (bricks/conv_module.py:209-213, native_batch_norm(_backward)).
  * ------------------------------------------------------------------------------------------ */
 int cvhip_bn_acc_shards(void);
+/* "tail" of a dgrad-producing call: the tensor whose gradient the call writes (its dx) is the OUTPUT z = act(bn(y)) of a
+ * Conv-BN-act layer P. With a tail the call's epilogue also adds P's BatchNorm-backward sums (sum du, sum du*xhat; du = dx *
+ * act'(scale*y + shift), xhat = (y - mean) * invstd, taken over the bf16-rounded dx it stores) into P's accumulator, so P's backward
+ * runs no reduction pass over (dz, y). y: P's raw convolution output — same pixel grid and channel count as dx, 16-byte aligned,
+ * y_ld % 8 == 0; scale / shift / mean / invstd: P's saved statistics (channel count floats each); act: none / ReLU / LeakyReLU /
+ * SiLU; acc: P's backward accumulator [CVHIP_BN_ACC_SHARDS][2][acc_ld]. */
+typedef struct cvhip_bn_tail {
+  const void* y;
+  int32_t y_ld;
+  const float *scale, *shift, *mean, *invstd;
+  int32_t act;
+  float act_param;
+  double* acc;
+  int32_t acc_ld;
+} cvhip_bn_tail;
+/* cvhip_conv2d_dgrad / _dgrad_add (addend may be NULL) with a tail; CVHIP_ERR_UNSUPPORTED when the geometry has no packed
+ * epilogue (C % 8, dx pitch / alignment) — the caller then runs the plain dgrad and the layer's own reduction pass */
+int cvhip_conv2d_dgrad_tail(const cvhip_conv_desc* d, const void* dy, const void* w_dgrad, const void* addend, int32_t addend_ld, void* dx,
+                            const cvhip_bn_tail* tail, void* stream);
 /* convolution (no bias) whose epilogue adds (sum y, sum y^2) of the fp32 accumulators into bn_acc[shards][2][K] */
 int cvhip_conv2d_fprop_acc(const cvhip_conv_desc* d, const void* x, const void* w, void* y, double* bn_acc, void* stream);
 /* z = act(bn(y)) (+ residual; res_pre: before the activation). Every block derives scale / shift of its channels from `acc`
@@ -590,12 +609,13 @@ int cvhip_bn_act_bwd_sums_acc(const void* dz, int32_t ld_dz, const void* y, int3
 int cvhip_bn_act_bwd_apply_acc(const void* dz, int32_t ld_dz, const void* y, int32_t ld_y, void* dy, int32_t ld_dy, int64_t M, int32_t C,
                                const float* scale, const float* shift, const float* mean, const float* invstd, const double* acc,
                                int32_t acc_ld, float* dgamma, float* dbeta, int32_t accumulate, int32_t act, float act_param, void* stream);
-/* cvhip_conv1x1_bwd_fused with the two sums taken from `acc` (K = k_split .. both siblings' channels) */
+/* cvhip_conv1x1_bwd_fused with the two sums taken from `acc` (K channels: both siblings'); `acc` may be NULL for a layer
+ * without training-mode BatchNorm that still wants a tail */
 int cvhip_conv1x1_bwd_fused_acc(const cvhip_conv_desc* d, const void* dz0, int32_t dz0_ld, const void* dz1, int32_t dz1_ld, int32_t k_split,
                                 const void* y, const void* x, const void* w_dgrad, const float* scale, const float* shift, const float* mean,
                                 const float* invstd, const double* acc, int32_t acc_ld, float* dgamma_out, float* dbeta_out, int32_t accumulate,
                                 int32_t act, float act_param, const void* addend, int32_t addend_ld, void* dx, int32_t dx_ld, float* dw,
-                                void* stream);
+                                const cvhip_bn_tail* tail /* optional: the layer that produced x */, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Hardware probes used by the GPU test-suite to pin the MFMA / LDS-transpose lane layouts the
@@ -629,6 +649,10 @@ int cvhip_probe_load_path(int32_t mode, int32_t depth, const void* src, int64_t 
 int cvhip_probe_atomic_add(int32_t f32, void* acc_zeroed, int32_t shards, int32_t n, int32_t blocks, void* stream);
 /* the implicit GEMM's A-tile staging pattern alone: every block fetches its 256 rows (pitch row_stride bytes) in K steps of row_bytes
  * (64 | 128) bytes per row, sweeping k_bytes per row, `depth` K steps in flight per wave; bytes = blocks * iters * 256 * row_bytes */
+/* the implicit GEMM's staging structure: flags bit 0 barrier per K step, 1 ring + counted waits, 2 shared weight tile, 3 tap shifts;
+ * 64-byte rows, 256 threads; `weights`: >= 128 * k_bytes * 9 bytes; bytes = blocks * iters * (16 KiB + 8 KiB with bit 2) */
+int cvhip_probe_stage(int32_t flags, const void* src, int64_t span, const void* weights, int32_t row_stride, int32_t k_bytes, int32_t iters,
+                      int32_t blocks, float* out, void* stream);
 int cvhip_probe_gather(int32_t row_bytes, const void* src, int64_t span, int32_t row_stride, int32_t k_bytes, int32_t iters, int32_t depth,
                        int32_t blocks, int32_t threads, float* out, void* stream);
 

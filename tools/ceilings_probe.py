@@ -94,6 +94,24 @@ def gather():
                         rowb, stride, kb, threads, blocks, depth, ms, nbytes / ms / 1e9, nbytes / CUS / (ms * 1e-3) / (GHZ * 1e9)))
 
 
+def stage():
+    print("== the implicit GEMM's staging STRUCTURE around the same loads (64-B rows, pitch 256 B = 128 channels, 256 threads) ==")
+    big = torch.empty((1 << 27,), dtype=torch.uint8, device=dev)     # 128 MiB: the activations of a 40x40x128 layer at batch 256
+    big.random_(0, 255)
+    w = torch.empty((128 * 256 * 9,), dtype=torch.uint8, device=dev)
+    w.random_(0, 255)
+    names = {0: "batch of 2 steps + drain", 1: "+ barrier", 2: "ring, counted waits", 3: "ring + barrier", 7: "ring + barrier + weight tile",
+             11: "ring + barrier + tap shifts", 15: "ring + barrier + weights + tap shifts (the kernel)"}
+    for span_name, span in (("32 MiB", 1 << 25), ("128 MiB", 1 << 27)):
+        for blocks in (400, 1600):
+            for flags in (0, 1, 2, 3, 7, 11, 15):
+                iters = 36 * 8
+                ms = timed(lambda: L.call("cvhip_probe_stage", flags, big.data_ptr(), span, w.data_ptr(), 256, 256, iters, blocks, out.data_ptr(), st))
+                nbytes = blocks * iters * (16384.0 + (8192.0 if flags & 4 else 0.0))
+                print("  span %-8s %4d blocks  %-52s %7.3f ms  %6.2f TB/s  %5.1f B/clk/CU" % (
+                    span_name, blocks, names[flags], ms, nbytes / ms / 1e9, nbytes / CUS / (ms * 1e-3) / (GHZ * 1e9)))
+
+
 def atomic():
     print("== per-block atomics into sharded accumulators: `blocks` blocks x n adds (a conv epilogue folding 2 x K BatchNorm sums) ==")
     acc = torch.zeros((64 * 256,), dtype=torch.float64, device=dev)
@@ -115,7 +133,7 @@ def atomic():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["lds", "mfma", "load", "gather", "atomic"]
+    which = sys.argv[1:] or ["lds", "mfma", "load", "gather", "stage", "atomic"]
     print("device:", torch.cuda.get_device_name(0))
     for w in which:
-        {"lds": lds, "mfma": mfma, "load": load, "gather": gather, "atomic": atomic}[w]()
+        {"lds": lds, "mfma": mfma, "load": load, "gather": gather, "stage": stage, "atomic": atomic}[w]()
