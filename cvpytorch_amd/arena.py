@@ -115,11 +115,13 @@ class FlatTrainState:
         import os
         ops.enable_async_wgrad(os.environ.get("CVHIP_ASYNC_WGRAD", "0") in ("1", "2"), after_dgrad=os.environ.get("CVHIP_ASYNC_WGRAD", "0") == "2")
         # BatchNorm step counters: one multi-tensor add per step (bricks.bn_tick) instead of one tiny kernel per layer
-        self._nbt = []
-        for m in model.modules():
-            if isinstance(m, torch.nn.BatchNorm2d) and m.track_running_stats and m.num_batches_tracked is not None:
-                m._nbt_deferred = True
-                self._nbt.append(m.num_batches_tracked)
+        nbt_mods = [m for m in model.modules()
+                    if isinstance(m, torch.nn.BatchNorm2d) and m.track_running_stats and m.num_batches_tracked is not None]
+        self._nbt = torch.zeros(len(nbt_mods), dtype=torch.int64, device=dev) if nbt_mods else None
+        for i, m in enumerate(nbt_mods):   # the counters become views of ONE int64 buffer (state_dict keys unchanged)
+            self._nbt[i] = m.num_batches_tracked
+            m._buffers["num_batches_tracked"] = self._nbt[i]
+            m._nbt_deferred = True
         # dynamic loss scaling (torch.cuda.amp.GradScaler, trainer.py:189-201) — on by default exactly when the engine stores
         # activations in fp16 (ops.set_precision("fp16")), as the reference pairs autocast(fp16) with GradScaler(enabled=AMP).
         # State lives on the device: {scale, growth_tracker, found_inf, skipped_steps}; ls_dyn = {1/scale or 0, skip}
@@ -128,6 +130,7 @@ class FlatTrainState:
         self.ls_dyn = torch.tensor([1.0 / float(init_scale), 0.0], dtype=torch.float32, device=dev)
         self.ls_hyper = (float(growth_factor), float(backoff_factor), int(growth_interval))
         self.prep_plan = None
+        self._seeds = {}
         self.lr_scale = 1.0
         self.dyn = torch.tensor([0.0, 1.0], dtype=torch.float32, device=dev)  # {ema_decay, lr_scale}, read by the kernels
         self._dyn_host = torch.zeros((256, 2), dtype=torch.float32).pin_memory()
@@ -308,6 +311,18 @@ class FlatTrainState:
             ops.zero_fill(self.stat_acc)
         ops.bump_acc_epoch()
 
+    def backward(self, loss):
+        """scaler.scale(loss).backward() with a PRE-ALLOCATED seed gradient: autograd's implicit ones_like(loss) is an ATen fill
+        kernel in every (replayed) step"""
+        loss = self.scale_loss(loss)
+        key = (tuple(loss.shape), loss.dtype)
+        seed = self._seeds.get(key)
+        if seed is None:
+            if torch.cuda.is_current_stream_capturing():
+                return loss.backward()
+            seed = self._seeds[key] = torch.ones_like(loss)
+        loss.backward(gradient=seed)
+
     def scale_loss(self, loss):
         """scaler.scale(loss): the backward pass is seeded with the CURRENT loss scale, read from device memory (so a replayed
         hipGraph follows the scale as it grows / backs off). Identity when loss scaling is off."""
@@ -351,8 +366,8 @@ class FlatTrainState:
                    int(self.nesterov), 0, 0.0, 1.0 / self.world, self.dyn.data_ptr(), st)
         if self.ema_buf is not None and self.buf.numel():
             L.call("cvhip_ema_update", self.ema_buf.data_ptr(), self.buf.data_ptr(), self.buf.numel(), 0.0, self.dyn.data_ptr(), st)
-        if self._nbt and self.model.training:
-            torch._foreach_add_(self._nbt, 1)
+        if self._nbt is not None and self.model.training:
+            L.call("cvhip_i64_add", self._nbt.data_ptr(), self._nbt.numel(), 1, st)
         self.zero_grad()
         self.zero_stats()
 
@@ -420,7 +435,7 @@ class FlatTrainStep:
     def _eager(self, imgs, targets):
         self.state.prepare_weights()
         losses = self.model(imgs, targets, "train")
-        self.state.scale_loss(losses["loss"]).backward()
+        self.state.backward(losses["loss"])
         self.state.step_kernels()
         return losses
 
@@ -456,7 +471,7 @@ class FlatTrainStep:
                 st.prepare_weights()
                 _, feats = m.forward_features(self.static_imgs)
                 losses = m.loss_from_features(feats, self.static_targets)
-                st.scale_loss(losses["loss"]).backward()
+                st.backward(losses["loss"])
                 ops.join_side()
                 if not self.eager_tail:
                     st.step_kernels()

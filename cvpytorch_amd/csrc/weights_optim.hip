@@ -408,6 +408,22 @@ int cvhip_prep_plan_run(const void* table_device, int32_t n, int32_t total_block
   return check_launch("prep_all_kernel");
 }
 
+extern "C++" {
+namespace cvhip {
+__global__ void i64_add_kernel(long long* v, int64_t n, long long delta) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] += delta;
+}
+}  // namespace cvhip
+}
+
+int cvhip_i64_add(int64_t* v, int64_t n, int64_t delta, void* stream) {
+  if (!v || n < 0) return CVHIP_ERR_INVALID;
+  if (n == 0) return CVHIP_OK;
+  hipLaunchKernelGGL(i64_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long long*)v, n, (long long)delta);
+  return check_launch("i64_add_kernel");
+}
+
 int cvhip_ema_update(float* ema, const float* src, int64_t n, float decay, const float* dyn_decay, void* stream) {
   if (!ema || !src || n < 0) return CVHIP_ERR_INVALID;
   if (n == 0) return CVHIP_OK;

@@ -158,6 +158,7 @@ SIGNATURES = {
     "cvhip_sgd_nesterov_ema_scaled": (_i32, [_p, _p, _p, _p, _i64, _p, _p, _p, _i32, _f32, _i32, _i32, _f32, _f32, _p, _p, _p]),
     "cvhip_loss_scale_check": (_i32, [_p, _i64, _p, _p]),
     "cvhip_loss_scale_update": (_i32, [_p, _p, _f32, _f32, _i32, _p]),
+    "cvhip_i64_add": (_i32, [_p, _i64, _i64, _p]),
     "cvhip_ema_update": (_i32, [_p, _p, _i64, _f32, _p, _p]),
     "cvhip_u8_nhwc_to_bf16_norm": (_i32, [_p, _i64, _i32, _p, _i32, _p, _p, _p]),
     "cvhip_yolov5_loss_workspace_bytes": (_i64, [_ylp]),

@@ -1401,6 +1401,38 @@ def add(a, b):
     return Add.apply(a, b)
 
 
+class Fanout(torch.autograd.Function):
+    """A tensor with several consumers (backbone outputs that feed the next stage AND the neck, SPPF's chained pools, the neck's side
+    outputs): autograd would sum the arriving gradients with an ATen add kernel per extra consumer. This op hands every consumer its own
+    alias and sums the gradients with the engine's own kernel (cvhip_add2d) — no ATen kernel in the step."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        acc, la = as_nhwc(gs[0])
+        for g in gs[1:]:
+            b, lb = as_nhwc(g)
+            N, Cc, H, W = acc.shape
+            out = empty_nhwc(N, Cc, H, W, acc.device)
+            L.call("cvhip_add2d", acc.data_ptr(), la, b.data_ptr(), lb, out.data_ptr(), Cc, N * H * W, Cc, _stream())
+            acc, la = out, Cc
+        return acc, None
+
+
+def fanout(x, n=2):
+    """n aliases of x for n consumers (training only; a plain tuple of x otherwise)"""
+    if n < 2 or not (torch.is_grad_enabled() and x.requires_grad) or nhwc_ld(x) is None:
+        return (x,) * n
+    return Fanout.apply(x, n)
+
+
 class AddAct(torch.autograd.Function):
     """out = act(a + b) — ResNet bottleneck tail. Backward recomputes act' from the saved OUTPUT (valid for the
     activations whose derivative is a function of the output's sign: ReLU / LeakyReLU)."""
@@ -1757,6 +1789,7 @@ class YoloV5LossFused(torch.autograd.Function):
         ctx.cfg, ctx.descs, ctx.wss, ctx.ncells, ctx.bs = cfg, descs, wss, ncells, bs
         ctx.save_for_backward(tg, sums, *maps)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)   # no zeros tensor (an ATen fill kernel) for the unused gradient of `stats`
         return total, stats
 
     @staticmethod

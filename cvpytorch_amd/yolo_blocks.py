@@ -151,8 +151,8 @@ class UpsamplingModule(nn.Module):
         self.fuse = CSPLayer(c2 * 2, c2, n=layer, shortcut=False, norm_cfg=norm_cfg, act_cfg=act_cfg)
 
     def forward(self, x, y):
-        x_conv = self.conv(x)
-        return self.fuse(ops.upsample2x_cat(x_conv, y)), x_conv
+        x_conv, side = ops.fanout(self.conv(x), 2)   # -> the upsample + concat here and, as side output, a later DownsamplingModule
+        return self.fuse(ops.upsample2x_cat(x_conv, y)), side
 
 
 class DownsamplingModule(nn.Module):
@@ -189,9 +189,11 @@ class SPPF(nn.Module):
     def forward(self, x):
         x = self.conv1(x)
         if isinstance(self.kernel_sizes, int):
-            y1 = self.m(x)
-            y2 = self.m(y1)
-            x = ops.cat([x, y1, y2, self.m(y2)])
+            x, xa = ops.fanout(x, 2)          # every tensor of the chain feeds the next pool AND the concat
+            y1, y1a = ops.fanout(self.m(xa), 2)
+            y2, y2a = ops.fanout(self.m(y1a), 2)
+            x = ops.cat([x, y1, y2, self.m(y2a)])
         else:
-            x = ops.cat([x] + [m(x) for m in self.m])
+            xs = ops.fanout(x, 1 + len(self.m))
+            x = ops.cat([xs[0]] + [m(xi) for m, xi in zip(self.m, xs[1:])])
         return self.conv2(x)

@@ -66,7 +66,11 @@ class YOLOv5CSPDarknet(nn.Module):
         for i in range(1, 5):
             x = getattr(self, "stage%d" % i)(x)
             if i in self.out_stages:
-                output.append(x)
+                if i < 4:   # feeds the next stage AND the neck: explicit fan-out (ops.Fanout sums the two gradients itself)
+                    x, keep = ops.fanout(x, 2)
+                    output.append(keep)
+                else:
+                    output.append(x)
         return output if len(self.out_stages) > 1 else output[0]
 
 
@@ -89,9 +93,11 @@ class YOLOv5Neck(nn.Module):
         x3, x4, x5 = x
         x4_up, x4_t = self.up_1(x5, x4)
         x3_up, x3_t = self.up_2(x4_up, x3)
+        x3_up, x3_out = ops.fanout(x3_up, 2)      # -> down_1 and the detect head
         x4_down = self.down_1(x3_up, x3_t)
+        x4_down, x4_out = ops.fanout(x4_down, 2)  # -> down_2 and the detect head
         x5_down = self.down_2(x4_down, x4_t)
-        return [x3_up, x4_down, x5_down]
+        return [x3_out, x4_out, x5_down]
 
 
 class YOLOv5Detect(nn.Module):

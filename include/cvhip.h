@@ -447,6 +447,9 @@ int cvhip_sgd_nesterov_ema_scaled(float* param, const float* grad, float* moment
  * `ema_decay` and multiplies every segment lr, so the values can change between hipGraph replays. */
 /* ema[i] = d*ema[i] + (1-d)*src[i] over a flat fp32 range (buffers: BN running stats);
  * dyn_decay: optional DEVICE float[1] overriding `decay`. */
+/* v[i] += delta for an int64 array (the BatchNorm num_batches_tracked counters of a model, kept in one buffer by the flat
+ * training state: one launch per step instead of one add per layer) */
+int cvhip_i64_add(int64_t* v, int64_t n, int64_t delta, void* stream);
 int cvhip_ema_update(float* ema, const float* src, int64_t n, float decay, const float* dyn_decay,
                      void* stream);
 
