@@ -4,13 +4,16 @@
           'train' -> {'loss', 'loss_<label>'...} with the per-class weighted CE terms of :61-65
   loss  : src/losses/seg_loss.py:39-45
   net   : src/models/backbones/seg/resnet.py:96-99,149-153 (classifier=True)
-The backbone (all conv/BN/ReLU/pool work) runs on libcvhip; the 2048->classes fc and the cross-entropy on (N, classes)
-logits are a few kFLOP and stay on torch's device ops.
+Everything differentiable runs on libcvhip: the backbone, the 2048 -> classes fc (a 1x1 convolution on the pooled map) and the
+cross-entropy (cvhip_seg_ce_* on the (N, classes, 1, 1) logits). The per-class REPORTING terms of :61-65 are a handful of torch ops
+on the (N, classes) fp32 logits; non-uniform class weights (never used by the reference configs: every dictionary entry is 1.0) keep
+torch's weighted cross-entropy.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from .deeplab import ResNet
 
 
@@ -27,14 +30,21 @@ class Classification(nn.Module):
         self.register_buffer("class_weight", torch.tensor(self.weight).float(), persistent=False)
 
     def forward(self, imgs, targets=None, mode="infer", **kwargs):
-        outputs = self.backbone(imgs)
+        raw = self.backbone(imgs)
+        # the engine's backbone hands over NHWC logits (N, classes, 1, 1); a foreign backbone plain (N, classes)
+        outputs = ops.to_nchw_f32(raw).flatten(1) if raw.dim() == 4 else raw
         if mode == "infer":
             return F.softmax(outputs, dim=1)
         targets = targets.long()
-        losses = {"loss": F.cross_entropy(outputs, targets, weight=self.class_weight, ignore_index=255, reduction="mean")}
+        if raw.dim() == 4 and raw.is_cuda and len(set(self.weight)) == 1:
+            # uniform class weights: weighted mean == mean (nn.CrossEntropyLoss divides by the sum of the weights of the valid targets)
+            losses = {"loss": ops.seg_cross_entropy(raw, targets.view(-1, 1, 1), ignore_index=255)}
+        else:
+            losses = {"loss": F.cross_entropy(outputs, targets, weight=self.class_weight, ignore_index=255, reduction="mean")}
         if mode == "val":
             return losses, torch.max(outputs, 1)[1]
         # per-class terms (:61-65): mean CE over the samples of class c, times the class weight; only present classes get a key
+        outputs = outputs.detach() if raw.dim() == 4 else outputs   # reporting terms only (the reference never back-propagates them)
         ce = F.cross_entropy(outputs, targets.clamp(max=self.num_classes - 1), reduction="none")
         onehot = F.one_hot(targets.clamp(max=self.num_classes - 1), self.num_classes).to(ce.dtype) * (targets < self.num_classes)[:, None]
         cnt = onehot.sum(0)

@@ -123,9 +123,24 @@ class ResNet(nn.Module):
             if i in self.out_stages and not self.classifier:
                 output.append(x)
         if self.classifier:
-            x = ops.to_nchw_f32(ops.global_avg_pool(x)).flatten(1)
-            return self.fc(x)
+            # torchvision's avgpool + fc (seg/resnet.py:149-153): the fc is a 1x1 convolution on the pooled (N, 2048, 1, 1) map —
+            # the engine's conv kernels (bias in the epilogue, fp32 master weight = the nn.Linear parameter viewed as K x C x 1 x 1)
+            return self._fc(ops.global_avg_pool(x))
         return output if len(self.out_stages) > 1 else output[0]
+
+    def _fc(self, pooled):
+        """(N, C, 1, 1) -> logits (N, classes, 1, 1), NHWC storage dtype"""
+        fc = self.fc
+        st = self.__dict__.setdefault("_hip_fc_state", ops.ConvState())
+        w = fc.weight.view(fc.out_features, fc.in_features, 1, 1)
+        cfg = ops.ConvCfg((1, 1), (0, 0), (1, 1), state=st)
+        cfg.vkey = (id(fc.weight), fc.weight._version)
+        ar = getattr(fc.weight, "_hip_arena", None)
+        if ar is not None and torch.is_grad_enabled():
+            cfg.arena, cfg.gw, cfg.idx_w = ar[0], fc.weight._hip_grad.view_as(w), ar[1]
+            if fc.bias is not None and getattr(fc.bias, "_hip_arena", None) is not None:
+                cfg.gb, cfg.idx_b = fc.bias._hip_grad, fc.bias._hip_arena[1]
+        return ops.conv_bn_act(pooled, w, fc.bias, None, None, None, None, None, cfg)
 
 
 class ASPP(nn.ModuleList):

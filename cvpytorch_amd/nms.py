@@ -65,9 +65,17 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     if classes is not None:
         raise L.CvhipError("non_max_suppression(classes=...) is not supported by the batched device path")
     assert 0 <= conf_thres <= 1 and 0 <= iou_thres <= 1
-    dets, counts, _ = detect_postprocess(prediction, conf_thres, iou_thres, 0, multi_label, agnostic, max_det, cap)
-    cnt = counts.tolist()
-    return [dets[i, :c] for i, c in enumerate(cnt)]
+    dets, counts, overflow = detect_postprocess(prediction, conf_thres, iou_thres, 0, multi_label, agnostic, max_det, cap)
+    host = torch.stack((counts, overflow)).tolist()   # ONE host read: counts and overflow flags of every image
+    out = [dets[i, :c] for i, c in enumerate(host[0])]
+    over = [i for i, o in enumerate(host[1]) if o]
+    if over:
+        # an image with more candidates than the batched kernels' capacity: the reference keeps up to max_nms = 30000 of them
+        # (models/yolov5.py:66,131-132); those images take the per-image loop, whose device sort / NMS kernels have no capacity limit
+        from .yolov5 import non_max_suppression as per_image
+        for i in over:
+            out[i] = per_image(prediction[i:i + 1], conf_thres, iou_thres, None, agnostic, multi_label, max_det, nms_fn=nms)[0]
+    return out
 
 
 def yolox_post_process(pred, num_classes, conf_thre, nms_thre, cap=4096):
@@ -77,9 +85,32 @@ def yolox_post_process(pred, num_classes, conf_thre, nms_thre, cap=4096):
     pred = pred.float().contiguous()
     B, n, no = pred.shape
     cap = _pow2_at_least(min(int(cap), 8192))
-    dets, counts, _ = _run(pred, B, n, no, int(num_classes), conf_thre, nms_thre, 1, False, False, cap, cap, None, 0.0)
-    cnt = counts.tolist()
-    return [dets[i, :c] if c else None for i, c in enumerate(cnt)]
+    dets, counts, overflow = _run(pred, B, n, no, int(num_classes), conf_thre, nms_thre, 1, False, False, cap, cap, None, 0.0)
+    host = torch.stack((counts, overflow)).tolist()
+    out = [dets[i, :c] if c else None for i, c in enumerate(host[0])]
+    for i, (c, o) in enumerate(zip(*host)):
+        if o or c >= cap:
+            # more candidates (or detections) than the fixed capacity: the reference is unbounded (models/yolox.py:48-68) — redo this
+            # image with the per-box kernels (device sort + NMS of any length)
+            out[i] = _yolox_one_image(pred[i], int(num_classes), conf_thre, nms_thre)
+    return out
+
+
+def _yolox_one_image(p, num_classes, conf_thre, nms_thre):
+    """models/yolox.py:48-68 for one image on the per-box kernels: (x1, y1, x2, y2, obj_conf, class_conf, class_pred) or None"""
+    box = torch.empty_like(p[:, :4])
+    box[:, 0] = p[:, 0] - p[:, 2] / 2
+    box[:, 1] = p[:, 1] - p[:, 3] / 2
+    box[:, 2] = p[:, 0] + p[:, 2] / 2
+    box[:, 3] = p[:, 1] + p[:, 3] / 2
+    class_conf, class_pred = torch.max(p[:, 5:5 + num_classes], 1, keepdim=True)
+    mask = (p[:, 4] * class_conf.squeeze(1) >= conf_thre)
+    d = torch.cat((box, p[:, 4:5], class_conf, class_pred.float()), 1)[mask]
+    if not d.shape[0]:
+        return None
+    offs = d[:, 6:7] * (d[:, :4].max() + 1)          # torchvision.ops.batched_nms: per-class coordinate offsets
+    keep = nms(d[:, :4] + offs, d[:, 4] * d[:, 5], nms_thre)
+    return d[keep]
 
 
 def argsort_desc(scores):

@@ -351,7 +351,9 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     `classes=` filter, a custom `nms_fn`, and more candidates per image than the batched kernels' capacity allows."""
     if prediction.is_cuda and classes is None and nms_fn is None:
         from . import nms as NMS
-        return NMS.non_max_suppression(prediction, conf_thres, iou_thres, None, agnostic, multi_label, max_det)
+        # (validation thresholds — conf 0.001, multi_label — produce thousands of candidates per image: largest capacity; images
+        # that still overflow it come back through the loop below, see nms.non_max_suppression)
+        return NMS.non_max_suppression(prediction, conf_thres, iou_thres, None, agnostic, multi_label, max_det, cap=8192)
     nms_fn = nms_fn or ops.nms
     nc = prediction.shape[2] - 5
     xc = prediction[..., 4] > conf_thres

@@ -88,6 +88,22 @@ def test_batched_nms_capacity_is_the_references_max_nms():
         assert torch.equal(dets[b, :i.shape[0]].cpu(), x[i])
 
 
+def test_images_over_the_batched_capacity_fall_back_to_the_reference_loop():
+    """the reference keeps up to max_nms = 30000 candidates per image (models/yolov5.py:66); an image with more
+    candidates than the batched kernels' capacity (8192) must not be silently truncated — the adapter reads the overflow flags
+    with the counts and redoes those images with the per-image loop. Validation-style thresholds (conf 0.001, multi_label)."""
+    B, n, nc = 2, 6000, 6
+    pred = _synthetic_pred(B, n, nc, seed=21, hot=0.9, clusters=3000)
+    pred[1, :, 4] *= 0.01                                  # image 1 stays far below the capacity
+    ref = R.non_max_suppression(pred.clone(), 0.001, 0.6, None, False, True, 300)
+    _, _, overflow = NMS.detect_postprocess(pred.to(dev()), 0.001, 0.6, 0, True, False, 300, cap=8192)
+    assert overflow.tolist()[0] == 1                       # the case is what it claims to be
+    from cvpytorch_amd import yolov5
+    got = yolov5.non_max_suppression(pred.to(dev()), 0.001, 0.6, multi_label=True)
+    for a, r in zip(got, ref):
+        assert torch.equal(a.cpu(), r)
+
+
 def test_yolox_post_process_equals_reference_loop():
     from oracle import yolox_ref as RX
     B, nc = 3, 6

@@ -94,8 +94,10 @@ def test_stdc1_full_structure_on_device():
     assert [list(f.shape) for f in feats] == [list(map(int, r)) for r in s["shapes"]]
 
 
-def test_classification_resnet50_step_vs_oracle():
-    """BASELINE config 1 at reduced resolution: ResNet-50 + fc + CE, bs 8, 100 classes."""
+@pytest.mark.parametrize("size", [96, 224])
+def test_classification_resnet50_step_vs_oracle(size):
+    """BASELINE config 1 (conf/mini-imagenet.yml: ResNet-50 + fc + CE, 224x224, bs 8, 100 classes) at its own size, and a reduced
+    one; fc and cross-entropy run on the engine's 1x1-convolution and CE kernels."""
     from oracle import cls_ref as RC
     torch.manual_seed(0)
     dictionary = [{"c%d" % i: 1.0} for i in range(100)]
@@ -104,7 +106,7 @@ def test_classification_resnet50_step_vs_oracle():
     sd = {k: v for k, v in ref.state_dict().items() if not k.startswith("criterion.")}
     missing, unexpected = hip.load_state_dict(sd, strict=True)
     assert not missing and not unexpected
-    imgs, tg = RC.synthetic_cls_batch(8, 96, 100)
+    imgs, tg = RC.synthetic_cls_batch(8, size, 100)
     ref.train()
     lr = ref(imgs, tg, "train")
     lr["loss"].backward()
