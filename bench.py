@@ -424,9 +424,12 @@ def h2d_leg(model, state, a, dev, imgs_f32, gts, steps):
         step(step.static_imgs, step.static_targets)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    done = [None, None]
     for i in range(steps):
         feed.commit()
-        feed.stage(host[i & 1], tgt_host)
+        if done[i & 1] is not None:
+            done[i & 1].synchronize()   # the loader may only refill a pinned batch once its previous upload has read it
+        done[i & 1] = feed.stage(host[i & 1], tgt_host)
         losses = step(step.static_imgs, step.static_targets)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0

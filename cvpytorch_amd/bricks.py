@@ -228,8 +228,8 @@ def sync_of(bn):
     c = bn.comm if bn.comm is not None else CM.default_comm(bn.process_group)
     if c is None or c.world <= 1:
         return None
-    if bn.comm is None:
-        bn.comm = c   # one transport object per layer (keeps async work handles of the test transport together)
+    # (the transport is NOT cached on the module: an RcclComm holds a ctypes handle, which would break deepcopy / pickling of the
+    # model — ModelEMA, FlatTrainState, checkpoints — after the first training forward; default_comm returns the shared instance)
     return (c, c.world)
 
 

@@ -171,13 +171,18 @@ def default_comm(process_group=None):
     try:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
-            return TorchDistComm(process_group)
+            key = id(process_group) if process_group is not None else None
+            c = _TD_CACHE.get(key)
+            if c is None or c.group is not process_group:
+                c = _TD_CACHE[key] = TorchDistComm(process_group)   # one transport object per group (shared async work list)
+            return c
     except Exception:
         pass
     return None
 
 
 _DEFAULT = [None]
+_TD_CACHE = {}
 
 
 def set_default(comm):

@@ -425,7 +425,10 @@ template <int KB, int CB>
 static int launch_b1(const Bwd1x1Params& p, int blocks, hipStream_t s) {
   constexpr int LDS = CB * (KB * 2 + 16) + 64 * KB * 2 + 64 * CB * 2 + 4 * CB * (int)sizeof(float);
   auto kern = bwd1x1_kernel<KB, CB>;
-  static bool attr_set = false;  // per instantiation
+  static bool attr_done[64] = {};  // per instantiation AND device: the attribute is a per-device property of the function
+  int devid = 0;
+  (void)hipGetDevice(&devid);
+  bool& attr_set = attr_done[devid & 63];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {

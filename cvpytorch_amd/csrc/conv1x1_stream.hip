@@ -327,7 +327,10 @@ static int launch_s1(const IgemmParams& p, int blocks, int ntiles, hipStream_t s
   int lds = bn * (cin_pad * 2 + 16) + 5 * bn * (int)sizeof(float);  // weight tile + bias + the tail layer's 4 constant rows
   if (lds < 4 * bn * 2 * (int)sizeof(float)) lds = 4 * bn * 2 * (int)sizeof(float);
   auto kern = conv1x1_stream_kernel<NF, MF, STATS>;
-  static bool attr_set = false;  // per instantiation
+  static bool attr_done[64] = {};  // per instantiation AND device: the attribute is a per-device property of the function
+  int devid = 0;
+  (void)hipGetDevice(&devid);
+  bool& attr_set = attr_done[devid & 63];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kS1MaxLds + 4096);
     if (e != hipSuccess) {

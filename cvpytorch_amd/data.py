@@ -142,6 +142,7 @@ class GraphFeed:
         self._copied = [torch.cuda.Event(), torch.cuda.Event()]    # H2D into slot finished
         self._consumed = [torch.cuda.Event(), torch.cuda.Event()]  # main stream finished reading slot
         self._used = [False, False]
+        self._staged = [False, False]   # staged and not yet committed
         self._w = self._r = 0
 
     def stage(self, u8_host, tgt_host):
@@ -150,6 +151,8 @@ class GraphFeed:
         if u8_host.dtype != torch.uint8 or tuple(u8_host.shape) != self.shape or not u8_host.is_pinned():
             raise L.CvhipError("GraphFeed.stage expects a pinned uint8 %s batch" % (self.shape,))
         s = self._w
+        if self._staged[s]:
+            raise L.CvhipError("GraphFeed.stage: slot %d was staged and not committed yet (stage and commit must alternate, at most two batches ahead)" % s)
         self._w ^= 1
         if self._used[s]:
             self.stream.wait_event(self._consumed[s])   # the normalise kernel of two batches ago has read this slot
@@ -158,11 +161,25 @@ class GraphFeed:
             self._tg[s].copy_(tgt_host, non_blocking=True)
             self._copied[s].record(self.stream)
         self._used[s] = True
+        self._staged[s] = True
+        # the caller may refill these pinned host buffers once this event has completed (`host_done(slot).synchronize()`): the copies
+        # above are asynchronous and still read them
+        return self._copied[s]
+
+    def host_done(self, slot=None):
+        """event that completes when the H2D copies of the most recently staged batch (or of `slot`) have read their host buffers"""
+        return self._copied[(self._w ^ 1) if slot is None else slot]
+
+    def _noop(self):
+        pass
 
     def commit(self):
         """Main stream: wait for the oldest staged batch, normalise it into the static image tensor, copy its targets."""
         from . import lib as L
         s = self._r
+        if not self._staged[s]:
+            raise L.CvhipError("GraphFeed.commit: nothing staged in slot %d" % s)
+        self._staged[s] = False
         self._r ^= 1
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(self._copied[s])
