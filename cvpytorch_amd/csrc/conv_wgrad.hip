@@ -326,6 +326,219 @@ __global__ __launch_bounds__(256 * kWgGroups, kWgGroups == 1 ? 2 : 1) void wgrad
   }
 }
 
+// =====================================================================================================================================
+// The same kernel with LDS-DMA staging (round 3). Both operand tiles go global -> LDS with global_load_lds_dwordx4 (no VGPR hop, no
+// ds_write pass, ~40 staging VGPRs less), NST ring slots of one 32-pixel step each, ONE raw s_barrier and a counted s_waitcnt vmcnt
+// per step: NST - 1 steps of operands are in flight while one is multiplied (the register-staged form kept 1-3). The LDS image is
+// the register form's (row-major [pixel][channel] tiles, 32-byte segments XOR-swizzled by the pixel row), so the fragment gathers
+// (ds_read_b64_tr_b16) and the epilogue are unchanged: a DMA instruction writes 1 KiB lane-linearly = RPP whole tile rows, and
+// every lane fetches the LOGICAL 16-byte chunk that belongs at its physical position (swizzle on the source side, rule 21). The
+// row a lane serves inside a piece and the XOR term of that row are lane constants, so a lane's (tap, channel) decode is done once.
+// Masked lanes (halo, rows past the slab, columns past Ktot) read a zero page, which keeps the DMA count per wave uniform.
+// =====================================================================================================================================
+__device__ __attribute__((aligned(64))) unsigned int g_wgrad_zero[16];
+
+#define CVHIP_WG_GLDS16(src, dst)                                                                               \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                       \
+                                   (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+template <int TN, int WN, int WK, int kWgGroups, int NST>
+__global__ __launch_bounds__(256 * kWgGroups, kWgGroups == 1 ? 2 : 1) void wgrad_dma_kernel(const WgradParams p) {
+  constexpr int TK = 128;
+  constexpr int WAVES_K = TK / WK;
+  static_assert((TN / WN) * WAVES_K == 4, "4 waves per group");
+  constexpr int NF = WN / 16, KF = WK / 16;
+  constexpr int DV = TN / 8;            // 16-B chunks per dY row
+  constexpr int D_RPP = 64 / DV;        // dY rows per DMA instruction: 4 / 8 / 16
+  constexpr int D_PIECES = 32 / D_RPP;  // 8 / 4 / 2 per step
+  constexpr int D_ROWB = TN * 2;
+  constexpr int D_SEGM = TN / 16 - 1;
+  constexpr int X_ROWB = TK * 2;
+  constexpr int D_BYTES = 32 * D_ROWB, X_BYTES = 32 * X_ROWB;
+  constexpr int ST_BYTES = D_BYTES + X_BYTES;
+  constexpr int GROUP_BYTES = NST * ST_BYTES;
+  static_assert(kWgGroups == 1 || kWgGroups * GROUP_BYTES >= (kWgGroups / 2) * 4 * NF * KF * 4 * 64 * 4, "LDS must hold half the groups' accumulators for the fold");
+  constexpr int D_PW = D_PIECES >= 4 ? D_PIECES / 4 : 1;  // dY pieces per issuing wave (TN 32: only waves 0 and 1 issue one)
+  constexpr int PER_FULL = 2 + D_PW;                      // DMA instructions per step of a wave that stages dY
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[kWgGroups * GROUP_BYTES];
+  const int grp = threadIdx.x >> 8;
+  unsigned char* const ring = smem + grp * GROUP_BYTES;
+
+  const int t = threadIdx.x & 255, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wn = wave / WAVES_K, wk = wave % WAVES_K;
+
+  const int tiles = p.n_tiles * p.k_tiles;
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = lin / tiles;
+  const int tile = lin - split * tiles;
+  const int ntile = tile / p.k_tiles, ktile = tile - ntile * p.k_tiles;
+  const int n0 = ntile * TN, k0 = ktile * TK;
+  const int blk_begin = split * p.m_per_split;
+  const int blk_end = min(p.M, blk_begin + p.m_per_split);
+  if (blk_end <= blk_begin) return;
+  const int half = (((blk_end - blk_begin + kWgGroups - 1) / kWgGroups + 31) >> 5) << 5;
+  const int m_begin = blk_begin + grp * half;
+  const int m_end = min(blk_end, m_begin + half);
+  const int nsteps = half >> 5;
+  const int OHWi = p.OHi * p.OWi;
+  const h16_t* const zero = reinterpret_cast<const h16_t*>(g_wgrad_zero);
+
+  // ---- X staging geometry: wave w issues pieces 2w and 2w+1 (tile rows 8w .. 8w+7); lane = (row in piece, physical chunk) -------
+  const int x_r = lane >> 4, x_j = lane & 15;
+  const int x_h = x_r | ((wave & 1) << 2);                 // h(px) = (px & 3) | ((px >> 1) & 4) for px = 8w + 4i + x_r
+  const int xv = ((((x_j >> 1) ^ x_h) & 7) << 1) | (x_j & 1);  // the logical chunk that belongs at physical chunk x_j of that row
+  const int kcol = k0 + xv * 8;
+  const bool k_ok = kcol < p.Ktot;
+  int c0 = 0, dh = 0, dw = 0;
+  if (k_ok) {
+    const int tap = kcol / p.Cin;
+    c0 = kcol - tap * p.Cin;
+    const int tr = tap / p.TS, ts = tap - tr * p.TS;
+    dh = p.dh0 + tr * p.dh_step;
+    dw = p.dw0 + ts * p.dw_step;
+  }
+  // ---- dY staging geometry ---------------------------------------------------------------------------------------------------------
+  const int d_r = lane / DV, d_j = lane % DV;              // row inside the piece, physical chunk
+  const bool d_issue = D_PIECES >= 4 || wave < D_PIECES;   // TN 32: two pieces, waves 0 and 1
+  // px = (first piece of this wave) * D_RPP + d_r; the XOR term only needs (px & 3) and bit 3 of px
+  const int d_px0 = (D_PIECES >= 4 ? wave * D_PW : wave) * D_RPP + d_r;   // (+ i * D_RPP for the wave's second piece: multiples of 4, bit 3 unchanged for TN 128)
+  const int d_h = ((d_px0 & 3) | ((d_px0 >> 1) & 4)) & D_SEGM;
+  const int dv = ((((d_j >> 1) ^ d_h) & D_SEGM) << 1) | (d_j & 1);
+  const int dn = n0 + dv * 8;
+  const bool dn_ok = dn < p.Nout;
+
+  auto stage = [&](int step, int slot) {
+    unsigned char* const sD = ring + slot * ST_BYTES;
+    unsigned char* const sX = sD + D_BYTES;
+    const int mb = m_begin + step * 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int px = wave * 8 + i * 4 + x_r;
+      const int m = mb + px;
+      const int n = (int)fast_div31((unsigned)m, p.ohw_mul, p.ohw_sh);
+      const int rem = m - n * OHWi;
+      const int oh = (int)fast_div31((unsigned)rem, p.ow_mul, p.ow_sh);
+      const int ow = rem - oh * p.OWi;
+      const int ih = oh * p.in_sh + dh, iw = ow * p.in_sw + dw;
+      const bool ok = k_ok && m < m_end && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+      const h16_t* src = ok ? p.x + ((int64_t)((n * p.IH + ih) * p.IW + iw) * p.x_ld + c0) : zero;
+      CVHIP_WG_GLDS16(src, sX + (wave * 2 + i) * 1024);
+    }
+    if (d_issue) {
+#pragma unroll
+      for (int i = 0; i < D_PW; ++i) {
+        const int q = (D_PIECES >= 4 ? wave * D_PW : wave) + i;
+        const int m = mb + q * D_RPP + d_r;
+        const bool ok = dn_ok && m < m_end;
+        const h16_t* src = ok ? p.dy + ((int64_t)m * p.dy_ld + dn) : zero;
+        CVHIP_WG_GLDS16(src, sD + q * 1024);
+      }
+    }
+  };
+
+  f32x4 acc[NF][KF];
+#pragma unroll
+  for (int a = 0; a < NF; ++a)
+#pragma unroll
+    for (int b = 0; b < KF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int g = lane >> 4, q4 = (lane >> 2) & 3;
+  const int hsw = q4 | ((g & 1) << 2);
+  const int px0 = 8 * g + q4;
+  auto compute = [&](int slot) {
+    const unsigned char* const sD = ring + slot * ST_BYTES;
+    const unsigned char* const sX = sD + D_BYTES;
+    h16x8 fd[NF], fx[KF];
+#pragma unroll
+    for (int a = 0; a < NF; ++a) {
+      const int seg = (wn * WN + a * 16) >> 4;
+      const unsigned char* base = sD + (((seg ^ hsw) & D_SEGM) << 5) + (lane & 3) * 8;
+      fd[a] = tr_read8(base + px0 * D_ROWB, base + (px0 + 4) * D_ROWB);
+    }
+#pragma unroll
+    for (int b = 0; b < KF; ++b) {
+      const int seg = (wk * WK + b * 16) >> 4;
+      const unsigned char* base = sX + (((seg ^ hsw) & 7) << 5) + (lane & 3) * 8;
+      fx[b] = tr_read8(base + px0 * X_ROWB, base + (px0 + 4) * X_ROWB);
+    }
+#pragma unroll
+    for (int a = 0; a < NF; ++a)
+#pragma unroll
+      for (int b = 0; b < KF; ++b)
+        acc[a][b] = CVHIP_MFMA_16X16X32(fd[a], fx[b], acc[a][b], 0, 0, 0);
+  };
+
+  // ---- ring: steps s .. s + NST - 2 in flight while step s is multiplied ---------------------------------------------------------------
+#pragma unroll
+  for (int s0 = 0; s0 < NST - 1; ++s0)
+    if (s0 < nsteps) stage(s0, s0);
+  int slot = 0, slot_in = NST - 1;
+  for (int step = 0; step < nsteps; ++step) {
+    // step `step` has landed when at most the NST - 2 younger steps are outstanding (uniform count only while they all exist)
+    if (step + NST - 2 < nsteps) {
+      if (d_issue) wgrad_wait_vm<(NST - 2) * PER_FULL>();
+      else wgrad_wait_vm<(NST - 2) * 2>();
+    } else {
+      wgrad_wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();  // everybody's DMAs of this step landed; everybody finished reading the slot refilled below
+    if (step + NST - 1 < nsteps) stage(step + NST - 1, slot_in);
+    compute(slot);
+    slot = slot == NST - 1 ? 0 : slot + 1;
+    slot_in = slot_in == NST - 1 ? 0 : slot_in + 1;
+  }
+  __syncthreads();  // the ring is dead: the fold below re-uses it
+
+  if constexpr (kWgGroups >= 2) {
+    float* fold = reinterpret_cast<float*>(smem);
+    constexpr int ACC_FLOATS = 4 * NF * KF * 4 * 64;
+#pragma unroll
+    for (int live = kWgGroups; live > 1; live >>= 1) {
+      const int hl = live >> 1;
+      if (grp >= hl && grp < live) {
+        float* dst = fold + (grp - hl) * ACC_FLOATS;
+#pragma unroll
+        for (int a = 0; a < NF; ++a)
+#pragma unroll
+          for (int b = 0; b < KF; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[((wave * NF * KF + a * KF + b) * 4 + r) * 64 + lane] = acc[a][b][r];
+      }
+      __syncthreads();
+      if (grp < hl) {
+        const float* src = fold + grp * ACC_FLOATS;
+#pragma unroll
+        for (int a = 0; a < NF; ++a)
+#pragma unroll
+          for (int b = 0; b < KF; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][b][r] += src[((wave * NF * KF + a * KF + b) * 4 + r) * 64 + lane];
+      }
+      if (live > 2) __syncthreads();
+    }
+    if (grp != 0) return;
+  }
+  if (p.ablate == 1 && acc[0][0][0] != 12345.678f) return;
+  float* const dwp = p.ablate >= 2 ? p.scratch + (int64_t)split * p.split_stride : p.dw;
+#pragma unroll
+  for (int a = 0; a < NF; ++a) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wn * WN + a * 16 + 4 * (lane >> 4) + r;
+      if (n >= p.Nout) continue;
+#pragma unroll
+      for (int b = 0; b < KF; ++b) {
+        const int kc = k0 + wk * WK + b * 16 + (lane & 15);
+        if (kc < p.Ktot) {
+          if (p.ablate == 3) dwp[(int64_t)n * p.Ktot + kc] = acc[a][b][r];
+          else unsafeAtomicAdd(dwp + ((int64_t)n * p.Ktot + kc), acc[a][b][r]);
+        }
+      }
+    }
+  }
+}
+
 template <int TN, int WN, int WK>
 static int launch_wg(WgradParams& p, hipStream_t stream) {
   p.n_tiles = cdiv(p.Nout, TN);
@@ -371,6 +584,23 @@ static int launch_wg(WgradParams& p, hipStream_t stream) {
   if (pd_force < 0) {
     const char* e = getenv("CVHIP_WGRAD_PD");
     pd_force = e ? atoi(e) : 0;
+  }
+  static int dma = -1, nst = -1;
+  if (dma < 0) {
+    const char* e = getenv("CVHIP_WGRAD_DMA");
+    dma = e ? atoi(e) : 0;
+    const char* f = getenv("CVHIP_WGRAD_NST");
+    nst = f ? atoi(f) : 4;
+  }
+  if (dma && (p.x_ld & 7) == 0 && (p.dy_ld & 7) == 0 && (p.Cin & 7) == 0 && ((((uintptr_t)p.x) | ((uintptr_t)p.dy)) & 15) == 0) {
+    if (nst == 3) {
+      if (groups >= 2) hipLaunchKernelGGL((wgrad_dma_kernel<TN, WN, WK, 2, 3>), dim3(tiles * splits), dim3(512), 0, stream, p);
+      else hipLaunchKernelGGL((wgrad_dma_kernel<TN, WN, WK, 1, 3>), dim3(tiles * splits), dim3(256), 0, stream, p);
+    } else {
+      if (groups >= 2) hipLaunchKernelGGL((wgrad_dma_kernel<TN, WN, WK, 2, 4>), dim3(tiles * splits), dim3(512), 0, stream, p);
+      else hipLaunchKernelGGL((wgrad_dma_kernel<TN, WN, WK, 1, 4>), dim3(tiles * splits), dim3(256), 0, stream, p);
+    }
+    return check_launch("wgrad_dma_kernel");
   }
   const int pd = pd_force == 1 || pd_force == 3 ? pd_force : (TN == 64 ? 3 : 1);
   if (pd == 1) {

@@ -59,9 +59,12 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         # identity blocks: the skip connection's gradient is added in conv1's dgrad epilogue (ops.GradLink), not by autograd
         link = ops.GradLink() if (_GRAD_LINK and self.downsample is None and x.requires_grad and torch.is_grad_enabled()) else None
+        xd = x
+        if self.downsample is not None:
+            x, xd = ops.fanout(x, 2)   # conv1 and the projection shortcut both read x: explicit fan-out (no ATen accumulation add)
         out = _cba(x, self.conv1, self.bn1, L.ACT_RELU, dx_link=link)
         out = _cba(out, self.conv2, self.bn2, L.ACT_RELU)
-        identity = x if self.downsample is None else _cba(x, self.downsample[0], self.downsample[1], L.ACT_NONE)
+        identity = x if self.downsample is None else _cba(xd, self.downsample[0], self.downsample[1], L.ACT_NONE)
         if _FUSE_TAIL:   # relu(bn3(conv3(out)) + identity) in conv3's own BN pass (one pass over the 4x-wide tensor less)
             return _cba(out, self.conv3, self.bn3, L.ACT_RELU, residual=identity, res_pre=True, res_link=link)
         out = _cba(out, self.conv3, self.bn3, L.ACT_NONE)
@@ -121,7 +124,11 @@ class ResNet(nn.Module):
         for i in range(1, 5):
             x = getattr(self, "layer%d" % i)(x)
             if i in self.out_stages and not self.classifier:
-                output.append(x)
+                if i < 4:
+                    x, keep = ops.fanout(x, 2)   # feeds the next layer and the head
+                    output.append(keep)
+                else:
+                    output.append(x)
         if self.classifier:
             # torchvision's avgpool + fc (seg/resnet.py:149-153): the fc is a 1x1 convolution on the pooled (N, 2048, 1, 1) map —
             # the engine's conv kernels (bias in the epilogue, fp32 master weight = the nn.Linear parameter viewed as K x C x 1 x 1)
@@ -157,7 +164,8 @@ class ASPP(nn.ModuleList):
                                        norm_cfg=norm_cfg, act_cfg=act_cfg))
 
     def forward(self, x):
-        return [m(x) for m in self]
+        xs = x if isinstance(x, (tuple, list)) else ops.fanout(x, len(self))   # one alias per branch (ops.Fanout sums their gradients)
+        return [m(xi) for m, xi in zip(self, xs)]
 
 
 class _GAP(nn.Module):
@@ -187,9 +195,10 @@ class Deeplabv3PlusHead(nn.Module):
         return self.cls_seg(feat)
 
     def forward(self, x):
-        hi = x[1]
+        his = ops.fanout(x[1], 1 + len(self.aspp))   # the image-pooling branch and the ASPP branches all read the same map
+        hi = his[0]
         outs = [ops.resize_bilinear(self.proj(hi), hi.shape[2:], False)]
-        outs.extend(self.aspp(hi))
+        outs.extend(self.aspp(his[1:]))
         outs = self.reduce(ops.cat(outs))
         if self.low_proj is not None:
             low = self.low_proj(x[0])
