@@ -148,6 +148,8 @@ int plan_dgrad(const cvhip_conv_desc* d, IgemmParams* p) {
 
 int pack_weights(const cvhip_conv_desc* d, const float* master, void* w_fprop, void* w_dgrad, hipStream_t stream);
 int launch_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, hipStream_t stream);
+int launch_wgrad_impl(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, hipStream_t stream, float* det_ws, int64_t* det_ws_floats,
+                      int det_accumulate);
 
 // ---- probes ---------------------------------------------------------------------------------------
 __global__ void probe_mfma_kernel(const h16_t* a, const h16_t* b, float* d) {
@@ -480,6 +482,28 @@ int cvhip_conv2d_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, 
     if (zs) return zs;
   }
   return launch_wgrad(d, x, dy, dw, s);
+}
+
+int64_t cvhip_conv2d_wgrad_det_workspace_bytes(const cvhip_conv_desc* d) {
+  int st = validate_dense_desc(d);
+  if (st) return st;
+  if ((d->K & 7) || (d->y_ld & 7)) return CVHIP_ERR_UNSUPPORTED;
+  int64_t floats = -1;  // size query: no launch
+  float dummy = 0.f;
+  st = launch_wgrad_impl(d, &dummy, &dummy, &dummy, nullptr, &dummy, &floats, 0);
+  if (st) return st;
+  return floats * (int64_t)sizeof(float);
+}
+
+int cvhip_conv2d_wgrad_det(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate, void* workspace, int64_t ws_bytes,
+                           void* stream) {
+  int st = validate_dense_desc(d);
+  if (st) return st;
+  if (!x || !dy || !dw || !workspace) return CVHIP_ERR_INVALID;
+  if ((d->K & 7) || (d->y_ld & 7)) return CVHIP_ERR_UNSUPPORTED;
+  if ((((uintptr_t)x) & 15) || (((uintptr_t)dy) & 15) || (((uintptr_t)workspace) & 15)) return CVHIP_ERR_INVALID;
+  int64_t floats = ws_bytes / (int64_t)sizeof(float);
+  return launch_wgrad_impl(d, x, dy, dw, (hipStream_t)stream, (float*)workspace, &floats, accumulate ? 1 : 0);
 }
 
 int cvhip_zero_fill(void* ptr, int64_t bytes, void* stream) {

@@ -29,10 +29,49 @@ struct WgradParams {
   int Ktot, M;
   int n_tiles, k_tiles, m_per_split;
   unsigned ohw_mul, ohw_sh, ow_mul, ow_sh;  // fast_div31 constants of OHi*OWi and OWi
-  int ablate;  // CVHIP_WGRAD_ABLATE: 1 = skip the atomic epilogue, 2 = atomics into per-split scratch, 3 = plain stores into it (profiling only)
+  int ablate;  // CVHIP_WGRAD_ABLATE: 1 = skip the atomic epilogue, 2 = atomics into per-split scratch, 3 = plain stores into it
+               // (3 is also the DETERMINISTIC mode: every pixel split stores its partial tile into its own slab of the caller's
+               // workspace and wgrad_fold_kernel adds the slabs in split order — no floating-point atomics anywhere)
   float* scratch;
   int64_t split_stride;
+  float* det_ws;      // deterministic mode: caller's workspace (>= splits * Nout * Ktot floats), else NULL
+  int64_t det_ws_floats;
+  int det_accumulate;
 };
+
+// dw[i] (+)= sum over the splits, in split order (fixed order => bit-reproducible), 4 floats per thread, 4 independent loads in flight
+__global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* __restrict__ ws, int splits, int64_t n, float* __restrict__ dw, int accumulate) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 3 < n && ((((uintptr_t)ws) | ((uintptr_t)dw) | (uintptr_t)(n * 4)) & 15) == 0) {
+    float4 a = accumulate ? *reinterpret_cast<const float4*>(dw + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    int sidx = 0;
+    for (; sidx + 3 < splits; sidx += 4) {
+      const float4 v0 = *reinterpret_cast<const float4*>(ws + (int64_t)sidx * n + i);
+      const float4 v1 = *reinterpret_cast<const float4*>(ws + (int64_t)(sidx + 1) * n + i);
+      const float4 v2 = *reinterpret_cast<const float4*>(ws + (int64_t)(sidx + 2) * n + i);
+      const float4 v3 = *reinterpret_cast<const float4*>(ws + (int64_t)(sidx + 3) * n + i);
+      a.x = (((a.x + v0.x) + v1.x) + v2.x) + v3.x;
+      a.y = (((a.y + v0.y) + v1.y) + v2.y) + v3.y;
+      a.z = (((a.z + v0.z) + v1.z) + v2.z) + v3.z;
+      a.w = (((a.w + v0.w) + v1.w) + v2.w) + v3.w;
+    }
+    for (; sidx < splits; ++sidx) {
+      const float4 v = *reinterpret_cast<const float4*>(ws + (int64_t)sidx * n + i);
+      a.x += v.x;
+      a.y += v.y;
+      a.z += v.z;
+      a.w += v.w;
+    }
+    *reinterpret_cast<float4*>(dw + i) = a;
+  } else {
+    for (int64_t j = i; j < n && j < i + 4; ++j) {
+      float a = accumulate ? dw[j] : 0.f;
+      for (int sidx = 0; sidx < splits; ++sidx) a += ws[(int64_t)sidx * n + j];
+      dw[j] = a;
+    }
+  }
+}
 
 typedef __attribute__((address_space(3))) h16x4 lds_h16x4;
 
@@ -555,10 +594,10 @@ static int launch_wg(WgradParams& p, hipStream_t stream) {
     const char* a = getenv("CVHIP_WGRAD_ABLATE");
     abl = a ? atoi(a) : 0;
   }
-  p.ablate = abl;
+  p.ablate = p.det_ws ? 3 : abl;
   p.scratch = nullptr;
   p.split_stride = 0;
-  if (abl >= 2) {  // profiling only: 512 MB of scratch, one region per pixel split
+  if (!p.det_ws && abl >= 2) {  // profiling only: 512 MB of scratch, one region per pixel split
     static float* scratch = nullptr;
     if (!scratch && hipMalloc(&scratch, 512ull << 20) != hipSuccess) return CVHIP_ERR_LAUNCH;
     p.scratch = scratch;
@@ -577,6 +616,23 @@ static int launch_wg(WgradParams& p, hipStream_t stream) {
   mps = ((mps + 63) / 64) * 64;
   splits = cdiv(p.M, mps);
   p.m_per_split = mps;
+  if (p.det_ws) {
+    const int64_t n = (int64_t)p.Nout * p.Ktot;
+    if (p.det_ws_floats == -1) {  // size query
+      p.det_ws_floats = (int64_t)splits * n;
+      return CVHIP_OK;
+    }
+    if (p.det_ws_floats < (int64_t)splits * n) return CVHIP_ERR_INVALID;
+    p.scratch = p.det_ws;
+    p.split_stride = n;
+    // register-staged kernels only (the DMA variant is an experiment); every (n, k) of every split slab is written exactly once
+    if (groups >= 2) hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 2, 1>), dim3(tiles * splits), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 1, 1>), dim3(tiles * splits), dim3(256), 0, stream, p);
+    int st = check_launch("wgrad_kernel(det)");
+    if (st) return st;
+    hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, stream, p.det_ws, splits, n, p.dw, p.det_accumulate);
+    return check_launch("wgrad_fold_kernel");
+  }
   // (four groups per block were measured too: 1024-thread blocks in lockstep lose 10-50 % on every YOLOv5-s layer)
   // Prefetch depth (CVHIP_WGRAD_PD=1/3 forces one): three steps in flight pay for the 64-wide tile (-10...-17 % per launch) but
   // cost the 128-wide tile a resident block (178 VGPRs: +10 %) and do nothing for the 32-wide one (profiles/r02_wgrad_pd.log)
@@ -611,10 +667,16 @@ static int launch_wg(WgradParams& p, hipStream_t stream) {
   return check_launch("wgrad_kernel");
 }
 
-int launch_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, hipStream_t stream) {
-  const int stem = try_launch_stem_wgrad(d, x, dy, dw, stream);  // 8-channel image stem: patch kernel (conv_stem.hip)
-  if (stem >= 0) return stem;
+int launch_wgrad_impl(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, hipStream_t stream, float* det_ws, int64_t* det_ws_floats,
+                      int det_accumulate) {
+  if (!det_ws) {
+    const int stem = try_launch_stem_wgrad(d, x, dy, dw, stream);  // 8-channel image stem: patch kernel (conv_stem.hip; atomic epilogue)
+    if (stem >= 0) return stem;
+  }
   WgradParams p;
+  p.det_ws = det_ws;
+  p.det_ws_floats = det_ws_floats ? *det_ws_floats : 0;
+  p.det_accumulate = det_accumulate;
   p.x = (const h16_t*)x;
   p.dy = (const h16_t*)dy;
   p.dw = dw;
@@ -658,9 +720,16 @@ int launch_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float*
   } else if (d->K >= 256 && d->C <= 1024) {
     tn = 64;
   }
-  if (tn == 32) return launch_wg<32, 32, 32>(p, stream);
-  if (tn == 64) return launch_wg<64, 32, 64>(p, stream);
-  return launch_wg<128, 64, 64>(p, stream);
+  int rc;
+  if (tn == 32) rc = launch_wg<32, 32, 32>(p, stream);
+  else if (tn == 64) rc = launch_wg<64, 32, 64>(p, stream);
+  else rc = launch_wg<128, 64, 64>(p, stream);
+  if (det_ws_floats) *det_ws_floats = p.det_ws_floats;
+  return rc;
+}
+
+int launch_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, hipStream_t stream) {
+  return launch_wgrad_impl(d, x, dy, dw, stream, nullptr, nullptr, 0);
 }
 
 }  // namespace cvhip

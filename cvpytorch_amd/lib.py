@@ -95,6 +95,8 @@ SIGNATURES = {
     "cvhip_conv2d_dgrad": (_i32, [_dp, _p, _p, _p, _p]),
     "cvhip_conv2d_dgrad_add": (_i32, [_dp, _p, _p, _p, _i32, _p, _p]),
     "cvhip_conv2d_wgrad": (_i32, [_dp, _p, _p, _p, _i32, _p]),
+    "cvhip_conv2d_wgrad_det_workspace_bytes": (_i64, [_dp]),
+    "cvhip_conv2d_wgrad_det": (_i32, [_dp, _p, _p, _p, _i32, _p, _i64, _p]),
     "cvhip_conv1x1_bwd_fused_ok": (_i32, [_dp]),
     "cvhip_conv1x1_bwd_fused": (_i32, [_dp, _p, _i32, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _f32, _p, _i32, _p, _i32,
                                 _p, _p]),

@@ -56,6 +56,38 @@ _BN_ACC_MAX_C = 2048
 _acc_epoch = 0
 
 
+# ---- deterministic mode --------------------------------------------------------------------------------------------------------------
+# set_deterministic(True): every floating-point reduction of the train step runs in a FIXED order — dense weight gradients through
+# cvhip_conv2d_wgrad_det (per-split slabs + ordered fold instead of fp32 atomics), BatchNorm statistics through the partial-row +
+# finalize kernels instead of the fp64 accumulators, no fused 1x1 backward and no stem patch-wgrad (their dW flushes are atomic).
+# Two runs from the same state then give bit-identical gradient arenas (tests/test_gpu_deterministic.py). Costs one fold launch per
+# layer and the finalize launches back: opt-in, like torch.use_deterministic_algorithms. (Depthwise weight gradients keep their
+# atomic epilogue.)
+_DETERMINISTIC = __import__("os").environ.get("CVHIP_DETERMINISTIC", "0") == "1"
+
+
+def set_deterministic(flag=True):
+    global _DETERMINISTIC
+    _DETERMINISTIC = bool(flag)
+
+
+def is_deterministic():
+    return _DETERMINISTIC
+
+
+def _wgrad(kname, geom, desc, x, dy, dst, accumulate, st):
+    """dense weight gradient into `dst` (fp32 KRSC): the atomic split-K kernel, or its deterministic two-stage form"""
+    if _DETERMINISTIC:
+        nb = L.load().cvhip_conv2d_wgrad_det_workspace_bytes(C.byref(desc))
+        if nb < 0:
+            L.check(int(nb), "cvhip_conv2d_wgrad_det_workspace_bytes")
+        ws = torch.empty((max(int(nb), 16),), dtype=torch.uint8, device=x.device)
+        _timed_call(kname, geom, "cvhip_conv2d_wgrad_det", C.byref(desc), x.data_ptr(), dy.data_ptr(), dst.data_ptr(), int(accumulate),
+                    ws.data_ptr(), int(nb), st)
+    else:
+        _timed_call(kname, geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(), dst.data_ptr(), int(accumulate), st)
+
+
 def bump_acc_epoch():
     """called by whoever has just zeroed the persistent accumulators (arena.FlatTrainState.zero_stats)"""
     global _acc_epoch
@@ -586,7 +618,7 @@ def _conv_grads(ctx, x, weight, dy, dy_ld, need_dx, need_dw, need_db):
             desc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, x_ld, dy_ld, kv, cv)
             padded = (Kp != K) or (Cg != Cc)
             geom = (N, Cc, H, W, K, R, S, P, Q)
-            if not padded and direct_w and _Side.enabled and not TIMER.enabled and (not arena.multi or arena.defer_allreduce):
+            if not padded and direct_w and _Side.enabled and not TIMER.enabled and not _DETERMINISTIC and (not arena.multi or arena.defer_allreduce):
                 # same, on the side stream (see _Side): runs concurrently with the BN-backward chain of the layers below. With
                 # _Side.after_dgrad the fork is taken AFTER this layer's dgrad launch, so wgrad (MFMA / LDS bound) shares the chip
                 # with the HBM-bound BN passes that follow instead of with the dgrad kernel (same resources: both slowed down)
@@ -601,18 +633,15 @@ def _conv_grads(ctx, x, weight, dy, dy_ld, need_dx, need_dw, need_db):
                     side_wgrad()
             elif not padded and direct_w:
                 # accumulate straight into the parameter's KRSC slot of the flat gradient arena
-                _timed_call(_wgrad_name(Kp, R, S, Cc, N * P * Q, desc), geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(),
-                            cfg.gw.data_ptr(), 1, st)
+                _wgrad(_wgrad_name(Kp, R, S, Cc, N * P * Q, desc), geom, desc, x, dy, cfg.gw, 1, st)
             elif not padded:
                 # logical OIHW, KRSC (channels_last) memory: a fresh non-view tensor autograd can adopt as .grad
                 dw = torch.empty((K, Cc, R, S), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
-                _timed_call(_wgrad_name(Kp, R, S, Cc, N * P * Q, desc), geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(),
-                            dw.data_ptr(), 0, st)
+                _wgrad(_wgrad_name(Kp, R, S, Cc, N * P * Q, desc), geom, desc, x, dy, dw, 0, st)
             else:
                 # padded problem: wgrad into a [Kp][R][S][Cc] scratch, then fold the valid block into the real gradient
                 tmp = torch.empty((Kp, R, S, Cc), dtype=torch.float32, device=dev)
-                _timed_call(_wgrad_name(Kp, R, S, Cc, N * P * Q, desc), geom, "cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(),
-                            tmp.data_ptr(), 0, st)
+                _wgrad(_wgrad_name(Kp, R, S, Cc, N * P * Q, desc), geom, desc, x, dy, tmp, 0, st)
                 if direct_w:
                     dst = cfg.gw
                 else:
@@ -670,6 +699,8 @@ def _bwd1x1_ok(ctx, cfg, x, need_dx, need_dw, need_db, segs):
     """True when the fused 1x1 backward kernel (conv1x1_bwd.hip: BN/act backward on load + dgrad + wgrad in one pass) takes
     this layer: dense 1x1 stride-1, K in {32, 64, 128}, unpadded channels, both gradients wanted, 16-byte aligned operands."""
     N, Cc, H, W, K, R, S, P, Q, Kp, x_ld, Cg = ctx.geom
+    if _DETERMINISTIC:   # the fused kernel flushes dW with fp32 atomics
+        return False
     if ctx.depthwise or R != 1 or S != 1 or Kp != K or Cg != Cc or ctx.c_orig != Cc or not (need_dx and need_dw):
         return False
     if (ctx.has_bias and need_db) or ctx.w_dgrad is None or x.data_ptr() % 16 or x_ld % 8:
@@ -815,7 +846,7 @@ class ConvBnAct(torch.autograd.Function):
             # pack descriptor: contiguous pitches (the packed images do not depend on activation pitches)
             pdesc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, Cc, Kp, kv, cv)
             cfg.state.prepare(weight, pdesc, need_dx, cfg.vkey)
-            use_acc = _BN_ACC and epilogue_stats and cfg.sync is None and K <= _BN_ACC_MAX_C
+            use_acc = _BN_ACC and not _DETERMINISTIC and epilogue_stats and cfg.sync is None and K <= _BN_ACC_MAX_C
             if use_acc:
                 acc_f, acc_b = _layer_acc(cfg, K, dev)
             elif epilogue_stats:

@@ -174,6 +174,14 @@ int cvhip_conv1x1_bwd_fused(const cvhip_conv_desc* d, const void* dz0_bf16, int3
  * fp32 atomics. accumulate==0 zero-fills dw first (hipMemsetAsync on `stream`). */
 int cvhip_conv2d_wgrad(const cvhip_conv_desc* d, const void* x_bf16, const void* dy_bf16,
                        float* dw_krsc_f32, int accumulate, void* stream);
+/* Deterministic weight gradient: the pixel splits store their partial tiles into private slabs of `workspace` (plain stores) and a
+ * second kernel adds the slabs in split order — no floating-point atomics, two runs give bit-identical gradients. Same operands and
+ * result as cvhip_conv2d_wgrad (accumulate != 0: dw += ...). cvhip_conv2d_wgrad_det_workspace_bytes(desc) sizes the workspace
+ * (16-byte aligned). */
+int64_t cvhip_conv2d_wgrad_det_workspace_bytes(const cvhip_conv_desc* d);
+int cvhip_conv2d_wgrad_det(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate, void* workspace, int64_t ws_bytes,
+                           void* stream);
+
 
 /* depthwise conv (groups == C == K), direct, bandwidth-bound.
  * src/models/bricks/depthwise_separable_conv_module.py:76-94 (DeepLabv3+ ASPP / fuse convs).

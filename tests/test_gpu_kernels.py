@@ -248,6 +248,46 @@ def test_conv_wgrad(case):
         assert float(dw[K:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_wgrad_deterministic(case):
+    """cvhip_conv2d_wgrad_det: per-split slabs + ordered fold — same values as the atomic kernel to rounding, BIT-identical
+    from call to call, and accumulate=1 adds onto the destination"""
+    N, Cc, H, W, K, R, S, s, p, d = case
+    x, w = _mk(case, 4)
+    wr = w.clone().requires_grad_(True)
+    y = F.conv2d(x, wr, None, stride=s, padding=p, dilation=d)
+    dy = bf(torch.randn(y.shape, generator=torch.Generator().manual_seed(5)))
+    (gw,) = torch.autograd.grad(y, wr, dy)
+    Kp = (K + 7) // 8 * 8
+    P, Q = y.shape[2:]
+    xd = to_nhwc_dev(x)
+    dyd = torch.zeros((N, P, Q, Kp), dtype=BF, device=dev())
+    dyd[..., :K] = dy.permute(0, 2, 3, 1).to(dev()).to(BF)
+    desc = ops.conv_desc(N, Cc, H, W, Kp, R, S, (s, s), (p, p), (d, d), 1, Cc, Kp)
+    nb = int(L.load().cvhip_conv2d_wgrad_det_workspace_bytes(C.byref(desc)))
+    assert nb >= 0
+    ws = torch.empty((max(nb, 16),), dtype=torch.uint8, device=dev())
+    outs = []
+    for rep in range(3):
+        dw = torch.full((Kp, R, S, Cc), float("nan"), device=dev())
+        ws.random_(0, 255)                                   # stale workspace contents must not matter
+        L.call("cvhip_conv2d_wgrad_det", C.byref(desc), xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), 0, ws.data_ptr(), nb, ops._stream())
+        torch.cuda.synchronize()
+        outs.append(dw.clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    got = outs[0][:K].permute(0, 3, 1, 2).cpu()
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, gw) < 1e-3, rel_l2(got, gw)
+    base = torch.full((Kp, R, S, Cc), 0.5, device=dev())
+    L.call("cvhip_conv2d_wgrad_det", C.byref(desc), xd.data_ptr(), dyd.data_ptr(), base.data_ptr(), 1, ws.data_ptr(), nb, ops._stream())
+    torch.cuda.synchronize()
+    assert torch.allclose(base, outs[0] + 0.5, rtol=2e-6, atol=1e-6 * float(outs[0].abs().max()) + 1e-5)      # (the fold adds the old value in its own fixed order)
+    # a workspace that is too small is refused, not overrun
+    if nb > 16:
+        rc = L.load().cvhip_conv2d_wgrad_det(C.byref(desc), xd.data_ptr(), dyd.data_ptr(), base.data_ptr(), 0, ws.data_ptr(), nb - 4, ops._stream())
+        assert rc != 0
+
+
 def test_conv_channel_slice_operands():
     """x read from / y written into channel slices of wider buffers (pitch != channels)."""
     torch.manual_seed(0)
