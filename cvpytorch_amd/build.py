@@ -60,11 +60,17 @@ def _compile(job):
     path = os.path.join(CSRC, src)
     if not _newer(obj, [path] + _deps()):
         return obj, None
-    cmd = [HIPCC] + FLAGS + (["-DCVHIP_F16=1"] if f16 else []) + ["-c", path, "-o", obj]
+    # -Rpass-analysis=kernel-resource-usage: per-kernel VGPR / scratch / occupancy remarks, kept next to the object
+    # (<obj>.usage.txt; tools/resource_usage.py tabulates them, tests/test_abi_plan.py fails on a kernel that started to spill)
+    cmd = [HIPCC] + FLAGS + ["-Rpass-analysis=kernel-resource-usage"] + (["-DCVHIP_F16=1"] if f16 else []) + ["-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
-    return obj, r.stderr
+    remarks = [ln for ln in r.stderr.splitlines() if "kernel-resource-usage" in ln]
+    with open(obj + ".usage.txt", "w") as fh:
+        fh.write("\n".join(remarks) + "\n")
+    other = "\n".join(ln for ln in r.stderr.splitlines() if "kernel-resource-usage" not in ln and "remark generated" not in ln).strip()
+    return obj, other
 
 
 def _sync_f16_names():

@@ -95,7 +95,9 @@ __device__ __forceinline__ f32x8 bnact_bwd8(const f32x8& dz, const f32x8& y, con
   return o;
 }
 
-template <int KB, int CB>
+// TAIL: the tail-sums form is its own instantiation — its 2 x CB/4 per-lane partial sums are live across the whole trip loop and
+// pushed the 128 x 128 configuration to 104 spilled VGPRs (300 B/lane of scratch, 106 -> 195 us per launch) when it was a runtime flag
+template <int KB, int CB, bool TAIL>
 __global__ __launch_bounds__(256, 2) void bwd1x1_kernel(const Bwd1x1Params p) {
   constexpr int RT = 64;
   constexpr int KV = KB / 8, CV = CB / 8;
@@ -229,16 +231,17 @@ __global__ __launch_bounds__(256, 2) void bwd1x1_kernel(const Bwd1x1Params p) {
     }
   };
 
-  const bool tail = p.tail_y != nullptr;  // block-uniform
+  constexpr bool tail = TAIL;
   if (tail && t < CB) {
     sT[t] = p.tail_scale[c0 + t];
     sT[CB + t] = p.tail_shift[c0 + t];
     sT[2 * CB + t] = p.tail_mean[c0 + t];
     sT[3 * CB + t] = p.tail_invstd[c0 + t];
   }
-  float ts1[NF / 2][8], ts2[NF / 2][8];  // this lane's share of the tail sums for channels c0 + j*32 + g*8 + e
+  constexpr int TSN = TAIL ? NF / 2 : 1;
+  float ts1[TSN][8], ts2[TSN][8];  // this lane's share of the tail sums for channels c0 + j*32 + g*8 + e
 #pragma unroll
-  for (int j = 0; j < NF / 2; ++j)
+  for (int j = 0; j < TSN; ++j)
 #pragma unroll
     for (int e = 0; e < 8; ++e) ts1[j][e] = ts2[j][e] = 0.f;
 
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void bwd1x1_kernel(const Bwd1x1Params p) {
           }
           const uint4 packed = pack8(v);
           *reinterpret_cast<uint4*>(drow_p + j * 32) = packed;
-          if (tail) {  // sums over the ROUNDED gradient, i.e. over what the tail layer's backward reads
+          if constexpr (TAIL) {  // sums over the ROUNDED gradient, i.e. over what the tail layer's backward reads
             const f32x8 dzr = unpack8(packed);
             const f32x8 yv = unpack8(*reinterpret_cast<const uint4*>(p.tail_y + (int64_t)m * p.tail_y_ld + c0 + j * 32 + g * 8));
             const float* const k = sT + j * 32 + g * 8;
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void bwd1x1_kernel(const Bwd1x1Params p) {
   }
 
   // ---- tail sums: channel c0 + j*32 + g*8 + e is shared by the 16 lanes of a DPP row and by the 4 waves ----------------------------
-  if (tail) {
+  if constexpr (TAIL) {
     float* const red = reinterpret_cast<float*>(sD);  // [4 waves][CB][2]; the loop's last barrier freed the tiles
 #pragma unroll
     for (int j = 0; j < NF / 2; ++j)
@@ -421,10 +424,10 @@ int bwd1x1_fits(const cvhip_conv_desc* d) {
   return trips >= 2400 ? 1 : 0;
 }
 
-template <int KB, int CB>
-static int launch_b1(const Bwd1x1Params& p, int blocks, hipStream_t s) {
+template <int KB, int CB, bool TAIL>
+static int launch_b1t(const Bwd1x1Params& p, int blocks, hipStream_t s) {
   constexpr int LDS = CB * (KB * 2 + 16) + 64 * KB * 2 + 64 * CB * 2 + 4 * CB * (int)sizeof(float);
-  auto kern = bwd1x1_kernel<KB, CB>;
+  auto kern = bwd1x1_kernel<KB, CB, TAIL>;
   static bool attr_done[64] = {};  // per instantiation AND device: the attribute is a per-device property of the function
   int devid = 0;
   (void)hipGetDevice(&devid);
@@ -439,6 +442,11 @@ static int launch_b1(const Bwd1x1Params& p, int blocks, hipStream_t s) {
   }
   hipLaunchKernelGGL(kern, dim3(blocks, p.C / CB), dim3(256), LDS, s, p);
   return check_launch("bwd1x1_kernel");
+}
+
+template <int KB, int CB>
+static int launch_b1(const Bwd1x1Params& p, int blocks, hipStream_t s) {
+  return p.tail_y ? launch_b1t<KB, CB, true>(p, blocks, s) : launch_b1t<KB, CB, false>(p, blocks, s);
 }
 
 int launch_bwd1x1(Bwd1x1Params& p, hipStream_t s) {

@@ -160,13 +160,15 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwParams p, int row
         const f32x8 g = dw_load8(p.dy + m * p.y_ld, c, p.C, vec);
 #pragma unroll
         for (int a = 0; a < kDwMaxTaps; ++a) {
-          if (a >= T) break;
+          // no break / continue in here: an early exit keeps hipcc from unrolling, `a` becomes a runtime index and the whole
+          // accumulator array moves to scratch memory (304 B/lane: every FMA through memory)
           const int r = a / p.S, s = a - r * p.S;
           const int ih = pp * p.sh - p.ph + r * p.dh, iw = q * p.sw - p.pw + s * p.dw_;
-          if ((unsigned)ih >= (unsigned)p.H || (unsigned)iw >= (unsigned)p.W) continue;
-          const f32x8 v = dw_load8(p.x + ((int64_t)(n * p.H + ih) * p.W + iw) * p.x_ld, c, p.C, vec);
+          if (a < T && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
+            const f32x8 v = dw_load8(p.x + ((int64_t)(n * p.H + ih) * p.W + iw) * p.x_ld, c, p.C, vec);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[a][j] += g.v[j] * v.v[j];
+            for (int j = 0; j < 8; ++j) acc[a][j] += g.v[j] * v.v[j];
+          }
         }
       }
     }
