@@ -5,6 +5,7 @@
 // Replaces aten::native_batch_norm(_backward) + aten::silu_/relu_ (+ residual add) reached from
 // reference src/models/bricks/conv_module.py:211-213 and src/models/modules/yolo_modules.py:102.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace cvhip {
@@ -100,7 +101,9 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const RedParams p) {
       };
       int64_t r = r_begin + ty;
       if (vec) {
-        // 4 rows per trip: 4-8 independent 16-B loads in flight per lane before any arithmetic (HBM latency hiding)
+        // 4 rows per trip: 4-8 independent 16-B loads in flight per lane before any arithmetic (HBM latency hiding).
+        // (Software-pipelining the trips — next trip's loads issued before this trip's arithmetic — was measured in round 3: +32
+        // VGPRs, no gain on the backward passes: they are co-limited by the quarter-rate v_exp_f32 / v_rcp_f32 of the SiLU derivative.)
         const int64_t stp = rows_per_pass;
         for (; r + 3 * stp < r_end; r += 4 * stp) {
           uint4 ua[4], uy[4];
@@ -546,79 +549,91 @@ __global__ __launch_bounds__(256) void ew_kernel(const EwParams p) {
         }
       }
     }
-    auto math = [&](const f32x8& a, const f32x8& y, const f32x8& rs) -> f32x8 {
-      f32x8 o;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (MODE == 0) {
-          float v;
-          if (p.res && p.res_pre) {
-            v = act_fwd(a.v[j] * sc[j] + sh[j] + rs.v[j], ACT, p.ap);
-          } else {
-            v = act_fwd(a.v[j] * sc[j] + sh[j], ACT, p.ap);
-            if (p.res) v += rs.v[j];
-          }
-          o.v[j] = v;
-        } else if (MODE == 1) {
-          const float u = y.v[j] * sc[j] + sh[j];
-          const float du = a.v[j] * act_bwd(u, ACT, p.ap);
-          if (p.mean) {
-            const float xh = (y.v[j] - mu[j]) * is[j];
-            o.v[j] = sc[j] * (du - k1[j] - xh * k2[j]);
-          } else {
-            o.v[j] = sc[j] * du;
-          }
-        } else if (MODE == 2) {
-          o.v[j] = a.v[j];
-        } else {
-          o.v[j] = a.v[j] + rs.v[j];
-        }
-      }
-      return o;
-    };
-    int64_t r = r_begin + ty;
-    if (vec) {
-      // 4 rows per trip: all loads of the trip are issued before the arithmetic (bytes in flight per lane x4)
-      const int64_t stp = rows_per_pass;
-      const bool has_res = (MODE == 0 || MODE == 3) && p.res;
-      for (; r + 3 * stp < r_end; r += 4 * stp) {
-        uint4 ua[4], uy[4], ur[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          ua[q] = *reinterpret_cast<const uint4*>(p.a + (r + q * stp) * p.ld_a + c);
-          if (MODE == 1) uy[q] = *reinterpret_cast<const uint4*>(p.y + (r + q * stp) * p.ld_y + c);
-          if (has_res) ur[q] = *reinterpret_cast<const uint4*>(p.res + (r + q * stp) * p.ld_res + c);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x8 o = math(unpack8(ua[q]), MODE == 1 ? unpack8(uy[q]) : f32x8{}, has_res ? unpack8(ur[q]) : f32x8{});
-          *reinterpret_cast<uint4*>(p.out + (r + q * stp) * p.ld_out + c) = pack8(o);
-        }
-      }
-    }
-    for (; r < r_end; r += rows_per_pass) {
-      f32x8 a, y, rs;
-      if (vec) {
-        a = unpack8(*reinterpret_cast<const uint4*>(p.a + r * p.ld_a + c));
-        if (MODE == 1) y = unpack8(*reinterpret_cast<const uint4*>(p.y + r * p.ld_y + c));
-        if ((MODE == 0 || MODE == 3) && p.res) rs = unpack8(*reinterpret_cast<const uint4*>(p.res + r * p.ld_res + c));
-      } else {
+    // the residual mode is block-uniform: one branch-free instance of the row loops per mode (with the runtime tests inside the
+    // element loop hipcc emitted a branch per element and no packed fp32 math: ISA of ew_kernel<0, SILU>, round 3)
+    auto rows = [&](auto rm) {
+      constexpr int RES = decltype(rm)::value;  // 0: no residual, 1: added after the activation (MODE 3: the add itself), 2: before
+      auto math = [&](const f32x8& a, const f32x8& y, const f32x8& rs) -> f32x8 {
+        f32x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const bool ok = c + j < p.C;
-          a.v[j] = ok ? (float)p.a[r * p.ld_a + c + j] : 0.f;
-          if (MODE == 1) y.v[j] = ok ? (float)p.y[r * p.ld_y + c + j] : 0.f;
-          if ((MODE == 0 || MODE == 3) && p.res) rs.v[j] = ok ? (float)p.res[r * p.ld_res + c + j] : 0.f;
+          if (MODE == 0) {
+            float u = a.v[j] * sc[j] + sh[j];
+            if (RES == 2) u += rs.v[j];
+            float v = act_fwd(u, ACT, p.ap);
+            if (RES == 1) v += rs.v[j];
+            o.v[j] = v;
+          } else if (MODE == 1) {
+            const float u = y.v[j] * sc[j] + sh[j];
+            const float du = a.v[j] * act_bwd(u, ACT, p.ap);
+            if (p.mean) {
+              const float xh = (y.v[j] - mu[j]) * is[j];
+              o.v[j] = sc[j] * (du - k1[j] - xh * k2[j]);
+            } else {
+              o.v[j] = sc[j] * du;
+            }
+          } else if (MODE == 2) {
+            o.v[j] = a.v[j];
+          } else {
+            o.v[j] = a.v[j] + rs.v[j];
+          }
+        }
+        return o;
+      };
+      constexpr bool has_res = RES != 0;
+      int64_t r = r_begin + ty;
+      if (vec) {
+        // 4 rows per trip: all loads of the trip are issued before the arithmetic (bytes in flight per lane x4)
+        // 4 rows per trip: all loads of the trip are issued before the arithmetic (bytes in flight per lane x4)
+        const int64_t stp = rows_per_pass;
+        for (; r + 3 * stp < r_end; r += 4 * stp) {
+          uint4 ua[4], uy[4], ur[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            ua[q] = *reinterpret_cast<const uint4*>(p.a + (r + q * stp) * p.ld_a + c);
+            if (MODE == 1) uy[q] = *reinterpret_cast<const uint4*>(p.y + (r + q * stp) * p.ld_y + c);
+            if (has_res) ur[q] = *reinterpret_cast<const uint4*>(p.res + (r + q * stp) * p.ld_res + c);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x8 o = math(unpack8(ua[q]), MODE == 1 ? unpack8(uy[q]) : f32x8{}, has_res ? unpack8(ur[q]) : f32x8{});
+            *reinterpret_cast<uint4*>(p.out + (r + q * stp) * p.ld_out + c) = pack8(o);
+          }
         }
       }
-      const f32x8 o = math(a, y, rs);
-      if (vec) {
-        *reinterpret_cast<uint4*>(p.out + r * p.ld_out + c) = pack8(o);
-      } else {
+      for (; r < r_end; r += rows_per_pass) {
+        f32x8 a, y, rs;
+        if (vec) {
+          a = unpack8(*reinterpret_cast<const uint4*>(p.a + r * p.ld_a + c));
+          if (MODE == 1) y = unpack8(*reinterpret_cast<const uint4*>(p.y + r * p.ld_y + c));
+          if (has_res) rs = unpack8(*reinterpret_cast<const uint4*>(p.res + r * p.ld_res + c));
+        } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (c + j < p.C) p.out[r * p.ld_out + c + j] = (h16_t)o.v[j];
+          for (int j = 0; j < 8; ++j) {
+            const bool ok = c + j < p.C;
+            a.v[j] = ok ? (float)p.a[r * p.ld_a + c + j] : 0.f;
+            if (MODE == 1) y.v[j] = ok ? (float)p.y[r * p.ld_y + c + j] : 0.f;
+            if (has_res) rs.v[j] = ok ? (float)p.res[r * p.ld_res + c + j] : 0.f;
+          }
+        }
+        const f32x8 o = math(a, y, rs);
+        if (vec) {
+          *reinterpret_cast<uint4*>(p.out + r * p.ld_out + c) = pack8(o);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (c + j < p.C) p.out[r * p.ld_out + c + j] = (h16_t)o.v[j];
+        }
       }
+    };
+    if constexpr (MODE == 3) {
+      rows(std::integral_constant<int, 1>{});
+    } else if constexpr (MODE == 0) {
+      if (!p.res) rows(std::integral_constant<int, 0>{});
+      else if (p.res_pre) rows(std::integral_constant<int, 2>{});
+      else rows(std::integral_constant<int, 1>{});
+    } else {
+      rows(std::integral_constant<int, 0>{});
     }
   }
 }

@@ -5,6 +5,7 @@
 //    src/models/segmentors/encoder_decoder.py:93-107 (after the bilinear resize to label size).
 //  * per-(sample, channel) scaling = Dropout2d apply / backward (src/models/heads/seg/base_seg_head.py:32-37).
 #include "common.h"
+#include "bilinear_index.h"
 
 namespace cvhip {
 
@@ -136,6 +137,315 @@ __global__ __launch_bounds__(256) void seg_ce_bwd_rows_kernel(const h16_t* __res
   }
 }
 
+// ---- bilinear resize + cross-entropy in one pass (round 3) --------------------------------------------------------------------------
+// encoder_decoder.py:93-107 resizes the 1/4-resolution logits to label size and takes the pixel-wise CE there. Done as two ops, the
+// full-resolution logits (16 x 512 x 1024 x 24 bf16 = 400 MB for DeepLabv3+ at batch 16) are written by the resize, read by the CE
+// forward, read again and their gradient written by the CE backward, and that is read by the resize backward: 2 GB of traffic and 2.7 ms
+// of a 36 ms step for a tensor nobody needs. Here the label-resolution logits exist only in registers:
+//   forward : one thread per label pixel interpolates its C logits from the 4 source pixels (L2-resident: the low-resolution
+//             tensor is 25 MB), reduces max / sum-exp and adds -log p_target to the block's partial;
+//   backward: one block per TH x TW tile of LOW-resolution pixels re-derives softmax - onehot for every label pixel of the tile's
+//             footprint (the pixels whose interpolation reads a tile pixel; halo pixels are recomputed by the neighbouring blocks:
+//             1.4x the pixels for x4 upsampling) into an LDS tile, then every (pixel, class) of the tile gathers its footprint with
+//             the interpolation weights. No atomics: each low-resolution gradient element is written once, in a fixed order.
+// The interpolated logits are not rounded to 16 bits in between (the two-op form rounds them and their gradient).
+struct CeBilParams {
+  const h16_t* x;  // [N][Hi][Wi][ld_x] low-resolution logits
+  int ld_x;
+  const int64_t* target;  // [N][Ho][Wo]
+  int N, C, Hi, Wi, Ho, Wo, align, ignore;
+  float sh, sw;
+  float* partial;  // forward: [gridDim.x][2] = (sum of -log p_t, #valid)
+  const float* stat;    // backward: forward's (mean loss, count)
+  const float* gscale;  // backward: upstream gradient of the mean loss (1 element) or NULL
+  h16_t* dx;            // backward: [N][Hi][Wi][ld_dx]
+  int ld_dx;
+  int tiles_h, tiles_w, fh_max, fw_max;
+};
+
+// interpolated logits of label pixel (oy, ox): z[c] = a0*(b0*v00 + b1*v01) + a1*(b0*v10 + b1*v11) (bilinear_fwd_kernel's expression)
+// `img` holds source rows [h_org, ...) x columns [w_org, w_org + pw) with `ld` elements per pixel: the image in global memory
+// (h_org = w_org = 0, pw = Wi) or a patch of it staged in the LDS
+template <int CMAX>
+__device__ __forceinline__ void cebil_logits(const CeBilParams& p, const h16_t* img, int h_org, int w_org, int pw, int ld, bool vec, int oy, int ox,
+                                             float (&z)[CMAX]) {
+  int h0, h1, w0, w1;
+  float lh, lw;
+  bil_src(oy, p.sh, p.align, p.Hi, &h0, &h1, &lh);
+  bil_src(ox, p.sw, p.align, p.Wi, &w0, &w1, &lw);
+  const h16_t* r00 = img + ((int64_t)(h0 - h_org) * pw + (w0 - w_org)) * ld;
+  const h16_t* r01 = img + ((int64_t)(h0 - h_org) * pw + (w1 - w_org)) * ld;
+  const h16_t* r10 = img + ((int64_t)(h1 - h_org) * pw + (w0 - w_org)) * ld;
+  const h16_t* r11 = img + ((int64_t)(h1 - h_org) * pw + (w1 - w_org)) * ld;
+  const float a0 = 1.f - lh, a1 = lh, b0 = 1.f - lw, b1 = lw;
+#pragma unroll
+  for (int v = 0; v < CMAX / 8; ++v) {
+    f32x8 q00, q01, q10, q11;
+    if (vec) {  // pad lanes carry whatever the buffer holds: never used (c < C below)
+      q00 = unpack8(*reinterpret_cast<const uint4*>(r00 + v * 8));
+      q01 = unpack8(*reinterpret_cast<const uint4*>(r01 + v * 8));
+      q10 = unpack8(*reinterpret_cast<const uint4*>(r10 + v * 8));
+      q11 = unpack8(*reinterpret_cast<const uint4*>(r11 + v * 8));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool ok = v * 8 + j < p.C;
+        q00.v[j] = ok ? (float)r00[v * 8 + j] : 0.f;
+        q01.v[j] = ok ? (float)r01[v * 8 + j] : 0.f;
+        q10.v[j] = ok ? (float)r10[v * 8 + j] : 0.f;
+        q11.v[j] = ok ? (float)r11[v * 8 + j] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[v * 8 + j] = a0 * (b0 * q00.v[j] + b1 * q01.v[j]) + a1 * (b0 * q10.v[j] + b1 * q11.v[j]);
+  }
+}
+
+// the same from an fp32 patch in the LDS (rows [h_org, ..) x columns [w_org, w_org + pw), ldp floats per pixel, 16-byte aligned): no
+// 16-bit unpacking per tap — 4 taps x CMAX channels of shifts / masks were a quarter of the backward kernel's instructions
+template <int CMAX>
+__device__ __forceinline__ void cebil_logits_lds(const CeBilParams& p, const float* P, int h_org, int w_org, int pw, int ldp, int oy, int ox,
+                                                 float (&z)[CMAX]) {
+  int h0, h1, w0, w1;
+  float lh, lw;
+  bil_src(oy, p.sh, p.align, p.Hi, &h0, &h1, &lh);
+  bil_src(ox, p.sw, p.align, p.Wi, &w0, &w1, &lw);
+  const float* r00 = P + ((h0 - h_org) * pw + (w0 - w_org)) * ldp;
+  const float* r01 = P + ((h0 - h_org) * pw + (w1 - w_org)) * ldp;
+  const float* r10 = P + ((h1 - h_org) * pw + (w0 - w_org)) * ldp;
+  const float* r11 = P + ((h1 - h_org) * pw + (w1 - w_org)) * ldp;
+  const float a0 = 1.f - lh, a1 = lh, b0 = 1.f - lw, b1 = lw;
+  const float c00 = a0 * b0, c01 = a0 * b1, c10 = a1 * b0, c11 = a1 * b1;
+#pragma unroll
+  for (int v = 0; v < CMAX / 4; ++v) {
+    const float4 q00 = *reinterpret_cast<const float4*>(r00 + v * 4);
+    const float4 q01 = *reinterpret_cast<const float4*>(r01 + v * 4);
+    const float4 q10 = *reinterpret_cast<const float4*>(r10 + v * 4);
+    const float4 q11 = *reinterpret_cast<const float4*>(r11 + v * 4);
+    z[v * 4 + 0] = (c00 * q00.x + c01 * q01.x) + (c10 * q10.x + c11 * q11.x);
+    z[v * 4 + 1] = (c00 * q00.y + c01 * q01.y) + (c10 * q10.y + c11 * q11.y);
+    z[v * 4 + 2] = (c00 * q00.z + c01 * q01.z) + (c10 * q10.z + c11 * q11.z);
+    z[v * 4 + 3] = (c00 * q00.w + c01 * q01.w) + (c10 * q10.w + c11 * q11.w);
+  }
+}
+
+template <int CMAX>
+__global__ __launch_bounds__(256) void seg_ce_bilinear_fwd_kernel(const CeBilParams p) {
+  __shared__ float red[2][256];
+  float loss = 0.f, cnt = 0.f;
+  const int64_t total = (int64_t)p.N * p.Ho * p.Wo;
+  for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < total; m += (int64_t)gridDim.x * 256) {
+    const int64_t t = p.target[m];
+    if (t == p.ignore || t < 0 || t >= p.C) continue;
+    const int ox = (int)(m % p.Wo);
+    const int64_t q = m / p.Wo;
+    const int oy = (int)(q % p.Ho);
+    const int n = (int)(q / p.Ho);
+    float z[CMAX];
+    const bool vec = (p.ld_x & 7) == 0 && p.ld_x >= CMAX && ((uintptr_t)p.x & 15) == 0;
+    cebil_logits<CMAX>(p, p.x + (int64_t)n * p.Hi * p.Wi * p.ld_x, 0, 0, p.Wi, p.ld_x, vec, oy, ox, z);
+    float mx = -INFINITY, zt = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < p.C) {
+        mx = fmaxf(mx, z[c]);
+        if (c == (int)t) zt = z[c];
+      }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < p.C) se += __expf(z[c] - mx);
+    loss += (mx + __logf(se)) - zt;
+    cnt += 1.f;
+  }
+  red[0][threadIdx.x] = loss;
+  red[1][threadIdx.x] = cnt;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + s];
+      red[1][threadIdx.x] += red[1][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    p.partial[2 * blockIdx.x] = red[0][0];
+    p.partial[2 * blockIdx.x + 1] = red[1][0];
+  }
+}
+
+constexpr int kCeBilTH = 4, kCeBilTW = 8;  // low-resolution tile of a backward block
+
+template <int CMAX>
+__global__ __launch_bounds__(256) void seg_ce_bilinear_bwd_kernel(const CeBilParams p) {
+  extern __shared__ __attribute__((aligned(16))) float cebil_smem[];
+  constexpr int TH = kCeBilTH, TW = kCeBilTW;
+  // LDS: G[fh_max * fw_max][C] (fp16: softmax - onehot lies in [-1, 1], 11 significant bits there; fp32 cost half the resident
+  // blocks) | WY[fh_max][TH] | WX[fw_max][TW] | P[(TH + 2) * (TW + 2)][ldp] (the source patch, 16-bit)
+  _Float16* const G = reinterpret_cast<_Float16*>(cebil_smem);
+  float* const WY = cebil_smem + ((((size_t)p.fh_max * p.fw_max * p.C + 1) / 2 + 3) & ~(size_t)3);  // (multiples of 4 floats: P is 16-byte aligned)
+  float* const WX = WY + p.fh_max * TH;
+  const int ldp = CMAX;  // patch pitch in floats (channels >= ld_x are zero)
+  float* const P = WX + (((p.fw_max * TW) + 3) & ~3);
+  __shared__ int geo[4 + 2 * TW];  // oy_lo, FH, ox_lo, FW, then per tile column the [first, last] footprint column with a non-zero weight
+  const int t = threadIdx.x;
+  int b = blockIdx.x;
+  const int tj = b % p.tiles_w;
+  b /= p.tiles_w;
+  const int ti = b % p.tiles_h;
+  const int n = b / p.tiles_h;
+  const int i0 = ti * TH, j0 = tj * TW;
+  const int i1 = min(i0 + TH, p.Hi) - 1, j1 = min(j0 + TW, p.Wi) - 1;  // last tile row / column inside the image
+
+  if (t == 0) {
+    int lo, hi, l2, h2, a, bb;
+    float l;
+    bil_range(i0, p.sh, p.align, p.Ho, &lo, &h2);
+    bil_range(i1, p.sh, p.align, p.Ho, &l2, &hi);
+    // tighten the conservative bounds to the exact footprint: label rows that read a tile row
+    for (; lo < hi; ++lo) {
+      bil_src(lo, p.sh, p.align, p.Hi, &a, &bb, &l);
+      if (bb >= i0) break;
+    }
+    for (; hi > lo; --hi) {
+      bil_src(hi, p.sh, p.align, p.Hi, &a, &bb, &l);
+      if (a <= i1) break;
+    }
+    geo[0] = lo;
+    geo[1] = min(hi - lo + 1, p.fh_max);
+  } else if (t == 64) {
+    int lo, hi, l2, h2, a, bb;
+    float l;
+    bil_range(j0, p.sw, p.align, p.Wo, &lo, &h2);
+    bil_range(j1, p.sw, p.align, p.Wo, &l2, &hi);
+    for (; lo < hi; ++lo) {
+      bil_src(lo, p.sw, p.align, p.Wi, &a, &bb, &l);
+      if (bb >= j0) break;
+    }
+    for (; hi > lo; --hi) {
+      bil_src(hi, p.sw, p.align, p.Wi, &a, &bb, &l);
+      if (a <= j1) break;
+    }
+    geo[2] = lo;
+    geo[3] = min(hi - lo + 1, p.fw_max);
+  } else if (t >= 128 && t < 128 + TW) {
+    geo[4 + 2 * (t - 128)] = 1 << 30;
+    geo[5 + 2 * (t - 128)] = -1;
+  }
+  // source patch: every footprint pixel interpolates from rows [i0 - 1, i1 + 1] x columns [j0 - 1, j1 + 1] (clamped to the image).
+  // Staged once, coalesced: the 4 taps x 3 vectors of a footprint pixel then come from the LDS instead of 12 dependent L2 round
+  // trips behind the label load (the unstaged form ran at a third of the forward kernel's pixel rate)
+  const int ph0 = max(i0 - 1, 0), pw0 = max(j0 - 1, 0);
+  const int prow = min(i1 + 1, p.Hi - 1) - ph0 + 1, pcol = min(j1 + 1, p.Wi - 1) - pw0 + 1;
+  {
+    const h16_t* img = p.x + (int64_t)n * p.Hi * p.Wi * p.ld_x;
+    const bool vsrc = (p.ld_x & 7) == 0 && ((uintptr_t)p.x & 15) == 0;
+    constexpr int vpp = CMAX / 8;
+    for (int e = t; e < prow * pcol * vpp; e += 256) {
+      const int v = e % vpp, px = e / vpp;
+      const int pc = px % pcol, pr = px / pcol;
+      const h16_t* src = img + ((int64_t)(ph0 + pr) * p.Wi + pw0 + pc) * p.ld_x + v * 8;
+      f32x8 q;
+      if (vsrc && v * 8 + 8 <= p.ld_x) {
+        q = unpack8(*reinterpret_cast<const uint4*>(src));
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) q.v[k] = v * 8 + k < p.ld_x ? (float)src[k] : 0.f;
+      }
+      float* dst = P + (size_t)px * ldp + v * 8;
+      *reinterpret_cast<float4*>(dst) = make_float4(q.v[0], q.v[1], q.v[2], q.v[3]);
+      *reinterpret_cast<float4*>(dst + 4) = make_float4(q.v[4], q.v[5], q.v[6], q.v[7]);
+    }
+  }
+  __syncthreads();
+  const int oy_lo = geo[0], FH = geo[1], ox_lo = geo[2], FW = geo[3];
+  // interpolation weight of footprint row f for tile row li (0 when the row does not read it), and the same for columns
+  for (int e = t; e < FH * TH; e += 256) {
+    const int f = e / TH, li = e - f * TH;
+    int a, bb;
+    float l;
+    bil_src(oy_lo + f, p.sh, p.align, p.Hi, &a, &bb, &l);
+    float w = 0.f;
+    if (a == i0 + li) w += 1.f - l;
+    if (bb == i0 + li) w += l;
+    WY[e] = w;
+  }
+  for (int e = t; e < FW * TW; e += 256) {
+    const int f = e / TW, lj = e - f * TW;
+    int a, bb;
+    float l;
+    bil_src(ox_lo + f, p.sw, p.align, p.Wi, &a, &bb, &l);
+    float w = 0.f;
+    if (a == j0 + lj) w += 1.f - l;
+    if (bb == j0 + lj) w += l;
+    WX[e] = w;
+    if (w != 0.f) {  // a tile column's footprint columns are contiguous (src is monotone): keep [first, last]
+      atomicMin(&geo[4 + 2 * lj], f);
+      atomicMax(&geo[5 + 2 * lj], f);
+    }
+  }
+  // softmax - onehot of every footprint pixel (0 for ignored labels)
+  const int64_t* tg = p.target + (int64_t)n * p.Ho * p.Wo;
+  for (int f = t; f < FH * FW; f += 256) {
+    const int fy = f / FW, fx = f - fy * FW;
+    const int oy = oy_lo + fy, ox = ox_lo + fx;
+    const int64_t tt = tg[(int64_t)oy * p.Wo + ox];
+    _Float16* const g = G + (size_t)f * p.C;
+    if (tt == p.ignore || tt < 0 || tt >= p.C) {
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c)
+        if (c < p.C) g[c] = (_Float16)0.f;
+      continue;
+    }
+    float z[CMAX];
+    cebil_logits_lds<CMAX>(p, P, ph0, pw0, pcol, ldp, oy, ox, z);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < p.C) mx = fmaxf(mx, z[c]);
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < p.C) {
+        z[c] = __expf(z[c] - mx);
+        se += z[c];
+      }
+    const float inv = 1.f / se;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < p.C) g[c] = (_Float16)(z[c] * inv - (c == (int)tt ? 1.f : 0.f));
+  }
+  __syncthreads();
+  const float cnt = p.stat[1];
+  const float gs = (cnt > 0.f ? 1.f / cnt : 0.f) * (p.gscale ? p.gscale[0] : 1.f);
+  // gather: a thread owns (tile column lj, class c) — c fastest, ld_dx entries per pixel, the pad channels are written as zeros —
+  // and walks the footprint rows once: the row sums over the footprint columns are shared by the TH tile rows, the <= 2r
+  // independent LDS reads of a row are in flight together
+  const int per_px = p.ld_dx;
+  for (int o = t; o < TW * per_px; o += 256) {
+    const int c = o % per_px, lj = o / per_px;
+    const int j = j0 + lj;
+    if (j >= p.Wi) continue;
+    float acc[TH];
+#pragma unroll
+    for (int li = 0; li < TH; ++li) acc[li] = 0.f;
+    if (c < p.C) {
+      const int fx0 = geo[4 + 2 * lj], fx1 = geo[5 + 2 * lj];
+      for (int fy = 0; fy < FH; ++fy) {
+        const _Float16* const g = G + (size_t)fy * FW * p.C + c;
+        float row = 0.f;
+#pragma unroll 4
+        for (int fx = fx0; fx <= fx1; ++fx) row += WX[fx * TW + lj] * (float)g[(size_t)fx * p.C];
+#pragma unroll
+        for (int li = 0; li < TH; ++li) acc[li] += WY[fy * TH + li] * row;
+      }
+    }
+#pragma unroll
+    for (int li = 0; li < TH; ++li)
+      if (i0 + li < p.Hi) p.dx[((int64_t)(n * p.Hi + i0 + li) * p.Wi + j) * p.ld_dx + c] = (h16_t)(acc[li] * gs);
+  }
+}
+
 // y[n][hw][c] = x[n][hw][c] * s[n][c]
 __global__ __launch_bounds__(256) void scale_nc_kernel(const h16_t* __restrict__ x, int ld_x, const float* __restrict__ s, h16_t* __restrict__ y,
                                                        int ld_y, int N, int C, int HW) {
@@ -164,6 +474,26 @@ static inline int grid_for(int64_t total) {
   if (b < 1) b = 1;
   return (int)b;
 }
+
+template <int CMAX>
+static int cebil_launch_bwd(const CeBilParams& p, int lds, hipStream_t s) {
+  auto kern = seg_ce_bilinear_bwd_kernel<CMAX>;
+  static bool attr_done[64] = {};  // per instantiation and device
+  int devid = 0;
+  (void)hipGetDevice(&devid);
+  bool& done = attr_done[devid & 63];
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e != hipSuccess) {
+      set_last_error("hipFuncSetAttribute(seg_ce_bilinear_bwd_kernel)", e);
+      return CVHIP_ERR_LAUNCH;
+    }
+    done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.N * p.tiles_h * p.tiles_w), dim3(256), lds, s, p);
+  return check_launch("seg_ce_bilinear_bwd_kernel");
+}
+
 
 }  // namespace cvhip
 
@@ -198,6 +528,81 @@ int cvhip_seg_ce_bwd(const void* logits, int32_t ld, const int64_t* target, int6
                        ignore_index, out2, grad_scale, (h16_t*)dlogits, ld_d);
   }
   return check_launch("seg_ce_bwd_kernel");
+}
+
+// footprint bound (label rows read by TH consecutive source rows) for the LDS tile: exact footprints are <= this
+static int cebil_fbound(int in, int out, int T) {
+  const int r = (out + in - 1) / in;  // label pixels per source pixel, rounded up
+  int f = (T + 1) * r + 2;
+  return f < out ? f : out;
+}
+
+static int cebil_lds_bytes(int C, int ld_x, int Hi, int Wi, int Ho, int Wo) {
+  const int fh = cebil_fbound(Hi, Ho, kCeBilTH), fw = cebil_fbound(Wi, Wo, kCeBilTW);
+  const int ldp = C <= 24 ? 24 : 32;  // the kernel's CMAX
+  (void)ld_x;
+  return ((((fh * fw * C + 1) / 2 + 3) & ~3) + fh * kCeBilTH + ((fw * kCeBilTW + 3) & ~3)) * 4 + (kCeBilTH + 2) * (kCeBilTW + 2) * ldp * 4;
+}
+
+int cvhip_seg_ce_bilinear_ok(int32_t C, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo) {
+  if (C <= 0 || C > 32 || Hi <= 0 || Wi <= 0 || Ho < Hi || Wo < Wi) return 0;  // upsampling only
+  return cebil_lds_bytes(C, (C + 7) & ~7, Hi, Wi, Ho, Wo) <= 96 * 1024 ? 1 : 0;  // (the logits' usual pitch: C rounded up to 8)
+}
+
+static int cebil_fill(CeBilParams& p, const void* x, int32_t ld_x, const int64_t* target, int32_t N, int32_t C, int32_t Hi, int32_t Wi,
+                      int32_t Ho, int32_t Wo, int32_t align_corners, int32_t ignore_index) {
+  if (!x || !target || N <= 0 || ld_x < C) return CVHIP_ERR_INVALID;
+  if (!cvhip_seg_ce_bilinear_ok(C, Hi, Wi, Ho, Wo)) return CVHIP_ERR_UNSUPPORTED;
+  p.x = (const h16_t*)x;
+  p.ld_x = ld_x;
+  p.target = target;
+  p.N = N;
+  p.C = C;
+  p.Hi = Hi;
+  p.Wi = Wi;
+  p.Ho = Ho;
+  p.Wo = Wo;
+  p.align = align_corners;
+  p.ignore = ignore_index;
+  bil_scales(Hi, Wi, Ho, Wo, align_corners, &p.sh, &p.sw);
+  return CVHIP_OK;
+}
+
+int cvhip_seg_ce_bilinear_fwd(const void* x, int32_t ld_x, const int64_t* target, int32_t N, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho,
+                              int32_t Wo, int32_t align_corners, int32_t ignore_index, float* partial, float* out2, void* stream) {
+  CeBilParams p{};
+  int st = cebil_fill(p, x, ld_x, target, N, C, Hi, Wi, Ho, Wo, align_corners, ignore_index);
+  if (st) return st;
+  if (!partial || !out2) return CVHIP_ERR_INVALID;
+  p.partial = partial;
+  const int rows = grid_for((int64_t)N * Ho * Wo);
+  if (C <= 24) hipLaunchKernelGGL(seg_ce_bilinear_fwd_kernel<24>, dim3(rows), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(seg_ce_bilinear_fwd_kernel<32>, dim3(rows), dim3(256), 0, (hipStream_t)stream, p);
+  st = check_launch("seg_ce_bilinear_fwd_kernel");
+  if (st) return st;
+  hipLaunchKernelGGL(seg_ce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, rows, out2);
+  return check_launch("seg_ce_finalize_kernel");
+}
+
+int cvhip_seg_ce_bilinear_bwd(const void* x, int32_t ld_x, const int64_t* target, int32_t N, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho,
+                              int32_t Wo, int32_t align_corners, int32_t ignore_index, const float* out2, const float* grad_scale, void* dx,
+                              int32_t ld_dx, void* stream) {
+  CeBilParams p{};
+  int st = cebil_fill(p, x, ld_x, target, N, C, Hi, Wi, Ho, Wo, align_corners, ignore_index);
+  if (st) return st;
+  if (!out2 || !dx || ld_dx < C) return CVHIP_ERR_INVALID;
+  p.stat = out2;
+  p.gscale = grad_scale;
+  p.dx = (h16_t*)dx;
+  p.ld_dx = ld_dx;
+  p.tiles_h = (Hi + kCeBilTH - 1) / kCeBilTH;
+  p.tiles_w = (Wi + kCeBilTW - 1) / kCeBilTW;
+  p.fh_max = cebil_fbound(Hi, Ho, kCeBilTH);
+  p.fw_max = cebil_fbound(Wi, Wo, kCeBilTW);
+  const int lds = cebil_lds_bytes(C, ld_x, Hi, Wi, Ho, Wo);
+  if (lds > 96 * 1024) return CVHIP_ERR_UNSUPPORTED;
+  if (C <= 24) return cebil_launch_bwd<24>(p, lds, (hipStream_t)stream);
+  return cebil_launch_bwd<32>(p, lds, (hipStream_t)stream);
 }
 
 int cvhip_scale_nc(const void* x, int32_t ld_x, const float* scale_nc, void* y, int32_t ld_y, int32_t N, int32_t C, int32_t HW, void* stream) {

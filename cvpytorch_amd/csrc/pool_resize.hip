@@ -6,6 +6,7 @@
 // src/models/segmentors/encoder_decoder.py:99 (bilinear), src/models/modules/yolo_modules.py:30-36
 // (Focus space-to-depth).
 #include "common.h"
+#include "bilinear_index.h"
 
 namespace cvhip {
 
@@ -234,21 +235,6 @@ struct BilParams {
   float sh, sw;  // source-index scale
 };
 
-__device__ __forceinline__ void bil_src(int o, float scale, int align, int in, int* i0, int* i1, float* l1) {
-  float s;
-  if (align) s = scale * o;
-  else {
-    s = scale * (o + 0.5f) - 0.5f;
-    if (s < 0.f) s = 0.f;
-  }
-  int a = (int)s;
-  if (a > in - 1) a = in - 1;
-  const int b = a + ((a < in - 1) ? 1 : 0);
-  *i0 = a;
-  *i1 = b;
-  *l1 = s - (float)a;
-}
-
 __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const BilParams p) {
   const int CV = (p.C + 7) >> 3;
   // 16-B vectors also for odd channel counts when both pitches leave room for the padded tail vector (19-class logits in
@@ -343,30 +329,6 @@ __global__ __launch_bounds__(256) void nearest_bwd_kernel(const BilParams p) {
       }
     store8(p.dst + ((int64_t)(n * p.Hi + ih) * p.Wi + iw) * p.ld_dst, cv * 8, p.C, vec, acc);
   }
-}
-
-// backward as a deterministic gather: each INPUT pixel scans the (small) range of output pixels that
-// can reference it and re-derives their interpolation weights.
-__device__ __forceinline__ void bil_range(int i, float scale, int align, int out, int* lo, int* hi) {
-  // outputs o with floor(src(o)) in {i-1, i}; src is monotone in o. Conservative bounds, then exact test.
-  const float inv = scale > 0.f ? 1.f / scale : 0.f;
-  float a, b;
-  if (align) {
-    a = (i - 1) * inv;
-    b = (i + 1) * inv;
-  } else {
-    a = (i - 1 + 0.5f) * inv - 0.5f;
-    b = (i + 1 + 0.5f) * inv - 0.5f;
-  }
-  int l = (int)floorf(a) - 1, h = (int)ceilf(b) + 1;
-  if (scale <= 0.f) {
-    l = 0;
-    h = out - 1;
-  }
-  if (l < 0) l = 0;
-  if (h > out - 1) h = out - 1;
-  *lo = l;
-  *hi = h;
 }
 
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const BilParams p) {
@@ -695,16 +657,6 @@ int cvhip_upsample2x_bwd(const void* dout, int32_t ld_dout, void* da, int32_t ld
   const int64_t total = (int64_t)N * Ha * Wa * ((Ca + 7) / 8);
   hipLaunchKernelGGL(up2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("up2_bwd_kernel");
-}
-
-static void bil_scales(int Hi, int Wi, int Ho, int Wo, int align, float* sh, float* sw) {
-  if (align) {
-    *sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
-    *sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
-  } else {
-    *sh = (float)Hi / (float)Ho;
-    *sw = (float)Wi / (float)Wo;
-  }
 }
 
 int cvhip_resize_nearest_fwd(const void* x, int32_t ld_x, void* y, int32_t ld_y, int32_t N, int32_t C, int32_t Hi, int32_t Wi,

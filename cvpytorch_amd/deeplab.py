@@ -221,8 +221,8 @@ class EncoderDecoder(nn.Module):
         return None, [self.head(self.backbone(imgs))]
 
     def loss_from_features(self, feats, targets):
-        preds = ops.resize_bilinear(feats[0], targets.shape[-2:], False)
-        ce = ops.seg_cross_entropy(preds, targets, self.ignore_index)
+        # resize to label size + CE as one fused pass (ops.seg_cross_entropy_resized): the label-resolution logits stay in registers
+        ce = ops.seg_cross_entropy_resized(feats[0], targets, self.ignore_index, False)
         return {"ce_loss": ce, "loss": ce}
 
     def forward(self, imgs, targets=None, mode="infer", **kwargs):

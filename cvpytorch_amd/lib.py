@@ -136,6 +136,9 @@ SIGNATURES = {
     "cvhip_seg_ce_rows": (_i32, [_i64]),
     "cvhip_seg_ce_fwd": (_i32, [_p, _i32, _p, _i64, _i32, _i32, _p, _p, _p]),
     "cvhip_seg_ce_bwd": (_i32, [_p, _i32, _p, _i64, _i32, _i32, _p, _p, _p, _i32, _p]),
+    "cvhip_seg_ce_bilinear_ok": (_i32, [_i32, _i32, _i32, _i32, _i32]),
+    "cvhip_seg_ce_bilinear_fwd": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p]),
+    "cvhip_seg_ce_bilinear_bwd": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p]),
     "cvhip_resize_nearest_fwd": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "cvhip_resize_nearest_bwd": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "cvhip_resize_bilinear_fwd": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),

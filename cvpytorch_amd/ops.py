@@ -1600,6 +1600,50 @@ def seg_cross_entropy(logits, target, ignore_index=255):
     return SegCrossEntropy.apply(logits, target, ignore_index)
 
 
+class SegCrossEntropyBilinear(torch.autograd.Function):
+    """F.interpolate(logits, size=target.shape[-2:], mode='bilinear', align_corners) followed by nn.CrossEntropyLoss(ignore_index,
+    'mean') — encoder_decoder.py:93-107 — as ONE pass forward and one backward (cvhip_seg_ce_bilinear_fwd / _bwd): the
+    label-resolution logits and their gradient are never materialised."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index, align_corners):
+        logits, ld = as_nhwc(logits)
+        N, Cc, Hi, Wi = logits.shape
+        target = target.long().contiguous()
+        Ho, Wo = int(target.shape[-2]), int(target.shape[-1])
+        lib = L.load()
+        partial = torch.empty((2 * lib.cvhip_seg_ce_rows(N * Ho * Wo),), dtype=torch.float32, device=logits.device)
+        out2 = torch.empty((2,), dtype=torch.float32, device=logits.device)
+        L.call("cvhip_seg_ce_bilinear_fwd", logits.data_ptr(), ld, target.data_ptr(), N, Cc, Hi, Wi, Ho, Wo, int(align_corners), int(ignore_index),
+               partial.data_ptr(), out2.data_ptr(), _stream())
+        ctx.meta = (N, Cc, Hi, Wi, Ho, Wo, ld, int(ignore_index), int(align_corners))
+        ctx.save_for_backward(logits, target, out2)
+        return out2[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, out2 = ctx.saved_tensors
+        N, Cc, Hi, Wi, Ho, Wo, ld, ign, ac = ctx.meta
+        Cp = _round8(Cc)
+        gs = g.detach().float().reshape(1).contiguous()
+        buf = torch.empty((N, Hi, Wi, Cp), dtype=ACT_DTYPE, device=logits.device)
+        L.call("cvhip_seg_ce_bilinear_bwd", logits.data_ptr(), ld, target.data_ptr(), N, Cc, Hi, Wi, Ho, Wo, ac, ign, out2.data_ptr(), gs.data_ptr(),
+               buf.data_ptr(), Cp, _stream())
+        return buf.permute(0, 3, 1, 2)[:, :Cc], None, None, None
+
+
+_SEG_CE_FUSED = __import__("os").environ.get("CVHIP_SEG_CE_FUSED", "1") != "0"
+
+
+def seg_cross_entropy_resized(logits, target, ignore_index=255, align_corners=False):
+    """CE of `logits` bilinearly resized to the label size; the fused kernels when the geometry allows, else the two ops"""
+    N, Cc, Hi, Wi = logits.shape
+    Ho, Wo = int(target.shape[-2]), int(target.shape[-1])
+    if _SEG_CE_FUSED and L.load().cvhip_seg_ce_bilinear_ok(Cc, Hi, Wi, Ho, Wo):
+        return SegCrossEntropyBilinear.apply(logits, target, ignore_index, align_corners)
+    return seg_cross_entropy(resize_bilinear(logits, (Ho, Wo), align_corners), target, ignore_index)
+
+
 class ResizeBilinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, Ho, Wo, align_corners):

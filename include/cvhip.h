@@ -327,6 +327,21 @@ int cvhip_seg_ce_bwd(const void* logits_bf16, int32_t ld, const int64_t* target,
                      int32_t C, int32_t ignore_index, const float* out2, const float* grad_scale,
                      void* dlogits_bf16, int32_t ld_d, void* stream);
 
+/* Bilinear resize of the logits to label size + the cross-entropy above in ONE pass (encoder_decoder.py:93-107 does
+ * F.interpolate(seg_logit, size=label.shape, mode='bilinear', align_corners=...) and then the loss): the label-resolution logits and
+ * their gradient never exist in memory. x: [N][Hi][Wi][ld_x] low-resolution logits, target int64 [N][Ho][Wo]; partial / out2 /
+ * grad_scale as for cvhip_seg_ce_fwd / _bwd with M = N*Ho*Wo; bwd writes dx [N][Hi][Wi][ld_dx] = d loss / d x (pad channels zero),
+ * deterministically (a gather, no atomics). The interpolated logits are kept in fp32 (the two-op form rounds them to 16 bits).
+ * cvhip_seg_ce_bilinear_ok: 1 when the geometry is supported (upsampling, C <= 32, footprint tile fits the LDS), else the entry
+ * points return CVHIP_ERR_UNSUPPORTED and the caller composes cvhip_resize_bilinear_* with cvhip_seg_ce_*. */
+int cvhip_seg_ce_bilinear_ok(int32_t C, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo);
+int cvhip_seg_ce_bilinear_fwd(const void* x_bf16, int32_t ld_x, const int64_t* target, int32_t N, int32_t C, int32_t Hi, int32_t Wi,
+                              int32_t Ho, int32_t Wo, int32_t align_corners, int32_t ignore_index, float* partial, float* out2,
+                              void* stream);
+int cvhip_seg_ce_bilinear_bwd(const void* x_bf16, int32_t ld_x, const int64_t* target, int32_t N, int32_t C, int32_t Hi, int32_t Wi,
+                              int32_t Ho, int32_t Wo, int32_t align_corners, int32_t ignore_index, const float* out2,
+                              const float* grad_scale, void* dx_bf16, int32_t ld_dx, void* stream);
+
 /* nearest-neighbour resize to an arbitrary size: F.interpolate(x, size, mode="nearest") of the STDC neck (src/models/necks/seg:
  * stdc neck `F.interpolate(..., mode='nearest')` calls; torch's index rule src = min(floor(dst * in/out), in-1)). Forward is an
  * exact copy (bit-exact); backward a deterministic gather-sum over the output pixels of each input pixel. */

@@ -89,6 +89,65 @@ def test_seg_cross_entropy(Cc, H, W):
     assert float(l0) == 0.0
 
 
+@pytest.mark.parametrize("Cc,Hi,Wi,Ho,Wo,ac,fused", [(19, 8, 16, 32, 64, False, True),      # x4: DeepLabv3+ head -> label size
+                                                    (19, 7, 9, 28, 36, False, True),       # ragged tiles (7 rows, 9 columns of 4 x 8 tiles)
+                                                    (19, 8, 16, 32, 64, True, True),       # align_corners
+                                                    (21, 6, 10, 17, 23, False, True),      # non-integer ratio
+                                                    (8, 5, 5, 5, 5, False, True),          # identity resize
+                                                    (32, 4, 8, 16, 32, False, True),       # widest supported class count
+                                                    (19, 3, 4, 36, 48, False, True),       # x12: the footprint is the whole label map
+                                                    (19, 2, 2, 64, 64, False, False),      # x32: footprint tile does not fit the LDS -> two ops
+                                                    (40, 8, 8, 16, 16, False, False)])     # too many classes -> two ops
+def test_seg_cross_entropy_resized_fused(Cc, Hi, Wi, Ho, Wo, ac, fused):
+    """ops.seg_cross_entropy_resized == F.cross_entropy(F.interpolate(logits, label size, bilinear), labels) in fp32
+    (encoder_decoder.py:93-107), values and the gradient w.r.t. the LOW-resolution logits"""
+    torch.manual_seed(1)
+    N = 3
+    logits = bf(torch.randn(N, Cc, Hi, Wi) * 3)
+    tgt = torch.randint(0, Cc, (N, Ho, Wo))
+    tgt[torch.rand(N, Ho, Wo) < 0.2] = 255
+    lr = logits.clone().requires_grad_(True)
+    ref = F.cross_entropy(F.interpolate(lr, size=(Ho, Wo), mode="bilinear", align_corners=ac), tgt, ignore_index=255)
+    (gref,) = torch.autograd.grad(ref, lr)
+    fused_ok = bool(L.load().cvhip_seg_ce_bilinear_ok(Cc, Hi, Wi, Ho, Wo))
+    assert fused_ok == fused
+    calls = []
+    real = L.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return real(name, *a)
+
+    L.call = spy
+    try:
+        ld = nhwc(logits).requires_grad_(True)
+        loss = ops.seg_cross_entropy_resized(ld, tgt.to(dev()), 255, ac)
+        (g,) = torch.autograd.grad(loss * 2.0, ld)
+    finally:
+        L.call = real
+    assert ("cvhip_seg_ce_bilinear_fwd" in calls) == fused_ok and ("cvhip_seg_ce_bilinear_bwd" in calls) == fused_ok
+    tol = 1e-4 if fused_ok else 3e-3          # fused: fp32 interpolated logits; two-op: they are rounded to bf16 in between
+    assert abs(float(loss) - float(ref)) < tol * max(1.0, abs(float(ref)))
+    assert rel_l2(g.float(), 2.0 * gref) < 4e-3
+    if fused_ok:
+        # bit-identical from run to run (a gather, no atomics) and equal to the two-op composition to 16-bit rounding
+        ld2 = nhwc(logits).requires_grad_(True)
+        (g2,) = torch.autograd.grad(ops.seg_cross_entropy_resized(ld2, tgt.to(dev()), 255, ac) * 2.0, ld2)
+        assert torch.equal(g, g2)
+        ld3 = nhwc(logits).requires_grad_(True)
+        two = ops.seg_cross_entropy(ops.resize_bilinear(ld3, (Ho, Wo), ac), tgt.to(dev()), 255)
+        (g3,) = torch.autograd.grad(two * 2.0, ld3)
+        assert abs(float(two) - float(loss)) < 3e-3 * max(1.0, abs(float(ref)))
+        assert rel_l2(g.float(), g3.float()) < 8e-3
+        # pad channels of the gradient buffer are zero (the 1x1 classifier's backward reads the padded pitch)
+        base = g._base
+        if base is not None and base.dim() == 4 and base.shape[-1] > Cc:   # [N][Hi][Wi][round8(C)]
+            assert float(base[..., Cc:].abs().max()) == 0.0
+    allign = torch.full((N, Ho, Wo), 255)
+    l0 = ops.seg_cross_entropy_resized(nhwc(logits).requires_grad_(True), allign.to(dev()), 255, ac)
+    assert float(l0) == 0.0
+
+
 def _load(name):
     z = np.load(os.path.join(GOLD, name + ".npz"))
     out = {}
