@@ -114,7 +114,11 @@ __device__ __forceinline__ h16x8 tr_read8(const unsigned char* p0, const unsigne
 // less than the load latency under load: the waves sat in s_waitcnt for 41-59 % of their cycles (profiles/r02_sq_step_summary.txt).
 // Loads are unconditional (masked lanes read the tensor's first bytes and are zeroed on the way into the LDS), so hipcc emits
 // counted vmcnt waits and the younger steps stay in flight across the store of the oldest one.
-template <int TN, int WN, int WK, int kWgGroups, int PD = 3>
+// ABL (profiling builds of the same kernel, CVHIP_WGRAD_ABLATE=4/5): 4 = no fragment reads / MFMAs (staging only), 5 = no global
+// loads after the first step (LDS writes, fragment reads and MFMAs only)
+template <int TN, int WN, int WK, int kWgGroups, int PD = 3, int ABL = 0>
+// (launch bounds: PD 1 with a 128-VGPR cap — 4 blocks per CU instead of 3 — was measured in round 3: the 128-wide tile spills
+// 12-20 B/lane and loses 15-50 % per launch, profiles/r03_wgrad_ablation.log)
 __global__ __launch_bounds__(256 * kWgGroups, kWgGroups == 1 ? 2 : 1) void wgrad_kernel(const WgradParams p) {
   constexpr int TK = 128;
   constexpr int WAVES_K = TK / WK;
@@ -180,6 +184,7 @@ __global__ __launch_bounds__(256 * kWgGroups, kWgGroups == 1 ? 2 : 1) void wgrad
 
   auto load_step = [&](int step, auto setc) {
     constexpr int S = decltype(setc)::value;
+    if (ABL == 5 && step >= PD) return;
     const int mb = m_begin + step * 32;
     unsigned lv = 0;
 #pragma unroll
@@ -213,7 +218,8 @@ __global__ __launch_bounds__(256 * kWgGroups, kWgGroups == 1 ? 2 : 1) void wgrad
     constexpr int S = decltype(setc)::value;
     const uint4 z = make_uint4(0, 0, 0, 0);
     // the oldest step in flight has landed when only the PD-1 younger ones are outstanding (2 + D_IT loads per step, every lane)
-    wgrad_wait_vm<(PD - 1) * (2 + D_IT)>();
+    if (ABL == 5) wgrad_wait_vm<0>();
+    else wgrad_wait_vm<(PD - 1) * (2 + D_IT)>();
 #pragma unroll
     for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(rx[S][i]));
 #pragma unroll
@@ -257,6 +263,7 @@ __global__ __launch_bounds__(256 * kWgGroups, kWgGroups == 1 ? 2 : 1) void wgrad
   const int hsw = q | ((g & 1) << 2);
   const int px0 = 8 * g + q;
   auto compute = [&](int cur) {
+    if (ABL == 4) return;
     h16x8 fd[NF], fx[KF];
 #pragma unroll
     for (int a = 0; a < NF; ++a) {
@@ -597,7 +604,7 @@ static int launch_wg(WgradParams& p, hipStream_t stream) {
   p.ablate = p.det_ws ? 3 : abl;
   p.scratch = nullptr;
   p.split_stride = 0;
-  if (!p.det_ws && abl >= 2) {  // profiling only: 512 MB of scratch, one region per pixel split
+  if (!p.det_ws && (abl == 2 || abl == 3)) {  // profiling only: 512 MB of scratch, one region per pixel split
     static float* scratch = nullptr;
     if (!scratch && hipMalloc(&scratch, 512ull << 20) != hipSuccess) return CVHIP_ERR_LAUNCH;
     p.scratch = scratch;
@@ -659,6 +666,21 @@ static int launch_wg(WgradParams& p, hipStream_t stream) {
     return check_launch("wgrad_dma_kernel");
   }
   const int pd = pd_force == 1 || pd_force == 3 ? pd_force : (TN == 64 ? 3 : 1);
+  if (abl == 4 || abl == 5) {  // profiling instances (one group per block or two, the depth the shape would get)
+    p.ablate = 1;              // and no atomic epilogue
+    if (abl == 4) {
+      if (pd == 1 && groups >= 2) hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 2, 1, 4>), dim3(tiles * splits), dim3(512), 0, stream, p);
+      else if (pd == 1) hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 1, 1, 4>), dim3(tiles * splits), dim3(256), 0, stream, p);
+      else if (groups >= 2) hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 2, 3, 4>), dim3(tiles * splits), dim3(512), 0, stream, p);
+      else hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 1, 3, 4>), dim3(tiles * splits), dim3(256), 0, stream, p);
+    } else {
+      if (pd == 1 && groups >= 2) hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 2, 1, 5>), dim3(tiles * splits), dim3(512), 0, stream, p);
+      else if (pd == 1) hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 1, 1, 5>), dim3(tiles * splits), dim3(256), 0, stream, p);
+      else if (groups >= 2) hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 2, 3, 5>), dim3(tiles * splits), dim3(512), 0, stream, p);
+      else hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 1, 3, 5>), dim3(tiles * splits), dim3(256), 0, stream, p);
+    }
+    return check_launch("wgrad_kernel(ablation)");
+  }
   if (pd == 1) {
     if (groups >= 2) hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 2, 1>), dim3(tiles * splits), dim3(512), 0, stream, p);
     else hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 1, 1>), dim3(tiles * splits), dim3(256), 0, stream, p);
