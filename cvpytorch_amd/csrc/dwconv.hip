@@ -385,6 +385,284 @@ static void dw3_launch_geom(Dw3Params& q, int* grid, bool wgrad = false) {
   *grid = (int)(cdiv64(rows, (int64_t)rpp * rpt) * nseg * ncv);
 }
 
+// ---- 3x3 / stride 1 / dilation 1 through an LDS ring fed by LDS-DMA (round 3) -----------------------------------------------------------
+// The register-window walk above keeps 3 x 16 B per lane in flight behind a ~2 us round trip with 2 waves per SIMD: 1.5 TB/s on the
+// DeepLabv3+ decoder tensors (412-453 us per pass over 319 MB in / out), and every input row is fetched three times (by the three
+// output rows that use it) through L1/L2. Here a block owns a STRIP — TW output columns x RB output rows of one image, a chunk of
+// <= 64 channel vectors — and walks it top to bottom:
+//   * input row segments (TW + 2 pixels x chunk) go global -> LDS with global_load_lds_dwordx4 into a ring of NR rows, issued NR - 3
+//     rows ahead of their first use: two row segments (24 KB per block, 2 blocks per CU) are in flight while a row is computed, no
+//     VGPRs are spent on staging, and each input element is fetched from memory ONCE per strip (halo: 2 columns per TW, 2 rows per RB);
+//   * a thread owns one channel vector (weights in registers, as before) and PXT adjacent output pixels of the row: 3 x (PXT + 2)
+//     ds_read_b128 per PXT outputs;
+//   * the weight gradient reads its dy row segments through a second ring the same way (an ordinary global load beside LDS-DMAs in
+//     flight makes hipcc drain the DMA queue with s_waitcnt vmcnt(0)).
+// One raw s_barrier per row; the counted s_waitcnt leaves the younger rows in flight. Output stores are not counted in the wait
+// (vmcnt is shared with stores on gfx9: counting only the younger LOADS makes the wait at worst stricter, never weaker).
+// Out-of-image rows / columns and lanes past the segment read a zero page, so every wave issues the same number of DMAs per row.
+__device__ __attribute__((aligned(64))) unsigned int g_dw_zero[16];
+
+#define CVHIP_DW_GLDS16(src, dst)                                                                               \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                       \
+                                   (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+template <int N>
+__device__ __forceinline__ void dw_wait_vm_barrier() {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+struct Dw3LdsGeom {
+  int cols, rpp, TW, RB, nstrip, nrowblk, ncv;  // chunk width (channel vectors), pixel lanes, strip width / height, grid factors
+};
+
+// KX / KD: DMA instructions per 256 lanes per input / dy row segment (host: ceil((TW + 2) * cols / 256), ceil(TW * cols / 256)).
+// Block = kDwLdsCW compute waves + 1 PRODUCER wave. The producer issues every LDS-DMA of the block (4 * KX per input row) and
+// is the only wave that waits on them: its VM queue holds nothing but those DMAs, so the counted s_waitcnt is exact. (With the
+// compute waves issuing the DMAs themselves, their output stores sit in the same in-order vmcnt queue behind the look-ahead row:
+// the wait for "row j+2 landed" then also waits for the look-ahead row j+3 — measured 199 us fprop / 503 us wgrad against 250 / 269
+// for the register-window kernel on the 304-channel decoder tensor.)
+constexpr int kDwLdsCW = 3;  // compute waves per block (+ 1 producer wave): 2 blocks per CU at ~200 VGPRs need <= 8 waves per CU
+template <int MODE, int PXT, int KX, int KD>
+__global__ __launch_bounds__((kDwLdsCW + 1) * 64) void dw3x3_lds_kernel(const Dw3Params p, const Dw3LdsGeom g) {
+  constexpr int NR = MODE == 1 ? 5 : 6;  // input-row ring: rows j .. j+2 in use, j+3 (and j+4: fprop / dgrad) in flight
+  constexpr int ND = MODE == 1 ? 3 : 1;  // dy-row ring (weight gradient): row j in use, j+1 and j+2 in flight (a ring of 2 exposed the
+                                         // DMA latency of the dy row every iteration: 421 vs 269 us for the register-window kernel)
+  extern __shared__ __attribute__((aligned(1024))) unsigned char dw_smem[];
+  const int cols = g.cols, TW = g.TW, TWI = g.TW + 2;
+  constexpr int xrow_bytes = KX * 4096, drow_bytes = KD * 4096;  // ring slots are whole DMA groups (256 lanes x 16 B)
+  unsigned char* const sX = dw_smem;
+  unsigned char* const sD = dw_smem + NR * xrow_bytes;
+  const int CV = p.C >> 3;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  int b = blockIdx.x;
+  const int cvc = b % g.ncv;
+  b /= g.ncv;
+  const int strip = b % g.nstrip;
+  b /= g.nstrip;
+  const int rowblk = b % g.nrowblk;
+  const int n = b / g.nrowblk;
+  const int q0 = strip * TW;
+  const int r0 = rowblk * g.RB;
+  const int r1 = min(r0 + g.RB, p.OH);
+  const int nrows = r1 - r0;
+
+  constexpr int NCT = kDwLdsCW * 64;  // compute threads
+  if (wave == kDwLdsCW) {
+    // ================================ producer ================================
+    const h16_t* const zero = reinterpret_cast<const h16_t*>(g_dw_zero) + (lane & 3) * 8;
+    // element e = k * 64 + lane of a row segment is pixel e / cols, channel vector e % cols; its offset inside an image row
+    // (pixels * pitch + channel) or -1 = zero page (halo outside the image, lanes past the segment, channels past C)
+    int xoff[4 * KX], doff[KD > 0 ? 4 * KD : 1];
+#pragma unroll
+    for (int k = 0; k < 4 * KX; ++k) {
+      const int e = k * 64 + lane;
+      const int px = e / cols, v = e - px * cols;
+      const int iw = q0 - p.pw + px;
+      const bool ok = px < TWI && (unsigned)iw < (unsigned)p.IW && cvc * cols + v < CV;
+      xoff[k] = ok ? iw * p.in_ld + (cvc * cols + v) * 8 : -1;
+    }
+    if (MODE == 1) {
+#pragma unroll
+      for (int k = 0; k < 4 * KD; ++k) {
+        const int e = k * 64 + lane;
+        const int px = e / cols, v = e - px * cols;
+        const int ow = q0 + px;
+        const bool ok = px < TW && ow < p.OW && cvc * cols + v < CV;
+        doff[k] = ok ? ow * p.dy_ld + (cvc * cols + v) * 8 : -1;
+      }
+    }
+    const int i_first = r0 - p.ph;  // first input row of the strip (may be < 0: zero rows)
+    auto issue_x = [&](int j) {     // j-th input row of the strip -> ring slot j % NR
+      const int ih = i_first + j;
+      const bool rok = (unsigned)ih < (unsigned)p.IH;
+      const h16_t* const row = p.in + ((int64_t)(n * p.IH + (rok ? ih : 0)) * p.IW) * p.in_ld;
+      unsigned char* const dst = sX + (j % NR) * xrow_bytes;
+#pragma unroll
+      for (int k = 0; k < 4 * KX; ++k) {
+        const h16_t* src = (rok && xoff[k] >= 0) ? row + xoff[k] : zero;
+        CVHIP_DW_GLDS16(src, dst + k * 1024);
+      }
+    };
+    auto issue_d = [&](int j) {  // dy row r0 + j -> ring slot j % ND
+      const int oh = r0 + j;
+      const bool rok = oh < r1;
+      const h16_t* const row = p.dy + ((int64_t)(n * p.OH + (rok ? oh : 0)) * p.OW) * p.dy_ld;
+      unsigned char* const dst = sD + (j % ND) * drow_bytes;
+#pragma unroll
+      for (int k = 0; k < 4 * KD; ++k) {
+        const h16_t* src = (rok && doff[k] >= 0) ? row + doff[k] : zero;
+        CVHIP_DW_GLDS16(src, dst + k * 1024);
+      }
+    };
+    // prologue. Per iteration the dy row is issued BEFORE the input row; the prologue interleaves the same way, so that at every
+    // barrier the groups younger than what the compute waves are about to read are exactly the look-ahead of the last NR - 4
+    // iterations: (dy row, input row) pairs for the weight gradient (NR 5: one pair), input rows otherwise (NR 6: two rows)
+    if (MODE == 1) {
+      issue_x(0);
+      issue_x(1);
+      issue_d(0);
+      issue_x(2);
+      issue_d(1);
+      issue_x(3);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NR - 1; ++j) issue_x(j);
+    }
+    for (int j = 0; j < nrows; ++j) {
+      dw_wait_vm_barrier<(NR - 4) * (4 * KX + (MODE == 1 ? 4 * KD : 0))>();  // input rows j .. j+2 and dy row j have landed
+      if (MODE == 1) issue_d(j + 2);  // into the slot of dy row j-1
+      issue_x(j + NR - 1);            // into the slot of row j-1: every compute wave has passed the barrier, i.e. finished output row j-1
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // look-ahead rows past the strip must not land after the block retires
+    if (MODE == 1) {
+      for (int a = 0; a < 18; ++a) __syncthreads();  // the 18 barriers of the compute waves' reduction below
+    }
+    return;
+  }
+
+  // ================================ compute waves ================================
+  const int tx = t % cols, ty = t / cols;
+  const int cv = cvc * cols + tx;
+  const bool active = ty < g.rpp && cv < CV;
+  const int c = (cv < CV ? cv : CV - 1) * 8;
+  float w[3][3][8];
+  float acc9[MODE == 1 ? 9 : 1][8];
+  float bias[8];
+  if (MODE == 0) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s2 = 0; s2 < 3; ++s2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[r][s2][j] = p.w[(int64_t)(c + j) * 9 + (p.flip ? (2 - r) * 3 + (2 - s2) : r * 3 + s2)];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bias[j] = p.bias ? p.bias[c + j] : 0.f;
+  } else {
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc9[a][j] = 0.f;
+  }
+  const int px0 = ty * PXT;  // first output pixel of this thread inside the strip
+  for (int j = 0; j < nrows; ++j) {
+    asm volatile("s_barrier" ::: "memory");  // the producer arrives here after rows j .. j+2 (and dy row j) have landed
+    if (active) {
+      const int oh = r0 + j;
+      f32x8 win[3][PXT + 2];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const unsigned char* const row = sX + ((j + r) % NR) * xrow_bytes;
+#pragma unroll
+        for (int s2 = 0; s2 < PXT + 2; ++s2) win[r][s2] = unpack8(*reinterpret_cast<const uint4*>(row + ((px0 + s2) * cols + tx) * 16));
+      }
+#pragma unroll
+      for (int q = 0; q < PXT; ++q) {
+        const int ow = q0 + px0 + q;
+        if (MODE == 0) {
+          f32x8 o;
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) {
+            float a = bias[jj];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+              for (int s2 = 0; s2 < 3; ++s2) a += win[r][q + s2].v[jj] * w[r][s2][jj];
+            o.v[jj] = a;
+          }
+          if (ow < p.OW) *reinterpret_cast<uint4*>(p.out + ((int64_t)(n * p.OH + oh) * p.OW + ow) * p.out_ld + c) = pack8(o);
+        } else {
+          // dy of pixels past the image / strip edge was staged as zeros
+          const f32x8 gq = unpack8(*reinterpret_cast<const uint4*>(sD + (j % ND) * drow_bytes + ((px0 + q) * cols + tx) * 16));
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s2 = 0; s2 < 3; ++s2)
+#pragma unroll
+              for (int jj = 0; jj < 8; ++jj) acc9[r * 3 + s2][jj] += gq.v[jj] * win[r][q + s2].v[jj];
+        }
+      }
+    }
+  }
+  if (MODE == 1) {
+    __syncthreads();  // (the producer has drained its queue before it joins: the rings are dead)
+    float* const red = reinterpret_cast<float*>(dw_smem);  // NCT x 8 floats
+#pragma unroll
+    for (int a = 0; a < 9; ++a) {
+      if (a > 0) __syncthreads();
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) red[t * 8 + jj] = active ? acc9[a][jj] : 0.f;
+      __syncthreads();
+      for (int idx = t; idx < cols * 8; idx += NCT) {
+        const int x = idx >> 3, jj = idx & 7;
+        float sum = 0.f;
+        for (int yy = 0; yy < g.rpp; ++yy) sum += red[(yy * cols + x) * 8 + jj];
+        const int cc = (cvc * cols + x) * 8 + jj;
+        if (cvc * cols + x < CV && sum != 0.f) unsafeAtomicAdd(p.dw + (int64_t)cc * 9 + a, sum);
+      }
+    }
+  }
+}
+
+// strip geometry + launch; false when the LDS form does not apply (then the register-window kernel runs)
+template <int MODE>
+static bool dw3_lds_launch(const Dw3Params& q, hipStream_t s, int* status) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("CVHIP_DW3_LDS");
+    on = e ? atoi(e) : 1;
+  }
+  if (!on) return false;
+  constexpr int PXT = MODE == 1 ? 2 : 3;
+  const int CV = q.C >> 3;
+  Dw3LdsGeom g;
+  g.cols = CV < 64 ? CV : 64;
+  g.ncv = (CV + g.cols - 1) / g.cols;
+  g.rpp = (kDwLdsCW * 64) / g.cols;
+  g.TW = g.rpp * PXT;
+  if (q.OW < g.TW || q.OH < 8) return false;  // small maps: the strip would be mostly halo
+  g.nstrip = (q.OW + g.TW - 1) / g.TW;
+  const int kx = ((g.TW + 2) * g.cols + 255) / 256, kd = (g.TW * g.cols + 255) / 256;
+  // strip height: >= ~1024 blocks for the chip, >= 16 rows to amortise the 2 halo rows and the prologue
+  // (weight gradient: every block ends with 9 * C atomics onto the SAME 9 * C addresses — 1664 blocks of 32 rows spent more time
+  // serialised on them than walking: 407 us; whole-height strips, ~400 blocks, as long as they still cover the CUs)
+  const int min_blocks = MODE == 1 ? 384 : 1024;
+  int rb = q.OH;
+  while (rb > 16 && (int64_t)q.N * g.nstrip * g.ncv * ((q.OH + rb - 1) / rb) < min_blocks) rb = (rb + 1) / 2;
+  g.RB = rb;
+  g.nrowblk = (q.OH + rb - 1) / rb;
+  const int64_t grid = (int64_t)q.N * g.nrowblk * g.nstrip * g.ncv;
+  if (grid > 0x7fffffff) return false;
+  const int lds = (MODE == 1 ? 5 : 6) * kx * 4096 + (MODE == 1 ? 3 * kd * 4096 : 0);
+  if (lds < 256 * 8 * 4 || lds > 96 * 1024) return false;
+#define CVHIP_DW3L(KXV, KDV)                                                                                                 \
+  {                                                                                                                          \
+    auto kern = dw3x3_lds_kernel<MODE, PXT, KXV, (MODE == 1 ? KDV : 0)>;                                                    \
+    static bool attr_done[64] = {};                                                                                          \
+    int devid = 0;                                                                                                           \
+    (void)hipGetDevice(&devid);                                                                                              \
+    if (!attr_done[devid & 63]) {                                                                                            \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) { \
+        *status = CVHIP_ERR_LAUNCH;                                                                                          \
+        return true;                                                                                                         \
+      }                                                                                                                      \
+      attr_done[devid & 63] = true;                                                                                          \
+    }                                                                                                                        \
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((kDwLdsCW + 1) * 64), lds, s, q, g);                                                 \
+    *status = check_launch("dw3x3_lds_kernel");                                                                              \
+    return true;                                                                                                             \
+  }
+  if (kx == 3 && kd == 2) CVHIP_DW3L(3, 2)
+  if (kx == 3 && kd == 3) CVHIP_DW3L(3, 3)
+  if (kx == 4 && kd == 3) CVHIP_DW3L(4, 3)
+  if (kx == 4 && kd == 4) CVHIP_DW3L(4, 4)
+  if (kx == 2 && kd == 2) CVHIP_DW3L(2, 2)
+  if (kx == 2 && kd == 1) CVHIP_DW3L(2, 1)
+#undef CVHIP_DW3L
+  return false;
+}
+
 static int fill(const cvhip_conv_desc* d, DwParams* p) {
   if (!d) return CVHIP_ERR_INVALID;
   if (d->groups != d->C || d->K != d->C) return CVHIP_ERR_UNSUPPORTED;
@@ -439,7 +717,8 @@ int cvhip_dwconv2d_fprop(const cvhip_conv_desc* d, const void* x, const float* w
     q.in = p.x; q.w = w; q.bias = bias; q.out = p.y;
     q.N = p.N; q.C = p.C; q.IH = p.H; q.IW = p.W; q.OH = p.P; q.OW = p.Q; q.ph = p.ph; q.pw = p.pw;
     q.in_ld = p.x_ld; q.out_ld = p.y_ld; q.flip = 0;
-    int grid;
+    int grid, lst = CVHIP_OK;
+    if (dw3_lds_launch<0>(q, (hipStream_t)stream, &lst)) return lst;
     dw3_launch_geom(q, &grid);
     hipLaunchKernelGGL(dw3x3_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, q);
     return check_launch("dw3x3_kernel<0>");
@@ -465,7 +744,8 @@ int cvhip_dwconv2d_dgrad(const cvhip_conv_desc* d, const void* dy, const float* 
     q.in = p.x; q.w = w; q.bias = nullptr; q.out = p.y;
     q.N = p.N; q.C = p.C; q.IH = p.P; q.IW = p.Q; q.OH = p.H; q.OW = p.W; q.ph = 2 - p.ph; q.pw = 2 - p.pw;
     q.in_ld = p.x_ld; q.out_ld = p.y_ld; q.flip = 1;
-    int grid;
+    int grid, lst = CVHIP_OK;
+    if (dw3_lds_launch<0>(q, (hipStream_t)stream, &lst)) return lst;
     dw3_launch_geom(q, &grid);
     hipLaunchKernelGGL(dw3x3_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, q);
     return check_launch("dw3x3_kernel<0>(dgrad)");
@@ -496,7 +776,8 @@ int cvhip_dwconv2d_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy
     q.in = p.x; q.dy = p.dy; q.dw = dw;
     q.N = p.N; q.C = p.C; q.IH = p.H; q.IW = p.W; q.OH = p.P; q.OW = p.Q; q.ph = p.ph; q.pw = p.pw;
     q.in_ld = p.x_ld; q.dy_ld = p.y_ld;
-    int grid;
+    int grid, lst = CVHIP_OK;
+    if (dw3_lds_launch<1>(q, s, &lst)) return lst;
     dw3_launch_geom(q, &grid, true);
     hipLaunchKernelGGL(dw3x3_kernel<1>, dim3(grid), dim3(256), 0, s, q);
     return check_launch("dw3x3_kernel<1>");
