@@ -101,33 +101,41 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const RedParams p) {
       };
       int64_t r = r_begin + ty;
       if (vec) {
-        // 4 rows per trip: 4-8 independent 16-B loads in flight per lane before any arithmetic (HBM latency hiding).
+        // 4 rows per trip: 4-8 independent 16-B loads in flight per lane before any arithmetic (HBM latency hiding). The LAST trip
+        // of a block is the same code with its missing rows masked (clamped address, zero contribution): a remainder walked one
+        // row per iteration cost up to 3 extra dependent memory round trips per block — on the 26 MB layers (100 rows per block,
+        // one 64-row trip + 36 rows of remainder) more than the trip itself (2.4 TB/s against 3.8 for the aligned shapes).
         // (Software-pipelining the trips — next trip's loads issued before this trip's arithmetic — was measured in round 3: +32
         // VGPRs, no gain on the backward passes: they are co-limited by the quarter-rate v_exp_f32 / v_rcp_f32 of the SiLU derivative.)
         const int64_t stp = rows_per_pass;
-        for (; r + 3 * stp < r_end; r += 4 * stp) {
+        for (; r < r_end; r += 4 * stp) {
           uint4 ua[4], uy[4];
+          bool ok[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            ua[q] = *reinterpret_cast<const uint4*>(p.a + (r + q * stp) * p.ld_a + cv * 8);
-            if (MODE == 1) uy[q] = *reinterpret_cast<const uint4*>(p.y + (r + q * stp) * p.ld_y + cv * 8);
+            const int64_t rq = r + q * stp;
+            ok[q] = rq < r_end;
+            const int64_t rc = ok[q] ? rq : r;
+            ua[q] = *reinterpret_cast<const uint4*>(p.a + rc * p.ld_a + cv * 8);
+            if (MODE == 1) uy[q] = *reinterpret_cast<const uint4*>(p.y + rc * p.ld_y + cv * 8);
           }
+          // every load of the trip is issued before any arithmetic: without the fence hipcc's scheduler sinks the loads of rows
+          // 1..3 below the arithmetic of row 0 (fewer live registers) and waits vmcnt(0) after each — one row in flight per lane
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) accum(unpack8(ua[q]), MODE == 1 ? unpack8(uy[q]) : f32x8{});
+          for (int q = 0; q < 4; ++q) {
+            if (!ok[q]) ua[q] = make_uint4(0u, 0u, 0u, 0u);  // x = 0 / dz = 0: no contribution to either sum
+            accum(unpack8(ua[q]), MODE == 1 ? unpack8(uy[q]) : f32x8{});
+          }
         }
       }
-      for (; r < r_end; r += rows_per_pass) {
+      for (; r < r_end; r += rows_per_pass) {  // (scalar path only: the vector loop above leaves nothing)
         f32x8 a, y;
-        if (vec) {
-          a = unpack8(*reinterpret_cast<const uint4*>(p.a + r * p.ld_a + cv * 8));
-          if (MODE == 1) y = unpack8(*reinterpret_cast<const uint4*>(p.y + r * p.ld_y + cv * 8));
-        } else {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int c = cv * 8 + j;
-            a.v[j] = c < p.C ? (float)p.a[r * p.ld_a + c] : 0.f;
-            if (MODE == 1) y.v[j] = c < p.C ? (float)p.y[r * p.ld_y + c] : 0.f;
-          }
+        for (int j = 0; j < 8; ++j) {
+          const int c = cv * 8 + j;
+          a.v[j] = c < p.C ? (float)p.a[r * p.ld_a + c] : 0.f;
+          if (MODE == 1) y.v[j] = c < p.C ? (float)p.y[r * p.ld_y + c] : 0.f;
         }
         accum(a, y);
       }
@@ -583,47 +591,42 @@ __global__ __launch_bounds__(256) void ew_kernel(const EwParams p) {
       constexpr bool has_res = RES != 0;
       int64_t r = r_begin + ty;
       if (vec) {
-        // 4 rows per trip: all loads of the trip are issued before the arithmetic (bytes in flight per lane x4)
-        // 4 rows per trip: all loads of the trip are issued before the arithmetic (bytes in flight per lane x4)
+        // 4 rows per trip: all loads of the trip are issued before the arithmetic (bytes in flight per lane x4); the block's last
+        // trip runs the same code with its missing rows masked (clamped loads, no store) instead of a row-at-a-time remainder
         const int64_t stp = rows_per_pass;
-        for (; r + 3 * stp < r_end; r += 4 * stp) {
+        for (; r < r_end; r += 4 * stp) {
           uint4 ua[4], uy[4], ur[4];
+          bool ok[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            ua[q] = *reinterpret_cast<const uint4*>(p.a + (r + q * stp) * p.ld_a + c);
-            if (MODE == 1) uy[q] = *reinterpret_cast<const uint4*>(p.y + (r + q * stp) * p.ld_y + c);
-            if (has_res) ur[q] = *reinterpret_cast<const uint4*>(p.res + (r + q * stp) * p.ld_res + c);
+            const int64_t rq = r + q * stp;
+            ok[q] = rq < r_end;
+            const int64_t rc = ok[q] ? rq : r;
+            ua[q] = *reinterpret_cast<const uint4*>(p.a + rc * p.ld_a + c);
+            if (MODE == 1) uy[q] = *reinterpret_cast<const uint4*>(p.y + rc * p.ld_y + c);
+            if (has_res) ur[q] = *reinterpret_cast<const uint4*>(p.res + rc * p.ld_res + c);
           }
+          __builtin_amdgcn_sched_barrier(0);  // loads of all 4 rows first (see colreduce_kernel)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x8 o = math(unpack8(ua[q]), MODE == 1 ? unpack8(uy[q]) : f32x8{}, has_res ? unpack8(ur[q]) : f32x8{});
-            *reinterpret_cast<uint4*>(p.out + (r + q * stp) * p.ld_out + c) = pack8(o);
+            if (ok[q]) *reinterpret_cast<uint4*>(p.out + (r + q * stp) * p.ld_out + c) = pack8(o);
           }
         }
       }
-      for (; r < r_end; r += rows_per_pass) {
+      for (; r < r_end; r += rows_per_pass) {  // (scalar path only)
         f32x8 a, y, rs;
-        if (vec) {
-          a = unpack8(*reinterpret_cast<const uint4*>(p.a + r * p.ld_a + c));
-          if (MODE == 1) y = unpack8(*reinterpret_cast<const uint4*>(p.y + r * p.ld_y + c));
-          if (has_res) rs = unpack8(*reinterpret_cast<const uint4*>(p.res + r * p.ld_res + c));
-        } else {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const bool ok = c + j < p.C;
-            a.v[j] = ok ? (float)p.a[r * p.ld_a + c + j] : 0.f;
-            if (MODE == 1) y.v[j] = ok ? (float)p.y[r * p.ld_y + c + j] : 0.f;
-            if (has_res) rs.v[j] = ok ? (float)p.res[r * p.ld_res + c + j] : 0.f;
-          }
+        for (int j = 0; j < 8; ++j) {
+          const bool okc = c + j < p.C;
+          a.v[j] = okc ? (float)p.a[r * p.ld_a + c + j] : 0.f;
+          if (MODE == 1) y.v[j] = okc ? (float)p.y[r * p.ld_y + c + j] : 0.f;
+          if (has_res) rs.v[j] = okc ? (float)p.res[r * p.ld_res + c + j] : 0.f;
         }
         const f32x8 o = math(a, y, rs);
-        if (vec) {
-          *reinterpret_cast<uint4*>(p.out + r * p.ld_out + c) = pack8(o);
-        } else {
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (c + j < p.C) p.out[r * p.ld_out + c + j] = (h16_t)o.v[j];
-        }
+        for (int j = 0; j < 8; ++j)
+          if (c + j < p.C) p.out[r * p.ld_out + c + j] = (h16_t)o.v[j];
       }
     };
     if constexpr (MODE == 3) {
