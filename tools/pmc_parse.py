@@ -31,6 +31,19 @@ def main():
                   "fetch_size_raw_kb_per_launch": (F[k][1] / F[k][0]) if k in F and F[k][0] else None,
                   "write_size_raw_kb_per_launch": (W[k][1] / W[k][0]) if k in W and W[k][0] else None}
     json.dump(res, open(out, "w"), indent=1)
+    # HBM-side bytes per train step: (2 x FETCH_SIZE + WRITE_SIZE) KiB over the cvhip kernels, divided by the eager steps of the
+    # workload (tools/pmc_workload.py: PMC_STEPS, default 2; the calibration copies and one-off ATen kernels are excluded)
+    steps = int(os.environ.get("PMC_STEPS", "2"))
+    fam = collections.defaultdict(float)
+    for k, v in res.items():
+        if "cvhip::" not in k or "copy2d" in k:
+            continue
+        b = v["launches"] * (2.0 * (v["fetch_size_raw_kb_per_launch"] or 0.0) + (v["write_size_raw_kb_per_launch"] or 0.0)) * 1024.0 / steps
+        f = ("BN / activation passes" if ("ew_kernel" in k or "colreduce" in k) else "fused 1x1 backward" if "bwd1x1" in k else
+             "conv (igemm, 1x1 stream, wgrad, stem)" if any(t in k for t in ("igemm", "conv1x1_stream", "wgrad", "stem_")) else "rest")
+        fam[f] += b
+    print("HBM traffic per step (PMC, FETCH x2 + WRITE): %.1f GB  =  %s" % (
+        sum(fam.values()) / 1e9, ", ".join("%s %.1f" % (f, b / 1e9) for f, b in sorted(fam.items(), key=lambda kv: -kv[1]))))
     for k, v in sorted(res.items(), key=lambda kv: -(kv[1]["fetch_size_raw_kb_per_launch"] or 0) * kv[1]["launches"])[:25]:
         print("%-90s n=%5d fetch %10.1f KB  write %10.1f KB" % (k[:90], v["launches"], v["fetch_size_raw_kb_per_launch"] or -1, v["write_size_raw_kb_per_launch"] or -1))
 
