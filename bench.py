@@ -353,35 +353,48 @@ def pmc_traffic(kernel_label):
 
 
 def measured_peaks(dev):
-    """What THIS box attains: a plain device copy (cvhip_copy2d over 512 MiB: bytes read + written per second) and a bare MFMA loop
-    (cvhip_probe_mfma_peak: 8 independent v_mfma_f32_32x32x16_bf16 per round, operands in registers). The nominal peaks
-    (8 TB/s, 2.5 PFLOP/s dense bf16) stay the denominators of `frac`; these are printed beside them."""
+    """What THIS box attains, with the probes of csrc/probes.hip (tools/ceilings_probe.py prints the full tables, profiles/
+    r03_ceilings_probe.log): a device copy, a read-only HBM stream (8 KiB per wave in flight), and bare MFMA loops on zero operands
+    (the guide's 2.4-2.5 PFLOP/s) and on full-range data (DVFS lowers the clock). The nominal peaks (8 TB/s, 2.5 PFLOP/s dense bf16)
+    stay the denominators of `frac`; these are printed beside them."""
     from cvpytorch_amd import lib as L
     out = {}
+    st = torch.cuda.current_stream().cuda_stream
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def best(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        ms = 1e30
+        for _ in range(reps):
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = min(ms, e0.elapsed_time(e1))
+        return ms
+
     M, C = 1 << 18, 1024                       # 256 Ki rows x 1024 bf16 = 512 MiB
     a = torch.empty((M, C), dtype=torch.bfloat16, device=dev).normal_()
     b = torch.empty_like(a)
-    st = torch.cuda.current_stream().cuda_stream
-    for _ in range(2):
-        L.call("cvhip_copy2d", a.data_ptr(), C, b.data_ptr(), C, M, C, st)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    reps = 5
-    for _ in range(reps):
-        L.call("cvhip_copy2d", a.data_ptr(), C, b.data_ptr(), C, M, C, st)
-    e1.record()
-    torch.cuda.synchronize()
-    out["hbm_copy_gbs"] = round(reps * 2.0 * M * C * 2 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+    ms = best(lambda: L.call("cvhip_copy2d", a.data_ptr(), C, b.data_ptr(), C, M, C, st))
+    out["hbm_copy_gbs"] = round(2.0 * M * C * 2 / (ms * 1e-3) / 1e9, 1)
     del a, b
-    blocks, iters = 256 * 4, 4096
-    scratch = torch.zeros(blocks, dtype=torch.float32, device=dev)
-    L.call("cvhip_probe_mfma_peak", 64, blocks, scratch.data_ptr(), st)
-    e0.record()
-    L.call("cvhip_probe_mfma_peak", iters, blocks, scratch.data_ptr(), st)
-    e1.record()
-    torch.cuda.synchronize()
-    out["mfma_bf16_tflops"] = round(blocks * 4.0 * iters * 8 * 2 * 32 * 32 * 16 / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
-    out["how"] = "device copy of 512 MiB bf16 (read+write bytes / time); 1024 blocks x 4 waves x 4096 rounds of 8 independent v_mfma_f32_32x32x16_bf16"
+    scratch = torch.zeros(8192, dtype=torch.float32, device=dev)
+    big = torch.empty((1 << 32,), dtype=torch.uint8, device=dev)   # 4 GiB: 512 blocks x 8 MiB, streamed once
+    big.random_(0, 255)
+    threads, blocks, depth = 256, 512, 8
+    iters = 2048 // (threads // 64) * 4 // depth * 2
+    ms = best(lambda: L.call("cvhip_probe_load_path", 1, depth, big.data_ptr(), 1 << 23, 1 << 23, iters, blocks, threads, scratch.data_ptr(), st))
+    out["hbm_read_stream_gbs"] = round(blocks * (threads // 64) * iters * depth * 1024.0 / (ms * 1e-3) / 1e9, 1)
+    del big
+    for data, key in ((0, "mfma_bf16_tflops_zero_operands"), (2, "mfma_bf16_tflops_full_range_operands")):
+        blocks, threads, iters = 1024, 256, 4000
+        ms = best(lambda: L.call("cvhip_probe_mfma_peak2", 0, data, iters, blocks, threads, scratch.data_ptr(), st))
+        out[key] = round(blocks * (threads // 64) * iters * 8 * 32768.0 / (ms * 1e-3) / 1e12, 1)
+    out["how"] = ("cvhip_copy2d of 512 MiB bf16 (read + write bytes / time); cvhip_probe_load_path: 512 blocks x 4 waves streaming 8 MiB each, "
+                  "8 x global_load_dwordx4 per lane in flight; cvhip_probe_mfma_peak2: 1024 blocks x 4 waves x 4000 rounds of 8 independent "
+                  "v_mfma_f32_32x32x16_bf16 (accumulator chains), operands all-zero / full-range; best of 3")
     return out
 
 

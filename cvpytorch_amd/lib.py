@@ -248,8 +248,14 @@ def load():
 def check(status, what):
     if status != OK:
         lib = load()
+        # the library keeps one error string per build of the sources: the 16-bit-typed entry points of the active precision and the
+        # single-precision sources (communicator, post-processing) report through different copies — show whichever is set
+        errs = [(getattr(lib, n)() or b"").decode() for n in ("cvhip_last_error", "cvhip_last_error_f16") if hasattr(lib, n)]
+        if PRECISION == "fp16":
+            errs.reverse()
+        last = "; ".join(dict.fromkeys(e for e in errs if e))
         msg = {ERR_INVALID: "invalid argument", ERR_UNSUPPORTED: "unsupported shape/feature",
-               ERR_LAUNCH: "HIP launch error: " + (fn("cvhip_last_error")() or b"").decode()}.get(status, "status %d" % status)
+               ERR_LAUNCH: "HIP launch error: " + last}.get(status, "status %d" % status)
         raise CvhipError("%s failed: %s" % (what, msg))
 
 

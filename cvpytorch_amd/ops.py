@@ -1457,9 +1457,12 @@ class Fanout(torch.autograd.Function):
         return acc, None
 
 
+_FANOUT = __import__("os").environ.get("CVHIP_FANOUT", "1") != "0"   # 0: leave the gradient sums to autograd (A/B switch)
+
+
 def fanout(x, n=2):
     """n aliases of x for n consumers (training only; a plain tuple of x otherwise)"""
-    if n < 2 or not (torch.is_grad_enabled() and x.requires_grad) or nhwc_ld(x) is None:
+    if n < 2 or not _FANOUT or not (torch.is_grad_enabled() and x.requires_grad) or nhwc_ld(x) is None:
         return (x,) * n
     return Fanout.apply(x, n)
 

@@ -64,12 +64,13 @@ class DownA(nn.Module):
     def _branches(self, x, extra=0):
         """both branch results written straight into one concat buffer (plus `extra` trailing channels for DownB's y)"""
         c2 = self.branch1[1].out_channels
+        x, xb = ops.fanout(x, 2)   # the pool branch and the conv branch read x: explicit fan-out (ops.Fanout sums the two gradients)
         a = self.branch1[0](x)
         if not (x.is_cuda and c2 % 8 == 0 and extra % 8 == 0):
-            return None, self.branch1[1](a), self.branch2(x)
+            return None, self.branch1[1](a), self.branch2(xb)
         buf = ops.empty_nhwc(a.shape[0], 2 * c2 + extra, a.shape[2], a.shape[3], x.device)
         b1 = self.branch1[1](a, out=buf[:, :c2])
-        b2 = self.branch2[1](self.branch2[0](x), out=buf[:, c2:2 * c2])
+        b2 = self.branch2[1](self.branch2[0](xb), out=buf[:, c2:2 * c2])
         return buf, b1, b2
 
     def forward(self, x):
@@ -100,12 +101,13 @@ class EELAN(nn.Module):
         c2 = self.conv1.out_channels
         buf = ops.empty_nhwc(x.shape[0], 4 * c2, x.shape[2], x.shape[3], x.device) if (x.is_cuda and c2 % 8 == 0) else None
         x1, x2 = _siblings(self.conv1, self.conv2, x, self, out=None if buf is None else buf[:, :2 * c2])
+        x2, x2n = ops.fanout(x2, 2)   # x2 and x3 feed the concat AND the next pair of convs
         if buf is None:
-            x3 = self.conv3(x2)
-            x4 = self.conv4(x3)
+            x3, x3n = ops.fanout(self.conv3(x2n), 2)
+            x4 = self.conv4(x3n)
         else:
-            x3 = self.conv3[1](self.conv3[0](x2), out=buf[:, 2 * c2:3 * c2])
-            x4 = self.conv4[1](self.conv4[0](x3), out=buf[:, 3 * c2:])
+            x3, x3n = ops.fanout(self.conv3[1](self.conv3[0](x2n), out=buf[:, 2 * c2:3 * c2]), 2)
+            x4 = self.conv4[1](self.conv4[0](x3n), out=buf[:, 3 * c2:])
         return self.conv5(ops.cat([x1, x2, x3, x4]))
 
 
@@ -141,16 +143,18 @@ class FeatureFusion(nn.Module):
             buf = ops.empty_nhwc(x.shape[0], 2 * c2 + 4 * mid, x.shape[2], x.shape[3], x.device)
             o = 2 * c2
             x1, x2 = _siblings(self.conv1, self.conv2, x, self, out=buf[:, :o])
-            x3 = self.conv3(x2, out=buf[:, o:o + mid])
-            x4 = self.conv4(x3, out=buf[:, o + mid:o + 2 * mid])
-            x5 = self.conv4(x4, out=buf[:, o + 2 * mid:o + 3 * mid])
-            x6 = self.conv4(x5, out=buf[:, o + 3 * mid:])
+            x2, x2n = ops.fanout(x2, 2)   # every tensor of the chain feeds the concat AND the next conv
+            x3, x3n = ops.fanout(self.conv3(x2n, out=buf[:, o:o + mid]), 2)
+            x4, x4n = ops.fanout(self.conv4(x3n, out=buf[:, o + mid:o + 2 * mid]), 2)
+            x5, x5n = ops.fanout(self.conv4(x4n, out=buf[:, o + 2 * mid:o + 3 * mid]), 2)
+            x6 = self.conv4(x5n, out=buf[:, o + 3 * mid:])
         else:
             x1, x2 = _siblings(self.conv1, self.conv2, x, self)
-            x3 = self.conv3(x2)
-            x4 = self.conv4(x3)
-            x5 = self.conv4(x4)
-            x6 = self.conv4(x5)
+            x2, x2n = ops.fanout(x2, 2)
+            x3, x3n = ops.fanout(self.conv3(x2n), 2)
+            x4, x4n = ops.fanout(self.conv4(x3n), 2)
+            x5, x5n = ops.fanout(self.conv4(x4n), 2)
+            x6 = self.conv4(x5n)
         return self.conv7(ops.cat([x1, x2, x3, x4, x5, x6]))
 
 
@@ -176,13 +180,13 @@ class SPPCSPC(nn.Module):
         a, b = _siblings(self.cv1, self.cv2, x, self)
         if inplace:
             pool_buf = ops.empty_nhwc(x.shape[0], 4 * c_, x.shape[2], x.shape[3], x.device)
-            x1 = self.cv4(self.cv3(a), out=pool_buf[:, :c_])
-            pooled = ops.cat([x1] + [m(x1) for m in self.m], into=pool_buf)      # the pools are copied, x1 is in place
+            xs = ops.fanout(self.cv4(self.cv3(a), out=pool_buf[:, :c_]), 1 + len(self.m))   # the concat and the three pools read x1
+            pooled = ops.cat([xs[0]] + [m(xi) for m, xi in zip(self.m, xs[1:])], into=pool_buf)      # the pools are copied, x1 is in place
             out_buf = ops.empty_nhwc(x.shape[0], 2 * c_, x.shape[2], x.shape[3], x.device)
             y1 = self.cv6(self.cv5(pooled), out=out_buf[:, :c_])
             return self.cv7(ops.cat([y1, b], into=out_buf))
-        x1 = self.cv4(self.cv3(a))
-        y1 = self.cv6(self.cv5(ops.cat([x1] + [m(x1) for m in self.m])))
+        xs = ops.fanout(self.cv4(self.cv3(a)), 1 + len(self.m))
+        y1 = self.cv6(self.cv5(ops.cat([xs[0]] + [m(xi) for m, xi in zip(self.m, xs[1:])])))
         return self.cv7(ops.cat([y1, b]))
 
 
@@ -238,12 +242,12 @@ class YOLOv7Neck(nn.Module):
 
     def forward(self, x):
         x3, x4, x5 = x
-        x5 = self.spp(x5)
-        x4_up = self.featurefusion1_1(self.up1_1(x5, x4))
-        x3_up = self.featurefusion1_2(self.up1_2(x4_up, x3))
-        x4_down = self.featurefusion2_1(self.down2_1(x3_up, x4_up))
-        x5_down = self.featurefusion2_2(self.down2_2(x4_down, x5))
-        return [x3_up, x4_down, x5_down]
+        x5, x5b = ops.fanout(self.spp(x5), 2)                                        # -> up1_1 and down2_2
+        x4_up, x4_upb = ops.fanout(self.featurefusion1_1(self.up1_1(x5, x4)), 2)     # -> up1_2 and down2_1
+        x3_up, x3_out = ops.fanout(self.featurefusion1_2(self.up1_2(x4_up, x3)), 2)  # -> down2_1 and the head
+        x4_down, x4_out = ops.fanout(self.featurefusion2_1(self.down2_1(x3_up, x4_upb)), 2)   # -> down2_2 and the head
+        x5_down = self.featurefusion2_2(self.down2_2(x4_down, x5b))
+        return [x3_out, x4_out, x5_down]
 
 
 class YOLOv7Head(nn.Module):
@@ -305,9 +309,9 @@ class YOLOv7Backbone(nn.Module):
 
     def forward(self, x):
         x = self.stage1(self.stem(x))
-        p3 = self.stage2(x)
-        p4 = self.stage3(p3)
-        p5 = self.stage4(p4)
+        p3, p3n = ops.fanout(self.stage2(x), 2)    # each stage output feeds the next stage and the neck
+        p4, p4n = ops.fanout(self.stage3(p3n), 2)
+        p5 = self.stage4(p4n)
         return [p3, p4, p5]
 
 

@@ -63,7 +63,11 @@ class YOLOXCSPDarknet(nn.Module):
         for i in range(1, 5):
             x = getattr(self, "stage%d" % i)(x)
             if i in self.out_stages:
-                out.append(x)
+                if i < 4:
+                    x, keep = ops.fanout(x, 2)   # feeds the next stage AND the neck (ops.Fanout sums the two gradients on the engine)
+                    out.append(keep)
+                else:
+                    out.append(x)
         return out if len(self.out_stages) > 1 else out[0]
 
 
@@ -109,7 +113,11 @@ class CSPDarknet(nn.Module):
         for i in range(1, 5):
             x = getattr(self, "stage%d" % i)(x)
             if i in self.out_stages:
-                output.append(x)
+                if i < 4:
+                    x, keep = ops.fanout(x, 2)
+                    output.append(keep)
+                else:
+                    output.append(x)
         return output if len(self.out_stages) > 1 else output[0]
 
 
@@ -137,14 +145,18 @@ class YOLOXNeck(nn.Module):
         n = len(self.in_channels)
         inner = [x[-1]]
         for idx in range(n - 1, 0, -1):
-            hi = self.reduce_layers[n - 1 - idx](inner[0])
-            inner[0] = hi
+            hi, hi_keep = ops.fanout(self.reduce_layers[n - 1 - idx](inner[0]), 2)   # -> the upsample here and a bottom-up concat below
+            inner[0] = hi_keep
             # nn.Upsample(2, 'nearest') + cat in one kernel (yolox_neck.py:90-92)
             inner.insert(0, self.top_down_blocks[n - 1 - idx](ops.upsample2x_cat(hi, x[idx - 1])))
         outs = [inner[0]]
+        heads = []
         for idx in range(n - 1):
-            outs.append(self.bottom_up_blocks[idx](ops.cat([self.downsamples[idx](outs[-1]), inner[idx + 1]])))
-        return [conv(o) for conv, o in zip(self.out_convs, outs)]
+            o, o_head = ops.fanout(outs[-1], 2)                                        # -> the downsample and its out_conv
+            heads.append(o_head)
+            outs.append(self.bottom_up_blocks[idx](ops.cat([self.downsamples[idx](o), inner[idx + 1]])))
+        heads.append(outs[-1])
+        return [conv(o) for conv, o in zip(self.out_convs, heads)]
 
 
 class YOLOXHead(nn.Module):
@@ -175,9 +187,10 @@ class YOLOXHead(nn.Module):
     def forward(self, x):
         outs = []
         for k, xx in enumerate(x):
-            cls_feat = self.cls_convs[k](xx)
-            reg_feat = self.reg_convs[k](xx)
-            outs.append(ops.cat([self.reg_preds[k](reg_feat), self.obj_preds[k](reg_feat), self.cls_preds[k](cls_feat)]))
+            xc, xr = ops.fanout(xx, 2)                         # class tower and box tower
+            cls_feat = self.cls_convs[k](xc)
+            rf, of = ops.fanout(self.reg_convs[k](xr), 2)      # box and objectness predictors
+            outs.append(ops.cat([self.reg_preds[k](rf), self.obj_preds[k](of), self.cls_preds[k](cls_feat)]))
         return outs
 
 

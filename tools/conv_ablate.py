@@ -7,7 +7,7 @@ from cvpytorch_amd import bricks
 dev = torch.device("cuda:0")
 NB = int(os.environ.get("ABL_BATCH", "256"))
 SHAPES = [(64, 128, 128, 3, 1, 40), (64, 64, 64, 3, 1, 80), (64, 256, 128, 1, 1, 40), (64, 128, 256, 3, 2, 80), (64, 256, 256, 3, 1, 20),
-          (64, 512, 256, 1, 1, 20), (64, 64, 128, 3, 2, 160), (64, 32, 32, 3, 1, 160), (64, 64, 32, 1, 1, 160)]
+          (64, 512, 256, 1, 1, 20), (64, 64, 128, 3, 2, 160), (64, 32, 32, 3, 1, 160), (64, 64, 32, 1, 1, 160), (64, 32, 64, 3, 2, 320)]
 if os.environ.get("ABL_ONLY"):
     SHAPES = [SHAPES[int(i)] for i in os.environ["ABL_ONLY"].split(",")]
 tag = "abl=%s v1=%s" % (os.environ.get("CVHIP_IGEMM_ABLATE", "0"), os.environ.get("CVHIP_IGEMM_V1", "0"))
