@@ -57,17 +57,23 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernA
 
   // pipeline position of the NEXT load
   int ld_tile = blockIdx.x, ld_kc = 0;
+  // Loads are UNCONDITIONAL: rows past M (and whole tiles past the block's last one) read row M-1, channel chunks past Cin read chunk
+  // 0 — real, finite data whose products are dropped (rows: never stored, never summed) or meet the zero-padded weight columns
+  // (chunks). With `ok ? load : 0` hipcc put every load in its own branch and, unable to count the younger prefetch loads, waited
+  // s_waitcnt vmcnt(0) before the first MFMA of every stage: the next stage's loads never overlapped this stage's arithmetic.
   auto load = [&](h16x8 (&dst)[MF][KS]) {
     const int row0 = ld_tile * RT + wave * (MF * 16) + r;
     const int kbase = ld_kc * KC + g * 8;
 #pragma unroll
     for (int b = 0; b < MF; ++b) {
-      const int m = row0 + b * 16;
-      const h16_t* src = p.x + (int64_t)m * p.x_ld + kbase;
+      int m = row0 + b * 16;
+      m = m < M ? m : M - 1;
+      const h16_t* src = p.x + (int64_t)m * p.x_ld;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const bool ok = m < M && kbase + ks * 32 < Cin;
-        dst[b][ks] = ok ? *reinterpret_cast<const h16x8*>(src + ks * 32) : zero8;
+        int kk = kbase + ks * 32;
+        kk = kk < Cin ? kk : 0;
+        dst[b][ks] = *reinterpret_cast<const h16x8*>(src + kk);
       }
     }
     if (++ld_kc == nkc) {
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernA
     }
   };
 
-  if (total > 0) load(buf0);
+  load(buf0);   // (a block without tiles loads clamped rows and stores nothing)
 
   // ---- weight tile -> LDS, rows permuted: LDS row a*16 + i holds channel n0 + (a>>1)*32 + (i>>2)*8 + (a&1)*4 + (i&3)
   {
@@ -160,6 +166,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernA
           v.v[4 + q] = acc[2 * j + 1][b][q];
         }
         if constexpr (STATS == 1) {
+          const float keep = m < M ? 1.f : 0.f;  // rows past M were computed from a clamped row: not part of the statistics
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v.v[q] *= keep;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             s1[2 * j][q] += v.v[q];
@@ -229,13 +238,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernA
     cp_tile += gridDim.x;
   };
 
+  // branch-free body: a stage past the end loads clamped rows and computes a tile whose rows are all >= M (nothing stored or summed)
   for (int it = 0; it < total; it += 2) {
-    if (it + 1 < total) load(buf1);
+    load(buf1);
     compute(buf0);
-    if (it + 1 < total) {
-      if (it + 2 < total) load(buf0);
-      compute(buf1);
-    }
+    load(buf0);
+    compute(buf1);
   }
 
   if constexpr (STATS) {
