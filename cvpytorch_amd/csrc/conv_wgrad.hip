@@ -615,7 +615,12 @@ static int launch_wg(WgradParams& p, hipStream_t stream) {
   // (the 32-wide output tile always gains: its blocks have the least MFMA work per atomic)
   int groups = force_groups ? force_groups : ((TN == 32 || (int64_t)p.M * tiles <= kWgTwoGroupWork) ? 2 : 1);
   const int rows_min = min_rows * groups;
-  int splits = cdiv(target, tiles);
+  // block target: every block ends by flushing its TN x 128 tile with fp32 atomics, so the atomic volume is blocks x 64 KB whatever the
+  // layer; for the 128-wide tile on short pixel ranges (1x1 layers of <= 40 k pixels: ResNet layer3 / layer4 at batch 16, the 20x20 maps
+  // of the detectors) 768 blocks flush more bytes than they read — 256 blocks are 15-19 % faster there (profiles/r03_wgrad_ablation.log)
+  int tgt = target;
+  if (!getenv("CVHIP_WGRAD_BLOCKS") && TN == 128 && p.TR == 1 && p.TS == 1 && p.M <= 40000) tgt = 256;
+  int splits = cdiv(tgt, tiles);
   const int max_splits = (p.M + rows_min - 1) / rows_min;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
