@@ -312,7 +312,10 @@ def test_conv_channel_slice_operands():
 # ------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("Cc,H,W,s,p,d", [(32, 12, 14, 1, 1, 1), (64, 10, 10, 1, 3, 3), (48, 11, 9, 2, 1, 1), (20, 8, 8, 1, 1, 1),
                                          # 3x3/s1/d1 register-window fast path: several row segments, ragged tails, pad 0 / 2, > 256 channels
-                                         (304, 21, 200, 1, 1, 1), (16, 9, 130, 1, 0, 1), (24, 9, 70, 1, 2, 1), (2304, 5, 7, 1, 1, 1)])
+                                         (304, 21, 200, 1, 1, 1), (16, 9, 130, 1, 0, 1), (24, 9, 70, 1, 2, 1), (2304, 5, 7, 1, 1, 1),
+                                         # LDS-ring kernel (dw3x3_lds_kernel): 32-vector chunks, two chunks with a ragged second one (65 vectors),
+                                         # pad 0 and pad 2, strips that do not divide the width, row blocks that do not divide the height
+                                         (256, 40, 64, 1, 1, 1), (520, 17, 40, 1, 1, 1), (304, 33, 50, 1, 0, 1), (128, 19, 120, 1, 2, 1)])
 def test_depthwise(Cc, H, W, s, p, d):
     torch.manual_seed(0)
     N = 2
