@@ -143,6 +143,8 @@ SIGNATURES = {
     "cvhip_resize_nearest_bwd": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "cvhip_resize_bilinear_fwd": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "cvhip_resize_bilinear_bwd": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "cvhip_resize_bilinear_bwd_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32, _i32]),
+    "cvhip_resize_bilinear_bwd_ws": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _i64, _p]),
     "cvhip_global_avgpool_fwd": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _p]),
     "cvhip_global_avgpool_bwd": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _p]),
     "cvhip_nchw_f32_to_nhwc_bf16": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p]),

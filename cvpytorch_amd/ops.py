@@ -1664,7 +1664,12 @@ class ResizeBilinear(torch.autograd.Function):
         dy, ld = as_nhwc(dy)
         xld = _round8(Cc)
         dx = empty_nhwc(N, Cc, Hi, Wi, dy.device, ld=xld)
-        L.call("cvhip_resize_bilinear_bwd", dy.data_ptr(), ld, dx.data_ptr(), xld, N, Cc, Hi, Wi, Ho, Wo, ac, _stream())
+        nb = int(L.fn("cvhip_resize_bilinear_bwd_workspace_bytes")(N, Cc, Hi, Wi, Ho, Wo))   # > 0: the separable form pays (ratio >= 4)
+        if nb > 0:
+            ws = torch.empty((nb,), dtype=torch.uint8, device=dy.device)
+            L.call("cvhip_resize_bilinear_bwd_ws", dy.data_ptr(), ld, dx.data_ptr(), xld, N, Cc, Hi, Wi, Ho, Wo, ac, ws.data_ptr(), nb, _stream())
+        else:
+            L.call("cvhip_resize_bilinear_bwd", dy.data_ptr(), ld, dx.data_ptr(), xld, N, Cc, Hi, Wi, Ho, Wo, ac, _stream())
         return dx, None, None, None
 
 

@@ -358,6 +358,14 @@ int cvhip_resize_bilinear_fwd(const void* x_bf16, int32_t ld_x, void* y_bf16, in
 int cvhip_resize_bilinear_bwd(const void* dy_bf16, int32_t ld_dy, void* dx_bf16, int32_t ld_dx,
                               int32_t N, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
                               int32_t align_corners, void* stream);
+/* The same backward in separable form for upsampling ratios >= 4 on both axes (encoder_decoder.py / the DeepLabv3+ head upsample
+ * x8): a vertical pass reads dy ONCE into an fp32 workspace [N][Hi][Wo][round8(C)], a horizontal pass reduces it — the gather form
+ * fetches every dy element four times. workspace_bytes returns 0 when the gather form is the better one; _ws then falls back to it
+ * (also when the workspace is NULL / too small), so callers may always use _ws. Deterministic (no atomics), fp32 intermediate. */
+int64_t cvhip_resize_bilinear_bwd_workspace_bytes(int32_t N, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo);
+int cvhip_resize_bilinear_bwd_ws(const void* dy_bf16, int32_t ld_dy, void* dx_bf16, int32_t ld_dx, int32_t N, int32_t C, int32_t Hi,
+                                 int32_t Wi, int32_t Ho, int32_t Wo, int32_t align_corners, void* workspace, int64_t ws_bytes,
+                                 void* stream);
 
 /* global average pool (AdaptiveAvgPool2d(1)) fwd/bwd: y[n][c] = mean_hw x */
 int cvhip_global_avgpool_fwd(const void* x_bf16, int32_t ld_x, void* y_bf16, int32_t N, int32_t C,

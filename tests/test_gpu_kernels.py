@@ -450,7 +450,8 @@ def test_head_permute_exact():
 
 
 @pytest.mark.parametrize("align", [False, True])
-@pytest.mark.parametrize("Hi,Wi,Ho,Wo", [(4, 8, 16, 32), (1, 1, 4, 8), (5, 7, 20, 21), (16, 16, 8, 8)])
+@pytest.mark.parametrize("Hi,Wi,Ho,Wo", [(4, 8, 16, 32), (1, 1, 4, 8), (5, 7, 20, 21), (16, 16, 8, 8),
+                                         (4, 6, 32, 48), (3, 5, 13, 27), (2, 3, 19, 12)])   # x8, ragged x4.3 / x5.4 (separable backward), x9.5 / x4
 def test_bilinear(align, Hi, Wi, Ho, Wo):
     torch.manual_seed(0)
     x = bf(torch.randn(2, 24, Hi, Wi))
@@ -464,6 +465,19 @@ def test_bilinear(align, Hi, Wi, Ho, Wo):
     torch.cuda.synchronize()
     assert rel_l2(y.detach().float().cpu(), yr.detach()) < 4e-3
     assert rel_l2(xd.grad.float().cpu(), gx) < 4e-3
+    # the separable two-pass backward (ratios >= 4 on both axes) and the gather form are the same sum: equal to fp32 rounding
+    nb = int(L.load().cvhip_resize_bilinear_bwd_workspace_bytes(2, 24, Hi, Wi, Ho, Wo))
+    assert (nb > 0) == (Ho >= 4 * Hi and Wo >= 4 * Wi)
+    if nb > 0:
+        dyd = to_nhwc_dev(dy)
+        a = ops.empty_nhwc(2, 24, Hi, Wi, dev())
+        b = ops.empty_nhwc(2, 24, Hi, Wi, dev())
+        ws = torch.empty((nb,), dtype=torch.uint8, device=dev())
+        L.call("cvhip_resize_bilinear_bwd", dyd.data_ptr(), 24, a.data_ptr(), 24, 2, 24, Hi, Wi, Ho, Wo, int(align), ops._stream())
+        L.call("cvhip_resize_bilinear_bwd_ws", dyd.data_ptr(), 24, b.data_ptr(), 24, 2, 24, Hi, Wi, Ho, Wo, int(align), ws.data_ptr(), nb, ops._stream())
+        torch.cuda.synchronize()
+        assert rel_l2(b.float().cpu(), a.float().cpu()) < 2e-3
+        assert rel_l2(b.float().cpu(), gx) < 4e-3
 
 
 def test_global_avg_pool():
