@@ -190,23 +190,51 @@ __global__ __launch_bounds__(256) void sgd_ema_kernel(float* __restrict__ param,
       return;
     }
   }
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    // binary search the segment containing i (segments are sorted, disjoint, cover [0,n))
+  auto seg_of = [&](int64_t i) {  // binary search the segment containing i (segments are sorted, disjoint, cover [0,n))
     int lo = 0, hi = nseg - 1;
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
       if (i >= seg[2 * mid + 1]) lo = mid + 1;
       else hi = mid;
     }
-    const float lr = seg_lr[lo] * lr_scale, wd = seg_wd[lo];
-    float pv = param[i];
-    float d = grad[i] * gscale + wd * pv;
-    float b = first ? d : momentum * mom[i] + d;
-    mom[i] = b;
+    return lo;
+  };
+  auto upd = [&](float& pv, float g, float& mv, float& ev, float lr, float wd) {
+    float d = g * gscale + wd * pv;
+    const float b = first ? d : momentum * mv + d;
+    mv = b;
     d = nesterov ? d + momentum * b : b;
     pv -= lr * d;
+    if (ema) ev = decay * ev + (1.f - decay) * pv;
+  };
+  // 16 bytes per lane per array (the arenas are 16-byte aligned; the element-at-a-time walk ran at 2.1 TB/s on DeepLabv3+'s 44 M
+  // parameters: 414 us per step); a vector that straddles a segment boundary looks its elements up one by one
+  const bool v4 = ((((uintptr_t)param) | ((uintptr_t)grad) | ((uintptr_t)mom) | ((uintptr_t)ema)) & 15) == 0;
+  const int64_t n4 = v4 ? (n >> 2) : 0;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256) {
+    const int64_t i = q << 2;
+    float4 pv = *reinterpret_cast<const float4*>(param + i);
+    const float4 gv = *reinterpret_cast<const float4*>(grad + i);
+    float4 mv = first ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(mom + i);
+    float4 ev = ema ? *reinterpret_cast<const float4*>(ema + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int s0 = seg_of(i);
+    const bool one = i + 3 < seg[2 * s0 + 1];
+    const int s1 = one ? s0 : seg_of(i + 1), s2 = one ? s0 : seg_of(i + 2), s3 = one ? s0 : seg_of(i + 3);
+    upd(pv.x, gv.x, mv.x, ev.x, seg_lr[s0] * lr_scale, seg_wd[s0]);
+    upd(pv.y, gv.y, mv.y, ev.y, seg_lr[s1] * lr_scale, seg_wd[s1]);
+    upd(pv.z, gv.z, mv.z, ev.z, seg_lr[s2] * lr_scale, seg_wd[s2]);
+    upd(pv.w, gv.w, mv.w, ev.w, seg_lr[s3] * lr_scale, seg_wd[s3]);
+    *reinterpret_cast<float4*>(param + i) = pv;
+    *reinterpret_cast<float4*>(mom + i) = mv;
+    if (ema) *reinterpret_cast<float4*>(ema + i) = ev;
+  }
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int lo = seg_of(i);
+    float pv = param[i], mv = first ? 0.f : mom[i], ev = ema ? ema[i] : 0.f;
+    upd(pv, grad[i], mv, ev, seg_lr[lo] * lr_scale, seg_wd[lo]);
     param[i] = pv;
-    if (ema) ema[i] = decay * ema[i] + (1.f - decay) * pv;
+    mom[i] = mv;
+    if (ema) ema[i] = ev;
   }
 }
 
