@@ -202,4 +202,31 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + bid / NX;
 }
 
+// (cv, a, b, n) of a flat index i = ((n * Y + b) * X + a) * CV + cv. Flat indices below 2^31 (every tensor of the workloads: 16 x 128 x
+// 256 x 64 vectors = 33.5 M) take the 32-bit path: three 64-bit divisions by run-time values cost ~250 instructions per thread
+// iteration, which is what the light gather kernels (pooling, resize, generic depthwise, channel scaling) were spending their time on.
+__device__ __forceinline__ void split_index(int64_t i, int CV, int X, int Y, int* cv, int* a, int* b, int* n) {
+  if ((((uint64_t)i) >> 31) == 0) {
+    uint32_t u = (uint32_t)i;
+    uint32_t q = u / (uint32_t)CV;
+    *cv = (int)(u - q * (uint32_t)CV);
+    u = q;
+    q = u / (uint32_t)X;
+    *a = (int)(u - q * (uint32_t)X);
+    u = q;
+    q = u / (uint32_t)Y;
+    *b = (int)(u - q * (uint32_t)Y);
+    *n = (int)q;
+  } else {
+    int64_t pix = i / CV;
+    *cv = (int)(i - pix * CV);
+    int64_t r = pix / X;
+    *a = (int)(pix - r * X);
+    pix = r;
+    r = pix / Y;
+    *b = (int)(pix - r * Y);
+    *n = (int)r;
+  }
+}
+
 }  // namespace cvhip

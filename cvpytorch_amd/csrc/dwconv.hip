@@ -50,12 +50,8 @@ __global__ __launch_bounds__(256) void dw_fprop_kernel(const DwParams p) {
   const bool vec = dw_vec_ok(p);
   const int64_t total = (int64_t)p.N * p.P * p.Q * CV;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int cv = (int)(i % CV);
-    int64_t pix = i / CV;
-    const int q = (int)(pix % p.Q);
-    pix /= p.Q;
-    const int pp = (int)(pix % p.P);
-    const int n = (int)(pix / p.P);
+    int cv, q, pp, n;
+    split_index(i, CV, p.Q, p.P, &cv, &q, &pp, &n);
     const int c = cv * 8;
     float acc[8];
 #pragma unroll
@@ -88,12 +84,8 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const DwParams p) {
   const bool vec = dw_vec_ok(p);
   const int64_t total = (int64_t)p.N * p.H * p.W * CV;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int cv = (int)(i % CV);
-    int64_t pix = i / CV;
-    const int w = (int)(pix % p.W);
-    pix /= p.W;
-    const int h = (int)(pix % p.H);
-    const int n = (int)(pix / p.H);
+    int cv, w, h, n;
+    split_index(i, CV, p.W, p.H, &cv, &w, &h, &n);
     const int c = cv * 8;
     float acc[8];
 #pragma unroll

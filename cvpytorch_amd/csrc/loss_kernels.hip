@@ -453,9 +453,10 @@ __global__ __launch_bounds__(256) void scale_nc_kernel(const h16_t* __restrict__
   const bool vec = (C & 7) == 0 && (ld_x & 7) == 0 && (ld_y & 7) == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
   const int64_t total = (int64_t)N * HW * CV;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int cv = (int)(i % CV);
-    const int64_t pix = i / CV;
-    const int n = (int)(pix / HW);
+    int cv, hw, n0, n;   // i = (n * HW + hw) * CV + cv (common.h split_index with Y = 2^30: the last split is the identity, n0 = 0)
+    split_index(i, CV, HW, 1 << 30, &cv, &hw, &n, &n0);
+    (void)n0;
+    const int64_t pix = (int64_t)n * HW + hw;
     const int c = cv * 8;
     if (vec) {
       f32x8 v = unpack8(*reinterpret_cast<const uint4*>(x + pix * ld_x + c));

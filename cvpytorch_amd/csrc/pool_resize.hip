@@ -50,12 +50,8 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const PoolParams p) {
   const bool vec = (p.C & 7) == 0 && (p.ld_x & 7) == 0 && (p.ld_y & 7) == 0 && aligned16(p.x) && aligned16(p.y);
   const int64_t total = (int64_t)p.N * p.OH * p.OW * CV;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int cv = (int)(i % CV);
-    int64_t pix = i / CV;
-    const int ow = (int)(pix % p.OW);
-    pix /= p.OW;
-    const int oh = (int)(pix % p.OH);
-    const int n = (int)(pix / p.OH);
+    int cv, ow, oh, n;
+    split_index(i, CV, p.OW, p.OH, &cv, &ow, &oh, &n);
     const int c = cv * 8;
     const int h0 = oh * p.s - p.pad, w0 = ow * p.s - p.pad;
     float best[8];
@@ -105,12 +101,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolParams p) {
   const bool vec = (p.C & 7) == 0 && (p.ld_dy & 7) == 0 && (p.ld_dx & 7) == 0 && aligned16(p.dy) && aligned16(p.dx);
   const int64_t total = (int64_t)p.N * p.H * p.W * CV;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int cv = (int)(i % CV);
-    int64_t pix = i / CV;
-    const int iw = (int)(pix % p.W);
-    pix /= p.W;
-    const int ih = (int)(pix % p.H);
-    const int n = (int)(pix / p.H);
+    int cv, iw, ih, n;
+    split_index(i, CV, p.W, p.H, &cv, &iw, &ih, &n);
     const int c = cv * 8;
     float acc[8];
 #pragma unroll
@@ -179,12 +171,8 @@ __global__ __launch_bounds__(256) void up2cat_fwd_kernel(const UpParams p) {
   (void)Ct;
   const int64_t total = (int64_t)p.N * OH * OW * CV;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int cv = (int)(i % CV);
-    int64_t pix = i / CV;
-    const int ow = (int)(pix % OW);
-    pix /= OW;
-    const int oh = (int)(pix % OH);
-    const int n = (int)(pix / OH);
+    int cv, ow, oh, n;
+    split_index(i, CV, OW, OH, &cv, &ow, &oh, &n);
     h16_t* orow = p.out + ((int64_t)(n * OH + oh) * OW + ow) * p.ld_out;
     if (cv < CVa) {
       const f32x8 v = load8(p.a + ((int64_t)(n * p.Ha + (oh >> 1)) * p.Wa + (ow >> 1)) * p.ld_a, cv * 8, p.Ca, vec);
@@ -204,12 +192,8 @@ __global__ __launch_bounds__(256) void up2_bwd_kernel(const UpParams p) {
   const bool vec = (p.Ca & 7) == 0 && (p.ld_a & 7) == 0 && (p.ld_out & 7) == 0 && aligned16(p.a) && aligned16(p.out);
   const int64_t total = (int64_t)p.N * p.Ha * p.Wa * CV;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int cv = (int)(i % CV);
-    int64_t pix = i / CV;
-    const int w = (int)(pix % p.Wa);
-    pix /= p.Wa;
-    const int h = (int)(pix % p.Ha);
-    const int n = (int)(pix / p.Ha);
+    int cv, w, h, n;
+    split_index(i, CV, p.Wa, p.Ha, &cv, &w, &h, &n);
     f32x8 s;
 #pragma unroll
     for (int j = 0; j < 8; ++j) s.v[j] = 0.f;
@@ -243,12 +227,8 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const BilParams p) {
                    aligned16(p.src) && aligned16(p.dst);
   const int64_t total = (int64_t)p.N * p.Ho * p.Wo * CV;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int cv = (int)(i % CV);
-    int64_t pix = i / CV;
-    const int ow = (int)(pix % p.Wo);
-    pix /= p.Wo;
-    const int oh = (int)(pix % p.Ho);
-    const int n = (int)(pix / p.Ho);
+    int cv, ow, oh, n;
+    split_index(i, CV, p.Wo, p.Ho, &cv, &ow, &oh, &n);
     int h0, h1, w0, w1;
     float lh, lw;
     bil_src(oh, p.sh, p.align, p.Hi, &h0, &h1, &lh);
@@ -280,12 +260,8 @@ __global__ __launch_bounds__(256) void nearest_fwd_kernel(const BilParams p) {
                    aligned16(p.src) && aligned16(p.dst);
   const int64_t total = (int64_t)p.N * p.Ho * p.Wo * CV;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int cv = (int)(i % CV);
-    int64_t pix = i / CV;
-    const int ow = (int)(pix % p.Wo);
-    pix /= p.Wo;
-    const int oh = (int)(pix % p.Ho);
-    const int n = (int)(pix / p.Ho);
+    int cv, ow, oh, n;
+    split_index(i, CV, p.Wo, p.Ho, &cv, &ow, &oh, &n);
     const int ih = nn_src(oh, p.sh, p.Hi), iw = nn_src(ow, p.sw, p.Wi);
     const f32x8 v = load8(p.src + ((int64_t)(n * p.Hi + ih) * p.Wi + iw) * p.ld_src, cv * 8, p.C, vec);
     store8(p.dst + ((int64_t)(n * p.Ho + oh) * p.Wo + ow) * p.ld_dst, cv * 8, p.C, vec, v);
@@ -309,12 +285,8 @@ __global__ __launch_bounds__(256) void nearest_bwd_kernel(const BilParams p) {
                    aligned16(p.src) && aligned16(p.dst);
   const int64_t total = (int64_t)p.N * p.Hi * p.Wi * CV;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int cv = (int)(i % CV);
-    int64_t pix = i / CV;
-    const int iw = (int)(pix % p.Wi);
-    pix /= p.Wi;
-    const int ih = (int)(pix % p.Hi);
-    const int n = (int)(pix / p.Hi);
+    int cv, iw, ih, n;
+    split_index(i, CV, p.Wi, p.Hi, &cv, &iw, &ih, &n);
     int h0, h1, w0, w1;
     nn_range(ih, p.sh, p.Hi, p.Ho, &h0, &h1);
     nn_range(iw, p.sw, p.Wi, p.Wo, &w0, &w1);
@@ -340,12 +312,8 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const BilParams p) {
                    aligned16(p.src) && aligned16(p.dst);
   const int64_t total = (int64_t)p.N * p.Hi * p.Wi * CV;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int cv = (int)(i % CV);
-    int64_t pix = i / CV;
-    const int iw = (int)(pix % p.Wi);
-    pix /= p.Wi;
-    const int ih = (int)(pix % p.Hi);
-    const int n = (int)(pix / p.Hi);
+    int cv, iw, ih, n;
+    split_index(i, CV, p.Wi, p.Hi, &cv, &iw, &ih, &n);
     int oh_lo, oh_hi, ow_lo, ow_hi;
     bil_range(ih, p.sh, p.align, p.Ho, &oh_lo, &oh_hi);
     bil_range(iw, p.sw, p.align, p.Wo, &ow_lo, &ow_hi);
