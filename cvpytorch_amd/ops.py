@@ -1649,11 +1649,15 @@ def seg_cross_entropy_resized(logits, target, ignore_index=255, align_corners=Fa
 
 class ResizeBilinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, Ho, Wo, align_corners):
+    def forward(ctx, x, Ho, Wo, align_corners, out=None):
         x, ld = as_nhwc(x)
         N, Cc, Hi, Wi = x.shape
-        yld = _round8(Cc)  # padded pitch: odd channel counts (19-class logits) keep the 16-byte vector path
-        y = empty_nhwc(N, Cc, Ho, Wo, x.device, ld=yld)
+        if out is None:
+            yld = _round8(Cc)  # padded pitch: odd channel counts (19-class logits) keep the 16-byte vector path
+            y = empty_nhwc(N, Cc, Ho, Wo, x.device, ld=yld)
+        else:  # `out=`: a channel slice of the buffer the consumer reads (concat elimination, as for the conv layers)
+            y, yld = _check_out(out, N, Cc, Ho, Wo)
+            y = y.as_strided(y.shape, y.stride())   # fresh alias (the result must not BE an argument)
         L.call("cvhip_resize_bilinear_fwd", x.data_ptr(), ld, y.data_ptr(), yld, N, Cc, Hi, Wi, Ho, Wo, int(align_corners), _stream())
         ctx.meta = (N, Cc, Hi, Wi, Ho, Wo, int(align_corners))
         return y
@@ -1670,11 +1674,11 @@ class ResizeBilinear(torch.autograd.Function):
             L.call("cvhip_resize_bilinear_bwd_ws", dy.data_ptr(), ld, dx.data_ptr(), xld, N, Cc, Hi, Wi, Ho, Wo, ac, ws.data_ptr(), nb, _stream())
         else:
             L.call("cvhip_resize_bilinear_bwd", dy.data_ptr(), ld, dx.data_ptr(), xld, N, Cc, Hi, Wi, Ho, Wo, ac, _stream())
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
-def resize_bilinear(x, size, align_corners=False):
-    return ResizeBilinear.apply(x, int(size[0]), int(size[1]), bool(align_corners))
+def resize_bilinear(x, size, align_corners=False, out=None):
+    return ResizeBilinear.apply(x, int(size[0]), int(size[1]), bool(align_corners), out)
 
 
 class ResizeNearest(torch.autograd.Function):
