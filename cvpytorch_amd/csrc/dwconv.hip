@@ -186,6 +186,140 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwParams p, int row
   }
 }
 
+// ---- generic depthwise forward / stride-1 input gradient with the taps in registers (round 3) ----------------------------------------------
+// out[n][oh][ow][c] = bias[c] + sum_t in[n][oh*sh + offh[t]][ow*sw + offw[t]][c] * w[c][t]            (t < R*S <= 9)
+// fprop: offh = r*dh - ph; stride-1 dgrad: in = dy, offh = ph - r*dh (no stride holes). The kernels above re-read 8 scalar weights per tap
+// per pixel (72 loads per output vector) and keep every tap load in its own branch: on DeepLabv3+'s ASPP (2048 channels @16x32, dilation
+// 12 / 24 / 36: 67 MB per pass) they ran at 0.7 TB/s. Here a thread owns one channel vector — its <= 9 x 8 weights live in registers — and
+// walks pixels; all tap loads of a pixel are issued unconditionally (clamped address, weight 0 outside the image) before any arithmetic.
+struct DwTapParams {
+  const h16_t* in;
+  const float* w;
+  const float* bias;
+  h16_t* out;
+  int N, C, IH, IW, OH, OW, sh, sw, T, in_ld, out_ld, ppb;  // ppb: pixels per block
+  int offh[kDwMaxTaps], offw[kDwMaxTaps];
+};
+
+__global__ __launch_bounds__(256) void dw_taps_kernel(const DwTapParams p) {
+  const int CV = p.C >> 3;
+  const int cols = CV < 256 ? CV : 256;
+  const int rpp = 256 / cols;
+  const int t = threadIdx.x;
+  const int tx = t % cols, ty = t / cols;
+  const int cv = blockIdx.y * cols + tx;
+  if (ty >= rpp || cv >= CV) return;
+  const int c = cv * 8;
+  float w[kDwMaxTaps][8], bias[8];
+  if (p.T == kDwMaxTaps && ((((uintptr_t)p.w) & 15) == 0)) {  // 3x3: the thread's 8 x 9 weights are 72 consecutive floats (18 x 16 bytes)
+    float flat[8 * kDwMaxTaps];
+    const float4* src = reinterpret_cast<const float4*>(p.w + (int64_t)c * kDwMaxTaps);
+#pragma unroll
+    for (int v = 0; v < 2 * kDwMaxTaps; ++v) {
+      const float4 f = src[v];
+      flat[4 * v] = f.x;
+      flat[4 * v + 1] = f.y;
+      flat[4 * v + 2] = f.z;
+      flat[4 * v + 3] = f.w;
+    }
+#pragma unroll
+    for (int a = 0; a < kDwMaxTaps; ++a)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[a][j] = flat[j * kDwMaxTaps + a];
+  } else {
+#pragma unroll
+    for (int a = 0; a < kDwMaxTaps; ++a)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[a][j] = a < p.T ? p.w[(int64_t)(c + j) * p.T + a] : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bias[j] = p.bias ? p.bias[c + j] : 0.f;
+  const int npix = p.N * p.OH * p.OW;  // (< 2^31: checked by the host)
+  const int p_end = min(npix, ((int)blockIdx.x + 1) * p.ppb);
+  for (int pix = (int)blockIdx.x * p.ppb + ty; pix < p_end; pix += rpp) {
+    const unsigned ohw = (unsigned)(p.OH * p.OW);
+    const unsigned n = (unsigned)pix / ohw;
+    const unsigned rem = (unsigned)pix - n * ohw;
+    const int oh = (int)(rem / (unsigned)p.OW), ow = (int)(rem - (rem / (unsigned)p.OW) * (unsigned)p.OW);
+    const h16_t* const img = p.in + (int64_t)n * p.IH * p.IW * p.in_ld + c;
+    uint4 raw[kDwMaxTaps];
+    float m[kDwMaxTaps];
+#pragma unroll
+    for (int a = 0; a < kDwMaxTaps; ++a) {
+      const int ih = oh * p.sh + p.offh[a], iw = ow * p.sw + p.offw[a];
+      const bool ok = a < p.T && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+      m[a] = ok ? 1.f : 0.f;
+      const int64_t off = ok ? ((int64_t)ih * p.IW + iw) * p.in_ld : 0;
+      raw[a] = *reinterpret_cast<const uint4*>(img + off);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // every tap load ahead of the arithmetic
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = bias[j];
+#pragma unroll
+    for (int a = 0; a < kDwMaxTaps; ++a) {
+      const f32x8 v = unpack8(raw[a]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += (v.v[j] * m[a]) * w[a][j];
+    }
+    f32x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.v[j] = acc[j];
+    *reinterpret_cast<uint4*>(p.out + (int64_t)pix * p.out_ld + c) = pack8(o);
+  }
+}
+
+// launch for fprop (dgrad == false) or the stride-1 input gradient; false when the taps form does not apply
+static bool dw_taps_launch(const DwParams& p, bool dgrad, hipStream_t s, int* status) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("CVHIP_DW_TAPS");
+    on = e ? atoi(e) : 1;
+  }
+  const int T = p.R * p.S;
+  if (!on || T > kDwMaxTaps || (p.C & 7) || (p.x_ld & 7) || (p.y_ld & 7) || ((((uintptr_t)p.x) | ((uintptr_t)p.y)) & 15)) return false;
+  if (dgrad && (p.sh != 1 || p.sw != 1)) return false;
+  DwTapParams q{};
+  q.in = p.x;   // fprop: x; dgrad: dy (the caller swapped the pitches)
+  q.w = p.w;
+  q.bias = dgrad ? nullptr : p.bias;
+  q.out = p.y;
+  q.N = p.N;
+  q.C = p.C;
+  q.T = T;
+  q.in_ld = p.x_ld;
+  q.out_ld = p.y_ld;
+  if (!dgrad) {
+    q.IH = p.H; q.IW = p.W; q.OH = p.P; q.OW = p.Q; q.sh = p.sh; q.sw = p.sw;
+    for (int r = 0; r < p.R; ++r)
+      for (int c2 = 0; c2 < p.S; ++c2) {
+        q.offh[r * p.S + c2] = r * p.dh - p.ph;
+        q.offw[r * p.S + c2] = c2 * p.dw_ - p.pw;
+      }
+  } else {
+    q.IH = p.P; q.IW = p.Q; q.OH = p.H; q.OW = p.W; q.sh = 1; q.sw = 1;
+    for (int r = 0; r < p.R; ++r)
+      for (int c2 = 0; c2 < p.S; ++c2) {
+        q.offh[r * p.S + c2] = p.ph - r * p.dh;
+        q.offw[r * p.S + c2] = p.pw - c2 * p.dw_;
+      }
+  }
+  const int64_t npix = (int64_t)q.N * q.OH * q.OW;
+  if (npix <= 0 || npix >= (1ll << 31) - 65536) return false;
+  const int CV = q.C >> 3;
+  const int cols = CV < 256 ? CV : 256;
+  const int rpp = 256 / cols;
+  const int chunks = (CV + cols - 1) / cols;
+  // >= ~1024 blocks, >= 8 pixels per pixel lane (the 72 weight loads are paid once per block)
+  int64_t ppb = (npix * chunks + 1023) / 1024;
+  if (ppb < (int64_t)rpp * 8) ppb = (int64_t)rpp * 8;
+  q.ppb = (int)ppb;
+  const int64_t bx = (npix + ppb - 1) / ppb;
+  hipLaunchKernelGGL(dw_taps_kernel, dim3((unsigned)bx, (unsigned)chunks), dim3(256), 0, s, q);
+  *status = check_launch("dw_taps_kernel");
+  return true;
+}
+
 // ---- 3x3 / stride 1 / dilation 1 fast path -------------------------------------------------------------------------------
 // The generic kernels above issue 9 tap loads (+ 72 scalar weight loads) per output vector and walk pixels in flat order:
 // on DeepLabv3+'s decoder (304 / 512 channels @128x256, batch 16) every tap missed L2 and the three passes took 1.7-2.2 ms
@@ -715,6 +849,10 @@ int cvhip_dwconv2d_fprop(const cvhip_conv_desc* d, const void* x, const float* w
     hipLaunchKernelGGL(dw3x3_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, q);
     return check_launch("dw3x3_kernel<0>");
   }
+  {
+    int tst = CVHIP_OK;
+    if (dw_taps_launch(p, false, (hipStream_t)stream, &tst)) return tst;
+  }
   hipLaunchKernelGGL(dw_fprop_kernel, dim3(grid_for((int64_t)p.N * p.P * p.Q * ((p.C + 7) / 8))), dim3(256), 0,
                      (hipStream_t)stream, p);
   return check_launch("dw_fprop_kernel");
@@ -741,6 +879,10 @@ int cvhip_dwconv2d_dgrad(const cvhip_conv_desc* d, const void* dy, const float* 
     dw3_launch_geom(q, &grid);
     hipLaunchKernelGGL(dw3x3_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, q);
     return check_launch("dw3x3_kernel<0>(dgrad)");
+  }
+  {
+    int tst = CVHIP_OK;
+    if (dw_taps_launch(p, true, (hipStream_t)stream, &tst)) return tst;
   }
   hipLaunchKernelGGL(dw_dgrad_kernel, dim3(grid_for((int64_t)p.N * p.H * p.W * ((p.C + 7) / 8))), dim3(256), 0,
                      (hipStream_t)stream, p);
