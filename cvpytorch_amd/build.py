@@ -17,6 +17,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = [
     "api.hip",
     "conv_igemm.hip",
+    "conv_patch.hip",
     "conv_wgrad.hip",
     "bn_act.hip",
     "pool_resize.hip",

@@ -308,7 +308,26 @@ int cvhip_conv2d_fprop_stats_rows(const cvhip_conv_desc* d) {
     const int blocks = stream1x1_blocks(d->K, d->C, (int64_t)d->N * P * Q, true);  // same decision as launch_igemm
     if (blocks > 0) return blocks;
   }
+  {
+    IgemmParams p;
+    plan_fprop(d, &p);
+    int rows = 0;
+    if (patch_takes(p, &rows)) return rows;  // same decision as launch_igemm (conv_patch.hip: one row per spatial tile)
+  }
   return cdiv(d->N * P * Q, igemm_block_m(d->K, (int64_t)d->N * P * Q, d->R * d->S * d->C));
+}
+
+int cvhip_conv2d_patch_plan(const cvhip_conv_desc* d, int flags, int32_t* out, int max_classes) {
+  int st = validate_dense_desc(d);
+  if (st) return st;
+  IgemmParams p;
+  if (flags & 1) {
+    if ((d->K & 7) || (d->y_ld & 7)) return CVHIP_ERR_UNSUPPORTED;
+    plan_dgrad(d, &p);
+  } else {
+    plan_fprop(d, &p);
+  }
+  return patch_plan_export(p, out, max_classes, (flags & 2) != 0);
 }
 
 int cvhip_conv_stem_blocks(const cvhip_conv_desc* d) {
@@ -410,6 +429,54 @@ int cvhip_conv2d_fprop_acc(const cvhip_conv_desc* d, const void* x, const void* 
   p.tail_y = nullptr;
   p.y_vec_ok = ((d->y_ld & 3) == 0) && ((((uintptr_t)y) & 7) == 0);
   return launch_igemm(p, (hipStream_t)stream);
+}
+
+int cvhip_conv2d_fprop_fused(const cvhip_conv_desc* d, const void* x, const void* w, void* y, const cvhip_conv_fuse* f, void* stream) {
+  int st = validate_dense_desc(d);
+  if (st) return st;
+  if (!x || !w || !y || !f) return CVHIP_ERR_INVALID;
+  if ((((uintptr_t)x) & 15) || (((uintptr_t)w) & 15)) return CVHIP_ERR_INVALID;
+  if (f->stats_partial && f->bn_acc) return CVHIP_ERR_INVALID;
+  if ((f->stats_partial || f->bn_acc) && (f->bias || f->ep_scale || f->ep_act != CVHIP_ACT_NONE)) return CVHIP_ERR_INVALID;
+  if ((f->ep_scale == nullptr) != (f->ep_shift == nullptr) || (f->pro_scale == nullptr) != (f->pro_shift == nullptr)) return CVHIP_ERR_INVALID;
+  if (f->z_out && !f->pro_scale) return CVHIP_ERR_INVALID;
+  if (f->bn_acc && (((uintptr_t)f->bn_acc) & 7)) return CVHIP_ERR_INVALID;
+  IgemmParams p;
+  plan_fprop(d, &p);
+  p.x = (const h16_t*)x;
+  p.w = (const h16_t*)w;
+  p.y = (h16_t*)y;
+  p.bias = f->bias;
+  p.bias_n = d->k_valid > 0 ? d->k_valid : d->K;
+  p.stats = f->bn_acc ? reinterpret_cast<float*>(f->bn_acc) : f->stats_partial;
+  p.stats_acc = f->bn_acc ? 1 : 0;
+  p.stats_ld = d->K;
+  p.tail_y = nullptr;
+  p.y_vec_ok = ((d->y_ld & 3) == 0) && ((((uintptr_t)y) & 7) == 0);
+  p.ep_scale = f->ep_scale;
+  p.ep_shift = f->ep_shift;
+  p.ep_act = f->ep_act;
+  p.ep_ap = f->ep_act_param;
+  p.pro_scale = f->pro_scale;
+  p.pro_shift = f->pro_shift;
+  p.pro_act = f->pro_act;
+  p.pro_ap = f->pro_act_param;
+  p.z_out = (h16_t*)f->z_out;
+  p.z_ld = f->z_ld;
+  return launch_igemm(p, (hipStream_t)stream);
+}
+
+int cvhip_conv2d_fprop_prologue_ok(const cvhip_conv_desc* d, int with_z_out) {
+  if (validate_dense_desc(d)) return 0;
+  IgemmParams p;
+  plan_fprop(d, &p);
+  if (!patch_takes(p, nullptr) || d->C > 1024) return 0;
+  if (with_z_out) {
+    const int P = conv_out_dim(d->H, d->pad_h, d->dil_h, d->R, d->stride_h);
+    const int Q = conv_out_dim(d->W, d->pad_w, d->dil_w, d->S, d->stride_w);
+    if (P != d->H || Q != d->W || d->stride_h != 1 || d->stride_w != 1) return 0;
+  }
+  return 1;
 }
 
 static int dgrad_impl(const cvhip_conv_desc* d, const void* dy, const void* w_dgrad, const void* addend, int addend_ld, void* dx, void* stream,

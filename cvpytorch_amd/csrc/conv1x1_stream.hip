@@ -30,7 +30,38 @@ constexpr int kS1MinTiles = 192;       // below this the grid cannot cover the c
 
 // STATS: 0 = none, 1 = BatchNorm sums of the outputs (fprop), 2 = "tail" (dgrad; conv_plan.h IgemmCommon::tail_y): BatchNorm-BACKWARD
 // sums of the layer whose output gradient this launch produces, from the stored dz and that layer's y / statistics
-template <int NF, int MF, int STATS>
+
+// activation of 8 / 4 values with ONE switch (a switch per element multiplied the unrolled epilogue's code size and pushed the
+// 256-wide streaming kernel's accumulators into scratch)
+template <int NV>
+__device__ __forceinline__ void s1_act_vec(float (&v)[NV], int act, float ap) {
+  switch (act) {
+    case CVHIP_ACT_NONE: break;
+    case CVHIP_ACT_RELU:
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v[q] = act_fwd(v[q], CVHIP_ACT_RELU, ap);
+      break;
+    case CVHIP_ACT_SILU:
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v[q] = act_fwd(v[q], CVHIP_ACT_SILU, ap);
+      break;
+    case CVHIP_ACT_LEAKY:
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v[q] = act_fwd(v[q], CVHIP_ACT_LEAKY, ap);
+      break;
+    case CVHIP_ACT_SIGMOID:
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v[q] = act_fwd(v[q], CVHIP_ACT_SIGMOID, ap);
+      break;
+    default:
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v[q] = act_fwd(v[q], CVHIP_ACT_HSWISH, ap);
+      break;
+  }
+}
+
+// EPI: fused epilogue instance (STATS == 0 only): out = act((acc + bias) * ep_scale + ep_shift)
+template <int NF, int MF, int STATS, bool EPI = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernArgs p, int ntiles, int vec16) {
   constexpr int BN = NF * 16;
   constexpr int RT = 64 * MF;   // pixel rows per block tile: 4 waves x MF fragments x 16
@@ -111,6 +142,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernA
   float* const sbias = reinterpret_cast<float*>(smem + BN * brow);  // [BN] fp32 behind the weight tile
   const float* const stail = sbias + BN;                            // [4][BN]: scale | shift | mean | invstd of the tail layer
   if (p.bias && t < BN) sbias[t] = (n0 + t < p.bias_n) ? p.bias[n0 + t] : 0.f;
+  // fused epilogue: the constants share the tail rows
+  static_assert(!EPI || STATS == 0, "the fused epilogue excludes BatchNorm sums");
+  if (EPI && t < BN) {
+    const int n = n0 + t < p.Nout ? n0 + t : p.Nout - 1;
+    sbias[BN + t] = p.ep_scale ? p.ep_scale[n] : 1.f;
+    sbias[2 * BN + t] = p.ep_scale ? p.ep_shift[n] : 0.f;
+  }
   if (STATS == 2 && t < BN) {
     const int n = n0 + t < p.Nout ? n0 + t : p.Nout - 1;
     sbias[BN + t] = p.tail_scale[n];
@@ -185,6 +223,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernA
             v.v[q] += b0[q];
             v.v[4 + q] += b1[q];
           }
+        }
+        if constexpr (EPI) {
+          const int cl8 = j * 32 + g * 8;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v.v[q] = v.v[q] * stail[cl8 + q] + stail[BN + cl8 + q];
+          s1_act_vec<8>(v.v, p.ep_act, p.ep_ap);
         }
         if (p.res && m < M) {  // skip-connection gradient folded into the epilogue
           const h16_t* rrow = p.res + (int64_t)m * p.res_ld + ch0;
@@ -327,14 +371,14 @@ static bool s1x1_structural(const IgemmParams& p) {
          c.out_oh == 0 && c.out_ow == 0 && c.OHi == p.OH && c.OWi == p.OW && p.IH == p.OH && p.IW == p.OW && (p.x_ld & 7) == 0;
 }
 
-template <int NF, int STATS>
+template <int NF, int STATS, bool EPI = false>
 static int launch_s1(const IgemmParams& p, int blocks, int ntiles, hipStream_t stream) {
   constexpr int MF = 2;
   const int bn = NF * 16;
   const int cin_pad = (p.Cin + 31) & ~31;
   int lds = bn * (cin_pad * 2 + 16) + 5 * bn * (int)sizeof(float);  // weight tile + bias + the tail layer's 4 constant rows
   if (lds < 4 * bn * 2 * (int)sizeof(float)) lds = 4 * bn * 2 * (int)sizeof(float);
-  auto kern = conv1x1_stream_kernel<NF, MF, STATS>;
+  auto kern = conv1x1_stream_kernel<NF, MF, STATS, EPI>;
   static bool attr_done[64] = {};  // per instantiation AND device: the attribute is a per-device property of the function
   int devid = 0;
   (void)hipGetDevice(&devid);
@@ -361,6 +405,7 @@ int try_launch_stream1x1(const IgemmParams& p, hipStream_t stream) {
   if (blocks <= 0) return -1;
   const int ntiles = (int)((M + 127) / 128);
   const int nf = s1x1_nf(p.Nout, p.Cin, p.stats != nullptr);
+  if (p.stats && (p.ep_scale || p.ep_act != CVHIP_ACT_NONE)) return CVHIP_ERR_INVALID;
   if (p.stats && p.tail_y) {
     if (nf == 2) return launch_s1<2, 2>(p, blocks, ntiles, stream);
     if (nf == 4) return launch_s1<4, 2>(p, blocks, ntiles, stream);
@@ -370,6 +415,12 @@ int try_launch_stream1x1(const IgemmParams& p, hipStream_t stream) {
     if (nf == 2) return launch_s1<2, 1>(p, blocks, ntiles, stream);
     if (nf == 4) return launch_s1<4, 1>(p, blocks, ntiles, stream);
     return launch_s1<8, 1>(p, blocks, ntiles, stream);
+  }
+  if (p.ep_scale || p.ep_act != CVHIP_ACT_NONE) {
+    if (nf == 2) return launch_s1<2, 0, true>(p, blocks, ntiles, stream);
+    if (nf == 4) return launch_s1<4, 0, true>(p, blocks, ntiles, stream);
+    if (nf == 16) return launch_s1<16, 0, true>(p, blocks, ntiles, stream);
+    return launch_s1<8, 0, true>(p, blocks, ntiles, stream);
   }
   if (nf == 2) return launch_s1<2, 0>(p, blocks, ntiles, stream);
   if (nf == 4) return launch_s1<4, 0>(p, blocks, ntiles, stream);

@@ -365,7 +365,38 @@ constexpr int igemm_min_waves(int BM, int BN, int BK, int NST, int NW, int LW, i
 //      consecutive steps read the same BK-channel segment of (almost) the same pixel rows, shifted by one tap, so the re-reads hit
 //      in L2 instead of going back to the Infinity Cache (profiles/r03_igemm_ablation.log: the pixel-tile DMA alone ran at the
 //      fabric's ~10 TB/s, 17 B/clk/CU, against 30-50 B/clk/CU for the same pattern from an L2-resident window).
-template <int BM, int BN, int WM, int WN, int ABL = 0, int NST = 3, int BK = 32, bool FAST = false, int NW = 4, bool WS = false, int ORD = 0>
+
+// activation of 8 / 4 values with ONE switch (a switch per element multiplied the unrolled epilogue's code size and pushed the
+// 256-wide streaming kernel's accumulators into scratch)
+template <int NV>
+__device__ __forceinline__ void ig_act_vec(float (&v)[NV], int act, float ap) {
+  switch (act) {
+    case CVHIP_ACT_NONE: break;
+    case CVHIP_ACT_RELU:
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v[q] = act_fwd(v[q], CVHIP_ACT_RELU, ap);
+      break;
+    case CVHIP_ACT_SILU:
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v[q] = act_fwd(v[q], CVHIP_ACT_SILU, ap);
+      break;
+    case CVHIP_ACT_LEAKY:
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v[q] = act_fwd(v[q], CVHIP_ACT_LEAKY, ap);
+      break;
+    case CVHIP_ACT_SIGMOID:
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v[q] = act_fwd(v[q], CVHIP_ACT_SIGMOID, ap);
+      break;
+    default:
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v[q] = act_fwd(v[q], CVHIP_ACT_HSWISH, ap);
+      break;
+  }
+}
+
+// EPI: fused-epilogue instance (out = act((acc + bias) * ep_scale + ep_shift)); the default instances carry none of its code
+template <int BM, int BN, int WM, int WN, int ABL = 0, int NST = 3, int BK = 32, bool FAST = false, int NW = 4, bool WS = false, int ORD = 0, bool EPI = false>
 __global__ __launch_bounds__(NW * 64, WS ? 2 : igemm_min_waves(BM, BN, BK, NST, NW, NW, WM * WN / 64)) void igemm_dma_kernel(const IgemmKernArgs p) {
   constexpr int WAVES_N = BN / WN;
   constexpr int WAVES_M = BM / WM;
@@ -726,10 +757,17 @@ __global__ __launch_bounds__(NW * 64, WS ? 2 : igemm_min_waves(BM, BN, BK, NST, 
   const float* const sbias = reinterpret_cast<const float*>(smem);
   const float* const stail = sbias + BN;  // [4][BN]: scale | shift | mean | invstd of the tail layer's channels n0 .. n0 + BN
   const bool tail = p.tail_y != nullptr;
-  if (p.bias || tail) {
+  // fused epilogue: out = act((acc + bias) * ep_scale + ep_shift); its constants share the tail layer's LDS rows (never both)
+  constexpr bool ep_on = EPI;  // (the host never combines it with a tail)
+  if (p.bias || tail || ep_on) {
     if (t < BN) {
       float* const w = reinterpret_cast<float*>(smem);
       if (p.bias) w[t] = (n0 + t < p.bias_n) ? p.bias[n0 + t] : 0.f;
+      if (ep_on) {
+        const int n = n0 + t < p.Nout ? n0 + t : p.Nout - 1;
+        w[BN + t] = p.ep_scale ? p.ep_scale[n] : 1.f;
+        w[2 * BN + t] = p.ep_scale ? p.ep_shift[n] : 0.f;
+      }
       if (tail) {
         const int n = n0 + t < p.Nout ? n0 + t : p.Nout - 1;
         w[BN + t] = p.tail_scale[n];
@@ -778,6 +816,15 @@ __global__ __launch_bounds__(NW * 64, WS ? 2 : igemm_min_waves(BM, BN, BK, NST, 
           v1 += bv[1];
           v2 += bv[2];
           v3 += bv[3];
+        }
+        if constexpr (ep_on) {
+          const f32x4 sv = *reinterpret_cast<const f32x4*>(stail + wn * WN + a * 16 + nq), tv = *reinterpret_cast<const f32x4*>(stail + BN + wn * WN + a * 16 + nq);
+          float ev[4] = {v0 * sv[0] + tv[0], v1 * sv[1] + tv[1], v2 * sv[2] + tv[2], v3 * sv[3] + tv[3]};
+          ig_act_vec<4>(ev, p.ep_act, p.ep_ap);
+          v0 = ev[0];
+          v1 = ev[1];
+          v2 = ev[2];
+          v3 = ev[3];
         }
         if (p.res) {  // skip-connection gradient folded into dgrad's epilogue (replaces autograd's accumulation add)
           const h16_t* rrow = rbase + n;
@@ -866,6 +913,15 @@ __global__ __launch_bounds__(NW * 64, WS ? 2 : igemm_min_waves(BM, BN, BK, NST, 
             v2 += bv[2];
             v3 += bv[3];
           }
+          if constexpr (ep_on) {
+            const f32x4 sv = *reinterpret_cast<const f32x4*>(stail + nl), tv = *reinterpret_cast<const f32x4*>(stail + BN + nl);
+            float ev[4] = {v0 * sv[0] + tv[0], v1 * sv[1] + tv[1], v2 * sv[2] + tv[2], v3 * sv[3] + tv[3]};
+            ig_act_vec<4>(ev, p.ep_act, p.ep_ap);
+            v0 = ev[0];
+            v1 = ev[1];
+            v2 = ev[2];
+            v3 = ev[3];
+          }
           if (rbase && n0 + nl < p.Nout) {
             const h16_t* rrow = rbase + n0 + nl;
             if (rvec) {
@@ -917,7 +973,7 @@ __global__ __launch_bounds__(NW * 64, WS ? 2 : igemm_min_waves(BM, BN, BK, NST, 
   }
 
   if (p.stats) {
-    if (p.bias || tail || staged) __syncthreads();  // the constants / the output tile staged above are dead now
+    if (p.bias || tail || ep_on || staged) __syncthreads();  // the constants / the output tile staged above are dead now
     float* red = reinterpret_cast<float*>(smem);  // [WAVES_M][BN][2]
 #pragma unroll
     for (int a = 0; a < NF; ++a) {
@@ -1079,9 +1135,20 @@ static int launch_group(IgemmKernArgs& p, hipStream_t stream) {
     for (int i = 1; i < p.ncls; ++i) same = same && cdiv(p.cls[i].M, BM) == cdiv(p.cls[0].M, BM);
     p.interleave = same ? 1 : 0;
   }
+  if (p.ep_scale || p.ep_act != CVHIP_ACT_NONE) {
+    // fused epilogue: the EPI instances of the default forms (32-deep slots; FAST staging when Cin % 32 == 0)
+    if (p.tail_y) return CVHIP_ERR_INVALID;
+    const bool nst2 = (BN <= 64 && nst2_level() >= 1) || (BM == 128 && nst2_level() >= 2) || nst2_level() >= 3;
+    const bool fast = fast_staging() && p.Cin % 32 == 0 && p.Cin <= kFastMaxCin;
+    if (fast && nst2) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 2, 32, true, 4, false, 0, true>), dim3(total), dim3(256), 0, stream, p);
+    else if (fast) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 3, 32, true, 4, false, 0, true>), dim3(total), dim3(256), 0, stream, p);
+    else if (nst2) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 2, 32, false, 4, false, 0, true>), dim3(total), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 3, 32, false, 4, false, 0, true>), dim3(total), dim3(256), 0, stream, p);
+    return check_launch("igemm_kernel(fused epilogue)");
+  }
   if constexpr (WM == 64 && BM >= 128 && (BM != 128 || BN == 128)) {
     if (use_v1()) {
-      if (p.res || p.tail_y) return CVHIP_ERR_UNSUPPORTED;
+      if (p.res || p.tail_y || p.ep_scale || p.ep_act != CVHIP_ACT_NONE) return CVHIP_ERR_UNSUPPORTED;
       hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), dim3(total), dim3(256), 0, stream, p);
       return check_launch("igemm_kernel");
     }
@@ -1228,10 +1295,15 @@ int igemm_block_m(int Nout, int64_t M, int Ktot) {
 }
 
 int launch_igemm(IgemmParams& p, hipStream_t stream) {
+  if ((p.ep_scale == nullptr) != (p.ep_shift == nullptr)) return CVHIP_ERR_INVALID;
+  if (p.stats && (p.ep_scale || p.ep_act != CVHIP_ACT_NONE)) return CVHIP_ERR_INVALID;  // BN sums are those of the raw accumulators
   const int s0 = try_launch_stem(p, stream);  // 8-channel image stem: direct convolution from an LDS patch (conv_stem.hip)
   if (s0 >= 0) return s0;
   const int s1 = try_launch_stream1x1(p, stream);  // 1x1 / stride 1: persistent streaming kernel (conv1x1_stream.hip)
   if (s1 >= 0) return s1;
+  const int s2 = try_launch_patch(p, stream);  // multi-tap, Cin % 32 == 0: patch-resident implicit GEMM (conv_patch.hip)
+  if (s2 != -1) return s2;
+  if (p.pro_scale || p.z_out) return CVHIP_ERR_UNSUPPORTED;  // a fused prologue exists in the patch kernel only
   if (narrow128() && !use_v1()) {
     if (p.Nout <= 32) return launch_cfg<128, 32, 32, 32>(p, stream);
     if (p.Nout <= 64) return launch_cfg<128, 64, 32, 64>(p, stream);

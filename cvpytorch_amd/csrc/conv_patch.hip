@@ -1,0 +1,829 @@
+// conv_patch.hip — patch-resident implicit-GEMM convolution for gfx950 (CDNA4): multi-tap (3x3, dilated 3x3, 2x2 / 1x2 dgrad parity
+// classes ...) fprop and dgrad whose gathered operand has a channel count that is a multiple of 32.
+//
+//   Out[m][n] = sum_{t,c} X[pix(m) + tap(t)][c] * Wt[n][t*Cin + c]              (same plan / operand images as conv_igemm.hip)
+//
+// Why a second implicit GEMM: conv_igemm.hip stages the pixel (A) tile once PER TAP — 9x for a 3x3 — as 64-byte rows, and sits on the
+// L2 -> LDS rate of that pattern (profiles/r03_stage_structure_probe.log: 17-24 B/clk/CU; the dominant kernel ran 1.09 waves per SIMD
+// at 21 % MFMA-pipe busy for three rounds). Here the block's INPUT PATCH (tile + halo) of one channel chunk is staged into the LDS
+// ONCE (1.3-1.6x the tile instead of 9x), pixel-major, and every tap reads its fragments from it at a wave-uniform pixel offset; only
+// the weight tile of a (tap, chunk) K step streams through a small LDS-DMA ring (128-byte rows when Cin % 64 == 0). Because the patch
+// passes through registers exactly once per element, the producer layer's BatchNorm scale/shift + activation can be applied on the
+// way in (PRO = 1: z = act(scale*y + shift), halo zero AFTER the activation; conv_module.py:201-214 `act(norm(conv(x)))` of the
+// layer below), and the activated interior can be written out once for the weight-gradient pass (z_out).
+//
+// Geometry. Output positions are tiled in a VIRTUAL row space: image n's output rows sit at virtual rows n*vho .. n*vho + OHi - 1
+// (vho >= OHi: a few dummy rows per image, computed and not stored), its input rows at virtual input rows n*vho*in_sh + (ih - lo_h).
+// A tile is TH virtual output rows x TW output columns (TH*TW <= 256); its patch is PH = (TH-1)*in_sh + EH virtual input rows x
+// PWc = (TW-1)*in_sw + EW columns and needs no per-image special case: rows that fall between images are zero rows (halo), tiles
+// may span images. Output position ml -> (th, tw) = (ml / TW, ml % TW); lane's patch pixel for tap (i, j) = base(th, tw) + a
+// wave-uniform offset. Stride-2 inputs keep even and odd patch columns in separate halves of a patch row so the 16 pixels of an MFMA
+// fragment stay consecutive in the LDS.
+//
+// LDS image (CK = 64): pixel rows of 128 bytes, 16-byte slot s of pixel pp stored at slot s ^ (pp & 7): conflict-free for the 4x16-lane
+// groups of ds_read_b128 at ANY pixel offset (taps shift the fragment by arbitrary amounts) and for the 8-lane groups of ds_write_b128.
+// CK = 32: 64-byte rows with the 4-slot XOR table of conv_igemm.hip (conflict-free at aligned offsets, <= 2-way otherwise).
+//
+// 512 threads = 8 waves (4 along M x 2 along N), wave tile 64 x BN/2, v_mfma_f32_16x16x32 with swapped operands (a lane ends up with
+// 4 consecutive output channels of one pixel), two waves per SIMD. The epilogue stages the output tile through the (dead) LDS and
+// leaves as 16-byte row stores; it can add a bias, apply a folded / eval-mode BatchNorm scale+shift and an activation, add a residual
+// (dgrad skip-connection gradient) and emit training-mode BatchNorm sums.
+//
+// Replaces aten::convolution / convolution_backward(input) reached from reference src/models/bricks/conv_module.py:209 and
+// trainer.py:189; the fused prologue/epilogue replace native_batch_norm + silu/relu of conv_module.py:210-213 and the folded
+// conv+act of src/utils/fuse.py:32-54.
+#include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
+
+#include "common.h"
+#include "conv_plan.h"
+
+namespace cvhip {
+
+constexpr int kPatchBM = 256;
+constexpr int kPatchTabC = 1024;  // PRO: scale | shift of up to this many input channels live in the LDS
+
+struct PatchClass {
+  int TR, TS, dh0, dh_step, dw0, dw_step;  // taps: input row = oh*in_sh + dh0 + i*dh_step, column likewise
+  int out_oh, out_ow;                      // output pixel = (oh*out_sh + out_oh, ow*out_sw + out_ow)
+  int OHi, OWi;                            // iteration grid of the class
+  int lo_h, lo_w;                          // smallest tap offsets (row / column)
+  int TH, TW;                              // tile: virtual output rows x output columns
+  int PH, PW, PWh, PWc;                    // patch rows, row pitch (pixels), half pitch (stride-2 de-interleave), valid columns
+  int vho;                                 // virtual output rows per image
+  int tiles_w;                             // column tiles per row band
+  int tile_begin;                          // first logical tile of the class
+  int64_t w_off;
+};
+
+struct PatchArgs {
+  const h16_t* x;
+  const h16_t* w;
+  h16_t* y;
+  const float* bias;
+  int bias_n;
+  float* stats;
+  int stats_ld, stats_acc;
+  int NB, IH, IW, Cin, x_ld, in_sh, in_sw;
+  int Nout, y_ld, OH, OW, out_sh, out_sw;
+  int n_tiles, total_tiles, ncls;
+  const h16_t* res;
+  int res_ld;
+  // prologue (PRO = 1): x holds the RAW convolution output of the producing layer; the patch loader applies act(scale*x + shift)
+  const float *pro_scale, *pro_shift;
+  float pro_ap;
+  h16_t* z_out;  // optional: the activated interior of the patch is stored here (same geometry as x: pitch z_ld)
+  int z_ld;
+  // epilogue: out = act((acc + bias) * ep_scale + ep_shift) (+ res); ep_scale / ep_shift optional (both or none)
+  const float *ep_scale, *ep_shift;
+  int ep_act;
+  float ep_ap;
+  PatchClass cls[kKernelClasses];
+};
+
+#define CVHIP_PGLDS16(src, dst)                                                                                 \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                       \
+                                   (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+typedef unsigned __attribute__((ext_vector_type(4))) pu32x4;
+// operand loads of the NEXT chunk's patch, issued through inline asm so that hipcc's waitcnt pass neither drains the LDS-DMA ring at
+// their use nor waits for them early; patch_wait_vm is the only vmcnt wait that covers them (see conv_wgrad.hip for the idiom)
+__device__ __forceinline__ void patch_gload16(pu32x4& dst, const void* ptr) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+}
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate must be a literal): waits until at most min(n, 15) are outstanding
+__device__ __forceinline__ void patch_wait_vm(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+  }
+}
+
+constexpr int patch_np(int CK) { return CK == 64 ? 6 : 5; }  // loader passes: 6 x 64 = 384 pixels (48 KB) / 5 x 128 = 640 pixels (40 KB)
+constexpr int patch_pix(int CK) { return patch_np(CK) * (512 / (CK / 8)); }
+constexpr int patch_b_rows(int BN, int CK) {
+  const int rpt = 8 * (1024 / (CK * 2));  // rows one pass of the 8 waves covers
+  return BN < rpt ? rpt : BN;
+}
+constexpr int patch_lds_bytes(int BN, int CK, int PRO, int PB, int NST) {
+  const int ring = PB * patch_pix(CK) * CK * 2 + NST * patch_b_rows(BN, CK) * CK * 2 + (PRO ? 2 * kPatchTabC * 4 : 0);
+  const int epi = 5 * BN * 4 + kPatchBM * (BN * 2 + 16);  // constants + staged output tile
+  return ring > epi ? ring : epi;
+}
+
+
+// activation of NV values with ONE switch (a switch per element multiplies the unrolled epilogue's code size)
+template <int NV>
+__device__ __forceinline__ void patch_act_vec(float (&v)[NV], int act, float ap) {
+  switch (act) {
+    case CVHIP_ACT_NONE: break;
+    case CVHIP_ACT_RELU:
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v[q] = act_fwd(v[q], CVHIP_ACT_RELU, ap);
+      break;
+    case CVHIP_ACT_SILU:
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v[q] = act_fwd(v[q], CVHIP_ACT_SILU, ap);
+      break;
+    case CVHIP_ACT_LEAKY:
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v[q] = act_fwd(v[q], CVHIP_ACT_LEAKY, ap);
+      break;
+    case CVHIP_ACT_SIGMOID:
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v[q] = act_fwd(v[q], CVHIP_ACT_SIGMOID, ap);
+      break;
+    default:
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v[q] = act_fwd(v[q], CVHIP_ACT_HSWISH, ap);
+      break;
+  }
+}
+
+// 16-byte slot swizzle of a pixel / weight row
+template <int CK>
+__device__ __forceinline__ int patch_swz(int row) {
+  if constexpr (CK == 64) return row & 7;
+  else return (0x78 >> (2 * ((row >> 2) & 3))) & 3;
+}
+
+// BN  : output channels per block (128 / 64 / 32)          CK : channels per patch chunk (64 / 32)
+// PRO : 0 = x is used as it is; 1 = x is a raw convolution output, act(scale*x + shift) applied on load (ACT: the activation)
+// PB  : patch buffers (2: the next chunk's patch is written while the current one is multiplied; 1: written between chunks)
+// NST : depth of the weight-tile DMA ring
+template <int BN, int CK, int PRO, int ACT, int PB, int NST>
+__global__ __launch_bounds__(512, 2) void conv_patch_kernel(const PatchArgs p) {
+  constexpr int NW = 8;
+  constexpr int WN = BN / 2;
+  constexpr int MF = 4, NF = WN / 16;
+  static_assert(NF >= 1, "BN >= 32");
+  constexpr int SLOTS = CK / 8;
+  constexpr int ROWB = CK * 2;
+  constexpr int PPP = 512 / SLOTS;
+  constexpr int NPL = patch_np(CK);
+  constexpr int PATCH_BYTES = patch_pix(CK) * ROWB;
+  constexpr int RPI = 1024 / ROWB;  // weight rows per DMA instruction
+  constexpr int B_ROWS = patch_b_rows(BN, CK);
+  constexpr int PERB = B_ROWS / (NW * RPI);  // DMA instructions per K step per wave
+  constexpr int B_BYTES = B_ROWS * ROWB;
+  constexpr int KS = CK / 32;
+  static_assert(NST >= 2 && NST <= 4 && (PB == 1 || PB == 2), "ring depths");
+
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[patch_lds_bytes(BN, CK, PRO, PB, NST)];
+  unsigned char* const sPatch = smem;
+  unsigned char* const sB = smem + PB * PATCH_BYTES;
+  float* const sTab = reinterpret_cast<float*>(sB + NST * B_BYTES);  // PRO: [scale | shift][kPatchTabC]
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g = lane >> 4;
+
+  // ---- which tile ---------------------------------------------------------------------------------------------
+  const int lt = xcd_remap(blockIdx.x, p.total_tiles);
+  int ci = 0;
+#pragma unroll
+  for (int i = 1; i < kKernelClasses; ++i)
+    if (i < p.ncls && lt >= p.cls[i].tile_begin) ci = i;
+  PatchClass cl = p.cls[0];  // by value, picked with compile-time indices (a run-time index would put the argument block in scratch)
+#pragma unroll
+  for (int i = 1; i < kKernelClasses; ++i)
+    if (ci == i) cl = p.cls[i];
+  const int local = lt - cl.tile_begin;
+  const int sp = local / p.n_tiles;
+  const int ntile = local - sp * p.n_tiles;
+  const int thi = sp / cl.tiles_w, twi = sp - thi * cl.tiles_w;
+  const int n0 = ntile * BN;
+  const int Gv0 = thi * cl.TH, ow0 = twi * cl.TW;
+  const int V0 = Gv0 * p.in_sh;
+  const int col0 = ow0 * p.in_sw + cl.lo_w;
+  const int pitch = cl.vho * p.in_sh;
+  const int T = cl.TR * cl.TS;
+  const int Cin = p.Cin;
+  const int NC = Cin / CK;
+  const int nk = T * NC;
+  const int Ktot = T * Cin;
+  const int PW = cl.PW;
+
+  // ---- patch loader: this thread owns slot lslot of pixels lpix + j*PPP ------------------------------------------
+  const int lslot = t % SLOTS, lpix = t / SLOTS;
+  int poff[NPL];      // pixel index into x, -1 = outside the image (zero)
+  unsigned own = 0;   // bit j: this patch pixel is an output position of the tile (z_out writes it)
+  {
+    const int npix = cl.PH * PW;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int pp = j * PPP + lpix;
+      const int pr = pp / PW;
+      const int q = pp - pr * PW;
+      const int pc = p.in_sw == 2 ? (q < cl.PWh ? 2 * q : 2 * (q - cl.PWh) + 1) : q;
+      const int V = V0 + pr;
+      const int n = V / pitch;
+      const int ih = V - n * pitch + cl.lo_h;
+      const int iw = col0 + pc;
+      const bool ok = pp < npix && pc < cl.PWc && n < p.NB && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+      poff[j] = ok ? (n * p.IH + ih) * p.IW + iw : -1;
+      if (PRO == 1) {
+        const int th = pr + cl.lo_h, tw = pc + cl.lo_w;  // (stride-1 "same" geometry only: the host checks)
+        if (ok && ntile == 0 && (unsigned)th < (unsigned)cl.TH && (unsigned)tw < (unsigned)cl.TW) own |= 1u << j;
+      }
+    }
+  }
+  pu32x4 rp[NPL];
+  // (always NPL loads per thread, so the vmcnt arithmetic of the main loop is shape-independent; `live` false = past the last chunk:
+  // every lane re-reads the tensor's first bytes and the values are never used. Unconditional asm definitions of rp[] also keep
+  // the register allocator from inserting copies of in-flight registers at a control-flow merge.)
+  auto issue_patch = [&](int c, bool live) {
+    const h16_t* const base = p.x + (c * CK + lslot * 8);
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) patch_gload16(rp[j], (live && poff[j] >= 0) ? base + (int64_t)poff[j] * p.x_ld : p.x);
+  };
+  auto write_patch = [&](int buf, int c) {
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) asm volatile("" : "+v"(rp[j]));  // no use of a loaded value above the wait that precedes this call
+    float sc[8], sh[8];
+    if constexpr (PRO == 1) {
+      const int ch = c * CK + lslot * 8;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(sTab + ch), a1 = *reinterpret_cast<const f32x4*>(sTab + ch + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(sTab + kPatchTabC + ch), b1 = *reinterpret_cast<const f32x4*>(sTab + kPatchTabC + ch + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sc[e] = a0[e];
+        sc[4 + e] = a1[e];
+        sh[e] = b0[e];
+        sh[4 + e] = b1[e];
+      }
+    }
+    unsigned char* const dst = sPatch + buf * PATCH_BYTES;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int pp = j * PPP + lpix;
+      uint4 v = make_uint4(rp[j][0], rp[j][1], rp[j][2], rp[j][3]);
+      if constexpr (PRO == 1) {
+        f32x8 f = unpack8(v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f.v[e] = act_fwd(f.v[e] * sc[e] + sh[e], ACT, p.pro_ap);
+        v = pack8(f);
+      }
+      const bool ok = poff[j] >= 0;
+      v.x = ok ? v.x : 0u;
+      v.y = ok ? v.y : 0u;
+      v.z = ok ? v.z : 0u;
+      v.w = ok ? v.w : 0u;
+      *reinterpret_cast<uint4*>(dst + pp * ROWB + ((lslot ^ patch_swz<CK>(pp)) << 4)) = v;
+      if constexpr (PRO == 1) {
+        if (p.z_out && ((own >> j) & 1u)) *reinterpret_cast<uint4*>(p.z_out + (int64_t)poff[j] * p.z_ld + (c * CK + lslot * 8)) = v;
+      }
+    }
+  };
+
+  // ---- weight-tile DMA: lane fetches the LOGICAL 16-byte slot that belongs at its physical position (rule 21) -----
+  const h16_t* bsrc[PERB];
+  {
+    const h16_t* const wbase = p.w + cl.w_off;
+#pragma unroll
+    for (int i = 0; i < PERB; ++i) {
+      const int row = i * NW * RPI + wave * RPI + lane / SLOTS;
+      int n = n0 + row;
+      n = n < p.Nout ? n : p.Nout - 1;  // rows past the tile / past Nout fetch a valid row: their columns are never stored or summed
+      const int ls = (lane % SLOTS) ^ patch_swz<CK>(row);
+      bsrc[i] = wbase + ((int64_t)n * Ktot + ls * 8);
+    }
+  }
+  int nb_c = 0, nb_t = 0;  // (chunk, tap) of the next weight tile to stage: K step = chunk * T + tap
+  auto issue_b = [&](int st) {
+    const int off = nb_t * Cin + nb_c * CK;
+    unsigned char* const dst = sB + st * B_BYTES;
+#pragma unroll
+    for (int i = 0; i < PERB; ++i) CVHIP_PGLDS16(bsrc[i] + off, dst + (i * NW * RPI + wave * RPI) * ROWB);
+    if (++nb_t == T) {
+      nb_t = 0;
+      ++nb_c;
+    }
+  };
+
+  // ---- fragment geometry ------------------------------------------------------------------------------------------
+  int abase[MF];
+#pragma unroll
+  for (int b = 0; b < MF; ++b) {
+    const int ml = wm * 64 + b * 16 + (lane & 15);
+    const int th = ml / cl.TW, tw = ml - th * cl.TW;
+    abase[b] = th < cl.TH ? th * p.in_sh * PW + tw : 0;  // rows past the tile read pixel 0 (valid memory; never stored or summed)
+  }
+  int baddr[NF];
+#pragma unroll
+  for (int a = 0; a < NF; ++a) {
+    const int row = wn * WN + a * 16 + (lane & 15);
+    baddr[a] = row * ROWB + ((g ^ patch_swz<CK>(row)) << 4);
+  }
+
+  f32x4 acc[NF][MF];
+#pragma unroll
+  for (int a = 0; a < NF; ++a)
+#pragma unroll
+    for (int b = 0; b < MF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int st, int pbuf, int toff) __attribute__((always_inline)) {
+    const unsigned char* const sA = sPatch + pbuf * PATCH_BYTES;
+    const unsigned char* const sBt = sB + st * B_BYTES;
+    int aaddr[MF];
+#pragma unroll
+    for (int b = 0; b < MF; ++b) {
+      const int pp = abase[b] + toff;
+      aaddr[b] = pp * ROWB + ((g ^ patch_swz<CK>(pp)) << 4);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      h16x8 xa[MF], wb[NF];
+#pragma unroll
+      for (int a = 0; a < NF; ++a) wb[a] = *reinterpret_cast<const h16x8*>(sBt + (baddr[a] ^ (ks * 64)));
+#pragma unroll
+      for (int b = 0; b < MF; ++b) xa[b] = *reinterpret_cast<const h16x8*>(sA + (aaddr[b] ^ (ks * 64)));
+#pragma unroll
+      for (int a = 0; a < NF; ++a)
+#pragma unroll
+        for (int b = 0; b < MF; ++b) acc[a][b] = CVHIP_MFMA_16X16X32(wb[a], xa[b], acc[a][b], 0, 0, 0);
+    }
+  };
+
+  // ---- prologue ----------------------------------------------------------------------------------------------------
+  if constexpr (PRO == 1) {
+    for (int c = t; c < Cin; c += 512) {
+      sTab[c] = p.pro_scale[c];
+      sTab[kPatchTabC + c] = p.pro_shift[c];
+    }
+  }
+  issue_patch(0, true);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (PRO == 1) __syncthreads();  // (no DMA in flight yet: a plain barrier)
+  write_patch(0, 0);
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nk) issue_b(s);
+
+  // ---- main loop: chunk-major, taps inside ---------------------------------------------------------------------------
+  // Per-wave VMEM queue, oldest first, at the top of K step k = c*T + tt: [weight tile k] [tiles k+1 .. k+NST-2] and, for
+  // 1 <= tt <= NST-1, the NPL patch loads of chunk c+1 (issued in step c*T right after tile c*T + NST - 1). Loads return in
+  // order, so "at most (younger instructions) outstanding" means tile k has landed.
+  int k = 0;
+  int st_cur = 0, st_nxt = NST - 1;
+  int tr = 0, ts = 0;
+  auto step = [&](int tt, int pbuf, auto first_c) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_c)::value;
+    {
+      int nb = nk - 1 - k;
+      nb = nb < NST - 2 ? nb : NST - 2;
+      const bool py = !FIRST && tt <= NST - 1;
+      patch_wait_vm(nb * PERB + (py ? NPL : 0));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's patch stores (chunk boundary) are in the LDS
+    __builtin_amdgcn_s_barrier();  // tile k landed everywhere; everybody finished reading ring slot st_nxt (tile k - 1)
+    if (k + NST - 1 < nk) issue_b(st_nxt);
+    const int cw = cl.dw0 + ts * cl.dw_step - cl.lo_w;
+    const int toff = (cl.dh0 + tr * cl.dh_step - cl.lo_h) * PW + (p.in_sw == 2 ? ((cw & 1) * cl.PWh + (cw >> 1)) : cw);
+    return toff;
+  };
+  for (int c = 0; c < NC; ++c) {
+    const bool more = c + 1 < NC;
+    const int pbuf = PB == 2 ? (c & 1) : 0;
+    tr = ts = 0;
+    int pafter = 0;  // DMA instructions this wave issued after the next chunk's patch loads
+    {
+      const int toff = step(0, pbuf, std::true_type{});
+      issue_patch(c + 1, more);
+      compute(st_cur, pbuf, toff);
+      st_cur = st_cur == NST - 1 ? 0 : st_cur + 1;
+      st_nxt = st_nxt == NST - 1 ? 0 : st_nxt + 1;
+      if (++ts == cl.TS) {
+        ts = 0;
+        ++tr;
+      }
+      ++k;
+    }
+    for (int tt = 1; tt < T; ++tt) {
+      if (k + NST - 1 < nk) pafter += PERB;
+      const int toff = step(tt, pbuf, std::false_type{});
+      compute(st_cur, pbuf, toff);
+      st_cur = st_cur == NST - 1 ? 0 : st_cur + 1;
+      st_nxt = st_nxt == NST - 1 ? 0 : st_nxt + 1;
+      if (++ts == cl.TS) {
+        ts = 0;
+        ++tr;
+      }
+      ++k;
+    }
+    if (more) {
+      if constexpr (PB == 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // everybody finished reading the (single) patch buffer
+      }
+      patch_wait_vm(pafter);  // the patch loads have landed once only the DMAs issued after them are outstanding
+      write_patch(PB == 2 ? ((c + 1) & 1) : 0, c + 1);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- epilogue ------------------------------------------------------------------------------------------------------
+  float* const sconst = reinterpret_cast<float*>(smem);  // [bias | ep_scale | ep_shift][BN]
+  const bool has_ss = p.ep_scale != nullptr;
+  if (t < BN) {
+    const int n = n0 + t;
+    const int nc = n < p.Nout ? n : p.Nout - 1;
+    sconst[t] = (p.bias && n < p.bias_n) ? p.bias[n] : 0.f;
+    sconst[BN + t] = has_ss ? p.ep_scale[nc] : 1.f;
+    sconst[2 * BN + t] = has_ss ? p.ep_shift[nc] : 0.f;
+  }
+  __syncthreads();
+  constexpr int EP_PITCH = BN * 2 + 16;
+  unsigned char* const tile = smem + 5 * BN * (int)sizeof(float);
+  const int nq = g * 4;
+  const bool plain = !p.bias && !has_ss && p.ep_act == CVHIP_ACT_NONE;
+  const bool rvec = p.res && (p.res_ld & 3) == 0 && ((((uintptr_t)p.res) & 7) == 0);
+  bool rok[MF];
+#pragma unroll
+  for (int b = 0; b < MF; ++b) {
+    const int row = wm * 64 + b * 16 + (lane & 15);
+    const int th = row / cl.TW, tw = row - th * cl.TW;
+    const int Gv = Gv0 + th;
+    const int n_img = Gv / cl.vho;
+    const int oh = Gv - n_img * cl.vho;
+    const int ow = ow0 + tw;
+    rok[b] = th < cl.TH && n_img < p.NB && oh < cl.OHi && ow < cl.OWi;
+    const h16_t* rbase = nullptr;
+    if (p.res && rok[b]) {
+      const int64_t opix = ((int64_t)n_img * p.OH + (oh * p.out_sh + cl.out_oh)) * p.OW + (ow * p.out_sw + cl.out_ow);
+      rbase = p.res + opix * p.res_ld;
+    }
+#pragma unroll
+    for (int a = 0; a < NF; ++a) {
+      const int nl = wn * WN + a * 16 + nq;
+      float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+      if (!plain) {  // block-uniform
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(sconst + nl);
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(sconst + BN + nl), tv = *reinterpret_cast<const f32x4*>(sconst + 2 * BN + nl);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (v[r] + bv[r]) * sv[r] + tv[r];
+        patch_act_vec<4>(v, p.ep_act, p.ep_ap);
+      }
+      if (rbase && n0 + nl < p.Nout) {
+        const h16_t* rrow = rbase + n0 + nl;
+        if (rvec) {
+          const uint2 u = *reinterpret_cast<const uint2*>(rrow);
+          float r0, r1, r2, r3;
+          unpack2(u.x, r0, r1);
+          unpack2(u.y, r2, r3);
+          v[0] += r0;
+          v[1] += r1;
+          v[2] += r2;
+          v[3] += r3;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n0 + nl + r < p.Nout) v[r] += (float)rrow[r];
+        }
+      }
+      uint2 u;
+      u.x = pack2(v[0], v[1]);
+      u.y = pack2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(tile + row * EP_PITCH + nl * 2) = u;
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int CPR = BN / 8;  // 16-byte chunks per tile row
+    const bool vec_ok = (p.Nout & 7) == 0 && (p.y_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0);
+    for (int idx = t; idx < kPatchBM * CPR; idx += 512) {
+      const int row = idx / CPR, ch = idx - row * CPR;
+      const int th = row / cl.TW, tw = row - th * cl.TW;
+      const int Gv = Gv0 + th;
+      const int n_img = Gv / cl.vho;
+      const int oh = Gv - n_img * cl.vho;
+      const int ow = ow0 + tw;
+      const int n = n0 + ch * 8;
+      if (!(th < cl.TH && n_img < p.NB && oh < cl.OHi && ow < cl.OWi) || n >= p.Nout) continue;
+      const int64_t opix = ((int64_t)n_img * p.OH + (oh * p.out_sh + cl.out_oh)) * p.OW + (ow * p.out_sw + cl.out_ow);
+      h16_t* const yrow = p.y + opix * p.y_ld + n;
+      const unsigned char* const src = tile + row * EP_PITCH + ch * 16;
+      if (vec_ok) {
+        *reinterpret_cast<uint4*>(yrow) = *reinterpret_cast<const uint4*>(src);
+      } else {
+        const h16_t* const sv = reinterpret_cast<const h16_t*>(src);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (n + e < p.Nout) yrow[e] = sv[e];
+      }
+    }
+  }
+  if (p.stats) {  // training-mode BatchNorm sums of the fp32 accumulators (valid output positions only)
+    __syncthreads();
+    float* const red = reinterpret_cast<float*>(smem);  // [4][BN][2]
+#pragma unroll
+    for (int a = 0; a < NF; ++a) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int b = 0; b < MF; ++b) {
+          const float v = rok[b] ? acc[a][b][r] : 0.f;
+          s1 += v;
+          s2 += v * v;
+        }
+        s1 = row16_sum(s1);
+        s2 = row16_sum(s2);
+        if ((lane & 15) == 0) {
+          const int nl = wn * WN + a * 16 + nq + r;
+          red[(wm * BN + nl) * 2 + 0] = s1;
+          red[(wm * BN + nl) * 2 + 1] = s2;
+        }
+      }
+    }
+    __syncthreads();
+    if (t < BN) {
+      const int n = n0 + t;
+      if (n < p.Nout) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          s1 += red[(w * BN + t) * 2 + 0];
+          s2 += red[(w * BN + t) * 2 + 1];
+        }
+        if (p.stats_acc) {
+          acc_add2(reinterpret_cast<double*>(p.stats), sp, p.stats_ld, n, s1, s2);
+        } else {
+          float* dst = p.stats + (int64_t)sp * 2 * p.Nout;
+          dst[n] = s1;
+          dst[p.Nout + n] = s2;
+        }
+      }
+    }
+  }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------
+
+static int patch_mode() {  // CVHIP_PATCH: 0 = never (the per-tap implicit GEMM runs), 1 = default policy, 2 = wherever the geometry allows
+  const char* e = getenv("CVHIP_PATCH");  // read per call (host-side, once per launch / plan query): the tests switch it
+  return e ? atoi(e) : 1;
+}
+static int patch_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+
+// tile search for one class: TH x TW <= 256 with the patch inside the LDS budget; fewest tiles wins, then the smaller patch
+static bool patch_plan_class(const IgemmClass& c, int NB, int IH, int in_sh, int in_sw, int max_pix, PatchClass* o) {
+  memset(o, 0, sizeof(*o));
+  o->TR = c.TR;
+  o->TS = c.TS;
+  o->dh0 = c.dh0;
+  o->dh_step = c.dh_step;
+  o->dw0 = c.dw0;
+  o->dw_step = c.dw_step;
+  o->out_oh = c.out_oh;
+  o->out_ow = c.out_ow;
+  o->OHi = c.OHi;
+  o->OWi = c.OWi;
+  o->w_off = c.w_off;
+  if (c.M <= 0 || c.TR <= 0 || c.TS <= 0) return false;
+  const int h_a = c.dh0, h_b = c.dh0 + (c.TR - 1) * c.dh_step;
+  const int w_a = c.dw0, w_b = c.dw0 + (c.TS - 1) * c.dw_step;
+  const int lo_h = imin(h_a, h_b), hi_h = imax(h_a, h_b), lo_w = imin(w_a, w_b), hi_w = imax(w_a, w_b);
+  const int EH = hi_h - lo_h + 1, EW = hi_w - lo_w + 1;
+  o->lo_h = lo_h;
+  o->lo_w = lo_w;
+  // virtual input rows per image: real rows keep their place (pitch >= IH - lo_h) and a row past the bottom of image n either stays
+  // inside n's slot (invalid) or lands on a row above the top of image n + 1 (pitch > largest row any tap reaches)
+  const int ih_max = (c.OHi - 1) * in_sh + hi_h;
+  int pitch = imax(imax(IH - lo_h, ih_max + 1), 1);
+  if (lo_h > 0) pitch = imax(pitch, IH);  // (rows below lo_h are never read; keep the mapping monotone)
+  pitch = (pitch + in_sh - 1) / in_sh * in_sh;
+  o->vho = pitch / in_sh;
+  if (o->vho < c.OHi) return false;
+  const int64_t rows_total = (int64_t)NB * o->vho;
+  if (rows_total * in_sh >= (1ll << 30)) return false;
+  int best_tw = 0, best_th = 0, best_pix = 0;
+  int64_t best_tiles = -1;
+  for (int TW = 1; TW <= imin(c.OWi, kPatchBM); ++TW) {
+    int TH = kPatchBM / TW;
+    if ((int64_t)TH > rows_total) TH = (int)rows_total;
+    for (; TH >= 1; --TH) {
+      const int PWc = (TW - 1) * in_sw + EW;
+      const int PWh = (PWc + 1) / 2;
+      const int PW = in_sw == 2 ? 2 * PWh : PWc;
+      const int PH = (TH - 1) * in_sh + EH;
+      if (PH * PW > max_pix) continue;
+      const int64_t tiles = ((rows_total + TH - 1) / TH) * ((c.OWi + TW - 1) / TW);
+      const int pix = PH * PW;
+      if (best_tiles < 0 || tiles < best_tiles || (tiles == best_tiles && pix < best_pix)) {
+        best_tiles = tiles;
+        best_tw = TW;
+        best_th = TH;
+        best_pix = pix;
+      }
+      break;  // smaller TH for this TW only means more tiles
+    }
+  }
+  if (best_tiles < 0) return false;
+  o->TH = best_th;
+  o->TW = best_tw;
+  o->PWc = (best_tw - 1) * in_sw + EW;
+  o->PWh = (o->PWc + 1) / 2;
+  o->PW = in_sw == 2 ? 2 * o->PWh : o->PWc;
+  o->PH = (best_th - 1) * in_sh + EH;
+  o->tiles_w = (c.OWi + best_tw - 1) / best_tw;
+  return true;
+}
+
+struct PatchPlan {
+  PatchArgs a;
+  int BN, CK;
+  int64_t useful, padded;  // output positions: real / computed
+};
+
+// fills the plan when the patch kernel takes this problem (geometry only; pointers are copied by the launcher)
+static bool patch_plan(const IgemmParams& p, PatchPlan* pl, bool any_geometry = false) {
+  if (p.ncls < 1 || p.ncls > kKernelClasses) return false;
+  if (p.in_sh != p.in_sw || p.in_sh != 1) return false;  // stride-2 inputs: not enabled yet
+  if (p.Cin % 32 != 0 || (p.x_ld & 7) != 0) return false;
+  if (p.tail_y) return false;
+  const int CK = p.Cin % 64 == 0 ? 64 : 32;
+  const int BN = p.Nout <= 32 ? 32 : p.Nout <= 64 ? 64 : 128;
+  memset(&pl->a, 0, sizeof(pl->a));
+  PatchArgs& a = pl->a;
+  a.NB = p.NB;
+  a.IH = p.IH;
+  a.IW = p.IW;
+  a.Cin = p.Cin;
+  a.x_ld = p.x_ld;
+  a.in_sh = p.in_sh;
+  a.in_sw = p.in_sw;
+  a.Nout = p.Nout;
+  a.y_ld = p.y_ld;
+  a.OH = p.OH;
+  a.OW = p.OW;
+  a.out_sh = p.out_sh;
+  a.out_sw = p.out_sw;
+  a.n_tiles = cdiv(p.Nout, BN);
+  a.ncls = 0;
+  int total = 0;
+  int taps_max = 0;
+  pl->useful = pl->padded = 0;
+  if ((int64_t)p.NB * p.IH * p.IW >= (1ll << 31)) return false;
+  for (int i = 0; i < p.ncls; ++i) {
+    const IgemmClass& c = p.cls[i];
+    if (c.M <= 0) continue;           // empty class (parity row/column past the image)
+    if (c.TR * c.TS <= 0) return false;  // a class without taps just writes zeros: the general kernel does that
+    PatchClass pc;
+    if (!patch_plan_class(c, p.NB, p.IH, p.in_sh, p.in_sw, patch_pix(CK), &pc)) return false;
+    pc.tile_begin = total;
+    const int64_t rows_total = (int64_t)p.NB * pc.vho;
+    const int64_t sp = ((rows_total + pc.TH - 1) / pc.TH) * pc.tiles_w;
+    if (sp * a.n_tiles + total >= (1ll << 30)) return false;
+    total += (int)sp * a.n_tiles;
+    pl->useful += c.M;
+    pl->padded += sp * kPatchBM;
+    taps_max = imax(taps_max, c.TR * c.TS);
+    a.cls[a.ncls++] = pc;
+  }
+  if (a.ncls == 0) return false;
+  for (int i = a.ncls; i < kKernelClasses; ++i) a.cls[i] = a.cls[0];
+  a.total_tiles = total;
+  pl->BN = BN;
+  pl->CK = CK;
+  if (taps_max < 2 && patch_mode() < 2) return false;  // single-tap problems have nothing to re-use
+  if (any_geometry) return true;
+  // policy: the virtual rows / partial tiles must not waste more than a third of the MFMA work
+  if (patch_mode() < 2 && pl->padded * 2 > pl->useful * 3) return false;
+  return true;
+}
+
+template <int BN, int CK, int PRO, int ACT>
+static int patch_launch_cfg(const PatchArgs& a, hipStream_t stream) {
+  // A/B switches (CK = 64 builds only): CVHIP_PATCH_PB=1 single patch buffer, CVHIP_PATCH_NST=2 two-deep weight ring
+  const int pb = patch_env("CVHIP_PATCH_PB", 2);  // (read per launch: in-process A/B)
+  const int nst = patch_env("CVHIP_PATCH_NST", 3);
+  const dim3 grid(a.total_tiles), block(512);
+  if constexpr (CK == 64) {
+    if (pb == 1) {
+      hipLaunchKernelGGL((conv_patch_kernel<BN, CK, PRO, ACT, 1, 3>), grid, block, 0, stream, a);
+      return check_launch("conv_patch_kernel(pb1)");
+    }
+    if (nst == 2) {
+      hipLaunchKernelGGL((conv_patch_kernel<BN, CK, PRO, ACT, 2, 2>), grid, block, 0, stream, a);
+      return check_launch("conv_patch_kernel(nst2)");
+    }
+  }
+  hipLaunchKernelGGL((conv_patch_kernel<BN, CK, PRO, ACT, 2, 3>), grid, block, 0, stream, a);
+  return check_launch("conv_patch_kernel");
+}
+
+template <int BN, int CK>
+static int patch_launch_pro(const PatchArgs& a, int pro_act, hipStream_t stream) {
+  if (!a.pro_scale) return patch_launch_cfg<BN, CK, 0, CVHIP_ACT_NONE>(a, stream);
+  switch (pro_act) {
+    case CVHIP_ACT_SILU: return patch_launch_cfg<BN, CK, 1, CVHIP_ACT_SILU>(a, stream);
+    case CVHIP_ACT_RELU: return patch_launch_cfg<BN, CK, 1, CVHIP_ACT_RELU>(a, stream);
+    case CVHIP_ACT_NONE: return patch_launch_cfg<BN, CK, 1, CVHIP_ACT_NONE>(a, stream);
+    default: return CVHIP_ERR_UNSUPPORTED;
+  }
+}
+
+// geometry-only query (plan queries of api.hip, the Python host's kernel labels): does the patch kernel take this plan?
+bool patch_takes(const IgemmParams& p, int* stats_rows) {
+  if (patch_mode() == 0) return false;
+  PatchPlan pl;
+  if (!patch_plan(p, &pl)) return false;
+  if (stats_rows) *stats_rows = pl.a.total_tiles / pl.a.n_tiles;
+  return true;
+}
+
+int patch_plan_export(const IgemmParams& p, int32_t* out, int max_classes, bool any_geometry) {
+  if (patch_mode() == 0) return 0;
+  PatchPlan pl;
+  if (!patch_plan(p, &pl, any_geometry)) return 0;
+  if (!out || max_classes < pl.a.ncls) return CVHIP_ERR_INVALID;
+  for (int i = 0; i < pl.a.ncls; ++i) {
+    const PatchClass& c = pl.a.cls[i];
+    int32_t* o = out + i * CVHIP_PATCH_CLASS_INTS;
+    const int32_t v[CVHIP_PATCH_CLASS_INTS] = {c.TR, c.TS, c.dh0, c.dh_step, c.dw0, c.dw_step, c.out_oh, c.out_ow, c.OHi, c.OWi, c.lo_h, c.lo_w,
+                                               c.TH, c.TW, c.PH, c.PW, c.PWh, c.PWc, c.vho, c.tiles_w, c.tile_begin,
+                                               (int32_t)(c.w_off & 0xffffffffll), (int32_t)(c.w_off >> 32), pl.a.n_tiles, pl.a.total_tiles,
+                                               pl.BN, pl.CK, patch_pix(pl.CK)};
+    for (int j = 0; j < CVHIP_PATCH_CLASS_INTS; ++j) o[j] = v[j];
+  }
+  return pl.a.ncls;
+}
+
+// -1 = not taken (the caller runs the per-tap implicit GEMM). A plan that carries a fused prologue (pro_scale / z_out) can only run
+// here: CVHIP_ERR_UNSUPPORTED then, and the caller falls back to separate passes.
+int try_launch_patch(const IgemmParams& p, hipStream_t stream) {
+  const bool need = p.pro_scale || p.z_out;
+  if (patch_mode() == 0 && !need) return -1;
+  PatchPlan pl;
+  if (!patch_plan(p, &pl)) return need ? CVHIP_ERR_UNSUPPORTED : -1;
+  PatchArgs& a = pl.a;
+  a.x = p.x;
+  a.w = p.w;
+  a.y = p.y;
+  a.bias = p.bias;
+  a.bias_n = p.bias_n;
+  a.stats = p.stats;
+  a.stats_ld = p.stats_ld;
+  a.stats_acc = p.stats_acc;
+  a.res = p.res;
+  a.res_ld = p.res_ld;
+  a.pro_scale = p.pro_scale;
+  a.pro_shift = p.pro_shift;
+  a.pro_ap = p.pro_ap;
+  const int pro_act = p.pro_act;
+  a.z_out = p.z_out;
+  a.z_ld = p.z_ld;
+  a.ep_scale = p.ep_scale;
+  a.ep_shift = p.ep_shift;
+  a.ep_act = p.ep_act;
+  a.ep_ap = p.ep_ap;
+  if (a.pro_scale) {
+    if (!a.pro_shift || p.Cin > kPatchTabC) return CVHIP_ERR_UNSUPPORTED;
+    if (a.z_out) {
+      // the activated interior is written at the pixels that are output positions: "same" geometry of a single stride-1 class
+      const PatchClass& c = a.cls[0];
+      if (a.ncls != 1 || p.out_sh != 1 || p.out_sw != 1 || c.OHi != p.IH || c.OWi != p.IW || (a.z_ld & 7) || (((uintptr_t)a.z_out) & 15))
+        return CVHIP_ERR_UNSUPPORTED;
+    }
+  } else if (a.z_out) {
+    return CVHIP_ERR_INVALID;
+  }
+  if ((a.ep_scale == nullptr) != (a.ep_shift == nullptr)) return CVHIP_ERR_INVALID;
+  if (a.stats && (a.ep_scale || a.ep_act != CVHIP_ACT_NONE)) return CVHIP_ERR_INVALID;  // the sums are those of the raw accumulators
+  if (pl.CK == 64) {
+    if (pl.BN == 128) return patch_launch_pro<128, 64>(a, pro_act, stream);
+    if (pl.BN == 64) return patch_launch_pro<64, 64>(a, pro_act, stream);
+    return patch_launch_pro<32, 64>(a, pro_act, stream);
+  }
+  if (pl.BN == 128) return patch_launch_pro<128, 32>(a, pro_act, stream);
+  if (pl.BN == 64) return patch_launch_pro<64, 32>(a, pro_act, stream);
+  return patch_launch_pro<32, 32>(a, pro_act, stream);
+}
+
+}  // namespace cvhip

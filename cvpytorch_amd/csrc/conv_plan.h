@@ -56,6 +56,20 @@ struct IgemmCommon {
   const float *tail_scale, *tail_shift, *tail_mean, *tail_invstd;
   int tail_act;
   float tail_ap;
+  // fused EPILOGUE (every conv kernel): out = act((acc + bias) * ep_scale + ep_shift) — a folded / eval-mode BatchNorm and the
+  // layer's activation in the convolution's own pass (conv_module.py:201-214 in eval mode, utils/fuse.py:32-54). ep_scale and
+  // ep_shift come together or not at all; never combined with `stats` (training-mode sums are those of the raw accumulators).
+  const float *ep_scale, *ep_shift;
+  int ep_act;
+  float ep_ap;
+  // fused PROLOGUE (conv_patch.hip only): x is the RAW convolution output of the producing Conv-BN-act layer; the patch loader
+  // applies act(pro_scale * x + pro_shift) per input channel on the way into the LDS and (z_out != NULL) stores the activated
+  // tensor once, for the weight-gradient pass
+  const float *pro_scale, *pro_shift;
+  int pro_act;
+  float pro_ap;
+  h16_t* z_out;
+  int z_ld;
 };
 
 constexpr int kKernelClasses = 4;
@@ -155,5 +169,11 @@ int try_launch_stream1x1(const IgemmParams& p, hipStream_t stream);
 int stem_blocks(int C, int x_ld, int K, int R, int S, int sh, int sw, int dh, int dw, int N, int OH, int OW);
 int try_launch_stem(const IgemmParams& p, hipStream_t stream);
 int try_launch_stem_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, hipStream_t stream);
+// conv_patch.hip: patch-resident implicit GEMM for multi-tap convolutions (launcher, -1 = not taken; geometry-only query with the
+// number of BatchNorm partial rows its epilogue writes)
+int try_launch_patch(const IgemmParams& p, hipStream_t stream);
+bool patch_takes(const IgemmParams& p, int* stats_rows);
+// per class CVHIP_PATCH_CLASS_INTS int32 of tile / patch geometry (cvhip_conv2d_patch_plan); returns the class count, 0 = not taken
+int patch_plan_export(const IgemmParams& p, int32_t* out, int max_classes, bool any_geometry);
 
 }  // namespace cvhip

@@ -36,11 +36,44 @@ struct StemParams {
   float* stats;
   int stats_acc;
   int bias_n;
+  const float *ep_scale, *ep_shift;  // fused epilogue (never with stats): out = act((acc + bias) * ep_scale + ep_shift)
+  int ep_act;
+  float ep_ap;
   int NB, IH, IW, OH, OW, K, y_ld, R, S, pad_h, pad_w;
   int tiles_x, tiles_y, ntiles;
 };
 
-template <int ST, int NSTEP, bool STATS>
+
+// activation of 8 / 4 values with ONE switch (a switch per element multiplied the unrolled epilogue's code size and pushed the
+// 256-wide streaming kernel's accumulators into scratch)
+template <int NV>
+__device__ __forceinline__ void stem_act_vec(float (&v)[NV], int act, float ap) {
+  switch (act) {
+    case CVHIP_ACT_NONE: break;
+    case CVHIP_ACT_RELU:
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v[q] = act_fwd(v[q], CVHIP_ACT_RELU, ap);
+      break;
+    case CVHIP_ACT_SILU:
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v[q] = act_fwd(v[q], CVHIP_ACT_SILU, ap);
+      break;
+    case CVHIP_ACT_LEAKY:
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v[q] = act_fwd(v[q], CVHIP_ACT_LEAKY, ap);
+      break;
+    case CVHIP_ACT_SIGMOID:
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v[q] = act_fwd(v[q], CVHIP_ACT_SIGMOID, ap);
+      break;
+    default:
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v[q] = act_fwd(v[q], CVHIP_ACT_HSWISH, ap);
+      break;
+  }
+}
+
+template <int ST, int NSTEP, bool STATS, bool EPI = false>
 __global__ __launch_bounds__(256, 2) void stem_fprop_kernel(const StemParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kStemPatchBytes];
   const int t = threadIdx.x, lane = t & 63;
@@ -183,6 +216,16 @@ __global__ __launch_bounds__(256, 2) void stem_fprop_kernel(const StemParams p) 
 #pragma unroll
           for (int q = 0; q < 8; ++q)
             if (ch0 + q < p.bias_n) v.v[q] += p.bias[ch0 + q];
+        }
+        if constexpr (EPI) {  // K <= 32: the constants are L1-resident
+          if (p.ep_scale) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const int cq = ch0 + q < p.K ? ch0 + q : p.K - 1;
+              v.v[q] = v.v[q] * p.ep_scale[cq] + p.ep_shift[cq];
+            }
+          }
+          stem_act_vec<8>(v.v, p.ep_act, p.ep_ap);
         }
         h16_t* yrow = p.y + ((int64_t)(n * p.OH + oy) * p.OW + ox) * p.y_ld + ch0;
         if (ch0 + 7 < p.K && (p.y_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0)) {
@@ -414,11 +457,11 @@ int stem_blocks(int C, int x_ld, int K, int R, int S, int sh, int sw, int dh, in
   return (int)(tiles < kStemBlocks ? tiles : kStemBlocks);
 }
 
-template <int ST, bool STATS>
+template <int ST, bool STATS, bool EPI = false>
 static int launch_stem_steps(const StemParams& sp, int blocks, int nstep, hipStream_t stream) {
 #define CVHIP_STEM_CASE(NS)                                                                                        \
   case NS:                                                                                                         \
-    hipLaunchKernelGGL((stem_fprop_kernel<ST, NS, STATS>), dim3(blocks), dim3(256), 0, stream, sp);                \
+    hipLaunchKernelGGL((stem_fprop_kernel<ST, NS, STATS, EPI>), dim3(blocks), dim3(256), 0, stream, sp);           \
     break;
   switch (nstep) {
     CVHIP_STEM_CASE(1)
@@ -449,6 +492,11 @@ int try_launch_stem(const IgemmParams& p, hipStream_t stream) {
   sp.bias_n = p.bias_n;
   sp.stats = p.stats;
   sp.stats_acc = p.stats_acc;
+  if (p.stats && (p.ep_scale || p.ep_act != CVHIP_ACT_NONE)) return CVHIP_ERR_INVALID;
+  sp.ep_scale = p.ep_scale;
+  sp.ep_shift = p.ep_shift;
+  sp.ep_act = p.ep_act;
+  sp.ep_ap = p.ep_ap;
   sp.NB = p.NB; sp.IH = p.IH; sp.IW = p.IW; sp.OH = p.OH; sp.OW = p.OW;
   sp.K = p.Nout; sp.y_ld = p.y_ld; sp.R = c.TR; sp.S = c.TS;
   sp.pad_h = -c.dh0; sp.pad_w = -c.dw0;
@@ -456,7 +504,9 @@ int try_launch_stem(const IgemmParams& p, hipStream_t stream) {
   sp.tiles_y = cdiv(p.OH, kStemTH);
   sp.ntiles = p.NB * sp.tiles_x * sp.tiles_y;
   int rc;
-  if (p.in_sh == 2) rc = p.stats ? launch_stem_steps<2, true>(sp, blocks, nstep, stream) : launch_stem_steps<2, false>(sp, blocks, nstep, stream);
+  if (sp.ep_scale || sp.ep_act != CVHIP_ACT_NONE)
+    rc = p.in_sh == 2 ? launch_stem_steps<2, false, true>(sp, blocks, nstep, stream) : launch_stem_steps<1, false, true>(sp, blocks, nstep, stream);
+  else if (p.in_sh == 2) rc = p.stats ? launch_stem_steps<2, true>(sp, blocks, nstep, stream) : launch_stem_steps<2, false>(sp, blocks, nstep, stream);
   else rc = p.stats ? launch_stem_steps<1, true>(sp, blocks, nstep, stream) : launch_stem_steps<1, false>(sp, blocks, nstep, stream);
   return rc;
 }

@@ -45,6 +45,17 @@ class BnTail(C.Structure):
                 ("invstd", C.c_void_p), ("act", C.c_int32), ("act_param", C.c_float), ("acc", C.c_void_p), ("acc_ld", C.c_int32)]
 
 
+class ConvFuse(C.Structure):
+    """cvhip_conv_fuse (include/cvhip.h): optional fused prologue / epilogue operands of cvhip_conv2d_fprop_fused."""
+    _fields_ = [("bias", C.c_void_p), ("stats_partial", C.c_void_p), ("bn_acc", C.c_void_p), ("ep_scale", C.c_void_p),
+                ("ep_shift", C.c_void_p), ("ep_act", C.c_int32), ("ep_act_param", C.c_float), ("pro_scale", C.c_void_p),
+                ("pro_shift", C.c_void_p), ("pro_act", C.c_int32), ("pro_act_param", C.c_float), ("z_out", C.c_void_p),
+                ("z_ld", C.c_int32)]
+
+
+PATCH_CLASS_INTS = 28  # CVHIP_PATCH_CLASS_INTS
+
+
 class PrepEntry(C.Structure):
     """cvhip_prep_entry (include/cvhip.h): one layer of a batched operand-preparation plan."""
     _fields_ = [("desc", ConvDesc), ("master", C.c_void_p), ("w_fprop", C.c_void_p), ("w_dgrad", C.c_void_p)]
@@ -92,6 +103,9 @@ SIGNATURES = {
     "cvhip_prep_plan_build": (_i32, [_p, _i32, _p, C.POINTER(_i32)]),
     "cvhip_prep_plan_run": (_i32, [_p, _i32, _i32, _p]),
     "cvhip_conv2d_fprop": (_i32, [_dp, _p, _p, _p, _p, _p, _p]),
+    "cvhip_conv2d_fprop_fused": (_i32, [_dp, _p, _p, _p, C.POINTER(ConvFuse), _p]),
+    "cvhip_conv2d_fprop_prologue_ok": (_i32, [_dp, _i32]),
+    "cvhip_conv2d_patch_plan": (_i32, [_dp, _i32, C.POINTER(_i32), _i32]),
     "cvhip_conv2d_dgrad": (_i32, [_dp, _p, _p, _p, _p]),
     "cvhip_conv2d_dgrad_add": (_i32, [_dp, _p, _p, _p, _i32, _p, _p]),
     "cvhip_conv2d_wgrad": (_i32, [_dp, _p, _p, _p, _i32, _p]),

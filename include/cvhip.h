@@ -652,6 +652,47 @@ int cvhip_conv1x1_bwd_fused_acc(const cvhip_conv_desc* d, const void* dz0, int32
                                 const cvhip_bn_tail* tail /* optional: the layer that produced x */, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused convolution (round 4). `ConvModule.forward` is act(norm(conv(x))) (src/models/bricks/conv_module.py:201-214); in eval
+ * mode / after utils/fuse.py:32-54 the BatchNorm is a per-channel scale + shift, so the whole module is ONE pass:
+ *   EPILOGUE  (every convolution kernel)    y = act((conv(x, w) + bias) * ep_scale + ep_shift)
+ *   PROLOGUE  (patch-resident kernel only)  the convolution reads act_p(pro_scale * x + pro_shift) instead of x — x is then the RAW
+ *             convolution output of the producing Conv-BN-act layer, whose BN-apply + activation pass disappears; the zero padding
+ *             is applied AFTER the activation. z_out (optional, stride-1 "same" geometry): the activated tensor is also stored,
+ *             once, for the weight-gradient pass of training.
+ * stats_partial / bn_acc: training-mode BatchNorm sums of the raw accumulators as in cvhip_conv2d_fprop / _fprop_acc (then no
+ * bias / epilogue). Unused members must be zero. CVHIP_ERR_UNSUPPORTED: the geometry has no kernel with the requested prologue
+ * (cvhip_conv2d_fprop_prologue_ok tells beforehand); epilogues are available for every dense geometry.
+ * ------------------------------------------------------------------------------------------ */
+#ifndef CVHIP_REDECLARE_F16
+typedef struct cvhip_conv_fuse {
+  const float* bias;
+  float* stats_partial;
+  double* bn_acc;
+  const float* ep_scale;
+  const float* ep_shift;
+  int32_t ep_act;
+  float ep_act_param;
+  const float* pro_scale;
+  const float* pro_shift;
+  int32_t pro_act;
+  float pro_act_param;
+  void* z_out;
+  int32_t z_ld;
+} cvhip_conv_fuse;
+#endif
+int cvhip_conv2d_fprop_fused(const cvhip_conv_desc* d, const void* x, const void* w, void* y, const cvhip_conv_fuse* f, void* stream);
+/* 1 when cvhip_conv2d_fprop_fused accepts a prologue (and, with_z_out != 0, the z_out side output) for this descriptor */
+int cvhip_conv2d_fprop_prologue_ok(const cvhip_conv_desc* d, int with_z_out);
+/* Plan query of the patch-resident kernel (conv_patch.hip; pure host arithmetic, exercised by the CPU test-suite against a numpy
+ * interpreter of the kernel's addressing): per class CVHIP_PATCH_CLASS_INTS int32
+ *   {TR, TS, dh0, dh_step, dw0, dw_step, out_oh, out_ow, OHi, OWi, lo_h, lo_w, TH, TW, PH, PW, PWh, PWc, vho, tiles_w, tile_begin,
+ *    w_off lo, w_off hi, n_tiles, total_tiles, BN, CK, patch capacity (pixels)}.
+ * Returns the class count, 0 when another kernel runs this problem. flags bit 0: the plan of cvhip_conv2d_dgrad instead of fprop;
+ * bit 1: geometry only (skip the launcher's "too much padding" policy — what the kernel WOULD do on a small problem). */
+#define CVHIP_PATCH_CLASS_INTS 28
+int cvhip_conv2d_patch_plan(const cvhip_conv_desc* d, int flags, int32_t* out_classes, int max_classes);
+
+/* ------------------------------------------------------------------------------------------
  * Hardware probes used by the GPU test-suite to pin the MFMA / LDS-transpose lane layouts the
  * kernels rely on (cdna_hip_programming.md §3, T10). out buffers are small fp32 arrays.
  * ------------------------------------------------------------------------------------------ */

@@ -90,12 +90,21 @@ def test_stats_rows_tiles():
     # the 8-channel image stem runs on the persistent direct kernel (conv_stem.hip): one partial row per block
     stem = desc(64, 8, 640, 640, 32, 6, 6, (2, 2), (2, 2))
     assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(stem)) == lib.cvhip_conv_stem_blocks(C.byref(stem)) == 768
-    # implicit GEMM: block-M is 256 for K <= 64 and 128 otherwise (conv_igemm.hip launch_igemm)
-    assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(desc(64, 32, 160, 160, 32, 3, 3, (1, 1), (1, 1)))) == (64 * 160 * 160 + 255) // 256
+    # multi-tap convolutions with Cin % 32 == 0 and a stride-1 input: the patch-resident kernel (conv_patch.hip), one row per spatial tile
+    def patch_rows(dd):
+        buf = (C.c_int32 * (4 * L.PATCH_CLASS_INTS))()
+        assert lib.cvhip_conv2d_patch_plan(C.byref(dd), 0, buf, 4) == 1
+        return buf[24] // buf[23]   # total_tiles / n_tiles
+    big = desc(64, 32, 160, 160, 32, 3, 3, (1, 1), (1, 1))
+    assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(big)) == patch_rows(big) >= (64 * 160 * 160 + 255) // 256
+    # per-tap implicit GEMM (stride-2 input): block-M is 256 for K <= 64 and 128 / 256 otherwise (conv_igemm.hip launch_igemm)
+    assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(desc(64, 32, 320, 320, 64, 3, 3, (2, 2), (1, 1)))) == (64 * 160 * 160 + 255) // 256
     # 1x1 stride 1 with enough rows: the persistent streaming kernel (conv1x1_stream.hip), balanced grid <= 512
     pw = desc(64, 64, 160, 160, 32, 1, 1)
     assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(pw)) == lib.cvhip_conv1x1_stream_blocks(32, 64, 64 * 160 * 160, 1) == 512
-    assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(desc(2, 128, 40, 40, 128, 3, 3, (1, 1), (1, 1)))) == (2 * 1600 + 127) // 128
+    small = desc(2, 128, 40, 40, 128, 3, 3, (1, 1), (1, 1))
+    assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(small)) == patch_rows(small)
+    assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(desc(2, 128, 80, 80, 128, 3, 3, (2, 2), (1, 1)))) == (2 * 1600 + 127) // 128
     assert lib.cvhip_colreduce_rows(10, 32) == 1
     assert lib.cvhip_colreduce_rows(10 ** 7, 32) == 1024
     assert lib.cvhip_nms_workspace_bytes(100) == (100 * 2 + 2) * 8
@@ -222,6 +231,7 @@ def test_default_path_kernels_do_not_spill():
         r"bwd1x1_kernelILi\d+ELi\d+ELb1E",                      # tail-sums form (CVHIP_BN_TAIL, off: measured net loss)
         r"conv1x1_stream_kernelILi\d+ELi\d+ELi2E",              # same, STATS == 2
         r"igemm_dma_kernelILi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELb[01]ELi8E",   # 8-wave experiment (CVHIP_IGEMM_W8, off)
+        r"stem_fprop_kernelILi1ELi13ELb0ELb1E",                 # fused-epilogue instance of the 7x7 stride-1 stem (inference only)
     )
     bad = []
     for obj, k, d in rows:

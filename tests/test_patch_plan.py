@@ -1,0 +1,162 @@
+"""CPU-only check of the patch-resident convolution kernel's HOST-SIDE plan (csrc/conv_patch.hip, cvhip_conv2d_patch_plan): the tile /
+patch geometry is interpreted in numpy exactly the way the kernel addresses its LDS patch — loader: LDS pixel position -> (image,
+row, column) or zero; consumer: output position -> patch pixel + wave-uniform tap offset — and the result is compared with torch's
+own convolution / convolution backward. No kernel is launched here (the GPU parity tests run the kernel itself on the same cases)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from cvpytorch_amd import lib as L
+from test_abi_plan import desc, dgrad_plan
+
+FIELDS = ("TR", "TS", "dh0", "dh_step", "dw0", "dw_step", "out_oh", "out_ow", "OHi", "OWi", "lo_h", "lo_w", "TH", "TW", "PH", "PW", "PWh",
+          "PWc", "vho", "tiles_w", "tile_begin", "w_lo", "w_hi", "n_tiles", "total_tiles", "BN", "CK", "cap")
+
+
+def patch_plan(dd, dgrad):
+    lib = L.load()
+    buf = (C.c_int32 * (4 * L.PATCH_CLASS_INTS))()
+    n = lib.cvhip_conv2d_patch_plan(C.byref(dd), int(dgrad) | 2, buf, 4)
+    assert n >= 0, n
+    out = []
+    for i in range(n):
+        v = [buf[i * L.PATCH_CLASS_INTS + j] for j in range(L.PATCH_CLASS_INTS)]
+        d = dict(zip(FIELDS, v))
+        d["w_off"] = (d["w_lo"] & 0xffffffff) | (d["w_hi"] << 32)
+        out.append(d)
+    return out
+
+
+def interpret(classes, x_nhwc, wt_of_class, NB, IH, IW, in_s, OH, OW, out_s, Nout):
+    """x_nhwc: the gathered operand (N, IH, IW, Cin); wt_of_class(i) -> (Nout, T, Cin). Returns (N, OH, OW, Nout) and a coverage count."""
+    Cin = x_nhwc.shape[-1]
+    out = np.zeros((NB, OH, OW, Nout))
+    hits = np.zeros((NB, OH, OW), dtype=np.int64)
+    for ci, cl in enumerate(classes):
+        wt = wt_of_class(ci)
+        T = cl["TR"] * cl["TS"]
+        assert cl["TH"] * cl["TW"] <= 256 and cl["PH"] * cl["PW"] <= cl["cap"]
+        pitch = cl["vho"] * in_s
+        rows_total = NB * cl["vho"]
+        tiles_h = -(-rows_total // cl["TH"])
+        nxt = classes[ci + 1]["tile_begin"] if ci + 1 < len(classes) else cl["total_tiles"]
+        assert tiles_h * cl["tiles_w"] * cl["n_tiles"] == nxt - cl["tile_begin"]
+        PW = cl["PW"]
+        for thi in range(tiles_h):
+            for twi in range(cl["tiles_w"]):
+                Gv0, ow0 = thi * cl["TH"], twi * cl["TW"]
+                V0, col0 = Gv0 * in_s, ow0 * in_s + cl["lo_w"]
+                # ---- loader: every LDS pixel position of the patch
+                patch = np.zeros((cl["cap"], Cin))
+                for pp in range(cl["PH"] * PW):
+                    pr, q = divmod(pp, PW)
+                    pc = (2 * q if q < cl["PWh"] else 2 * (q - cl["PWh"]) + 1) if in_s == 2 else q
+                    V = V0 + pr
+                    n, vr = divmod(V, pitch)
+                    ih, iw = vr + cl["lo_h"], col0 + pc
+                    if pc < cl["PWc"] and n < NB and 0 <= ih < IH and 0 <= iw < IW:
+                        patch[pp] = x_nhwc[n, ih, iw]
+                # ---- consumer: output positions of the tile
+                for ml in range(256):
+                    th, tw = divmod(ml, cl["TW"])
+                    if th >= cl["TH"]:
+                        continue
+                    Gv = Gv0 + th
+                    n, oh = divmod(Gv, cl["vho"])
+                    ow = ow0 + tw
+                    if not (n < NB and oh < cl["OHi"] and ow < cl["OWi"]):
+                        continue
+                    base = th * in_s * PW + tw
+                    acc = np.zeros(Nout)
+                    for i in range(cl["TR"]):
+                        for j in range(cl["TS"]):
+                            cw = cl["dw0"] + j * cl["dw_step"] - cl["lo_w"]
+                            coff = ((cw & 1) * cl["PWh"] + (cw >> 1)) if in_s == 2 else cw
+                            pos = base + (cl["dh0"] + i * cl["dh_step"] - cl["lo_h"]) * PW + coff
+                            assert 0 <= pos < cl["PH"] * PW, (pos, cl)
+                            acc += wt[:, i * cl["TS"] + j, :] @ patch[pos]
+                    oy, ox = oh * out_s + cl["out_oh"], ow * out_s + cl["out_ow"]
+                    out[n, oy, ox] = acc
+                    hits[n, oy, ox] += 1
+    return out, hits
+
+
+FPROP_CASES = [
+    # N, C, H, W, K, R, S, stride, pad, dil
+    (2, 64, 40, 40, 128, 3, 3, 1, 1, 1),
+    (3, 64, 20, 20, 64, 3, 3, 1, 1, 1),     # tiles span images
+    (1, 32, 23, 37, 32, 3, 3, 1, 1, 1),     # ragged: CK = 32
+    (2, 64, 16, 24, 64, 3, 3, 1, 2, 2),     # dilation 2
+    (2, 64, 12, 12, 32, 5, 5, 1, 2, 1),
+    (1, 64, 10, 14, 64, 3, 1, 1, 0, 1),     # no padding, 3x1
+    (2, 64, 9, 300, 64, 3, 3, 1, 1, 1),     # wider than one tile
+]
+
+
+@pytest.mark.parametrize("N,Cc,H,W,K,R,S,s,p,d", FPROP_CASES)
+def test_patch_fprop_plan_interpreted_matches_torch(N, Cc, H, W, K, R, S, s, p, d):
+    torch.manual_seed(1)
+    dd = desc(N, Cc, H, W, K, R, S, (s, s), (p, p), (d, d))
+    classes = patch_plan(dd, False)
+    assert len(classes) == 1, "the patch kernel should take this fprop"
+    x = torch.randn(N, Cc, H, W, dtype=torch.float64)
+    w = torch.randn(K, Cc, R, S, dtype=torch.float64)
+    ref = F.conv2d(x, w, stride=s, padding=p, dilation=d).permute(0, 2, 3, 1).numpy()
+    wt = w.permute(0, 2, 3, 1).reshape(K, R * S, Cc).numpy()   # [K][R*S][C] = the fprop operand image
+    got, hits = interpret(classes, x.permute(0, 2, 3, 1).numpy(), lambda i: wt, N, H, W, s, ref.shape[1], ref.shape[2], 1, K)
+    assert (hits == 1).all()
+    np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-10)
+
+
+DGRAD_CASES = [
+    (2, 64, 16, 20, 64, 3, 3, 1, 1, 1),
+    (2, 32, 16, 20, 64, 3, 3, 2, 1, 1),     # stride-2 parity classes: 1 + 2 + 2 + 4 taps
+    (1, 64, 17, 19, 64, 3, 3, 2, 1, 1),     # odd sizes: classes of unequal extent
+    (1, 64, 12, 12, 64, 3, 3, 1, 2, 2),
+]
+
+
+@pytest.mark.parametrize("N,Cc,H,W,K,R,S,s,p,d", DGRAD_CASES)
+def test_patch_dgrad_plan_interpreted_matches_torch(N, Cc, H, W, K, R, S, s, p, d):
+    torch.manual_seed(2)
+    dd = desc(N, Cc, H, W, K, R, S, (s, s), (p, p), (d, d))
+    classes = patch_plan(dd, True)
+    assert len(classes) == s * s, "the patch kernel should take this dgrad"
+    ref_cls = dgrad_plan(dd)
+    x = torch.randn(N, Cc, H, W, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(K, Cc, R, S, dtype=torch.float64)
+    y = F.conv2d(x, w, stride=s, padding=p, dilation=d)
+    dy = torch.randn_like(y)
+    (gx,) = torch.autograd.grad(y, x, dy)
+    w_krsc = w.permute(0, 2, 3, 1).numpy()
+
+    def wt_of(i):
+        cl, rc = classes[i], ref_cls[i]
+        assert (cl["TR"], cl["TS"], cl["dh0"], cl["dh_step"], cl["dw0"], cl["dw_step"], cl["w_off"]) == \
+               (rc["TR"], rc["TS"], rc["dh0"], rc["dh_step"], rc["dw0"], rc["dw_step"], rc["w_off"])
+        out = np.zeros((Cc, cl["TR"] * cl["TS"], K))   # dgrad operand image of the class: [C][taps][K]
+        for a in range(cl["TR"]):
+            for b in range(cl["TS"]):
+                out[:, a * cl["TS"] + b, :] = w_krsc[:, rc["r0"] + a * rc["r_step"], rc["s0"] + b * rc["s_step"], :].T
+        return out
+
+    P, Q = y.shape[2:]
+    got, hits = interpret(classes, dy.permute(0, 2, 3, 1).numpy(), wt_of, N, P, Q, 1, H, W, s, Cc)
+    assert (hits == 1).all()
+    np.testing.assert_allclose(got, gx.detach().permute(0, 2, 3, 1).numpy(), rtol=1e-10, atol=1e-10)
+
+
+def test_patch_plan_refuses_what_it_cannot_tile():
+    lib = L.load()
+    buf = (C.c_int32 * (4 * L.PATCH_CLASS_INTS))()
+    assert lib.cvhip_conv2d_patch_plan(C.byref(desc(2, 64, 40, 40, 64, 1, 1)), 0, buf, 4) == 0          # single tap
+    assert lib.cvhip_conv2d_patch_plan(C.byref(desc(2, 24, 40, 40, 64, 3, 3, (1, 1), (1, 1))), 0, buf, 4) == 0   # C % 32
+    assert lib.cvhip_conv2d_patch_plan(C.byref(desc(2, 64, 40, 40, 64, 3, 3, (2, 2), (1, 1))), 0, buf, 4) == 0   # stride-2 fprop
+    assert lib.cvhip_conv2d_patch_plan(C.byref(desc(2, 64, 8, 8, 64, 1, 1, (2, 2))), 1, buf, 4) == 0   # 1x1 s2 dgrad: empty classes
+    assert lib.cvhip_conv2d_fprop_prologue_ok(C.byref(desc(2, 64, 40, 40, 64, 3, 3, (1, 1), (1, 1))), 1) == 1
+    assert lib.cvhip_conv2d_fprop_prologue_ok(C.byref(desc(2, 64, 40, 40, 64, 3, 3, (1, 1), (0, 0))), 1) == 0   # not "same": no z_out
+    assert lib.cvhip_conv2d_fprop_prologue_ok(C.byref(desc(2, 64, 40, 40, 64, 3, 3, (1, 1), (0, 0))), 0) == 1
+    assert lib.cvhip_conv2d_fprop_prologue_ok(C.byref(desc(2, 64, 40, 40, 64, 1, 1)), 0) == 0
