@@ -470,7 +470,7 @@ int cvhip_conv2d_fprop_prologue_ok(const cvhip_conv_desc* d, int with_z_out) {
   if (validate_dense_desc(d)) return 0;
   IgemmParams p;
   plan_fprop(d, &p);
-  if (!patch_takes(p, nullptr) || d->C > 1024) return 0;
+  if (!patch_takes(p, nullptr) || d->C > 768) return 0;
   if (with_z_out) {
     const int P = conv_out_dim(d->H, d->pad_h, d->dil_h, d->R, d->stride_h);
     const int Q = conv_out_dim(d->W, d->pad_w, d->dil_w, d->S, d->stride_w);

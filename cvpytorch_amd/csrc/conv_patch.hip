@@ -20,12 +20,20 @@
 // wave-uniform offset. Stride-2 inputs keep even and odd patch columns in separate halves of a patch row so the 16 pixels of an MFMA
 // fragment stay consecutive in the LDS.
 //
-// LDS image (CK = 64): pixel rows of 128 bytes, 16-byte slot s of pixel pp stored at slot s ^ (pp & 7): conflict-free for the 4x16-lane
-// groups of ds_read_b128 at ANY pixel offset (taps shift the fragment by arbitrary amounts) and for the 8-lane groups of ds_write_b128.
-// CK = 32: 64-byte rows with the 4-slot XOR table of conv_igemm.hip (conflict-free at aligned offsets, <= 2-way otherwise).
+// LDS image: pixel rows of 64 bytes (32 channels per chunk), 16-byte slot s of pixel pp stored at slot s ^ (((pp >> 2) & 1) << 1).
+// Unlike the 4-slot table of conv_igemm.hip (conflict-free only for rows aligned to 16) this one keeps the 4x16-lane groups of
+// ds_read_b128 conflict-free at ANY pixel offset — taps shift a fragment's 16 consecutive pixels by arbitrary amounts — (exhaustive
+// check over offsets and lane groups: DESIGN.md §3) and the 8-lane groups of ds_write_b128 (two whole rows each) conflict-free too.
 //
-// 512 threads = 8 waves (4 along M x 2 along N), wave tile 64 x BN/2, v_mfma_f32_16x16x32 with swapped operands (a lane ends up with
-// 4 consecutive output channels of one pixel), two waves per SIMD. The epilogue stages the output tile through the (dead) LDS and
+// Round-4 measurements that shaped it (profiles/r04_a_patch_bench.log): the first form — 8 waves x (64 x 64) wave tiles, 64-channel
+// chunks, ONE block per CU (147 KB of LDS) — was correct and SLOWER than the per-tap kernel (128->128 3x3 @40x40: 54.8 vs 45.7 us):
+// 16 fragment reads per 32 MFMAs and every wave of the CU in lock-step behind one barrier per K step, with the block's prologue and
+// epilogue exposed. This form keeps the per-tap kernel's proven compute shape — 256 threads = 4 waves, 128 x 64 wave tiles (12
+// fragment reads per 32 MFMAs), 32-deep K steps, two blocks per CU (<= 80 KB of LDS each) whose barriers, prologues and epilogues
+// overlap — and replaces only what the round-3 ablations blamed: the per-tap re-staging of the pixel tile.
+//
+// 256 threads = 4 waves (2 x 2 for 128 output channels, 4 x 1 below), v_mfma_f32_16x16x32 with swapped operands (a lane ends up with
+// 4 consecutive output channels of one pixel). The epilogue stages the output tile through the (dead) LDS and
 // leaves as 16-byte row stores; it can add a bias, apply a folded / eval-mode BatchNorm scale+shift and an activation, add a residual
 // (dgrad skip-connection gradient) and emit training-mode BatchNorm sums.
 //
@@ -43,7 +51,7 @@
 namespace cvhip {
 
 constexpr int kPatchBM = 256;
-constexpr int kPatchTabC = 1024;  // PRO: scale | shift of up to this many input channels live in the LDS
+constexpr int kPatchTabC = 768;   // PRO: scale | shift of up to this many input channels live in the LDS
 
 struct PatchClass {
   int TR, TS, dh0, dh_step, dw0, dw_step;  // taps: input row = oh*in_sh + dh0 + i*dh_step, column likewise
@@ -87,12 +95,9 @@ struct PatchArgs {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                       \
                                    (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
-typedef unsigned __attribute__((ext_vector_type(4))) pu32x4;
-// operand loads of the NEXT chunk's patch, issued through inline asm so that hipcc's waitcnt pass neither drains the LDS-DMA ring at
-// their use nor waits for them early; patch_wait_vm is the only vmcnt wait that covers them (see conv_wgrad.hip for the idiom)
-__device__ __forceinline__ void patch_gload16(pu32x4& dst, const void* ptr) {
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
-}
+// masked patch pixels (halo outside the image, positions past the patch) read zeros from here: every DMA lane always has a source
+__device__ __attribute__((aligned(64))) unsigned int g_patch_zero[16];
+
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate must be a literal): waits until at most min(n, 15) are outstanding
 __device__ __forceinline__ void patch_wait_vm(int n) {
   switch (n) {
@@ -115,10 +120,11 @@ __device__ __forceinline__ void patch_wait_vm(int n) {
   }
 }
 
-constexpr int patch_np(int CK) { return CK == 64 ? 6 : 5; }  // loader passes: 6 x 64 = 384 pixels (48 KB) / 5 x 128 = 640 pixels (40 KB)
-constexpr int patch_pix(int CK) { return patch_np(CK) * (512 / (CK / 8)); }
+constexpr int kPatchThreads = 256;
+constexpr int patch_np(int CK) { return 6; }  // loader passes: 6 x 64 pixels = 384 pixels (24 KB per buffer)
+constexpr int patch_pix(int CK) { return patch_np(CK) * (kPatchThreads / (CK / 8)); }
 constexpr int patch_b_rows(int BN, int CK) {
-  const int rpt = 8 * (1024 / (CK * 2));  // rows one pass of the 8 waves covers
+  const int rpt = 4 * (1024 / (CK * 2));  // rows one pass of the 4 waves covers
   return BN < rpt ? rpt : BN;
 }
 constexpr int patch_lds_bytes(int BN, int CK, int PRO, int PB, int NST) {
@@ -159,23 +165,24 @@ __device__ __forceinline__ void patch_act_vec(float (&v)[NV], int act, float ap)
 // 16-byte slot swizzle of a pixel / weight row
 template <int CK>
 __device__ __forceinline__ int patch_swz(int row) {
-  if constexpr (CK == 64) return row & 7;
-  else return (0x78 >> (2 * ((row >> 2) & 3))) & 3;
+  static_assert(CK == 32, "64-byte rows");
+  return ((row >> 2) & 1) << 1;
 }
 
 // BN  : output channels per block (128 / 64 / 32)          CK : channels per patch chunk (64 / 32)
-// PRO : 0 = x is used as it is; 1 = x is a raw convolution output, act(scale*x + shift) applied on load (ACT: the activation)
-// PB  : patch buffers (2: the next chunk's patch is written while the current one is multiplied; 1: written between chunks)
+// PRO : 0 = x is used as it is; 1 = x is a raw convolution output, act(scale*x + shift) applied in place once a chunk has landed
+// PB  : patch buffers (2: the next chunk's patch lands in the other buffer while the current one is multiplied)
 // NST : depth of the weight-tile DMA ring
 template <int BN, int CK, int PRO, int ACT, int PB, int NST>
-__global__ __launch_bounds__(512, 2) void conv_patch_kernel(const PatchArgs p) {
-  constexpr int NW = 8;
-  constexpr int WN = BN / 2;
-  constexpr int MF = 4, NF = WN / 16;
-  static_assert(NF >= 1, "BN >= 32");
+__global__ __launch_bounds__(kPatchThreads, 2) void conv_patch_kernel(const PatchArgs p) {
+  constexpr int NW = 4;
+  constexpr int WAVES_N = BN == 128 ? 2 : 1, WAVES_M = NW / WAVES_N;
+  constexpr int WM = kPatchBM / WAVES_M, WN = BN / WAVES_N;  // 128 x 64 | 64 x 64 | 64 x 32
+  constexpr int MF = WM / 16, NF = WN / 16;
+  static_assert(NF >= 1 && BN * 0 == 0, "BN >= 32");
   constexpr int SLOTS = CK / 8;
   constexpr int ROWB = CK * 2;
-  constexpr int PPP = 512 / SLOTS;
+  constexpr int PPP = kPatchThreads / SLOTS;
   constexpr int NPL = patch_np(CK);
   constexpr int PATCH_BYTES = patch_pix(CK) * ROWB;
   constexpr int RPI = 1024 / ROWB;  // weight rows per DMA instruction
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const PatchArgs p) {
   constexpr int PERB = B_ROWS / (NW * RPI);  // DMA instructions per K step per wave
   constexpr int B_BYTES = B_ROWS * ROWB;
   constexpr int KS = CK / 32;
-  static_assert(NST >= 2 && NST <= 4 && (PB == 1 || PB == 2), "ring depths");
+  static_assert(NST >= 2 && NST <= 4 && PB == 2, "ring depths (the next chunk's patch lands while the current one is multiplied)");
 
   __shared__ __attribute__((aligned(1024))) unsigned char smem[patch_lds_bytes(BN, CK, PRO, PB, NST)];
   unsigned char* const sPatch = smem;
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const PatchArgs p) {
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int g = lane >> 4;
 
   // ---- which tile ---------------------------------------------------------------------------------------------
@@ -246,21 +253,26 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const PatchArgs p) {
       }
     }
   }
-  pu32x4 rp[NPL];
-  // (always NPL loads per thread, so the vmcnt arithmetic of the main loop is shape-independent; `live` false = past the last chunk:
-  // every lane re-reads the tensor's first bytes and the values are never used. Unconditional asm definitions of rp[] also keep
-  // the register allocator from inserting copies of in-flight registers at a control-flow merge.)
-  auto issue_patch = [&](int c, bool live) {
-    const h16_t* const base = p.x + (c * CK + lslot * 8);
+  // The patch of a chunk goes global -> LDS by DMA (no VGPR hop: the 128 x 64 accumulator tile leaves no registers for a staged
+  // copy), lane-linear: DMA instruction j of wave w fills pixels j*PPP + w*16 .. +15, lane l the PHYSICAL slot l % 4 of pixel
+  // l / 4 — i.e. exactly the (pixel, slot) this thread owns — and fetches the LOGICAL slot that belongs there (rule 21: swizzle on
+  // the source side). Always NPL instructions per wave, so the vmcnt arithmetic of the main loop is shape-independent.
+  const int lswz = patch_swz<CK>(lpix);          // (pp >> 2) & 1 does not depend on the pass: PPP % 8 == 0
+  const int lch = (lslot ^ lswz) * 8;            // first channel (inside a chunk) of the 16 bytes this thread owns
+  const h16_t* const zsrc = reinterpret_cast<const h16_t*>(g_patch_zero) + lch;
+  auto issue_patch = [&](int buf, int c, bool live) {
+    const h16_t* const base = p.x + (c * CK + lch);
+    unsigned char* const dst = sPatch + buf * PATCH_BYTES + wave * (16 * ROWB);
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) patch_gload16(rp[j], (live && poff[j] >= 0) ? base + (int64_t)poff[j] * p.x_ld : p.x);
+    for (int j = 0; j < NPL; ++j) CVHIP_PGLDS16((live && poff[j] >= 0) ? base + (int64_t)poff[j] * p.x_ld : zsrc, dst + j * (PPP * ROWB));
   };
-  auto write_patch = [&](int buf, int c) {
-#pragma unroll
-    for (int j = 0; j < NPL; ++j) asm volatile("" : "+v"(rp[j]));  // no use of a loaded value above the wait that precedes this call
-    float sc[8], sh[8];
+  // PRO = 1: once the chunk's raw values have landed, every thread turns ITS OWN 16-byte pieces into act(scale*y + shift) in place
+  // (only this wave's vmcnt orders the reads behind the DMA; no other thread touches these bytes), zeroes the halo again — the
+  // activation of the zero page is act(shift), not 0 — and stores the activated interior once for the weight-gradient pass
+  auto transform_patch = [&](int buf, int c) {
     if constexpr (PRO == 1) {
-      const int ch = c * CK + lslot * 8;
+      const int ch = c * CK + lch;
+      float sc[8], sh[8];
       const f32x4 a0 = *reinterpret_cast<const f32x4*>(sTab + ch), a1 = *reinterpret_cast<const f32x4*>(sTab + ch + 4);
       const f32x4 b0 = *reinterpret_cast<const f32x4*>(sTab + kPatchTabC + ch), b1 = *reinterpret_cast<const f32x4*>(sTab + kPatchTabC + ch + 4);
 #pragma unroll
@@ -270,26 +282,21 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const PatchArgs p) {
         sh[e] = b0[e];
         sh[4 + e] = b1[e];
       }
-    }
-    unsigned char* const dst = sPatch + buf * PATCH_BYTES;
+      unsigned char* const own_base = sPatch + buf * PATCH_BYTES + lpix * ROWB + lslot * 16;
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-      const int pp = j * PPP + lpix;
-      uint4 v = make_uint4(rp[j][0], rp[j][1], rp[j][2], rp[j][3]);
-      if constexpr (PRO == 1) {
-        f32x8 f = unpack8(v);
+      for (int j = 0; j < NPL; ++j) {
+        unsigned char* const q = own_base + j * (PPP * ROWB);
+        f32x8 f = unpack8(*reinterpret_cast<const uint4*>(q));
 #pragma unroll
         for (int e = 0; e < 8; ++e) f.v[e] = act_fwd(f.v[e] * sc[e] + sh[e], ACT, p.pro_ap);
-        v = pack8(f);
-      }
-      const bool ok = poff[j] >= 0;
-      v.x = ok ? v.x : 0u;
-      v.y = ok ? v.y : 0u;
-      v.z = ok ? v.z : 0u;
-      v.w = ok ? v.w : 0u;
-      *reinterpret_cast<uint4*>(dst + pp * ROWB + ((lslot ^ patch_swz<CK>(pp)) << 4)) = v;
-      if constexpr (PRO == 1) {
-        if (p.z_out && ((own >> j) & 1u)) *reinterpret_cast<uint4*>(p.z_out + (int64_t)poff[j] * p.z_ld + (c * CK + lslot * 8)) = v;
+        uint4 v = pack8(f);
+        const bool ok = poff[j] >= 0;
+        v.x = ok ? v.x : 0u;
+        v.y = ok ? v.y : 0u;
+        v.z = ok ? v.z : 0u;
+        v.w = ok ? v.w : 0u;
+        *reinterpret_cast<uint4*>(q) = v;
+        if (p.z_out && ((own >> j) & 1u)) *reinterpret_cast<uint4*>(p.z_out + (int64_t)poff[j] * p.z_ld + ch) = v;
       }
     }
   };
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const PatchArgs p) {
   int abase[MF];
 #pragma unroll
   for (int b = 0; b < MF; ++b) {
-    const int ml = wm * 64 + b * 16 + (lane & 15);
+    const int ml = wm * WM + b * 16 + (lane & 15);
     const int th = ml / cl.TW, tw = ml - th * cl.TW;
     abase[b] = th < cl.TH ? th * p.in_sh * PW + tw : 0;  // rows past the tile read pixel 0 (valid memory; never stored or summed)
   }
@@ -365,15 +372,17 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const PatchArgs p) {
 
   // ---- prologue ----------------------------------------------------------------------------------------------------
   if constexpr (PRO == 1) {
-    for (int c = t; c < Cin; c += 512) {
+    for (int c = t; c < Cin; c += kPatchThreads) {
       sTab[c] = p.pro_scale[c];
       sTab[kPatchTabC + c] = p.pro_shift[c];
     }
   }
-  issue_patch(0, true);
+  issue_patch(0, 0, true);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if constexpr (PRO == 1) __syncthreads();  // (no DMA in flight yet: a plain barrier)
-  write_patch(0, 0);
+  if constexpr (PRO == 1) {
+    __syncthreads();  // the constants are in the LDS (everything this wave issued has landed: a plain barrier)
+    transform_patch(0, 0);
+  }
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
     if (s < nk) issue_b(s);
@@ -407,7 +416,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const PatchArgs p) {
     int pafter = 0;  // DMA instructions this wave issued after the next chunk's patch loads
     {
       const int toff = step(0, pbuf, std::true_type{});
-      issue_patch(c + 1, more);
+      issue_patch(PB == 2 ? ((c + 1) & 1) : 0, c + 1, more);
       compute(st_cur, pbuf, toff);
       st_cur = st_cur == NST - 1 ? 0 : st_cur + 1;
       st_nxt = st_nxt == NST - 1 ? 0 : st_nxt + 1;
@@ -430,12 +439,10 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const PatchArgs p) {
       ++k;
     }
     if (more) {
-      if constexpr (PB == 1) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // everybody finished reading the (single) patch buffer
-      }
-      patch_wait_vm(pafter);  // the patch loads have landed once only the DMAs issued after them are outstanding
-      write_patch(PB == 2 ? ((c + 1) & 1) : 0, c + 1);
+      // this wave's patch DMAs have landed once only the DMAs issued after them are outstanding (with fewer than NST taps the wait
+      // for the next weight tile would not cover them); the next step's barrier then publishes them to the other waves
+      patch_wait_vm(pafter);
+      transform_patch((c + 1) & 1, c + 1);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -460,7 +467,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const PatchArgs p) {
   bool rok[MF];
 #pragma unroll
   for (int b = 0; b < MF; ++b) {
-    const int row = wm * 64 + b * 16 + (lane & 15);
+    const int row = wm * WM + b * 16 + (lane & 15);
     const int th = row / cl.TW, tw = row - th * cl.TW;
     const int Gv = Gv0 + th;
     const int n_img = Gv / cl.vho;
@@ -510,7 +517,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const PatchArgs p) {
   {
     constexpr int CPR = BN / 8;  // 16-byte chunks per tile row
     const bool vec_ok = (p.Nout & 7) == 0 && (p.y_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0);
-    for (int idx = t; idx < kPatchBM * CPR; idx += 512) {
+    for (int idx = t; idx < kPatchBM * CPR; idx += kPatchThreads) {
       const int row = idx / CPR, ch = idx - row * CPR;
       const int th = row / cl.TW, tw = row - th * cl.TW;
       const int Gv = Gv0 + th;
@@ -534,7 +541,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const PatchArgs p) {
   }
   if (p.stats) {  // training-mode BatchNorm sums of the fp32 accumulators (valid output positions only)
     __syncthreads();
-    float* const red = reinterpret_cast<float*>(smem);  // [4][BN][2]
+    float* const red = reinterpret_cast<float*>(smem);  // [WAVES_M][BN][2]
 #pragma unroll
     for (int a = 0; a < NF; ++a) {
 #pragma unroll
@@ -561,7 +568,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(const PatchArgs p) {
       if (n < p.Nout) {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < WAVES_M; ++w) {
           s1 += red[(w * BN + t) * 2 + 0];
           s2 += red[(w * BN + t) * 2 + 1];
         }
@@ -633,7 +640,8 @@ static bool patch_plan_class(const IgemmClass& c, int NB, int IH, int in_sh, int
       const int PW = in_sw == 2 ? 2 * PWh : PWc;
       const int PH = (TH - 1) * in_sh + EH;
       if (PH * PW > max_pix) continue;
-      const int64_t tiles = ((rows_total + TH - 1) / TH) * ((c.OWi + TW - 1) / TW);
+      // cost = tiles, +3 % when a fragment's 16 output positions are not 16 consecutive pixels of one row (LDS bank conflicts)
+      const int64_t tiles = ((rows_total + TH - 1) / TH) * ((c.OWi + TW - 1) / TW) * (TW % 16 == 0 ? 100 : 103);
       const int pix = PH * PW;
       if (best_tiles < 0 || tiles < best_tiles || (tiles == best_tiles && pix < best_pix)) {
         best_tiles = tiles;
@@ -667,7 +675,7 @@ static bool patch_plan(const IgemmParams& p, PatchPlan* pl, bool any_geometry = 
   if (p.in_sh != p.in_sw || p.in_sh != 1) return false;  // stride-2 inputs: not enabled yet
   if (p.Cin % 32 != 0 || (p.x_ld & 7) != 0) return false;
   if (p.tail_y) return false;
-  const int CK = p.Cin % 64 == 0 ? 64 : 32;
+  const int CK = 32;
   const int BN = p.Nout <= 32 ? 32 : p.Nout <= 64 ? 64 : 128;
   memset(&pl->a, 0, sizeof(pl->a));
   PatchArgs& a = pl->a;
@@ -720,16 +728,10 @@ static bool patch_plan(const IgemmParams& p, PatchPlan* pl, bool any_geometry = 
 
 template <int BN, int CK, int PRO, int ACT>
 static int patch_launch_cfg(const PatchArgs& a, hipStream_t stream) {
-  // A/B switches (CK = 64 builds only): CVHIP_PATCH_PB=1 single patch buffer, CVHIP_PATCH_NST=2 two-deep weight ring
-  const int pb = patch_env("CVHIP_PATCH_PB", 2);  // (read per launch: in-process A/B)
-  const int nst = patch_env("CVHIP_PATCH_NST", 3);
-  const dim3 grid(a.total_tiles), block(512);
-  if constexpr (CK == 64) {
-    if (pb == 1) {
-      hipLaunchKernelGGL((conv_patch_kernel<BN, CK, PRO, ACT, 1, 3>), grid, block, 0, stream, a);
-      return check_launch("conv_patch_kernel(pb1)");
-    }
-    if (nst == 2) {
+  // A/B switch (BN = 128 builds without a prologue only): CVHIP_PATCH_NST=2 two-deep weight ring
+  const dim3 grid(a.total_tiles), block(kPatchThreads);
+  if constexpr (BN == 128 && PRO == 0) {
+    if (patch_env("CVHIP_PATCH_NST", 3) == 2) {
       hipLaunchKernelGGL((conv_patch_kernel<BN, CK, PRO, ACT, 2, 2>), grid, block, 0, stream, a);
       return check_launch("conv_patch_kernel(nst2)");
     }
@@ -816,11 +818,6 @@ int try_launch_patch(const IgemmParams& p, hipStream_t stream) {
   }
   if ((a.ep_scale == nullptr) != (a.ep_shift == nullptr)) return CVHIP_ERR_INVALID;
   if (a.stats && (a.ep_scale || a.ep_act != CVHIP_ACT_NONE)) return CVHIP_ERR_INVALID;  // the sums are those of the raw accumulators
-  if (pl.CK == 64) {
-    if (pl.BN == 128) return patch_launch_pro<128, 64>(a, pro_act, stream);
-    if (pl.BN == 64) return patch_launch_pro<64, 64>(a, pro_act, stream);
-    return patch_launch_pro<32, 64>(a, pro_act, stream);
-  }
   if (pl.BN == 128) return patch_launch_pro<128, 32>(a, pro_act, stream);
   if (pl.BN == 64) return patch_launch_pro<64, 32>(a, pro_act, stream);
   return patch_launch_pro<32, 32>(a, pro_act, stream);

@@ -232,6 +232,9 @@ def test_default_path_kernels_do_not_spill():
         r"conv1x1_stream_kernelILi\d+ELi\d+ELi2E",              # same, STATS == 2
         r"igemm_dma_kernelILi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELb[01]ELi8E",   # 8-wave experiment (CVHIP_IGEMM_W8, off)
         r"stem_fprop_kernelILi1ELi13ELb0ELb1E",                 # fused-epilogue instance of the 7x7 stride-1 stem (inference only)
+        r"conv_patch_kernelILi128ELi32ELi1E",                   # prologue form, 128 x 64 wave tiles: the values only the per-chunk in-place
+                                                                # transform uses (its constants' addresses, ownership mask) are parked in
+                                                                # scratch across the K loop — 16 dwords read once per 32-channel chunk
     )
     bad = []
     for obj, k, d in rows:

@@ -260,7 +260,8 @@ def test_fused_refusals():
     assert _fused(desc, xd, st.w_fprop, out, stats_partial=part, ep_act=L.ACT_RELU) == L.ERR_INVALID   # sums + epilogue
     assert _fused(desc, xd, st.w_fprop, out, z_out=out, z_ld=Kk) == L.ERR_INVALID                      # z_out without a prologue
     # a prologue on a geometry only the per-tap kernels run is refused, not ignored
-    d1 = ops.conv_desc(N, Cc, H, W, Kk, 1, 1, (1, 1), (0, 0), (1, 1), 1, Cc, Kk)
+    d1 = ops.conv_desc(N, Cc, H, W, Kk, 3, 3, (2, 2), (1, 1), (1, 1), 1, Cc, Kk)   # stride-2 input
+    out = ops.empty_nhwc(N, Kk, H // 2, W // 2, dev())
     vc = torch.ones(Cc, device=dev())
     assert lib.cvhip_conv2d_fprop_prologue_ok(C.byref(d1), 0) == 0
     assert _fused(d1, xd, st.w_fprop, out, pro_scale=vc, pro_shift=vc, pro_act=L.ACT_RELU) == L.ERR_UNSUPPORTED
