@@ -78,6 +78,15 @@ def main():
     def record(name, build):
         m_hip, m_ref = build(HIPCFG), build(STOCK)
         bad = leaves_are_hip(m_hip, hip)
+        threaded = True
+        if bad:
+            # the reference does not thread conv_cfg everywhere (YOLOv5CSPDarknet.build_stem_layer / build_stage_layer pass only
+            # norm_cfg / act_cfg to ConvModule: yolov5_csp_darknet.py:38-61): norm and activation layers came out of the registries as
+            # Hip layers, the convolutions as nn.Conv2d. INTEGRATION.md §1 + §2: one convert_to_hip() call swaps what is left.
+            assert all(cls == "Conv2d" for _, cls in bad), (name, bad[:5])
+            threaded = False
+            m_hip = hip.convert_to_hip(m_hip)
+            bad = leaves_are_hip(m_hip, hip)
         assert not bad, (name, bad[:5])
         assert keys(m_hip) == keys(m_ref), name                     # same checkpoint layout as the stock build
         stock_tree, hip_tree = tree(m_ref), tree(m_hip)
@@ -86,10 +95,11 @@ def main():
         for mod in m_hip.modules():
             if isinstance(mod, hip.HipBN):
                 assert abs(mod.momentum - 0.03) < 1e-12 and abs(mod.eps - 0.001) < 1e-12
-        report[name] = dict(tree=hip_tree, stock_tree=stock_tree, state_dict=keys(m_hip))
+        report[name] = dict(tree=hip_tree, stock_tree=stock_tree, state_dict=keys(m_hip), conv_cfg_threaded=threaded)
         print("%-28s %4d modules, %4d state_dict entries, %d Hip conv / %d Hip BN / %d Hip act leaves" % (
             name, len(hip_tree), len(report[name]["state_dict"]), sum(isinstance(x, hip.HipConv2d) for x in m_hip.modules()),
-            sum(isinstance(x, hip.HipBN) for x in m_hip.modules()), sum(isinstance(x, hip._HipAct) for x in m_hip.modules())))
+            sum(isinstance(x, hip.HipBN) for x in m_hip.modules()), sum(isinstance(x, hip._HipAct) for x in m_hip.modules())) +
+              ("" if threaded else "   [conv_cfg not threaded by the reference: convert_to_hip() swapped the convolutions]"))
 
     record("convmodule_3x3", lambda c: ConvModule(32, 64, 3, stride=2, padding=1, **c))
     record("csplayer_64_n2", lambda c: CSPLayer(64, 64, n=2, shortcut=True, **c))
@@ -112,15 +122,11 @@ def main():
         report[name] = dict(tree=tree(swapped), stock_tree=before_tree, state_dict=keys(swapped))
         print("%-28s %4d modules, %4d state_dict entries (convert_to_hip)" % (name, len(before_tree), len(before_keys)))
 
-    anchors = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]
+    # (num_layers, num_anchors, 2), as models/yolov5.py hands them to the detect layer
+    anchors = [[[10, 13], [16, 30], [33, 23]], [[30, 61], [62, 45], [59, 119]], [[116, 90], [156, 198], [373, 326]]]
     record_swap("yolov5_detect_s", YOLOv5Detect(num_classes=80, in_channels=[256, 512, 1024], anchors=anchors, depth_mul=0.33, width_mul=0.5))
     record_swap("stdcnet_stdc1", STDCNet(subtype='stdc1'))
-    try:
-        head = Deeplabv3PlusHead(num_classes=19, in_channels=2048, c1_in_channels=256, c1_channels=48, channels=512, dilations=(1, 12, 24, 36))
-    except TypeError:
-        import inspect
-        print("Deeplabv3PlusHead signature:", inspect.signature(Deeplabv3PlusHead.__init__))
-        raise
+    head = Deeplabv3PlusHead(low_in_channels=256, low_channels=48, num_classes=19, in_channels=2048, channels=512, dilations=(1, 12, 24, 36))
     record_swap("deeplabv3plus_head", head)
 
     os.makedirs(OUT, exist_ok=True)
