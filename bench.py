@@ -453,6 +453,53 @@ def h2d_leg(model, state, a, dev, imgs_f32, gts, steps):
             "final_loss": round(float(losses["loss"]), 4)}
 
 
+def infer_leg(dev, a, steps, warmup):
+    """Forward only, eval mode, BatchNorm folded (deploy.fuse_model = utils/fuse.py:32-64): every ConvModule is ONE launch — conv +
+    bias + activation (+ residual) in the convolution's epilogue (cvhip_conv2d_fprop_fused) — followed by the detect decode; NMS
+    (data-dependent lengths) is outside. One hipGraph replay per batch. Also counts, in an eager pass, the BN / activation
+    element-wise launches that are left (the fused epilogue's point is that there are none)."""
+    from cvpytorch_amd import deploy, ops, yolov5
+    from cvpytorch_amd.data import synthetic_detection_batch
+    model = yolov5.YOLOv5(80, "s", fused_loss=True).to(dev).eval()
+    deploy.fuse_model(model)
+    imgs, _ = synthetic_detection_batch(a.batch, a.size, seed=7, device=dev)
+    x = ops.images_to_nhwc(imgs, cpad=8)
+    with torch.no_grad():
+        for _ in range(max(2, warmup)):
+            out, _raw = model.forward_features(x)
+        torch.cuda.synchronize()
+        ops.TIMER.enabled = True
+        ops.TIMER.reset()
+        model.forward_features(x)
+        torch.cuda.synchronize()
+        ops.TIMER.enabled = False
+        names = [r[0] for r in ops.TIMER.records]
+        ew = sum(1 for n in names if "ew_kernel" in n or "bn_act" in n)
+        convs = sum(1 for n in names if n == "conv_fused_inference")
+        ops.TIMER.reset()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            model.forward_features(x)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=s):
+                out, _raw = model.forward_features(x)
+        torch.cuda.current_stream().wait_stream(s)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.replay()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    return {"value": round(a.batch * steps / el, 2), "unit": "images/sec", "ms_per_batch": round(1e3 * el / steps, 3), "steps": steps,
+            "workload": "YOLOv5-s %dx%d bf16 forward + decode, batch %d, eval mode, BatchNorm folded (deploy.fuse_model)" % (a.size, a.size, a.batch),
+            "launch": "hipGraph replay", "fused_conv_launches": convs, "bn_act_elementwise_launches": ew,
+            "finite": bool(torch.isfinite(out).all())}
+
+
 class _Watchdog:
     """Never lose the headline line to a side leg that hangs (a collective one rank never joins, a wedged kernel): if `budget_s`
     pass before `done()`, rank 0 prints what it has — with the unfinished legs marked — and every rank exits."""
@@ -686,6 +733,12 @@ def main():
             except Exception as e:  # the headline line must still be printed
                 out["with_h2d"] = {"error": repr(e)[:300]}
         side_steps, side_warm = max(a.steps, 20), max(a.warmup, 3)
+        if not a.no_extra:
+            try:
+                out["infer"] = infer_leg(dev, a, side_steps, side_warm)
+            except Exception as e:
+                out["infer"] = {"error": repr(e)[:300]}
+            torch.cuda.empty_cache()
         if not a.no_deeplab:
             try:
                 out["config3_deeplabv3plus_r50"] = deeplab_workload(dev, a, steps=side_steps, warmup=side_warm)

@@ -59,9 +59,17 @@ def paired_arena_order(items, follow):
 class FlatTrainState:
     def __init__(self, model, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4, backbone_lr=None, ema_decay=0.9999,
                  use_ema=True, bucket_bytes=8 << 20, process_group=None, comm=None, force_collectives=False, loss_scaling=None,
-                 init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+                 init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, optimizer="sgd", betas=(0.9, 0.999),
+                 eps=1e-8):
+        """optimizer: "sgd" (momentum / nesterov: src/optimizers/__init__.py:60-68) or "adamw" (decoupled weight decay,
+        src/optimizers/__init__.py:71-73 — what conf/mini-imagenet.yml:91-99 trains config 1 with): both are ONE fused kernel over the
+        flat arenas with the EMA update folded in."""
         self.model = model
         self.momentum, self.nesterov = float(momentum), bool(nesterov)
+        self.optimizer = str(optimizer).lower()
+        if self.optimizer not in ("sgd", "adamw"):
+            raise L.CvhipError("FlatTrainState: optimizer must be 'sgd' or 'adamw'")
+        self.betas, self.adam_eps = (float(betas[0]), float(betas[1])), float(eps)
         groups = build_param_groups(model, lr, backbone_lr, weight_decay)
         hyper = {id(g["params"][0]): (g["lr"], g["weight_decay"]) for g in groups}
         # sibling layers that train as one convolution (ops.ConvBnActPair) need their tensors back to back: reorder so that the
@@ -94,7 +102,9 @@ class FlatTrainState:
         self.offsets, self.total = offs, total
         self.param = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.mom = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.mom = torch.zeros(total, dtype=torch.float32, device=dev)      # SGD momentum buffer / AdamW exp_avg
+        self.mom2 = torch.zeros(total, dtype=torch.float32, device=dev) if self.optimizer == "adamw" else None   # AdamW exp_avg_sq
+        self.adam_step = torch.zeros(1, dtype=torch.float32, device=dev)     # AdamW step count t, advanced on the device
         self.index = {}
         for i, (p, off) in enumerate(zip(self.params, offs)):
             v = _dense_view(self.param, off, p)
@@ -223,13 +233,14 @@ class FlatTrainState:
         per = 2 * L.BN_ACC_SHARDS * 2
         self.stat_acc = torch.zeros(sum(k for _, _, k in want) * per, dtype=torch.float64, device=dev)
         o = 0
+        self._acc_epoch = [0]   # this state's own "accumulators zeroed" counter (ops._layer_acc)
         for m, attr, k in want:
-            m.__dict__[attr] = [self.stat_acc[o:o + per * k].view(2, L.BN_ACC_SHARDS, 2, k), -1]
+            m.__dict__[attr] = [self.stat_acc[o:o + per * k].view(2, L.BN_ACC_SHARDS, 2, k), -1, self._acc_epoch, id(m)]
             o += per * k
         if self.world > 1:
             # DistributedDataParallel broadcasts rank 0's parameters and buffers when it wraps the model (trainer.py:312-313):
             # replicas that start from different weights would train apart silently, because only gradients are averaged
-            for t in (self.param, self.mom, self.buf):
+            for t in (self.param, self.mom, self.buf) + ((self.mom2,) if self.mom2 is not None else ()):
                 if t.numel():
                     self.comm.broadcast_(t, 0)
             self.comm.wait()
@@ -309,7 +320,7 @@ class FlatTrainState:
         """one launch zeroes every layer's BatchNorm statistic accumulators for the next step"""
         if self.stat_acc.numel():
             ops.zero_fill(self.stat_acc)
-        ops.bump_acc_epoch()
+        self._acc_epoch[0] += 1
 
     def backward(self, loss):
         """scaler.scale(loss).backward() with a PRE-ALLOCATED seed gradient: autograd's implicit ones_like(loss) is an ATen fill
@@ -357,6 +368,12 @@ class FlatTrainState:
             g, b, iv = self.ls_hyper
             L.call("cvhip_loss_scale_check", self.grad.data_ptr(), self.total, self.ls_state.data_ptr(), st)
             L.call("cvhip_loss_scale_update", self.ls_state.data_ptr(), self.ls_dyn.data_ptr(), g, b, iv, st)
+        if self.optimizer == "adamw":
+            L.call("cvhip_adamw_ema", self.param.data_ptr(), self.grad.data_ptr(), self.mom.data_ptr(), self.mom2.data_ptr(), ema_ptr, self.total,
+                   self.seg_bounds.data_ptr(), self.seg_lr.data_ptr(), self.seg_wd.data_ptr(), len(self.params), self.betas[0], self.betas[1],
+                   self.adam_eps, self.adam_step.data_ptr(), 0.0, 1.0 / self.world, self.dyn.data_ptr(),
+                   self.ls_dyn.data_ptr() if self.loss_scaling else None, st)
+        elif self.loss_scaling:
             L.call("cvhip_sgd_nesterov_ema_scaled", self.param.data_ptr(), self.grad.data_ptr(), self.mom.data_ptr(), ema_ptr, self.total,
                    self.seg_bounds.data_ptr(), self.seg_lr.data_ptr(), self.seg_wd.data_ptr(), len(self.params), self.momentum,
                    int(self.nesterov), 0, 0.0, 1.0 / self.world, self.dyn.data_ptr(), self.ls_dyn.data_ptr(), st)

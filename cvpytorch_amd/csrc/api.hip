@@ -463,6 +463,11 @@ int cvhip_conv2d_fprop_fused(const cvhip_conv_desc* d, const void* x, const void
   p.pro_ap = f->pro_act_param;
   p.z_out = (h16_t*)f->z_out;
   p.z_ld = f->z_ld;
+  if (f->residual) {
+    if (f->residual_ld < d->K) return CVHIP_ERR_INVALID;
+    p.res = (const h16_t*)f->residual;
+    p.res_ld = f->residual_ld;
+  }
   return launch_igemm(p, (hipStream_t)stream);
 }
 

@@ -61,6 +61,7 @@ struct PatchClass {
   int TH, TW;                              // tile: virtual output rows x output columns
   int PH, PW, PWh, PWc;                    // patch rows, row pitch (pixels), half pitch (stride-2 de-interleave), valid columns
   int vho;                                 // virtual output rows per image
+  int per_image;                           // 1: vho is a multiple of TH — tiles never span images, patch rows outside the image are zero
   int tiles_w;                             // column tiles per row band
   int tile_begin;                          // first logical tile of the class
   int64_t w_off;
@@ -88,6 +89,7 @@ struct PatchArgs {
   const float *ep_scale, *ep_shift;
   int ep_act;
   float ep_ap;
+  unsigned long long* dbg;  // census (dev tool): per block {HW_ID, XCC_ID, start, end} when non-null
   PatchClass cls[kKernelClasses];
 };
 
@@ -120,15 +122,29 @@ __device__ __forceinline__ void patch_wait_vm(int n) {
   }
 }
 
-constexpr int kPatchThreads = 256;
-constexpr int patch_np(int CK) { return 6; }  // loader passes: 6 x 64 pixels = 384 pixels (24 KB per buffer)
+template <int N>
+__device__ __forceinline__ void patch_wait_lit() {
+  static_assert(N >= 0 && N <= 8, "vmcnt literal table");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+
+constexpr int kPatchThreads = 512;
+constexpr int patch_np(int CK) { return 3; }  // loader passes: 3 x 128 pixels = 384 pixels (24 KB per buffer)
 constexpr int patch_pix(int CK) { return patch_np(CK) * (kPatchThreads / (CK / 8)); }
 constexpr int patch_b_rows(int BN, int CK) {
-  const int rpt = 4 * (1024 / (CK * 2));  // rows one pass of the 4 waves covers
+  const int rpt = (kPatchThreads / 64) * (1024 / (CK * 2));  // rows one pass of the block's waves covers
   return BN < rpt ? rpt : BN;
 }
-constexpr int patch_lds_bytes(int BN, int CK, int PRO, int PB, int NST) {
-  const int ring = PB * patch_pix(CK) * CK * 2 + NST * patch_b_rows(BN, CK) * CK * 2 + (PRO ? 2 * kPatchTabC * 4 : 0);
+constexpr int patch_lds_bytes(int BN, int CK, int PRO, int PB, int NST, int TPS) {
+  const int ring = PB * patch_pix(CK) * CK * 2 + NST * TPS * patch_b_rows(BN, CK) * CK * 2 + (PRO ? 2 * kPatchTabC * 4 : 0);
   const int epi = 5 * BN * 4 + kPatchBM * (BN * 2 + 16);  // constants + staged output tile
   return ring > epi ? ring : epi;
 }
@@ -173,11 +189,12 @@ __device__ __forceinline__ int patch_swz(int row) {
 // PRO : 0 = x is used as it is; 1 = x is a raw convolution output, act(scale*x + shift) applied in place once a chunk has landed
 // PB  : patch buffers (2: the next chunk's patch lands in the other buffer while the current one is multiplied)
 // NST : depth of the weight-tile DMA ring
-template <int BN, int CK, int PRO, int ACT, int PB, int NST>
-__global__ __launch_bounds__(kPatchThreads, 2) void conv_patch_kernel(const PatchArgs p) {
-  constexpr int NW = 4;
+// TPS : taps per K step / barrier (1, or 2: 64-deep steps — half the barriers per MFMA; the weight ring then holds 2-tap slots)
+template <int BN, int CK, int PRO, int ACT, int PB, int NST, int TPS = 1>
+__global__ __launch_bounds__(kPatchThreads, 4) void conv_patch_kernel(const PatchArgs p) {
+  constexpr int NW = kPatchThreads / 64;
   constexpr int WAVES_N = BN == 128 ? 2 : 1, WAVES_M = NW / WAVES_N;
-  constexpr int WM = kPatchBM / WAVES_M, WN = BN / WAVES_N;  // 128 x 64 | 64 x 64 | 64 x 32
+  constexpr int WM = kPatchBM / WAVES_M, WN = BN / WAVES_N;  // 64 x 64 | 32 x 64 | 32 x 32
   constexpr int MF = WM / 16, NF = WN / 16;
   static_assert(NF >= 1 && BN * 0 == 0, "BN >= 32");
   constexpr int SLOTS = CK / 8;
@@ -188,19 +205,22 @@ __global__ __launch_bounds__(kPatchThreads, 2) void conv_patch_kernel(const Patc
   constexpr int RPI = 1024 / ROWB;  // weight rows per DMA instruction
   constexpr int B_ROWS = patch_b_rows(BN, CK);
   constexpr int PERB = B_ROWS / (NW * RPI);  // DMA instructions per K step per wave
-  constexpr int B_BYTES = B_ROWS * ROWB;
+  constexpr int B_BYTES = B_ROWS * ROWB;     // one tap's weight tile
+  constexpr int SLOT_BYTES = TPS * B_BYTES;  // one ring slot = the tiles of one K step
+  constexpr int PERS = TPS * PERB;           // DMA instructions per K step per wave
   constexpr int KS = CK / 32;
   static_assert(NST >= 2 && NST <= 4 && PB == 2, "ring depths (the next chunk's patch lands while the current one is multiplied)");
 
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[patch_lds_bytes(BN, CK, PRO, PB, NST)];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[patch_lds_bytes(BN, CK, PRO, PB, NST, TPS)];
   unsigned char* const sPatch = smem;
   unsigned char* const sB = smem + PB * PATCH_BYTES;
-  float* const sTab = reinterpret_cast<float*>(sB + NST * B_BYTES);  // PRO: [scale | shift][kPatchTabC]
+  float* const sTab = reinterpret_cast<float*>(sB + NST * SLOT_BYTES);  // PRO: [scale | shift][kPatchTabC]
 
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const unsigned long long dbg_t0 = p.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
   const int g = lane >> 4;
 
   // ---- which tile ---------------------------------------------------------------------------------------------
@@ -225,7 +245,8 @@ __global__ __launch_bounds__(kPatchThreads, 2) void conv_patch_kernel(const Patc
   const int T = cl.TR * cl.TS;
   const int Cin = p.Cin;
   const int NC = Cin / CK;
-  const int nk = T * NC;
+  const int SPC = (T + TPS - 1) / TPS;  // K steps per chunk
+  const int nk = SPC * NC;
   const int Ktot = T * Cin;
   const int PW = cl.PW;
 
@@ -242,7 +263,7 @@ __global__ __launch_bounds__(kPatchThreads, 2) void conv_patch_kernel(const Patc
       const int q = pp - pr * PW;
       const int pc = p.in_sw == 2 ? (q < cl.PWh ? 2 * q : 2 * (q - cl.PWh) + 1) : q;
       const int V = V0 + pr;
-      const int n = V / pitch;
+      const int n = cl.per_image ? Gv0 / cl.vho : V / pitch;  // (per-image tiles: a row past the bottom must not wrap into image n + 1)
       const int ih = V - n * pitch + cl.lo_h;
       const int iw = col0 + pc;
       const bool ok = pp < npix && pc < cl.PWc && n < p.NB && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
@@ -314,25 +335,30 @@ __global__ __launch_bounds__(kPatchThreads, 2) void conv_patch_kernel(const Patc
       bsrc[i] = wbase + ((int64_t)n * Ktot + ls * 8);
     }
   }
-  int nb_c = 0, nb_t = 0;  // (chunk, tap) of the next weight tile to stage: K step = chunk * T + tap
+  int nb_c = 0, nb_t = 0;  // (chunk, first tap) of the next K step to stage
   auto issue_b = [&](int st) {
-    const int off = nb_t * Cin + nb_c * CK;
-    unsigned char* const dst = sB + st * B_BYTES;
+    unsigned char* const dst = sB + st * SLOT_BYTES;
 #pragma unroll
-    for (int i = 0; i < PERB; ++i) CVHIP_PGLDS16(bsrc[i] + off, dst + (i * NW * RPI + wave * RPI) * ROWB);
-    if (++nb_t == T) {
+    for (int u = 0; u < TPS; ++u) {
+      const int tap = nb_t + u < T ? nb_t + u : nb_t;  // an odd tap count's last step stages its one tap twice (uniform DMA count)
+      const int off = tap * Cin + nb_c * CK;
+#pragma unroll
+      for (int i = 0; i < PERB; ++i) CVHIP_PGLDS16(bsrc[i] + off, dst + u * B_BYTES + (i * NW * RPI + wave * RPI) * ROWB);
+    }
+    nb_t += TPS;
+    if (nb_t >= T) {
       nb_t = 0;
       ++nb_c;
     }
   };
 
   // ---- fragment geometry ------------------------------------------------------------------------------------------
-  int abase[MF];
+  int abase[MF];  // BYTE address of (this lane's pixel, logical slot g) before the swizzle
 #pragma unroll
   for (int b = 0; b < MF; ++b) {
     const int ml = wm * WM + b * 16 + (lane & 15);
     const int th = ml / cl.TW, tw = ml - th * cl.TW;
-    abase[b] = th < cl.TH ? th * p.in_sh * PW + tw : 0;  // rows past the tile read pixel 0 (valid memory; never stored or summed)
+    abase[b] = (th < cl.TH ? th * p.in_sh * PW + tw : 0) * ROWB + (g << 4);  // rows past the tile read pixel 0 (never stored or summed)
   }
   int baddr[NF];
 #pragma unroll
@@ -347,14 +373,15 @@ __global__ __launch_bounds__(kPatchThreads, 2) void conv_patch_kernel(const Patc
 #pragma unroll
     for (int b = 0; b < MF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto compute = [&](int st, int pbuf, int toff) __attribute__((always_inline)) {
+  auto compute = [&](int st, int u, int pbuf, int toff) __attribute__((always_inline)) {
     const unsigned char* const sA = sPatch + pbuf * PATCH_BYTES;
-    const unsigned char* const sBt = sB + st * B_BYTES;
+    const unsigned char* const sBt = sB + st * SLOT_BYTES + u * B_BYTES;
+    // swizzle of 64-byte rows: slot ^= 2 * bit 2 of the pixel index = byte-address bit 5 ^= byte-address bit 8
     int aaddr[MF];
 #pragma unroll
     for (int b = 0; b < MF; ++b) {
-      const int pp = abase[b] + toff;
-      aaddr[b] = pp * ROWB + ((g ^ patch_swz<CK>(pp)) << 4);
+      const int u = abase[b] + toff * ROWB;
+      aaddr[b] = u ^ ((u >> 3) & 32);
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -387,60 +414,65 @@ __global__ __launch_bounds__(kPatchThreads, 2) void conv_patch_kernel(const Patc
   for (int s = 0; s < NST - 1; ++s)
     if (s < nk) issue_b(s);
 
-  // ---- main loop: chunk-major, taps inside ---------------------------------------------------------------------------
-  // Per-wave VMEM queue, oldest first, at the top of K step k = c*T + tt: [weight tile k] [tiles k+1 .. k+NST-2] and, for
-  // 1 <= tt <= NST-1, the NPL patch loads of chunk c+1 (issued in step c*T right after tile c*T + NST - 1). Loads return in
-  // order, so "at most (younger instructions) outstanding" means tile k has landed.
+  // ---- main loop: chunk-major, K steps of TPS taps inside ------------------------------------------------------------
+  // Per-wave VMEM queue, oldest first, at the top of K step k (step si of chunk c): [weight tiles of step k] [steps k+1 .. k+NST-2]
+  // and, for 1 <= si <= NST-1, the NPL patch DMAs of chunk c+1 (issued in the chunk's first step right after step k+NST-1's tiles).
+  // Loads return in order, so "at most (younger instructions) outstanding" means step k's tiles have landed.
   int k = 0;
   int st_cur = 0, st_nxt = NST - 1;
   int tr = 0, ts = 0;
-  auto step = [&](int tt, int pbuf, auto first_c) __attribute__((always_inline)) {
+  auto tap_off = [&]() {
+    const int cw = cl.dw0 + ts * cl.dw_step - cl.lo_w;
+    return (cl.dh0 + tr * cl.dh_step - cl.lo_h) * PW + (p.in_sw == 2 ? ((cw & 1) * cl.PWh + (cw >> 1)) : cw);
+  };
+  auto next_tap = [&]() {
+    if (++ts == cl.TS) {
+      ts = 0;
+      ++tr;
+    }
+  };
+  auto step_top = [&](int si, auto first_c) __attribute__((always_inline)) {
     constexpr bool FIRST = decltype(first_c)::value;
-    {
-      int nb = nk - 1 - k;
-      nb = nb < NST - 2 ? nb : NST - 2;
-      const bool py = !FIRST && tt <= NST - 1;
-      patch_wait_vm(nb * PERB + (py ? NPL : 0));
+    // (literal counts behind two uniform branches; near the end of the K loop, where fewer younger steps exist, wait for everything)
+    if (k + NST - 2 < nk) {
+      if (!FIRST && si <= NST - 1) patch_wait_lit<(NST - 2) * PERS + NPL>();
+      else patch_wait_lit<(NST - 2) * PERS>();
+    } else {
+      patch_wait_lit<0>();
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's patch stores (chunk boundary) are in the LDS
-    __builtin_amdgcn_s_barrier();  // tile k landed everywhere; everybody finished reading ring slot st_nxt (tile k - 1)
+    __builtin_amdgcn_s_barrier();  // step k landed everywhere; everybody finished reading ring slot st_nxt (step k - 1)
     if (k + NST - 1 < nk) issue_b(st_nxt);
-    const int cw = cl.dw0 + ts * cl.dw_step - cl.lo_w;
-    const int toff = (cl.dh0 + tr * cl.dh_step - cl.lo_h) * PW + (p.in_sw == 2 ? ((cw & 1) * cl.PWh + (cw >> 1)) : cw);
-    return toff;
+  };
+  auto step_body = [&](int si, int pbuf) __attribute__((always_inline)) {
+    compute(st_cur, 0, pbuf, tap_off());
+    next_tap();
+    if constexpr (TPS == 2) {
+      if (si * 2 + 1 < T) {
+        compute(st_cur, 1, pbuf, tap_off());
+        next_tap();
+      }
+    }
+    st_cur = st_cur == NST - 1 ? 0 : st_cur + 1;
+    st_nxt = st_nxt == NST - 1 ? 0 : st_nxt + 1;
+    ++k;
   };
   for (int c = 0; c < NC; ++c) {
     const bool more = c + 1 < NC;
     const int pbuf = PB == 2 ? (c & 1) : 0;
     tr = ts = 0;
-    int pafter = 0;  // DMA instructions this wave issued after the next chunk's patch loads
-    {
-      const int toff = step(0, pbuf, std::true_type{});
-      issue_patch(PB == 2 ? ((c + 1) & 1) : 0, c + 1, more);
-      compute(st_cur, pbuf, toff);
-      st_cur = st_cur == NST - 1 ? 0 : st_cur + 1;
-      st_nxt = st_nxt == NST - 1 ? 0 : st_nxt + 1;
-      if (++ts == cl.TS) {
-        ts = 0;
-        ++tr;
-      }
-      ++k;
-    }
-    for (int tt = 1; tt < T; ++tt) {
-      if (k + NST - 1 < nk) pafter += PERB;
-      const int toff = step(tt, pbuf, std::false_type{});
-      compute(st_cur, pbuf, toff);
-      st_cur = st_cur == NST - 1 ? 0 : st_cur + 1;
-      st_nxt = st_nxt == NST - 1 ? 0 : st_nxt + 1;
-      if (++ts == cl.TS) {
-        ts = 0;
-        ++tr;
-      }
-      ++k;
+    int pafter = 0;  // DMA instructions this wave issued after the next chunk's patch DMAs
+    step_top(0, std::true_type{});
+    issue_patch(PB == 2 ? ((c + 1) & 1) : 0, c + 1, more);
+    step_body(0, pbuf);
+    for (int si = 1; si < SPC; ++si) {
+      if (k + NST - 1 < nk) pafter += PERS;
+      step_top(si, std::false_type{});
+      step_body(si, pbuf);
     }
     if (more) {
-      // this wave's patch DMAs have landed once only the DMAs issued after them are outstanding (with fewer than NST taps the wait
-      // for the next weight tile would not cover them); the next step's barrier then publishes them to the other waves
+      // this wave's patch DMAs have landed once only the DMAs issued after them are outstanding (with fewer than NST steps per
+      // chunk the wait for the next weight tiles would not cover them); the next step's barrier publishes them to the other waves
       patch_wait_vm(pafter);
       transform_patch((c + 1) & 1, c + 1);
     }
@@ -582,6 +614,13 @@ __global__ __launch_bounds__(kPatchThreads, 2) void conv_patch_kernel(const Patc
       }
     }
   }
+  if (p.dbg && t == 0) {
+    unsigned long long* d = p.dbg + (size_t)blockIdx.x * 4;
+    d[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+    d[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+    d[2] = dbg_t0;
+    d[3] = __builtin_amdgcn_s_memtime();
+  }
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
@@ -597,9 +636,10 @@ static int patch_env(const char* name, int dflt) {
 
 static inline int imin(int a, int b) { return a < b ? a : b; }
 static inline int imax(int a, int b) { return a > b ? a : b; }
+static inline int64_t imin64(int64_t a, int64_t b) { return a < b ? a : b; }
 
 // tile search for one class: TH x TW <= 256 with the patch inside the LDS budget; fewest tiles wins, then the smaller patch
-static bool patch_plan_class(const IgemmClass& c, int NB, int IH, int in_sh, int in_sw, int max_pix, PatchClass* o) {
+static bool patch_plan_class(const IgemmClass& c, int NB, int IH, int in_sh, int in_sw, int max_pix, int n_tiles, PatchClass* o) {
   memset(o, 0, sizeof(*o));
   o->TR = c.TR;
   o->TS = c.TS;
@@ -629,32 +669,46 @@ static bool patch_plan_class(const IgemmClass& c, int NB, int IH, int in_sh, int
   if (o->vho < c.OHi) return false;
   const int64_t rows_total = (int64_t)NB * o->vho;
   if (rows_total * in_sh >= (1ll << 30)) return false;
-  int best_tw = 0, best_th = 0, best_pix = 0;
-  int64_t best_tiles = -1;
+  // Candidates: TH x TW <= 256 whose patch fits, in two row layouts — tiles over the VIRTUAL rows of the whole batch (may span
+  // images) or per image (vho rounded up to a multiple of TH). Cost = rounds of the 512 resident-block slots (two 72-KB blocks per
+  // CU: a launch of <= 512 blocks takes about one block time whatever its size, 513 take two), +3 % when a fragment's 16 output
+  // positions are not 16 consecutive pixels of one row (LDS bank conflicts); ties: fewer blocks, then the smaller patch.
+  int best_tw = 0, best_th = 0, best_pix = 0, best_mode = 0;
+  int64_t best_tiles = -1, best_cost = -1;
+  const int vho_v = o->vho;
   for (int TW = 1; TW <= imin(c.OWi, kPatchBM); ++TW) {
-    int TH = kPatchBM / TW;
-    if ((int64_t)TH > rows_total) TH = (int)rows_total;
-    for (; TH >= 1; --TH) {
-      const int PWc = (TW - 1) * in_sw + EW;
-      const int PWh = (PWc + 1) / 2;
-      const int PW = in_sw == 2 ? 2 * PWh : PWc;
-      const int PH = (TH - 1) * in_sh + EH;
-      if (PH * PW > max_pix) continue;
-      // cost = tiles, +3 % when a fragment's 16 output positions are not 16 consecutive pixels of one row (LDS bank conflicts)
-      const int64_t tiles = ((rows_total + TH - 1) / TH) * ((c.OWi + TW - 1) / TW) * (TW % 16 == 0 ? 100 : 103);
-      const int pix = PH * PW;
-      if (best_tiles < 0 || tiles < best_tiles || (tiles == best_tiles && pix < best_pix)) {
-        best_tiles = tiles;
-        best_tw = TW;
-        best_th = TH;
-        best_pix = pix;
+    const int th_max = kPatchBM / TW;
+    for (int mode = 0; mode < 2; ++mode) {
+      for (int TH = imin(th_max, mode ? c.OHi : (int)imin64(rows_total, th_max)); TH >= 1; --TH) {
+        const int PWc = (TW - 1) * in_sw + EW;
+        const int PWh = (PWc + 1) / 2;
+        const int PW = in_sw == 2 ? 2 * PWh : PWc;
+        const int PH = (TH - 1) * in_sh + EH;
+        if (PH * PW > max_pix) continue;
+        const int64_t row_tiles = mode ? (int64_t)NB * ((c.OHi + TH - 1) / TH) : (rows_total + TH - 1) / TH;
+        const int64_t tiles = row_tiles * ((c.OWi + TW - 1) / TW);
+        const int64_t blocks = tiles * n_tiles;
+        const int64_t cost = ((blocks + 511) / 512) * 512 * (TW % 16 == 0 ? 100 : 103);
+        const int pix = PH * PW;
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && (tiles < best_tiles || (tiles == best_tiles && pix < best_pix)))) {
+          best_cost = cost;
+          best_tiles = tiles;
+          best_tw = TW;
+          best_th = TH;
+          best_pix = pix;
+          best_mode = mode;
+        }
+        if (mode == 0 || TH == 1) break;                           // virtual rows: a smaller TH only means more tiles
+        if ((c.OHi + TH - 2) / (TH - 1) != (c.OHi + TH - 1) / TH) break;  // per image: stop once the row-tile count would grow
       }
-      break;  // smaller TH for this TW only means more tiles
     }
   }
   if (best_tiles < 0) return false;
   o->TH = best_th;
   o->TW = best_tw;
+  o->per_image = best_mode;
+  if (best_mode) o->vho = ((c.OHi + best_th - 1) / best_th) * best_th;
+  (void)vho_v;
   o->PWc = (best_tw - 1) * in_sw + EW;
   o->PWh = (o->PWc + 1) / 2;
   o->PW = in_sw == 2 ? 2 * o->PWh : o->PWc;
@@ -703,7 +757,7 @@ static bool patch_plan(const IgemmParams& p, PatchPlan* pl, bool any_geometry = 
     if (c.M <= 0) continue;           // empty class (parity row/column past the image)
     if (c.TR * c.TS <= 0) return false;  // a class without taps just writes zeros: the general kernel does that
     PatchClass pc;
-    if (!patch_plan_class(c, p.NB, p.IH, p.in_sh, p.in_sw, patch_pix(CK), &pc)) return false;
+    if (!patch_plan_class(c, p.NB, p.IH, p.in_sh, p.in_sw, patch_pix(CK), a.n_tiles, &pc)) return false;
     pc.tile_begin = total;
     const int64_t rows_total = (int64_t)p.NB * pc.vho;
     const int64_t sp = ((rows_total + pc.TH - 1) / pc.TH) * pc.tiles_w;
@@ -728,15 +782,20 @@ static bool patch_plan(const IgemmParams& p, PatchPlan* pl, bool any_geometry = 
 
 template <int BN, int CK, int PRO, int ACT>
 static int patch_launch_cfg(const PatchArgs& a, hipStream_t stream) {
-  // A/B switch (BN = 128 builds without a prologue only): CVHIP_PATCH_NST=2 two-deep weight ring
+  // CVHIP_PATCH_TPS (read per launch: in-process A/B): taps per K step. 2 = 64-deep steps with a 2-deep ring of 2-tap slots
+  // (same 80 KB of LDS: two blocks per CU; no room for the prologue's constants, so PRO = 1 keeps 1-tap steps)
   const dim3 grid(a.total_tiles), block(kPatchThreads);
-  if constexpr (BN == 128 && PRO == 0) {
+  if constexpr (PRO == 0) {
+    if (patch_env("CVHIP_PATCH_TPS", 2) == 2) {
+      hipLaunchKernelGGL((conv_patch_kernel<BN, CK, PRO, ACT, 2, 2, 2>), grid, block, 0, stream, a);
+      return check_launch("conv_patch_kernel(tps2)");
+    }
     if (patch_env("CVHIP_PATCH_NST", 3) == 2) {
-      hipLaunchKernelGGL((conv_patch_kernel<BN, CK, PRO, ACT, 2, 2>), grid, block, 0, stream, a);
+      hipLaunchKernelGGL((conv_patch_kernel<BN, CK, PRO, ACT, 2, 2, 1>), grid, block, 0, stream, a);
       return check_launch("conv_patch_kernel(nst2)");
     }
   }
-  hipLaunchKernelGGL((conv_patch_kernel<BN, CK, PRO, ACT, 2, 3>), grid, block, 0, stream, a);
+  hipLaunchKernelGGL((conv_patch_kernel<BN, CK, PRO, ACT, 2, 3, 1>), grid, block, 0, stream, a);
   return check_launch("conv_patch_kernel");
 }
 
@@ -750,6 +809,11 @@ static int patch_launch_pro(const PatchArgs& a, int pro_act, hipStream_t stream)
     default: return CVHIP_ERR_UNSUPPORTED;
   }
 }
+
+static unsigned long long* g_patch_dbg = nullptr;
+#ifndef CVHIP_F16
+extern "C" void cvhip_patch_debug_buffer(void* p) { g_patch_dbg = (unsigned long long*)p; }  // dev tool (tools/patch_census.py; bf16 build)
+#endif
 
 // geometry-only query (plan queries of api.hip, the Python host's kernel labels): does the patch kernel take this plan?
 bool patch_takes(const IgemmParams& p, int* stats_rows) {
@@ -771,7 +835,7 @@ int patch_plan_export(const IgemmParams& p, int32_t* out, int max_classes, bool 
     const int32_t v[CVHIP_PATCH_CLASS_INTS] = {c.TR, c.TS, c.dh0, c.dh_step, c.dw0, c.dw_step, c.out_oh, c.out_ow, c.OHi, c.OWi, c.lo_h, c.lo_w,
                                                c.TH, c.TW, c.PH, c.PW, c.PWh, c.PWc, c.vho, c.tiles_w, c.tile_begin,
                                                (int32_t)(c.w_off & 0xffffffffll), (int32_t)(c.w_off >> 32), pl.a.n_tiles, pl.a.total_tiles,
-                                               pl.BN, pl.CK, patch_pix(pl.CK)};
+                                               pl.BN, pl.CK, patch_pix(pl.CK), c.per_image, 0};
     for (int j = 0; j < CVHIP_PATCH_CLASS_INTS; ++j) o[j] = v[j];
   }
   return pl.a.ncls;
@@ -805,6 +869,7 @@ int try_launch_patch(const IgemmParams& p, hipStream_t stream) {
   a.ep_shift = p.ep_shift;
   a.ep_act = p.ep_act;
   a.ep_ap = p.ep_ap;
+  a.dbg = g_patch_dbg;
   if (a.pro_scale) {
     if (!a.pro_shift || p.Cin > kPatchTabC) return CVHIP_ERR_UNSUPPORTED;
     if (a.z_out) {

@@ -545,7 +545,10 @@ static int cebil_lds_bytes(int C, int ld_x, int Hi, int Wi, int Ho, int Wo) {
   return ((((fh * fw * C + 1) / 2 + 3) & ~3) + fh * kCeBilTH + ((fw * kCeBilTW + 3) & ~3)) * 4 + (kCeBilTH + 2) * (kCeBilTW + 2) * ldp * 4;
 }
 
-int cvhip_seg_ce_bilinear_ok(int32_t C, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo) {
+int cvhip_seg_ce_bilinear_ok(int32_t C, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t align_corners) {
+  // align_corners: the backward's footprint bound (cebil_fbound) assumes the half-pixel mapping, whose label rows per source row are
+  // out/in; with align_corners they are (out-1)/(in-1) > out/in and part of the gradient would be dropped — the two-op path runs
+  if (align_corners) return 0;
   if (C <= 0 || C > 32 || Hi <= 0 || Wi <= 0 || Ho < Hi || Wo < Wi) return 0;  // upsampling only
   return cebil_lds_bytes(C, (C + 7) & ~7, Hi, Wi, Ho, Wo) <= 96 * 1024 ? 1 : 0;  // (the logits' usual pitch: C rounded up to 8)
 }
@@ -553,7 +556,7 @@ int cvhip_seg_ce_bilinear_ok(int32_t C, int32_t Hi, int32_t Wi, int32_t Ho, int3
 static int cebil_fill(CeBilParams& p, const void* x, int32_t ld_x, const int64_t* target, int32_t N, int32_t C, int32_t Hi, int32_t Wi,
                       int32_t Ho, int32_t Wo, int32_t align_corners, int32_t ignore_index) {
   if (!x || !target || N <= 0 || ld_x < C) return CVHIP_ERR_INVALID;
-  if (!cvhip_seg_ce_bilinear_ok(C, Hi, Wi, Ho, Wo)) return CVHIP_ERR_UNSUPPORTED;
+  if (!cvhip_seg_ce_bilinear_ok(C, Hi, Wi, Ho, Wo, align_corners)) return CVHIP_ERR_UNSUPPORTED;
   p.x = (const h16_t*)x;
   p.ld_x = ld_x;
   p.target = target;

@@ -238,6 +238,92 @@ __global__ __launch_bounds__(256) void sgd_ema_kernel(float* __restrict__ param,
   }
 }
 
+// fused AdamW + ModelEMA over the flat arenas (torch.optim.AdamW semantics, src/optimizers/__init__.py:71-73; config 1 trains with it:
+// conf/mini-imagenet.yml:91-99). Decoupled weight decay, amsgrad off, per element:
+//   p   *= 1 - lr_g * wd_g
+//   m    = b1*m + (1-b1)*g            v = b2*v + (1-b2)*g*g
+//   p   -= (lr_g / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+//   ema  = decay*ema + (1-decay)*p    (if ema != NULL)
+// The step count lives in DEVICE memory (step_state[0] = t as float, incremented by adamw_tick_kernel once per step), so a captured
+// step replays with the right bias corrections; {ema_decay, lr_scale} come from `dyn` like in the SGD kernel.
+__global__ void adamw_tick_kernel(float* step_state, const float* scaler) {
+  // (GradScaler.step() does not call optimizer.step() on non-finite gradients: the count stays)
+  if (threadIdx.x == 0 && blockIdx.x == 0 && !(scaler && scaler[1] != 0.f)) step_state[0] += 1.f;
+}
+__global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ m1,
+                                                        float* __restrict__ m2, float* __restrict__ ema, int64_t n,
+                                                        const int64_t* __restrict__ seg, const float* __restrict__ seg_lr,
+                                                        const float* __restrict__ seg_wd, int nseg, float beta1, float beta2, float eps,
+                                                        const float* __restrict__ step_state, float decay, float gscale,
+                                                        const float* __restrict__ dyn, const float* __restrict__ scaler) {
+  float lr_scale = 1.f;
+  if (dyn) {
+    decay = dyn[0];
+    lr_scale = dyn[1];
+  }
+  if (scaler) {
+    gscale *= scaler[0];
+    if (scaler[1] != 0.f) {  // non-finite gradients: the step is skipped, ModelEMA.update still runs (trainer.py:199-207)
+      if (ema)
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+          ema[i] = decay * ema[i] + (1.f - decay) * param[i];
+      return;
+    }
+  }
+  const float t = step_state[0];  // >= 1: the tick kernel ran before this one
+  // torch computes the corrections in double on the host; fp32 pow of a float t is exact enough only for small t, so use exp2/log2
+  // in fp64 here (one thread-uniform evaluation per thread: negligible against the memory pass)
+  const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+  const float inv_bc1 = (float)(1.0 / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  auto seg_of = [&](int64_t i) {
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (i >= seg[2 * mid + 1]) lo = mid + 1;
+      else hi = mid;
+    }
+    return lo;
+  };
+  auto upd = [&](float& pv, float g, float& a, float& b, float& ev, float lr, float wd) {
+    g *= gscale;
+    pv *= 1.f - lr * wd;
+    a = beta1 * a + (1.f - beta1) * g;
+    b = beta2 * b + (1.f - beta2) * g * g;
+    const float denom = sqrtf(b) * inv_sqrt_bc2 + eps;
+    pv -= (lr * inv_bc1) * (a / denom);
+    if (ema) ev = decay * ev + (1.f - decay) * pv;
+  };
+  const bool v4 = ((((uintptr_t)param) | ((uintptr_t)grad) | ((uintptr_t)m1) | ((uintptr_t)m2) | ((uintptr_t)ema)) & 15) == 0;
+  const int64_t n4 = v4 ? (n >> 2) : 0;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256) {
+    const int64_t i = q << 2;
+    float4 pv = *reinterpret_cast<const float4*>(param + i);
+    const float4 gv = *reinterpret_cast<const float4*>(grad + i);
+    float4 av = *reinterpret_cast<const float4*>(m1 + i), bv = *reinterpret_cast<const float4*>(m2 + i);
+    float4 ev = ema ? *reinterpret_cast<const float4*>(ema + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int s0 = seg_of(i);
+    const bool one = i + 3 < seg[2 * s0 + 1];
+    const int s1 = one ? s0 : seg_of(i + 1), s2 = one ? s0 : seg_of(i + 2), s3 = one ? s0 : seg_of(i + 3);
+    upd(pv.x, gv.x, av.x, bv.x, ev.x, seg_lr[s0] * lr_scale, seg_wd[s0]);
+    upd(pv.y, gv.y, av.y, bv.y, ev.y, seg_lr[s1] * lr_scale, seg_wd[s1]);
+    upd(pv.z, gv.z, av.z, bv.z, ev.z, seg_lr[s2] * lr_scale, seg_wd[s2]);
+    upd(pv.w, gv.w, av.w, bv.w, ev.w, seg_lr[s3] * lr_scale, seg_wd[s3]);
+    *reinterpret_cast<float4*>(param + i) = pv;
+    *reinterpret_cast<float4*>(m1 + i) = av;
+    *reinterpret_cast<float4*>(m2 + i) = bv;
+    if (ema) *reinterpret_cast<float4*>(ema + i) = ev;
+  }
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int lo = seg_of(i);
+    float pv = param[i], a = m1[i], b = m2[i], ev = ema ? ema[i] : 0.f;
+    upd(pv, grad[i], a, b, ev, seg_lr[lo] * lr_scale, seg_wd[lo]);
+    param[i] = pv;
+    m1[i] = a;
+    m2[i] = b;
+    if (ema) ema[i] = ev;
+  }
+}
+
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ ema, const float* __restrict__ src, int64_t n, float decay,
                                                   const float* __restrict__ dyn) {
   if (dyn) decay = dyn[0];
@@ -358,6 +444,18 @@ int cvhip_sgd_nesterov_ema_scaled(float* param, const float* grad, float* moment
                      seg_bounds, seg_lr, seg_wd, nseg, momentum, nesterov, first_step, ema_decay, grad_scale, dyn_decay_lrscale,
                      scaler2);
   return check_launch("sgd_ema_kernel(scaled)");
+}
+
+int cvhip_adamw_ema(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema, int64_t n, const int64_t* seg_bounds,
+                    const float* seg_lr, const float* seg_wd, int32_t nseg, float beta1, float beta2, float eps, float* step_state,
+                    float ema_decay, float grad_scale, const float* dyn_decay_lrscale, const float* scaler2, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || !seg_bounds || !seg_lr || !seg_wd || nseg <= 0 || !step_state) return CVHIP_ERR_INVALID;
+  if (!(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f)) return CVHIP_ERR_INVALID;
+  if (n == 0) return CVHIP_OK;
+  hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_state, scaler2);
+  hipLaunchKernelGGL(adamw_ema_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, ema, n, seg_bounds,
+                     seg_lr, seg_wd, nseg, beta1, beta2, eps, step_state, ema_decay, grad_scale, dyn_decay_lrscale, scaler2);
+  return check_launch("adamw_ema_kernel");
 }
 
 int cvhip_loss_scale_check(const float* grad, int64_t n, float* state4, void* stream) {

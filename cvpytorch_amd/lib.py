@@ -50,10 +50,10 @@ class ConvFuse(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("stats_partial", C.c_void_p), ("bn_acc", C.c_void_p), ("ep_scale", C.c_void_p),
                 ("ep_shift", C.c_void_p), ("ep_act", C.c_int32), ("ep_act_param", C.c_float), ("pro_scale", C.c_void_p),
                 ("pro_shift", C.c_void_p), ("pro_act", C.c_int32), ("pro_act_param", C.c_float), ("z_out", C.c_void_p),
-                ("z_ld", C.c_int32)]
+                ("z_ld", C.c_int32), ("residual", C.c_void_p), ("residual_ld", C.c_int32)]
 
 
-PATCH_CLASS_INTS = 28  # CVHIP_PATCH_CLASS_INTS
+PATCH_CLASS_INTS = 30  # CVHIP_PATCH_CLASS_INTS
 
 
 class PrepEntry(C.Structure):
@@ -150,7 +150,7 @@ SIGNATURES = {
     "cvhip_seg_ce_rows": (_i32, [_i64]),
     "cvhip_seg_ce_fwd": (_i32, [_p, _i32, _p, _i64, _i32, _i32, _p, _p, _p]),
     "cvhip_seg_ce_bwd": (_i32, [_p, _i32, _p, _i64, _i32, _i32, _p, _p, _p, _i32, _p]),
-    "cvhip_seg_ce_bilinear_ok": (_i32, [_i32, _i32, _i32, _i32, _i32]),
+    "cvhip_seg_ce_bilinear_ok": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "cvhip_seg_ce_bilinear_fwd": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p]),
     "cvhip_seg_ce_bilinear_bwd": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p]),
     "cvhip_resize_nearest_fwd": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
@@ -175,6 +175,7 @@ SIGNATURES = {
     "cvhip_sort_workspace_bytes": (_i64, [_i64]),
     "cvhip_argsort_desc_f32": (_i32, [_p, _i64, _p, _p, _p]),
     "cvhip_box_iou": (_i32, [_p, _i32, _p, _i32, _p, _p]),
+    "cvhip_adamw_ema": (_i32, [_p, _p, _p, _p, _p, _i64, _p, _p, _p, _i32, _f32, _f32, _f32, _p, _f32, _f32, _p, _p, _p]),
     "cvhip_sgd_nesterov_ema": (_i32, [_p, _p, _p, _p, _i64, _p, _p, _p, _i32, _f32, _i32, _i32, _f32, _f32, _p, _p]),
     "cvhip_sgd_nesterov_ema_scaled": (_i32, [_p, _p, _p, _p, _i64, _p, _p, _p, _i32, _f32, _i32, _i32, _f32, _f32, _p, _p, _p]),
     "cvhip_loss_scale_check": (_i32, [_p, _i64, _p, _p]),

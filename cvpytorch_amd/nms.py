@@ -6,8 +6,9 @@
                           src/models/yolov5.py:62-153 (non_max_suppression) and src/models/yolox.py:48-68 (yolox_post_process).
   non_max_suppression     reference-shaped adapter: list of (n_i, 6) tensors, ONE host read of the counts for all images.
   yolox_post_process      same for YOLOX: list of (n_i, 7) tensors / None.
-  batched_nms, multiclass_nms   mirrors of src/models/modules/nms.py:5-132 (same signatures and return values), sorting with
-                          cvhip_argsort_desc_f32 and suppressing with cvhip_nms_sorted instead of torch.sort / torchvision.ops.nms.
+  batched_nms, multiclass_nms   the contracts of src/models/modules/nms.py:5-132 (same signatures and return values) as fixed-shape
+                          device passes: sort keys instead of boolean-mask compaction, ONE class-shifted greedy NMS
+                          (cvhip_argsort_desc_f32 + cvhip_nms_sorted), one host read for the data-dependent output length.
 """
 import torch
 
@@ -144,55 +145,94 @@ def nms(boxes, scores, iou_threshold):
     return order[keep[:k].long()]
 
 
+def _nms_cfg(nms_cfg, class_agnostic):
+    """(iou threshold, class_agnostic) out of an mmdet-style nms_cfg dict (modules/nms.py:70-93 documents the keys)"""
+    cfg = dict(nms_cfg or {})
+    kind = cfg.get("type", "nms")
+    if kind != "nms":
+        raise L.CvhipError("nms_cfg type %r: only hard NMS ('nms') runs on the device kernels" % (kind,))
+    iou = cfg["iou_threshold"] if "iou_threshold" in cfg else cfg.get("iou_thr", 0.5)
+    return float(iou), bool(cfg.get("class_agnostic", class_agnostic))
+
+
+def nms_device(boxes_sorted, iou_threshold):
+    """Greedy NMS over boxes ALREADY in decreasing-score order, entirely on the device: returns (keep positions int32 [n] — the
+    first `count` entries are the kept positions in increasing order, count int32 [1]). No host synchronisation."""
+    n = boxes_sorted.shape[0]
+    dev = boxes_sorted.device
+    keep = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
+    cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
+    if n:
+        ws = torch.empty((int(L.load().cvhip_nms_workspace_bytes(n)),), dtype=torch.uint8, device=dev)
+        L.call("cvhip_nms_sorted", boxes_sorted.data_ptr(), n, float(iou_threshold), ws.data_ptr(), keep.data_ptr(), cnt.data_ptr(), _stream())
+    return keep, cnt
+
+
 def batched_nms(boxes, scores, idxs, nms_cfg, class_agnostic=False):
-    """src/models/modules/nms.py:70-132: per-class NMS through coordinate offsets; returns (dets (k, 5), keep (k,))."""
-    nms_cfg_ = nms_cfg.copy()
-    class_agnostic = nms_cfg_.pop("class_agnostic", class_agnostic)
-    if class_agnostic:
-        boxes_for_nms = boxes
-    else:
-        max_coordinate = boxes.max()
-        offsets = idxs.to(boxes) * (max_coordinate + 1)
-        boxes_for_nms = boxes + offsets[:, None]
-    nms_cfg_.pop("type", "nms")
-    split_thr = nms_cfg_.pop("split_thr", 10000)
-    iou_thr = nms_cfg_.pop("iou_threshold", nms_cfg_.pop("iou_thr", 0.5))
-    if len(boxes_for_nms) < split_thr:
-        keep = nms(boxes_for_nms, scores, iou_thr)
-        boxes = boxes[keep]
-        scores = scores[keep]
-    else:
-        total_mask = scores.new_zeros(scores.size(), dtype=torch.bool)
-        for id_ in torch.unique(idxs):
-            mask = (idxs == id_).nonzero(as_tuple=False).view(-1)
-            keep = nms(boxes_for_nms[mask], scores[mask], iou_thr)
-            total_mask[mask[keep]] = True
-        keep = total_mask.nonzero(as_tuple=False).view(-1)
-        keep = keep[argsort_desc(scores[keep])]
-        boxes = boxes[keep]
-        scores = scores[keep]
-    return torch.cat([boxes, scores[:, None]], -1), keep
+    """Contract of src/models/modules/nms.py:70-132 — NMS that never suppresses across different `idxs` — returning
+    (dets (k, 5) = [x1, y1, x2, y2, score] in decreasing score, keep (k,) int64 indices into `boxes`).
+
+    One device pass instead of the reference's two code paths: boxes of class c are shifted by c * (max coordinate + 1) so that
+    different classes cannot overlap, the scores are sorted on the device (cvhip_argsort_desc_f32: stable), ONE greedy NMS
+    (cvhip_nms_sorted) runs over all of them and ONE host read fetches the number of survivors. The reference's `split_thr` branch
+    (a per-class python loop it takes for >= 10000 boxes to bound torchvision's memory) computes the same set in the same order —
+    classes are disjoint after the shift — so it needs no counterpart here; the key is accepted and ignored."""
+    if not boxes.is_cuda:
+        raise L.CvhipError("cvpytorch_amd.nms needs CUDA/HIP tensors (no CPU fallback)")
+    iou, agnostic = _nms_cfg(nms_cfg, class_agnostic)
+    n = boxes.shape[0]
+    if n == 0:
+        return boxes.new_zeros((0, 5)), torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    b32 = boxes.float()
+    shifted = b32 if agnostic else b32 + (idxs.to(b32) * (b32.max() + 1))[:, None]
+    order = argsort_desc(scores)
+    keep_pos, cnt = nms_device(shifted[order].contiguous(), iou)
+    k = int(cnt.item())                       # the contract returns data-dependent lengths: the one host read
+    keep = order[keep_pos[:k].long()]
+    return torch.cat([boxes[keep], scores[keep][:, None].to(boxes.dtype)], -1), keep
 
 
-def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, score_factors=None):
-    """src/models/modules/nms.py:5-67: (n, #class*4 | 4) boxes, (n, #class + 1) scores (last column = background) ->
-    (dets (k, 5), labels (k,))."""
-    num_classes = multi_scores.size(1) - 1
-    if multi_bboxes.shape[1] > 4:
-        bboxes = multi_bboxes.view(multi_scores.size(0), -1, 4)
-    else:
-        bboxes = multi_bboxes[:, None].expand(multi_scores.size(0), num_classes, 4)
-    scores = multi_scores[:, :-1]
-    valid_mask = scores > score_thr
-    bboxes = torch.masked_select(bboxes, torch.stack((valid_mask, valid_mask, valid_mask, valid_mask), -1)).view(-1, 4)
-    if score_factors is not None:
-        scores = scores * score_factors[:, None]
-    scores = torch.masked_select(scores, valid_mask)
-    labels = valid_mask.nonzero(as_tuple=False)[:, 1]
-    if bboxes.numel() == 0:
-        return multi_bboxes.new_zeros((0, 5)), multi_bboxes.new_zeros((0,), dtype=torch.long)
-    dets, keep = batched_nms(bboxes, scores, labels, nms_cfg)
+def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, score_factors=None, cap=8192):
+    """Contract of src/models/modules/nms.py:5-67: boxes (n, 4) shared by all classes or (n, #class*4) per class, scores
+    (n, #class + 1) whose last column is the background -> (dets (k, 5), labels (k,)), at most `max_num`, decreasing score.
+
+    Fixed-shape device formulation (no boolean-mask compaction, no nonzero): every (box, class) pair is a candidate whose sort key is
+    its score if it passes `score_thr` and -inf otherwise; a stable device sort puts the passing pairs first (ties by candidate index,
+    i.e. the reference's row-major order); the `cap` best go through ONE class-shifted greedy NMS. A failing pair can never suppress a
+    passing one (it sorts after all of them), so nothing has to be removed before the NMS: the survivors among the first `n_valid`
+    positions are the answer. ONE host read returns (survivors, n_valid); only if more than `cap` pairs pass is the pass repeated
+    with the capacity that fits (the reference itself is unbounded)."""
+    if not multi_bboxes.is_cuda:
+        raise L.CvhipError("cvpytorch_amd.nms needs CUDA/HIP tensors (no CPU fallback)")
+    iou, agnostic = _nms_cfg(nms_cfg, False)
+    n, ncls = multi_scores.shape[0], multi_scores.shape[1] - 1
+    dev = multi_bboxes.device
+    if n == 0 or ncls <= 0:
+        return multi_bboxes.new_zeros((0, 5)), torch.zeros((0,), dtype=torch.long, device=dev)
+    per_class = multi_bboxes.shape[1] > 4
+    cand_boxes = (multi_bboxes.reshape(n, ncls, 4) if per_class else multi_bboxes[:, None, :].expand(n, ncls, 4)).reshape(n * ncls, 4).float()
+    raw = multi_scores[:, :ncls].float()
+    valid = (raw > score_thr).reshape(-1)
+    sc = (raw * score_factors[:, None].float() if score_factors is not None else raw).reshape(-1)
+    key = torch.where(valid, sc, torch.full_like(sc, float("-inf")))
+    order = argsort_desc(key)
+    n_valid = valid.sum()
+    # the class shift of the reference uses the largest coordinate of the PASSING boxes
+    max_coord = torch.where(valid[:, None], cand_boxes, torch.full_like(cand_boxes, float("-inf"))).max()
+    cap = int(min(n * ncls, max(1, cap)))
+    while True:
+        top = order[:cap]
+        lab = top % ncls
+        btop = cand_boxes[top]
+        shifted = btop if agnostic else btop + (lab.to(btop) * (max_coord + 1))[:, None]
+        keep_pos, cnt = nms_device(shifted.contiguous(), iou)
+        live = (torch.arange(keep_pos.shape[0], device=dev) < cnt) & (keep_pos < n_valid)
+        k, nv = torch.stack((live.sum(), n_valid)).tolist()        # ONE host read
+        if nv <= cap or cap >= n * ncls:
+            break
+        cap = int(min(n * ncls, _pow2_at_least(nv, hi=1 << 30)))   # more passing pairs than the capacity: redo with room for all
     if max_num > 0:
-        dets = dets[:max_num]
-        keep = keep[:max_num]
-    return dets, labels[keep]
+        k = min(k, max_num)
+    sel = keep_pos[:k].long()       # kept positions are increasing, the passing ones come first: the first k are the survivors
+    dets = torch.cat([btop[sel].to(multi_bboxes.dtype), sc[top][sel][:, None].to(multi_bboxes.dtype)], -1)
+    return dets, lab[sel]

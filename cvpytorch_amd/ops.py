@@ -51,6 +51,10 @@ def bump_weights_epoch():
 # kernels per YOLOv5-s step). A layer's accumulator pair [2 (forward, backward)][shards][2][K] lives in the flat training state
 # (arena.FlatTrainState: ONE zero-fill per step for all layers); without it — or when a layer runs a second time inside one step
 # (yolov7 FeatureFusion.conv4) — a scratch accumulator is zero-filled per call. CVHIP_BN_ACC=0 restores the partial-row path.
+# Inference (no operand requires a gradient, BatchNorm in eval mode or folded away): the whole ConvModule — conv, bias, BN scale/shift,
+# activation, residual — is ONE cvhip_conv2d_fprop_fused launch (conv_module.py:201-214 in eval mode; utils/fuse.py:32-54).
+# CVHIP_EPI_FUSE=0 restores conv + a separate BN/activation pass (A/B switch).
+_EPI_FUSE = __import__("os").environ.get("CVHIP_EPI_FUSE", "1") != "0"
 _BN_ACC = __import__("os").environ.get("CVHIP_BN_ACC", "1") != "0"
 _BN_ACC_MAX_C = 2048
 _acc_epoch = 0
@@ -89,18 +93,24 @@ def _wgrad(kname, geom, desc, x, dy, dst, accumulate, st):
 
 
 def bump_acc_epoch():
-    """called by whoever has just zeroed the persistent accumulators (arena.FlatTrainState.zero_stats)"""
+    """kept for callers that zero accumulators themselves (process-wide epoch of accumulators WITHOUT an owning state)"""
     global _acc_epoch
     _acc_epoch += 1
 
 
 def _layer_acc(cfg, K, dev):
-    """(forward, backward) accumulators [shards][2][K] fp64, zeroed, for ONE application of the layer behind `cfg`"""
+    """(forward, backward) accumulators [shards][2][K] fp64, zeroed, for ONE application of the layer behind `cfg`.
+
+    A layer's persistent accumulator entry is [tensor (2, shards, 2, K), epoch of its last use, epoch cell of the OWNING state,
+    id of the module it was made for]. It is clean exactly when the owning FlatTrainState has zeroed its accumulator arena since
+    the entry's last use (state.zero_stats bumps the state's own cell: another state's step must not make this one look clean —
+    teacher / student, GAN, back-to-back tests), and it belongs to THIS module (a deep copy carries a copy of the list whose tensor
+    no state ever zeroes). Everything else gets a scratch accumulator that is zero-filled per call."""
     owner = cfg.acc_owner
     if owner is not None:
-        ent = owner.__dict__.get(cfg.acc_attr)   # [tensor (2, shards, 2, K), epoch of its last use]
-        if ent is not None and ent[1] != _acc_epoch and ent[0].shape[-1] == K and ent[0].device == dev:
-            ent[1] = _acc_epoch
+        ent = owner.__dict__.get(cfg.acc_attr)
+        if ent is not None and len(ent) >= 4 and ent[3] == id(owner) and ent[1] != ent[2][0] and ent[0].shape[-1] == K and ent[0].device == dev:
+            ent[1] = ent[2][0]
             return ent[0][0], ent[0][1]
     t = zero_fill(torch.empty((2, L.BN_ACC_SHARDS, 2, K), dtype=torch.float64, device=dev))
     return t[0], t[1]
@@ -784,6 +794,50 @@ def _bn_fwd_acc(y, y_ld, z, z_ld, M, kh, off, K, acc_f, gamma, beta, running_mea
               cfg.act, cfg.act_param, _ptr(residual), res_ld, int(bool(res_pre)), st)
 
 
+def _eval_scale_shift(cfg, gamma, beta, running_mean, running_var, K, dev, st):
+    """(scale, shift) of an eval-mode BatchNorm, cached on the layer's ConvState until one of its tensors is written again"""
+    key = (running_mean.data_ptr(), running_mean._version, running_var._version, None if gamma is None else gamma._version,
+           None if beta is None else beta._version, float(cfg.eps))
+    cache = getattr(cfg.state, "ep_cache", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    ss = torch.empty((2, K), dtype=torch.float32, device=dev)
+    L.call("cvhip_bn_eval_scale_shift", K, _ptr(gamma.detach() if gamma is not None else None),
+           _ptr(beta.detach() if beta is not None else None), running_mean.data_ptr(), running_var.data_ptr(), cfg.eps,
+           ss[0].data_ptr(), ss[1].data_ptr(), st)
+    cfg.state.ep_cache = (key, ss)
+    return ss
+
+
+def _conv_fused_inference(x, x_ld, weight, bias, gamma, beta, running_mean, running_var, residual, cfg, geom, kv, cv, st):
+    """z = act(bn_eval(conv(x, W) + b)) (+ residual) in ONE launch: the convolution's epilogue applies the bias, the eval-mode
+    BatchNorm's scale / shift, the activation and the (post-activation) residual; the result goes straight to `cfg.out` when the
+    caller handed a concat slice. No tensor is saved: this path only runs when nothing requires a gradient."""
+    N, Cc, H, W, K, R, S, P, Q = geom
+    dev = x.device
+    if cfg.out is not None:
+        z, z_ld = _check_out(cfg.out, N, K, P, Q)
+    else:
+        z, z_ld = empty_nhwc(N, K, P, Q, dev), K
+    desc = conv_desc(N, Cc, H, W, K, R, S, cfg.stride, cfg.pad, cfg.dil, 1, x_ld, z_ld, kv, cv)
+    f = L.ConvFuse()
+    keep = [bias]
+    f.bias = _ptr(bias)
+    if cfg.has_bn:
+        ss = _eval_scale_shift(cfg, gamma, beta, running_mean, running_var, K, dev, st)
+        keep.append(ss)
+        f.ep_scale, f.ep_shift = ss[0].data_ptr(), ss[1].data_ptr()
+    f.ep_act, f.ep_act_param = int(cfg.act), float(cfg.act_param)
+    if residual is not None:
+        residual, res_ld = as_nhwc(residual)
+        keep.append(residual)
+        f.residual, f.residual_ld = residual.data_ptr(), res_ld
+    kname = "conv_fused_inference"
+    _timed_call(kname, geom, "cvhip_conv2d_fprop_fused", C.byref(desc), x.data_ptr(), cfg.state.w_fprop.data_ptr(), z.data_ptr(), C.byref(f), st)
+    cfg.prod = None
+    return z
+
+
 class ConvBnAct(torch.autograd.Function):
     """z = act(bn(conv(x, W) + b)) (+ residual)   — any of bn / act / bias / residual optional.
 
@@ -846,6 +900,10 @@ class ConvBnAct(torch.autograd.Function):
             # pack descriptor: contiguous pitches (the packed images do not depend on activation pitches)
             pdesc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, Cc, Kp, kv, cv)
             cfg.state.prepare(weight, pdesc, need_dx, cfg.vkey)
+            if (_EPI_FUSE and not any(ctx.needs_input_grad) and not train_bn and Kp == K and cfg.out_split is None
+                    and (cfg.has_bn or cfg.act != L.ACT_NONE or residual is not None) and not (cfg.res_pre and residual is not None)):
+                return _conv_fused_inference(x, x_ld, weight, b, gamma, beta, running_mean, running_var, residual, cfg,
+                                             (N, Cc, H, W, K, R, S, P, Q), kv, cv, st)
             use_acc = _BN_ACC and not _DETERMINISTIC and epilogue_stats and cfg.sync is None and K <= _BN_ACC_MAX_C
             if use_acc:
                 acc_f, acc_b = _layer_acc(cfg, K, dev)
@@ -972,6 +1030,9 @@ class ConvBnAct(torch.autograd.Function):
         if acc_b is not None:
             # (sum du, sum du*xhat) into the layer's accumulator — unless the kernel that wrote dz already folded them in
             # (ProdInfo); the consumer below folds the accumulator and stores dgamma / dbeta
+            if getattr(ctx, "_acc_b_used", False):
+                zero_fill(acc_b)   # backward(retain_graph=True) a second time: the sums of the first pass must not be added twice
+            ctx._acc_b_used = True
             have = _sums_already_done(getattr(ctx, "prod", None), dz)
             if have == "dirty":
                 zero_fill(acc_b)
@@ -1642,7 +1703,7 @@ def seg_cross_entropy_resized(logits, target, ignore_index=255, align_corners=Fa
     """CE of `logits` bilinearly resized to the label size; the fused kernels when the geometry allows, else the two ops"""
     N, Cc, Hi, Wi = logits.shape
     Ho, Wo = int(target.shape[-2]), int(target.shape[-1])
-    if _SEG_CE_FUSED and L.load().cvhip_seg_ce_bilinear_ok(Cc, Hi, Wi, Ho, Wo):
+    if _SEG_CE_FUSED and L.load().cvhip_seg_ce_bilinear_ok(Cc, Hi, Wi, Ho, Wo, int(bool(align_corners))):
         return SegCrossEntropyBilinear.apply(logits, target, ignore_index, align_corners)
     return seg_cross_entropy(resize_bilinear(logits, (Ho, Wo), align_corners), target, ignore_index)
 

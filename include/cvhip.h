@@ -334,7 +334,7 @@ int cvhip_seg_ce_bwd(const void* logits_bf16, int32_t ld, const int64_t* target,
  * deterministically (a gather, no atomics). The interpolated logits are kept in fp32 (the two-op form rounds them to 16 bits).
  * cvhip_seg_ce_bilinear_ok: 1 when the geometry is supported (upsampling, C <= 32, footprint tile fits the LDS), else the entry
  * points return CVHIP_ERR_UNSUPPORTED and the caller composes cvhip_resize_bilinear_* with cvhip_seg_ce_*. */
-int cvhip_seg_ce_bilinear_ok(int32_t C, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo);
+int cvhip_seg_ce_bilinear_ok(int32_t C, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t align_corners);
 int cvhip_seg_ce_bilinear_fwd(const void* x_bf16, int32_t ld_x, const int64_t* target, int32_t N, int32_t C, int32_t Hi, int32_t Wi,
                               int32_t Ho, int32_t Wo, int32_t align_corners, int32_t ignore_index, float* partial, float* out2,
                               void* stream);
@@ -452,6 +452,13 @@ int cvhip_box_iou(const float* a_xyxy, int32_t n, const float* b_xyxy, int32_t m
  * (src/utils/ema.py:30-39). wd/lr are per-element-range via a segment table.
  *   seg: int64 [nseg][2] = {begin, end} element ranges; seg_lr/seg_wd: float[nseg].
  * ------------------------------------------------------------------------------------------ */
+/* AdamW (decoupled weight decay; torch.optim.AdamW, src/optimizers/__init__.py:71-73 — conf/mini-imagenet.yml:91-99 trains config 1
+ * with it) + ModelEMA over the same flat arenas and segment table. step_state: ONE float in device memory holding the step count t
+ * (zero-initialised by the caller; the call increments it before use — not on a GradScaler skip — so a captured step replays with the
+ * right bias corrections). scaler2 (optional): {1/scale, skip} of the dynamic loss scaler, as in cvhip_sgd_nesterov_ema_scaled. */
+int cvhip_adamw_ema(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema, int64_t n, const int64_t* seg_bounds,
+                    const float* seg_lr, const float* seg_wd, int32_t nseg, float beta1, float beta2, float eps, float* step_state,
+                    float ema_decay, float grad_scale, const float* dyn_decay_lrscale, const float* scaler2, void* stream);
 int cvhip_sgd_nesterov_ema(float* param, const float* grad, float* momentum_buf, float* ema,
                            int64_t n, const int64_t* seg_bounds, const float* seg_lr,
                            const float* seg_wd, int32_t nseg, float momentum, int32_t nesterov,
@@ -678,6 +685,8 @@ typedef struct cvhip_conv_fuse {
   float pro_act_param;
   void* z_out;
   int32_t z_ld;
+  const void* residual; /* optional addend applied AFTER the activation (Darknet shortcut x + act(bn(conv))), pitch residual_ld */
+  int32_t residual_ld;
 } cvhip_conv_fuse;
 #endif
 int cvhip_conv2d_fprop_fused(const cvhip_conv_desc* d, const void* x, const void* w, void* y, const cvhip_conv_fuse* f, void* stream);
@@ -686,10 +695,10 @@ int cvhip_conv2d_fprop_prologue_ok(const cvhip_conv_desc* d, int with_z_out);
 /* Plan query of the patch-resident kernel (conv_patch.hip; pure host arithmetic, exercised by the CPU test-suite against a numpy
  * interpreter of the kernel's addressing): per class CVHIP_PATCH_CLASS_INTS int32
  *   {TR, TS, dh0, dh_step, dw0, dw_step, out_oh, out_ow, OHi, OWi, lo_h, lo_w, TH, TW, PH, PW, PWh, PWc, vho, tiles_w, tile_begin,
- *    w_off lo, w_off hi, n_tiles, total_tiles, BN, CK, patch capacity (pixels)}.
+ *    w_off lo, w_off hi, n_tiles, total_tiles, BN, CK, patch capacity (pixels), per_image (tiles never span images), reserved}.
  * Returns the class count, 0 when another kernel runs this problem. flags bit 0: the plan of cvhip_conv2d_dgrad instead of fprop;
  * bit 1: geometry only (skip the launcher's "too much padding" policy — what the kernel WOULD do on a small problem). */
-#define CVHIP_PATCH_CLASS_INTS 28
+#define CVHIP_PATCH_CLASS_INTS 30
 int cvhip_conv2d_patch_plan(const cvhip_conv_desc* d, int flags, int32_t* out_classes, int max_classes);
 
 /* ------------------------------------------------------------------------------------------

@@ -137,3 +137,48 @@ def test_nearest_resize_matches_torch_exactly(Cc, Hi, Wi, Ho, Wo):
     yr.backward(g.float())
     torch.cuda.synchronize()
     assert rel_l2(xd.grad.float().cpu(), xr.grad) < 4e-3
+
+
+def test_eval_forward_is_one_launch_per_convmodule_and_matches_the_oracle_and_the_two_pass_form():
+    """Round 4: in inference (nothing requires a gradient) a ConvModule — conv, eval-mode BatchNorm scale / shift, activation,
+    Darknet shortcut — is ONE cvhip_conv2d_fprop_fused launch (conv_module.py:201-214 in eval mode); after deploy.fuse_model the
+    BatchNorm is folded into the weights (utils/fuse.py:32-54) and only bias + activation remain in the epilogue. Checked on the
+    YOLOv5-n backbone + neck + head: (a) no BN / activation element-wise launch is left, (b) outputs equal the fp32 oracle's eval
+    forward within the storage tolerance, (c) and the two-pass form (CVHIP_EPI_FUSE off) to bf16 rounding."""
+    import importlib
+    from cvpytorch_amd import ops, yolov5
+    from oracle import torch_ref as R
+    torch.manual_seed(0)
+    ref = R.YOLOv5(20, "n")
+    _randomise_bn(ref)
+    ref.eval()
+    hip = yolov5.YOLOv5(20, "n").to(dev())
+    hip.load_state_dict(ref.state_dict(), strict=False)
+    hip.eval()
+    x = torch.randn(2, 3, 128, 160)
+    with torch.no_grad():
+        want = ref.forward_features(x)[0] if hasattr(ref, "forward_features") else ref.detect(ref.neck(ref.backbone(x)))[0]
+        ops.TIMER.enabled = True
+        ops.TIMER.reset()
+        got = hip.forward_features(x.to(dev()))[0]
+        torch.cuda.synchronize()
+        names = [r[0] for r in ops.TIMER.records]
+        ops.TIMER.enabled = False
+        ops.TIMER.reset()
+        assert not [n for n in names if "ew_kernel" in n or "bn_act" in n], names
+        assert sum(n == "conv_fused_inference" for n in names) >= 50
+        old = ops._EPI_FUSE
+        ops._EPI_FUSE = False
+        try:
+            two_pass = hip.forward_features(x.to(dev()))[0]
+        finally:
+            ops._EPI_FUSE = old
+        deploy.fuse_model(hip)
+        folded = hip.forward_features(x.to(dev()))[0]
+    torch.cuda.synchronize()
+    w = want.float()
+    scale = float(w.abs().max())
+    for name, t in (("fused eval BN", got), ("two-pass", two_pass), ("folded", folded)):
+        err = float((t.float().cpu() - w).abs().max())
+        assert err <= 3e-2 * scale, (name, err, scale)
+    assert float((got.float() - two_pass.float()).abs().max()) <= 2e-2 * scale

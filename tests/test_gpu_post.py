@@ -164,3 +164,42 @@ def test_batched_nms_and_multiclass_nms_mirror_the_reference_module():
     dets, labels = NMS.multiclass_nms(boxes.to(dev()), ms.to(dev()), 0.6, dict(type="nms", iou_threshold=0.45), max_num=50)
     assert torch.equal(labels.cpu(), lab[kr])
     assert torch.equal(dets.cpu(), torch.cat([bb[kr], sc[kr][:, None]], 1))
+
+
+@pytest.mark.parametrize("per_class,factors,agnostic,cap", [(False, False, False, 8192), (True, False, False, 8192), (False, True, False, 8192),
+                                                            (False, False, True, 8192), (True, True, False, 64)])
+def test_multiclass_nms_device_formulation(per_class, factors, agnostic, cap):
+    """nms.multiclass_nms (sort keys + ONE class-shifted NMS, fixed capacity, one host read) == the reference's mask / nonzero /
+    batched_nms formulation (modules/nms.py:5-67) restated with the oracle's nms: per-class boxes, score_factors, class_agnostic and
+    the capacity-overflow retry (cap = 64 with ~1400 passing pairs)."""
+    g = torch.Generator().manual_seed(5)
+    n, ncls = 500, 7
+    ctr = torch.rand(n, 2, generator=g) * 300
+    if per_class:
+        wh = torch.rand(n, ncls, 2, generator=g) * 50 + 4
+        c = ctr[:, None, :] + torch.randn(n, ncls, 2, generator=g) * 3
+        mb = torch.cat([c - wh / 2, c + wh / 2], -1).reshape(n, ncls * 4)
+    else:
+        wh = torch.rand(n, 2, generator=g) * 50 + 4
+        mb = torch.cat([ctr - wh / 2, ctr + wh / 2], 1)
+    ms = torch.rand(n, ncls + 1, generator=g)
+    sf = torch.rand(n, generator=g) * 0.5 + 0.5 if factors else None
+    cfg = dict(type="nms", iou_threshold=0.5, class_agnostic=agnostic)
+    # reference formulation
+    bboxes = mb.view(n, -1, 4) if per_class else mb[:, None].expand(n, ncls, 4)
+    scores = ms[:, :-1]
+    valid = scores > 0.6
+    bb = bboxes[valid]
+    if sf is not None:
+        scores = scores * sf[:, None]
+    sc = scores[valid]
+    lab = valid.nonzero()[:, 1]
+    shifted = bb if agnostic else bb + (lab.to(bb) * (bb.max() + 1))[:, None]
+    kr = R.nms(shifted, sc, 0.5)[:100]
+    assert valid.sum() > 64
+    dets, labels = NMS.multiclass_nms(mb.to(dev()), ms.to(dev()), 0.6, cfg, max_num=100, score_factors=None if sf is None else sf.to(dev()), cap=cap)
+    assert torch.equal(labels.cpu(), lab[kr])
+    assert torch.equal(dets.cpu(), torch.cat([bb[kr], sc[kr][:, None]], 1))
+    # nothing passes the threshold
+    d0, l0 = NMS.multiclass_nms(mb.to(dev()), ms.to(dev()), 2.0, cfg)
+    assert tuple(d0.shape) == (0, 5) and tuple(l0.shape) == (0,)

@@ -13,7 +13,7 @@ from cvpytorch_amd import lib as L
 from test_abi_plan import desc, dgrad_plan
 
 FIELDS = ("TR", "TS", "dh0", "dh_step", "dw0", "dw_step", "out_oh", "out_ow", "OHi", "OWi", "lo_h", "lo_w", "TH", "TW", "PH", "PW", "PWh",
-          "PWc", "vho", "tiles_w", "tile_begin", "w_lo", "w_hi", "n_tiles", "total_tiles", "BN", "CK", "cap")
+          "PWc", "vho", "tiles_w", "tile_begin", "w_lo", "w_hi", "n_tiles", "total_tiles", "BN", "CK", "cap", "per_image", "reserved")
 
 
 def patch_plan(dd, dgrad):
@@ -42,6 +42,7 @@ def interpret(classes, x_nhwc, wt_of_class, NB, IH, IW, in_s, OH, OW, out_s, Nou
         pitch = cl["vho"] * in_s
         rows_total = NB * cl["vho"]
         tiles_h = -(-rows_total // cl["TH"])
+        assert not cl["per_image"] or cl["vho"] % cl["TH"] == 0
         nxt = classes[ci + 1]["tile_begin"] if ci + 1 < len(classes) else cl["total_tiles"]
         assert tiles_h * cl["tiles_w"] * cl["n_tiles"] == nxt - cl["tile_begin"]
         PW = cl["PW"]
@@ -55,8 +56,8 @@ def interpret(classes, x_nhwc, wt_of_class, NB, IH, IW, in_s, OH, OW, out_s, Nou
                     pr, q = divmod(pp, PW)
                     pc = (2 * q if q < cl["PWh"] else 2 * (q - cl["PWh"]) + 1) if in_s == 2 else q
                     V = V0 + pr
-                    n, vr = divmod(V, pitch)
-                    ih, iw = vr + cl["lo_h"], col0 + pc
+                    n = Gv0 // cl["vho"] if cl["per_image"] else V // pitch      # per-image tiles never wrap into the next image
+                    ih, iw = V - n * pitch + cl["lo_h"], col0 + pc
                     if pc < cl["PWc"] and n < NB and 0 <= ih < IH and 0 <= iw < IW:
                         patch[pp] = x_nhwc[n, ih, iw]
                 # ---- consumer: output positions of the tile
@@ -93,6 +94,7 @@ FPROP_CASES = [
     (2, 64, 12, 12, 32, 5, 5, 1, 2, 1),
     (1, 64, 10, 14, 64, 3, 1, 1, 0, 1),     # no padding, 3x1
     (2, 64, 9, 300, 64, 3, 3, 1, 1, 1),     # wider than one tile
+    (16, 64, 64, 128, 128, 3, 3, 1, 1, 1),  # DeepLabv3+ layer2 shape (small batch): per-image tiling gives exactly 512 blocks
 ]
 
 
