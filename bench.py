@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--dry-launch", action="store_true", help="start the ranks, agree on the world size, print it, exit (no workload)")
     ap.add_argument("--no-extra", action="store_true", help="skip the side workloads (BASELINE configs 4 and 5 at N = 1, DeepLabv3+ OS-8)")
     ap.add_argument("--no-sync-bn-leg", action="store_true", help="N > 1: skip the extra K steps with SyncBN on (trainer.py:126-127)")
+    ap.add_argument("--no-exchange-ab", action="store_true", help="N > 1: skip the gradient-exchange legs (all-reduce vs reduce-scatter + all-gather, 8 vs 25 MiB buckets)")
     ap.add_argument("--allow-torch-dist", action="store_true", help="N > 1: if the native RCCL communicator cannot start, run over torch.distributed "
                     "(hipified ProcessGroupNCCL) and SAY SO in config.transport instead of failing")
     return ap.parse_args()
@@ -576,7 +577,7 @@ def main():
 
     max_boxes = 20
 
-    def build_step(sync_bn):
+    def build_step(sync_bn, grad_exchange="allreduce", bucket_mib=8):
         torch.manual_seed(1029)
         model = yolov5.YOLOv5(80, "s", max_targets=a.batch * max_boxes, fused_loss=not a.torch_loss).to(dev).train()
         if sync_bn and world > 1:
@@ -591,7 +592,8 @@ def main():
             step = TrainStep(model, opt, ema, bucketer, sync_buffers=world > 1)
         else:  # flat arenas: direct gradient writes, in-place bucketed all-reduce, ONE fused SGD+EMA kernel
             # (FlatTrainState broadcasts rank 0's parameters / momentum / buffers at construction, as DDP does)
-            state = FlatTrainState(model, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4, use_ema=(rank == 0), comm=comm)
+            state = FlatTrainState(model, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4, use_ema=(rank == 0), comm=comm,
+                                   grad_exchange=grad_exchange, bucket_bytes=int(bucket_mib) << 20)
             step = FlatTrainStep(model, state, sync_buffers=world > 1)
         return model, state, step
 
@@ -700,10 +702,53 @@ def main():
 
     # ---- side legs: everything below is extra keys of the same line; a leg that fails or hangs must not cost the headline ----
     dog = _Watchdog(out, rank, float(os.environ.get("CVHIP_BENCH_SIDE_BUDGET", "900")))
+    if world > 1:
+        # what every rank saw: its HIP device and the world size its communicator reports (the record shows RCCL ran N ranks)
+        try:
+            seen = torch.zeros(world, 2, device=dev, dtype=torch.float32)
+            seen[rank, 0] = float(torch.cuda.current_device())
+            seen[rank, 1] = float(comm.world)
+            comm.allreduce_(seen)
+            comm.wait()
+            if rank == 0:
+                out["config"]["ranks"] = [{"rank": r, "hip_device": int(seen[r, 0].item()), "comm_world": int(seen[r, 1].item())} for r in range(world)]
+                out["config"]["grad_exchange"] = "allreduce"
+                out["config"]["bucket_mib"] = 8
+        except Exception as e:
+            if rank == 0:
+                out["config"]["ranks"] = {"error": repr(e)[:200]}
+    if world > 1 and not a.no_exchange_ab and not a.stock_optimizer and not a.sync_bn:
+        # ONE invocation answers the open questions of the gradient exchange: ring all-reduce per bucket vs
+        # reduce-scatter + all-gather of the same range, and 8 vs 25 MiB buckets — the same K steps for each, same synthetic batch
+        res = {}
+        step = None
+        for key, ge, mib in (("rsag_8mib", "rsag", 8), ("allreduce_25mib", "allreduce", 25), ("rsag_25mib", "rsag", 25)):
+            try:
+                m2, st2, step2 = build_step(False, ge, mib)
+                i2, t2 = synthetic_detection_batch(a.batch, a.size, seed=1029 + rank, max_boxes=max_boxes, device=dev)
+                g2 = yolov5.targets_to_tensor(t2, a.batch * max_boxes, dev)
+                ug, i2, g2 = warm_and_capture(step2, i2, g2, False)
+                el2, l2, med2, _ = timed_steps(step2, i2, g2, a.steps, barrier)
+                t = torch.tensor([el2, med2], device=dev, dtype=torch.float64)
+                comm.allreduce_(t, "max")
+                comm.wait()
+                if rank == 0:
+                    res[key] = {"value": round(a.batch * world * a.steps / float(t[0].item()), 2), "ms_per_step": round(1e3 * float(t[0].item()) / a.steps, 3),
+                                "ms_per_step_median": round(float(t[1].item()), 3), "grad_buckets": len(st2.buckets),
+                                "launch": "hipGraph replay" if ug else "eager", "final_loss": round(float(l2["loss"]), 4)}
+                del m2, st2, step2
+                torch.cuda.empty_cache()
+            except Exception as e:
+                if rank == 0:
+                    res[key] = {"error": repr(e)[:300]}
+        if rank == 0:
+            res["allreduce_8mib"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "ms_per_step_median": out["ms_per_step_median"],
+                                     "grad_buckets": out["config"]["grad_buckets"], "what": "the headline configuration"}
+            out["grad_exchange_ab"] = res
     if world > 1 and not a.no_sync_bn_leg and not a.sync_bn and not a.stock_optimizer:
         # the reference forces SyncBN under DDP (trainer.py:126-127); SURVEY.md §8(d) config 4: report both
         try:
-            del step
+            step = None
             m2, st2, step2 = build_step(True)
             i2, t2 = synthetic_detection_batch(a.batch, a.size, seed=1029 + rank, max_boxes=max_boxes, device=dev)
             g2 = yolov5.targets_to_tensor(t2, a.batch * max_boxes, dev)

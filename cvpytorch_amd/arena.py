@@ -60,12 +60,18 @@ class FlatTrainState:
     def __init__(self, model, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4, backbone_lr=None, ema_decay=0.9999,
                  use_ema=True, bucket_bytes=8 << 20, process_group=None, comm=None, force_collectives=False, loss_scaling=None,
                  init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, optimizer="sgd", betas=(0.9, 0.999),
-                 eps=1e-8):
+                 eps=1e-8, grad_exchange="allreduce"):
         """optimizer: "sgd" (momentum / nesterov: src/optimizers/__init__.py:60-68) or "adamw" (decoupled weight decay,
         src/optimizers/__init__.py:71-73 — what conf/mini-imagenet.yml:91-99 trains config 1 with): both are ONE fused kernel over the
         flat arenas with the EMA update folded in."""
         self.model = model
         self.momentum, self.nesterov = float(momentum), bool(nesterov)
+        # how a gradient bucket is summed over the ranks: "allreduce" (one ring all-reduce per bucket) or "rsag" (reduce-scatter +
+        # all-gather of the same range: cvhip_comm_reduce_scatter_f32 / _all_gather_f32)
+        self.grad_exchange = str(grad_exchange).lower()
+        if self.grad_exchange not in ("allreduce", "rsag"):
+            raise L.CvhipError("FlatTrainState: grad_exchange must be 'allreduce' or 'rsag'")
+        self.bucket_bytes = int(bucket_bytes)
         self.optimizer = str(optimizer).lower()
         if self.optimizer not in ("sgd", "adamw"):
             raise L.CvhipError("FlatTrainState: optimizer must be 'sgd' or 'adamw'")
@@ -243,6 +249,18 @@ class FlatTrainState:
             for t in (self.param, self.mom, self.buf) + ((self.mom2,) if self.mom2 is not None else ()):
                 if t.numel():
                     self.comm.broadcast_(t, 0)
+            # ... and everything of the state_dict that does not live in an arena: frozen parameters, integer buffers
+            # (num_batches_tracked) — DDP broadcasts the whole module state
+            rest = [p.data for p in model.parameters() if not p.requires_grad] + [b for b in model.buffers() if b.dtype != torch.float32]
+            if self._nbt is not None:
+                rest = [t for t in rest if t.data_ptr() < self._nbt.data_ptr() or t.data_ptr() >= self._nbt.data_ptr() + 8 * self._nbt.numel()]
+                rest.append(self._nbt)
+            for t in rest:
+                if t.numel() and t.is_cuda:
+                    c = t if t.is_contiguous() else t.contiguous()
+                    self.comm.broadcast_(c, 0)
+                    if c is not t:
+                        t.copy_(c)
             self.comm.wait()
             if self.ema_param is not None:
                 self.ema_param.copy_(self.param)
@@ -290,13 +308,19 @@ class FlatTrainState:
         if self._stream is None:
             self._stream = torch.cuda.Stream()
         self._stream.wait_stream(torch.cuda.current_stream())
-        self.comm.allreduce_(flat, stream=self._stream)   # cvhip_allreduce_bucket on the side stream (a graph branch under capture)
+        if self.grad_exchange == "rsag":   # (a graph branch under capture, like the all-reduce)
+            self.comm.reduce_scatter_allgather_(flat, stream=self._stream)
+        else:
+            self.comm.allreduce_(flat, stream=self._stream)   # cvhip_allreduce_bucket on the side stream (a graph branch under capture)
 
     def finish_allreduce(self):
         if not self.multi:
             return
         if self.defer_allreduce:
-            self.comm.allreduce_(self.grad)
+            if self.grad_exchange == "rsag":
+                self.comm.reduce_scatter_allgather_(self.grad)
+            else:
+                self.comm.allreduce_(self.grad)
             self.comm.wait()
             return
         for bi in range(self._next_bucket, len(self.buckets)):  # parameters without a gradient this step: their slots are zero

@@ -37,6 +37,12 @@ class Comm:
     def broadcast_(self, t, root=0, stream=None):
         raise NotImplementedError
 
+    def reduce_scatter_allgather_(self, t, stream=None):
+        """the same sum as allreduce_ as its two ring phases (reduce-scatter, then all-gather of the owned chunks): what SURVEY.md
+        §8(d)/(e) recommends for 29-165 MB gradient payloads over the 7 point-to-point xGMI links. Transports without the split
+        form (and element counts that do not divide by the world size) run the plain all-reduce."""
+        return self.allreduce_(t, "sum", stream)
+
     def barrier(self):
         raise NotImplementedError
 
@@ -85,6 +91,15 @@ class RcclComm(Comm):
         self._check(t)
         st = stream.cuda_stream if stream is not None else torch.cuda.current_stream().cuda_stream
         L.call("cvhip_comm_broadcast", self._h, t.data_ptr(), t.numel() * t.element_size(), int(root), st)
+        return t
+
+    def reduce_scatter_allgather_(self, t, stream=None):
+        self._check(t)
+        if t.dtype != torch.float32 or t.numel() % self.world != 0 or t.numel() == 0:
+            return self.allreduce_(t, "sum", stream)
+        st = stream.cuda_stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        L.call("cvhip_comm_reduce_scatter_f32", self._h, t.data_ptr(), t.numel(), st)
+        L.call("cvhip_comm_all_gather_f32", self._h, t.data_ptr(), t.numel(), st)
         return t
 
     def barrier(self):
@@ -173,7 +188,9 @@ def default_comm(process_group=None):
         if dist.is_available() and dist.is_initialized():
             key = id(process_group) if process_group is not None else None
             c = _TD_CACHE.get(key)
-            if c is None or c.group is not process_group:
+            # a cached transport freezes world / rank: after destroy_process_group() + re-init (test-suite, elastic restart) the
+            # entry of the default group would be stale — rebuild it whenever it no longer describes the live group
+            if c is None or c.group is not process_group or c.world != dist.get_world_size(process_group) or c.rank != dist.get_rank(process_group):
                 c = _TD_CACHE[key] = TorchDistComm(process_group)   # one transport object per group (shared async work list)
             return c
     except Exception:

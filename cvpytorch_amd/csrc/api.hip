@@ -475,6 +475,8 @@ int cvhip_conv2d_fprop_prologue_ok(const cvhip_conv_desc* d, int with_z_out) {
   if (validate_dense_desc(d)) return 0;
   IgemmParams p;
   plan_fprop(d, &p);
+  static const float one = 1.f;
+  p.pro_scale = p.pro_shift = &one;  // "a prologue is requested": geometry decides, not the default speed policy
   if (!patch_takes(p, nullptr) || d->C > 768) return 0;
   if (with_z_out) {
     const int P = conv_out_dim(d->H, d->pad_h, d->dil_h, d->R, d->stride_h);

@@ -774,9 +774,15 @@ static bool patch_plan(const IgemmParams& p, PatchPlan* pl, bool any_geometry = 
   pl->BN = BN;
   pl->CK = CK;
   if (taps_max < 2 && patch_mode() < 2) return false;  // single-tap problems have nothing to re-use
-  if (any_geometry) return true;
-  // policy: the virtual rows / partial tiles must not waste more than a third of the MFMA work
-  if (patch_mode() < 2 && pl->padded * 2 > pl->useful * 3) return false;
+  if (any_geometry || patch_mode() >= 2) return true;
+  // Default policy = where it measured FASTER than the per-tap kernel (profiles/r04_g_patch_bench.log, isolated launches on rotating
+  // operands; 8 waves x 64x64 wave tiles, 2-tap K steps): 128-wide output tiles of a single stride-1 class whose blocks all fit
+  // the 512 resident slots at once — 128->128 3x3 @40x40 b64 43.8 vs 45.4 us, @64x128 b16 45.2 vs 50.2, 256->256 @32x64 46.8 vs 50.4.
+  // It LOSES on 64- / 32-wide outputs (more fragment reads per MFMA: 60.9 vs 58.7, 117 vs 86 us), on the stride-2 dgrad classes
+  // (129.7 vs 109.5) and whenever the tile count spills into a second round of slots (512->512 dilated: 592 blocks, 189 vs 154).
+  if (BN != 128 || a.ncls != 1) return false;
+  if ((int64_t)a.total_tiles > 512) return false;
+  if (pl->padded * 2 > pl->useful * 3) return false;  // virtual rows / partial tiles must not waste more than a third of the MFMA work
   return true;
 }
 
@@ -817,9 +823,10 @@ extern "C" void cvhip_patch_debug_buffer(void* p) { g_patch_dbg = (unsigned long
 
 // geometry-only query (plan queries of api.hip, the Python host's kernel labels): does the patch kernel take this plan?
 bool patch_takes(const IgemmParams& p, int* stats_rows) {
-  if (patch_mode() == 0) return false;
+  const bool need = p.pro_scale || p.z_out;
+  if (patch_mode() == 0 && !need) return false;
   PatchPlan pl;
-  if (!patch_plan(p, &pl)) return false;
+  if (!patch_plan(p, &pl, need)) return false;
   if (stats_rows) *stats_rows = pl.a.total_tiles / pl.a.n_tiles;
   return true;
 }
@@ -847,7 +854,7 @@ int try_launch_patch(const IgemmParams& p, hipStream_t stream) {
   const bool need = p.pro_scale || p.z_out;
   if (patch_mode() == 0 && !need) return -1;
   PatchPlan pl;
-  if (!patch_plan(p, &pl)) return need ? CVHIP_ERR_UNSUPPORTED : -1;
+  if (!patch_plan(p, &pl, need)) return need ? CVHIP_ERR_UNSUPPORTED : -1;  // (a prologue exists only here: the speed policy does not apply)
   PatchArgs& a = pl.a;
   a.x = p.x;
   a.w = p.w;

@@ -527,6 +527,7 @@ class ConvCfg:
         # producer records (ProdInfo): `prod` = what this layer's forward made for its output, `in_prod` = its input's record
         self.prod = None
         self.in_prod = None
+        self.no_grad = False   # conv_bn_act notes whether autograd was recording when the layer was called (inference fast path)
 
 
 # ---- SyncBatchNorm plumbing (trainer.py:126-127 -> torch.nn.SyncBatchNorm semantics) -------------------------------------
@@ -900,7 +901,7 @@ class ConvBnAct(torch.autograd.Function):
             # pack descriptor: contiguous pitches (the packed images do not depend on activation pitches)
             pdesc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, Cc, Kp, kv, cv)
             cfg.state.prepare(weight, pdesc, need_dx, cfg.vkey)
-            if (_EPI_FUSE and not any(ctx.needs_input_grad) and not train_bn and Kp == K and cfg.out_split is None
+            if (_EPI_FUSE and (cfg.no_grad or not any(ctx.needs_input_grad)) and not train_bn and Kp == K and cfg.out_split is None
                     and (cfg.has_bn or cfg.act != L.ACT_NONE or residual is not None) and not (cfg.res_pre and residual is not None)):
                 return _conv_fused_inference(x, x_ld, weight, b, gamma, beta, running_mean, running_var, residual, cfg,
                                              (N, Cc, H, W, K, R, S, P, Q), kv, cv, st)
@@ -1139,6 +1140,7 @@ class ConvBnAct(torch.autograd.Function):
 
 def conv_bn_act(x, weight, bias, gamma, beta, running_mean, running_var, residual, cfg):
     cfg.in_prod = _take_prod(x)
+    cfg.no_grad = not torch.is_grad_enabled()   # (inside Function.forward grad mode is always off: note it here)
     z = ConvBnAct.apply(x, weight, bias, gamma, beta, running_mean, running_var, residual, cfg)
     if cfg.prod is not None and torch.is_tensor(z):
         z._hip_prod = cfg.prod

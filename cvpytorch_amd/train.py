@@ -110,7 +110,7 @@ class GradBucketer:
             # DDP's construction-time broadcast of rank 0's parameters and buffers (trainer.py:312-313); tensors that are not
             # contiguous (channels_last weights) travel through a contiguous copy
             with torch.no_grad():
-                for t in list(model.parameters()) + [b for b in model.buffers() if b.is_floating_point()]:
+                for t in list(model.parameters()) + list(model.buffers()):   # (integer buffers too: num_batches_tracked)
                     d = t.data
                     if d.is_contiguous():
                         self.comm.broadcast_(d, 0)

@@ -90,14 +90,16 @@ def test_stats_rows_tiles():
     # the 8-channel image stem runs on the persistent direct kernel (conv_stem.hip): one partial row per block
     stem = desc(64, 8, 640, 640, 32, 6, 6, (2, 2), (2, 2))
     assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(stem)) == lib.cvhip_conv_stem_blocks(C.byref(stem)) == 768
-    # multi-tap convolutions with Cin % 32 == 0 and a stride-1 input: the patch-resident kernel (conv_patch.hip), one row per spatial tile
+    # multi-tap convolutions whose 128-wide output tiles all fit the 512 resident block slots: the patch-resident kernel
+    # (conv_patch.hip default policy), one partial row per spatial tile
     def patch_rows(dd):
         buf = (C.c_int32 * (4 * L.PATCH_CLASS_INTS))()
         assert lib.cvhip_conv2d_patch_plan(C.byref(dd), 0, buf, 4) == 1
         return buf[24] // buf[23]   # total_tiles / n_tiles
-    big = desc(64, 32, 160, 160, 32, 3, 3, (1, 1), (1, 1))
-    assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(big)) == patch_rows(big) >= (64 * 160 * 160 + 255) // 256
-    # per-tap implicit GEMM (stride-2 input): block-M is 256 for K <= 64 and 128 / 256 otherwise (conv_igemm.hip launch_igemm)
+    mid = desc(64, 128, 40, 40, 128, 3, 3, (1, 1), (1, 1))
+    assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(mid)) == patch_rows(mid) <= 512
+    # per-tap implicit GEMM (narrow outputs, stride-2 inputs, too many tiles): block-M is 256 for K <= 64 and 128 / 256 otherwise
+    assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(desc(64, 32, 160, 160, 32, 3, 3, (1, 1), (1, 1)))) == (64 * 160 * 160 + 255) // 256
     assert lib.cvhip_conv2d_fprop_stats_rows(C.byref(desc(64, 32, 320, 320, 64, 3, 3, (2, 2), (1, 1)))) == (64 * 160 * 160 + 255) // 256
     # 1x1 stride 1 with enough rows: the persistent streaming kernel (conv1x1_stream.hip), balanced grid <= 512
     pw = desc(64, 64, 160, 160, 32, 1, 1)

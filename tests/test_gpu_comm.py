@@ -75,14 +75,14 @@ def test_other_collectives(comm1):
     assert L.load().cvhip_comm_world(comm1._h) == 1 and L.load().cvhip_comm_rank(comm1._h) == 0
 
 
-def _steps(comm, capture, n=3):
+def _steps(comm, capture, n=3, grad_exchange="allreduce"):
     from cvpytorch_amd import yolov5
     from cvpytorch_amd.arena import FlatTrainState, FlatTrainStep
     from cvpytorch_amd.data import synthetic_detection_batch
     d = dev()
     torch.manual_seed(5)
     model = yolov5.YOLOv5(80, "n", max_targets=32, fused_loss=True).to(d).train()
-    state = FlatTrainState(model, use_ema=False, comm=comm, force_collectives=comm is not None, bucket_bytes=1 << 20)
+    state = FlatTrainState(model, use_ema=False, comm=comm, force_collectives=comm is not None, bucket_bytes=1 << 20, grad_exchange=grad_exchange)
     step = FlatTrainStep(model, state, sync_buffers=comm is not None)
     imgs, targets = synthetic_detection_batch(4, 128, seed=7, max_boxes=8, device=d)
     gts = yolov5.targets_to_tensor(targets, 32, d)
@@ -106,3 +106,25 @@ def test_train_step_with_live_bucket_allreduce_equals_plain_step(comm1, capture)
     for a, b in zip(l0, l1):
         assert abs(a - b) <= 2e-3 * abs(a), (l0, l1)
     assert float((p0 - p1).norm() / p0.norm()) <= 1e-3
+
+
+@pytest.mark.parametrize("capture", [False, True])
+def test_train_step_with_reduce_scatter_all_gather_exchange_equals_plain_step(comm1, capture):
+    """FlatTrainState(grad_exchange="rsag"): every bucket goes through cvhip_comm_reduce_scatter_f32 + cvhip_comm_all_gather_f32 on the
+    side stream (captured as a graph branch) instead of one all-reduce; over a 1-rank communicator both are the identity"""
+    l0, p0 = _steps(None, capture)
+    l1, p1 = _steps(comm1, capture, grad_exchange="rsag")
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 2e-3 * abs(a), (l0, l1)
+    assert float((p0 - p1).norm() / p0.norm()) <= 1e-3
+
+
+def test_reduce_scatter_allgather_entry_points(comm1):
+    t = torch.randn(4096, device=dev())
+    r = t.clone()
+    comm1.reduce_scatter_allgather_(t)
+    torch.cuda.synchronize()
+    assert torch.equal(t, r)                    # one rank: identity, and the buffer is left intact
+    h = torch.randn(1024, device=dev()).to(torch.bfloat16)   # not fp32: routed to the plain all-reduce
+    comm1.reduce_scatter_allgather_(h)
+    torch.cuda.synchronize()

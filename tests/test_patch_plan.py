@@ -158,7 +158,10 @@ def test_patch_plan_refuses_what_it_cannot_tile():
     assert lib.cvhip_conv2d_patch_plan(C.byref(desc(2, 24, 40, 40, 64, 3, 3, (1, 1), (1, 1))), 0, buf, 4) == 0   # C % 32
     assert lib.cvhip_conv2d_patch_plan(C.byref(desc(2, 64, 40, 40, 64, 3, 3, (2, 2), (1, 1))), 0, buf, 4) == 0   # stride-2 fprop
     assert lib.cvhip_conv2d_patch_plan(C.byref(desc(2, 64, 8, 8, 64, 1, 1, (2, 2))), 1, buf, 4) == 0   # 1x1 s2 dgrad: empty classes
-    assert lib.cvhip_conv2d_fprop_prologue_ok(C.byref(desc(2, 64, 40, 40, 64, 3, 3, (1, 1), (1, 1))), 1) == 1
+    assert lib.cvhip_conv2d_patch_plan(C.byref(desc(2, 64, 40, 40, 64, 3, 3, (1, 1), (1, 1))), 0, buf, 4) == 0    # default policy: 64-wide outputs
+    assert lib.cvhip_conv2d_patch_plan(C.byref(desc(2, 64, 40, 40, 64, 3, 3, (1, 1), (1, 1))), 2, buf, 4) == 1    # ... geometry-only: fine
+    assert lib.cvhip_conv2d_patch_plan(C.byref(desc(64, 128, 80, 80, 128, 3, 3, (1, 1), (1, 1))), 0, buf, 4) == 0  # > 512 blocks
+    assert lib.cvhip_conv2d_fprop_prologue_ok(C.byref(desc(2, 64, 40, 40, 64, 3, 3, (1, 1), (1, 1))), 1) == 1   # (geometry decides, not the speed policy)
     assert lib.cvhip_conv2d_fprop_prologue_ok(C.byref(desc(2, 64, 40, 40, 64, 3, 3, (1, 1), (0, 0))), 1) == 0   # not "same": no z_out
     assert lib.cvhip_conv2d_fprop_prologue_ok(C.byref(desc(2, 64, 40, 40, 64, 3, 3, (1, 1), (0, 0))), 0) == 1
     assert lib.cvhip_conv2d_fprop_prologue_ok(C.byref(desc(2, 64, 40, 40, 64, 1, 1)), 0) == 0
