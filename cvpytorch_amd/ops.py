@@ -495,7 +495,7 @@ class ConvCfg:
     """Static configuration of one conv(+BN+act) layer (python-side)."""
     __slots__ = ("stride", "pad", "dil", "groups", "act", "act_param", "has_bn", "bn_training", "momentum", "eps",
                  "state", "track", "vkey", "gw", "gb", "gg", "gbeta", "arena", "idx_w", "idx_b", "idx_bn", "sync", "out", "out_split", "dx_link", "res_link", "res_pre",
-                 "acc_owner", "acc_attr", "prod", "in_prod")
+                 "acc_owner", "acc_attr", "prod", "in_prod", "no_grad")
 
     def __init__(self, stride, pad, dil, groups=1, act=L.ACT_NONE, act_param=0.0, has_bn=False, bn_training=True,
                  momentum=0.1, eps=1e-5, state=None, track=True):
