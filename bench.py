@@ -454,38 +454,53 @@ def h2d_leg(model, state, a, dev, imgs_f32, gts, steps):
             "final_loss": round(float(losses["loss"]), 4)}
 
 
-def infer_leg(dev, a, steps, warmup):
+def infer_leg(dev, a, steps, warmup, kind="yolov5s"):
     """Forward only, eval mode, BatchNorm folded (deploy.fuse_model = utils/fuse.py:32-64): every ConvModule is ONE launch — conv +
-    bias + activation (+ residual) in the convolution's epilogue (cvhip_conv2d_fprop_fused) — followed by the detect decode; NMS
-    (data-dependent lengths) is outside. One hipGraph replay per batch. Also counts, in an eager pass, the BN / activation
-    element-wise launches that are left (the fused epilogue's point is that there are none)."""
-    from cvpytorch_amd import deploy, ops, yolov5
-    from cvpytorch_amd.data import synthetic_detection_batch
-    model = yolov5.YOLOv5(80, "s", fused_loss=True).to(dev).eval()
+    bias + activation (+ residual, before or after the activation) in the convolution's epilogue (cvhip_conv2d_fprop_fused; the
+    depthwise halves of DeepLabv3+'s separable modules through cvhip_dwconv2d_fprop_act) — followed by the detect decode (YOLOv5-s;
+    NMS, with its data-dependent lengths, is outside) or the segmentation head's logits (DeepLabv3+; the label-size resize + argmax
+    are outside). One hipGraph replay per batch. An eager pass counts the BN / activation element-wise launches that are left (the
+    fused epilogue's point is that there are none)."""
+    from cvpytorch_amd import deploy, ops
+    if kind == "yolov5s":
+        from cvpytorch_amd import yolov5
+        from cvpytorch_amd.data import synthetic_detection_batch
+        batch = a.batch
+        model = yolov5.YOLOv5(80, "s", fused_loss=True).to(dev).eval()
+        imgs, _ = synthetic_detection_batch(batch, a.size, seed=7, device=dev)
+        x = ops.images_to_nhwc(imgs, cpad=8)
+        what = "YOLOv5-s %dx%d bf16 forward + decode, batch %d" % (a.size, a.size, batch)
+        run = lambda: model.forward_features(x)[0]
+    else:
+        from cvpytorch_amd import deeplab
+        from cvpytorch_amd.data import synthetic_segmentation_batch
+        batch = 16
+        model = deeplab.EncoderDecoder(19, output_stride=32).to(dev).eval()
+        x, _ = synthetic_segmentation_batch(batch, (512, 1024), device=dev)
+        what = "DeepLabv3+ R50-v1c 1024x512 bf16 forward to the head's logits, batch %d, OS-32" % batch
+        run = lambda: model.forward_features(x)[1][0]
     deploy.fuse_model(model)
-    imgs, _ = synthetic_detection_batch(a.batch, a.size, seed=7, device=dev)
-    x = ops.images_to_nhwc(imgs, cpad=8)
     with torch.no_grad():
         for _ in range(max(2, warmup)):
-            out, _raw = model.forward_features(x)
+            out = run()
         torch.cuda.synchronize()
         ops.TIMER.enabled = True
         ops.TIMER.reset()
-        model.forward_features(x)
+        run()
         torch.cuda.synchronize()
         ops.TIMER.enabled = False
         names = [r[0] for r in ops.TIMER.records]
         ew = sum(1 for n in names if "ew_kernel" in n or "bn_act" in n)
-        convs = sum(1 for n in names if n == "conv_fused_inference")
+        convs = sum(1 for n in names if n in ("conv_fused_inference", "dw_fused_inference"))
         ops.TIMER.reset()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         g = torch.cuda.CUDAGraph()
         with torch.cuda.stream(s):
-            model.forward_features(x)
+            run()
             torch.cuda.synchronize()
             with torch.cuda.graph(g, stream=s):
-                out, _raw = model.forward_features(x)
+                out = run()
         torch.cuda.current_stream().wait_stream(s)
         for _ in range(3):
             g.replay()
@@ -495,10 +510,10 @@ def infer_leg(dev, a, steps, warmup):
             g.replay()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-    return {"value": round(a.batch * steps / el, 2), "unit": "images/sec", "ms_per_batch": round(1e3 * el / steps, 3), "steps": steps,
-            "workload": "YOLOv5-s %dx%d bf16 forward + decode, batch %d, eval mode, BatchNorm folded (deploy.fuse_model)" % (a.size, a.size, a.batch),
+    return {"value": round(batch * steps / el, 2), "unit": "images/sec", "ms_per_batch": round(1e3 * el / steps, 3), "steps": steps,
+            "workload": what + ", eval mode, BatchNorm folded (deploy.fuse_model)",
             "launch": "hipGraph replay", "fused_conv_launches": convs, "bn_act_elementwise_launches": ew,
-            "finite": bool(torch.isfinite(out).all())}
+            "finite": bool(torch.isfinite(out.float()).all())}
 
 
 class _Watchdog:
@@ -779,11 +794,12 @@ def main():
                 out["with_h2d"] = {"error": repr(e)[:300]}
         side_steps, side_warm = max(a.steps, 20), max(a.warmup, 3)
         if not a.no_extra:
-            try:
-                out["infer"] = infer_leg(dev, a, side_steps, side_warm)
-            except Exception as e:
-                out["infer"] = {"error": repr(e)[:300]}
-            torch.cuda.empty_cache()
+            for key, kind in (("infer", "yolov5s"), ("infer_deeplabv3plus_r50", "deeplab")):
+                try:
+                    out[key] = infer_leg(dev, a, side_steps, side_warm, kind)
+                except Exception as e:
+                    out[key] = {"error": repr(e)[:300]}
+                torch.cuda.empty_cache()
         if not a.no_deeplab:
             try:
                 out["config3_deeplabv3plus_r50"] = deeplab_workload(dev, a, steps=side_steps, warmup=side_warm)

@@ -467,6 +467,9 @@ int cvhip_conv2d_fprop_fused(const cvhip_conv_desc* d, const void* x, const void
     if (f->residual_ld < d->K) return CVHIP_ERR_INVALID;
     p.res = (const h16_t*)f->residual;
     p.res_ld = f->residual_ld;
+    p.res_pre = f->residual_pre ? 1 : 0;
+    // (the residual-before-activation form lives in the fused-epilogue instances: request them even for a bare residual add)
+    if (p.res_pre && !p.ep_scale && p.ep_act == CVHIP_ACT_NONE) p.res_pre = 0;
   }
   return launch_igemm(p, (hipStream_t)stream);
 }

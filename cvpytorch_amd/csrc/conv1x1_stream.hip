@@ -228,9 +228,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernA
           const int cl8 = j * 32 + g * 8;
 #pragma unroll
           for (int q = 0; q < 8; ++q) v.v[q] = v.v[q] * stail[cl8 + q] + stail[BN + cl8 + q];
+          if (p.res && p.res_pre && m < M) {  // residual before the activation (ResNet bottleneck tail)
+            const h16_t* rrow = p.res + (int64_t)m * p.res_ld + ch0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+              if (ch0 + q < p.Nout) v.v[q] += (float)rrow[q];
+          }
           s1_act_vec<8>(v.v, p.ep_act, p.ep_ap);
         }
-        if (p.res && m < M) {  // skip-connection gradient folded into the epilogue
+        if (p.res && !(EPI && p.res_pre) && m < M) {  // skip-connection gradient folded into the epilogue
           const h16_t* rrow = p.res + (int64_t)m * p.res_ld + ch0;
           if (ch0 + 7 < p.Nout && (p.res_ld & 7) == 0 && ((((uintptr_t)p.res) & 15) == 0)) {
             const f32x8 rv = unpack8(*reinterpret_cast<const uint4*>(rrow));

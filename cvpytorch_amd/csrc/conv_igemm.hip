@@ -820,13 +820,19 @@ __global__ __launch_bounds__(NW * 64, WS ? 2 : igemm_min_waves(BM, BN, BK, NST, 
         if constexpr (ep_on) {
           const f32x4 sv = *reinterpret_cast<const f32x4*>(stail + wn * WN + a * 16 + nq), tv = *reinterpret_cast<const f32x4*>(stail + BN + wn * WN + a * 16 + nq);
           float ev[4] = {v0 * sv[0] + tv[0], v1 * sv[1] + tv[1], v2 * sv[2] + tv[2], v3 * sv[3] + tv[3]};
+          if (p.res && p.res_pre) {  // residual before the activation (ResNet bottleneck tail)
+            const h16_t* rrow = rbase + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (n + r < p.Nout) ev[r] += (float)rrow[r];
+          }
           ig_act_vec<4>(ev, p.ep_act, p.ep_ap);
           v0 = ev[0];
           v1 = ev[1];
           v2 = ev[2];
           v3 = ev[3];
         }
-        if (p.res) {  // skip-connection gradient folded into dgrad's epilogue (replaces autograd's accumulation add)
+        if (p.res && !(ep_on && p.res_pre)) {  // skip-connection gradient folded into dgrad's epilogue (replaces autograd's accumulation add)
           const h16_t* rrow = rbase + n;
           if (VEC && rvec) {
             const uint2 u = *reinterpret_cast<const uint2*>(rrow);  // 4 consecutive channels, like the store below
@@ -916,13 +922,18 @@ __global__ __launch_bounds__(NW * 64, WS ? 2 : igemm_min_waves(BM, BN, BK, NST, 
           if constexpr (ep_on) {
             const f32x4 sv = *reinterpret_cast<const f32x4*>(stail + nl), tv = *reinterpret_cast<const f32x4*>(stail + BN + nl);
             float ev[4] = {v0 * sv[0] + tv[0], v1 * sv[1] + tv[1], v2 * sv[2] + tv[2], v3 * sv[3] + tv[3]};
+            if (rbase && p.res_pre && n0 + nl < p.Nout) {  // (the staged form needs Nout % 8 == 0: the 4 channels exist)
+              const h16_t* rrow = rbase + n0 + nl;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) ev[r] += (float)rrow[r];
+            }
             ig_act_vec<4>(ev, p.ep_act, p.ep_ap);
             v0 = ev[0];
             v1 = ev[1];
             v2 = ev[2];
             v3 = ev[3];
           }
-          if (rbase && n0 + nl < p.Nout) {
+          if (rbase && !(ep_on && p.res_pre) && n0 + nl < p.Nout) {
             const h16_t* rrow = rbase + n0 + nl;
             if (rvec) {
               const uint2 u = *reinterpret_cast<const uint2*>(rrow);

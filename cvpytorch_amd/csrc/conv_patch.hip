@@ -80,6 +80,7 @@ struct PatchArgs {
   int n_tiles, total_tiles, ncls;
   const h16_t* res;
   int res_ld;
+  int res_pre;  // `res` joins before the epilogue's activation
   // prologue (PRO = 1): x holds the RAW convolution output of the producing layer; the patch loader applies act(scale*x + shift)
   const float *pro_scale, *pro_shift;
   float pro_ap;
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(kPatchThreads, 4) void conv_patch_kernel(const Patc
   constexpr int EP_PITCH = BN * 2 + 16;
   unsigned char* const tile = smem + 5 * BN * (int)sizeof(float);
   const int nq = g * 4;
-  const bool plain = !p.bias && !has_ss && p.ep_act == CVHIP_ACT_NONE;
+  const bool plain = !p.bias && !has_ss && p.ep_act == CVHIP_ACT_NONE && !p.res_pre;
   const bool rvec = p.res && (p.res_ld & 3) == 0 && ((((uintptr_t)p.res) & 7) == 0);
   bool rok[MF];
 #pragma unroll
@@ -520,9 +521,15 @@ __global__ __launch_bounds__(kPatchThreads, 4) void conv_patch_kernel(const Patc
         const f32x4 sv = *reinterpret_cast<const f32x4*>(sconst + BN + nl), tv = *reinterpret_cast<const f32x4*>(sconst + 2 * BN + nl);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = (v[r] + bv[r]) * sv[r] + tv[r];
+        if (rbase && p.res_pre && n0 + nl < p.Nout) {  // residual before the activation (ResNet bottleneck tail)
+          const h16_t* rrow = rbase + n0 + nl;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n0 + nl + r < p.Nout) v[r] += (float)rrow[r];
+        }
         patch_act_vec<4>(v, p.ep_act, p.ep_ap);
       }
-      if (rbase && n0 + nl < p.Nout) {
+      if (rbase && !p.res_pre && n0 + nl < p.Nout) {
         const h16_t* rrow = rbase + n0 + nl;
         if (rvec) {
           const uint2 u = *reinterpret_cast<const uint2*>(rrow);
@@ -866,6 +873,7 @@ int try_launch_patch(const IgemmParams& p, hipStream_t stream) {
   a.stats_acc = p.stats_acc;
   a.res = p.res;
   a.res_ld = p.res_ld;
+  a.res_pre = (p.res && p.res_pre) ? 1 : 0;
   a.pro_scale = p.pro_scale;
   a.pro_shift = p.pro_shift;
   a.pro_ap = p.pro_ap;

@@ -62,6 +62,8 @@ struct IgemmCommon {
   const float *ep_scale, *ep_shift;
   int ep_act;
   float ep_ap;
+  int res_pre;  // with a fused epilogue: `res` joins BEFORE the activation — act(conv*scale + shift + res), the ResNet bottleneck tail
+                // (relu(bn3(conv3) + identity)) — instead of after it (Darknet shortcut x + act(bn(conv)))
   // fused PROLOGUE (conv_patch.hip only): x is the RAW convolution output of the producing Conv-BN-act layer; the patch loader
   // applies act(pro_scale * x + pro_shift) per input channel on the way into the LDS and (z_out != NULL) stores the activated
   // tensor once, for the weight-gradient pass

@@ -12,6 +12,35 @@
 
 namespace cvhip {
 
+// fused activation of the depthwise forward kernels (inference: ConvModule's act after a folded BatchNorm, utils/fuse.py:32-54):
+// one block-uniform switch per 8-channel vector; act == NONE (every training launch) costs one scalar compare
+__device__ __forceinline__ void dw_act8(f32x8& o, int act, float ap) {
+  if (act == CVHIP_ACT_NONE) return;
+  switch (act) {
+    case CVHIP_ACT_RELU:
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o.v[j] = act_fwd(o.v[j], CVHIP_ACT_RELU, ap);
+      break;
+    case CVHIP_ACT_SILU:
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o.v[j] = act_fwd(o.v[j], CVHIP_ACT_SILU, ap);
+      break;
+    case CVHIP_ACT_LEAKY:
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o.v[j] = act_fwd(o.v[j], CVHIP_ACT_LEAKY, ap);
+      break;
+    case CVHIP_ACT_SIGMOID:
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o.v[j] = act_fwd(o.v[j], CVHIP_ACT_SIGMOID, ap);
+      break;
+    default:
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o.v[j] = act_fwd(o.v[j], CVHIP_ACT_HSWISH, ap);
+      break;
+  }
+}
+
+
 struct DwParams {
   const h16_t* x;   // fprop: input; dgrad: dy; wgrad: x
   const h16_t* dy;  // wgrad only
@@ -21,6 +50,8 @@ struct DwParams {
   float* dw;
   int N, C, H, W, P, Q, R, S, sh, sw, ph, pw, dh, dw_;
   int x_ld, y_ld;
+  int act;    // fprop: activation applied to the result (CVHIP_ACT_NONE in training; memset by fill())
+  float ap;
 };
 
 __device__ __forceinline__ bool dw_vec_ok(const DwParams& p) {
@@ -73,6 +104,7 @@ __global__ __launch_bounds__(256) void dw_fprop_kernel(const DwParams p) {
     f32x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o.v[j] = acc[j];
+    dw_act8(o, p.act, p.ap);
     dw_store8(p.y + ((int64_t)(n * p.P + pp) * p.Q + q) * p.y_ld, c, p.C, vec, o);
   }
 }
@@ -199,6 +231,8 @@ struct DwTapParams {
   h16_t* out;
   int N, C, IH, IW, OH, OW, sh, sw, T, in_ld, out_ld, ppb;  // ppb: pixels per block
   int offh[kDwMaxTaps], offw[kDwMaxTaps];
+  int act;
+  float ap;
 };
 
 __global__ __launch_bounds__(256) void dw_taps_kernel(const DwTapParams p) {
@@ -265,6 +299,7 @@ __global__ __launch_bounds__(256) void dw_taps_kernel(const DwTapParams p) {
     f32x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o.v[j] = acc[j];
+    dw_act8(o, p.act, p.ap);
     *reinterpret_cast<uint4*>(p.out + (int64_t)pix * p.out_ld + c) = pack8(o);
   }
 }
@@ -283,6 +318,8 @@ static bool dw_taps_launch(const DwParams& p, bool dgrad, hipStream_t s, int* st
   q.in = p.x;   // fprop: x; dgrad: dy (the caller swapped the pitches)
   q.w = p.w;
   q.bias = dgrad ? nullptr : p.bias;
+  q.act = dgrad ? CVHIP_ACT_NONE : p.act;
+  q.ap = p.ap;
   q.out = p.y;
   q.N = p.N;
   q.C = p.C;
@@ -334,6 +371,8 @@ struct Dw3Params {
   h16_t* out;
   float* dw;
   int N, C, IH, IW, OH, OW, ph, pw, in_ld, out_ld, dy_ld, flip, seg_len, rows_per_thread;
+  int act;   // MODE 0 (fprop): fused activation
+  float ap;
 };
 
 __device__ __forceinline__ f32x8 dw3_load(const h16_t* row, bool row_ok, int iw, int IW, int in_ld, int c) {
@@ -443,6 +482,7 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const Dw3Params p) {
               for (int s2 = 0; s2 < 3; ++s2) a += win[r][s2].v[j] * w[r][s2][j];
             o.v[j] = a;
           }
+          dw_act8(o, p.act, p.ap);
           *reinterpret_cast<uint4*>(p.out + ((int64_t)row * p.OW + q) * p.out_ld + c) = pack8(o);
         } else {
           const f32x8 g = unpack8(cdy);
@@ -697,6 +737,7 @@ __global__ __launch_bounds__((kDwLdsCW + 1) * 64) void dw3x3_lds_kernel(const Dw
               for (int s2 = 0; s2 < 3; ++s2) a += win[r][q + s2].v[jj] * w[r][s2][jj];
             o.v[jj] = a;
           }
+          dw_act8(o, p.act, p.ap);
           if (ow < p.OW) *reinterpret_cast<uint4*>(p.out + ((int64_t)(n * p.OH + oh) * p.OW + ow) * p.out_ld + c) = pack8(o);
         } else {
           // dy of pixels past the image / strip edge was staged as zeros
@@ -827,7 +868,7 @@ using namespace cvhip;
 
 extern "C" {
 
-int cvhip_dwconv2d_fprop(const cvhip_conv_desc* d, const void* x, const float* w, const float* bias, void* y, void* stream) {
+static int dw_fprop_impl(const cvhip_conv_desc* d, const void* x, const float* w, const float* bias, int act, float ap, void* y, void* stream) {
   DwParams p;
   int st = fill(d, &p);
   if (st) return st;
@@ -835,12 +876,15 @@ int cvhip_dwconv2d_fprop(const cvhip_conv_desc* d, const void* x, const float* w
   p.x = (const h16_t*)x;
   p.w = w;
   p.bias = bias;
+  p.act = act;
+  p.ap = ap;
   p.y = (h16_t*)y;
   p.x_ld = d->x_ld;
   p.y_ld = d->y_ld;
   if (dw3_applicable(p, x, y, nullptr)) {
     Dw3Params q{};
     q.in = p.x; q.w = w; q.bias = bias; q.out = p.y;
+    q.act = act; q.ap = ap;
     q.N = p.N; q.C = p.C; q.IH = p.H; q.IW = p.W; q.OH = p.P; q.OW = p.Q; q.ph = p.ph; q.pw = p.pw;
     q.in_ld = p.x_ld; q.out_ld = p.y_ld; q.flip = 0;
     int grid, lst = CVHIP_OK;
@@ -856,6 +900,16 @@ int cvhip_dwconv2d_fprop(const cvhip_conv_desc* d, const void* x, const float* w
   hipLaunchKernelGGL(dw_fprop_kernel, dim3(grid_for((int64_t)p.N * p.P * p.Q * ((p.C + 7) / 8))), dim3(256), 0,
                      (hipStream_t)stream, p);
   return check_launch("dw_fprop_kernel");
+}
+
+int cvhip_dwconv2d_fprop(const cvhip_conv_desc* d, const void* x, const float* w, const float* bias, void* y, void* stream) {
+  return dw_fprop_impl(d, x, w, bias, CVHIP_ACT_NONE, 0.f, y, stream);
+}
+
+int cvhip_dwconv2d_fprop_act(const cvhip_conv_desc* d, const void* x, const float* w, const float* bias, int32_t act, float act_param, void* y,
+                             void* stream) {
+  if (act < CVHIP_ACT_NONE || act > CVHIP_ACT_HSWISH) return CVHIP_ERR_INVALID;
+  return dw_fprop_impl(d, x, w, bias, act, act_param, y, stream);
 }
 
 int cvhip_dwconv2d_dgrad(const cvhip_conv_desc* d, const void* dy, const float* w, void* dx, void* stream) {

@@ -23,6 +23,7 @@ from . import lib as L
 
 ACT_DTYPE = torch.bfloat16  # storage dtype of activations / operand images / activation gradients (set_precision)
 _weights_epoch = 0  # bumped by the fused optimizer (it updates parameters behind torch's back)
+_stats_epoch = [0]  # bumped by every training-mode BatchNorm forward (running statistics are updated by kernels, not torch ops)
 
 
 def set_precision(p):
@@ -797,8 +798,10 @@ def _bn_fwd_acc(y, y_ld, z, z_ld, M, kh, off, K, acc_f, gamma, beta, running_mea
 
 def _eval_scale_shift(cfg, gamma, beta, running_mean, running_var, K, dev, st):
     """(scale, shift) of an eval-mode BatchNorm, cached on the layer's ConvState until one of its tensors is written again"""
+    # (_weights_epoch: the fused optimizer step and the BN kernels write parameters / running statistics through raw pointers,
+    # behind torch's version counters)
     key = (running_mean.data_ptr(), running_mean._version, running_var._version, None if gamma is None else gamma._version,
-           None if beta is None else beta._version, float(cfg.eps))
+           None if beta is None else beta._version, float(cfg.eps), _weights_epoch, _stats_epoch[0])
     cache = getattr(cfg.state, "ep_cache", None)
     if cache is not None and cache[0] == key:
         return cache[1]
@@ -808,6 +811,24 @@ def _eval_scale_shift(cfg, gamma, beta, running_mean, running_var, K, dev, st):
            ss[0].data_ptr(), ss[1].data_ptr(), st)
     cfg.state.ep_cache = (key, ss)
     return ss
+
+
+def _dw_folded(cfg, wm, bias, gamma, beta, running_mean, running_var, K, dev, st):
+    """(weights [K][R][S], bias [K]) of a depthwise layer with its eval-mode BatchNorm folded in (fp32), cached on the layer's
+    ConvState until the weight or a BatchNorm tensor is written again"""
+    if not cfg.has_bn:
+        return wm, bias
+    key = (wm.data_ptr(), wm._version, running_mean.data_ptr(), running_mean._version, running_var._version,
+           None if gamma is None else gamma._version, None if beta is None else beta._version, None if bias is None else bias._version,
+           _weights_epoch, _stats_epoch[0])
+    cache = getattr(cfg.state, "dw_cache", None)
+    if cache is not None and cache[0] == key:
+        return cache[1], cache[2]
+    ss = _eval_scale_shift(cfg, gamma, beta, running_mean, running_var, K, dev, st)
+    wf = (wm * ss[0].view(K, 1, 1)).contiguous()
+    bf = ss[1].clone() if bias is None else (bias * ss[0] + ss[1])
+    cfg.state.dw_cache = (key, wf, bf)
+    return wf, bf
 
 
 def _conv_fused_inference(x, x_ld, weight, bias, gamma, beta, running_mean, running_var, residual, cfg, geom, kv, cv, st):
@@ -833,6 +854,7 @@ def _conv_fused_inference(x, x_ld, weight, bias, gamma, beta, running_mean, runn
         residual, res_ld = as_nhwc(residual)
         keep.append(residual)
         f.residual, f.residual_ld = residual.data_ptr(), res_ld
+        f.residual_pre = int(bool(cfg.res_pre))   # ResNet bottleneck tail: relu(bn3(conv3) + identity)
     kname = "conv_fused_inference"
     _timed_call(kname, geom, "cvhip_conv2d_fprop_fused", C.byref(desc), x.data_ptr(), cfg.state.w_fprop.data_ptr(), z.data_ptr(), C.byref(f), st)
     cfg.prod = None
@@ -879,6 +901,8 @@ class ConvBnAct(torch.autograd.Function):
         y = empty_nhwc(N, K, P, Q, dev, ld=Kp)
         st = _stream()
         train_bn = cfg.has_bn and cfg.bn_training
+        if train_bn:
+            _stats_epoch[0] += 1
         if cfg.has_bn and bias is not None:
             raise L.CvhipError("conv bias followed by BatchNorm is not supported (ConvModule never builds it)")
         stats = None
@@ -895,6 +919,20 @@ class ConvBnAct(torch.autograd.Function):
             wm = weight.detach()
             wm = (wm if wm.dtype == torch.float32 else wm.float()).reshape(K, R, S)
             wm = wm if wm.is_contiguous() else wm.contiguous()
+            if (_EPI_FUSE and (cfg.no_grad or not any(ctx.needs_input_grad)) and not train_bn and residual is None and cfg.out_split is None
+                    and (cfg.has_bn or cfg.act != L.ACT_NONE)):
+                # inference: depthwise conv + eval-mode BatchNorm + activation in ONE pass. The BatchNorm's scale / shift are folded
+                # into the (tiny, fp32) depthwise weights and bias on the way — utils/fuse.py:32-54 per call, cached per layer
+                wf, bf = _dw_folded(cfg, wm, b, gamma, beta, running_mean, running_var, K, dev, st)
+                if cfg.out is not None:
+                    z, z_ld = _check_out(cfg.out, N, K, P, Q)
+                else:
+                    z, z_ld = (y, Kp) if Kp == K else (empty_nhwc(N, K, P, Q, dev), K)
+                zdesc = conv_desc(N, Cc, H, W, K, R, S, cfg.stride, cfg.pad, cfg.dil, cfg.groups, x_ld, z_ld)
+                _timed_ew("dw_fused_inference", 2.0 * (N * H * W * Cc + M * K), "cvhip_dwconv2d_fprop_act", C.byref(zdesc), x.data_ptr(), wf.data_ptr(),
+                          _ptr(bf), int(cfg.act), float(cfg.act_param), z.data_ptr(), st)
+                cfg.prod = None
+                return z
             L.call("cvhip_dwconv2d_fprop", C.byref(desc), x.data_ptr(), wm.data_ptr(), _ptr(b), y.data_ptr(), st)
         else:
             desc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, x_ld, Kp, kv, cv)
@@ -902,7 +940,7 @@ class ConvBnAct(torch.autograd.Function):
             pdesc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, Cc, Kp, kv, cv)
             cfg.state.prepare(weight, pdesc, need_dx, cfg.vkey)
             if (_EPI_FUSE and (cfg.no_grad or not any(ctx.needs_input_grad)) and not train_bn and Kp == K and cfg.out_split is None
-                    and (cfg.has_bn or cfg.act != L.ACT_NONE or residual is not None) and not (cfg.res_pre and residual is not None)):
+                    and (cfg.has_bn or cfg.act != L.ACT_NONE or residual is not None)):
                 return _conv_fused_inference(x, x_ld, weight, b, gamma, beta, running_mean, running_var, residual, cfg,
                                              (N, Cc, H, W, K, R, S, P, Q), kv, cv, st)
             use_acc = _BN_ACC and not _DETERMINISTIC and epilogue_stats and cfg.sync is None and K <= _BN_ACC_MAX_C

@@ -188,6 +188,10 @@ int cvhip_conv2d_wgrad_det(const cvhip_conv_desc* d, const void* x, const void* 
  * weights: fp32 [C][R][S] master is used directly. */
 int cvhip_dwconv2d_fprop(const cvhip_conv_desc* d, const void* x_bf16, const float* w_crs,
                          const float* bias, void* y_bf16, void* stream);
+/* depthwise fprop with the layer's activation applied in the same pass (inference: after deploy.fuse_model the BatchNorm of a
+ * DepthwiseSeparableConvModule's depthwise half is folded into w / bias — utils/fuse.py:32-54 — and only the activation remains) */
+int cvhip_dwconv2d_fprop_act(const cvhip_conv_desc* d, const void* x, const float* w_crs, const float* bias, int32_t act, float act_param,
+                             void* y, void* stream);
 int cvhip_dwconv2d_dgrad(const cvhip_conv_desc* d, const void* dy_bf16, const float* w_crs,
                          void* dx_bf16, void* stream);
 int cvhip_dwconv2d_wgrad(const cvhip_conv_desc* d, const void* x_bf16, const void* dy_bf16,
@@ -685,8 +689,9 @@ typedef struct cvhip_conv_fuse {
   float pro_act_param;
   void* z_out;
   int32_t z_ld;
-  const void* residual; /* optional addend applied AFTER the activation (Darknet shortcut x + act(bn(conv))), pitch residual_ld */
+  const void* residual; /* optional addend, pitch residual_ld: applied AFTER the activation (Darknet shortcut x + act(bn(conv))) ... */
   int32_t residual_ld;
+  int32_t residual_pre; /* ... or, non-zero, BEFORE it: act(bn(conv) + residual), the ResNet bottleneck tail (torchvision Bottleneck) */
 } cvhip_conv_fuse;
 #endif
 int cvhip_conv2d_fprop_fused(const cvhip_conv_desc* d, const void* x, const void* w, void* y, const cvhip_conv_fuse* f, void* stream);

@@ -182,3 +182,65 @@ def test_eval_forward_is_one_launch_per_convmodule_and_matches_the_oracle_and_th
         err = float((t.float().cpu() - w).abs().max())
         assert err <= 3e-2 * scale, (name, err, scale)
     assert float((got.float() - two_pass.float()).abs().max()) <= 2e-2 * scale
+
+
+def test_deeplab_eval_forward_has_no_elementwise_bn_act_pass_and_matches_the_two_pass_form():
+    """DeepLabv3+ in inference: the ResNet bottleneck tails relu(bn3(conv3) + identity) (residual BEFORE the activation), the
+    dilated / depthwise-separable ASPP and decoder modules (cvhip_dwconv2d_fprop_act) and every other ConvModule run as ONE launch
+    each — before and after deploy.fuse_model — and give the two-pass result to 16-bit rounding."""
+    from cvpytorch_amd import deeplab, ops
+    torch.manual_seed(0)
+    m = deeplab.EncoderDecoder(19, output_stride=32).to(dev())
+    _randomise_bn(m)
+    m.eval()
+    x = torch.randn(2, 3, 64, 96).to(dev())
+
+    def run():
+        return m.forward_features(x)[1][0].float()
+
+    with torch.no_grad():
+        old = ops._EPI_FUSE
+        ops._EPI_FUSE = False
+        try:
+            ref = run()
+        finally:
+            ops._EPI_FUSE = old
+        ops.TIMER.enabled = True
+        ops.TIMER.reset()
+        got = run()
+        torch.cuda.synchronize()
+        names = [r[0] for r in ops.TIMER.records]
+        ops.TIMER.enabled = False
+        ops.TIMER.reset()
+        assert not [n for n in names if "ew_kernel" in n or "bn_act" in n], sorted(set(names))
+        assert sum(n == "dw_fused_inference" for n in names) >= 4 and sum(n == "conv_fused_inference" for n in names) >= 50
+        deploy.fuse_model(m)
+        folded = run()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 3e-2 * scale
+    assert float((folded - ref).abs().max()) <= 3e-2 * scale
+
+
+@pytest.mark.parametrize("act", [1, 2, 3])
+@pytest.mark.parametrize("Cc,H,W,k,s,p,d", [(32, 12, 14, 3, 1, 1, 1), (48, 11, 9, 3, 2, 1, 1), (64, 16, 16, 3, 1, 6, 6), (24, 9, 9, 5, 1, 2, 1), (128, 40, 48, 3, 1, 1, 1)])
+def test_depthwise_fprop_with_fused_activation(Cc, H, W, k, s, p, d, act):
+    """cvhip_dwconv2d_fprop_act == act(depthwise conv + bias) on every depthwise forward kernel (register window, LDS ring, taps in
+    registers, generic)"""
+    import ctypes as C
+    import torch.nn.functional as F
+    from cvpytorch_amd import lib as L, ops
+    g = torch.Generator().manual_seed(Cc + k)
+    x = torch.randn(2, Cc, H, W, generator=g).to(torch.bfloat16).float()
+    w = torch.randn(Cc, 1, k, k, generator=g) / k
+    b = torch.randn(Cc, generator=g) * 0.3
+    y = F.conv2d(x, w, b, stride=s, padding=p, dilation=d, groups=Cc)
+    ref = {1: torch.relu(y), 2: y * torch.sigmoid(y), 3: torch.where(y > 0, y, 0.1 * y)}[act]
+    xd = x.to(dev()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    P, Q = ref.shape[2:]
+    out = ops.empty_nhwc(2, Cc, P, Q, dev())
+    desc = ops.conv_desc(2, Cc, H, W, Cc, k, k, (s, s), (p, p), (d, d), Cc, Cc, Cc)
+    wd, bd = w.reshape(Cc, k, k).contiguous().to(dev()), b.to(dev())
+    L.call("cvhip_dwconv2d_fprop_act", C.byref(desc), xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), act, 0.1, out.data_ptr(), ops._stream())
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    assert float((got - ref).abs().max()) <= 2 ** -7 * float(ref.abs().max()) + 1e-3
