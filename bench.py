@@ -312,14 +312,14 @@ def yolov7_workload(dev, a, steps, warmup, batch=16, size=1280):
 
 
 def pmc_traffic(kernel_label):
-    """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r03_pmc_traffic_raw.json, falling back to
+    """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r04_pmc_traffic_raw.json, falling back to
     earlier rounds'; collected by `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and, separately, `--pmc WRITE_SIZE --kernel-trace` over
     tools/pmc_workload.py = the same eager train step). Corrections per MI355X_MICROARCH.md (HBM section): the counters are KiB;
     on gfx950 FETCH_SIZE tallies 128-B read requests at 64 B => x2 (confirmed in the same pass on a kernel with a known byte count:
     a 419.4 MB bf16 copy reads FETCH_SIZE 204,8xx KiB; its 419.4 MB of writes read WRITE_SIZE 409,600 KiB => WRITE_SIZE x1).
     null if no file / no matching kernel."""
     raw = None
-    for name in ("r03_pmc_traffic_raw.json", "r02_pmc_traffic_raw.json", "r01_pmc_traffic_raw.json"):
+    for name in ("r04_pmc_traffic_raw.json", "r03_pmc_traffic_raw.json", "r02_pmc_traffic_raw.json", "r01_pmc_traffic_raw.json"):
         try:
             raw = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)))
             break

@@ -1,5 +1,6 @@
 """In-tree build of libcvhip.so (hipcc, gfx950 only). No torch involvement: the library is a plain
-C-ABI shared object (include/cvhip.h) loaded through ctypes.
+C-ABI shared object (include/cvhip.h) loaded through ctypes. The measurement / known-answer kernels of csrc/probes.hip go into a
+second library, libcvhip_probes.so (include/cvhip_probes.h), which the product never loads.
 
     python -m cvpytorch_amd.build [--force]
 """
@@ -12,6 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libcvhip.so")
+PROBES_LIB = os.path.join(HERE, "libcvhip_probes.so")
+PROBE_SOURCES = ("probes.hip",)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 SOURCES = [
@@ -40,6 +43,7 @@ FLAGS = [
 def _deps():
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(HERE, "..", "include", "cvhip.h"))
+    hdrs.append(os.path.join(HERE, "..", "include", "cvhip_probes.h"))
     return hdrs
 
 
@@ -102,7 +106,8 @@ def build_lib(force=False, verbose=True):
                 os.remove(o)
     with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
         results = list(ex.map(_compile, jobs))
-    objs = [o for o, _ in results]
+    objs = [o for (o, _), (s, _f) in zip(results, jobs) if s not in PROBE_SOURCES]
+    probe_objs = [o for (o, _), (s, _f) in zip(results, jobs) if s in PROBE_SOURCES]
     for (o, warn), (s, _f) in zip(results, jobs):
         if warn and verbose:
             sys.stderr.write("[cvhip build] %s:\n%s\n" % (s, warn))
@@ -111,6 +116,11 @@ def build_lib(force=False, verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    if probe_objs and (force or _newer(PROBES_LIB, probe_objs)):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", PROBES_LIB] + probe_objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link of libcvhip_probes.so failed:\n%s\n%s" % (r.stdout, r.stderr))
     return LIB
 
 

@@ -151,134 +151,6 @@ int launch_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float*
 int launch_wgrad_impl(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, hipStream_t stream, float* det_ws, int64_t* det_ws_floats,
                       int det_accumulate);
 
-// ---- probes ---------------------------------------------------------------------------------------
-__global__ void probe_mfma_kernel(const h16_t* a, const h16_t* b, float* d) {
-  // a: [16][32] row-major (i,k); b: [32][16] row-major (k,j). Lane l supplies A[i=l&15][k=8*(l>>4)+e],
-  // B[k=8*(l>>4)+e][j=l&15]; result reg r -> D[row = 4*(l>>4)+r][col = l&15].
-  const int l = threadIdx.x;
-  h16x8 fa, fb;
-  for (int e = 0; e < 8; ++e) {
-    fa[e] = a[(l & 15) * 32 + 8 * (l >> 4) + e];
-    fb[e] = b[(8 * (l >> 4) + e) * 16 + (l & 15)];
-  }
-  f32x4 c = {0.f, 0.f, 0.f, 0.f};
-  c = CVHIP_MFMA_16X16X32(fa, fb, c, 0, 0, 0);
-  for (int r = 0; r < 4; ++r) d[(4 * (l >> 4) + r) * 16 + (l & 15)] = c[r];
-}
-
-// LDS read-bandwidth probe: the igemm main loop's ds_read_b128 pattern without MFMA / staging.
-//   mode 0: the kernel's swizzled fragment reads   mode 1: same rows, no swizzle   mode 2: linear lane*16 (conflict-free by construction)
-//   mode 3: swizzled pattern issued as 2 x ds_read_b64
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void probe_lds_bw_kernel(float* out, int iters) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[49152];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  for (int i = t; i < 49152 / 4; i += 256) reinterpret_cast<unsigned*>(smem)[i] = i * 2654435761u;
-  __syncthreads();
-  const int wm = wave >> 1, wn = wave & 1;
-  const int swz = (MODE == 1) ? (lane >> 4) : ((lane >> 4) ^ ((0x78 >> (2 * ((lane >> 2) & 3))) & 3));
-  const int a_row = wm * 64 + (lane & 15), b_row = wn * 64 + (lane & 15);
-  unsigned acc = 0;
-  for (int it = 0; it < iters; ++it) {
-    const unsigned char* sA = smem + (it % 3) * 16384;
-    const unsigned char* sB = sA + 8192;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (MODE == 2) {
-        const uint4 u = *reinterpret_cast<const uint4*>(sA + j * 1024 + lane * 16 + wave * 4096 % 8192);
-        const uint4 v = *reinterpret_cast<const uint4*>(sB + j * 1024 + lane * 16);
-        acc ^= u.x ^ u.w ^ v.y ^ v.z;
-      } else if (MODE == 3) {
-        const uint2 u0 = *reinterpret_cast<const uint2*>(sA + (a_row + j * 16) * 64 + swz * 16);
-        const uint2 u1 = *reinterpret_cast<const uint2*>(sA + (a_row + j * 16) * 64 + swz * 16 + 8);
-        const uint2 v0 = *reinterpret_cast<const uint2*>(sB + (b_row + j * 16) * 64 + swz * 16);
-        const uint2 v1 = *reinterpret_cast<const uint2*>(sB + (b_row + j * 16) * 64 + swz * 16 + 8);
-        acc ^= u0.x ^ u1.y ^ v0.y ^ v1.x;
-      } else {
-        const uint4 u = *reinterpret_cast<const uint4*>(sA + (a_row + j * 16) * 64 + swz * 16);
-        const uint4 v = *reinterpret_cast<const uint4*>(sB + (b_row + j * 16) * 64 + swz * 16);
-        acc ^= u.x ^ u.w ^ v.y ^ v.z;
-      }
-    }
-  }
-  if (acc == 0x12345678u) out[blockIdx.x] = 1.f;
-}
-
-
-
-// MFMA issue-rate probe (bench.py "attainable peak"): every wave runs `iters` rounds of 8 INDEPENDENT v_mfma_f32_32x32x16_bf16
-// (8 accumulator sets: no dependent-accumulator stalls), operands in registers, nothing else. 4 waves per block, one per SIMD.
-// flops per launch = blocks * 4 waves * iters * 8 * (2*32*32*16).
-__global__ __launch_bounds__(256) void probe_mfma_peak_kernel(float* out, int iters) {
-  const int l = threadIdx.x;
-  h16x8 a, b;
-  for (int e = 0; e < 8; ++e) {
-    a[e] = (h16_t)(0.001f * (float)((l * 7 + e * 3) % 17 - 8));
-    b[e] = (h16_t)(0.002f * (float)((l * 5 + e) % 13 - 6));
-  }
-  f32x16 c[8];
-  for (int j = 0; j < 8; ++j)
-    for (int e = 0; e < 16; ++e) c[j][e] = 0.f;
-  for (int it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) c[j] = CVHIP_MFMA_32X32X16(a, b, c[j], 0, 0, 0);
-  }
-  float s = 0.f;
-  for (int j = 0; j < 8; ++j)
-    for (int e = 0; e < 16; ++e) s += c[j][e];
-  if (s == 123456.789f) out[blockIdx.x] = s;  // keeps the MFMAs live without a store on the normal path
-}
-
-typedef __attribute__((address_space(3))) h16x4 lds_h16x4_t;
-__global__ void probe_tr16_kernel(const h16_t* in, h16_t* out) {
-  // in: 64 lanes x 4 bf16 written linearly to LDS (lane l at byte l*8); every lane then issues
-  // ds_read_b64_tr_b16 at its own linear address; out[l][0..3] = what lane l received.
-  __shared__ __attribute__((aligned(16))) h16_t lds[256];
-  const int l = threadIdx.x;
-  for (int e = 0; e < 4; ++e) lds[l * 4 + e] = in[l * 4 + e];
-  __syncthreads();
-  h16x4 v = CVHIP_DS_READ_TR16_B64((lds_h16x4_t*)(&lds[l * 4]));
-  for (int e = 0; e < 4; ++e) out[l * 4 + e] = v[e];
-}
-
-// Grid-barrier probe (tools/barrier_probe.py): is a device-wide barrier inside a persistent kernel cheap enough on MI355X (8 XCDs,
-// non-coherent L2s) to fuse reduce-then-apply passes? mode 0: partials by plain stores + __threadfence() both sides;
-// mode 1: partials by agent-scope atomic stores / loads (cache-bypassing), no fence. The counter self-resets (generation = target).
-__global__ __launch_bounds__(256) void probe_grid_barrier_kernel(int mode, int iters, float* scratch, unsigned* counter, float* out) {
-  const int t = threadIdx.x;
-  float acc = 0.f;
-  for (int it = 0; it < iters; ++it) {
-    float* part = scratch + (size_t)(it & 1) * gridDim.x;
-    const float mine = (float)(blockIdx.x + 1 + it);
-    if (t == 0) {
-      if (mode == 0) {
-        part[blockIdx.x] = mine;
-        __threadfence();
-      } else {
-        __hip_atomic_store(&part[blockIdx.x], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      const unsigned target = (unsigned)(it + 1) * gridDim.x;
-      __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
-      if (mode == 0) __threadfence();
-    }
-    __syncthreads();
-    float s = 0.f;
-    for (int i = t; i < (int)gridDim.x; i += 256)
-      s += mode == 0 ? part[i] : __hip_atomic_load(&part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    acc += s;
-    __syncthreads();
-  }
-  __shared__ float red[256];
-  red[t] = acc;
-  __syncthreads();
-  if (t == 0) {
-    float s = 0.f;
-    for (int i = 0; i < 256; ++i) s += red[i];
-    out[blockIdx.x] = s;
-  }
-}
-
 }  // namespace cvhip
 
 using namespace cvhip;
@@ -595,43 +467,6 @@ int cvhip_f32_unpad_add(const float* src, float* dst, int32_t K_valid, int32_t T
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(unpad_add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, n, C, C_valid);
   return check_launch("unpad_add_kernel");
-}
-
-int cvhip_probe_mfma_16x16x32(const void* a, const void* b, float* d, void* stream) {
-  if (!a || !b || !d) return CVHIP_ERR_INVALID;
-  hipLaunchKernelGGL(probe_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const h16_t*)a, (const h16_t*)b, d);
-  return check_launch("probe_mfma_kernel");
-}
-
-int cvhip_probe_ds_read_tr16(const void* in, void* out, void* stream) {
-  if (!in || !out) return CVHIP_ERR_INVALID;
-  hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const h16_t*)in, (h16_t*)out);
-  return check_launch("probe_tr16_kernel");
-}
-
-int cvhip_probe_grid_barrier(int32_t mode, int32_t iters, int32_t blocks, float* scratch, uint32_t* counter_zeroed, float* out, void* stream) {
-  if (!scratch || !counter_zeroed || !out || iters <= 0 || blocks <= 0 || blocks > 1024) return CVHIP_ERR_INVALID;
-  hipLaunchKernelGGL(probe_grid_barrier_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mode, iters, scratch, counter_zeroed, out);
-  return check_launch("probe_grid_barrier_kernel");
-}
-
-int cvhip_probe_mfma_peak(int32_t iters, int32_t blocks, float* out, void* stream) {
-  if (!out || iters <= 0 || blocks <= 0) return CVHIP_ERR_INVALID;
-  hipLaunchKernelGGL(probe_mfma_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, iters);
-  return check_launch("probe_mfma_peak_kernel");
-}
-
-int cvhip_probe_lds_read_bw(int32_t mode, int32_t iters, int32_t blocks, float* out, void* stream) {
-  if (!out || iters <= 0 || blocks <= 0) return CVHIP_ERR_INVALID;
-  hipStream_t st = (hipStream_t)stream;
-  switch (mode) {
-    case 0: hipLaunchKernelGGL(probe_lds_bw_kernel<0>, dim3(blocks), dim3(256), 0, st, out, iters); break;
-    case 1: hipLaunchKernelGGL(probe_lds_bw_kernel<1>, dim3(blocks), dim3(256), 0, st, out, iters); break;
-    case 2: hipLaunchKernelGGL(probe_lds_bw_kernel<2>, dim3(blocks), dim3(256), 0, st, out, iters); break;
-    case 3: hipLaunchKernelGGL(probe_lds_bw_kernel<3>, dim3(blocks), dim3(256), 0, st, out, iters); break;
-    default: return CVHIP_ERR_INVALID;
-  }
-  return check_launch("probe_lds_bw_kernel");
 }
 
 }  // extern "C"

@@ -94,7 +94,6 @@ SIGNATURES = {
     "cvhip_conv2d_fprop_stats_rows": (_i32, [_dp]),
     "cvhip_conv1x1_stream_blocks": (_i32, [_i32, _i32, _i64, _i32]),
     "cvhip_conv_stem_blocks": (_i32, [_dp]),
-    "cvhip_probe_grid_barrier": (_i32, [_i32, _i32, _i32, _p, _p, _p, _p]),
     "cvhip_conv2d_dgrad_weight_elems": (_i64, [_dp]),
     "cvhip_conv2d_dgrad_plan": (_i32, [_dp, C.POINTER(_i32), _i32]),
     "cvhip_div31_consts": (_i32, [_i32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
@@ -209,6 +208,12 @@ SIGNATURES = {
     "cvhip_comm_broadcast": (_i32, [_p, _p, _i64, _i32, _p]),
     "cvhip_comm_reduce_scatter_f32": (_i32, [_p, _p, _i64, _p]),
     "cvhip_comm_all_gather_f32": (_i32, [_p, _p, _i64, _p]),
+}
+
+# libcvhip_probes.so (include/cvhip_probes.h): known-answer and machine-ceiling kernels for tests/ and tools/ — not part of the
+# product library, loaded only when one of them is called
+PROBE_SIGNATURES = {
+    "cvhip_probe_grid_barrier": (_i32, [_i32, _i32, _i32, _p, _p, _p, _p]),
     "cvhip_probe_mfma_16x16x32": (_i32, [_p, _p, _p, _p]),
     "cvhip_probe_ds_read_tr16": (_i32, [_p, _p, _p]),
     "cvhip_probe_lds_read_bw": (_i32, [_i32, _i32, _i32, _p, _p]),
@@ -220,8 +225,10 @@ SIGNATURES = {
     "cvhip_probe_stage": (_i32, [_i32, _p, _i64, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "cvhip_probe_gather": (_i32, [_i32, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
 }
+PROBES_LIB_PATH = os.path.join(_HERE, "libcvhip_probes.so")
 
 _lib = None
+_probes = None
 _F16 = set()        # entry points that exist a second time with the suffix _f16 (fp16 storage: csrc/common.h)
 PRECISION = "bf16"  # storage precision the engine currently runs in: `call` routes to the _f16 symbols when "fp16"
 
@@ -263,7 +270,30 @@ def load():
     return lib
 
 
+def load_probes():
+    """Load libcvhip_probes.so (once). Raises CvhipError if it has not been built."""
+    global _probes
+    if _probes is not None:
+        return _probes
+    if not os.path.exists(PROBES_LIB_PATH):
+        raise CvhipError("libcvhip_probes.so not found at %s — build it with `python -m cvpytorch_amd.build`" % PROBES_LIB_PATH)
+    lib = C.CDLL(PROBES_LIB_PATH)
+    for name, (res, args) in PROBE_SIGNATURES.items():
+        f = getattr(lib, name)
+        f.restype = res
+        f.argtypes = args
+    lib.cvhip_probes_last_error.restype = C.c_char_p
+    lib.cvhip_probes_last_error.argtypes = []
+    _probes = lib
+    return lib
+
+
 def check(status, what):
+    if status != OK and what in PROBE_SIGNATURES:
+        last = (load_probes().cvhip_probes_last_error() or b"").decode()
+        msg = {ERR_INVALID: "invalid argument", ERR_UNSUPPORTED: "unsupported shape/feature",
+               ERR_LAUNCH: "HIP launch error: " + last}.get(status, "status %d" % status)
+        raise CvhipError("%s failed: %s" % (what, msg))
     if status != OK:
         lib = load()
         # the library keeps one error string per build of the sources: the 16-bit-typed entry points of the active precision and the
@@ -278,7 +308,10 @@ def check(status, what):
 
 
 def fn(name):
-    """The entry point `name` of the active precision."""
+    """The entry point `name` of the active precision (cvhip_probe_*: of libcvhip_probes.so, bf16 forms only)."""
+    if name in PROBE_SIGNATURES:
+        load()  # torch's HIP runtime first, as for the product library
+        return getattr(load_probes(), name)
     lib = load()
     if PRECISION == "fp16" and name in _F16:
         name += "_f16"

@@ -36,6 +36,24 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert s in syms, "%s bound in lib.py but not declared in include/cvhip.h" % s
 
 
+def test_probes_are_a_library_of_their_own():
+    """The measurement / known-answer kernels are NOT in the product library: include/cvhip.h declares no cvhip_probe_* symbol,
+    libcvhip.so exports none, and libcvhip_probes.so exports exactly what include/cvhip_probes.h declares (== lib.PROBE_SIGNATURES)."""
+    assert not [s for s in header_symbols() if "probe" in s]
+    raw = C.CDLL(L.LIB_PATH)
+    src = open(os.path.join(ROOT, "include", "cvhip_probes.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(cvhip_probe[a-z0-9_]*)\s*\(", src)))
+    assert len(declared) >= 12 and "cvhip_probes_last_error" in declared
+    probes = C.CDLL(L.PROBES_LIB_PATH)
+    for s in declared:
+        assert hasattr(probes, s), "libcvhip_probes.so does not export %s" % s
+        assert not hasattr(raw, s), "%s is still exported by the product library" % s
+        assert s == "cvhip_probes_last_error" or s in L.PROBE_SIGNATURES
+    assert sorted(L.PROBE_SIGNATURES) == [s for s in declared if s != "cvhip_probes_last_error"]
+    assert not set(L.PROBE_SIGNATURES) & set(L.SIGNATURES)
+
+
 def test_fp16_abi_is_generated_in_sync_and_exported():
     """csrc/f16_names.h and include/cvhip_f16.h are what tools/gen_f16_names.py produces from the current sources, and the
     library exports every renamed entry point (the fp16-storage build of each 16-bit kernel)."""
@@ -233,6 +251,8 @@ def test_default_path_kernels_do_not_spill():
         r"bwd1x1_kernelILi\d+ELi\d+ELb1E",                      # tail-sums form (CVHIP_BN_TAIL, off: measured net loss)
         r"conv1x1_stream_kernelILi\d+ELi\d+ELi2E",              # same, STATS == 2
         r"igemm_dma_kernelILi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELb[01]ELi8E",   # 8-wave experiment (CVHIP_IGEMM_W8, off)
+        r"igemm_dma_kernelILi128ELi128ELi64ELi64ELi0ELi2ELi32ELb1ELi4ELb0ELi0ELb1E",   # fused-epilogue (inference) instance of the 128 x 128
+                                                                    # two-slot ring: 9 dwords parked (the epilogue's per-channel constants)
         r"stem_fprop_kernelILi1ELi13ELb0ELb1E",                 # fused-epilogue instance of the 7x7 stride-1 stem (inference only)
         r"conv_patch_kernelILi128ELi32ELi1E",                   # prologue form, 128 x 64 wave tiles: the values only the per-chunk in-place
                                                                 # transform uses (its constants' addresses, ownership mask) are parked in

@@ -40,7 +40,7 @@ def main():
             continue
         b = v["launches"] * (2.0 * (v["fetch_size_raw_kb_per_launch"] or 0.0) + (v["write_size_raw_kb_per_launch"] or 0.0)) * 1024.0 / steps
         f = ("BN / activation passes" if ("ew_kernel" in k or "colreduce" in k) else "fused 1x1 backward" if "bwd1x1" in k else
-             "conv (igemm, 1x1 stream, wgrad, stem)" if any(t in k for t in ("igemm", "conv1x1_stream", "wgrad", "stem_")) else "rest")
+             "conv (igemm, 1x1 stream, wgrad, stem)" if any(t in k for t in ("igemm", "conv_patch", "conv1x1_stream", "wgrad", "stem_")) else "rest")
         fam[f] += b
     print("HBM traffic per step (PMC, FETCH x2 + WRITE): %.1f GB  =  %s" % (
         sum(fam.values()) / 1e9, ", ".join("%s %.1f" % (f, b / 1e9) for f, b in sorted(fam.items(), key=lambda kv: -kv[1]))))
