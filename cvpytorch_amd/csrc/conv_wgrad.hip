@@ -585,8 +585,18 @@ __global__ __launch_bounds__(256 * kWgGroups, kWgGroups == 1 ? 2 : 1) void wgrad
   }
 }
 
+// round-4 launcher policy (CVHIP_WGRAD_POLICY=3 restores round 3's): see launch_wgrad_impl
+static int wgrad_policy() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CVHIP_WGRAD_POLICY");
+    v = e ? atoi(e) : 4;
+  }
+  return v;
+}
+
 template <int TN, int WN, int WK>
-static int launch_wg(WgradParams& p, hipStream_t stream) {
+static int launch_wg(WgradParams& p, hipStream_t stream, int tgt_hint = 0, int groups_hint = 0) {
   p.n_tiles = cdiv(p.Nout, TN);
   p.k_tiles = cdiv(p.Ktot, 128);
   const int tiles = p.n_tiles * p.k_tiles;
@@ -613,13 +623,14 @@ static int launch_wg(WgradParams& p, hipStream_t stream) {
   // Two 4-wave groups per block (accumulators folded through LDS, half the atomics) when the atomic epilogue is a large
   // share of the block's work: few pixel rows per (n,k) tile. Otherwise 4-wave blocks (more resident blocks per CU).
   // (the 32-wide output tile always gains: its blocks have the least MFMA work per atomic)
-  int groups = force_groups ? force_groups : ((TN == 32 || (int64_t)p.M * tiles <= kWgTwoGroupWork) ? 2 : 1);
+  int groups = force_groups ? force_groups : groups_hint ? groups_hint : ((TN == 32 || (int64_t)p.M * tiles <= kWgTwoGroupWork) ? 2 : 1);
   const int rows_min = min_rows * groups;
   // block target: every block ends by flushing its TN x 128 tile with fp32 atomics, so the atomic volume is blocks x 64 KB whatever the
   // layer; for the 128-wide tile on short pixel ranges (1x1 layers of <= 40 k pixels: ResNet layer3 / layer4 at batch 16, the 20x20 maps
   // of the detectors) 768 blocks flush more bytes than they read — 256 blocks are 15-19 % faster there (profiles/r03_wgrad_ablation.log)
   int tgt = target;
   if (!getenv("CVHIP_WGRAD_BLOCKS") && TN == 128 && p.TR == 1 && p.TS == 1 && p.M <= 40000) tgt = 256;
+  if (!getenv("CVHIP_WGRAD_BLOCKS") && tgt_hint > 0) tgt = tgt_hint;
   int splits = cdiv(tgt, tiles);
   const int max_splits = (p.M + rows_min - 1) / rows_min;
   if (splits > max_splits) splits = max_splits;
@@ -627,6 +638,17 @@ static int launch_wg(WgradParams& p, hipStream_t stream) {
   int mps = cdiv(p.M, splits);
   mps = ((mps + 63) / 64) * 64;
   splits = cdiv(p.M, mps);
+  if (wgrad_policy() >= 4) {
+    // resident block slots of the instance that will run (VGPR / LDS occupancy from the compiler's resource remarks: a one-group block
+    // is one wave per SIMD, a two-group block two): a grid a few blocks larger than that runs a second, nearly empty round — rounding
+    // the rows per split up to 64 and the splits up to whole numbers overshot it (128 -> 128 3x3 at 64 x 128, batch 16: 774 blocks on 768
+    // slots, +11 %; profiles/r04_wgrad_sweep.log)
+    const int cap = groups >= 2 ? (TN == 32 ? 768 : 256) : (TN == 128 ? 768 : 1024);
+    while (tiles * splits > cap && tiles * splits < 2 * cap - cap / 4 && splits > 1) {
+      mps += 64;
+      splits = cdiv(p.M, mps);
+    }
+  }
   p.m_per_split = mps;
   if (p.det_ws) {
     const int64_t n = (int64_t)p.Nout * p.Ktot;
@@ -739,18 +761,36 @@ int launch_wgrad_impl(const cvhip_conv_desc* d, const void* x, const void* dy, f
   // the price of more LDS fragment reads per MFMA. Per-shape A/B on the YOLOv5-s layers (CVHIP_WGRAD_TNMAX=32/64/128):
   // and DeepLabv3+ R50 layers: memory-bound 1x1 layers of modest size (M*K*C <= 7.5e9: the 20x20..80x80 YOLO layers) want
   // the 32-wide tile — the large ResNet 1x1 layers lose up to 2x with it; 3x3 layers with >= 256 outputs the 64-wide one.
+  // Round 4 (isolated sweep of tile x block target x groups over 18 layer shapes, tools/wgrad_sweep.sh -> profiles/r04_wgrad_sweep.log,
+  // then a step A/B): (a) 1x1 layers with >= 256 channels on both sides used the 32-wide tile, whose 8 x 2 (n, k) tiles re-stage
+  // x eight times and dY twice from the L2 (525 MB per launch for 256 -> 256 @40x40: L2->LDS-bound at 45 us) — the 128-wide tile as ONE
+  // two-group block per CU (256 blocks, 2 x 2 tiles, 210 MB staged, 16.8 MB of atomics) runs them in 38-43 us instead of 52;
+  // (b) 3x3 layers with >= 256 outputs: the 128-wide tile with 512 blocks instead of the 64-wide one with 768 (-7...-14 %).
   int tn = d->K <= 32 ? 32 : d->K <= 64 ? 64 : 128;
+  int tgt_hint = 0, groups_hint = 0;
   if (tn_max > 0) {
     if (tn > tn_max) tn = tn_max;
   } else if (d->R == 1 && d->S == 1) {
-    if ((double)p.M * d->K * d->C <= 7.5e9) tn = 32;
+    if ((double)p.M * d->K * d->C <= 7.5e9) {
+      tn = 32;
+      if (wgrad_policy() >= 4 && d->K >= 256 && d->C >= 256) {
+        tn = 128;
+        tgt_hint = 256;
+        groups_hint = 2;
+      }
+    }
   } else if (d->K >= 256 && d->C <= 1024) {
     tn = 64;
+    if (wgrad_policy() >= 4) {
+      tn = 128;
+      tgt_hint = 512;
+      groups_hint = 1;
+    }
   }
   int rc;
-  if (tn == 32) rc = launch_wg<32, 32, 32>(p, stream);
-  else if (tn == 64) rc = launch_wg<64, 32, 64>(p, stream);
-  else rc = launch_wg<128, 64, 64>(p, stream);
+  if (tn == 32) rc = launch_wg<32, 32, 32>(p, stream, tgt_hint, groups_hint);
+  else if (tn == 64) rc = launch_wg<64, 32, 64>(p, stream, tgt_hint, groups_hint);
+  else rc = launch_wg<128, 64, 64>(p, stream, tgt_hint, groups_hint);
   if (det_ws_floats) *det_ws_floats = p.det_ws_floats;
   return rc;
 }

@@ -16,6 +16,10 @@ SHAPES = [(64, 128, 40, 40, 128, 3, 1), (64, 64, 80, 80, 64, 3, 1), (64, 256, 20
           (64, 256, 40, 40, 256, 1, 1), (64, 512, 20, 20, 512, 1, 1), (64, 128, 40, 40, 128, 1, 1), (64, 512, 40, 40, 256, 1, 1),
           (16, 64, 128, 256, 64, 3, 1), (16, 128, 64, 128, 128, 3, 1), (16, 256, 32, 64, 256, 3, 1), (16, 512, 16, 32, 512, 3, 1),
           (16, 256, 128, 256, 64, 1, 1), (16, 1024, 32, 64, 256, 1, 1), (16, 512, 16, 32, 2048, 1, 1)]
+if os.environ.get("WG_ONLY") == "k1":
+    SHAPES = [sh for sh in SHAPES if sh[5] == 1]
+elif os.environ.get("WG_ONLY") == "k3":
+    SHAPES = [sh for sh in SHAPES if sh[5] == 3]
 tag = " ".join("%s=%s" % (k[6:], v) for k, v in sorted(os.environ.items()) if k.startswith("CVHIP_WGRAD"))
 st = torch.cuda.current_stream().cuda_stream
 tot = 0.0
