@@ -643,7 +643,9 @@ static int launch_wg(WgradParams& p, hipStream_t stream, int tgt_hint = 0, int g
     // is one wave per SIMD, a two-group block two): a grid a few blocks larger than that runs a second, nearly empty round — rounding
     // the rows per split up to 64 and the splits up to whole numbers overshot it (128 -> 128 3x3 at 64 x 128, batch 16: 774 blocks on 768
     // slots, +11 %; profiles/r04_wgrad_sweep.log)
-    const int cap = groups >= 2 ? (TN == 32 ? 768 : 256) : (TN == 128 ? 768 : 1024);
+    const char* e128 = getenv("CVHIP_WGRAD_PD128");
+    const bool deep128 = TN == 128 && (e128 ? atoi(e128) == 3 : true) && !(getenv("CVHIP_WGRAD_PD") && atoi(getenv("CVHIP_WGRAD_PD")) == 1);
+    const int cap = groups >= 2 ? (TN == 32 ? 768 : 256) : (TN == 128 ? (deep128 ? 512 : 768) : 1024);
     while (tiles * splits > cap && tiles * splits < 2 * cap - cap / 4 && splits > 1) {
       mps += 64;
       splits = cdiv(p.M, mps);
@@ -692,7 +694,16 @@ static int launch_wg(WgradParams& p, hipStream_t stream, int tgt_hint = 0, int g
     }
     return check_launch("wgrad_dma_kernel");
   }
-  const int pd = pd_force == 1 || pd_force == 3 ? pd_force : (TN == 64 ? 3 : 1);
+  // Round 4: three steps in flight for the 128-wide tile too (CVHIP_WGRAD_PD128=1 restores one). 177-179 VGPRs = two resident one-group
+  // blocks per CU instead of three, which round 2 measured as +10 % on ISOLATED launches with hot operands; inside the train step
+  // x comes from the forward pass (cold: HBM latency, not the L2's) and the deeper prefetch is worth -0.4 ms per YOLOv5-s step
+  // (14.62 -> 14.24 ms, same box) and -0.5 ms per DeepLabv3+ step (profiles/r04_wgrad_step_ab.log)
+  static int pd128 = -1;
+  if (pd128 < 0) {
+    const char* e = getenv("CVHIP_WGRAD_PD128");
+    pd128 = e ? atoi(e) : (wgrad_policy() >= 4 ? 3 : 1);
+  }
+  const int pd = pd_force == 1 || pd_force == 3 ? pd_force : (TN == 64 ? 3 : TN == 128 ? (pd128 == 3 ? 3 : 1) : 1);
   if (abl == 4 || abl == 5) {  // profiling instances (one group per block or two, the depth the shape would get)
     p.ablate = 1;              // and no atomic epilogue
     if (abl == 4) {

@@ -31,7 +31,7 @@ for s, e, k in step:
 fam = collections.Counter()
 for k, (n, d) in agg.items():
     f = ("bn/act passes" if ("ew_kernel" in k or "colreduce" in k) else "bn finalize (small)" if ("sum_partials" in k or "bn_finalize" in k or "rows_reduce" in k) else
-         "igemm" if "igemm" in k else "wgrad" if "wgrad" in k else "1x1 stream" if "conv1x1_stream" in k else "bwd1x1 fused" if "bwd1x1" in k else
+         "igemm + patch" if ("igemm" in k or "conv_patch" in k) else "wgrad" if "wgrad" in k else "1x1 stream" if "conv1x1_stream" in k else "bwd1x1 fused" if "bwd1x1" in k else
          "stem" if "stem" in k else "aten" if "at::native" in k else "copy nodes" if "copyBuffer" in k else "other cvhip")
     fam[f] += d
 print("by family (ms):", ", ".join("%s %.2f" % (k, v / 1e6) for k, v in fam.most_common()))
