@@ -461,6 +461,17 @@ struct EwParams {
 };
 constexpr int kEwAccMaxC = 2048;
 
+// rows a lane loads per trip (all issued before the trip's arithmetic). Round 4: 8 rows for the one-tensor forms (-DCVHIP_EW_RPT0=8)
+// measured neutral in the step (14.17-14.20 vs 14.08-14.16 ms) and on rotating tensors (profiles/r04_ew_grid_ab.log): the passes
+// are not short of bytes in flight, and more, shorter blocks (CVHIP_EW_ROWS=4/8) LOSE 0.1-0.6 ms to the per-block prologue
+#ifndef CVHIP_EW_RPT0
+#define CVHIP_EW_RPT0 4
+#endif
+template <int MODE, bool HAS_RES>
+struct EW_RPT {
+  static constexpr int value = (MODE == 1 || HAS_RES || MODE == 3) ? 4 : CVHIP_EW_RPT0;
+};
+
 // MODE 0: out = act(a*scale+shift) (+res)         [a = conv output y]
 // MODE 1: out = dy from (a = dz, y)               [BN+act backward apply]
 // MODE 2: out = a (copy)       MODE 3: out = a + res
@@ -594,11 +605,12 @@ __global__ __launch_bounds__(256) void ew_kernel(const EwParams p) {
         // 4 rows per trip: all loads of the trip are issued before the arithmetic (bytes in flight per lane x4); the block's last
         // trip runs the same code with its missing rows masked (clamped loads, no store) instead of a row-at-a-time remainder
         const int64_t stp = rows_per_pass;
-        for (; r < r_end; r += 4 * stp) {
-          uint4 ua[4], uy[4], ur[4];
-          bool ok[4];
+        constexpr int RPT = EW_RPT<MODE, has_res>::value;
+        for (; r < r_end; r += RPT * stp) {
+          uint4 ua[RPT], uy[RPT], ur[RPT];
+          bool ok[RPT];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
+          for (int q = 0; q < RPT; ++q) {
             const int64_t rq = r + q * stp;
             ok[q] = rq < r_end;
             const int64_t rc = ok[q] ? rq : r;
@@ -606,9 +618,9 @@ __global__ __launch_bounds__(256) void ew_kernel(const EwParams p) {
             if (MODE == 1) uy[q] = *reinterpret_cast<const uint4*>(p.y + rc * p.ld_y + c);
             if (has_res) ur[q] = *reinterpret_cast<const uint4*>(p.res + rc * p.ld_res + c);
           }
-          __builtin_amdgcn_sched_barrier(0);  // loads of all 4 rows first (see colreduce_kernel)
+          __builtin_amdgcn_sched_barrier(0);  // loads of all rows of the trip first (see colreduce_kernel)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
+          for (int q = 0; q < RPT; ++q) {
             const f32x8 o = math(unpack8(ua[q]), MODE == 1 ? unpack8(uy[q]) : f32x8{}, has_res ? unpack8(ur[q]) : f32x8{});
             if (ok[q]) *reinterpret_cast<uint4*>(p.out + (r + q * stp) * p.ld_out + c) = pack8(o);
           }
