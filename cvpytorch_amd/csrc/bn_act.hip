@@ -464,6 +464,7 @@ constexpr int kEwAccMaxC = 2048;
 // rows a lane loads per trip (all issued before the trip's arithmetic). Round 4: 8 rows for the one-tensor forms (-DCVHIP_EW_RPT0=8)
 // measured neutral in the step (14.17-14.20 vs 14.08-14.16 ms) and on rotating tensors (profiles/r04_ew_grid_ab.log): the passes
 // are not short of bytes in flight, and more, shorter blocks (CVHIP_EW_ROWS=4/8) LOSE 0.1-0.6 ms to the per-block prologue
+// (requesting the first trip's rows AHEAD of the accumulator fold of the ACC forms was built too: 122 -> 186 VGPRs, 14.25 vs 14.07-14.18 ms: no gain)
 #ifndef CVHIP_EW_RPT0
 #define CVHIP_EW_RPT0 4
 #endif
