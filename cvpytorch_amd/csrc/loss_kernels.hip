@@ -446,25 +446,52 @@ __global__ __launch_bounds__(256) void seg_ce_bilinear_bwd_kernel(const CeBilPar
   }
 }
 
-// y[n][hw][c] = x[n][hw][c] * s[n][c]
+// y[n][hw][c] = x[n][hw][c] * s[n][c]   (Dropout2d's per-(image, channel) mask scale, SE / attention gating)
+// Round 4: a block owns `chunk` pixel rows of ONE image; a thread owns one 16-byte channel vector, keeps its 8 scales in registers and
+// walks the rows four per trip with all loads of a trip issued before the arithmetic (the grid-stride form re-decoded (n, hw, cv) and
+// re-read its 8 scales per element with ONE row in flight per lane: 232 us for 268 MB tensors = 2.3 TB/s in the DeepLabv3+ step).
 __global__ __launch_bounds__(256) void scale_nc_kernel(const h16_t* __restrict__ x, int ld_x, const float* __restrict__ s, h16_t* __restrict__ y,
-                                                       int ld_y, int N, int C, int HW) {
+                                                       int ld_y, int N, int C, int HW, int chunks) {
   const int CV = (C + 7) >> 3;
   const bool vec = (C & 7) == 0 && (ld_x & 7) == 0 && (ld_y & 7) == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
-  const int64_t total = (int64_t)N * HW * CV;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    int cv, hw, n0, n;   // i = (n * HW + hw) * CV + cv (common.h split_index with Y = 2^30: the last split is the identity, n0 = 0)
-    split_index(i, CV, HW, 1 << 30, &cv, &hw, &n, &n0);
-    (void)n0;
-    const int64_t pix = (int64_t)n * HW + hw;
+  const int n = blockIdx.x / chunks, chunk = blockIdx.x - n * chunks;
+  const int cols = CV < 256 ? CV : 256;
+  const int rpp = 256 / cols;
+  const int tx = threadIdx.x % cols, ty = threadIdx.x / cols;
+  if (ty >= rpp || n >= N) return;
+  const int rows = (HW + chunks - 1) / chunks;
+  const int r0 = chunk * rows;
+  const int r1 = r0 + rows < HW ? r0 + rows : HW;
+  const h16_t* const xn = x + (int64_t)n * HW * ld_x;
+  h16_t* const yn = y + (int64_t)n * HW * ld_y;
+  for (int cv = tx; cv < CV; cv += cols) {
     const int c = cv * 8;
-    if (vec) {
-      f32x8 v = unpack8(*reinterpret_cast<const uint4*>(x + pix * ld_x + c));
+    float sc[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v.v[j] *= s[(int64_t)n * C + c + j];
-      *reinterpret_cast<uint4*>(y + pix * ld_y + c) = pack8(v);
+    for (int j = 0; j < 8; ++j) sc[j] = c + j < C ? s[(int64_t)n * C + c + j] : 0.f;
+    int r = r0 + ty;
+    if (vec) {
+      for (; r < r1; r += 4 * rpp) {
+        uint4 u[4];
+        bool ok[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int rq = r + q * rpp;
+          ok[q] = rq < r1;
+          u[q] = *reinterpret_cast<const uint4*>(xn + (int64_t)(ok[q] ? rq : r) * ld_x + c);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // the four loads first
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x8 v = unpack8(u[q]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v.v[j] *= sc[j];
+          if (ok[q]) *reinterpret_cast<uint4*>(yn + (int64_t)(r + q * rpp) * ld_y + c) = pack8(v);
+        }
+      }
     } else {
-      for (int j = 0; j < 8 && c + j < C; ++j) y[pix * ld_y + c + j] = (h16_t)((float)x[pix * ld_x + c + j] * s[(int64_t)n * C + c + j]);
+      for (; r < r1; r += rpp)
+        for (int j = 0; j < 8 && c + j < C; ++j) yn[(int64_t)r * ld_y + c + j] = (h16_t)((float)xn[(int64_t)r * ld_x + c + j] * sc[j]);
     }
   }
 }
@@ -611,8 +638,15 @@ int cvhip_seg_ce_bilinear_bwd(const void* x, int32_t ld_x, const int64_t* target
 
 int cvhip_scale_nc(const void* x, int32_t ld_x, const float* scale_nc, void* y, int32_t ld_y, int32_t N, int32_t C, int32_t HW, void* stream) {
   if (!x || !scale_nc || !y || N <= 0 || C <= 0 || HW <= 0) return CVHIP_ERR_INVALID;
-  hipLaunchKernelGGL(scale_nc_kernel, dim3(grid_for((int64_t)N * HW * ((C + 7) / 8))), dim3(256), 0, (hipStream_t)stream, (const h16_t*)x,
-                     ld_x, scale_nc, (h16_t*)y, ld_y, N, C, HW);
+  const int cv = (C + 7) / 8;
+  const int rpp = 256 / (cv < 256 ? cv : 256);
+  // ~16 row visits per thread, at most ~4096 blocks over the batch
+  int chunks = (HW + rpp * 16 - 1) / (rpp * 16);
+  const int cap = 4096 / N > 1 ? 4096 / N : 1;
+  if (chunks > cap) chunks = cap;
+  if (chunks < 1) chunks = 1;
+  hipLaunchKernelGGL(scale_nc_kernel, dim3((unsigned)N * (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, (const h16_t*)x, ld_x, scale_nc,
+                     (h16_t*)y, ld_y, N, C, HW, chunks);
   return check_launch("scale_nc_kernel");
 }
 
