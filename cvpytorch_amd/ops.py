@@ -378,6 +378,9 @@ class _Side:
     stream = None
     keep = []
     dirty = False
+    # only layers with at most this many output pixel rows go to the side stream (CVHIP_ASYNC_WGRAD_MAXM: the small late layers leave
+    # CUs idle, the large early ones fill the chip by themselves)
+    max_rows = int(__import__("os").environ.get("CVHIP_ASYNC_WGRAD_MAXM", str(1 << 62)))
 
 
 def enable_async_wgrad(flag=True, after_dgrad=False):
@@ -630,7 +633,7 @@ def _conv_grads(ctx, x, weight, dy, dy_ld, need_dx, need_dw, need_db):
             desc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, x_ld, dy_ld, kv, cv)
             padded = (Kp != K) or (Cg != Cc)
             geom = (N, Cc, H, W, K, R, S, P, Q)
-            if not padded and direct_w and _Side.enabled and not TIMER.enabled and not _DETERMINISTIC and (not arena.multi or arena.defer_allreduce):
+            if not padded and direct_w and _Side.enabled and N * P * Q <= _Side.max_rows and not TIMER.enabled and not _DETERMINISTIC and (not arena.multi or arena.defer_allreduce):
                 # same, on the side stream (see _Side): runs concurrently with the BN-backward chain of the layers below. With
                 # _Side.after_dgrad the fork is taken AFTER this layer's dgrad launch, so wgrad (MFMA / LDS bound) shares the chip
                 # with the HBM-bound BN passes that follow instead of with the dgrad kernel (same resources: both slowed down)
