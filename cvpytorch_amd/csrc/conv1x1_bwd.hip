@@ -18,7 +18,7 @@
 //   * dgrad reads dy fragments with ds_read_b128 (pixel rows = MFMA B operand), wgrad reads dy^T and x^T fragments with the
 //     hardware transpose read ds_read_b64_tr_b16; the dW accumulators stay in registers across ALL trips of the block and
 //     are flushed once with fp32 atomics (K*C per block instead of K*C per 512..2048 rows).
-// K (output channels of the layer = reduction of dgrad) is 32 / 64 / 128 per block; wider inputs C run as 128-wide column
+// K (output channels of the layer = reduction of dgrad) is 32 / 64 / 128 (256 with C <= 128) per block; wider inputs C run as 128-wide column
 // slices (grid.y), which re-read dz / y.
 //
 // Replaces aten::native_batch_norm_backward + silu_backward + convolution_backward reached from trainer.py:189
@@ -97,8 +97,10 @@ __device__ __forceinline__ f32x8 bnact_bwd8(const f32x8& dz, const f32x8& y, con
 
 // TAIL: the tail-sums form is its own instantiation — its 2 x CB/4 per-lane partial sums are live across the whole trip loop and
 // pushed the 128 x 128 configuration to 104 spilled VGPRs (300 B/lane of scratch, 106 -> 195 us per launch) when it was a runtime flag
+// KB 256 (round 4: the 64 -> 256 / 128 -> 256 expansion layers of ResNet bottlenecks, C <= 128 = ONE input-channel slice): 128 dW
+// accumulator registers + 64 of dz / y prefetch per lane — one block per CU (launch bounds 1: up to 512 registers, AGPRs included)
 template <int KB, int CB, bool TAIL>
-__global__ __launch_bounds__(256, 2) void bwd1x1_kernel(const Bwd1x1Params p) {
+__global__ __launch_bounds__(256, KB >= 256 ? 1 : 2) void bwd1x1_kernel(const Bwd1x1Params p) {
   constexpr int RT = 64;
   constexpr int KV = KB / 8, CV = CB / 8;
   constexpr int D_PASS = 256 / KV, D_IT = RT / D_PASS;
@@ -399,12 +401,21 @@ static int bwd1x1_mode() {  // CVHIP_BWD1X1: 0 = never (three-pass backward), 1 
   return v;
 }
 
+static int bwd1x1_k256() {  // CVHIP_BWD1X1_K256=0: K = 256 layers back on the three-pass backward (A/B switch)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CVHIP_BWD1X1_K256");
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+
 static int bwd1x1_cb(int C) { return (C % 128 == 0) ? 128 : (C % 64 == 0) ? 64 : (C % 32 == 0) ? 32 : 0; }
 
 // structural fit: the kernel can run this layer geometry at all
 static int bwd1x1_structural(const cvhip_conv_desc* d) {
   if (d->groups != 1 || d->R != 1 || d->S != 1 || d->stride_h != 1 || d->stride_w != 1 || d->pad_h != 0 || d->pad_w != 0) return 0;
-  if (d->K != 32 && d->K != 64 && d->K != 128) return 0;
+  if (d->K != 32 && d->K != 64 && d->K != 128 && !(d->K == 256 && bwd1x1_k256() && d->C <= (bwd1x1_k256() >= 2 ? 256 : 128))) return 0;
   if (d->k_valid || d->c_valid) return 0;
   if (bwd1x1_cb(d->C) == 0 || d->C > 1024) return 0;
   if ((d->x_ld & 7) || (d->y_ld & 7)) return 0;
@@ -463,6 +474,7 @@ int launch_bwd1x1(Bwd1x1Params& p, hipStream_t s) {
   const int cb = bwd1x1_cb(p.C);
   const int slices = p.C / cb;
   int cap = max_blocks / slices;
+  if (p.K >= 256 && cap > 256 / slices) cap = 256 / slices;  // one resident block per CU (register budget of the K = 256 instances)
   if (cap < 64) cap = 64;
   int blocks = p.ntiles / min_trips;
   if (blocks > cap) blocks = cap;
@@ -473,6 +485,7 @@ int launch_bwd1x1(Bwd1x1Params& p, hipStream_t s) {
   if (cb == 128) return launch_b1<KBV, 128>(p, blocks, s);   \
   if (cb == 64) return launch_b1<KBV, 64>(p, blocks, s);     \
   return launch_b1<KBV, 32>(p, blocks, s);
+  if (p.K == 256) { CVHIP_B1(256) }
   if (p.K == 128) { CVHIP_B1(128) }
   if (p.K == 64) { CVHIP_B1(64) }
   CVHIP_B1(32)

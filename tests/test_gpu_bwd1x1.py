@@ -48,6 +48,8 @@ CASES = [
     (2, 40, 40, 64, 128, 64, L.ACT_LEAKY, True, True),
     (1, 64, 64, 96, 32, 32, L.ACT_NONE, True, False),      # C = 96 -> three 32-wide slices
     (1, 64, 64, 128, 64, 64, L.ACT_SILU, False, False),    # eval-mode BN: scale/shift only
+    (2, 40, 40, 64, 256, 256, L.ACT_NONE, True, True),     # K = 256 (round 4): ResNet expansion conv3 (BN, no activation) + addend
+    (1, 70, 61, 128, 256, 128, L.ACT_RELU, True, False),   # K = 256, C = 128, two gradient tensors, ragged M
 ]
 
 
@@ -118,7 +120,7 @@ def test_bwd1x1_policy_and_refusals():
     d = dev()
     buf = torch.zeros(1 << 20, dtype=BF, device=d)
     f32 = torch.zeros(1 << 18, dtype=torch.float32, device=d)
-    for (Cc, K, R, s) in [(64, 256, 1, 1), (64, 64, 3, 1), (64, 64, 1, 2), (24, 64, 1, 1), (64, 48, 1, 1)]:
+    for (Cc, K, R, s) in [(256, 256, 1, 1), (64, 512, 1, 1), (64, 64, 3, 1), (64, 64, 1, 2), (24, 64, 1, 1), (64, 48, 1, 1)]:
         desc = L.ConvDesc(2, Cc, 16, 16, K, R, R, s, s, R // 2, R // 2, 1, 1, 1, Cc, K, 0, 0)
         assert lib.cvhip_conv1x1_bwd_fused_ok(C.byref(desc)) == 0
         st = lib.cvhip_conv1x1_bwd_fused(C.byref(desc), buf.data_ptr(), K, None, 0, K, buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), None, None,
