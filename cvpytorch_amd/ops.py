@@ -803,8 +803,9 @@ def _eval_scale_shift(cfg, gamma, beta, running_mean, running_var, K, dev, st):
     """(scale, shift) of an eval-mode BatchNorm, cached on the layer's ConvState until one of its tensors is written again"""
     # (_weights_epoch: the fused optimizer step and the BN kernels write parameters / running statistics through raw pointers,
     # behind torch's version counters)
-    key = (running_mean.data_ptr(), running_mean._version, running_var._version, None if gamma is None else gamma._version,
-           None if beta is None else beta._version, float(cfg.eps), _weights_epoch, _stats_epoch[0])
+    key = (running_mean.data_ptr(), running_mean._version, running_var.data_ptr(), running_var._version,
+           None if gamma is None else (gamma.data_ptr(), gamma._version), None if beta is None else (beta.data_ptr(), beta._version),
+           float(cfg.eps), _weights_epoch, _stats_epoch[0])
     cache = getattr(cfg.state, "ep_cache", None)
     if cache is not None and cache[0] == key:
         return cache[1]
@@ -821,9 +822,9 @@ def _dw_folded(cfg, wm, bias, gamma, beta, running_mean, running_var, K, dev, st
     ConvState until the weight or a BatchNorm tensor is written again"""
     if not cfg.has_bn:
         return wm, bias
-    key = (wm.data_ptr(), wm._version, running_mean.data_ptr(), running_mean._version, running_var._version,
-           None if gamma is None else gamma._version, None if beta is None else beta._version, None if bias is None else bias._version,
-           _weights_epoch, _stats_epoch[0])
+    key = (wm.data_ptr(), wm._version, running_mean.data_ptr(), running_mean._version, running_var.data_ptr(), running_var._version,
+           None if gamma is None else (gamma.data_ptr(), gamma._version), None if beta is None else (beta.data_ptr(), beta._version),
+           None if bias is None else (bias.data_ptr(), bias._version), _weights_epoch, _stats_epoch[0])
     cache = getattr(cfg.state, "dw_cache", None)
     if cache is not None and cache[0] == key:
         return cache[1], cache[2]
