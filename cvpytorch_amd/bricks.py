@@ -173,6 +173,10 @@ class HipConv2d(nn.Conv2d):
         w = self.weight
         if (x.dim() == 4 and x.shape[1] == self.in_channels and self.in_channels % 8 != 0 and self.groups == 1
                 and not x.requires_grad and x.dtype != ops.ACT_DTYPE):
+            if ops._STEM_IMAGE and x.dtype == torch.float32 and self.in_channels <= 4 and x.is_cuda and x.is_contiguous():
+                # round 4: an image stem reads the fp32 NCHW batch itself (ops.ConvBnAct decides per descriptor and falls back to the
+                # conversion pass below for everything the image-stem kernel does not run)
+                return x, w
             cp = (self.in_channels + 7) // 8 * 8
             if x.dtype == torch.float32 and ops.nhwc_ld(x) is None:
                 x = ops.images_to_nhwc(x, cpad=cp)

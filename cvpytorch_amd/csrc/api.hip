@@ -306,8 +306,9 @@ int cvhip_conv2d_fprop_acc(const cvhip_conv_desc* d, const void* x, const void* 
 int cvhip_conv2d_fprop_fused(const cvhip_conv_desc* d, const void* x, const void* w, void* y, const cvhip_conv_fuse* f, void* stream) {
   int st = validate_dense_desc(d);
   if (st) return st;
-  if (!x || !w || !y || !f) return CVHIP_ERR_INVALID;
-  if ((((uintptr_t)x) & 15) || (((uintptr_t)w) & 15)) return CVHIP_ERR_INVALID;
+  if (!w || !y || !f || (!x && !f->x_image)) return CVHIP_ERR_INVALID;
+  if ((!f->x_image && (((uintptr_t)x) & 15)) || (((uintptr_t)w) & 15)) return CVHIP_ERR_INVALID;
+  if (f->x_image && (f->x_image_planes < 1 || f->x_image_planes > 4 || f->pro_scale || f->residual)) return CVHIP_ERR_INVALID;
   if (f->stats_partial && f->bn_acc) return CVHIP_ERR_INVALID;
   if ((f->stats_partial || f->bn_acc) && (f->bias || f->ep_scale || f->ep_act != CVHIP_ACT_NONE)) return CVHIP_ERR_INVALID;
   if ((f->ep_scale == nullptr) != (f->ep_shift == nullptr) || (f->pro_scale == nullptr) != (f->pro_shift == nullptr)) return CVHIP_ERR_INVALID;
@@ -343,7 +344,23 @@ int cvhip_conv2d_fprop_fused(const cvhip_conv_desc* d, const void* x, const void
     // (the residual-before-activation form lives in the fused-epilogue instances: request them even for a bare residual add)
     if (p.res_pre && !p.ep_scale && p.ep_act == CVHIP_ACT_NONE) p.res_pre = 0;
   }
+  if (f->x_image) {  // fp32 NCHW image input: only the image-stem kernel reads it (cvhip_conv_stem_blocks(d) > 0 says whether it runs this d)
+    p.x = nullptr;
+    p.x_image = f->x_image;
+    p.x_planes = f->x_image_planes;
+    const int rc = try_launch_stem(p, (hipStream_t)stream);
+    return rc >= 0 || rc < -1 ? rc : CVHIP_ERR_UNSUPPORTED;
+  }
   return launch_igemm(p, (hipStream_t)stream);
+}
+
+int cvhip_conv2d_wgrad_image(const cvhip_conv_desc* d, const float* x_nchw, int32_t planes, const void* dy, float* dw, void* stream) {
+  int st = validate_dense_desc(d);
+  if (st) return st;
+  if (!x_nchw || !dy || !dw || planes < 1 || planes > 4) return CVHIP_ERR_INVALID;
+  if ((d->K & 7) || (d->y_ld & 7)) return CVHIP_ERR_UNSUPPORTED;
+  const int rc = try_launch_stem_wgrad(d, nullptr, dy, dw, (hipStream_t)stream, x_nchw, planes);
+  return rc >= 0 || rc < -1 ? rc : CVHIP_ERR_UNSUPPORTED;
 }
 
 int cvhip_conv2d_fprop_prologue_ok(const cvhip_conv_desc* d, int with_z_out) {

@@ -72,6 +72,10 @@ struct IgemmCommon {
   float pro_ap;
   h16_t* z_out;
   int z_ld;
+  // image stems (conv_stem.hip only): the input is the dataloader's own tensor, fp32 NCHW [NB][x_planes][IH][IW] (x_planes <= 4 real
+  // channels), read plane by plane and rounded to 16 bits on the way into the LDS patch — `x` is unused then
+  const float* x_image;
+  int x_planes;
 };
 
 constexpr int kKernelClasses = 4;
@@ -170,7 +174,8 @@ int try_launch_stream1x1(const IgemmParams& p, hipStream_t stream);
 // conv_stem.hip: direct convolution for 8-channel image stems (grid size, 0 = not taken; launcher, -1 = not taken)
 int stem_blocks(int C, int x_ld, int K, int R, int S, int sh, int sw, int dh, int dw, int N, int OH, int OW);
 int try_launch_stem(const IgemmParams& p, hipStream_t stream);
-int try_launch_stem_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, hipStream_t stream);
+int try_launch_stem_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, hipStream_t stream, const float* x_image = nullptr,
+                          int x_planes = 0);
 // conv_patch.hip: patch-resident implicit GEMM for multi-tap convolutions (launcher, -1 = not taken; geometry-only query with the
 // number of BatchNorm partial rows its epilogue writes)
 int try_launch_patch(const IgemmParams& p, hipStream_t stream);

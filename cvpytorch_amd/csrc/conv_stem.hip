@@ -30,6 +30,8 @@ constexpr int kStemBlocks = 768;   // persistent grid (3 blocks per CU by LDS)
 
 struct StemParams {
   const h16_t* x;
+  const float* xf;  // != NULL: fp32 NCHW image [NB][planes][IH][IW] instead of x (round 4: no layout / precision pass in front of the stem)
+  int planes;
   const h16_t* w;  // [K][R*S*8] bf16
   h16_t* y;
   const float* bias;
@@ -135,6 +137,26 @@ __global__ __launch_bounds__(256, 2) void stem_fprop_kernel(const StemParams p) 
     int n, oy0, ox0;
     tile_origin(tile, n, oy0, ox0);
     const int iy0 = oy0 * ST - p.pad_h, ix0 = ox0 * ST - p.pad_w;
+    if (p.xf) {  // block-uniform: planar fp32 image, one 4-byte load per real channel (adjacent lanes = adjacent columns: coalesced)
+      const int64_t plane = (int64_t)p.IH * p.IW;
+      const float* img = p.xf + (int64_t)n * p.planes * plane;
+#pragma unroll
+      for (int i = 0; i < LD_IT; ++i) {
+        const int iy = iy0 + (pk[i] >> 16), ix = ix0 + (pk[i] & 0xffff);
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+        if (pk[i] >= 0 && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) {
+          const float* px = img + (int64_t)iy * p.IW + ix;
+          c0 = px[0];
+          if (p.planes > 1) c1 = px[plane];
+          if (p.planes > 2) c2 = px[2 * plane];
+          if (p.planes > 3) c3 = px[3 * plane];
+        }
+        f32x8 v8;
+        v8.v[0] = c0; v8.v[1] = c1; v8.v[2] = c2; v8.v[3] = c3;
+        v8.v[4] = v8.v[5] = v8.v[6] = v8.v[7] = 0.f;
+        pre[i] = pack8(v8);
+      }
+    } else {
     const h16_t* img = p.x + (int64_t)n * p.IH * p.IW * 8;
 #pragma unroll
     for (int i = 0; i < LD_IT; ++i) {
@@ -143,6 +165,7 @@ __global__ __launch_bounds__(256, 2) void stem_fprop_kernel(const StemParams p) 
       if (pk[i] >= 0 && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW)
         v = *reinterpret_cast<const uint4*>(img + (int64_t)(iy * p.IW + ix) * 8);
       pre[i] = v;
+    }
     }
   };
   auto lstore = [&](int buf) {
@@ -294,6 +317,8 @@ __device__ __forceinline__ h16x8 stem_tr_read8(const unsigned char* p0, const un
 
 struct StemWgradParams {
   const h16_t* x;
+  const float* xf;  // as in StemParams
+  int planes;
   const h16_t* dy;
   float* dw;  // [K][R*S][8] fp32, accumulated with atomics
   int NB, IH, IW, OH, OW, K, dy_ld, R, S, pad_h, pad_w;
@@ -340,6 +365,26 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const StemWgradParam
     int n, oy0, ox0;
     tile_origin(tile, n, oy0, ox0);
     const int iy0 = oy0 * ST - p.pad_h, ix0 = ox0 * ST - p.pad_w;
+    if (p.xf) {  // block-uniform: planar fp32 image, one 4-byte load per real channel (adjacent lanes = adjacent columns: coalesced)
+      const int64_t plane = (int64_t)p.IH * p.IW;
+      const float* img = p.xf + (int64_t)n * p.planes * plane;
+#pragma unroll
+      for (int i = 0; i < LD_IT; ++i) {
+        const int iy = iy0 + (pk[i] >> 16), ix = ix0 + (pk[i] & 0xffff);
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+        if (pk[i] >= 0 && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) {
+          const float* px = img + (int64_t)iy * p.IW + ix;
+          c0 = px[0];
+          if (p.planes > 1) c1 = px[plane];
+          if (p.planes > 2) c2 = px[2 * plane];
+          if (p.planes > 3) c3 = px[3 * plane];
+        }
+        f32x8 v8;
+        v8.v[0] = c0; v8.v[1] = c1; v8.v[2] = c2; v8.v[3] = c3;
+        v8.v[4] = v8.v[5] = v8.v[6] = v8.v[7] = 0.f;
+        pre[i] = pack8(v8);
+      }
+    } else {
     const h16_t* img = p.x + (int64_t)n * p.IH * p.IW * 8;
 #pragma unroll
     for (int i = 0; i < LD_IT; ++i) {
@@ -348,6 +393,7 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const StemWgradParam
       if (pk[i] >= 0 && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW)
         v = *reinterpret_cast<const uint4*>(img + (int64_t)(iy * p.IW + ix) * 8);
       pre[i] = v;
+    }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -482,10 +528,13 @@ int try_launch_stem(const IgemmParams& p, hipStream_t stream) {
   const IgemmClass& c = p.cls[0];
   if (c.out_oh != 0 || c.out_ow != 0 || c.OHi != p.OH || c.OWi != p.OW || c.dh0 > 0 || c.dw0 > 0) return -1;
   const int blocks = stem_blocks(p.Cin, p.x_ld, p.Nout, c.TR, c.TS, p.in_sh, p.in_sw, c.dh_step, c.dw_step, p.NB, p.OH, p.OW);
-  if (blocks <= 0 || p.res || p.tail_y || (((uintptr_t)p.x) & 15) || (((uintptr_t)p.w) & 15)) return -1;
+  if (blocks <= 0 || p.res || p.tail_y || (((uintptr_t)p.w) & 15)) return -1;
+  if (p.x_image ? (p.x_planes < 1 || p.x_planes > 4 || (((uintptr_t)p.x_image) & 3)) : ((((uintptr_t)p.x) & 15) != 0)) return -1;
   const int nstep = (c.TR * c.TS + 3) / 4;
   StemParams sp;
   sp.x = p.x;
+  sp.xf = p.x_image;
+  sp.planes = p.x_planes;
   sp.w = p.w;
   sp.y = p.y;
   sp.bias = p.bias;
@@ -512,11 +561,12 @@ int try_launch_stem(const IgemmParams& p, hipStream_t stream) {
 }
 
 // wgrad twin of try_launch_stem: same eligibility (descriptor level), dw = [K][R*S][8] fp32 (already zeroed / holding the sum)
-int try_launch_stem_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, hipStream_t stream) {
+int try_launch_stem_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, hipStream_t stream, const float* x_image, int x_planes) {
   const int OH = conv_out_dim(d->H, d->pad_h, d->dil_h, d->R, d->stride_h);
   const int OW = conv_out_dim(d->W, d->pad_w, d->dil_w, d->S, d->stride_w);
   const int blocks = stem_blocks(d->C, d->x_ld, d->K, d->R, d->S, d->stride_h, d->stride_w, d->dil_h, d->dil_w, d->N, OH, OW);
-  if (blocks <= 0 || (d->y_ld & 7) || (((uintptr_t)x) & 15) || (((uintptr_t)dy) & 15)) return -1;
+  if (blocks <= 0 || (d->y_ld & 7) || (((uintptr_t)dy) & 15)) return -1;
+  if (x_image ? (x_planes < 1 || x_planes > 4 || (((uintptr_t)x_image) & 3)) : ((((uintptr_t)x) & 15) != 0)) return -1;
   static int off = -1;
   if (off < 0) {
     const char* e = getenv("CVHIP_STEM_WGRAD");
@@ -525,6 +575,8 @@ int try_launch_stem_wgrad(const cvhip_conv_desc* d, const void* x, const void* d
   if (off) return -1;
   StemWgradParams sp;
   sp.x = (const h16_t*)x;
+  sp.xf = x_image;
+  sp.planes = x_planes;
   sp.dy = (const h16_t*)dy;
   sp.dw = dw;
   sp.NB = d->N; sp.IH = d->H; sp.IW = d->W; sp.OH = OH; sp.OW = OW;

@@ -50,7 +50,8 @@ class ConvFuse(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("stats_partial", C.c_void_p), ("bn_acc", C.c_void_p), ("ep_scale", C.c_void_p),
                 ("ep_shift", C.c_void_p), ("ep_act", C.c_int32), ("ep_act_param", C.c_float), ("pro_scale", C.c_void_p),
                 ("pro_shift", C.c_void_p), ("pro_act", C.c_int32), ("pro_act_param", C.c_float), ("z_out", C.c_void_p),
-                ("z_ld", C.c_int32), ("residual", C.c_void_p), ("residual_ld", C.c_int32), ("residual_pre", C.c_int32)]
+                ("z_ld", C.c_int32), ("residual", C.c_void_p), ("residual_ld", C.c_int32), ("residual_pre", C.c_int32),
+                ("x_image", C.c_void_p), ("x_image_planes", C.c_int32)]
 
 
 PATCH_CLASS_INTS = 30  # CVHIP_PATCH_CLASS_INTS
@@ -103,6 +104,7 @@ SIGNATURES = {
     "cvhip_prep_plan_run": (_i32, [_p, _i32, _i32, _p]),
     "cvhip_conv2d_fprop": (_i32, [_dp, _p, _p, _p, _p, _p, _p]),
     "cvhip_conv2d_fprop_fused": (_i32, [_dp, _p, _p, _p, C.POINTER(ConvFuse), _p]),
+    "cvhip_conv2d_wgrad_image": (_i32, [_dp, _p, _i32, _p, _p, _p]),
     "cvhip_conv2d_fprop_prologue_ok": (_i32, [_dp, _i32]),
     "cvhip_conv2d_patch_plan": (_i32, [_dp, _i32, C.POINTER(_i32), _i32]),
     "cvhip_conv2d_dgrad": (_i32, [_dp, _p, _p, _p, _p]),

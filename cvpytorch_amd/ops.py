@@ -54,6 +54,8 @@ def bump_weights_epoch():
 # (yolov7 FeatureFusion.conv4) — a scratch accumulator is zero-filled per call. CVHIP_BN_ACC=0 restores the partial-row path.
 # Inference (no operand requires a gradient, BatchNorm in eval mode or folded away): the whole ConvModule — conv, bias, BN scale/shift,
 # activation, residual — is ONE cvhip_conv2d_fprop_fused launch (conv_module.py:201-214 in eval mode; utils/fuse.py:32-54).
+# CVHIP_STEM_IMAGE=0: image stems get their input through the explicit fp32 NCHW -> 16-bit NHWC pass again (A/B switch).
+_STEM_IMAGE = __import__("os").environ.get("CVHIP_STEM_IMAGE", "1") != "0"
 # CVHIP_EPI_FUSE=0 restores conv + a separate BN/activation pass (A/B switch).
 _EPI_FUSE = __import__("os").environ.get("CVHIP_EPI_FUSE", "1") != "0"
 _BN_ACC = __import__("os").environ.get("CVHIP_BN_ACC", "1") != "0"
@@ -240,10 +242,8 @@ def _wgrad_name(k, r=3, s=3, c=0, m=0, desc=None):
         return "stem_wgrad_kernel"
     tn = 32 if k <= 32 else 64 if k <= 64 else 128
     if r == 1 and s == 1:
-        if float(m) * k * c <= 7.5e9:
+        if float(m) * k * c <= 7.5e9 and not (k >= 256 and c >= 256):   # (launcher policy 4, conv_wgrad.hip)
             tn = 32
-    elif k >= 256 and c <= 1024:
-        tn = 64
     return {32: "wgrad_kernel<32,32,32>", 64: "wgrad_kernel<64,32,64>", 128: "wgrad_kernel<128,64,64>"}[tn]
 
 
@@ -656,7 +656,16 @@ def _conv_grads(ctx, x, weight, dy, dy_ld, need_dx, need_dw, need_db):
             else:
                 # padded problem: wgrad into a [Kp][R][S][Cc] scratch, then fold the valid block into the real gradient
                 tmp = torch.empty((Kp, R, S, Cc), dtype=torch.float32, device=dev)
-                _wgrad(_wgrad_name(Kp, R, S, Cc, N * P * Q, desc), geom, desc, x, dy, tmp, 0, st)
+                planes = getattr(ctx, "image_planes", 0)
+                if planes and not _DETERMINISTIC:
+                    # image stem whose forward read the fp32 NCHW batch directly: so does its weight gradient (x IS that batch)
+                    zero_fill(tmp)
+                    _timed_call("stem_wgrad_kernel", geom, "cvhip_conv2d_wgrad_image", C.byref(desc), x.data_ptr(), planes, dy.data_ptr(),
+                                tmp.data_ptr(), st)
+                else:
+                    if planes:
+                        x, _ = as_nhwc(images_to_nhwc(x, cpad=Cc))
+                    _wgrad(_wgrad_name(Kp, R, S, Cc, N * P * Q, desc), geom, desc, x, dy, tmp, 0, st)
                 if direct_w:
                     dst = cfg.gw
                 else:
@@ -875,11 +884,20 @@ class ConvBnAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, residual, cfg):
         lib = L.load()
-        x, x_ld = as_nhwc(x)
-        N, Cc, H, W = x.shape
         K, Cg, R, S = weight.shape
-        dev = x.device
         depthwise = cfg.groups != 1
+        # image stems: an fp32 NCHW image batch (what the reference's dataloader delivers, <= 4 channels) can be read by the stem
+        # kernel itself — no layout / precision pass in front of the first convolution (decided below, once the descriptor is known)
+        image = None
+        if (_STEM_IMAGE and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == Cg <= 4 and not depthwise and x.is_contiguous()
+                and not x.requires_grad and x.is_cuda):
+            image = x
+            N, planes, H, W = x.shape
+            Cc, x_ld = 8, 8
+        else:
+            x, x_ld = as_nhwc(x)
+            N, Cc, H, W = x.shape
+        dev = x.device
         c_orig = Cc
         if not depthwise and Cc == Cg and (Cc % 8 != 0 or x_ld % 8 != 0 or x.data_ptr() % 16 != 0):
             # the MFMA gather reads 16-byte channel vectors: repack odd channel counts / pitches / slice offsets into a
@@ -943,8 +961,13 @@ class ConvBnAct(torch.autograd.Function):
             # pack descriptor: contiguous pitches (the packed images do not depend on activation pitches)
             pdesc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, Cc, Kp, kv, cv)
             cfg.state.prepare(weight, pdesc, need_dx, cfg.vkey)
-            if (_EPI_FUSE and (cfg.no_grad or not any(ctx.needs_input_grad)) and not train_bn and Kp == K and cfg.out_split is None
-                    and (cfg.has_bn or cfg.act != L.ACT_NONE or residual is not None)):
+            infer = (_EPI_FUSE and (cfg.no_grad or not any(ctx.needs_input_grad)) and not train_bn and Kp == K and cfg.out_split is None
+                     and (cfg.has_bn or cfg.act != L.ACT_NONE or residual is not None))
+            if image is not None and (infer or residual is not None or lib.cvhip_conv_stem_blocks(C.byref(desc)) <= 0):
+                # not a problem the image-stem kernel runs (or the one-launch inference form): the explicit conversion pass
+                x, x_ld = as_nhwc(images_to_nhwc(image, cpad=8))
+                image = None
+            if infer:
                 return _conv_fused_inference(x, x_ld, weight, b, gamma, beta, running_mean, running_var, residual, cfg,
                                              (N, Cc, H, W, K, R, S, P, Q), kv, cv, st)
             use_acc = _BN_ACC and not _DETERMINISTIC and epilogue_stats and cfg.sync is None and K <= _BN_ACC_MAX_C
@@ -956,7 +979,16 @@ class ConvBnAct(torch.autograd.Function):
                     L.check(rows, "cvhip_conv2d_fprop_stats_rows")
                 partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
             kname = "stem_fprop_kernel" if lib.cvhip_conv_stem_blocks(C.byref(desc)) > 0 else _igemm_name(Kp, N * P * Q, R * S * Cc, _pointwise(R, S, cfg), x_ld, epilogue_stats)
-            if use_acc:
+            if image is not None:
+                f = L.ConvFuse()
+                f.x_image, f.x_image_planes = image.data_ptr(), planes
+                if use_acc:
+                    f.bn_acc = acc_f.data_ptr()
+                else:
+                    f.bias, f.stats_partial = _ptr(b), _ptr(partial)
+                _timed_call(kname, (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv2d_fprop_fused", C.byref(desc), None,
+                            cfg.state.w_fprop.data_ptr(), y.data_ptr(), C.byref(f), st)
+            elif use_acc:
                 _timed_call(kname, (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv2d_fprop_acc", C.byref(desc), x.data_ptr(),
                             cfg.state.w_fprop.data_ptr(), y.data_ptr(), acc_f.data_ptr(), st)
             else:
@@ -1036,9 +1068,10 @@ class ConvBnAct(torch.autograd.Function):
             cfg.prod = ctx.prod = ProdInfo(y, Kp, stats, cfg.act, cfg.act_param, acc_b, K, 0, K, (N, K, P, Q))
         ctx.res_pre = bool(cfg.res_pre and residual is not None and not isinstance(z, tuple))
         if ctx.res_pre:
-            ctx.save_for_backward(x, y, stats, weight, z)   # the activation's derivative is taken from the OUTPUT's sign
+            ctx.save_for_backward(x if image is None else image, y, stats, weight, z)   # the activation's derivative is taken from the OUTPUT's sign
         else:
-            ctx.save_for_backward(x, y, stats, weight)
+            ctx.save_for_backward(x if image is None else image, y, stats, weight)
+        ctx.image_planes = planes if image is not None else 0
         return z
 
     @staticmethod

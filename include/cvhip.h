@@ -692,9 +692,18 @@ typedef struct cvhip_conv_fuse {
   const void* residual; /* optional addend, pitch residual_ld: applied AFTER the activation (Darknet shortcut x + act(bn(conv))) ... */
   int32_t residual_ld;
   int32_t residual_pre; /* ... or, non-zero, BEFORE it: act(bn(conv) + residual), the ResNet bottleneck tail (torchvision Bottleneck) */
+  /* image stems (round 4): != NULL = the input is the dataloader's own tensor, fp32 NCHW [N][x_image_planes][H][W] (1..4 real channels;
+   * d->C stays 8, d->c_valid = x_image_planes, `x` may be NULL) — read plane by plane and rounded to 16 bits inside the stem kernel, so
+   * the layout / precision pass (cvhip_nchw_f32_to_nhwc_bf16) disappears from the step. Only for descriptors the image-stem kernel
+   * runs (cvhip_conv_stem_blocks(d) > 0), else CVHIP_ERR_UNSUPPORTED; no prologue, no residual. */
+  const float* x_image;
+  int32_t x_image_planes;
 } cvhip_conv_fuse;
 #endif
 int cvhip_conv2d_fprop_fused(const cvhip_conv_desc* d, const void* x, const void* w, void* y, const cvhip_conv_fuse* f, void* stream);
+/* weight gradient of an image stem straight from the fp32 NCHW image (see cvhip_conv_fuse.x_image): dw = [K][R*S][8] fp32, ACCUMULATED
+ * (atomics) like cvhip_conv2d_wgrad with accumulate != 0. CVHIP_ERR_UNSUPPORTED unless cvhip_conv_stem_blocks(d) > 0. */
+int cvhip_conv2d_wgrad_image(const cvhip_conv_desc* d, const float* x_nchw, int32_t planes, const void* dy, float* dw, void* stream);
 /* 1 when cvhip_conv2d_fprop_fused accepts a prologue (and, with_z_out != 0, the z_out side output) for this descriptor */
 int cvhip_conv2d_fprop_prologue_ok(const cvhip_conv_desc* d, int with_z_out);
 /* Plan query of the patch-resident kernel (conv_patch.hip; pure host arithmetic, exercised by the CPU test-suite against a numpy
