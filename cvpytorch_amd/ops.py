@@ -241,9 +241,10 @@ def _wgrad_name(k, r=3, s=3, c=0, m=0, desc=None):
     if desc is not None and L.load().cvhip_conv_stem_blocks(C.byref(desc)) > 0 and desc.y_ld % 8 == 0:
         return "stem_wgrad_kernel"
     tn = 32 if k <= 32 else 64 if k <= 64 else 128
-    if r == 1 and s == 1:
-        if float(m) * k * c <= 7.5e9 and not (k >= 256 and c >= 256):   # (launcher policy 4, conv_wgrad.hip)
-            tn = 32
+    if r == 1 and s == 1 and float(m) * k * c <= 7.5e9:
+        if k >= 256 and c >= 256:   # launcher policy 4 (conv_wgrad.hip): the 128-wide tile as one two-group block per CU — its own kernel
+            return "wgrad_kernel<128,64,64,2>"   # instance in rocprof (wgrad_kernel<128, 64, 64, 2, 3, 0>), so its own label here
+        tn = 32
     return {32: "wgrad_kernel<32,32,32>", 64: "wgrad_kernel<64,32,64>", 128: "wgrad_kernel<128,64,64>"}[tn]
 
 
