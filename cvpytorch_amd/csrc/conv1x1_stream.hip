@@ -84,7 +84,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernA
   const int total = my_tiles * nkc;
 
   h16x8 buf0[MF][KS], buf1[MF][KS];
-  const h16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
   // pipeline position of the NEXT load
   int ld_tile = blockIdx.x, ld_kc = 0;

@@ -25,7 +25,6 @@ namespace cvhip {
 constexpr int kStemTH = 4, kStemTW = 64;
 constexpr int kStemMaxPH = 3 * 2 + 7, kStemMaxPW = 63 * 2 + 7 + 1;  // R, S <= 7, stride <= 2 (PW rounded up to even)
 constexpr int kStemPatchBytes = kStemMaxPH * kStemMaxPW * 16;
-constexpr int kStemMaxSteps = 13;  // ceil(49 / 4)
 constexpr int kStemBlocks = 768;   // persistent grid (3 blocks per CU by LDS)
 
 struct StemParams {
