@@ -499,7 +499,13 @@ int stem_blocks(int C, int x_ld, int K, int R, int S, int sh, int sw, int dh, in
   if (nstep != 1 && nstep != 2 && nstep != 3 && nstep != 7 && nstep != 9 && nstep != 13) return 0;  // instantiated step counts
   const int64_t tiles = (int64_t)N * cdiv(OH, kStemTH) * cdiv(OW, kStemTW);
   if (tiles < 512 || tiles >= (1ll << 31)) return 0;  // small problems: the general kernel (and its tests) stay in charge
-  return (int)(tiles < kStemBlocks ? tiles : kStemBlocks);
+  static int cap = -1;
+  if (cap < 0) {
+    const char* e = getenv("CVHIP_STEM_BLOCKS");  // A/B switch of the persistent grid
+    cap = e ? atoi(e) : kStemBlocks;
+    if (cap < 64) cap = kStemBlocks;
+  }
+  return (int)(tiles < cap ? tiles : cap);
 }
 
 template <int ST, bool STATS, bool EPI = false>
