@@ -152,6 +152,227 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolParams p) {
   }
 }
 
+// ---- stride-1 "same" max pool of small maps through the LDS (round 4: SPPF / SPP pools, 3x3 / 5x5 on maps of <= 1024 pixels) ----------
+// The gather kernels above issue k*k 16-byte L2 loads (+ k*k index loads in backward) and k*k compare / select chains per output
+// vector: 38.6 / 45.8 us for SPPF's 13 MB tensors. Here a block stages ONE image x 4 channel vectors (32 channels) of the map in the
+// LDS with coalesced 64-byte row pieces. Forward is SEPARABLE with ATen's exact (value, arg-max) semantics — first in-bounds tap
+// seeds the index, a later tap wins only if strictly greater or NaN: pass 1 gives every pixel its ROW result (value and kw of the
+// row's first maximum, or last NaN), pass 2 combines the k row results top to bottom (an earlier row keeps ties): k + k comparisons
+// per output instead of k * k, the same answer as the row-major scan (tests/test_gpu_kernels.py compares values AND arg-max bytes
+// with max_pool2d_with_indices, ties / -inf / NaN included). Backward sums, per input pixel, the windows that selected it in the
+// gather kernel's order (bit-identical sums) from LDS copies of dy and the arg-max bytes. 24.5 / 33.6 us in the YOLOv5-s step.
+constexpr int kPoolLdsCvb = 4;        // channel vectors per block (32 channels: 512 blocks for SPPF's 64 x 256-channel maps)
+constexpr int kPoolLdsMaxPix = 1024;  // H * W limit: 1024 x 4 x 40 B = 160 KB of LDS (forward: input + row values + row arg-max)
+
+template <int K>
+__global__ __launch_bounds__(256) void maxpool_s1_lds_fwd_kernel(const PoolParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pool_smem[];
+  const int CV = p.C >> 3;
+  const int groups = (CV + kPoolLdsCvb - 1) / kPoolLdsCvb;
+  const int n = blockIdx.x / groups, cv0 = (blockIdx.x - n * groups) * kPoolLdsCvb;
+  const int cvb = min(kPoolLdsCvb, CV - cv0);
+  const int HW = p.H * p.W;
+  const int items = HW * kPoolLdsCvb;
+  uint4* const xs = reinterpret_cast<uint4*>(pool_smem);                       // [H*W][CVB] input vectors
+  uint4* const rvs = xs + items;                                               // [H*W][CVB] ROW results: value of the row's first maximum
+  uint2* const rks = reinterpret_cast<uint2*>(rvs + items);                    // ... and its kw, one byte per channel
+  const h16_t* const xn = p.x + (int64_t)n * HW * p.ld_x + cv0 * 8;
+  for (int i = threadIdx.x; i < items; i += 256) {
+    const int pix = i / kPoolLdsCvb, cv = i - pix * kPoolLdsCvb;
+    if (cv < cvb) xs[i] = *reinterpret_cast<const uint4*>(xn + (int64_t)pix * p.ld_x + cv * 8);
+  }
+  __syncthreads();
+  constexpr int PAD = K / 2;
+  // pass 1: every (pixel, channel vector) scans its ROW window (the values are 16-bit inputs, -inf or NaN: pack8 keeps them exactly)
+  for (int i = threadIdx.x; i < items; i += 256) {
+    const int pix = i / kPoolLdsCvb, cv = i - pix * kPoolLdsCvb;
+    if (cv >= cvb) continue;
+    const int h = pix / p.W, w = pix - h * p.W;
+    f32x8 ov;
+    int ok[8];
+    bool first = true;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      ov.v[j] = -INFINITY;
+      ok[j] = 0;
+    }
+#pragma unroll
+    for (int kw = 0; kw < K; ++kw) {
+      const int iw = w + kw - PAD;
+      if ((unsigned)iw >= (unsigned)p.W) continue;
+      const f32x8 v = unpack8(xs[(h * p.W + iw) * kPoolLdsCvb + cv]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (first) ok[j] = kw;
+        if (v.v[j] > ov.v[j] || v.v[j] != v.v[j]) {
+          ov.v[j] = v.v[j];
+          ok[j] = kw;
+        }
+      }
+      first = false;
+    }
+    rvs[i] = pack8(ov);
+    uint2 kk;
+    kk.x = (unsigned)ok[0] | ((unsigned)ok[1] << 8) | ((unsigned)ok[2] << 16) | ((unsigned)ok[3] << 24);
+    kk.y = (unsigned)ok[4] | ((unsigned)ok[5] << 8) | ((unsigned)ok[6] << 16) | ((unsigned)ok[7] << 24);
+    rks[i] = kk;
+  }
+  __syncthreads();
+  // pass 2: combine the row results top to bottom
+  for (int i = threadIdx.x; i < items; i += 256) {
+    const int pix = i / kPoolLdsCvb, cv = i - pix * kPoolLdsCvb;
+    if (cv >= cvb) continue;
+    const int h = pix / p.W, w = pix - h * p.W;
+    float best[8];
+    int bi[8];
+    bool first = true;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      best[j] = -INFINITY;
+      bi[j] = 0;
+    }
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh) {
+      const int ih = h + kh - PAD;
+      if ((unsigned)ih >= (unsigned)p.H) continue;
+      const int o = (ih * p.W + w) * kPoolLdsCvb + cv;
+      const f32x8 v = unpack8(rvs[o]);
+      const uint2 kk = rks[o];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int off = kh * K + (int)(((j < 4 ? kk.x : kk.y) >> (8 * (j & 3))) & 0xffu);
+        if (first) bi[j] = off;
+        if (v.v[j] > best[j] || v.v[j] != v.v[j]) {
+          best[j] = v.v[j];
+          bi[j] = off;
+        }
+      }
+      first = false;
+    }
+    {
+      const int64_t opix = (int64_t)n * HW + h * p.W + w;
+      f32x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o.v[j] = best[j];
+      *reinterpret_cast<uint4*>(p.y + opix * p.ld_y + (cv0 + cv) * 8) = pack8(o);
+      if (p.idx) {
+        uint2 iv;
+        iv.x = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
+        iv.y = (unsigned)bi[4] | ((unsigned)bi[5] << 8) | ((unsigned)bi[6] << 16) | ((unsigned)bi[7] << 24);
+        *reinterpret_cast<uint2*>(p.idx + opix * p.C + (cv0 + cv) * 8) = iv;
+      }
+    }
+  }
+}
+
+// backward twin: dy and the arg-max bytes of one image x 4 channel vectors in the LDS, a thread per input pixel x channel vector sums the
+// windows that selected it (k * k LDS reads instead of k * k L2 gathers)
+template <int K>
+__global__ __launch_bounds__(256) void maxpool_s1_lds_bwd_kernel(const PoolParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pool_smem[];
+  const int HW = p.H * p.W;
+  uint4* const gs = reinterpret_cast<uint4*>(pool_smem);                               // [H*W][CVB] dy
+  uint2* const is = reinterpret_cast<uint2*>(pool_smem + (size_t)HW * kPoolLdsCvb * 16);  // [H*W][CVB] arg-max bytes
+  const int CV = p.C >> 3;
+  const int groups = (CV + kPoolLdsCvb - 1) / kPoolLdsCvb;
+  const int n = blockIdx.x / groups, cv0 = (blockIdx.x - n * groups) * kPoolLdsCvb;
+  const int cvb = min(kPoolLdsCvb, CV - cv0);
+  for (int i = threadIdx.x; i < HW * kPoolLdsCvb; i += 256) {
+    const int pix = i / kPoolLdsCvb, cv = i - pix * kPoolLdsCvb;
+    if (cv < cvb) {
+      const int64_t opix = (int64_t)n * HW + pix;
+      gs[i] = *reinterpret_cast<const uint4*>(p.dy + opix * p.ld_dy + (cv0 + cv) * 8);
+      is[i] = *reinterpret_cast<const uint2*>(p.cidx + opix * p.C + (cv0 + cv) * 8);
+    }
+  }
+  __syncthreads();
+  constexpr int PAD = K / 2;
+  for (int i = threadIdx.x; i < HW * kPoolLdsCvb; i += 256) {
+    const int pix = i / kPoolLdsCvb, cv = i - pix * kPoolLdsCvb;
+    if (cv >= cvb) continue;
+    const int ih = pix / p.W, iw = pix - ih * p.W;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    // window (oh, ow) covers (ih, iw) with tap kh = ih - oh + PAD, kw = iw - ow + PAD; same accumulation order as maxpool_bwd_kernel
+    // (oh ascending, then ow ascending): bit-identical sums
+    const int oh_lo = max(0, ih - PAD), oh_hi = min(p.H - 1, ih + PAD);
+    const int ow_lo = max(0, iw - PAD), ow_hi = min(p.W - 1, iw + PAD);
+    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+      const int kh = ih - oh + PAD;
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        const unsigned off = (unsigned)(kh * K + (iw - ow + PAD));
+        const int o = (oh * p.W + ow) * kPoolLdsCvb + cv;
+        const f32x8 g = unpack8(gs[o]);
+        const uint2 iv = is[o];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned b = ((j < 4 ? iv.x : iv.y) >> (8 * (j & 3))) & 0xffu;
+          if (b == off) acc[j] += g.v[j];
+        }
+      }
+    }
+    h16_t* const dst = p.dx + ((int64_t)n * HW + pix) * p.ld_dx + (cv0 + cv) * 8;
+    f32x8 o;
+    if (p.accumulate) {
+      const f32x8 old = unpack8(*reinterpret_cast<const uint4*>(dst));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o.v[j] = old.v[j] + acc[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o.v[j] = acc[j];
+    }
+    *reinterpret_cast<uint4*>(dst) = pack8(o);
+  }
+}
+
+static bool pool_lds_ok(const PoolParams& p, bool bwd) {
+  auto a16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("CVHIP_POOL_LDS");  // 0: the gather kernels for every shape (A/B switch)
+    on = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!on || p.s != 1 || !(p.k & 1) || p.pad != p.k / 2 || p.OH != p.H || p.OW != p.W || (p.k != 3 && p.k != 5)) return false;   // (9 x 9 / 13 x 13: the register window would spill)
+  if ((p.C & 7) || p.H * p.W > kPoolLdsMaxPix || p.H * p.W * kPoolLdsCvb * (bwd ? 24 : 40) > 160 * 1024 || (int64_t)p.N * ((p.C / 8 + kPoolLdsCvb - 1) / kPoolLdsCvb) < 128) return false;
+  if (bwd) return (p.ld_dy & 7) == 0 && (p.ld_dx & 7) == 0 && a16(p.dy) && a16(p.dx) && ((((uintptr_t)p.cidx) & 7) == 0);
+  return (p.ld_x & 7) == 0 && (p.ld_y & 7) == 0 && a16(p.x) && a16(p.y) && (!p.idx || ((((uintptr_t)p.idx) & 7) == 0));
+}
+
+template <int K>
+static int launch_pool_lds(const PoolParams& p, bool bwd, hipStream_t s) {
+  const int groups = (p.C / 8 + kPoolLdsCvb - 1) / kPoolLdsCvb;
+  const int lds = p.H * p.W * kPoolLdsCvb * (bwd ? 24 : 40);
+  auto kf = maxpool_s1_lds_fwd_kernel<K>;
+  auto kb = maxpool_s1_lds_bwd_kernel<K>;
+  static bool attr_done[2][64] = {};
+  int devid = 0;
+  (void)hipGetDevice(&devid);
+  bool& done = attr_done[bwd ? 1 : 0][devid & 63];
+  if (!done) {
+    int cap = kPoolLdsMaxPix * kPoolLdsCvb * (bwd ? 24 : 40);
+    if (cap > 160 * 1024) cap = 160 * 1024;  // the CU's LDS (pool_lds_ok keeps every launch below it)
+    hipError_t e = bwd ? hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, cap)
+                       : hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    if (e != hipSuccess) {
+      set_last_error("hipFuncSetAttribute(maxpool_s1_lds)", e);
+      return CVHIP_ERR_LAUNCH;
+    }
+    done = true;
+  }
+  if (bwd) hipLaunchKernelGGL(kb, dim3(p.N * groups), dim3(256), lds, s, p);
+  else hipLaunchKernelGGL(kf, dim3(p.N * groups), dim3(256), lds, s, p);
+  return check_launch(bwd ? "maxpool_s1_lds_bwd_kernel" : "maxpool_s1_lds_fwd_kernel");
+}
+
+static int try_pool_lds(const PoolParams& p, bool bwd, hipStream_t s) {
+  if (!pool_lds_ok(p, bwd)) return -1;
+  switch (p.k) {
+    case 3: return launch_pool_lds<3>(p, bwd, s);
+    default: return launch_pool_lds<5>(p, bwd, s);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // nearest x2 upsample + channel concat
 // ---------------------------------------------------------------------------------------------------
@@ -685,6 +906,10 @@ int cvhip_maxpool2d_fwd(const void* x, int32_t ld_x, void* y, int32_t ld_y, uint
   p.pad = pad;
   p.OH = (H + 2 * pad - k) / stride + 1;
   p.OW = (W + 2 * pad - k) / stride + 1;
+  {
+    const int rc = try_pool_lds(p, false, (hipStream_t)stream);
+    if (rc >= 0 || rc < -1) return rc;
+  }
   const int64_t total = (int64_t)N * p.OH * p.OW * ((C + 7) / 8);
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("maxpool_fwd_kernel");
@@ -711,6 +936,10 @@ int cvhip_maxpool2d_bwd(const void* dy, int32_t ld_dy, const uint8_t* argmax, vo
   p.OH = (H + 2 * pad - k) / stride + 1;
   p.OW = (W + 2 * pad - k) / stride + 1;
   p.accumulate = accumulate;
+  {
+    const int rc = try_pool_lds(p, true, (hipStream_t)stream);
+    if (rc >= 0 || rc < -1) return rc;
+  }
   const int64_t total = (int64_t)N * H * W * ((C + 7) / 8);
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("maxpool_bwd_kernel");

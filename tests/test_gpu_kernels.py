@@ -394,6 +394,47 @@ def test_maxpool_exact(k, s, p, Cc, H, W):
     assert torch.equal(xd.grad.float().cpu() != 0, bf(gx) != 0) or rel_l2(xd.grad.float().cpu(), gx) < 1e-3
 
 
+@pytest.mark.parametrize("k,N,Cc,H,W", [(5, 16, 512, 20, 20), (5, 8, 1024, 13, 17), (3, 32, 256, 32, 32), (5, 130, 8, 20, 20)])
+def test_maxpool_lds_path_values_argmax_and_gradient(k, N, Cc, H, W):
+    """stride-1 "same" pools of small maps with >= 128 (image, 64-channel) blocks run through the LDS kernels (pool_resize.hip,
+    round 4): values AND arg-max bytes (tap index kh * k + kw) equal to ATen's max_pool2d_with_indices — ties (coarse values), -inf
+    borders and NaNs included — and the backward routes every cotangent to the same input pixel."""
+    import ctypes as C
+    from cvpytorch_amd import lib as L
+    torch.manual_seed(k * 100 + N)
+    x = (torch.randint(-3, 4, (N, Cc, H, W)).float() * 0.5)
+    x[0, 0, 3, 4] = float("nan")
+    x[1, 1, 0, 0] = float("nan")
+    x[1, 1, 0, 1] = float("nan")
+    x[2, 2] = float("-inf")
+    p = k // 2
+    yr, ir = F.max_pool2d(x, k, 1, p, return_indices=True)
+    xd = to_nhwc_dev(x)
+    x4, ld = ops.as_nhwc(xd)
+    y = ops.empty_nhwc(N, Cc, H, W, xd.device)
+    idx = torch.empty((N, H, W, Cc), dtype=torch.uint8, device=xd.device)
+    L.call("cvhip_maxpool2d_fwd", x4.data_ptr(), ld, y.data_ptr(), Cc, idx.data_ptr(), N, Cc, H, W, k, 1, p, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    yc = y.float().cpu()
+    assert torch.equal(torch.nan_to_num(yc, nan=123.0), torch.nan_to_num(yr, nan=123.0))
+    # ATen's index is the flat input position ih * W + iw; ours the tap (kh, kw) of the window of output (oh, ow)
+    tap = idx.permute(0, 3, 1, 2).cpu().long()
+    oh = torch.arange(H).view(1, 1, H, 1)
+    ow = torch.arange(W).view(1, 1, 1, W)
+    flat = (oh + tap // k - p) * W + (ow + tap % k - p)
+    assert torch.equal(flat, ir)
+    dy = bf(torch.randn(N, Cc, H, W))
+    xr = x.clone().requires_grad_(True)
+    (gx,) = torch.autograd.grad(F.max_pool2d(xr, k, 1, p), xr, dy)
+    dyd = to_nhwc_dev(dy)
+    d4, ldd = ops.as_nhwc(dyd)
+    dx = ops.empty_nhwc(N, Cc, H, W, xd.device)
+    L.call("cvhip_maxpool2d_bwd", d4.data_ptr(), ldd, idx.data_ptr(), dx.data_ptr(), Cc, N, Cc, H, W, k, 1, p, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert rel_l2(dx.float().cpu(), gx) < 4e-3
+    assert torch.equal(dx.float().cpu() != 0, bf(gx) != 0) or rel_l2(dx.float().cpu(), gx) < 1e-3
+
+
 def test_upsample_cat_exact():
     torch.manual_seed(0)
     a, b = bf(torch.randn(2, 32, 5, 7)), bf(torch.randn(2, 24, 10, 14))
