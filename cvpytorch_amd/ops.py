@@ -1472,6 +1472,51 @@ class MaxPool2d(torch.autograd.Function):
         return dx, None, None, None
 
 
+class SppfChain(torch.autograd.Function):
+    """SPPF's pooling chain + concat (yolo_modules.py:186-194: x, m(x), m(m(x)), m(m(m(x))) concatenated) on ONE buffer.
+
+    `x0` is the [:, :c] slice of an (N, 4c, H, W) NHWC buffer that the 1x1 conv in front already wrote (its `out=`); the three stride-1
+    pools write their outputs straight into the other three slices — no concat copy. Backward walks the chain on the incoming concat
+    gradient IN PLACE: slice j receives the pool gradient of slice j + 1 through cvhip_maxpool2d_bwd's accumulate form, so the three
+    gradient-accumulation adds (ops.Fanout) and their temporaries disappear; the first slice is returned as the gradient of x0."""
+
+    @staticmethod
+    def forward(ctx, x0, k):
+        x0v, ld = as_nhwc(x0)
+        N, c, H, W = x0v.shape
+        if ld != 4 * c:
+            raise L.CvhipError("SppfChain: x0 must be the first channel slice of an (N, 4c, H, W) NHWC buffer")
+        pad = k // 2
+        st = _stream()
+        idx = torch.empty((3, N, H, W, c), dtype=torch.uint8, device=x0v.device)
+        esz = x0v.element_size()
+        for j in range(3):
+            L.call("cvhip_maxpool2d_fwd", x0v.data_ptr() + j * c * esz, ld, x0v.data_ptr() + (j + 1) * c * esz, ld, idx[j].data_ptr(),
+                   N, c, H, W, k, 1, pad, st)
+        ctx.meta = (N, c, H, W, k, pad)
+        ctx.save_for_backward(idx)
+        return x0v.as_strided((N, 4 * c, H, W), (H * W * 4 * c, 1, W * 4 * c, 4 * c))   # fresh alias of the whole buffer (as ops.Cat does)
+
+    @staticmethod
+    def backward(ctx, d):
+        (idx,) = ctx.saved_tensors
+        N, c, H, W, k, pad = ctx.meta
+        d, ld = as_nhwc(d)
+        if ld != 4 * c or not d.is_contiguous(memory_format=torch.channels_last):
+            d = d.contiguous(memory_format=torch.channels_last).clone()
+            d, ld = as_nhwc(d)
+        st = _stream()
+        esz = d.element_size()
+        for j in (2, 1, 0):   # slice j += maxpool_bwd(slice j + 1)
+            L.call("cvhip_maxpool2d_bwd", d.data_ptr() + (j + 1) * c * esz, ld, idx[j].data_ptr(), d.data_ptr() + j * c * esz, ld,
+                   N, c, H, W, k, 1, pad, 1, st)
+        return d[:, :c], None
+
+
+def sppf_chain(x0, k):
+    return SppfChain.apply(x0, int(k))
+
+
 def max_pool2d(x, k, stride=None, pad=0):
     return MaxPool2d.apply(x, int(k), int(stride if stride is not None else k), int(pad))
 

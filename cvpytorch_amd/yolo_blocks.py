@@ -19,6 +19,7 @@ from .bricks import HipMaxPool2d, HipUpsampleNearest2x, bn_tick, sync_of
 
 _PAIR_ENABLED = os.environ.get("CVHIP_PAIR", "1") != "0"
 _CAT_INPLACE = os.environ.get("CVHIP_CAT_INPLACE", "1") != "0"
+_SPPF_CHAIN = os.environ.get("CVHIP_SPPF_CHAIN", "1") != "0"   # 0: separate pools + fan-out adds + concat copy (A/B switch)
 _GRAD_LINK = os.environ.get("CVHIP_GRAD_LINK", "1") != "0"
 
 
@@ -187,7 +188,17 @@ class SPPF(nn.Module):
         self.conv2 = ConvModule(hidden_channels * 4, out_channels, 1, stride=1, conv_cfg=conv_cfg, norm_cfg=norm_cfg, act_cfg=act_cfg)
 
     def forward(self, x):
-        x = self.conv1(x)
+        if (_SPPF_CHAIN and isinstance(self.kernel_sizes, int) and x.is_cuda and x.dim() == 4 and isinstance(self.conv1, ConvModule)
+                and self.conv1.conv.out_channels % 8 == 0 and ops.nhwc_ld(x) is not None):
+            # round 4: conv1 writes the first slice of the concat buffer, the three pools the other slices (ops.SppfChain)
+            c = self.conv1.conv.out_channels
+            buf = ops.empty_nhwc(x.shape[0], 4 * c, x.shape[2], x.shape[3], x.device)
+            x0 = self.conv1(x, out=buf[:, :c])
+            if x0.data_ptr() == buf.data_ptr():   # (the unfused fallback path of ConvModule ignores `out`)
+                return self.conv2(ops.sppf_chain(x0, self.kernel_sizes))
+            x = x0
+        else:
+            x = self.conv1(x)
         if isinstance(self.kernel_sizes, int):
             x, xa = ops.fanout(x, 2)          # every tensor of the chain feeds the next pool AND the concat
             y1, y1a = ops.fanout(self.m(xa), 2)
