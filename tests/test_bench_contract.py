@@ -1,0 +1,55 @@
+"""CPU checks of the measurement contract on the COMMITTED bench line (profiles/r04_bench_final.json.log = the default `python bench.py`
+of the round's final commit): the keys the driver and the judge read are there, mutually consistent, and `roofline` / `cpu_baseline`
+carry what the task statement asks for. (The line itself can only be produced on the GPU box.)"""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line():
+    return json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_final.json.log")).read().strip().splitlines()[-1])
+
+
+def test_headline_keys_and_consistency():
+    d = _line()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["unit"] == "images/sec" and d["dtype"] == "bf16" and "synthetic" in d["data"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    batch = 64
+    # value = images of K steps / time of K steps
+    assert abs(d["value"] - batch * 1e3 / d["ms_per_step"]) <= 2e-3 * d["value"]
+
+
+def test_roofline_object():
+    r = _line()["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["peak"] == (8000.0 if r["bound"] == "hbm" else 2500.0)
+    assert r["traffic"] is None or r["traffic"] > 0
+    # the dominant kernel's HIP-event duration is in the line; the rocprof summary of the same commit must agree within 15 %
+    stats = open(os.path.join(ROOT, "profiles", "r04_yolov5s_bs64_kernel_stats.csv")).read().splitlines()
+    row = [ln for ln in stats if "colreduce_kernel<1, 2>" in ln]
+    if "colreduce" in r["kernel"] and row:
+        avg_ns = float(row[0].split('",')[1].split(",")[2])
+        assert abs(avg_ns / 1e3 - r["avg_launch_us"]) <= 0.15 * r["avg_launch_us"], (avg_ns, r["avg_launch_us"])
+
+
+def test_cpu_baseline_object():
+    c = _line()["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "images/sec"
+
+
+def test_side_workloads_and_inference_keys():
+    d = _line()
+    for k in ("with_h2d", "config3_deeplabv3plus_r50", "config4_yolox_s", "config5_yolov7l_fp16", "infer", "infer_deeplabv3plus_r50"):
+        assert k in d and d[k].get("value", 0) > 0, k
+    assert d["infer"]["bn_act_elementwise_launches"] == 0 and d["infer_deeplabv3plus_r50"]["bn_act_elementwise_launches"] == 0
+    assert d["with_h2d"]["value"] < d["value"]   # the host-fed figure is the lower one; `value` is the HBM-resident step
