@@ -616,21 +616,30 @@ class HipConvModule(nn.Module):
             return None
         return bn, aid
 
-    def forward(self, x, activate=True, norm=True, residual=None, out=None, dx_link=None, res_link=None):
+    def forward(self, x, activate=True, norm=True, residual=None, out=None, dx_link=None, res_link=None, lazy=False):
         """`out`: optional NHWC channel-slice view that receives the result (concat elimination: the caller hands every
-        producer its slice of the concat buffer, ops.cat then has nothing to copy). Ignored on the unfused fallback path."""
+        producer its slice of the concat buffer, ops.cat then has nothing to copy). Ignored on the unfused fallback path.
+        `lazy`: the caller passes the result ONLY to Hip conv modules / blocks (which understand ops.LazyAct): in training the
+        layer may then skip its BN-apply + activation pass and return its raw convolution output, tagged (ops, round 5)."""
         fus = self._fusable(activate, norm)
         if fus is not None:
             bn, (aid, ap) = fus
             conv = self.conv
-            x, w = conv._effective(x)
+            if ops.lazy_of(x) is None:
+                x, w = conv._effective(x)
+            else:
+                w = conv.weight
             cfg = conv.make_cfg(aid, ap, bn)
+            cfg.lazy_out = bool(lazy)
             cfg.out = out
             cfg.dx_link, cfg.res_link = dx_link, (res_link if residual is not None else None)
             if bn is not None:
                 bn_tick(bn)
                 return ops.conv_bn_act(x, w, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, cfg)
             return ops.conv_bn_act(x, w, conv.bias, None, None, None, None, residual, cfg)
+        x = ops.materialize(x)
+        if residual is not None:
+            residual = ops.materialize(residual)
         for layer in self.order:
             if layer == "conv":
                 x = self.conv(x)

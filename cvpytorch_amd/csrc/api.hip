@@ -336,6 +336,8 @@ int cvhip_conv2d_fprop_fused(const cvhip_conv_desc* d, const void* x, const void
   p.pro_ap = f->pro_act_param;
   p.z_out = (h16_t*)f->z_out;
   p.z_ld = f->z_ld;
+  p.pro_lo = f->pro_lo;
+  p.pro_hi = f->pro_hi > 0 ? f->pro_hi : d->C;
   if (f->residual) {
     if (f->residual_ld < d->K) return CVHIP_ERR_INVALID;
     p.res = (const h16_t*)f->residual;
@@ -376,6 +378,13 @@ int cvhip_conv2d_fprop_prologue_ok(const cvhip_conv_desc* d, int with_z_out) {
     if (P != d->H || Q != d->W || d->stride_h != 1 || d->stride_w != 1) return 0;
   }
   return 1;
+}
+
+int cvhip_conv1x1_stream_prologue_ok(const cvhip_conv_desc* d, int with_stats) {
+  if (validate_dense_desc(d)) return 0;
+  IgemmParams p;
+  plan_fprop(d, &p);
+  return stream1x1_prologue_ok(p, with_stats != 0) ? 1 : 0;
 }
 
 static int dgrad_impl(const cvhip_conv_desc* d, const void* dy, const void* w_dgrad, const void* addend, int addend_ld, void* dx, void* stream,

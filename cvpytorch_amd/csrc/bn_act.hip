@@ -458,6 +458,9 @@ struct EwParams {
   float *o_mean, *o_invstd, *o_scale, *o_shift;   // MODE 0: block 0 stores the layer's statistics for backward
   float *o_dgamma, *o_dbeta;                       // MODE 1: block 0 stores (accumulate != 0: adds) the parameter gradients
   int accumulate;
+  // RLZ instances (round 5, lazy activations): `res` is the RAW convolution output of the layer that produced the residual; the
+  // pass applies that layer's BatchNorm scale / shift and the (same) activation to it on load: out = act(a*sc+sh) + act(res*rsc+rsh)
+  const float *res_scale, *res_shift;
 };
 constexpr int kEwAccMaxC = 2048;
 
@@ -476,8 +479,10 @@ struct EW_RPT {
 // MODE 0: out = act(a*scale+shift) (+res)         [a = conv output y]
 // MODE 1: out = dy from (a = dz, y)               [BN+act backward apply]
 // MODE 2: out = a (copy)       MODE 3: out = a + res
-template <int MODE, int ACT = 0, bool ACC = false>
+// RLZ (MODE 0 only): the residual operand is a LAZY activation — see EwParams::res_scale
+template <int MODE, int ACT = 0, bool ACC = false, bool RLZ = false>
 __global__ __launch_bounds__(256) void ew_kernel(const EwParams p) {
+  static_assert(!RLZ || MODE == 0, "lazy residuals exist in the forward apply pass only");
   __shared__ float cst[ACC ? 2 * kEwAccMaxC : 1];  // ACC: MODE 0 scale | shift; MODE 1 dbeta/M | dgamma/M
   if constexpr (ACC) {
     for (int c = threadIdx.x; c < p.C; c += 256) {
@@ -569,10 +574,15 @@ __global__ __launch_bounds__(256) void ew_kernel(const EwParams p) {
         }
       }
     }
+    float rsc[RLZ ? 8 : 1], rsh[RLZ ? 8 : 1];
+    if constexpr (RLZ) {
+      load8c(p.res_scale, c, p.C, rsc);
+      load8c(p.res_shift, c, p.C, rsh);
+    }
     // the residual mode is block-uniform: one branch-free instance of the row loops per mode (with the runtime tests inside the
     // element loop hipcc emitted a branch per element and no packed fp32 math: ISA of ew_kernel<0, SILU>, round 3)
     auto rows = [&](auto rm) {
-      constexpr int RES = decltype(rm)::value;  // 0: no residual, 1: added after the activation (MODE 3: the add itself), 2: before
+      constexpr int RES = decltype(rm)::value;  // 0: no residual, 1: added after the activation (MODE 3: the add itself), 2: before, 3: lazy, after
       auto math = [&](const f32x8& a, const f32x8& y, const f32x8& rs) -> f32x8 {
         f32x8 o;
 #pragma unroll
@@ -582,6 +592,7 @@ __global__ __launch_bounds__(256) void ew_kernel(const EwParams p) {
             if (RES == 2) u += rs.v[j];
             float v = act_fwd(u, ACT, p.ap);
             if (RES == 1) v += rs.v[j];
+            if constexpr (RES == 3) v += act_fwd(rs.v[j] * rsc[j] + rsh[j], ACT, p.ap);
             o.v[j] = v;
           } else if (MODE == 1) {
             const float u = y.v[j] * sc[j] + sh[j];
@@ -642,7 +653,9 @@ __global__ __launch_bounds__(256) void ew_kernel(const EwParams p) {
           if (c + j < p.C) p.out[r * p.ld_out + c + j] = (h16_t)o.v[j];
       }
     };
-    if constexpr (MODE == 3) {
+    if constexpr (RLZ) {
+      rows(std::integral_constant<int, 3>{});
+    } else if constexpr (MODE == 3) {
       rows(std::integral_constant<int, 1>{});
     } else if constexpr (MODE == 0) {
       if (!p.res) rows(std::integral_constant<int, 0>{});
@@ -651,6 +664,33 @@ __global__ __launch_bounds__(256) void ew_kernel(const EwParams p) {
     } else {
       rows(std::integral_constant<int, 0>{});
     }
+  }
+}
+
+// Round 5 (lazy activations): a layer whose BN + activation apply pass is deferred into its consumers' loads still needs its
+// statistics finalized — mean | invstd | scale | shift for backward and for the consumers' prologues, running statistics updated.
+// The same arithmetic as block 0 of ew_kernel<0, ACT, true>'s prologue, as a launch of its own (C / 256 blocks).
+__global__ __launch_bounds__(256) void bn_finalize_acc_kernel(const double* acc, int acc_ld, int C, double count, const float* gamma,
+                                                              const float* beta, float* rmean, float* rvar, float momentum, float eps,
+                                                              float* o_mean, float* o_invstd, float* o_scale, float* o_shift) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s1, s2;
+  acc_fold2(acc, acc_ld, c, s1, s2);
+  const double m = s1 / count;
+  double var = s2 / count - m * m;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float sc = g * is, sh = b - (float)m * sc;
+  o_mean[c] = (float)m;
+  o_invstd[c] = is;
+  o_scale[c] = sc;
+  o_shift[c] = sh;
+  if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+  if (rvar) {
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
   }
 }
 
@@ -1003,6 +1043,59 @@ int cvhip_bn_act_fwd_acc(const void* y, int32_t ld_y, void* z, int32_t ld_z, int
   p.o_shift = shift;
   CVHIP_LAUNCH_ACT_ACC(ew_kernel, 0, act, dim3(ew_grid(M, C)), (hipStream_t)stream, p)
   return check_launch("ew_kernel<0,acc>");
+}
+
+int cvhip_bn_finalize_acc(const double* acc, int32_t acc_ld, int32_t C, int64_t count, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
+                          float* shift, void* stream) {
+  if (!acc || !mean || !invstd || !scale || !shift || C <= 0 || count <= 0 || acc_ld < C) return CVHIP_ERR_INVALID;
+  hipLaunchKernelGGL(bn_finalize_acc_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, acc, acc_ld, C, (double)count, gamma, beta,
+                     running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+  return check_launch("bn_finalize_acc_kernel");
+}
+
+int cvhip_bn_act_fwd_acc_lazyres(const void* y, int32_t ld_y, void* z, int32_t ld_z, int64_t M, int32_t C, const double* acc, int32_t acc_ld,
+                                 int64_t count, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                 float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int32_t act,
+                                 float act_param, const void* residual_raw, int32_t ld_res, const float* res_scale, const float* res_shift,
+                                 void* stream) {
+  if (!y || !z || !acc || !mean || !invstd || !scale || !shift || M <= 0 || C <= 0 || count <= 0 || acc_ld < C) return CVHIP_ERR_INVALID;
+  if (!residual_raw || !res_scale || !res_shift) return CVHIP_ERR_INVALID;
+  if (C > kEwAccMaxC) return CVHIP_ERR_UNSUPPORTED;
+  EwParams p{};
+  p.a = (const h16_t*)y;
+  p.ld_a = ld_y;
+  p.out = (h16_t*)z;
+  p.ld_out = ld_z;
+  p.res = (const h16_t*)residual_raw;
+  p.ld_res = ld_res;
+  p.res_scale = res_scale;
+  p.res_shift = res_shift;
+  p.M = M;
+  p.C = C;
+  p.act = act;
+  p.ap = act_param;
+  p.acc = acc;
+  p.acc_ld = acc_ld;
+  p.count = (double)count;
+  p.gamma = gamma;
+  p.beta = beta;
+  p.rmean = running_mean;
+  p.rvar = running_var;
+  p.momentum = momentum;
+  p.eps = eps;
+  p.o_mean = mean;
+  p.o_invstd = invstd;
+  p.o_scale = scale;
+  p.o_shift = shift;
+  const dim3 grid(ew_grid(M, C));
+  switch (act) {
+    case CVHIP_ACT_RELU: hipLaunchKernelGGL((ew_kernel<0, CVHIP_ACT_RELU, true, true>), grid, dim3(256), 0, (hipStream_t)stream, p); break;
+    case CVHIP_ACT_SILU: hipLaunchKernelGGL((ew_kernel<0, CVHIP_ACT_SILU, true, true>), grid, dim3(256), 0, (hipStream_t)stream, p); break;
+    case CVHIP_ACT_LEAKY: hipLaunchKernelGGL((ew_kernel<0, CVHIP_ACT_LEAKY, true, true>), grid, dim3(256), 0, (hipStream_t)stream, p); break;
+    default: return CVHIP_ERR_UNSUPPORTED;
+  }
+  return check_launch("ew_kernel<0,acc,lazyres>");
 }
 
 int cvhip_bn_act_bwd_apply_acc(const void* dz, int32_t ld_dz, const void* y, int32_t ld_y, void* dy, int32_t ld_dy, int64_t M, int32_t C,

@@ -64,6 +64,13 @@ struct Bwd1x1Params {
   float tail_ap;
   double* tail_acc;
   int tail_acc_ld;
+  // XPRO instances (round 5, lazy activations): `x` is the RAW convolution output of the layer that produced this layer's input; the
+  // weight gradient needs the ACTIVATED input, so the x rows are transformed on their way into the LDS tile,
+  // x' = act(xs[c] * x + xh[c]) for input channels c in [x_lo, x_hi), rounded to 16 bits as the stand-alone pass would have stored them
+  const float *xs, *xh;
+  int x_act;
+  float x_ap;
+  int x_lo, x_hi;
 };
 
 typedef __attribute__((address_space(3))) h16x4 lds_h16x4_b;
@@ -99,8 +106,9 @@ __device__ __forceinline__ f32x8 bnact_bwd8(const f32x8& dz, const f32x8& y, con
 // pushed the 128 x 128 configuration to 104 spilled VGPRs (300 B/lane of scratch, 106 -> 195 us per launch) when it was a runtime flag
 // KB 256 (round 4: the 64 -> 256 / 128 -> 256 expansion layers of ResNet bottlenecks, C <= 128 = ONE input-channel slice): 128 dW
 // accumulator registers + 64 of dz / y prefetch per lane — one block per CU (launch bounds 1: up to 512 registers, AGPRs included)
-template <int KB, int CB, bool TAIL>
+template <int KB, int CB, bool TAIL, bool XPRO = false>
 __global__ __launch_bounds__(256, KB >= 256 ? 1 : 2) void bwd1x1_kernel(const Bwd1x1Params p) {
+  static_assert(!(TAIL && XPRO), "a lazy input has no tail form");
   constexpr int RT = 64;
   constexpr int KV = KB / 8, CV = CB / 8;
   constexpr int D_PASS = 256 / KV, D_IT = RT / D_PASS;
@@ -186,6 +194,17 @@ __global__ __launch_bounds__(256, KB >= 256 ? 1 : 2) void bwd1x1_kernel(const Bw
 
   if (p.acc) __syncthreads();  // everybody has its constants before the first store_tile overwrites the scratch
 
+  // XPRO: constants of this thread's input-channel vector (thread-constant: xv); vectors outside [x_lo, x_hi) pass through
+  float xsc[XPRO ? 8 : 1], xsh[XPRO ? 8 : 1];
+  bool xlazy = false;
+  if constexpr (XPRO) {
+    const int xc = c0 + xv * 8;
+    xlazy = xc >= p.x_lo && xc < p.x_hi;
+    const int xcc = xlazy ? xc : p.x_lo;
+    load8c(p.xs, xcc, p.C, xsc);
+    load8c(p.xh, xcc, p.C, xsh);
+  }
+
   uint4 rd[D_IT], ry[D_IT], rx[X_IT];
   // loads are unconditional (rows past M read row 0 and are zeroed when the tile is written): no load sits in a branch
   auto load_tile = [&](int tile) {
@@ -228,6 +247,29 @@ __global__ __launch_bounds__(256, KB >= 256 ? 1 : 2) void bwd1x1_kernel(const Bw
     for (int i = 0; i < X_IT; ++i) {
       const int px = i * X_PASS + xrow;
       uint4 v = rx[i];
+      if constexpr (XPRO) {
+        if (xlazy) {
+          f32x8 f = unpack8(v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f.v[j] = f.v[j] * xsc[j] + xsh[j];
+          switch (p.x_act) {  // block-uniform
+            case CVHIP_ACT_SILU:
+#pragma unroll
+              for (int j = 0; j < 8; ++j) f.v[j] = act_fwd(f.v[j], CVHIP_ACT_SILU, p.x_ap);
+              break;
+            case CVHIP_ACT_RELU:
+#pragma unroll
+              for (int j = 0; j < 8; ++j) f.v[j] = act_fwd(f.v[j], CVHIP_ACT_RELU, p.x_ap);
+              break;
+            case CVHIP_ACT_LEAKY:
+#pragma unroll
+              for (int j = 0; j < 8; ++j) f.v[j] = act_fwd(f.v[j], CVHIP_ACT_LEAKY, p.x_ap);
+              break;
+            default: break;
+          }
+          v = pack8(f);
+        }
+      }
       if (m0 + px >= M) v = z;
       *reinterpret_cast<uint4*>(sX + px * X_ROWB + swz_off<X_SEGM>(px & 31, xv)) = v;
     }
@@ -435,10 +477,10 @@ int bwd1x1_fits(const cvhip_conv_desc* d) {
   return trips >= 2400 ? 1 : 0;
 }
 
-template <int KB, int CB, bool TAIL>
+template <int KB, int CB, bool TAIL, bool XPRO = false>
 static int launch_b1t(const Bwd1x1Params& p, int blocks, hipStream_t s) {
   constexpr int LDS = CB * (KB * 2 + 16) + 64 * KB * 2 + 64 * CB * 2 + 4 * CB * (int)sizeof(float);
-  auto kern = bwd1x1_kernel<KB, CB, TAIL>;
+  auto kern = bwd1x1_kernel<KB, CB, TAIL, XPRO>;
   static bool attr_done[64] = {};  // per instantiation AND device: the attribute is a per-device property of the function
   int devid = 0;
   (void)hipGetDevice(&devid);
@@ -457,6 +499,11 @@ static int launch_b1t(const Bwd1x1Params& p, int blocks, hipStream_t s) {
 
 template <int KB, int CB>
 static int launch_b1(const Bwd1x1Params& p, int blocks, hipStream_t s) {
+  if (p.xs) {
+    if (p.tail_y) return CVHIP_ERR_UNSUPPORTED;
+    if constexpr (KB <= 128) return launch_b1t<KB, CB, false, true>(p, blocks, s);
+    return CVHIP_ERR_UNSUPPORTED;  // (the K = 256 instances sit at their register budget)
+  }
   return p.tail_y ? launch_b1t<KB, CB, true>(p, blocks, s) : launch_b1t<KB, CB, false>(p, blocks, s);
 }
 
@@ -504,8 +551,13 @@ static int bwd1x1_impl(const cvhip_conv_desc* d, const void* dz0, int32_t dz0_ld
                        const void* y, const void* x, const void* w_dgrad, const float* scale, const float* shift, const float* mean,
                        const float* invstd, const float* dgamma, const float* dbeta, const double* acc, int32_t acc_ld, float* o_dgamma,
                        float* o_dbeta, int32_t accumulate, int32_t act, float act_param, const void* addend, int32_t addend_ld, void* dx,
-                       int32_t dx_ld, float* dw, void* stream, const cvhip_bn_tail* tail = nullptr) {
+                       int32_t dx_ld, float* dw, void* stream, const cvhip_bn_tail* tail = nullptr, const cvhip_lazy_in* xin = nullptr) {
   if (!d || !dz0 || !y || !x || !w_dgrad || !dx || !dw) return CVHIP_ERR_INVALID;
+  if (xin) {
+    if (!xin->scale || !xin->shift) return CVHIP_ERR_INVALID;
+    if (tail || d->K > 128) return CVHIP_ERR_UNSUPPORTED;
+    if (xin->act != CVHIP_ACT_NONE && xin->act != CVHIP_ACT_RELU && xin->act != CVHIP_ACT_LEAKY && xin->act != CVHIP_ACT_SILU) return CVHIP_ERR_UNSUPPORTED;
+  }
   if (!bwd1x1_structural(d)) return CVHIP_ERR_UNSUPPORTED;
   if (k_split <= 0 || k_split > d->K || (k_split & 7)) return CVHIP_ERR_INVALID;
   if (k_split < d->K && (!dz1 || (dz1_ld & 7) || (((uintptr_t)dz1) & 15))) return CVHIP_ERR_INVALID;
@@ -548,6 +600,15 @@ static int bwd1x1_impl(const cvhip_conv_desc* d, const void* dz0, int32_t dz0_ld
   p.o_dgamma = o_dgamma;
   p.o_dbeta = o_dbeta;
   p.accumulate = accumulate;
+  if (xin) {
+    p.xs = xin->scale;
+    p.xh = xin->shift;
+    p.x_act = xin->act;
+    p.x_ap = xin->act_param;
+    p.x_lo = xin->c_lo;
+    p.x_hi = xin->c_hi > 0 ? xin->c_hi : d->C;
+    if (p.x_lo < 0 || p.x_hi > d->C || p.x_lo >= p.x_hi || (p.x_lo & 7) || (p.x_hi & 7)) return CVHIP_ERR_INVALID;
+  }
   p.tail_y = nullptr;
   if (tail) {
     if (!tail->y || !tail->scale || !tail->shift || !tail->mean || !tail->invstd || !tail->acc || tail->acc_ld < d->C) return CVHIP_ERR_INVALID;
@@ -583,6 +644,17 @@ int cvhip_conv1x1_bwd_fused_acc(const cvhip_conv_desc* d, const void* dz0, int32
   if (!acc && mean) return CVHIP_ERR_INVALID;
   return bwd1x1_impl(d, dz0, dz0_ld, dz1, dz1_ld, k_split, y, x, w_dgrad, scale, shift, mean, invstd, nullptr, nullptr, acc, acc_ld, dgamma_out,
                      dbeta_out, accumulate, act, act_param, addend, addend_ld, dx, dx_ld, dw, stream, tail);
+}
+
+int cvhip_conv1x1_bwd_fused_lazy(const cvhip_conv_desc* d, const void* dz0, int32_t dz0_ld, const void* dz1, int32_t dz1_ld, int32_t k_split,
+                                 const void* y, const void* x_raw, const void* w_dgrad, const float* scale, const float* shift, const float* mean,
+                                 const float* invstd, const double* acc, int32_t acc_ld, float* dgamma_out, float* dbeta_out, int32_t accumulate,
+                                 int32_t act, float act_param, const void* addend, int32_t addend_ld, void* dx, int32_t dx_ld, float* dw,
+                                 const cvhip_lazy_in* xin, void* stream) {
+  if (!acc && mean) return CVHIP_ERR_INVALID;
+  if (!xin) return CVHIP_ERR_INVALID;
+  return bwd1x1_impl(d, dz0, dz0_ld, dz1, dz1_ld, k_split, y, x_raw, w_dgrad, scale, shift, mean, invstd, nullptr, nullptr, acc, acc_ld, dgamma_out,
+                     dbeta_out, accumulate, act, act_param, addend, addend_ld, dx, dx_ld, dw, stream, nullptr, xin);
 }
 
 }  // extern "C"

@@ -61,7 +61,11 @@ __device__ __forceinline__ void s1_act_vec(float (&v)[NV], int act, float ap) {
 }
 
 // EPI: fused epilogue instance (STATS == 0 only): out = act((acc + bias) * ep_scale + ep_shift)
-template <int NF, int MF, int STATS, bool EPI = false>
+// PRO (round 5, lazy activations): x is the RAW convolution output of the producing Conv-BN-act layer(s); input channels
+// [pro_lo, pro_hi) are transformed ON LOAD, z = act(pro_scale[c] * x + pro_shift[c]), in fp32 and rounded to 16 bits exactly as the
+// stand-alone BN + activation pass (ew_kernel<0>) would have stored them — the pass, and the activated tensor, do not exist. The
+// transform sits between the register prefetch and the MFMAs of a pipeline stage: the kernel is HBM-bound, its VALU is idle.
+template <int NF, int MF, int STATS, bool EPI = false, bool PRO = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernArgs p, int ntiles, int vec16) {
   constexpr int BN = NF * 16;
   constexpr int RT = 64 * MF;   // pixel rows per block tile: 4 waves x MF fragments x 16
@@ -154,6 +158,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernA
     sbias[2 * BN + t] = p.tail_shift[n];
     sbias[3 * BN + t] = p.tail_mean[n];
     sbias[4 * BN + t] = p.tail_invstd[n];
+  }
+  float* const spro = sbias + 5 * BN;  // PRO: [2][cin_pad] scale | shift of the input channels, behind the tail rows
+  if constexpr (PRO) {
+    for (int c = t; c < cin_pad; c += 256) {
+      const bool in = c >= p.pro_lo && c < p.pro_hi && c < Cin;
+      spro[c] = in ? p.pro_scale[c] : 1.f;
+      spro[cin_pad + c] = in ? p.pro_shift[c] : 0.f;
+    }
   }
   __syncthreads();
 
@@ -287,11 +299,41 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernA
     cp_tile += gridDim.x;
   };
 
+  // PRO: the stage that is about to be multiplied, transformed in its registers (same channel arithmetic as `load`: a chunk past Cin
+  // holds chunk 0 again and meets zero weights). Channel vectors outside [pro_lo, pro_hi) — a concatenation's already-activated
+  // slices — pass through untouched.
+  auto xform = [&](h16x8 (&buf)[MF][KS]) {
+    const int kbase = cp_kc * KC + g * 8;
+    const int ksn = min(KS, (cin_pad - cp_kc * KC) >> 5);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      int kk = kbase + ks * 32;
+      kk = kk < Cin ? kk : 0;
+      if (ks < ksn && kk >= p.pro_lo && kk < p.pro_hi) {
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(spro + kk), c1 = *reinterpret_cast<const f32x4*>(spro + kk + 4);
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(spro + cin_pad + kk), h1 = *reinterpret_cast<const f32x4*>(spro + cin_pad + kk + 4);
+#pragma unroll
+        for (int b = 0; b < MF; ++b) {
+          f32x8 v = unpack8(__builtin_bit_cast(uint4, buf[b][ks]));
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            v.v[q] = v.v[q] * c0[q] + h0[q];
+            v.v[4 + q] = v.v[4 + q] * c1[q] + h1[q];
+          }
+          s1_act_vec<8>(v.v, p.pro_act, p.pro_ap);
+          buf[b][ks] = __builtin_bit_cast(h16x8, pack8(v));
+        }
+      }
+    }
+  };
+
   // branch-free body: a stage past the end loads clamped rows and computes a tile whose rows are all >= M (nothing stored or summed)
   for (int it = 0; it < total; it += 2) {
     load(buf1);
+    if constexpr (PRO) xform(buf0);
     compute(buf0);
     load(buf0);
+    if constexpr (PRO) xform(buf1);
     compute(buf1);
   }
 
@@ -382,14 +424,22 @@ static bool s1x1_structural(const IgemmParams& p) {
          c.out_oh == 0 && c.out_ow == 0 && c.OHi == p.OH && c.OWi == p.OW && p.IH == p.OH && p.IW == p.OW && (p.x_ld & 7) == 0;
 }
 
-template <int NF, int STATS, bool EPI = false>
+// LDS bytes of a launch: weight tile + bias + the tail layer's 4 constant rows (+ the prologue's scale | shift rows)
+static int s1x1_lds(int bn, int cin_pad, bool pro) {
+  int lds = bn * (cin_pad * 2 + 16) + 5 * bn * (int)sizeof(float) + (pro ? 2 * cin_pad * (int)sizeof(float) : 0);
+  if (lds < 4 * bn * 2 * (int)sizeof(float)) lds = 4 * bn * 2 * (int)sizeof(float);
+  return lds;
+}
+constexpr int kS1MaxLdsPro = kS1MaxLds + 4096;  // what hipFuncSetAttribute grants every instance: a prologue must fit under it
+
+template <int NF, int STATS, bool EPI = false, bool PRO = false>
 static int launch_s1(const IgemmParams& p, int blocks, int ntiles, hipStream_t stream) {
   constexpr int MF = 2;
   const int bn = NF * 16;
   const int cin_pad = (p.Cin + 31) & ~31;
-  int lds = bn * (cin_pad * 2 + 16) + 5 * bn * (int)sizeof(float);  // weight tile + bias + the tail layer's 4 constant rows
-  if (lds < 4 * bn * 2 * (int)sizeof(float)) lds = 4 * bn * 2 * (int)sizeof(float);
-  auto kern = conv1x1_stream_kernel<NF, MF, STATS, EPI>;
+  const int lds = s1x1_lds(bn, cin_pad, PRO);
+  if (lds > kS1MaxLdsPro) return CVHIP_ERR_UNSUPPORTED;
+  auto kern = conv1x1_stream_kernel<NF, MF, STATS, EPI, PRO>;
   static bool attr_done[64] = {};  // per instantiation AND device: the attribute is a per-device property of the function
   int devid = 0;
   (void)hipGetDevice(&devid);
@@ -409,6 +459,15 @@ static int launch_s1(const IgemmParams& p, int blocks, int ntiles, hipStream_t s
 }
 
 // returns -1 when the problem is not taken (caller falls through to the general kernel)
+// 1 when the streaming kernel runs this fprop problem AND can apply a prologue to its input (the plan of cvhip_conv2d_fprop[_acc/_fused])
+bool stream1x1_prologue_ok(const IgemmParams& p, bool stats) {
+  if (!s1x1_structural(p)) return false;
+  if (stream1x1_blocks(p.Nout, p.Cin, p.cls[0].M, stats) <= 0) return false;
+  const int nf = s1x1_nf(p.Nout, p.Cin, stats);
+  if (nf == 16) return false;  // (the 256-wide detection-head instances have no prologue form)
+  return s1x1_lds(nf * 16, (p.Cin + 31) & ~31, true) <= kS1MaxLdsPro;
+}
+
 int try_launch_stream1x1(const IgemmParams& p, hipStream_t stream) {
   if (!s1x1_structural(p)) return -1;
   const int64_t M = p.cls[0].M;
@@ -417,6 +476,20 @@ int try_launch_stream1x1(const IgemmParams& p, hipStream_t stream) {
   const int ntiles = (int)((M + 127) / 128);
   const int nf = s1x1_nf(p.Nout, p.Cin, p.stats != nullptr);
   if (p.stats && (p.ep_scale || p.ep_act != CVHIP_ACT_NONE)) return CVHIP_ERR_INVALID;
+  if (p.z_out) return CVHIP_ERR_UNSUPPORTED;  // (the activated side output exists in the patch-resident kernel only)
+  if (p.pro_scale) {
+    // lazy input: BN scale / shift + activation of the producing layer applied on load (training forms: raw output, optional BN sums)
+    if (p.tail_y || p.ep_scale || p.ep_act != CVHIP_ACT_NONE || p.res || !stream1x1_prologue_ok(p, p.stats != nullptr)) return CVHIP_ERR_UNSUPPORTED;
+    if (p.pro_lo < 0 || p.pro_hi > p.Cin || p.pro_lo >= p.pro_hi || (p.pro_lo & 7) || (p.pro_hi & 7)) return CVHIP_ERR_INVALID;
+    if (p.stats) {
+      if (nf == 2) return launch_s1<2, 1, false, true>(p, blocks, ntiles, stream);
+      if (nf == 4) return launch_s1<4, 1, false, true>(p, blocks, ntiles, stream);
+      return launch_s1<8, 1, false, true>(p, blocks, ntiles, stream);
+    }
+    if (nf == 2) return launch_s1<2, 0, false, true>(p, blocks, ntiles, stream);
+    if (nf == 4) return launch_s1<4, 0, false, true>(p, blocks, ntiles, stream);
+    return launch_s1<8, 0, false, true>(p, blocks, ntiles, stream);
+  }
   if (p.stats && p.tail_y) {
     if (nf == 2) return launch_s1<2, 2>(p, blocks, ntiles, stream);
     if (nf == 4) return launch_s1<4, 2>(p, blocks, ntiles, stream);

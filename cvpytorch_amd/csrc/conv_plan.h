@@ -72,6 +72,9 @@ struct IgemmCommon {
   float pro_ap;
   h16_t* z_out;
   int z_ld;
+  // (round 5) the streaming 1x1 kernel takes the same prologue (no z_out) on the input-channel range [pro_lo, pro_hi): the other
+  // channels of x — slices of a concatenation that were materialised — pass through untouched
+  int pro_lo, pro_hi;
   // image stems (conv_stem.hip only): the input is the dataloader's own tensor, fp32 NCHW [NB][x_planes][IH][IW] (x_planes <= 4 real
   // channels), read plane by plane and rounded to 16 bits on the way into the LDS patch — `x` is unused then
   const float* x_image;
@@ -171,6 +174,7 @@ int launch_igemm(IgemmParams& p, hipStream_t stream);
 // conv1x1_stream.hip: grid size of the streaming 1x1 kernel (0 = the general kernel runs) and its launcher (-1 = not taken)
 int stream1x1_blocks(int Nout, int Cin, int64_t M, bool stats);
 int try_launch_stream1x1(const IgemmParams& p, hipStream_t stream);
+bool stream1x1_prologue_ok(const IgemmParams& p, bool stats);
 // conv_stem.hip: direct convolution for 8-channel image stems (grid size, 0 = not taken; launcher, -1 = not taken)
 int stem_blocks(int C, int x_ld, int K, int R, int S, int sh, int sw, int dh, int dw, int N, int OH, int OW);
 int try_launch_stem(const IgemmParams& p, hipStream_t stream);

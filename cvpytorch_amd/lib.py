@@ -51,7 +51,13 @@ class ConvFuse(C.Structure):
                 ("ep_shift", C.c_void_p), ("ep_act", C.c_int32), ("ep_act_param", C.c_float), ("pro_scale", C.c_void_p),
                 ("pro_shift", C.c_void_p), ("pro_act", C.c_int32), ("pro_act_param", C.c_float), ("z_out", C.c_void_p),
                 ("z_ld", C.c_int32), ("residual", C.c_void_p), ("residual_ld", C.c_int32), ("residual_pre", C.c_int32),
-                ("x_image", C.c_void_p), ("x_image_planes", C.c_int32)]
+                ("x_image", C.c_void_p), ("x_image_planes", C.c_int32), ("pro_lo", C.c_int32), ("pro_hi", C.c_int32)]
+
+
+class LazyIn(C.Structure):
+    """cvhip_lazy_in (include/cvhip.h): a lazily activated input operand of a backward kernel."""
+    _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("act", C.c_int32), ("act_param", C.c_float), ("c_lo", C.c_int32),
+                ("c_hi", C.c_int32)]
 
 
 PATCH_CLASS_INTS = 30  # CVHIP_PATCH_CLASS_INTS
@@ -107,6 +113,12 @@ SIGNATURES = {
     "cvhip_conv2d_wgrad_image": (_i32, [_dp, _p, _i32, _p, _p, _p]),
     "cvhip_conv2d_fprop_prologue_ok": (_i32, [_dp, _i32]),
     "cvhip_conv2d_patch_plan": (_i32, [_dp, _i32, C.POINTER(_i32), _i32]),
+    "cvhip_conv1x1_stream_prologue_ok": (_i32, [_dp, _i32]),
+    "cvhip_bn_finalize_acc": (_i32, [_p, _i32, _i32, _i64, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _p]),
+    "cvhip_bn_act_fwd_acc_lazyres": (_i32, [_p, _i32, _p, _i32, _i64, _i32, _p, _i32, _i64, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _i32, _f32,
+                                     _p, _i32, _p, _p, _p]),
+    "cvhip_conv1x1_bwd_fused_lazy": (_i32, [_dp, _p, _i32, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _i32, _f32, _p, _i32,
+                                     _p, _i32, _p, C.POINTER(LazyIn), _p]),
     "cvhip_conv2d_dgrad": (_i32, [_dp, _p, _p, _p, _p]),
     "cvhip_conv2d_dgrad_add": (_i32, [_dp, _p, _p, _p, _i32, _p, _p]),
     "cvhip_conv2d_wgrad": (_i32, [_dp, _p, _p, _p, _i32, _p]),

@@ -123,6 +123,70 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- lazy activations (round 5) ---------------------------------------------------------------------------------------------------
+# `ConvModule.forward` is act(norm(conv(x))) (conv_module.py:201-214). In training the BatchNorm statistics need the whole batch, so
+# the apply pass z = act(scale*y + shift) cannot ride in the convolution's own epilogue — but it can ride in the CONSUMER's load: a
+# layer asked for a lazy result (ConvCfg.lazy_out) only finalizes its statistics (one tiny launch) and hands out its RAW convolution
+# output y tagged with a LazyAct; a consumer that reads every input element exactly once through registers — the streaming 1x1
+# kernel (conv1x1_stream.hip PRO), the fused 1x1 backward (conv1x1_bwd.hip XPRO: the weight gradient needs the activated input), the
+# residual operand of a BN+act pass (ew_kernel RLZ) — applies the transform on load, bit-identically to the stand-alone pass. The
+# activated tensor then never exists in HBM (one read + one write of the tensor less per edge). Every other consumer (3x3 implicit
+# GEMMs stage their operand by LDS-DMA and re-read each element per tap: an on-load SiLU there is VALU-infeasible)
+# calls `materialize`, which runs exactly the pass the producer skipped. CVHIP_LAZY=0 switches the whole mechanism off.
+_LAZY = __import__("os").environ.get("CVHIP_LAZY", "1") != "0"
+_LAZY_ACTS = (L.ACT_NONE, L.ACT_RELU, L.ACT_LEAKY, L.ACT_SILU)
+
+
+def set_lazy(flag=True):
+    global _LAZY
+    _LAZY = bool(flag)
+
+
+class LazyAct:
+    """tag of a tensor that holds the RAW output y of a training-mode Conv-BN-act layer: its logical value is act(scale*y + shift)"""
+    __slots__ = ("scale", "shift", "act", "ap", "z")
+
+    def __init__(self, scale, shift, act, ap):
+        self.scale, self.shift, self.act, self.ap = scale, shift, int(act), float(ap)
+        self.z = None   # the materialised tensor, once some consumer needed it
+
+
+def lazy_of(t):
+    return getattr(t, "_hip_lazy", None) if t is not None else None
+
+
+class Materialize(torch.autograd.Function):
+    """z = act(scale*y + shift): the BN-apply + activation pass a lazy producer skipped, for a consumer that cannot transform on load"""
+
+    @staticmethod
+    def forward(ctx, y, lz):
+        yy, y_ld = as_nhwc(y, lazy_ok=True)
+        N, K, P, Q = yy.shape
+        z = empty_nhwc(N, K, P, Q, yy.device)
+        _timed_ew("bn_act_fwd(ew_kernel<0>)", 4.0 * N * P * Q * K, "cvhip_bn_act_fwd", yy.data_ptr(), y_ld, z.data_ptr(), K, N * P * Q, K,
+                  lz.scale.data_ptr(), lz.shift.data_ptr(), lz.act, lz.ap, None, 0, _stream())
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        return dz, None
+
+
+def materialize(x):
+    """the activated tensor behind a lazy one (computed once, shared by all consumers that need it); any other tensor unchanged"""
+    lz = lazy_of(x)
+    if lz is None:
+        return x
+    if lz.z is None:
+        lz.z = Materialize.apply(x, lz)
+    return lz.z
+
+
+def _lazy_in(lz, c_off=0):
+    """cvhip_lazy_in of a lazy operand whose channel 0 is channel `c_off` of the kernel's operand (whole tensor lazy)"""
+    return L.LazyIn(lz.scale.data_ptr() - 4 * c_off, lz.shift.data_ptr() - 4 * c_off, lz.act, lz.ap, c_off, c_off + lz.scale.numel())
+
+
 # ---- producer records: BN-backward sums from the kernel that writes the gradient ------------------------------------------------------
 # The gradient dz at the output of a Conv-BN-act layer P is, for most layers, written by exactly one kernel: the dgrad (or fused
 # 1x1 backward) of the layer that consumed P's output. That kernel can fold P's BatchNorm-backward sums (sum du, sum du*xhat) into
@@ -314,10 +378,13 @@ def nhwc_ld(t):
     return ld
 
 
-def as_nhwc(t):
+def as_nhwc(t, lazy_ok=False):
     """NHWC view of `t` (no copy when it already is one; otherwise one channels_last relayout)."""
     if not t.is_cuda:
         raise L.CvhipError("cvpytorch_amd ops need CUDA/HIP tensors (no CPU fallback); got %s" % t.device)
+    if not lazy_ok and getattr(t, "_hip_lazy", None) is not None:
+        # a lazy tensor holds RAW convolution outputs: only ops that apply its transform on load may read it
+        raise L.CvhipError("a lazy activation reached an op that does not transform on load (ops.materialize it first)")
     if t.dtype != ACT_DTYPE:
         t = t.to(ACT_DTYPE)
     ld = nhwc_ld(t)
@@ -500,7 +567,7 @@ class ConvCfg:
     """Static configuration of one conv(+BN+act) layer (python-side)."""
     __slots__ = ("stride", "pad", "dil", "groups", "act", "act_param", "has_bn", "bn_training", "momentum", "eps",
                  "state", "track", "vkey", "gw", "gb", "gg", "gbeta", "arena", "idx_w", "idx_b", "idx_bn", "sync", "out", "out_split", "dx_link", "res_link", "res_pre",
-                 "acc_owner", "acc_attr", "prod", "in_prod", "no_grad")
+                 "acc_owner", "acc_attr", "prod", "in_prod", "no_grad", "lazy_out", "lazy_half1", "lazy_made", "in_lazy", "res_lazy")
 
     def __init__(self, stride, pad, dil, groups=1, act=L.ACT_NONE, act_param=0.0, has_bn=False, bn_training=True,
                  momentum=0.1, eps=1e-5, state=None, track=True):
@@ -533,6 +600,14 @@ class ConvCfg:
         self.prod = None
         self.in_prod = None
         self.no_grad = False   # conv_bn_act notes whether autograd was recording when the layer was called (inference fast path)
+        # lazy activations (LazyAct above): `lazy_out` = the caller wants the RAW output (its consumers transform on load); `lazy_half1`
+        # = the same for the first sibling of a pair; `lazy_made` = what forward actually made (None: the activated tensor, as ever);
+        # `in_lazy` / `res_lazy` = the input's / residual's tag when THIS layer's kernels take them on load (set by the wrappers)
+        self.lazy_out = False
+        self.lazy_half1 = False
+        self.lazy_made = None
+        self.in_lazy = None
+        self.res_lazy = None
 
 
 # ---- SyncBatchNorm plumbing (trainer.py:126-127 -> torch.nn.SyncBatchNorm semantics) -------------------------------------
@@ -720,6 +795,16 @@ def _conv_grads(ctx, x, weight, dy, dy_ld, need_dx, need_dw, need_db):
     return dx, dw, dbias
 
 
+def _materialize_tmp(x, x_ld, lz):
+    """backward-side fallback: the activated copy of a lazily consumed input (same shape and pitch), for kernels without an on-load
+    transform — costs the pass the forward saved, never more"""
+    N, Cc, H, W = x.shape
+    z = empty_nhwc(N, Cc, H, W, x.device, ld=x_ld)
+    _timed_ew("bn_act_fwd(ew_kernel<0>)", 4.0 * N * H * W * Cc, "cvhip_bn_act_fwd", x.data_ptr(), x_ld, z.data_ptr(), x_ld, N * H * W, Cc,
+              lz.scale.data_ptr(), lz.shift.data_ptr(), lz.act, lz.ap, None, 0, _stream())
+    return z
+
+
 def _bwd1x1_ok(ctx, cfg, x, need_dx, need_dw, need_db, segs):
     """True when the fused 1x1 backward kernel (conv1x1_bwd.hip: BN/act backward on load + dgrad + wgrad in one pass) takes
     this layer: dense 1x1 stride-1, K in {32, 64, 128}, unpadded channels, both gradients wanted, 16-byte aligned operands."""
@@ -737,7 +822,8 @@ def _bwd1x1_ok(ctx, cfg, x, need_dx, need_dw, need_db, segs):
     return bool(L.load().cvhip_conv1x1_bwd_fused_ok(C.byref(desc)))
 
 
-def _bwd1x1(ctx, cfg, x, y, weight, segs, k_split, stats, with_mean, ag, ab, act, act_param, acc=None, g_out=None, b_out=None, accumulate=0):
+def _bwd1x1(ctx, cfg, x, y, weight, segs, k_split, stats, with_mean, ag, ab, act, act_param, acc=None, g_out=None, b_out=None, accumulate=0,
+            xin=None):
     """dx, dw of a 1x1 Conv-BN-act layer from the gradient(s) at its OUTPUT in one launch (`segs`: one (tensor, pitch), or two
     for sibling pairs; `stats` rows: mean, invstd, scale, shift; ag / ab: sum du*xhat / sum du — or `acc`: the layer's backward
     accumulator, folded by the kernel itself, which then also stores dgamma / dbeta into g_out / b_out)."""
@@ -771,7 +857,16 @@ def _bwd1x1(ctx, cfg, x, y, weight, segs, k_split, stats, with_mean, ag, ab, act
     mu = stats[0].data_ptr() if with_mean else None
     isd = stats[1].data_ptr() if with_mean else None
     M = N * H * W
-    if acc is not None:
+    if xin is not None:
+        # x is the RAW output of the layer that made it (lazy activation): the kernel transforms the rows it stages for the weight gradient
+        if acc is None:
+            raise L.CvhipError("lazy input without the accumulator form of the fused 1x1 backward")
+        li = _lazy_in(xin)
+        _timed_call("bwd1x1_kernel", (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv1x1_bwd_fused_lazy", C.byref(desc), d0.data_ptr(), d0_ld,
+                    _ptr(d1), d1_ld, k_split, y.data_ptr(), x.data_ptr(), ctx.w_dgrad.data_ptr(), sc, sh, mu, isd,
+                    acc.data_ptr(), K, _ptr(g_out), _ptr(b_out), int(accumulate), act, act_param, _ptr(g), g_ld,
+                    dx.data_ptr(), Cc, dst.data_ptr(), C.byref(li), st, passes=2, nbytes=2.0 * M * (2 * K + 2 * Cc))
+    elif acc is not None:
         pin = getattr(ctx, "in_prod", None)
         tail = _tail_for(pin, N, Cc, H, W) if (_BN_TAIL_MASK & 4) else None
         _timed_call("bwd1x1_kernel", (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv1x1_bwd_fused_acc", C.byref(desc), d0.data_ptr(), d0_ld,
@@ -801,6 +896,16 @@ def _bn_fwd_acc(y, y_ld, z, z_ld, M, kh, off, K, acc_f, gamma, beta, running_mea
     rv = running_var if cfg.track else None
     g = gamma.detach() if gamma is not None else None
     bt = beta.detach() if beta is not None else None
+    rl = cfg.res_lazy if residual is not None else None
+    if rl is not None:
+        # the residual is a LAZY activation (raw output of the layer that made it): its transform rides in this pass
+        _timed_ew("bn_act_fwd(ew_kernel<0>)", 6.0 * M * kh, "cvhip_bn_act_fwd_acc_lazyres",
+                  y.data_ptr() + 2 * off, y_ld, z.data_ptr(), z_ld, M, kh, acc_f.data_ptr() + o8, K, M,
+                  (g.data_ptr() + o4) if g is not None else None, (bt.data_ptr() + o4) if bt is not None else None,
+                  (rm.data_ptr() + o4) if rm is not None else None, (rv.data_ptr() + o4) if rv is not None else None,
+                  cfg.momentum, cfg.eps, stats[0].data_ptr() + o4, stats[1].data_ptr() + o4, stats[2].data_ptr() + o4, stats[3].data_ptr() + o4,
+                  cfg.act, cfg.act_param, residual.data_ptr(), res_ld, rl.scale.data_ptr(), rl.shift.data_ptr(), st)
+        return
     _timed_ew("bn_act_fwd(ew_kernel<0>)", 2.0 * M * kh * (3 if residual is not None else 2), "cvhip_bn_act_fwd_acc",
               y.data_ptr() + 2 * off, y_ld, z.data_ptr(), z_ld, M, kh, acc_f.data_ptr() + o8, K, M,
               (g.data_ptr() + o4) if g is not None else None, (bt.data_ptr() + o4) if bt is not None else None,
@@ -896,7 +1001,7 @@ class ConvBnAct(torch.autograd.Function):
             N, planes, H, W = x.shape
             Cc, x_ld = 8, 8
         else:
-            x, x_ld = as_nhwc(x)
+            x, x_ld = as_nhwc(x, lazy_ok=cfg.in_lazy is not None)
             N, Cc, H, W = x.shape
         dev = x.device
         c_orig = Cc
@@ -980,7 +1085,18 @@ class ConvBnAct(torch.autograd.Function):
                     L.check(rows, "cvhip_conv2d_fprop_stats_rows")
                 partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
             kname = "stem_fprop_kernel" if lib.cvhip_conv_stem_blocks(C.byref(desc)) > 0 else _igemm_name(Kp, N * P * Q, R * S * Cc, _pointwise(R, S, cfg), x_ld, epilogue_stats)
-            if image is not None:
+            if cfg.in_lazy is not None:
+                # lazy input: the producing layer's BN scale / shift + activation are applied on load by the streaming 1x1 kernel
+                lzi = cfg.in_lazy
+                f = L.ConvFuse()
+                f.pro_scale, f.pro_shift, f.pro_act, f.pro_act_param = lzi.scale.data_ptr(), lzi.shift.data_ptr(), lzi.act, lzi.ap
+                if use_acc:
+                    f.bn_acc = acc_f.data_ptr()
+                else:
+                    f.bias, f.stats_partial = _ptr(b), _ptr(partial)
+                _timed_call(kname, (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv2d_fprop_fused", C.byref(desc), x.data_ptr(),
+                            cfg.state.w_fprop.data_ptr(), y.data_ptr(), C.byref(f), st)
+            elif image is not None:
                 f = L.ConvFuse()
                 f.x_image, f.x_image_planes = image.data_ptr(), planes
                 if use_acc:
@@ -1019,13 +1135,34 @@ class ConvBnAct(torch.autograd.Function):
                    cfg.eps, stats[2].data_ptr(), stats[3].data_ptr(), st)
         res_ld = 0
         if residual is not None:
-            residual, res_ld = as_nhwc(residual)
-        if cfg.out_split is not None and cfg.has_bn and residual is None:
+            residual, res_ld = as_nhwc(residual, lazy_ok=cfg.res_lazy is not None)
+        cfg.lazy_made = None
+        lazy_able = _LAZY and train_bn and use_acc and residual is None and Kp == K and cfg.act in _LAZY_ACTS and any(ctx.needs_input_grad)
+        if cfg.lazy_out and lazy_able and cfg.out_split is None and cfg.out is None:
+            # lazy result: statistics finalized (tiny launch), NO apply pass — the consumers read the raw y and transform on load
+            o8 = 0
+            L.call("cvhip_bn_finalize_acc", acc_f.data_ptr(), K, K, M, _ptr(gamma.detach() if gamma is not None else None),
+                   _ptr(beta.detach() if beta is not None else None), _ptr(running_mean if cfg.track else None),
+                   _ptr(running_var if cfg.track else None), cfg.momentum, cfg.eps, stats[0].data_ptr(), stats[1].data_ptr(),
+                   stats[2].data_ptr(), stats[3].data_ptr(), st)
+            z = y
+            cfg.lazy_made = (stats, 0, K)
+        elif cfg.out_split is not None and cfg.has_bn and residual is None:
             # two destinations: channels [0, k1) -> a fresh tensor, [k1, K) -> the caller's slice of a concat buffer
             k1, z2 = cfg.out_split
             z2, z2_ld = _check_out(z2, N, K - k1, P, Q)
-            z1 = empty_nhwc(N, k1, P, Q, dev)
+            lazy_h1 = cfg.lazy_half1 and lazy_able and k1 % 8 == 0
+            z1 = y[:, :k1] if lazy_h1 else empty_nhwc(N, k1, P, Q, dev)
             for off, kh, zz, zld in ((0, k1, z1, k1), (k1, K - k1, z2, z2_ld)):
+                if lazy_h1 and off == 0:
+                    # first sibling lazy: its statistics only (the second sibling's apply pass finalizes its own channel range)
+                    g = gamma.detach() if gamma is not None else None
+                    bt = beta.detach() if beta is not None else None
+                    L.call("cvhip_bn_finalize_acc", acc_f.data_ptr(), K, kh, M, _ptr(g), _ptr(bt), _ptr(running_mean if cfg.track else None),
+                           _ptr(running_var if cfg.track else None), cfg.momentum, cfg.eps, stats[0].data_ptr(), stats[1].data_ptr(),
+                           stats[2].data_ptr(), stats[3].data_ptr(), st)
+                    cfg.lazy_made = (stats, 0, k1)
+                    continue
                 if use_acc:
                     _bn_fwd_acc(y, Kp, zz, zld, M, kh, off, K, acc_f, gamma, beta, running_mean, running_var, cfg, stats, None, 0, False, st)
                 else:
@@ -1040,6 +1177,8 @@ class ConvBnAct(torch.autograd.Function):
             res_pre = bool(cfg.res_pre and residual is not None)
             if res_pre and (cfg.act not in (L.ACT_NONE, L.ACT_RELU, L.ACT_LEAKY) or Kp != K):
                 raise L.CvhipError("res_pre needs none / ReLU / LeakyReLU and an unpadded channel count")
+            if cfg.res_lazy is not None and not (use_acc and not res_pre):
+                raise L.CvhipError("lazy residual without the accumulator form of the BN+act pass (the wrapper should have materialised it)")
             if use_acc:
                 _bn_fwd_acc(y, Kp, z, z_ld, M, K, 0, K, acc_f, gamma, beta, running_mean, running_var, cfg, stats, residual, res_ld, res_pre, st)
             else:
@@ -1064,6 +1203,7 @@ class ConvBnAct(torch.autograd.Function):
         ctx.w_dgrad = cfg.state.w_dgrad if not depthwise else None
         ctx.acc_b = acc_b if use_acc else None   # this application's backward accumulator (sum du, sum du*xhat), zeroed
         ctx.in_prod = cfg.in_prod if (need_dx and not depthwise and c_orig == Cc) else None
+        ctx.in_lazy = cfg.in_lazy   # x (saved below) is then the producer's RAW output: backward transforms it on load too
         cfg.prod = ctx.prod = None
         if use_acc and _BN_TAIL and cfg.act in _TAIL_ACTS and not (cfg.res_pre and residual is not None) and any(ctx.needs_input_grad):  # (grad mode is off inside forward)
             cfg.prod = ctx.prod = ProdInfo(y, Kp, stats, cfg.act, cfg.act_param, acc_b, K, 0, K, (N, K, P, Q))
@@ -1103,6 +1243,11 @@ class ConvBnAct(torch.autograd.Function):
         arena = cfg.arena
         fused = pointwise and _bwd1x1_ok(ctx, cfg, x, need_dx, need_dw, need_db, ((dz, dz_ld),))
         acc_b = ctx.acc_b if ctx.train_bn else None
+        lzi = getattr(ctx, "in_lazy", None)
+        if lzi is not None and not (fused and acc_b is not None and K <= 128):
+            # (not expected: the wrapper admits a lazy input only when this layer's backward is the fused 1x1 kernel) the pass the forward saved
+            x = _materialize_tmp(x, x_ld, lzi)
+            lzi = None
         direct_bn = arena is not None and cfg.gg is not None and cfg.gbeta is not None
         if acc_b is not None:
             # (sum du, sum du*xhat) into the layer's accumulator — unless the kernel that wrote dz already folded them in
@@ -1124,7 +1269,7 @@ class ConvBnAct(torch.autograd.Function):
                 b_out = dbeta = torch.empty((K,), dtype=torch.float32, device=dev)
                 accum = 0
         if fused and acc_b is not None:
-            dx, dw = _bwd1x1(ctx, cfg, x, y, weight, ((dz, dz_ld),), K, stats, True, None, None, act, act_param, acc_b, g_out, b_out, accum)
+            dx, dw = _bwd1x1(ctx, cfg, x, y, weight, ((dz, dz_ld),), K, stats, True, None, None, act, act_param, acc_b, g_out, b_out, accum, xin=lzi)
             if direct_bn:
                 need_dg = need_dbeta = False
                 for i in cfg.idx_bn:
@@ -1214,12 +1359,58 @@ class ConvBnAct(torch.autograd.Function):
         return dx, dw, dbias, (dgamma if need_dg else None), (dbeta if need_dbeta else None), None, None, dres, None
 
 
+def _lazy_consumer_ok(x, K, R, S, has_bias, cfg, lz):
+    """True when THIS layer can read the lazy tensor x as it is: forward on the streaming 1x1 kernel (transform on load), backward
+    on the fused 1x1 kernel (which transforms the rows it stages for the weight gradient)"""
+    if not _LAZY or _DETERMINISTIC or not torch.is_grad_enabled() or not x.requires_grad:
+        return False
+    if cfg.groups != 1 or (R, S) != (1, 1) or tuple(cfg.stride) != (1, 1) or tuple(cfg.pad) != (0, 0) or has_bias:
+        return False
+    if not (cfg.has_bn and cfg.bn_training) or cfg.sync is not None or not _BN_ACC or K > 128 or K % 8:
+        return False
+    if lz.act not in _LAZY_ACTS or x.dim() != 4 or x.dtype != ACT_DTYPE:
+        return False
+    ld = nhwc_ld(x)
+    N, Cc, H, W = x.shape
+    if ld is None or Cc % 8 or ld % 8 or x.data_ptr() % 16 or lz.scale.numel() != Cc:
+        return False
+    desc = conv_desc(N, Cc, H, W, K, 1, 1, (1, 1), (0, 0), (1, 1), 1, ld, K)
+    lib = L.load()
+    return bool(lib.cvhip_conv1x1_stream_prologue_ok(C.byref(desc), 1)) and bool(lib.cvhip_conv1x1_bwd_fused_ok(C.byref(desc)))
+
+
+def _admit_lazy(x, residual, K, R, S, has_bias, cfg):
+    """Decide how this layer reads a lazy input / residual: on load (cfg.in_lazy / cfg.res_lazy) or through ops.materialize"""
+    cfg.in_lazy = cfg.res_lazy = None
+    lz = lazy_of(x)
+    if lz is not None:
+        if _lazy_consumer_ok(x, K, R, S, has_bias, cfg, lz):
+            cfg.in_lazy = lz
+        else:
+            x = materialize(x)
+    rl = lazy_of(residual)
+    if rl is not None:
+        ok = (_LAZY and cfg.has_bn and cfg.bn_training and cfg.sync is None and _BN_ACC and not _DETERMINISTIC and cfg.groups == 1 and not cfg.res_pre
+              and K % 8 == 0 and K <= _BN_ACC_MAX_C and rl.act == cfg.act and rl.ap == cfg.act_param and rl.act in (L.ACT_RELU, L.ACT_LEAKY, L.ACT_SILU)
+              and torch.is_grad_enabled() and rl.scale.numel() == K and nhwc_ld(residual) is not None and nhwc_ld(residual) % 8 == 0
+              and residual.data_ptr() % 16 == 0)
+        if ok:
+            cfg.res_lazy = rl
+        else:
+            residual = materialize(residual)
+    return x, residual
+
+
 def conv_bn_act(x, weight, bias, gamma, beta, running_mean, running_var, residual, cfg):
     cfg.in_prod = _take_prod(x)
     cfg.no_grad = not torch.is_grad_enabled()   # (inside Function.forward grad mode is always off: note it here)
+    x, residual = _admit_lazy(x, residual, weight.shape[0], weight.shape[2], weight.shape[3], bias is not None, cfg)
     z = ConvBnAct.apply(x, weight, bias, gamma, beta, running_mean, running_var, residual, cfg)
     if cfg.prod is not None and torch.is_tensor(z):
         z._hip_prod = cfg.prod
+    if cfg.lazy_made is not None and torch.is_tensor(z):
+        st4, off, kh = cfg.lazy_made
+        z._hip_lazy = LazyAct(st4[2][off:off + kh], st4[3][off:off + kh], cfg.act, cfg.act_param)
     return z
 
 
@@ -1268,9 +1459,12 @@ class ConvBnActPair(torch.autograd.Function):
                 sc, sh, mean, invstd = (stats[i].data_ptr() + 4 * off for i in (2, 3, 0, 1))
                 _timed_ew("bn_act_bwd_sums(colreduce_kernel<1>)", 4.0 * M * kh, "cvhip_bn_act_bwd_sums_acc", d.data_ptr(), d_ld, y.data_ptr() + 2 * off, Kp, M, kh,
                           sc, sh, mean, invstd, cfg.act, cfg.act_param, acc_b.data_ptr() + 8 * off, K, st)
-            if _bwd1x1_ok(ctx, cfg, x, ctx.needs_input_grad[0], True, False, segs):
-                dx, _ = _bwd1x1(ctx, cfg, x, y, weight, segs, ctx.k1, stats, True, None, None, cfg.act, cfg.act_param, acc_b, cfg.gg, cfg.gbeta, 1)
+            lzi = getattr(ctx, "in_lazy", None)
+            if _bwd1x1_ok(ctx, cfg, x, ctx.needs_input_grad[0], True, False, segs) and (lzi is None or K <= 128):
+                dx, _ = _bwd1x1(ctx, cfg, x, y, weight, segs, ctx.k1, stats, True, None, None, cfg.act, cfg.act_param, acc_b, cfg.gg, cfg.gbeta, 1, xin=lzi)
             else:
+                if lzi is not None:
+                    x = _materialize_tmp(x, x_ld, lzi)
                 dy = empty_nhwc(N, K, P, Q, dev)
                 for (d, d_ld), kh, off in halves:
                     sc, sh, mean, invstd = (stats[i].data_ptr() + 4 * off for i in (2, 3, 0, 1))
@@ -1281,6 +1475,8 @@ class ConvBnActPair(torch.autograd.Function):
             for i in cfg.idx_bn:
                 cfg.arena.mark_ready(i)
             return dx, None, None, None, None, None, None, None
+        if getattr(ctx, "in_lazy", None) is not None:
+            x = _materialize_tmp(x, x_ld, ctx.in_lazy)   # (a lazy input is only admitted with the accumulator form: not reached)
         if ctx.train_bn and cfg.sync is None and _bwd1x1_ok(ctx, cfg, x, ctx.needs_input_grad[0], True, False, segs):
             # fused form: per-half BN sums, then ONE kernel for BN/act backward + dgrad + wgrad of both siblings
             dgamma = torch.empty((K,), dtype=torch.float32, device=dev)
@@ -1365,7 +1561,11 @@ def conv_bn_act_pair(x, operands, cfg, out2=None):
     cfg.out_split = (k1, out2) if out2 is not None else None
     cfg.arena, cfg.gw, cfg.gg, cfg.gbeta, cfg.idx_w, cfg.idx_bn = arena, gw, gg, gb, idx_w, idx_bn
     cfg.in_prod = _take_prod(x)
+    x, _ = _admit_lazy(x, None, wf.shape[0], 1, 1, False, cfg)
     z1, z2 = ConvBnActPair.apply(x, wf, gf, bf, rmf, rvf, cfg, k1)
+    if cfg.lazy_made is not None:   # the first sibling's result is lazy: z1 is the channel slice [0, k1) of the pair's raw output
+        st4, off, kh = cfg.lazy_made
+        z1._hip_lazy = LazyAct(st4[2][off:off + kh], st4[3][off:off + kh], cfg.act, cfg.act_param)
     if cfg.prod is not None:
         kt = cfg.prod.kh
         cfg.prod.halves = (cfg.prod.half(0, k1), cfg.prod.half(k1, kt - k1))

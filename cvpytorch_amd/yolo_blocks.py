@@ -23,7 +23,7 @@ _SPPF_CHAIN = os.environ.get("CVHIP_SPPF_CHAIN", "1") != "0"   # 0: separate poo
 _GRAD_LINK = os.environ.get("CVHIP_GRAD_LINK", "1") != "0"
 
 
-def sibling_pair_forward(m1, m2, x, owner, out2=None, out=None):
+def sibling_pair_forward(m1, m2, x, owner, out2=None, out=None, lazy1=False):
     """Run two 1x1 Conv-BN-act modules that share the input `x` as ONE fused convolution (ops.ConvBnActPair) when their
     tensors are adjacent in the flat training arenas; None -> the caller runs them one by one (eval mode, no arena, SyncBN,
     odd channel counts, CVHIP_PAIR=0)."""
@@ -51,6 +51,7 @@ def sibling_pair_forward(m1, m2, x, owner, out2=None, out=None):
     bn_tick(bn1)
     bn_tick(bn2)
     cfg.out = out   # both halves side by side into one slice of a concat buffer (or None)
+    cfg.lazy_half1 = bool(lazy1)   # the first sibling's consumers are Hip conv modules: its result may stay raw (ops.LazyAct)
     cfg.acc_owner, cfg.acc_attr = bn1, "_hip_acc_pair"   # the pair's statistic accumulators (K1 + K2 channels) hang on the first layer
     return ops.conv_bn_act_pair(x, operands, cfg, out2)
 
@@ -131,11 +132,14 @@ class CSPLayer(nn.Module):
         if _CAT_INPLACE and x.is_cuda and len(self.m) > 0 and not self.m[-1].depthwise and hid % 8 == 0:
             buf = ops.empty_nhwc(N, 2 * hid, H, W, x.device)
         out2 = buf[:, hid:] if buf is not None else None
-        pair = sibling_pair_forward(self.conv1, self.conv2, x, self, out2) if self.training else None
+        # conv1's result only feeds the first bottleneck (its 1x1 conv1 and, with a shortcut, conv2's residual operand): both read a
+        # lazy activation on load, so the branch may stay raw (ops.LazyAct)
+        lazy1 = len(self.m) > 0 and not self.m[0].depthwise and isinstance(self.m[0], DarknetBottleneck)
+        pair = sibling_pair_forward(self.conv1, self.conv2, x, self, out2, lazy1=lazy1) if self.training else None
         if pair is not None:
             x_1, x_2 = pair
         else:
-            x_1 = self.conv1(x)
+            x_1 = self.conv1(x, lazy=lazy1)
             x_2 = self.conv2(x, out=out2)
         for i, blk in enumerate(self.m):
             x_1 = blk(x_1, out=buf[:, :hid]) if (buf is not None and i == len(self.m) - 1) else blk(x_1)

@@ -64,7 +64,11 @@ class YOLOv5CSPDarknet(nn.Module):
         x = self.stem(x)
         output = []
         for i in range(1, 5):
-            x = getattr(self, "stage%d" % i)(x)
+            stage = getattr(self, "stage%d" % i)
+            # the stride-2 conv's result only feeds the CSP layer's two 1x1 siblings: it may stay lazy (ops.LazyAct)
+            x = stage[0](x, lazy=isinstance(stage[1], CSPLayer))
+            for m in list(stage)[1:]:
+                x = m(x)
             if i in self.out_stages:
                 if i < 4:   # feeds the next stage AND the neck: explicit fan-out (ops.Fanout sums the two gradients itself)
                     x, keep = ops.fanout(x, 2)

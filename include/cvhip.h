@@ -698,7 +698,23 @@ typedef struct cvhip_conv_fuse {
    * runs (cvhip_conv_stem_blocks(d) > 0), else CVHIP_ERR_UNSUPPORTED; no prologue, no residual. */
   const float* x_image;
   int32_t x_image_planes;
+  /* (round 5) LAZY ACTIVATIONS in training: with pro_scale / pro_shift set and the streaming 1x1 kernel running the problem
+   * (cvhip_conv1x1_stream_prologue_ok), the prologue covers the input-channel range [pro_lo, pro_hi) only (0, 0 = every channel):
+   * channels outside it — slices of a concatenation that were materialised — are read as they are. pro_scale / pro_shift are indexed
+   * by the ABSOLUTE input channel (only [pro_lo, pro_hi) is dereferenced). Combines with stats_partial / bn_acc (the consumer's own
+   * training-mode BatchNorm sums); no z_out, residual or epilogue in that form. */
+  int32_t pro_lo;
+  int32_t pro_hi;
 } cvhip_conv_fuse;
+/* a lazy input operand of a backward kernel: x' = act(scale[c] * x + shift[c]) for channels [c_lo, c_hi) (c_hi 0 = all), as above */
+typedef struct cvhip_lazy_in {
+  const float* scale;
+  const float* shift;
+  int32_t act;
+  float act_param;
+  int32_t c_lo;
+  int32_t c_hi;
+} cvhip_lazy_in;
 #endif
 int cvhip_conv2d_fprop_fused(const cvhip_conv_desc* d, const void* x, const void* w, void* y, const cvhip_conv_fuse* f, void* stream);
 /* weight gradient of an image stem straight from the fp32 NCHW image (see cvhip_conv_fuse.x_image): dw = [K][R*S][8] fp32, ACCUMULATED
@@ -706,6 +722,30 @@ int cvhip_conv2d_fprop_fused(const cvhip_conv_desc* d, const void* x, const void
 int cvhip_conv2d_wgrad_image(const cvhip_conv_desc* d, const float* x_nchw, int32_t planes, const void* dy, float* dw, void* stream);
 /* 1 when cvhip_conv2d_fprop_fused accepts a prologue (and, with_z_out != 0, the z_out side output) for this descriptor */
 int cvhip_conv2d_fprop_prologue_ok(const cvhip_conv_desc* d, int with_z_out);
+/* (round 5) 1 when the STREAMING 1x1 kernel runs this fprop descriptor (with_stats != 0: with training-mode BatchNorm sums) and takes
+ * a prologue on its input: the lazy-activation form of `ConvModule.forward` (src/models/bricks/conv_module.py:201-214) in training —
+ * the producing layer's BN-apply + activation pass is not run, its consumers read the raw convolution output */
+int cvhip_conv1x1_stream_prologue_ok(const cvhip_conv_desc* d, int with_stats);
+/* statistics of a training-mode BatchNorm from its fp64 accumulator (what block 0 of cvhip_bn_act_fwd_acc does in its prologue), for
+ * a layer whose apply pass is deferred into its consumers: mean | invstd | scale | shift stored, running statistics updated */
+int cvhip_bn_finalize_acc(const double* acc, int32_t acc_ld, int32_t C, int64_t count, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
+                          float* shift, void* stream);
+/* cvhip_bn_act_fwd_acc whose (post-activation) residual is itself LAZY: z = act(bn(y)) + act(res_scale * residual_raw + res_shift),
+ * the residual's activation being the layer's own (DarknetBottleneck shortcut whose input is a lazy CSP branch:
+ * src/models/modules/yolo_modules.py:102). ReLU / LeakyReLU / SiLU. */
+int cvhip_bn_act_fwd_acc_lazyres(const void* y, int32_t ld_y, void* z, int32_t ld_z, int64_t M, int32_t C, const double* acc, int32_t acc_ld,
+                                 int64_t count, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                 float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int32_t act,
+                                 float act_param, const void* residual_raw, int32_t ld_res, const float* res_scale, const float* res_shift,
+                                 void* stream);
+/* cvhip_conv1x1_bwd_fused_acc whose input operand x is LAZY (raw output of the producing layer, `xin` describes the transform the
+ * weight gradient needs); K <= 128, no tail */
+int cvhip_conv1x1_bwd_fused_lazy(const cvhip_conv_desc* d, const void* dz0, int32_t dz0_ld, const void* dz1, int32_t dz1_ld, int32_t k_split,
+                                 const void* y, const void* x_raw, const void* w_dgrad, const float* scale, const float* shift, const float* mean,
+                                 const float* invstd, const double* acc, int32_t acc_ld, float* dgamma_out, float* dbeta_out, int32_t accumulate,
+                                 int32_t act, float act_param, const void* addend, int32_t addend_ld, void* dx, int32_t dx_ld, float* dw,
+                                 const cvhip_lazy_in* xin, void* stream);
 /* Plan query of the patch-resident kernel (conv_patch.hip; pure host arithmetic, exercised by the CPU test-suite against a numpy
  * interpreter of the kernel's addressing): per class CVHIP_PATCH_CLASS_INTS int32
  *   {TR, TS, dh0, dh_step, dw0, dw_step, out_oh, out_ow, OHi, OWi, lo_h, lo_w, TH, TW, PH, PW, PWh, PWc, vho, tiles_w, tile_begin,
