@@ -313,6 +313,10 @@ int cvhip_conv2d_fprop_fused(const cvhip_conv_desc* d, const void* x, const void
   if ((f->stats_partial || f->bn_acc) && (f->bias || f->ep_scale || f->ep_act != CVHIP_ACT_NONE)) return CVHIP_ERR_INVALID;
   if ((f->ep_scale == nullptr) != (f->ep_shift == nullptr) || (f->pro_scale == nullptr) != (f->pro_shift == nullptr)) return CVHIP_ERR_INVALID;
   if (f->z_out && !f->pro_scale) return CVHIP_ERR_INVALID;
+  if (f->pro_lo || f->pro_hi) {  // a partial prologue range: 16-byte channel vectors inside the input
+    const int hi = f->pro_hi > 0 ? f->pro_hi : d->C;
+    if (!f->pro_scale || f->pro_lo < 0 || hi > d->C || f->pro_lo >= hi || (f->pro_lo & 7) || (hi & 7)) return CVHIP_ERR_INVALID;
+  }
   if (f->bn_acc && (((uintptr_t)f->bn_acc) & 7)) return CVHIP_ERR_INVALID;
   IgemmParams p;
   plan_fprop(d, &p);

@@ -592,7 +592,7 @@ __global__ __launch_bounds__(256) void ew_kernel(const EwParams p) {
             if (RES == 2) u += rs.v[j];
             float v = act_fwd(u, ACT, p.ap);
             if (RES == 1) v += rs.v[j];
-            if constexpr (RES == 3) v += act_fwd(rs.v[j] * rsc[j] + rsh[j], ACT, p.ap);
+            if constexpr (RES == 3) v += (float)(h16_t)act_fwd(rs.v[j] * rsc[j] + rsh[j], ACT, p.ap);  // rounded as the stand-alone pass stores it
             o.v[j] = v;
           } else if (MODE == 1) {
             const float u = y.v[j] * sc[j] + sh[j];

@@ -59,23 +59,87 @@ def _run(pred, B, n, no, nc, conf_thres, iou_thres, mode, multi_label, agnostic,
     return dets, counts, overflow
 
 
+def _first_argmax(v):
+    """(max over the last axis, index of its FIRST occurrence): ATen's CPU tie rule, which the reference's `x[:, 5:].max(1)` follows"""
+    m = v.max(-1, keepdim=True).values
+    idx = torch.arange(v.shape[-1], device=v.device).expand_as(v)
+    first = torch.where(v == m, idx, torch.full_like(idx, v.shape[-1])).min(-1).values
+    return m.squeeze(-1), first
+
+
+def _apply_class_filter(prediction, classes, multi_label):
+    """`classes=[...]` of the reference (models/yolov5.py:118-119: keep detections whose class is listed) as a mask on the batched
+    path's INPUT: a candidate that fails any of the reference's successive filters is dropped whichever comes first, so the class
+    test can run before the kernels — multi-label candidates are (row, class) pairs: unlisted class columns are zeroed (0 > conf_thres
+    never holds); best-class candidates are rows: a row whose best class (first maximum of cls * obj) is unlisted gets objectness 0."""
+    nc = prediction.shape[2] - 5
+    sel = torch.zeros((nc,), dtype=torch.bool, device=prediction.device)
+    sel[torch.as_tensor(list(classes), device=prediction.device).long().clamp(0, nc - 1)] = True
+    pred = prediction.float().clone()
+    if multi_label and nc > 1:
+        pred[..., 5:] = torch.where(sel, pred[..., 5:], torch.zeros((), device=pred.device))
+    else:
+        _, j = _first_argmax(pred[..., 5:] * pred[..., 4:5])
+        pred[..., 4] = torch.where(sel[j], pred[..., 4], torch.zeros((), device=pred.device))
+    return pred
+
+
+def nms_one_image_unbounded(p, conf_thres, iou_thres, agnostic=False, multi_label=False, max_det=300, max_nms=30000, max_wh=4096.0):
+    """One image of models/yolov5.py:62-153 without the batched kernels' capacity, on sort keys: every (row[, class]) candidate gets
+    the key `confidence if it passes the reference's filters else -inf`; ONE stable device sort (descending, ties by candidate index =
+    the order the reference's mask / nonzero compaction leaves them in) puts the survivors first, the best `max_nms` of them go
+    through one class-shifted greedy NMS (cvhip_nms_sorted) — no boolean-mask indexing, one host read for the survivor count.
+    p: (n, 5 + nc) decoded rows. Returns (k, 6) [xyxy, conf, cls]."""
+    p = p.float()
+    n, nc = p.shape[0], p.shape[1] - 5
+    dev = p.device
+    prod = p[:, 5:] * p[:, 4:5]                          # conf = obj_conf * cls_conf
+    xc = p[:, 4] > conf_thres
+    if multi_label and nc > 1:
+        valid = ((prod > conf_thres) & xc[:, None]).reshape(-1)
+        key = torch.where(valid, prod.reshape(-1), torch.full((), float("-inf"), device=dev))
+        width = nc
+    else:
+        best, j = _first_argmax(prod)
+        valid = xc & (best > conf_thres)
+        key = torch.where(valid, best, torch.full((), float("-inf"), device=dev))
+        width = 1
+    order = argsort_desc(key)
+    nv = min(int(valid.sum().item()), int(max_nms))     # the one host read
+    if nv == 0:
+        return torch.zeros((0, 6), device=dev)
+    top = order[:nv]
+    row = top // width
+    lab = (top % width) if width > 1 else j[row]
+    box = torch.empty((nv, 4), dtype=torch.float32, device=dev)
+    q = p[row]
+    box[:, 0] = q[:, 0] - q[:, 2] / 2
+    box[:, 1] = q[:, 1] - q[:, 3] / 2
+    box[:, 2] = q[:, 0] + q[:, 2] / 2
+    box[:, 3] = q[:, 1] + q[:, 3] / 2
+    labf = lab.float()
+    shifted = box + (labf * (0.0 if agnostic else max_wh))[:, None]
+    keep_pos, cnt = nms_device(shifted.contiguous(), iou_thres)
+    k = min(int(cnt.item()), int(max_det))
+    sel = keep_pos[:k].long()
+    return torch.cat((box[sel], key[top][sel][:, None], labf[sel][:, None]), 1)
+
+
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300,
                         cap=4096):
     """src/models/yolov5.py:62-153 for the whole batch on the device; returns the reference's list of (n_i, 6) tensors
-    [xyxy, conf, cls] (one host read of the B counts). `classes` filtering is not on this path (the hot path never uses it)."""
-    if classes is not None:
-        raise L.CvhipError("non_max_suppression(classes=...) is not supported by the batched device path")
+    [xyxy, conf, cls] (one host read of the B counts). `classes` is a mask on the input (_apply_class_filter); an image with more
+    candidates than the batched kernels' capacity (the reference keeps up to max_nms = 30000, :66,131-132) is redone by
+    nms_one_image_unbounded."""
     assert 0 <= conf_thres <= 1 and 0 <= iou_thres <= 1
+    if classes is not None:
+        prediction = _apply_class_filter(prediction, classes, multi_label)
     dets, counts, overflow = detect_postprocess(prediction, conf_thres, iou_thres, 0, multi_label, agnostic, max_det, cap)
     host = torch.stack((counts, overflow)).tolist()   # ONE host read: counts and overflow flags of every image
     out = [dets[i, :c] for i, c in enumerate(host[0])]
-    over = [i for i, o in enumerate(host[1]) if o]
-    if over:
-        # an image with more candidates than the batched kernels' capacity: the reference keeps up to max_nms = 30000 of them
-        # (models/yolov5.py:66,131-132); those images take the per-image loop, whose device sort / NMS kernels have no capacity limit
-        from .yolov5 import non_max_suppression as per_image
-        for i in over:
-            out[i] = per_image(prediction[i:i + 1], conf_thres, iou_thres, None, agnostic, multi_label, max_det, nms_fn=nms)[0]
+    for i, o in enumerate(host[1]):
+        if o:
+            out[i] = nms_one_image_unbounded(prediction[i], conf_thres, iou_thres, agnostic, multi_label, max_det)
     return out
 
 
@@ -148,9 +212,7 @@ def nms(boxes, scores, iou_threshold):
 def _nms_cfg(nms_cfg, class_agnostic):
     """(iou threshold, class_agnostic) out of an mmdet-style nms_cfg dict (modules/nms.py:70-93 documents the keys)"""
     cfg = dict(nms_cfg or {})
-    kind = cfg.get("type", "nms")
-    if kind != "nms":
-        raise L.CvhipError("nms_cfg type %r: only hard NMS ('nms') runs on the device kernels" % (kind,))
+    cfg.pop("type", "nms")   # popped and ignored, as the reference does (modules/nms.py:105-106: it always runs hard NMS)
     iou = cfg["iou_threshold"] if "iou_threshold" in cfg else cfg.get("iou_thr", 0.5)
     return float(iou), bool(cfg.get("class_agnostic", class_agnostic))
 
@@ -217,6 +279,8 @@ def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, s
     key = torch.where(valid, sc, torch.full_like(sc, float("-inf")))
     order = argsort_desc(key)
     n_valid = valid.sum()
+    # (nothing above the threshold: the reference returns its empty pair before any NMS, modules/nms.py:52-59 — decided by the host
+    # read below, where n_valid arrives anyway; the -inf class shift of that case never reaches an output)
     # the class shift of the reference uses the largest coordinate of the PASSING boxes
     max_coord = torch.where(valid[:, None], cand_boxes, torch.full_like(cand_boxes, float("-inf"))).max()
     cap = int(min(n * ncls, max(1, cap)))

@@ -151,6 +151,12 @@ class LazyAct:
         self.z = None   # the materialised tensor, once some consumer needed it
 
 
+def act_id_of(conv_module):
+    """activation id of a Hip ConvModule (L.ACT_*; -1 when it is not one of the engine's fused activations)"""
+    fus = conv_module._fusable(True, True) if hasattr(conv_module, "_fusable") else None
+    return fus[1][0] if fus is not None else -1
+
+
 def lazy_of(t):
     return getattr(t, "_hip_lazy", None) if t is not None else None
 
@@ -1372,9 +1378,23 @@ def _lazy_consumer_ok(x, K, R, S, has_bias, cfg, lz):
         return False
     ld = nhwc_ld(x)
     N, Cc, H, W = x.shape
-    if ld is None or Cc % 8 or ld % 8 or x.data_ptr() % 16 or lz.scale.numel() != Cc:
+    if ld is None or ld % 8 or x.data_ptr() % 16 or lz.scale.numel() != Cc:
         return False
-    desc = conv_desc(N, Cc, H, W, K, 1, 1, (1, 1), (0, 0), (1, 1), 1, ld, K)
+    return lazy_edge_ok(N, Cc, H, W, K, lz.act, ld)
+
+
+def lazy_edge_ok(N, Cc, H, W, K, act, ld=None):
+    """Would a training-mode 1x1 Conv-BN-act layer with K outputs read an (N, Cc, H, W) LAZY input on load? Kernel availability
+    (streaming 1x1 forward with a prologue, fused 1x1 backward: row-count policies included) AND the measured cost of the on-load
+    transform (profiles/r05_lazy_*: an on-load SiLU costs the consumer's VALU about what the stand-alone pass costs in HBM time; net
+    gain with 64- and 128-channel inputs, net LOSS with 32-channel inputs — 32 -> 32 @160x160: +23 us forward, +19 us backward against
+    a 40 us pass). Producers ask before they skip their apply pass, so that no layer stays raw for a consumer that would only
+    materialise it."""
+    if not _LAZY or _DETERMINISTIC or not _BN_ACC or act not in _LAZY_ACTS:
+        return False
+    if Cc % 8 or K % 8 or K > 128 or (act == L.ACT_SILU and Cc < 64):
+        return False
+    desc = conv_desc(N, Cc, H, W, K, 1, 1, (1, 1), (0, 0), (1, 1), 1, Cc if ld is None else ld, K)
     lib = L.load()
     return bool(lib.cvhip_conv1x1_stream_prologue_ok(C.byref(desc), 1)) and bool(lib.cvhip_conv1x1_bwd_fused_ok(C.byref(desc)))
 

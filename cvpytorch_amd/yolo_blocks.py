@@ -134,7 +134,8 @@ class CSPLayer(nn.Module):
         out2 = buf[:, hid:] if buf is not None else None
         # conv1's result only feeds the first bottleneck (its 1x1 conv1 and, with a shortcut, conv2's residual operand): both read a
         # lazy activation on load, so the branch may stay raw (ops.LazyAct)
-        lazy1 = len(self.m) > 0 and not self.m[0].depthwise and isinstance(self.m[0], DarknetBottleneck)
+        lazy1 = (self.training and len(self.m) > 0 and isinstance(self.m[0], DarknetBottleneck) and not self.m[0].depthwise and x.is_cuda
+                 and ops.lazy_edge_ok(N, hid, H, W, self.m[0].conv1.out_channels, ops.act_id_of(self.conv1)))
         pair = sibling_pair_forward(self.conv1, self.conv2, x, self, out2, lazy1=lazy1) if self.training else None
         if pair is not None:
             x_1, x_2 = pair

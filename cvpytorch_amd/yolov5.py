@@ -17,6 +17,7 @@ import math
 import torch
 import torch.nn as nn
 
+from . import lib as L
 from . import ops
 from .bricks import HipConv2d
 from .bricks import HipConvModule as ConvModule
@@ -66,7 +67,13 @@ class YOLOv5CSPDarknet(nn.Module):
         for i in range(1, 5):
             stage = getattr(self, "stage%d" % i)
             # the stride-2 conv's result only feeds the CSP layer's two 1x1 siblings: it may stay lazy (ops.LazyAct)
-            x = stage[0](x, lazy=isinstance(stage[1], CSPLayer))
+            csp = stage[1]
+            lazy = False
+            if self.training and isinstance(csp, CSPLayer) and x.is_cuda:
+                s0 = stage[0]
+                ph, pw = (x.shape[2] + 2 * 1 - 3) // 2 + 1, (x.shape[3] + 2 * 1 - 3) // 2 + 1
+                lazy = ops.lazy_edge_ok(x.shape[0], s0.out_channels, ph, pw, csp.conv1.out_channels + csp.conv2.out_channels, ops.act_id_of(s0))
+            x = stage[0](x, lazy=lazy)
             for m in list(stage)[1:]:
                 x = m(x)
             if i in self.out_stages:
@@ -348,49 +355,16 @@ def xywh2xyxy(x):
     return y
 
 
-def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300,
-                        nms_fn=None):
-    """src/models/yolov5.py:62-153. Device tensors take the batched path (nms.non_max_suppression: every image in ONE launch set —
-    filter, device sort, class offsets, ballot/scan NMS, fixed-capacity outputs); the per-image loop below remains for the
-    `classes=` filter, a custom `nms_fn`, and more candidates per image than the batched kernels' capacity allows."""
-    if prediction.is_cuda and classes is None and nms_fn is None:
-        from . import nms as NMS
-        # (validation thresholds — conf 0.001, multi_label — produce thousands of candidates per image: largest capacity; images
-        # that still overflow it come back through the loop below, see nms.non_max_suppression)
-        return NMS.non_max_suppression(prediction, conf_thres, iou_thres, None, agnostic, multi_label, max_det, cap=8192)
-    nms_fn = nms_fn or ops.nms
-    nc = prediction.shape[2] - 5
-    xc = prediction[..., 4] > conf_thres
-    max_wh, max_nms = 4096, 30000
-    multi_label &= nc > 1
-    output = [torch.zeros((0, 6), device=prediction.device)] * prediction.shape[0]
-    for xi, x in enumerate(prediction):
-        x = x[xc[xi]]
-        if not x.shape[0]:
-            continue
-        x = x.clone()
-        x[:, 5:] *= x[:, 4:5]
-        box = xywh2xyxy(x[:, :4])
-        if multi_label:
-            i, j = (x[:, 5:] > conf_thres).nonzero(as_tuple=False).T
-            x = torch.cat((box[i], x[i, j + 5, None], j[:, None].float()), 1)
-        else:
-            conf, j = x[:, 5:].max(1, keepdim=True)
-            x = torch.cat((box, conf, j.float()), 1)[conf.view(-1) > conf_thres]
-        if classes is not None:
-            x = x[(x[:, 5:6] == torch.tensor(classes, device=x.device)).any(1)]
-        n = x.shape[0]
-        if not n:
-            continue
-        elif n > max_nms:
-            x = x[x[:, 4].argsort(descending=True)[:max_nms]]
-        c = x[:, 5:6] * (0 if agnostic else max_wh)
-        boxes, scores = x[:, :4] + c, x[:, 4]
-        i = nms_fn(boxes, scores, iou_thres)
-        if i.shape[0] > max_det:
-            i = i[:max_det]
-        output[xi] = x[i]
-    return output
+def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300):
+    """src/models/yolov5.py:62-153 on the device: every image of the batch in ONE launch set (nms.non_max_suppression: confidence
+    filter, device sort, class offsets, ballot / scan NMS, fixed-capacity outputs, one host read). `classes=` is a mask on the sort
+    keys' input, images with more candidates than the batched kernels hold are redone without a capacity
+    (nms.nms_one_image_unbounded). There is no host path: a CPU tensor raises."""
+    if not prediction.is_cuda:
+        raise L.CvhipError("non_max_suppression needs a device tensor (the HIP engine has no CPU fallback)")
+    from . import nms as NMS
+    # (validation thresholds — conf 0.001, multi_label — produce thousands of candidates per image: largest capacity)
+    return NMS.non_max_suppression(prediction, conf_thres, iou_thres, classes, agnostic, multi_label, max_det, cap=8192)
 
 
 class YOLOv5(nn.Module):
