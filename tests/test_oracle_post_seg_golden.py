@@ -128,6 +128,12 @@ def test_seg_resnet_wrapper_equals_reference(name, subtype, stages):
     assert sig == [str(s) for s in z["state_sig"].tolist()]           # same state_dict keys and shapes as the reference's module
     assert list(z["out_channels"]) == [{1: 256, 2: 512, 3: 1024, 4: 2048}[s] for s in stages]
     x = T(z["x"]).clone().requires_grad_(True)
+    m.eval()
+    with torch.no_grad():
+        ev = m(x.detach())
+    for i, o in enumerate(ev if isinstance(ev, (list, tuple)) else [ev]):
+        close(o, z["eval_out%d" % i])
+    m.train()
     outs = m(x)
     outs = outs if isinstance(outs, (list, tuple)) else [outs]
     loss = sum((o.float() ** 2).mean() for o in outs)
@@ -153,6 +159,10 @@ def test_encoder_decoder_equals_reference():
             mod.p = 0.0
     x = T(z["x"]).clone().requires_grad_(True)
     tgt = T(z["target"])
+    m.eval()
+    with torch.no_grad():
+        close(m.head(m.backbone(x.detach())), z["eval_logits"])
+    m.train()
     losses = m(x, tgt, mode="train")
     keys = [str(k) for k in z["loss_keys"].tolist()]
     assert sorted(losses.keys()) == keys
