@@ -77,6 +77,7 @@ class FlatTrainState:
             raise L.CvhipError("FlatTrainState: optimizer must be 'sgd' or 'adamw'")
         self.betas, self.adam_eps = (float(betas[0]), float(betas[1])), float(eps)
         groups = build_param_groups(model, lr, backbone_lr, weight_decay)
+        self._groups = groups   # one group per parameter, in the order the reference's optimizer enumerates them (optimizer_state_dict)
         hyper = {id(g["params"][0]): (g["lr"], g["weight_decay"]) for g in groups}
         # sibling layers that train as one convolution (ops.ConvBnActPair) need their tensors back to back: reorder so that the
         # second layer's weight / BN weight / BN bias / running statistics directly follow the first layer's
@@ -262,6 +263,8 @@ class FlatTrainState:
                     if c is not t:
                         t.copy_(c)
             self.comm.wait()
+            ops._stats_epoch[0] += 1    # running statistics were rewritten through raw pointers: cached eval-mode scale / shift are stale
+            ops.bump_weights_epoch()
             if self.ema_param is not None:
                 self.ema_param.copy_(self.param)
                 self.ema_buf.copy_(self.buf)
@@ -332,6 +335,81 @@ class FlatTrainState:
             torch.cuda.current_stream().wait_stream(self._stream)
 
     # ---- optimizer ------------------------------------------------------------------------------------------
+    # ---- checkpoint of the optimizer (src/utils/checkpoints.py:39-57 stores / reloads optimizer.state_dict()) ------------------------
+    def optimizer_state_dict(self):
+        """The state of the fused optimizer in the layout of `torch.optim.SGD(...)` / `torch.optim.AdamW(...)`.state_dict() built over
+        the reference's parameter groups (one group per parameter, src/optimizers/__init__.py:36-73): {"state": {i: {"momentum_buffer"}
+        | {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...]}. Tensors are copies in the parameters' logical (OIHW) layout, so
+        the dict loads into a stock torch optimizer built the same way, and back (load_optimizer_state_dict).
+        NOTE: the fused kernels update EVERY arena segment each step — a parameter that received no gradient in a step
+        still sees its (decoupled) weight decay and moment decay, where torch.optim skips parameters whose .grad is None; all
+        parameters of the assembled models receive gradients every step, so the trajectories coincide."""
+        state, pgs = {}, []
+        for gi, g in enumerate(self._groups):
+            p = g["params"][0]
+            i = self.index[id(p)]
+            off = self.offsets[i]
+            if self.optimizer == "adamw":
+                state[gi] = {"step": self.adam_step.detach().clone().reshape(()),
+                             "exp_avg": _dense_view(self.mom, off, p).detach().clone().contiguous(),
+                             "exp_avg_sq": _dense_view(self.mom2, off, p).detach().clone().contiguous()}
+                pgs.append({"lr": float(self.seg_lr[i]), "betas": self.betas, "eps": self.adam_eps, "weight_decay": float(self.seg_wd[i]),
+                            "amsgrad": False, "params": [gi]})
+            else:
+                if self.steps > 0:   # (torch creates the buffer at the first step)
+                    state[gi] = {"momentum_buffer": _dense_view(self.mom, off, p).detach().clone().contiguous()}
+                pgs.append({"lr": float(self.seg_lr[i]), "momentum": self.momentum, "dampening": 0, "weight_decay": float(self.seg_wd[i]),
+                            "nesterov": self.nesterov, "params": [gi]})
+        return {"state": state, "param_groups": pgs, "cvhip": {"steps": self.steps, "ema_updates": self.ema_updates, "lr_scale": self.lr_scale}}
+
+    def load_optimizer_state_dict(self, sd):
+        """Inverse of optimizer_state_dict (also accepts the state_dict of a stock torch.optim.SGD / AdamW over the same one-parameter
+        groups): moments, AdamW step count, per-group lr / weight decay. At world > 1 the arenas are re-broadcast from rank 0, as after
+        construction."""
+        groups = sd["param_groups"]
+        if len(groups) != len(self._groups):
+            raise L.CvhipError("optimizer state has %d parameter groups, the model has %d" % (len(groups), len(self._groups)))
+        ops.zero_fill(self.mom)
+        if self.mom2 is not None:
+            ops.zero_fill(self.mom2)
+        step = None
+        lrs, wds = self.seg_lr.tolist(), self.seg_wd.tolist()
+        for gi, (g, mine) in enumerate(zip(groups, self._groups)):
+            if len(g["params"]) != 1:
+                raise L.CvhipError("optimizer state: one parameter per group expected (src/optimizers/__init__.py:36-56)")
+            p = mine["params"][0]
+            i = self.index[id(p)]
+            off = self.offsets[i]
+            lrs[i], wds[i] = float(g["lr"]), float(g.get("weight_decay", wds[i]))
+            ent = sd["state"].get(g["params"][0], sd["state"].get(gi))
+            if not ent:
+                continue
+            if self.optimizer == "adamw":
+                for key, arena in (("exp_avg", self.mom), ("exp_avg_sq", self.mom2)):
+                    t = ent[key]
+                    if tuple(t.shape) != tuple(p.shape):
+                        raise L.CvhipError("optimizer state %s of group %d has shape %s, the parameter %s" % (key, gi, tuple(t.shape), tuple(p.shape)))
+                    _dense_view(arena, off, p).copy_(t.to(arena.device, torch.float32))
+                step = float(ent["step"]) if step is None else max(step, float(ent["step"]))
+            elif "momentum_buffer" in ent and ent["momentum_buffer"] is not None:
+                t = ent["momentum_buffer"]
+                if tuple(t.shape) != tuple(p.shape):
+                    raise L.CvhipError("momentum buffer of group %d has shape %s, the parameter %s" % (gi, tuple(t.shape), tuple(p.shape)))
+                _dense_view(self.mom, off, p).copy_(t.to(self.mom.device, torch.float32))
+        self.seg_lr.copy_(torch.tensor(lrs, dtype=torch.float32))
+        self.seg_wd.copy_(torch.tensor(wds, dtype=torch.float32))
+        self.base_lr = list(lrs)
+        if step is not None:
+            self.adam_step.fill_(step)
+        extra = sd.get("cvhip", {})
+        self.steps = int(extra.get("steps", max(self.steps, 1 if sd["state"] else 0)))
+        self.ema_updates = int(extra.get("ema_updates", self.ema_updates))
+        self.lr_scale = float(extra.get("lr_scale", self.lr_scale))
+        if self.world > 1:
+            for t in (self.mom,) + ((self.mom2, self.adam_step) if self.mom2 is not None else ()):
+                self.comm.broadcast_(t, 0)
+            self.comm.wait()
+
     def set_lr_scale(self, scale):
         """lr = base_lr * scale for every parameter (warm-up / scheduler hook: lr_schedulers/__init__.py); takes
         effect at the next step through device memory, so it also works under hipGraph replay."""
@@ -354,9 +432,17 @@ class FlatTrainState:
         seed = self._seeds.get(key)
         if seed is None:
             if torch.cuda.is_current_stream_capturing():
-                return loss.backward()
+                ops._OWNED_BACKWARD[0] = True
+                try:
+                    return loss.backward()
+                finally:
+                    ops._OWNED_BACKWARD[0] = False
             seed = self._seeds[key] = torch.ones_like(loss)
-        loss.backward(gradient=seed)
+        ops._OWNED_BACKWARD[0] = True   # the engine drives this backward pass itself: its ops may work in place on gradients (ops.SppfChain)
+        try:
+            loss.backward(gradient=seed)
+        finally:
+            ops._OWNED_BACKWARD[0] = False
 
     def scale_loss(self, loss):
         """scaler.scale(loss): the backward pass is seeded with the CURRENT loss scale, read from device memory (so a replayed

@@ -21,6 +21,7 @@ subclass the torch layers they replace, so parameter names, `state_dict()` keys,
 unchanged. Their forward has no eager fallback: off-GPU it raises.
 """
 import inspect
+import logging
 import warnings
 
 import torch
@@ -701,13 +702,35 @@ def _swap_bn(m):
     return new
 
 
+def hip_conv_unsupported(m):
+    """Why the engine cannot run this nn.Conv2d (None when it can): the conditions HipConv2d's constructor and ops.ConvBnAct refuse"""
+    if m.padding_mode != "zeros":
+        return "padding_mode=%r (zero padding only)" % (m.padding_mode,)
+    if isinstance(m.padding, str):
+        return "padding=%r (numeric padding only)" % (m.padding,)
+    if m.groups != 1 and not (m.groups == m.in_channels == m.out_channels):
+        return "groups=%d with %d -> %d channels (dense or depthwise only)" % (m.groups, m.in_channels, m.out_channels)
+    return None
+
+
+_log = logging.getLogger("cvpytorch_amd")
+
+
 def convert_to_hip(module):
     """Recursively replace torch layers by their Hip equivalents, sharing Parameters/buffers so
     `state_dict()` keys and values are unchanged (reference checkpoints keep loading:
-    src/utils/checkpoints.py:30-41)."""
+    src/utils/checkpoints.py:30-41). A layer the engine cannot run (hip_conv_unsupported) is LEFT in place — the idiom of
+    SyncBatchNorm.convert_sync_batchnorm (trainer.py:127, src/nn/syncBN.py:10-27), which leaves foreign modules untouched — with one
+    logged line; it keeps running on stock torch (NCHW) tensors, so a model that routes engine activations through it must convert
+    them itself."""
     out = module
     if type(module) is nn.Conv2d:
-        out = _swap_conv(module)
+        why = hip_conv_unsupported(module)
+        if why is None:
+            out = _swap_conv(module)
+        else:
+            _log.warning("convert_to_hip: keeping the stock nn.Conv2d (%d -> %d, k %s): %s", module.in_channels, module.out_channels,
+                         tuple(module.kernel_size), why)
     elif type(module) in (nn.BatchNorm2d, nn.SyncBatchNorm):
         out = _swap_bn(module)
     elif type(module) is nn.SiLU:

@@ -137,6 +137,11 @@ _LAZY = __import__("os").environ.get("CVHIP_LAZY", "1") != "0"
 _LAZY_ACTS = (L.ACT_NONE, L.ACT_RELU, L.ACT_LEAKY, L.ACT_SILU)
 
 
+# True while arena.FlatTrainState.backward runs: the engine owns every gradient tensor between its ops, so backward passes may work in
+# place on the gradients they receive (SppfChain). Anything else (plain loss.backward(), hooks, retain_grad) gets copies.
+_OWNED_BACKWARD = [False]
+
+
 def set_lazy(flag=True):
     global _LAZY
     _LAZY = bool(flag)
@@ -739,12 +744,20 @@ def _conv_grads(ctx, x, weight, dy, dy_ld, need_dx, need_dw, need_db):
                 # padded problem: wgrad into a [Kp][R][S][Cc] scratch, then fold the valid block into the real gradient
                 tmp = torch.empty((Kp, R, S, Cc), dtype=torch.float32, device=dev)
                 planes = getattr(ctx, "image_planes", 0)
+                done = False
                 if planes and not _DETERMINISTIC:
-                    # image stem whose forward read the fp32 NCHW batch directly: so does its weight gradient (x IS that batch)
+                    # image stem whose forward read the fp32 NCHW batch directly: so does its weight gradient (x IS that batch) — unless
+                    # the stem weight-gradient kernel refuses the operands (CVHIP_STEM_WGRAD=0, pitch / alignment of dy): then the
+                    # conversion pass + the generic kernel below, as in deterministic mode
                     zero_fill(tmp)
-                    _timed_call("stem_wgrad_kernel", geom, "cvhip_conv2d_wgrad_image", C.byref(desc), x.data_ptr(), planes, dy.data_ptr(),
-                                tmp.data_ptr(), st)
-                else:
+                    try:
+                        _timed_call("stem_wgrad_kernel", geom, "cvhip_conv2d_wgrad_image", C.byref(desc), x.data_ptr(), planes, dy.data_ptr(),
+                                    tmp.data_ptr(), st)
+                        done = True
+                    except L.CvhipError as e:
+                        if "unsupported" not in str(e):
+                            raise
+                if not done:
                     if planes:
                         x, _ = as_nhwc(images_to_nhwc(x, cpad=Cc))
                     _wgrad(_wgrad_name(Kp, R, S, Cc, N * P * Q, desc), geom, desc, x, dy, tmp, 0, st)
@@ -945,7 +958,7 @@ def _dw_folded(cfg, wm, bias, gamma, beta, running_mean, running_var, K, dev, st
         return wm, bias
     key = (wm.data_ptr(), wm._version, running_mean.data_ptr(), running_mean._version, running_var.data_ptr(), running_var._version,
            None if gamma is None else (gamma.data_ptr(), gamma._version), None if beta is None else (beta.data_ptr(), beta._version),
-           None if bias is None else (bias.data_ptr(), bias._version), _weights_epoch, _stats_epoch[0])
+           None if bias is None else (bias.data_ptr(), bias._version), float(cfg.eps), _weights_epoch, _stats_epoch[0])
     cache = getattr(cfg.state, "dw_cache", None)
     if cache is not None and cache[0] == key:
         return cache[1], cache[2]
@@ -1606,6 +1619,8 @@ class BnAct(torch.autograd.Function):
         stats = None
         train_bn = has_bn and training
         if train_bn:
+            _stats_epoch[0] += 1   # running statistics are about to be rewritten through raw pointers (cached eval scale / shift go stale)
+        if train_bn:
             rows = _colreduce_rows(M, K)
             partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
             L.call("cvhip_bn_stats_partial", y.data_ptr(), M, K, y_ld, partial.data_ptr(), st)
@@ -1724,6 +1739,12 @@ class SppfChain(torch.autograd.Function):
         d, ld = as_nhwc(d)
         if ld != 4 * c or not d.is_contiguous(memory_format=torch.channels_last):
             d = d.contiguous(memory_format=torch.channels_last).clone()
+            d, ld = as_nhwc(d)
+        elif not _OWNED_BACKWARD[0]:
+            # autograd's contract: a Function must not modify the gradient it receives (tensor hooks, retain_grad() on the concat or on
+            # conv2's input gradient would see slices 1..3 overwritten). Only a backward pass that the flat train state drives itself
+            # (arena.FlatTrainState.backward: no user hooks between the engine's ops) walks the chain on the incoming tensor.
+            d = d.clone(memory_format=torch.channels_last)
             d, ld = as_nhwc(d)
         st = _stream()
         esz = d.element_size()

@@ -129,3 +129,27 @@ def test_deeplab_state_dict_matches_oracle_layout():
     hip.load_state_dict(ref.state_dict())
     r8 = R.EncoderDecoder(19, output_stride=8)
     assert [tuple(v.shape) for v in r8.state_dict().values()] == [tuple(v.shape) for v in deeplab.EncoderDecoder(19, output_stride=8).state_dict().values()]
+
+
+def test_convert_to_hip_skips_what_the_engine_refuses(caplog):
+    """VERDICT r04 task 9: convert_to_hip leaves layers the engine cannot run (non-zero padding modes, string padding, grouped but not
+    depthwise convolutions) in place — as convert_sync_batchnorm leaves foreign modules (trainer.py:127) — with one logged line each,
+    and converts their neighbours; parameters stay shared, state_dict keys unchanged."""
+    import logging
+    import torch.nn as nn
+    from cvpytorch_amd import bricks
+    m = nn.Sequential(nn.Conv2d(8, 8, 3, padding=1), nn.Conv2d(8, 8, 3, padding=1, padding_mode="reflect"), nn.Conv2d(8, 8, 3, padding="same"),
+                      nn.Conv2d(8, 16, 3, padding=1, groups=2), nn.Conv2d(16, 16, 3, padding=1, groups=16), nn.BatchNorm2d(16), nn.SiLU())
+    keys = list(m.state_dict().keys())
+    w1 = m[1].weight
+    with caplog.at_level(logging.WARNING, logger="cvpytorch_amd"):
+        out = bricks.convert_to_hip(m)
+    assert isinstance(out[0], bricks.HipConv2d) and isinstance(out[4], bricks.HipConv2d)           # dense and depthwise: converted
+    for i in (1, 2, 3):
+        assert type(out[i]) is nn.Conv2d                                                            # refused geometries: untouched
+    assert out[1].weight is w1
+    assert isinstance(out[5], bricks.HipBN) and isinstance(out[6], bricks.HipSiLU)
+    assert list(out.state_dict().keys()) == keys
+    msgs = [r.getMessage() for r in caplog.records if "convert_to_hip" in r.getMessage()]
+    assert len(msgs) == 3 and any("reflect" in s for s in msgs) and any("same" in s for s in msgs) and any("groups=2" in s for s in msgs)
+    assert bricks.hip_conv_unsupported(nn.Conv2d(8, 8, 1)) is None

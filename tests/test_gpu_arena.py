@@ -214,3 +214,57 @@ def test_prep_plan_equals_per_layer_preparation():
     # and the training step uses it: no per-layer packer runs once the plan exists (keys are fresh after run())
     state.prepare_weights()
     assert state.prep_plan is not None and all(s.key[1] == ops._weights_epoch for s in states)
+
+
+@pytest.mark.parametrize("optimizer", ["sgd", "adamw"])
+def test_optimizer_state_dict_round_trip_and_torch_layout(optimizer):
+    """the fused optimizer's state saves / reloads in torch's optimizer.state_dict() layout
+    (src/utils/checkpoints.py:39-57 stores and reloads it): (i) a stock torch optimizer over the same one-parameter groups accepts
+    the dict; (ii) a FRESH flat state that loads it continues exactly like the original (same parameters after two more steps,
+    bit for bit up to the weight gradient's atomics); (iii) without the load the trajectories differ."""
+    from cvpytorch_amd.train import build_param_groups
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    base = yolov5.YOLOv5(80, "n", max_targets=64, fused_loss=True).to(dev).train()
+    imgs, targets = synthetic_detection_batch(4, 96, seed=11, max_boxes=8, device=dev)
+    gts = yolov5.targets_to_tensor(targets, 64, dev)
+    kw = dict(lr=0.01, weight_decay=5e-4, use_ema=False, optimizer=optimizer)
+    a = copy.deepcopy(base)
+    sa = FlatTrainState(a, **kw)
+    stepa = FlatTrainStep(a, sa)
+    for _ in range(2):
+        stepa(imgs, gts)
+    torch.cuda.synchronize()
+    sd = sa.optimizer_state_dict()
+    model_sd = {k: v.clone() for k, v in a.state_dict().items()}
+    # (i) torch layout
+    groups = build_param_groups(copy.deepcopy(base), 0.01, None, 5e-4)
+    topt = (torch.optim.AdamW if optimizer == "adamw" else torch.optim.SGD)(groups, lr=0.01, **({} if optimizer == "adamw" else dict(momentum=0.937, nesterov=True)))
+    topt.load_state_dict({"state": sd["state"], "param_groups": [dict(topt.state_dict()["param_groups"][i], **{k: v for k, v in g.items() if k != "params"},
+                                                                      params=g["params"]) for i, g in enumerate(sd["param_groups"])]})
+    key = "exp_avg" if optimizer == "adamw" else "momentum_buffer"
+    assert len(topt.state) == len(groups)
+    for g in topt.param_groups:
+        assert topt.state[g["params"][0]][key].shape == g["params"][0].shape
+    # (ii) resume in a fresh state
+    outs = {}
+    for load in (True, False):
+        b = copy.deepcopy(base)
+        sb = FlatTrainState(b, **kw)
+        b.load_state_dict(model_sd)
+        if load:
+            sb.load_optimizer_state_dict(sd)
+            assert rel(sb.mom, sa.mom) == 0.0
+            if optimizer == "adamw":
+                assert rel(sb.mom2, sa.mom2) == 0.0 and float(sb.adam_step) == float(sa.adam_step) == 2.0
+        stepb = FlatTrainStep(b, sb)
+        for _ in range(2):
+            stepb(imgs, gts)
+        torch.cuda.synchronize()
+        outs[load] = sb.param.clone()
+    for _ in range(2):
+        stepa(imgs, gts)
+    torch.cuda.synchronize()
+    e_resumed, e_cold = rel(outs[True], sa.param), rel(outs[False], sa.param)
+    assert e_resumed <= 2e-4, e_resumed                    # (weight-gradient atomics: run-to-run spread of the same trajectory)
+    assert e_cold > 4 * max(e_resumed, 1e-6), (e_cold, e_resumed)   # zero moments / step 0 are a different trajectory

@@ -95,3 +95,35 @@ def test_stem_module_train_step_with_and_without_the_conversion_pass():
     (za, ga, _), (zb, gb, _) = outs
     assert torch.equal(za, zb)
     assert float((ga - gb).abs().max()) <= 1e-4 * float(gb.abs().max()) + 1e-7
+
+
+def test_stem_wgrad_falls_back_when_the_stem_kernel_refuses(monkeypatch):
+    """cvhip_conv2d_wgrad_image may answer CVHIP_ERR_UNSUPPORTED (CVHIP_STEM_WGRAD=0, operand pitch / alignment): the step
+    must then take the conversion pass + the generic weight-gradient kernel instead of raising."""
+    import torch
+    from cvpytorch_amd import bricks, lib as L, ops
+    d = torch.device("cuda:0")
+    torch.manual_seed(4)
+    m = bricks.HipConvModule(3, 32, 6, 2, 2, norm_cfg=dict(type="BN"), act_cfg=dict(type="SiLU")).to(d).train()
+    x = torch.rand(4, 3, 128, 128, device=d)
+    g = (torch.randn(4, 32, 64, 64, device=d) * 0.1).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    def run(refuse):
+        for p in m.parameters():
+            p.grad = None
+        real = L.call
+
+        def call(name, *a):
+            if refuse and name == "cvhip_conv2d_wgrad_image":
+                raise L.CvhipError("cvhip_conv2d_wgrad_image failed: unsupported shape/feature")
+            return real(name, *a)
+
+        monkeypatch.setattr(L, "call", call)
+        m(x).backward(g)
+        torch.cuda.synchronize()
+        monkeypatch.setattr(L, "call", real)
+        return m.conv.weight.grad.float().clone()
+
+    a, b = run(False), run(True)
+    rel = float((a - b).norm() / a.norm())
+    assert rel <= 2e-3, rel     # the image path rounds the fp32 pixels to 16 bits exactly like the conversion pass: same operands
