@@ -159,6 +159,8 @@ def _cpu_sample(size, cpu_batch, budget_s, threads):
     torch.set_num_threads(threads)
     model = R.YOLOv5(80, "s").train()
     opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4)
+    from cvpytorch_amd.train import ModelEMA   # (pure torch: the reference's ModelEMA.update, src/utils/ema.py:30-39 — the GPU step includes it)
+    ema = ModelEMA(model)
     imgs, targets = R.synthetic_batch(cpu_batch, size, seed=1029)
 
     def step(b):
@@ -166,6 +168,7 @@ def _cpu_sample(size, cpu_batch, budget_s, threads):
         loss.backward()
         opt.step()
         opt.zero_grad(set_to_none=True)
+        ema.update(model)
 
     t0 = time.perf_counter()
     step(1)  # warm-up on one image (allocator, thread pool, lazy inits)
@@ -195,7 +198,7 @@ def cpu_baseline(size, cpu_batch, budget_s=12.0, max_threads=32):
     return {"value": round(v, 3), "unit": "images/sec", "cores": threads, "kind": "port",
             "value_1_thread": round(v1, 3), "cpu_model": _cpu_model(), "logical_cores": os.cpu_count() or 1,
             "torch": torch.__version__,
-            "sample": "oracle (oracle/torch_ref.py) YOLOv5-s fp32 train step (fwd+loss+bwd+SGD-nesterov) @%dx%d: batch %d, %d timed step(s) after a "
+            "sample": "oracle (oracle/torch_ref.py) YOLOv5-s fp32 train step (fwd+loss+bwd+SGD-nesterov+EMA) @%dx%d: batch %d, %d timed step(s) after a "
                       "1-image warm-up, %.1f s, %d intra-op threads of %d logical cores; 1-thread figure: batch %d, %d step(s), %.1f s"
                       % (size, size, b, n, el, threads, os.cpu_count() or 1, b1, n1, el1)}
 
@@ -520,16 +523,16 @@ class _Watchdog:
     """Never lose the headline line to a side leg that hangs (a collective one rank never joins, a wedged kernel): if `budget_s`
     pass before `done()`, rank 0 prints what it has — with the unfinished legs marked — and every rank exits."""
 
-    def __init__(self, out, rank, budget_s):
+    def __init__(self, out, rank, budget_s, note="side legs exceeded their time budget; unfinished legs are missing from this line"):
         import threading
-        self.out, self.rank = out, rank
+        self.out, self.rank, self.note = out, rank, note
         self.t = threading.Timer(budget_s, self._fire)
         self.t.daemon = True
         self.t.start()
 
     def _fire(self):
         if self.rank == 0 and self.out is not None:
-            self.out["watchdog"] = "side legs exceeded their time budget; unfinished legs are missing from this line"
+            self.out["watchdog"] = self.note
             print(json.dumps(self.out), flush=True)
         os._exit(0)
 
@@ -650,6 +653,55 @@ def main():
                 use_graph = False
         return use_graph, imgs, gts
 
+    def headline(el, med, loss_val, launch):
+        gb = a.batch * world
+        return {
+            "metric": "images/sec/node train step, YOLOv5-s@640 (value: batch resident in HBM when the timed region starts; with_h2d.value: the same "
+                      "step fed from pinned host memory inside the region) & DeepLabv3+R50@1024x512 (config3_deeplabv3plus_r50.value)",
+            "value": round(gb * a.steps / el, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * el / a.steps, 3),
+            "ms_per_step_median": round(med, 3), "value_median": round(gb / (med * 1e-3), 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "coco_yolov5_s.yml YOLOv5-s %dx%d bf16 train step (fwd+loss+bwd+SGD-nesterov+EMA), per-GPU batch %d, "
+                                   "synthetic COCO-shape tensors resident in HBM" % (a.size, a.size, a.batch),
+                       "global_batch": gb, "parallelism": "dp%d" % world, "final_loss": round(loss_val, 4), "launch": launch,
+                       "world": comm.world if comm is not None else 1, "transport": transport,
+                       "grad_buckets": (len(state.buckets) if (state is not None and world > 1) else 0),
+                       "sync_bn": bool(a.sync_bn and world > 1),
+                       "statistic": "value = global_batch * K / wall time of the K timed steps (max over ranks); *_median from per-step HIP events"},
+        }
+
+    def ranks_seen():
+        """what every rank saw: its HIP device and the world size its communicator reports (the record shows RCCL ran N ranks)"""
+        seen = torch.zeros(world, 2, device=dev, dtype=torch.float32)
+        seen[rank, 0] = float(torch.cuda.current_device())
+        seen[rank, 1] = float(comm.world)
+        comm.allreduce_(seen)
+        comm.wait()
+        return [{"rank": r, "hip_device": int(seen[r, 0].item()), "comm_world": int(seen[r, 1].item())} for r in range(world)]
+
+    # N > 1: the K steps are timed TWICE. First eagerly (kernel launches and bucketed collectives issued by the host, collectives on a
+    # side stream beside backward: the path with the least machinery), then as ONE replayed hipGraph with the collectives captured
+    # inside it. The graph leg is the headline; it runs under a watchdog whose fallback line IS the eager leg (with config.ranks /
+    # config.world), so that a capture- or replay-time RCCL stall on a node this code has never seen cannot return an empty record.
+    pre, head_dog = None, None
+    if world > 1 and not a.no_graph and not a.stock_optimizer:
+        for _ in range(a.warmup):
+            step(imgs, gts)
+        el0, l0, med0, _ = timed_steps(step, imgs, gts, a.steps, barrier)
+        t0 = torch.tensor([el0, med0], device=dev, dtype=torch.float64)
+        comm.allreduce_(t0, "max")
+        comm.wait()
+        ranks0 = ranks_seen()
+        if rank == 0:
+            pre = headline(float(t0[0].item()), float(t0[1].item()), float(l0["loss"]),
+                           "eager launches, bucketed collectives on a side stream beside backward")
+            pre["config"]["ranks"] = ranks0
+            pre["config"]["grad_exchange"], pre["config"]["bucket_mib"] = "allreduce", 8
+        head_dog = _Watchdog(pre, rank, float(os.environ.get("CVHIP_BENCH_HEADLINE_BUDGET", "420")),
+                             note="the hipGraph leg (collectives captured inside the step graph) did not finish within its budget: this line is "
+                                  "the EAGER leg of the same K steps, measured before it")
+
     use_graph, imgs, gts = warm_and_capture(step, imgs, gts, a.sync_bn)
     ops.TIMER.enabled = (not a.no_kernel_timing) and rank == 0 and not use_graph
     ops.TIMER.reset()
@@ -672,6 +724,8 @@ def main():
         comm.wait()
         el, med = float(t[0].item()), float(t[1].item())
     loss_val = float(losses["loss"])
+    if head_dog is not None:
+        head_dog.done()
 
     out = None
     if rank == 0:
@@ -682,21 +736,11 @@ def main():
             if world > 1:
                 launch = ("hipGraph replay of the whole step incl. the bucketed all-reduces on a forked stream beside backward" if not step.eager_tail
                           else "hipGraph replay of forward+loss+backward, then one all-reduce of the gradient arena + fused optimizer")
-        out = {
-            "metric": "images/sec/node train step, YOLOv5-s@640 (value: batch resident in HBM when the timed region starts; with_h2d.value: the same "
-                      "step fed from pinned host memory inside the region) & DeepLabv3+R50@1024x512 (config3_deeplabv3plus_r50.value)",
-            "value": round(gb * a.steps / el, 2), "unit": "images/sec",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * el / a.steps, 3),
-            "ms_per_step_median": round(med, 3), "value_median": round(gb / (med * 1e-3), 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "coco_yolov5_s.yml YOLOv5-s %dx%d bf16 train step (fwd+loss+bwd+SGD-nesterov+EMA), per-GPU batch %d, "
-                                   "synthetic COCO-shape tensors resident in HBM" % (a.size, a.size, a.batch),
-                       "global_batch": gb, "parallelism": "dp%d" % world, "final_loss": round(loss_val, 4), "launch": launch,
-                       "world": comm.world if comm is not None else 1, "transport": transport,
-                       "grad_buckets": (len(state.buckets) if (state is not None and world > 1) else 0),
-                       "sync_bn": bool(a.sync_bn and world > 1),
-                       "statistic": "value = global_batch * K / wall time of the K timed steps (max over ranks); *_median from per-step HIP events"},
-        }
+        out = headline(el, med, loss_val, launch)
+        if pre is not None:
+            out["eager_collectives"] = {"value": pre["value"], "ms_per_step": pre["ms_per_step"], "ms_per_step_median": pre["ms_per_step_median"],
+                                        "launch": pre["config"]["launch"], "final_loss": pre["config"]["final_loss"],
+                                        "what": "the same K steps timed before the headline leg without a hipGraph (the watchdog's fallback line)"}
         summ = ops.TIMER.summary()
         if summ:
             # the step's dominant kernel over EVERYTHING that was timed (convs, the fused 1x1 backward, BN/activation passes) ...
@@ -720,13 +764,9 @@ def main():
     if world > 1:
         # what every rank saw: its HIP device and the world size its communicator reports (the record shows RCCL ran N ranks)
         try:
-            seen = torch.zeros(world, 2, device=dev, dtype=torch.float32)
-            seen[rank, 0] = float(torch.cuda.current_device())
-            seen[rank, 1] = float(comm.world)
-            comm.allreduce_(seen)
-            comm.wait()
+            rs = ranks_seen()
             if rank == 0:
-                out["config"]["ranks"] = [{"rank": r, "hip_device": int(seen[r, 0].item()), "comm_world": int(seen[r, 1].item())} for r in range(world)]
+                out["config"]["ranks"] = rs
                 out["config"]["grad_exchange"] = "allreduce"
                 out["config"]["bucket_mib"] = 8
         except Exception as e:
