@@ -369,6 +369,20 @@ int cvhip_conv2d_wgrad_image(const cvhip_conv_desc* d, const float* x_nchw, int3
   return rc >= 0 || rc < -1 ? rc : CVHIP_ERR_UNSUPPORTED;
 }
 
+int cvhip_conv2d_wgrad_stem_bn(const cvhip_conv_desc* d, const void* x, const float* x_nchw, int32_t planes, const void* dz, const void* y,
+                               const float* scale, const float* shift, const float* mean, const float* invstd, const double* acc, int32_t acc_ld,
+                               float* dgamma_out, float* dbeta_out, int32_t accumulate, int32_t act, float act_param, float* dw, void* stream) {
+  int st = validate_dense_desc(d);
+  if (st) return st;
+  if ((!x && !x_nchw) || !dz || !y || !dw || !scale || !shift || !mean || !invstd || !acc) return CVHIP_ERR_INVALID;
+  if (x_nchw && (planes < 1 || planes > 4)) return CVHIP_ERR_INVALID;
+  if ((d->K & 7) || (d->y_ld & 7)) return CVHIP_ERR_UNSUPPORTED;
+  if (act != CVHIP_ACT_NONE && act != CVHIP_ACT_RELU && act != CVHIP_ACT_LEAKY && act != CVHIP_ACT_SILU) return CVHIP_ERR_UNSUPPORTED;
+  StemWgradBn bn{y, d->y_ld, scale, shift, mean, invstd, acc, acc_ld, act, act_param, dgamma_out, dbeta_out, accumulate};
+  const int rc = try_launch_stem_wgrad(d, x, dz, dw, (hipStream_t)stream, x_nchw, planes, &bn);
+  return rc >= 0 || rc < -1 ? rc : CVHIP_ERR_UNSUPPORTED;
+}
+
 int cvhip_conv2d_fprop_prologue_ok(const cvhip_conv_desc* d, int with_z_out) {
   if (validate_dense_desc(d)) return 0;
   IgemmParams p;

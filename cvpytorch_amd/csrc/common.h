@@ -138,6 +138,20 @@ __device__ __forceinline__ float act_bwd(float u, int act, float ap) {
   }
 }
 
+// BN + activation BACKWARD of 8 channels from (dz, y) with per-channel constants (u = sc*y + sh; dy = sc*du + b1*y + c1: the affine
+// form of gamma*invstd*(du - dbeta/M - xhat*dgamma/M), see conv1x1_bwd.hip) — the on-load transform of the fused backward kernels
+struct f32x8;
+template <int ACT>
+__device__ __forceinline__ void bnact_bwd8_into(const float (&dz)[8], const float (&y)[8], const float (&sc)[8], const float (&sh)[8],
+                                                const float (&b1)[8], const float (&c1)[8], float ap, float (&o)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float u = y[j] * sc[j] + sh[j];
+    const float du = dz[j] * act_bwd(u, ACT, ap);
+    o[j] = sc[j] * du + (b1[j] * y[j] + c1[j]);
+  }
+}
+
 // 8 per-channel constants for the channel vector starting at c: UNCONDITIONAL clamped loads (a per-element
 // `ok ? p[c] : dflt` compiles to 8 exec-masked blocks with an s_waitcnt vmcnt(0) at every join: 16-48 serialized
 // ~1 us round trips per thread, i.e. a fixed ~17 us per launch — measured, tools/stream_probe.py)

@@ -178,8 +178,20 @@ bool stream1x1_prologue_ok(const IgemmParams& p, bool stats);
 // conv_stem.hip: direct convolution for 8-channel image stems (grid size, 0 = not taken; launcher, -1 = not taken)
 int stem_blocks(int C, int x_ld, int K, int R, int S, int sh, int sw, int dh, int dw, int N, int OH, int OW);
 int try_launch_stem(const IgemmParams& p, hipStream_t stream);
+// BN + activation backward applied on load by the stem weight-gradient kernel (`dy` is then dz, the gradient at the layer's output)
+struct StemWgradBn {
+  const void* y;
+  int y_ld;
+  const float *scale, *shift, *mean, *invstd;
+  const double* acc;
+  int acc_ld;
+  int act;
+  float act_param;
+  float *dgamma_out, *dbeta_out;
+  int accumulate;
+};
 int try_launch_stem_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, hipStream_t stream, const float* x_image = nullptr,
-                          int x_planes = 0);
+                          int x_planes = 0, const StemWgradBn* bn = nullptr);
 // conv_patch.hip: patch-resident implicit GEMM for multi-tap convolutions (launcher, -1 = not taken; geometry-only query with the
 // number of BatchNorm partial rows its epilogue writes)
 int try_launch_patch(const IgemmParams& p, hipStream_t stream);

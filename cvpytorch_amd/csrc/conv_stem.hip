@@ -322,12 +322,27 @@ struct StemWgradParams {
   float* dw;  // [K][R*S][8] fp32, accumulated with atomics
   int NB, IH, IW, OH, OW, K, dy_ld, R, S, pad_h, pad_w;
   int tiles_x, tiles_y, ntiles;
+  // BNB instances (round 5): `dy` is dz, the gradient at the OUTPUT of the stem's Conv-BN-act layer; the BN + activation backward is
+  // applied ON LOAD (dy = sc*du + b1*y + c1 with du = dz*act'(sc*y + sh), rounded to 16 bits as the stand-alone pass stores it), so the
+  // apply pass (read dz, read y, write dy) and the dy tensor disappear — the image stem has no input gradient, the weight gradient is
+  // dy's only consumer. (sum du, sum du*xhat) come from the layer's fp64 accumulator; block 0 stores dgamma / dbeta.
+  const h16_t* y;
+  int y_ld;
+  const float *scale, *shift, *mean, *invstd;
+  const double* acc;
+  int acc_ld;
+  float inv_count;
+  int act;
+  float ap;
+  float *o_dgamma, *o_dbeta;
+  int accumulate;
 };
 
-template <int ST, int NFW>
+template <int ST, int NFW, bool BNB = false>
 __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const StemWgradParams p) {
   constexpr int DY_BYTES = kStemTH * kStemTW * 64;  // [256 pixels][32 channels] bf16
-  __shared__ __attribute__((aligned(16))) unsigned char smem[kStemPatchBytes + DY_BYTES];
+  // BNB: the 4 x 32 per-channel constants live in the LDS (in registers they cost the third resident block: 194 VGPRs, 423 us)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kStemPatchBytes + DY_BYTES + (BNB ? 4 * 32 * 4 : 0)];
   unsigned char* const sP = smem;
   unsigned char* const sD = smem + kStemPatchBytes;
   const int t = threadIdx.x, lane = t & 63;
@@ -343,13 +358,31 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const StemWgradParam
   // ---- loaders (patch: as in stem_fprop_kernel; dY: thread owns 16-byte chunk (t & 3) of pixels (t >> 2) + 64 i)
   constexpr int LD_IT = (kStemMaxPH * kStemMaxPW + 255) / 256;
   uint4 pre[LD_IT], pred[4];
-  int pk[LD_IT], loff[LD_IT];
+  uint4 predy[BNB ? 4 : 1];
+  unsigned pvalid = 0;  // BNB: which of this thread's 4 dY pixels exist (the transform of a zero-filled pixel is c1, not zero)
+  // (row << 16 | column) and LDS byte offset of this thread's i-th patch slot: tables in registers — or, in the BNB instances (which
+  // need the registers for the second operand's prefetch), recomputed per use with an exact multiply-shift division by PW
+  int pk_t[BNB ? 1 : LD_IT], loff_t[BNB ? 1 : LD_IT];
+  const unsigned pw_magic = (unsigned)((0x100000000ull + (unsigned)PW - 1) / (unsigned)PW);  // exact qq / PW for qq < 2^16 (conv_plan.h div_magic)
+  auto slot = [&](int i, int& pkv, int& loffv) {
+    if constexpr (BNB) {
+      const int qq = t + i * 256;
+      const int pr = (int)__umulhi((unsigned)qq, pw_magic), pc = qq - pr * PW;
+      pkv = qq < nchunk ? ((pr << 16) | pc) : -1;
+      loffv = (pr * PW + (ST == 2 ? (pc & 1) * HALF + (pc >> 1) : pc)) * 16;
+    } else {
+      pkv = pk_t[i];
+      loffv = loff_t[i];
+    }
+  };
+  if constexpr (!BNB) {
 #pragma unroll
-  for (int i = 0; i < LD_IT; ++i) {
-    const int qq = t + i * 256;
-    const int pr = qq / PW, pc = qq - pr * PW;
-    pk[i] = qq < nchunk ? ((pr << 16) | pc) : -1;
-    loff[i] = (pr * PW + (ST == 2 ? (pc & 1) * HALF + (pc >> 1) : pc)) * 16;
+    for (int i = 0; i < LD_IT; ++i) {
+      const int qq = t + i * 256;
+      const int pr = qq / PW, pc = qq - pr * PW;
+      pk_t[i] = qq < nchunk ? ((pr << 16) | pc) : -1;
+      loff_t[i] = (pr * PW + (ST == 2 ? (pc & 1) * HALF + (pc >> 1) : pc)) * 16;
+    }
   }
   auto tile_origin = [&](int tile, int& n, int& oy0, int& ox0) {
     const int tx = tile % p.tiles_x;
@@ -369,9 +402,11 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const StemWgradParam
       const float* img = p.xf + (int64_t)n * p.planes * plane;
 #pragma unroll
       for (int i = 0; i < LD_IT; ++i) {
-        const int iy = iy0 + (pk[i] >> 16), ix = ix0 + (pk[i] & 0xffff);
+        int pkv, loffv;
+        slot(i, pkv, loffv);
+        const int iy = iy0 + (pkv >> 16), ix = ix0 + (pkv & 0xffff);
         float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-        if (pk[i] >= 0 && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) {
+        if (pkv >= 0 && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) {
           const float* px = img + (int64_t)iy * p.IW + ix;
           c0 = px[0];
           if (p.planes > 1) c1 = px[plane];
@@ -387,9 +422,11 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const StemWgradParam
     const h16_t* img = p.x + (int64_t)n * p.IH * p.IW * 8;
 #pragma unroll
     for (int i = 0; i < LD_IT; ++i) {
-      const int iy = iy0 + (pk[i] >> 16), ix = ix0 + (pk[i] & 0xffff);
+      int pkv, loffv;
+      slot(i, pkv, loffv);
+      const int iy = iy0 + (pkv >> 16), ix = ix0 + (pkv & 0xffff);
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (pk[i] >= 0 && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW)
+      if (pkv >= 0 && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW)
         v = *reinterpret_cast<const uint4*>(img + (int64_t)(iy * p.IW + ix) * 8);
       pre[i] = v;
     }
@@ -399,20 +436,96 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const StemWgradParam
       const int px = (t >> 2) + 64 * i;  // tile pixel: row px / 64, column px % 64
       const int oy = oy0 + (px >> 6), ox = ox0 + (px & 63);
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (oy < p.OH && ox < p.OW && dchunk * 8 < p.K)
-        v = *reinterpret_cast<const uint4*>(p.dy + ((int64_t)(n * p.OH + oy) * p.OW + ox) * p.dy_ld + dchunk * 8);
+      const bool ok = oy < p.OH && ox < p.OW && dchunk * 8 < p.K;
+      if (ok) v = *reinterpret_cast<const uint4*>(p.dy + ((int64_t)(n * p.OH + oy) * p.OW + ox) * p.dy_ld + dchunk * 8);
       pred[i] = v;
+      if constexpr (BNB) {
+        uint4 w = make_uint4(0u, 0u, 0u, 0u);
+        if (ok) w = *reinterpret_cast<const uint4*>(p.y + ((int64_t)(n * p.OH + oy) * p.OW + ox) * p.y_ld + dchunk * 8);
+        predy[i] = w;
+        pvalid = ok ? (pvalid | (1u << i)) : (pvalid & ~(1u << i));
+      }
     }
   };
+  // BNB: per-channel constants of this thread's channel vector (dchunk: thread-constant), from the layer's backward accumulator
+  float* const sK = reinterpret_cast<float*>(smem + kStemPatchBytes + DY_BYTES);  // [4][32]: sc | sh | b1 | c1
+  if constexpr (BNB) {
+    float bsc[8], bsh[8], bb1[8], bc1[8];
+    float* const kst = reinterpret_cast<float*>(sD);  // [2][32]: the dY tile is not in use yet
+    if (t < 32) {
+      double s1 = 0.0, s2 = 0.0;
+      if (t < p.K) acc_fold2(p.acc, p.acc_ld, t, s1, s2);
+      kst[t] = (float)s1;
+      kst[32 + t] = (float)s2;
+      if (blockIdx.x == 0 && t < p.K) {
+        if (p.o_dbeta) p.o_dbeta[t] = p.accumulate ? p.o_dbeta[t] + (float)s1 : (float)s1;
+        if (p.o_dgamma) p.o_dgamma[t] = p.accumulate ? p.o_dgamma[t] + (float)s2 : (float)s2;
+      }
+    }
+    __syncthreads();
+    const int c0 = dchunk * 8 < p.K ? dchunk * 8 : 0;
+    float mu[8], is[8];
+    load8c(p.scale, c0, p.K, bsc);
+    load8c(p.shift, c0, p.K, bsh);
+    load8c(p.mean, c0, p.K, mu);
+    load8c(p.invstd, c0, p.K, is);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float q2 = bsc[j] * is[j] * (kst[32 + c0 + j] * p.inv_count);
+      bb1[j] = -q2;
+      bc1[j] = q2 * mu[j] - bsc[j] * (kst[c0 + j] * p.inv_count);
+    }
+    if (t < 4) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        sK[c0 + j] = bsc[j];
+        sK[32 + c0 + j] = bsh[j];
+        sK[64 + c0 + j] = bb1[j];
+        sK[96 + c0 + j] = bc1[j];
+      }
+    }
+    __syncthreads();  // the constants are published (and the scratch is free) before the first lstore
+  }
   auto lstore = [&]() {
 #pragma unroll
-    for (int i = 0; i < LD_IT; ++i)
-      if (pk[i] >= 0) *reinterpret_cast<uint4*>(sP + loff[i]) = pre[i];
+    for (int i = 0; i < LD_IT; ++i) {
+      int pkv, loffv;
+      slot(i, pkv, loffv);
+      if (pkv >= 0) *reinterpret_cast<uint4*>(sP + loffv) = pre[i];
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int px = (t >> 2) + 64 * i;
       const int h = (px & 3) | ((px >> 1) & 4);  // 32-byte-segment swizzle of conv_wgrad.hip (2 segments per 64-byte row)
-      *reinterpret_cast<uint4*>(sD + px * 64 + ((((dchunk >> 1) ^ h) & 1) << 5) + (dchunk & 1) * 16) = pred[i];
+      uint4 v = pred[i];
+      if constexpr (BNB) {
+        // two channel pairs at a time: (dz, y) 32-bit words in, one packed word out — keeps the transform's live registers small
+        const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+        const uint32_t wy[4] = {predy[i].x, predy[i].y, predy[i].z, predy[i].w};
+        uint32_t wo[4];
+        const float* k = sK + dchunk * 8;
+#pragma unroll
+        for (int h2 = 0; h2 < 4; ++h2) {
+          float d0, d1, y0, y1;
+          unpack2(wd[h2], d0, d1);
+          unpack2(wy[h2], y0, y1);
+          const int j = 2 * h2;
+          const float u0 = y0 * k[j] + k[32 + j], u1 = y1 * k[j + 1] + k[32 + j + 1];
+          float a0, a1;
+          switch (p.act) {  // block-uniform
+            case CVHIP_ACT_SILU: a0 = act_bwd(u0, CVHIP_ACT_SILU, p.ap); a1 = act_bwd(u1, CVHIP_ACT_SILU, p.ap); break;
+            case CVHIP_ACT_RELU: a0 = act_bwd(u0, CVHIP_ACT_RELU, p.ap); a1 = act_bwd(u1, CVHIP_ACT_RELU, p.ap); break;
+            case CVHIP_ACT_LEAKY: a0 = act_bwd(u0, CVHIP_ACT_LEAKY, p.ap); a1 = act_bwd(u1, CVHIP_ACT_LEAKY, p.ap); break;
+            default: a0 = a1 = 1.f; break;
+          }
+          const float o0 = k[j] * (d0 * a0) + (k[64 + j] * y0 + k[96 + j]);
+          const float o1 = k[j + 1] * (d1 * a1) + (k[64 + j + 1] * y1 + k[96 + j + 1]);
+          wo[h2] = pack2(o0, o1);
+        }
+        v = make_uint4(wo[0], wo[1], wo[2], wo[3]);
+        if (!((pvalid >> i) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
+      }
+      *reinterpret_cast<uint4*>(sD + px * 64 + ((((dchunk >> 1) ^ h) & 1) << 5) + (dchunk & 1) * 16) = v;
     }
   };
 
@@ -566,7 +679,8 @@ int try_launch_stem(const IgemmParams& p, hipStream_t stream) {
 }
 
 // wgrad twin of try_launch_stem: same eligibility (descriptor level), dw = [K][R*S][8] fp32 (already zeroed / holding the sum)
-int try_launch_stem_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, hipStream_t stream, const float* x_image, int x_planes) {
+int try_launch_stem_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, hipStream_t stream, const float* x_image, int x_planes,
+                          const StemWgradBn* bn) {
   const int OH = conv_out_dim(d->H, d->pad_h, d->dil_h, d->R, d->stride_h);
   const int OW = conv_out_dim(d->W, d->pad_w, d->dil_w, d->S, d->stride_w);
   const int blocks = stem_blocks(d->C, d->x_ld, d->K, d->R, d->S, d->stride_h, d->stride_w, d->dil_h, d->dil_w, d->N, OH, OW);
@@ -589,12 +703,40 @@ int try_launch_stem_wgrad(const cvhip_conv_desc* d, const void* x, const void* d
   sp.tiles_x = cdiv(OW, kStemTW);
   sp.tiles_y = cdiv(OH, kStemTH);
   sp.ntiles = d->N * sp.tiles_x * sp.tiles_y;
+  sp.y = nullptr;
+  if (bn) {
+    if (!bn->y || !bn->scale || !bn->shift || !bn->mean || !bn->invstd || !bn->acc || bn->acc_ld < d->K || (bn->y_ld & 7) || (((uintptr_t)bn->y) & 15)) return -1;
+    sp.y = (const h16_t*)bn->y;
+    sp.y_ld = bn->y_ld;
+    sp.scale = bn->scale; sp.shift = bn->shift; sp.mean = bn->mean; sp.invstd = bn->invstd;
+    sp.acc = bn->acc; sp.acc_ld = bn->acc_ld;
+    sp.inv_count = 1.f / (float)((int64_t)d->N * OH * OW);
+    sp.act = bn->act; sp.ap = bn->act_param;
+    sp.o_dgamma = bn->dgamma_out; sp.o_dbeta = bn->dbeta_out; sp.accumulate = bn->accumulate;
+  }
   const int nfrag = (d->R * d->S + 1) / 2;
   const int nfw = cdiv(nfrag, 4);
   const bool s2 = d->stride_h == 2;
+  const bool bnb = bn != nullptr;
+  int grid = blocks;
+  if (bnb) {
+    // the on-load instances hold dz AND y of the next tile in registers (~180 VGPRs): two resident blocks per CU, not three — a
+    // persistent grid larger than the resident slots would run its last third after everything else. Measured on the YOLOv5-s stem
+    // (profiles/r05_stem_bn_*): 768 blocks 423 us, 512 blocks 354 us, 256 blocks 577 us; forcing three blocks per CU
+    // (__launch_bounds__(256, 3): 168 VGPRs + 68 B of scratch) 436 us — against 215 us (plain) + 217 us (the apply pass it replaces)
+    static int cap = -1;
+    if (cap < 0) {
+      const char* e = getenv("CVHIP_STEM_BN_BLOCKS");
+      cap = e ? atoi(e) : 512;
+      if (cap < 64) cap = 512;
+    }
+    if (grid > cap) grid = cap;
+  }
 #define CVHIP_STEMW_CASE(NF)                                                                                          \
   case NF:                                                                                                            \
-    if (s2) hipLaunchKernelGGL((stem_wgrad_kernel<2, NF>), dim3(blocks), dim3(256), 0, stream, sp);                   \
+    if (s2 && bnb) hipLaunchKernelGGL((stem_wgrad_kernel<2, NF, true>), dim3(grid), dim3(256), 0, stream, sp);        \
+    else if (bnb) hipLaunchKernelGGL((stem_wgrad_kernel<1, NF, true>), dim3(grid), dim3(256), 0, stream, sp);         \
+    else if (s2) hipLaunchKernelGGL((stem_wgrad_kernel<2, NF>), dim3(blocks), dim3(256), 0, stream, sp);              \
     else hipLaunchKernelGGL((stem_wgrad_kernel<1, NF>), dim3(blocks), dim3(256), 0, stream, sp);                      \
     break;
   switch (nfw) {

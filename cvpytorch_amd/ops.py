@@ -824,6 +824,42 @@ def _materialize_tmp(x, x_ld, lz):
     return z
 
 
+_STEM_BN = __import__("os").environ.get("CVHIP_STEM_BN", "1") != "0"   # 0: apply pass + plain stem weight gradient (A/B switch)
+
+
+def _stem_wgrad_bn(ctx, cfg, x, y, weight, dz, stats, acc_b, g_out, b_out, accum, act, act_param):
+    """dW of an image-stem Conv-BN-act layer straight from dz (BN + activation backward on load). Returns the weight gradient
+    (None when it went into the flat gradient arena), or False when the stem kernel does not run this problem."""
+    N, Cc, H, W, K, R, S, P, Q, Kp, x_ld, Cg = ctx.geom
+    dev = dz.device
+    st = _stream()
+    cv = Cg if Cg != Cc else 0
+    desc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, x_ld, Kp, 0, cv)
+    if L.load().cvhip_conv_stem_blocks(C.byref(desc)) <= 0:
+        return False
+    planes = getattr(ctx, "image_planes", 0)
+    tmp = zero_fill(torch.empty((Kp, R, S, Cc), dtype=torch.float32, device=dev))
+    try:
+        _timed_call("stem_wgrad_kernel", (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv2d_wgrad_stem_bn", C.byref(desc),
+                    None if planes else x.data_ptr(), x.data_ptr() if planes else None, planes, dz.data_ptr(), y.data_ptr(),
+                    stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), acc_b.data_ptr(), K,
+                    g_out.data_ptr(), b_out.data_ptr(), int(accum), act, act_param, tmp.data_ptr(), st,
+                    nbytes=2.0 * (N * H * W * Cc + 2 * N * P * Q * K))
+    except L.CvhipError as e:
+        if "unsupported" not in str(e):
+            raise
+        return False
+    arena = cfg.arena
+    direct_w = arena is not None and cfg.gw is not None and tuple(cfg.gw.shape) == tuple(weight.shape)
+    if direct_w:
+        L.call("cvhip_f32_unpad_add", tmp.data_ptr(), cfg.gw.data_ptr(), K, R * S, Cc, Cg, st)
+        _mark(arena, cfg.idx_w)
+        return None
+    dw = zero_fill(torch.empty((K, Cg, R, S), dtype=torch.float32, device=dev, memory_format=torch.channels_last))
+    L.call("cvhip_f32_unpad_add", tmp.data_ptr(), dw.data_ptr(), K, R * S, Cc, Cg, st)
+    return dw if dw.dtype == weight.dtype else dw.to(weight.dtype)
+
+
 def _bwd1x1_ok(ctx, cfg, x, need_dx, need_dw, need_db, segs):
     """True when the fused 1x1 backward kernel (conv1x1_bwd.hip: BN/act backward on load + dgrad + wgrad in one pass) takes
     this layer: dense 1x1 stride-1, K in {32, 64, 128}, unpadded channels, both gradients wanted, 16-byte aligned operands."""
@@ -1287,6 +1323,19 @@ class ConvBnAct(torch.autograd.Function):
                 g_out = dgamma = torch.empty((K,), dtype=torch.float32, device=dev)
                 b_out = dbeta = torch.empty((K,), dtype=torch.float32, device=dev)
                 accum = 0
+        if (acc_b is not None and _STEM_BN and not fused and not need_dx and need_dw and pointwise and not ctx.depthwise and not _DETERMINISTIC
+                and Kp == K and dz_ld == K and dz.data_ptr() % 16 == 0 and Cc == 8 and x_ld == 8 and act in _LAZY_ACTS and not (ctx.has_bias and need_db)
+                and lzi is None):
+            # image stem: no input gradient, so the weight gradient is the only consumer of dy — the BN + activation backward rides in
+            # the stem weight-gradient kernel's loads (cvhip_conv2d_wgrad_stem_bn): no apply pass, no dy tensor
+            dw = _stem_wgrad_bn(ctx, cfg, x, y, weight, dz, stats, acc_b, g_out, b_out, accum, act, act_param)
+            if dw is not False:
+                if direct_bn:
+                    need_dg = need_dbeta = False
+                    for i in cfg.idx_bn:
+                        arena.mark_ready(i)
+                dres = dz if ctx.has_res else None
+                return None, dw, None, (dgamma if need_dg else None), (dbeta if need_dbeta else None), None, None, dres, None
         if fused and acc_b is not None:
             dx, dw = _bwd1x1(ctx, cfg, x, y, weight, ((dz, dz_ld),), K, stats, True, None, None, act, act_param, acc_b, g_out, b_out, accum, xin=lzi)
             if direct_bn:

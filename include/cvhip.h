@@ -720,6 +720,15 @@ int cvhip_conv2d_fprop_fused(const cvhip_conv_desc* d, const void* x, const void
 /* weight gradient of an image stem straight from the fp32 NCHW image (see cvhip_conv_fuse.x_image): dw = [K][R*S][8] fp32, ACCUMULATED
  * (atomics) like cvhip_conv2d_wgrad with accumulate != 0. CVHIP_ERR_UNSUPPORTED unless cvhip_conv_stem_blocks(d) > 0. */
 int cvhip_conv2d_wgrad_image(const cvhip_conv_desc* d, const float* x_nchw, int32_t planes, const void* dy, float* dw, void* stream);
+/* (round 5) weight gradient of an image STEM Conv-BN-act layer straight from dz, the gradient at the layer's OUTPUT: the BN + activation
+ * backward (what cvhip_bn_act_bwd_apply_acc computes) is applied on load inside the stem weight-gradient kernel, so that pass and the
+ * dy tensor do not exist — an image stem has no input gradient, the weight gradient is dy's only consumer
+ * (src/models/backbones/det/yolov5_csp_darknet.py:38-45 under trainer.py:189). x: bf16 NHWC 8-channel image, or x_nchw: the fp32 NCHW
+ * batch (cvhip_conv_fuse.x_image). (sum du, sum du*xhat) are taken from `acc`; dgamma / dbeta are stored (accumulate != 0: added).
+ * dw = [K][R*S][8] fp32, ACCUMULATED. CVHIP_ERR_UNSUPPORTED unless cvhip_conv_stem_blocks(d) > 0. */
+int cvhip_conv2d_wgrad_stem_bn(const cvhip_conv_desc* d, const void* x, const float* x_nchw, int32_t planes, const void* dz, const void* y,
+                               const float* scale, const float* shift, const float* mean, const float* invstd, const double* acc, int32_t acc_ld,
+                               float* dgamma_out, float* dbeta_out, int32_t accumulate, int32_t act, float act_param, float* dw, void* stream);
 /* 1 when cvhip_conv2d_fprop_fused accepts a prologue (and, with_z_out != 0, the z_out side output) for this descriptor */
 int cvhip_conv2d_fprop_prologue_ok(const cvhip_conv_desc* d, int with_z_out);
 /* (round 5) 1 when the STREAMING 1x1 kernel runs this fprop descriptor (with_stats != 0: with training-mode BatchNorm sums) and takes

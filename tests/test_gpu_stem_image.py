@@ -127,3 +127,49 @@ def test_stem_wgrad_falls_back_when_the_stem_kernel_refuses(monkeypatch):
     a, b = run(False), run(True)
     rel = float((a - b).norm() / a.norm())
     assert rel <= 2e-3, rel     # the image path rounds the fp32 pixels to 16 bits exactly like the conversion pass: same operands
+
+
+@pytest.mark.parametrize("k,s,pad,act", [(6, 2, 2, "SiLU"), (3, 2, 1, "ReLU"), (3, 1, 1, "SiLU")])
+def test_stem_wgrad_with_bn_backward_on_load_equals_apply_pass(k, s, pad, act):
+    """Round 5: the image stem's weight gradient taken straight from dz (cvhip_conv2d_wgrad_stem_bn: BN + activation backward applied on
+    load, no apply pass, no dy tensor) == apply pass + plain stem weight gradient. Same fp32 sums; dy is formed as sc*du + b1*y + c1
+    instead of sc*(du - k1 - xhat*k2), so single values may round to the neighbouring 16-bit number: dW rel-L2 <= 3e-3 (the fused 1x1
+    backward's own bound), dgamma / dbeta identical (both read the same accumulator)."""
+    import torch
+    from cvpytorch_amd import bricks, lib as L, ops
+    d = torch.device("cuda:0")
+    torch.manual_seed(6)
+    m = bricks.HipConvModule(3, 32, k, s, pad, norm_cfg=dict(type="BN"), act_cfg=dict(type=act)).to(d).train()
+    with torch.no_grad():
+        m.bn.weight.uniform_(0.5, 1.5)
+        m.bn.bias.normal_(0, 0.2)
+    N, H = (8, 256) if s == 2 else (8, 128)
+    x = torch.rand(N, 3, H, H, device=d)
+    P = (H + 2 * pad - k) // s + 1
+    g = (torch.randn(N, 32, P, P, device=d) * 0.1).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    calls = []
+    real = L.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return real(name, *a)
+
+    out = {}
+    try:
+        L.call = spy
+        for flag in (False, True):
+            ops._STEM_BN = flag
+            calls.clear()
+            for p_ in m.parameters():
+                p_.grad = None
+            m(x).backward(g)
+            torch.cuda.synchronize()
+            out[flag] = (m.conv.weight.grad.float().clone(), m.bn.weight.grad.float().clone(), m.bn.bias.grad.float().clone(), list(calls))
+    finally:
+        L.call = real
+        ops._STEM_BN = True
+    assert "cvhip_conv2d_wgrad_stem_bn" in out[True][3] and "cvhip_bn_act_bwd_apply_acc" not in out[True][3]
+    assert "cvhip_conv2d_wgrad_stem_bn" not in out[False][3] and "cvhip_bn_act_bwd_apply_acc" in out[False][3]
+    rel = lambda a, b: float((a - b).norm() / b.norm())  # noqa: E731
+    assert rel(out[True][0], out[False][0]) <= 3e-3, rel(out[True][0], out[False][0])
+    assert torch.equal(out[True][1], out[False][1]) and torch.equal(out[True][2], out[False][2])
