@@ -31,6 +31,11 @@ for (N, Cc, H, W, K, R, s) in SHAPES:
     dw = torch.zeros(K, R, R, Cc, device=dev)
     desc = ops.conv_desc(N, Cc, H, W, K, R, R, (s, s), (p, p), (1, 1), 1, Cc, K)
     fn = lambda: L.call("cvhip_conv2d_wgrad", C.byref(desc), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), 1, st)  # noqa: E731
+    if os.environ.get("WG_DET") == "1":   # the slab + ordered-fold form (no floating-point atomics): cvhip_conv2d_wgrad_det
+        nb = int(L.load().cvhip_conv2d_wgrad_det_workspace_bytes(C.byref(desc)))
+        ws = torch.empty((max(nb, 16),), dtype=torch.uint8, device=dev)
+        fn = lambda: L.call("cvhip_conv2d_wgrad_det", C.byref(desc), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), 1, ws.data_ptr(), nb, st)  # noqa: E731
+        tag = "DET"
     for _ in range(3):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
