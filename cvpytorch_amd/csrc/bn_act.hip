@@ -28,9 +28,16 @@ static inline int colreduce_rows_host(int64_t M, int32_t C) {
 }
 
 // MODE 0: (sum x, sum x^2)          MODE 1: (sum du, sum du*xhat)       MODE 2: (sum x, -)
+// MODE 3 (round 5): the residual TAIL z = act(bn(y) + identity) of a ResNet bottleneck (torchvision Bottleneck.forward, reached through
+// src/models/backbones/seg/resnet.py:91-94): du = dz * act'(z) from the saved OUTPUT z is computed, STORED (the identity branch's
+// gradient) and reduced to the BatchNorm-backward sums (sum du, sum du*xhat) in ONE pass — read dz, read z, read y, write du — instead
+// of an apply pass (read dz, read z, write du) followed by a reduction pass (read du, read y)
 struct RedParams {
-  const h16_t* a;   // x (mode 0/2) or dz (mode 1)
-  const h16_t* y;   // conv output (mode 1)
+  const h16_t* a;   // x (mode 0/2) or dz (mode 1/3)
+  const h16_t* y;   // conv output (mode 1/3)
+  const h16_t* z;   // mode 3: the layer's saved output
+  h16_t* du;        // mode 3: dz * act'(z), stored
+  int ld_z, ld_du;
   int ld_a, ld_y;
   int64_t M;
   int C;
@@ -49,7 +56,8 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const RedParams p) {
   __shared__ float red[256 * 16];
   const int t = threadIdx.x;
   const int CV = (p.C + 7) >> 3;  // 16-B column vectors (C % 8 == 0 on the fast path)
-  const bool vec = (p.C & 7) == 0 && (p.ld_a & 7) == 0 && (MODE != 1 || (p.ld_y & 7) == 0) &&
+  const bool vec = (p.C & 7) == 0 && (p.ld_a & 7) == 0 && ((MODE != 1 && MODE != 3) || (p.ld_y & 7) == 0) &&
+                   (MODE != 3 || ((p.ld_z & 7) == 0 && (p.ld_du & 7) == 0 && (((uintptr_t)p.z | (uintptr_t)p.du) & 15) == 0)) &&
                    (((uintptr_t)p.a | (uintptr_t)p.y) & 15) == 0;
   const int cols_per_pass = CV < 256 ? CV : 256;
   const int rows_per_pass = 256 / cols_per_pass;
@@ -70,7 +78,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const RedParams p) {
     fill8c(0.f, sh);
     fill8c(0.f, mu);
     fill8c(1.f, is);
-    if (MODE == 1) {
+    if (MODE == 1 || MODE == 3) {
       const int cc = (cv < CV ? cv : CV - 1) * 8;
       if (p.scale) {  // uniform: scale/shift come together, mean/invstd come together
         load8c(p.scale, cc, p.C, sc);
@@ -90,6 +98,11 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const RedParams p) {
             s2[j] += a.v[j] * a.v[j];
           } else if (MODE == 2) {
             s1[j] += a.v[j];
+          } else if (MODE == 3) {
+            // a = du (already masked and rounded to 16 bits by the caller below): the BatchNorm branch has no activation of its own
+            const float xh = (y.v[j] - mu[j]) * is[j];
+            s1[j] += a.v[j];
+            s2[j] += a.v[j] * xh;
           } else {
             const float u = y.v[j] * sc[j] + sh[j];
             const float du = a.v[j] * act_bwd(u, ACT, p.ap);
@@ -109,7 +122,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const RedParams p) {
         // VGPRs, no gain on the backward passes: they are co-limited by the quarter-rate v_exp_f32 / v_rcp_f32 of the SiLU derivative.)
         const int64_t stp = rows_per_pass;
         for (; r < r_end; r += 4 * stp) {
-          uint4 ua[4], uy[4];
+          uint4 ua[4], uy[4], uz[MODE == 3 ? 4 : 1];
           bool ok[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -117,7 +130,8 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const RedParams p) {
             ok[q] = rq < r_end;
             const int64_t rc = ok[q] ? rq : r;
             ua[q] = *reinterpret_cast<const uint4*>(p.a + rc * p.ld_a + cv * 8);
-            if (MODE == 1) uy[q] = *reinterpret_cast<const uint4*>(p.y + rc * p.ld_y + cv * 8);
+            if (MODE == 1 || MODE == 3) uy[q] = *reinterpret_cast<const uint4*>(p.y + rc * p.ld_y + cv * 8);
+            if constexpr (MODE == 3) uz[q] = *reinterpret_cast<const uint4*>(p.z + rc * p.ld_z + cv * 8);
           }
           // every load of the trip is issued before any arithmetic: without the fence hipcc's scheduler sinks the loads of rows
           // 1..3 below the arithmetic of row 0 (fewer live registers) and waits vmcnt(0) after each — one row in flight per lane
@@ -125,7 +139,18 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const RedParams p) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             if (!ok[q]) ua[q] = make_uint4(0u, 0u, 0u, 0u);  // x = 0 / dz = 0: no contribution to either sum
-            accum(unpack8(ua[q]), MODE == 1 ? unpack8(uy[q]) : f32x8{});
+            if constexpr (MODE == 3) {
+              // du = dz * act'(z), rounded to 16 bits (what the stand-alone apply pass stores and the reduction pass then reads)
+              f32x8 d = unpack8(ua[q]);
+              const f32x8 zz = unpack8(uz[q]);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) d.v[j] *= act_bwd(zz.v[j], ACT, p.ap);
+              const uint4 packed = pack8(d);
+              if (ok[q]) *reinterpret_cast<uint4*>(p.du + (r + q * stp) * p.ld_du + cv * 8) = packed;
+              accum(unpack8(packed), unpack8(uy[q]));
+            } else {
+              accum(unpack8(ua[q]), MODE == 1 ? unpack8(uy[q]) : f32x8{});
+            }
           }
         }
       }
@@ -135,7 +160,14 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const RedParams p) {
         for (int j = 0; j < 8; ++j) {
           const int c = cv * 8 + j;
           a.v[j] = c < p.C ? (float)p.a[r * p.ld_a + c] : 0.f;
-          if (MODE == 1) y.v[j] = c < p.C ? (float)p.y[r * p.ld_y + c] : 0.f;
+          if (MODE == 1 || MODE == 3) y.v[j] = c < p.C ? (float)p.y[r * p.ld_y + c] : 0.f;
+          if constexpr (MODE == 3) {
+            if (c < p.C) {
+              const h16_t dq = (h16_t)(a.v[j] * act_bwd((float)p.z[r * p.ld_z + c], ACT, p.ap));
+              p.du[r * p.ld_du + c] = dq;
+              a.v[j] = (float)dq;
+            }
+          }
         }
         accum(a, y);
       }
@@ -1008,6 +1040,38 @@ int cvhip_bn_act_bwd_sums_acc(const void* dz, int32_t ld_dz, const void* y, int3
   const int rows = colreduce_rows_host(M, C);
   CVHIP_LAUNCH_ACT(colreduce_kernel, 1, act, dim3(rows), (hipStream_t)stream, p)
   return check_launch("colreduce_kernel(acc)");
+}
+
+int cvhip_bn_tail_bwd_sums_acc(const void* dz, int32_t ld_dz, const void* z_out, int32_t ld_z, const void* y, int32_t ld_y, void* du, int32_t ld_du,
+                               int64_t M, int32_t C, const float* mean, const float* invstd, int32_t act, float act_param, double* acc,
+                               int32_t acc_ld, void* stream) {
+  if (!dz || !z_out || !y || !du || !mean || !invstd || !acc || M < 0 || C <= 0 || acc_ld < C) return CVHIP_ERR_INVALID;
+  if (act != CVHIP_ACT_NONE && act != CVHIP_ACT_RELU && act != CVHIP_ACT_LEAKY) return CVHIP_ERR_UNSUPPORTED;  // act'(z) from the OUTPUT's sign
+  if (M == 0) return CVHIP_OK;
+  RedParams p{};
+  p.a = (const h16_t*)dz;
+  p.ld_a = ld_dz;
+  p.y = (const h16_t*)y;
+  p.ld_y = ld_y;
+  p.z = (const h16_t*)z_out;
+  p.ld_z = ld_z;
+  p.du = (h16_t*)du;
+  p.ld_du = ld_du;
+  p.M = M;
+  p.C = C;
+  p.mean = mean;
+  p.invstd = invstd;
+  p.act = act;
+  p.ap = act_param;
+  p.acc = acc;
+  p.acc_ld = acc_ld;
+  const int rows = colreduce_rows_host(M, C);
+  switch (act) {
+    case CVHIP_ACT_RELU: hipLaunchKernelGGL((colreduce_kernel<3, CVHIP_ACT_RELU>), dim3(rows), dim3(256), 0, (hipStream_t)stream, p); break;
+    case CVHIP_ACT_LEAKY: hipLaunchKernelGGL((colreduce_kernel<3, CVHIP_ACT_LEAKY>), dim3(rows), dim3(256), 0, (hipStream_t)stream, p); break;
+    default: hipLaunchKernelGGL((colreduce_kernel<3, CVHIP_ACT_NONE>), dim3(rows), dim3(256), 0, (hipStream_t)stream, p); break;
+  }
+  return check_launch("colreduce_kernel<3>(acc)");
 }
 
 int cvhip_bn_act_fwd_acc(const void* y, int32_t ld_y, void* z, int32_t ld_z, int64_t M, int32_t C, const double* acc, int32_t acc_ld,

@@ -146,6 +146,7 @@ SIGNATURES = {
     "cvhip_bn_act_fwd_acc": (_i32, [_p, _i32, _p, _i32, _i64, _i32, _p, _i32, _i64, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _i32, _f32, _p, _i32,
                              _i32, _p]),
     "cvhip_bn_act_bwd_sums_acc": (_i32, [_p, _i32, _p, _i32, _i64, _i32, _p, _p, _p, _p, _i32, _f32, _p, _i32, _p]),
+    "cvhip_bn_tail_bwd_sums_acc": (_i32, [_p, _i32, _p, _i32, _p, _i32, _p, _i32, _i64, _i32, _p, _p, _i32, _f32, _p, _i32, _p]),
     "cvhip_bn_act_bwd_apply_acc": (_i32, [_p, _i32, _p, _i32, _p, _i32, _i64, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _i32, _f32, _p]),
     "cvhip_conv1x1_bwd_fused_acc": (_i32, [_dp, _p, _i32, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _i32, _f32, _p, _i32,
                                     _p, _i32, _p, _p, _p]),

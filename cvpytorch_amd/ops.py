@@ -824,6 +824,7 @@ def _materialize_tmp(x, x_ld, lz):
     return z
 
 
+_TAIL_MERGE = __import__("os").environ.get("CVHIP_TAIL_MERGE", "1") != "0"   # 0: residual tails as mask pass + reduction pass (A/B switch)
 _STEM_BN = __import__("os").environ.get("CVHIP_STEM_BN", "1") != "0"   # 0: apply pass + plain stem weight gradient (A/B switch)
 
 
@@ -1278,14 +1279,23 @@ class ConvBnAct(torch.autograd.Function):
         st = _stream()
         dz, dz_ld = as_nhwc(dz)
         act, act_param = cfg.act, cfg.act_param
+        tail_sums_done = False
         if ctx.res_pre:
             # z = act(bn(y) + r): first du = dz * act'(z) from the saved output (shared by the BN branch and the residual),
             # then the BN backward below sees a layer WITHOUT activation
             x, y, stats, weight, zout = ctx.saved_tensors
             zout, z_ld = as_nhwc(zout)
             du = empty_nhwc(N, K, P, Q, x.device)
-            L.call("cvhip_bn_act_bwd_apply", dz.data_ptr(), dz_ld, zout.data_ptr(), z_ld, du.data_ptr(), K, M, K, None, None, None, None,
-                   None, None, act, act_param, st)
+            acc_t = ctx.acc_b if ctx.train_bn else None
+            if (_TAIL_MERGE and acc_t is not None and not getattr(ctx, "_acc_b_used", False) and Kp == K and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LEAKY)
+                    and dz_ld % 8 == 0 and z_ld % 8 == 0 and dz.data_ptr() % 16 == 0 and zout.data_ptr() % 16 == 0):
+                # round 5: the mask pass and the BN-backward reduction in ONE pass (read dz, z, y; write du; sums into the accumulator)
+                _timed_ew("bn_tail_bwd_sums(colreduce_kernel<3>)", 8.0 * M * K, "cvhip_bn_tail_bwd_sums_acc", dz.data_ptr(), dz_ld, zout.data_ptr(), z_ld,
+                          y.data_ptr(), Kp, du.data_ptr(), K, M, K, stats[0].data_ptr(), stats[1].data_ptr(), act, act_param, acc_t.data_ptr(), K, st)
+                tail_sums_done = True
+            else:
+                L.call("cvhip_bn_act_bwd_apply", dz.data_ptr(), dz_ld, zout.data_ptr(), z_ld, du.data_ptr(), K, M, K, None, None, None, None,
+                       None, None, act, act_param, st)
             dz, dz_ld, act = du, K, L.ACT_NONE
         else:
             x, y, stats, weight = ctx.saved_tensors
@@ -1314,6 +1324,8 @@ class ConvBnAct(torch.autograd.Function):
             if have == "dirty":
                 zero_fill(acc_b)
                 have = False
+            if tail_sums_done:
+                have = True   # (the residual-tail pass above reduced while it masked)
             if not have:
                 _timed_ew("bn_act_bwd_sums(colreduce_kernel<1>)", 4.0 * M * K, "cvhip_bn_act_bwd_sums_acc", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, M, K,
                           stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), act, act_param, acc_b.data_ptr(), K, st)

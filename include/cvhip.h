@@ -650,6 +650,13 @@ int cvhip_bn_act_fwd_acc(const void* y, int32_t ld_y, void* z, int32_t ld_z, int
 int cvhip_bn_act_bwd_sums_acc(const void* dz, int32_t ld_dz, const void* y, int32_t ld_y, int64_t M, int32_t C, const float* scale,
                               const float* shift, const float* mean, const float* invstd, int32_t act, float act_param, double* acc,
                               int32_t acc_ld, void* stream);
+/* (round 5) residual TAIL z = act(bn(y) + identity) of a ResNet bottleneck (torchvision Bottleneck.forward through
+ * src/models/backbones/seg/resnet.py:91-94): du = dz * act'(z_out) is STORED (it is the identity branch's gradient and the input of
+ * the layer's BN backward) and (sum du, sum du*xhat) are added to `acc`, in one pass over (dz, z_out, y) — what cvhip_bn_act_bwd_apply
+ * on z_out followed by cvhip_bn_act_bwd_sums_acc (activation none) computes in two. none / ReLU / LeakyReLU. */
+int cvhip_bn_tail_bwd_sums_acc(const void* dz, int32_t ld_dz, const void* z_out, int32_t ld_z, const void* y, int32_t ld_y, void* du, int32_t ld_du,
+                               int64_t M, int32_t C, const float* mean, const float* invstd, int32_t act, float act_param, double* acc,
+                               int32_t acc_ld, void* stream);
 /* dy from (dz, y) with the two sums taken from `acc`; block 0 stores (accumulate != 0: adds) dgamma / dbeta (either may be NULL) */
 int cvhip_bn_act_bwd_apply_acc(const void* dz, int32_t ld_dz, const void* y, int32_t ld_y, void* dy, int32_t ld_dy, int64_t M, int32_t C,
                                const float* scale, const float* shift, const float* mean, const float* invstd, const double* acc,
