@@ -6,7 +6,7 @@
 TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
-PARTS=${PARTS:-"bench stats y5s deeplab infer pmc sq cache rotate"}
+PARTS=${PARTS:-"bench stats y5s deeplab yolox yolov7 infer pmc sq cache rotate"}
 mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 has() { [[ " $PARTS " == *" $1 "* ]]; }
 stats_csv() { find $1 -name "*kernel_stats.csv" | head -1; }
@@ -26,6 +26,16 @@ if has deeplab; then
   rm -rf /tmp/p_dl; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_dl -- python $R/tools/prof_deeplab.py > /dev/null 2>&1
   cp $(stats_csv /tmp/p_dl) $O/${TAG}_deeplabv3plus_bs16_kernel_stats.csv
   python $R/tools/trace_gaps.py /tmp/p_dl > $O/${TAG}_step_trace_deeplab_one_replay.txt 2>&1
+fi
+if has yolox; then
+  rm -rf /tmp/p_yx; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_yx -- python $R/tools/prof_extra.py yolox > $O/${TAG}_yoloxs_run.log 2>&1
+  cp $(stats_csv /tmp/p_yx) $O/${TAG}_yoloxs_bs64_kernel_stats.csv
+  python $R/tools/trace_gaps.py /tmp/p_yx > $O/${TAG}_step_trace_yoloxs_one_replay.txt 2>&1
+fi
+if has yolov7; then
+  rm -rf /tmp/p_y7; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_y7 -- python $R/tools/prof_extra.py yolov7 > $O/${TAG}_yolov7l_run.log 2>&1
+  cp $(stats_csv /tmp/p_y7) $O/${TAG}_yolov7l_fp16_bs16_kernel_stats.csv
+  python $R/tools/trace_gaps.py /tmp/p_y7 > $O/${TAG}_step_trace_yolov7l_one_replay.txt 2>&1
 fi
 if has infer; then
   rm -rf /tmp/p_inf; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_inf -- python $R/tools/prof_infer.py > $O/${TAG}_infer_run.log 2>&1
