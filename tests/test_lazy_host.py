@@ -1,0 +1,83 @@
+"""Host-side logic of the lazy-activation path (round 5), no GPU needed: the admission policy is pure arithmetic inside libcvhip
+(cvhip_conv1x1_stream_prologue_ok / cvhip_conv1x1_bwd_fused_ok) + ops.lazy_edge_ok; argument validation of the prologue range happens
+before any launch. Reference call site: ConvModule.forward, src/models/bricks/conv_module.py:201-214 (training mode)."""
+import ctypes as C
+
+import pytest
+import torch  # noqa: F401  (one HIP runtime per process: torch first)
+
+from cvpytorch_amd import lib as L
+from cvpytorch_amd import ops
+
+
+def desc(N, Cc, H, W, K):
+    return L.ConvDesc(N, Cc, H, W, K, 1, 1, 1, 1, 0, 0, 1, 1, 1, Cc, K, 0, 0)
+
+
+def test_struct_layouts_match_the_header():
+    # cvhip_conv_fuse grew two int32 members at its END (older members keep their offsets); cvhip_lazy_in is 2 pointers + 4 x 32 bit
+    assert C.sizeof(L.ConvFuse) == 128 and L.ConvFuse.pro_lo.offset == 116 and L.ConvFuse.pro_hi.offset == 120
+    assert L.ConvFuse.x_image_planes.offset == 112
+    assert C.sizeof(L.LazyIn) == 32 and L.LazyIn.c_hi.offset == 28
+
+
+def test_policy_on_the_yolov5s_edges_at_batch_64():
+    """which producer -> consumer edges of YOLOv5-s (batch 64, 640 x 640) stay lazy: 64- and 128-channel inputs of 1x1 layers whose forward
+    is the streaming kernel and whose backward is the fused kernel (>= 2400 64-row trips); never 32-channel SiLU inputs (measured loss),
+    never K > 128 (implicit GEMM / three-pass backward), never the small maps"""
+    ok = lambda *a: ops.lazy_edge_ok(*a, L.ACT_SILU)  # noqa: E731
+    assert ok(64, 64, 160, 160, 64)          # stride-2 conv -> CSP1 sibling pair
+    assert ok(64, 128, 80, 80, 128)          # stride-2 conv -> CSP2 sibling pair
+    assert ok(64, 64, 80, 80, 64)            # CSP2 / neck first sibling -> bottleneck conv1
+    assert not ok(64, 32, 160, 160, 32)      # CSP1 first sibling -> bottleneck conv1: 32-channel SiLU edge, excluded by measurement
+    assert ops.lazy_edge_ok(64, 32, 160, 160, 32, L.ACT_RELU)   # ... the same edge with ReLU (1 VALU instruction) is admitted
+    assert not ok(64, 256, 40, 40, 256)      # CSP3 pair: K > 128
+    assert not ok(64, 128, 40, 40, 128)      # 1600 trips: the fused backward's policy says three-pass
+    assert not ok(4, 64, 32, 32, 64)         # smoke-sized maps: neither kernel's policy takes them
+    assert not ok(64, 60, 160, 160, 64)      # channel count not a multiple of 8
+    assert not ops.lazy_edge_ok(64, 64, 160, 160, 64, L.ACT_HSWISH)   # activation without an on-load instance
+
+
+def test_policy_respects_the_global_switches(monkeypatch):
+    assert ops.lazy_edge_ok(64, 64, 160, 160, 64, L.ACT_SILU)
+    monkeypatch.setattr(ops, "_LAZY", False)
+    assert not ops.lazy_edge_ok(64, 64, 160, 160, 64, L.ACT_SILU)
+    monkeypatch.setattr(ops, "_LAZY", True)
+    monkeypatch.setattr(ops, "_DETERMINISTIC", True)
+    assert not ops.lazy_edge_ok(64, 64, 160, 160, 64, L.ACT_SILU)
+
+
+def test_prologue_argument_validation_happens_before_any_launch():
+    lib = L.load()
+    buf = (C.c_char * 8192)()
+    a = (C.addressof(buf) + 63) // 64 * 64
+    d = desc(4, 64, 80, 80, 64)
+    assert lib.cvhip_conv1x1_stream_prologue_ok(C.byref(d), 1) == 1 and lib.cvhip_conv1x1_stream_prologue_ok(C.byref(d), 0) == 1
+    for lo, hi in ((4, 60), (0, 72), (32, 32), (-8, 8)):
+        f = L.ConvFuse()
+        f.pro_scale, f.pro_shift, f.pro_act, f.pro_lo, f.pro_hi = a, a, L.ACT_SILU, lo, hi
+        assert lib.cvhip_conv2d_fprop_fused(C.byref(d), a, a, a, C.byref(f), None) == L.ERR_INVALID, (lo, hi)
+    f = L.ConvFuse()
+    f.pro_lo, f.pro_hi = 0, 32                                   # a range without a prologue
+    assert lib.cvhip_conv2d_fprop_fused(C.byref(d), a, a, a, C.byref(f), None) == L.ERR_INVALID
+    for dd in (L.ConvDesc(2, 64, 40, 40, 64, 1, 1, 2, 2, 0, 0, 1, 1, 1, 64, 64, 0, 0), desc(1, 64, 16, 16, 64), desc(4, 64, 80, 80, 256)):
+        assert lib.cvhip_conv1x1_stream_prologue_ok(C.byref(dd), 1) == 0   # strided; too few tiles; 256-wide with BN sums: no on-load form
+    li = L.LazyIn(a, a, L.ACT_SIGMOID, 0.0, 0, 0)                  # an activation the fused backward has no on-load instance for
+    big = desc(64, 64, 80, 80, 64)
+    st = lib.cvhip_conv1x1_bwd_fused_lazy(C.byref(big), a, 64, None, 0, 64, a, a, a, a, a, a, a, a, 64, None, None, 0, L.ACT_SILU, 0.0, None, 0, a, 64,
+                                          a, C.byref(li), None)
+    assert st == L.ERR_UNSUPPORTED
+    k256 = desc(64, 64, 80, 80, 256)
+    li = L.LazyIn(a, a, L.ACT_SILU, 0.0, 0, 0)
+    st = lib.cvhip_conv1x1_bwd_fused_lazy(C.byref(k256), a, 256, None, 0, 256, a, a, a, a, a, a, a, a, 256, None, None, 0, L.ACT_SILU, 0.0, None, 0, a, 64,
+                                          a, C.byref(li), None)
+    assert st == L.ERR_UNSUPPORTED                                # K = 256 instances sit at their register budget: no lazy-input form
+
+
+def test_lazy_tensor_reaching_an_unaware_op_raises():
+    """a lazy tensor holds RAW convolution outputs: an op without an on-load transform must never read it silently"""
+    t = torch.zeros(1, 8, 2, 2).to(memory_format=torch.channels_last)
+    t._hip_lazy = ops.LazyAct(torch.ones(8), torch.zeros(8), L.ACT_SILU, 0.0)
+    with pytest.raises(L.CvhipError):
+        ops.as_nhwc(t)          # (raises for the CPU tensor first or for the tag: either way nothing reads it)
+    assert ops.lazy_of(t) is not None and ops.lazy_of(torch.zeros(1)) is None
