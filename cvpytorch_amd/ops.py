@@ -650,11 +650,12 @@ class GradLink:
     """One skip connection x -> (conv_a -> ... -> + x): carries the gradient of the identity branch from the op that performs the
     add (which returns None for that input, so autograd has nothing to accumulate) to conv_a's backward, whose dgrad kernel adds
     it in its epilogue. Created per forward call by the block that owns the skip connection; only when x requires grad."""
-    __slots__ = ("g", "ok")
+    __slots__ = ("g", "ok", "consumed")
 
     def __init__(self):
         self.g = None
         self.ok = False   # set by the consuming layer's forward once it is certain to run a dense dgrad on the unpadded input
+        self.consumed = False   # set when the consuming layer's backward has started (a gradient parked after that would be lost)
 
 
 def _check_out(out, N, K, P, Q):
@@ -1274,6 +1275,8 @@ class ConvBnAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz):
         cfg = ctx.cfg
+        if cfg.dx_link is not None:
+            cfg.dx_link.consumed = True   # (ParkGrad: gradients arriving from now on go back to autograd)
         N, Cc, H, W, K, R, S, P, Q, Kp, x_ld, Cg = ctx.geom
         M = N * P * Q
         st = _stream()
@@ -1944,6 +1947,46 @@ class Fanout(torch.autograd.Function):
 
 
 _FANOUT = __import__("os").environ.get("CVHIP_FANOUT", "1") != "0"   # 0: leave the gradient sums to autograd (A/B switch)
+_FANOUT_LINK = __import__("os").environ.get("CVHIP_FANOUT_LINK", "1") != "0"   # 0: every fan-out sums its gradients with cvhip_add2d (A/B switch)
+
+
+class ParkGrad(torch.autograd.Function):
+    """The SIDE alias of a two-consumer fan-out whose MAIN consumer is a Hip convolution (round 5): instead of summing the two arriving
+    gradients with an add pass (read, read, write), the side branch's gradient is parked in a GradLink and the main consumer's dgrad
+    kernel adds it in its epilogue (cvhip_conv2d_dgrad_add: one extra read). Correct for any execution order: if the main consumer's
+    backward has already started (link.consumed) — or it cannot fold an addend (link.ok unset) — the gradient is returned to autograd,
+    which sums it as usual. In the detectors the order is fixed by data dependence: the side consumers (neck concats, detect
+    convolutions) sit downstream of the main consumer's own outputs, so their gradients exist before its backward can run."""
+
+    @staticmethod
+    def forward(ctx, x, link):
+        ctx.link = link
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        link = ctx.link
+        if g is None or not link.ok or link.consumed or link.g is not None:
+            return g, None
+        link.g = g
+        return None, None
+
+
+def fanout_linked(x):
+    """(main alias, side alias or None, link) of a tensor with two consumers, the first of them a Hip conv module that takes
+    `dx_link=link`. Protocol: call the main consumer FIRST, then `side = fanout_side(x, side, link)` for the other one — the side
+    alias's autograd node is then the younger of the two, so whenever both are ready the engine parks the side gradient before the main
+    consumer's backward runs. link None (nothing records gradients, or CVHIP_FANOUT_LINK=0): the aliases of ops.fanout, whose backward
+    sums the two gradients with cvhip_add2d."""
+    if not (_FANOUT and _FANOUT_LINK and torch.is_grad_enabled() and x.requires_grad) or nhwc_ld(x) is None:
+        a, b2 = fanout(x, 2)
+        return a, b2, None
+    return x, None, GradLink()
+
+
+def fanout_side(x, side, link):
+    """the side alias of fanout_linked, to be called after the main consumer's forward"""
+    return side if link is None else ParkGrad.apply(x, link)
 
 
 def fanout(x, n=2):

@@ -169,12 +169,13 @@ class DownsamplingModule(nn.Module):
         self.down = ConvModule(c1, c1, 3, 2, 1, conv_cfg=conv_cfg, norm_cfg=norm_cfg, act_cfg=act_cfg)
         self.fuse = CSPLayer(c1 * 2, c2, n=layer, shortcut=False, norm_cfg=norm_cfg, act_cfg=act_cfg)
 
-    def forward(self, x, y):
+    def forward(self, x, y, dx_link=None):
+        """`dx_link`: x is the main alias of ops.fanout_linked — the side consumer's gradient rides into the stride-2 conv's dgrad"""
         if _CAT_INPLACE and x.is_cuda and y.dim() == 4:
             c1 = self.down.out_channels
             buf = ops.empty_nhwc(y.shape[0], c1 + y.shape[1], y.shape[2], y.shape[3], y.device)
-            return self.fuse(ops.cat([self.down(x, out=buf[:, :c1]), y], into=buf))   # only y is copied
-        return self.fuse(ops.cat([self.down(x), y]))
+            return self.fuse(ops.cat([self.down(x, out=buf[:, :c1], dx_link=dx_link), y], into=buf))   # only y is copied
+        return self.fuse(ops.cat([self.down(x, dx_link=dx_link), y]))
 
 
 class SPPF(nn.Module):

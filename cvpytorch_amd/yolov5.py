@@ -64,6 +64,7 @@ class YOLOv5CSPDarknet(nn.Module):
     def forward(self, x):
         x = self.stem(x)
         output = []
+        link, pending = None, None   # fan-out link of the previous stage's output (its neck-side gradient folds into this stage's stride-2 dgrad)
         for i in range(1, 5):
             stage = getattr(self, "stage%d" % i)
             # the stride-2 conv's result only feeds the CSP layer's two 1x1 siblings: it may stay lazy (ops.LazyAct)
@@ -73,13 +74,19 @@ class YOLOv5CSPDarknet(nn.Module):
                 s0 = stage[0]
                 ph, pw = (x.shape[2] + 2 * 1 - 3) // 2 + 1, (x.shape[3] + 2 * 1 - 3) // 2 + 1
                 lazy = ops.lazy_edge_ok(x.shape[0], s0.out_channels, ph, pw, csp.conv1.out_channels + csp.conv2.out_channels, ops.act_id_of(s0))
-            x = stage[0](x, lazy=lazy)
+            x_in = x
+            x = stage[0](x_in, lazy=lazy, dx_link=link)
+            if pending is not None:   # the previous stage's output also feeds the neck: its side alias, made after the main consumer ran
+                output.append(ops.fanout_side(pending[0], pending[1], link))
+                pending = None
+            link = None
             for m in list(stage)[1:]:
                 x = m(x)
             if i in self.out_stages:
-                if i < 4:   # feeds the next stage AND the neck: explicit fan-out (ops.Fanout sums the two gradients itself)
-                    x, keep = ops.fanout(x, 2)
-                    output.append(keep)
+                if i < 4:   # feeds the next stage AND the neck: explicit fan-out; the neck's gradient rides into the next stage's dgrad
+                    x_full = x
+                    x, keep, link = ops.fanout_linked(x_full)
+                    pending = (x_full, keep)
                 else:
                     output.append(x)
         return output if len(self.out_stages) > 1 else output[0]
@@ -104,10 +111,14 @@ class YOLOv5Neck(nn.Module):
         x3, x4, x5 = x
         x4_up, x4_t = self.up_1(x5, x4)
         x3_up, x3_t = self.up_2(x4_up, x3)
-        x3_up, x3_out = ops.fanout(x3_up, 2)      # -> down_1 and the detect head
-        x4_down = self.down_1(x3_up, x3_t)
-        x4_down, x4_out = ops.fanout(x4_down, 2)  # -> down_2 and the detect head
-        x5_down = self.down_2(x4_down, x4_t)
+        # x3_up -> down_1 (main consumer: folds the detect head's gradient into its stride-2 dgrad) and the detect head; same for x4_down
+        x3_full = x3_up
+        x3_up, x3_out, l3 = ops.fanout_linked(x3_full)
+        x4_full = self.down_1(x3_up, x3_t, dx_link=l3)
+        x3_out = ops.fanout_side(x3_full, x3_out, l3)
+        x4_down, x4_out, l4 = ops.fanout_linked(x4_full)
+        x5_down = self.down_2(x4_down, x4_t, dx_link=l4)
+        x4_out = ops.fanout_side(x4_full, x4_out, l4)
         return [x3_out, x4_out, x5_down]
 
 

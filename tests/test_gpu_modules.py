@@ -377,3 +377,51 @@ def test_resnet_tail_fused_into_bn_pass_equals_separate_add():
         assert rel_l2(a, b) < 6e-2
     for a, b in zip(res[True][3], res[False][3]):
         assert torch.equal(a, b)          # BN statistics come from the conv epilogue: identical
+
+
+@pytest.mark.parametrize("k,s", [(3, 2), (1, 1), (3, 1)])
+def test_fanout_link_folds_the_side_gradient_into_the_main_dgrad(k, s):
+    """Round 5: ops.fanout_linked — the side consumer's gradient is parked and added by the main consumer's dgrad epilogue
+    (cvhip_conv2d_dgrad_add; stride-2 3x3 = four interleaved parity classes) instead of by an add pass. The fused form adds in fp32
+    before the one 16-bit rounding (the add pass rounds twice): dx equal to one bf16 ulp of the sum (rel-L2 <= 4e-3), every parameter
+    gradient untouched."""
+    import torch
+    from cvpytorch_amd import bricks, ops
+    from cvpytorch_amd import lib as L
+    d = torch.device("cuda:0")
+    torch.manual_seed(8)
+    main = bricks.HipConvModule(64, 64, k, s, k // 2, norm_cfg=dict(type="BN"), act_cfg=dict(type="SiLU")).to(d).train()
+    side = bricks.HipConv2d(64, 24, 1).to(d)
+    x0 = torch.randn(4, 64, 40, 40, device=d).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    out = {}
+    calls = []
+    real = L.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return real(name, *a)
+
+    try:
+        L.call = spy
+        for flag in (False, True):
+            ops._FANOUT_LINK = flag
+            calls.clear()
+            for p_ in list(main.parameters()) + list(side.parameters()):
+                p_.grad = None
+            x = x0.clone().requires_grad_(True)
+            h = bricks.HipSiLU()(x)                      # a producer in front, so that x's consumers are engine ops on an engine tensor
+            a, b, link = ops.fanout_linked(h)
+            za = main(a, dx_link=link)
+            zb = side(ops.fanout_side(h, b, link))
+            (za.float().square().mean() + zb.float().square().mean()).backward()
+            torch.cuda.synchronize()
+            out[flag] = (x.grad.float().clone(), [p_.grad.float().clone() for p_ in list(main.parameters()) + list(side.parameters())], list(calls))
+    finally:
+        L.call = real
+        ops._FANOUT_LINK = True
+    assert "cvhip_add2d" in out[False][2] and "cvhip_add2d" not in out[True][2]
+    assert any(n in out[True][2] for n in ("cvhip_conv2d_dgrad_add", "cvhip_conv1x1_bwd_fused_acc", "cvhip_conv1x1_bwd_fused"))
+    e = float((out[True][0] - out[False][0]).norm() / out[False][0].norm())
+    assert e <= 4e-3, e
+    for u, v in zip(out[True][1], out[False][1]):
+        assert float((u - v).norm() / max(float(v.norm()), 1e-12)) <= 1e-3
