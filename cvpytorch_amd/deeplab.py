@@ -59,10 +59,15 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         # identity blocks: the skip connection's gradient is added in conv1's dgrad epilogue (ops.GradLink), not by autograd
         link = ops.GradLink() if (_GRAD_LINK and self.downsample is None and x.requires_grad and torch.is_grad_enabled()) else None
-        xd = x
+        xd, x_full = x, x
         if self.downsample is not None:
-            x, xd = ops.fanout(x, 2)   # conv1 and the projection shortcut both read x: explicit fan-out (no ATen accumulation add)
+            # conv1 and the projection shortcut both read x: explicit fan-out; round 5: the shortcut's gradient rides into conv1's dgrad
+            # epilogue (ops.fanout_linked) — the projection's backward runs right after the tail's, long before conv1's
+            x, xd, link = ops.fanout_linked(x_full)
         out = _cba(x, self.conv1, self.bn1, L.ACT_RELU, dx_link=link)
+        if self.downsample is not None:
+            xd = ops.fanout_side(x_full, xd, link)
+            link = None   # (not a skip-connection link: the tail below must not park the identity gradient in it)
         out = _cba(out, self.conv2, self.bn2, L.ACT_RELU)
         identity = x if self.downsample is None else _cba(xd, self.downsample[0], self.downsample[1], L.ACT_NONE)
         if _FUSE_TAIL:   # relu(bn3(conv3(out)) + identity) in conv3's own BN pass (one pass over the 4x-wide tensor less)
