@@ -56,7 +56,9 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x):
+    def forward(self, x, in_link=None):
+        """`in_link`: x is the main alias of an ops.fanout_linked in the caller (the stage output that also feeds the head): the side
+        consumer's gradient is folded into this block's projection-shortcut dgrad (projection blocks only; else the caller keeps it)"""
         # identity blocks: the skip connection's gradient is added in conv1's dgrad epilogue (ops.GradLink), not by autograd
         link = ops.GradLink() if (_GRAD_LINK and self.downsample is None and x.requires_grad and torch.is_grad_enabled()) else None
         xd, x_full = x, x
@@ -69,7 +71,7 @@ class Bottleneck(nn.Module):
             xd = ops.fanout_side(x_full, xd, link)
             link = None   # (not a skip-connection link: the tail below must not park the identity gradient in it)
         out = _cba(out, self.conv2, self.bn2, L.ACT_RELU)
-        identity = x if self.downsample is None else _cba(xd, self.downsample[0], self.downsample[1], L.ACT_NONE)
+        identity = x if self.downsample is None else _cba(xd, self.downsample[0], self.downsample[1], L.ACT_NONE, dx_link=in_link)
         if _FUSE_TAIL:   # relu(bn3(conv3(out)) + identity) in conv3's own BN pass (one pass over the 4x-wide tensor less)
             return _cba(out, self.conv3, self.bn3, L.ACT_RELU, residual=identity, res_pre=True, res_link=link)
         out = _cba(out, self.conv3, self.bn3, L.ACT_NONE)
@@ -126,12 +128,32 @@ class ResNet(nn.Module):
             x = _cba(x, self.stem[i], self.stem[i + 1], L.ACT_RELU)
         x = self.maxpool(x)
         output = []
+        link, pending = None, None
         for i in range(1, 5):
-            x = getattr(self, "layer%d" % i)(x)
+            blocks = list(getattr(self, "layer%d" % i))
+            # a stage output that also feeds the head: its head-side gradient folds into the next stage's first (projection) block
+            take = link is not None and blocks[0].downsample is not None
+            x_in = x
+            x = blocks[0](x_in, in_link=link) if take else blocks[0](x_in)
+            if pending is not None:
+                if take:
+                    output.append(ops.fanout_side(pending[0], pending[1], link))
+                else:   # (no projection block to fold into: the plain fan-out's summing alias)
+                    output.append(pending[1] if pending[1] is not None else pending[0])
+                pending = None
+            link = None
+            for blk in blocks[1:]:
+                x = blk(x)
             if i in self.out_stages and not self.classifier:
                 if i < 4:
-                    x, keep = ops.fanout(x, 2)   # feeds the next layer and the head
-                    output.append(keep)
+                    nxt = getattr(self, "layer%d" % (i + 1))[0]
+                    if getattr(nxt, "downsample", None) is not None:
+                        x_full = x
+                        x, keep, link = ops.fanout_linked(x_full)   # feeds the next layer and the head
+                        pending = (x_full, keep)
+                    else:
+                        x, keep = ops.fanout(x, 2)
+                        output.append(keep)
                 else:
                     output.append(x)
         if self.classifier:

@@ -379,7 +379,7 @@ def test_resnet_tail_fused_into_bn_pass_equals_separate_add():
         assert torch.equal(a, b)          # BN statistics come from the conv epilogue: identical
 
 
-@pytest.mark.parametrize("k,s", [(3, 2), (1, 1), (3, 1)])
+@pytest.mark.parametrize("k,s", [(3, 2), (1, 1), (3, 1), (1, 2)])
 def test_fanout_link_folds_the_side_gradient_into_the_main_dgrad(k, s):
     """Round 5: ops.fanout_linked — the side consumer's gradient is parked and added by the main consumer's dgrad epilogue
     (cvhip_conv2d_dgrad_add; stride-2 3x3 = four interleaved parity classes) instead of by an add pass. The fused form adds in fp32
