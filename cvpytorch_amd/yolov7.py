@@ -64,13 +64,18 @@ class DownA(nn.Module):
     def _branches(self, x, extra=0):
         """both branch results written straight into one concat buffer (plus `extra` trailing channels for DownB's y)"""
         c2 = self.branch1[1].out_channels
-        x, xb = ops.fanout(x, 2)   # the pool branch and the conv branch read x: explicit fan-out (ops.Fanout sums the two gradients)
+        # the pool branch and the conv branch read x: explicit fan-out. Round 5: the conv branch runs FIRST and is the main consumer
+        # (ops.fanout_linked) — the pool branch's gradient rides into its 1x1 conv's dgrad instead of an add pass
+        x_full = x
+        xb, xs, link = ops.fanout_linked(x_full)
+        h = self.branch2[0](xb, dx_link=link)
+        x = ops.fanout_side(x_full, xs, link)
         a = self.branch1[0](x)
         if not (x.is_cuda and c2 % 8 == 0 and extra % 8 == 0):
-            return None, self.branch1[1](a), self.branch2(xb)
+            return None, self.branch1[1](a), self.branch2[1](h)
         buf = ops.empty_nhwc(a.shape[0], 2 * c2 + extra, a.shape[2], a.shape[3], x.device)
+        b2 = self.branch2[1](h, out=buf[:, c2:2 * c2])
         b1 = self.branch1[1](a, out=buf[:, :c2])
-        b2 = self.branch2[1](self.branch2[0](xb), out=buf[:, c2:2 * c2])
         return buf, b1, b2
 
     def forward(self, x):
@@ -101,13 +106,16 @@ class EELAN(nn.Module):
         c2 = self.conv1.out_channels
         buf = ops.empty_nhwc(x.shape[0], 4 * c2, x.shape[2], x.shape[3], x.device) if (x.is_cuda and c2 % 8 == 0) else None
         x1, x2 = _siblings(self.conv1, self.conv2, x, self, out=None if buf is None else buf[:, :2 * c2])
-        x2, x2n = ops.fanout(x2, 2)   # x2 and x3 feed the concat AND the next pair of convs
-        if buf is None:
-            x3, x3n = ops.fanout(self.conv3(x2n), 2)
-            x4 = self.conv4(x3n)
-        else:
-            x3, x3n = ops.fanout(self.conv3[1](self.conv3[0](x2n), out=buf[:, 2 * c2:3 * c2]), 2)
-            x4 = self.conv4[1](self.conv4[0](x3n), out=buf[:, 3 * c2:])
+        # x2 and x3 feed the concat AND the next pair of convs: the concat-side gradient (a slice of conv5's input gradient, ready before
+        # anything upstream runs) rides into the next conv's dgrad (ops.fanout_linked) instead of an add pass
+        x2n, x2s, l2 = ops.fanout_linked(x2)
+        h3 = self.conv3[0](x2n, dx_link=l2)
+        x2 = ops.fanout_side(x2, x2s, l2)
+        t3 = self.conv3[1](h3) if buf is None else self.conv3[1](h3, out=buf[:, 2 * c2:3 * c2])
+        x3n, x3s, l3 = ops.fanout_linked(t3)
+        h4 = self.conv4[0](x3n, dx_link=l3)
+        x3 = ops.fanout_side(t3, x3s, l3)
+        x4 = self.conv4[1](h4) if buf is None else self.conv4[1](h4, out=buf[:, 3 * c2:])
         return self.conv5(ops.cat([x1, x2, x3, x4]))
 
 
@@ -143,18 +151,20 @@ class FeatureFusion(nn.Module):
             buf = ops.empty_nhwc(x.shape[0], 2 * c2 + 4 * mid, x.shape[2], x.shape[3], x.device)
             o = 2 * c2
             x1, x2 = _siblings(self.conv1, self.conv2, x, self, out=buf[:, :o])
-            x2, x2n = ops.fanout(x2, 2)   # every tensor of the chain feeds the concat AND the next conv
-            x3, x3n = ops.fanout(self.conv3(x2n, out=buf[:, o:o + mid]), 2)
-            x4, x4n = ops.fanout(self.conv4(x3n, out=buf[:, o + mid:o + 2 * mid]), 2)
-            x5, x5n = ops.fanout(self.conv4(x4n, out=buf[:, o + 2 * mid:o + 3 * mid]), 2)
-            x6 = self.conv4(x5n, out=buf[:, o + 3 * mid:])
+            outs = [buf[:, o:o + mid], buf[:, o + mid:o + 2 * mid], buf[:, o + 2 * mid:o + 3 * mid], buf[:, o + 3 * mid:]]
         else:
             x1, x2 = _siblings(self.conv1, self.conv2, x, self)
-            x2, x2n = ops.fanout(x2, 2)
-            x3, x3n = ops.fanout(self.conv3(x2n), 2)
-            x4, x4n = ops.fanout(self.conv4(x3n), 2)
-            x5, x5n = ops.fanout(self.conv4(x4n), 2)
-            x6 = self.conv4(x5n)
+            outs = [None] * 4
+        # every tensor of the chain feeds the concat AND the next conv: the concat-side gradient rides into that conv's dgrad
+        # (ops.fanout_linked; round 5) instead of an add pass per link of the chain
+        chain, t = [], x2
+        for conv, dst in zip((self.conv3, self.conv4, self.conv4, self.conv4), outs):
+            tn, ts, lk = ops.fanout_linked(t)
+            nxt = conv(tn, out=dst, dx_link=lk) if dst is not None else conv(tn, dx_link=lk)
+            chain.append(ops.fanout_side(t, ts, lk))
+            t = nxt
+        x2, x3, x4, x5 = chain
+        x6 = t
         return self.conv7(ops.cat([x1, x2, x3, x4, x5, x6]))
 
 
