@@ -60,12 +60,23 @@ class YOLOXCSPDarknet(nn.Module):
     def forward(self, x):
         x = self.stem(x)
         out = []
+        link, pending = None, None
         for i in range(1, 5):
-            x = getattr(self, "stage%d" % i)(x)
+            stage = list(getattr(self, "stage%d" % i))
+            # (round 5) a stage output that also feeds the neck: the neck-side gradient rides into the next stage's stride-2 dgrad
+            x_in = x
+            x = stage[0](x_in, dx_link=link)
+            if pending is not None:
+                out.append(ops.fanout_side(pending[0], pending[1], link))
+                pending = None
+            link = None
+            for m in stage[1:]:
+                x = m(x)
             if i in self.out_stages:
                 if i < 4:
-                    x, keep = ops.fanout(x, 2)   # feeds the next stage AND the neck (ops.Fanout sums the two gradients on the engine)
-                    out.append(keep)
+                    x_full = x
+                    x, keep, link = ops.fanout_linked(x_full)   # feeds the next stage AND the neck
+                    pending = (x_full, keep)
                 else:
                     out.append(x)
         return out if len(self.out_stages) > 1 else out[0]
@@ -152,9 +163,12 @@ class YOLOXNeck(nn.Module):
         outs = [inner[0]]
         heads = []
         for idx in range(n - 1):
-            o, o_head = ops.fanout(outs[-1], 2)                                        # -> the downsample and its out_conv
-            heads.append(o_head)
-            outs.append(self.bottom_up_blocks[idx](ops.cat([self.downsamples[idx](o), inner[idx + 1]])))
+            # -> the downsample (main consumer: folds the out_conv's gradient into its stride-2 dgrad) and its out_conv
+            o_full = outs[-1]
+            o, o_head, lk = ops.fanout_linked(o_full)
+            d = self.downsamples[idx](o, dx_link=lk)
+            heads.append(ops.fanout_side(o_full, o_head, lk))
+            outs.append(self.bottom_up_blocks[idx](ops.cat([d, inner[idx + 1]])))
         heads.append(outs[-1])
         return [conv(o) for conv, o in zip(self.out_convs, heads)]
 
@@ -187,9 +201,13 @@ class YOLOXHead(nn.Module):
     def forward(self, x):
         outs = []
         for k, xx in enumerate(x):
-            xc, xr = ops.fanout(xx, 2)                         # class tower and box tower
+            # class tower and box tower: the box tower runs first and is the main consumer (the class tower's gradient rides into its
+            # first 3x3 dgrad: ops.fanout_linked)
+            xr, xs, lk = ops.fanout_linked(xx)
+            reg = self.reg_convs[k][1:](self.reg_convs[k][0](xr, dx_link=lk))
+            xc = ops.fanout_side(xx, xs, lk)
             cls_feat = self.cls_convs[k](xc)
-            rf, of = ops.fanout(self.reg_convs[k](xr), 2)      # box and objectness predictors
+            rf, of = ops.fanout(reg, 2)      # box and objectness predictors
             outs.append(ops.cat([self.reg_preds[k](rf), self.obj_preds[k](of), self.cls_preds[k](cls_feat)]))
         return outs
 
