@@ -334,6 +334,15 @@ def _timed_call(kname, geom, fname, *args, passes=1, nbytes=None):
     flops = 2.0 * N * P * Q * K * R * S * Cc * passes
     if nbytes is None:
         nbytes = 2.0 * (N * H * W * Cc + N * P * Q * K + K * R * S * Cc)
+    if kname.startswith("igemm_kernel") and (fname.startswith("cvhip_conv2d_fprop") or fname.startswith("cvhip_conv2d_dgrad")):
+        # launch_igemm hands some multi-tap problems to the patch-resident kernel (conv_patch.hip): label those launches as what runs,
+        # so that a row of the bench line's kernel table is ONE device kernel family (as in rocprofv3's per-kernel statistics)
+        try:
+            buf = (C.c_int32 * (L.PATCH_CLASS_INTS * 4))()
+            if L.load().cvhip_conv2d_patch_plan(args[0], 1 if fname.startswith("cvhip_conv2d_dgrad") else 0, buf, 4) > 0:
+                kname = "conv_patch_kernel<128>"
+        except Exception:
+            pass
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     L.call(fname, *args)
