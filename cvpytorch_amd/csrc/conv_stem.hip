@@ -27,6 +27,23 @@ constexpr int kStemMaxPH = 3 * 2 + 7, kStemMaxPW = 63 * 2 + 7 + 1;  // R, S <= 7
 constexpr int kStemPatchBytes = kStemMaxPH * kStemMaxPW * 16;
 constexpr int kStemBlocks = 768;   // persistent grid (3 blocks per CU by LDS)
 
+// XCD-aware start tile of a persistent block (CVHIP_STEM_XCD=1; default OFF): hardware places block b on XCD b % 8; with the identity
+// mapping the vertically adjacent tiles (t, t + tiles_x) — which share R - stride input rows — run on different XCDs and each fetches
+// the shared rows into its own L2 (the stem kernels read 1.3 - 2.0x their algorithmic input bytes: profiles/r05_pmc_summary.txt).
+// Giving each XCD a contiguous chunk of the tile space makes them L2 neighbours. MEASURED, round 5 (VERDICT r04 task 7's question):
+// no gain — fprop 256 / 260 us -> 266 / 275 us, fused weight gradient 372 / 379 -> 359 / 383 us: the re-fetched halo rows come out of
+// the Infinity Cache, they are not what these (latency-bound, 3.3 TB/s) kernels wait for. An LDS row ring across vertically
+// consecutive tiles would remove the same bytes and was therefore not built.
+__device__ __forceinline__ int stem_first_tile(int xcd) { return xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x; }
+static int stem_xcd_mode() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CVHIP_STEM_XCD");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v;
+}
+
 struct StemParams {
   const h16_t* x;
   const float* xf;  // != NULL: fp32 NCHW image [NB][planes][IH][IW] instead of x (round 4: no layout / precision pass in front of the stem)
@@ -42,6 +59,7 @@ struct StemParams {
   float ep_ap;
   int NB, IH, IW, OH, OW, K, y_ld, R, S, pad_h, pad_w;
   int tiles_x, tiles_y, ntiles;
+  int xcd;  // XCD-aware start tile (stem_first_tile)
 };
 
 
@@ -180,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void stem_fprop_kernel(const StemParams p) 
 #pragma unroll
     for (int q = 0; q < 4; ++q) s1[a][q] = s2[a][q] = 0.f;
 
-  int tile = blockIdx.x;
+  int tile = stem_first_tile(p.xcd);
   if (tile < p.ntiles) {
     gload(tile);
     lstore(0);
@@ -322,6 +340,7 @@ struct StemWgradParams {
   float* dw;  // [K][R*S][8] fp32, accumulated with atomics
   int NB, IH, IW, OH, OW, K, dy_ld, R, S, pad_h, pad_w;
   int tiles_x, tiles_y, ntiles;
+  int xcd;  // XCD-aware start tile (stem_first_tile)
   // BNB instances (round 5): `dy` is dz, the gradient at the OUTPUT of the stem's Conv-BN-act layer; the BN + activation backward is
   // applied ON LOAD (dy = sc*du + b1*y + c1 with du = dz*act'(sc*y + sh), rounded to 16 bits as the stand-alone pass stores it), so the
   // apply pass (read dz, read y, write dy) and the dy tensor disappear — the image stem has no input gradient, the weight gradient is
@@ -548,7 +567,7 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const StemWgradParam
 #pragma unroll
     for (int j = 0; j < NFW; ++j) acc[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  int tile = blockIdx.x;
+  int tile = stem_first_tile(p.xcd);
   if (tile < p.ntiles) gload(tile);
   for (; tile < p.ntiles; tile += gridDim.x) {
     lstore();
@@ -670,6 +689,7 @@ int try_launch_stem(const IgemmParams& p, hipStream_t stream) {
   sp.tiles_x = cdiv(p.OW, kStemTW);
   sp.tiles_y = cdiv(p.OH, kStemTH);
   sp.ntiles = p.NB * sp.tiles_x * sp.tiles_y;
+  sp.xcd = stem_xcd_mode();
   int rc;
   if (sp.ep_scale || sp.ep_act != CVHIP_ACT_NONE)
     rc = p.in_sh == 2 ? launch_stem_steps<2, false, true>(sp, blocks, nstep, stream) : launch_stem_steps<1, false, true>(sp, blocks, nstep, stream);
@@ -703,6 +723,7 @@ int try_launch_stem_wgrad(const cvhip_conv_desc* d, const void* x, const void* d
   sp.tiles_x = cdiv(OW, kStemTW);
   sp.tiles_y = cdiv(OH, kStemTH);
   sp.ntiles = d->N * sp.tiles_x * sp.tiles_y;
+  sp.xcd = stem_xcd_mode();
   sp.y = nullptr;
   if (bn) {
     if (!bn->y || !bn->scale || !bn->shift || !bn->mean || !bn->invstd || !bn->acc || bn->acc_ld < d->K || (bn->y_ld & 7) || (((uintptr_t)bn->y) & 15)) return -1;
