@@ -342,6 +342,16 @@ int cvhip_conv2d_fprop_fused(const cvhip_conv_desc* d, const void* x, const void
   p.z_ld = f->z_ld;
   p.pro_lo = f->pro_lo;
   p.pro_hi = f->pro_hi > 0 ? f->pro_hi : d->C;
+  if (f->y2) {
+    if (f->residual || f->z_out || f->x_image) return CVHIP_ERR_INVALID;
+    // two non-empty halves made of whole 16-byte channel vectors, both destinations vector-aligned
+    if (f->y_split <= 0 || f->y_split >= d->K || (f->y_split & 7) || (d->K & 7) || (f->y2_ld & 7) || f->y2_ld < d->K - f->y_split ||
+        (((uintptr_t)f->y2) & 15) || (((uintptr_t)y) & 15) || (d->y_ld & 7))
+      return CVHIP_ERR_INVALID;
+    p.y2 = (h16_t*)f->y2;
+    p.y2_ld = f->y2_ld;
+    p.y_split = f->y_split;
+  }
   if (f->residual) {
     if (f->residual_ld < d->K) return CVHIP_ERR_INVALID;
     p.res = (const h16_t*)f->residual;

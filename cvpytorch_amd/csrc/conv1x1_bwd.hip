@@ -36,6 +36,8 @@ struct Bwd1x1Params {
   int dz0_ld, dz1_ld, k_split;
   const h16_t* y;    // raw convolution output (pre-BN)
   int y_ld;
+  const h16_t* y1;   // (round 5, split store) channels [k_split, K) of the raw output when they live in another buffer; NULL: inside y
+  int y1_ld;
   const h16_t* x;    // layer input
   int x_ld;
   const h16_t* w;    // dgrad image [C][K]
@@ -142,7 +144,9 @@ __global__ __launch_bounds__(256, KB >= 256 ? 1 : 2) void bwd1x1_kernel(const Bw
   const bool seg1 = kv * 8 >= p.k_split;
   const h16_t* const dzp = seg1 ? p.dz1 + (kv * 8 - p.k_split) : p.dz0 + kv * 8;
   const int dz_ld = seg1 ? p.dz1_ld : p.dz0_ld;
-  const h16_t* const yp = p.y + kv * 8;
+  const bool ysplit = seg1 && p.y1 != nullptr;
+  const h16_t* const yp = ysplit ? p.y1 + (kv * 8 - p.k_split) : p.y + kv * 8;
+  const int yp_ld = ysplit ? p.y1_ld : p.y_ld;
   const h16_t* const xp = p.x + c0 + xv * 8;
 
   // per-channel constants of this thread's 8 channels: u = sc*y + sh; dy = sc*du + b1*y + c1
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(256, KB >= 256 ? 1 : 2) void bwd1x1_kernel(const Bw
       int m = m0 + i * D_PASS + drow;
       m = m < M ? m : 0;
       rd[i] = *reinterpret_cast<const uint4*>(dzp + (int64_t)m * dz_ld);
-      ry[i] = *reinterpret_cast<const uint4*>(yp + (int64_t)m * p.y_ld);
+      ry[i] = *reinterpret_cast<const uint4*>(yp + (int64_t)m * yp_ld);
     }
 #pragma unroll
     for (int i = 0; i < X_IT; ++i) {
@@ -551,7 +555,8 @@ static int bwd1x1_impl(const cvhip_conv_desc* d, const void* dz0, int32_t dz0_ld
                        const void* y, const void* x, const void* w_dgrad, const float* scale, const float* shift, const float* mean,
                        const float* invstd, const float* dgamma, const float* dbeta, const double* acc, int32_t acc_ld, float* o_dgamma,
                        float* o_dbeta, int32_t accumulate, int32_t act, float act_param, const void* addend, int32_t addend_ld, void* dx,
-                       int32_t dx_ld, float* dw, void* stream, const cvhip_bn_tail* tail = nullptr, const cvhip_lazy_in* xin = nullptr) {
+                       int32_t dx_ld, float* dw, void* stream, const cvhip_bn_tail* tail = nullptr, const cvhip_lazy_in* xin = nullptr,
+                       const void* y1 = nullptr, int32_t y1_ld = 0) {
   if (!d || !dz0 || !y || !x || !w_dgrad || !dx || !dw) return CVHIP_ERR_INVALID;
   if (xin) {
     if (!xin->scale || !xin->shift) return CVHIP_ERR_INVALID;
@@ -575,6 +580,13 @@ static int bwd1x1_impl(const cvhip_conv_desc* d, const void* dz0, int32_t dz0_ld
   p.k_split = k_split;
   p.y = (const h16_t*)y;
   p.y_ld = d->y_ld;
+  p.y1 = nullptr;
+  p.y1_ld = 0;
+  if (y1) {
+    if (k_split >= d->K || (y1_ld & 7) || (((uintptr_t)y1) & 15) || tail) return CVHIP_ERR_INVALID;
+    p.y1 = (const h16_t*)y1;
+    p.y1_ld = y1_ld;
+  }
   p.x = (const h16_t*)x;
   p.x_ld = d->x_ld;
   p.w = (const h16_t*)w_dgrad;
@@ -644,6 +656,17 @@ int cvhip_conv1x1_bwd_fused_acc(const cvhip_conv_desc* d, const void* dz0, int32
   if (!acc && mean) return CVHIP_ERR_INVALID;
   return bwd1x1_impl(d, dz0, dz0_ld, dz1, dz1_ld, k_split, y, x, w_dgrad, scale, shift, mean, invstd, nullptr, nullptr, acc, acc_ld, dgamma_out,
                      dbeta_out, accumulate, act, act_param, addend, addend_ld, dx, dx_ld, dw, stream, tail);
+}
+
+int cvhip_conv1x1_bwd_fused_split(const cvhip_conv_desc* d, const void* dz0, int32_t dz0_ld, const void* dz1, int32_t dz1_ld, int32_t k_split,
+                                  const void* y, const void* y1, int32_t y1_ld, const void* x, const void* w_dgrad, const float* scale,
+                                  const float* shift, const float* mean, const float* invstd, const double* acc, int32_t acc_ld,
+                                  float* dgamma_out, float* dbeta_out, int32_t accumulate, int32_t act, float act_param, const void* addend,
+                                  int32_t addend_ld, void* dx, int32_t dx_ld, float* dw, const cvhip_lazy_in* xin, void* stream) {
+  if (!acc && mean) return CVHIP_ERR_INVALID;
+  if (!y1) return CVHIP_ERR_INVALID;
+  return bwd1x1_impl(d, dz0, dz0_ld, dz1, dz1_ld, k_split, y, x, w_dgrad, scale, shift, mean, invstd, nullptr, nullptr, acc, acc_ld, dgamma_out,
+                     dbeta_out, accumulate, act, act_param, addend, addend_ld, dx, dx_ld, dw, stream, nullptr, xin, y1, y1_ld);
 }
 
 int cvhip_conv1x1_bwd_fused_lazy(const cvhip_conv_desc* d, const void* dz0, int32_t dz0_ld, const void* dz1, int32_t dz1_ld, int32_t k_split,

@@ -281,12 +281,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const IgemmKernA
           }
         }
         if (m < M) {
+          // split store: the channel vectors from y_split on belong to the second destination (8-aligned split: a vector never straddles)
+          h16_t* const dst = (p.y2 && ch0 >= p.y_split) ? p.y2 + (int64_t)m * p.y2_ld + (ch0 - p.y_split) : yrow + ch0;
           if (vec16 && ch0 + 7 < p.Nout) {
-            *reinterpret_cast<uint4*>(yrow + ch0) = pack8(v);
+            *reinterpret_cast<uint4*>(dst) = pack8(v);
           } else {
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-              if (ch0 + q < p.Nout) yrow[ch0 + q] = (h16_t)v.v[q];
+              if (ch0 + q < p.Nout) dst[q] = (h16_t)v.v[q];
           }
         }
       }
@@ -477,6 +479,9 @@ int try_launch_stream1x1(const IgemmParams& p, hipStream_t stream) {
   const int nf = s1x1_nf(p.Nout, p.Cin, p.stats != nullptr);
   if (p.stats && (p.ep_scale || p.ep_act != CVHIP_ACT_NONE)) return CVHIP_ERR_INVALID;
   if (p.z_out) return CVHIP_ERR_UNSUPPORTED;  // (the activated side output exists in the patch-resident kernel only)
+  if (p.y2 && ((p.y_split & 7) || p.y_split <= 0 || p.y_split >= p.Nout || (p.y2_ld & 7) || (((uintptr_t)p.y2) & 15) || (p.y_ld & 7) ||
+               (((uintptr_t)p.y) & 15) || (p.Nout & 7)))
+    return CVHIP_ERR_INVALID;
   if (p.pro_scale) {
     // lazy input: BN scale / shift + activation of the producing layer applied on load (training forms: raw output, optional BN sums)
     if (p.tail_y || p.ep_scale || p.ep_act != CVHIP_ACT_NONE || p.res || !stream1x1_prologue_ok(p, p.stats != nullptr)) return CVHIP_ERR_UNSUPPORTED;

@@ -1314,7 +1314,7 @@ int launch_igemm(IgemmParams& p, hipStream_t stream) {
   if (s1 >= 0) return s1;
   const int s2 = try_launch_patch(p, stream);  // multi-tap, Cin % 32 == 0: patch-resident implicit GEMM (conv_patch.hip)
   if (s2 != -1) return s2;
-  if (p.pro_scale || p.z_out) return CVHIP_ERR_UNSUPPORTED;  // a fused prologue exists in the patch kernel only
+  if (p.pro_scale || p.z_out || p.y2) return CVHIP_ERR_UNSUPPORTED;  // a prologue: patch / streaming kernels only; a split store: streaming kernel only
   if (narrow128() && !use_v1()) {
     if (p.Nout <= 32) return launch_cfg<128, 32, 32, 32>(p, stream);
     if (p.Nout <= 64) return launch_cfg<128, 64, 32, 64>(p, stream);

@@ -858,6 +858,7 @@ int patch_plan_export(const IgemmParams& p, int32_t* out, int max_classes, bool 
 // -1 = not taken (the caller runs the per-tap implicit GEMM). A plan that carries a fused prologue (pro_scale / z_out) can only run
 // here: CVHIP_ERR_UNSUPPORTED then, and the caller falls back to separate passes.
 int try_launch_patch(const IgemmParams& p, hipStream_t stream) {
+  if (p.y2) return -1;  // (split stores exist in the streaming 1x1 kernel only)
   const bool need = p.pro_scale || p.z_out;
   if (patch_mode() == 0 && !need) return -1;
   PatchPlan pl;

@@ -75,6 +75,10 @@ struct IgemmCommon {
   // (round 5) the streaming 1x1 kernel takes the same prologue (no z_out) on the input-channel range [pro_lo, pro_hi): the other
   // channels of x — slices of a concatenation that were materialised — pass through untouched
   int pro_lo, pro_hi;
+  // (round 5) SPLIT STORE of the streaming 1x1 kernel (sibling pairs): output channels [y_split, Nout) go to y2 (pitch y2_ld) instead of
+  // y — the second sibling's raw output lands straight in its channel slice of the concat buffer its consumer reads lazily
+  h16_t* y2;
+  int y2_ld, y_split;
   // image stems (conv_stem.hip only): the input is the dataloader's own tensor, fp32 NCHW [NB][x_planes][IH][IW] (x_planes <= 4 real
   // channels), read plane by plane and rounded to 16 bits on the way into the LDS patch — `x` is unused then
   const float* x_image;

@@ -661,6 +661,7 @@ static int launch_stem_steps(const StemParams& sp, int blocks, int nstep, hipStr
 
 // returns -1 when the problem is not taken (caller falls through to the general kernel)
 int try_launch_stem(const IgemmParams& p, hipStream_t stream) {
+  if (p.y2) return -1;
   if (p.ncls != 1 || p.out_sh != 1 || p.out_sw != 1) return -1;
   const IgemmClass& c = p.cls[0];
   if (c.out_oh != 0 || c.out_ow != 0 || c.OHi != p.OH || c.OWi != p.OW || c.dh0 > 0 || c.dw0 > 0) return -1;

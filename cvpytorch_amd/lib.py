@@ -51,7 +51,8 @@ class ConvFuse(C.Structure):
                 ("ep_shift", C.c_void_p), ("ep_act", C.c_int32), ("ep_act_param", C.c_float), ("pro_scale", C.c_void_p),
                 ("pro_shift", C.c_void_p), ("pro_act", C.c_int32), ("pro_act_param", C.c_float), ("z_out", C.c_void_p),
                 ("z_ld", C.c_int32), ("residual", C.c_void_p), ("residual_ld", C.c_int32), ("residual_pre", C.c_int32),
-                ("x_image", C.c_void_p), ("x_image_planes", C.c_int32), ("pro_lo", C.c_int32), ("pro_hi", C.c_int32)]
+                ("x_image", C.c_void_p), ("x_image_planes", C.c_int32), ("pro_lo", C.c_int32), ("pro_hi", C.c_int32),
+                ("y2", C.c_void_p), ("y2_ld", C.c_int32), ("y_split", C.c_int32)]
 
 
 class LazyIn(C.Structure):
@@ -118,6 +119,8 @@ SIGNATURES = {
     "cvhip_bn_finalize_acc": (_i32, [_p, _i32, _i32, _i64, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _p]),
     "cvhip_bn_act_fwd_acc_lazyres": (_i32, [_p, _i32, _p, _i32, _i64, _i32, _p, _i32, _i64, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _i32, _f32,
                                      _p, _i32, _p, _p, _p]),
+    "cvhip_conv1x1_bwd_fused_split": (_i32, [_dp, _p, _i32, _p, _i32, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _i32, _f32, _p,
+                                      _i32, _p, _i32, _p, C.POINTER(LazyIn), _p]),
     "cvhip_conv1x1_bwd_fused_lazy": (_i32, [_dp, _p, _i32, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _i32, _f32, _p, _i32,
                                      _p, _i32, _p, C.POINTER(LazyIn), _p]),
     "cvhip_conv2d_dgrad": (_i32, [_dp, _p, _p, _p, _p]),

@@ -148,12 +148,26 @@ def set_lazy(flag=True):
 
 
 class LazyAct:
-    """tag of a tensor that holds the RAW output y of a training-mode Conv-BN-act layer: its logical value is act(scale*y + shift)"""
-    __slots__ = ("scale", "shift", "act", "ap", "z")
+    """tag of a tensor that holds the RAW output y of a training-mode Conv-BN-act layer: its logical value is act(scale*y + shift) —
+    on the channel range [lo, hi) of the tagged tensor (a concat buffer whose other slices were materialised: lo > 0 or hi < C);
+    `scale` / `shift` hold hi - lo values (channel lo first)"""
+    __slots__ = ("scale", "shift", "act", "ap", "z", "lo", "hi")
 
-    def __init__(self, scale, shift, act, ap):
+    def __init__(self, scale, shift, act, ap, lo=0, hi=None):
         self.scale, self.shift, self.act, self.ap = scale, shift, int(act), float(ap)
+        self.lo = int(lo)
+        self.hi = int(hi) if hi is not None else self.lo + int(scale.numel())
         self.z = None   # the materialised tensor, once some consumer needed it
+
+    def full(self, Cc):
+        return self.lo == 0 and self.hi == Cc
+
+    def scale_ptr(self):
+        """base pointers indexed by the ABSOLUTE channel of the tagged tensor (only [lo, hi) is ever dereferenced)"""
+        return self.scale.data_ptr() - 4 * self.lo
+
+    def shift_ptr(self):
+        return self.shift.data_ptr() - 4 * self.lo
 
 
 def act_id_of(conv_module):
@@ -174,13 +188,24 @@ class Materialize(torch.autograd.Function):
         yy, y_ld = as_nhwc(y, lazy_ok=True)
         N, K, P, Q = yy.shape
         z = empty_nhwc(N, K, P, Q, yy.device)
-        _timed_ew("bn_act_fwd(ew_kernel<0>)", 4.0 * N * P * Q * K, "cvhip_bn_act_fwd", yy.data_ptr(), y_ld, z.data_ptr(), K, N * P * Q, K,
-                  lz.scale.data_ptr(), lz.shift.data_ptr(), lz.act, lz.ap, None, 0, _stream())
+        _materialize_into(yy, y_ld, z, K, lz)
         return z
 
     @staticmethod
     def backward(ctx, dz):
         return dz, None
+
+
+def _materialize_into(x, x_ld, z, z_ld, lz):
+    """z = the activated form of the lazy tensor x (N, C, H, W): the pass its producer skipped on [lo, hi), a copy elsewhere"""
+    N, Cc, H, W = x.shape
+    M = N * H * W
+    st = _stream()
+    if not lz.full(Cc):
+        L.call("cvhip_copy2d", x.data_ptr(), x_ld, z.data_ptr(), z_ld, M, Cc, st)
+    kh = lz.hi - lz.lo
+    _timed_ew("bn_act_fwd(ew_kernel<0>)", 4.0 * M * kh, "cvhip_bn_act_fwd", x.data_ptr() + 2 * lz.lo, x_ld, z.data_ptr() + 2 * lz.lo, z_ld, M, kh,
+              lz.scale.data_ptr(), lz.shift.data_ptr(), lz.act, lz.ap, None, 0, st)
 
 
 def materialize(x):
@@ -193,9 +218,9 @@ def materialize(x):
     return lz.z
 
 
-def _lazy_in(lz, c_off=0):
-    """cvhip_lazy_in of a lazy operand whose channel 0 is channel `c_off` of the kernel's operand (whole tensor lazy)"""
-    return L.LazyIn(lz.scale.data_ptr() - 4 * c_off, lz.shift.data_ptr() - 4 * c_off, lz.act, lz.ap, c_off, c_off + lz.scale.numel())
+def _lazy_in(lz):
+    """cvhip_lazy_in of a lazy operand (its channel range [lo, hi), constants indexed by the absolute channel)"""
+    return L.LazyIn(lz.scale_ptr(), lz.shift_ptr(), lz.act, lz.ap, lz.lo, lz.hi)
 
 
 # ---- producer records: BN-backward sums from the kernel that writes the gradient ------------------------------------------------------
@@ -366,8 +391,8 @@ def _timed_ew(kname, nbytes, fname, *args):
     TIMER.detail.append((fname, None))
 
 
-def _ptr(t):
-    return None if t is None else t.data_ptr()
+def _ptr(t, off=0):
+    return None if t is None else t.data_ptr() + off
 
 
 def empty_nhwc(N, Cc, H, W, device, ld=None):
@@ -587,7 +612,7 @@ class ConvCfg:
     """Static configuration of one conv(+BN+act) layer (python-side)."""
     __slots__ = ("stride", "pad", "dil", "groups", "act", "act_param", "has_bn", "bn_training", "momentum", "eps",
                  "state", "track", "vkey", "gw", "gb", "gg", "gbeta", "arena", "idx_w", "idx_b", "idx_bn", "sync", "out", "out_split", "dx_link", "res_link", "res_pre",
-                 "acc_owner", "acc_attr", "prod", "in_prod", "no_grad", "lazy_out", "lazy_half1", "lazy_made", "in_lazy", "res_lazy")
+                 "acc_owner", "acc_attr", "prod", "in_prod", "no_grad", "lazy_out", "lazy_half1", "lazy_half2", "lazy_made", "lazy_made2", "in_lazy", "res_lazy")
 
     def __init__(self, stride, pad, dil, groups=1, act=L.ACT_NONE, act_param=0.0, has_bn=False, bn_training=True,
                  momentum=0.1, eps=1e-5, state=None, track=True):
@@ -625,7 +650,9 @@ class ConvCfg:
         # `in_lazy` / `res_lazy` = the input's / residual's tag when THIS layer's kernels take them on load (set by the wrappers)
         self.lazy_out = False
         self.lazy_half1 = False
+        self.lazy_half2 = False   # sibling pairs: the SECOND sibling's raw output goes straight into its concat slice (split store) and stays lazy
         self.lazy_made = None
+        self.lazy_made2 = None
         self.in_lazy = None
         self.res_lazy = None
 
@@ -829,8 +856,7 @@ def _materialize_tmp(x, x_ld, lz):
     transform — costs the pass the forward saved, never more"""
     N, Cc, H, W = x.shape
     z = empty_nhwc(N, Cc, H, W, x.device, ld=x_ld)
-    _timed_ew("bn_act_fwd(ew_kernel<0>)", 4.0 * N * H * W * Cc, "cvhip_bn_act_fwd", x.data_ptr(), x_ld, z.data_ptr(), x_ld, N * H * W, Cc,
-              lz.scale.data_ptr(), lz.shift.data_ptr(), lz.act, lz.ap, None, 0, _stream())
+    _materialize_into(x, x_ld, z, x_ld, lz)
     return z
 
 
@@ -889,7 +915,7 @@ def _bwd1x1_ok(ctx, cfg, x, need_dx, need_dw, need_db, segs):
 
 
 def _bwd1x1(ctx, cfg, x, y, weight, segs, k_split, stats, with_mean, ag, ab, act, act_param, acc=None, g_out=None, b_out=None, accumulate=0,
-            xin=None):
+            xin=None, y1=None):
     """dx, dw of a 1x1 Conv-BN-act layer from the gradient(s) at its OUTPUT in one launch (`segs`: one (tensor, pitch), or two
     for sibling pairs; `stats` rows: mean, invstd, scale, shift; ag / ab: sum du*xhat / sum du — or `acc`: the layer's backward
     accumulator, folded by the kernel itself, which then also stores dgamma / dbeta into g_out / b_out)."""
@@ -923,7 +949,17 @@ def _bwd1x1(ctx, cfg, x, y, weight, segs, k_split, stats, with_mean, ag, ab, act
     mu = stats[0].data_ptr() if with_mean else None
     isd = stats[1].data_ptr() if with_mean else None
     M = N * H * W
-    if xin is not None:
+    if y1 is not None:
+        # sibling pair whose second half was stored straight into its concat slice (split store): the raw output has two homes
+        if acc is None:
+            raise L.CvhipError("split raw output without the accumulator form of the fused 1x1 backward")
+        li = _lazy_in(xin) if xin is not None else None
+        _timed_call("bwd1x1_kernel", (N, Cc, H, W, K, R, S, P, Q), "cvhip_conv1x1_bwd_fused_split", C.byref(desc), d0.data_ptr(), d0_ld,
+                    _ptr(d1), d1_ld, k_split, y.data_ptr(), y1[0].data_ptr(), y1[1], x.data_ptr(), ctx.w_dgrad.data_ptr(), sc, sh, mu, isd,
+                    acc.data_ptr(), K, _ptr(g_out), _ptr(b_out), int(accumulate), act, act_param, _ptr(g), g_ld,
+                    dx.data_ptr(), Cc, dst.data_ptr(), C.byref(li) if li is not None else None, st, passes=2,
+                    nbytes=2.0 * M * (2 * K + 2 * Cc))
+    elif xin is not None:
         # x is the RAW output of the layer that made it (lazy activation): the kernel transforms the rows it stages for the weight gradient
         if acc is None:
             raise L.CvhipError("lazy input without the accumulator form of the fused 1x1 backward")
@@ -1104,6 +1140,7 @@ class ConvBnAct(torch.autograd.Function):
         rows = 0
         use_acc = False
         acc_f = acc_b = None
+        split2 = None
         epilogue_stats = train_bn and not depthwise and Kp == K  # BN sums straight from the MFMA accumulators
         b = bias.detach() if bias is not None else None
         if b is not None and b.dtype != torch.float32:
@@ -1151,11 +1188,25 @@ class ConvBnAct(torch.autograd.Function):
                     L.check(rows, "cvhip_conv2d_fprop_stats_rows")
                 partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
             kname = "stem_fprop_kernel" if lib.cvhip_conv_stem_blocks(C.byref(desc)) > 0 else _igemm_name(Kp, N * P * Q, R * S * Cc, _pointwise(R, S, cfg), x_ld, epilogue_stats)
-            if cfg.in_lazy is not None:
+            if (cfg.lazy_half2 and cfg.out_split is not None and _LAZY and train_bn and use_acc and residual is None and Kp == K
+                    and cfg.act in _LAZY_ACTS and any(ctx.needs_input_grad) and image is None and _pointwise(R, S, cfg)):
+                # second sibling lazy: the streaming kernel stores channels [k1, K) of the RAW output straight into the caller's concat
+                # slice (split store) and that slice stays raw — no apply pass, no copy; the concat's consumer transforms it on load
+                k1s, z2s = cfg.out_split
+                z2s, z2s_ld = _check_out(z2s, N, K - k1s, P, Q)
+                if (k1s % 8 == 0 and (K - k1s) % 8 == 0 and z2s_ld % 8 == 0 and z2s.data_ptr() % 16 == 0
+                        and lib.cvhip_conv1x1_stream_prologue_ok(C.byref(desc), 1) > 0):   # (= the streaming kernel runs this problem)
+                    split2 = (k1s, z2s, z2s_ld)
+            if cfg.in_lazy is not None or split2 is not None:
                 # lazy input: the producing layer's BN scale / shift + activation are applied on load by the streaming 1x1 kernel
                 lzi = cfg.in_lazy
                 f = L.ConvFuse()
-                f.pro_scale, f.pro_shift, f.pro_act, f.pro_act_param = lzi.scale.data_ptr(), lzi.shift.data_ptr(), lzi.act, lzi.ap
+                if lzi is not None:
+                    f.pro_scale, f.pro_shift, f.pro_act, f.pro_act_param = lzi.scale_ptr(), lzi.shift_ptr(), lzi.act, lzi.ap
+                    if not lzi.full(Cc):
+                        f.pro_lo, f.pro_hi = lzi.lo, lzi.hi
+                if split2 is not None:
+                    f.y2, f.y2_ld, f.y_split = split2[1].data_ptr(), split2[2], split2[0]
                 if use_acc:
                     f.bn_acc = acc_f.data_ptr()
                 else:
@@ -1202,7 +1253,7 @@ class ConvBnAct(torch.autograd.Function):
         res_ld = 0
         if residual is not None:
             residual, res_ld = as_nhwc(residual, lazy_ok=cfg.res_lazy is not None)
-        cfg.lazy_made = None
+        cfg.lazy_made = cfg.lazy_made2 = None
         lazy_able = _LAZY and train_bn and use_acc and residual is None and Kp == K and cfg.act in _LAZY_ACTS and any(ctx.needs_input_grad)
         if cfg.lazy_out and lazy_able and cfg.out_split is None and cfg.out is None:
             # lazy result: statistics finalized (tiny launch), NO apply pass — the consumers read the raw y and transform on load
@@ -1220,14 +1271,18 @@ class ConvBnAct(torch.autograd.Function):
             lazy_h1 = cfg.lazy_half1 and lazy_able and k1 % 8 == 0
             z1 = y[:, :k1] if lazy_h1 else empty_nhwc(N, k1, P, Q, dev)
             for off, kh, zz, zld in ((0, k1, z1, k1), (k1, K - k1, z2, z2_ld)):
-                if lazy_h1 and off == 0:
-                    # first sibling lazy: its statistics only (the second sibling's apply pass finalizes its own channel range)
+                if (lazy_h1 and off == 0) or (split2 is not None and off):
+                    # lazy sibling: its statistics only (each half finalizes its own channel range of the shared accumulator)
                     g = gamma.detach() if gamma is not None else None
                     bt = beta.detach() if beta is not None else None
-                    L.call("cvhip_bn_finalize_acc", acc_f.data_ptr(), K, kh, M, _ptr(g), _ptr(bt), _ptr(running_mean if cfg.track else None),
-                           _ptr(running_var if cfg.track else None), cfg.momentum, cfg.eps, stats[0].data_ptr(), stats[1].data_ptr(),
-                           stats[2].data_ptr(), stats[3].data_ptr(), st)
-                    cfg.lazy_made = (stats, 0, k1)
+                    o4, o8 = 4 * off, 8 * off
+                    L.call("cvhip_bn_finalize_acc", acc_f.data_ptr() + o8, K, kh, M, _ptr(g, o4), _ptr(bt, o4),
+                           _ptr(running_mean if cfg.track else None, o4), _ptr(running_var if cfg.track else None, o4), cfg.momentum, cfg.eps,
+                           stats[0].data_ptr() + o4, stats[1].data_ptr() + o4, stats[2].data_ptr() + o4, stats[3].data_ptr() + o4, st)
+                    if off:
+                        cfg.lazy_made2 = (stats, off, kh)
+                    else:
+                        cfg.lazy_made = (stats, 0, k1)
                     continue
                 if use_acc:
                     _bn_fwd_acc(y, Kp, zz, zld, M, kh, off, K, acc_f, gamma, beta, running_mean, running_var, cfg, stats, None, 0, False, st)
@@ -1274,7 +1329,11 @@ class ConvBnAct(torch.autograd.Function):
         if use_acc and _BN_TAIL and cfg.act in _TAIL_ACTS and not (cfg.res_pre and residual is not None) and any(ctx.needs_input_grad):  # (grad mode is off inside forward)
             cfg.prod = ctx.prod = ProdInfo(y, Kp, stats, cfg.act, cfg.act_param, acc_b, K, 0, K, (N, K, P, Q))
         ctx.res_pre = bool(cfg.res_pre and residual is not None and not isinstance(z, tuple))
-        if ctx.res_pre:
+        ctx.split2 = split2 is not None
+        if split2 is not None:
+            cfg.prod = ctx.prod = None
+            ctx.save_for_backward(x, y, stats, weight, z[1])   # y's channels [k1, K) were never written: the raw half lives in the concat slice
+        elif ctx.res_pre:
             ctx.save_for_backward(x if image is None else image, y, stats, weight, z)   # the activation's derivative is taken from the OUTPUT's sign
         else:
             ctx.save_for_backward(x if image is None else image, y, stats, weight)
@@ -1464,7 +1523,7 @@ def _lazy_consumer_ok(x, K, R, S, has_bias, cfg, lz):
         return False
     ld = nhwc_ld(x)
     N, Cc, H, W = x.shape
-    if ld is None or ld % 8 or x.data_ptr() % 16 or lz.scale.numel() != Cc:
+    if ld is None or ld % 8 or x.data_ptr() % 16 or not (0 <= lz.lo < lz.hi <= Cc) or lz.lo % 8 or lz.hi % 8 or lz.scale.numel() != lz.hi - lz.lo:
         return False
     return lazy_edge_ok(N, Cc, H, W, K, lz.act, ld)
 
@@ -1498,7 +1557,7 @@ def _admit_lazy(x, residual, K, R, S, has_bias, cfg):
     if rl is not None:
         ok = (_LAZY and cfg.has_bn and cfg.bn_training and cfg.sync is None and _BN_ACC and not _DETERMINISTIC and cfg.groups == 1 and not cfg.res_pre
               and K % 8 == 0 and K <= _BN_ACC_MAX_C and rl.act == cfg.act and rl.ap == cfg.act_param and rl.act in (L.ACT_RELU, L.ACT_LEAKY, L.ACT_SILU)
-              and torch.is_grad_enabled() and rl.scale.numel() == K and nhwc_ld(residual) is not None and nhwc_ld(residual) % 8 == 0
+              and torch.is_grad_enabled() and rl.full(K) and rl.scale.numel() == K and nhwc_ld(residual) is not None and nhwc_ld(residual) % 8 == 0
               and residual.data_ptr() % 16 == 0)
         if ok:
             cfg.res_lazy = rl
@@ -1538,12 +1597,19 @@ class ConvBnActPair(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d1, d2):
-        x, y, stats, weight = ctx.saved_tensors
+        y1 = None
+        if getattr(ctx, "split2", False):
+            x, y, stats, weight, yh2 = ctx.saved_tensors
+            y1 = as_nhwc(yh2, lazy_ok=True)   # (tensor, pitch): the second sibling's RAW output, in its concat slice
+        else:
+            x, y, stats, weight = ctx.saved_tensors
         cfg = ctx.cfg
         N, Cc, H, W, K, R, S, P, Q, Kp, x_ld, Cg = ctx.geom
         dev = x.device
         M = N * P * Q
         st = _stream()
+        # per half: (address of its channel 0 in the raw output, pitch)
+        yat = [(y.data_ptr(), Kp), (y.data_ptr() + 2 * ctx.k1, Kp) if y1 is None else (y1[0].data_ptr(), y1[1])]
         segs = []
         for d, kh in ((d1, ctx.k1), (d2, K - ctx.k1)):
             if d is None:
@@ -1559,22 +1625,23 @@ class ConvBnActPair(torch.autograd.Function):
             if "dirty" in have:   # sums were folded over a tensor that is not the gradient we received: start over
                 zero_fill(acc_b)
                 have = [False, False]
-            for ((d, d_ld), kh, off), hv in zip(halves, have):
+            for ((d, d_ld), kh, off), hv, (ya, ya_ld) in zip(halves, have, yat):
                 if hv:
                     continue
                 sc, sh, mean, invstd = (stats[i].data_ptr() + 4 * off for i in (2, 3, 0, 1))
-                _timed_ew("bn_act_bwd_sums(colreduce_kernel<1>)", 4.0 * M * kh, "cvhip_bn_act_bwd_sums_acc", d.data_ptr(), d_ld, y.data_ptr() + 2 * off, Kp, M, kh,
+                _timed_ew("bn_act_bwd_sums(colreduce_kernel<1>)", 4.0 * M * kh, "cvhip_bn_act_bwd_sums_acc", d.data_ptr(), d_ld, ya, ya_ld, M, kh,
                           sc, sh, mean, invstd, cfg.act, cfg.act_param, acc_b.data_ptr() + 8 * off, K, st)
             lzi = getattr(ctx, "in_lazy", None)
             if _bwd1x1_ok(ctx, cfg, x, ctx.needs_input_grad[0], True, False, segs) and (lzi is None or K <= 128):
-                dx, _ = _bwd1x1(ctx, cfg, x, y, weight, segs, ctx.k1, stats, True, None, None, cfg.act, cfg.act_param, acc_b, cfg.gg, cfg.gbeta, 1, xin=lzi)
+                dx, _ = _bwd1x1(ctx, cfg, x, y, weight, segs, ctx.k1, stats, True, None, None, cfg.act, cfg.act_param, acc_b, cfg.gg, cfg.gbeta, 1, xin=lzi,
+                                y1=y1)
             else:
                 if lzi is not None:
                     x = _materialize_tmp(x, x_ld, lzi)
                 dy = empty_nhwc(N, K, P, Q, dev)
-                for (d, d_ld), kh, off in halves:
+                for ((d, d_ld), kh, off), (ya, ya_ld) in zip(halves, yat):
                     sc, sh, mean, invstd = (stats[i].data_ptr() + 4 * off for i in (2, 3, 0, 1))
-                    _timed_ew("bn_act_bwd_apply(ew_kernel<1>)", 6.0 * M * kh, "cvhip_bn_act_bwd_apply_acc", d.data_ptr(), d_ld, y.data_ptr() + 2 * off, Kp,
+                    _timed_ew("bn_act_bwd_apply(ew_kernel<1>)", 6.0 * M * kh, "cvhip_bn_act_bwd_apply_acc", d.data_ptr(), d_ld, ya, ya_ld,
                               dy.data_ptr() + 2 * off, Kp, M, kh, sc, sh, mean, invstd, acc_b.data_ptr() + 8 * off, K,
                               cfg.gg.data_ptr() + 4 * off, cfg.gbeta.data_ptr() + 4 * off, 1, cfg.act, cfg.act_param, st)
                 dx, _, _ = _conv_grads(ctx, x, weight, dy, Kp, ctx.needs_input_grad[0], True, False)
@@ -1672,6 +1739,9 @@ def conv_bn_act_pair(x, operands, cfg, out2=None):
     if cfg.lazy_made is not None:   # the first sibling's result is lazy: z1 is the channel slice [0, k1) of the pair's raw output
         st4, off, kh = cfg.lazy_made
         z1._hip_lazy = LazyAct(st4[2][off:off + kh], st4[3][off:off + kh], cfg.act, cfg.act_param)
+    if cfg.lazy_made2 is not None:  # the second sibling's slice of the concat buffer holds its RAW output (split store)
+        st4, off, kh = cfg.lazy_made2
+        z2._hip_lazy = LazyAct(st4[2][off:off + kh], st4[3][off:off + kh], cfg.act, cfg.act_param)
     if cfg.prod is not None:
         kt = cfg.prod.kh
         cfg.prod.halves = (cfg.prod.half(0, k1), cfg.prod.half(k1, kt - k1))
@@ -1874,11 +1944,30 @@ class Cat(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, into, *xs):
-        xs = [as_nhwc(x) for x in xs]
+        lzs = [lazy_of(x) for x in xs]
+        xs = [as_nhwc(x, lazy_ok=True) for x in xs]
         N, _, H, W = xs[0][0].shape
         Ct = sum(x.shape[1] for x, _ in xs)
         ctx.sizes = [x.shape[1] for x, _ in xs]
-        if into is None and all(ld == Ct for _, ld in xs) and all(b[0].data_ptr() == a[0].data_ptr() + 2 * a[0].shape[1] for a, b in zip(xs, xs[1:])):
+        _cat_lazy[0] = None
+        # a lazy input (RAW conv output + pending BN/act) may stay lazy when it already IS its slice of the destination, its whole channel
+        # range is lazy and it is the only such input (consumers transform ONE channel range on load); every other lazy input is activated
+        # on its way into the destination (the copy this op makes anyway). Raw data is never overwritten: its producer's backward reads it.
+        where = None
+        if into is not None:
+            where = _check_out(into, N, Ct, H, W)[0].data_ptr()
+        elif all(ld == Ct for _, ld in xs) and all(b[0].data_ptr() == a[0].data_ptr() + 2 * a[0].shape[1] for a, b in zip(xs, xs[1:])):
+            where = xs[0][0].data_ptr()
+        offs = [sum(ctx.sizes[:i]) for i in range(len(xs))]
+        placed = [where is not None and ld == Ct and x.data_ptr() == where + 2 * o for (x, ld), o in zip(xs, offs)]
+        lazy_placed = [i for i, lz in enumerate(lzs) if lz is not None and placed[i]]
+        if len(lazy_placed) > 1 or any(not lzs[i].full(ctx.sizes[i]) or offs[i] % 8 or ctx.sizes[i] % 8 for i in lazy_placed):
+            into, where, placed, lazy_placed = None, None, [False] * len(xs), []   # (rare) a fresh buffer: everything is copied / activated into it
+        if lazy_placed:
+            i = lazy_placed[0]
+            lz = lzs[i]
+            _cat_lazy[0] = LazyAct(lz.scale, lz.shift, lz.act, lz.ap, offs[i], offs[i] + ctx.sizes[i])
+        if into is None and where is not None and all(placed):
             # every producer wrote straight into consecutive channel slices of one buffer: nothing to copy
             return xs[0][0].as_strided((N, Ct, H, W), (H * W * Ct, 1, W * Ct, Ct))
         if into is not None:
@@ -1891,10 +1980,15 @@ class Cat(torch.autograd.Function):
         st = _stream()
         off = 0
         M = N * H * W
-        for x, ld in xs:
+        for (x, ld), lz in zip(xs, lzs):
             Cc = x.shape[1]
             if not (ld == Ct and x.data_ptr() == out.data_ptr() + 2 * off):
-                L.call("cvhip_copy2d", x.data_ptr(), ld, out.data_ptr() + 2 * off, Ct, M, Cc, st)
+                if lz is None or not lz.full(Cc):
+                    L.call("cvhip_copy2d", x.data_ptr(), ld, out.data_ptr() + 2 * off, Ct, M, Cc, st)
+                if lz is not None:   # activate the lazy channel range on its way into the destination
+                    kh = lz.hi - lz.lo
+                    _timed_ew("bn_act_fwd(ew_kernel<0>)", 4.0 * M * kh, "cvhip_bn_act_fwd", x.data_ptr() + 2 * lz.lo, ld, out.data_ptr() + 2 * (off + lz.lo), Ct,
+                              M, kh, lz.scale.data_ptr(), lz.shift.data_ptr(), lz.act, lz.ap, None, 0, st)
             off += Cc
         return out
 
@@ -1907,8 +2001,14 @@ class Cat(torch.autograd.Function):
         return (None,) + tuple(outs)
 
 
+_cat_lazy = [None]
+
+
 def cat(xs, into=None):
-    return Cat.apply(into, *xs)
+    out = Cat.apply(into, *xs)
+    if _cat_lazy[0] is not None:
+        out._hip_lazy, _cat_lazy[0] = _cat_lazy[0], None
+    return out
 
 
 class Add(torch.autograd.Function):

@@ -19,11 +19,12 @@ from .bricks import HipMaxPool2d, HipUpsampleNearest2x, bn_tick, sync_of
 
 _PAIR_ENABLED = os.environ.get("CVHIP_PAIR", "1") != "0"
 _CAT_INPLACE = os.environ.get("CVHIP_CAT_INPLACE", "1") != "0"
+_LAZY_CAT = os.environ.get("CVHIP_LAZY_CAT", "1") != "0"   # CSP conv2's concat slice stays raw (split store + on-load transform in conv3)
 _SPPF_CHAIN = os.environ.get("CVHIP_SPPF_CHAIN", "1") != "0"   # 0: separate pools + fan-out adds + concat copy (A/B switch)
 _GRAD_LINK = os.environ.get("CVHIP_GRAD_LINK", "1") != "0"
 
 
-def sibling_pair_forward(m1, m2, x, owner, out2=None, out=None, lazy1=False):
+def sibling_pair_forward(m1, m2, x, owner, out2=None, out=None, lazy1=False, lazy2=False):
     """Run two 1x1 Conv-BN-act modules that share the input `x` as ONE fused convolution (ops.ConvBnActPair) when their
     tensors are adjacent in the flat training arenas; None -> the caller runs them one by one (eval mode, no arena, SyncBN,
     odd channel counts, CVHIP_PAIR=0)."""
@@ -52,6 +53,8 @@ def sibling_pair_forward(m1, m2, x, owner, out2=None, out=None, lazy1=False):
     bn_tick(bn2)
     cfg.out = out   # both halves side by side into one slice of a concat buffer (or None)
     cfg.lazy_half1 = bool(lazy1)   # the first sibling's consumers are Hip conv modules: its result may stay raw (ops.LazyAct)
+    # the second sibling's concat slice may hold its RAW output (split store): the concat's only consumer is a Hip 1x1 conv module
+    cfg.lazy_half2 = bool(lazy2) and out2 is not None
     cfg.acc_owner, cfg.acc_attr = bn1, "_hip_acc_pair"   # the pair's statistic accumulators (K1 + K2 channels) hang on the first layer
     return ops.conv_bn_act_pair(x, operands, cfg, out2)
 
@@ -136,7 +139,10 @@ class CSPLayer(nn.Module):
         # lazy activation on load, so the branch may stay raw (ops.LazyAct)
         lazy1 = (self.training and len(self.m) > 0 and isinstance(self.m[0], DarknetBottleneck) and not self.m[0].depthwise and x.is_cuda
                  and ops.lazy_edge_ok(N, hid, H, W, self.m[0].conv1.out_channels, ops.act_id_of(self.conv1)))
-        pair = sibling_pair_forward(self.conv1, self.conv2, x, self, out2, lazy1=lazy1) if self.training else None
+        # conv2's result only feeds the concat that conv3 reads: its slice may stay raw too (conv3 transforms that channel range on load)
+        lazy2 = (_LAZY_CAT and self.training and buf is not None and x.is_cuda
+                 and ops.lazy_edge_ok(N, 2 * hid, H, W, self.conv3.out_channels, ops.act_id_of(self.conv2)))
+        pair = sibling_pair_forward(self.conv1, self.conv2, x, self, out2, lazy1=lazy1, lazy2=lazy2) if self.training else None
         if pair is not None:
             x_1, x_2 = pair
         else:

@@ -712,6 +712,13 @@ typedef struct cvhip_conv_fuse {
    * training-mode BatchNorm sums); no z_out, residual or epilogue in that form. */
   int32_t pro_lo;
   int32_t pro_hi;
+  /* (round 5) SPLIT STORE, streaming 1x1 kernel only (CVHIP_ERR_UNSUPPORTED elsewhere): output channels [y_split, K) are written to y2
+   * (pitch y2_ld elements) instead of y — the second layer of a sibling pair (ops.ConvBnActPair: CSP conv1 / conv2,
+   * modules/yolo_modules.py:131-139) puts its raw output straight into its slice of the concat buffer. 8-aligned split, 16-byte
+   * aligned destinations. */
+  void* y2;
+  int32_t y2_ld;
+  int32_t y_split;
 } cvhip_conv_fuse;
 /* a lazy input operand of a backward kernel: x' = act(scale[c] * x + shift[c]) for channels [c_lo, c_hi) (c_hi 0 = all), as above */
 typedef struct cvhip_lazy_in {
@@ -757,6 +764,13 @@ int cvhip_bn_act_fwd_acc_lazyres(const void* y, int32_t ld_y, void* z, int32_t l
                                  void* stream);
 /* cvhip_conv1x1_bwd_fused_acc whose input operand x is LAZY (raw output of the producing layer, `xin` describes the transform the
  * weight gradient needs); K <= 128, no tail */
+/* cvhip_conv1x1_bwd_fused_lazy for a layer whose raw output lives in TWO buffers (split store above): y holds channels [0, k_split),
+ * y1 (pitch y1_ld) channels [k_split, K); xin may be NULL (no lazy input) */
+int cvhip_conv1x1_bwd_fused_split(const cvhip_conv_desc* d, const void* dz0, int32_t dz0_ld, const void* dz1, int32_t dz1_ld, int32_t k_split,
+                                  const void* y, const void* y1, int32_t y1_ld, const void* x, const void* w_dgrad, const float* scale,
+                                  const float* shift, const float* mean, const float* invstd, const double* acc, int32_t acc_ld,
+                                  float* dgamma_out, float* dbeta_out, int32_t accumulate, int32_t act, float act_param, const void* addend,
+                                  int32_t addend_ld, void* dx, int32_t dx_ld, float* dw, const cvhip_lazy_in* xin, void* stream);
 int cvhip_conv1x1_bwd_fused_lazy(const cvhip_conv_desc* d, const void* dz0, int32_t dz0_ld, const void* dz1, int32_t dz1_ld, int32_t k_split,
                                  const void* y, const void* x_raw, const void* w_dgrad, const float* scale, const float* shift, const float* mean,
                                  const float* invstd, const double* acc, int32_t acc_ld, float* dgamma_out, float* dbeta_out, int32_t accumulate,

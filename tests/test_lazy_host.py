@@ -15,8 +15,10 @@ def desc(N, Cc, H, W, K):
 
 
 def test_struct_layouts_match_the_header():
-    # cvhip_conv_fuse grew two int32 members at its END (older members keep their offsets); cvhip_lazy_in is 2 pointers + 4 x 32 bit
-    assert C.sizeof(L.ConvFuse) == 128 and L.ConvFuse.pro_lo.offset == 116 and L.ConvFuse.pro_hi.offset == 120
+    # cvhip_conv_fuse grew at its END only (older members keep their offsets): pro_lo / pro_hi, then the split-store triple;
+    # cvhip_lazy_in is 2 pointers + 4 x 32 bit
+    assert C.sizeof(L.ConvFuse) == 144 and L.ConvFuse.pro_lo.offset == 116 and L.ConvFuse.pro_hi.offset == 120
+    assert L.ConvFuse.y2.offset == 128 and L.ConvFuse.y2_ld.offset == 136 and L.ConvFuse.y_split.offset == 140
     assert L.ConvFuse.x_image_planes.offset == 112
     assert C.sizeof(L.LazyIn) == 32 and L.LazyIn.c_hi.offset == 28
 
