@@ -21,6 +21,7 @@ SOURCES = [
     "api.hip",
     "conv_igemm.hip",
     "conv_patch.hip",
+    "conv_band.hip",
     "conv_wgrad.hip",
     "bn_act.hip",
     "pool_resize.hip",

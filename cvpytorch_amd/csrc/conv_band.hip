@@ -1,0 +1,509 @@
+// conv_band.hip — row-band 3x3 implicit-GEMM convolution for gfx950 (CDNA4): stride-1 3x3 (any padding / dilation) fprop and dgrad
+// whose input channel count is a multiple of 32 and whose output channel count is 32, 64 or a multiple of 128.
+//
+//   Out[m][n] = sum_{t,c} X[pix(m) + tap(t)][c] * Wt[n][t*Cin + c]              (same plan / operand images as conv_igemm.hip)
+//
+// Why a third implicit GEMM (round 5; VERDICT r04 task 2). The per-tap kernel (conv_igemm.hip) and the patch-resident kernel
+// (conv_patch.hip) both hand the weight tile of every K step to the waves through an LDS ring: one block-wide barrier per K step (or
+// per two), with every wave of the CU arriving in phase — 20 % / 30 % MFMA-pipe busy for four rounds — and both tile the output in
+// fixed 256-pixel tiles that quantise badly against the 256 CUs (102 400 output pixels of the dominant 128 -> 128 @40x40 layer = 400
+// tiles: 1.56 rounds). Here
+//   * a block owns a BAND: TH whole output rows of one image (TH x OW pixels, up to 416 per block: 10 rows x 40 = 400 pixels for the
+//     dominant layer -> exactly 256 blocks, one per CU), all output channels of a 128-wide tile;
+//   * the band's input patch ((TH + 2) x (OW + 2) pixels) of one 32-channel chunk is staged into the LDS once by LDS-DMA, pixel-major,
+//     double-buffered across chunks; the nine taps read their fragments from it (as conv_patch.hip does);
+//   * the WEIGHT fragments never touch the LDS: a wave owns a 32-channel slice of the output channels and loads its two 16 x 32
+//     fragments of a K step straight from global memory (L2-resident: <= 1.2 MB per layer) into registers, two K steps ahead — so
+//     inside a chunk (9 K steps, 234 MFMAs per wave) NO wave waits for any other wave: one barrier per 32-channel chunk instead of one
+//     per K step.
+// 512 threads = 8 waves = WN (output-channel slices of 32) x WM (pixel parts of <= MFW fragments of 16 pixels); v_mfma_f32_16x16x32
+// with swapped operands (a lane ends up with 4 consecutive output channels of one pixel).
+//
+// LDS image: pixel rows of 64 bytes (one 32-channel chunk), row pitch PW pixels (a multiple of 8, so a fragment whose 16 output
+// pixels wrap to the next image row keeps the bank pattern of 16 consecutive pixels), 16-byte slot s of patch pixel pp stored at slot
+// s ^ (((pp >> 2) & 1) << 1) — the swizzle of conv_patch.hip (conflict-free ds_read_b128 at any pixel offset).
+//
+// VMEM queue discipline. A wave's weight loads are inline-asm global_load_dwordx4 (hipcc drains vmcnt to 0 at the first use of an
+// ordinary load's result while an LDS-DMA is in flight: cdna_hip_programming.md "Pipelining across barriers"); the waits are counted
+// by hand: at K step k the wave issues B(k + 2) and its share of the next chunk's patch DMAs (<= PPS instructions), then waits until
+// only the instructions younger than B(k) are outstanding. A patch piece issued at step t is therefore complete at step t + 2 at the
+// latest; the pieces of a chunk are issued in its first six steps, so the chunk-end barrier publishes a landed patch.
+//
+// Epilogue: raw 16-bit stores (8 bytes per lane: 4 channels of a pixel), optional addend (dgrad: the gradient arriving over a skip
+// connection), optional training-mode BatchNorm sums into the layer's fp64 accumulator (common.h acc_add2).
+//
+// Replaces aten::convolution / convolution_backward(input) reached from reference src/models/bricks/conv_module.py:209 and
+// trainer.py:189 for the 3x3 stride-1 layers (DarknetBottleneck conv2: modules/yolo_modules.py:95-104; torchvision Bottleneck conv2).
+#include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
+
+#include "common.h"
+#include "conv_plan.h"
+
+namespace cvhip {
+
+constexpr int kBandThreads = 512;
+constexpr int kBandWaves = 8;
+constexpr int kBandSteps = 9;        // 3 x 3 taps per chunk
+constexpr int kBandPieceSteps = 6;   // the next chunk's patch DMAs go out in the first six K steps of a chunk
+constexpr int kBandLdsMax = 156 * 1024;
+
+struct BandArgs {
+  const h16_t* x;
+  const h16_t* w;
+  h16_t* y;
+  double* stats;  // fp64 accumulator [kAccShards][2][stats_ld] or NULL
+  int stats_ld;
+  const h16_t* res;
+  int res_ld;
+  int NB, IH, IW, Cin, x_ld;
+  int Nout, y_ld, OH, OW;
+  int dh0, dh_step, dw0, dw_step, lo_h, lo_w;
+  int TH, bands, PH, PW;
+  int nplw;            // patch DMA instructions per wave per chunk
+  int dummy_off;       // byte offset of the 8 x 1 KB dummy DMA slots
+  int buf_bytes;       // one patch buffer
+  int n_tiles, total_tiles, Ktot;
+  unsigned ow_magic;   // ceil(2^32 / OW)
+  unsigned pw_magic;   // ceil(2^32 / PW)
+};
+
+#define CVHIP_BGLDS16(src, dst)                                                                                 \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                       \
+                                   (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+__device__ __attribute__((aligned(64))) unsigned int g_band_zero[16];
+
+typedef unsigned int band_u32x4 __attribute__((ext_vector_type(4)));
+
+// weight fragment: 16 bytes per lane, global -> VGPRs, outside the compiler's waitcnt bookkeeping (see the header)
+__device__ __forceinline__ void band_gload16(band_u32x4& dst, const h16_t* ptr) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+}
+
+// wait until at most N VMEM instructions of this wave are outstanding; the two fragments are in/out operands so that no use of them
+// can be scheduled above the wait. N is a LITERAL and the asm sits in straight-line code: behind a run-time switch the register
+// allocator merged the cases with copies of the fragments placed BEFORE the s_waitcnt — copies of registers whose loads had not landed
+template <int N>
+__device__ __forceinline__ void band_wait(band_u32x4& a, band_u32x4& b) {
+  static_assert(N >= 0 && N <= 15, "vmcnt literal");
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+
+__device__ __forceinline__ int band_div(int n, unsigned magic) { return magic ? (int)__umulhi((unsigned)n, magic) : n; }
+
+// WN : waves along the output channels (32 channels each): 4 (128-wide tile), 2 (64), 1 (32); WM = 8 / WN pixel parts
+// MFW: 16-pixel fragments per wave (7 or 13)        PPS: patch DMA instructions per wave per K step (1 or 2)
+template <int WN, int MFW, int PPS, int OCC = 1>
+__global__ __launch_bounds__(kBandThreads, 2 * OCC) void conv_band_kernel(const BandArgs p) {
+  constexpr int WM = kBandWaves / WN;
+  constexpr int NF = 2;
+  constexpr int BN = WN * 32;
+  constexpr int NPL = PPS * kBandPieceSteps;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wn = wave % WN, wm = wave / WN;
+  const int g = lane >> 4;
+
+  // ---- which band ---------------------------------------------------------------------------------------------------
+  const int lt = xcd_remap(blockIdx.x, p.total_tiles);
+  const int sp = lt / p.n_tiles;
+  const int ntile = lt - sp * p.n_tiles;
+  const int n_img = sp / p.bands;
+  const int band = sp - n_img * p.bands;
+  const int oh0 = band * p.TH;
+  const int rows = min(p.TH, p.OH - oh0);
+  const int npx = rows * p.OW;
+  const int nfrag = (npx + 15) >> 4;
+  const int n0 = ntile * BN;
+  const int f0 = wm * MFW;
+  const int nfr = min(max(nfrag - f0, 0), MFW);
+  const int Cin = p.Cin;
+  const int NC = Cin >> 5;
+  const int PW = p.PW;
+  unsigned char* const sbuf = smem;
+
+  // ---- patch loader: DMA instruction j of wave w fills the 16 patch pixels (j*8 + w)*16 .. +15, lane l the PHYSICAL slot l % 4 of
+  // pixel l / 4 and fetches the LOGICAL slot that belongs there (swizzle on the source side) -----------------------------------
+  const int lsl = (lane & 3) ^ (((lane >> 4) & 1) << 1);   // (pp >> 2) & 1 == bit 4 of the lane: the same for every j
+  const h16_t* const zsrc = reinterpret_cast<const h16_t*>(g_band_zero) + lsl * 8;
+  int poff[NPL];
+  {
+    const int npix = p.PH * PW;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int pp = ((j * kBandWaves + wave) << 4) + (lane >> 2);
+      const int pr = band_div(pp, p.pw_magic);
+      const int pc = pp - pr * PW;
+      const int ih = oh0 + p.lo_h + pr;
+      const int iw = p.lo_w + pc;
+      const bool ok = pp < npix && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+      poff[j] = ok ? (n_img * p.IH + ih) * p.IW + iw : -1;
+    }
+  }
+  // `live` false (no next chunk, or j past the patch): the same instruction fetches the zero page into this wave's 1-KB dummy slot, so
+  // that every K step carries a compile-time number of VMEM instructions
+  unsigned char* const sdummy = sbuf + p.dummy_off + (wave << 10);
+  auto issue_piece = [&](int j, int c, unsigned char* buf, bool live) __attribute__((always_inline)) {
+    live = live && j < p.nplw;
+    const h16_t* const src = (live && poff[j] >= 0) ? p.x + ((int64_t)poff[j] * p.x_ld + (c * 32 + lsl * 8)) : zsrc;
+    CVHIP_BGLDS16(src, live ? buf + ((j * kBandWaves + wave) << 10) : sdummy);
+  };
+
+  // ---- fragment geometry --------------------------------------------------------------------------------------------
+  // ab[b]: BYTE address of (this lane's output pixel, logical slot g) in a patch buffer before the tap shift and the swizzle. The
+  // column shift of a tap moves the pixel index, so the swizzle (bit 5 ^= bit 8 of the byte address) is applied per read; the row
+  // shift is a multiple of PW pixels = of 512 bytes and the buffer base a multiple of 8 KB: neither touches bit 8 relative to bit 5
+  int ab[MFW];
+#pragma unroll
+  for (int b = 0; b < MFW; ++b) {
+    int q = ((f0 + b) << 4) + (lane & 15);
+    q = q < npx ? q : (npx > 0 ? npx - 1 : 0);
+    const int r = band_div(q, p.ow_magic);
+    const int c = q - r * p.OW;
+    ab[b] = ((r * PW + c) << 6) + (g << 4);
+  }
+  // K steps visit the taps COLUMN-major (step ts: tap column j = ts / 3, tap row i = ts % 3): the swizzled address of a column is
+  // computed once (4 VALU per fragment) and serves three steps with one add each — the inner loop is VALU-issue bound otherwise
+  // (profiles/r05_band_sq.txt: 3.1 VALU per MFMA with the per-read swizzle)
+  int coff[3], roff[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) coff[j] = __builtin_amdgcn_readfirstlane((p.dw0 + j * p.dw_step - p.lo_w) * 64);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) roff[i] = __builtin_amdgcn_readfirstlane((p.dh0 + i * p.dh_step - p.lo_h) * PW * 64);
+  int aj[MFW];
+
+  // weight fragments: lane (row n = lane & 15, K group g) reads Wt[n][k0 + g*8 .. +7]
+  const h16_t* wbp[NF];
+#pragma unroll
+  for (int a = 0; a < NF; ++a) wbp[a] = p.w + ((int64_t)(n0 + wn * 32 + a * 16 + (lane & 15)) * p.Ktot + g * 8);
+
+  f32x4 acc[NF][MFW];
+#pragma unroll
+  for (int a = 0; a < NF; ++a)
+#pragma unroll
+    for (int b = 0; b < MFW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  band_u32x4 wb[3][NF];
+  auto load_b = [&](int set, int tt, int cc) __attribute__((always_inline)) {
+    cc = cc < NC ? cc : NC - 1;  // (past the end: a valid, unused fetch — the VMEM counts stay uniform)
+    const int off = tt * Cin + (cc << 5);
+#pragma unroll
+    for (int a = 0; a < NF; ++a) band_gload16(wb[set][a], wbp[a] + off);
+  };
+
+  // ---- prologue: the first chunk's patch, the first two K steps' weights ------------------------------------------------
+#pragma unroll
+  for (int j = 0; j < NPL; ++j)
+    if (j < p.nplw) issue_piece(j, 0, sbuf, true);
+  load_b(0, 0, 0);   // step 0: tap (0, 0)
+  load_b(1, 3, 0);   // step 1: tap (1, 0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // ---- main loop: chunk-major, nine K steps (taps) inside ---------------------------------------------------------------
+  for (int c = 0; c < NC; ++c) {
+    const bool more = c + 1 < NC;
+    unsigned char* const sNext = sbuf + ((c + 1) & 1) * p.buf_bytes;
+    auto step = [&](auto tsc) __attribute__((always_inline)) {
+      constexpr int ts = decltype(tsc)::value;
+      // (1) weights of K step k + 2
+      constexpr int ts2 = (ts + 2) % kBandSteps;
+      load_b((ts + 2) % 3, (ts2 % 3) * 3 + ts2 / 3, ts + 2 < kBandSteps ? c : c + 1);
+      // (2) this step's share of the next chunk's patch (always PPS instructions in the first six steps)
+      if (ts < kBandPieceSteps) {
+#pragma unroll
+        for (int u = 0; u < PPS; ++u) issue_piece(ts * PPS + u, c + 1, sNext, more);
+      }
+      // (3) K step k's weights have landed once at most the instructions issued after step k - 2's pieces are outstanding: B(k + 1),
+      // the pieces of step k - 1, B(k + 2), the pieces of step k (the pieces of step k - 2 are younger than B(k) too: waiting for them
+      // as well keeps the count simple and gives a piece two full steps to land)
+      constexpr int PPREV = (ts >= 1 && ts - 1 < kBandPieceSteps) ? PPS : 0;
+      constexpr int PCUR = ts < kBandPieceSteps ? PPS : 0;
+      band_wait<2 * NF + PPREV + PCUR>(wb[ts % 3][0], wb[ts % 3][1]);
+      // (4) the tap's fragments from the patch, 2 MFMAs per fragment
+      if constexpr (ts % 3 == 0) {
+#pragma unroll
+        for (int b = 0; b < MFW; ++b) {
+          const int u = ab[b] + coff[ts / 3];
+          aj[b] = u ^ ((u >> 3) & 32);
+        }
+      }
+      const int tsh = roff[ts % 3] + (c & 1) * p.buf_bytes;
+      const h16x8 w0 = __builtin_bit_cast(h16x8, wb[ts % 3][0]);
+      const h16x8 w1 = __builtin_bit_cast(h16x8, wb[ts % 3][1]);
+      // (no per-fragment guards: a branch per fragment would fence the scheduler; fragments past the band read a clamped, valid
+      // pixel and are never stored or summed — the planner sizes the bands so that few of them exist). Groups of 7 / 5 fragments bound
+      // the registers the fragment reads hold.
+      constexpr int GF = MFW <= 7 ? 7 : 5;
+#pragma unroll
+      for (int b0 = 0; b0 < MFW; b0 += GF) {
+        h16x8 xa[GF];
+#pragma unroll
+        for (int b = b0; b < b0 + GF && b < MFW; ++b) {
+          xa[b - b0] = *reinterpret_cast<const h16x8*>(sbuf + (aj[b] + tsh));
+        }
+#pragma unroll
+        for (int b = b0; b < b0 + GF && b < MFW; ++b) {
+          acc[0][b] = CVHIP_MFMA_16X16X32(w0, xa[b - b0], acc[0][b], 0, 0, 0);
+          acc[1][b] = CVHIP_MFMA_16X16X32(w1, xa[b - b0], acc[1][b], 0, 0, 0);
+        }
+      }
+    };
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{});
+    step(std::integral_constant<int, 4>{});
+    step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{});
+    step(std::integral_constant<int, 7>{});
+    step(std::integral_constant<int, 8>{});
+    // every piece of chunk c + 1 this wave issued has landed (header); the barrier publishes them and frees buffer c & 1
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  // the weight fetches issued past the last K step are still in flight: their destination registers stay LIVE (in/out operands) until
+  // they have landed — the compiler sees an asm load as instantaneous and would hand a dead destination to the epilogue's addresses
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(wb[0][0]), "+v"(wb[0][1]), "+v"(wb[1][0]), "+v"(wb[1][1]), "+v"(wb[2][0]), "+v"(wb[2][1])
+               :
+               : "memory");
+
+  // ---- epilogue ---------------------------------------------------------------------------------------------------------
+  const int chb = n0 + wn * 32 + g * 4;  // + a*16: first of the lane's 4 consecutive output channels
+  const bool r8 = p.res != nullptr;
+#pragma unroll
+  for (int b = 0; b < MFW; ++b) {
+    const int q = ((f0 + b) << 4) + (lane & 15);
+    if (b < nfr && q < npx) {
+      const int r = band_div(q, p.ow_magic);
+      const int cc = q - r * p.OW;
+      const int64_t opix = ((int64_t)n_img * p.OH + (oh0 + r)) * p.OW + cc;
+      h16_t* const yrow = p.y + opix * p.y_ld + chb;
+#pragma unroll
+      for (int a = 0; a < NF; ++a) {
+        float v0 = acc[a][b][0], v1 = acc[a][b][1], v2 = acc[a][b][2], v3 = acc[a][b][3];
+        if (r8) {
+          const uint2 u = *reinterpret_cast<const uint2*>(p.res + opix * p.res_ld + chb + a * 16);
+          float r0, r1, r2, r3;
+          unpack2(u.x, r0, r1);
+          unpack2(u.y, r2, r3);
+          v0 += r0;
+          v1 += r1;
+          v2 += r2;
+          v3 += r3;
+        }
+        uint2 o;
+        o.x = pack2(v0, v1);
+        o.y = pack2(v2, v3);
+        *reinterpret_cast<uint2*>(yrow + a * 16) = o;
+      }
+    }
+  }
+  if (p.stats) {  // training-mode BatchNorm sums of the fp32 accumulators (valid output positions only)
+    float* const red = reinterpret_cast<float*>(smem);  // [WM][BN][2] (the patch buffers are dead: every wave passed the last barrier)
+#pragma unroll
+    for (int a = 0; a < NF; ++a) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int b = 0; b < MFW; ++b) {
+          const int q = ((f0 + b) << 4) + (lane & 15);
+          const float v = (b < nfr && q < npx) ? acc[a][b][r] : 0.f;
+          s1 += v;
+          s2 += v * v;
+        }
+        s1 = row16_sum(s1);
+        s2 = row16_sum(s2);
+        if ((lane & 15) == 0) {
+          const int nl = wn * 32 + a * 16 + g * 4 + r;
+          red[(wm * BN + nl) * 2 + 0] = s1;
+          red[(wm * BN + nl) * 2 + 1] = s2;
+        }
+      }
+    }
+    __syncthreads();
+    if (t < BN) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        s1 += red[(w * BN + t) * 2 + 0];
+        s2 += red[(w * BN + t) * 2 + 1];
+      }
+      acc_add2(p.stats, sp, p.stats_ld, n0 + t, s1, s2);
+    }
+  }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------
+
+static int band_mode() {  // CVHIP_BAND: 0 = never, 1 = default policy, 2 = wherever the geometry allows (read per launch: in-process A/B)
+  const char* e = getenv("CVHIP_BAND");
+  return e ? atoi(e) : 1;
+}
+
+struct BandPlan {
+  BandArgs a;
+  int WN, MFW, PPS, lds, occ2;
+};
+
+static inline int band_imin(int a, int b) { return a < b ? a : b; }
+static inline int band_imax(int a, int b) { return a > b ? a : b; }
+
+static bool band_plan(const IgemmParams& p, BandPlan* pl) {
+  if (p.ncls != 1 || p.in_sh != 1 || p.in_sw != 1 || p.out_sh != 1 || p.out_sw != 1) return false;
+  const IgemmClass& c = p.cls[0];
+  if (c.TR != 3 || c.TS != 3 || c.out_oh != 0 || c.out_ow != 0 || c.OHi != p.OH || c.OWi != p.OW || c.M <= 0) return false;
+  if (p.bias || p.ep_scale || p.ep_shift || p.ep_act != CVHIP_ACT_NONE || p.pro_scale || p.z_out || p.y2 || p.x_image || p.tail_y) return false;
+  if (p.stats && !p.stats_acc) return false;
+  if ((p.Cin & 31) || (p.x_ld & 7) || (((uintptr_t)p.x) & 15) || (((uintptr_t)p.w) & 15) || (c.w_off & 7)) return false;
+  if (!(p.Nout == 32 || p.Nout == 64 || (p.Nout & 127) == 0)) return false;
+  if ((p.y_ld & 3) || (((uintptr_t)p.y) & 7)) return false;
+  if (p.res && ((p.res_ld & 3) || (((uintptr_t)p.res) & 7))) return false;
+  if (p.OW >= 65536 || p.OW < 1 || (int64_t)p.NB * p.IH * p.IW >= (1ll << 31)) return false;
+  const int BN = band_imin(p.Nout, 128);
+  const int WN = BN / 32, WM = kBandWaves / WN;
+  const int h_a = c.dh0, h_b = c.dh0 + 2 * c.dh_step, w_a = c.dw0, w_b = c.dw0 + 2 * c.dw_step;
+  const int lo_h = band_imin(h_a, h_b), hi_h = band_imax(h_a, h_b), lo_w = band_imin(w_a, w_b), hi_w = band_imax(w_a, w_b);
+  const int EH = hi_h - lo_h + 1, EW = hi_w - lo_w + 1;
+  const int PW = (p.OW - 1 + EW + 7) & ~7;
+  const int NC = p.Cin / 32;
+  const int n_tiles = p.Nout / BN;
+  int best_th = 0;
+  int64_t best_cost = -1;
+  int best_nplw = 0;
+  const char* eth = getenv("CVHIP_BAND_TH");  // dev: force the band height
+  for (int TH = 1; TH <= p.OH; ++TH) {
+    if (eth && atoi(eth) > 0 && TH != atoi(eth)) continue;
+    const int frags = (TH * p.OW + 15) / 16;
+    const int per_wave = (frags + WM - 1) / WM;
+    if (per_wave > 13) break;
+    const int PH = TH - 1 + EH;
+    if ((int64_t)PH * PW >= 65536) break;
+    const int nplw = (PH * PW * 4 + kBandThreads - 1) / kBandThreads;
+    if (nplw > 2 * kBandPieceSteps) break;
+    const int lds = (NC > 1 ? 2 : 1) * nplw * 8192 + kBandWaves * 1024;
+    if (lds > kBandLdsMax) break;
+    const int64_t tiles = (int64_t)p.NB * ((p.OH + TH - 1) / TH) * n_tiles;
+    // rounds of the 256 CUs (one block per CU) x (MFMA work of the busiest wave + prologue / epilogue, in fragment units)
+    const int64_t cost = ((tiles + 255) / 256) * ((per_wave <= 7 ? 7 : 13) * NC + 2 + NC / 2);
+    if (best_cost < 0 || cost <= best_cost) {
+      best_cost = cost;
+      best_th = TH;
+      best_nplw = nplw;
+    }
+  }
+  if (!best_th) return false;
+  const int TH = best_th;
+  const int frags = (TH * p.OW + 15) / 16;
+  const int per_wave = (frags + WM - 1) / WM;
+  memset(&pl->a, 0, sizeof(pl->a));
+  BandArgs& a = pl->a;
+  a.NB = p.NB;
+  a.IH = p.IH;
+  a.IW = p.IW;
+  a.Cin = p.Cin;
+  a.x_ld = p.x_ld;
+  a.Nout = p.Nout;
+  a.y_ld = p.y_ld;
+  a.OH = p.OH;
+  a.OW = p.OW;
+  a.dh0 = c.dh0;
+  a.dh_step = c.dh_step;
+  a.dw0 = c.dw0;
+  a.dw_step = c.dw_step;
+  a.lo_h = lo_h;
+  a.lo_w = lo_w;
+  a.TH = TH;
+  a.bands = (p.OH + TH - 1) / TH;
+  a.PH = TH - 1 + EH;
+  a.PW = PW;
+  a.nplw = best_nplw;
+  a.buf_bytes = best_nplw * 8192;
+  a.n_tiles = n_tiles;
+  const int64_t total = (int64_t)p.NB * a.bands * n_tiles;
+  if (total >= (1ll << 30)) return false;
+  a.total_tiles = (int)total;
+  a.Ktot = 9 * p.Cin;
+  a.ow_magic = div_magic(p.OW);
+  a.pw_magic = div_magic(PW);
+  pl->WN = WN;
+  pl->MFW = per_wave <= 7 ? 7 : 13;
+  pl->PPS = best_nplw <= kBandPieceSteps ? 1 : 2;
+  a.dummy_off = (NC > 1 ? 2 : 1) * a.buf_bytes;
+  pl->lds = band_imax(a.dummy_off + kBandWaves * 1024, WM * BN * 2 * (int)sizeof(float));
+  {
+    const char* eo = getenv("CVHIP_BAND_OCC");  // dev: two co-resident blocks per CU (128 VGPRs, <= 78 KB of LDS each)
+    pl->occ2 = (eo && atoi(eo) == 2 && pl->MFW == 7 && pl->PPS == 1 && pl->lds <= 78 * 1024) ? 1 : 0;
+  }
+  if (band_mode() >= 2) return true;
+  // Default policy = where it measured FASTER than the patch-resident / per-tap kernels (profiles/r05_band_bench.log, isolated launches on
+  // rotating operands): one 64- or 128-wide channel tile, 13-fragment waves that are nearly full, a block count that fills whole rounds
+  // of the 256 CUs — YOLOv5-s 128 -> 128 @40x40 b64 37.6 vs 43.9 us, 64 -> 64 @80x80 54.8 vs 57.9. It LOSES with 200-pixel bands
+  // (256 -> 256 @20x20: 43.9 vs 40.9: two channel tiles re-stage the same patch and a weight fragment serves 7 MFMAs), with 32-wide
+  // outputs (every wave fetches the same fragments) and when the bands leave CUs idle (DeepLabv3+ b16: 352 blocks, 69 vs 46.6 us).
+  if (n_tiles != 1 || WN < 2 || pl->MFW != 13) return false;
+  if (per_wave * WM * 16 * 9 > TH * p.OW * 10) return false;            // <= 10 % of the fragment slots idle
+  const int64_t rounds = (total + 255) / 256;
+  if (total * 10 < rounds * 256 * 9) return false;                       // >= 90 % of the CU slots of every round busy
+  return true;
+}
+
+template <int WN, int MFW, int PPS, int OCC = 1>
+static int band_launch(const BandPlan& pl, hipStream_t stream) {
+  auto kern = conv_band_kernel<WN, MFW, PPS, OCC>;
+  static bool attr_done[64] = {};
+  int devid = 0;
+  (void)hipGetDevice(&devid);
+  bool& attr_set = attr_done[devid & 63];
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kBandLdsMax);
+    if (e != hipSuccess) {
+      set_last_error("hipFuncSetAttribute(conv_band_kernel)", e);
+      return CVHIP_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(pl.a.total_tiles), dim3(kBandThreads), pl.lds, stream, pl.a);
+  return check_launch("conv_band_kernel");
+}
+
+template <int WN>
+static int band_launch_wn(const BandPlan& pl, hipStream_t stream) {
+  if (pl.MFW == 7 && pl.PPS == 1 && pl.occ2) return band_launch<WN, 7, 1, 2>(pl, stream);
+  if (pl.MFW == 7) return pl.PPS == 1 ? band_launch<WN, 7, 1>(pl, stream) : band_launch<WN, 7, 2>(pl, stream);
+  return pl.PPS == 1 ? band_launch<WN, 13, 1>(pl, stream) : band_launch<WN, 13, 2>(pl, stream);
+}
+
+bool band_takes(const IgemmParams& p) {
+  if (band_mode() == 0) return false;
+  BandPlan pl;
+  return band_plan(p, &pl);
+}
+
+// -1 = not taken (the caller goes on to the patch-resident / per-tap kernels)
+int try_launch_band(const IgemmParams& p, hipStream_t stream) {
+  if (band_mode() == 0) return -1;
+  BandPlan pl;
+  if (!band_plan(p, &pl)) return -1;
+  BandArgs& a = pl.a;
+  a.x = p.x;
+  a.w = p.w + p.cls[0].w_off;
+  a.y = p.y;
+  a.stats = p.stats ? reinterpret_cast<double*>(p.stats) : nullptr;
+  a.stats_ld = p.stats_ld;
+  a.res = p.res;
+  a.res_ld = p.res_ld;
+  if (pl.WN == 4) return band_launch_wn<4>(pl, stream);
+  if (pl.WN == 2) return band_launch_wn<2>(pl, stream);
+  return band_launch_wn<1>(pl, stream);
+}
+
+}  // namespace cvhip

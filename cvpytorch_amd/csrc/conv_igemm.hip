@@ -1312,6 +1312,8 @@ int launch_igemm(IgemmParams& p, hipStream_t stream) {
   if (s0 >= 0) return s0;
   const int s1 = try_launch_stream1x1(p, stream);  // 1x1 / stride 1: persistent streaming kernel (conv1x1_stream.hip)
   if (s1 >= 0) return s1;
+  const int sb = try_launch_band(p, stream);  // 3x3 stride 1, Cin % 32 == 0: row bands, weights in registers (conv_band.hip)
+  if (sb != -1) return sb;
   const int s2 = try_launch_patch(p, stream);  // multi-tap, Cin % 32 == 0: patch-resident implicit GEMM (conv_patch.hip)
   if (s2 != -1) return s2;
   if (p.pro_scale || p.z_out || p.y2) return CVHIP_ERR_UNSUPPORTED;  // a prologue: patch / streaming kernels only; a split store: streaming kernel only

@@ -201,6 +201,9 @@ int try_launch_stem_wgrad(const cvhip_conv_desc* d, const void* x, const void* d
 int try_launch_patch(const IgemmParams& p, hipStream_t stream);
 bool patch_takes(const IgemmParams& p, int* stats_rows);
 // per class CVHIP_PATCH_CLASS_INTS int32 of tile / patch geometry (cvhip_conv2d_patch_plan); returns the class count, 0 = not taken
+// conv_band.hip: row-band 3x3 stride-1 implicit GEMM with register-resident weight fragments (launcher, -1 = not taken)
+int try_launch_band(const IgemmParams& p, hipStream_t stream);
+bool band_takes(const IgemmParams& p);
 int patch_plan_export(const IgemmParams& p, int32_t* out, int max_classes, bool any_geometry);
 
 }  // namespace cvhip

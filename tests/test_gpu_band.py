@@ -1,0 +1,103 @@
+"""GPU parity tests of the row-band 3x3 convolution kernel (csrc/conv_band.hip: band-resident input patch, weight fragments loaded
+straight into registers, one barrier per 32-channel chunk) through the C ABI, against fp32 CPU arithmetic on the same 16-bit-rounded
+operands — `aten::convolution` / `convolution_backward(input)` of the stride-1 3x3 layers (conv_module.py:209, trainer.py:189).
+
+Tolerances as for the other convolution kernels (test_gpu_kernels.py): outputs stored in 16 bits: max |err| <= 2^-7 max|ref|, relative
+L2 <= 4e-3; fp32 BatchNorm sums: relative L2 <= 1e-3.
+
+CVHIP_BAND=2 (read per launch) makes the launcher pick the band kernel for every geometry it can run."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import test_gpu_kernels as K
+from cvpytorch_amd import lib as L
+from cvpytorch_amd import ops
+
+dev, rel_l2, max_rel, to_nhwc_dev = K.dev, K.rel_l2, K.max_rel, K.to_nhwc_dev
+
+
+def rnd(x):
+    return x.to(K.BF).float()
+
+
+@pytest.fixture(autouse=True)
+def force_band(monkeypatch):
+    monkeypatch.setenv("CVHIP_BAND", "2")
+    yield
+
+
+BAND_CASES = [
+    # N, C, H, W, K, R, S, stride, pad, dil
+    (3, 128, 40, 40, 128, 3, 3, 1, 1, 1),    # the dominant YOLOv5-s shape: 10-row bands, 4 x 2 waves x 13 fragments
+    (2, 64, 80, 80, 64, 3, 3, 1, 1, 1),      # 2 x 4 waves
+    (2, 32, 160, 160, 32, 3, 3, 1, 1, 1),    # 1 x 8 waves, one chunk (single patch buffer)
+    (3, 256, 20, 20, 256, 3, 3, 1, 1, 1),    # two 128-wide channel tiles, 8 chunks
+    (2, 128, 17, 19, 128, 3, 3, 1, 1, 1),    # ragged: last band shorter, fragments wrap image rows at odd widths
+    (1, 32, 23, 37, 32, 3, 3, 1, 1, 1),
+    (2, 64, 16, 16, 64, 3, 3, 1, 2, 2),      # dilation 2
+    (2, 64, 14, 18, 128, 3, 3, 1, 0, 1),     # no padding: output smaller than the input
+    (2, 64, 9, 300, 64, 3, 3, 1, 1, 1),      # wide rows: one-row bands
+    (2, 96, 12, 12, 64, 3, 3, 1, 1, 1),      # three chunks
+    (1, 128, 64, 128, 128, 3, 3, 1, 1, 1),   # DeepLabv3+ decoder shape
+    (2, 512, 16, 32, 512, 3, 3, 1, 2, 2),    # ASPP-like dilated, four channel tiles, 16 chunks
+]
+
+
+@pytest.mark.parametrize("case", BAND_CASES)
+def test_band_fprop(case):
+    K.test_conv_fprop(case)
+
+
+@pytest.mark.parametrize("case", BAND_CASES)
+def test_band_fprop_bn_acc(case):
+    """training form: raw output + BatchNorm sums folded into the layer's fp64 accumulator (cvhip_conv2d_fprop_acc)"""
+    N, Cc, H, W, Kk, R, S, s, p, d = case
+    x, w = K._mk(case, 1)
+    ref = F.conv2d(x, w, None, stride=s, padding=p, dilation=d)
+    st, Kp = K._prep(case, w, False)
+    xd = to_nhwc_dev(x)
+    P, Q = ref.shape[2:]
+    y = ops.empty_nhwc(N, Kk, P, Q, dev())
+    desc = ops.conv_desc(N, Cc, H, W, Kk, R, S, (s, s), (p, p), (d, d), 1, Cc, Kk)
+    acc = torch.zeros(L.BN_ACC_SHARDS, 2, Kk, dtype=torch.float64, device=dev())
+    L.call("cvhip_conv2d_fprop_acc", C.byref(desc), xd.data_ptr(), st.w_fprop.data_ptr(), y.data_ptr(), acc.data_ptr(), ops._stream())
+    torch.cuda.synchronize()
+    s1, s2 = acc.sum(0).cpu()
+    r = ref.double()
+    assert rel_l2(s1, r.sum((0, 2, 3))) < 1e-3 or float((s1 - r.sum((0, 2, 3))).abs().max()) < 1e-2
+    assert rel_l2(s2, (r * r).sum((0, 2, 3))) < 1e-3
+    assert rel_l2(y.float().cpu(), ref) < 4e-3
+
+
+@pytest.mark.parametrize("case", BAND_CASES)
+def test_band_dgrad(case):
+    K.test_conv_dgrad(case)
+
+
+@pytest.mark.parametrize("case", [BAND_CASES[0], BAND_CASES[4], BAND_CASES[6]])
+def test_band_dgrad_add(case):
+    """dgrad with the skip-connection gradient added in the epilogue (cvhip_conv2d_dgrad_add)"""
+    N, Cc, H, W, Kk, R, S, s, p, d = case
+    x, w = K._mk(case, 2)
+    xr = x.clone().requires_grad_(True)
+    y = F.conv2d(xr, w, None, stride=s, padding=p, dilation=d)
+    dy = rnd(torch.randn(y.shape, generator=torch.Generator().manual_seed(3)))
+    add = rnd(torch.randn(x.shape, generator=torch.Generator().manual_seed(4)))
+    (gx,) = torch.autograd.grad(y, xr, dy)
+    gx = gx + add
+    st, Kp = K._prep(case, w, True)
+    dyd = to_nhwc_dev(dy)
+    addd = to_nhwc_dev(add)
+    dx = ops.empty_nhwc(N, Cc, H, W, dev())
+    dx.fill_(float("nan"))
+    desc = ops.conv_desc(N, Cc, H, W, Kp, R, S, (s, s), (p, p), (d, d), 1, Cc, Kp)
+    L.call("cvhip_conv2d_dgrad_add", C.byref(desc), dyd.data_ptr(), st.w_dgrad.data_ptr(), addd.data_ptr(), Cc, dx.data_ptr(), ops._stream())
+    torch.cuda.synchronize()
+    got = dx.float().cpu()
+    assert torch.isfinite(got).all()
+    assert max_rel(got, gx) < 2 ** -7 and rel_l2(got, gx) < 4e-3

@@ -33,6 +33,7 @@ def rnd(x):
 @pytest.fixture(autouse=True)
 def force_patch(monkeypatch):
     monkeypatch.setenv("CVHIP_PATCH", "2")
+    monkeypatch.setenv("CVHIP_BAND", "0")   # (the row-band kernel would take the stride-1 3x3 cases first: tests/test_gpu_band.py)
     yield
 
 

@@ -45,7 +45,8 @@ def timed(fn, nsets):
 
 def main():
     lib = L.load()
-    variants = [("per-tap", {"CVHIP_PATCH": "0"}), ("patch", {"CVHIP_PATCH": "1"})]
+    variants = [("per-tap", {"CVHIP_PATCH": "0", "CVHIP_BAND": "0"}), ("patch", {"CVHIP_PATCH": "1", "CVHIP_BAND": "0"}),
+                ("band", {"CVHIP_PATCH": "1", "CVHIP_BAND": "2"})]   # (conv_band.hip: stride-1 3x3 only; elsewhere it falls through to "patch")
     for extra in os.environ.get("VARIANTS", "").split(";"):
         if extra:
             name, kv = extra.split(":")
