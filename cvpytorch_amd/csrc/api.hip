@@ -202,6 +202,21 @@ int cvhip_conv2d_patch_plan(const cvhip_conv_desc* d, int flags, int32_t* out, i
   return patch_plan_export(p, out, max_classes, (flags & 2) != 0);
 }
 
+int cvhip_conv2d_band_plan(const cvhip_conv_desc* d, int flags, int32_t* out) {
+  int st = validate_dense_desc(d);
+  if (st) return st;
+  IgemmParams p;
+  if (flags & 1) {
+    if ((d->K & 7) || (d->y_ld & 7)) return CVHIP_ERR_UNSUPPORTED;
+    plan_dgrad(d, &p);
+  } else {
+    plan_fprop(d, &p);
+  }
+  // (operand pointers are not part of the descriptor: the query assumes the 16-byte alignment every arena tensor has; the training
+  // form's BatchNorm sums go to the fp64 accumulator, which the band kernel supports)
+  return band_plan_export(p, out);
+}
+
 int cvhip_conv_stem_blocks(const cvhip_conv_desc* d) {
   int st = validate_dense_desc(d);
   if (st) return st;

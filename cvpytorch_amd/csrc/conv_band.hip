@@ -44,11 +44,14 @@
 
 namespace cvhip {
 
-constexpr int kBandThreads = 512;
-constexpr int kBandWaves = 8;
+constexpr int kBandWavesMax = 8;     // NW = 8: one 512-thread block per CU; NW = 4: two co-resident 256-thread blocks of half the band each
 constexpr int kBandSteps = 9;        // 3 x 3 taps per chunk
 constexpr int kBandPieceSteps = 6;   // the next chunk's patch DMAs go out in the first six K steps of a chunk
 constexpr int kBandLdsMax = 156 * 1024;
+constexpr int kBandWavesDefault = 8;          // waves per block (CVHIP_BAND_NW overrides)
+constexpr bool kBandWideDefault = false;     // default policy takes the wide-wave (NF = 4) form where it fits (CVHIP_BAND_NF overrides)
+constexpr int kBandWidePF = 4;                // wide-wave form with LDS prefetch: fragments read one step ahead (register budget)
+constexpr int kBandPrefetchDefault = 0;      // 7-fragment forms: LDS reads one K step ahead (CVHIP_BAND_PF overrides)
 
 struct BandArgs {
   const h16_t* x;
@@ -66,6 +69,7 @@ struct BandArgs {
   int dummy_off;       // byte offset of the 8 x 1 KB dummy DMA slots
   int buf_bytes;       // one patch buffer
   int n_tiles, total_tiles, Ktot;
+  int probe_coalesced; // dev (CVHIP_BAND_PROBE_W=1): every weight fetch reads 1 KB of contiguous memory — WRONG results, timing only
   unsigned ow_magic;   // ceil(2^32 / OW)
   unsigned pw_magic;   // ceil(2^32 / PW)
 };
@@ -79,8 +83,10 @@ __device__ __attribute__((aligned(64))) unsigned int g_band_zero[16];
 typedef unsigned int band_u32x4 __attribute__((ext_vector_type(4)));
 
 // weight fragment: 16 bytes per lane, global -> VGPRs, outside the compiler's waitcnt bookkeeping (see the header)
-__device__ __forceinline__ void band_gload16(band_u32x4& dst, const h16_t* ptr) {
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+// (SGPR base + 32-bit lane offset: the wave-uniform part of the address — channel slice, tap, chunk — is scalar arithmetic, the lane's
+// part one VGPR for all fragments)
+__device__ __forceinline__ void band_gload16(band_u32x4& dst, const h16_t* sbase, unsigned voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
 }
 
 // wait until at most N VMEM instructions of this wave are outstanding; the two fragments are in/out operands so that no use of them
@@ -91,16 +97,49 @@ __device__ __forceinline__ void band_wait(band_u32x4& a, band_u32x4& b) {
   static_assert(N >= 0 && N <= 15, "vmcnt literal");
   asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
 }
+template <int N>
+__device__ __forceinline__ void band_wait(band_u32x4& a, band_u32x4& b, band_u32x4& c, band_u32x4& d) {
+  static_assert(N >= 0 && N <= 15, "vmcnt literal");
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+
+// pixel fragment: 16 bytes per lane, LDS -> VGPRs by hand (PF > 0 forms). hipcc waits for ALL outstanding LDS reads before the first
+// MFMA of a K step (s_waitcnt lgkmcnt(0) throughout the compiled loop: round-5 ISA listing), so a read-ahead it schedules itself is
+// waited for in the very step that issued it. Here the reads are asm (outside its bookkeeping) and the waits are counted: LDS reads
+// return in order, so "at most N outstanding" = everything but the N youngest has landed.
+__device__ __forceinline__ void band_lds16(band_u32x4& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void band_lwait(band_u32x4& a) {
+  static_assert(N >= 0 && N <= 15, "lgkmcnt literal");
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N) : "memory");
+}
 
 __device__ __forceinline__ int band_div(int n, unsigned magic) { return magic ? (int)__umulhi((unsigned)n, magic) : n; }
 
-// WN : waves along the output channels (32 channels each): 4 (128-wide tile), 2 (64), 1 (32); WM = 8 / WN pixel parts
+// WN : waves along the output channels (16 * NF channels each); WM = 8 / WN pixel parts
 // MFW: 16-pixel fragments per wave (7 or 13)        PPS: patch DMA instructions per wave per K step (1 or 2)
-template <int WN, int MFW, int PPS, int OCC = 1>
-__global__ __launch_bounds__(kBandThreads, 2 * OCC) void conv_band_kernel(const BandArgs p) {
+// NF : 16-channel weight fragments per wave. 2 = the first form: 4 / 2 / 1 waves across a 128 / 64 / 32-wide tile, 13 (or 7) pixel
+//      fragments per wave, weights two K steps ahead. 4 = the WIDE-WAVE form (64 channels x 7 pixel fragments per wave, 2 / 1 waves
+//      across a 128 / 64-wide tile): every pixel fragment read from the LDS feeds FOUR MFMAs instead of two — half the ds_read_b128
+//      instructions, address adds and LDS waits per MFMA — at twice the weight bytes per wave and K step (four fragments, L2 / L1).
+// LEAD: K steps the weight fragments are fetched ahead (2; 1 keeps NF = 4 inside 256 registers: two sets of four fragments live)
+// PF : pixel fragments of the NEXT K step read from the LDS before this step's MFMAs (0 = none; MFW = all of them: the step's MFMAs
+//      never wait for the LDS inside a chunk). Only inside a chunk: the next chunk's buffer is published by the chunk-end barrier.
+// NW : waves per block. 8 = one block per CU (256 VGPRs per wave at two waves per SIMD). 4 = half-height bands in 256-thread blocks, two
+//      of them resident per CU (the same registers per wave, <= 78 KB of LDS each): the same per-CU work, but the two blocks are not
+//      coupled by barriers — one's prologue, chunk barriers and store epilogue can run under the other's MFMAs.
+template <int WN, int MFW, int PPS, int NF = 2, int LEAD = 2, int PF = 0, int NW = 8>
+__global__ __launch_bounds__(NW * 64, 2) void conv_band_kernel(const BandArgs p) {
+  constexpr int kBandWaves = NW;
+  static_assert(NW == 4 || NW == 8, "waves per block");
+  static_assert(WN <= NW, "channel slices per block");
+  static_assert(NF == 2 || NF == 4, "weight fragments per wave");
+  static_assert(LEAD == 1 || LEAD == 2, "weight prefetch distance");
+  static_assert(PF >= 0 && PF <= MFW, "LDS prefetch: fragments of the next step");
   constexpr int WM = kBandWaves / WN;
-  constexpr int NF = 2;
-  constexpr int BN = WN * 32;
+  constexpr int BN = WN * 16 * NF;
   constexpr int NPL = PPS * kBandPieceSteps;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
@@ -143,15 +182,20 @@ __global__ __launch_bounds__(kBandThreads, 2 * OCC) void conv_band_kernel(const 
       const int ih = oh0 + p.lo_h + pr;
       const int iw = p.lo_w + pc;
       const bool ok = pp < npix && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
-      poff[j] = ok ? (n_img * p.IH + ih) * p.IW + iw : -1;
+      poff[j] = ok ? ((n_img * p.IH + ih) * p.IW + iw) * (p.x_ld >> 3) : -1;   // in 16-byte units (the planner bounds the tensor)
     }
   }
   // `live` false (no next chunk, or j past the patch): the same instruction fetches the zero page into this wave's 1-KB dummy slot, so
   // that every K step carries a compile-time number of VMEM instructions
   unsigned char* const sdummy = sbuf + p.dummy_off + (wave << 10);
+  const h16_t* const xlane = p.x + lsl * 8;
   auto issue_piece = [&](int j, int c, unsigned char* buf, bool live) __attribute__((always_inline)) {
     live = live && j < p.nplw;
-    const h16_t* const src = (live && poff[j] >= 0) ? p.x + ((int64_t)poff[j] * p.x_ld + (c * 32 + lsl * 8)) : zsrc;
+    // (the offset is made opaque per use: otherwise the compiler hoists the twelve `poff[j] >= 0` lane masks out of the K loop into
+    // 24 SGPRs, and the kernel spills scalars into the vector file)
+    int po = poff[j];
+    asm volatile("" : "+v"(po));
+    const h16_t* const src = (live && po >= 0) ? xlane + (((int64_t)po << 3) + c * 32) : zsrc;
     CVHIP_BGLDS16(src, live ? buf + ((j * kBandWaves + wave) << 10) : sdummy);
   };
 
@@ -179,9 +223,9 @@ __global__ __launch_bounds__(kBandThreads, 2 * OCC) void conv_band_kernel(const 
   int aj[MFW];
 
   // weight fragments: lane (row n = lane & 15, K group g) reads Wt[n][k0 + g*8 .. +7]
-  const h16_t* wbp[NF];
-#pragma unroll
-  for (int a = 0; a < NF; ++a) wbp[a] = p.w + ((int64_t)(n0 + wn * 32 + a * 16 + (lane & 15)) * p.Ktot + g * 8);
+  const h16_t* const wbase = p.w + (int64_t)(n0 + wn * (16 * NF)) * p.Ktot;   // wave-uniform
+  const unsigned wlane = p.probe_coalesced ? (unsigned)(lane * 16) : (unsigned)(((lane & 15) * p.Ktot + g * 8) * (int)sizeof(h16_t));
+  const int wfrag = 16 * p.Ktot;                                                // elements between two 16-channel fragments
 
   f32x4 acc[NF][MFW];
 #pragma unroll
@@ -189,70 +233,140 @@ __global__ __launch_bounds__(kBandThreads, 2 * OCC) void conv_band_kernel(const 
 #pragma unroll
     for (int b = 0; b < MFW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  band_u32x4 wb[3][NF];
+  band_u32x4 wb[3][NF];  // sets named by K step % 3; LEAD + 1 of them are live at a time
   auto load_b = [&](int set, int tt, int cc) __attribute__((always_inline)) {
     cc = cc < NC ? cc : NC - 1;  // (past the end: a valid, unused fetch — the VMEM counts stay uniform)
     const int off = tt * Cin + (cc << 5);
 #pragma unroll
-    for (int a = 0; a < NF; ++a) band_gload16(wb[set][a], wbp[a] + off);
+    for (int a = 0; a < NF; ++a) band_gload16(wb[set][a], wbase + (off + a * wfrag), wlane);
   };
 
-  // ---- prologue: the first chunk's patch, the first two K steps' weights ------------------------------------------------
+  // ---- prologue: the first chunk's patch, the first LEAD K steps' weights --------------------------------------------------
 #pragma unroll
   for (int j = 0; j < NPL; ++j)
     if (j < p.nplw) issue_piece(j, 0, sbuf, true);
-  load_b(0, 0, 0);   // step 0: tap (0, 0)
-  load_b(1, 3, 0);   // step 1: tap (1, 0)
+  load_b(0, 0, 0);                          // step 0: tap (0, 0)
+  if constexpr (LEAD == 2) load_b(1, 3, 0);  // step 1: tap (1, 0)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+
+  band_u32x4 xq[PF > 0 ? PF : 1];  // PF > 0: the next K step's first pixel fragments, read one step ahead
+  const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem);
 
   // ---- main loop: chunk-major, nine K steps (taps) inside ---------------------------------------------------------------
   for (int c = 0; c < NC; ++c) {
     const bool more = c + 1 < NC;
     unsigned char* const sNext = sbuf + ((c + 1) & 1) * p.buf_bytes;
+    const int cbuf = (c & 1) * p.buf_bytes;
+    if constexpr (PF > 0) {
+      // (the three tap columns' swizzled addresses of every fragment are loop-invariant; hoisted out of the chunk loop they cost
+      // 3 x MFW registers the read-ahead forms do not have — made opaque once per chunk, they are 3 VALU instructions per fragment and column)
+#pragma unroll
+      for (int b = 0; b < MFW; ++b) asm volatile("" : "+v"(ab[b]));
+    }
     auto step = [&](auto tsc) __attribute__((always_inline)) {
       constexpr int ts = decltype(tsc)::value;
-      // (1) weights of K step k + 2
-      constexpr int ts2 = (ts + 2) % kBandSteps;
-      load_b((ts + 2) % 3, (ts2 % 3) * 3 + ts2 / 3, ts + 2 < kBandSteps ? c : c + 1);
+      // (1) weights of K step k + LEAD
+      constexpr int tsl = (ts + LEAD) % kBandSteps;
+      load_b((ts + LEAD) % 3, (tsl % 3) * 3 + tsl / 3, ts + LEAD < kBandSteps ? c : c + 1);
       // (2) this step's share of the next chunk's patch (always PPS instructions in the first six steps)
       if (ts < kBandPieceSteps) {
 #pragma unroll
         for (int u = 0; u < PPS; ++u) issue_piece(ts * PPS + u, c + 1, sNext, more);
       }
-      // (3) K step k's weights have landed once at most the instructions issued after step k - 2's pieces are outstanding: B(k + 1),
-      // the pieces of step k - 1, B(k + 2), the pieces of step k (the pieces of step k - 2 are younger than B(k) too: waiting for them
-      // as well keeps the count simple and gives a piece two full steps to land)
+      // (3) K step k's weights have landed once at most the instructions issued after them are outstanding. LEAD = 2: B(k + 1), the
+      // pieces of step k - 1, B(k + 2), the pieces of step k (the pieces of step k - 2 are younger than B(k) too: waiting for them as
+      // well keeps the count simple). LEAD = 1: the pieces of step k - 1, B(k + 1), the pieces of step k. Either way a piece issued
+      // at step t is complete at step t + 2 at the latest (it is older than B(t + 2) / B(t + 3)).
       constexpr int PPREV = (ts >= 1 && ts - 1 < kBandPieceSteps) ? PPS : 0;
       constexpr int PCUR = ts < kBandPieceSteps ? PPS : 0;
-      band_wait<2 * NF + PPREV + PCUR>(wb[ts % 3][0], wb[ts % 3][1]);
-      // (4) the tap's fragments from the patch, 2 MFMAs per fragment
-      if constexpr (ts % 3 == 0) {
+      if constexpr (NF == 2)
+        band_wait<LEAD * NF + PPREV + PCUR>(wb[ts % 3][0], wb[ts % 3][1]);
+      else
+        band_wait<LEAD * NF + PPREV + PCUR>(wb[ts % 3][0], wb[ts % 3][1], wb[ts % 3][2], wb[ts % 3][3]);
+      // (4) the tap's fragments from the patch, NF MFMAs per fragment
+      if constexpr (ts % 3 == 0 && (PF == 0 || ts == 0)) {
 #pragma unroll
         for (int b = 0; b < MFW; ++b) {
           const int u = ab[b] + coff[ts / 3];
           aj[b] = u ^ ((u >> 3) & 32);
         }
       }
-      const int tsh = roff[ts % 3] + (c & 1) * p.buf_bytes;
-      const h16x8 w0 = __builtin_bit_cast(h16x8, wb[ts % 3][0]);
-      const h16x8 w1 = __builtin_bit_cast(h16x8, wb[ts % 3][1]);
-      // (no per-fragment guards: a branch per fragment would fence the scheduler; fragments past the band read a clamped, valid
-      // pixel and are never stored or summed — the planner sizes the bands so that few of them exist). Groups of 7 / 5 fragments bound
-      // the registers the fragment reads hold.
-      constexpr int GF = MFW <= 7 ? 7 : 5;
+      const int tsh = roff[ts % 3] + cbuf;
+      h16x8 wf[NF];
 #pragma unroll
-      for (int b0 = 0; b0 < MFW; b0 += GF) {
-        h16x8 xa[GF];
+      for (int a = 0; a < NF; ++a) wf[a] = __builtin_bit_cast(h16x8, wb[ts % 3][a]);
+      if constexpr (PF == 0) {
+        // (no per-fragment guards: a branch per fragment would fence the scheduler; fragments past the band read a clamped, valid
+        // pixel and are never stored or summed — the planner sizes the bands so that few of them exist). Groups of 7 / 5 fragments
+        // bound the registers the fragment reads hold.
+        constexpr int GF = MFW <= 7 ? 7 : 5;
 #pragma unroll
-        for (int b = b0; b < b0 + GF && b < MFW; ++b) {
-          xa[b - b0] = *reinterpret_cast<const h16x8*>(sbuf + (aj[b] + tsh));
+        for (int b0 = 0; b0 < MFW; b0 += GF) {
+          h16x8 xa[GF];
+#pragma unroll
+          for (int b = b0; b < b0 + GF && b < MFW; ++b) {
+            xa[b - b0] = *reinterpret_cast<const h16x8*>(sbuf + (aj[b] + tsh));
+          }
+#pragma unroll
+          for (int b = b0; b < b0 + GF && b < MFW; ++b) {
+#pragma unroll
+            for (int a = 0; a < NF; ++a) acc[a][b] = CVHIP_MFMA_16X16X32(wf[a], xa[b - b0], acc[a][b], 0, 0, 0);
+          }
         }
+      } else {
+        // LDS one step ahead: this step's first PF fragments were read during the previous step (step 0 of a chunk reads its own: the
+        // buffer was published by the barrier just passed), the others are read now and land under the MFMAs of the first PF; the
+        // next step's first PF reads go out BEFORE this step's MFMAs too. Counted waits (band_lds16): of the NEW reads issued in
+        // this step, fragment B0 + i may be used once at most NEW - 1 - i reads are outstanding, the read-ahead ones once at most NEW.
+        constexpr int B0 = ts == 0 ? 0 : PF;
+        constexpr int NNEXT = ts + 1 < kBandSteps ? PF : 0;
+        constexpr int NEW = (MFW - B0) + NNEXT;
+        band_u32x4 xa[MFW];
 #pragma unroll
-        for (int b = b0; b < b0 + GF && b < MFW; ++b) {
-          acc[0][b] = CVHIP_MFMA_16X16X32(w0, xa[b - b0], acc[0][b], 0, 0, 0);
-          acc[1][b] = CVHIP_MFMA_16X16X32(w1, xa[b - b0], acc[1][b], 0, 0, 0);
+        for (int b = 0; b < B0; ++b) xa[b] = xq[b];
+#pragma unroll
+        for (int b = B0; b < MFW; ++b) band_lds16(xa[b], lds0 + (unsigned)(aj[b] + tsh));
+        if constexpr (NNEXT > 0) {
+          if constexpr ((ts + 1) % 3 == 0) {
+#pragma unroll
+            for (int b = 0; b < MFW; ++b) {
+              const int u = ab[b] + coff[(ts + 1) / 3];
+              aj[b] = u ^ ((u >> 3) & 32);
+            }
+          }
+          const int tsn = roff[(ts + 1) % 3] + cbuf;
+#pragma unroll
+          for (int b = 0; b < PF; ++b) band_lds16(xq[b], lds0 + (unsigned)(aj[b] + tsn));
         }
+        auto mfmas = [&](auto bc) __attribute__((always_inline)) {
+          constexpr int b = decltype(bc)::value;
+          if constexpr (b < MFW) {
+            // (MFMAs and asm statements do not cross: without the fence hipcc gathers the counted waits into one run ahead of all the
+            // step's MFMAs — lgkmcnt(10), (9), ... (4) back to back — which is the blanket wait again)
+            if constexpr (b == 0 || b >= B0) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (b < B0) {
+              if constexpr (b == 0) {
+                band_lwait<NEW>(xa[0]);            // everything issued before this step has landed: all B0 read-ahead fragments
+                __builtin_amdgcn_sched_barrier(0);  // (only xa[0] is an operand of the wait: the others' MFMAs stay below it too)
+              }
+            } else {
+              band_lwait<NEW - 1 - (b - B0)>(xa[b]);
+            }
+            const h16x8 xv = __builtin_bit_cast(h16x8, xa[b]);
+#pragma unroll
+            for (int a = 0; a < NF; ++a) acc[a][b] = CVHIP_MFMA_16X16X32(wf[a], xv, acc[a][b], 0, 0, 0);
+            if constexpr (b == MFW - 1) __builtin_amdgcn_sched_barrier(0);
+          }
+        };
+        mfmas(std::integral_constant<int, 0>{});
+        mfmas(std::integral_constant<int, 1>{});
+        mfmas(std::integral_constant<int, 2>{});
+        mfmas(std::integral_constant<int, 3>{});
+        mfmas(std::integral_constant<int, 4>{});
+        mfmas(std::integral_constant<int, 5>{});
+        mfmas(std::integral_constant<int, 6>{});
+        static_assert(MFW <= 7, "the read-ahead forms hold at most 7 pixel fragments per wave");
       }
     };
     step(std::integral_constant<int, 0>{});
@@ -270,13 +384,20 @@ __global__ __launch_bounds__(kBandThreads, 2 * OCC) void conv_band_kernel(const 
   }
   // the weight fetches issued past the last K step are still in flight: their destination registers stay LIVE (in/out operands) until
   // they have landed — the compiler sees an asm load as instantaneous and would hand a dead destination to the epilogue's addresses
-  asm volatile("s_waitcnt vmcnt(0)"
-               : "+v"(wb[0][0]), "+v"(wb[0][1]), "+v"(wb[1][0]), "+v"(wb[1][1]), "+v"(wb[2][0]), "+v"(wb[2][1])
-               :
-               : "memory");
+  if constexpr (NF == 2) {
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(wb[0][0]), "+v"(wb[0][1]), "+v"(wb[1][0]), "+v"(wb[1][1]), "+v"(wb[2][0]), "+v"(wb[2][1])
+                 :
+                 : "memory");
+  } else {
+    // (LEAD = 1: only set 0 — step 0 of the chunk past the end — is in flight; the other sets' last fetches were waited for and used)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(wb[0][0]), "+v"(wb[0][1]), "+v"(wb[0][2]), "+v"(wb[0][3]) : : "memory");
+    if constexpr (LEAD == 2)
+      asm volatile("" : "+v"(wb[1][0]), "+v"(wb[1][1]), "+v"(wb[1][2]), "+v"(wb[1][3]) : : "memory");
+  }
 
   // ---- epilogue ---------------------------------------------------------------------------------------------------------
-  const int chb = n0 + wn * 32 + g * 4;  // + a*16: first of the lane's 4 consecutive output channels
+  const int chb = n0 + wn * (16 * NF) + g * 4;  // + a*16: first of the lane's 4 consecutive output channels
   const bool r8 = p.res != nullptr;
 #pragma unroll
   for (int b = 0; b < MFW; ++b) {
@@ -323,7 +444,7 @@ __global__ __launch_bounds__(kBandThreads, 2 * OCC) void conv_band_kernel(const 
         s1 = row16_sum(s1);
         s2 = row16_sum(s2);
         if ((lane & 15) == 0) {
-          const int nl = wn * 32 + a * 16 + g * 4 + r;
+          const int nl = wn * (16 * NF) + a * 16 + g * 4 + r;
           red[(wm * BN + nl) * 2 + 0] = s1;
           red[(wm * BN + nl) * 2 + 1] = s2;
         }
@@ -351,11 +472,65 @@ static int band_mode() {  // CVHIP_BAND: 0 = never, 1 = default policy, 2 = wher
 
 struct BandPlan {
   BandArgs a;
-  int WN, MFW, PPS, lds, occ2;
+  int WN, MFW, PPS, lds, NF, PF, NW;
 };
 
 static inline int band_imin(int a, int b) { return a < b ? a : b; }
 static inline int band_imax(int a, int b) { return a > b ? a : b; }
+
+static int band_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+// One candidate form (NF weight fragments per wave, at most `cap` pixel fragments per wave): the best band height and its cost in
+// rounds of the 256 CUs x fragment units of the busiest wave. false = the geometry does not fit this form.
+static bool band_fit(const IgemmParams& p, int NF, int cap, int NW, int EH, int PW, int* th_out, int* nplw_out, int64_t* rounds_out) {
+  const int BN = band_imin(p.Nout, 128);
+  if (BN % (16 * NF)) return false;
+  const int WN = BN / (16 * NF);
+  if (WN > NW) return false;
+  const int WM = NW / WN;
+  const int threads = NW * 64;
+  const int slots = NW == 4 ? 512 : 256;              // resident blocks on the chip
+  const int lds_max = NW == 4 ? 78 * 1024 : kBandLdsMax;
+  const int NC = p.Cin / 32;
+  const int n_tiles = p.Nout / BN;
+  int best_th = 0, best_nplw = 0;
+  int64_t best_cost = -1;
+  const int eth = band_env("CVHIP_BAND_TH", 0);  // dev: force the band height
+  for (int TH = 1; TH <= p.OH; ++TH) {
+    if (eth > 0 && TH != eth) continue;
+    const int frags = (TH * p.OW + 15) / 16;
+    const int per_wave = (frags + WM - 1) / WM;
+    if (per_wave > cap) break;
+    const int PH = TH - 1 + EH;
+    if ((int64_t)PH * PW >= 65536) break;
+    const int nplw = (PH * PW * 4 + threads - 1) / threads;
+    if (nplw > 2 * kBandPieceSteps) break;
+    const int lds = (NC > 1 ? 2 : 1) * nplw * NW * 1024 + NW * 1024;
+    if (lds > lds_max) break;
+    const int64_t tiles = (int64_t)p.NB * ((p.OH + TH - 1) / TH) * n_tiles;
+    // rounds of the resident block slots x (MFMA work of the busiest wave + prologue / epilogue, in units of NF = 2 fragments)
+    const int64_t cost = ((tiles + slots - 1) / slots) * ((per_wave <= 7 ? 7 : 13) * (NF / 2) * NC + 2 + NC / 2);
+    if (best_cost < 0 || cost <= best_cost) {
+      best_cost = cost;
+      best_th = TH;
+      best_nplw = nplw;
+    }
+  }
+  if (!best_th) return false;
+  if (eth <= 0) {
+    // same number of bands, evenly high: 40 rows in bands of 11 are 11 + 11 + 11 + 7 — four bands of 10 cost the same MFMA slots and stage
+    // less patch (a lower band always fits where a higher one did)
+    best_th = (p.OH + ((p.OH + best_th - 1) / best_th) - 1) / ((p.OH + best_th - 1) / best_th);
+    best_nplw = ((best_th - 1 + EH) * PW * 4 + threads - 1) / threads;
+  }
+  *th_out = best_th;
+  *nplw_out = best_nplw;
+  *rounds_out = ((int64_t)p.NB * ((p.OH + best_th - 1) / best_th) * n_tiles + slots - 1) / slots;
+  return true;
+}
 
 static bool band_plan(const IgemmParams& p, BandPlan* pl) {
   if (p.ncls != 1 || p.in_sh != 1 || p.in_sw != 1 || p.out_sh != 1 || p.out_sw != 1) return false;
@@ -367,41 +542,35 @@ static bool band_plan(const IgemmParams& p, BandPlan* pl) {
   if (!(p.Nout == 32 || p.Nout == 64 || (p.Nout & 127) == 0)) return false;
   if ((p.y_ld & 3) || (((uintptr_t)p.y) & 7)) return false;
   if (p.res && ((p.res_ld & 3) || (((uintptr_t)p.res) & 7))) return false;
-  if (p.OW >= 65536 || p.OW < 1 || (int64_t)p.NB * p.IH * p.IW >= (1ll << 31)) return false;
+  if (p.OW >= 65536 || p.OW < 1 || (int64_t)p.NB * p.IH * p.IW * (p.x_ld >> 3) >= (1ll << 31)) return false;  // 16-byte units in 31 bits
   const int BN = band_imin(p.Nout, 128);
-  const int WN = BN / 32, WM = kBandWaves / WN;
   const int h_a = c.dh0, h_b = c.dh0 + 2 * c.dh_step, w_a = c.dw0, w_b = c.dw0 + 2 * c.dw_step;
   const int lo_h = band_imin(h_a, h_b), hi_h = band_imax(h_a, h_b), lo_w = band_imin(w_a, w_b), hi_w = band_imax(w_a, w_b);
   const int EH = hi_h - lo_h + 1, EW = hi_w - lo_w + 1;
   const int PW = (p.OW - 1 + EW + 7) & ~7;
   const int NC = p.Cin / 32;
   const int n_tiles = p.Nout / BN;
-  int best_th = 0;
-  int64_t best_cost = -1;
-  int best_nplw = 0;
-  const char* eth = getenv("CVHIP_BAND_TH");  // dev: force the band height
-  for (int TH = 1; TH <= p.OH; ++TH) {
-    if (eth && atoi(eth) > 0 && TH != atoi(eth)) continue;
-    const int frags = (TH * p.OW + 15) / 16;
-    const int per_wave = (frags + WM - 1) / WM;
-    if (per_wave > 13) break;
-    const int PH = TH - 1 + EH;
-    if ((int64_t)PH * PW >= 65536) break;
-    const int nplw = (PH * PW * 4 + kBandThreads - 1) / kBandThreads;
-    if (nplw > 2 * kBandPieceSteps) break;
-    const int lds = (NC > 1 ? 2 : 1) * nplw * 8192 + kBandWaves * 1024;
-    if (lds > kBandLdsMax) break;
-    const int64_t tiles = (int64_t)p.NB * ((p.OH + TH - 1) / TH) * n_tiles;
-    // rounds of the 256 CUs (one block per CU) x (MFMA work of the busiest wave + prologue / epilogue, in fragment units)
-    const int64_t cost = ((tiles + 255) / 256) * ((per_wave <= 7 ? 7 : 13) * NC + 2 + NC / 2);
-    if (best_cost < 0 || cost <= best_cost) {
-      best_cost = cost;
-      best_th = TH;
-      best_nplw = nplw;
-    }
+  // CVHIP_BAND_NF (read per launch): 2 = narrow waves (32 channels x <= 13 pixel fragments), 4 = wide waves (64 channels x <= 7 pixel
+  // fragments) wherever the tile is 64 or 128 channels wide and the geometry fits (narrow elsewhere), 0 = default policy (below)
+  const int want_nf = band_env("CVHIP_BAND_NF", 0);
+  int th2 = 0, np2 = 0, th4 = 0, np4 = 0;
+  int64_t rounds2 = 0, rounds4 = 0;
+  // CVHIP_BAND_NW (read per launch): 8 = one 512-thread block per CU, 4 = two co-resident 256-thread blocks (where the geometry fits:
+  // 512-thread blocks elsewhere)
+  int NW = band_env("CVHIP_BAND_NW", kBandWavesDefault) == 4 ? 4 : 8;
+  bool fit4 = false, fit2 = false;
+  for (;; NW = 8) {
+    fit4 = want_nf != 2 && band_fit(p, 4, 7, NW, EH, PW, &th4, &np4, &rounds4);
+    fit2 = !(want_nf == 4 && fit4) && band_fit(p, 2, 13, NW, EH, PW, &th2, &np2, &rounds2);
+    if (fit2 || fit4 || NW == 8) break;
   }
-  if (!best_th) return false;
-  const int TH = best_th;
+  if (!fit2 && !fit4) return false;
+  // default: the wide-wave form where its bands fill the CUs in as few rounds as the narrow form's (measured: profiles/r05_band_bench.log)
+  const bool wide = fit4 && (!fit2 || want_nf == 4 || (kBandWideDefault && rounds4 <= rounds2));
+  const int NF = wide ? 4 : 2;
+  const int TH = wide ? th4 : th2;
+  const int best_nplw = wide ? np4 : np2;
+  const int WN = BN / (16 * NF), WM = NW / WN;
   const int frags = (TH * p.OW + 15) / 16;
   const int per_wave = (frags + WM - 1) / WM;
   memset(&pl->a, 0, sizeof(pl->a));
@@ -426,39 +595,42 @@ static bool band_plan(const IgemmParams& p, BandPlan* pl) {
   a.PH = TH - 1 + EH;
   a.PW = PW;
   a.nplw = best_nplw;
-  a.buf_bytes = best_nplw * 8192;
+  a.buf_bytes = best_nplw * NW * 1024;
   a.n_tiles = n_tiles;
   const int64_t total = (int64_t)p.NB * a.bands * n_tiles;
   if (total >= (1ll << 30)) return false;
   a.total_tiles = (int)total;
   a.Ktot = 9 * p.Cin;
+  a.probe_coalesced = band_env("CVHIP_BAND_PROBE_W", 0);
   a.ow_magic = div_magic(p.OW);
   a.pw_magic = div_magic(PW);
   pl->WN = WN;
-  pl->MFW = per_wave <= 7 ? 7 : 13;
+  pl->NF = NF;
+  pl->MFW = (NF == 4 || per_wave <= 7) ? 7 : 13;
   pl->PPS = best_nplw <= kBandPieceSteps ? 1 : 2;
+  // CVHIP_BAND_PF (read per launch): 1 = the 7-fragment forms read the next K step's pixel fragments one step ahead, 0 = not
+  pl->PF = (pl->MFW == 7 && band_env("CVHIP_BAND_PF", kBandPrefetchDefault)) ? (NF == 4 ? kBandWidePF : 7) : 0;
   a.dummy_off = (NC > 1 ? 2 : 1) * a.buf_bytes;
-  pl->lds = band_imax(a.dummy_off + kBandWaves * 1024, WM * BN * 2 * (int)sizeof(float));
-  {
-    const char* eo = getenv("CVHIP_BAND_OCC");  // dev: two co-resident blocks per CU (128 VGPRs, <= 78 KB of LDS each)
-    pl->occ2 = (eo && atoi(eo) == 2 && pl->MFW == 7 && pl->PPS == 1 && pl->lds <= 78 * 1024) ? 1 : 0;
-  }
+  pl->NW = NW;
+  pl->lds = band_imax(a.dummy_off + NW * 1024, WM * BN * 2 * (int)sizeof(float));
   if (band_mode() >= 2) return true;
   // Default policy = where it measured FASTER than the patch-resident / per-tap kernels (profiles/r05_band_bench.log, isolated launches on
-  // rotating operands): one 64- or 128-wide channel tile, 13-fragment waves that are nearly full, a block count that fills whole rounds
+  // rotating operands): one 64- or 128-wide channel tile, waves that are nearly full, a block count that fills whole rounds
   // of the 256 CUs — YOLOv5-s 128 -> 128 @40x40 b64 37.6 vs 43.9 us, 64 -> 64 @80x80 54.8 vs 57.9. It LOSES with 200-pixel bands
   // (256 -> 256 @20x20: 43.9 vs 40.9: two channel tiles re-stage the same patch and a weight fragment serves 7 MFMAs), with 32-wide
   // outputs (every wave fetches the same fragments) and when the bands leave CUs idle (DeepLabv3+ b16: 352 blocks, 69 vs 46.6 us).
-  if (n_tiles != 1 || WN < 2 || pl->MFW != 13) return false;
-  if (per_wave * WM * 16 * 9 > TH * p.OW * 10) return false;            // <= 10 % of the fragment slots idle
-  const int64_t rounds = (total + 255) / 256;
-  if (total * 10 < rounds * 256 * 9) return false;                       // >= 90 % of the CU slots of every round busy
+  if (n_tiles != 1 || BN < 64) return false;
+  if (NF == 2 && pl->MFW != 13) return false;
+  if (pl->MFW * WM * 16 * (NF == 4 ? 17 : 18) > TH * p.OW * 20) return false;   // <= 10 % of the fragment slots idle (wide waves: 15 %)
+  const int slots = NW == 4 ? 512 : 256;
+  const int64_t rounds = (total + slots - 1) / slots;
+  if (total * 10 < rounds * slots * 9) return false;                     // >= 90 % of the resident block slots of every round busy
   return true;
 }
 
-template <int WN, int MFW, int PPS, int OCC = 1>
+template <int WN, int MFW, int PPS, int NF, int LEAD, int PF, int NW>
 static int band_launch(const BandPlan& pl, hipStream_t stream) {
-  auto kern = conv_band_kernel<WN, MFW, PPS, OCC>;
+  auto kern = conv_band_kernel<WN, MFW, PPS, NF, LEAD, PF, NW>;
   static bool attr_done[64] = {};
   int devid = 0;
   (void)hipGetDevice(&devid);
@@ -471,21 +643,53 @@ static int band_launch(const BandPlan& pl, hipStream_t stream) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(pl.a.total_tiles), dim3(kBandThreads), pl.lds, stream, pl.a);
+  hipLaunchKernelGGL(kern, dim3(pl.a.total_tiles), dim3(NW * 64), pl.lds, stream, pl.a);
   return check_launch("conv_band_kernel");
 }
 
-template <int WN>
-static int band_launch_wn(const BandPlan& pl, hipStream_t stream) {
-  if (pl.MFW == 7 && pl.PPS == 1 && pl.occ2) return band_launch<WN, 7, 1, 2>(pl, stream);
-  if (pl.MFW == 7) return pl.PPS == 1 ? band_launch<WN, 7, 1>(pl, stream) : band_launch<WN, 7, 2>(pl, stream);
-  return pl.PPS == 1 ? band_launch<WN, 13, 1>(pl, stream) : band_launch<WN, 13, 2>(pl, stream);
+template <int WN, int NW>
+static int band_launch_narrow(const BandPlan& pl, hipStream_t stream) {  // NF = 2: 32 channels per wave
+  if constexpr (WN <= NW) {
+    if (pl.MFW == 7) {
+      if (pl.PF) return pl.PPS == 1 ? band_launch<WN, 7, 1, 2, 2, 7, NW>(pl, stream) : band_launch<WN, 7, 2, 2, 2, 7, NW>(pl, stream);
+      return pl.PPS == 1 ? band_launch<WN, 7, 1, 2, 2, 0, NW>(pl, stream) : band_launch<WN, 7, 2, 2, 2, 0, NW>(pl, stream);
+    }
+    return pl.PPS == 1 ? band_launch<WN, 13, 1, 2, 2, 0, NW>(pl, stream) : band_launch<WN, 13, 2, 2, 2, 0, NW>(pl, stream);
+  } else {
+    return CVHIP_ERR_UNSUPPORTED;
+  }
+}
+
+template <int WN, int NW>
+static int band_launch_wide(const BandPlan& pl, hipStream_t stream) {  // NF = 4: 64 channels x 7 pixel fragments per wave
+  if (pl.PF) return pl.PPS == 1 ? band_launch<WN, 7, 1, 4, 1, kBandWidePF, NW>(pl, stream) : band_launch<WN, 7, 2, 4, 1, kBandWidePF, NW>(pl, stream);
+  return pl.PPS == 1 ? band_launch<WN, 7, 1, 4, 1, 0, NW>(pl, stream) : band_launch<WN, 7, 2, 4, 1, 0, NW>(pl, stream);
+}
+
+template <int NW>
+static int band_launch_nw(const BandPlan& pl, hipStream_t stream) {
+  if (pl.NF == 4) return pl.WN == 2 ? band_launch_wide<2, NW>(pl, stream) : band_launch_wide<1, NW>(pl, stream);
+  if (pl.WN == 4) return band_launch_narrow<4, NW>(pl, stream);
+  if (pl.WN == 2) return band_launch_narrow<2, NW>(pl, stream);
+  return band_launch_narrow<1, NW>(pl, stream);
 }
 
 bool band_takes(const IgemmParams& p) {
   if (band_mode() == 0) return false;
   BandPlan pl;
   return band_plan(p, &pl);
+}
+
+// plan query (api.hip cvhip_conv2d_band_plan): {NF, WN, MFW, PPS, PF, TH, bands, n_tiles, total_tiles, lds bytes, PH, PW, NW}
+int band_plan_export(const IgemmParams& p, int32_t* out) {
+  if (band_mode() == 0) return 0;
+  BandPlan pl;
+  if (!band_plan(p, &pl)) return 0;
+  if (out) {
+    const int32_t v[CVHIP_BAND_PLAN_INTS] = {pl.NF, pl.WN, pl.MFW, pl.PPS, pl.PF, pl.a.TH, pl.a.bands, pl.a.n_tiles, pl.a.total_tiles, pl.lds, pl.a.PH, pl.a.PW, pl.NW};
+    for (int i = 0; i < CVHIP_BAND_PLAN_INTS; ++i) out[i] = v[i];
+  }
+  return 1;
 }
 
 // -1 = not taken (the caller goes on to the patch-resident / per-tap kernels)
@@ -501,9 +705,7 @@ int try_launch_band(const IgemmParams& p, hipStream_t stream) {
   a.stats_ld = p.stats_ld;
   a.res = p.res;
   a.res_ld = p.res_ld;
-  if (pl.WN == 4) return band_launch_wn<4>(pl, stream);
-  if (pl.WN == 2) return band_launch_wn<2>(pl, stream);
-  return band_launch_wn<1>(pl, stream);
+  return pl.NW == 4 ? band_launch_nw<4>(pl, stream) : band_launch_nw<8>(pl, stream);
 }
 
 }  // namespace cvhip

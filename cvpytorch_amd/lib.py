@@ -14,7 +14,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcvhip.so")
+# CVHIP_LIB: A/B of two BUILDS of the library in one gpurun call (tools/ab_env.sh); unset = the in-tree library
+LIB_PATH = os.environ.get("CVHIP_LIB") or os.path.join(_HERE, "libcvhip.so")
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -1, -2, -3
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_LEAKY, ACT_SIGMOID, ACT_HSWISH = 0, 1, 2, 3, 4, 5
@@ -62,6 +63,7 @@ class LazyIn(C.Structure):
 
 
 PATCH_CLASS_INTS = 30  # CVHIP_PATCH_CLASS_INTS
+BAND_PLAN_INTS = 13    # CVHIP_BAND_PLAN_INTS
 
 
 class PrepEntry(C.Structure):
@@ -114,6 +116,7 @@ SIGNATURES = {
     "cvhip_conv2d_wgrad_image": (_i32, [_dp, _p, _i32, _p, _p, _p]),
     "cvhip_conv2d_fprop_prologue_ok": (_i32, [_dp, _i32]),
     "cvhip_conv2d_patch_plan": (_i32, [_dp, _i32, C.POINTER(_i32), _i32]),
+    "cvhip_conv2d_band_plan": (_i32, [_dp, _i32, C.POINTER(_i32)]),
     "cvhip_conv1x1_stream_prologue_ok": (_i32, [_dp, _i32]),
     "cvhip_conv2d_wgrad_stem_bn": (_i32, [_dp, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _i32, _f32, _p, _p]),
     "cvhip_bn_finalize_acc": (_i32, [_p, _i32, _i32, _i64, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _p]),
@@ -273,6 +276,8 @@ def load():
             "(hipcc --offload-arch=gfx950). The HIP engine has no CPU fallback." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if os.environ.get("CVHIP_LIB") and not hasattr(lib, name):
+            continue  # an older build under A/B (CVHIP_LIB): entry points added since are simply absent from it
         fn = getattr(lib, name)  # AttributeError here == ABI drift; let it propagate loudly
         fn.restype = res
         fn.argtypes = args

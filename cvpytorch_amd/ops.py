@@ -363,8 +363,12 @@ def _timed_call(kname, geom, fname, *args, passes=1, nbytes=None):
         # launch_igemm hands some multi-tap problems to the patch-resident kernel (conv_patch.hip): label those launches as what runs,
         # so that a row of the bench line's kernel table is ONE device kernel family (as in rocprofv3's per-kernel statistics)
         try:
+            dg = 1 if fname.startswith("cvhip_conv2d_dgrad") else 0
+            bb = (C.c_int32 * L.BAND_PLAN_INTS)()
             buf = (C.c_int32 * (L.PATCH_CLASS_INTS * 4))()
-            if L.load().cvhip_conv2d_patch_plan(args[0], 1 if fname.startswith("cvhip_conv2d_dgrad") else 0, buf, 4) > 0:
+            if L.load().cvhip_conv2d_band_plan(args[0], dg, bb) > 0:      # launch_igemm's order: band, patch, per-tap
+                kname = "conv_band_kernel<%d ch/wave>" % (16 * bb[0])
+            elif L.load().cvhip_conv2d_patch_plan(args[0], dg, buf, 4) > 0:
                 kname = "conv_patch_kernel<128>"
         except Exception:
             pass

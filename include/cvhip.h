@@ -785,6 +785,15 @@ int cvhip_conv1x1_bwd_fused_lazy(const cvhip_conv_desc* d, const void* dz0, int3
 #define CVHIP_PATCH_CLASS_INTS 30
 int cvhip_conv2d_patch_plan(const cvhip_conv_desc* d, int flags, int32_t* out_classes, int max_classes);
 
+/* Plan query of the row-band 3x3 kernel (conv_band.hip; pure host arithmetic): returns 1 when launch_igemm hands this problem to the band
+ * kernel under the current policy (CVHIP_BAND / CVHIP_BAND_NF / CVHIP_BAND_PF are read per call), 0 when another kernel runs it.
+ * out (may be NULL): {NF (16-channel weight fragments per wave: 2 narrow / 4 wide), WN (waves across the channel tile), MFW (pixel
+ * fragments per wave), PPS (patch DMA instructions per wave and K step), PF (pixel fragments read one K step ahead), TH (output rows per
+ * band), bands per image, channel tiles, blocks, LDS bytes, patch rows, patch row pitch (pixels), NW (waves per block: 8, or 4 = two
+ * co-resident blocks per CU)}. flags bit 0: cvhip_conv2d_dgrad's plan. */
+#define CVHIP_BAND_PLAN_INTS 13
+int cvhip_conv2d_band_plan(const cvhip_conv_desc* d, int flags, int32_t* out);
+
 /* The hardware probes (lane-layout known-answer kernels, machine-ceiling micro-benchmarks) are NOT part of this library: they live in
  * libcvhip_probes.so, declared in include/cvhip_probes.h. */
 

@@ -1,0 +1,102 @@
+"""CPU-only check of the row-band convolution kernel's HOST-SIDE plan (csrc/conv_band.hip, cvhip_conv2d_band_plan): band heights, wave
+layout, LDS budget and the default policy are pure host arithmetic — every invariant the device code relies on is checked here without a
+GPU, for each of the kernel's forms (narrow / wide waves, with and without the LDS read-ahead). The device side of the same plans is
+tests/test_gpu_band.py. Replaces aten::convolution's algorithm choice for the stride-1 3x3 layers (conv_module.py:209)."""
+import ctypes as C
+import os
+
+import pytest
+
+from cvpytorch_amd import lib as L
+from cvpytorch_amd import ops
+
+KEYS = ("NF", "WN", "MFW", "PPS", "PF", "TH", "bands", "n_tiles", "total", "lds", "PH", "PW", "NW")
+ENV = ("CVHIP_BAND", "CVHIP_BAND_NF", "CVHIP_BAND_PF", "CVHIP_BAND_TH", "CVHIP_BAND_NW")
+
+
+def plan(shape, dgrad=False, pad=1, dil=1, **env):
+    N, Cc, H, W, K = shape
+    for k in ENV:
+        os.environ.pop(k, None)
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        d = ops.conv_desc(N, Cc, H, W, K, 3, 3, (1, 1), (pad, pad), (dil, dil), 1, Cc, K)
+        buf = (C.c_int32 * L.BAND_PLAN_INTS)()
+        r = L.load().cvhip_conv2d_band_plan(C.byref(d), 1 if dgrad else 0, buf)
+    finally:
+        for k in ENV:
+            os.environ.pop(k, None)
+    assert r in (0, 1)
+    return dict(zip(KEYS, buf)) if r else None
+
+
+SHAPES = [
+    (64, 128, 40, 40, 128), (64, 64, 80, 80, 64), (64, 32, 160, 160, 32), (64, 256, 20, 20, 256),   # YOLOv5-s, batch 64
+    (16, 64, 128, 256, 64), (16, 128, 64, 128, 128), (16, 256, 32, 64, 256), (16, 512, 32, 64, 512),  # DeepLabv3+ R50, batch 16
+    (3, 128, 17, 19, 128), (1, 32, 23, 37, 32), (2, 64, 9, 300, 64), (2, 96, 12, 12, 64), (2, 64, 14, 18, 128),
+]
+FORMS = [dict(CVHIP_BAND_NF=2, CVHIP_BAND_PF=0), dict(CVHIP_BAND_NF=2, CVHIP_BAND_PF=1), dict(CVHIP_BAND_NF=4, CVHIP_BAND_PF=0),
+         dict(CVHIP_BAND_NF=4, CVHIP_BAND_PF=1), dict(CVHIP_BAND_NF=2, CVHIP_BAND_PF=0, CVHIP_BAND_NW=4), dict(CVHIP_BAND_NF=4, CVHIP_BAND_PF=1, CVHIP_BAND_NW=4)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("form", FORMS)
+@pytest.mark.parametrize("geom", [(1, 1), (2, 2), (0, 1)])
+def test_band_plan_invariants(shape, form, geom):
+    pad, dil = geom
+    N, Cc, H, W, K = shape
+    OH, OW = H + 2 * pad - 2 * dil, W + 2 * pad - 2 * dil
+    fOH, fOW, fK, fC = OH, OW, K, Cc
+    for dgrad in (False, True):
+        # dgrad is the same GEMM with the roles swapped: it writes the H x W input gradient (Cc channels) from the K-channel output gradient
+        OH, OW, K, Cc = (H, W, shape[1], shape[4]) if dgrad else (fOH, fOW, fK, fC)
+        pl = plan(shape, dgrad, pad, dil, CVHIP_BAND=2, **form)
+        if pl is None:
+            # the forced form does not fit: wide waves need a 64- or 128-channel tile; rows wider than a block's fragment slots
+            # the kernel's channel shapes: output 32, 64 or a multiple of 128, input a multiple of 32
+            # ... and even a one-row band must fit the LDS (two patch buffers when there is more than one 32-channel chunk)
+            pw1 = (OW + 2 * dil + 7) // 8 * 8
+            pieces1 = -(-(1 + 2 * dil) * pw1 * 4 // 512)
+            assert not (K in (32, 64) or K % 128 == 0) or Cc % 32 or OW > 16 * 13 * (8 // max(1, min(K, 128) // 32)) or \
+                pieces1 > 12 or (2 if Cc > 32 else 1) * pieces1 * 8192 + 8192 > 156 * 1024, (shape, dgrad)
+            continue
+        assert pl["NF"] == form["CVHIP_BAND_NF"] or (form["CVHIP_BAND_NF"] == 4 and pl["NF"] == 2)   # wide where it fits, narrow elsewhere
+        BN = min(K, 128)
+        assert pl["WN"] * 16 * pl["NF"] == BN and pl["n_tiles"] * BN == K
+        assert pl["NW"] in (4, 8) and (pl["NW"] == 8 or form.get("CVHIP_BAND_NW") == 4) and pl["WN"] <= pl["NW"]
+        WM = pl["NW"] // pl["WN"]
+        assert pl["MFW"] in (7, 13) and (pl["NF"] == 2 or pl["MFW"] == 7)
+        # every output pixel of a band has a fragment slot; the bands cover the image; one block per (image, band, channel tile)
+        assert pl["MFW"] * WM * 16 >= pl["TH"] * OW
+        assert pl["bands"] == -(-OH // pl["TH"]) and pl["total"] == N * pl["bands"] * pl["n_tiles"]
+        # even bands: no band is more than one row higher than another would have to be
+        assert pl["TH"] == -(-OH // pl["bands"])
+        # the patch: TH output rows + the taps' halo, row pitch a multiple of 8 pixels that holds a row and its halo
+        assert pl["PH"] == pl["TH"] + 2 * dil and pl["PW"] % 8 == 0 and pl["PW"] >= OW + 2 * dil
+        # the DMA pieces (PPS per wave and K step, six steps, 16 pixels each, NW waves) cover it, in one or two buffers + the dummy slots;
+        # two co-resident 4-wave blocks share the CU's 160 KB
+        pieces = -(-pl["PH"] * pl["PW"] * 4 // (64 * pl["NW"]))
+        assert pieces <= pl["PPS"] * 6 and (pl["PPS"] == 1) == (pieces <= 6)
+        bufs = 2 if Cc > 32 else 1
+        assert pl["lds"] >= (bufs * pieces + 1) * pl["NW"] * 1024 and pl["lds"] <= (78 if pl["NW"] == 4 else 156) * 1024
+        # the read-ahead exists in the 7-fragment forms only, and never holds more fragments than the wave owns
+        assert pl["PF"] == 0 or (form["CVHIP_BAND_PF"] == 1 and pl["MFW"] == 7 and 0 < pl["PF"] <= 7)
+        if form["CVHIP_BAND_PF"] == 1 and pl["MFW"] == 7:
+            assert pl["PF"] > 0
+
+
+def test_band_default_policy():
+    """the default policy (profiles/r05_band_bench.log) takes the two YOLOv5-s shapes the kernel measured faster on — one block per CU
+    and round, nearly full waves — and leaves the others to the patch-resident / per-tap kernels"""
+    for shape in ((64, 128, 40, 40, 128), (64, 64, 80, 80, 64)):
+        for dgrad in (False, True):
+            pl = plan(shape, dgrad)
+            assert pl is not None and pl["n_tiles"] == 1 and pl["total"] % 256 == 0 and pl["TH"] == 10, (shape, pl)
+    for shape in ((64, 32, 160, 160, 32), (64, 256, 20, 20, 256), (16, 128, 64, 128, 128), (16, 64, 128, 256, 64), (16, 256, 32, 64, 256)):
+        assert plan(shape) is None, shape
+    assert plan((64, 128, 40, 40, 128), CVHIP_BAND=0) is None
+    # stride 2, 1x1 and grouped convolutions never reach the kernel
+    d = ops.conv_desc(64, 128, 40, 40, 128, 3, 3, (2, 2), (1, 1), (1, 1), 1, 128, 128)
+    assert L.load().cvhip_conv2d_band_plan(C.byref(d), 0, None) == 0
+    d = ops.conv_desc(64, 128, 40, 40, 128, 1, 1, (1, 1), (0, 0), (1, 1), 1, 128, 128)
+    assert L.load().cvhip_conv2d_band_plan(C.byref(d), 0, None) == 0

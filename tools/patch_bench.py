@@ -98,7 +98,7 @@ def main():
                 if s == 1:
                     res.setdefault((name, "fprop"), []).append(timed(fprop, nsets))
                 res.setdefault((name, "dgrad"), []).append(timed(dgrad, nsets))
-                if name != "per-tap" and s == 1 and lib.cvhip_conv2d_fprop_prologue_ok(C.byref(pdesc), 1):
+                if name != "per-tap" and s == 1 and not os.environ.get("NO_PRO") and lib.cvhip_conv2d_fprop_prologue_ok(C.byref(pdesc), 1):
                     res.setdefault((name, "fprop+pro"), []).append(timed(fprop_pro, nsets))
                     res.setdefault((name, "fprop+pro+z"), []).append(timed(fprop_pro_z, nsets))
                 for k in env:
@@ -109,6 +109,14 @@ def main():
         ncl = lib.cvhip_conv2d_patch_plan(C.byref(pdesc), 0, buf, 4)
         geo = "TH x TW = %d x %d, patch %d x %d, tiles %d, BN %d, CK %d" % (buf[12], buf[13], buf[14], buf[15], buf[24], buf[25], buf[26]) if ncl > 0 else "fprop: per-tap"
         print("%-32s %s  (%d operand sets)" % (label, geo, nsets))
+        for name, env in variants:   # which form of the band kernel each variant's fprop runs (conv_band.hip; 0 = another kernel)
+            os.environ.update(env)
+            bb = (C.c_int32 * L.BAND_PLAN_INTS)()
+            if hasattr(lib, "cvhip_conv2d_band_plan") and lib.cvhip_conv2d_band_plan(C.byref(pdesc), 0, bb) > 0:
+                print("    %-10s band plan: %d ch/wave, %d x %d waves x %d fragments, PPS %d, read-ahead %d, TH %d, %d blocks, LDS %d KB" %
+                      (name, 16 * bb[0], bb[1], 8 // bb[1], bb[2], bb[3], bb[4], bb[5], bb[8], bb[9] // 1024))
+            for k in env:
+                os.environ.pop(k, None)
         for (name, what), v in res.items():
             us = sorted(v)[len(v) // 2]
             print("    %-10s %-12s %8.1f us   %7.1f TF/s   (min %.1f)" % (name, what, us, flops / us / 1e6 if "bn_act" not in what else 0.0, min(v)))

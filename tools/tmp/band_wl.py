@@ -13,7 +13,9 @@ nsets = 6
 xs = [torch.randn(N, H, W, Cc, device=dev).to(ops.ACT_DTYPE) for _ in range(nsets)]
 ys = [torch.empty(N, H, W, K, device=dev, dtype=ops.ACT_DTYPE) for _ in range(nsets)]
 stream = ops._stream()
-for name, env in (("band", {"CVHIP_BAND": "2"}), ("patch", {"CVHIP_BAND": "0", "CVHIP_PATCH": "1"}), ("tap", {"CVHIP_BAND": "0", "CVHIP_PATCH": "0"})):
+for name, env in (("narrow", {"CVHIP_BAND": "2", "CVHIP_BAND_NF": "2", "CVHIP_BAND_PF": "0"}), ("wide", {"CVHIP_BAND": "2", "CVHIP_BAND_NF": "4", "CVHIP_BAND_PF": "0"}),
+                  ("wide_pf", {"CVHIP_BAND": "2", "CVHIP_BAND_NF": "4", "CVHIP_BAND_PF": "1"}),
+                  ("patch", {"CVHIP_BAND": "0", "CVHIP_PATCH": "1"}), ("tap", {"CVHIP_BAND": "0", "CVHIP_PATCH": "0"})):
     os.environ.update(env)
     for i in range(30):
         L.call("cvhip_conv2d_fprop", C.byref(pdesc), xs[i % nsets].data_ptr(), st.w_fprop.data_ptr(), None, ys[i % nsets].data_ptr(), None, stream)
