@@ -102,6 +102,7 @@ void plan_fprop(const cvhip_conv_desc* d, IgemmParams* p) {
   c.r_step = 1;
   c.s0 = 0;
   c.s_step = 1;
+  p->band_image = band_image_fprop(d) ? 1 : 0;
 }
 
 int plan_dgrad(const cvhip_conv_desc* d, IgemmParams* p) {
@@ -143,6 +144,7 @@ int plan_dgrad(const cvhip_conv_desc* d, IgemmParams* p) {
     }
   }
   p->ncls = n;
+  p->band_image = band_image_dgrad(d) ? 1 : 0;
   return n;
 }
 
@@ -235,6 +237,16 @@ int64_t cvhip_conv2d_dgrad_weight_elems(const cvhip_conv_desc* d) {
   int64_t e = 0;
   for (int i = 0; i < n; ++i) e += (int64_t)d->C * p.cls[i].TR * p.cls[i].TS * d->K;
   return e;
+}
+
+int64_t cvhip_conv2d_weight_image_elems(const cvhip_conv_desc* d, int which) {
+  int st = validate_dense_desc(d);
+  if (st) return st;
+  const int64_t krsc = (int64_t)d->K * d->R * d->S * d->C;
+  if (which == 0) return krsc + (band_image_fprop(d) ? krsc : 0);
+  if (which != 1) return CVHIP_ERR_INVALID;
+  const int64_t e = cvhip_conv2d_dgrad_weight_elems(d);
+  return e < 0 ? e : e + (band_image_dgrad(d) ? krsc : 0);
 }
 
 int cvhip_div31_consts(int32_t d, uint32_t* mul, uint32_t* shift) {

@@ -48,8 +48,6 @@ constexpr int kBandWavesMax = 8;     // NW = 8: one 512-thread block per CU; NW 
 constexpr int kBandSteps = 9;        // 3 x 3 taps per chunk
 constexpr int kBandPieceSteps = 6;   // the next chunk's patch DMAs go out in the first six K steps of a chunk
 constexpr int kBandLdsMax = 156 * 1024;
-constexpr int kBandWavesDefault = 8;          // waves per block (CVHIP_BAND_NW overrides)
-constexpr bool kBandWideDefault = false;     // default policy takes the wide-wave (NF = 4) form where it fits (CVHIP_BAND_NF overrides)
 constexpr int kBandWidePF = 4;                // wide-wave form with LDS prefetch: fragments read one step ahead (register budget)
 constexpr int kBandPrefetchDefault = 0;      // 7-fragment forms: LDS reads one K step ahead (CVHIP_BAND_PF overrides)
 
@@ -69,7 +67,6 @@ struct BandArgs {
   int dummy_off;       // byte offset of the 8 x 1 KB dummy DMA slots
   int buf_bytes;       // one patch buffer
   int n_tiles, total_tiles, Ktot;
-  int probe_coalesced; // dev (CVHIP_BAND_PROBE_W=1): every weight fetch reads 1 KB of contiguous memory — WRONG results, timing only
   unsigned ow_magic;   // ceil(2^32 / OW)
   unsigned pw_magic;   // ceil(2^32 / PW)
 };
@@ -222,10 +219,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_band_kernel(const BandArgs p)
   for (int i = 0; i < 3; ++i) roff[i] = __builtin_amdgcn_readfirstlane((p.dh0 + i * p.dh_step - p.lo_h) * PW * 64);
   int aj[MFW];
 
-  // weight fragments: lane (row n = lane & 15, K group g) reads Wt[n][k0 + g*8 .. +7]
-  const h16_t* const wbase = p.w + (int64_t)(n0 + wn * (16 * NF)) * p.Ktot;   // wave-uniform
-  const unsigned wlane = p.probe_coalesced ? (unsigned)(lane * 16) : (unsigned)(((lane & 15) * p.Ktot + g * 8) * (int)sizeof(h16_t));
-  const int wfrag = 16 * p.Ktot;                                                // elements between two 16-channel fragments
+  // weight fragments from the layer's BAND IMAGE (conv_plan.h): the fragment of (K step = tap * NC + chunk, 16-channel group f) is the
+  // 1 KB at ((step * (Nout / 16) + f) * 64 + lane) * 16 bytes — lane (row n = lane & 15, K group g = lane >> 4) holds Wt[n][k0 + g*8 .. +7]
+  // as the MFMA wants it, and the wave's fetch is one contiguous KB instead of sixteen 64-byte row pieces
+  const int nfr16 = p.Nout >> 4;
+  const h16_t* const wbase = p.w + (int64_t)((n0 >> 4) + wn * NF) * 512;   // wave-uniform
+  const unsigned wlane = (unsigned)(lane * 16);
 
   f32x4 acc[NF][MFW];
 #pragma unroll
@@ -236,9 +235,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_band_kernel(const BandArgs p)
   band_u32x4 wb[3][NF];  // sets named by K step % 3; LEAD + 1 of them are live at a time
   auto load_b = [&](int set, int tt, int cc) __attribute__((always_inline)) {
     cc = cc < NC ? cc : NC - 1;  // (past the end: a valid, unused fetch — the VMEM counts stay uniform)
-    const int off = tt * Cin + (cc << 5);
+    const int off = (tt * NC + cc) * nfr16 * 512;
 #pragma unroll
-    for (int a = 0; a < NF; ++a) band_gload16(wb[set][a], wbase + (off + a * wfrag), wlane);
+    for (int a = 0; a < NF; ++a) band_gload16(wb[set][a], wbase + (off + a * 512), wlane);
   };
 
   // ---- prologue: the first chunk's patch, the first LEAD K steps' weights --------------------------------------------------
@@ -532,17 +531,9 @@ static bool band_fit(const IgemmParams& p, int NF, int cap, int NW, int EH, int 
   return true;
 }
 
-static bool band_plan(const IgemmParams& p, BandPlan* pl) {
-  if (p.ncls != 1 || p.in_sh != 1 || p.in_sw != 1 || p.out_sh != 1 || p.out_sw != 1) return false;
+// One candidate: blocks of NW waves. *policy_ok = the default policy would launch it (below).
+static bool band_plan_nw(const IgemmParams& p, int NW, BandPlan* pl, bool* policy_ok) {
   const IgemmClass& c = p.cls[0];
-  if (c.TR != 3 || c.TS != 3 || c.out_oh != 0 || c.out_ow != 0 || c.OHi != p.OH || c.OWi != p.OW || c.M <= 0) return false;
-  if (p.bias || p.ep_scale || p.ep_shift || p.ep_act != CVHIP_ACT_NONE || p.pro_scale || p.z_out || p.y2 || p.x_image || p.tail_y) return false;
-  if (p.stats && !p.stats_acc) return false;
-  if ((p.Cin & 31) || (p.x_ld & 7) || (((uintptr_t)p.x) & 15) || (((uintptr_t)p.w) & 15) || (c.w_off & 7)) return false;
-  if (!(p.Nout == 32 || p.Nout == 64 || (p.Nout & 127) == 0)) return false;
-  if ((p.y_ld & 3) || (((uintptr_t)p.y) & 7)) return false;
-  if (p.res && ((p.res_ld & 3) || (((uintptr_t)p.res) & 7))) return false;
-  if (p.OW >= 65536 || p.OW < 1 || (int64_t)p.NB * p.IH * p.IW * (p.x_ld >> 3) >= (1ll << 31)) return false;  // 16-byte units in 31 bits
   const int BN = band_imin(p.Nout, 128);
   const int h_a = c.dh0, h_b = c.dh0 + 2 * c.dh_step, w_a = c.dw0, w_b = c.dw0 + 2 * c.dw_step;
   const int lo_h = band_imin(h_a, h_b), hi_h = band_imax(h_a, h_b), lo_w = band_imin(w_a, w_b), hi_w = band_imax(w_a, w_b);
@@ -551,22 +542,14 @@ static bool band_plan(const IgemmParams& p, BandPlan* pl) {
   const int NC = p.Cin / 32;
   const int n_tiles = p.Nout / BN;
   // CVHIP_BAND_NF (read per launch): 2 = narrow waves (32 channels x <= 13 pixel fragments), 4 = wide waves (64 channels x <= 7 pixel
-  // fragments) wherever the tile is 64 or 128 channels wide and the geometry fits (narrow elsewhere), 0 = default policy (below)
+  // fragments) wherever the tile is 64 or 128 channels wide and the geometry fits (narrow elsewhere), 0 = default (narrow: below)
   const int want_nf = band_env("CVHIP_BAND_NF", 0);
   int th2 = 0, np2 = 0, th4 = 0, np4 = 0;
   int64_t rounds2 = 0, rounds4 = 0;
-  // CVHIP_BAND_NW (read per launch): 8 = one 512-thread block per CU, 4 = two co-resident 256-thread blocks (where the geometry fits:
-  // 512-thread blocks elsewhere)
-  int NW = band_env("CVHIP_BAND_NW", kBandWavesDefault) == 4 ? 4 : 8;
-  bool fit4 = false, fit2 = false;
-  for (;; NW = 8) {
-    fit4 = want_nf != 2 && band_fit(p, 4, 7, NW, EH, PW, &th4, &np4, &rounds4);
-    fit2 = !(want_nf == 4 && fit4) && band_fit(p, 2, 13, NW, EH, PW, &th2, &np2, &rounds2);
-    if (fit2 || fit4 || NW == 8) break;
-  }
+  const bool fit4 = want_nf == 4 && band_fit(p, 4, 7, NW, EH, PW, &th4, &np4, &rounds4);
+  const bool fit2 = !fit4 && band_fit(p, 2, 13, NW, EH, PW, &th2, &np2, &rounds2);
   if (!fit2 && !fit4) return false;
-  // default: the wide-wave form where its bands fill the CUs in as few rounds as the narrow form's (measured: profiles/r05_band_bench.log)
-  const bool wide = fit4 && (!fit2 || want_nf == 4 || (kBandWideDefault && rounds4 <= rounds2));
+  const bool wide = fit4;
   const int NF = wide ? 4 : 2;
   const int TH = wide ? th4 : th2;
   const int best_nplw = wide ? np4 : np2;
@@ -601,7 +584,6 @@ static bool band_plan(const IgemmParams& p, BandPlan* pl) {
   if (total >= (1ll << 30)) return false;
   a.total_tiles = (int)total;
   a.Ktot = 9 * p.Cin;
-  a.probe_coalesced = band_env("CVHIP_BAND_PROBE_W", 0);
   a.ow_magic = div_magic(p.OW);
   a.pw_magic = div_magic(PW);
   pl->WN = WN;
@@ -613,19 +595,44 @@ static bool band_plan(const IgemmParams& p, BandPlan* pl) {
   a.dummy_off = (NC > 1 ? 2 : 1) * a.buf_bytes;
   pl->NW = NW;
   pl->lds = band_imax(a.dummy_off + NW * 1024, WM * BN * 2 * (int)sizeof(float));
-  if (band_mode() >= 2) return true;
-  // Default policy = where it measured FASTER than the patch-resident / per-tap kernels (profiles/r05_band_bench.log, isolated launches on
-  // rotating operands): one 64- or 128-wide channel tile, waves that are nearly full, a block count that fills whole rounds
-  // of the 256 CUs — YOLOv5-s 128 -> 128 @40x40 b64 37.6 vs 43.9 us, 64 -> 64 @80x80 54.8 vs 57.9. It LOSES with 200-pixel bands
-  // (256 -> 256 @20x20: 43.9 vs 40.9: two channel tiles re-stage the same patch and a weight fragment serves 7 MFMAs), with 32-wide
-  // outputs (every wave fetches the same fragments) and when the bands leave CUs idle (DeepLabv3+ b16: 352 blocks, 69 vs 46.6 us).
-  if (n_tiles != 1 || BN < 64) return false;
-  if (NF == 2 && pl->MFW != 13) return false;
-  if (pl->MFW * WM * 16 * (NF == 4 ? 17 : 18) > TH * p.OW * 20) return false;   // <= 10 % of the fragment slots idle (wide waves: 15 %)
+  // Default policy = the classes of problems the kernel measured FASTER on than the patch-resident / per-tap kernels, isolated launches on
+  // rotating operands AND in the replayed train step (profiles/r05_band_image_bench.log, r05_band_policy_step_ab.log): at most two
+  // 128-wide channel tiles, block counts that fill whole rounds of the resident block slots, waves that are nearly full (a
+  // single-chunk layer — 32 input channels — is bound by its patch and output traffic, not by MFMA slots: exempt). YOLOv5-s batch 64:
+  // 128 -> 128 @40x40 34.5 vs 44.1 us, 256 -> 256 @20x20 32.3 vs 42.1, 32 -> 32 @160x160 71.3 vs 82.1, 64 -> 64 @80x80 55.4 vs 58.6.
+  // It LOSES where the bands leave slots or fragment slots idle (DeepLabv3+ batch 16: 128 -> 128 @64x128 59 vs 45.4 us, 64 -> 64
+  // @128x256 92 vs 70) and is level on four-tile problems (512 -> 512 dilated: 149 vs 149).
   const int slots = NW == 4 ? 512 : 256;
   const int64_t rounds = (total + slots - 1) / slots;
-  if (total * 10 < rounds * slots * 9) return false;                     // >= 90 % of the resident block slots of every round busy
+  *policy_ok = n_tiles <= 2 && total * 10 >= rounds * slots * 9 &&                                 // >= 90 % of the block slots of every round busy
+               (NC == 1 || (int64_t)TH * p.OW * 20 >= (int64_t)pl->MFW * WM * 16 * 17);          // >= 85 % of the fragment slots busy
   return true;
+}
+
+static bool band_plan(const IgemmParams& p, BandPlan* pl) {
+  if (p.ncls != 1 || p.in_sh != 1 || p.in_sw != 1 || p.out_sh != 1 || p.out_sw != 1) return false;
+  const IgemmClass& c = p.cls[0];
+  if (c.TR != 3 || c.TS != 3 || c.out_oh != 0 || c.out_ow != 0 || c.OHi != p.OH || c.OWi != p.OW || c.M <= 0) return false;
+  if (p.bias || p.ep_scale || p.ep_shift || p.ep_act != CVHIP_ACT_NONE || p.pro_scale || p.z_out || p.y2 || p.x_image || p.tail_y) return false;
+  if (p.stats && !p.stats_acc) return false;
+  if (!p.band_image) return false;   // the fragment-ordered weight copy exists for this layer (conv_plan.h: band_image_fprop / _dgrad)
+  if ((p.Cin & 31) || (p.x_ld & 7) || (((uintptr_t)p.x) & 15) || (((uintptr_t)p.w) & 15) || (c.w_off & 7)) return false;
+  if (!(p.Nout == 32 || p.Nout == 64 || (p.Nout & 127) == 0)) return false;
+  if ((p.y_ld & 3) || (((uintptr_t)p.y) & 7)) return false;
+  if (p.res && ((p.res_ld & 3) || (((uintptr_t)p.res) & 7))) return false;
+  if (p.OW >= 65536 || p.OW < 1 || (int64_t)p.NB * p.IH * p.IW * (p.x_ld >> 3) >= (1ll << 31)) return false;  // 16-byte units in 31 bits
+  // CVHIP_BAND_NW (read per launch): 8 = 512-thread blocks only (one per CU), 4 = 256-thread blocks (two co-resident per CU) wherever the
+  // geometry fits, 0 = default: two co-resident blocks where the policy accepts that plan, else one 512-thread block
+  const int want_nw = band_env("CVHIP_BAND_NW", 0);
+  const bool any = band_mode() >= 2;
+  for (int k = 0; k < 2; ++k) {
+    const int NW = k == 0 ? 4 : 8;
+    if (want_nw == 8 && NW == 4) continue;
+    bool ok = false;
+    if (!band_plan_nw(p, NW, pl, &ok)) continue;
+    if (ok || any) return true;
+  }
+  return false;
 }
 
 template <int WN, int MFW, int PPS, int NF, int LEAD, int PF, int NW>
@@ -699,7 +706,7 @@ int try_launch_band(const IgemmParams& p, hipStream_t stream) {
   if (!band_plan(p, &pl)) return -1;
   BandArgs& a = pl.a;
   a.x = p.x;
-  a.w = p.w + p.cls[0].w_off;
+  a.w = p.w + p.cls[0].w_off + (int64_t)p.Nout * 9 * p.Cin;   // the band image behind the row-major one
   a.y = p.y;
   a.stats = p.stats ? reinterpret_cast<double*>(p.stats) : nullptr;
   a.stats_ld = p.stats_ld;

@@ -83,6 +83,8 @@ struct IgemmCommon {
   // channels), read plane by plane and rounded to 16 bits on the way into the LDS patch — `x` is unused then
   const float* x_image;
   int x_planes;
+  // the weight image carries the band kernel's fragment-ordered copy behind the row-major one (band_image_fprop / band_image_dgrad below)
+  int band_image;
 };
 
 constexpr int kKernelClasses = 4;
@@ -105,6 +107,36 @@ inline IgemmKernArgs narrow_plan(const IgemmParams& p, int first, int count) {
 
 inline int conv_out_dim(int in, int pad, int dil, int k, int stride) {
   return (in + 2 * pad - dil * (k - 1) - 1) / stride + 1;
+}
+
+// ---- band image (conv_band.hip) ----------------------------------------------------------------------------------------------
+// The row-band kernel's waves fetch their weight fragments (16 output channels x 32 reduction elements of one tap) straight from
+// global memory. In the row-major image Wt[n][tap * cin + c] such a fragment is 16 rows x 64 bytes — sixteen half cache lines per
+// wave instruction, and the texture addresser, not the MFMA pipe, bounds the kernel (profiles/r05_band_coalesced_weight_probe.log:
+// 256 -> 256 @20x20 44 -> 32 us with the same fetches made contiguous). So stride-1 3x3 layers whose channel counts the band kernel
+// accepts get a SECOND copy of their weights, in fragment order, appended to the row-major image (element offset nrows * 9 * cin):
+//   16-byte vector v = ((tap * (cin / 32) + c / 32) * (nrows / 16) + n / 16) * 64 + ((c % 32) / 8) * 16 + n % 16
+// holds Wt[n][tap * cin + c .. c + 7] (c % 8 == 0): a fragment is 1 KB of contiguous memory, lane l of the MFMA operand at l * 16.
+// nrows / cin: output / reduction channels of the GEMM (fprop: K / C of the layer; dgrad: C / K). Pure functions of the descriptor:
+// the packers (weights_optim.hip), the allocation size (cvhip_conv2d_weight_image_elems) and the planners agree by construction.
+inline bool band_image_shape(int nrows, int cin) { return (cin & 31) == 0 && (nrows == 32 || nrows == 64 || (nrows > 0 && (nrows & 127) == 0)); }
+inline bool band_image_layer(const cvhip_conv_desc* d) {
+  return d->R == 3 && d->S == 3 && d->stride_h == 1 && d->stride_w == 1 && (d->k_valid <= 0 || d->k_valid == d->K) &&
+         (d->c_valid <= 0 || d->c_valid == d->C);
+}
+inline bool band_image_fprop(const cvhip_conv_desc* d) { return band_image_layer(d) && band_image_shape(d->K, d->C); }
+inline bool band_image_dgrad(const cvhip_conv_desc* d) { return band_image_layer(d) && band_image_shape(d->C, d->K); }
+// vector v of a band image -> (row n, tap, first reduction channel c0)
+__host__ __device__ __forceinline__ void band_image_decode(int64_t v, int nrows, int cin, int* n, int* tap, int* c0) {
+  const int lane = (int)(v & 63);
+  const int64_t fr = v >> 6;
+  const int nf = nrows >> 4;
+  const int f = (int)(fr % nf);
+  const int st = (int)(fr / nf);
+  const int nc = cin >> 5;
+  *tap = st / nc;
+  *c0 = (st - *tap * nc) * 32 + (lane >> 4) * 8;
+  *n = f * 16 + (lane & 15);
 }
 
 // exact n / d for n, d < 2^16 as __umulhi(n, magic), magic = ceil(2^32 / d)  (d == 1 -> magic 0: caller returns n)

@@ -72,6 +72,41 @@ __global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* __restrict
   }
 }
 
+// ---- band image (conv_plan.h): the fragment-ordered copy of a stride-1 3x3 layer's weights, straight from the fp32 master ------
+// One thread per 16-byte vector of the copy. fprop (rows = K, reduction = C): eight consecutive floats of master[n][tap][c0..];
+// dgrad (rows = C, reduction = K): master[k0 .. k0 + 7][r][s][n], a gather with a stride of R*S*C floats (weights are L2-resident).
+__device__ __forceinline__ void band_image_store(const float* __restrict__ master, h16_t* __restrict__ dst, int64_t v, int K, int C, bool dgrad,
+                                                 int r0, int r_step, int s0, int s_step) {
+  int n, tap, c0;
+  float f[8];
+  if (!dgrad) {
+    band_image_decode(v, K, C, &n, &tap, &c0);
+    const float4* q = reinterpret_cast<const float4*>(master + ((int64_t)n * 9 + tap) * C + c0);
+    const float4 a = q[0], b = q[1];
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+  } else {
+    band_image_decode(v, C, K, &n, &tap, &c0);
+    const int i = tap / 3, j = tap - i * 3;
+    const int r = r0 + i * r_step, s2 = s0 + j * s_step;
+    const float* q = master + ((int64_t)c0 * 9 + r * 3 + s2) * C + n;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = q[(int64_t)e * 9 * C];
+  }
+  uint4 u;
+  u.x = pack2(f[0], f[1]);
+  u.y = pack2(f[2], f[3]);
+  u.z = pack2(f[4], f[5]);
+  u.w = pack2(f[6], f[7]);
+  reinterpret_cast<uint4*>(dst)[v] = u;
+}
+
+__global__ __launch_bounds__(256) void band_image_kernel(const float* __restrict__ master, h16_t* __restrict__ dst, int K, int C, int dgrad, int r0,
+                                                         int r_step, int s0, int s_step) {
+  const int64_t nv = (int64_t)K * 9 * C / 8;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nv; v += (int64_t)gridDim.x * 256)
+    band_image_store(master, dst, v, K, C, dgrad != 0, r0, r_step, s0, s_step);
+}
+
 // ---- batched operand preparation ------------------------------------------------------------------------
 // One launch packs the bf16 fprop AND dgrad images of every conv layer of a model (a training step otherwise pays one cast
 // and one pack launch per layer: ~115 sub-5-us kernels on the step's critical path for YOLOv5-s). The table lives in device
@@ -88,6 +123,7 @@ struct PrepItem {
   h16_t* wd;
   int K, R, S, C, Kv, Cv;
   int ncls, blk_begin, nblk_f, nblk_d;
+  int nblk_bf, nblk_bd;  // band images (conv_plan.h) behind the fprop / dgrad image: 256 16-byte vectors per block
   int ktiles, ctiles;  // dgrad image: one block per (tap, 64 x 64 tile of the [K][C] slice of that tap)
   PrepClass cls[kMaxClasses];
 };
@@ -133,6 +169,14 @@ __global__ __launch_bounds__(256) void prep_all_kernel(const PrepItem* __restric
   // reads coalesced along c, writes coalesced along k (the one-element-per-thread version read with a stride of R*S*C floats:
   // 0.36 ms per step for the 26 M parameters of DeepLabv3+)
   b -= it.nblk_f;
+  if (b >= it.nblk_d) {  // band images, fprop's first
+    b -= it.nblk_d;
+    const bool dg = b >= it.nblk_bf;
+    if (dg) b -= it.nblk_bf;
+    const int64_t v = (int64_t)b * 256 + threadIdx.x;
+    if (v < n / 8) band_image_store(src, (dg ? it.wd : it.wf) + n, v, K, C, dg, it.cls[0].r0, it.cls[0].r_step, it.cls[0].s0, it.cls[0].s_step);
+    return;
+  }
   __shared__ float tile[kPrepTile][kPrepTile + 1];
   const int per_tap = it.ktiles * it.ctiles;
   const int tapidx = b / per_tap;
@@ -411,7 +455,18 @@ int pack_weights(const cvhip_conv_desc* d, const float* master, void* w_fprop, v
       if (e > maxe) maxe = e;
     }
     hipLaunchKernelGGL(pack_dgrad_kernel, dim3(grid1d(maxe), ncls), dim3(256), 0, stream, master, (h16_t*)w_dgrad, p);
-    return check_launch("pack_dgrad_kernel");
+    int st = check_launch("pack_dgrad_kernel");
+    if (st) return st;
+    if (band_image_dgrad(d)) {  // (stride 1: one class, its image is the whole K*R*S*C)
+      hipLaunchKernelGGL(band_image_kernel, dim3(grid1d(n / 8)), dim3(256), 0, stream, master, (h16_t*)w_dgrad + n, d->K, d->C, 1, ip.cls[0].r0,
+                         ip.cls[0].r_step, ip.cls[0].s0, ip.cls[0].s_step);
+      st = check_launch("band_image_kernel(dgrad)");
+      if (st) return st;
+    }
+  }
+  if (w_fprop && band_image_fprop(d)) {
+    hipLaunchKernelGGL(band_image_kernel, dim3(grid1d(n / 8)), dim3(256), 0, stream, master, (h16_t*)w_fprop + n, d->K, d->C, 0, 0, 1, 0, 1);
+    return check_launch("band_image_kernel(fprop)");
   }
   return CVHIP_OK;
 }
@@ -522,7 +577,9 @@ int cvhip_prep_plan_build(const cvhip_prep_entry* entries, int32_t n, void* tabl
       it.ctiles = cdiv(d->C, kPrepTile);
       it.nblk_d = tapn * it.ktiles * it.ctiles;
     }
-    blk += it.nblk_f + it.nblk_d;
+    it.nblk_bf = band_image_fprop(d) ? (int)cdiv64(nel / 8, 256) : 0;
+    it.nblk_bd = (it.wd && band_image_dgrad(d)) ? (int)cdiv64(nel / 8, 256) : 0;
+    blk += it.nblk_f + it.nblk_d + it.nblk_bf + it.nblk_bd;
   }
   *total_blocks = blk;
   return CVHIP_OK;

@@ -105,6 +105,7 @@ SIGNATURES = {
     "cvhip_conv1x1_stream_blocks": (_i32, [_i32, _i32, _i64, _i32]),
     "cvhip_conv_stem_blocks": (_i32, [_dp]),
     "cvhip_conv2d_dgrad_weight_elems": (_i64, [_dp]),
+    "cvhip_conv2d_weight_image_elems": (_i64, [_dp, _i32]),
     "cvhip_conv2d_dgrad_plan": (_i32, [_dp, C.POINTER(_i32), _i32]),
     "cvhip_div31_consts": (_i32, [_i32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "cvhip_conv2d_prep_weights": (_i32, [_dp, _p, _p, _p, _p]),

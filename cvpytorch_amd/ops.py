@@ -543,14 +543,21 @@ class ConvState:
         master = _krsc_master(weight)
         lib = L.load()
         shape = (pdesc.K, pdesc.R, pdesc.S, pdesc.C)
-        if self.w_fprop is None or tuple(self.w_fprop.shape) != shape or self.w_fprop.device != dev or self.w_fprop.dtype != ACT_DTYPE:
-            self.w_fprop = torch.empty(shape, dtype=ACT_DTYPE, device=dev)
+        # image sizes from the library: stride-1 3x3 layers carry a second, fragment-ordered copy behind each image (the row-band
+        # kernel's operand, include/cvhip.h cvhip_conv2d_prep_weights); w_fprop is the [K][R][S][C] view of the front of its buffer
+        nf = int(lib.cvhip_conv2d_weight_image_elems(C.byref(pdesc), 0))
+        if nf < 0:
+            L.check(nf, "cvhip_conv2d_weight_image_elems")
+        if (self.w_fprop is None or tuple(self.w_fprop.shape) != shape or self.w_fprop.device != dev or self.w_fprop.dtype != ACT_DTYPE
+                or getattr(self, "_wf_buf", None) is None or self._wf_buf.numel() != nf):
+            self._wf_buf = torch.empty((nf,), dtype=ACT_DTYPE, device=dev)
+            self.w_fprop = self._wf_buf[:shape[0] * shape[1] * shape[2] * shape[3]].view(shape)
             self.w_dgrad = None
         wd = None
         if need_dgrad:
-            n = lib.cvhip_conv2d_dgrad_weight_elems(C.byref(pdesc))
+            n = lib.cvhip_conv2d_weight_image_elems(C.byref(pdesc), 1)
             if n < 0:
-                L.check(int(n), "cvhip_conv2d_dgrad_weight_elems")
+                L.check(int(n), "cvhip_conv2d_weight_image_elems")
             n = max(int(n), 8)
             wd = self.w_dgrad if (self.w_dgrad is not None and self.w_dgrad.numel() == n) else torch.empty((n,), dtype=ACT_DTYPE, device=dev)
         L.call("cvhip_conv2d_prep_weights", C.byref(pdesc), master.data_ptr(), self.w_fprop.data_ptr(), _ptr(wd), _stream())

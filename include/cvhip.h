@@ -114,7 +114,11 @@ int cvhip_div31_consts(int32_t d, uint32_t* mul, uint32_t* shift);
  *   w_fprop : bf16 [K][R*S*C]              (also the wgrad output layout)
  *   w_dgrad : bf16, per stride-parity class [C][taps(class)][K], classes concatenated
  *             (may be NULL when the layer's input needs no gradient)
+ * Stride-1 3x3 layers whose channel counts the row-band kernel accepts (conv_band.hip) carry a second, FRAGMENT-ORDERED copy of the
+ * same values behind each image (csrc/conv_plan.h "band image": 1 KB per MFMA weight fragment, so that a wave's fetch is contiguous):
+ * the buffers must hold cvhip_conv2d_weight_image_elems(d, 0 / 1) elements — K*R*S*C, or twice that where the copy exists.
  * Replaces the implicit fp32->half weight cast autocast performs at trainer.py:179-184. */
+int64_t cvhip_conv2d_weight_image_elems(const cvhip_conv_desc* d, int which /* 0 = w_fprop, 1 = w_dgrad */);
 int cvhip_conv2d_prep_weights(const cvhip_conv_desc* d, const float* w_master_krsc,
                               void* w_fprop_bf16, void* w_dgrad_bf16, void* stream);
 

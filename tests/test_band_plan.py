@@ -35,8 +35,9 @@ SHAPES = [
     (16, 64, 128, 256, 64), (16, 128, 64, 128, 128), (16, 256, 32, 64, 256), (16, 512, 32, 64, 512),  # DeepLabv3+ R50, batch 16
     (3, 128, 17, 19, 128), (1, 32, 23, 37, 32), (2, 64, 9, 300, 64), (2, 96, 12, 12, 64), (2, 64, 14, 18, 128),
 ]
-FORMS = [dict(CVHIP_BAND_NF=2, CVHIP_BAND_PF=0), dict(CVHIP_BAND_NF=2, CVHIP_BAND_PF=1), dict(CVHIP_BAND_NF=4, CVHIP_BAND_PF=0),
-         dict(CVHIP_BAND_NF=4, CVHIP_BAND_PF=1), dict(CVHIP_BAND_NF=2, CVHIP_BAND_PF=0, CVHIP_BAND_NW=4), dict(CVHIP_BAND_NF=4, CVHIP_BAND_PF=1, CVHIP_BAND_NW=4)]
+FORMS = [dict(CVHIP_BAND_NF=2, CVHIP_BAND_PF=0, CVHIP_BAND_NW=8), dict(CVHIP_BAND_NF=2, CVHIP_BAND_PF=1, CVHIP_BAND_NW=8),
+         dict(CVHIP_BAND_NF=4, CVHIP_BAND_PF=0, CVHIP_BAND_NW=8), dict(CVHIP_BAND_NF=4, CVHIP_BAND_PF=1, CVHIP_BAND_NW=8),
+         dict(CVHIP_BAND_NF=2, CVHIP_BAND_PF=0, CVHIP_BAND_NW=4), dict(CVHIP_BAND_NF=4, CVHIP_BAND_PF=1, CVHIP_BAND_NW=4)]
 
 
 @pytest.mark.parametrize("shape", SHAPES)
@@ -63,7 +64,7 @@ def test_band_plan_invariants(shape, form, geom):
         assert pl["NF"] == form["CVHIP_BAND_NF"] or (form["CVHIP_BAND_NF"] == 4 and pl["NF"] == 2)   # wide where it fits, narrow elsewhere
         BN = min(K, 128)
         assert pl["WN"] * 16 * pl["NF"] == BN and pl["n_tiles"] * BN == K
-        assert pl["NW"] in (4, 8) and (pl["NW"] == 8 or form.get("CVHIP_BAND_NW") == 4) and pl["WN"] <= pl["NW"]
+        assert pl["NW"] in (4, 8) and (pl["NW"] == 8 or form["CVHIP_BAND_NW"] == 4) and pl["WN"] <= pl["NW"]   # (NW = 4 falls back to 8)
         WM = pl["NW"] // pl["WN"]
         assert pl["MFW"] in (7, 13) and (pl["NF"] == 2 or pl["MFW"] == 7)
         # every output pixel of a band has a fragment slot; the bands cover the image; one block per (image, band, channel tile)
@@ -86,14 +87,19 @@ def test_band_plan_invariants(shape, form, geom):
 
 
 def test_band_default_policy():
-    """the default policy (profiles/r05_band_bench.log) takes the two YOLOv5-s shapes the kernel measured faster on — one block per CU
-    and round, nearly full waves — and leaves the others to the patch-resident / per-tap kernels"""
-    for shape in ((64, 128, 40, 40, 128), (64, 64, 80, 80, 64)):
+    """the default policy (conv_band.hip band_plan_nw; profiles/r05_band_image_bench.log) takes the YOLOv5-s shapes the kernel measured
+    faster on — whole rounds of block slots, nearly full waves, two co-resident 4-wave blocks per CU where that plan qualifies — and leaves
+    DeepLabv3+'s (batch 16: idle slots) to the patch-resident / per-tap kernels"""
+    want = {(64, 128, 40, 40, 128): (4, 5, 512), (64, 64, 80, 80, 64): (8, 10, 512), (64, 32, 160, 160, 32): (4, 2, 5120),
+            (64, 256, 20, 20, 256): (4, 5, 512)}
+    for shape, (nw, th, total) in want.items():
         for dgrad in (False, True):
             pl = plan(shape, dgrad)
-            assert pl is not None and pl["n_tiles"] == 1 and pl["total"] % 256 == 0 and pl["TH"] == 10, (shape, pl)
-    for shape in ((64, 32, 160, 160, 32), (64, 256, 20, 20, 256), (16, 128, 64, 128, 128), (16, 64, 128, 256, 64), (16, 256, 32, 64, 256)):
+            assert pl is not None and pl["NF"] == 2 and pl["PF"] == 0 and (pl["NW"], pl["TH"], pl["total"]) == (nw, th, total), (shape, pl)
+            assert pl["total"] % (512 if nw == 4 else 256) == 0
+    for shape in ((16, 128, 64, 128, 128), (16, 64, 128, 256, 64), (16, 256, 32, 64, 256), (16, 512, 32, 64, 512)):
         assert plan(shape) is None, shape
+    assert plan((64, 128, 40, 40, 128), CVHIP_BAND_NW=8)["NW"] == 8
     assert plan((64, 128, 40, 40, 128), CVHIP_BAND=0) is None
     # stride 2, 1x1 and grouped convolutions never reach the kernel
     d = ops.conv_desc(64, 128, 40, 40, 128, 3, 3, (2, 2), (1, 1), (1, 1), 1, 128, 128)

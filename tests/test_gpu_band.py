@@ -144,3 +144,46 @@ def test_band_dgrad_add(case, force_band):
     got = dx.float().cpu()
     assert torch.isfinite(got).all()
     assert max_rel(got, gx) < 2 ** -7 and rel_l2(got, gx) < 4e-3
+
+
+def _band_image_expected(rowmajor, nrows, cin):
+    """conv_plan.h "band image": 16-byte vector v = ((tap * (cin/32) + c/32) * (nrows/16) + n/16) * 64 + ((c%32)/8) * 16 + n%16 holds
+    Wt[n][tap*cin + c .. c+7] of the row-major image Wt[nrows][9*cin]"""
+    w = rowmajor.reshape(nrows, 9, cin // 32, 4, 8)            # n, tap, chunk, g, e
+    w = w.reshape(nrows // 16, 16, 9, cin // 32, 4, 8)         # f, r, tap, chunk, g, e
+    return w.permute(2, 3, 0, 4, 1, 5).contiguous().reshape(-1)  # tap, chunk, f, g, r, e
+
+
+@pytest.mark.parametrize("shape", [(128, 128), (64, 64), (32, 32), (64, 128), (256, 96), (128, 32)])
+@pytest.mark.parametrize("batched", [False, True])
+def test_band_image_layout(shape, batched):
+    """the fragment-ordered weight copies behind the fprop / dgrad images (cvhip_conv2d_prep_weights and the batched cvhip_prep_plan_run)
+    hold exactly the row-major images' values, permuted as csrc/conv_plan.h states"""
+    Kk, Cc = shape
+    w = torch.randn(Kk, Cc, 3, 3, generator=torch.Generator().manual_seed(Kk + Cc)).to(dev()).contiguous(memory_format=torch.channels_last)
+    desc = ops.conv_desc(2, Cc, 12, 12, Kk, 3, 3, (1, 1), (1, 1), (1, 1), 1, Cc, Kk)
+    n = Kk * 9 * Cc
+    lib = L.load()
+    has_f = Cc % 32 == 0 and (Kk in (32, 64) or Kk % 128 == 0)
+    has_d = Kk % 32 == 0 and (Cc in (32, 64) or Cc % 128 == 0)
+    assert lib.cvhip_conv2d_weight_image_elems(C.byref(desc), 0) == n * (2 if has_f else 1)
+    assert lib.cvhip_conv2d_weight_image_elems(C.byref(desc), 1) == n * (2 if has_d else 1)
+    st = ops.ConvState()
+    st.prepare(w, desc, True, ("img", Kk, Cc))
+    if batched:
+        plan = ops.PrepPlan([st])
+        assert plan.n == 1
+        st._wf_buf.fill_(float("nan"))
+        st.w_dgrad.fill_(float("nan"))
+        plan.run()
+    torch.cuda.synchronize()
+    wf, wd = st._wf_buf.float().cpu(), st.w_dgrad.float().cpu()
+    master = w.permute(0, 2, 3, 1).contiguous().float().cpu()          # K, R, S, C
+    ref_f = master.to(K.BF).float().reshape(-1)
+    assert torch.equal(wf[:n], ref_f)
+    ref_d = master.permute(3, 1, 2, 0).contiguous().to(K.BF).float().reshape(-1)   # C, R, S, K (stride 1: taps in kernel order)
+    assert torch.equal(wd[:n], ref_d)
+    if has_f:
+        assert torch.equal(wf[n:], _band_image_expected(ref_f, Kk, Cc))
+    if has_d:
+        assert torch.equal(wd[n:2 * n], _band_image_expected(ref_d, Cc, Kk))
