@@ -64,7 +64,7 @@ struct BandArgs {
   int dh0, dh_step, dw0, dw_step, lo_h, lo_w;
   int TH, bands, PH, PW;
   int nplw;            // patch DMA instructions per wave per chunk
-  int dummy_off;       // byte offset of the 8 x 1 KB dummy DMA slots
+  int dummy_off;       // byte offset of the 1-KB dummy DMA slot
   int buf_bytes;       // one patch buffer
   int n_tiles, total_tiles, Ktot;
   unsigned ow_magic;   // ceil(2^32 / OW)
@@ -169,8 +169,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_band_kernel(const BandArgs p)
   const int lsl = (lane & 3) ^ (((lane >> 4) & 1) << 1);   // (pp >> 2) & 1 == bit 4 of the lane: the same for every j
   const h16_t* const zsrc = reinterpret_cast<const h16_t*>(g_band_zero) + lsl * 8;
   int poff[NPL];
+  const int npix = p.PH * PW;
   {
-    const int npix = p.PH * PW;
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
       const int pp = ((j * kBandWaves + wave) << 4) + (lane >> 2);
@@ -182,12 +182,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_band_kernel(const BandArgs p)
       poff[j] = ok ? ((n_img * p.IH + ih) * p.IW + iw) * (p.x_ld >> 3) : -1;   // in 16-byte units (the planner bounds the tensor)
     }
   }
-  // `live` false (no next chunk, or j past the patch): the same instruction fetches the zero page into this wave's 1-KB dummy slot, so
+  // `live` false (no next chunk, or j past the patch): the same instruction fetches the zero page into the block's 1-KB dummy slot, so
   // that every K step carries a compile-time number of VMEM instructions
-  unsigned char* const sdummy = sbuf + p.dummy_off + (wave << 10);
+  unsigned char* const sdummy = sbuf + p.dummy_off;   // ONE dummy KB for all waves: it is written (zeros, any order) and never read
   const h16_t* const xlane = p.x + lsl * 8;
   auto issue_piece = [&](int j, int c, unsigned char* buf, bool live) __attribute__((always_inline)) {
-    live = live && j < p.nplw;
+    live = live && j < p.nplw && (((j * kBandWaves + wave) << 4) < npix);   // (a KB wholly past the patch has no room in the buffer)
     // (the offset is made opaque per use: otherwise the compiler hoists the twelve `poff[j] >= 0` lane masks out of the K loop into
     // 24 SGPRs, and the kernel spills scalars into the vector file)
     int po = poff[j];
@@ -492,7 +492,7 @@ static bool band_fit(const IgemmParams& p, int NF, int cap, int NW, int EH, int 
   const int WM = NW / WN;
   const int threads = NW * 64;
   const int slots = NW == 4 ? 512 : 256;              // resident blocks on the chip
-  const int lds_max = NW == 4 ? 78 * 1024 : kBandLdsMax;
+  const int lds_max = NW == 4 ? 79 * 1024 : kBandLdsMax;   // two co-resident blocks share the CU's 160 KB (1 KB each left to the runtime)
   const int NC = p.Cin / 32;
   const int n_tiles = p.Nout / BN;
   int best_th = 0, best_nplw = 0;
@@ -507,7 +507,7 @@ static bool band_fit(const IgemmParams& p, int NF, int cap, int NW, int EH, int 
     if ((int64_t)PH * PW >= 65536) break;
     const int nplw = (PH * PW * 4 + threads - 1) / threads;
     if (nplw > 2 * kBandPieceSteps) break;
-    const int lds = (NC > 1 ? 2 : 1) * nplw * NW * 1024 + NW * 1024;
+    const int lds = (NC > 1 ? 2 : 1) * ((PH * PW + 15) / 16) * 1024 + 1024;   // patch buffers in whole KBs (16 pixels) + the dummy KB
     if (lds > lds_max) break;
     const int64_t tiles = (int64_t)p.NB * ((p.OH + TH - 1) / TH) * n_tiles;
     // rounds of the resident block slots x (MFMA work of the busiest wave + prologue / epilogue, in units of NF = 2 fragments)
@@ -578,7 +578,7 @@ static bool band_plan_nw(const IgemmParams& p, int NW, BandPlan* pl, bool* polic
   a.PH = TH - 1 + EH;
   a.PW = PW;
   a.nplw = best_nplw;
-  a.buf_bytes = best_nplw * NW * 1024;
+  a.buf_bytes = ((a.PH * a.PW + 15) / 16) * 1024;
   a.n_tiles = n_tiles;
   const int64_t total = (int64_t)p.NB * a.bands * n_tiles;
   if (total >= (1ll << 30)) return false;
@@ -594,7 +594,7 @@ static bool band_plan_nw(const IgemmParams& p, int NW, BandPlan* pl, bool* polic
   pl->PF = (pl->MFW == 7 && band_env("CVHIP_BAND_PF", kBandPrefetchDefault)) ? (NF == 4 ? kBandWidePF : 7) : 0;
   a.dummy_off = (NC > 1 ? 2 : 1) * a.buf_bytes;
   pl->NW = NW;
-  pl->lds = band_imax(a.dummy_off + NW * 1024, WM * BN * 2 * (int)sizeof(float));
+  pl->lds = band_imax(a.dummy_off + 1024, WM * BN * 2 * (int)sizeof(float));
   // Default policy = the classes of problems the kernel measured FASTER on than the patch-resident / per-tap kernels, isolated launches on
   // rotating operands AND in the replayed train step (profiles/r05_band_image_bench.log, r05_band_policy_step_ab.log): at most two
   // 128-wide channel tiles, block counts that fill whole rounds of the resident block slots, waves that are nearly full (a

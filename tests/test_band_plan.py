@@ -79,7 +79,7 @@ def test_band_plan_invariants(shape, form, geom):
         pieces = -(-pl["PH"] * pl["PW"] * 4 // (64 * pl["NW"]))
         assert pieces <= pl["PPS"] * 6 and (pl["PPS"] == 1) == (pieces <= 6)
         bufs = 2 if Cc > 32 else 1
-        assert pl["lds"] >= (bufs * pieces + 1) * pl["NW"] * 1024 and pl["lds"] <= (78 if pl["NW"] == 4 else 156) * 1024
+        assert pl["lds"] >= bufs * -(-pl["PH"] * pl["PW"] // 16) * 1024 + 1024 and pl["lds"] <= (79 if pl["NW"] == 4 else 156) * 1024
         # the read-ahead exists in the 7-fragment forms only, and never holds more fragments than the wave owns
         assert pl["PF"] == 0 or (form["CVHIP_BAND_PF"] == 1 and pl["MFW"] == 7 and 0 < pl["PF"] <= 7)
         if form["CVHIP_BAND_PF"] == 1 and pl["MFW"] == 7:
@@ -90,7 +90,7 @@ def test_band_default_policy():
     """the default policy (conv_band.hip band_plan_nw; profiles/r05_band_image_bench.log) takes the YOLOv5-s shapes the kernel measured
     faster on — whole rounds of block slots, nearly full waves, two co-resident 4-wave blocks per CU where that plan qualifies — and leaves
     DeepLabv3+'s (batch 16: idle slots) to the patch-resident / per-tap kernels"""
-    want = {(64, 128, 40, 40, 128): (4, 5, 512), (64, 64, 80, 80, 64): (8, 10, 512), (64, 32, 160, 160, 32): (4, 2, 5120),
+    want = {(64, 128, 40, 40, 128): (4, 5, 512), (64, 64, 80, 80, 64): (4, 5, 1024), (64, 32, 160, 160, 32): (4, 2, 5120),
             (64, 256, 20, 20, 256): (4, 5, 512)}
     for shape, (nw, th, total) in want.items():
         for dgrad in (False, True):
