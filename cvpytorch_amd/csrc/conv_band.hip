@@ -8,26 +8,37 @@
 // per two), with every wave of the CU arriving in phase — 20 % / 30 % MFMA-pipe busy for four rounds — and both tile the output in
 // fixed 256-pixel tiles that quantise badly against the 256 CUs (102 400 output pixels of the dominant 128 -> 128 @40x40 layer = 400
 // tiles: 1.56 rounds). Here
-//   * a block owns a BAND: TH whole output rows of one image (TH x OW pixels, up to 416 per block: 10 rows x 40 = 400 pixels for the
-//     dominant layer -> exactly 256 blocks, one per CU), all output channels of a 128-wide tile;
+//   * a block owns a BAND: TH whole output rows of one image (TH x OW pixels), all output channels of a <= 128-wide tile. Default plan:
+//     NW = 4 waves per block, TWO blocks resident per CU (5 rows x 40 = 200 pixels for the dominant layer -> 512 blocks = exactly the
+//     512 block slots): the halves are not coupled by barriers, so one block's prologue fetch, chunk barriers and store epilogue run
+//     under the other's MFMAs; NW = 8 (one 512-thread block per CU, twice the band) where the small plan does not fit or fill the chip;
 //   * the band's input patch ((TH + 2) x (OW + 2) pixels) of one 32-channel chunk is staged into the LDS once by LDS-DMA, pixel-major,
 //     double-buffered across chunks; the nine taps read their fragments from it (as conv_patch.hip does);
-//   * the WEIGHT fragments never touch the LDS: a wave owns a 32-channel slice of the output channels and loads its two 16 x 32
-//     fragments of a K step straight from global memory (L2-resident: <= 1.2 MB per layer) into registers, two K steps ahead — so
-//     inside a chunk (9 K steps, 234 MFMAs per wave) NO wave waits for any other wave: one barrier per 32-channel chunk instead of one
-//     per K step.
-// 512 threads = 8 waves = WN (output-channel slices of 32) x WM (pixel parts of <= MFW fragments of 16 pixels); v_mfma_f32_16x16x32
+//   * the WEIGHT fragments never touch the LDS: a wave owns a 16*NF-channel slice of the output channels and loads its NF 16 x 32
+//     fragments of a K step straight from global memory into registers, LEAD K steps ahead — so inside a chunk (9 K steps, 234 MFMAs
+//     per wave) NO wave waits for any other wave: one barrier per 32-channel chunk instead of one per K step;
+//   * those fragments come from the layer's BAND IMAGE (conv_plan.h): a second, fragment-ordered copy of the weights behind the
+//     row-major image, 1 KB of contiguous memory per fragment. From the row-major image a wave's fetch was 16 rows x 64 bytes — sixteen
+//     half cache lines per instruction — and the texture addresser, not the MFMA pipe or the LDS, bounded the kernel
+//     (profiles/r05_band_coalesced_weight_probe.log: 256 -> 256 @20x20 44 -> 32 us with the fetches made contiguous).
+// 64 * NW threads = WN (output-channel slices of 16*NF) x WM (pixel parts of <= MFW fragments of 16 pixels) waves; v_mfma_f32_16x16x32
 // with swapped operands (a lane ends up with 4 consecutive output channels of one pixel).
+//
+// Forms (template parameters below; launch_igemm's default is NF = 2, PF = 0; the others are measured options):
+// narrow waves (32 channels x 13 or 7 pixel fragments) / wide waves (64 channels x 7 fragments: every pixel fragment read from the LDS
+// feeds four MFMAs); compiler-scheduled LDS reads / a hand-counted read-ahead of the next K step's fragments.
 //
 // LDS image: pixel rows of 64 bytes (one 32-channel chunk), row pitch PW pixels (a multiple of 8, so a fragment whose 16 output
 // pixels wrap to the next image row keeps the bank pattern of 16 consecutive pixels), 16-byte slot s of patch pixel pp stored at slot
-// s ^ (((pp >> 2) & 1) << 1) — the swizzle of conv_patch.hip (conflict-free ds_read_b128 at any pixel offset).
+// s ^ (((pp >> 2) & 1) << 1) — the swizzle of conv_patch.hip (conflict-free ds_read_b128 at any pixel offset). Buffers are whole KBs
+// (16 pixels: one DMA instruction of one wave); DMA instructions with nothing to fetch write one shared dummy KB.
 //
 // VMEM queue discipline. A wave's weight loads are inline-asm global_load_dwordx4 (hipcc drains vmcnt to 0 at the first use of an
 // ordinary load's result while an LDS-DMA is in flight: cdna_hip_programming.md "Pipelining across barriers"); the waits are counted
-// by hand: at K step k the wave issues B(k + 2) and its share of the next chunk's patch DMAs (<= PPS instructions), then waits until
+// by hand: at K step k the wave issues B(k + LEAD) and its share of the next chunk's patch DMAs (<= PPS instructions), then waits until
 // only the instructions younger than B(k) are outstanding. A patch piece issued at step t is therefore complete at step t + 2 at the
-// latest; the pieces of a chunk are issued in its first six steps, so the chunk-end barrier publishes a landed patch.
+// latest; the pieces of a chunk are issued in its first six steps, so the chunk-end barrier publishes a landed patch. (Spill code would
+// only ADD instructions to the queue: a counted wait then waits for more than it needs, never for less.)
 //
 // Epilogue: raw 16-bit stores (8 bytes per lane: 4 channels of a pixel), optional addend (dgrad: the gradient arriving over a skip
 // connection), optional training-mode BatchNorm sums into the layer's fp64 accumulator (common.h acc_add2).
