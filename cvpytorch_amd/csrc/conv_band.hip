@@ -127,7 +127,7 @@ __device__ __forceinline__ void band_lwait(band_u32x4& a) {
 __device__ __forceinline__ int band_div(int n, unsigned magic) { return magic ? (int)__umulhi((unsigned)n, magic) : n; }
 
 // WN : waves along the output channels (16 * NF channels each); WM = 8 / WN pixel parts
-// MFW: 16-pixel fragments per wave (7 or 13)        PPS: patch DMA instructions per wave per K step (1 or 2)
+// MFW: 16-pixel fragments per wave (7, 10 or 13)    PPS: patch DMA instructions per wave per K step (1 or 2)
 // NF : 16-channel weight fragments per wave. 2 = the first form: 4 / 2 / 1 waves across a 128 / 64 / 32-wide tile, 13 (or 7) pixel
 //      fragments per wave, weights two K steps ahead. 4 = the WIDE-WAVE form (64 channels x 7 pixel fragments per wave, 2 / 1 waves
 //      across a 128 / 64-wide tile): every pixel fragment read from the LDS feeds FOUR MFMAs instead of two — half the ds_read_b128
@@ -493,6 +493,9 @@ static int band_env(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
+// pixel-fragment slots per wave of the compiled instances: 7, 10 or 13 (10: rows of 160 / 320 pixels split exactly — YOLOv7-l @1280)
+static inline int band_mfw(int per_wave) { return per_wave <= 7 ? 7 : per_wave <= 10 ? 10 : 13; }
+
 // One candidate form (NF weight fragments per wave, at most `cap` pixel fragments per wave): the best band height and its cost in
 // rounds of the 256 CUs x fragment units of the busiest wave. false = the geometry does not fit this form.
 static bool band_fit(const IgemmParams& p, int NF, int cap, int NW, int EH, int PW, int* th_out, int* nplw_out, int64_t* rounds_out) {
@@ -522,7 +525,7 @@ static bool band_fit(const IgemmParams& p, int NF, int cap, int NW, int EH, int 
     if (lds > lds_max) break;
     const int64_t tiles = (int64_t)p.NB * ((p.OH + TH - 1) / TH) * n_tiles;
     // rounds of the resident block slots x (MFMA work of the busiest wave + prologue / epilogue, in units of NF = 2 fragments)
-    const int64_t cost = ((tiles + slots - 1) / slots) * ((per_wave <= 7 ? 7 : 13) * (NF / 2) * NC + 2 + NC / 2);
+    const int64_t cost = ((tiles + slots - 1) / slots) * (band_mfw(per_wave) * (NF / 2) * NC + 2 + NC / 2);
     if (best_cost < 0 || cost <= best_cost) {
       best_cost = cost;
       best_th = TH;
@@ -599,7 +602,7 @@ static bool band_plan_nw(const IgemmParams& p, int NW, BandPlan* pl, bool* polic
   a.pw_magic = div_magic(PW);
   pl->WN = WN;
   pl->NF = NF;
-  pl->MFW = (NF == 4 || per_wave <= 7) ? 7 : 13;
+  pl->MFW = NF == 4 ? 7 : band_mfw(per_wave);
   pl->PPS = best_nplw <= kBandPieceSteps ? 1 : 2;
   // CVHIP_BAND_PF (read per launch): 1 = the 7-fragment forms read the next K step's pixel fragments one step ahead, 0 = not
   pl->PF = (pl->MFW == 7 && band_env("CVHIP_BAND_PF", kBandPrefetchDefault)) ? (NF == 4 ? kBandWidePF : 7) : 0;
@@ -672,6 +675,7 @@ static int band_launch_narrow(const BandPlan& pl, hipStream_t stream) {  // NF =
       if (pl.PF) return pl.PPS == 1 ? band_launch<WN, 7, 1, 2, 2, 7, NW>(pl, stream) : band_launch<WN, 7, 2, 2, 2, 7, NW>(pl, stream);
       return pl.PPS == 1 ? band_launch<WN, 7, 1, 2, 2, 0, NW>(pl, stream) : band_launch<WN, 7, 2, 2, 2, 0, NW>(pl, stream);
     }
+    if (pl.MFW == 10) return pl.PPS == 1 ? band_launch<WN, 10, 1, 2, 2, 0, NW>(pl, stream) : band_launch<WN, 10, 2, 2, 2, 0, NW>(pl, stream);
     return pl.PPS == 1 ? band_launch<WN, 13, 1, 2, 2, 0, NW>(pl, stream) : band_launch<WN, 13, 2, 2, 2, 0, NW>(pl, stream);
   } else {
     return CVHIP_ERR_UNSUPPORTED;

@@ -66,7 +66,7 @@ def test_band_plan_invariants(shape, form, geom):
         assert pl["WN"] * 16 * pl["NF"] == BN and pl["n_tiles"] * BN == K
         assert pl["NW"] in (4, 8) and (pl["NW"] == 8 or form["CVHIP_BAND_NW"] == 4) and pl["WN"] <= pl["NW"]   # (NW = 4 falls back to 8)
         WM = pl["NW"] // pl["WN"]
-        assert pl["MFW"] in (7, 13) and (pl["NF"] == 2 or pl["MFW"] == 7)
+        assert pl["MFW"] in (7, 10, 13) and (pl["NF"] == 2 or pl["MFW"] == 7)
         # every output pixel of a band has a fragment slot; the bands cover the image; one block per (image, band, channel tile)
         assert pl["MFW"] * WM * 16 >= pl["TH"] * OW
         assert pl["bands"] == -(-OH // pl["TH"]) and pl["total"] == N * pl["bands"] * pl["n_tiles"]

@@ -1,5 +1,5 @@
 """Dev tool: per-shape timing of every conv launch of one train step (eager, HIP events): YOLOv5-s 640x640 bs64, or with
-MODEL=deeplab DeepLabv3+ R50 1024x512 bs16."""
+MODEL=deeplab DeepLabv3+ R50 1024x512 bs16, MODEL=yolox YOLOX-s bs64, MODEL=yolov7 YOLOv7-l 1280x1280 fp16 bs16."""
 import sys, os, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,6 +15,25 @@ if os.environ.get("MODEL") == "deeplab":
     state = FlatTrainState(model, lr=0.01, momentum=0.9, nesterov=True, weight_decay=5e-4, backbone_lr=0.001, use_ema=False)
     step = FlatTrainStep(model, state)
     imgs, gts = synthetic_segmentation_batch(B, (512, 1024), device=dev)
+elif os.environ.get("MODEL") == "yolox":
+    from cvpytorch_amd import yolox
+    B = 64
+    model = yolox.YOLOX(80, "s", max_labels=20, fused_loss=True).to(dev).train()
+    state = FlatTrainState(model, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4, use_ema=False)
+    step = FlatTrainStep(model, state)
+    imgs, targets = synthetic_detection_batch(B, 640, device=dev)
+    for t in targets:
+        t["boxes"] = t["boxes"] * 640.0
+    gts = yolox.targets_to_padded(targets, 20, dev)
+elif os.environ.get("MODEL") == "yolov7":
+    from cvpytorch_amd import yolov7
+    B = 16
+    ops.set_precision("fp16")
+    model = yolov7.YOLOv7(80, 1.0, max_targets=B * 20, fused_loss=True).to(dev).train()
+    state = FlatTrainState(model, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4, use_ema=False)
+    step = FlatTrainStep(model, state)
+    imgs, targets = synthetic_detection_batch(B, 1280, device=dev)
+    gts = yolov5.targets_to_tensor(targets, B * 20, dev)
 else:
     B = 64
     model = yolov5.YOLOv5(80, "s", max_targets=B * 20, fused_loss=True).to(dev).train()
