@@ -751,6 +751,12 @@ def main():
             if convs:
                 cname, cd = max(convs.items(), key=lambda kv: kv[1]["ms"])
                 out["conv_roofline"] = _roof(cname, cd, timing_source)
+                # the stride-1 3x3 layers' kernel (conv_band.hip), averaged over every shape it runs in the step — its own row, whether
+                # or not it is the dominant one by time (conv_roofline above is, by definition, the family that takes longest)
+                band = {k: v for k, v in convs.items() if k.startswith("conv_band_kernel")}
+                if band:
+                    bname, bd = max(band.items(), key=lambda kv: kv[1]["ms"])
+                    out["conv_band_roofline"] = _roof(bname, bd, timing_source)
             out["kernels"] = {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / a.steps, 3),
                                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), "alg_gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
                               for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}

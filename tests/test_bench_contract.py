@@ -1,4 +1,4 @@
-"""CPU checks of the measurement contract on the COMMITTED bench line (profiles/r04_bench_final.json.log = the default `python bench.py`
+"""CPU checks of the measurement contract on the COMMITTED bench line (profiles/r05_bench_final.json.log = the default `python bench.py`
 of the round's final commit): the keys the driver and the judge read are there, mutually consistent, and `roofline` / `cpu_baseline`
 carry what the task statement asks for. (The line itself can only be produced on the GPU box.)"""
 import json
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    return json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_final.json.log")).read().strip().splitlines()[-1])
+    return json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_final.json.log")).read().strip().splitlines()[-1])
 
 
 def test_headline_keys_and_consistency():
@@ -33,7 +33,7 @@ def test_roofline_object():
     assert r["peak"] == (8000.0 if r["bound"] == "hbm" else 2500.0)
     assert r["traffic"] is None or r["traffic"] > 0
     # the dominant kernel's HIP-event duration is in the line; the rocprof summary of the same commit must agree within 15 %
-    stats = open(os.path.join(ROOT, "profiles", "r04_yolov5s_bs64_kernel_stats.csv")).read().splitlines()
+    stats = open(os.path.join(ROOT, "profiles", "r05_yolov5s_bs64_kernel_stats.csv")).read().splitlines()
     row = [ln for ln in stats if "colreduce_kernel<1, 2>" in ln]
     if "colreduce" in r["kernel"] and row:
         avg_ns = float(row[0].split('",')[1].split(",")[2])
