@@ -55,7 +55,6 @@
 
 namespace cvhip {
 
-constexpr int kBandWavesMax = 8;     // NW = 8: one 512-thread block per CU; NW = 4: two co-resident 256-thread blocks of half the band each
 constexpr int kBandSteps = 9;        // 3 x 3 taps per chunk
 constexpr int kBandPieceSteps = 6;   // the next chunk's patch DMAs go out in the first six K steps of a chunk
 constexpr int kBandLdsMax = 156 * 1024;
@@ -694,12 +693,6 @@ static int band_launch_nw(const BandPlan& pl, hipStream_t stream) {
   if (pl.WN == 4) return band_launch_narrow<4, NW>(pl, stream);
   if (pl.WN == 2) return band_launch_narrow<2, NW>(pl, stream);
   return band_launch_narrow<1, NW>(pl, stream);
-}
-
-bool band_takes(const IgemmParams& p) {
-  if (band_mode() == 0) return false;
-  BandPlan pl;
-  return band_plan(p, &pl);
 }
 
 // plan query (api.hip cvhip_conv2d_band_plan): {NF, WN, MFW, PPS, PF, TH, bands, n_tiles, total_tiles, lds bytes, PH, PW, NW}

@@ -235,7 +235,6 @@ bool patch_takes(const IgemmParams& p, int* stats_rows);
 // per class CVHIP_PATCH_CLASS_INTS int32 of tile / patch geometry (cvhip_conv2d_patch_plan); returns the class count, 0 = not taken
 // conv_band.hip: row-band 3x3 stride-1 implicit GEMM with register-resident weight fragments (launcher, -1 = not taken)
 int try_launch_band(const IgemmParams& p, hipStream_t stream);
-bool band_takes(const IgemmParams& p);
 int band_plan_export(const IgemmParams& p, int32_t* out);  // 1 = the band kernel runs this plan (out: CVHIP_BAND_PLAN_INTS values), 0 = another kernel
 int patch_plan_export(const IgemmParams& p, int32_t* out, int max_classes, bool any_geometry);
 

@@ -527,7 +527,8 @@ class ConvState:
 
     def __init__(self):
         self.key = None
-        self.w_fprop = None
+        self.w_fprop = None     # [K][R][S][C] view of the front of _wf_buf (the row-major image)
+        self._wf_buf = None     # the whole fprop image buffer: row-major image (+ the band kernel's fragment-ordered copy)
         self.w_dgrad = None
         self.rec = None
 
@@ -549,7 +550,7 @@ class ConvState:
         if nf < 0:
             L.check(nf, "cvhip_conv2d_weight_image_elems")
         if (self.w_fprop is None or tuple(self.w_fprop.shape) != shape or self.w_fprop.device != dev or self.w_fprop.dtype != ACT_DTYPE
-                or getattr(self, "_wf_buf", None) is None or self._wf_buf.numel() != nf):
+                or self._wf_buf is None or self._wf_buf.numel() != nf):
             self._wf_buf = torch.empty((nf,), dtype=ACT_DTYPE, device=dev)
             self.w_fprop = self._wf_buf[:shape[0] * shape[1] * shape[2] * shape[3]].view(shape)
             self.w_dgrad = None
