@@ -106,3 +106,28 @@ def test_band_default_policy():
     assert L.load().cvhip_conv2d_band_plan(C.byref(d), 0, None) == 0
     d = ops.conv_desc(64, 128, 40, 40, 128, 1, 1, (1, 1), (0, 0), (1, 1), 1, 128, 128)
     assert L.load().cvhip_conv2d_band_plan(C.byref(d), 0, None) == 0
+
+
+def test_weight_image_sizes():
+    """cvhip_conv2d_weight_image_elems (pure host arithmetic): the fragment-ordered copy exists behind an image exactly when the layer is a
+    stride-1 3x3 convolution without channel padding whose GEMM has 32 | 64 | 128k output rows and a reduction width that is a multiple
+    of 32 — fprop: rows K, reduction C; dgrad: rows C, reduction K (csrc/conv_plan.h band_image_fprop / band_image_dgrad)"""
+    lib = L.load()
+
+    def sizes(Cc, K, R=3, stride=1, k_valid=0, c_valid=0, dil=1):
+        d = ops.conv_desc(2, Cc, 24, 24, K, R, R, (stride, stride), (R // 2 * dil, R // 2 * dil), (dil, dil), 1, Cc, K, k_valid, c_valid)
+        n = K * R * R * Cc
+        f, g = lib.cvhip_conv2d_weight_image_elems(C.byref(d), 0), lib.cvhip_conv2d_weight_image_elems(C.byref(d), 1)
+        assert g - (lib.cvhip_conv2d_dgrad_weight_elems(C.byref(d)) - 0) in (0, n)
+        return f // n, g // n if stride == 1 else None
+
+    assert sizes(128, 128) == (2, 2) and sizes(64, 64) == (2, 2) and sizes(32, 32) == (2, 2) and sizes(256, 256, dil=2) == (2, 2)
+    assert sizes(64, 128) == (2, 2) and sizes(128, 64) == (2, 2)
+    assert sizes(96, 64) == (2, 1)          # dgrad would write 96 rows: not a tile shape of the kernel
+    assert sizes(64, 96) == (1, 2)
+    assert sizes(8, 32) == (1, 1)           # image stem: 8 input channels
+    assert sizes(128, 128, R=1) == (1, 1)   # 1x1
+    assert sizes(128, 128, stride=2)[0] == 1
+    assert sizes(128, 256, k_valid=255) == (1, 1)   # padded channels (the detect layers' 255 outputs)
+    d = ops.conv_desc(2, 64, 24, 24, 64, 3, 3, (1, 1), (1, 1), (1, 1), 1, 64, 64)
+    assert lib.cvhip_conv2d_weight_image_elems(C.byref(d), 2) == L.ERR_INVALID
