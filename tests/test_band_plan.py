@@ -131,3 +131,103 @@ def test_weight_image_sizes():
     assert sizes(128, 256, k_valid=255) == (1, 1)   # padded channels (the detect layers' 255 outputs)
     d = ops.conv_desc(2, 64, 24, 24, 64, 3, 3, (1, 1), (1, 1), (1, 1), 1, 64, 64)
     assert lib.cvhip_conv2d_weight_image_elems(C.byref(d), 2) == L.ERR_INVALID
+
+
+def _interpret_band_fprop(x, w, pad, dil, pl):
+    """numpy interpreter of the band kernel's ADDRESSING (csrc/conv_band.hip header): the DMA loader's lane -> (patch pixel, slot) map with the
+    source-side swizzle, the fragment reads' byte addresses (row pitch PW, tap shifts, bit 5 ^= bit 8), the band image's fragment order
+    (csrc/conv_plan.h) and the MFMA operand layout (lane = row + 16 * k-group) — executed for one 32-channel chunk at a time exactly as
+    the plan lays the work out. x: [N][H][W][C] float, w: [K][3][3][C] float. Returns y [N][OH][OW][K]."""
+    import numpy as np
+    N, H, W, Cc = x.shape
+    K = w.shape[0]
+    OH, OW = H + 2 * pad - 2 * dil, W + 2 * pad - 2 * dil
+    NW, WN, MFW, TH, PH, PW = pl["NW"], pl["WN"], pl["MFW"], pl["TH"], pl["PH"], pl["PW"]
+    WM, NF, BN, NC = NW // WN, pl["NF"], min(K, 128), Cc // 32
+    lo = -pad
+    # band image of the row-major weights Wt[n][tap*C + c]
+    wt = w.reshape(K, 9 * Cc)
+    nvec = K * 9 * Cc // 8
+    img = np.zeros((nvec, 8), dtype=np.float64)
+    for v in range(nvec):
+        lane, fr = v & 63, v >> 6
+        f, st = fr % (K // 16), fr // (K // 16)
+        tap, cc = st // NC, st % NC
+        n, c0 = f * 16 + (lane & 15), cc * 32 + (lane >> 4) * 8
+        img[v] = wt[n, tap * Cc + c0: tap * Cc + c0 + 8]
+    y = np.zeros((N, OH, OW, K))
+    npieces = -(-PH * PW * 4 // (64 * NW))
+    buf_kb = -(-PH * PW // 16)
+    for n_img in range(N):
+        for band in range(pl["bands"]):
+            oh0 = band * TH
+            rows = min(TH, OH - oh0)
+            npx = rows * OW
+            for ntile in range(pl["n_tiles"]):
+                n0 = ntile * BN
+                acc = {}
+                for c in range(NC):
+                    lds = np.full((buf_kb * 1024 // 16, 8), np.nan)          # 16-byte slots of one patch buffer
+                    for j in range(npieces):                                   # ---- the loader
+                        for wave in range(NW):
+                            if ((j * NW + wave) << 4) >= PH * PW:
+                                continue                                        # a KB wholly past the patch: the dummy slot
+                            for lane in range(64):
+                                pp = ((j * NW + wave) << 4) + (lane >> 2)
+                                lsl = (lane & 3) ^ (((lane >> 4) & 1) << 1)
+                                pr, pc = divmod(pp, PW)
+                                ih, iw = oh0 + lo + pr, lo + pc
+                                ok = pp < PH * PW and 0 <= ih < H and 0 <= iw < W
+                                val = x[n_img, ih, iw, c * 32 + lsl * 8: c * 32 + lsl * 8 + 8] if ok else np.zeros(8)
+                                lds[(j * NW + wave) * 64 + lane] = val
+                    for wave in range(NW):                                     # ---- the waves
+                        wn, wm = wave % WN, wave // WN
+                        for b in range(MFW):
+                            for ti in range(3):
+                                for tj in range(3):
+                                    tap = ti * 3 + tj
+                                    bfrag = np.zeros((64, 8))                  # pixel fragment: lane = pixel + 16 * k-group
+                                    for lane in range(64):
+                                        q = min(((wm * MFW + b) << 4) + (lane & 15), max(npx - 1, 0))
+                                        r, cc = divmod(q, OW)
+                                        ab = ((r * PW + cc) << 6) + ((lane >> 4) << 4)
+                                        u = ab + (tj * dil) * 64
+                                        aj = u ^ ((u >> 3) & 32)
+                                        addr = aj + (ti * dil) * PW * 64
+                                        assert addr % 16 == 0 and addr // 16 < lds.shape[0]
+                                        bfrag[lane] = lds[addr // 16]
+                                    for a in range(NF):
+                                        fi = (n0 >> 4) + wn * NF + a
+                                        afrag = img[((tap * NC + c) * (K // 16) + fi) * 64: ((tap * NC + c) * (K // 16) + fi) * 64 + 64]
+                                        d = acc.setdefault((wave, a, b), np.zeros((16, 16)))
+                                        for g in range(4):                     # D[n][pix] += sum_g A[n + 16g] . B[pix + 16g]
+                                            d += afrag[16 * g: 16 * g + 16] @ bfrag[16 * g: 16 * g + 16].T
+                for (wave, a, b), d in acc.items():                            # ---- the epilogue
+                    wn, wm = wave % WN, wave // WN
+                    for pix in range(16):
+                        q = ((wm * MFW + b) << 4) + pix
+                        if q < npx:
+                            r, cc = divmod(q, OW)
+                            y[n_img, oh0 + r, cc, n0 + wn * 16 * NF + a * 16: n0 + wn * 16 * NF + a * 16 + 16] = d[:, pix]
+    return y
+
+
+@pytest.mark.parametrize("case", [(1, 32, 7, 9, 32, 1, 1, {}), (1, 64, 6, 11, 64, 1, 1, {"CVHIP_BAND_NW": 8}), (1, 32, 9, 6, 64, 2, 2, {}),
+                                  (1, 32, 5, 20, 64, 0, 1, {"CVHIP_BAND_NF": 4, "CVHIP_BAND_NW": 8}), (1, 64, 8, 12, 256, 1, 1, {})])
+def test_band_addressing_interpreter(case):
+    """the addressing the kernel's header and conv_plan.h state (loader swizzle, fragment addresses, band image order, MFMA operand
+    layout), run in numpy on the plan the library returns, reproduces torch's convolution"""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    N, Cc, H, W, K, pad, dil, env = case
+    pl = plan((N, Cc, H, W, K), False, pad, dil, CVHIP_BAND=2, **env)
+    assert pl is not None, case
+    if env.get("CVHIP_BAND_NF") == 4 and pl["NF"] != 4:
+        pytest.skip("the wide form does not fit this geometry")
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(N, Cc, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(K, Cc, 3, 3, generator=g, dtype=torch.float64)
+    ref = F.conv2d(x, w, None, 1, pad, dil).permute(0, 2, 3, 1).numpy()
+    got = _interpret_band_fprop(x.permute(0, 2, 3, 1).numpy(), w.permute(0, 2, 3, 1).contiguous().numpy(), pad, dil, pl)
+    assert np.allclose(got, ref, rtol=1e-9, atol=1e-9), float(np.abs(got - ref).max())
