@@ -315,14 +315,14 @@ def yolov7_workload(dev, a, steps, warmup, batch=16, size=1280):
 
 
 def pmc_traffic(kernel_label):
-    """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r04_pmc_traffic_raw.json, falling back to
+    """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r05_pmc_traffic_raw.json, falling back to
     earlier rounds'; collected by `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and, separately, `--pmc WRITE_SIZE --kernel-trace` over
     tools/pmc_workload.py = the same eager train step). Corrections per MI355X_MICROARCH.md (HBM section): the counters are KiB;
     on gfx950 FETCH_SIZE tallies 128-B read requests at 64 B => x2 (confirmed in the same pass on a kernel with a known byte count:
     a 419.4 MB bf16 copy reads FETCH_SIZE 204,8xx KiB; its 419.4 MB of writes read WRITE_SIZE 409,600 KiB => WRITE_SIZE x1).
     null if no file / no matching kernel."""
     raw = None
-    for name in ("r04_pmc_traffic_raw.json", "r03_pmc_traffic_raw.json", "r02_pmc_traffic_raw.json", "r01_pmc_traffic_raw.json"):
+    for name in ("r05_pmc_traffic_raw.json", "r04_pmc_traffic_raw.json", "r03_pmc_traffic_raw.json", "r02_pmc_traffic_raw.json", "r01_pmc_traffic_raw.json"):
         try:
             raw = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)))
             break
@@ -343,6 +343,10 @@ def pmc_traffic(kernel_label):
         need = ["stem_wgrad_kernel"]
     elif kernel_label.startswith("stem"):
         need = ["stem_fprop_kernel"]
+    elif kernel_label.startswith("conv_band_kernel"):   # every instance the step runs (launch-weighted mean over its shapes)
+        need = ["conv_band_kernel<"]
+    elif kernel_label.startswith("conv_patch_kernel"):
+        need = ["conv_patch_kernel<"]
     elif kernel_label.startswith("conv1x1_stream"):  # label carries the output-tile width, the template its fragment count
         need = ["conv1x1_stream_kernel<%d, " % (int(kernel_label[kernel_label.index("<") + 1:kernel_label.index(">")]) // 16)]
     else:
