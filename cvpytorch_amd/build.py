@@ -23,6 +23,7 @@ SOURCES = [
     "conv_patch.hip",
     "conv_band.hip",
     "conv_wgrad.hip",
+    "conv_wgrad_band.hip",
     "bn_act.hip",
     "pool_resize.hip",
     "weights_optim.hip",

@@ -152,6 +152,7 @@ int pack_weights(const cvhip_conv_desc* d, const float* master, void* w_fprop, v
 int launch_wgrad(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, hipStream_t stream);
 int launch_wgrad_impl(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, hipStream_t stream, float* det_ws, int64_t* det_ws_floats,
                       int det_accumulate);
+int wgband_plan_export(const cvhip_conv_desc* d, int32_t* out);
 
 }  // namespace cvhip
 
@@ -217,6 +218,13 @@ int cvhip_conv2d_band_plan(const cvhip_conv_desc* d, int flags, int32_t* out) {
   // (operand pointers are not part of the descriptor: the query assumes the 16-byte alignment every arena tensor has; the training
   // form's BatchNorm sums go to the fp64 accumulator, which the band kernel supports)
   return band_plan_export(p, out);
+}
+
+int cvhip_conv2d_wgrad_band_plan(const cvhip_conv_desc* d, int32_t* out) {
+  int st = validate_dense_desc(d);
+  if (st) return st;
+  if ((d->K & 7) || (d->y_ld & 7)) return CVHIP_ERR_UNSUPPORTED;
+  return wgband_plan_export(d, out);
 }
 
 int cvhip_conv_stem_blocks(const cvhip_conv_desc* d) {

@@ -727,11 +727,15 @@ static int launch_wg(WgradParams& p, hipStream_t stream, int tgt_hint = 0, int g
   return check_launch("wgrad_kernel");
 }
 
+int try_launch_wgrad_band(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, hipStream_t stream);  // conv_wgrad_band.hip
+
 int launch_wgrad_impl(const cvhip_conv_desc* d, const void* x, const void* dy, float* dw, hipStream_t stream, float* det_ws, int64_t* det_ws_floats,
                       int det_accumulate) {
   if (!det_ws) {
     const int stem = try_launch_stem_wgrad(d, x, dy, dw, stream);  // 8-channel image stem: patch kernel (conv_stem.hip; atomic epilogue)
     if (stem >= 0) return stem;
+    const int band = try_launch_wgrad_band(d, x, dy, dw, stream);  // stride-1 3x3 "same" layers: tap-resident tiles, replicas folded in the LDS
+    if (band >= 0) return band;
   }
   WgradParams p;
   p.det_ws = det_ws;

@@ -798,6 +798,13 @@ int cvhip_conv2d_patch_plan(const cvhip_conv_desc* d, int flags, int32_t* out_cl
 #define CVHIP_BAND_PLAN_INTS 13
 int cvhip_conv2d_band_plan(const cvhip_conv_desc* d, int flags, int32_t* out);
 
+/* Plan query of the tap-resident 3x3 weight-gradient kernel (conv_wgrad_band.hip; pure host arithmetic): returns 1 when
+ * cvhip_conv2d_wgrad hands this problem to it under the current policy (CVHIP_WGRAD_BAND is read per call), 0 when the general
+ * kernel runs. out (may be NULL): {KF (16-channel dY fragments per wave: block tile = 16*KF output channels x 32 input channels x 9
+ * taps), tiles, pixel splits, 256-pixel ranges per split, blocks, LDS bytes, patch row pitch (pixels), patch KB pieces per buffer}. */
+#define CVHIP_WGRAD_BAND_PLAN_INTS 8
+int cvhip_conv2d_wgrad_band_plan(const cvhip_conv_desc* d, int32_t* out);
+
 /* The hardware probes (lane-layout known-answer kernels, machine-ceiling micro-benchmarks) are NOT part of this library: they live in
  * libcvhip_probes.so, declared in include/cvhip_probes.h. */
 
