@@ -62,6 +62,7 @@ struct WgBandArgs {
   int M;
   int c_tiles, tiles, ranges_per_split;
   unsigned ow_mul, ow_sh, oh_mul, oh_sh, vp_mul, vp_sh, pw_mul, pw_sh;
+  int abl;
 };
 
 __device__ __attribute__((aligned(64))) unsigned int g_wgband_zero[16];
@@ -70,12 +71,22 @@ __device__ __attribute__((aligned(64))) unsigned int g_wgband_zero[16];
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                       \
                                    (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
-typedef __attribute__((address_space(3))) h16x4 wb_lds_h16x4;
-__device__ __forceinline__ h16x8 wb_tr_read8(const unsigned char* p0, const unsigned char* p1) {
-  h16x4 lo = CVHIP_DS_READ_TR16_B64((wb_lds_h16x4*)(p0));
-  h16x4 hi = CVHIP_DS_READ_TR16_B64((wb_lds_h16x4*)(p1));
-  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+// Fragment gathers by hand. hipcc (ROCm 7.2) puts an s_waitcnt vmcnt(0) in front of every ds_read_b64_tr_b16 it emits for the
+// builtin while an LDS-DMA is outstanding (it does not for a plain ds_read_b128: measured on a two-line kernel) — i.e. the next
+// range's staging would be drained before the first fragment of this range is read. As asm the reads are outside its bookkeeping;
+// the lgkmcnt waits are counted by hand (LDS operations return in order: "at most N outstanding" = all but the N youngest landed)
+// and carry the fragment as an in/out operand, so no MFMA that uses it can be scheduled above the wait.
+typedef unsigned int wb_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int wb_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wb_tr_read(wb_u32x2& dst, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
 }
+template <int N>
+__device__ __forceinline__ void wb_lwait(wb_u32x4& a) {
+  static_assert(N >= 0 && N <= 15, "lgkmcnt literal");
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N) : "memory");
+}
+__device__ __forceinline__ wb_u32x4 wb_join(const wb_u32x2& lo, const wb_u32x2& hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3); }
 
 // KF: 16-channel dY fragments per wave (KT = 16 * KF output channels per block tile)
 template <int KF>
@@ -181,11 +192,12 @@ __global__ __launch_bounds__(kWbWaves * 64, 2) void wgrad_band_kernel(const WgBa
   const int lane8 = (lane & 3) * 8;
   const int roff = p.dil_h * p.PW * 64;
 
-  auto compute_step = [&](int s, int q0, int vbase, const unsigned char* buf) __attribute__((always_inline)) {
-    const unsigned char* const db = buf;
-    const unsigned char* const xb = buf + D_BYTES;
-    const unsigned char* adA[2][KF];
-    const unsigned char* aj[2][3];
+  const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem);
+  auto compute_step = [&](int s, int q0, int vbase, unsigned bufoff) __attribute__((always_inline)) {
+    const unsigned db = lds0 + bufoff;
+    const unsigned xb = db + D_BYTES;
+    unsigned adA[2][KF];
+    unsigned aj[2][3];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int pl = 32 * s + 16 * h + 4 * g + q4;
@@ -203,18 +215,54 @@ __global__ __launch_bounds__(kWbWaves * 64, 2) void wgrad_band_kernel(const WgBa
         aj[h][j] = xb + (u << 6) + ((ch ^ ((u >> 2) & 1)) << 5) + lane8;
       }
     }
-    h16x8 fd[KF];
+    // reads in flight: the KF dY fragments and the x fragments of three taps; tap t is multiplied once everything older than the
+    // reads of taps t + 1, t + 2 has landed, then the reads of tap t + 3 go out (<= 2 * KF + 6 <= 14 outstanding)
+    wb_u32x2 alo[KF], ahi[KF];
 #pragma unroll
-    for (int a = 0; a < KF; ++a) fd[a] = wb_tr_read8(adA[0][a], adA[1][a]);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const h16x8 fx = wb_tr_read8(aj[0][j] + i * roff, aj[1][j] + i * roff);
-#pragma unroll
-        for (int a = 0; a < KF; ++a) acc[a][i * 3 + j] = CVHIP_MFMA_16X16X32(fd[a], fx, acc[a][i * 3 + j], 0, 0, 0);
-      }
+    for (int a = 0; a < KF; ++a) {
+      wb_tr_read(alo[a], adA[0][a]);
+      wb_tr_read(ahi[a], adA[1][a]);
     }
+    wb_u32x2 xlo[3], xhi[3];
+    auto xread = [&](int tp, int slot) __attribute__((always_inline)) {
+      const int i = tp / 3, j = tp - i * 3;
+      wb_tr_read(xlo[slot], aj[0][j] + i * roff);
+      wb_tr_read(xhi[slot], aj[1][j] + i * roff);
+    };
+    xread(0, 0);
+    xread(1, 1);
+    xread(2, 2);
+    h16x8 fd[KF];
+    auto tap = [&](auto tc) __attribute__((always_inline)) {
+      constexpr int tp = decltype(tc)::value;
+      wb_u32x4 fx = wb_join(xlo[tp % 3], xhi[tp % 3]);
+      constexpr int YOUNGER = tp + 2 < 9 ? 4 : (tp + 1 < 9 ? 2 : 0);   // reads of the taps issued after this one
+      wb_lwait<YOUNGER>(fx);
+      if constexpr (tp == 0) {
+        // (the dY fragments are older than every x read: they have landed too; naming them here keeps their uses below the wait)
+#pragma unroll
+        for (int a = 0; a < KF; ++a) {
+          wb_u32x4 fa = wb_join(alo[a], ahi[a]);
+          asm volatile("" : "+v"(fa));
+          fd[a] = __builtin_bit_cast(h16x8, fa);
+        }
+      }
+      const h16x8 fxv = __builtin_bit_cast(h16x8, fx);
+#pragma unroll
+      for (int a = 0; a < KF; ++a) acc[a][tp] = CVHIP_MFMA_16X16X32(fd[a], fxv, acc[a][tp], 0, 0, 0);
+      if constexpr (tp + 3 < 9) xread(tp + 3, tp % 3);
+      __builtin_amdgcn_sched_barrier(0);   // (MFMAs and asm statements do not cross: the counted waits stay between the taps)
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    tap(std::integral_constant<int, 0>{});
+    tap(std::integral_constant<int, 1>{});
+    tap(std::integral_constant<int, 2>{});
+    tap(std::integral_constant<int, 3>{});
+    tap(std::integral_constant<int, 4>{});
+    tap(std::integral_constant<int, 5>{});
+    tap(std::integral_constant<int, 6>{});
+    tap(std::integral_constant<int, 7>{});
+    tap(std::integral_constant<int, 8>{});
   };
 
   // ---- main loop: range rg is multiplied from buffer rg & 1 while range rg + 1 lands in the other ------------------------------------
@@ -222,19 +270,21 @@ __global__ __launch_bounds__(kWbWaves * 64, 2) void wgrad_band_kernel(const WgBa
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   for (int rg = 0; rg < nranges; ++rg) {
-    unsigned char* const cur = smem + (rg & 1) * bufstride;
-    if (rg + 1 < nranges) issue_range(rg + 1, smem + ((rg + 1) & 1) * bufstride);
+    const unsigned cur = (unsigned)((rg & 1) * bufstride);
+    if (rg + 1 < nranges && !(p.abl & 8)) issue_range(rg + 1, smem + ((rg + 1) & 1) * bufstride);
     const int q0 = m_begin + rg * kWbRange;
     int phr;
     range_rows(q0, &vbase_cur, &phr);
 #pragma unroll
-    for (int jj = 0; jj < kWbJ; ++jj) compute_step(rep + kWbReps * jj, q0, vbase_cur, cur);
+    for (int jj = 0; jj < kWbJ; ++jj)
+      if (!(p.abl & 4)) compute_step(rep + kWbReps * jj, q0, vbase_cur, cur);
     // the next range has landed (this wave's share; the barrier publishes everybody's) and every wave is done reading `cur`
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
 
   // ---- fold the four replicas through the LDS (fixed tree: 2,3 -> 0,1; 1 -> 0), then replica 0 flushes -------------------------------
+  if ((p.abl & 2) && acc[0][0][0] != 12345.678f) return;
   f32x4* const park = reinterpret_cast<f32x4*>(smem);
   if (rep >= 2) {
     f32x4* dst = park + ((rep - 2) * 2 + ch) * (ACCN * 64) + lane;
@@ -268,6 +318,7 @@ __global__ __launch_bounds__(kWbWaves * 64, 2) void wgrad_band_kernel(const WgBa
 #pragma unroll
       for (int tp = 0; tp < 9; ++tp) acc[a][tp] += src[(a * 9 + tp) * 64];
   }
+  if ((p.abl & 1) && acc[0][0][0] != 12345.678f) return;
   // lane holds D[k = 4 * (lane >> 4) + r][c = lane & 15] of every (fragment a, tap) tile
   float* const dwl = p.dw + (int64_t)(k0 + 4 * g) * p.Ktot + c0 + ch * 16 + (lane & 15);
 #pragma unroll
@@ -387,6 +438,7 @@ int try_launch_wgrad_band(const cvhip_conv_desc* d, const void* x, const void* d
   pl.a.x = (const h16_t*)x;
   pl.a.dy = (const h16_t*)dy;
   pl.a.dw = dw;
+  { const char* e = getenv("CVHIP_WGB_ABL"); pl.a.abl = e ? atoi(e) : 0; }
   return pl.KF == 4 ? wgband_launch<4>(pl, stream) : wgband_launch<2>(pl, stream);
 }
 
