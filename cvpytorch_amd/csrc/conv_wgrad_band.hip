@@ -43,7 +43,7 @@ namespace cvhip {
 
 constexpr int kWbWaves = 8;             // 512 threads: one block per CU, two waves per SIMD
 constexpr int kWbReps = 4;              // pixel replicas (waves 2r, 2r + 1 = the two 16-channel halves of replica r)
-constexpr int kWbJ = 2;                 // steps per replica and range
+constexpr int kWbJ = 2;                 // steps per replica and range (the main loop is written for 2)
 constexpr int kWbRange = 32 * kWbReps * kWbJ;   // 256 output pixels
 constexpr int kWbXPieces = 8;           // patch DMA instructions per wave and range (<= 64 KB of patch per buffer)
 constexpr int kWbLdsMax = 159 * 1024;
@@ -271,13 +271,17 @@ __global__ __launch_bounds__(kWbWaves * 64, 2) void wgrad_band_kernel(const WgBa
   __builtin_amdgcn_s_barrier();
   for (int rg = 0; rg < nranges; ++rg) {
     const unsigned cur = (unsigned)((rg & 1) * bufstride);
-    if (rg + 1 < nranges && !(p.abl & 8)) issue_range(rg + 1, smem + ((rg + 1) & 1) * bufstride);
+    const bool more = rg + 1 < nranges && !(p.abl & 8);
+    // the two waves of a SIMD (replicas r and r + 2) issue their share of the next range's staging at different times — r before its
+    // first step, r + 2 between its steps — so that one's address arithmetic and DMA issue run under the other's MFMAs
+    const bool late = (p.abl & 16) ? false : rep >= 2;
+    if (more && !late) issue_range(rg + 1, smem + ((rg + 1) & 1) * bufstride);
     const int q0 = m_begin + rg * kWbRange;
     int phr;
     range_rows(q0, &vbase_cur, &phr);
-#pragma unroll
-    for (int jj = 0; jj < kWbJ; ++jj)
-      if (!(p.abl & 4)) compute_step(rep + kWbReps * jj, q0, vbase_cur, cur);
+    if (!(p.abl & 4)) compute_step(rep, q0, vbase_cur, cur);
+    if (more && late) issue_range(rg + 1, smem + ((rg + 1) & 1) * bufstride);
+    if (!(p.abl & 4)) compute_step(rep + kWbReps, q0, vbase_cur, cur);
     // the next range has landed (this wave's share; the barrier publishes everybody's) and every wave is done reading `cur`
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
