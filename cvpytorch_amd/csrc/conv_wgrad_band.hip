@@ -193,7 +193,23 @@ __global__ __launch_bounds__(kWbWaves * 64, 2) void wgrad_band_kernel(const WgBa
   const int roff = p.dil_h * p.PW * 64;
 
   const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem);
-  auto compute_step = [&](int s, int q0, int vbase, unsigned bufoff) __attribute__((always_inline)) {
+  // Patch pixel of every output pixel this wave multiplies in a range, computed ONCE per wave: the wave's two steps x two half-steps x
+  // 16 pixels are 64 pixels = one per lane (lane = step << 5 | half << 4 | pixel-in-16); the division chain runs once per lane and
+  // range, and every lane fetches the four values it gathers from (its pixel-in-16 = 4g + q4) with ds_bpermute_b32
+  auto range_pixels = [&](int q0, int vbase, int (&u)[2][2]) __attribute__((always_inline)) {
+    const int pl = 32 * (rep + kWbReps * (lane >> 5)) + (lane & 31);
+    int m = q0 + pl;
+    m = m < m_end ? m : m_end - 1;   // rows past the split: dY is zero there, the patch address only has to be valid
+    const int gr = (int)fast_div31((unsigned)m, p.ow_mul, p.ow_sh);
+    const int ow = m - gr * p.OW;
+    const int n = (int)fast_div31((unsigned)gr, p.oh_mul, p.oh_sh);
+    const int ppb = (gr + n * p.G - vbase) * p.PW + ow;
+#pragma unroll
+    for (int si = 0; si < 2; ++si)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) u[si][h] = __builtin_amdgcn_ds_bpermute(((si << 5) | (h << 4) | (4 * g + q4)) << 2, ppb);
+  };
+  auto compute_step = [&](int s, const int (&uu)[2], unsigned bufoff) __attribute__((always_inline)) {
     const unsigned db = lds0 + bufoff;
     const unsigned xb = db + D_BYTES;
     unsigned adA[2][KF];
@@ -201,17 +217,11 @@ __global__ __launch_bounds__(kWbWaves * 64, 2) void wgrad_band_kernel(const WgBa
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int pl = 32 * s + 16 * h + 4 * g + q4;
-      int m = q0 + pl;
-      m = m < m_end ? m : m_end - 1;   // rows past the split: dY is zero there, the patch address only has to be valid
-      const int gr = (int)fast_div31((unsigned)m, p.ow_mul, p.ow_sh);
-      const int ow = m - gr * p.OW;
-      const int n = (int)fast_div31((unsigned)gr, p.oh_mul, p.oh_sh);
-      const int ppb = (gr + n * p.G - vbase) * p.PW + ow;
 #pragma unroll
       for (int a = 0; a < KF; ++a) adA[h][a] = db + pl * D_ROWB + (((a ^ fD) & (KF - 1)) << 5) + lane8;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        const int u = ppb + j * p.dil_w;
+        const int u = uu[h] + j * p.dil_w;
         aj[h][j] = xb + (u << 6) + ((ch ^ ((u >> 2) & 1)) << 5) + lane8;
       }
     }
@@ -279,9 +289,11 @@ __global__ __launch_bounds__(kWbWaves * 64, 2) void wgrad_band_kernel(const WgBa
     const int q0 = m_begin + rg * kWbRange;
     int phr;
     range_rows(q0, &vbase_cur, &phr);
-    if (!(p.abl & 4)) compute_step(rep, q0, vbase_cur, cur);
+    int upix[2][2];
+    range_pixels(q0, vbase_cur, upix);
+    if (!(p.abl & 4)) compute_step(rep, upix[0], cur);
     if (more && late) issue_range(rg + 1, smem + ((rg + 1) & 1) * bufstride);
-    if (!(p.abl & 4)) compute_step(rep + kWbReps, q0, vbase_cur, cur);
+    if (!(p.abl & 4)) compute_step(rep + kWbReps, upix[1], cur);
     // the next range has landed (this wave's share; the barrier publishes everybody's) and every wave is done reading `cur`
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -352,6 +364,7 @@ static bool wgband_plan(const cvhip_conv_desc* d, WgBandPlan* pl) {
   if (d->W >= 65536 || d->H >= 32768) return false;
   const int64_t M = (int64_t)d->N * d->H * d->W;
   if (M >= (1ll << 30) || M < kWbRange) return false;
+  if (wgband_mode() < 2 && M < 4096) return false;   // default policy: small problems stay on the general kernel
   const int KF = (d->K & 63) ? 2 : 4;
   const int KT = 16 * KF;
   WgBandArgs& a = pl->a;
