@@ -62,7 +62,6 @@ struct WgBandArgs {
   int M;
   int c_tiles, tiles, ranges_per_split;
   unsigned ow_mul, ow_sh, oh_mul, oh_sh, vp_mul, vp_sh, pw_mul, pw_sh;
-  int abl;
 };
 
 __device__ __attribute__((aligned(64))) unsigned int g_wgband_zero[16];
@@ -281,26 +280,25 @@ __global__ __launch_bounds__(kWbWaves * 64, 2) void wgrad_band_kernel(const WgBa
   __builtin_amdgcn_s_barrier();
   for (int rg = 0; rg < nranges; ++rg) {
     const unsigned cur = (unsigned)((rg & 1) * bufstride);
-    const bool more = rg + 1 < nranges && !(p.abl & 8);
+    const bool more = rg + 1 < nranges;
     // the two waves of a SIMD (replicas r and r + 2) issue their share of the next range's staging at different times — r before its
     // first step, r + 2 between its steps — so that one's address arithmetic and DMA issue run under the other's MFMAs
-    const bool late = (p.abl & 16) ? false : rep >= 2;
+    const bool late = rep >= 2;
     if (more && !late) issue_range(rg + 1, smem + ((rg + 1) & 1) * bufstride);
     const int q0 = m_begin + rg * kWbRange;
     int phr;
     range_rows(q0, &vbase_cur, &phr);
     int upix[2][2];
     range_pixels(q0, vbase_cur, upix);
-    if (!(p.abl & 4)) compute_step(rep, upix[0], cur);
+    compute_step(rep, upix[0], cur);
     if (more && late) issue_range(rg + 1, smem + ((rg + 1) & 1) * bufstride);
-    if (!(p.abl & 4)) compute_step(rep + kWbReps, upix[1], cur);
+    compute_step(rep + kWbReps, upix[1], cur);
     // the next range has landed (this wave's share; the barrier publishes everybody's) and every wave is done reading `cur`
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
 
   // ---- fold the four replicas through the LDS (fixed tree: 2,3 -> 0,1; 1 -> 0), then replica 0 flushes -------------------------------
-  if ((p.abl & 2) && acc[0][0][0] != 12345.678f) return;
   f32x4* const park = reinterpret_cast<f32x4*>(smem);
   if (rep >= 2) {
     f32x4* dst = park + ((rep - 2) * 2 + ch) * (ACCN * 64) + lane;
@@ -334,7 +332,6 @@ __global__ __launch_bounds__(kWbWaves * 64, 2) void wgrad_band_kernel(const WgBa
 #pragma unroll
       for (int tp = 0; tp < 9; ++tp) acc[a][tp] += src[(a * 9 + tp) * 64];
   }
-  if ((p.abl & 1) && acc[0][0][0] != 12345.678f) return;
   // lane holds D[k = 4 * (lane >> 4) + r][c = lane & 15] of every (fragment a, tap) tile
   float* const dwl = p.dw + (int64_t)(k0 + 4 * g) * p.Ktot + c0 + ch * 16 + (lane & 15);
 #pragma unroll
@@ -455,7 +452,6 @@ int try_launch_wgrad_band(const cvhip_conv_desc* d, const void* x, const void* d
   pl.a.x = (const h16_t*)x;
   pl.a.dy = (const h16_t*)dy;
   pl.a.dw = dw;
-  { const char* e = getenv("CVHIP_WGB_ABL"); pl.a.abl = e ? atoi(e) : 0; }
   return pl.KF == 4 ? wgband_launch<4>(pl, stream) : wgband_launch<2>(pl, stream);
 }
 
