@@ -74,7 +74,11 @@ def _apply_class_filter(prediction, classes, multi_label):
     never holds); best-class candidates are rows: a row whose best class (first maximum of cls * obj) is unlisted gets objectness 0."""
     nc = prediction.shape[2] - 5
     sel = torch.zeros((nc,), dtype=torch.bool, device=prediction.device)
-    sel[torch.as_tensor(list(classes), device=prediction.device).long().clamp(0, nc - 1)] = True
+    # the reference compares `x[:, 5:6] == torch.tensor(classes)`: an id outside [0, nc) (or a non-integer one) matches NO detection —
+    # it must not be folded onto class 0 / nc - 1
+    ids = torch.as_tensor(list(classes), device=prediction.device).double().reshape(-1)
+    ids = ids[(ids >= 0) & (ids < nc) & (ids == ids.floor())].long()
+    sel[ids] = True
     pred = prediction.float().clone()
     if multi_label and nc > 1:
         pred[..., 5:] = torch.where(sel, pred[..., 5:], torch.zeros((), device=pred.device))

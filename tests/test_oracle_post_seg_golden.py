@@ -49,7 +49,7 @@ NMS_V5 = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLD, "
 
 
 def test_fixture_inventory():
-    assert len(NMS_V5) == 7
+    assert len(NMS_V5) == 9
     assert len(glob.glob(os.path.join(GOLD, "post_yolox_*.npz"))) == 3
     assert len(glob.glob(os.path.join(GOLD, "post_batched_nms_*.npz"))) == 3
     assert len(glob.glob(os.path.join(GOLD, "post_multiclass_nms_*.npz"))) == 5

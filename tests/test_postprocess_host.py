@@ -40,3 +40,31 @@ def test_oracle_nms_against_hand_derived_known_answers(golden_dir):
         scores = torch.tensor(c["scores"], dtype=torch.float32)
         got = R.nms(boxes, scores, c["iou_threshold"]).tolist()
         assert got == c["keep"] or got in c["keep_alternatives"], (c["name"], got, c["keep"])
+
+
+@pytest.mark.parametrize("name", ["post_nms_v5_classes", "post_nms_v5_classes_oob", "post_nms_v5_classes_oob_multi"])
+def test_class_filter_as_input_mask_equals_reference(name, golden_dir):
+    """`classes=` of non_max_suppression (models/yolov5.py:118-119) is applied by the product as a mask on the kernels' INPUT
+    (nms._apply_class_filter). On the reference-run fixtures — including class ids outside [0, nc), which must match nothing, not be
+    clamped onto class 0 / nc - 1 — the masked prediction run through the oracle's loop WITHOUT `classes` gives exactly
+    what the reference returned WITH it."""
+    import os
+    from cvpytorch_amd import nms as NMS
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    conf, iou, agn, ml, max_det = z["cfg"].tolist()
+    classes = z["classes"].tolist()
+    pred = torch.from_numpy(z["pred"])
+    masked = NMS._apply_class_filter(pred, classes, bool(ml))
+    got = R.non_max_suppression(masked, conf, iou, None, bool(agn), bool(ml), int(max_det))
+    counts = z["counts"].tolist()
+    ref, o = [], 0
+    for c in counts:
+        ref.append(torch.from_numpy(z["out"][o:o + max(c, 0)]))
+        o += max(c, 0)
+    assert sum(counts) > 0
+    for a, r in zip(got, ref):
+        assert torch.equal(a, r)
+    nc = pred.shape[2] - 5
+    if any(c < 0 or c >= nc for c in classes):   # what clamping would have kept: detections of class 0 / nc - 1 that are not listed
+        kept = torch.cat([a[:, 5] for a in got]).long().tolist()
+        assert all(k in classes for k in kept)

@@ -109,11 +109,17 @@ def gen_nms_v5():
         ("multi", 4, 900, 12, 4, 0.08, 0.25, 0.45, None, False, True, 300),
         ("agnostic", 3, 900, 6, 5, 0.10, 0.25, 0.45, None, True, False, 300),
         ("classes", 3, 900, 8, 6, 0.10, 0.25, 0.45, [1, 3, 6], False, False, 300),
+        # class ids outside [0, nc) match nothing in the reference (yolov5.py:118-119 compares x[:, 5:6] == classes): ADVICE r05
+        ("classes_oob", 3, 900, 8, 6, 0.10, 0.25, 0.45, [8, 3, -1, 6], False, False, 300),
+        ("classes_oob_multi", 2, 700, 8, 11, 0.10, 0.25, 0.45, [8, 0, -2], False, True, 300),
         ("maxdet", 2, 1500, 4, 7, 0.60, 0.25, 0.70, None, False, False, 20),
         ("val_thresholds", 2, 500, 5, 8, 0.30, 0.001, 0.6, None, False, True, 300),
         ("single_class", 2, 600, 1, 9, 0.20, 0.25, 0.45, None, False, True, 300),
     ]
+    only = os.environ.get("GEN_ONLY")   # regenerate a subset (new cases) without touching the committed fixtures
     for (name, B, n, nc, seed, hot, conf, iou, classes, agn, ml, max_det) in cases:
+        if only and name not in only.split(","):
+            continue
         pred = synthetic_pred(B, n, nc, seed, hot=hot, clusters=60 if name != "maxdet" else 500)
         pred[1, :, 4] = 0.0   # an image without any candidate
         out = RY.non_max_suppression(pred.clone(), conf, iou, classes=classes, agnostic=agn, multi_label=ml, max_det=max_det)
