@@ -340,7 +340,8 @@ class FlatTrainState:
         """The state of the fused optimizer in the layout of `torch.optim.SGD(...)` / `torch.optim.AdamW(...)`.state_dict() built over
         the reference's parameter groups (one group per parameter, src/optimizers/__init__.py:36-73): {"state": {i: {"momentum_buffer"}
         | {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...]}. Tensors are copies in the parameters' logical (OIHW) layout, so
-        the dict loads into a stock torch optimizer built the same way, and back (load_optimizer_state_dict).
+        the dict loads into a stock torch optimizer built the same way, and back (load_optimizer_state_dict). As torch's schedulers
+        do, "lr" is the CURRENT learning rate (base x lr_scale) and "initial_lr" the unscaled one; loading prefers "initial_lr".
         NOTE: the fused kernels update EVERY arena segment each step — a parameter that received no gradient in a step
         still sees its (decoupled) weight decay and moment decay, where torch.optim skips parameters whose .grad is None; all
         parameters of the assembled models receive gradients every step, so the trajectories coincide."""
@@ -353,13 +354,13 @@ class FlatTrainState:
                 state[gi] = {"step": self.adam_step.detach().clone().reshape(()),
                              "exp_avg": _dense_view(self.mom, off, p).detach().clone().contiguous(),
                              "exp_avg_sq": _dense_view(self.mom2, off, p).detach().clone().contiguous()}
-                pgs.append({"lr": float(self.seg_lr[i]), "betas": self.betas, "eps": self.adam_eps, "weight_decay": float(self.seg_wd[i]),
+                pgs.append({"lr": float(self.seg_lr[i]) * self.lr_scale, "initial_lr": float(self.seg_lr[i]), "betas": self.betas, "eps": self.adam_eps, "weight_decay": float(self.seg_wd[i]),
                             "amsgrad": False, "params": [gi]})
             else:
                 if self.steps > 0:   # (torch creates the buffer at the first step)
                     state[gi] = {"momentum_buffer": _dense_view(self.mom, off, p).detach().clone().contiguous()}
-                pgs.append({"lr": float(self.seg_lr[i]), "momentum": self.momentum, "dampening": 0, "weight_decay": float(self.seg_wd[i]),
-                            "nesterov": self.nesterov, "params": [gi]})
+                pgs.append({"lr": float(self.seg_lr[i]) * self.lr_scale, "initial_lr": float(self.seg_lr[i]), "momentum": self.momentum, "dampening": 0,
+                            "weight_decay": float(self.seg_wd[i]), "nesterov": self.nesterov, "params": [gi]})
         return {"state": state, "param_groups": pgs, "cvhip": {"steps": self.steps, "ema_updates": self.ema_updates, "lr_scale": self.lr_scale}}
 
     def load_optimizer_state_dict(self, sd):
@@ -380,7 +381,10 @@ class FlatTrainState:
             p = mine["params"][0]
             i = self.index[id(p)]
             off = self.offsets[i]
-            lrs[i], wds[i] = float(g["lr"]), float(g.get("weight_decay", wds[i]))
+            #  a stock torch / reference checkpoint (utils/checkpoints.py:39-57) stores the SCHEDULER-ADJUSTED lr in "lr" and the
+            # unscaled one in "initial_lr"; this engine keeps the unscaled lr per segment and applies lr_scale on the device. Taking a
+            # mid-schedule "lr" as the base would apply the schedule factor twice at the next set_lr_scale()
+            lrs[i], wds[i] = float(g.get("initial_lr", g["lr"])), float(g.get("weight_decay", wds[i]))
             ent = sd["state"].get(g["params"][0], sd["state"].get(gi))
             if not ent:
                 continue
@@ -434,15 +438,18 @@ class FlatTrainState:
             if torch.cuda.is_current_stream_capturing():
                 ops._OWNED_BACKWARD[0] = True
                 try:
-                    return loss.backward()
+                    loss.backward()
                 finally:
                     ops._OWNED_BACKWARD[0] = False
+                ops.check_parked()
+                return None
             seed = self._seeds[key] = torch.ones_like(loss)
         ops._OWNED_BACKWARD[0] = True   # the engine drives this backward pass itself: its ops may work in place on gradients (ops.SppfChain)
         try:
             loss.backward(gradient=seed)
         finally:
             ops._OWNED_BACKWARD[0] = False
+        ops.check_parked()   # a gradient parked for a consumer whose backward never ran would be dropped silently
 
     def scale_loss(self, loss):
         """scaler.scale(loss): the backward pass is seeded with the CURRENT loss scale, read from device memory (so a replayed

@@ -64,6 +64,7 @@ class LazyIn(C.Structure):
 
 PATCH_CLASS_INTS = 30  # CVHIP_PATCH_CLASS_INTS
 BAND_PLAN_INTS = 13    # CVHIP_BAND_PLAN_INTS
+WGRAD_BAND_PLAN_INTS = 8   # include/cvhip.h CVHIP_WGRAD_BAND_PLAN_INTS
 
 
 class PrepEntry(C.Structure):

@@ -180,6 +180,57 @@ def lazy_of(t):
     return getattr(t, "_hip_lazy", None) if t is not None else None
 
 
+# names of the torch.Tensor methods / property getters that do NOT read a tensor's elements: metadata the engine's own ops (and
+# autograd) ask a lazy tensor for. Everything else is a stock torch op about to read RAW convolution outputs.
+_LAZY_META = frozenset((
+    "size", "stride", "dim", "ndimension", "numel", "nelement", "data_ptr", "storage_offset", "is_contiguous", "element_size", "__len__",
+    "shape", "device", "dtype", "is_cuda", "requires_grad", "grad_fn", "is_leaf", "layout", "names", "ndim", "_version", "_base", "grad",
+    "is_floating_point", "is_complex", "get_device", "is_sparse", "is_quantized", "is_meta", "untyped_storage", "_is_view", "output_nr",
+    "register_hook", "retain_grad", "retains_grad", "__hash__", "__repr__", "__format__", "_backward_hooks", "is_pinned", "is_shared"))
+
+
+class LazyRaw(torch.Tensor):
+    """The tensor type of a LAZY activation: the storage holds the RAW output y of a training-mode Conv-BN-act layer
+    (conv_module.py:201-214 with the norm / activation deferred into the consumers' loads), the tag `_hip_lazy` says how to read it.
+    The engine's ops (autograd Functions, `as_nhwc(..., lazy_ok=True)`) see the raw storage; ANY stock torch function — a view, a
+    slice, `.float()`, `detach`, an `nn.Conv2d` that `convert_to_hip` left in place, a forward hook's arithmetic, torch.utils.checkpoint —
+    is given the ACTIVATED tensor instead (`ops.materialize`: the pass the producer skipped, computed once and shared), so a consumer
+    that does not know about the tag can never read un-normalised, un-activated data."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        name = getattr(func, "__name__", "")
+        if name == "__get__" or name == "__set__":   # property access: func.__self__ is the descriptor
+            name = getattr(getattr(func, "__self__", None), "__name__", name)
+        if name in _LAZY_META:
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
+        from torch.utils._pytree import tree_map
+
+        def fix(a):
+            if isinstance(a, LazyRaw):
+                with torch._C.DisableTorchFunctionSubclass():
+                    return materialize(a) if lazy_of(a) is not None else a.as_subclass(torch.Tensor)
+            return a
+
+        args, kwargs = tree_map(fix, args), tree_map(fix, kwargs)
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
+
+
+def tag_lazy(t, lz):
+    """`t` as a LazyRaw carrying the tag (same storage, same autograd node); other engine tags on the tensor object move along"""
+    with torch._C.DisableTorchFunctionSubclass():
+        z = t.as_subclass(LazyRaw)
+    for k in ("_hip_prod",):
+        v = getattr(t, k, None)
+        if v is not None:
+            setattr(z, k, v)
+    z._hip_lazy = lz
+    return z
+
+
 class Materialize(torch.autograd.Function):
     """z = act(scale*y + shift): the BN-apply + activation pass a lazy producer skipped, for a consumer that cannot transform on load"""
 
@@ -370,6 +421,14 @@ def _timed_call(kname, geom, fname, *args, passes=1, nbytes=None):
                 kname = "conv_band_kernel<%d ch/wave>" % (16 * bb[0])
             elif L.load().cvhip_conv2d_patch_plan(args[0], dg, buf, 4) > 0:
                 kname = "conv_patch_kernel<128>"
+        except Exception:
+            pass
+    elif kname.startswith("wgrad_kernel") and fname == "cvhip_conv2d_wgrad":
+        # stride-1 3x3 "same" layers run on the tap-resident weight-gradient kernel (conv_wgrad_band.hip) where its plan fits
+        try:
+            wb = (C.c_int32 * L.WGRAD_BAND_PLAN_INTS)()
+            if L.load().cvhip_conv2d_wgrad_band_plan(args[0], wb) > 0:
+                kname = "wgrad_band_kernel<%d>" % wb[0]
         except Exception:
             pass
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -697,13 +756,44 @@ def _colreduce_rows(M, Cc):
 class GradLink:
     """One skip connection x -> (conv_a -> ... -> + x): carries the gradient of the identity branch from the op that performs the
     add (which returns None for that input, so autograd has nothing to accumulate) to conv_a's backward, whose dgrad kernel adds
-    it in its epilogue. Created per forward call by the block that owns the skip connection; only when x requires grad."""
-    __slots__ = ("g", "ok", "consumed")
+    it in its epilogue. Created per forward call by the block that owns the skip connection; only when x requires grad.
+    A parked gradient (`g` set through the property) is entered in `_PARKED`; the layer that folds it takes it out again by setting
+    `g = None`. `check_parked()` at the end of a backward pass finds gradients nobody picked up."""
+    __slots__ = ("_g", "ok", "consumed", "__weakref__")
 
     def __init__(self):
-        self.g = None
+        self._g = None
         self.ok = False   # set by the consuming layer's forward once it is certain to run a dense dgrad on the unpadded input
         self.consumed = False   # set when the consuming layer's backward has started (a gradient parked after that would be lost)
+
+    @property
+    def g(self):
+        return self._g
+
+    @g.setter
+    def g(self, v):
+        self._g = v
+        if v is None:
+            _PARKED.discard(self)
+        else:
+            _PARKED.add(self)
+
+
+_PARKED = __import__("weakref").WeakSet()   # links holding a gradient that no dgrad epilogue has folded yet
+
+
+def check_parked(clear=True):
+    """Raise if a gradient parked in a GradLink (skip connections, ops.fanout_linked's side branches) was never folded by its main
+    consumer — the main consumer's output did not contribute to the loss (partial losses, a pruned or frozen branch,
+    autograd.grad on a subset), so its backward never ran and the parked gradient would be silently DROPPED. Called by
+    arena.FlatTrainState.backward after autograd returns; callers that drive loss.backward() themselves can call it too."""
+    left = [l for l in list(_PARKED) if l.g is not None]
+    if clear:
+        for l in left:
+            l.g = None
+    if left:
+        raise L.CvhipError("%d parked gradient(s) were never folded: the main consumer of a linked fan-out / skip connection did not run its "
+                           "backward (its output does not reach the loss?). Set CVHIP_FANOUT_LINK=0 / CVHIP_GRAD_LINK=0 for such graphs." % len(left))
 
 
 def _check_out(out, N, K, P, Q):
@@ -1587,7 +1677,7 @@ def conv_bn_act(x, weight, bias, gamma, beta, running_mean, running_var, residua
         z._hip_prod = cfg.prod
     if cfg.lazy_made is not None and torch.is_tensor(z):
         st4, off, kh = cfg.lazy_made
-        z._hip_lazy = LazyAct(st4[2][off:off + kh], st4[3][off:off + kh], cfg.act, cfg.act_param)
+        z = tag_lazy(z, LazyAct(st4[2][off:off + kh], st4[3][off:off + kh], cfg.act, cfg.act_param))
     return z
 
 
@@ -1750,10 +1840,10 @@ def conv_bn_act_pair(x, operands, cfg, out2=None):
     z1, z2 = ConvBnActPair.apply(x, wf, gf, bf, rmf, rvf, cfg, k1)
     if cfg.lazy_made is not None:   # the first sibling's result is lazy: z1 is the channel slice [0, k1) of the pair's raw output
         st4, off, kh = cfg.lazy_made
-        z1._hip_lazy = LazyAct(st4[2][off:off + kh], st4[3][off:off + kh], cfg.act, cfg.act_param)
+        z1 = tag_lazy(z1, LazyAct(st4[2][off:off + kh], st4[3][off:off + kh], cfg.act, cfg.act_param))
     if cfg.lazy_made2 is not None:  # the second sibling's slice of the concat buffer holds its RAW output (split store)
         st4, off, kh = cfg.lazy_made2
-        z2._hip_lazy = LazyAct(st4[2][off:off + kh], st4[3][off:off + kh], cfg.act, cfg.act_param)
+        z2 = tag_lazy(z2, LazyAct(st4[2][off:off + kh], st4[3][off:off + kh], cfg.act, cfg.act_param))
     if cfg.prod is not None:
         kt = cfg.prod.kh
         cfg.prod.halves = (cfg.prod.half(0, k1), cfg.prod.half(k1, kt - k1))
@@ -2013,13 +2103,28 @@ class Cat(torch.autograd.Function):
         return (None,) + tuple(outs)
 
 
-_cat_lazy = [None]
+class _CatLazy(__import__("threading").local):
+    """what Cat.forward found out about lazy slices, handed to `cat` on the SAME thread right after apply returns (a Function cannot
+    return a python object): a thread-local list, so that two threads assembling models cannot see each other's tag"""
+
+    def __init__(self):
+        self.v = [None]
+
+    def __getitem__(self, i):
+        return self.v[i]
+
+    def __setitem__(self, i, x):
+        self.v[i] = x
+
+
+_cat_lazy = _CatLazy()
 
 
 def cat(xs, into=None):
     out = Cat.apply(into, *xs)
     if _cat_lazy[0] is not None:
-        out._hip_lazy, _cat_lazy[0] = _cat_lazy[0], None
+        lz, _cat_lazy[0] = _cat_lazy[0], None
+        out = tag_lazy(out, lz)
     return out
 
 

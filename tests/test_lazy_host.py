@@ -83,3 +83,68 @@ def test_lazy_tensor_reaching_an_unaware_op_raises():
     with pytest.raises(L.CvhipError):
         ops.as_nhwc(t)          # (raises for the CPU tensor first or for the tag: either way nothing reads it)
     assert ops.lazy_of(t) is not None and ops.lazy_of(torch.zeros(1)) is None
+
+
+def test_lazy_raw_tensor_is_safe_outside_the_engine():
+    """the storage of a lazy activation holds RAW convolution outputs. Its type (ops.LazyRaw) hands every stock torch
+    function the ACTIVATED tensor (ops.materialize; here the cache is pre-filled, so no kernel runs on this CPU box): views, slices,
+    casts, detach, arithmetic, a stock nn.Conv2d, torch.cat — none of them can read the un-normalised data; metadata queries and the
+    engine's own tag lookups still see the raw tensor."""
+    import torch.nn as nn
+    raw = torch.arange(2 * 4 * 3 * 3, dtype=torch.float32).reshape(2, 4, 3, 3)
+    act = torch.tanh(raw * 0.01) + 5.0                      # stands for act(scale * y + shift)
+    lz = ops.LazyAct(torch.ones(4), torch.zeros(4), 2, 0.0)
+    lz.z = act                                              # "already materialised"
+    z = ops.tag_lazy(raw, lz)
+    assert isinstance(z, ops.LazyRaw) and ops.lazy_of(z) is lz
+    assert z.shape == raw.shape and z.data_ptr() == raw.data_ptr() and z.stride() == raw.stride() and z.dim() == 4 and z.numel() == raw.numel()
+    assert z.dtype == torch.float32 and not z.is_cuda and z.device == raw.device
+    checks = {
+        "relu": (torch.relu(z), torch.relu(act)),
+        "add": (z + 1.0, act + 1.0),
+        "radd": (1.0 + z, act + 1.0),
+        "slice": (z[:, 1:3], act[:, 1:3]),
+        "view": (z.view(2, -1), act.view(2, -1)),
+        "float64": (z.double(), act.double()),
+        "detach": (z.detach(), act),
+        "clone": (z.clone(), act),
+        "cat": (torch.cat([z, z], 1), torch.cat([act, act], 1)),
+        "mean": (z.mean(), act.mean()),
+        "permute": (z.permute(0, 2, 3, 1), act.permute(0, 2, 3, 1)),
+        "F.silu": (torch.nn.functional.silu(z), torch.nn.functional.silu(act)),
+    }
+    conv = nn.Conv2d(4, 2, 1)
+    checks["nn.Conv2d"] = (conv(z), conv(act))
+    for name, (got, exp) in checks.items():
+        assert type(got) is torch.Tensor, name             # results are ordinary tensors: the tag does not leak
+        assert torch.equal(got, exp), name
+    # a hook-style consumer that indexes and compares
+    assert bool((z > 4.0).all()) and not bool((raw > 4.0).all())
+    # an untagged LazyRaw (tag removed) behaves as the plain tensor it is
+    z2 = ops.tag_lazy(raw.clone(), lz)
+    z2._hip_lazy = None
+    assert torch.equal(z2 + 0.0, raw)
+
+
+def test_cat_lazy_tag_is_thread_local():
+    import threading
+    ops._cat_lazy[0] = "main"
+    seen = []
+    th = threading.Thread(target=lambda: seen.append(ops._cat_lazy[0]))
+    th.start()
+    th.join()
+    assert seen == [None] and ops._cat_lazy[0] == "main"
+    ops._cat_lazy[0] = None
+
+
+def test_parked_gradients_are_accounted_for():
+    """a gradient parked in a GradLink whose main consumer never runs its backward must not vanish silently"""
+    link = ops.GradLink()
+    ops.check_parked()                       # nothing parked
+    link.g = torch.ones(2)
+    with pytest.raises(L.CvhipError):
+        ops.check_parked()
+    assert link.g is None                    # cleared for the next step
+    link.g = torch.ones(2)
+    link.g = None                            # the folding layer took it
+    ops.check_parked()
