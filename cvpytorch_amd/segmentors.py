@@ -187,7 +187,7 @@ STDC1_CFG = dict(
 class STDCEncoderDecoder(nn.Module):
     """encoder_decoder.py:21-150 for the STDC configuration: backbone -> neck (-> (feats, aux_feats)) -> head; in train mode every
     head's logits are resized to label size (bilinear, align_corners False: encoder_decoder.py:96) and fed to its loss; auxiliary
-    losses are prefixed 'aux<i>.' (utils/misc.py add_prefix) and `loss` is the sum of all entries."""
+    losses are prefixed "aux<i>_" (utils/misc.py add_prefix) and `loss` is the sum of all entries."""
 
     def __init__(self, cfg=None, min_kept=None):
         super().__init__()
@@ -236,7 +236,7 @@ class STDCEncoderDecoder(nn.Module):
         losses = {}
         self._loss_forward(feats[0], targets, self.loss, losses)
         for i, (pred, l) in enumerate(zip(feats[1:], self.auxiliary_loss)):
-            self._loss_forward(pred, targets, l, losses, "aux%d." % i)
+            self._loss_forward(pred, targets, l, losses, "aux%d_" % i)
         losses["loss"] = sum(losses.values())
         return losses
 

@@ -170,3 +170,131 @@ class STDCNeck(nn.Module):
             feature_up = self.convs[i](F.interpolate(x_arm, x[i].shape[2:], mode="nearest"))
             arms_out.append(feature_up)
         return self.ffm(x[0], arms_out[1]), [x[0]] + arms_out
+
+
+# ---- STDC train path (round 6): heads, losses, the EncoderDecoder with auxiliary heads ---------------------------------------------------
+# Pinned by tests/test_oracle_stdc_train.py against fixtures captured from the reference's own classes (tools/gen_golden_stdc_train.py).
+#   heads     : src/models/heads/seg/fcn_head.py:14-63 (FCNHead), stdc_head.py:16-18 (STDCHead), base_seg_head.py:12-41 (dropout + cls_seg)
+#   losses    : src/losses/seg/cross_entropy_loss.py:51-69 (OhemCrossEntropyLoss2d), src/losses/seg/detail_loss.py:11-88 (DetailAggregateLoss)
+#   segmentor : src/models/segmentors/encoder_decoder.py:89-150 (loss_forward, forward with the auxiliary-head branch)
+class FCNHead(nn.Module):
+    def __init__(self, num_classes, in_channels, channels, num_convs=2, kernel_size=3, is_concat=True, dilation=1, dropout_ratio=0.1,
+                 norm_cfg=dict(type="BN", requires_grad=True), act_cfg=dict(type="ReLU")):
+        super().__init__()
+        self.is_concat = is_concat
+        self.dropout = nn.Dropout2d(dropout_ratio) if dropout_ratio > 0 else None
+        self.cls_seg = nn.Conv2d(channels, num_classes, kernel_size=1)
+        if num_convs == 0:
+            self.convs = nn.Identity()
+        else:
+            pad = (kernel_size // 2) * dilation
+            convs = [ConvModule(in_channels, channels, kernel_size, padding=pad, dilation=dilation, norm_cfg=norm_cfg, act_cfg=act_cfg)]
+            for _ in range(num_convs - 1):
+                convs.append(ConvModule(channels, channels, kernel_size, padding=pad, dilation=dilation, norm_cfg=norm_cfg, act_cfg=act_cfg))
+            self.convs = nn.Sequential(*convs)
+        if is_concat:
+            self.conv_cat = ConvModule(in_channels + channels, channels, kernel_size, padding=kernel_size // 2, norm_cfg=norm_cfg, act_cfg=act_cfg)
+
+    def forward(self, x):
+        feats = self.convs(x)
+        if self.is_concat:
+            feats = self.conv_cat(torch.cat([x, feats], dim=1))
+        if self.dropout is not None:
+            feats = self.dropout(feats)
+        return self.cls_seg(feats)
+
+
+class OhemCrossEntropyLoss2d(nn.Module):
+    """the reference's control flow, literally: sort, branch on loss[min_kept], boolean mask / slice, mean"""
+    loss_name = "ohem_ce_loss"
+
+    def __init__(self, thresh=0.7, min_kept=100000, ignore_index=255, loss_weight=1.0):
+        super().__init__()
+        self.thresh = -torch.log(torch.tensor(thresh, dtype=torch.float))
+        self.min_kept, self.ignore_index, self.loss_weight = min_kept, ignore_index, loss_weight
+
+    def forward(self, pred, target):
+        loss = self.loss_weight * F.cross_entropy(pred, target.long(), ignore_index=self.ignore_index, reduction="none").view(-1)
+        loss, _ = torch.sort(loss, descending=True)
+        if loss[self.min_kept] > self.thresh:
+            loss = loss[loss > self.thresh]
+        else:
+            loss = loss[:self.min_kept]
+        return torch.mean(loss)
+
+
+class DetailAggregateLoss(nn.Module):
+    loss_name = "detail_agg_loss"
+
+    def __init__(self, loss_weight=1.0, bce_loss_weight=1.0, dice_loss_weight=1.0, boundary_threshold=0.1):
+        super().__init__()
+        self.loss_weight, self.bce_loss_weight, self.dice_loss_weight, self.thr = loss_weight, bce_loss_weight, dice_loss_weight, boundary_threshold
+        self.lap = torch.tensor([-1, -1, -1, -1, 8, -1, -1, -1, -1], dtype=torch.float32).reshape(1, 1, 3, 3)
+        self.fuse = torch.tensor([[6.0 / 10], [3.0 / 10], [1.0 / 10]], dtype=torch.float32).reshape(1, 3, 1, 1)
+
+    def forward(self, boundary_logits, gtmasks):
+        g = gtmasks.unsqueeze(1).float()
+
+        def level(stride):
+            t = F.conv2d(g, self.lap, stride=stride, padding=1).clamp(min=0)
+            return t
+
+        b1 = level(1)
+        b1[b1 > self.thr] = 1
+        b1[b1 <= self.thr] = 0
+        ups = []
+        for s in (2, 4):
+            t = F.interpolate(level(s), b1.shape[2:], mode="nearest")
+            t[t > self.thr] = 1
+            t[t <= self.thr] = 0
+            ups.append(t)
+        pyr = F.conv2d(torch.stack((b1, ups[0], ups[1]), dim=1).squeeze(2), self.fuse)
+        pyr[pyr > self.thr] = 1
+        pyr[pyr <= self.thr] = 0
+        if boundary_logits.shape[-1] != b1.shape[-1]:
+            boundary_logits = F.interpolate(boundary_logits, b1.shape[2:], mode="bilinear", align_corners=True)
+        bce = F.binary_cross_entropy_with_logits(boundary_logits, pyr)
+        p = torch.sigmoid(boundary_logits)
+        n = p.size(0)
+        pf, tf = p.view(n, -1), pyr.view(n, -1)
+        dice = (1 - ((2.0 * (pf * tf).sum(1) + 1.0) / (pf.sum(1) + tf.sum(1) + 1.0))).mean()
+        return self.loss_weight * (self.bce_loss_weight * bce + self.dice_loss_weight * dice)
+
+
+class STDCEncoderDecoder(nn.Module):
+    """STDCNet -> STDCNeck -> head (+ auxiliary heads on the neck's auxiliary maps); the small-width configuration of the fixture
+    (tools/gen_golden_stdc_train.py gen_encoder_decoder) or the full conf/seg/stdc/cityscapes_stdc1.yml:55-68"""
+
+    def __init__(self, out_channels=(32, 64, 256, 512, 1024), neck_out=256, aux_out=128, head_channels=256, aux_channels=(64, 64, 64), num_classes=19,
+                 min_kept=100000, dropout_ratio=0.1):
+        super().__init__()
+        oc = list(out_channels)
+        self.backbone = STDCNet("stdc1", out_channels=oc, layers=[2, 2, 2], block_num=4, out_stages=[2, 3, 4])
+        self.neck = STDCNeck(in_channels=oc[2:], out_channels=neck_out, aux_out_channels=aux_out)
+        self.head = FCNHead(num_classes, neck_out, head_channels, num_convs=1, is_concat=False, dropout_ratio=dropout_ratio)
+        self.auxiliary_head = nn.ModuleList([
+            FCNHead(1, oc[2], aux_channels[0], num_convs=1, is_concat=False, dropout_ratio=dropout_ratio),
+            FCNHead(num_classes, aux_out, aux_channels[1], num_convs=1, is_concat=False, dropout_ratio=dropout_ratio),
+            FCNHead(num_classes, aux_out, aux_channels[2], num_convs=1, is_concat=False, dropout_ratio=dropout_ratio)])
+        self.loss = [OhemCrossEntropyLoss2d(min_kept=min_kept)]
+        self.auxiliary_loss = [DetailAggregateLoss(), OhemCrossEntropyLoss2d(min_kept=min_kept), OhemCrossEntropyLoss2d(min_kept=min_kept)]
+
+    @staticmethod
+    def loss_forward(preds, targets, loss):
+        preds = F.interpolate(preds, size=targets.shape[-2:], mode="bilinear", align_corners=False)
+        out = {}
+        for l in (loss if isinstance(loss, (list, tuple)) else [loss]):
+            out[l.loss_name] = out.get(l.loss_name, 0) + l(preds, targets)
+        return out
+
+    def forward(self, imgs, targets=None, mode="infer"):
+        feats, aux_feats = self.neck(self.backbone(imgs))
+        preds = self.head(feats)
+        if mode != "train":
+            return torch.argmax(F.interpolate(preds, size=targets.shape[-2:], mode="bilinear", align_corners=False), dim=1)
+        losses = self.loss_forward(preds, targets, self.loss)
+        for i, (h, f, l) in enumerate(zip(self.auxiliary_head, aux_feats, self.auxiliary_loss)):
+            for k, v in self.loss_forward(h(f), targets, l).items():
+                losses["aux%d_%s" % (i, k)] = v
+        losses["loss"] = sum(losses.values())
+        return losses
