@@ -209,27 +209,30 @@ def _physical_cores():
 
 def cpu_baseline(size, cpu_batch, budget_s=12.0, max_threads=None):
     """Oracle train step on the host cores: bounded samples (SURVEY.md §8d 'CPU baseline: all physical cores') with one intra-op
-    thread per PHYSICAL core (CVHIP_BENCH_CPU_THREADS overrides) and with ONE thread. With all 256 LOGICAL cores of the GPU box
-    torch's intra-op pool oversubscribes (one batch-8 step took 192 s, 0.04 img/s, round 2), so SMT siblings are not used; the
-    samples are sized so that warm-up + timed steps stay within ~30 s together. `value_32_threads` keeps the figure earlier rounds
-    reported."""
+    thread per PHYSICAL core, with 64 and 32 threads, and with ONE thread (CVHIP_BENCH_CPU_THREADS forces a single count). With
+    all 256 LOGICAL cores of the GPU box torch's intra-op pool oversubscribes (one batch-8 step took 192 s, 0.04 img/s, round 2), and
+    even one thread per physical core of the two-socket EPYC 9575F box is SLOWER than 32 threads (1.8 vs 8.5 img/s, round 6): every
+    count is reported (`by_threads`), `value` is the best of them; the samples together stay within ~40 s."""
     phys = _physical_cores()
-    threads = int(os.environ.get("CVHIP_BENCH_CPU_THREADS", "0")) or (max_threads or phys)
-    threads = max(1, min(threads, os.cpu_count() or 1))
-    v, b, n, el = _cpu_sample(size, cpu_batch, budget_s, threads)
+    forced = int(os.environ.get("CVHIP_BENCH_CPU_THREADS", "0"))
+    counts = [forced] if forced else sorted({max(1, min(c, os.cpu_count() or 1)) for c in ((max_threads or phys), 64, 32)}, reverse=True)
+    by, best = {}, None
+    for i, th in enumerate(counts):
+        v, b, n, el = _cpu_sample(size, cpu_batch, budget_s if i == 0 else min(6.0, budget_s), th)
+        by[str(th)] = round(v, 3)
+        if best is None or v > best[0]:
+            best = (v, b, n, el, th)
+    v, b, n, el, threads = best
     v1, b1, n1, el1 = _cpu_sample(size, 1, min(8.0, budget_s), 1)
-    v32 = None
-    if threads > 32:
-        try:
-            v32 = round(_cpu_sample(size, cpu_batch, min(6.0, budget_s), 32)[0], 3)
-        except Exception:
-            v32 = None
+    by["1"] = round(v1, 3)
     return {"value": round(v, 3), "unit": "images/sec", "cores": threads, "kind": "port",
-            "value_1_thread": round(v1, 3), "value_32_threads": v32, "cpu_model": _cpu_model(), "physical_cores": phys, "logical_cores": os.cpu_count() or 1,
+            "value_1_thread": round(v1, 3), "value_all_physical_cores": by.get(str(max(1, min(phys, os.cpu_count() or 1)))), "by_threads": by,
+            "cpu_model": _cpu_model(), "physical_cores": phys, "logical_cores": os.cpu_count() or 1,
             "torch": torch.__version__,
-            "sample": "oracle (oracle/torch_ref.py) YOLOv5-s fp32 train step (fwd+loss+bwd+SGD-nesterov+EMA) @%dx%d: batch %d, %d timed step(s) after a "
-                      "1-image warm-up, %.1f s, %d intra-op threads of %d logical cores; 1-thread figure: batch %d, %d step(s), %.1f s"
-                      % (size, size, b, n, el, threads, os.cpu_count() or 1, b1, n1, el1)}
+            "sample": "oracle (oracle/torch_ref.py) YOLOv5-s fp32 train step (fwd+loss+bwd+SGD-nesterov+EMA) @%dx%d on the box's host cores: one bounded "
+                      "sample per intra-op thread count (all %d physical cores, 64, 32: `by_threads`, images/sec); `value` is the BEST of them (%d threads: "
+                      "batch %d, %d timed step(s) after a 1-image warm-up, %.1f s; `cores` = that count); 1-thread figure: batch %d, %d step(s), %.1f s"
+                      % (size, size, phys, threads, b, n, el, b1, n1, el1)}
 
 
 def _median(xs):
@@ -299,6 +302,29 @@ def deeplab_workload(dev, a, batch=16, size=(512, 1024), steps=20, warmup=3, out
     return _side_result("DeepLabv3+ R50-v1c %dx%d bf16 batch %d OS-%d (%s), SGD-nesterov, synthetic"
                         % (size[1], size[0], batch, output_stride, "as written" if output_stride == 32 else "as the yml intends"),
                         batch, steps, warmup, el, med, losses, fl, by, graph)
+
+
+def stdc_workload(dev, a, steps, warmup, batch=16, size=(512, 1024)):
+    """STDC1-Seg train step as conf/seg/stdc/cityscapes_stdc1.yml wires it (STDCNet -> STDCNeck -> FCNHead + three auxiliary heads, OHEM
+    cross-entropy x3 + detail loss; 1024x512 crops, batch 16 here as for config 3): forward graph, eager loss island (the two STDC
+    losses are fixed-shape torch ops on engine-resized logits), backward + SGD graph."""
+    from cvpytorch_amd import segmentors
+    from cvpytorch_amd.arena import FlatTrainState, FlatTrainStep
+    from cvpytorch_amd.data import synthetic_segmentation_batch
+    torch.manual_seed(1029)
+    model = segmentors.STDCEncoderDecoder().to(dev).train()
+    state = FlatTrainState(model, lr=0.01, momentum=0.9, nesterov=True, weight_decay=1e-4, use_ema=False)
+    step = FlatTrainStep(model, state)
+    imgs, tgt = synthetic_segmentation_batch(batch, size, device=dev)
+    graph = not a.no_graph
+    imgs, tgt = _graph_step(step, imgs, tgt, warmup, graph)
+    el, losses, med, _ = timed_steps(step, imgs, tgt, steps)
+    out = _side_result("cityscapes_stdc1.yml STDC1-Seg %dx%d bf16 batch %d, OHEM CE x3 + detail loss, SGD-nesterov, synthetic" % (size[1], size[0], batch),
+                       batch, steps, warmup, el, med, losses, 0.0, 0.0, graph)
+    out.pop("step_roofline", None)   # (no algorithmic FLOP / byte count was derived for this widening workload)
+    out["launch"] = "two hipGraphs around an eager loss island" if graph else "eager"
+    out["loss_terms"] = {k: round(float(v), 4) for k, v in losses.items()}
+    return out
 
 
 def yolox_workload(dev, a, steps, warmup, batch=64):
@@ -904,6 +930,7 @@ def main():
         if not a.no_extra:
             for key, fn in (("config3_os8", lambda: deeplab_workload(dev, a, steps=10, warmup=2, output_stride=8)),
                             ("config4_yolox_s", lambda: yolox_workload(dev, a, side_steps, side_warm)),
+                            ("stdc1_cityscapes", lambda: stdc_workload(dev, a, 10, 2)),
                             ("config5_yolov7l_fp16", lambda: yolov7_workload(dev, a, max(10, a.steps // 2), 2))):
                 try:
                     out[key] = fn()

@@ -32,259 +32,9 @@
 
 namespace cvhip {
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmKernArgs p) {
-  constexpr int WAVES_N = BN / WN;
-  constexpr int WAVES_M = BM / WM;
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
-  constexpr int MF = WM / 16, NF = WN / 16;
-  constexpr int A_IT = BM / 64;
-  constexpr int B_IT = (BN + 63) / 64;
-  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
-
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_BYTES + 2 * B_BYTES];
-  unsigned char* const sA = smem;
-  unsigned char* const sB = smem + 2 * A_BYTES;
-
-  const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int wave = t >> 6;
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-
-  // ---- which tile ---------------------------------------------------------------------------
-  const int lt = xcd_remap(blockIdx.x, p.total_tiles);
-  int ci = 0;
-#pragma unroll 1
-  for (int i = 1; i < p.ncls; ++i)
-    if (lt >= p.cls[i].tile_begin) ci = i;
-  const IgemmClass& cl = p.cls[ci];
-  const int local = lt - cl.tile_begin;
-  const int mtile = local / p.n_tiles;
-  const int ntile = local - mtile * p.n_tiles;
-  const int m0 = mtile * BM, n0 = ntile * BN;
-  const int TR = cl.TR, TS = cl.TS;
-  const int Cin = p.Cin;
-  const int Ktot = TR * TS * Cin;
-  const int nk = (Ktot + 31) >> 5;
-  const int M = cl.M;
-  const int OWi = cl.OWi, OHWi = cl.OHi * cl.OWi;
-
-  // ---- per-thread A rows: this thread stages rows (t>>2) + 64*i, 16-B slot (t&3) --------------
-  int ih0[A_IT], iw0[A_IT], pbase[A_IT];
-#pragma unroll
-  for (int i = 0; i < A_IT; ++i) {
-    const int m = m0 + i * 64 + (t >> 2);
-    if (m < M) {
-      const int n = m / OHWi;
-      const int rem = m - n * OHWi;
-      const int oh = rem / OWi;
-      const int ow = rem - oh * OWi;
-      ih0[i] = oh * p.in_sh + cl.dh0;
-      iw0[i] = ow * p.in_sw + cl.dw0;
-      pbase[i] = n * p.IH * p.IW;
-    } else {
-      ih0[i] = -(1 << 28);
-      iw0[i] = 0;
-      pbase[i] = 0;
-    }
-  }
-  // branch-free tap decode for this thread's 16-B slot: element k -> (tr, ts, c0) by exact magic-number division
-  const unsigned cin_magic = p.cin_magic, ts_magic = cl.ts_magic;
-  auto fdiv = [](unsigned n, unsigned magic) -> unsigned { return magic ? __umulhi(n, magic) : n; };
-  const h16_t* __restrict__ wbase = p.w + cl.w_off;
-
-  // swizzled 16-B slot for the LDS write (thread-constant) and the fragment read (lane-constant)
-  const int swz_w = (t & 3) ^ ((0x78 >> (2 * ((t >> 4) & 3))) & 3);
-  const int swz_r = (lane >> 4) ^ ((0x78 >> (2 * ((lane >> 2) & 3))) & 3);
-
-  // Two register stages: while tile kt is consumed from LDS, tiles kt+2 and kt+3 are in flight from L2/HBM
-  // (the kernel is latency x concurrency bound: bytes in flight per CU set its speed).
-  uint4 ra0[A_IT], rb0[B_IT], ra1[A_IT], rb1[B_IT];
-
-  // Loads are UNCONDITIONAL (masked lanes read a safe address and are zeroed when the tile is written to LDS):
-  // a load inside a divergent branch makes hipcc fall back to s_waitcnt vmcnt(0) at every join, which would drain
-  // both register stages each step; branch-free loads let it emit the counted waits the pipeline needs.
-  unsigned msk0 = 0, msk1 = 0;
-  auto load_tile = [&](int kt, uint4(&ra)[A_IT], uint4(&rb)[B_IT], unsigned& msk) {
-    const unsigned k = (unsigned)(kt * 32 + (t & 3) * 8);
-    const unsigned tap = fdiv(k, cin_magic);
-    const int c0 = (int)(k - tap * (unsigned)Cin);
-    const unsigned tr = fdiv(tap, ts_magic);
-    const int ts = (int)(tap - tr * (unsigned)TS);
-    const bool tap_ok = (int)tr < TR;  // also false for every k >= Ktot (tiles past the end are all-zero)
-    const int dh = (int)tr * cl.dh_step, dw = ts * cl.dw_step;
-    unsigned m = 0;
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-      const int ih = ih0[i] + dh, iw = iw0[i] + dw;
-      const bool ok = tap_ok && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
-      const int64_t off = ok ? ((int64_t)(pbase[i] + ih * p.IW + iw) * p.x_ld + c0) : 0;
-      ra[i] = *reinterpret_cast<const uint4*>(p.x + off);
-      m |= (ok ? 1u : 0u) << i;
-    }
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      const int row = i * 64 + (t >> 2);
-      const int n = n0 + row;
-      const bool ok = row < BN && n < p.Nout && (int)k < Ktot;
-      const int64_t off = ok ? ((int64_t)n * Ktot + k) : 0;
-      rb[i] = *reinterpret_cast<const uint4*>(wbase + off);
-      m |= (ok ? 1u : 0u) << (8 + i);
-    }
-    msk = m;
-  };
-  auto store_tile = [&](int buf, const uint4(&ra)[A_IT], const uint4(&rb)[B_IT], unsigned msk) {
-    const uint4 z = make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-      const bool ok = (msk >> i) & 1u;
-      uint4 v = ra[i];
-      v.x = ok ? v.x : z.x;
-      v.y = ok ? v.y : z.y;
-      v.z = ok ? v.z : z.z;
-      v.w = ok ? v.w : z.w;
-      *reinterpret_cast<uint4*>(sA + buf * A_BYTES + (i * 64 + (t >> 2)) * 64 + swz_w * 16) = v;
-    }
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      const int row = i * 64 + (t >> 2);
-      const bool ok = (msk >> (8 + i)) & 1u;
-      uint4 v = rb[i];
-      v.x = ok ? v.x : z.x;
-      v.y = ok ? v.y : z.y;
-      v.z = ok ? v.z : z.z;
-      v.w = ok ? v.w : z.w;
-      if (BN >= 64 || row < BN) *reinterpret_cast<uint4*>(sB + buf * B_BYTES + row * 64 + swz_w * 16) = v;
-    }
-  };
-
-  f32x4 acc[NF][MF];
-#pragma unroll
-  for (int a = 0; a < NF; ++a)
-#pragma unroll
-    for (int b = 0; b < MF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int a_row = wm * WM + (lane & 15);
-  const int b_row = wn * WN + (lane & 15);
-  auto compute = [&](int cur) {
-    h16x8 xa[MF], wb[NF];
-#pragma unroll
-    for (int b = 0; b < MF; ++b)
-      xa[b] = *reinterpret_cast<const h16x8*>(sA + cur * A_BYTES + (a_row + b * 16) * 64 + swz_r * 16);
-#pragma unroll
-    for (int a = 0; a < NF; ++a)
-      wb[a] = *reinterpret_cast<const h16x8*>(sB + cur * B_BYTES + (b_row + a * 16) * 64 + swz_r * 16);
-#pragma unroll
-    for (int a = 0; a < NF; ++a)
-#pragma unroll
-      for (int b = 0; b < MF; ++b)
-        acc[a][b] = CVHIP_MFMA_16X16X32(wb[a], xa[b], acc[a][b], 0, 0, 0);
-  };
-
-  // prologue: tiles 0,1 -> registers; tile 0 -> LDS[0]; tile 2 -> registers. Loads/stores are issued
-  // unconditionally (tiles past nk decode to tap_ok == false: masked, zero) so the loop body is straight-line code.
-  load_tile(0, ra0, rb0, msk0);
-  load_tile(1, ra1, rb1, msk1);
-  store_tile(0, ra0, rb0, msk0);
-  load_tile(2, ra0, rb0, msk0);
-  __syncthreads();
-  // step kt: [tile kt+1: registers -> LDS[nxt]] [issue tile kt+3 -> the freed registers] [MFMA on LDS[cur]] barrier
-  for (int kt = 0; kt < nk; kt += 2) {
-    store_tile(1, ra1, rb1, msk1);
-    load_tile(kt + 3, ra1, rb1, msk1);
-    compute(0);
-    __syncthreads();
-    if (kt + 1 >= nk) break;
-    store_tile(0, ra0, rb0, msk0);
-    load_tile(kt + 4, ra0, rb0, msk0);
-    compute(1);
-    __syncthreads();
-  }
-
-  // ---- epilogue: lane holds D'[n = 4*(lane>>4)+r][m = lane&15] per fragment --------------------
-  const int nq = (lane >> 4) * 4;
-#pragma unroll
-  for (int b = 0; b < MF; ++b) {
-    const int m = m0 + wm * WM + b * 16 + (lane & 15);
-    if (m >= M) continue;
-    const int n_img = m / OHWi;
-    const int rem = m - n_img * OHWi;
-    const int oh = rem / OWi;
-    const int ow = rem - oh * OWi;
-    const int64_t opix = ((int64_t)n_img * p.OH + (oh * p.out_sh + cl.out_oh)) * p.OW + (ow * p.out_sw + cl.out_ow);
-    h16_t* yrow = p.y + opix * p.y_ld;
-#pragma unroll
-    for (int a = 0; a < NF; ++a) {
-      const int n = n0 + wn * WN + a * 16 + nq;
-      if (n >= p.Nout) continue;
-      float v0 = acc[a][b][0], v1 = acc[a][b][1], v2 = acc[a][b][2], v3 = acc[a][b][3];
-      if (p.bias) {
-        if (n < p.bias_n) v0 += p.bias[n];
-        if (n + 1 < p.bias_n) v1 += p.bias[n + 1];
-        if (n + 2 < p.bias_n) v2 += p.bias[n + 2];
-        if (n + 3 < p.bias_n) v3 += p.bias[n + 3];
-      }
-      if (p.y_vec_ok && n + 3 < p.Nout) {
-        uint2 u;
-        u.x = pack2(v0, v1);
-        u.y = pack2(v2, v3);
-        *reinterpret_cast<uint2*>(yrow + n) = u;
-      } else {
-        yrow[n] = (h16_t)v0;
-        if (n + 1 < p.Nout) yrow[n + 1] = (h16_t)v1;
-        if (n + 2 < p.Nout) yrow[n + 2] = (h16_t)v2;
-        if (n + 3 < p.Nout) yrow[n + 3] = (h16_t)v3;
-      }
-    }
-  }
-
-  // ---- optional BatchNorm statistics (sum, sum^2 of the fp32 accumulators) ----------------------
-  if (p.stats) {
-    float* red = reinterpret_cast<float*>(smem);  // [WAVES_M][BN][2]; tile buffers are dead now
-#pragma unroll
-    for (int a = 0; a < NF; ++a) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int b = 0; b < MF; ++b) {
-          const float v = acc[a][b][r];  // rows m >= M contributed zero A rows -> v == 0
-          s1 += v;
-          s2 += v * v;
-        }
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {
-          s1 += __shfl_xor(s1, off, 64);
-          s2 += __shfl_xor(s2, off, 64);
-        }
-        if ((lane & 15) == 0) {
-          const int nl = wn * WN + a * 16 + nq + r;
-          red[(wm * BN + nl) * 2 + 0] = s1;
-          red[(wm * BN + nl) * 2 + 1] = s2;
-        }
-      }
-    }
-    __syncthreads();
-    if (t < BN) {
-      const int n = n0 + t;
-      if (n < p.Nout) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < WAVES_M; ++w) {
-          s1 += red[(w * BN + t) * 2 + 0];
-          s2 += red[(w * BN + t) * 2 + 1];
-        }
-        if (p.stats_acc) {
-          acc_add2(reinterpret_cast<double*>(p.stats), mtile, p.stats_ld, n, s1, s2);
-        } else {
-          float* dst = p.stats + (int64_t)mtile * 2 * p.Nout;
-          dst[n] = s1;
-          dst[p.Nout + n] = s2;
-        }
-      }
-    }
-  }
-}
+// (The register-staged v1 kernel of round 1 and the measured-and-rejected launch forms — 64-deep ring slots, 8-wave blocks, wave
+// specialisation, chunk-major K order, the ablation instances — left the product library in round 6: git history and DESIGN.md 4.0 keep
+// their measurements.)
 
 // =====================================================================================================
 // v2: the same implicit GEMM with LDS-DMA staging (global_load_lds_dwordx4: HBM/L2 -> LDS without a VGPR hop and
@@ -1035,101 +785,12 @@ __global__ __launch_bounds__(NW * 64, WS ? 2 : igemm_min_waves(BM, BN, BK, NST, 
 
 // ---- host side ----------------------------------------------------------------------------------
 
-static int ablate_mode() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CVHIP_IGEMM_ABLATE");
-    v = (e && e[0] >= '1' && e[0] <= '6') ? e[0] - '0' : 0;
-  }
-  return v;
-}
-
-// LDS ring depth policy (CVHIP_IGEMM_NST2): 0 = 3-deep everywhere, 1 = 2-deep for the narrow-output configurations (default:
-// measured -0.6 ms/step on YOLOv5-s, they are bandwidth/latency-bound and gain from twice the resident blocks), 2 = also the
-// 128x128 configuration, 3 = all configurations
-static int nst2_level() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CVHIP_IGEMM_NST2");
-    v = e ? atoi(e) : 1;
-  }
-  return v;
-}
-
-// CVHIP_IGEMM_BK64: 0 = 32-deep ring slots, 1 = 64-deep slots with a 2-deep ring, 2 = 64-deep slots with a 3-deep ring
-static int bk64_level() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CVHIP_IGEMM_BK64");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
-}
-
-// CVHIP_IGEMM_FAST=0 restores per-step tap decoding for every shape (A/B switch; default on)
-static bool fast_staging() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CVHIP_IGEMM_FAST");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v == 1;
-}
-
-static int w8_level() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CVHIP_IGEMM_W8");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
-}
-
-static int staged_epilogue() {  // CVHIP_IGEMM_STAGED=0 restores the direct fragment-layout stores
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CVHIP_IGEMM_STAGED");
-    v = e ? atoi(e) : 1;
-  }
-  return v;
-}
-
-static int ord_level() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CVHIP_IGEMM_ORD");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
-}
-
-static int ws_level() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CVHIP_IGEMM_WS");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
-}
-
-static bool use_v1() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CVHIP_IGEMM_V1");
-    v = (e && e[0] == '1') ? 1 : 0;
-  }
-  return v == 1;
-}
-
-static bool interleave_classes() {  // CVHIP_IGEMM_INTERLEAVE=0 restores class-major tile order
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CVHIP_IGEMM_INTERLEAVE");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v == 1;
-}
-
+// Launch policy (every value below was an A/B switch while it was being measured; DESIGN.md 4.0 / 4.00 hold the numbers):
+//   * LDS ring depth: 2-deep for the narrow-output configurations (BN <= 64: bandwidth / latency-bound, twice the resident blocks:
+//     -0.6 ms per YOLOv5-s step), 3-deep elsewhere;
+//   * FAST staging (running DMA pointers, one tap decode per tap) wherever Cin % 32 == 0;
+//   * staged epilogue (output tile through the LDS, 16-byte row stores);
+//   * stride-parity classes of one spatial tile get consecutive tile ids (the half-line writes of interleaved pixels merge in one L2).
 template <int BM, int BN, int WM, int WN>
 static int launch_group(IgemmKernArgs& p, hipStream_t stream) {
   int total = 0;
@@ -1139,117 +800,25 @@ static int launch_group(IgemmKernArgs& p, hipStream_t stream) {
   }
   p.total_tiles = total;
   if (total == 0) return CVHIP_OK;
-  p.staged_epilogue = staged_epilogue();
+  p.staged_epilogue = 1;
   p.interleave = 0;
-  if (p.ncls > 1 && interleave_classes() && !use_v1()) {
+  if (p.ncls > 1) {
     bool same = true;
     for (int i = 1; i < p.ncls; ++i) same = same && cdiv(p.cls[i].M, BM) == cdiv(p.cls[0].M, BM);
     p.interleave = same ? 1 : 0;
   }
+  constexpr bool nst2 = BN <= 64;
+  constexpr int NST = nst2 ? 2 : 3;
+  const bool fast = p.Cin % 32 == 0 && p.Cin <= kFastMaxCin;
   if (p.ep_scale || p.ep_act != CVHIP_ACT_NONE) {
-    // fused epilogue: the EPI instances of the default forms (32-deep slots; FAST staging when Cin % 32 == 0)
+    // fused epilogue: the EPI instances of the same forms
     if (p.tail_y) return CVHIP_ERR_INVALID;
-    const bool nst2 = (BN <= 64 && nst2_level() >= 1) || (BM == 128 && nst2_level() >= 2) || nst2_level() >= 3;
-    const bool fast = fast_staging() && p.Cin % 32 == 0 && p.Cin <= kFastMaxCin;
-    if (fast && nst2) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 2, 32, true, 4, false, 0, true>), dim3(total), dim3(256), 0, stream, p);
-    else if (fast) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 3, 32, true, 4, false, 0, true>), dim3(total), dim3(256), 0, stream, p);
-    else if (nst2) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 2, 32, false, 4, false, 0, true>), dim3(total), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 3, 32, false, 4, false, 0, true>), dim3(total), dim3(256), 0, stream, p);
+    if (fast) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, NST, 32, true, 4, false, 0, true>), dim3(total), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, NST, 32, false, 4, false, 0, true>), dim3(total), dim3(256), 0, stream, p);
     return check_launch("igemm_kernel(fused epilogue)");
   }
-  if constexpr (WM == 64 && BM >= 128 && (BM != 128 || BN == 128)) {
-    if (use_v1()) {
-      if (p.res || p.tail_y || p.ep_scale || p.ep_act != CVHIP_ACT_NONE) return CVHIP_ERR_UNSUPPORTED;
-      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), dim3(total), dim3(256), 0, stream, p);
-      return check_launch("igemm_kernel");
-    }
-  }
-  if (bk64_level() > 0 && ablate_mode() == 0 && !(fast_staging() && p.Cin % 64 == 0 && p.Cin <= kFastMaxCin)) {
-    // BK = 64 ring slots (full 128-byte lines per DMA row): level 1 = 2-deep ring, 2 = 3-deep ring
-    if (bk64_level() >= 2) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 3, 64>), dim3(total), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 2, 64>), dim3(total), dim3(256), 0, stream, p);
-    return check_launch("igemm_kernel(bk64)");
-  }
-  const bool nst2 = (BN <= 64 && nst2_level() >= 1) || (BM == 128 && nst2_level() >= 2) || nst2_level() >= 3;
-  if (ablate_mode() == 3) {
-    if (p.Cin % 32 != 0 || p.Cin > kFastMaxCin) return CVHIP_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 3, 2, 32, true>), dim3(total), dim3(256), 0, stream, p);
-    return check_launch("igemm_kernel(abl3)");
-  }
-  if ((ablate_mode() == 0 || (ws_level() >= 1 && ablate_mode() <= 2)) && fast_staging() && p.Cin % 32 == 0 && p.Cin <= kFastMaxCin) {
-    // FAST staging. Ring slot depth: 32 (64-byte LDS rows: a DMA instruction fetches 16 HALF cache lines) or, when Cin % 64 == 0
-    // and CVHIP_IGEMM_BK64 asks for it, 64 (8 FULL lines per instruction: profiles/r03_ceilings_probe.log measures the
-    // L2 -> LDS path at 28-35 B/clk/CU for half-line rows against 47-55 for full lines). 8-wave blocks: CVHIP_IGEMM_W8.
-    const bool bk64 = bk64_level() > 0 && p.Cin % 64 == 0;
-    const bool three = bk64 ? bk64_level() >= 2 : !nst2;
-    if constexpr (BM == 256 && BN == 128 && WM == 128) {
-      // wave-specialised form of the 256x128 tile (CVHIP_IGEMM_WS: 1 = 64-deep slots when Cin % 64 == 0, 2 = also 32-deep slots)
-      if (ws_level() >= 1 && p.Cin % 64 == 0 && ablate_mode() == 1) {
-        hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 1, 3, 64, true, 8, true>), dim3(total), dim3(512), 0, stream, p);
-        return check_launch("igemm_kernel(ws abl1)");
-      }
-      if (ws_level() >= 1 && p.Cin % 64 == 0 && ablate_mode() == 2) {
-        hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 2, 3, 64, true, 8, true>), dim3(total), dim3(512), 0, stream, p);
-        return check_launch("igemm_kernel(ws abl2)");
-      }
-      if (ws_level() >= 1 && p.Cin % 64 == 0) {
-        hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 3, 64, true, 8, true>), dim3(total), dim3(512), 0, stream, p);
-        return check_launch("igemm_kernel(wave-specialised, 64-deep)");
-      }
-      if (ws_level() >= 2) {
-        hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 3, 32, true, 8, true>), dim3(total), dim3(512), 0, stream, p);
-        return check_launch("igemm_kernel(wave-specialised, 32-deep)");
-      }
-    }
-    bool w8 = false;
-    if constexpr (BM == 256 && BN >= 64 && WM >= 64) w8 = w8_level() >= (BN == 128 ? 1 : 2);
-    if constexpr (BM == 256 && BN >= 64 && WM >= 64) {
-      constexpr int WM8 = WM == 128 ? 64 : 32;  // 256x128: 4(M) x 2(N) waves of 64x64; 256x64: 8(M) x 1(N) waves of 32x64
-      if (w8) {
-        if (bk64) {
-          if (three) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM8, WN, 0, 3, 64, true, 8>), dim3(total), dim3(512), 0, stream, p);
-          else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM8, WN, 0, 2, 64, true, 8>), dim3(total), dim3(512), 0, stream, p);
-        } else {
-          if (three) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM8, WN, 0, 3, 32, true, 8>), dim3(total), dim3(512), 0, stream, p);
-          else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM8, WN, 0, 2, 32, true, 8>), dim3(total), dim3(512), 0, stream, p);
-        }
-        return check_launch("igemm_kernel(fast, 8 waves)");
-      }
-    }
-    bool taps32 = true;
-    for (int i = 0; i < p.ncls; ++i) taps32 = taps32 && p.cls[i].TR * p.cls[i].TS <= 32;
-    if (ord_level() >= 1 && taps32 && !bk64) {  // chunk-major K order (CVHIP_IGEMM_ORD)
-      if (three) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 3, 32, true, 4, false, 1>), dim3(total), dim3(256), 0, stream, p);
-      else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 2, 32, true, 4, false, 1>), dim3(total), dim3(256), 0, stream, p);
-      return check_launch("igemm_kernel(fast, chunk-major)");
-    }
-    if (ord_level() >= 1 && taps32 && bk64) {
-      if (three) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 3, 64, true, 4, false, 1>), dim3(total), dim3(256), 0, stream, p);
-      else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 2, 64, true, 4, false, 1>), dim3(total), dim3(256), 0, stream, p);
-      return check_launch("igemm_kernel(fast, chunk-major, 64-deep)");
-    }
-    if (bk64) {
-      if (three) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 3, 64, true>), dim3(total), dim3(256), 0, stream, p);
-      else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 2, 64, true>), dim3(total), dim3(256), 0, stream, p);
-    } else {
-      if (three) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 3, 32, true>), dim3(total), dim3(256), 0, stream, p);
-      else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 2, 32, true>), dim3(total), dim3(256), 0, stream, p);
-    }
-    return check_launch("igemm_kernel(fast)");
-  }
-  if ((ablate_mode() == 1 || ablate_mode() == 2 || ablate_mode() >= 4) && fast_staging() && p.Cin % 32 == 0 && p.Cin <= kFastMaxCin && !nst2) {
-    // the ablations of the FAST 3-deep-ring form (what the large layers run): 1 = staging only, 2 = fragment reads + MFMA only
-    if (ablate_mode() == 1) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 1, 3, 32, true>), dim3(total), dim3(256), 0, stream, p);
-    else if (ablate_mode() == 4) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 4, 3, 32, true>), dim3(total), dim3(256), 0, stream, p);
-    else if (ablate_mode() == 5) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 5, 3, 32, true>), dim3(total), dim3(256), 0, stream, p);
-    else if (ablate_mode() == 6) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 6, 3, 32, true>), dim3(total), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 2, 3, 32, true>), dim3(total), dim3(256), 0, stream, p);
-    return check_launch("igemm_kernel(fast ablation)");
-  }
-  if (ablate_mode() == 1) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 1>), dim3(total), dim3(256), 0, stream, p);
-  else if (ablate_mode() == 2) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 2>), dim3(total), dim3(256), 0, stream, p);
-  else if (nst2) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, 2>), dim3(total), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN>), dim3(total), dim3(256), 0, stream, p);
+  if (fast) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, NST, 32, true>), dim3(total), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, NST>), dim3(total), dim3(256), 0, stream, p);
   return check_launch("igemm_kernel");
 }
 
@@ -1277,27 +846,8 @@ static int launch_cfg(IgemmParams& p, hipStream_t stream) {
 // reads per MFMA drop by 25 % (12 ds_read_b128 per 32 MFMAs instead of 8 per 16) and global->LDS bytes per flop by 25 %
 // — the two limits profiles/r01_igemm_ablation.log and r01_lds_read_bw_probe.log measure. Small problems keep 128x128
 // so the grid still covers the 256 CUs.
-static bool big_tile_disabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CVHIP_IGEMM_NO256");
-    v = (e && e[0] == '1') ? 1 : 0;
-  }
-  return v == 1;
-}
-
-static bool narrow128() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CVHIP_IGEMM_NARROW128");
-    v = (e && e[0] == '1') ? 1 : 0;
-  }
-  return v == 1;
-}
-
 int igemm_block_m(int Nout, int64_t M, int Ktot) {
-  if (Nout <= 64) return (narrow128() && !use_v1()) ? 128 : 256;
-  if (use_v1() || big_tile_disabled()) return 128;
+  if (Nout <= 64) return 256;
   // shallow reductions (1x1 convs with < 512 input channels) are memory-bound: more, smaller blocks hide latency better
   // (measured per shape: gpurun conv_table A/B)
   if (Ktot < 512) return 128;
@@ -1317,10 +867,6 @@ int launch_igemm(IgemmParams& p, hipStream_t stream) {
   const int s2 = try_launch_patch(p, stream);  // multi-tap, Cin % 32 == 0: patch-resident implicit GEMM (conv_patch.hip)
   if (s2 != -1) return s2;
   if (p.pro_scale || p.z_out || p.y2) return CVHIP_ERR_UNSUPPORTED;  // a prologue: patch / streaming kernels only; a split store: streaming kernel only
-  if (narrow128() && !use_v1()) {
-    if (p.Nout <= 32) return launch_cfg<128, 32, 32, 32>(p, stream);
-    if (p.Nout <= 64) return launch_cfg<128, 64, 32, 64>(p, stream);
-  }
   if (p.Nout <= 32) return launch_cfg<256, 32, 64, 32>(p, stream);
   if (p.Nout <= 64) return launch_cfg<256, 64, 64, 64>(p, stream);
   int64_t M = 0;
