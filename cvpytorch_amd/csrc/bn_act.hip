@@ -15,12 +15,7 @@ constexpr int kRedRowsPerBlockMin = 64;
 
 static inline int colreduce_rows_host(int64_t M, int32_t C) {
   (void)C;
-  static int min_rows = -1;
-  if (min_rows < 0) {
-    const char* e = getenv("CVHIP_RED_MINROWS");  // rows per block of the streaming reductions (A/B switch)
-    min_rows = e ? atoi(e) : kRedRowsPerBlockMin;
-    if (min_rows < 1) min_rows = kRedRowsPerBlockMin;
-  }
+  const int min_rows = kRedRowsPerBlockMin;
   int64_t b = cdiv64(M, min_rows);
   if (b > kRedBlocksMax) b = kRedBlocksMax;
   if (b < 1) b = 1;
@@ -227,15 +222,7 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restric
 }
 
 // returns the (possibly pre-reduced) partial pointer and updates *rows
-static int direct_rows() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CVHIP_FINALIZE_DIRECT_ROWS");
-    v = e ? atoi(e) : kDirectRows;
-    if (v < kStage2Rows) v = kStage2Rows;
-  }
-  return v;
-}
+static int direct_rows() { return kDirectRows; }
 
 static const float* prereduce(const float* partial, int* rows, int Wd, hipStream_t s) {
   if (*rows <= direct_rows()) return partial;  // few enough rows for the 16-lane finalize kernels (4 independent chains per lane)
@@ -456,11 +443,7 @@ __global__ __launch_bounds__(256) void rows_reduce_fin_kernel(const float* __res
 
 // launch the fused form; false when it does not apply (few rows: the plain finalize kernels need no pre-reduction)
 static bool launch_fused_finalize(const float* partial, int rows, int C, const FinParams& fp, hipStream_t s) {
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("CVHIP_FUSED_FINALIZE");
-    on = (e && e[0] == '1') ? 1 : 0;
-  }
+  constexpr bool on = false;   // (pre-reduction + finalize in one launch: built in round 2, measured no faster than the two launches)
   if (!on || rows <= kStage2Rows || cdiv(C, 32) > 256) return false;
   float* scratch = const_cast<float*>(partial) + (int64_t)rows * 2 * C;
   hipLaunchKernelGGL(rows_reduce_fin_kernel, dim3(cdiv(C, 32), kStage2Rows), dim3(256), 0, s, partial, rows, C, scratch, fp);
@@ -749,15 +732,7 @@ __global__ __launch_bounds__(256) void bn_finalize_acc_kernel(const double* acc,
     default: hipLaunchKernelGGL((KERNEL<MODE, CVHIP_ACT_NONE>), GRID, dim3(256), 0, STREAM, PARAMS); break;                   \
   }
 
-static int ew_rows_per_thread() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CVHIP_EW_ROWS");
-    v = e ? atoi(e) : 16;
-    if (v < 1) v = 16;
-  }
-  return v;
-}
+static int ew_rows_per_thread() { return 16; }   // (4 / 8 rows per thread lose 0.1-0.6 ms per step to the per-block prologue: profiles/r04_ew_grid_ab.log)
 
 static inline int ew_grid(int64_t M, int C) {
   const int CV = (C + 7) / 8;

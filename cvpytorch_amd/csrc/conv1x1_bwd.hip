@@ -447,14 +447,7 @@ static int bwd1x1_mode() {  // CVHIP_BWD1X1: 0 = never (three-pass backward), 1 
   return v;
 }
 
-static int bwd1x1_k256() {  // CVHIP_BWD1X1_K256=0: K = 256 layers back on the three-pass backward (A/B switch)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CVHIP_BWD1X1_K256");
-    v = e ? atoi(e) : 1;
-  }
-  return v;
-}
+static int bwd1x1_k256() { return 1; }   // K = 256 layers take the fused kernel (31.50 -> 31.02 ms per DeepLabv3+ step, profiles/r04_bwd1x1_k256_ab.log)
 
 static int bwd1x1_cb(int C) { return (C % 128 == 0) ? 128 : (C % 64 == 0) ? 64 : (C % 32 == 0) ? 32 : 0; }
 
@@ -515,13 +508,7 @@ int launch_bwd1x1(Bwd1x1Params& p, hipStream_t s) {
   p.ntiles = (p.M + 63) / 64;
   // persistent grid: <= 2 blocks per CU, >= 16 trips per block (the dW flush costs K*C atomics per block; A/B on the 80x80
   // layers: 16 trips 101 us, 8 trips 110 us, <= 256 blocks 122 us)
-  static int max_blocks = -1, min_trips = -1;
-  if (max_blocks < 0) {
-    const char* e = getenv("CVHIP_BWD1X1_BLOCKS");
-    max_blocks = e ? atoi(e) : 512;
-    const char* f = getenv("CVHIP_BWD1X1_MINTRIPS");
-    min_trips = f ? atoi(f) : 16;
-  }
+  const int max_blocks = 512, min_trips = 16;
   const int cb = bwd1x1_cb(p.C);
   const int slices = p.C / cb;
   int cap = max_blocks / slices;

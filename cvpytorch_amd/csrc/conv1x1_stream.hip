@@ -409,12 +409,7 @@ int stream1x1_blocks(int Nout, int Cin, int64_t M, bool stats) {
     // layers; with larger operands DeepLabv3+ lost 7 % end to end)
     if (Nout > bn && (Nout > 4 * bn || stats || (double)M * Cin * 2.0 > 64e6)) return 0;
   }
-  static int max_blocks = -1;
-  if (max_blocks < 0) {
-    const char* e = getenv("CVHIP_S1X1_MAXBLOCKS");  // A/B switch of the persistent grid's size
-    max_blocks = e ? atoi(e) : kS1MaxBlocks;
-    if (max_blocks < 64) max_blocks = kS1MaxBlocks;
-  }
+  const int max_blocks = kS1MaxBlocks;   // (768 / 1024-block grids: measured, slower — DESIGN.md 4.00)
   const int rounds = cdiv(ntiles, max_blocks);
   return cdiv(ntiles, rounds);  // balanced: every block walks `rounds` (or rounds-1) tiles
 }

@@ -58,8 +58,6 @@ namespace cvhip {
 constexpr int kBandSteps = 9;        // 3 x 3 taps per chunk
 constexpr int kBandPieceSteps = 6;   // the next chunk's patch DMAs go out in the first six K steps of a chunk
 constexpr int kBandLdsMax = 156 * 1024;
-constexpr int kBandWidePF = 4;                // wide-wave form with LDS prefetch: fragments read one step ahead (register budget)
-constexpr int kBandPrefetchDefault = 0;      // 7-fragment forms: LDS reads one K step ahead (CVHIP_BAND_PF overrides)
 
 struct BandArgs {
   const h16_t* x;
@@ -510,7 +508,7 @@ static bool band_fit(const IgemmParams& p, int NF, int cap, int NW, int EH, int 
   const int n_tiles = p.Nout / BN;
   int best_th = 0, best_nplw = 0;
   int64_t best_cost = -1;
-  const int eth = band_env("CVHIP_BAND_TH", 0);  // dev: force the band height
+  constexpr int eth = 0;
   for (int TH = 1; TH <= p.OH; ++TH) {
     if (eth > 0 && TH != eth) continue;
     const int frags = (TH * p.OW + 15) / 16;
@@ -554,13 +552,13 @@ static bool band_plan_nw(const IgemmParams& p, int NW, BandPlan* pl, bool* polic
   const int PW = (p.OW - 1 + EW + 7) & ~7;
   const int NC = p.Cin / 32;
   const int n_tiles = p.Nout / BN;
-  // CVHIP_BAND_NF (read per launch): 2 = narrow waves (32 channels x <= 13 pixel fragments), 4 = wide waves (64 channels x <= 7 pixel
-  // fragments) wherever the tile is 64 or 128 channels wide and the geometry fits (narrow elsewhere), 0 = default (narrow: below)
-  const int want_nf = band_env("CVHIP_BAND_NF", 0);
+  // Narrow waves (32 channels x <= 13 pixel fragments). The wide-wave form (64 channels x 7 fragments) and the hand-counted LDS read-ahead
+  // were measured in round 5 (profiles/r05_band_forms_bench.log: never ahead once the band image exists) and are no longer instantiated;
+  // the kernel template keeps their code paths (NF = 4, PF > 0) for the record.
   int th2 = 0, np2 = 0, th4 = 0, np4 = 0;
-  int64_t rounds2 = 0, rounds4 = 0;
-  const bool fit4 = want_nf == 4 && band_fit(p, 4, 7, NW, EH, PW, &th4, &np4, &rounds4);
-  const bool fit2 = !fit4 && band_fit(p, 2, 13, NW, EH, PW, &th2, &np2, &rounds2);
+  int64_t rounds2 = 0;
+  const bool fit4 = false;
+  const bool fit2 = band_fit(p, 2, 13, NW, EH, PW, &th2, &np2, &rounds2);
   if (!fit2 && !fit4) return false;
   const bool wide = fit4;
   const int NF = wide ? 4 : 2;
@@ -603,8 +601,7 @@ static bool band_plan_nw(const IgemmParams& p, int NW, BandPlan* pl, bool* polic
   pl->NF = NF;
   pl->MFW = NF == 4 ? 7 : band_mfw(per_wave);
   pl->PPS = best_nplw <= kBandPieceSteps ? 1 : 2;
-  // CVHIP_BAND_PF (read per launch): 1 = the 7-fragment forms read the next K step's pixel fragments one step ahead, 0 = not
-  pl->PF = (pl->MFW == 7 && band_env("CVHIP_BAND_PF", kBandPrefetchDefault)) ? (NF == 4 ? kBandWidePF : 7) : 0;
+  pl->PF = 0;
   a.dummy_off = (NC > 1 ? 2 : 1) * a.buf_bytes;
   pl->NW = NW;
   pl->lds = band_imax(a.dummy_off + 1024, WM * BN * 2 * (int)sizeof(float));
@@ -670,10 +667,7 @@ static int band_launch(const BandPlan& pl, hipStream_t stream) {
 template <int WN, int NW>
 static int band_launch_narrow(const BandPlan& pl, hipStream_t stream) {  // NF = 2: 32 channels per wave
   if constexpr (WN <= NW) {
-    if (pl.MFW == 7) {
-      if (pl.PF) return pl.PPS == 1 ? band_launch<WN, 7, 1, 2, 2, 7, NW>(pl, stream) : band_launch<WN, 7, 2, 2, 2, 7, NW>(pl, stream);
-      return pl.PPS == 1 ? band_launch<WN, 7, 1, 2, 2, 0, NW>(pl, stream) : band_launch<WN, 7, 2, 2, 2, 0, NW>(pl, stream);
-    }
+    if (pl.MFW == 7) return pl.PPS == 1 ? band_launch<WN, 7, 1, 2, 2, 0, NW>(pl, stream) : band_launch<WN, 7, 2, 2, 2, 0, NW>(pl, stream);
     if (pl.MFW == 10) return pl.PPS == 1 ? band_launch<WN, 10, 1, 2, 2, 0, NW>(pl, stream) : band_launch<WN, 10, 2, 2, 2, 0, NW>(pl, stream);
     return pl.PPS == 1 ? band_launch<WN, 13, 1, 2, 2, 0, NW>(pl, stream) : band_launch<WN, 13, 2, 2, 2, 0, NW>(pl, stream);
   } else {
@@ -681,15 +675,8 @@ static int band_launch_narrow(const BandPlan& pl, hipStream_t stream) {  // NF =
   }
 }
 
-template <int WN, int NW>
-static int band_launch_wide(const BandPlan& pl, hipStream_t stream) {  // NF = 4: 64 channels x 7 pixel fragments per wave
-  if (pl.PF) return pl.PPS == 1 ? band_launch<WN, 7, 1, 4, 1, kBandWidePF, NW>(pl, stream) : band_launch<WN, 7, 2, 4, 1, kBandWidePF, NW>(pl, stream);
-  return pl.PPS == 1 ? band_launch<WN, 7, 1, 4, 1, 0, NW>(pl, stream) : band_launch<WN, 7, 2, 4, 1, 0, NW>(pl, stream);
-}
-
 template <int NW>
 static int band_launch_nw(const BandPlan& pl, hipStream_t stream) {
-  if (pl.NF == 4) return pl.WN == 2 ? band_launch_wide<2, NW>(pl, stream) : band_launch_wide<1, NW>(pl, stream);
   if (pl.WN == 4) return band_launch_narrow<4, NW>(pl, stream);
   if (pl.WN == 2) return band_launch_narrow<2, NW>(pl, stream);
   return band_launch_narrow<1, NW>(pl, stream);

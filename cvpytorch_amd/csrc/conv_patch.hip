@@ -636,10 +636,6 @@ static int patch_mode() {  // CVHIP_PATCH: 0 = never (the per-tap implicit GEMM 
   const char* e = getenv("CVHIP_PATCH");  // read per call (host-side, once per launch / plan query): the tests switch it
   return e ? atoi(e) : 1;
 }
-static int patch_env(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
 
 static inline int imin(int a, int b) { return a < b ? a : b; }
 static inline int imax(int a, int b) { return a > b ? a : b; }
@@ -795,18 +791,12 @@ static bool patch_plan(const IgemmParams& p, PatchPlan* pl, bool any_geometry = 
 
 template <int BN, int CK, int PRO, int ACT>
 static int patch_launch_cfg(const PatchArgs& a, hipStream_t stream) {
-  // CVHIP_PATCH_TPS (read per launch: in-process A/B): taps per K step. 2 = 64-deep steps with a 2-deep ring of 2-tap slots
-  // (same 80 KB of LDS: two blocks per CU; no room for the prologue's constants, so PRO = 1 keeps 1-tap steps)
+  // taps per K step: 2 = 64-deep steps with a 2-deep ring of 2-tap slots (half the barriers; same 80 KB of LDS: two blocks per CU). The
+  // prologue form has no room for its constants beside that ring and keeps 1-tap steps with a 3-deep ring.
   const dim3 grid(a.total_tiles), block(kPatchThreads);
   if constexpr (PRO == 0) {
-    if (patch_env("CVHIP_PATCH_TPS", 2) == 2) {
-      hipLaunchKernelGGL((conv_patch_kernel<BN, CK, PRO, ACT, 2, 2, 2>), grid, block, 0, stream, a);
-      return check_launch("conv_patch_kernel(tps2)");
-    }
-    if (patch_env("CVHIP_PATCH_NST", 3) == 2) {
-      hipLaunchKernelGGL((conv_patch_kernel<BN, CK, PRO, ACT, 2, 2, 1>), grid, block, 0, stream, a);
-      return check_launch("conv_patch_kernel(nst2)");
-    }
+    hipLaunchKernelGGL((conv_patch_kernel<BN, CK, PRO, ACT, 2, 2, 2>), grid, block, 0, stream, a);
+    return check_launch("conv_patch_kernel(tps2)");
   }
   hipLaunchKernelGGL((conv_patch_kernel<BN, CK, PRO, ACT, 2, 3, 1>), grid, block, 0, stream, a);
   return check_launch("conv_patch_kernel");

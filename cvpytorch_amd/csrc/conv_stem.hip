@@ -35,14 +35,7 @@ constexpr int kStemBlocks = 768;   // persistent grid (3 blocks per CU by LDS)
 // the Infinity Cache, they are not what these (latency-bound, 3.3 TB/s) kernels wait for. An LDS row ring across vertically
 // consecutive tiles would remove the same bytes and was therefore not built.
 __device__ __forceinline__ int stem_first_tile(int xcd) { return xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x; }
-static int stem_xcd_mode() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CVHIP_STEM_XCD");
-    v = (e && e[0] == '1') ? 1 : 0;
-  }
-  return v;
-}
+static int stem_xcd_mode() { return 0; }   // (XCD-contiguous tile chunks: measured, no gain — DESIGN.md 4.000 "Stem halo")
 
 struct StemParams {
   const h16_t* x;
@@ -631,12 +624,7 @@ int stem_blocks(int C, int x_ld, int K, int R, int S, int sh, int sw, int dh, in
   if (nstep != 1 && nstep != 2 && nstep != 3 && nstep != 7 && nstep != 9 && nstep != 13) return 0;  // instantiated step counts
   const int64_t tiles = (int64_t)N * cdiv(OH, kStemTH) * cdiv(OW, kStemTW);
   if (tiles < 512 || tiles >= (1ll << 31)) return 0;  // small problems: the general kernel (and its tests) stay in charge
-  static int cap = -1;
-  if (cap < 0) {
-    const char* e = getenv("CVHIP_STEM_BLOCKS");  // A/B switch of the persistent grid
-    cap = e ? atoi(e) : kStemBlocks;
-    if (cap < 64) cap = kStemBlocks;
-  }
+  const int cap = kStemBlocks;
   return (int)(tiles < cap ? tiles : cap);
 }
 
@@ -746,12 +734,7 @@ int try_launch_stem_wgrad(const cvhip_conv_desc* d, const void* x, const void* d
     // persistent grid larger than the resident slots would run its last third after everything else. Measured on the YOLOv5-s stem
     // (profiles/r05_stem_bn_*): 768 blocks 423 us, 512 blocks 354 us, 256 blocks 577 us; forcing three blocks per CU
     // (__launch_bounds__(256, 3): 168 VGPRs + 68 B of scratch) 436 us — against 215 us (plain) + 217 us (the apply pass it replaces)
-    static int cap = -1;
-    if (cap < 0) {
-      const char* e = getenv("CVHIP_STEM_BN_BLOCKS");
-      cap = e ? atoi(e) : 512;
-      if (cap < 64) cap = 512;
-    }
+    const int cap = 512;
     if (grid > cap) grid = cap;
   }
 #define CVHIP_STEMW_CASE(NF)                                                                                          \

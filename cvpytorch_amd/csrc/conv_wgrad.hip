@@ -29,9 +29,8 @@ struct WgradParams {
   int Ktot, M;
   int n_tiles, k_tiles, m_per_split;
   unsigned ohw_mul, ohw_sh, ow_mul, ow_sh;  // fast_div31 constants of OHi*OWi and OWi
-  int ablate;  // CVHIP_WGRAD_ABLATE: 1 = skip the atomic epilogue, 2 = atomics into per-split scratch, 3 = plain stores into it
-               // (3 is also the DETERMINISTIC mode: every pixel split stores its partial tile into its own slab of the caller's
-               // workspace and wgrad_fold_kernel adds the slabs in split order — no floating-point atomics anywhere)
+  int ablate;  // 0 = fp32 atomics into dW; 3 = the DETERMINISTIC mode: every pixel split stores its partial tile into its own slab of the
+               // caller's workspace and wgrad_fold_kernel adds the slabs in split order — no floating-point atomics anywhere
   float* scratch;
   int64_t split_stride;
   float* det_ws;      // deterministic mode: caller's workspace (>= splits * Nout * Ktot floats), else NULL
@@ -114,7 +113,7 @@ __device__ __forceinline__ h16x8 tr_read8(const unsigned char* p0, const unsigne
 // less than the load latency under load: the waves sat in s_waitcnt for 41-59 % of their cycles (profiles/r02_sq_step_summary.txt).
 // Loads are unconditional (masked lanes read the tensor's first bytes and are zeroed on the way into the LDS), so hipcc emits
 // counted vmcnt waits and the younger steps stay in flight across the store of the oldest one.
-// ABL (profiling builds of the same kernel, CVHIP_WGRAD_ABLATE=4/5): 4 = no fragment reads / MFMAs (staging only), 5 = no global
+// ABL: always 0 in the library (profiling builds of round 2 / 3 used 4 = no fragment reads / MFMAs, 5 = no global
 // loads after the first step (LDS writes, fragment reads and MFMAs only)
 template <int TN, int WN, int WK, int kWgGroups, int PD = 3, int ABL = 0>
 // (launch bounds: PD 1 with a 128-VGPR cap — 4 blocks per CU instead of 3 — was measured in round 3: the 128-wide tile spills
@@ -352,8 +351,7 @@ __global__ __launch_bounds__(256 * kWgGroups, kWgGroups == 1 ? 2 : 1) void wgrad
     if (grp != 0) return;
   }
   // epilogue: lane holds D[n = 4*(lane>>4)+r][kcol = lane&15]
-  if (p.ablate == 1 && acc[0][0][0] != 12345.678f) return;
-  float* const dwp = p.ablate >= 2 ? p.scratch + (int64_t)split * p.split_stride : p.dw;
+  float* const dwp = p.ablate == 3 ? p.scratch + (int64_t)split * p.split_stride : p.dw;
 #pragma unroll
   for (int a = 0; a < NF; ++a) {
 #pragma unroll
@@ -372,265 +370,33 @@ __global__ __launch_bounds__(256 * kWgGroups, kWgGroups == 1 ? 2 : 1) void wgrad
   }
 }
 
-// =====================================================================================================================================
-// The same kernel with LDS-DMA staging (round 3). Both operand tiles go global -> LDS with global_load_lds_dwordx4 (no VGPR hop, no
-// ds_write pass, ~40 staging VGPRs less), NST ring slots of one 32-pixel step each, ONE raw s_barrier and a counted s_waitcnt vmcnt
-// per step: NST - 1 steps of operands are in flight while one is multiplied (the register-staged form kept 1-3). The LDS image is
-// the register form's (row-major [pixel][channel] tiles, 32-byte segments XOR-swizzled by the pixel row), so the fragment gathers
-// (ds_read_b64_tr_b16) and the epilogue are unchanged: a DMA instruction writes 1 KiB lane-linearly = RPP whole tile rows, and
-// every lane fetches the LOGICAL 16-byte chunk that belongs at its physical position (swizzle on the source side, rule 21). The
-// row a lane serves inside a piece and the XOR term of that row are lane constants, so a lane's (tap, channel) decode is done once.
-// Masked lanes (halo, rows past the slab, columns past Ktot) read a zero page, which keeps the DMA count per wave uniform.
-// =====================================================================================================================================
-__device__ __attribute__((aligned(64))) unsigned int g_wgrad_zero[16];
+// (The LDS-DMA staged variant of this kernel (round 3) left the library in round 6: hipcc drains an outstanding LDS-DMA before every
+// ds_read_b64_tr_b16 builtin it emits — conv_wgrad_band.hip has the measurement — so that form could never overlap staging with the
+// gathers; profiles/r03_wgrad_dma_ab.log holds its numbers.)
 
-#define CVHIP_WG_GLDS16(src, dst)                                                                               \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                       \
-                                   (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
-
-template <int TN, int WN, int WK, int kWgGroups, int NST>
-__global__ __launch_bounds__(256 * kWgGroups, kWgGroups == 1 ? 2 : 1) void wgrad_dma_kernel(const WgradParams p) {
-  constexpr int TK = 128;
-  constexpr int WAVES_K = TK / WK;
-  static_assert((TN / WN) * WAVES_K == 4, "4 waves per group");
-  constexpr int NF = WN / 16, KF = WK / 16;
-  constexpr int DV = TN / 8;            // 16-B chunks per dY row
-  constexpr int D_RPP = 64 / DV;        // dY rows per DMA instruction: 4 / 8 / 16
-  constexpr int D_PIECES = 32 / D_RPP;  // 8 / 4 / 2 per step
-  constexpr int D_ROWB = TN * 2;
-  constexpr int D_SEGM = TN / 16 - 1;
-  constexpr int X_ROWB = TK * 2;
-  constexpr int D_BYTES = 32 * D_ROWB, X_BYTES = 32 * X_ROWB;
-  constexpr int ST_BYTES = D_BYTES + X_BYTES;
-  constexpr int GROUP_BYTES = NST * ST_BYTES;
-  static_assert(kWgGroups == 1 || kWgGroups * GROUP_BYTES >= (kWgGroups / 2) * 4 * NF * KF * 4 * 64 * 4, "LDS must hold half the groups' accumulators for the fold");
-  constexpr int D_PW = D_PIECES >= 4 ? D_PIECES / 4 : 1;  // dY pieces per issuing wave (TN 32: only waves 0 and 1 issue one)
-  constexpr int PER_FULL = 2 + D_PW;                      // DMA instructions per step of a wave that stages dY
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[kWgGroups * GROUP_BYTES];
-  const int grp = threadIdx.x >> 8;
-  unsigned char* const ring = smem + grp * GROUP_BYTES;
-
-  const int t = threadIdx.x & 255, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wn = wave / WAVES_K, wk = wave % WAVES_K;
-
-  const int tiles = p.n_tiles * p.k_tiles;
-  const int lin = xcd_remap(blockIdx.x, gridDim.x);
-  const int split = lin / tiles;
-  const int tile = lin - split * tiles;
-  const int ntile = tile / p.k_tiles, ktile = tile - ntile * p.k_tiles;
-  const int n0 = ntile * TN, k0 = ktile * TK;
-  const int blk_begin = split * p.m_per_split;
-  const int blk_end = min(p.M, blk_begin + p.m_per_split);
-  if (blk_end <= blk_begin) return;
-  const int half = (((blk_end - blk_begin + kWgGroups - 1) / kWgGroups + 31) >> 5) << 5;
-  const int m_begin = blk_begin + grp * half;
-  const int m_end = min(blk_end, m_begin + half);
-  const int nsteps = half >> 5;
-  const int OHWi = p.OHi * p.OWi;
-  const h16_t* const zero = reinterpret_cast<const h16_t*>(g_wgrad_zero);
-
-  // ---- X staging geometry: wave w issues pieces 2w and 2w+1 (tile rows 8w .. 8w+7); lane = (row in piece, physical chunk) -------
-  const int x_r = lane >> 4, x_j = lane & 15;
-  const int x_h = x_r | ((wave & 1) << 2);                 // h(px) = (px & 3) | ((px >> 1) & 4) for px = 8w + 4i + x_r
-  const int xv = ((((x_j >> 1) ^ x_h) & 7) << 1) | (x_j & 1);  // the logical chunk that belongs at physical chunk x_j of that row
-  const int kcol = k0 + xv * 8;
-  const bool k_ok = kcol < p.Ktot;
-  int c0 = 0, dh = 0, dw = 0;
-  if (k_ok) {
-    const int tap = kcol / p.Cin;
-    c0 = kcol - tap * p.Cin;
-    const int tr = tap / p.TS, ts = tap - tr * p.TS;
-    dh = p.dh0 + tr * p.dh_step;
-    dw = p.dw0 + ts * p.dw_step;
-  }
-  // ---- dY staging geometry ---------------------------------------------------------------------------------------------------------
-  const int d_r = lane / DV, d_j = lane % DV;              // row inside the piece, physical chunk
-  const bool d_issue = D_PIECES >= 4 || wave < D_PIECES;   // TN 32: two pieces, waves 0 and 1
-  // px = (first piece of this wave) * D_RPP + d_r; the XOR term only needs (px & 3) and bit 3 of px
-  const int d_px0 = (D_PIECES >= 4 ? wave * D_PW : wave) * D_RPP + d_r;   // (+ i * D_RPP for the wave's second piece: multiples of 4, bit 3 unchanged for TN 128)
-  const int d_h = ((d_px0 & 3) | ((d_px0 >> 1) & 4)) & D_SEGM;
-  const int dv = ((((d_j >> 1) ^ d_h) & D_SEGM) << 1) | (d_j & 1);
-  const int dn = n0 + dv * 8;
-  const bool dn_ok = dn < p.Nout;
-
-  auto stage = [&](int step, int slot) {
-    unsigned char* const sD = ring + slot * ST_BYTES;
-    unsigned char* const sX = sD + D_BYTES;
-    const int mb = m_begin + step * 32;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int px = wave * 8 + i * 4 + x_r;
-      const int m = mb + px;
-      const int n = (int)fast_div31((unsigned)m, p.ohw_mul, p.ohw_sh);
-      const int rem = m - n * OHWi;
-      const int oh = (int)fast_div31((unsigned)rem, p.ow_mul, p.ow_sh);
-      const int ow = rem - oh * p.OWi;
-      const int ih = oh * p.in_sh + dh, iw = ow * p.in_sw + dw;
-      const bool ok = k_ok && m < m_end && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
-      const h16_t* src = ok ? p.x + ((int64_t)((n * p.IH + ih) * p.IW + iw) * p.x_ld + c0) : zero;
-      CVHIP_WG_GLDS16(src, sX + (wave * 2 + i) * 1024);
-    }
-    if (d_issue) {
-#pragma unroll
-      for (int i = 0; i < D_PW; ++i) {
-        const int q = (D_PIECES >= 4 ? wave * D_PW : wave) + i;
-        const int m = mb + q * D_RPP + d_r;
-        const bool ok = dn_ok && m < m_end;
-        const h16_t* src = ok ? p.dy + ((int64_t)m * p.dy_ld + dn) : zero;
-        CVHIP_WG_GLDS16(src, sD + q * 1024);
-      }
-    }
-  };
-
-  f32x4 acc[NF][KF];
-#pragma unroll
-  for (int a = 0; a < NF; ++a)
-#pragma unroll
-    for (int b = 0; b < KF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int g = lane >> 4, q4 = (lane >> 2) & 3;
-  const int hsw = q4 | ((g & 1) << 2);
-  const int px0 = 8 * g + q4;
-  auto compute = [&](int slot) {
-    const unsigned char* const sD = ring + slot * ST_BYTES;
-    const unsigned char* const sX = sD + D_BYTES;
-    h16x8 fd[NF], fx[KF];
-#pragma unroll
-    for (int a = 0; a < NF; ++a) {
-      const int seg = (wn * WN + a * 16) >> 4;
-      const unsigned char* base = sD + (((seg ^ hsw) & D_SEGM) << 5) + (lane & 3) * 8;
-      fd[a] = tr_read8(base + px0 * D_ROWB, base + (px0 + 4) * D_ROWB);
-    }
-#pragma unroll
-    for (int b = 0; b < KF; ++b) {
-      const int seg = (wk * WK + b * 16) >> 4;
-      const unsigned char* base = sX + (((seg ^ hsw) & 7) << 5) + (lane & 3) * 8;
-      fx[b] = tr_read8(base + px0 * X_ROWB, base + (px0 + 4) * X_ROWB);
-    }
-#pragma unroll
-    for (int a = 0; a < NF; ++a)
-#pragma unroll
-      for (int b = 0; b < KF; ++b)
-        acc[a][b] = CVHIP_MFMA_16X16X32(fd[a], fx[b], acc[a][b], 0, 0, 0);
-  };
-
-  // ---- ring: steps s .. s + NST - 2 in flight while step s is multiplied ---------------------------------------------------------------
-#pragma unroll
-  for (int s0 = 0; s0 < NST - 1; ++s0)
-    if (s0 < nsteps) stage(s0, s0);
-  int slot = 0, slot_in = NST - 1;
-  for (int step = 0; step < nsteps; ++step) {
-    // step `step` has landed when at most the NST - 2 younger steps are outstanding (uniform count only while they all exist)
-    if (step + NST - 2 < nsteps) {
-      if (d_issue) wgrad_wait_vm<(NST - 2) * PER_FULL>();
-      else wgrad_wait_vm<(NST - 2) * 2>();
-    } else {
-      wgrad_wait_vm<0>();
-    }
-    __builtin_amdgcn_s_barrier();  // everybody's DMAs of this step landed; everybody finished reading the slot refilled below
-    if (step + NST - 1 < nsteps) stage(step + NST - 1, slot_in);
-    compute(slot);
-    slot = slot == NST - 1 ? 0 : slot + 1;
-    slot_in = slot_in == NST - 1 ? 0 : slot_in + 1;
-  }
-  __syncthreads();  // the ring is dead: the fold below re-uses it
-
-  if constexpr (kWgGroups >= 2) {
-    float* fold = reinterpret_cast<float*>(smem);
-    constexpr int ACC_FLOATS = 4 * NF * KF * 4 * 64;
-#pragma unroll
-    for (int live = kWgGroups; live > 1; live >>= 1) {
-      const int hl = live >> 1;
-      if (grp >= hl && grp < live) {
-        float* dst = fold + (grp - hl) * ACC_FLOATS;
-#pragma unroll
-        for (int a = 0; a < NF; ++a)
-#pragma unroll
-          for (int b = 0; b < KF; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dst[((wave * NF * KF + a * KF + b) * 4 + r) * 64 + lane] = acc[a][b][r];
-      }
-      __syncthreads();
-      if (grp < hl) {
-        const float* src = fold + grp * ACC_FLOATS;
-#pragma unroll
-        for (int a = 0; a < NF; ++a)
-#pragma unroll
-          for (int b = 0; b < KF; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[a][b][r] += src[((wave * NF * KF + a * KF + b) * 4 + r) * 64 + lane];
-      }
-      if (live > 2) __syncthreads();
-    }
-    if (grp != 0) return;
-  }
-  if (p.ablate == 1 && acc[0][0][0] != 12345.678f) return;
-  float* const dwp = p.ablate >= 2 ? p.scratch + (int64_t)split * p.split_stride : p.dw;
-#pragma unroll
-  for (int a = 0; a < NF; ++a) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = n0 + wn * WN + a * 16 + 4 * (lane >> 4) + r;
-      if (n >= p.Nout) continue;
-#pragma unroll
-      for (int b = 0; b < KF; ++b) {
-        const int kc = k0 + wk * WK + b * 16 + (lane & 15);
-        if (kc < p.Ktot) {
-          if (p.ablate == 3) dwp[(int64_t)n * p.Ktot + kc] = acc[a][b][r];
-          else unsafeAtomicAdd(dwp + ((int64_t)n * p.Ktot + kc), acc[a][b][r]);
-        }
-      }
-    }
-  }
-}
-
-// round-4 launcher policy (CVHIP_WGRAD_POLICY=3 restores round 3's): see launch_wgrad_impl
-static int wgrad_policy() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CVHIP_WGRAD_POLICY");
-    v = e ? atoi(e) : 4;
-  }
-  return v;
-}
-
+// Launcher policy (round 4, tools/wgrad_sweep.sh -> profiles/r04_wgrad_sweep.log: 38 configurations x 18 shapes, then step A/Bs): block
+// target 768 (256 for the 128-wide tile on short 1x1 pixel ranges), >= 512 pixel rows per 4-wave group, two-group blocks where the atomic
+// epilogue dominates, three 32-pixel steps in flight for the 64- and 128-wide tiles, no grid a few blocks over the resident slots.
 template <int TN, int WN, int WK>
 static int launch_wg(WgradParams& p, hipStream_t stream, int tgt_hint = 0, int groups_hint = 0) {
   p.n_tiles = cdiv(p.Nout, TN);
   p.k_tiles = cdiv(p.Ktot, 128);
   const int tiles = p.n_tiles * p.k_tiles;
-  static int target = -1, min_rows = -1, force_groups = -1, abl = -1;
-  if (target < 0) {
-    const char* e = getenv("CVHIP_WGRAD_BLOCKS");
-    target = e ? atoi(e) : 768;
-    const char* f = getenv("CVHIP_WGRAD_MINROWS");
-    min_rows = f ? atoi(f) : 512;  // per 4-wave group
-    const char* g = getenv("CVHIP_WGRAD_GROUPS");
-    force_groups = g ? atoi(g) : 0;
-    const char* a = getenv("CVHIP_WGRAD_ABLATE");
-    abl = a ? atoi(a) : 0;
-  }
-  p.ablate = p.det_ws ? 3 : abl;
+  constexpr int kTarget = 768, kMinRows = 512;
+  p.ablate = p.det_ws ? 3 : 0;
   p.scratch = nullptr;
   p.split_stride = 0;
-  if (!p.det_ws && (abl == 2 || abl == 3)) {  // profiling only: 512 MB of scratch, one region per pixel split
-    static float* scratch = nullptr;
-    if (!scratch && hipMalloc(&scratch, 512ull << 20) != hipSuccess) return CVHIP_ERR_LAUNCH;
-    p.scratch = scratch;
-    p.split_stride = (int64_t)p.Nout * p.Ktot;
-  }
   // Two 4-wave groups per block (accumulators folded through LDS, half the atomics) when the atomic epilogue is a large
   // share of the block's work: few pixel rows per (n,k) tile. Otherwise 4-wave blocks (more resident blocks per CU).
   // (the 32-wide output tile always gains: its blocks have the least MFMA work per atomic)
-  int groups = force_groups ? force_groups : groups_hint ? groups_hint : ((TN == 32 || (int64_t)p.M * tiles <= kWgTwoGroupWork) ? 2 : 1);
-  const int rows_min = min_rows * groups;
+  const int groups = groups_hint ? groups_hint : ((TN == 32 || (int64_t)p.M * tiles <= kWgTwoGroupWork) ? 2 : 1);
+  const int rows_min = kMinRows * groups;
   // block target: every block ends by flushing its TN x 128 tile with fp32 atomics, so the atomic volume is blocks x 64 KB whatever the
   // layer; for the 128-wide tile on short pixel ranges (1x1 layers of <= 40 k pixels: ResNet layer3 / layer4 at batch 16, the 20x20 maps
   // of the detectors) 768 blocks flush more bytes than they read — 256 blocks are 15-19 % faster there (profiles/r03_wgrad_ablation.log)
-  int tgt = target;
-  if (!getenv("CVHIP_WGRAD_BLOCKS") && TN == 128 && p.TR == 1 && p.TS == 1 && p.M <= 40000) tgt = 256;
-  if (!getenv("CVHIP_WGRAD_BLOCKS") && tgt_hint > 0) tgt = tgt_hint;
+  int tgt = kTarget;
+  if (TN == 128 && p.TR == 1 && p.TS == 1 && p.M <= 40000) tgt = 256;
+  if (tgt_hint > 0) tgt = tgt_hint;
   int splits = cdiv(tgt, tiles);
   const int max_splits = (p.M + rows_min - 1) / rows_min;
   if (splits > max_splits) splits = max_splits;
@@ -638,14 +404,12 @@ static int launch_wg(WgradParams& p, hipStream_t stream, int tgt_hint = 0, int g
   int mps = cdiv(p.M, splits);
   mps = ((mps + 63) / 64) * 64;
   splits = cdiv(p.M, mps);
-  if (wgrad_policy() >= 4) {
+  {
     // resident block slots of the instance that will run (VGPR / LDS occupancy from the compiler's resource remarks: a one-group block
     // is one wave per SIMD, a two-group block two): a grid a few blocks larger than that runs a second, nearly empty round — rounding
     // the rows per split up to 64 and the splits up to whole numbers overshot it (128 -> 128 3x3 at 64 x 128, batch 16: 774 blocks on 768
     // slots, +11 %; profiles/r04_wgrad_sweep.log)
-    const char* e128 = getenv("CVHIP_WGRAD_PD128");
-    const bool deep128 = TN == 128 && (e128 ? atoi(e128) == 3 : true) && !(getenv("CVHIP_WGRAD_PD") && atoi(getenv("CVHIP_WGRAD_PD")) == 1);
-    const int cap = groups >= 2 ? (TN == 32 ? 768 : 256) : (TN == 128 ? (deep128 ? 512 : 768) : 1024);
+    const int cap = groups >= 2 ? (TN == 32 ? 768 : 256) : (TN == 128 ? 512 : 1024);
     while (tiles * splits > cap && tiles * splits < 2 * cap - cap / 4 && splits > 1) {
       mps += 64;
       splits = cdiv(p.M, mps);
@@ -661,7 +425,7 @@ static int launch_wg(WgradParams& p, hipStream_t stream, int tgt_hint = 0, int g
     if (p.det_ws_floats < (int64_t)splits * n) return CVHIP_ERR_INVALID;
     p.scratch = p.det_ws;
     p.split_stride = n;
-    // register-staged kernels only (the DMA variant is an experiment); every (n, k) of every split slab is written exactly once
+    // every (n, k) of every split slab is written exactly once
     if (groups >= 2) hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 2, 1>), dim3(tiles * splits), dim3(512), 0, stream, p);
     else hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 1, 1>), dim3(tiles * splits), dim3(256), 0, stream, p);
     int st = check_launch("wgrad_kernel(det)");
@@ -670,60 +434,12 @@ static int launch_wg(WgradParams& p, hipStream_t stream, int tgt_hint = 0, int g
     return check_launch("wgrad_fold_kernel");
   }
   // (four groups per block were measured too: 1024-thread blocks in lockstep lose 10-50 % on every YOLOv5-s layer)
-  // Prefetch depth (CVHIP_WGRAD_PD=1/3 forces one): three steps in flight pay for the 64-wide tile (-10...-17 % per launch) but
-  // cost the 128-wide tile a resident block (178 VGPRs: +10 %) and do nothing for the 32-wide one (profiles/r02_wgrad_pd.log)
-  static int pd_force = -1;
-  if (pd_force < 0) {
-    const char* e = getenv("CVHIP_WGRAD_PD");
-    pd_force = e ? atoi(e) : 0;
-  }
-  static int dma = -1, nst = -1;
-  if (dma < 0) {
-    const char* e = getenv("CVHIP_WGRAD_DMA");
-    dma = e ? atoi(e) : 0;
-    const char* f = getenv("CVHIP_WGRAD_NST");
-    nst = f ? atoi(f) : 4;
-  }
-  if (dma && (p.x_ld & 7) == 0 && (p.dy_ld & 7) == 0 && (p.Cin & 7) == 0 && ((((uintptr_t)p.x) | ((uintptr_t)p.dy)) & 15) == 0) {
-    if (nst == 3) {
-      if (groups >= 2) hipLaunchKernelGGL((wgrad_dma_kernel<TN, WN, WK, 2, 3>), dim3(tiles * splits), dim3(512), 0, stream, p);
-      else hipLaunchKernelGGL((wgrad_dma_kernel<TN, WN, WK, 1, 3>), dim3(tiles * splits), dim3(256), 0, stream, p);
-    } else {
-      if (groups >= 2) hipLaunchKernelGGL((wgrad_dma_kernel<TN, WN, WK, 2, 4>), dim3(tiles * splits), dim3(512), 0, stream, p);
-      else hipLaunchKernelGGL((wgrad_dma_kernel<TN, WN, WK, 1, 4>), dim3(tiles * splits), dim3(256), 0, stream, p);
-    }
-    return check_launch("wgrad_dma_kernel");
-  }
-  // Round 4: three steps in flight for the 128-wide tile too (CVHIP_WGRAD_PD128=1 restores one). 177-179 VGPRs = two resident one-group
-  // blocks per CU instead of three, which round 2 measured as +10 % on ISOLATED launches with hot operands; inside the train step
-  // x comes from the forward pass (cold: HBM latency, not the L2's) and the deeper prefetch is worth -0.4 ms per YOLOv5-s step
-  // (14.62 -> 14.24 ms, same box) and -0.5 ms per DeepLabv3+ step (profiles/r04_wgrad_step_ab.log)
-  static int pd128 = -1;
-  if (pd128 < 0) {
-    const char* e = getenv("CVHIP_WGRAD_PD128");
-    pd128 = e ? atoi(e) : (wgrad_policy() >= 4 ? 3 : 1);
-  }
-  const int pd = pd_force == 1 || pd_force == 3 ? pd_force : (TN == 64 ? 3 : TN == 128 ? (pd128 == 3 ? 3 : 1) : 1);
-  if (abl == 4 || abl == 5) {  // profiling instances (one group per block or two, the depth the shape would get)
-    p.ablate = 1;              // and no atomic epilogue
-    if (abl == 4) {
-      if (pd == 1 && groups >= 2) hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 2, 1, 4>), dim3(tiles * splits), dim3(512), 0, stream, p);
-      else if (pd == 1) hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 1, 1, 4>), dim3(tiles * splits), dim3(256), 0, stream, p);
-      else if (groups >= 2) hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 2, 3, 4>), dim3(tiles * splits), dim3(512), 0, stream, p);
-      else hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 1, 3, 4>), dim3(tiles * splits), dim3(256), 0, stream, p);
-    } else {
-      if (pd == 1 && groups >= 2) hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 2, 1, 5>), dim3(tiles * splits), dim3(512), 0, stream, p);
-      else if (pd == 1) hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 1, 1, 5>), dim3(tiles * splits), dim3(256), 0, stream, p);
-      else if (groups >= 2) hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 2, 3, 5>), dim3(tiles * splits), dim3(512), 0, stream, p);
-      else hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 1, 3, 5>), dim3(tiles * splits), dim3(256), 0, stream, p);
-    }
-    return check_launch("wgrad_kernel(ablation)");
-  }
-  if (pd == 1) {
-    if (groups >= 2) hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 2, 1>), dim3(tiles * splits), dim3(512), 0, stream, p);
-    else hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 1, 1>), dim3(tiles * splits), dim3(256), 0, stream, p);
-  } else if (groups >= 2) hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 2, 3>), dim3(tiles * splits), dim3(512), 0, stream, p);
-  else hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 1, 3>), dim3(tiles * splits), dim3(256), 0, stream, p);
+  // Prefetch depth: three steps in flight pay for the 64-wide tile (-10...-17 % per launch, profiles/r02_wgrad_pd.log) and, inside the
+  // train step where x is cold, for the 128-wide tile too (177-179 VGPRs = two resident one-group blocks per CU instead of three:
+  // -0.4 ms per YOLOv5-s step, -0.5 ms per DeepLabv3+ step, profiles/r04_wgrad_step_ab.log); nothing for the 32-wide one
+  constexpr int pd = TN == 32 ? 1 : 3;
+  if (groups >= 2) hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 2, pd>), dim3(tiles * splits), dim3(512), 0, stream, p);
+  else hipLaunchKernelGGL((wgrad_kernel<TN, WN, WK, 1, pd>), dim3(tiles * splits), dim3(256), 0, stream, p);
   return check_launch("wgrad_kernel");
 }
 
@@ -766,14 +482,9 @@ int launch_wgrad_impl(const cvhip_conv_desc* d, const void* x, const void* dy, f
   if (p.M <= 0) return CVHIP_OK;
   div31_consts(p.OHi * p.OWi, &p.ohw_mul, &p.ohw_sh);
   div31_consts(p.OWi, &p.ow_mul, &p.ow_sh);
-  static int tn_max = -1;
-  if (tn_max < 0) {
-    const char* e = getenv("CVHIP_WGRAD_TNMAX");
-    tn_max = e ? atoi(e) : 0;
-  }
-  // Out-channel tile. The fp32 atomic epilogue is 20-45 % of a launch for the small-M layers (gpurun conv_table with
-  // CVHIP_WGRAD_ABLATE=1): narrower tiles mean more (n, k) tiles, hence fewer pixel splits and fewer atomics per MFMA, at
-  // the price of more LDS fragment reads per MFMA. Per-shape A/B on the YOLOv5-s layers (CVHIP_WGRAD_TNMAX=32/64/128):
+  // Out-channel tile. The fp32 atomic epilogue is 20-45 % of a launch for the small-M layers (measured in round 1 with the
+  // epilogue switched off): narrower tiles mean more (n, k) tiles, hence fewer pixel splits and fewer atomics per MFMA, at
+  // the price of more LDS fragment reads per MFMA. Per-shape A/B on the YOLOv5-s layers (tile forced to 32 / 64 / 128)
   // and DeepLabv3+ R50 layers: memory-bound 1x1 layers of modest size (M*K*C <= 7.5e9: the 20x20..80x80 YOLO layers) want
   // the 32-wide tile — the large ResNet 1x1 layers lose up to 2x with it; 3x3 layers with >= 256 outputs the 64-wide one.
   // Round 4 (isolated sweep of tile x block target x groups over 18 layer shapes, tools/wgrad_sweep.sh -> profiles/r04_wgrad_sweep.log,
@@ -783,24 +494,19 @@ int launch_wgrad_impl(const cvhip_conv_desc* d, const void* x, const void* dy, f
   // (b) 3x3 layers with >= 256 outputs: the 128-wide tile with 512 blocks instead of the 64-wide one with 768 (-7...-14 %).
   int tn = d->K <= 32 ? 32 : d->K <= 64 ? 64 : 128;
   int tgt_hint = 0, groups_hint = 0;
-  if (tn_max > 0) {
-    if (tn > tn_max) tn = tn_max;
-  } else if (d->R == 1 && d->S == 1) {
+  if (d->R == 1 && d->S == 1) {
     if ((double)p.M * d->K * d->C <= 7.5e9) {
       tn = 32;
-      if (wgrad_policy() >= 4 && d->K >= 256 && d->C >= 256) {
+      if (d->K >= 256 && d->C >= 256) {
         tn = 128;
         tgt_hint = 256;
         groups_hint = 2;
       }
     }
   } else if (d->K >= 256 && d->C <= 1024) {
-    tn = 64;
-    if (wgrad_policy() >= 4) {
-      tn = 128;
-      tgt_hint = 512;
-      groups_hint = 1;
-    }
+    tn = 128;
+    tgt_hint = 512;
+    groups_hint = 1;
   }
   int rc;
   if (tn == 32) rc = launch_wg<32, 32, 32>(p, stream, tgt_hint, groups_hint);

@@ -306,13 +306,8 @@ __global__ __launch_bounds__(256) void dw_taps_kernel(const DwTapParams p) {
 
 // launch for fprop (dgrad == false) or the stride-1 input gradient; false when the taps form does not apply
 static bool dw_taps_launch(const DwParams& p, bool dgrad, hipStream_t s, int* status) {
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("CVHIP_DW_TAPS");
-    on = e ? atoi(e) : 1;
-  }
   const int T = p.R * p.S;
-  if (!on || T > kDwMaxTaps || (p.C & 7) || (p.x_ld & 7) || (p.y_ld & 7) || ((((uintptr_t)p.x) | ((uintptr_t)p.y)) & 15)) return false;
+  if (T > kDwMaxTaps || (p.C & 7) || (p.x_ld & 7) || (p.y_ld & 7) || ((((uintptr_t)p.x) | ((uintptr_t)p.y)) & 15)) return false;
   if (dgrad && (p.sh != 1 || p.sw != 1)) return false;
   DwTapParams q{};
   q.in = p.x;   // fprop: x; dgrad: dy (the caller swapped the pitches)
@@ -529,13 +524,7 @@ static void dw3_launch_geom(Dw3Params& q, int* grid, bool wgrad = false) {
   const int CV = q.C >> 3;
   const int cols = CV < 256 ? CV : 256;
   const int rpp = 256 / cols;
-  static int seg_env = -1, rpt_env = -1;
-  if (seg_env < 0) {
-    const char* e = getenv("CVHIP_DW3_SEG");
-    seg_env = e ? atoi(e) : 0;
-    const char* f = getenv("CVHIP_DW3_RPT");
-    rpt_env = f ? atoi(f) : 0;
-  }
+  constexpr int seg_env = 0, rpt_env = 0;   // (forced segment length / rows per thread: dev sweeps of round 3, tools/dw_bench.py)
   // row segment one thread walks: 64 columns for fprop / dgrad; the weight-gradient walk keeps 9 x 8 sums in registers and
   // pays an LDS fold + atomics per block, so it takes whole rows up to 256 columns (tools/dw_bench.py: 397 -> 262 us on the
   // DeepLabv3+ decoder's 304-channel tensor)

@@ -11,7 +11,7 @@ from cvpytorch_amd import lib as L
 from cvpytorch_amd import ops
 
 KEYS = ("NF", "WN", "MFW", "PPS", "PF", "TH", "bands", "n_tiles", "total", "lds", "PH", "PW", "NW")
-ENV = ("CVHIP_BAND", "CVHIP_BAND_NF", "CVHIP_BAND_PF", "CVHIP_BAND_TH", "CVHIP_BAND_NW")
+ENV = ("CVHIP_BAND", "CVHIP_BAND_NW")
 
 
 def plan(shape, dgrad=False, pad=1, dil=1, **env):
@@ -35,9 +35,7 @@ SHAPES = [
     (16, 64, 128, 256, 64), (16, 128, 64, 128, 128), (16, 256, 32, 64, 256), (16, 512, 32, 64, 512),  # DeepLabv3+ R50, batch 16
     (3, 128, 17, 19, 128), (1, 32, 23, 37, 32), (2, 64, 9, 300, 64), (2, 96, 12, 12, 64), (2, 64, 14, 18, 128),
 ]
-FORMS = [dict(CVHIP_BAND_NF=2, CVHIP_BAND_PF=0, CVHIP_BAND_NW=8), dict(CVHIP_BAND_NF=2, CVHIP_BAND_PF=1, CVHIP_BAND_NW=8),
-         dict(CVHIP_BAND_NF=4, CVHIP_BAND_PF=0, CVHIP_BAND_NW=8), dict(CVHIP_BAND_NF=4, CVHIP_BAND_PF=1, CVHIP_BAND_NW=8),
-         dict(CVHIP_BAND_NF=2, CVHIP_BAND_PF=0, CVHIP_BAND_NW=4), dict(CVHIP_BAND_NF=4, CVHIP_BAND_PF=1, CVHIP_BAND_NW=4)]
+FORMS = [dict(CVHIP_BAND_NW=8), dict(CVHIP_BAND_NW=4)]   # (the wide-wave / read-ahead forms of round 5 are no longer instantiated)
 
 
 @pytest.mark.parametrize("shape", SHAPES)
@@ -61,7 +59,7 @@ def test_band_plan_invariants(shape, form, geom):
             assert not (K in (32, 64) or K % 128 == 0) or Cc % 32 or OW > 16 * 13 * (8 // max(1, min(K, 128) // 32)) or \
                 pieces1 > 12 or (2 if Cc > 32 else 1) * pieces1 * 8192 + 8192 > 156 * 1024, (shape, dgrad)
             continue
-        assert pl["NF"] == form["CVHIP_BAND_NF"] or (form["CVHIP_BAND_NF"] == 4 and pl["NF"] == 2)   # wide where it fits, narrow elsewhere
+        assert pl["NF"] == 2   # narrow waves (the only instantiated form)
         BN = min(K, 128)
         assert pl["WN"] * 16 * pl["NF"] == BN and pl["n_tiles"] * BN == K
         assert pl["NW"] in (4, 8) and (pl["NW"] == 8 or form["CVHIP_BAND_NW"] == 4) and pl["WN"] <= pl["NW"]   # (NW = 4 falls back to 8)
@@ -80,10 +78,7 @@ def test_band_plan_invariants(shape, form, geom):
         assert pieces <= pl["PPS"] * 6 and (pl["PPS"] == 1) == (pieces <= 6)
         bufs = 2 if Cc > 32 else 1
         assert pl["lds"] >= bufs * -(-pl["PH"] * pl["PW"] // 16) * 1024 + 1024 and pl["lds"] <= (79 if pl["NW"] == 4 else 156) * 1024
-        # the read-ahead exists in the 7-fragment forms only, and never holds more fragments than the wave owns
-        assert pl["PF"] == 0 or (form["CVHIP_BAND_PF"] == 1 and pl["MFW"] == 7 and 0 < pl["PF"] <= 7)
-        if form["CVHIP_BAND_PF"] == 1 and pl["MFW"] == 7:
-            assert pl["PF"] > 0
+        assert pl["PF"] == 0   # (no LDS read-ahead form in the library)
 
 
 def test_band_default_policy():
@@ -213,7 +208,7 @@ def _interpret_band_fprop(x, w, pad, dil, pl):
 
 
 @pytest.mark.parametrize("case", [(1, 32, 7, 9, 32, 1, 1, {}), (1, 64, 6, 11, 64, 1, 1, {"CVHIP_BAND_NW": 8}), (1, 32, 9, 6, 64, 2, 2, {}),
-                                  (1, 32, 5, 20, 64, 0, 1, {"CVHIP_BAND_NF": 4, "CVHIP_BAND_NW": 8}), (1, 64, 8, 12, 256, 1, 1, {})])
+                                  (1, 32, 5, 20, 64, 0, 1, {"CVHIP_BAND_NW": 8}), (1, 64, 8, 12, 256, 1, 1, {})])
 def test_band_addressing_interpreter(case):
     """the addressing the kernel's header and conv_plan.h state (loader swizzle, fragment addresses, band image order, MFMA operand
     layout), run in numpy on the plan the library returns, reproduces torch's convolution"""
@@ -223,8 +218,6 @@ def test_band_addressing_interpreter(case):
     N, Cc, H, W, K, pad, dil, env = case
     pl = plan((N, Cc, H, W, K), False, pad, dil, CVHIP_BAND=2, **env)
     assert pl is not None, case
-    if env.get("CVHIP_BAND_NF") == 4 and pl["NF"] != 4:
-        pytest.skip("the wide form does not fit this geometry")
     g = torch.Generator().manual_seed(7)
     x = torch.randn(N, Cc, H, W, generator=g, dtype=torch.float64)
     w = torch.randn(K, Cc, 3, 3, generator=g, dtype=torch.float64)

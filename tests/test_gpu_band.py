@@ -25,10 +25,9 @@ def rnd(x):
     return x.to(K.BF).float()
 
 
-# the kernel's forms (conv_band.hip header): narrow waves (32 channels x <= 13 pixel fragments) / wide waves (64 channels x 7 pixel
-# fragments), each with the compiler-scheduled LDS reads or with the hand-counted read-ahead (CVHIP_BAND_PF=1: 7-fragment forms only)
-FORMS = {"narrow": ("2", "0", "8"), "narrow_pf": ("2", "1", "8"), "wide": ("4", "0", "8"), "wide_pf": ("4", "1", "8"),
-         "narrow_nw4": ("2", "0", "4"), "narrow_pf_nw4": ("2", "1", "4"), "wide_pf_nw4": ("4", "1", "4")}   # ..., waves per block
+# the kernel's forms (conv_band.hip header): narrow waves (32 channels x <= 13 pixel fragments) as one 8-wave block per CU or as two
+# co-resident 4-wave blocks. (The wide-wave and LDS-read-ahead forms of round 5 — measured, never ahead — left the library in round 6.)
+FORMS = {"narrow": ("2", "0", "8"), "narrow_nw4": ("2", "0", "4")}   # (weight fragments per wave, read-ahead, waves per block)
 
 
 @pytest.fixture(autouse=True, params=sorted(FORMS))
@@ -36,8 +35,6 @@ def force_band(request, monkeypatch):
     nf, pf, nw = FORMS[request.param]
     monkeypatch.setenv("CVHIP_BAND_NW", nw)
     monkeypatch.setenv("CVHIP_BAND", "2")
-    monkeypatch.setenv("CVHIP_BAND_NF", nf)
-    monkeypatch.setenv("CVHIP_BAND_PF", pf)
     yield request.param
 
 

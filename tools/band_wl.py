@@ -16,9 +16,8 @@ ys = [torch.empty(N, H, W, K, device=dev, dtype=ops.ACT_DTYPE) for _ in range(ns
 stream = ops._stream()
 for name, env in (("band, default plan (two 4-wave blocks per CU)", {"CVHIP_BAND": "2"}),
                   ("band, one 8-wave block per CU", {"CVHIP_BAND": "2", "CVHIP_BAND_NW": "8"}),
-                  ("band, wide waves + LDS read-ahead", {"CVHIP_BAND": "2", "CVHIP_BAND_NW": "8", "CVHIP_BAND_NF": "4", "CVHIP_BAND_PF": "1"}),
                   ("patch", {"CVHIP_BAND": "0", "CVHIP_PATCH": "1"}), ("tap", {"CVHIP_BAND": "0", "CVHIP_PATCH": "0"})):
-    for k in ("CVHIP_BAND", "CVHIP_BAND_NW", "CVHIP_BAND_NF", "CVHIP_BAND_PF", "CVHIP_PATCH"):
+    for k in ("CVHIP_BAND", "CVHIP_BAND_NW", "CVHIP_PATCH"):
         os.environ.pop(k, None)
     os.environ.update(env)
     for i in range(30):
