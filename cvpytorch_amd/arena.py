@@ -56,7 +56,84 @@ def paired_arena_order(items, follow):
     return out, [pos[id(t)] for t in out]
 
 
-class FlatTrainState:
+def build_buckets(seg, cap):
+    """Gradient buckets over the arena: `seg[i] = (lo, hi)` is parameter i's float range (arena order), `cap` the bucket size in
+    floats. Buckets are contiguous arena ranges filled from the LAST parameter backwards (gradients arrive in roughly reverse
+    registration order, as DDP's reducer assumes); a parameter larger than `cap` is a bucket of its own. Pure arithmetic: every rank
+    derives the same list from the same model. Returns [(lo, hi, first_param, last_param)], bucket 0 = the last parameters."""
+    buckets = []
+    hi_i = len(seg) - 1
+    i = hi_i
+    while i >= 0:
+        lo_i = i
+        while lo_i - 1 >= 0 and (seg[hi_i][1] - seg[lo_i - 1][0]) <= cap:
+            lo_i -= 1
+        buckets.append((seg[lo_i][0], seg[hi_i][1], lo_i, hi_i))
+        i = hi_i = lo_i - 1
+    return buckets
+
+
+class BucketSchedule:
+    """Host-side bookkeeping of the bucketed gradient exchange (the part of DistributedDataParallel's reducer that decides WHEN a
+    bucket's collective is issued; trainer.py:312-313 wraps the model in DDP). Pure Python — no device, no transport: `_launch(bi)`
+    is the subclass's (FlatTrainState issues the collective on its side stream; tests/test_ddp_gloo.py records / runs it over gloo).
+    Invariant the tests pin: buckets are launched in INDEX order 0, 1, 2, ... on every rank — whatever order the gradients complete in
+    and whichever parameters receive no gradient at all on a rank — so the collective sequence (and, under hipGraph capture, the
+    side-stream fork / collective / join node sequence) is identical on all ranks and cannot deadlock on order."""
+
+    def _init_schedule(self, buckets):
+        self.buckets = list(buckets)  # [lo, hi, first_param, last_param]
+        self.bucket_of = {}
+        for bi, (_, _, lo_i, hi_i) in enumerate(self.buckets):
+            for k in range(lo_i, hi_i + 1):
+                self.bucket_of[k] = bi
+        self._reset_buckets()
+
+    def _reset_buckets(self):
+        self._pending = [hi - lo + 1 for (_, _, lo, hi) in self.buckets]
+        self._seen = set()
+        self._uses = {}
+        self._next_bucket = 0
+
+    def note_use(self, i):
+        """Forward-side count of the ops that will accumulate into parameter i's gradient slot this step: a layer applied twice
+        must not release its bucket after the FIRST backward use (the second one is still accumulating into the same slot)."""
+        if self.multi:
+            for k in (i if isinstance(i, tuple) else (i,)):
+                if k is not None:
+                    self._uses[k] = self._uses.get(k, 0) + 1
+
+    def mark_ready(self, i):
+        """Called when an op has finished writing its contribution to parameter i's gradient in the arena; the parameter is
+        complete once every forward use (note_use) has reported."""
+        if not self.multi or self.defer_allreduce or i in self._seen:
+            return
+        left = self._uses.get(i, 0)
+        if left > 1:
+            self._uses[i] = left - 1
+            return
+        self._seen.add(i)
+        bi = self.bucket_of[i]
+        self._pending[bi] -= 1
+        # buckets go out in INDEX order only (as DDP's reducer does): the collective sequence is identical on every rank
+        # whatever order gradients complete in
+        while self._next_bucket < len(self.buckets) and self._pending[self._next_bucket] == 0:
+            self._launch(self._next_bucket)
+            self._next_bucket += 1
+
+    def _launch_rest(self):
+        """end of backward: buckets still waiting for parameters that received no gradient this step (their slots are zero) go out
+        now, in index order"""
+        for bi in range(self._next_bucket, len(self.buckets)):
+            self._pending[bi] = 0
+            self._launch(bi)
+        self._next_bucket = len(self.buckets)
+
+    def _launch(self, bi):
+        raise NotImplementedError
+
+
+class FlatTrainState(BucketSchedule):
     def __init__(self, model, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4, backbone_lr=None, ema_decay=0.9999,
                  use_ema=True, bucket_bytes=8 << 20, process_group=None, comm=None, force_collectives=False, loss_scaling=None,
                  init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, optimizer="sgd", betas=(0.9, 0.999),
@@ -201,20 +278,7 @@ class FlatTrainState:
         # `multi`: the collective machinery is live. force_collectives runs it over a 1-rank communicator too (every collective is
         # then the identity): how the captured-RCCL path is exercised on a single GPU (tests/test_gpu_comm.py)
         self.multi = self.world > 1 or (self.comm is not None and force_collectives)
-        self.buckets = []  # [lo, hi, first_param, last_param]
-        cap = max(1, bucket_bytes // 4)
-        hi_i = len(self.params) - 1
-        i = hi_i
-        while i >= 0:
-            lo_i = i
-            while lo_i - 1 >= 0 and (seg[hi_i][1] - seg[lo_i - 1][0]) <= cap:
-                lo_i -= 1
-            self.buckets.append((seg[lo_i][0], seg[hi_i][1], lo_i, hi_i))
-            i = hi_i = lo_i - 1
-        self.bucket_of = {}
-        for bi, (_, _, lo_i, hi_i2) in enumerate(self.buckets):
-            for k in range(lo_i, hi_i2 + 1):
-                self.bucket_of[k] = bi
+        buckets = build_buckets(seg, max(1, bucket_bytes // 4))
         self._pending = None
         self._stream = None
         self._uses = {}
@@ -225,7 +289,7 @@ class FlatTrainState:
         if self.multi:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
-        self._reset_buckets()
+        self._init_schedule(buckets)
         # BatchNorm statistic accumulators (ops._layer_acc): fp64 [2 (forward, backward)][shards][2][K] per BN layer and one more of
         # K1 + K2 channels per sibling pair, in ONE buffer that step_kernels() zero-fills with a single launch
         want = []
@@ -269,41 +333,9 @@ class FlatTrainState:
                 self.ema_param.copy_(self.param)
                 self.ema_buf.copy_(self.buf)
 
-    # ---- gradient readiness / all-reduce ------------------------------------------------------------------
-    def _reset_buckets(self):
-        self._pending = [hi - lo + 1 for (_, _, lo, hi) in self.buckets]
-        self._seen = set()
-        self._uses = {}
-        self._next_bucket = 0
-
+    # ---- gradient readiness / all-reduce (bookkeeping: BucketSchedule) -----------------------------------------
     def _hook(self, p):
         self.mark_ready(self.index[id(p)])
-
-    def note_use(self, i):
-        """Forward-side count of the ops that will accumulate into parameter i's gradient slot this step: a layer applied twice
-        must not release its bucket after the FIRST backward use (the second one is still accumulating into the same slot)."""
-        if self.multi:
-            for k in (i if isinstance(i, tuple) else (i,)):
-                if k is not None:
-                    self._uses[k] = self._uses.get(k, 0) + 1
-
-    def mark_ready(self, i):
-        """Called when an op has finished writing its contribution to parameter i's gradient in the arena; the parameter is
-        complete once every forward use (note_use) has reported."""
-        if not self.multi or self.defer_allreduce or i in self._seen:
-            return
-        left = self._uses.get(i, 0)
-        if left > 1:
-            self._uses[i] = left - 1
-            return
-        self._seen.add(i)
-        bi = self.bucket_of[i]
-        self._pending[bi] -= 1
-        # buckets go out in INDEX order only (as DDP's reducer does): the collective sequence is identical on every rank
-        # whatever order gradients complete in
-        while self._next_bucket < len(self.buckets) and self._pending[self._next_bucket] == 0:
-            self._launch(self._next_bucket)
-            self._next_bucket += 1
 
     def _launch(self, bi):
         lo, hi = self.buckets[bi][0], self.buckets[bi][1]
@@ -326,10 +358,7 @@ class FlatTrainState:
                 self.comm.allreduce_(self.grad)
             self.comm.wait()
             return
-        for bi in range(self._next_bucket, len(self.buckets)):  # parameters without a gradient this step: their slots are zero
-            self._pending[bi] = 0
-            self._launch(bi)
-        self._next_bucket = len(self.buckets)
+        self._launch_rest()   # parameters without a gradient this step: their slots are zero
         self.comm.wait()
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
