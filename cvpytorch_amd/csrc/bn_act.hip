@@ -682,187 +682,6 @@ __global__ __launch_bounds__(256) void ew_kernel(const EwParams p) {
   }
 }
 
-
-// =====================================================================================================================================
-// (round 6) BN + activation BACKWARD of a small layer as ONE resident launch. The two-pass form reads (dz, y) for the sums
-// (colreduce_kernel<1>), then reads (dz, y) AGAIN and writes dy (ew_kernel<1>): 10 bytes per element and two launches whose fixed
-// cost (launch boundary, ramp, per-block accumulator fold, a dependent trip chain) is most of their time on the 13 - 52 MB tensors of
-// the 40 x 40 / 20 x 20 layers (19.6 + 15.5 us for 26 MB, i.e. 2.7 - 3.4 TB/s; tools/mall_probe.py). Here one block per CU keeps its
-// slice of (dz, y) IN REGISTERS across a device-wide barrier: phase 1 loads every row visit at once (all loads of the kernel in flight
-// together), reduces (sum du, sum du * xhat) into the layer's fp64 accumulator; barrier; phase 2 folds the accumulator and turns the
-// resident values into dy — 6 bytes per element, one launch. 256 blocks x 512 threads x <= 16 visits x 32 B hold 67 MB of (dz + y): the 13 and 26 MB tensors.
-// The barrier is a counter in caller memory (cvhip_bn_act_bwd_fused_acc's `barrier_ws`, two zeroed 32-bit words; the last block to leave
-// re-zeroes them): the grid never exceeds one block per CU, so every block is resident and the barrier completes; the spin is bounded
-// all the same (a stuck launch produces garbage and sets barrier_ws[2], it does not hang the GPU). Cross-block data are the fp64
-// atomics (performed at the memory side) read back with agent-scope atomic loads. Replaces aten::native_batch_norm_backward +
-// aten::silu_backward reached from conv_module.py:211-213 under trainer.py:189.
-// =====================================================================================================================================
-struct BnFusedParams {
-  const h16_t *dz, *y;
-  h16_t* dy;
-  int ld_dz, ld_y, ld_dy;
-  int64_t M;
-  int C, cols, rows_per_pass, nv;
-  const float *scale, *shift, *mean, *invstd;
-  float ap, inv_count;
-  double* acc;
-  int acc_ld;
-  float *o_dgamma, *o_dbeta;
-  int accumulate;
-  unsigned* bar;
-};
-constexpr int kBnFusedThreads = 512;
-
-template <int ACT, int VMAX>
-__global__ __launch_bounds__(kBnFusedThreads, 2) void bn_bwd_fused_kernel(const BnFusedParams p) {
-  __shared__ float red[kBnFusedThreads * 16];
-  __shared__ float cst[2 * kEwAccMaxC];
-  const int t = threadIdx.x;
-  const int tx = t % p.cols, ty = t / p.cols;
-  const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_pass * p.nv + ty;
-
-  uint4 ua[VMAX], uy[VMAX];
-  const int c = tx * 8;   // (cols == C / 8: a thread owns one channel vector)
-  // ---- phase 1: every row visit of this thread requested at once; masked visits read row 0 and contribute nothing ---------------------
-  {
-    float sc[8], sh[8], mu[8], is[8];
-    load8c(p.scale, c, p.C, sc);
-    load8c(p.shift, c, p.C, sh);
-    load8c(p.mean, c, p.C, mu);
-    load8c(p.invstd, c, p.C, is);
-#pragma unroll
-    for (int v = 0; v < VMAX; ++v) {
-      const int64_t r = r0 + (int64_t)v * p.rows_per_pass;
-      const bool ok = v < p.nv && r < p.M;
-      const int64_t rc = ok ? r : 0;
-      ua[v] = *reinterpret_cast<const uint4*>(p.dz + rc * p.ld_dz + c);
-      uy[v] = *reinterpret_cast<const uint4*>(p.y + rc * p.ld_y + c);
-    }
-    float s1[8], s2[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
-#pragma unroll
-    for (int v = 0; v < VMAX; ++v) {
-      // the visit's packed rows become visible to the compiler only AFTER the previous visit's sums (the asm ties them to s1 / s2): without
-      // the chain it unpacks every visit up front and keeps 16 fp32 per visit alive — 32 registers per visit instead of 8
-      asm volatile("" : "+v"(ua[v].x), "+v"(ua[v].y), "+v"(ua[v].z), "+v"(ua[v].w), "+v"(s1[0]));
-      asm volatile("" : "+v"(uy[v].x), "+v"(uy[v].y), "+v"(uy[v].z), "+v"(uy[v].w), "+v"(s2[0]));
-      const int64_t r = r0 + (int64_t)v * p.rows_per_pass;
-      const float m = (v < p.nv && r < p.M) ? 1.f : 0.f;
-      const f32x8 a = unpack8(ua[v]), y = unpack8(uy[v]);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float u = y.v[j] * sc[j] + sh[j];
-        const float du = m * a.v[j] * act_bwd(u, ACT, p.ap);
-        const float xh = (y.v[j] - mu[j]) * is[j];
-        s1[j] += du;
-        s2[j] += du * xh;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      red[t * 16 + j] = s1[j];
-      red[t * 16 + 8 + j] = s2[j];
-    }
-  }
-  __syncthreads();
-  for (int idx = t; idx < p.cols * 16; idx += kBnFusedThreads) {
-    const int x = idx >> 4, j = idx & 15;
-    float sum = 0.f;
-    for (int yy = 0; yy < p.rows_per_pass; ++yy) sum += red[(yy * p.cols + x) * 16 + j];
-    const int cc = x * 8 + (j & 7);
-    unsafeAtomicAdd(p.acc + ((size_t)((blockIdx.x & (kAccShards - 1)) * 2 + (j >> 3))) * p.acc_ld + cc, (double)sum);
-  }
-  // ---- device-wide barrier: this block's atomics are out (vmcnt 0 in every wave, then the release), one arrival per block --------------
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (t == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_fetch_add(p.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned spins = 0;
-    while (__hip_atomic_load(p.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-      __builtin_amdgcn_s_sleep(4);
-      if (++spins > (1u << 22)) {   // ~1 s: never in a resident grid; a stuck launch must not hang the GPU
-        __hip_atomic_store(p.bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  __syncthreads();
-  // ---- phase 2: fold the accumulator (agent-scope loads: the sums were made by memory-side atomics), constants, dy ------------------------
-  for (int c = t; c < p.C; c += kBnFusedThreads) {
-    double a = 0.0, b = 0.0;
-#pragma unroll
-    for (int sd = 0; sd < kAccShards; ++sd) {
-      a += __hip_atomic_load(p.acc + (size_t)sd * 2 * p.acc_ld + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      b += __hip_atomic_load(p.acc + (size_t)sd * 2 * p.acc_ld + p.acc_ld + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    cst[c] = (float)a * p.inv_count;                 // dbeta / M
-    cst[kEwAccMaxC + c] = (float)b * p.inv_count;    // dgamma / M
-    if (blockIdx.x == 0) {
-      if (p.o_dbeta) p.o_dbeta[c] = p.accumulate ? p.o_dbeta[c] + (float)a : (float)a;
-      if (p.o_dgamma) p.o_dgamma[c] = p.accumulate ? p.o_dgamma[c] + (float)b : (float)b;
-    }
-  }
-  __syncthreads();
-  {
-    float sc[8], sh[8], mu[8], is[8], k1[8], k2[8];
-    load8c(p.scale, c, p.C, sc);
-    load8c(p.shift, c, p.C, sh);
-    load8c(p.mean, c, p.C, mu);
-    load8c(p.invstd, c, p.C, is);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      k1[j] = cst[c + j];
-      k2[j] = cst[kEwAccMaxC + c + j];
-    }
-#pragma unroll
-    for (int v = 0; v < VMAX; ++v) {
-      // (ordered behind the previous visit's store by the memory clobber: one visit unpacked at a time here too; being opaque, the rows
-      // also cannot be paired with phase 1's du / xhat, which would otherwise be kept alive across the barrier)
-      asm volatile("" : "+v"(ua[v].x), "+v"(ua[v].y), "+v"(ua[v].z), "+v"(ua[v].w) : : "memory");
-      asm volatile("" : "+v"(uy[v].x), "+v"(uy[v].y), "+v"(uy[v].z), "+v"(uy[v].w) : : "memory");
-      const int64_t r = r0 + (int64_t)v * p.rows_per_pass;
-      const f32x8 a = unpack8(ua[v]), y = unpack8(uy[v]);
-      f32x8 o;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float u = y.v[j] * sc[j] + sh[j];
-        const float du = a.v[j] * act_bwd(u, ACT, p.ap);
-        const float xh = (y.v[j] - mu[j]) * is[j];
-        o.v[j] = sc[j] * (du - k1[j] - xh * k2[j]);
-      }
-      if (v < p.nv && r < p.M) *reinterpret_cast<uint4*>(p.dy + r * p.ld_dy + c) = pack8(o);
-    }
-  }
-  // ---- the last block to leave re-arms the barrier for the next launch ------------------------------------------------------------------
-  if (t == 0) {
-    const unsigned gone = __hip_atomic_fetch_add(p.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (gone == gridDim.x - 1) {
-      __hip_atomic_store(p.bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(p.bar + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
-// geometry of the resident form, or false: C / 8 channel vectors must be a power of two <= 512 (a block covers whole rows), the layer's
-// (dz, y) must fit the registers of one block per CU (<= 16 row visits per thread), and a tensor too small to give every CU a block gains nothing
-static bool bn_fused_geom(int64_t M, int C, int ncu, int* cols, int* rpp, int* nv, int* blocks) {
-  if (C < 64 || (C & 7) || C > kEwAccMaxC) return false;
-  const int CV = C >> 3;
-  if ((CV & (CV - 1)) || CV > kBnFusedThreads) return false;
-  *cols = CV;
-  *rpp = kBnFusedThreads / CV;
-  const int64_t passes = cdiv64(M, *rpp);          // row passes of one block-wide sweep
-  const int64_t v = cdiv64(passes, ncu);
-  if (v > 16 || passes < ncu) return false;   // (16 visits: 244 VGPRs; 26 would spill)
-  *nv = (int)v;
-  *blocks = (int)cdiv64(passes, v);
-  return true;
-}
-
 // Round 5 (lazy activations): a layer whose BN + activation apply pass is deferred into its consumers' loads still needs its
 // statistics finalized — mean | invstd | scale | shift for backward and for the consumers' prologues, running statistics updated.
 // The same arithmetic as block 0 of ew_kernel<0, ACT, true>'s prologue, as a launch of its own (C / 256 blocks).
@@ -1346,69 +1165,6 @@ int cvhip_bn_act_bwd_apply_acc(const void* dz, int32_t ld_dz, const void* y, int
   p.accumulate = accumulate;
   CVHIP_LAUNCH_ACT_ACC(ew_kernel, 1, act, dim3(ew_grid(M, C)), (hipStream_t)stream, p)
   return check_launch("ew_kernel<1,acc>");
-}
-
-static int bn_fused_cus() {
-  static int n = -1;
-  if (n < 0) {
-    int dev = 0;
-    hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) n = 0;
-    else n = pr.multiProcessorCount;
-  }
-  return n;
-}
-
-int cvhip_bn_act_bwd_fused_ok(int64_t M, int32_t C) {
-  int cols, rpp, nv, blocks;
-  const int ncu = bn_fused_cus();
-  return (ncu > 0 && M > 0 && bn_fused_geom(M, C, ncu, &cols, &rpp, &nv, &blocks)) ? 1 : 0;
-}
-
-int cvhip_bn_act_bwd_fused_acc(const void* dz, int32_t ld_dz, const void* y, int32_t ld_y, void* dy, int32_t ld_dy, int64_t M, int32_t C,
-                               const float* scale, const float* shift, const float* mean, const float* invstd, double* acc, int32_t acc_ld,
-                               float* dgamma, float* dbeta, int32_t accumulate, int32_t act, float act_param, uint32_t* barrier_ws, void* stream) {
-  if (!dz || !y || !dy || !scale || !shift || !mean || !invstd || !acc || !barrier_ws || M <= 0 || C <= 0 || acc_ld < C) return CVHIP_ERR_INVALID;
-  if ((ld_dz & 7) || (ld_y & 7) || (ld_dy & 7) || ((((uintptr_t)dz) | ((uintptr_t)y) | ((uintptr_t)dy)) & 15)) return CVHIP_ERR_UNSUPPORTED;
-  BnFusedParams p{};
-  int blocks = 0;
-  const int ncu = bn_fused_cus();
-  if (ncu <= 0 || !bn_fused_geom(M, C, ncu, &p.cols, &p.rows_per_pass, &p.nv, &blocks)) return CVHIP_ERR_UNSUPPORTED;
-  p.dz = (const h16_t*)dz;
-  p.y = (const h16_t*)y;
-  p.dy = (h16_t*)dy;
-  p.ld_dz = ld_dz;
-  p.ld_y = ld_y;
-  p.ld_dy = ld_dy;
-  p.M = M;
-  p.C = C;
-  p.scale = scale;
-  p.shift = shift;
-  p.mean = mean;
-  p.invstd = invstd;
-  p.ap = act_param;
-  p.inv_count = 1.f / (float)M;
-  p.acc = acc;
-  p.acc_ld = acc_ld;
-  p.o_dgamma = dgamma;
-  p.o_dbeta = dbeta;
-  p.accumulate = accumulate;
-  p.bar = barrier_ws;
-  hipStream_t s = (hipStream_t)stream;
-#define CVHIP_BNF_LAUNCH(ACTV, VM) hipLaunchKernelGGL((bn_bwd_fused_kernel<ACTV, VM>), dim3(blocks), dim3(kBnFusedThreads), 0, s, p)
-#define CVHIP_BNF_ACT(ACTV)                                    \
-  if (p.nv <= 8) CVHIP_BNF_LAUNCH(ACTV, 8);                    \
-  else CVHIP_BNF_LAUNCH(ACTV, 16);
-  switch (act) {
-    case CVHIP_ACT_SILU: CVHIP_BNF_ACT(CVHIP_ACT_SILU) break;
-    case CVHIP_ACT_RELU: CVHIP_BNF_ACT(CVHIP_ACT_RELU) break;
-    case CVHIP_ACT_LEAKY: CVHIP_BNF_ACT(CVHIP_ACT_LEAKY) break;
-    case CVHIP_ACT_NONE: CVHIP_BNF_ACT(CVHIP_ACT_NONE) break;
-    default: return CVHIP_ERR_UNSUPPORTED;
-  }
-#undef CVHIP_BNF_ACT
-#undef CVHIP_BNF_LAUNCH
-  return check_launch("bn_bwd_fused_kernel");
 }
 
 }  // extern "C"

@@ -120,8 +120,6 @@ SIGNATURES = {
     "cvhip_conv2d_patch_plan": (_i32, [_dp, _i32, C.POINTER(_i32), _i32]),
     "cvhip_conv2d_band_plan": (_i32, [_dp, _i32, C.POINTER(_i32)]),
     "cvhip_conv2d_wgrad_band_plan": (_i32, [_dp, C.POINTER(_i32)]),
-    "cvhip_bn_act_bwd_fused_ok": (_i32, [_i64, _i32]),
-    "cvhip_bn_act_bwd_fused_acc": (_i32, [_p, _i32, _p, _i32, _p, _i32, _i64, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _i32, _f32, _p, _p]),
     "cvhip_conv1x1_stream_prologue_ok": (_i32, [_dp, _i32]),
     "cvhip_conv2d_wgrad_stem_bn": (_i32, [_dp, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _i32, _f32, _p, _p]),
     "cvhip_bn_finalize_acc": (_i32, [_p, _i32, _i32, _i64, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _p]),

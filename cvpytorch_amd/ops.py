@@ -71,29 +71,6 @@ _acc_epoch = 0
 # layer and the finalize launches back: opt-in, like torch.use_deterministic_algorithms. (Depthwise weight gradients keep their
 # atomic epilogue.)
 _DETERMINISTIC = __import__("os").environ.get("CVHIP_DETERMINISTIC", "0") == "1"
-# (round 6) BN + activation backward of small layers as ONE resident launch (cvhip_bn_act_bwd_fused_acc: the layer's (dz, y) stay in
-# registers across a device-wide barrier): CVHIP_BN_FUSED_BWD=0 restores the two passes (A/B)
-_BN_FUSED_BWD = __import__("os").environ.get("CVHIP_BN_FUSED_BWD", "1") != "0"
-_bn_bar = {}
-
-
-def _bn_barrier_ws(dev):
-    """the fused BN backward's barrier words (three zeroed 32-bit words per device, re-armed by every launch)"""
-    key = str(dev)
-    t = _bn_bar.get(key)
-    if t is None:
-        t = _bn_bar[key] = torch.zeros((4,), dtype=torch.int32, device=dev)
-    return t
-
-
-def _bn_fused_bwd_ok(arena, M, K, Kp, dz, dz_ld, y):
-    """the one-launch BN backward runs single-stream steps only: with the gradient exchange live (arena.multi) communication kernels of a
-    parallel graph branch may hold blocks resident while the grid waits at its barrier"""
-    if not (_BN_FUSED_BWD and not _DETERMINISTIC and Kp == K and dz_ld % 8 == 0 and dz.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0):
-        return False
-    if arena is not None and getattr(arena, "multi", False):
-        return False
-    return L.load().cvhip_bn_act_bwd_fused_ok(M, K) == 1
 
 
 def set_deterministic(flag=True):
@@ -1522,10 +1499,7 @@ class ConvBnAct(torch.autograd.Function):
                 have = False
             if tail_sums_done:
                 have = True   # (the residual-tail pass above reduced while it masked)
-            stem_case = (_STEM_BN and not fused and not need_dx and need_dw and pointwise and not ctx.depthwise and Cc == 8 and x_ld == 8)
-            bn_one_launch = (not have and not fused and pointwise and not stem_case and cfg.sync is None
-                             and _bn_fused_bwd_ok(arena, M, K, Kp, dz, dz_ld, y))
-            if not have and not bn_one_launch:
+            if not have:
                 _timed_ew("bn_act_bwd_sums(colreduce_kernel<1>)", 4.0 * M * K, "cvhip_bn_act_bwd_sums_acc", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, M, K,
                           stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), act, act_param, acc_b.data_ptr(), K, st)
             if direct_bn:
@@ -1588,12 +1562,7 @@ class ConvBnAct(torch.autograd.Function):
                 dy = zero_fill(torch.empty((N, P, Q, Kp), dtype=ACT_DTYPE, device=dev)).permute(0, 3, 1, 2)[:, :K]
             else:
                 dy = empty_nhwc(N, K, P, Q, dev)
-            if acc_b is not None and bn_one_launch:
-                # sums + apply in one resident launch: (dz, y) are read once
-                _timed_ew("bn_act_bwd_fused(bn_bwd_fused_kernel)", 6.0 * M * K, "cvhip_bn_act_bwd_fused_acc", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, dy.data_ptr(), Kp,
-                          M, K, stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), acc_b.data_ptr(), K,
-                          g_out.data_ptr(), b_out.data_ptr(), accum, act, act_param, _bn_barrier_ws(dev).data_ptr(), st)
-            elif acc_b is not None:
+            if acc_b is not None:
                 _timed_ew("bn_act_bwd_apply(ew_kernel<1>)", 6.0 * M * K, "cvhip_bn_act_bwd_apply_acc", dz.data_ptr(), dz_ld, y.data_ptr(), Kp, dy.data_ptr(), Kp, M, K,
                           stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), acc_b.data_ptr(), K,
                           g_out.data_ptr(), b_out.data_ptr(), accum, act, act_param, st)
@@ -1758,33 +1727,22 @@ class ConvBnActPair(torch.autograd.Function):
             if "dirty" in have:   # sums were folded over a tensor that is not the gradient we received: start over
                 zero_fill(acc_b)
                 have = [False, False]
-            lzi = getattr(ctx, "in_lazy", None)
-            use_bwd1x1 = _bwd1x1_ok(ctx, cfg, x, ctx.needs_input_grad[0], True, False, segs) and (lzi is None or K <= 128)
-            # (round 6) a half whose (dz, y) fit one resident launch skips the reduction pass here: sums + apply run together below
-            one_launch = [(not use_bwd1x1 and not hv and _BN_FUSED_BWD and not _DETERMINISTIC and cfg.sync is None and not getattr(cfg.arena, "multi", False)
-                           and d_ld % 8 == 0 and ya_ld % 8 == 0 and Kp % 8 == 0 and off % 8 == 0 and d.data_ptr() % 16 == 0 and ya % 16 == 0
-                           and L.load().cvhip_bn_act_bwd_fused_ok(M, kh) == 1)
-                          for ((d, d_ld), kh, off), hv, (ya, ya_ld) in zip(halves, have, yat)]
-            for ((d, d_ld), kh, off), hv, (ya, ya_ld), one in zip(halves, have, yat, one_launch):
-                if hv or one:
+            for ((d, d_ld), kh, off), hv, (ya, ya_ld) in zip(halves, have, yat):
+                if hv:
                     continue
                 sc, sh, mean, invstd = (stats[i].data_ptr() + 4 * off for i in (2, 3, 0, 1))
                 _timed_ew("bn_act_bwd_sums(colreduce_kernel<1>)", 4.0 * M * kh, "cvhip_bn_act_bwd_sums_acc", d.data_ptr(), d_ld, ya, ya_ld, M, kh,
                           sc, sh, mean, invstd, cfg.act, cfg.act_param, acc_b.data_ptr() + 8 * off, K, st)
-            if use_bwd1x1:
+            lzi = getattr(ctx, "in_lazy", None)
+            if _bwd1x1_ok(ctx, cfg, x, ctx.needs_input_grad[0], True, False, segs) and (lzi is None or K <= 128):
                 dx, _ = _bwd1x1(ctx, cfg, x, y, weight, segs, ctx.k1, stats, True, None, None, cfg.act, cfg.act_param, acc_b, cfg.gg, cfg.gbeta, 1, xin=lzi,
                                 y1=y1)
             else:
                 if lzi is not None:
                     x = _materialize_tmp(x, x_ld, lzi)
                 dy = empty_nhwc(N, K, P, Q, dev)
-                for ((d, d_ld), kh, off), (ya, ya_ld), one in zip(halves, yat, one_launch):
+                for ((d, d_ld), kh, off), (ya, ya_ld) in zip(halves, yat):
                     sc, sh, mean, invstd = (stats[i].data_ptr() + 4 * off for i in (2, 3, 0, 1))
-                    if one:
-                        _timed_ew("bn_act_bwd_fused(bn_bwd_fused_kernel)", 6.0 * M * kh, "cvhip_bn_act_bwd_fused_acc", d.data_ptr(), d_ld, ya, ya_ld,
-                                  dy.data_ptr() + 2 * off, Kp, M, kh, sc, sh, mean, invstd, acc_b.data_ptr() + 8 * off, K,
-                                  cfg.gg.data_ptr() + 4 * off, cfg.gbeta.data_ptr() + 4 * off, 1, cfg.act, cfg.act_param, _bn_barrier_ws(dev).data_ptr(), st)
-                        continue
                     _timed_ew("bn_act_bwd_apply(ew_kernel<1>)", 6.0 * M * kh, "cvhip_bn_act_bwd_apply_acc", d.data_ptr(), d_ld, ya, ya_ld,
                               dy.data_ptr() + 2 * off, Kp, M, kh, sc, sh, mean, invstd, acc_b.data_ptr() + 8 * off, K,
                               cfg.gg.data_ptr() + 4 * off, cfg.gbeta.data_ptr() + 4 * off, 1, cfg.act, cfg.act_param, st)

@@ -665,18 +665,6 @@ int cvhip_bn_tail_bwd_sums_acc(const void* dz, int32_t ld_dz, const void* z_out,
 int cvhip_bn_act_bwd_apply_acc(const void* dz, int32_t ld_dz, const void* y, int32_t ld_y, void* dy, int32_t ld_dy, int64_t M, int32_t C,
                                const float* scale, const float* shift, const float* mean, const float* invstd, const double* acc,
                                int32_t acc_ld, float* dgamma, float* dbeta, int32_t accumulate, int32_t act, float act_param, void* stream);
-/* (round 6) cvhip_bn_act_bwd_sums_acc + cvhip_bn_act_bwd_apply_acc as ONE launch for layers whose (dz, y) fit the register file of one
- * block per CU: the slice stays resident across a device-wide barrier, so (dz, y) are read once (6 bytes per element instead of 10).
- * `barrier_ws`: three 32-bit words of caller memory, ZERO before the first call; the kernel leaves words 0 / 1 zero again, word 2 becomes
- * non-zero if a launch ever gave up waiting (never in a resident grid; results are then invalid). Must not run concurrently with another
- * launch that uses the same barrier words, nor next to kernels that keep blocks resident on most CUs for its whole duration (a
- * communication kernel on a parallel stream): callers use it on single-stream steps only.
- * cvhip_bn_act_bwd_fused_ok: 1 when the geometry is supported on this device (C / 8 a power of two, 64 <= C, <= 16 row visits per
- * thread of a 512-thread block per CU, at least one row pass per CU); otherwise the entry point returns CVHIP_ERR_UNSUPPORTED. */
-int cvhip_bn_act_bwd_fused_ok(int64_t M, int32_t C);
-int cvhip_bn_act_bwd_fused_acc(const void* dz, int32_t ld_dz, const void* y, int32_t ld_y, void* dy, int32_t ld_dy, int64_t M, int32_t C,
-                               const float* scale, const float* shift, const float* mean, const float* invstd, double* acc, int32_t acc_ld,
-                               float* dgamma, float* dbeta, int32_t accumulate, int32_t act, float act_param, uint32_t* barrier_ws, void* stream);
 /* cvhip_conv1x1_bwd_fused with the two sums taken from `acc` (K channels: both siblings'); `acc` may be NULL for a layer
  * without training-mode BatchNorm that still wants a tail */
 int cvhip_conv1x1_bwd_fused_acc(const cvhip_conv_desc* d, const void* dz0, int32_t dz0_ld, const void* dz1, int32_t dz1_ld, int32_t k_split,
