@@ -791,7 +791,7 @@ __global__ __launch_bounds__(NW * 64, WS ? 2 : igemm_min_waves(BM, BN, BK, NST, 
 //   * FAST staging (running DMA pointers, one tap decode per tap) wherever Cin % 32 == 0;
 //   * staged epilogue (output tile through the LDS, 16-byte row stores);
 //   * stride-parity classes of one spatial tile get consecutive tile ids (the half-line writes of interleaved pixels merge in one L2).
-template <int BM, int BN, int WM, int WN, int NWV = 4>
+template <int BM, int BN, int WM, int WN>
 static int launch_group(IgemmKernArgs& p, hipStream_t stream) {
   int total = 0;
   for (int i = 0; i < p.ncls; ++i) {
@@ -813,24 +813,16 @@ static int launch_group(IgemmKernArgs& p, hipStream_t stream) {
   if (p.ep_scale || p.ep_act != CVHIP_ACT_NONE) {
     // fused epilogue: the EPI instances of the same forms
     if (p.tail_y) return CVHIP_ERR_INVALID;
-    if constexpr (NWV == 8) return CVHIP_ERR_UNSUPPORTED;
-    else if (fast) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, NST, 32, true, 4, false, 0, true>), dim3(total), dim3(256), 0, stream, p);
+    if (fast) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, NST, 32, true, 4, false, 0, true>), dim3(total), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, NST, 32, false, 4, false, 0, true>), dim3(total), dim3(256), 0, stream, p);
     return check_launch("igemm_kernel(fused epilogue)");
   }
-  if constexpr (NWV == 8) {
-    // 256 x 256 block tile, eight waves of 128 x 64 (launch_igemm: large plain GEMMs): FAST staging only
-    if (!fast) return CVHIP_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, NST, 32, true, 8>), dim3(total), dim3(512), 0, stream, p);
-    return check_launch("igemm_kernel(256x256)");
-  } else {
-    if (fast) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, NST, 32, true>), dim3(total), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, NST>), dim3(total), dim3(256), 0, stream, p);
-    return check_launch("igemm_kernel");
-  }
+  if (fast) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, NST, 32, true>), dim3(total), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0, NST>), dim3(total), dim3(256), 0, stream, p);
+  return check_launch("igemm_kernel");
 }
 
-template <int BM, int BN, int WM, int WN, int NWV = 4>
+template <int BM, int BN, int WM, int WN>
 static int launch_cfg(IgemmParams& p, hipStream_t stream) {
   p.n_tiles = cdiv(p.Nout, BN);
   p.cin_magic = div_magic(p.Cin);
@@ -844,7 +836,7 @@ static int launch_cfg(IgemmParams& p, hipStream_t stream) {
   for (int first = 0; first < p.ncls; first += kKernelClasses) {
     const int count = p.ncls - first < kKernelClasses ? p.ncls - first : kKernelClasses;
     IgemmKernArgs k = narrow_plan(p, first, count);
-    const int st = launch_group<BM, BN, WM, WN, NWV>(k, stream);
+    const int st = launch_group<BM, BN, WM, WN>(k, stream);
     if (st) return st;
   }
   return CVHIP_OK;
@@ -883,13 +875,6 @@ int launch_igemm(IgemmParams& p, hipStream_t stream) {
     M += p.cls[i].M;
     const int k = p.cls[i].TR * p.cls[i].TS * p.Cin;
     ktot = k > ktot ? k : ktot;
-  }
-  {
-    // (dev A/B) 256 x 256 tiles for large plain GEMMs: wide outputs, a deep reduction, many tiles, no fused epilogue / tail
-    const char* e = getenv("CVHIP_IGEMM_T256");
-    if (e && atoi(e) == 1 && p.Nout % 256 == 0 && p.Cin % 32 == 0 && p.Cin <= kFastMaxCin && !p.ep_scale && p.ep_act == CVHIP_ACT_NONE && !p.tail_y &&
-        ((M + 255) / 256) * (p.Nout / 256) >= 512)
-      return launch_cfg<256, 256, 128, 64, 8>(p, stream);
   }
   if (igemm_block_m(p.Nout, M, ktot) == 256) return launch_cfg<256, 128, 128, 64>(p, stream);
   return launch_cfg<128, 128, 64, 64>(p, stream);
