@@ -616,6 +616,13 @@ static bool band_plan_nw(const IgemmParams& p, int NW, BandPlan* pl, bool* polic
   const int64_t rounds = (total + slots - 1) / slots;
   *policy_ok = n_tiles <= 2 && total * 10 >= rounds * slots * 9 &&                                 // >= 90 % of the block slots of every round busy
                (NC == 1 || (int64_t)TH * p.OW * 20 >= (int64_t)pl->MFW * WM * 16 * 17);          // >= 85 % of the fragment slots busy
+  // Round 6: DEEP reductions (>= 8 chunks of 32 input channels: ResNet layer3 / layer4 conv2, the ASPP / reduce convolutions) are where one
+  // barrier per nine K steps and weights straight into registers pay most and where the patch-resident / per-tap kernels are weakest, so
+  // the kernel wins with emptier rounds and waves too (DeepLabv3+ batch 16, profiles/r06_band_deep_policy.log: 256 -> 256 @32x64 45.9 vs
+  // 54.9 us, 512 -> 512 @16x32 53.9 vs 89.1 (per-tap 63.1), 2560 -> 512 @16x32 225.6 vs 372.7 (278.6); dgrad alike); the shallow
+  // 64- / 128-channel layers of the same network still lose (80.9 vs 69.8, 54.0 vs 49.9) and stay out.
+  if (!*policy_ok && NC >= 8 && n_tiles <= 32 && total * 10 >= rounds * slots * 7 && (int64_t)TH * p.OW * 4 >= (int64_t)pl->MFW * WM * 16 * 3)
+    *policy_ok = true;
   return true;
 }
 

@@ -92,8 +92,13 @@ def test_band_default_policy():
             pl = plan(shape, dgrad)
             assert pl is not None and pl["NF"] == 2 and pl["PF"] == 0 and (pl["NW"], pl["TH"], pl["total"]) == (nw, th, total), (shape, pl)
             assert pl["total"] % (512 if nw == 4 else 256) == 0
-    for shape in ((16, 128, 64, 128, 128), (16, 64, 128, 256, 64), (16, 256, 32, 64, 256), (16, 512, 32, 64, 512)):
-        assert plan(shape) is None, shape
+    for shape in ((16, 128, 64, 128, 128), (16, 64, 128, 256, 64)):
+        assert plan(shape) is None, shape        # shallow reductions with idle fragment slots: the patch-resident / per-tap kernels stay faster
+    # round 6: DEEP reductions (>= 8 chunks of 32 channels) are taken with emptier rounds / waves too (profiles/r06_band_deep_policy.log)
+    for shape, dil in (((16, 256, 32, 64, 256), 1), ((16, 512, 16, 32, 512), 1), ((16, 2560, 16, 32, 512), 1), ((16, 512, 32, 64, 512), 2)):
+        for dgrad in (False, True):
+            pl = plan(shape, dgrad, dil, dil)
+            assert pl is not None and pl["NF"] == 2, (shape, dgrad)
     assert plan((64, 128, 40, 40, 128), CVHIP_BAND_NW=8)["NW"] == 8
     assert plan((64, 128, 40, 40, 128), CVHIP_BAND=0) is None
     # stride 2, 1x1 and grouped convolutions never reach the kernel
