@@ -362,8 +362,8 @@ static bool wgband_plan(const cvhip_conv_desc* d, WgBandPlan* pl) {
   const int64_t M = (int64_t)d->N * d->H * d->W;
   if (M >= (1ll << 30) || M < kWbRange) return false;
   if (wgband_mode() < 2 && M < 4096) return false;   // default policy: small problems stay on the general kernel
-  const int KF = (d->K & 63) ? 2 : 4;
-  const int KT = 16 * KF;
+  int KF = (d->K & 63) ? 2 : 4;
+  int KT = 16 * KF;
   WgBandArgs& a = pl->a;
   memset(&a, 0, sizeof(a));
   a.NB = d->N;
@@ -389,6 +389,16 @@ static bool wgband_plan(const cvhip_conv_desc* d, WgBandPlan* pl) {
   if (a.nxp > kWbXPieces * kWbWaves) return false;
   a.xbuf = a.nxp * 1024;
   a.dbuf = kWbRange * KT * 2;
+  if (KF == 4 && 2 * (a.xbuf + a.dbuf) > kWbLdsMax) {
+    // wide rows (128 - 200 pixels: the patch of a range is 50 - 63 KB): the 32-channel output tile's dY rows are half as long, and two
+    // [dY | patch] buffers fit again — 18 instead of 36 MFMAs per step and wave, still ahead of the general kernel (YOLOv7-l's 160-pixel
+    // rows, DeepLabv3+'s 128-pixel rows: profiles/r06_wgrad_band_wide.log) — on the smaller problems only: with many tiles x pixels the
+    // 18-MFMA steps lose to the general kernel's 128-wide tile (128 -> 128 @160x160 batch 16: 232 vs 224 us, 256 -> 256: 834 vs 741)
+    if (wgband_mode() < 2 && (double)M * (d->K / 32) * (d->C / 32) > 4.0e6) return false;
+    KF = 2;
+    KT = 32;
+    a.dbuf = kWbRange * KT * 2;
+  }
   const int fold = 4 * KF * 9 * 64 * 16;
   int lds = 2 * (a.xbuf + a.dbuf);
   if (lds < fold) lds = fold;

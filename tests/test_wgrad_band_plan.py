@@ -58,11 +58,15 @@ def test_plan_invariants(shape, dil):
         rows = (RANGE - 1 + W - 1) // W + 1
         ph = rows + (rows + H - 1) // H * dil + 2 * dil
         nxp = (ph * pw + 15) // 16
-        kt = 64 if K % 64 == 0 else 32
-        assert nxp > 64 or 2 * (nxp * 1024 + RANGE * kt * 2) > 159 * 1024, (shape, dil)
+        assert nxp > 64 or 2 * (nxp * 1024 + RANGE * 32 * 2) > 159 * 1024, (shape, dil)   # not even the 32-channel tile's buffers fit
         return
     kt = 16 * pl["KF"]
-    assert pl["KF"] == (4 if K % 64 == 0 else 2)
+    # 64-channel output tiles where K allows AND two [dY | patch] buffers fit; the 32-channel tile otherwise (wide rows: round 6)
+    pw0 = (W + 2 * dil + 7) // 8 * 8
+    rows0 = (RANGE - 1 + W - 1) // W + 1
+    nxp0 = ((rows0 + (rows0 + H - 1) // H * dil + 2 * dil) * pw0 + 15) // 16
+    fits64 = 2 * (nxp0 * 1024 + RANGE * 64 * 2) <= 159 * 1024
+    assert pl["KF"] == (4 if (K % 64 == 0 and fits64) else 2)
     assert pl["tiles"] == (K // kt) * (Cc // 32)
     assert pl["blocks"] == pl["tiles"] * pl["splits"]
     total_ranges = -(-M // RANGE)
@@ -90,6 +94,9 @@ def test_default_policy_and_refusals():
     assert plan((2, 64, 20, 20, 64), 1, pad=0) is None                           # not "same"
     assert plan((2, 48, 20, 20, 64), 1) is None and plan((2, 64, 20, 20, 40), 1) is None   # channel counts
     assert plan((1, 64, 8, 8, 64), 1) is None                                    # fewer pixels than one range
+    # wide rows: the 32-channel-tile fallback is taken by default on the smaller problems only (profiles/r06_wgrad_band_wide.log)
+    assert plan((16, 128, 64, 128, 128), 1, mode="1")["KF"] == 2 and plan((16, 64, 160, 160, 64), 1, mode="1")["KF"] == 2
+    assert plan((16, 128, 160, 160, 128), 1, mode="1") is None and plan((16, 128, 160, 160, 128), 1, mode="2")["KF"] == 2
 
 
 # ---- the kernel's addressing, restated -------------------------------------------------------------------------------------------------
