@@ -67,6 +67,10 @@ struct BandArgs {
   int stats_ld;
   const h16_t* res;
   int res_ld;
+  // fused epilogue (EPI instances, round 6): out = act(acc * ep_scale + ep_shift) with `res` joining before (res_pre) or after the activation
+  const float *ep_scale, *ep_shift, *bias;   // (the bias folds into the shift: (acc + b) * s + t = acc * s + (b * s + t))
+  int ep_act, res_pre;
+  float ep_ap;
   int NB, IH, IW, Cin, x_ld;
   int Nout, y_ld, OH, OW;
   int dh0, dh_step, dw0, dw_step, lo_h, lo_w;
@@ -135,7 +139,35 @@ __device__ __forceinline__ int band_div(int n, unsigned magic) { return magic ? 
 // NW : waves per block. 8 = one block per CU (256 VGPRs per wave at two waves per SIMD). 4 = half-height bands in 256-thread blocks, two
 //      of them resident per CU (the same registers per wave, <= 78 KB of LDS each): the same per-CU work, but the two blocks are not
 //      coupled by barriers — one's prologue, chunk barriers and store epilogue can run under the other's MFMAs.
-template <int WN, int MFW, int PPS, int NF = 2, int LEAD = 2, int PF = 0, int NW = 8>
+// EPI: fused-epilogue instance (inference: folded BatchNorm scale / shift + activation + residual in the convolution's own pass:
+//      conv_module.py:201-214 in eval mode, utils/fuse.py:32-54); the training instances carry none of its code
+__device__ __forceinline__ void band_act4(float (&v)[4], int act, float ap) {
+  switch (act) {
+    case CVHIP_ACT_NONE: break;
+    case CVHIP_ACT_RELU:
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = act_fwd(v[q], CVHIP_ACT_RELU, ap);
+      break;
+    case CVHIP_ACT_SILU:
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = act_fwd(v[q], CVHIP_ACT_SILU, ap);
+      break;
+    case CVHIP_ACT_LEAKY:
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = act_fwd(v[q], CVHIP_ACT_LEAKY, ap);
+      break;
+    case CVHIP_ACT_SIGMOID:
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = act_fwd(v[q], CVHIP_ACT_SIGMOID, ap);
+      break;
+    default:
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = act_fwd(v[q], CVHIP_ACT_HSWISH, ap);
+      break;
+  }
+}
+
+template <int WN, int MFW, int PPS, int NF = 2, int LEAD = 2, int PF = 0, int NW = 8, bool EPI = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv_band_kernel(const BandArgs p) {
   constexpr int kBandWaves = NW;
   static_assert(NW == 4 || NW == 8, "waves per block");
@@ -406,6 +438,17 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_band_kernel(const BandArgs p)
   // ---- epilogue ---------------------------------------------------------------------------------------------------------
   const int chb = n0 + wn * (16 * NF) + g * 4;  // + a*16: first of the lane's 4 consecutive output channels
   const bool r8 = p.res != nullptr;
+  float esc[EPI ? NF : 1][4], esh[EPI ? NF : 1][4];
+  if constexpr (EPI) {
+#pragma unroll
+    for (int a = 0; a < NF; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        esc[a][q] = p.ep_scale ? p.ep_scale[chb + a * 16 + q] : 1.f;
+        esh[a][q] = p.ep_shift ? p.ep_shift[chb + a * 16 + q] : 0.f;
+        if (p.bias) esh[a][q] += p.bias[chb + a * 16 + q] * esc[a][q];
+      }
+  }
 #pragma unroll
   for (int b = 0; b < MFW; ++b) {
     const int q = ((f0 + b) << 4) + (lane & 15);
@@ -417,11 +460,32 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_band_kernel(const BandArgs p)
 #pragma unroll
       for (int a = 0; a < NF; ++a) {
         float v0 = acc[a][b][0], v1 = acc[a][b][1], v2 = acc[a][b][2], v3 = acc[a][b][3];
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
         if (r8) {
           const uint2 u = *reinterpret_cast<const uint2*>(p.res + opix * p.res_ld + chb + a * 16);
-          float r0, r1, r2, r3;
           unpack2(u.x, r0, r1);
           unpack2(u.y, r2, r3);
+        }
+        if constexpr (EPI) {
+          float v[4] = {v0 * esc[a][0] + esh[a][0], v1 * esc[a][1] + esh[a][1], v2 * esc[a][2] + esh[a][2], v3 * esc[a][3] + esh[a][3]};
+          if (p.res_pre) {   // residual before the activation (ResNet bottleneck tail)
+            v[0] += r0;
+            v[1] += r1;
+            v[2] += r2;
+            v[3] += r3;
+          }
+          band_act4(v, p.ep_act, p.ep_ap);
+          if (!p.res_pre) {  // Darknet shortcut: x + act(bn(conv))
+            v[0] += r0;
+            v[1] += r1;
+            v[2] += r2;
+            v[3] += r3;
+          }
+          v0 = v[0];
+          v1 = v[1];
+          v2 = v[2];
+          v3 = v[3];
+        } else {
           v0 += r0;
           v1 += r1;
           v2 += r2;
@@ -630,7 +694,9 @@ static bool band_plan(const IgemmParams& p, BandPlan* pl) {
   if (p.ncls != 1 || p.in_sh != 1 || p.in_sw != 1 || p.out_sh != 1 || p.out_sw != 1) return false;
   const IgemmClass& c = p.cls[0];
   if (c.TR != 3 || c.TS != 3 || c.out_oh != 0 || c.out_ow != 0 || c.OHi != p.OH || c.OWi != p.OW || c.M <= 0) return false;
-  if (p.bias || p.ep_scale || p.ep_shift || p.ep_act != CVHIP_ACT_NONE || p.pro_scale || p.z_out || p.y2 || p.x_image || p.tail_y) return false;
+  if (p.pro_scale || p.z_out || p.y2 || p.x_image || p.tail_y) return false;
+  if ((p.ep_scale == nullptr) != (p.ep_shift == nullptr)) return false;
+  if ((p.bias || p.ep_scale || p.ep_act != CVHIP_ACT_NONE) && p.stats) return false;   // (BN sums are those of the raw accumulators: never with an epilogue)
   if (p.stats && !p.stats_acc) return false;
   if (!p.band_image) return false;   // the fragment-ordered weight copy exists for this layer (conv_plan.h: band_image_fprop / _dgrad)
   if ((p.Cin & 31) || (p.x_ld & 7) || (((uintptr_t)p.x) & 15) || (((uintptr_t)p.w) & 15) || (c.w_off & 7)) return false;
@@ -652,9 +718,9 @@ static bool band_plan(const IgemmParams& p, BandPlan* pl) {
   return false;
 }
 
-template <int WN, int MFW, int PPS, int NF, int LEAD, int PF, int NW>
+template <int WN, int MFW, int PPS, int NF, int LEAD, int PF, int NW, bool EPI = false>
 static int band_launch(const BandPlan& pl, hipStream_t stream) {
-  auto kern = conv_band_kernel<WN, MFW, PPS, NF, LEAD, PF, NW>;
+  auto kern = conv_band_kernel<WN, MFW, PPS, NF, LEAD, PF, NW, EPI>;
   static bool attr_done[64] = {};
   int devid = 0;
   (void)hipGetDevice(&devid);
@@ -671,22 +737,22 @@ static int band_launch(const BandPlan& pl, hipStream_t stream) {
   return check_launch("conv_band_kernel");
 }
 
-template <int WN, int NW>
+template <int WN, int NW, bool EPI>
 static int band_launch_narrow(const BandPlan& pl, hipStream_t stream) {  // NF = 2: 32 channels per wave
   if constexpr (WN <= NW) {
-    if (pl.MFW == 7) return pl.PPS == 1 ? band_launch<WN, 7, 1, 2, 2, 0, NW>(pl, stream) : band_launch<WN, 7, 2, 2, 2, 0, NW>(pl, stream);
-    if (pl.MFW == 10) return pl.PPS == 1 ? band_launch<WN, 10, 1, 2, 2, 0, NW>(pl, stream) : band_launch<WN, 10, 2, 2, 2, 0, NW>(pl, stream);
-    return pl.PPS == 1 ? band_launch<WN, 13, 1, 2, 2, 0, NW>(pl, stream) : band_launch<WN, 13, 2, 2, 2, 0, NW>(pl, stream);
+    if (pl.MFW == 7) return pl.PPS == 1 ? band_launch<WN, 7, 1, 2, 2, 0, NW, EPI>(pl, stream) : band_launch<WN, 7, 2, 2, 2, 0, NW, EPI>(pl, stream);
+    if (pl.MFW == 10) return pl.PPS == 1 ? band_launch<WN, 10, 1, 2, 2, 0, NW, EPI>(pl, stream) : band_launch<WN, 10, 2, 2, 2, 0, NW, EPI>(pl, stream);
+    return pl.PPS == 1 ? band_launch<WN, 13, 1, 2, 2, 0, NW, EPI>(pl, stream) : band_launch<WN, 13, 2, 2, 2, 0, NW, EPI>(pl, stream);
   } else {
     return CVHIP_ERR_UNSUPPORTED;
   }
 }
 
-template <int NW>
+template <int NW, bool EPI>
 static int band_launch_nw(const BandPlan& pl, hipStream_t stream) {
-  if (pl.WN == 4) return band_launch_narrow<4, NW>(pl, stream);
-  if (pl.WN == 2) return band_launch_narrow<2, NW>(pl, stream);
-  return band_launch_narrow<1, NW>(pl, stream);
+  if (pl.WN == 4) return band_launch_narrow<4, NW, EPI>(pl, stream);
+  if (pl.WN == 2) return band_launch_narrow<2, NW, EPI>(pl, stream);
+  return band_launch_narrow<1, NW, EPI>(pl, stream);
 }
 
 // plan query (api.hip cvhip_conv2d_band_plan): {NF, WN, MFW, PPS, PF, TH, bands, n_tiles, total_tiles, lds bytes, PH, PW, NW}
@@ -714,7 +780,14 @@ int try_launch_band(const IgemmParams& p, hipStream_t stream) {
   a.stats_ld = p.stats_ld;
   a.res = p.res;
   a.res_ld = p.res_ld;
-  return pl.NW == 4 ? band_launch_nw<4>(pl, stream) : band_launch_nw<8>(pl, stream);
+  a.ep_scale = p.ep_scale;
+  a.ep_shift = p.ep_shift;
+  a.bias = p.bias;
+  a.ep_act = p.ep_act;
+  a.ep_ap = p.ep_ap;
+  a.res_pre = p.res_pre;
+  if (p.bias || p.ep_scale || p.ep_act != CVHIP_ACT_NONE) return pl.NW == 4 ? band_launch_nw<4, true>(pl, stream) : band_launch_nw<8, true>(pl, stream);
+  return pl.NW == 4 ? band_launch_nw<4, false>(pl, stream) : band_launch_nw<8, false>(pl, stream);
 }
 
 }  // namespace cvhip

@@ -70,8 +70,7 @@ BAND_CASES = [
 
 @pytest.mark.parametrize("case", BAND_CASES)
 def test_band_fprop(case, force_band):
-    """plain forward, no bias (a bias sends the problem to the other kernels: the band kernel has no bias epilogue — ConvModule
-    convolutions in front of a norm layer carry none, conv_module.py:112-119)"""
+    """plain forward, no bias (ConvModule convolutions in front of a norm layer carry none, conv_module.py:112-119)"""
     _skip_unless_form_runs(case, force_band, False)
     N, Cc, H, W, Kk, R, S, s, p, d = case
     x, w = K._mk(case)
@@ -88,6 +87,78 @@ def test_band_fprop(case, force_band):
     assert torch.isfinite(got).all()
     assert max_rel(got, ref) < 2 ** -7, max_rel(got, ref)
     assert rel_l2(got, ref) < 4e-3
+
+
+def _act(u, act):
+    if act == L.ACT_RELU:
+        return torch.relu(u)
+    if act == L.ACT_SILU:
+        return u * torch.sigmoid(u)
+    if act == L.ACT_LEAKY:
+        return torch.where(u > 0, u, 0.1 * u)
+    if act == L.ACT_SIGMOID:
+        return torch.sigmoid(u)
+    if act == L.ACT_HSWISH:
+        return u * torch.clamp(u + 3, 0, 6) / 6
+    return u
+
+
+def _fused(desc, xd, wimg, y, **kw):
+    f = L.ConvFuse()
+    keep = []
+    for k, v in kw.items():
+        if torch.is_tensor(v):
+            keep.append(v)
+            v = v.data_ptr()
+        setattr(f, k, v)
+    return L.fn("cvhip_conv2d_fprop_fused")(C.byref(desc), xd.data_ptr(), wimg.data_ptr(), y.data_ptr(), C.byref(f), ops._stream())
+
+
+@pytest.mark.parametrize("act", [L.ACT_SILU, L.ACT_RELU, L.ACT_LEAKY, L.ACT_HSWISH, L.ACT_SIGMOID, L.ACT_NONE])
+@pytest.mark.parametrize("case", [BAND_CASES[0], BAND_CASES[2], BAND_CASES[4], BAND_CASES[6], BAND_CASES[8], BAND_CASES[10]])
+def test_band_fused_epilogue(case, act, force_band):
+    """inference form (round 6): y = act((conv(x) + bias) * scale + shift) (+ residual before or after the activation) in the band
+    kernel's own store pass — the eval-mode ConvModule (conv_module.py:201-214), the Darknet shortcut x + act(bn(conv)) and the ResNet
+    tail relu(bn(conv) + identity)"""
+    _skip_unless_form_runs(case, force_band, False)
+    N, Cc, H, W, Kk, R, S, s, p, d = case
+    x, w = K._mk(case, 21)
+    g = torch.Generator().manual_seed(22)
+    bias = torch.randn(Kk, generator=g) * 0.2
+    sc = torch.rand(Kk, generator=g) + 0.5
+    sh = torch.randn(Kk, generator=g) * 0.3
+    conv = F.conv2d(x, w, None, stride=s, padding=p, dilation=d)
+    P, Q = conv.shape[2:]
+    res = rnd(torch.randn(N, Kk, P, Q, generator=g))
+    st, Kp = K._prep(case, w, False)
+    xd, resd = to_nhwc_dev(x), to_nhwc_dev(res)
+    desc = ops.conv_desc(N, Cc, H, W, Kk, R, S, (s, s), (p, p), (d, d), 1, Cc, Kk)
+    scd, shd, bd = sc.to(dev()), sh.to(dev()), bias.to(dev())
+    v = lambda t: t.view(1, -1, 1, 1)
+
+    def run(**kw):
+        out = ops.empty_nhwc(N, Kk, P, Q, dev())
+        out.fill_(float("nan"))
+        L.check(_fused(desc, xd, st.w_fprop, out, **kw), "cvhip_conv2d_fprop_fused")
+        torch.cuda.synchronize()
+        return out.float().cpu()
+
+    def close(got, ref):
+        assert torch.isfinite(got).all()
+        assert max_rel(got, ref) < 2 ** -7, max_rel(got, ref)
+        assert rel_l2(got, ref) < 4e-3
+
+    # folded BatchNorm + activation
+    close(run(ep_scale=scd, ep_shift=shd, ep_act=act, ep_act_param=0.1), _act(conv * v(sc) + v(sh), act))
+    # + bias, + residual after the activation (Darknet shortcut)
+    close(run(bias=bd, ep_scale=scd, ep_shift=shd, ep_act=act, ep_act_param=0.1, residual=resd, residual_ld=Kk),
+          _act((conv + v(bias)) * v(sc) + v(sh), act) + res)
+    # residual before the activation (ResNet tail)
+    close(run(ep_scale=scd, ep_shift=shd, ep_act=act, ep_act_param=0.1, residual=resd, residual_ld=Kk, residual_pre=1),
+          _act(conv * v(sc) + v(sh) + res, act))
+    # activation only / bias only
+    close(run(ep_act=act, ep_act_param=0.1), _act(conv, act))
+    close(run(bias=bd), conv + v(bias))
 
 
 @pytest.mark.parametrize("case", BAND_CASES)
