@@ -19,7 +19,8 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3  # us
 
 
-for (N, H, C) in [(64, 160, 64), (64, 320, 32), (64, 80, 128), (64, 40, 256), (64, 20, 512)]:
+SHAPES = [(64, 160, 64), (64, 320, 32), (64, 80, 128), (64, 40, 256), (64, 20, 512), (64, 80, 64), (64, 40, 128), (64, 20, 256)]
+for (N, H, C) in SHAPES:
     M = N * H * H
     y = torch.randn(M, C, device=dev).to(torch.bfloat16)
     dz = torch.randn(M, C, device=dev).to(torch.bfloat16)
