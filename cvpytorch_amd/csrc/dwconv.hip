@@ -591,9 +591,22 @@ __global__ __launch_bounds__((kDwLdsCW + 1) * 64) void dw3x3_lds_kernel(const Dw
   const int CV = p.C >> 3;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  int b = blockIdx.x;
-  const int cvc = b % g.ncv;
-  b /= g.ncv;
+  // The channel chunks of one strip share cache lines wherever a chunk boundary is not 128-byte aligned (560 channels: 35 + 35 vectors
+  // at a 1120-byte pixel pitch). Blocks are dealt round-robin to the 8 XCDs, each with its own L2: blocks i and i + 8 of a group of
+  // 8 * ncv take the chunks of the same strip, so the shared lines are fetched (and the partial output lines merged) in ONE L2.
+  int b = blockIdx.x, cvc;
+  {
+    const int rest_all = gridDim.x / g.ncv, r8 = rest_all & ~7;
+    if (b < r8 * g.ncv) {
+      const int lo = b & 7, hi = b >> 3;
+      cvc = hi % g.ncv;
+      b = (hi / g.ncv) * 8 + lo;
+    } else {
+      const int tl = b - r8 * g.ncv;
+      cvc = tl % g.ncv;
+      b = r8 + tl / g.ncv;
+    }
+  }
   const int strip = b % g.nstrip;
   b /= g.nstrip;
   const int rowblk = b % g.nrowblk;
@@ -773,8 +786,13 @@ static bool dw3_lds_launch(const Dw3Params& q, hipStream_t s, int* status) {
   constexpr int PXT = MODE == 1 ? 2 : 3;
   const int CV = q.C >> 3;
   Dw3LdsGeom g;
-  g.cols = CV < 64 ? CV : 64;
-  g.ncv = (CV + g.cols - 1) / g.cols;
+  // channel chunks of equal width (560 channels = 70 vectors ran as 64 + 6: half of the blocks moved 9 % of the bytes at the full
+  // per-row latency), at most kColsMax vectors wide: narrower chunks leave more pixel lanes, i.e. wider strips and less column halo
+  // (measured on rotating 560- / 512- / 304- / 256-channel 16 x 128 x 256 tensors, tools/dw_bench_cold.py, profiles/r06_dw_chunks.log:
+  // the weight gradient 326 / 309 / 195 / 222 us at 64 -> 255 / 234 / 166 / 192 at 24; fprop / dgrad flat within the noise)
+  constexpr int cols_max = MODE == 1 ? 24 : 64;
+  g.ncv = (CV + cols_max - 1) / cols_max;
+  g.cols = (CV + g.ncv - 1) / g.ncv;
   g.rpp = (kDwLdsCW * 64) / g.cols;
   g.TW = g.rpp * PXT;
   if (q.OW < g.TW || q.OH < 8) return false;  // small maps: the strip would be mostly halo

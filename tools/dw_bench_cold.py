@@ -6,8 +6,8 @@ import torch
 from cvpytorch_amd import ops, lib as L
 dev = torch.device("cuda:0")
 BF = torch.bfloat16
-NSET = int(os.environ.get("NSET", "6"))
-SHAPES = [(16, 304, 128, 256), (16, 256, 128, 256)]
+NSET = int(os.environ.get("NSET", "4"))
+SHAPES = [(16, 560, 128, 256), (16, 512, 128, 256), (16, 304, 128, 256), (16, 256, 128, 256)]
 if os.environ.get("MORE"):
     SHAPES += [(16, 128, 64, 128), (16, 512, 32, 64), (64, 256, 40, 40)]
 for (N, Cc, H, W) in SHAPES:
