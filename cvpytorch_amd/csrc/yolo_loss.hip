@@ -187,6 +187,44 @@ __global__ __launch_bounds__(1024) void yolo_cand_reduce_kernel(const YoloLossPa
   }
 }
 
+// ---- backward of stage B as ONE streaming pass over the head gradient (round 6) --------------------------------------------------
+// The gradient map is zero except the objectness channel of every anchor (dense) and the box / class channels of the matched cells
+// (sparse, yolo_cand_bwd_kernel afterwards). Before: a zero-fill of the whole map (275 MB for the three YOLOv5-s levels at batch 64)
+// followed by a pass that read the objectness logits and wrote 2-byte gradients at a 170-byte stride. Here a lane owns one 16-byte
+// channel vector of one pixel and stores it once — zeros, or zeros with the objectness gradient of the anchor whose channel falls
+// inside: the map is written exactly once, fully coalesced; same fp32 formula and rounding as yolo_obj_kernel<true>.
+__global__ __launch_bounds__(256) void yolo_obj_bwd_fill_kernel(const YoloLossParams p) {
+  const int VP = p.ld >> 3;  // 16-byte vectors per pixel
+  const int64_t nvec = (int64_t)p.N * p.H * p.W * VP;
+  const float go = (p.gout ? p.gout[0] : 1.f) * p.k_obj;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const int64_t pix = i / VP;
+    const int v = (int)(i - pix * VP);
+    const int c0 = v * 8;
+    h16_t out[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] = (h16_t)0.f;
+    for (int a = 0; a < p.A; ++a) {
+      const int oc = a * p.NO + 4;
+      if (oc >= c0 && oc < c0 + 8) {
+        const int gi = (int)(pix % p.W);
+        int64_t r = pix / p.W;
+        const int gj = (int)(r % p.H);
+        const int n = (int)(r / p.H);
+        const int64_t cellidx = (((int64_t)n * p.A + a) * p.H + gj) * p.W + gi;
+        const float x = (float)p.raw[pix * p.ld + oc];
+        const int w = p.winner[cellidx];
+        const float tt = w > 0 ? fmaxf(p.cand[(int64_t)(w - 1) * kCandStride], 0.f) : 0.f;
+        const h16_t gq = (h16_t)((sigmoid_ref(x) - tt) * go);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (c0 + j == oc) out[j] = gq;
+      }
+    }
+    *reinterpret_cast<uint4*>(p.draw + pix * p.ld + c0) = *reinterpret_cast<const uint4*>(out);
+  }
+}
+
 // ---- stage B: objectness over every cell ------------------------------------------------------------------
 template <bool BWD>
 __global__ __launch_bounds__(256) void yolo_obj_kernel(const YoloLossParams p) {
@@ -411,10 +449,16 @@ int cvhip_yolov5_loss_level_bwd(const cvhip_yolo_loss_desc* d, const void* raw, 
   p.k_obj = k_obj;
   hipStream_t st = (hipStream_t)stream;
   const int64_t ncell = (int64_t)p.N * p.A * p.H * p.W;
-  rc = zero_fill(p.draw, (int64_t)p.N * p.H * p.W * p.ld * 2, st);
-  if (rc != CVHIP_OK) return rc;
-  const int nb = (int)(cdiv64(ncell, 256) < 8192 ? cdiv64(ncell, 256) : 8192);
-  hipLaunchKernelGGL(yolo_obj_kernel<true>, dim3(nb), dim3(256), 0, st, p);
+  if ((p.ld & 7) == 0 && (((uintptr_t)p.draw) & 15) == 0) {
+    const int64_t nvec = (int64_t)p.N * p.H * p.W * (p.ld >> 3);
+    const int nbf = (int)(cdiv64(nvec, 256 * 4) < 8192 ? cdiv64(nvec, 256 * 4) : 8192);
+    hipLaunchKernelGGL(yolo_obj_bwd_fill_kernel, dim3(nbf > 0 ? nbf : 1), dim3(256), 0, st, p);
+  } else {
+    rc = zero_fill(p.draw, (int64_t)p.N * p.H * p.W * p.ld * 2, st);
+    if (rc != CVHIP_OK) return rc;
+    const int nb = (int)(cdiv64(ncell, 256) < 8192 ? cdiv64(ncell, 256) : 8192);
+    hipLaunchKernelGGL(yolo_obj_kernel<true>, dim3(nb), dim3(256), 0, st, p);
+  }
   hipLaunchKernelGGL(yolo_cand_bwd_kernel, dim3(cdiv(p.ncand, 4)), dim3(256), 0, st, p);
   return check_launch("yolov5_loss_level_bwd");
 }
