@@ -193,12 +193,15 @@ __global__ __launch_bounds__(1024) void yolo_cand_reduce_kernel(const YoloLossPa
 // followed by a pass that read the objectness logits and wrote 2-byte gradients at a 170-byte stride. Here a lane owns one 16-byte
 // channel vector of one pixel and stores it once — zeros, or zeros with the objectness gradient of the anchor whose channel falls
 // inside: the map is written exactly once, fully coalesced; same fp32 formula and rounding as yolo_obj_kernel<true>.
+// IT: index type of the flat walks below — unsigned 32-bit whenever the element count allows (the 64-bit divisions by run-time values
+// cost ~100 instructions each; every launch of the benchmarked configurations takes the 32-bit instance)
+template <typename IT>
 __global__ __launch_bounds__(256) void yolo_obj_bwd_fill_kernel(const YoloLossParams p) {
-  const int VP = p.ld >> 3;  // 16-byte vectors per pixel
-  const int64_t nvec = (int64_t)p.N * p.H * p.W * VP;
+  const IT VP = (IT)(p.ld >> 3);  // 16-byte vectors per pixel
+  const IT nvec = (IT)p.N * (IT)p.H * (IT)p.W * VP;
   const float go = (p.gout ? p.gout[0] : 1.f) * p.k_obj;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
-    const int64_t pix = i / VP;
+  for (IT i = (IT)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (IT)gridDim.x * 256) {
+    const IT pix = i / VP;
     const int v = (int)(i - pix * VP);
     const int c0 = v * 8;
     h16_t out[8];
@@ -207,12 +210,12 @@ __global__ __launch_bounds__(256) void yolo_obj_bwd_fill_kernel(const YoloLossPa
     for (int a = 0; a < p.A; ++a) {
       const int oc = a * p.NO + 4;
       if (oc >= c0 && oc < c0 + 8) {
-        const int gi = (int)(pix % p.W);
-        int64_t r = pix / p.W;
-        const int gj = (int)(r % p.H);
-        const int n = (int)(r / p.H);
+        const IT r = pix / (IT)p.W;
+        const int gi = (int)(pix - r * (IT)p.W);
+        const int n = (int)(r / (IT)p.H);
+        const int gj = (int)(r - (IT)n * (IT)p.H);
         const int64_t cellidx = (((int64_t)n * p.A + a) * p.H + gj) * p.W + gi;
-        const float x = (float)p.raw[pix * p.ld + oc];
+        const float x = (float)p.raw[(int64_t)pix * p.ld + oc];
         const int w = p.winner[cellidx];
         const float tt = w > 0 ? fmaxf(p.cand[(int64_t)(w - 1) * kCandStride], 0.f) : 0.f;
         const h16_t gq = (h16_t)((sigmoid_ref(x) - tt) * go);
@@ -221,25 +224,25 @@ __global__ __launch_bounds__(256) void yolo_obj_bwd_fill_kernel(const YoloLossPa
           if (c0 + j == oc) out[j] = gq;
       }
     }
-    *reinterpret_cast<uint4*>(p.draw + pix * p.ld + c0) = *reinterpret_cast<const uint4*>(out);
+    *reinterpret_cast<uint4*>(p.draw + (int64_t)pix * p.ld + c0) = *reinterpret_cast<const uint4*>(out);
   }
 }
 
 // ---- stage B: objectness over every cell ------------------------------------------------------------------
-template <bool BWD>
+template <bool BWD, typename IT>
 __global__ __launch_bounds__(256) void yolo_obj_kernel(const YoloLossParams p) {
   __shared__ float red[256];
-  const int64_t ncell = (int64_t)p.N * p.A * p.H * p.W;
+  const IT ncell = (IT)p.N * (IT)p.A * (IT)p.H * (IT)p.W;
   const float go = BWD ? (p.gout ? p.gout[0] : 1.f) * p.k_obj : 0.f;
   float acc = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ncell; i += (int64_t)gridDim.x * 256) {
+  for (IT i = (IT)blockIdx.x * 256 + threadIdx.x; i < ncell; i += (IT)gridDim.x * 256) {
     // cell order (n, a, gj, gi); memory order pixel-major: walk pixels so neighbouring lanes touch neighbouring rows
-    const int gi = (int)(i % p.W);
-    int64_t r = i / p.W;
-    const int gj = (int)(r % p.H);
-    r /= p.H;
-    const int a = (int)(r % p.A);
-    const int n = (int)(r / p.A);
+    IT r = i / (IT)p.W;
+    const int gi = (int)(i - r * (IT)p.W);
+    const IT r2 = r / (IT)p.H;
+    const int gj = (int)(r - r2 * (IT)p.H);
+    const int n = (int)(r2 / (IT)p.A);
+    const int a = (int)(r2 - (IT)n * (IT)p.A);
     const int64_t o = ((int64_t)(n * p.H + gj) * p.W + gi) * p.ld + a * p.NO + 4;
     const float x = (float)p.raw[o];
     const int w = p.winner[i];
@@ -423,7 +426,8 @@ static int level_fwd(const cvhip_yolo_loss_desc* d, const void* raw, const float
   hipLaunchKernelGGL(yolo_cand_kernel, dim3(cdiv(p.ncand, 4)), dim3(256), 0, st, p);
   hipLaunchKernelGGL(yolo_cand_reduce_kernel, dim3(1), dim3(1024), 0, st, p);
   const int nb = (int)(cdiv64(ncell, 256) < 1024 ? cdiv64(ncell, 256) : 1024);
-  hipLaunchKernelGGL(yolo_obj_kernel<false>, dim3(nb), dim3(256), 0, st, p);
+  if (ncell + (int64_t)nb * 256 < (1ll << 32)) hipLaunchKernelGGL((yolo_obj_kernel<false, unsigned>), dim3(nb), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((yolo_obj_kernel<false, int64_t>), dim3(nb), dim3(256), 0, st, p);
   hipLaunchKernelGGL(yolo_obj_reduce_kernel, dim3(1), dim3(1024), 0, st, p, nb);
   return check_launch("yolov5_loss_level_fwd");
 }
@@ -452,12 +456,14 @@ int cvhip_yolov5_loss_level_bwd(const cvhip_yolo_loss_desc* d, const void* raw, 
   if ((p.ld & 7) == 0 && (((uintptr_t)p.draw) & 15) == 0) {
     const int64_t nvec = (int64_t)p.N * p.H * p.W * (p.ld >> 3);
     const int nbf = (int)(cdiv64(nvec, 256 * 4) < 8192 ? cdiv64(nvec, 256 * 4) : 8192);
-    hipLaunchKernelGGL(yolo_obj_bwd_fill_kernel, dim3(nbf > 0 ? nbf : 1), dim3(256), 0, st, p);
+    if (nvec + (int64_t)nbf * 256 < (1ll << 32)) hipLaunchKernelGGL(yolo_obj_bwd_fill_kernel<unsigned>, dim3(nbf > 0 ? nbf : 1), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(yolo_obj_bwd_fill_kernel<int64_t>, dim3(nbf > 0 ? nbf : 1), dim3(256), 0, st, p);
   } else {
     rc = zero_fill(p.draw, (int64_t)p.N * p.H * p.W * p.ld * 2, st);
     if (rc != CVHIP_OK) return rc;
     const int nb = (int)(cdiv64(ncell, 256) < 8192 ? cdiv64(ncell, 256) : 8192);
-    hipLaunchKernelGGL(yolo_obj_kernel<true>, dim3(nb), dim3(256), 0, st, p);
+    if (ncell + (int64_t)nb * 256 < (1ll << 32)) hipLaunchKernelGGL((yolo_obj_kernel<true, unsigned>), dim3(nb), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((yolo_obj_kernel<true, int64_t>), dim3(nb), dim3(256), 0, st, p);
   }
   hipLaunchKernelGGL(yolo_cand_bwd_kernel, dim3(cdiv(p.ncand, 4)), dim3(256), 0, st, p);
   return check_launch("yolov5_loss_level_bwd");
