@@ -38,6 +38,7 @@ struct YoloLossParams {
   float* cgrad;    // [ncand][gstride] unscaled d/dlogit: box channels 0-3 = -dCIoU/dlogit, class channels = sigmoid(x) - t
   int gstride;
   float* partial;  // [1024] objectness partial sums
+  float* dobj;     // [N*A*H*W] sigmoid(x_obj) - t_obj per cell, kept by the forward objectness pass for the backward fill
   float* sums;     // [4] n, sum(1 - ciou), sum(cls bce), sum(obj bce)
   // backward scales
   const float* gout;  // upstream gradient of the total loss (device scalar) or nullptr (= 1)
@@ -192,7 +193,9 @@ __global__ __launch_bounds__(1024) void yolo_cand_reduce_kernel(const YoloLossPa
 // (sparse, yolo_cand_bwd_kernel afterwards). Before: a zero-fill of the whole map (275 MB for the three YOLOv5-s levels at batch 64)
 // followed by a pass that read the objectness logits and wrote 2-byte gradients at a 170-byte stride. Here a lane owns one 16-byte
 // channel vector of one pixel and stores it once — zeros, or zeros with the objectness gradient of the anchor whose channel falls
-// inside: the map is written exactly once, fully coalesced; same fp32 formula and rounding as yolo_obj_kernel<true>.
+// inside: the map is written exactly once, fully coalesced; same fp32 formula and rounding as yolo_obj_kernel<true>. The factor
+// sigmoid(x) - t of every cell comes from the forward objectness pass (YoloLossParams::dobj): re-deriving it here put a three-deep chain
+// of dependent gathers (logit, winner, candidate IoU) into 3 of every 32 lanes and held the whole pass at 1.9 TB/s.
 // IT: index type of the flat walks below — unsigned 32-bit whenever the element count allows (the 64-bit divisions by run-time values
 // cost ~100 instructions each; every launch of the benchmarked configurations takes the 32-bit instance)
 template <typename IT>
@@ -215,10 +218,7 @@ __global__ __launch_bounds__(256) void yolo_obj_bwd_fill_kernel(const YoloLossPa
         const int n = (int)(r / (IT)p.H);
         const int gj = (int)(r - (IT)n * (IT)p.H);
         const int64_t cellidx = (((int64_t)n * p.A + a) * p.H + gj) * p.W + gi;
-        const float x = (float)p.raw[(int64_t)pix * p.ld + oc];
-        const int w = p.winner[cellidx];
-        const float tt = w > 0 ? fmaxf(p.cand[(int64_t)(w - 1) * kCandStride], 0.f) : 0.f;
-        const h16_t gq = (h16_t)((sigmoid_ref(x) - tt) * go);
+        const h16_t gq = (h16_t)(p.dobj[cellidx] * go);   // (sigmoid(x) - t): the forward pass kept it, one coalesced fp32 read
 #pragma unroll
         for (int j = 0; j < 8; ++j)
           if (c0 + j == oc) out[j] = gq;
@@ -248,7 +248,10 @@ __global__ __launch_bounds__(256) void yolo_obj_kernel(const YoloLossParams p) {
     const int w = p.winner[i];
     const float tt = w > 0 ? fmaxf(p.cand[(int64_t)(w - 1) * kCandStride], 0.f) : 0.f;
     if (BWD) p.draw[o] = (h16_t)((sigmoid_ref(x) - tt) * go);
-    else acc += bce_logits(x, tt);
+    else {
+      acc += bce_logits(x, tt);
+      p.dobj[i] = sigmoid_ref(x) - tt;
+    }
   }
   if (!BWD) {
     red[threadIdx.x] = acc;
@@ -378,6 +381,7 @@ static int fill(YoloLossParams& p, const cvhip_yolo_loss_desc* d, const void* ra
   p.cand = (float*)take(ncand * kCandStride * 4);
   p.cgrad = (float*)take(ncand * p.gstride * 4);
   p.partial = (float*)take(1024 * 4);
+  p.dobj = (float*)take(ncell * 4);
   p.sums = sums;
   p.gout = nullptr;
   p.k_box = p.k_cls = p.k_obj = 0.f;
@@ -396,7 +400,7 @@ int64_t cvhip_yolov5_loss_workspace_bytes(const cvhip_yolo_loss_desc* d) {
   const int64_t ncand = (int64_t)5 * d->A * d->T;
   const int64_t gs = (d->NO + 3) / 4 * 4;
   auto r = [](int64_t b) { return (b + 255) / 256 * 256; };
-  return r(ncell * 4) * 2 + r(ncand * 4) * 2 + r(ncand * kCandStride * 4) + r(ncand * gs * 4) + r(1024 * 4);
+  return r(ncell * 4) * 2 + r(ncand * 4) * 2 + r(ncand * kCandStride * 4) + r(ncand * gs * 4) + r(1024 * 4) + r(ncell * 4);
 }
 
 static int level_fwd(const cvhip_yolo_loss_desc* d, const void* raw, const float* targets, const int32_t* assign, void* ws, float* sums4,

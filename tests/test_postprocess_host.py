@@ -68,3 +68,24 @@ def test_class_filter_as_input_mask_equals_reference(name, golden_dir):
     if any(c < 0 or c >= nc for c in classes):   # what clamping would have kept: detections of class 0 / nc - 1 that are not listed
         kept = torch.cat([a[:, 5] for a in got]).long().tolist()
         assert all(k in classes for k in kept)
+
+
+def test_decode_row_offset_division_is_exact():
+    """csrc/post.hip yolov5_decode_kernel splits a row offset t = x * NO + o with one multiply-high by inv = ceil(2^32 / NO); the
+    launcher refuses W * NO * NO >= 2^32. The split must be the exact quotient for every offset of every admissible row."""
+    import numpy as np
+    for NO in (5, 6, 7, 25, 85, 86, 255, 256, 1000):
+        inv = ((1 << 32) + NO - 1) // NO
+        assert inv < (1 << 32)
+        for W in (1, 20, 80, 160, 1333):
+            if W * NO * NO >= (1 << 32):
+                continue
+            t = np.arange(W * NO, dtype=np.uint64)
+            x = (t * np.uint64(inv)) >> np.uint64(32)
+            assert np.array_equal(x, t // np.uint64(NO)), (NO, W)
+    # the bound itself: the largest t the launcher admits for a wide row
+    NO = 255
+    inv = ((1 << 32) + NO - 1) // NO
+    tmax = (1 << 32) // NO - 1
+    for t in (tmax, tmax - 1, tmax // 2, NO * 7 - 1, NO * 7):
+        assert (t * inv) >> 32 == t // NO
