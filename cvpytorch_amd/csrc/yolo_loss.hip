@@ -323,6 +323,75 @@ __global__ __launch_bounds__(256) void yolo_cand_bwd_kernel(const YoloLossParams
   if (ch1 < p.NO) dst[ch1] = (h16_t)(acc1 * kc);
 }
 
+// ---- stage D (backward, round 6): column sums of the head gradient from the loss's own compact state -------------------------------
+// The detect convolutions carry a bias (yolov5_head.py: nn.Conv2d(ch, na * no, 1)): its gradient is the column sum of the gradient
+// map, which the engine used to compute by reading the whole map again (275 MB per YOLOv5-s step, 3 x 52 us) — although the map is
+// zero except one objectness channel per anchor and the box / class channels of the matched cells. Here every block sums its slice of
+// the candidates' unscaled gradients (cgrad, the rows yolo_cand_bwd_kernel folds into the map) and of the per-cell objectness factors
+// (dobj) and writes ONE partial row; cvhip_colsum_finalize folds the CVHIP_YOLO_BIAS_ROWS rows. Fixed partition, fixed orders:
+// deterministic. The sums are those of the fp32 values BEFORE their rounding into the 16-bit map.
+constexpr int kBiasRows = CVHIP_YOLO_BIAS_ROWS;
+template <typename IT>
+__global__ __launch_bounds__(256) void yolo_bias_partial_kernel(const YoloLossParams p, float* __restrict__ part) {
+  __shared__ float wacc[4][kLossMaxA * 128];
+  __shared__ float ored[kLossMaxA][256];
+  const int K = p.A * p.NO;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int i = t; i < 4 * kLossMaxA * 128; i += 256) (&wacc[0][0])[i] = 0.f;
+  __syncthreads();
+  // candidates: a contiguous slice per block, groups of 64 dealt to the waves in order; a lane owns channels lane, lane + 64
+  const int per_blk = (p.ncand + gridDim.x - 1) / gridDim.x;
+  const int c_begin = blockIdx.x * per_blk, c_end = min(c_begin + per_blk, p.ncand);
+  for (int g0 = c_begin + wave * 64; g0 < c_end; g0 += 256) {
+    const int c = g0 + lane;
+    unsigned long long m = __ballot(c < c_end && p.cell[c] >= 0);
+    while (m) {
+      const int l = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const int cc = g0 + l;
+      const int a = (cc / p.T) % p.A;
+      const float* gr = p.cgrad + (int64_t)cc * p.gstride;
+      if (lane < p.NO && lane != 4) wacc[wave][a * p.NO + lane] += gr[lane];
+      if (lane + 64 < p.NO) wacc[wave][a * p.NO + lane + 64] += gr[lane + 64];
+    }
+  }
+  // objectness: a contiguous slice of the cells (n, a, gj, gi) per block
+  float oa[kLossMaxA];
+#pragma unroll
+  for (int k = 0; k < kLossMaxA; ++k) oa[k] = 0.f;
+  {
+    const IT ncell = (IT)p.N * (IT)p.A * (IT)p.H * (IT)p.W, HW = (IT)p.H * (IT)p.W;
+    const IT per = (ncell + gridDim.x - 1) / gridDim.x;
+    const IT i_begin = (IT)blockIdx.x * per;
+    IT i_end = i_begin + per;
+    if (i_end > ncell) i_end = ncell;
+    for (IT i = i_begin + t; i < i_end; i += 256) {
+      const int a = (int)((i / HW) % (IT)p.A);
+      const float d = p.dobj[i];
+#pragma unroll
+      for (int k = 0; k < kLossMaxA; ++k) oa[k] += k == a ? d : 0.f;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kLossMaxA; ++k) ored[k][t] = oa[k];
+  __syncthreads();
+  if (t < p.A) {
+    float s = 0.f;
+    for (int j = 0; j < 256; ++j) s += ored[t][j];
+    ored[t][0] = s;
+  }
+  __syncthreads();
+  const float n = p.sums[0];
+  const float g = p.gout ? p.gout[0] : 1.f;
+  const float kb = n > 0.f ? g * p.k_box / n : 0.f, kc = n > 0.f ? g * p.k_cls / n : 0.f, go = g * p.k_obj;
+  float* const row = part + (int64_t)blockIdx.x * 2 * K;
+  for (int ch = t; ch < K; ch += 256) {
+    const int a = ch / p.NO, o = ch - a * p.NO;
+    const float v = ((wacc[0][ch] + wacc[1][ch]) + wacc[2][ch]) + wacc[3][ch];
+    row[ch] = o == 4 ? ored[a][0] * go : v * (o < 4 ? kb : kc);
+  }
+}
+
 // ---- final scalars ----------------------------------------------------------------------------------------
 __global__ void yolo_finalize_kernel(const float* sums, int L, const float* ncell, const float* balance, float hyp_box,
                                      float hyp_obj, float hyp_cls, int nc, float bs, float* total, float* stats) {
@@ -444,8 +513,23 @@ int cvhip_yolov5_loss_finalize(const float* sums, int32_t levels, const float* n
   return check_launch("yolov5_loss_finalize");
 }
 
+static int level_bwd(const cvhip_yolo_loss_desc* d, const void* raw, const float* targets, void* ws, const float* sums4, const float* gout,
+                     float k_box, float k_cls, float k_obj, void* draw, float* bias_partial, void* stream);
+
 int cvhip_yolov5_loss_level_bwd(const cvhip_yolo_loss_desc* d, const void* raw, const float* targets, void* ws, const float* sums4,
                                 const float* gout, float k_box, float k_cls, float k_obj, void* draw, void* stream) {
+  return level_bwd(d, raw, targets, ws, sums4, gout, k_box, k_cls, k_obj, draw, nullptr, stream);
+}
+
+int cvhip_yolov5_loss_level_bwd_bias(const cvhip_yolo_loss_desc* d, const void* raw, const float* targets, void* ws, const float* sums4,
+                                     const float* gout, float k_box, float k_cls, float k_obj, void* draw, float* bias_partial,
+                                     void* stream) {
+  if (!bias_partial) return CVHIP_ERR_INVALID;
+  return level_bwd(d, raw, targets, ws, sums4, gout, k_box, k_cls, k_obj, draw, bias_partial, stream);
+}
+
+static int level_bwd(const cvhip_yolo_loss_desc* d, const void* raw, const float* targets, void* ws, const float* sums4, const float* gout,
+                     float k_box, float k_cls, float k_obj, void* draw, float* bias_partial, void* stream) {
   YoloLossParams p;
   int rc = fill(p, d, raw, targets, ws, const_cast<float*>(sums4));
   if (rc != CVHIP_OK) return rc;
@@ -470,6 +554,10 @@ int cvhip_yolov5_loss_level_bwd(const cvhip_yolo_loss_desc* d, const void* raw, 
     else hipLaunchKernelGGL((yolo_obj_kernel<true, int64_t>), dim3(nb), dim3(256), 0, st, p);
   }
   hipLaunchKernelGGL(yolo_cand_bwd_kernel, dim3(cdiv(p.ncand, 4)), dim3(256), 0, st, p);
+  if (bias_partial) {
+    if (ncell < (1ll << 31)) hipLaunchKernelGGL(yolo_bias_partial_kernel<unsigned>, dim3(kBiasRows), dim3(256), 0, st, p, bias_partial);
+    else hipLaunchKernelGGL(yolo_bias_partial_kernel<int64_t>, dim3(kBiasRows), dim3(256), 0, st, p, bias_partial);
+  }
   return check_launch("yolov5_loss_level_bwd");
 }
 

@@ -23,6 +23,7 @@ DTYPE_F32, DTYPE_F64, DTYPE_I32, DTYPE_BF16, DTYPE_U8 = 0, 1, 2, 3, 4
 RED_SUM, RED_MAX, RED_MIN = 0, 1, 2
 DGRAD_CLASS_INTS = 12
 REDUCE_SCRATCH_ROWS = 64  # CVHIP_REDUCE_SCRATCH_ROWS
+YOLO_BIAS_ROWS = 64  # CVHIP_YOLO_BIAS_ROWS
 BN_ACC_SHARDS = 16  # CVHIP_BN_ACC_SHARDS
 
 
@@ -212,6 +213,7 @@ SIGNATURES = {
     "cvhip_yolov5_loss_level_fwd": (_i32, [_ylp, _p, _p, _p, _p, _p]),
     "cvhip_yolov5_loss_finalize": (_i32, [_p, _i32, _p, _p, _f32, _f32, _f32, _i32, _f32, _p, _p, _p]),
     "cvhip_yolov5_loss_level_bwd": (_i32, [_ylp, _p, _p, _p, _p, _p, _f32, _f32, _f32, _p, _p]),
+    "cvhip_yolov5_loss_level_bwd_bias": (_i32, [_ylp, _p, _p, _p, _p, _p, _f32, _f32, _f32, _p, _p, _p]),
     "cvhip_ota_workspace_bytes": (_i64, [_otp]),
     "cvhip_ota_assign": (_i32, [_otp, _pp, _p, _p, _p, _p]),
     "cvhip_ota_read_overflow": (_i32, [_otp, _p, _p, _p]),

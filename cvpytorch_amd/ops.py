@@ -811,6 +811,29 @@ def _mark(arena, idx):
         arena.mark_ready(i)
 
 
+# Column sums a PRODUCER of a gradient map already knows (the YOLOv5 loss: cvhip_yolov5_loss_level_bwd_bias): keyed by the map's address,
+# taken by the bias gradient of the convolution that receives exactly that map (one backward pass: the producer clears the table first).
+_COLSUMS = {}   # (one table: the producer's backward and the consumer's run on autograd's device thread, tests look from the main thread)
+_COLSUM_OFFER = __import__("os").environ.get("CVHIP_COLSUM_OFFER", "1") != "0"   # 0: consumers compute their column sums themselves (A/B switch)
+
+
+def offer_colsum(draw, partial, rows, K):
+    """`partial`: fp32 [rows + scratch][2][K] partial rows of the column sums of the NHWC gradient map `draw` (channel 0 at its address)"""
+    if _COLSUM_OFFER:
+        _COLSUMS[draw.data_ptr()] = (partial, int(rows), int(K), draw)   # (the map stays alive with its sums: its address cannot be re-used meanwhile)
+
+
+def clear_colsums():
+    _COLSUMS.clear()
+
+
+def _take_colsum(ptr, K):
+    hit = _COLSUMS.pop(ptr, None) if _COLSUMS else None
+    if hit is None or hit[2] != K:
+        return None
+    return hit[0], hit[1]
+
+
 def _conv_grads(ctx, x, weight, dy, dy_ld, need_dx, need_dw, need_db):
     """bias / weight / input gradients of the convolution itself from dy (the gradient at the conv output, NHWC bf16 with pitch
     dy_ld): shared by ConvBnAct.backward and ConvBnActPair.backward."""
@@ -824,9 +847,13 @@ def _conv_grads(ctx, x, weight, dy, dy_ld, need_dx, need_dw, need_db):
     arena = cfg.arena
     dbias = None
     if ctx.has_bias and need_db and not ctx.train_bn:
-        rows = _colreduce_rows(M, K)
-        partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
-        L.call("cvhip_colsum_partial", dy.data_ptr(), M, K, dy_ld, partial.data_ptr(), st)
+        pre = _take_colsum(dy.data_ptr(), K)
+        if pre is not None:   # the producer of this gradient map handed its column sums over (detect heads: the fused YOLOv5 loss)
+            partial, rows = pre
+        else:
+            rows = _colreduce_rows(M, K)
+            partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
+            L.call("cvhip_colsum_partial", dy.data_ptr(), M, K, dy_ld, partial.data_ptr(), st)
         if arena is not None and cfg.gb is not None:
             L.call("cvhip_colsum_finalize", partial.data_ptr(), rows, K, cfg.gb.data_ptr(), 1, st)
             arena.mark_ready(cfg.idx_b)
@@ -2644,13 +2671,18 @@ class YoloV5LossFused(torch.autograd.Function):
             g = g.float().contiguous()
         outs = []
         nc = cfg.num_classes
+        clear_colsums()
         for i, r in enumerate(maps):
             d = ctx.descs[i]
             draw = torch.empty((d.N, d.H, d.W, d.ld), dtype=ACT_DTYPE, device=r.device)
-            L.call("cvhip_yolov5_loss_level_bwd", C.byref(d), r.data_ptr(), tg.data_ptr(), ctx.wss[i].data_ptr(), sums[i].data_ptr(),
+            K = d.A * d.NO
+            bp = torch.empty((L.YOLO_BIAS_ROWS + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=r.device)
+            L.call("cvhip_yolov5_loss_level_bwd_bias", C.byref(d), r.data_ptr(), tg.data_ptr(), ctx.wss[i].data_ptr(), sums[i].data_ptr(),
                    g.data_ptr(), float(cfg.hyp_box) * ctx.bs, (float(cfg.hyp_cls) * ctx.bs / nc) if nc > 1 else 0.0,
-                   float(cfg.hyp_obj) * float(cfg.balance[i]) * ctx.bs / ctx.ncells[i], draw.data_ptr(), st)
-            outs.append(draw.permute(0, 3, 1, 2)[:, :d.A * d.NO])
+                   float(cfg.hyp_obj) * float(cfg.balance[i]) * ctx.bs / ctx.ncells[i], draw.data_ptr(), bp.data_ptr(), st)
+            # the detect convolution that receives this map takes its bias gradient from these rows (ops._conv_grads)
+            offer_colsum(draw, bp, L.YOLO_BIAS_ROWS, K)
+            outs.append(draw.permute(0, 3, 1, 2)[:, :K])
         return (None, None, *outs)
 
 

@@ -527,6 +527,15 @@ int cvhip_yolov5_loss_finalize(const float* sums, int32_t levels, const float* n
 int cvhip_yolov5_loss_level_bwd(const cvhip_yolo_loss_desc* d, const void* raw_bf16, const float* targets, void* ws,
                                 const float* sums4, const float* gout, float k_box, float k_cls, float k_obj,
                                 void* draw_bf16, void* stream);
+/* level_bwd that also produces the COLUMN SUMS of the gradient map — the bias gradient of the detect convolution in front of the
+ * loss (yolov5_head.py: nn.Conv2d(ch, na * no, 1) with bias; aten::convolution_backward's bias output reached from trainer.py:189) —
+ * from the loss's own compact state instead of a pass over the map: bias_partial = fp32 [CVHIP_YOLO_BIAS_ROWS][2][A*NO] partial rows
+ * (first half of every row written) for cvhip_colsum_finalize(bias_partial, CVHIP_YOLO_BIAS_ROWS, A*NO, out, accumulate). The sums are
+ * taken BEFORE the 16-bit rounding of the map's entries; deterministic. */
+#define CVHIP_YOLO_BIAS_ROWS 64
+int cvhip_yolov5_loss_level_bwd_bias(const cvhip_yolo_loss_desc* d, const void* raw_bf16, const float* targets, void* ws,
+                                     const float* sums4, const float* gout, float k_box, float k_cls, float k_obj,
+                                     void* draw_bf16, float* bias_partial, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * YOLOv7 OTA label assignment on device (ota_assign.hip) + the loss on that assignment.

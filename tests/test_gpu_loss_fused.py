@@ -86,6 +86,73 @@ def test_fused_loss_duplicate_cells_and_borders():
     _check(raws, t.to(dev()))
 
 
+@pytest.mark.parametrize("bs,sizes,nmax,seed", [(2, (16, 8, 4), 6, 0), (8, (40, 20, 10), 20, 4), (2, (16, 8, 4), 0, 3)])
+def test_fused_loss_offers_the_bias_gradient(bs, sizes, nmax, seed):
+    """cvhip_yolov5_loss_level_bwd_bias: the column sums of every level's gradient map (the detect convolutions' bias gradient), summed
+    from the loss's compact state, equal the sums of the torch formulation's fp32 gradient — and the sums of the map the kernel wrote, up
+    to that map's 16-bit rounding; no targets at all (n = 0) gives finite sums (objectness only)."""
+    import ctypes as C
+    from cvpytorch_amd import lib as L, ops
+    raws, tg = _maps(bs, sizes, seed), _targets(bs, nmax, seed, bs * 24)
+    _, _, grads_t = _torch_path(raws, tg)
+    rr = [r.clone().requires_grad_(True) for r in raws]
+    total_f, _ = yolov5.YOLOv5LossFused(80)(rr, tg)
+    grads_f = torch.autograd.grad(total_f, rr)
+    tab = dict(ops._COLSUMS)
+    assert len(tab) == 3
+    for gf, gt in zip(grads_f, grads_t):
+        hit = [v for k, v in tab.items() if k == gf.data_ptr()]
+        assert len(hit) == 1, "the sums are keyed by the address of channel 0 of the map"
+        partial, rows, K, _keep = hit[0]
+        assert rows == L.YOLO_BIAS_ROWS and K == 255
+        out = torch.empty(K, dtype=torch.float32, device=gf.device)
+        L.call("cvhip_colsum_finalize", partial.data_ptr(), rows, K, out.data_ptr(), 0, None)
+        torch.cuda.synchronize()
+        ref = gt.double().sum((0, 2, 3)).cpu()
+        got = out.double().cpu()
+        assert torch.isfinite(got).all()
+        scale = float(ref.abs().max()) + 1e-12
+        assert float((got - ref).abs().max()) <= 2e-4 * scale + 1e-9, (float((got - ref).abs().max()), scale)
+        wrote = gf.double().sum((0, 2, 3)).cpu()   # the 16-bit map: every entry rounded, so only close
+        assert float((got - wrote).abs().max()) <= 2e-2 * scale + 1e-9
+    ops.clear_colsums()
+
+
+def test_detect_bias_gradient_through_the_offer_equals_the_map_sum():
+    """end to end: a bias-carrying 1x1 convolution in front of the fused loss takes its bias gradient from the offered sums (no pass over
+    the map) and gets the same gradient as with the table emptied (the colsum pass), up to the map's rounding"""
+    from cvpytorch_amd import ops, bricks
+    torch.manual_seed(3)
+    tg = _targets(4, 10, 9, 96)
+    xs = [torch.randn(4, 64, s, s).to(torch.bfloat16).to(dev()).contiguous(memory_format=torch.channels_last) for s in (16, 8, 4)]
+    convs = [bricks.HipConv2d(64, 255, 1, bias=True).to(dev()) for _ in range(3)]
+    loss = yolov5.YOLOv5LossFused(80)
+
+    def run(drop_offer):
+        for c in convs:
+            c.zero_grad(set_to_none=True)
+        raws = [c(x) for c, x in zip(convs, xs)]
+        total, _ = loss(raws, tg)
+        if drop_offer:
+            orig = ops.offer_colsum
+            ops.offer_colsum = lambda *a, **k: None
+            try:
+                total.backward()
+            finally:
+                ops.offer_colsum = orig
+        else:
+            total.backward()
+        torch.cuda.synchronize()
+        return [c.bias.grad.detach().float().cpu().clone() for c in convs]
+
+    a, b = run(False), run(True)
+    assert not ops._COLSUMS, "every offered sum was taken by its convolution"
+    for ga, gb in zip(a, b):
+        scale = float(gb.abs().max()) + 1e-12
+        assert float((ga - gb).abs().max()) <= 2e-2 * scale, (float((ga - gb).abs().max()), scale)
+        assert float(ga.abs().max()) > 0
+
+
 @pytest.mark.parametrize("trial", [0, 1, 2])
 def test_fused_loss_equals_reference_vectors(trial):
     """the reference's own golden vectors (p in (N,3,H,W,85) fp32): rounded to bf16 maps first, so the expectation is the
