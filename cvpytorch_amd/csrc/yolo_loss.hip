@@ -201,24 +201,46 @@ __global__ __launch_bounds__(1024) void yolo_cand_reduce_kernel(const YoloLossPa
 template <typename IT>
 __global__ __launch_bounds__(256) void yolo_obj_bwd_fill_kernel(const YoloLossParams p) {
   const IT VP = (IT)(p.ld >> 3);  // 16-byte vectors per pixel
-  const IT nvec = (IT)p.N * (IT)p.H * (IT)p.W * VP;
+  const IT HW = (IT)p.H * (IT)p.W;
+  const IT nvec = (IT)p.N * HW * VP;
   const float go = (p.gout ? p.gout[0] : 1.f) * p.k_obj;
-  for (IT i = (IT)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (IT)gridDim.x * 256) {
-    const IT pix = i / VP;
-    const int v = (int)(i - pix * VP);
-    const int c0 = v * 8;
+  const IT step = (IT)gridDim.x * 256;
+  // the vector's position inside its pixel is thread-invariant when VP is a power of two dividing the grid stride (ld = 256: VP = 32):
+  // which anchors' objectness channels fall into it is then decided once, and only those lanes (3 of 32) do any index arithmetic
+  const bool inv = (VP & (VP - 1)) == 0 && (step & (VP - 1)) == 0;
+  const int vp_shift = inv ? __ffs((int)VP) - 1 : 0;
+  auto anchors_of = [&](int c0) {  // bit a set: channel a * NO + 4 lies in [c0, c0 + 8)
+    unsigned m = 0;
+    for (int a = 0; a < p.A; ++a) {
+      const int oc = a * p.NO + 4;
+      if (oc >= c0 && oc < c0 + 8) m |= 1u << a;
+    }
+    return m;
+  };
+  const unsigned my_mask = inv ? anchors_of((int)(((IT)blockIdx.x * 256 + threadIdx.x) & (VP - 1)) * 8) : 0u;
+  for (IT i = (IT)blockIdx.x * 256 + threadIdx.x; i < nvec; i += step) {
+    IT pix;
+    int c0;
+    unsigned mask;
+    if (inv) {
+      pix = i >> vp_shift;
+      c0 = (int)(i & (VP - 1)) * 8;
+      mask = my_mask;
+    } else {
+      pix = i / VP;
+      c0 = (int)(i - pix * VP) * 8;
+      mask = anchors_of(c0);
+    }
     h16_t out[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) out[j] = (h16_t)0.f;
-    for (int a = 0; a < p.A; ++a) {
-      const int oc = a * p.NO + 4;
-      if (oc >= c0 && oc < c0 + 8) {
-        const IT r = pix / (IT)p.W;
-        const int gi = (int)(pix - r * (IT)p.W);
-        const int n = (int)(r / (IT)p.H);
-        const int gj = (int)(r - (IT)n * (IT)p.H);
-        const int64_t cellidx = (((int64_t)n * p.A + a) * p.H + gj) * p.W + gi;
-        const h16_t gq = (h16_t)(p.dobj[cellidx] * go);   // (sigmoid(x) - t): the forward pass kept it, one coalesced fp32 read
+    if (mask) {
+      const IT n = pix / HW;
+      const IT cell0 = pix + n * (IT)(p.A - 1) * HW;  // cell (n, a = 0, gj, gi); anchor a adds a * HW
+      for (int a = 0; a < p.A; ++a) {
+        if (!((mask >> a) & 1u)) continue;
+        const int oc = a * p.NO + 4;
+        const h16_t gq = (h16_t)(p.dobj[(int64_t)cell0 + (int64_t)a * (int64_t)HW] * go);   // (sigmoid(x) - t): kept by the forward pass
 #pragma unroll
         for (int j = 0; j < 8; ++j)
           if (c0 + j == oc) out[j] = gq;
@@ -345,14 +367,33 @@ __global__ __launch_bounds__(256) void yolo_bias_partial_kernel(const YoloLossPa
   for (int g0 = c_begin + wave * 64; g0 < c_end; g0 += 256) {
     const int c = g0 + lane;
     unsigned long long m = __ballot(c < c_end && p.cell[c] >= 0);
-    while (m) {
-      const int l = __ffsll((long long)m) - 1;
-      m &= m - 1;
-      const int cc = g0 + l;
-      const int a = (cc / p.T) % p.A;
-      const float* gr = p.cgrad + (int64_t)cc * p.gstride;
-      if (lane < p.NO && lane != 4) wacc[wave][a * p.NO + lane] += gr[lane];
-      if (lane + 64 < p.NO) wacc[wave][a * p.NO + lane + 64] += gr[lane + 64];
+    while (m) {  // eight candidates' rows in flight per wave, folded in candidate order
+      int cc[8];
+      float v0[8], v1[8];
+      int nv = 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        cc[u] = -1;
+        if (m) {
+          cc[u] = g0 + __ffsll((long long)m) - 1;
+          m &= m - 1;
+          nv = u + 1;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float* gr = p.cgrad + (int64_t)(cc[u] >= 0 ? cc[u] : 0) * p.gstride;
+        v0[u] = (cc[u] >= 0 && lane < p.NO && lane != 4) ? gr[lane] : 0.f;
+        v1[u] = (cc[u] >= 0 && lane + 64 < p.NO) ? gr[lane + 64] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (u < nv) {
+          const int a = (cc[u] / p.T) % p.A;
+          if (lane < p.NO && lane != 4) wacc[wave][a * p.NO + lane] += v0[u];
+          if (lane + 64 < p.NO) wacc[wave][a * p.NO + lane + 64] += v1[u];
+        }
+      }
     }
   }
   // objectness: a contiguous slice of the cells (n, a, gj, gi) per block
@@ -365,22 +406,32 @@ __global__ __launch_bounds__(256) void yolo_bias_partial_kernel(const YoloLossPa
     const IT i_begin = (IT)blockIdx.x * per;
     IT i_end = i_begin + per;
     if (i_end > ncell) i_end = ncell;
-    for (IT i = i_begin + t; i < i_end; i += 256) {
-      const int a = (int)((i / HW) % (IT)p.A);
-      const float d = p.dobj[i];
+    for (IT i0 = i_begin + t; i0 < i_end; i0 += 256 * 8) {  // 8 independent loads in flight per lane (64 blocks walk 1.2 M cells)
+      float d[8];
+      int a[8];
 #pragma unroll
-      for (int k = 0; k < kLossMaxA; ++k) oa[k] += k == a ? d : 0.f;
+      for (int u = 0; u < 8; ++u) {
+        const IT i = i0 + (IT)u * 256;
+        const bool ok = i < i_end;
+        d[u] = ok ? p.dobj[ok ? i : i_begin] : 0.f;
+        a[u] = (int)(((ok ? i : i_begin) / HW) % (IT)p.A);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k < kLossMaxA; ++k) oa[k] += k == a[u] ? d[u] : 0.f;
     }
   }
 #pragma unroll
   for (int k = 0; k < kLossMaxA; ++k) ored[k][t] = oa[k];
   __syncthreads();
-  if (t < p.A) {
-    float s = 0.f;
-    for (int j = 0; j < 256; ++j) s += ored[t][j];
-    ored[t][0] = s;
+  for (int st = 128; st > 0; st >>= 1) {  // fixed tree: the same sums on every run
+    if (t < st) {
+#pragma unroll
+      for (int k = 0; k < kLossMaxA; ++k) ored[k][t] += ored[k][t + st];
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const float n = p.sums[0];
   const float g = p.gout ? p.gout[0] : 1.f;
   const float kb = n > 0.f ? g * p.k_box / n : 0.f, kc = n > 0.f ? g * p.k_cls / n : 0.f, go = g * p.k_obj;

@@ -23,7 +23,7 @@ DTYPE_F32, DTYPE_F64, DTYPE_I32, DTYPE_BF16, DTYPE_U8 = 0, 1, 2, 3, 4
 RED_SUM, RED_MAX, RED_MIN = 0, 1, 2
 DGRAD_CLASS_INTS = 12
 REDUCE_SCRATCH_ROWS = 64  # CVHIP_REDUCE_SCRATCH_ROWS
-YOLO_BIAS_ROWS = 64  # CVHIP_YOLO_BIAS_ROWS
+YOLO_BIAS_ROWS = 256  # CVHIP_YOLO_BIAS_ROWS
 BN_ACC_SHARDS = 16  # CVHIP_BN_ACC_SHARDS
 
 

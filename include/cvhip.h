@@ -532,7 +532,7 @@ int cvhip_yolov5_loss_level_bwd(const cvhip_yolo_loss_desc* d, const void* raw_b
  * from the loss's own compact state instead of a pass over the map: bias_partial = fp32 [CVHIP_YOLO_BIAS_ROWS][2][A*NO] partial rows
  * (first half of every row written) for cvhip_colsum_finalize(bias_partial, CVHIP_YOLO_BIAS_ROWS, A*NO, out, accumulate). The sums are
  * taken BEFORE the 16-bit rounding of the map's entries; deterministic. */
-#define CVHIP_YOLO_BIAS_ROWS 64
+#define CVHIP_YOLO_BIAS_ROWS 256
 int cvhip_yolov5_loss_level_bwd_bias(const cvhip_yolo_loss_desc* d, const void* raw_bf16, const float* targets, void* ws,
                                      const float* sums4, const float* gout, float k_box, float k_cls, float k_obj,
                                      void* draw_bf16, float* bias_partial, void* stream);
