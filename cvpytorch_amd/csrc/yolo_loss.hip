@@ -168,14 +168,31 @@ __device__ __forceinline__ float block_sum_1024(float v, float* red) {
   return r;
 }
 
-__global__ __launch_bounds__(1024) void yolo_cand_reduce_kernel(const YoloLossParams p) {
-  __shared__ float red[1024];
+// (a device function since round 6: it runs as block 1 of yolo_obj_reduce_kernel, beside the objectness fold, instead of as a launch of
+// its own between the candidate and the objectness passes — nothing before the finalize reads its three sums)
+__device__ __forceinline__ void yolo_cand_reduce(const YoloLossParams& p, float* red) {
   float n = 0.f, lb = 0.f, lc = 0.f;
-  for (int c = threadIdx.x; c < p.ncand; c += 1024) {
-    if (p.cell[c] >= 0) {
-      n += 1.f;
-      lb += p.cand[(int64_t)c * kCandStride + 1];
-      lc += p.cand[(int64_t)c * kCandStride + 2];
+  for (int c0 = threadIdx.x; c0 < p.ncand; c0 += 8 * 1024) {  // eight candidates' loads in flight per thread, folded in candidate order
+    int cl[8];
+    float b8[8], c8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = c0 + u * 1024;
+      cl[u] = c < p.ncand ? p.cell[c] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t c = cl[u] >= 0 ? c0 + u * 1024 : 0;
+      b8[u] = p.cand[c * kCandStride + 1];
+      c8[u] = p.cand[c * kCandStride + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (cl[u] >= 0) {
+        n += 1.f;
+        lb += b8[u];
+        lc += c8[u];
+      }
     }
   }
   n = block_sum_1024(n, red);
@@ -288,6 +305,10 @@ __global__ __launch_bounds__(256) void yolo_obj_kernel(const YoloLossParams p) {
 
 __global__ __launch_bounds__(1024) void yolo_obj_reduce_kernel(const YoloLossParams p, int nblocks) {
   __shared__ float red[1024];
+  if (blockIdx.x == 1) {
+    yolo_cand_reduce(p, red);
+    return;
+  }
   float v = 0.f;
   for (int i = threadIdx.x; i < nblocks; i += 1024) v += p.partial[i];
   v = block_sum_1024(v, red);
@@ -548,11 +569,10 @@ static int level_fwd(const cvhip_yolo_loss_desc* d, const void* raw, const float
   rc = zero_fill(p.winner, (ncell * 4 + 255) / 256 * 256 * 2, st);  // winner + head are adjacent
   if (rc != CVHIP_OK) return rc;
   hipLaunchKernelGGL(yolo_cand_kernel, dim3(cdiv(p.ncand, 4)), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(yolo_cand_reduce_kernel, dim3(1), dim3(1024), 0, st, p);
   const int nb = (int)(cdiv64(ncell, 256) < 1024 ? cdiv64(ncell, 256) : 1024);
   if (ncell + (int64_t)nb * 256 < (1ll << 32)) hipLaunchKernelGGL((yolo_obj_kernel<false, unsigned>), dim3(nb), dim3(256), 0, st, p);
   else hipLaunchKernelGGL((yolo_obj_kernel<false, int64_t>), dim3(nb), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(yolo_obj_reduce_kernel, dim3(1), dim3(1024), 0, st, p, nb);
+  hipLaunchKernelGGL(yolo_obj_reduce_kernel, dim3(2), dim3(1024), 0, st, p, nb);  // block 0: objectness partials, block 1: candidate sums
   return check_launch("yolov5_loss_level_fwd");
 }
 
