@@ -167,9 +167,15 @@ __device__ __forceinline__ float sim_cost(const SimotaParams& p, int b, int a, c
   return (cls_cost + 3.0f * (-logf(iou + 1e-8f))) + 100000.0f * ((ib && ic) ? 0.f : 1.f);
 }
 
-// ---- K2: one wave per (image, gt): dynamic k and the k cheapest candidates ------------------------------------------------
-__global__ __launch_bounds__(64) void sim_match_kernel(const SimotaParams p) {
-  const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+// ---- K2: one 4-wave block per (image, gt): dynamic k and the k cheapest candidates ------------------------------------------------
+// (round 6: one WAVE per pair scanned the image's 8400 anchors 131 to a lane, 1280 waves for the whole chip: 259 us. Four waves share
+// the scan; the arg-max / arg-min rounds go wave shuffle -> four LDS slots -> every thread picks the block's winner with the same
+// total order — (value, thread) for the IoU list, (cost, anchor) for the cost list — so the selection does not depend on the split.)
+constexpr int kSimMatchThreads = 512;
+__global__ __launch_bounds__(kSimMatchThreads) void sim_match_kernel(const SimotaParams p) {
+  __shared__ float sbest[kSimMatchThreads / 64];
+  __shared__ int swho[kSimMatchThreads / 64];
+  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (g >= p.nlabel[b]) return;
   const float* t = p.targets + ((int64_t)b * p.G + g) * 5;
   int gcls = (int)t[0];
@@ -182,7 +188,7 @@ __global__ __launch_bounds__(64) void sim_match_kernel(const SimotaParams p) {
     tc[k] = INFINITY;
     ta[k] = 0x7fffffff;
   }
-  for (int a = lane; a < p.A; a += 64) {
+  for (int a = tid; a < p.A; a += kSimMatchThreads) {
     if (!p.cand[(int64_t)b * p.A + a]) continue;
     float iou;
     const float cost = sim_cost(p, b, a, t, gcls, &iou);
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(64) void sim_match_kernel(const SimotaParams p) {
   float ksum = 0.f;
   for (int r = 0; r < 10; ++r) {
     float best = ti[0];
-    int who = lane;
+    int who = tid;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const float ob = __shfl_xor(best, o, 64);
@@ -225,9 +231,23 @@ __global__ __launch_bounds__(64) void sim_match_kernel(const SimotaParams p) {
         who = ow;
       }
     }
+    if (lane == 0) {
+      sbest[wave] = best;
+      swho[wave] = who;
+    }
+    __syncthreads();
+    best = sbest[0];
+    who = swho[0];
+#pragma unroll
+    for (int w = 1; w < kSimMatchThreads / 64; ++w)
+      if (sbest[w] > best || (sbest[w] == best && swho[w] < who)) {
+        best = sbest[w];
+        who = swho[w];
+      }
+    __syncthreads();
     if (best < 0.f) break;  // fewer than 10 candidates
     ksum += best;
-    if (lane == who) {
+    if (tid == who) {
 #pragma unroll
       for (int k = 0; k < 9; ++k) ti[k] = ti[k + 1];
       ti[9] = -1.f;
@@ -247,8 +267,22 @@ __global__ __launch_bounds__(64) void sim_match_kernel(const SimotaParams p) {
         ba = oa;
       }
     }
+    if (lane == 0) {
+      sbest[wave] = best;
+      swho[wave] = ba;
+    }
+    __syncthreads();
+    best = sbest[0];
+    ba = swho[0];
+#pragma unroll
+    for (int w = 1; w < kSimMatchThreads / 64; ++w)
+      if (sbest[w] < best || (sbest[w] == best && swho[w] < ba)) {
+        best = sbest[w];
+        ba = swho[w];
+      }
+    __syncthreads();
     if (!(best < INFINITY)) break;
-    if (ta[0] == ba) {  // the owning lane consumes its head and publishes the match
+    if (ta[0] == ba) {  // the owning thread consumes its head and publishes the match
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
         tc[k] = tc[k + 1];
@@ -498,7 +532,7 @@ int cvhip_simota_loss_fwd(const cvhip_simota_desc* d, const void* const* raws, c
   const int nb = cdiv(BA, 256);
   hipLaunchKernelGGL(sim_nlabel_kernel, dim3(cdiv(p.B, 64)), dim3(64), 0, st, p);
   hipLaunchKernelGGL(sim_prep_kernel, dim3(nb), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(sim_match_kernel, dim3(p.G, p.B), dim3(64), 0, st, p);
+  hipLaunchKernelGGL(sim_match_kernel, dim3(p.G, p.B), dim3(kSimMatchThreads), 0, st, p);
   hipLaunchKernelGGL(sim_resolve_kernel, dim3(nb), dim3(256), 0, st, p);
   hipLaunchKernelGGL(sim_loss_kernel<false>, dim3(nb), dim3(256), 0, st, p);
   hipLaunchKernelGGL(sim_finalize_kernel, dim3(1), dim3(1024), 0, st, p, nb, out5);
