@@ -160,6 +160,9 @@ struct CeBilParams {
   const float* gscale;  // backward: upstream gradient of the mean loss (1 element) or NULL
   h16_t* dx;            // backward: [N][Hi][Wi][ld_dx]
   int ld_dx;
+  // per-pixel forms (round 6: OHEM, cross_entropy_loss.py:51-69 — the selection of hard pixels happens between the two passes)
+  float* loss_px;       // forward: [N][Ho][Wo] -log p_t of every label pixel (0 where ignored); no reduction
+  const float* w_px;    // backward: [N][Ho][Wo] weights in [0, 1]: dx = gscale * sum_m w_px[m] * d(-log p_t(m)) / dx (no 1 / #valid)
   int tiles_h, tiles_w, fh_max, fw_max;
 };
 
@@ -236,7 +239,10 @@ __global__ __launch_bounds__(256) void seg_ce_bilinear_fwd_kernel(const CeBilPar
   const int64_t total = (int64_t)p.N * p.Ho * p.Wo;
   for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < total; m += (int64_t)gridDim.x * 256) {
     const int64_t t = p.target[m];
-    if (t == p.ignore || t < 0 || t >= p.C) continue;
+    if (t == p.ignore || t < 0 || t >= p.C) {
+      if (p.loss_px) p.loss_px[m] = 0.f;
+      continue;
+    }
     const int ox = (int)(m % p.Wo);
     const int64_t q = m / p.Wo;
     const int oy = (int)(q % p.Ho);
@@ -255,9 +261,12 @@ __global__ __launch_bounds__(256) void seg_ce_bilinear_fwd_kernel(const CeBilPar
 #pragma unroll
     for (int c = 0; c < CMAX; ++c)
       if (c < p.C) se += __expf(z[c] - mx);
-    loss += (mx + __logf(se)) - zt;
+    const float lm = (mx + __logf(se)) - zt;
+    if (p.loss_px) p.loss_px[m] = lm;
+    loss += lm;
     cnt += 1.f;
   }
+  if (p.loss_px) return;   // (per-pixel form: the caller reduces what it selects)
   red[0][threadIdx.x] = loss;
   red[1][threadIdx.x] = cnt;
   __syncthreads();
@@ -274,12 +283,13 @@ __global__ __launch_bounds__(256) void seg_ce_bilinear_fwd_kernel(const CeBilPar
   }
 }
 
-constexpr int kCeBilTH = 4, kCeBilTW = 8;  // low-resolution tile of a backward block
+// low-resolution tile of a backward block: 4 x 8 source pixels; smaller tiles (round 6) where the label footprint of that tile would not
+// fit the LDS — the x8 up-sampling of the STDC heads (64 x 128 logits against 512 x 1024 labels) runs 4 x 4
+constexpr int kCeBilTiles[4][2] = {{4, 8}, {4, 4}, {2, 4}, {2, 2}};
 
-template <int CMAX>
+template <int CMAX, int TH, int TW>
 __global__ __launch_bounds__(256) void seg_ce_bilinear_bwd_kernel(const CeBilParams p) {
   extern __shared__ __attribute__((aligned(16))) float cebil_smem[];
-  constexpr int TH = kCeBilTH, TW = kCeBilTW;
   // LDS: G[fh_max * fw_max][C] (fp16: softmax - onehot lies in [-1, 1], 11 significant bits there; fp32 cost half the resident
   // blocks) | WY[fh_max][TH] | WX[fw_max][TW] | P[(TH + 2) * (TW + 2)][ldp] (the source patch, 16-bit)
   _Float16* const G = reinterpret_cast<_Float16*>(cebil_smem);
@@ -391,7 +401,8 @@ __global__ __launch_bounds__(256) void seg_ce_bilinear_bwd_kernel(const CeBilPar
     const int oy = oy_lo + fy, ox = ox_lo + fx;
     const int64_t tt = tg[(int64_t)oy * p.Wo + ox];
     _Float16* const g = G + (size_t)f * p.C;
-    if (tt == p.ignore || tt < 0 || tt >= p.C) {
+    const float wm = p.w_px ? p.w_px[((int64_t)n * p.Ho + oy) * p.Wo + ox] : 1.f;
+    if (tt == p.ignore || tt < 0 || tt >= p.C || wm == 0.f) {
 #pragma unroll
       for (int c = 0; c < CMAX; ++c)
         if (c < p.C) g[c] = (_Float16)0.f;
@@ -413,10 +424,10 @@ __global__ __launch_bounds__(256) void seg_ce_bilinear_bwd_kernel(const CeBilPar
     const float inv = 1.f / se;
 #pragma unroll
     for (int c = 0; c < CMAX; ++c)
-      if (c < p.C) g[c] = (_Float16)(z[c] * inv - (c == (int)tt ? 1.f : 0.f));
+      if (c < p.C) g[c] = (_Float16)((z[c] * inv - (c == (int)tt ? 1.f : 0.f)) * wm);
   }
   __syncthreads();
-  const float cnt = p.stat[1];
+  const float cnt = p.w_px ? 1.f : p.stat[1];
   const float gs = (cnt > 0.f ? 1.f / cnt : 0.f) * (p.gscale ? p.gscale[0] : 1.f);
   // gather: a thread owns (tile column lj, class c) — c fastest, ld_dx entries per pixel, the pad channels are written as zeros —
   // and walks the footprint rows once: the row sums over the footprint columns are shared by the TH tile rows, the <= 2r
@@ -443,6 +454,51 @@ __global__ __launch_bounds__(256) void seg_ce_bilinear_bwd_kernel(const CeBilPar
 #pragma unroll
     for (int li = 0; li < TH; ++li)
       if (i0 + li < p.Hi) p.dx[((int64_t)(n * p.Hi + i0 + li) * p.Wi + j) * p.ld_dx + c] = (h16_t)(acc[li] * gs);
+  }
+}
+
+// ---- boundary targets of the STDC detail loss (round 6) ------------------------------------------------------------------------------
+// detail_loss.py:37-79: three Laplacian convolutions of the LABEL map (3x3 kernel [-1 .. 8 .. -1], padding 1, strides 1 / 2 / 4,
+// clamp(min=0)), the strided ones brought back to label size by nearest up-sampling, each thresholded to {0, 1}; the three planes fused
+// by a 1x1 convolution with weights 0.6 / 0.3 / 0.1 and thresholded again. Written with torch ops that was three F.conv2d on
+// [N, 1, H, W] fp32 tensors (MIOpen's naive direct kernel: 2 ms each at 16 x 512 x 1024), two F.interpolate, a cat and a fourth conv
+// — per step, without a gradient. One thread per label pixel here; the sums are small integers, exact in fp32.
+__device__ __forceinline__ float detail_lap(const int64_t* __restrict__ g, int H, int W, int cy, int cx) {
+  // sum_{dy, dx} k[dy][dx] * g[cy + dy][cx + dx] with zero padding, k = 8 at the centre and -1 around it
+  float s = 0.f;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int y = cy + dy, x = cx + dx;
+      if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+        const float v = (float)g[(int64_t)y * W + x];
+        s += (dy == 0 && dx == 0) ? 8.f * v : -v;
+      }
+    }
+  return s;
+}
+
+__global__ __launch_bounds__(256) void detail_targets_kernel(const int64_t* __restrict__ labels, int N, int H, int W, float thr, float* __restrict__ out) {
+  const unsigned total = (unsigned)N * (unsigned)H * (unsigned)W;
+  // strided outputs: floor((H + 2 - 3) / s) + 1 rows; F.interpolate(mode="nearest") reads src = min(floor(dst * in / out), in - 1)
+  const int H2 = (H - 1) / 2 + 1, W2 = (W - 1) / 2 + 1, H4 = (H - 1) / 4 + 1, W4 = (W - 1) / 4 + 1;
+  const float sh2 = (float)H2 / (float)H, sw2 = (float)W2 / (float)W, sh4 = (float)H4 / (float)H, sw4 = (float)W4 / (float)W;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const unsigned r = i / (unsigned)W, x = i - r * (unsigned)W;
+    const unsigned n = r / (unsigned)H, y = r - n * (unsigned)H;
+    const int64_t* g = labels + (int64_t)n * H * W;
+    const float l1 = fmaxf(detail_lap(g, H, W, (int)y, (int)x), 0.f) > thr ? 1.f : 0.f;
+    int y2 = (int)floorf((float)y * sh2), x2 = (int)floorf((float)x * sw2);
+    y2 = y2 < H2 - 1 ? y2 : H2 - 1;
+    x2 = x2 < W2 - 1 ? x2 : W2 - 1;
+    const float l2 = fmaxf(detail_lap(g, H, W, 2 * y2, 2 * x2), 0.f) > thr ? 1.f : 0.f;
+    int y4 = (int)floorf((float)y * sh4), x4 = (int)floorf((float)x * sw4);
+    y4 = y4 < H4 - 1 ? y4 : H4 - 1;
+    x4 = x4 < W4 - 1 ? x4 : W4 - 1;
+    const float l4 = fmaxf(detail_lap(g, H, W, 4 * y4, 4 * x4), 0.f) > thr ? 1.f : 0.f;
+    const float pyr = (0.6f * l1 + 0.3f * l2) + 0.1f * l4;
+    out[i] = pyr > thr ? 1.f : 0.f;
   }
 }
 
@@ -503,9 +559,9 @@ static inline int grid_for(int64_t total) {
   return (int)b;
 }
 
-template <int CMAX>
+template <int CMAX, int TH, int TW>
 static int cebil_launch_bwd(const CeBilParams& p, int lds, hipStream_t s) {
-  auto kern = seg_ce_bilinear_bwd_kernel<CMAX>;
+  auto kern = seg_ce_bilinear_bwd_kernel<CMAX, TH, TW>;
   static bool attr_done[64] = {};  // per instantiation and device
   int devid = 0;
   (void)hipGetDevice(&devid);
@@ -520,6 +576,50 @@ static int cebil_launch_bwd(const CeBilParams& p, int lds, hipStream_t s) {
   }
   hipLaunchKernelGGL(kern, dim3(p.N * p.tiles_h * p.tiles_w), dim3(256), lds, s, p);
   return check_launch("seg_ce_bilinear_bwd_kernel");
+}
+
+
+// footprint bound (label rows read by TH consecutive source rows) for the LDS tile: exact footprints are <= this
+static int cebil_fbound(int in, int out, int T) {
+  const int r = (out + in - 1) / in;  // label pixels per source pixel, rounded up
+  int f = (T + 1) * r + 2;
+  return f < out ? f : out;
+}
+
+static int cebil_lds_bytes_tile(int C, int Hi, int Wi, int Ho, int Wo, int th, int tw) {
+  const int fh = cebil_fbound(Hi, Ho, th), fw = cebil_fbound(Wi, Wo, tw);
+  const int ldp = C <= 24 ? 24 : 32;  // the kernel's CMAX
+  return ((((fh * fw * C + 1) / 2 + 3) & ~3) + fh * th + ((fw * tw + 3) & ~3)) * 4 + (th + 2) * (tw + 2) * ldp * 4;
+}
+
+// the largest backward tile whose footprint fits the LDS budget (two resident blocks per CU): index into kCeBilTiles, -1 = none
+static int cebil_pick_tile(int C, int Hi, int Wi, int Ho, int Wo, int* lds_out) {
+  for (int i = 0; i < 4; ++i) {
+    const int lds = cebil_lds_bytes_tile(C, Hi, Wi, Ho, Wo, kCeBilTiles[i][0], kCeBilTiles[i][1]);
+    if (lds <= 96 * 1024) {
+      if (lds_out) *lds_out = lds;
+      return i;
+    }
+  }
+  return -1;
+}
+
+template <int CMAX>
+static int cebil_launch_bwd_tile(CeBilParams& p, hipStream_t s) {
+  int lds = 0;
+  const int ti = cebil_pick_tile(p.C, p.Hi, p.Wi, p.Ho, p.Wo, &lds);
+  if (ti < 0) return CVHIP_ERR_UNSUPPORTED;
+  const int th = kCeBilTiles[ti][0], tw = kCeBilTiles[ti][1];
+  p.tiles_h = (p.Hi + th - 1) / th;
+  p.tiles_w = (p.Wi + tw - 1) / tw;
+  p.fh_max = cebil_fbound(p.Hi, p.Ho, th);
+  p.fw_max = cebil_fbound(p.Wi, p.Wo, tw);
+  switch (ti) {
+    case 0: return cebil_launch_bwd<CMAX, 4, 8>(p, lds, s);
+    case 1: return cebil_launch_bwd<CMAX, 4, 4>(p, lds, s);
+    case 2: return cebil_launch_bwd<CMAX, 2, 4>(p, lds, s);
+    default: return cebil_launch_bwd<CMAX, 2, 2>(p, lds, s);
+  }
 }
 
 
@@ -558,26 +658,12 @@ int cvhip_seg_ce_bwd(const void* logits, int32_t ld, const int64_t* target, int6
   return check_launch("seg_ce_bwd_kernel");
 }
 
-// footprint bound (label rows read by TH consecutive source rows) for the LDS tile: exact footprints are <= this
-static int cebil_fbound(int in, int out, int T) {
-  const int r = (out + in - 1) / in;  // label pixels per source pixel, rounded up
-  int f = (T + 1) * r + 2;
-  return f < out ? f : out;
-}
-
-static int cebil_lds_bytes(int C, int ld_x, int Hi, int Wi, int Ho, int Wo) {
-  const int fh = cebil_fbound(Hi, Ho, kCeBilTH), fw = cebil_fbound(Wi, Wo, kCeBilTW);
-  const int ldp = C <= 24 ? 24 : 32;  // the kernel's CMAX
-  (void)ld_x;
-  return ((((fh * fw * C + 1) / 2 + 3) & ~3) + fh * kCeBilTH + ((fw * kCeBilTW + 3) & ~3)) * 4 + (kCeBilTH + 2) * (kCeBilTW + 2) * ldp * 4;
-}
-
 int cvhip_seg_ce_bilinear_ok(int32_t C, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t align_corners) {
   // align_corners: the backward's footprint bound (cebil_fbound) assumes the half-pixel mapping, whose label rows per source row are
   // out/in; with align_corners they are (out-1)/(in-1) > out/in and part of the gradient would be dropped — the two-op path runs
   if (align_corners) return 0;
   if (C <= 0 || C > 32 || Hi <= 0 || Wi <= 0 || Ho < Hi || Wo < Wi) return 0;  // upsampling only
-  return cebil_lds_bytes(C, (C + 7) & ~7, Hi, Wi, Ho, Wo) <= 96 * 1024 ? 1 : 0;  // (the logits' usual pitch: C rounded up to 8)
+  return cebil_pick_tile(C, Hi, Wi, Ho, Wo, nullptr) >= 0 ? 1 : 0;
 }
 
 static int cebil_fill(CeBilParams& p, const void* x, int32_t ld_x, const int64_t* target, int32_t N, int32_t C, int32_t Hi, int32_t Wi,
@@ -626,14 +712,44 @@ int cvhip_seg_ce_bilinear_bwd(const void* x, int32_t ld_x, const int64_t* target
   p.gscale = grad_scale;
   p.dx = (h16_t*)dx;
   p.ld_dx = ld_dx;
-  p.tiles_h = (Hi + kCeBilTH - 1) / kCeBilTH;
-  p.tiles_w = (Wi + kCeBilTW - 1) / kCeBilTW;
-  p.fh_max = cebil_fbound(Hi, Ho, kCeBilTH);
-  p.fw_max = cebil_fbound(Wi, Wo, kCeBilTW);
-  const int lds = cebil_lds_bytes(C, ld_x, Hi, Wi, Ho, Wo);
-  if (lds > 96 * 1024) return CVHIP_ERR_UNSUPPORTED;
-  if (C <= 24) return cebil_launch_bwd<24>(p, lds, (hipStream_t)stream);
-  return cebil_launch_bwd<32>(p, lds, (hipStream_t)stream);
+  if (C <= 24) return cebil_launch_bwd_tile<24>(p, (hipStream_t)stream);
+  return cebil_launch_bwd_tile<32>(p, (hipStream_t)stream);
+}
+
+int cvhip_seg_ce_bilinear_fwd_px(const void* x, int32_t ld_x, const int64_t* target, int32_t N, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho,
+                                 int32_t Wo, int32_t align_corners, int32_t ignore_index, float* loss_px, void* stream) {
+  CeBilParams p{};
+  int st = cebil_fill(p, x, ld_x, target, N, C, Hi, Wi, Ho, Wo, align_corners, ignore_index);
+  if (st) return st;
+  if (!loss_px) return CVHIP_ERR_INVALID;
+  p.loss_px = loss_px;
+  const int rows = grid_for((int64_t)N * Ho * Wo);
+  if (C <= 24) hipLaunchKernelGGL(seg_ce_bilinear_fwd_kernel<24>, dim3(rows), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(seg_ce_bilinear_fwd_kernel<32>, dim3(rows), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("seg_ce_bilinear_fwd_kernel(px)");
+}
+
+int cvhip_seg_ce_bilinear_bwd_px(const void* x, int32_t ld_x, const int64_t* target, int32_t N, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho,
+                                 int32_t Wo, int32_t align_corners, int32_t ignore_index, const float* w_px, const float* grad_scale, void* dx,
+                                 int32_t ld_dx, void* stream) {
+  CeBilParams p{};
+  int st = cebil_fill(p, x, ld_x, target, N, C, Hi, Wi, Ho, Wo, align_corners, ignore_index);
+  if (st) return st;
+  if (!w_px || !dx || ld_dx < C) return CVHIP_ERR_INVALID;
+  p.w_px = w_px;
+  p.gscale = grad_scale;
+  p.dx = (h16_t*)dx;
+  p.ld_dx = ld_dx;
+  if (C <= 24) return cebil_launch_bwd_tile<24>(p, (hipStream_t)stream);
+  return cebil_launch_bwd_tile<32>(p, (hipStream_t)stream);
+}
+
+int cvhip_detail_boundary_targets(const int64_t* labels, int32_t N, int32_t H, int32_t W, float threshold, float* out, void* stream) {
+  if (!labels || !out || N <= 0 || H <= 0 || W <= 0) return CVHIP_ERR_INVALID;
+  const int64_t total = (int64_t)N * H * W;
+  if (total >= (1ll << 31)) return CVHIP_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(detail_targets_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, labels, N, H, W, threshold, out);
+  return check_launch("detail_targets_kernel");
 }
 
 int cvhip_scale_nc(const void* x, int32_t ld_x, const float* scale_nc, void* y, int32_t ld_y, int32_t N, int32_t C, int32_t HW, void* stream) {

@@ -2417,6 +2417,73 @@ class SegCrossEntropyBilinear(torch.autograd.Function):
         return buf.permute(0, 3, 1, 2)[:, :Cc], None, None, None
 
 
+class OhemCrossEntropyBilinear(torch.autograd.Function):
+    """OhemCrossEntropyLoss2d (src/losses/seg/cross_entropy_loss.py:51-69) of logits that encoder_decoder.py:96 first resizes to the
+    label size — on the LOW-resolution logits: the per-pixel losses come from cvhip_seg_ce_bilinear_fwd_px (the label-resolution
+    logits never exist), the selection of the hard pixels is the fixed-shape formulation of segmentors.OhemCrossEntropyLoss2d on that
+    fp32 vector (one topk, masked sums, where: no host sync), and the backward is cvhip_seg_ce_bilinear_bwd_px with the selection as
+    per-pixel weights. forward(logits, target, thresh_nlog (device scalar -log(thresh)), min_kept, ignore_index, loss_weight)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, thr, min_kept, ignore_index, loss_weight):
+        logits, ld = as_nhwc(logits)
+        N, Cc, Hi, Wi = logits.shape
+        target = target.long().contiguous()
+        Ho, Wo = int(target.shape[-2]), int(target.shape[-1])
+        M = N * Ho * Wo
+        if M <= min_kept:
+            raise IndexError("OhemCrossEntropyLoss2d: %d pixels, min_kept %d (the reference indexes loss[min_kept])" % (M, min_kept))
+        per = torch.empty((M,), dtype=torch.float32, device=logits.device)
+        L.call("cvhip_seg_ce_bilinear_fwd_px", logits.data_ptr(), ld, target.data_ptr(), N, Cc, Hi, Wi, Ho, Wo, 0, int(ignore_index),
+               per.data_ptr(), _stream())
+        lw = float(loss_weight)
+        loss = per * lw if lw != 1.0 else per
+        v = torch.topk(loss, min_kept + 1, sorted=True).values[min_kept]   # = sorted(loss, descending)[min_kept]
+        thr = thr.to(loss.dtype)
+        above = (loss > thr).to(loss.dtype)
+        n_above = above.sum().clamp_min(1.0)
+        mean_above = (loss * above).sum() / n_above
+        gt = (loss > v).to(loss.dtype)
+        n_gt = gt.sum()
+        mean_top = ((loss * gt).sum() + (min_kept - n_gt) * v) / float(min_kept)
+        ties = (loss == v).to(loss.dtype)
+        hard = v > thr
+        # d out / d loss[m]: `above` / n_above on the threshold branch; 1 / min_kept for the pixels above v and the tied pixels' common
+        # share (min_kept - n_gt) / n_ties / min_kept on the other (segmentors.OhemCrossEntropyLoss2d, the tie term) — as weights in
+        # [0, 1] times one scalar
+        w = torch.where(hard, above, gt + ties * ((min_kept - n_gt) / ties.sum().clamp_min(1.0)).clamp(0.0, 1.0))
+        scal = torch.where(hard, 1.0 / n_above, torch.full_like(n_above, 1.0 / float(min_kept))) * lw
+        ctx.meta = (N, Cc, Hi, Wi, Ho, Wo, ld, int(ignore_index))
+        ctx.save_for_backward(logits, target, w, scal)
+        return torch.where(hard, mean_above, mean_top)
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, w, scal = ctx.saved_tensors
+        N, Cc, Hi, Wi, Ho, Wo, ld, ign = ctx.meta
+        Cp = _round8(Cc)
+        gs = (g.detach().float().reshape(1) * scal.reshape(1)).contiguous()
+        buf = torch.empty((N, Hi, Wi, Cp), dtype=ACT_DTYPE, device=logits.device)
+        L.call("cvhip_seg_ce_bilinear_bwd_px", logits.data_ptr(), ld, target.data_ptr(), N, Cc, Hi, Wi, Ho, Wo, 0, ign, w.data_ptr(), gs.data_ptr(),
+               buf.data_ptr(), Cp, _stream())
+        return buf.permute(0, 3, 1, 2)[:, :Cc], None, None, None, None, None
+
+
+def ohem_cross_entropy_resized_ok(logits, target):
+    """the fused OHEM path runs this geometry (half-pixel bilinear up-sampling to the label size, <= 32 classes, tile fits the LDS)"""
+    N, Cc, Hi, Wi = logits.shape
+    return bool(_SEG_CE_FUSED and logits.is_cuda and L.load().cvhip_seg_ce_bilinear_ok(Cc, Hi, Wi, int(target.shape[-2]), int(target.shape[-1]), 0))
+
+
+def detail_boundary_targets(labels, threshold=0.1):
+    """detail_loss.py:37-79 on an int64 label map (N, H, W) -> fp32 (N, 1, H, W) in {0, 1} (cvhip_detail_boundary_targets)"""
+    labels = labels.long().contiguous()
+    N, H, W = labels.shape
+    out = torch.empty((N, 1, H, W), dtype=torch.float32, device=labels.device)
+    L.call("cvhip_detail_boundary_targets", labels.data_ptr(), N, H, W, float(threshold), out.data_ptr(), _stream())
+    return out
+
+
 _SEG_CE_FUSED = __import__("os").environ.get("CVHIP_SEG_CE_FUSED", "1") != "0"
 
 

@@ -97,6 +97,11 @@ class OhemCrossEntropyLoss2d(nn.Module):
         self.min_kept, self.ignore_index, self.loss_weight, self.loss_name = int(min_kept), ignore_index, loss_weight, loss_name
         self.register_buffer("thresh", -torch.log(torch.tensor(thresh, dtype=torch.float)), persistent=False)
 
+    def forward_lowres(self, pred_lowres, target):
+        """the same loss of `pred_lowres` resized (bilinear, half-pixel) to the label size, without the label-resolution logits: per-pixel
+        losses and the weighted backward from the fused resize + cross-entropy kernels (ops.OhemCrossEntropyBilinear)"""
+        return ops.OhemCrossEntropyBilinear.apply(pred_lowres, target, self.thresh, self.min_kept, self.ignore_index, self.loss_weight)
+
     def forward(self, pred, target):
         loss = self.loss_weight * F.cross_entropy(pred, target.long(), ignore_index=self.ignore_index, reduction="none").view(-1)
         if loss.numel() <= self.min_kept:
@@ -136,6 +141,12 @@ class DetailAggregateLoss(nn.Module):
 
     @torch.no_grad()
     def boundary_targets(self, gtmasks):
+        if gtmasks.is_cuda and gtmasks.dim() == 3:
+            return ops.detail_boundary_targets(gtmasks, self.boundary_threshold)   # one kernel (cvhip_detail_boundary_targets)
+        return self.boundary_targets_torch(gtmasks)
+
+    @torch.no_grad()
+    def boundary_targets_torch(self, gtmasks):
         g = gtmasks.unsqueeze(1).float()
         thr = self.boundary_threshold
         size = g.shape[2:]
@@ -225,11 +236,19 @@ class STDCEncoderDecoder(nn.Module):
 
     @staticmethod
     def _loss_forward(pred, targets, loss, into, prefix=""):
-        """encoder_decoder.py:89-107: resize to the label size, then every loss of the list (same-named entries add up)"""
-        pred = ops.to_nchw_f32(ops.resize_bilinear(pred, targets.shape[-2:], False))
-        for l in (loss if isinstance(loss, (list, tuple, nn.ModuleList)) else [loss]):
+        """encoder_decoder.py:89-107: resize to the label size, then every loss of the list (same-named entries add up). OHEM losses
+        take the low-resolution logits (resize + cross-entropy in one kernel, round 6) when the geometry allows; the others get the
+        label-resolution fp32 logits, resized once"""
+        ls = list(loss) if isinstance(loss, (list, tuple, nn.ModuleList)) else [loss]
+        full = None
+        for l in ls:
             k = prefix + l.loss_name
-            v = l(pred, targets)
+            if isinstance(l, OhemCrossEntropyLoss2d) and ops.ohem_cross_entropy_resized_ok(pred, targets):
+                v = l.forward_lowres(pred, targets)
+            else:
+                if full is None:
+                    full = ops.to_nchw_f32(ops.resize_bilinear(pred, targets.shape[-2:], False))
+                v = l(full, targets)
             into[k] = into[k] + v if k in into else v
 
     def loss_from_features(self, feats, targets):

@@ -350,6 +350,23 @@ int cvhip_seg_ce_bilinear_bwd(const void* x_bf16, int32_t ld_x, const int64_t* t
                               int32_t Ho, int32_t Wo, int32_t align_corners, int32_t ignore_index, const float* out2,
                               const float* grad_scale, void* dx_bf16, int32_t ld_dx, void* stream);
 
+/* Per-pixel forms of the fused resize + cross-entropy (round 6) for OHEM (src/losses/seg/cross_entropy_loss.py:51-69:
+ * F.cross_entropy(..., reduction='none') on the label-resolution logits, then a data-dependent selection of the hard pixels):
+ *   fwd_px : loss_px[N*Ho*Wo] = -log p_target of every label pixel (0 where ignored); nothing is reduced
+ *   bwd_px : dx = grad_scale[0] * sum_m w_px[m] * d(-log p_target(m)) / dx with per-pixel weights w_px in [0, 1] (the selection
+ *            mask, kept in 16 bits inside the kernel: put the common 1 / count into the DEVICE scalar grad_scale, NULL = 1)
+ * Same geometry limits as cvhip_seg_ce_bilinear_ok. */
+int cvhip_seg_ce_bilinear_fwd_px(const void* x_bf16, int32_t ld_x, const int64_t* target, int32_t N, int32_t C, int32_t Hi, int32_t Wi,
+                                 int32_t Ho, int32_t Wo, int32_t align_corners, int32_t ignore_index, float* loss_px, void* stream);
+int cvhip_seg_ce_bilinear_bwd_px(const void* x_bf16, int32_t ld_x, const int64_t* target, int32_t N, int32_t C, int32_t Hi, int32_t Wi,
+                                 int32_t Ho, int32_t Wo, int32_t align_corners, int32_t ignore_index, const float* w_px,
+                                 const float* grad_scale, void* dx_bf16, int32_t ld_dx, void* stream);
+
+/* Boundary targets of the STDC detail loss (src/losses/seg/detail_loss.py:37-79): Laplacian pyramid of the int64 label map
+ * (3x3 kernel, padding 1, strides 1 / 2 / 4, clamp(min=0), nearest up-sampling, threshold), fused with weights 0.6 / 0.3 / 0.1 and
+ * thresholded again -> out fp32 [N][H][W] in {0, 1}. Replaces three F.conv2d + two F.interpolate + cat + a 1x1 F.conv2d per step. */
+int cvhip_detail_boundary_targets(const int64_t* labels, int32_t N, int32_t H, int32_t W, float threshold, float* out, void* stream);
+
 /* nearest-neighbour resize to an arbitrary size: F.interpolate(x, size, mode="nearest") of the STDC neck (src/models/necks/seg:
  * stdc neck `F.interpolate(..., mode='nearest')` calls; torch's index rule src = min(floor(dst * in/out), in-1)). Forward is an
  * exact copy (bit-exact); backward a deterministic gather-sum over the output pixels of each input pixel. */

@@ -10,6 +10,7 @@ of the heads within 25 %."""
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
@@ -118,3 +119,62 @@ def test_full_stdc1_train_steps_through_the_flat_arena():
     assert sorted(l0.keys()) == ["aux0_detail_agg_loss", "aux1_ohem_ce_loss", "aux2_ohem_ce_loss", "loss", "ohem_ce_loss"]
     assert all(np.isfinite(float(v)) for v in l0.values()) and all(np.isfinite(float(v)) for v in l1.values())
     assert float((state.param != before).float().mean()) > 0.99
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 48), (3, 33, 47), (1, 8, 8), (2, 64, 128), (1, 5, 7)])
+def test_detail_boundary_targets_kernel_equals_the_torch_formulation(shape):
+    """cvhip_detail_boundary_targets == detail_loss.py:37-79 written with F.conv2d / F.interpolate (segmentors.DetailAggregateLoss.
+    boundary_targets_torch, pinned by the reference-run fixtures of test_oracle_stdc_train.py) — exactly, odd sizes and ignore labels
+    included"""
+    from cvpytorch_amd import ops, segmentors
+    g = torch.Generator().manual_seed(sum(shape))
+    N, H, W = shape
+    lab = torch.zeros(N, H, W, dtype=torch.int64)
+    for i in range(8):
+        y0, x0 = int(torch.randint(0, max(H - 2, 1), (1,), generator=g)), int(torch.randint(0, max(W - 2, 1), (1,), generator=g))
+        lab[:, y0:y0 + int(torch.randint(1, max(H // 2, 2), (1,), generator=g)), x0:x0 + int(torch.randint(1, max(W // 2, 2), (1,), generator=g))] = int(torch.randint(0, 19, (1,), generator=g))
+    lab[0, :2, :3] = 255
+    if N > 1:
+        lab[1] = torch.roll(lab[1], 3, 1)
+    l = segmentors.DetailAggregateLoss().to(dev())
+    ref = l.boundary_targets_torch(lab.to(dev())).cpu()
+    got = ops.detail_boundary_targets(lab.to(dev()), 0.1).cpu()
+    assert got.shape == ref.shape
+    assert torch.equal(got, ref), int((got != ref).sum())
+    assert 0 < float(got.mean()) < 1
+
+
+@pytest.mark.parametrize("case", [("hard", 1.0, 300), ("easy", 9.0, 300), ("ties", 6.0, 900)])
+def test_fused_ohem_on_lowres_logits_equals_the_two_op_form(case):
+    """ops.OhemCrossEntropyBilinear (per-pixel losses and weighted backward from the fused resize + cross-entropy kernels) against
+    segmentors.OhemCrossEntropyLoss2d on the engine-resized fp32 logits: both branches (threshold / top-k) and the tie case (min_kept
+    reaching into the zero losses of ignored pixels). The fused form interpolates in fp32, the two-op form rounds the resized logits to
+    16 bits first: loss within 2e-3 relative, gradient cosine >= 0.995."""
+    from cvpytorch_amd import ops, segmentors
+    name, scale, min_kept = case
+    g = torch.Generator().manual_seed(len(name) + min_kept)
+    tgt = torch.randint(0, 6, (2, 24, 32), generator=g)
+    low = torch.randn(2, 6, 12, 16, generator=g)
+    if scale > 1.0:   # confident predictions: up-weight the true class of the low-resolution cell
+        t_low = tgt[:, ::2, ::2]
+        low = low + scale * F.one_hot(t_low, 6).permute(0, 3, 1, 2).float()
+    tgt[:, :5] = 255
+    tgt = tgt.to(dev())
+    l = segmentors.OhemCrossEntropyLoss2d(thresh=0.7, min_kept=min_kept).to(dev())
+    xa = to_nhwc_bf16(low).requires_grad_(True)
+    xb = to_nhwc_bf16(low).requires_grad_(True)
+    assert ops.ohem_cross_entropy_resized_ok(xa, tgt)
+    la = l.forward_lowres(xa, tgt)
+    la.backward()
+    lb = l(ops.to_nchw_f32(ops.resize_bilinear(xb, tgt.shape[-2:], False)), tgt)
+    lb.backward()
+    torch.cuda.synchronize()
+    assert abs(float(la) - float(lb)) <= 2e-3 * abs(float(lb)) + 1e-6, (float(la), float(lb))
+    ga, gb = xa.grad.float().cpu(), xb.grad.float().cpu()
+    assert torch.isfinite(ga).all()
+    assert cosine(ga, gb) > 0.995, cosine(ga, gb)
+    assert abs(float(ga.norm()) / float(gb.norm()) - 1.0) < 2e-2
+
+
+def to_nhwc_bf16(x):
+    return x.to(torch.bfloat16).to(dev()).contiguous(memory_format=torch.channels_last)
