@@ -306,8 +306,9 @@ def deeplab_workload(dev, a, batch=16, size=(512, 1024), steps=20, warmup=3, out
 
 def stdc_workload(dev, a, steps, warmup, batch=16, size=(512, 1024)):
     """STDC1-Seg train step as conf/seg/stdc/cityscapes_stdc1.yml wires it (STDCNet -> STDCNeck -> FCNHead + three auxiliary heads, OHEM
-    cross-entropy x3 + detail loss; 1024x512 crops, batch 16 here as for config 3): forward graph, eager loss island (the two STDC
-    losses are fixed-shape torch ops on engine-resized logits), backward + SGD graph."""
+    cross-entropy x3 + detail loss; 1024x512 crops, batch 16 here as for config 3): forward graph, eager loss island (OHEM: per-pixel
+    losses and weighted backward from the fused resize + cross-entropy kernels on the low-resolution logits, the selection as fixed-shape
+    torch ops; detail loss: boundary targets in one kernel), backward + SGD graph."""
     from cvpytorch_amd import segmentors
     from cvpytorch_amd.arena import FlatTrainState, FlatTrainStep
     from cvpytorch_amd.data import synthetic_segmentation_batch

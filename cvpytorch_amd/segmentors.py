@@ -15,7 +15,13 @@ indexing and no host read, so a step keeps static shapes:
   * Detail loss: the Laplacian pyramid of the label map is label-only arithmetic (no gradient); BCE-with-logits + dice on the boundary
     logits. (The reference's `fuse_kernel` is an nn.Parameter that receives no gradient — the targets are thresholded — and is kept as
     a buffer here.)
-Losses made of torch ops mean `loss_capturable = False`: arena.FlatTrainStep replays two hipGraphs around an eager loss island."""
+Round 6: the label-resolution logits no longer exist for the OHEM heads. The per-pixel losses come from the fused resize +
+cross-entropy kernel on the LOW-resolution logits (cvhip_seg_ce_bilinear_fwd_px), the selection above runs on that fp32 vector, and
+the backward is the fused kernel with the selection as per-pixel weights (ops.OhemCrossEntropyBilinear; x8 / x16 up-sampling through
+smaller backward tiles); the detail loss's boundary targets are one kernel (cvhip_detail_boundary_targets). The torch-op forms above
+remain the fallback (CPU, geometries the fused kernels refuse) and the statement the tests compare against.
+The selection (topk, masked sums) is still made of torch ops, so `loss_capturable = False`: arena.FlatTrainStep replays two hipGraphs
+around an eager loss island."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
