@@ -54,7 +54,7 @@ struct DwParams {
   float ap;
 };
 
-__device__ __forceinline__ bool dw_vec_ok(const DwParams& p) {
+__host__ __device__ __forceinline__ bool dw_vec_ok(const DwParams& p) {
   return (p.C & 7) == 0 && (p.x_ld & 7) == 0 && (p.y_ld & 7) == 0 && ((((uintptr_t)p.x) | ((uintptr_t)p.y) | ((uintptr_t)p.dy)) & 15) == 0;
 }
 
@@ -144,6 +144,79 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const DwParams p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) o.v[j] = acc[j];
     dw_store8(p.y + ((int64_t)(n * p.H + h) * p.W + w) * p.y_ld, c, p.C, vec, o);
+  }
+}
+
+// 3x3 / stride 2 / padding 1 / dilation 1 input gradient (round 6: STDC's stride-2 blocks — the depthwise `avd_layer` and the
+// AvgPool2d(3, 2, 1) skip, stdcnet.py — ran the generic gather above: run-time tap loops with a division and a modulo per tap and
+// eight scalar weight loads per tap and element, 224 us per launch for 167 MB = 0.75 TB/s). An input row / column of parity e takes
+// tap 1 of output index i / 2 when even, taps 0 and 2 of (i + 1) / 2 and (i - 1) / 2 when odd: at most four taps, decided by parity.
+// A thread owns one channel vector (its 9 x 8 weights in registers) and walks pixels; a block owns a contiguous pixel range.
+__global__ __launch_bounds__(256) void dw3x3_s2_dgrad_kernel(const DwParams p, int pix_per_block) {
+  const int CV = p.C >> 3;
+  const int cols = CV < 256 ? CV : 256;
+  const int rpp = 256 / cols;
+  const int tx = threadIdx.x % cols, ty = threadIdx.x / cols;
+  if (ty >= rpp) return;
+  const int64_t npix = (int64_t)p.N * p.H * p.W;
+  const int64_t p_begin = (int64_t)blockIdx.x * pix_per_block;
+  int64_t p_end = p_begin + pix_per_block;
+  if (p_end > npix) p_end = npix;
+  for (int cv = tx; cv < CV; cv += cols) {
+    const int c = cv * 8;
+    float w[3][3][8];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[r][s][j] = p.w[(int64_t)(c + j) * 9 + r * 3 + s];
+    for (int64_t i = p_begin + ty; i < p_end; i += rpp) {
+      const int wx = (int)(i % p.W);
+      const int64_t q = i / p.W;
+      const int h = (int)(q % p.H);
+      const int n = (int)(q / p.H);
+      // rows: (tap r, output row) pairs; th = h + 1 - r must be even and th / 2 < P
+      int rr[2], oh[2], nr = 0;
+      if ((h & 1) == 0) {
+        if (h / 2 < p.P) { rr[0] = 1; oh[0] = h / 2; nr = 1; }
+      } else {
+        if ((h + 1) / 2 < p.P) { rr[nr] = 0; oh[nr] = (h + 1) / 2; ++nr; }
+        rr[nr] = 2; oh[nr] = (h - 1) / 2; ++nr;   // (h - 1) / 2 <= P - 1 always: P = floor((H - 1) / 2) + 1
+      }
+      int ss[2], ow[2], ns = 0;
+      if ((wx & 1) == 0) {
+        if (wx / 2 < p.Q) { ss[0] = 1; ow[0] = wx / 2; ns = 1; }
+      } else {
+        if ((wx + 1) / 2 < p.Q) { ss[ns] = 0; ow[ns] = (wx + 1) / 2; ++ns; }
+        ss[ns] = 2; ow[ns] = (wx - 1) / 2; ++ns;
+      }
+      float acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+      // same accumulation order as the generic kernel (r ascending, then s ascending)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        if (a >= nr) continue;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          if (b >= ns) continue;
+          const f32x8 g = unpack8(*reinterpret_cast<const uint4*>(p.x + ((int64_t)(n * p.P + oh[a]) * p.Q + ow[b]) * p.x_ld + c));
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+              if (r == rr[a] && s == ss[b]) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += g.v[j] * w[r][s][j];
+              }
+        }
+      }
+      f32x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o.v[j] = acc[j];
+      *reinterpret_cast<uint4*>(p.y + i * p.y_ld + c) = pack8(o);
+    }
   }
 }
 
@@ -944,6 +1017,16 @@ int cvhip_dwconv2d_dgrad(const cvhip_conv_desc* d, const void* dy, const float* 
   {
     int tst = CVHIP_OK;
     if (dw_taps_launch(p, true, (hipStream_t)stream, &tst)) return tst;
+  }
+  if (p.R == 3 && p.S == 3 && p.sh == 2 && p.sw == 2 && p.ph == 1 && p.pw == 1 && p.dh == 1 && p.dw_ == 1 && dw_vec_ok(p) &&
+      p.P == (p.H - 1) / 2 + 1 && p.Q == (p.W - 1) / 2 + 1) {
+    const int CV = p.C >> 3;
+    const int rpp = 256 / (CV < 256 ? CV : 256);
+    const int64_t npix = (int64_t)p.N * p.H * p.W;
+    int ppb = rpp * 16;   // ~16 pixel visits per thread
+    while (cdiv64(npix, ppb) > 256 * 32) ppb *= 2;
+    hipLaunchKernelGGL(dw3x3_s2_dgrad_kernel, dim3((unsigned)cdiv64(npix, ppb)), dim3(256), 0, (hipStream_t)stream, p, ppb);
+    return check_launch("dw3x3_s2_dgrad_kernel");
   }
   hipLaunchKernelGGL(dw_dgrad_kernel, dim3(grid_for((int64_t)p.N * p.H * p.W * ((p.C + 7) / 8))), dim3(256), 0,
                      (hipStream_t)stream, p);

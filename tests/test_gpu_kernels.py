@@ -315,7 +315,10 @@ def test_conv_channel_slice_operands():
                                          (304, 21, 200, 1, 1, 1), (16, 9, 130, 1, 0, 1), (24, 9, 70, 1, 2, 1), (2304, 5, 7, 1, 1, 1),
                                          # LDS-ring kernel (dw3x3_lds_kernel): 32-vector chunks, two chunks with a ragged second one (65 vectors),
                                          # pad 0 and pad 2, strips that do not divide the width, row blocks that do not divide the height
-                                         (256, 40, 64, 1, 1, 1), (520, 17, 40, 1, 1, 1), (304, 33, 50, 1, 0, 1), (128, 19, 120, 1, 2, 1)])
+                                         (256, 40, 64, 1, 1, 1), (520, 17, 40, 1, 1, 1), (304, 33, 50, 1, 0, 1), (128, 19, 120, 1, 2, 1),
+                                         # 3x3 / stride 2 / pad 1 input gradient by tap parity (dw3x3_s2_dgrad_kernel, round 6): even and odd
+                                         # sizes (the last odd row / column has no (i + 1) / 2 output), > 256 channels, one-pixel outputs
+                                         (64, 16, 20, 2, 1, 1), (128, 9, 8, 2, 1, 1), (2304, 6, 5, 2, 1, 1), (32, 2, 2, 2, 1, 1), (8, 1, 7, 2, 1, 1)])
 def test_depthwise(Cc, H, W, s, p, d):
     torch.manual_seed(0)
     N = 2
