@@ -148,3 +148,28 @@ def test_parked_gradients_are_accounted_for():
     link.g = torch.ones(2)
     link.g = None                            # the folding layer took it
     ops.check_parked()
+
+
+def test_offered_column_sums_are_taken_once_by_address_and_width():
+    """ops.offer_colsum / _take_colsum (round 6: the fused YOLOv5 loss hands the detect convolutions their bias gradient): keyed by the
+    gradient map's address, consumed by the first taker, refused on a width mismatch, emptied by the next producer's backward; the
+    entry keeps the map alive so that its address cannot be re-used while the sums wait"""
+    import torch
+    from cvpytorch_amd import ops
+    ops.clear_colsums()
+    draw = torch.zeros(2, 4, 4, 8)
+    part = torch.zeros(3, 2, 5)
+    ops.offer_colsum(draw, part, 3, 5)
+    assert ops._take_colsum(draw.data_ptr() + 2, 5) is None          # a channel slice that does not start at channel 0
+    assert ops._take_colsum(draw.data_ptr(), 4) is None              # width mismatch: refused (and dropped: the taker computes its own sums)
+    assert ops._take_colsum(draw.data_ptr(), 5) is None
+    ops.offer_colsum(draw, part, 3, 5)
+    ptr = draw.data_ptr()
+    del draw
+    got = ops._take_colsum(ptr, 5)
+    assert got is not None and got[0] is part and got[1] == 3
+    assert ops._take_colsum(ptr, 5) is None                          # taken once
+    other = torch.zeros(2, 4, 4, 8)
+    ops.offer_colsum(other, part, 3, 5)
+    ops.clear_colsums()
+    assert not ops._COLSUMS
