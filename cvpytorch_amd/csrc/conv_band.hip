@@ -687,6 +687,13 @@ static bool band_plan_nw(const IgemmParams& p, int NW, BandPlan* pl, bool* polic
   // 64- / 128-channel layers of the same network still lose (80.9 vs 69.8, 54.0 vs 49.9) and stay out.
   if (!*policy_ok && NC >= 8 && n_tiles <= 32 && total * 10 >= rounds * slots * 7 && (int64_t)TH * p.OW * 4 >= (int64_t)pl->MFW * WM * 16 * 3)
     *policy_ok = true;
+  // Round 6, later: SMALL problems (STDC1-Seg at batch 16: 64x128 / 32x64 / 16x32 maps, profiles/r06_band_small_policy.log). The
+  // patch-resident kernel's 16x16 tiles leave most of the chip idle there (32 - 128 tiles) and the per-tap kernel's 256-pixel tiles are few;
+  // the row bands still make hundreds of blocks: 256 -> 128 @32x64 30.1 vs 47.6 us, 512 -> 256 @16x32 37.9 vs 76.5, 1024 -> 128 @16x32
+  // 69.8 vs 146.2, 128 -> 64 @64x128 30.2 vs 40.4, 64 -> 32 @64x128 14.6 vs 19.0. Up to 32 K output pixels for any width, up to 128 K
+  // for <= 64 output channels (128 -> 128 @64x128 and 64 -> 64 @128x256 of DeepLabv3+ still lose and stay out).
+  const int64_t Mout = (int64_t)p.NB * p.OH * p.OW;
+  if (!*policy_ok && (Mout <= 32768 || (Mout <= 131072 && p.Nout <= 64))) *policy_ok = true;
   return true;
 }
 

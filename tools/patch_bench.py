@@ -25,6 +25,16 @@ SHAPES = [
     (16, 256, 32, 64, 256, 3, 3, 1, 1, 1, "dl 256->256 @32x64"),
     (16, 512, 32, 64, 512, 3, 3, 1, 2, 2, "dl 512->512 dil2 @32x64"),
 ]
+if os.environ.get("STDC"):   # STDC1-Seg (batch 16, 1024x512): the 3x3 stride-1 layers of the STDC blocks, the neck and the heads
+    SHAPES = [
+        (16, 128, 64, 128, 64, 3, 3, 1, 1, 1, "stdc 128->64 @64x128"), (16, 64, 64, 128, 32, 3, 3, 1, 1, 1, "stdc 64->32 @64x128"),
+        (16, 32, 64, 128, 32, 3, 3, 1, 1, 1, "stdc 32->32 @64x128"), (16, 256, 32, 64, 128, 3, 3, 1, 1, 1, "stdc 256->128 @32x64"),
+        (16, 128, 32, 64, 64, 3, 3, 1, 1, 1, "stdc 128->64 @32x64"), (16, 64, 32, 64, 64, 3, 3, 1, 1, 1, "stdc 64->64 @32x64"),
+        (16, 512, 16, 32, 256, 3, 3, 1, 1, 1, "stdc 512->256 @16x32"), (16, 256, 16, 32, 128, 3, 3, 1, 1, 1, "stdc 256->128 @16x32"),
+        (16, 128, 16, 32, 128, 3, 3, 1, 1, 1, "stdc 128->128 @16x32"), (16, 256, 64, 128, 256, 3, 3, 1, 1, 1, "stdc head 256->256 @64x128"),
+        (16, 256, 64, 128, 64, 3, 3, 1, 1, 1, "stdc detail head 256->64 @64x128"), (16, 1024, 16, 32, 128, 3, 3, 1, 1, 1, "stdc arm 1024->128 @16x32"),
+        (16, 512, 32, 64, 128, 3, 3, 1, 1, 1, "stdc arm 512->128 @32x64"),
+    ]
 REPS = int(os.environ.get("REPS", "20"))
 ROUNDS = int(os.environ.get("ROUNDS", "3"))
 only = os.environ.get("ONLY")
@@ -46,7 +56,7 @@ def timed(fn, nsets):
 def main():
     lib = L.load()
     variants = [("per-tap", {"CVHIP_PATCH": "0", "CVHIP_BAND": "0"}), ("patch", {"CVHIP_PATCH": "1", "CVHIP_BAND": "0"}),
-                ("band", {"CVHIP_PATCH": "1", "CVHIP_BAND": "2"})]   # (conv_band.hip: stride-1 3x3 only; elsewhere it falls through to "patch")
+                ("band", {"CVHIP_PATCH": "1", "CVHIP_BAND": "2"}), ("default", {"CVHIP_PATCH": "1", "CVHIP_BAND": "1"})]   # (conv_band.hip: stride-1 3x3 only; elsewhere it falls through to "patch")
     for extra in os.environ.get("VARIANTS", "").split(";"):
         if extra:
             name, kv = extra.split(":")
