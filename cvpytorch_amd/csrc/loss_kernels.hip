@@ -163,6 +163,10 @@ struct CeBilParams {
   // per-pixel forms (round 6: OHEM, cross_entropy_loss.py:51-69 — the selection of hard pixels happens between the two passes)
   float* loss_px;       // forward: [N][Ho][Wo] -log p_t of every label pixel (0 where ignored); no reduction
   const float* w_px;    // backward: [N][Ho][Wo] weights in [0, 1]: dx = gscale * sum_m w_px[m] * d(-log p_t(m)) / dx (no 1 / #valid)
+  // OHEM selection on the device (cvhip_ohem_select): the weight of a pixel follows from its forward loss and the selection record
+  const float* sel;     // float[8]: [0] loss value, [1] backward scalar, [2] weight of the tied pixels, [3] threshold branch?, [4] v, [5] thr
+  const float* sel_loss;  // [N][Ho][Wo] the forward's per-pixel losses (loss_px of fwd_px)
+  float sel_lw;           // loss_weight: the selection compares loss_px * loss_weight
   int tiles_h, tiles_w, fh_max, fw_max;
 };
 
@@ -401,7 +405,12 @@ __global__ __launch_bounds__(256) void seg_ce_bilinear_bwd_kernel(const CeBilPar
     const int oy = oy_lo + fy, ox = ox_lo + fx;
     const int64_t tt = tg[(int64_t)oy * p.Wo + ox];
     _Float16* const g = G + (size_t)f * p.C;
-    const float wm = p.w_px ? p.w_px[((int64_t)n * p.Ho + oy) * p.Wo + ox] : 1.f;
+    float wm = 1.f;
+    if (p.w_px) wm = p.w_px[((int64_t)n * p.Ho + oy) * p.Wo + ox];
+    else if (p.sel) {
+      const float l = p.sel_loss[((int64_t)n * p.Ho + oy) * p.Wo + ox] * p.sel_lw;
+      wm = p.sel[3] != 0.f ? (l > p.sel[5] ? 1.f : 0.f) : (l > p.sel[4] ? 1.f : (l == p.sel[4] ? p.sel[2] : 0.f));
+    }
     if (tt == p.ignore || tt < 0 || tt >= p.C || wm == 0.f) {
 #pragma unroll
       for (int c = 0; c < CMAX; ++c)
@@ -427,8 +436,8 @@ __global__ __launch_bounds__(256) void seg_ce_bilinear_bwd_kernel(const CeBilPar
       if (c < p.C) g[c] = (_Float16)((z[c] * inv - (c == (int)tt ? 1.f : 0.f)) * wm);
   }
   __syncthreads();
-  const float cnt = p.w_px ? 1.f : p.stat[1];
-  const float gs = (cnt > 0.f ? 1.f / cnt : 0.f) * (p.gscale ? p.gscale[0] : 1.f);
+  const float cnt = (p.w_px || p.sel) ? 1.f : p.stat[1];
+  const float gs = (cnt > 0.f ? 1.f / cnt : 0.f) * (p.gscale ? p.gscale[0] : 1.f) * (p.sel ? p.sel[1] : 1.f);
   // gather: a thread owns (tile column lj, class c) — c fastest, ld_dx entries per pixel, the pad channels are written as zeros —
   // and walks the footprint rows once: the row sums over the footprint columns are shared by the TH tile rows, the <= 2r
   // independent LDS reads of a row are in flight together
@@ -454,6 +463,155 @@ __global__ __launch_bounds__(256) void seg_ce_bilinear_bwd_kernel(const CeBilPar
 #pragma unroll
     for (int li = 0; li < TH; ++li)
       if (i0 + li < p.Hi) p.dx[((int64_t)(n * p.Hi + i0 + li) * p.Wi + j) * p.ld_dx + c] = (h16_t)(acc[li] * gs);
+  }
+}
+
+// ---- OHEM selection on the device (round 6) ------------------------------------------------------------------------------------------
+// cross_entropy_loss.py:51-69 sorts all per-pixel losses and branches on loss_sorted[min_kept] > thresh. Everything it needs is the
+// value v = the (min_kept + 1)-th largest loss and five masked sums (segmentors.OhemCrossEntropyLoss2d has the derivation): v by a
+// three-pass radix select on the order-preserving integer image of the fp32 losses (12 + 12 + 8 bits: block-local LDS histograms, one
+// single-block scan per pass), the sums by one deterministic two-stage reduction. Four reads of the 33-MB loss vector instead of a
+// full radix sort (torch.topk) plus ~15 element-wise / reduction launches.
+__device__ __forceinline__ unsigned ohem_key(float l) {
+  const unsigned b = __float_as_uint(l);
+  return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);   // larger float <=> larger key
+}
+__device__ __forceinline__ float ohem_unkey(unsigned k) {
+  return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
+}
+
+struct OhemWs {
+  unsigned hist[4096];
+  unsigned prefix;   // key bits fixed so far (aligned at the top)
+  unsigned rank;     // descending rank still to descend inside the fixed prefix
+  unsigned pad[2];
+  double partial[1024][5];
+};
+
+template <int PASS>
+__global__ __launch_bounds__(256) void ohem_hist_kernel(const float* __restrict__ loss, int64_t M, float lw, OhemWs* ws) {
+  __shared__ unsigned h[4096];
+  constexpr int NB = PASS == 2 ? 256 : 4096;
+  for (int i = threadIdx.x; i < NB; i += 256) h[i] = 0u;
+  __syncthreads();
+  const unsigned prefix = PASS == 0 ? 0u : ws->prefix;
+  for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
+    const unsigned k = ohem_key(loss[m] * lw);
+    if (PASS == 0) atomicAdd(&h[k >> 20], 1u);
+    else if (PASS == 1) {
+      if ((k >> 20) == (prefix >> 20)) atomicAdd(&h[(k >> 8) & 0xfffu], 1u);
+    } else {
+      if ((k >> 8) == (prefix >> 8)) atomicAdd(&h[k & 0xffu], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NB; i += 256)
+    if (h[i]) atomicAdd(&ws->hist[i], h[i]);
+}
+
+// one block: the bin (descending) in which the running count passes the rank; fixes its bits, leaves the rank inside it, clears the
+// histogram for the next pass
+template <int PASS>
+__global__ __launch_bounds__(256) void ohem_scan_kernel(OhemWs* ws, unsigned rank0) {
+  constexpr int NB = PASS == 2 ? 256 : 4096;
+  constexpr int PER = NB / 256;
+  __shared__ unsigned chunk[256];
+  __shared__ unsigned found[2];
+  const int t = threadIdx.x;
+  const unsigned rank = PASS == 0 ? rank0 : ws->rank;
+  // thread t owns bins [NB - 1 - t * PER, ...) descending
+  unsigned s = 0;
+  for (int j = 0; j < PER; ++j) s += ws->hist[NB - 1 - (t * PER + j)];
+  chunk[t] = s;
+  __syncthreads();
+  if (t == 0) {
+    unsigned cum = 0;
+    int c = 0;
+    for (; c < 256; ++c) {
+      if (cum + chunk[c] > rank) break;
+      cum += chunk[c];
+    }
+    if (c == 256) c = 255;   // (rank >= count: cannot happen for rank < M)
+    int bin = NB - 1 - c * PER;
+    for (int j = 0; j < PER; ++j) {
+      const unsigned hcount = ws->hist[NB - 1 - (c * PER + j)];
+      bin = NB - 1 - (c * PER + j);
+      if (cum + hcount > rank) break;
+      cum += hcount;
+    }
+    found[0] = (unsigned)bin;
+    found[1] = rank - cum;
+  }
+  __syncthreads();
+  for (int i = t; i < NB; i += 256) ws->hist[i] = 0u;
+  if (t == 0) {
+    const unsigned prev = PASS == 0 ? 0u : ws->prefix;
+    ws->prefix = PASS == 0 ? (found[0] << 20) : PASS == 1 ? (prev | (found[0] << 8)) : (prev | found[0]);
+    ws->rank = found[1];
+  }
+}
+
+__global__ __launch_bounds__(256) void ohem_stats_kernel(const float* __restrict__ loss, int64_t M, float lw, float thr, OhemWs* ws) {
+  __shared__ double red[5][256];
+  const float v = ohem_unkey(ws->prefix);
+  double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
+    const float l = loss[m] * lw;
+    if (l > thr) {
+      a[0] += (double)l;
+      a[1] += 1.0;
+    }
+    if (l > v) {
+      a[2] += (double)l;
+      a[3] += 1.0;
+    } else if (l == v) a[4] += 1.0;
+  }
+#pragma unroll
+  for (int q = 0; q < 5; ++q) red[q][threadIdx.x] = a[q];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 5) ws->partial[blockIdx.x][threadIdx.x] = red[threadIdx.x][0];
+}
+
+__global__ __launch_bounds__(256) void ohem_finalize_kernel(OhemWs* ws, int nblocks, int min_kept, float thr, float lw, float* sel) {
+  __shared__ double red[5][256];
+  double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int b = threadIdx.x; b < nblocks; b += 256)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) a[q] += ws->partial[b][q];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) red[q][threadIdx.x] = a[q];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float v = ohem_unkey(ws->prefix);
+    const double s_above = red[0][0], n_above = red[1][0] > 1.0 ? red[1][0] : 1.0, s_gt = red[2][0], n_gt = red[3][0];
+    const double n_ties = red[4][0] > 1.0 ? red[4][0] : 1.0;
+    const bool hard = v > thr;
+    const double mean_above = s_above / n_above;
+    const double mean_top = (s_gt + ((double)min_kept - n_gt) * (double)v) / (double)min_kept;
+    double tie = ((double)min_kept - n_gt) / n_ties;
+    tie = tie < 0.0 ? 0.0 : (tie > 1.0 ? 1.0 : tie);
+    sel[0] = (float)(hard ? mean_above : mean_top);
+    sel[1] = (float)((hard ? 1.0 / n_above : 1.0 / (double)min_kept) * (double)lw);
+    sel[2] = (float)tie;
+    sel[3] = hard ? 1.f : 0.f;
+    sel[4] = v;
+    sel[5] = thr;
+    sel[6] = (float)red[3][0];
+    sel[7] = (float)red[4][0];
   }
 }
 
@@ -737,6 +895,46 @@ int cvhip_seg_ce_bilinear_bwd_px(const void* x, int32_t ld_x, const int64_t* tar
   if (st) return st;
   if (!w_px || !dx || ld_dx < C) return CVHIP_ERR_INVALID;
   p.w_px = w_px;
+  p.gscale = grad_scale;
+  p.dx = (h16_t*)dx;
+  p.ld_dx = ld_dx;
+  if (C <= 24) return cebil_launch_bwd_tile<24>(p, (hipStream_t)stream);
+  return cebil_launch_bwd_tile<32>(p, (hipStream_t)stream);
+}
+
+int64_t cvhip_ohem_select_workspace_bytes(void) { return (int64_t)sizeof(OhemWs); }
+
+int cvhip_ohem_select(const float* loss_px, int64_t M, int32_t min_kept, float thresh_nlog, float loss_weight, void* workspace, float* sel8,
+                      void* stream) {
+  if (!loss_px || !workspace || !sel8 || M <= 0 || min_kept <= 0 || (int64_t)min_kept >= M || M >= (1ll << 32)) return CVHIP_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  OhemWs* ws = (OhemWs*)workspace;
+  int st = zero_fill(ws, sizeof(unsigned) * 4096 + 16, s);
+  if (st) return st;
+  int64_t nb = cdiv64(M, 256 * 16);
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(ohem_hist_kernel<0>, dim3((unsigned)nb), dim3(256), 0, s, loss_px, M, loss_weight, ws);
+  hipLaunchKernelGGL(ohem_scan_kernel<0>, dim3(1), dim3(256), 0, s, ws, (unsigned)min_kept);
+  hipLaunchKernelGGL(ohem_hist_kernel<1>, dim3((unsigned)nb), dim3(256), 0, s, loss_px, M, loss_weight, ws);
+  hipLaunchKernelGGL(ohem_scan_kernel<1>, dim3(1), dim3(256), 0, s, ws, 0u);
+  hipLaunchKernelGGL(ohem_hist_kernel<2>, dim3((unsigned)nb), dim3(256), 0, s, loss_px, M, loss_weight, ws);
+  hipLaunchKernelGGL(ohem_scan_kernel<2>, dim3(1), dim3(256), 0, s, ws, 0u);
+  hipLaunchKernelGGL(ohem_stats_kernel, dim3((unsigned)nb), dim3(256), 0, s, loss_px, M, loss_weight, thresh_nlog, ws);
+  hipLaunchKernelGGL(ohem_finalize_kernel, dim3(1), dim3(256), 0, s, ws, (int)nb, min_kept, thresh_nlog, loss_weight, sel8);
+  return check_launch("ohem_select");
+}
+
+int cvhip_seg_ce_bilinear_bwd_ohem(const void* x, int32_t ld_x, const int64_t* target, int32_t N, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho,
+                                   int32_t Wo, int32_t align_corners, int32_t ignore_index, const float* loss_px, float loss_weight,
+                                   const float* sel8, const float* grad_scale, void* dx, int32_t ld_dx, void* stream) {
+  CeBilParams p{};
+  int st = cebil_fill(p, x, ld_x, target, N, C, Hi, Wi, Ho, Wo, align_corners, ignore_index);
+  if (st) return st;
+  if (!loss_px || !sel8 || !dx || ld_dx < C) return CVHIP_ERR_INVALID;
+  p.sel = sel8;
+  p.sel_loss = loss_px;
+  p.sel_lw = loss_weight;
   p.gscale = grad_scale;
   p.dx = (h16_t*)dx;
   p.ld_dx = ld_dx;

@@ -182,6 +182,9 @@ SIGNATURES = {
     "cvhip_seg_ce_bilinear_fwd_px": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     "cvhip_seg_ce_bilinear_bwd_px": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p]),
     "cvhip_detail_boundary_targets": (_i32, [_p, _i32, _i32, _i32, _f32, _p, _p]),
+    "cvhip_ohem_select_workspace_bytes": (_i64, []),
+    "cvhip_ohem_select": (_i32, [_p, _i64, _i32, _f32, _f32, _p, _p, _p]),
+    "cvhip_seg_ce_bilinear_bwd_ohem": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _f32, _p, _p, _p, _i32, _p]),
     "cvhip_resize_nearest_fwd": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "cvhip_resize_nearest_bwd": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "cvhip_resize_bilinear_fwd": (_i32, [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),

@@ -2469,6 +2469,47 @@ class OhemCrossEntropyBilinear(torch.autograd.Function):
         return buf.permute(0, 3, 1, 2)[:, :Cc], None, None, None, None, None
 
 
+class OhemCrossEntropyBilinearFused(torch.autograd.Function):
+    """OhemCrossEntropyBilinear with the selection on the device too (cvhip_ohem_select: three-pass radix select of the cut value + one
+    reduction instead of torch.topk and ~15 element-wise / reduction launches; the backward kernel derives every pixel's weight from its
+    forward loss and the selection record). forward(logits, target, thresh_nlog (python float), min_kept, ignore_index, loss_weight)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, thr, min_kept, ignore_index, loss_weight):
+        logits, ld = as_nhwc(logits)
+        N, Cc, Hi, Wi = logits.shape
+        target = target.long().contiguous()
+        Ho, Wo = int(target.shape[-2]), int(target.shape[-1])
+        M = N * Ho * Wo
+        if M <= min_kept:
+            raise IndexError("OhemCrossEntropyLoss2d: %d pixels, min_kept %d (the reference indexes loss[min_kept])" % (M, min_kept))
+        dev = logits.device
+        st = _stream()
+        per = torch.empty((M,), dtype=torch.float32, device=dev)
+        L.call("cvhip_seg_ce_bilinear_fwd_px", logits.data_ptr(), ld, target.data_ptr(), N, Cc, Hi, Wi, Ho, Wo, 0, int(ignore_index),
+               per.data_ptr(), st)
+        ws = torch.empty((int(L.load().cvhip_ohem_select_workspace_bytes()),), dtype=torch.uint8, device=dev)
+        sel = torch.empty((8,), dtype=torch.float32, device=dev)
+        L.call("cvhip_ohem_select", per.data_ptr(), M, int(min_kept), float(thr), float(loss_weight), ws.data_ptr(), sel.data_ptr(), st)
+        ctx.meta = (N, Cc, Hi, Wi, Ho, Wo, ld, int(ignore_index), float(loss_weight))
+        ctx.save_for_backward(logits, target, per, sel)
+        return sel[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, per, sel = ctx.saved_tensors
+        N, Cc, Hi, Wi, Ho, Wo, ld, ign, lw = ctx.meta
+        Cp = _round8(Cc)
+        gs = g.detach().float().reshape(1).contiguous()
+        buf = torch.empty((N, Hi, Wi, Cp), dtype=ACT_DTYPE, device=logits.device)
+        L.call("cvhip_seg_ce_bilinear_bwd_ohem", logits.data_ptr(), ld, target.data_ptr(), N, Cc, Hi, Wi, Ho, Wo, 0, ign, per.data_ptr(), lw,
+               sel.data_ptr(), gs.data_ptr(), buf.data_ptr(), Cp, _stream())
+        return buf.permute(0, 3, 1, 2)[:, :Cc], None, None, None, None, None
+
+
+_OHEM_SELECT = __import__("os").environ.get("CVHIP_OHEM_SELECT", "1") != "0"   # 0: the selection as torch ops (OhemCrossEntropyBilinear)
+
+
 def ohem_cross_entropy_resized_ok(logits, target):
     """the fused OHEM path runs this geometry (half-pixel bilinear up-sampling to the label size, <= 32 classes, tile fits the LDS)"""
     N, Cc, Hi, Wi = logits.shape

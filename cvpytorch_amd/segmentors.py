@@ -102,10 +102,13 @@ class OhemCrossEntropyLoss2d(nn.Module):
         super().__init__()
         self.min_kept, self.ignore_index, self.loss_weight, self.loss_name = int(min_kept), ignore_index, loss_weight, loss_name
         self.register_buffer("thresh", -torch.log(torch.tensor(thresh, dtype=torch.float)), persistent=False)
+        self.thresh_nlog = float(-torch.log(torch.tensor(thresh, dtype=torch.float)))   # the same fp32 value as a host scalar
 
     def forward_lowres(self, pred_lowres, target):
         """the same loss of `pred_lowres` resized (bilinear, half-pixel) to the label size, without the label-resolution logits: per-pixel
         losses and the weighted backward from the fused resize + cross-entropy kernels (ops.OhemCrossEntropyBilinear)"""
+        if ops._OHEM_SELECT:   # the selection on the device as well (cvhip_ohem_select)
+            return ops.OhemCrossEntropyBilinearFused.apply(pred_lowres, target, self.thresh_nlog, self.min_kept, self.ignore_index, self.loss_weight)
         return ops.OhemCrossEntropyBilinear.apply(pred_lowres, target, self.thresh, self.min_kept, self.ignore_index, self.loss_weight)
 
     def forward(self, pred, target):

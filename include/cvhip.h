@@ -362,6 +362,21 @@ int cvhip_seg_ce_bilinear_bwd_px(const void* x_bf16, int32_t ld_x, const int64_t
                                  int32_t Ho, int32_t Wo, int32_t align_corners, int32_t ignore_index, const float* w_px,
                                  const float* grad_scale, void* dx_bf16, int32_t ld_dx, void* stream);
 
+/* OHEM selection on the device (cross_entropy_loss.py:51-69: sort the per-pixel losses, branch on loss_sorted[min_kept] > thresh, average
+ * either the losses above the threshold or the min_kept largest): the (min_kept + 1)-th largest value of loss_px * loss_weight by a
+ * three-pass radix select, the masked sums by one two-stage reduction — no sort, no host read.
+ *   sel8 (DEVICE float[8]): [0] the loss, [1] d loss / d(selected per-pixel CE) incl. loss_weight, [2] common weight of the pixels tied
+ *   at the cut, [3] 1 = threshold branch, [4] the cut value v, [5] thresh_nlog = -log(thresh), [6] #pixels above v, [7] #pixels tied.
+ * cvhip_seg_ce_bilinear_bwd_ohem: the weighted backward of the fused resize + cross-entropy with the weights derived from loss_px and
+ * sel8 inside the kernel (times the DEVICE scalar grad_scale, NULL = 1). workspace: cvhip_ohem_select_workspace_bytes(). */
+int64_t cvhip_ohem_select_workspace_bytes(void);
+int cvhip_ohem_select(const float* loss_px, int64_t M, int32_t min_kept, float thresh_nlog, float loss_weight, void* workspace,
+                      float* sel8, void* stream);
+int cvhip_seg_ce_bilinear_bwd_ohem(const void* x_bf16, int32_t ld_x, const int64_t* target, int32_t N, int32_t C, int32_t Hi, int32_t Wi,
+                                   int32_t Ho, int32_t Wo, int32_t align_corners, int32_t ignore_index, const float* loss_px,
+                                   float loss_weight, const float* sel8, const float* grad_scale, void* dx_bf16, int32_t ld_dx,
+                                   void* stream);
+
 /* Boundary targets of the STDC detail loss (src/losses/seg/detail_loss.py:37-79): Laplacian pyramid of the int64 label map
  * (3x3 kernel, padding 1, strides 1 / 2 / 4, clamp(min=0), nearest up-sampling, threshold), fused with weights 0.6 / 0.3 / 0.1 and
  * thresholded again -> out fp32 [N][H][W] in {0, 1}. Replaces three F.conv2d + two F.interpolate + cat + a 1x1 F.conv2d per step. */

@@ -136,8 +136,9 @@ def test_detail_boundary_targets_kernel_equals_the_torch_formulation(shape):
     lab[0, :2, :3] = 255
     if N > 1:
         lab[1] = torch.roll(lab[1], 3, 1)
-    l = segmentors.DetailAggregateLoss().to(dev())
-    ref = l.boundary_targets_torch(lab.to(dev())).cpu()
+    # the torch formulation on the CPU (exact integer arithmetic in fp32): on the GPU the same F.conv2d goes through whatever MIOpen
+    # solver its find step picked — an inexact one flips a handful of thresholded pixels from run to run
+    ref = segmentors.DetailAggregateLoss().boundary_targets_torch(lab)
     got = ops.detail_boundary_targets(lab.to(dev()), 0.1).cpu()
     assert got.shape == ref.shape
     assert torch.equal(got, ref), int((got != ref).sum())
@@ -178,3 +179,52 @@ def test_fused_ohem_on_lowres_logits_equals_the_two_op_form(case):
 
 def to_nhwc_bf16(x):
     return x.to(torch.bfloat16).to(dev()).contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("case", [("hard", 1.0, 300, 1.0), ("easy", 9.0, 300, 1.0), ("ties", 6.0, 900, 1.0), ("weighted", 9.0, 500, 0.4),
+                                  ("big", 1.0, 100000, 1.0)])
+def test_device_ohem_selection_equals_the_torch_formulation(case):
+    """ops.OhemCrossEntropyBilinearFused (cvhip_ohem_select: radix select of the cut + masked sums on the device, weights derived in the
+    backward kernel) against ops.OhemCrossEntropyBilinear (the same per-pixel losses, selection as torch.topk + masked sums): the cut
+    value exactly, loss to 1e-5, gradients to 16-bit rounding — both branches, the tie case (min_kept reaching into the zero losses of
+    the ignored pixels), loss_weight != 1, and a label-size problem (8.4 M pixels, min_kept 100 000)"""
+    from cvpytorch_amd import ops, lib as L
+    import ctypes as C
+    name, scale, min_kept, lw = case
+    g = torch.Generator().manual_seed(len(name) + min_kept)
+    if name == "big":
+        N, nc, Ho, Wo, Hi, Wi = 2, 19, 512, 1024, 64, 128
+    else:
+        N, nc, Ho, Wo, Hi, Wi = 2, 6, 24, 32, 12, 16
+    tgt = torch.randint(0, nc, (N, Ho, Wo), generator=g)
+    low = torch.randn(N, nc, Hi, Wi, generator=g)
+    if scale > 1.0:
+        t_low = tgt[:, ::Ho // Hi, ::Wo // Wi]
+        low = low + scale * F.one_hot(t_low, nc).permute(0, 3, 1, 2).float()
+    tgt[:, :5] = 255
+    tgt = tgt.to(dev())
+    thr_t = -torch.log(torch.tensor(0.7, dtype=torch.float)).to(dev())
+    xa = to_nhwc_bf16(low).requires_grad_(True)
+    xb = to_nhwc_bf16(low).requires_grad_(True)
+    la = ops.OhemCrossEntropyBilinearFused.apply(xa, tgt, float(thr_t), min_kept, 255, lw)
+    la.backward()
+    lb = ops.OhemCrossEntropyBilinear.apply(xb, tgt, thr_t, min_kept, 255, lw)
+    lb.backward()
+    torch.cuda.synchronize()
+    assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb)) + 1e-7, (float(la), float(lb))
+    ga, gb = xa.grad.float().cpu(), xb.grad.float().cpu()
+    assert torch.isfinite(ga).all()
+    assert rel_l2(ga, gb) < 4e-3, rel_l2(ga, gb)
+    # the cut value itself: the (min_kept + 1)-th largest per-pixel loss, bit for bit
+    per = torch.empty(N * Ho * Wo, dtype=torch.float32, device=dev())
+    x4, ld = ops.as_nhwc(xa.detach())
+    L.call("cvhip_seg_ce_bilinear_fwd_px", x4.data_ptr(), ld, tgt.data_ptr(), N, nc, Hi, Wi, Ho, Wo, 0, 255, per.data_ptr(), None)
+    ws = torch.empty(int(L.load().cvhip_ohem_select_workspace_bytes()), dtype=torch.uint8, device=dev())
+    sel = torch.empty(8, dtype=torch.float32, device=dev())
+    L.call("cvhip_ohem_select", per.data_ptr(), per.numel(), min_kept, float(thr_t), lw, ws.data_ptr(), sel.data_ptr(), None)
+    torch.cuda.synchronize()
+    loss = per * lw if lw != 1.0 else per
+    v = torch.topk(loss, min_kept + 1, sorted=True).values[min_kept]
+    assert float(sel[4]) == float(v), (float(sel[4]), float(v))
+    assert int(sel[6]) == int((loss > v).sum()) and int(sel[7]) == int((loss == v).sum())
+    assert bool(sel[3] != 0) == bool(v > thr_t)
