@@ -306,9 +306,9 @@ def deeplab_workload(dev, a, batch=16, size=(512, 1024), steps=20, warmup=3, out
 
 def stdc_workload(dev, a, steps, warmup, batch=16, size=(512, 1024)):
     """STDC1-Seg train step as conf/seg/stdc/cityscapes_stdc1.yml wires it (STDCNet -> STDCNeck -> FCNHead + three auxiliary heads, OHEM
-    cross-entropy x3 + detail loss; 1024x512 crops, batch 16 here as for config 3): forward graph, eager loss island (OHEM: per-pixel
-    losses and weighted backward from the fused resize + cross-entropy kernels on the low-resolution logits, the selection as fixed-shape
-    torch ops; detail loss: boundary targets in one kernel), backward + SGD graph."""
+    cross-entropy x3 + detail loss; 1024x512 crops, batch 16 here as for config 3): OHEM: per-pixel losses and weighted backward
+    from the fused resize + cross-entropy kernels on the low-resolution logits, the selection by cvhip_ohem_select; detail loss: boundary
+    targets in one kernel, BCE + dice as torch ops — all captured with the rest of the step in one hipGraph."""
     from cvpytorch_amd import segmentors
     from cvpytorch_amd.arena import FlatTrainState, FlatTrainStep
     from cvpytorch_amd.data import synthetic_segmentation_batch
@@ -323,7 +323,7 @@ def stdc_workload(dev, a, steps, warmup, batch=16, size=(512, 1024)):
     out = _side_result("cityscapes_stdc1.yml STDC1-Seg %dx%d bf16 batch %d, OHEM CE x3 + detail loss, SGD-nesterov, synthetic" % (size[1], size[0], batch),
                        batch, steps, warmup, el, med, losses, 0.0, 0.0, graph)
     out.pop("step_roofline", None)   # (no algorithmic FLOP / byte count was derived for this widening workload)
-    out["launch"] = "two hipGraphs around an eager loss island" if graph else "eager"
+    out["launch"] = ("hipGraph replay" if getattr(model, "loss_capturable", False) else "two hipGraphs around an eager loss island") if graph else "eager"
     out["loss_terms"] = {k: round(float(v), 4) for k, v in losses.items()}
     return out
 

@@ -20,8 +20,9 @@ cross-entropy kernel on the LOW-resolution logits (cvhip_seg_ce_bilinear_fwd_px)
 the backward is the fused kernel with the selection as per-pixel weights (ops.OhemCrossEntropyBilinear; x8 / x16 up-sampling through
 smaller backward tiles); the detail loss's boundary targets are one kernel (cvhip_detail_boundary_targets). The torch-op forms above
 remain the fallback (CPU, geometries the fused kernels refuse) and the statement the tests compare against.
-The selection (topk, masked sums) is still made of torch ops, so `loss_capturable = False`: arena.FlatTrainStep replays two hipGraphs
-around an eager loss island."""
+Later in round 6 the selection moved to the device as well (cvhip_ohem_select: a three-pass radix select of the cut value and one
+masked-sum reduction; the backward kernel derives each pixel's weight from its forward loss): nothing in the loss sorts or reads back,
+`loss_capturable = True`, and arena.FlatTrainStep captures the whole step as one hipGraph."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -212,7 +213,10 @@ class STDCEncoderDecoder(nn.Module):
     def __init__(self, cfg=None, min_kept=None):
         super().__init__()
         cfg = dict(STDC1_CFG if cfg is None else cfg)
-        self.loss_capturable = False   # the STDC losses are torch ops: two hipGraphs around an eager loss island (arena.FlatTrainStep)
+        # Round 6: with the OHEM selection on the device the loss has no sort and no host read left (the detail loss's BCE / dice are
+        # plain fixed-shape torch ops): arena.FlatTrainStep captures the whole step as ONE hipGraph. CVHIP_STDC_CAPTURE=0 keeps the
+        # two graphs around an eager loss island (and is what runs when the selection falls back to torch.topk: CVHIP_OHEM_SELECT=0)
+        self.loss_capturable = ops._OHEM_SELECT and __import__("os").environ.get("CVHIP_STDC_CAPTURE", "1") != "0"
         self.backbone = STDCNet(**cfg["BACKBONE"])
         self.neck = STDCNeck(**cfg.get("NECK", {}))
         self.head = build_head(cfg["HEAD"])

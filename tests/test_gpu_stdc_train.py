@@ -2,7 +2,7 @@
 kernels, the fixed-shape OHEM / detail losses on engine-resized logits, the EncoderDecoder with auxiliary heads) against the
 reference-run fixtures of tools/gen_golden_stdc_train.py (fcn_head.py:14-63, cross_entropy_loss.py:51-69, detail_loss.py:23-88,
 encoder_decoder.py:109-150) and against the oracle; the full conf/seg/stdc/cityscapes_stdc1.yml:55-68 model takes a train step
-through arena.FlatTrainStep (two hipGraphs around the eager loss island).
+through arena.FlatTrainStep (one hipGraph since the OHEM selection runs on the device; two around an eager loss island before).
 
 Tolerances (16-bit activation storage, as tests/test_gpu_modules.py): head outputs relative L2 <= 2.5e-2, input-gradient cosine
 >= 0.97; the assembled model's losses within 3 % of the fp32 reference values (26 train-mode BN layers of 16-bit storage), gradient norms
@@ -103,8 +103,8 @@ def test_encoder_decoder_with_auxiliary_heads_vs_reference_vectors():
 
 
 def test_full_stdc1_train_steps_through_the_flat_arena():
-    """conf/seg/stdc/cityscapes_stdc1.yml at 512 x 1024, batch 4: two steps of the fused-arena train step (forward graph, eager loss
-    island, backward + SGD graph); the loss is finite, every parameter moves, and the loss keys are the reference's"""
+    """conf/seg/stdc/cityscapes_stdc1.yml at 512 x 1024, batch 4: two steps of the fused-arena train step — ONE hipGraph (round 6: no
+    sort and no host read left in the losses); the loss is finite, every parameter moves, and the loss keys are the reference's"""
     torch.manual_seed(3)
     m = S.STDCEncoderDecoder().to(dev()).train()
     imgs = torch.randn(4, 3, 512, 1024, device=dev())
@@ -113,10 +113,14 @@ def test_full_stdc1_train_steps_through_the_flat_arena():
     state = arena.FlatTrainState(m, lr=0.01, momentum=0.9, weight_decay=1e-4)
     step = arena.FlatTrainStep(m, state)
     before = state.param.clone()
-    l0 = step(imgs, tgt)
-    l1 = step(imgs, tgt)
+    l0 = {k: float(v) for k, v in step(imgs, tgt).items()}          # eager
+    step.capture(imgs, tgt, warmup=1)
+    assert step.g1 is not None and step.g2 is None, "the whole step (losses included) is one captured graph"
+    l1 = {k: float(v) for k, v in step(step.static_imgs, step.static_targets).items()}   # replayed
     torch.cuda.synchronize()
     assert sorted(l0.keys()) == ["aux0_detail_agg_loss", "aux1_ohem_ce_loss", "aux2_ohem_ce_loss", "loss", "ohem_ce_loss"]
+    assert abs(l0["loss"] - sum(v for k, v in l0.items() if k != "loss")) <= 1e-3 * abs(l0["loss"])
+    assert l1["loss"] != l0["loss"], "the replay recomputes the losses from the updated parameters"
     assert all(np.isfinite(float(v)) for v in l0.values()) and all(np.isfinite(float(v)) for v in l1.values())
     assert float((state.param != before).float().mean()) > 0.99
 
