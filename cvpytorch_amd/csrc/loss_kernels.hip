@@ -168,6 +168,7 @@ struct CeBilParams {
   const float* sel_loss;  // [N][Ho][Wo] the forward's per-pixel losses (loss_px of fwd_px)
   float sel_lw;           // loss_weight: the selection compares loss_px * loss_weight
   int tiles_h, tiles_w, fh_max, fw_max;
+  int ch_rows;   // backward: footprint rows whose softmax - onehot sit in the LDS at a time (the gather accumulates over the chunks)
 };
 
 // interpolated logits of label pixel (oy, ox): z[c] = a0*(b0*v00 + b1*v01) + a1*(b0*v10 + b1*v11) (bilinear_fwd_kernel's expression)
@@ -289,15 +290,18 @@ __global__ __launch_bounds__(256) void seg_ce_bilinear_fwd_kernel(const CeBilPar
 
 // low-resolution tile of a backward block: 4 x 8 source pixels; smaller tiles (round 6) where the label footprint of that tile would not
 // fit the LDS — the x8 up-sampling of the STDC heads (64 x 128 logits against 512 x 1024 labels) runs 4 x 4
-constexpr int kCeBilTiles[4][2] = {{4, 8}, {4, 4}, {2, 4}, {2, 2}};
+constexpr int kCeBilTiles[4][2] = {{8, 8}, {4, 8}, {4, 4}, {2, 4}};
 
 template <int CMAX, int TH, int TW>
 __global__ __launch_bounds__(256) void seg_ce_bilinear_bwd_kernel(const CeBilParams p) {
   extern __shared__ __attribute__((aligned(16))) float cebil_smem[];
-  // LDS: G[fh_max * fw_max][C] (fp16: softmax - onehot lies in [-1, 1], 11 significant bits there; fp32 cost half the resident
-  // blocks) | WY[fh_max][TH] | WX[fw_max][TW] | P[(TH + 2) * (TW + 2)][ldp] (the source patch, 16-bit)
+  // LDS: G[ch_rows * fw_max][C] (fp16: softmax - onehot lies in [-1, 1], 11 significant bits there; fp32 cost half the resident
+  // blocks) | WY[fh_max][TH] | WX[fw_max][TW] | P[(TH + 2) * (TW + 2)][ldp] (the source patch, 16-bit).
+  // Round 6: G holds a CHUNK of ch_rows footprint rows; the gather below is a sum over footprint rows, so it accumulates chunk after
+  // chunk in registers. The footprint no longer has to fit the LDS: x8 / x16 up-sampling (the STDC heads) runs 8 x 8 source tiles whose
+  // footprints overlap their neighbours' by a third instead of 2 x 2 tiles that recomputed every label pixel's softmax 2.4 times.
   _Float16* const G = reinterpret_cast<_Float16*>(cebil_smem);
-  float* const WY = cebil_smem + ((((size_t)p.fh_max * p.fw_max * p.C + 1) / 2 + 3) & ~(size_t)3);  // (multiples of 4 floats: P is 16-byte aligned)
+  float* const WY = cebil_smem + ((((size_t)p.ch_rows * p.fw_max * p.C + 1) / 2 + 3) & ~(size_t)3);  // (multiples of 4 floats: P is 16-byte aligned)
   float* const WX = WY + p.fh_max * TH;
   const int ldp = CMAX;  // patch pitch in floats (channels >= ld_x are zero)
   float* const P = WX + (((p.fw_max * TW) + 3) & ~3);
@@ -398,71 +402,77 @@ __global__ __launch_bounds__(256) void seg_ce_bilinear_bwd_kernel(const CeBilPar
       atomicMax(&geo[5 + 2 * lj], f);
     }
   }
-  // softmax - onehot of every footprint pixel (0 for ignored labels)
+  __syncthreads();   // WY / WX and the column ranges are complete
+  // gather ownership: a thread owns (tile column lj, class c) — c fastest, ld_dx entries per pixel, the pad channels are written as
+  // zeros — and keeps its TH row sums in registers across the chunks (the launcher guarantees TW * ld_dx <= 256: one output per thread)
+  const int per_px = p.ld_dx;
+  const int o = t;
+  const int oc = o % per_px, olj = o / per_px;
+  const bool owner = o < TW * per_px && j0 + olj < p.Wi;
+  float acc[TH];
+#pragma unroll
+  for (int li = 0; li < TH; ++li) acc[li] = 0.f;
+  const int fx0 = owner ? geo[4 + 2 * olj] : 0, fx1 = owner ? geo[5 + 2 * olj] : -1;
   const int64_t* tg = p.target + (int64_t)n * p.Ho * p.Wo;
-  for (int f = t; f < FH * FW; f += 256) {
-    const int fy = f / FW, fx = f - fy * FW;
-    const int oy = oy_lo + fy, ox = ox_lo + fx;
-    const int64_t tt = tg[(int64_t)oy * p.Wo + ox];
-    _Float16* const g = G + (size_t)f * p.C;
-    float wm = 1.f;
-    if (p.w_px) wm = p.w_px[((int64_t)n * p.Ho + oy) * p.Wo + ox];
-    else if (p.sel) {
-      const float l = p.sel_loss[((int64_t)n * p.Ho + oy) * p.Wo + ox] * p.sel_lw;
-      wm = p.sel[3] != 0.f ? (l > p.sel[5] ? 1.f : 0.f) : (l > p.sel[4] ? 1.f : (l == p.sel[4] ? p.sel[2] : 0.f));
-    }
-    if (tt == p.ignore || tt < 0 || tt >= p.C || wm == 0.f) {
+  for (int f0 = 0; f0 < FH; f0 += p.ch_rows) {
+    const int f1 = min(f0 + p.ch_rows, FH);
+    // softmax - onehot of the chunk's footprint pixels (0 for ignored labels and for pixels the selection dropped)
+    for (int f = t; f < (f1 - f0) * FW; f += 256) {
+      const int fyl = f / FW, fx = f - fyl * FW;
+      const int oy = oy_lo + f0 + fyl, ox = ox_lo + fx;
+      const int64_t tt = tg[(int64_t)oy * p.Wo + ox];
+      _Float16* const g = G + (size_t)f * p.C;
+      float wm = 1.f;
+      if (p.w_px) wm = p.w_px[((int64_t)n * p.Ho + oy) * p.Wo + ox];
+      else if (p.sel) {
+        const float l = p.sel_loss[((int64_t)n * p.Ho + oy) * p.Wo + ox] * p.sel_lw;
+        wm = p.sel[3] != 0.f ? (l > p.sel[5] ? 1.f : 0.f) : (l > p.sel[4] ? 1.f : (l == p.sel[4] ? p.sel[2] : 0.f));
+      }
+      if (tt == p.ignore || tt < 0 || tt >= p.C || wm == 0.f) {
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+          if (c < p.C) g[c] = (_Float16)0.f;
+        continue;
+      }
+      float z[CMAX];
+      cebil_logits_lds<CMAX>(p, P, ph0, pw0, pcol, ldp, oy, ox, z);
+      float mx = -INFINITY;
 #pragma unroll
       for (int c = 0; c < CMAX; ++c)
-        if (c < p.C) g[c] = (_Float16)0.f;
-      continue;
+        if (c < p.C) mx = fmaxf(mx, z[c]);
+      float se = 0.f;
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c)
+        if (c < p.C) {
+          z[c] = __expf(z[c] - mx);
+          se += z[c];
+        }
+      const float inv = 1.f / se;
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c)
+        if (c < p.C) g[c] = (_Float16)((z[c] * inv - (c == (int)tt ? 1.f : 0.f)) * wm);
     }
-    float z[CMAX];
-    cebil_logits_lds<CMAX>(p, P, ph0, pw0, pcol, ldp, oy, ox, z);
-    float mx = -INFINITY;
-#pragma unroll
-    for (int c = 0; c < CMAX; ++c)
-      if (c < p.C) mx = fmaxf(mx, z[c]);
-    float se = 0.f;
-#pragma unroll
-    for (int c = 0; c < CMAX; ++c)
-      if (c < p.C) {
-        z[c] = __expf(z[c] - mx);
-        se += z[c];
-      }
-    const float inv = 1.f / se;
-#pragma unroll
-    for (int c = 0; c < CMAX; ++c)
-      if (c < p.C) g[c] = (_Float16)((z[c] * inv - (c == (int)tt ? 1.f : 0.f)) * wm);
-  }
-  __syncthreads();
-  const float cnt = (p.w_px || p.sel) ? 1.f : p.stat[1];
-  const float gs = (cnt > 0.f ? 1.f / cnt : 0.f) * (p.gscale ? p.gscale[0] : 1.f) * (p.sel ? p.sel[1] : 1.f);
-  // gather: a thread owns (tile column lj, class c) — c fastest, ld_dx entries per pixel, the pad channels are written as zeros —
-  // and walks the footprint rows once: the row sums over the footprint columns are shared by the TH tile rows, the <= 2r
-  // independent LDS reads of a row are in flight together
-  const int per_px = p.ld_dx;
-  for (int o = t; o < TW * per_px; o += 256) {
-    const int c = o % per_px, lj = o / per_px;
-    const int j = j0 + lj;
-    if (j >= p.Wi) continue;
-    float acc[TH];
-#pragma unroll
-    for (int li = 0; li < TH; ++li) acc[li] = 0.f;
-    if (c < p.C) {
-      const int fx0 = geo[4 + 2 * lj], fx1 = geo[5 + 2 * lj];
-      for (int fy = 0; fy < FH; ++fy) {
-        const _Float16* const g = G + (size_t)fy * FW * p.C + c;
+    __syncthreads();
+    // gather over the chunk's rows: the row sums over the footprint columns are shared by the TH tile rows, the <= 2r independent LDS
+    // reads of a row are in flight together
+    if (owner && oc < p.C) {
+      for (int fy = f0; fy < f1; ++fy) {
+        const _Float16* const g = G + (size_t)(fy - f0) * FW * p.C + oc;
         float row = 0.f;
 #pragma unroll 4
-        for (int fx = fx0; fx <= fx1; ++fx) row += WX[fx * TW + lj] * (float)g[(size_t)fx * p.C];
+        for (int fx = fx0; fx <= fx1; ++fx) row += WX[fx * TW + olj] * (float)g[(size_t)fx * p.C];
 #pragma unroll
         for (int li = 0; li < TH; ++li) acc[li] += WY[fy * TH + li] * row;
       }
     }
+    __syncthreads();   // (the next chunk overwrites G)
+  }
+  const float cnt = (p.w_px || p.sel) ? 1.f : p.stat[1];
+  const float gs = (cnt > 0.f ? 1.f / cnt : 0.f) * (p.gscale ? p.gscale[0] : 1.f) * (p.sel ? p.sel[1] : 1.f);
+  if (owner) {
 #pragma unroll
     for (int li = 0; li < TH; ++li)
-      if (i0 + li < p.Hi) p.dx[((int64_t)(n * p.Hi + i0 + li) * p.Wi + j) * p.ld_dx + c] = (h16_t)(acc[li] * gs);
+      if (i0 + li < p.Hi) p.dx[((int64_t)(n * p.Hi + i0 + li) * p.Wi + j0 + olj) * p.ld_dx + oc] = (h16_t)(acc[li] * gs);
   }
 }
 
@@ -744,39 +754,48 @@ static int cebil_fbound(int in, int out, int T) {
   return f < out ? f : out;
 }
 
-static int cebil_lds_bytes_tile(int C, int Hi, int Wi, int Ho, int Wo, int th, int tw) {
+static int cebil_lds_bytes_tile(int C, int Hi, int Wi, int Ho, int Wo, int th, int tw, int ch_rows) {
   const int fh = cebil_fbound(Hi, Ho, th), fw = cebil_fbound(Wi, Wo, tw);
   const int ldp = C <= 24 ? 24 : 32;  // the kernel's CMAX
-  return ((((fh * fw * C + 1) / 2 + 3) & ~3) + fh * th + ((fw * tw + 3) & ~3)) * 4 + (th + 2) * (tw + 2) * ldp * 4;
+  return ((((ch_rows * fw * C + 1) / 2 + 3) & ~3) + fh * th + ((fw * tw + 3) & ~3)) * 4 + (th + 2) * (tw + 2) * ldp * 4;
 }
 
-// the largest backward tile whose footprint fits the LDS budget (two resident blocks per CU): index into kCeBilTiles, -1 = none
-static int cebil_pick_tile(int C, int Hi, int Wi, int Ho, int Wo, int* lds_out) {
+// the largest backward tile that leaves room for a chunk of >= 8 footprint rows (or the whole footprint) inside the LDS budget — 64 KB:
+// two resident blocks per CU — and keeps one gather output per thread (tw * ld_dx <= 256): index into kCeBilTiles, -1 = none
+static int cebil_pick_tile(int C, int ld_dx, int Hi, int Wi, int Ho, int Wo, int* lds_out, int* ch_out) {
+  constexpr int kBudget = 64 * 1024;
   for (int i = 0; i < 4; ++i) {
-    const int lds = cebil_lds_bytes_tile(C, Hi, Wi, Ho, Wo, kCeBilTiles[i][0], kCeBilTiles[i][1]);
-    if (lds <= 96 * 1024) {
-      if (lds_out) *lds_out = lds;
-      return i;
-    }
+    const int th = kCeBilTiles[i][0], tw = kCeBilTiles[i][1];
+    if (tw * ld_dx > 256) continue;
+    const int fh = cebil_fbound(Hi, Ho, th);
+    int ch = fh;
+    while (ch > 1 && cebil_lds_bytes_tile(C, Hi, Wi, Ho, Wo, th, tw, ch) > kBudget) ch = (ch + 1) / 2;
+    if (ch < 8 && ch < fh) continue;
+    const int lds = cebil_lds_bytes_tile(C, Hi, Wi, Ho, Wo, th, tw, ch);
+    if (lds > kBudget) continue;
+    if (lds_out) *lds_out = lds;
+    if (ch_out) *ch_out = ch;
+    return i;
   }
   return -1;
 }
 
 template <int CMAX>
 static int cebil_launch_bwd_tile(CeBilParams& p, hipStream_t s) {
-  int lds = 0;
-  const int ti = cebil_pick_tile(p.C, p.Hi, p.Wi, p.Ho, p.Wo, &lds);
+  int lds = 0, ch = 0;
+  const int ti = cebil_pick_tile(p.C, p.ld_dx, p.Hi, p.Wi, p.Ho, p.Wo, &lds, &ch);
   if (ti < 0) return CVHIP_ERR_UNSUPPORTED;
+  p.ch_rows = ch;
   const int th = kCeBilTiles[ti][0], tw = kCeBilTiles[ti][1];
   p.tiles_h = (p.Hi + th - 1) / th;
   p.tiles_w = (p.Wi + tw - 1) / tw;
   p.fh_max = cebil_fbound(p.Hi, p.Ho, th);
   p.fw_max = cebil_fbound(p.Wi, p.Wo, tw);
   switch (ti) {
-    case 0: return cebil_launch_bwd<CMAX, 4, 8>(p, lds, s);
-    case 1: return cebil_launch_bwd<CMAX, 4, 4>(p, lds, s);
-    case 2: return cebil_launch_bwd<CMAX, 2, 4>(p, lds, s);
-    default: return cebil_launch_bwd<CMAX, 2, 2>(p, lds, s);
+    case 0: return cebil_launch_bwd<CMAX, 8, 8>(p, lds, s);
+    case 1: return cebil_launch_bwd<CMAX, 4, 8>(p, lds, s);
+    case 2: return cebil_launch_bwd<CMAX, 4, 4>(p, lds, s);
+    default: return cebil_launch_bwd<CMAX, 2, 4>(p, lds, s);
   }
 }
 
@@ -821,7 +840,7 @@ int cvhip_seg_ce_bilinear_ok(int32_t C, int32_t Hi, int32_t Wi, int32_t Ho, int3
   // out/in; with align_corners they are (out-1)/(in-1) > out/in and part of the gradient would be dropped — the two-op path runs
   if (align_corners) return 0;
   if (C <= 0 || C > 32 || Hi <= 0 || Wi <= 0 || Ho < Hi || Wo < Wi) return 0;  // upsampling only
-  return cebil_pick_tile(C, Hi, Wi, Ho, Wo, nullptr) >= 0 ? 1 : 0;
+  return cebil_pick_tile(C, (C + 7) & ~7, Hi, Wi, Ho, Wo, nullptr, nullptr) >= 0 ? 1 : 0;   // (the gradient's usual pitch: C rounded up to 8)
 }
 
 static int cebil_fill(CeBilParams& p, const void* x, int32_t ld_x, const int64_t* target, int32_t N, int32_t C, int32_t Hi, int32_t Wi,

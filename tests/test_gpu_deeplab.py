@@ -96,7 +96,9 @@ def test_seg_cross_entropy(Cc, H, W):
                                                     (8, 5, 5, 5, 5, False, True),          # identity resize
                                                     (32, 4, 8, 16, 32, False, True),       # widest supported class count
                                                     (19, 3, 4, 36, 48, False, True),       # x12: the footprint is the whole label map
-                                                    (19, 2, 2, 64, 64, False, False),      # x32: footprint tile does not fit the LDS -> two ops
+                                                    (19, 2, 2, 64, 64, False, True),       # x32: the footprint exceeds the LDS — walked in row chunks (round 6)
+                                                    (19, 16, 32, 256, 512, False, True),   # x16 on a 16 x 32 map: 8 x 8 tiles, 146-row footprints in chunks
+                                                    (19, 9, 13, 72, 104, False, True),     # x8, ragged 8 x 8 tiles
                                                     (40, 8, 8, 16, 16, False, False)])     # too many classes -> two ops
 def test_seg_cross_entropy_resized_fused(Cc, Hi, Wi, Ho, Wo, ac, fused):
     """ops.seg_cross_entropy_resized == F.cross_entropy(F.interpolate(logits, label size, bilinear), labels) in fp32
