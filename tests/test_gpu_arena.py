@@ -95,7 +95,10 @@ def test_hipgraph_replay_matches_eager():
         tol = max(2e-3 * abs(x), 3 * abs(x - z))
         assert abs(x - y) <= tol + 1e-2 * abs(x), (la, lb, lc)
     assert sa.steps == sb.steps == 5 and sa.ema_updates == sb.ema_updates
-    noise = max(rel(sc.param, sa.param), 1e-4)
+    # (floor 2e-4 since round 6: an eager step folds a parked side gradient into the main consumer's dgrad epilogue OR lets autograd add it,
+    # depending on the order autograd happens to run the two branches in; the captured graph froze one of the two. One 16-bit rounding
+    # apart, five SGD steps later: 6.8e-4 on this network — the same value every time it occurs, in about one run of six)
+    noise = max(rel(sc.param, sa.param), 2e-4)
     assert rel(sb.param, sa.param) < 5 * noise, (rel(sb.param, sa.param), noise)
     assert rel(sb.ema_param, sa.ema_param) < 1e-3
     # new batch contents flow through the static buffers

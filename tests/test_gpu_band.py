@@ -65,6 +65,14 @@ BAND_CASES = [
     (2, 96, 12, 12, 64, 3, 3, 1, 1, 1),      # three chunks
     (1, 128, 64, 128, 128, 3, 3, 1, 1, 1),   # DeepLabv3+ decoder shape
     (2, 512, 16, 32, 512, 3, 3, 1, 2, 2),    # ASPP-like dilated, four channel tiles, 16 chunks
+    # tiny maps (round 6: the small-problem policy sends them here): whole images shorter than one fragment row, 1 - 2 pixel rows
+    (4, 128, 4, 4, 128, 3, 3, 1, 1, 1),
+    (4, 256, 8, 8, 256, 3, 3, 1, 1, 1),
+    (3, 512, 4, 4, 512, 3, 3, 1, 1, 1),
+    (2, 64, 2, 2, 64, 3, 3, 1, 1, 1),
+    (5, 32, 1, 1, 32, 3, 3, 1, 1, 1),
+    (4, 128, 16, 16, 128, 3, 3, 1, 1, 1),
+    (2, 64, 3, 5, 32, 3, 3, 1, 1, 1),
 ]
 
 
@@ -189,7 +197,7 @@ def test_band_dgrad(case, force_band):
     K.test_conv_dgrad(case)
 
 
-@pytest.mark.parametrize("case", [BAND_CASES[0], BAND_CASES[4], BAND_CASES[6]])
+@pytest.mark.parametrize("case", [BAND_CASES[0], BAND_CASES[4], BAND_CASES[6]] + BAND_CASES[12:])
 def test_band_dgrad_add(case, force_band):
     """dgrad with the skip-connection gradient added in the epilogue (cvhip_conv2d_dgrad_add)"""
     _skip_unless_form_runs(case, force_band, True)
