@@ -774,6 +774,54 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const h16_t* x, int ld_x, 
   }
 }
 
+// Round 6: the same with 1024 threads = 256 row lanes x four 16-byte channel vectors (STDC's attention modules pool 16 x 128..1024
+// channels over 2048 / 512 pixels: the form above ran 64 - 512 blocks whose threads walked 256 - 1024 two-byte loads one after the
+// other, 88 us per launch; here a lane makes HW / 256 sixteen-byte loads, four in flight)
+__global__ __launch_bounds__(1024) void gap_fwd_vec_kernel(const h16_t* __restrict__ x, int ld_x, h16_t* __restrict__ y, int N, int C, int HW) {
+  __shared__ float red[256][4][8];
+  const int n = blockIdx.y, tx = threadIdx.x & 3, ry = threadIdx.x >> 2;
+  const int c = (blockIdx.x * 4 + tx) * 8;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (c < C) {
+    const h16_t* base = x + (int64_t)n * HW * ld_x + c;
+    int r = ry;
+    for (; r + 3 * 256 < HW; r += 4 * 256) {
+      uint4 u[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) u[q] = *reinterpret_cast<const uint4*>(base + (int64_t)(r + q * 256) * ld_x);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x8 v = unpack8(u[q]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += v.v[j];
+      }
+    }
+    for (; r < HW; r += 256) {
+      const f32x8 v = unpack8(*reinterpret_cast<const uint4*>(base + (int64_t)r * ld_x));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += v.v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[ry][tx][j] = acc[j];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (ry < s) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[ry][tx][j] += red[ry + s][tx][j];
+    }
+    __syncthreads();
+  }
+  if (ry == 0 && c < C) {
+    f32x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.v[j] = red[0][tx][j] / (float)HW;
+    *reinterpret_cast<uint4*>(y + (int64_t)n * C + c) = pack8(o);
+  }
+}
+
 __global__ __launch_bounds__(256) void gap_bwd_kernel(const h16_t* dy, h16_t* dx, int ld_dx, int N, int C, int HW) {
   const int64_t total = (int64_t)N * HW * C;
   const float inv = 1.f / (float)HW;
@@ -1145,6 +1193,10 @@ int cvhip_resize_bilinear_bwd_ws(const void* dy, int32_t ld_dy, void* dx, int32_
 
 int cvhip_global_avgpool_fwd(const void* x, int32_t ld_x, void* y, int32_t N, int32_t C, int32_t HW, void* stream) {
   if (!x || !y || N <= 0 || C <= 0 || HW <= 0) return CVHIP_ERR_INVALID;
+  if ((C & 7) == 0 && (ld_x & 7) == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0 && HW >= 256) {
+    hipLaunchKernelGGL(gap_fwd_vec_kernel, dim3(cdiv(C, 32), N), dim3(1024), 0, (hipStream_t)stream, (const h16_t*)x, ld_x, (h16_t*)y, N, C, HW);
+    return check_launch("gap_fwd_vec_kernel");
+  }
   hipLaunchKernelGGL(gap_fwd_kernel, dim3(cdiv(C, 32), N), dim3(256), 0, (hipStream_t)stream, (const h16_t*)x, ld_x,
                      (h16_t*)y, N, C, HW);
   return check_launch("gap_fwd_kernel");
