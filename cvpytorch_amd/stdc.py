@@ -92,17 +92,28 @@ class CatBottleneck(nn.Module):
         self.conv_list = _conv_list(in_planes, out_planes, block_num)
 
     def forward(self, x):
-        out1 = self.conv_list[0](x)
+        convs = list(self.conv_list)
+        widths = [c.conv.out_channels for c in convs]
+        # Round 6: the ConvX outputs go straight into their channel slices of the concat buffer (`out=`: the BatchNorm + ReLU pass of each
+        # ConvModule writes there) — four copy kernels per block before; the stride-2 block's pooled first slice is still copied in
+        buf = None
+        if (x.is_cuda and x.dim() == 4 and ops.nhwc_ld(x) is not None and all(w % 8 == 0 for w in widths) and torch.is_grad_enabled()):
+            N, _, H, W = x.shape
+            Ho, Wo = ((H - 1) // 2 + 1, (W - 1) // 2 + 1) if self.stride == 2 else (H, W)
+            buf = ops.empty_nhwc(N, sum(widths), Ho, Wo, x.device)
+        offs = [sum(widths[:i]) for i in range(len(widths))]
+        sl = (lambda i: buf[:, offs[i]:offs[i] + widths[i]]) if buf is not None else (lambda i: None)
+        out1 = convs[0](x, out=sl(0) if self.stride == 1 else None)
         outs, out = [], None
-        for idx, conv in enumerate(list(self.conv_list)[1:]):
+        for idx, conv in enumerate(convs[1:]):
             if idx == 0:
-                out = conv(self.avd_layer(out1)) if self.stride == 2 else conv(out1)
+                out = conv(self.avd_layer(out1), out=sl(1)) if self.stride == 2 else conv(out1, out=sl(1))
             else:
-                out = conv(out)
+                out = conv(out, out=sl(idx + 1))
             outs.append(out)
         if self.stride == 2:
             out1 = self.skip(out1)
-        return ops.cat([out1] + outs)
+        return ops.cat([out1] + outs, into=buf)
 
 
 class STDCNet(nn.Module):
