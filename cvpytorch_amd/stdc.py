@@ -104,16 +104,20 @@ class CatBottleneck(nn.Module):
         offs = [sum(widths[:i]) for i in range(len(widths))]
         sl = (lambda i: buf[:, offs[i]:offs[i] + widths[i]]) if buf is not None else (lambda i: None)
         out1 = convs[0](x, out=sl(0) if self.stride == 1 else None)
-        outs, out = [], None
+        # every ConvX output but the last feeds the next ConvX AND the concat: the concat's share of its gradient rides into the next
+        # convolution's dgrad epilogue (ops.fanout_linked) instead of an autograd add pass per tensor
+        cat_in, cur = [], out1
         for idx, conv in enumerate(convs[1:]):
-            if idx == 0:
-                out = conv(self.avd_layer(out1), out=sl(1)) if self.stride == 2 else conv(out1, out=sl(1))
+            if idx == 0 and self.stride == 2:
+                nxt = conv(self.avd_layer(cur), out=sl(1))
+                cat_in.append(self.skip(cur))
             else:
-                out = conv(out, out=sl(idx + 1))
-            outs.append(out)
-        if self.stride == 2:
-            out1 = self.skip(out1)
-        return ops.cat([out1] + outs, into=buf)
+                xr, xs, lk = ops.fanout_linked(cur)
+                nxt = conv(xr, out=sl(idx + 1), dx_link=lk)
+                cat_in.append(ops.fanout_side(cur, xs, lk))
+            cur = nxt
+        cat_in.append(cur)
+        return ops.cat(cat_in, into=buf)
 
 
 class STDCNet(nn.Module):
