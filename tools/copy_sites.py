@@ -15,6 +15,10 @@ if which == "yolox":
     for t in targets:
         t["boxes"] = t["boxes"] * 640.0
     gts = yolox.targets_to_padded(targets, 20, dev)
+elif which == "deeplab":
+    from cvpytorch_amd import deeplab
+    model = deeplab.EncoderDecoder(19, output_stride=32).to(dev).train()
+    imgs, gts = synthetic_segmentation_batch(16, (512, 1024), device=dev)
 elif which == "stdc":
     from cvpytorch_amd import segmentors
     model = segmentors.STDCEncoderDecoder().to(dev).train()
