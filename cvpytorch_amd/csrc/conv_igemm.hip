@@ -644,13 +644,50 @@ __global__ __launch_bounds__(NW * 64, WS ? 2 : igemm_min_waves(BM, BN, BK, NST, 
   const bool staged = CAN_STAGE && ABL == 0 && !tail && p.staged_epilogue && (p.Nout & 7) == 0 && (p.y_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0);
   if (staged) {
     unsigned char* const tile = smem + EP_BASE;
+    // Addend through the LDS (round 6): the skip-connection gradient of dgrad_add was read in the MFMA fragment layout — 8 bytes per
+    // lane, 32 contiguous bytes per pixel row and instruction, MF * NF dependent-address loads per lane — and cost 1.3 - 2x its own HBM
+    // time ON TOP of the plain input gradient (tools/dgrad_add_bench.py). Here the block first copies its BM x BN addend tile into the
+    // output tile's LDS rows with the store loop's own coalesced pattern (16 bytes per lane, whole pixel rows, every load of a batch
+    // independent), and each lane then takes its 4-channel groups from there: same values, same single rounding of acc + addend.
+    constexpr int CPR_R = BN / 8;
+    constexpr int RES_IT = BM * CPR_R / (NW * 64);
+    const bool res_lds = p.staged_epilogue == 2 && p.res && !ep_on && rvec && (p.res_ld & 7) == 0 && ((((uintptr_t)p.res) & 15) == 0);
+    if (res_lds) {
+      constexpr int RB = BN >= 128 ? (RES_IT < 8 ? RES_IT : 8) : (RES_IT < 4 ? RES_IT : 4);   // loads in flight per lane (the narrow tiles run at a 128-register cap)
+#pragma unroll
+      for (int it0 = 0; it0 < RES_IT; it0 += RB) {
+        uint4 rv[RB];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+          const int idx = t + (it0 + j) * (NW * 64);
+          const int row = idx / CPR_R, ch = idx - row * CPR_R;
+          const int m = m0 + row;
+          rv[j] = uint4{0u, 0u, 0u, 0u};
+          if (m < M && n0 + ch * 8 < p.Nout) {
+            const int n_img = (int)fast_div31((unsigned)m, cl.ohw_mul, cl.ohw_sh);
+            const int rem = m - n_img * OHWi;
+            const int oh = (int)fast_div31((unsigned)rem, cl.ow_mul, cl.ow_sh);
+            const int ow = rem - oh * OWi;
+            const int64_t opix = ((int64_t)n_img * p.OH + (oh * p.out_sh + cl.out_oh)) * p.OW + (ow * p.out_sw + cl.out_ow);
+            rv[j] = *reinterpret_cast<const uint4*>(p.res + opix * p.res_ld + n0 + ch * 8);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+          const int idx = t + (it0 + j) * (NW * 64);
+          const int row = idx / CPR_R, ch = idx - row * CPR_R;
+          *reinterpret_cast<uint4*>(tile + row * EP_PITCH + ch * 16) = rv[j];
+        }
+      }
+      __syncthreads();
+    }
     if (consumer) {
 #pragma unroll
       for (int b = 0; b < MF; ++b) {
         const int row = wm * WM + b * 16 + (lane & 15);
         const int m = m0 + row;
         const h16_t* rbase = nullptr;
-        if (p.res && m < M) {
+        if (p.res && !res_lds && m < M) {
           const int n_img = (int)fast_div31((unsigned)m, cl.ohw_mul, cl.ohw_sh);
           const int rem = m - n_img * OHWi;
           const int oh = (int)fast_div31((unsigned)rem, cl.ow_mul, cl.ow_sh);
@@ -683,7 +720,16 @@ __global__ __launch_bounds__(NW * 64, WS ? 2 : igemm_min_waves(BM, BN, BK, NST, 
             v2 = ev[2];
             v3 = ev[3];
           }
-          if (rbase && !(ep_on && p.res_pre) && n0 + nl < p.Nout) {
+          if (res_lds) {  // (block-uniform) this lane's 4 addend channels from the tile rows filled above; the sum goes back to the same 8 bytes
+            const uint2 u = *reinterpret_cast<const uint2*>(tile + row * EP_PITCH + nl * 2);
+            float r0, r1, r2, r3;
+            unpack2(u.x, r0, r1);
+            unpack2(u.y, r2, r3);
+            v0 += r0;
+            v1 += r1;
+            v2 += r2;
+            v3 += r3;
+          } else if (rbase && !(ep_on && p.res_pre) && n0 + nl < p.Nout) {
             const h16_t* rrow = rbase + n0 + nl;
             if (rvec) {
               const uint2 u = *reinterpret_cast<const uint2*>(rrow);
@@ -800,7 +846,14 @@ static int launch_group(IgemmKernArgs& p, hipStream_t stream) {
   }
   p.total_tiles = total;
   if (total == 0) return CVHIP_OK;
-  p.staged_epilogue = 1;
+  // 2 = staged, and the addend of dgrad_add goes through the LDS tile too (kernel: res_lds). Measured on rotating operands
+  // (profiles/r06_dgrad_add_res_lds.log): dgrad_add 128 -> 256 k3 s2 @80 157 -> 139 us, 32 -> 64 k3 s2 @320 371 -> 302,
+  // DeepLabv3+ 256 -> 512 k1 s2 @128x256 302 -> 247, 1024 -> 256 k1 @32x64 60 -> 51. CVHIP_IGEMM_RES_LDS=0 restores the direct read (A/B).
+  p.staged_epilogue = 2;
+  {
+    const char* e = getenv("CVHIP_IGEMM_RES_LDS");
+    if (e && atoi(e) == 0) p.staged_epilogue = 1;
+  }
   p.interleave = 0;
   if (p.ncls > 1) {
     bool same = true;
@@ -875,6 +928,15 @@ int launch_igemm(IgemmParams& p, hipStream_t stream) {
     M += p.cls[i].M;
     const int k = p.cls[i].TR * p.cls[i].TS * p.Cin;
     ktot = k > ktot ? k : ktot;
+  }
+  {  // DEV (round 6 experiment): CVHIP_IGEMM_BM = 64 / 128 / 256 forces the block tile of the wide-output launches without BN sums
+    const char* e = getenv("CVHIP_IGEMM_BM");
+    const int bm = e ? atoi(e) : 0;
+    if (bm && !p.stats) {
+      if (bm == 64) return launch_cfg<64, 128, 32, 64>(p, stream);
+      if (bm == 128) return launch_cfg<128, 128, 64, 64>(p, stream);
+      if (bm == 256) return launch_cfg<256, 128, 128, 64>(p, stream);
+    }
   }
   if (igemm_block_m(p.Nout, M, ktot) == 256) return launch_cfg<256, 128, 128, 64>(p, stream);
   return launch_cfg<128, 128, 64, 64>(p, stream);
