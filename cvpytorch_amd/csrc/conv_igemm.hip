@@ -182,8 +182,19 @@ __global__ __launch_bounds__(NW * 64, WS ? 2 : igemm_min_waves(BM, BN, BK, NST, 
   if (p.interleave) {
     // dgrad parity classes with equal tile counts: the classes of one spatial tile run back to back on the same XCD, so the
     // stride-2-interleaved pixels they write (half cache lines each) meet in that L2 before they are written back
-    ci = lt % p.ncls;
-    local = lt / p.ncls;
+    if (p.interleave == 3) {
+      const int G = p.il_group, g4 = G * p.ncls;
+      const int g = lt / g4, k = lt - g * g4;
+      const int nfull = p.il_tiles / G;
+      const int Gt = g < nfull ? G : p.il_tiles - nfull * G;   // the last group holds the remainder
+      const int o = k / Gt;
+      ci = (p.il_order >> (4 * o)) & 15;
+      local = g * G + (k - o * Gt);
+    } else {
+      local = lt / p.ncls;
+      ci = lt - local * p.ncls;
+      if (p.interleave == 2) ci = (ci + local) % p.ncls;  // rotated class order (launch_group)
+    }
   } else {
     int tb = 0;
 #pragma unroll
@@ -210,6 +221,30 @@ __global__ __launch_bounds__(NW * 64, WS ? 2 : igemm_min_waves(BM, BN, BK, NST, 
   const int nk = (Ktot + BK - 1) / BK;
   const int M = cl.M;
   const int OWi = cl.OWi, OHWi = cl.OHi * cl.OWi;
+
+  // A class WITHOUT taps (1x1 stride-2 dgrad: three of the four pixel parities — the ResNet projection shortcuts) has nothing to multiply:
+  // its pixels are the addend, or zero. Copy them row by row (16 bytes per lane, whole pixel rows) and leave: no accumulators, no LDS
+  // tile, no barriers (round 6: DeepLabv3+ 256 -> 512 k1 s2 @128x256, three quarters of whose tiles are of this kind).
+  if constexpr (!EPI && ABL == 0) {
+    if (nk == 0 && p.staged_epilogue && !p.bias && !p.stats && !p.tail_y && (p.Nout & 7) == 0 && (p.y_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0) &&
+        (!p.res || ((p.res_ld & 7) == 0 && ((((uintptr_t)p.res) & 15) == 0)))) {
+      constexpr int CPR0 = BN / 8;
+      for (int idx = t; idx < BM * CPR0; idx += NW * 64) {
+        const int row = idx / CPR0, ch = idx - row * CPR0;
+        const int m = m0 + row;
+        if (m >= M || n0 + ch * 8 >= p.Nout) continue;
+        const int n_img = (int)fast_div31((unsigned)m, cl.ohw_mul, cl.ohw_sh);
+        const int rem = m - n_img * OHWi;
+        const int oh = (int)fast_div31((unsigned)rem, cl.ow_mul, cl.ow_sh);
+        const int ow = rem - oh * OWi;
+        const int64_t opix = ((int64_t)n_img * p.OH + (oh * p.out_sh + cl.out_oh)) * p.OW + (ow * p.out_sw + cl.out_ow);
+        uint4 v = uint4{0u, 0u, 0u, 0u};
+        if (p.res) v = *reinterpret_cast<const uint4*>(p.res + opix * p.res_ld + n0 + ch * 8);
+        *reinterpret_cast<uint4*>(p.y + opix * p.y_ld + n0 + ch * 8) = v;
+      }
+      return;
+    }
+  }
 
   // staging geometry: this thread's row inside a 4-wave pass and its physical 16-B slot inside the LDS row
   const int srow = BK == 32 ? (st_t >> 2) : (swave * 8 + (lane >> 3));
@@ -859,6 +894,34 @@ static int launch_group(IgemmKernArgs& p, hipStream_t stream) {
     bool same = true;
     for (int i = 1; i < p.ncls; ++i) same = same && cdiv(p.cls[i].M, BM) == cdiv(p.cls[0].M, BM);
     p.interleave = same ? 1 : 0;
+    {
+      // Class order (round 6). The hardware hands consecutive workgroups to the CUs of an XCD in turn, so with (spatial tile, class)
+      // order the heavy class of a 3x3 stride-2 plan (4 taps against 1 / 2 / 2) — or the ONE class with a tap of a 1x1 stride-2 plan —
+      // kept landing on the same quarter of the CUs. Groups of 16 spatial tiles, inside a group class-major with the heaviest class
+      // first: every CU gets its share of every class, longest first, and the four classes of a spatial tile still run within
+      // 64 tile ids of each other on one XCD (their interleaved half-line writes and their shared dy tile still meet in that L2).
+      // profiles/r06_dgrad_class_order.log: dgrad_add 128 -> 256 k3 s2 @80 132 -> 109 us, 256 -> 512 @40 119 -> 95, DeepLabv3+
+      // 256 -> 512 k1 s2 @128x256 dgrad 212 -> 107. CVHIP_IGEMM_CLASS_ORDER (A/B): 0 = (tile, class) order, 1 = rotated, N >= 2 = group size.
+      const char* e = getenv("CVHIP_IGEMM_CLASS_ORDER");
+      const int v = e ? atoi(e) : 16;
+      if (same && v == 1) p.interleave = 2;
+      if (same && v >= 2) {
+        p.interleave = 3;
+        p.il_group = v;
+        p.il_tiles = cdiv(p.cls[0].M, BM) * p.n_tiles;
+        int ord[kKernelClasses];
+        for (int i = 0; i < p.ncls; ++i) ord[i] = i;
+        for (int i = 0; i < p.ncls; ++i)   // heaviest class (most taps) first
+          for (int j = i + 1; j < p.ncls; ++j)
+            if (p.cls[ord[j]].TR * p.cls[ord[j]].TS > p.cls[ord[i]].TR * p.cls[ord[i]].TS) {
+              const int tmp = ord[i];
+              ord[i] = ord[j];
+              ord[j] = tmp;
+            }
+        p.il_order = 0;
+        for (int i = 0; i < p.ncls; ++i) p.il_order |= ord[i] << (4 * i);
+      }
+    }
   }
   constexpr bool nst2 = BN <= 64;
   constexpr int NST = nst2 ? 2 : 3;
@@ -929,15 +992,10 @@ int launch_igemm(IgemmParams& p, hipStream_t stream) {
     const int k = p.cls[i].TR * p.cls[i].TS * p.Cin;
     ktot = k > ktot ? k : ktot;
   }
-  {  // DEV (round 6 experiment): CVHIP_IGEMM_BM = 64 / 128 / 256 forces the block tile of the wide-output launches without BN sums
-    const char* e = getenv("CVHIP_IGEMM_BM");
-    const int bm = e ? atoi(e) : 0;
-    if (bm && !p.stats) {
-      if (bm == 64) return launch_cfg<64, 128, 32, 64>(p, stream);
-      if (bm == 128) return launch_cfg<128, 128, 64, 64>(p, stream);
-      if (bm == 256) return launch_cfg<256, 128, 128, 64>(p, stream);
-    }
-  }
+  // stride-parity plans (dgrad of a strided convolution): 128-row tiles — three co-resident blocks per CU overlap the short per-class K
+  // loops with the other blocks' store epilogues (profiles/r06_dgrad_class_order.log, columns bm128 / bm256: 128 -> 128 k3 s2 @80
+  // 52.3 vs 61.6 us, DeepLabv3+ 256 -> 512 k1 s2 dgrad_add 150.8 vs 161.2, level elsewhere)
+  if (p.ncls > 1 && !p.stats) return launch_cfg<128, 128, 64, 64>(p, stream);
   if (igemm_block_m(p.Nout, M, ktot) == 256) return launch_cfg<256, 128, 128, 64>(p, stream);
   return launch_cfg<128, 128, 64, 64>(p, stream);
 }

@@ -45,6 +45,9 @@ struct IgemmCommon {
   int y_vec_ok;
   int staged_epilogue;  // 1: the implicit GEMM stores its output tile through the LDS (16-byte rows) when the geometry allows
   int interleave;  // 1: logical tile id = spatial tile * ncls + class (classes with equal tile counts: stride-parity dgrad)
+                   // 2: the same with the class order rotated from one spatial tile to the next
+                   // 3: groups of il_group spatial tiles, inside a group class-major in il_order (heaviest class first)
+  int il_group, il_tiles, il_order;  // (3) group size, tiles per class, class order packed 4 bits per position
   const h16_t* res;  // optional addend, same pixel grid and channel count as y (dgrad: the gradient arriving over a skip connection)
   int res_ld;
   // "tail" (dgrad only): this launch produces dz, the gradient at the OUTPUT of a Conv-BN-act layer P (the layer whose activations
