@@ -382,6 +382,22 @@ __global__ __launch_bounds__(NW * 64, WS ? 2 : igemm_min_waves(BM, BN, BK, NST, 
     // ABL 3 (experiment, wrong results): pixel rows are fetched for 2 of 9 taps only — the DMA volume a patch-in-LDS layout with
     // tap reuse would have; measures how much of the kernel's time is the issue cost of the A-tile DMA pieces
     const bool a_live = (ABL != 3 || ((f_tr * TS + f_ts) % 6 == 0)) && ABL != 5;  // ABL 5: weight tile only
+    if (f_c + BK > Cin) {
+      // (wave-uniform, rare) the LAST step of a single-tap plan whose channel count is not a multiple of the step (round 6: the
+      // 560 -> 512 1x1 of DeepLabv3+'s decoder ran the general staging path — 610 us against 458 for its input gradient): the 16-byte
+      // slots past the last channel come from the zero page, pixel tile and weight tile alike
+      const bool dead = f_c + lslot * 8 >= Cin;
+      if (a_live) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) CVHIP_GLDS16(dead ? zero : aptr[i], sA + (i * RPT + swave * RPI) * ROWB);
+      }
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) {
+        if (ABL != 4) CVHIP_GLDS16(dead ? zero : bptr[i], sB + (i * RPT + swave * RPI) * ROWB);
+      }
+      f_c += BK;
+      return;
+    }
     if (a_live) {
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) CVHIP_GLDS16(aptr[i], sA + (i * RPT + swave * RPI) * ROWB);
@@ -925,7 +941,10 @@ static int launch_group(IgemmKernArgs& p, hipStream_t stream) {
   }
   constexpr bool nst2 = BN <= 64;
   constexpr int NST = nst2 ? 2 : 3;
-  const bool fast = p.Cin % 32 == 0 && p.Cin <= kFastMaxCin;
+  // FAST staging: the reduction step lies inside one tap — any Cin % 32 == 0, or a single-tap plan (1x1) whose last step is partial
+  bool one_tap = true;
+  for (int i = 0; i < p.ncls; ++i) one_tap = one_tap && p.cls[i].TR * p.cls[i].TS <= 1;
+  const bool fast = (p.Cin % 32 == 0 || (one_tap && p.Cin % 8 == 0)) && p.Cin <= kFastMaxCin;
   if (p.ep_scale || p.ep_act != CVHIP_ACT_NONE) {
     // fused epilogue: the EPI instances of the same forms
     if (p.tail_y) return CVHIP_ERR_INVALID;

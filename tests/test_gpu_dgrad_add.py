@@ -94,3 +94,29 @@ def test_dgrad_add_addend_slice(case, extra, monkeypatch):
     a = got.float().cpu()
     assert torch.isfinite(a).all()
     assert max_rel(a, ref) < 2 ** -7 and rel_l2(a, ref) < 4e-3
+
+
+# ---- single-tap plans whose channel count is not a multiple of the 32-deep reduction step (round 6: FAST staging with a partial last
+# step; before, the 560 -> 512 1x1 of DeepLabv3+'s decoder — deeplabv3plus_head.py:63-68 — ran the general per-row decode path) -----------
+ONE_TAP_RAGGED = [
+    (2, 560, 16, 24, 512, 1, 1, 1, 0, 1),     # the decoder's 1x1 (17 full steps + 16 channels)
+    (2, 304, 16, 16, 256, 1, 1, 1, 0, 1),     # torchvision-style decoder concat (256 + 48)
+    (2, 72, 15, 17, 136, 1, 1, 2, 0, 1),      # stride 2 keeps small 1x1 problems off the streaming kernel
+    (1, 24, 9, 9, 40, 1, 1, 2, 0, 1),         # fewer channels than one step
+    (3, 40, 12, 12, 64, 1, 1, 2, 0, 1),
+]
+
+
+@pytest.mark.parametrize("case", ONE_TAP_RAGGED)
+def test_one_tap_ragged_channels_fprop(case):
+    K.test_conv_fprop(case)
+
+
+@pytest.mark.parametrize("case", ONE_TAP_RAGGED)
+def test_one_tap_ragged_channels_dgrad(case):
+    K.test_conv_dgrad(case)
+
+
+@pytest.mark.parametrize("case", [c for c in ONE_TAP_RAGGED if c[4] % 8 == 0])
+def test_one_tap_ragged_channels_bn_stats(case):
+    K.test_conv_fprop_bn_stats(case)

@@ -28,6 +28,8 @@ SHAPES = [
     (16, 512, 64, 128, 128, 1, 1, 1, 0, "dl 512->128 k1 @64x128"),
     (16, 256, 32, 64, 1024, 1, 1, 1, 0, "dl 256->1024 k1 @32x64"),
     (16, 512, 16, 32, 2048, 1, 1, 1, 0, "dl 512->2048 k1 @16x32"),
+    (16, 560, 128, 256, 512, 1, 1, 1, 0, "dl 560->512 k1 @128x256"),
+    (16, 512, 128, 256, 512, 1, 1, 1, 0, "dl 512->512 k1 @128x256"),
 ]
 REPS = int(os.environ.get("REPS", "20"))
 ROUNDS = int(os.environ.get("ROUNDS", "3"))
