@@ -384,8 +384,8 @@ __global__ __launch_bounds__(NW * 64, WS ? 2 : igemm_min_waves(BM, BN, BK, NST, 
     const bool a_live = (ABL != 3 || ((f_tr * TS + f_ts) % 6 == 0)) && ABL != 5;  // ABL 5: weight tile only
     if (f_c + BK > Cin) {
       // (wave-uniform, rare) the LAST step of a single-tap plan whose channel count is not a multiple of the step (round 6: the
-      // 560 -> 512 1x1 of DeepLabv3+'s decoder ran the general staging path — 610 us against 458 for its input gradient): the 16-byte
-      // slots past the last channel come from the zero page, pixel tile and weight tile alike
+      // 560 -> 512 1x1 of DeepLabv3+'s decoder ran the general staging path): the 16-byte slots past the last channel come from the
+      // zero page, pixel tile and weight tile alike. (No early return: it sent the lambda's by-reference state to scratch memory.)
       const bool dead = f_c + lslot * 8 >= Cin;
       if (a_live) {
 #pragma unroll
@@ -395,19 +395,18 @@ __global__ __launch_bounds__(NW * 64, WS ? 2 : igemm_min_waves(BM, BN, BK, NST, 
       for (int i = 0; i < B_IT; ++i) {
         if (ABL != 4) CVHIP_GLDS16(dead ? zero : bptr[i], sB + (i * RPT + swave * RPI) * ROWB);
       }
-      f_c += BK;
-      return;
-    }
-    if (a_live) {
+    } else {
+      if (a_live) {
 #pragma unroll
-      for (int i = 0; i < A_IT; ++i) CVHIP_GLDS16(aptr[i], sA + (i * RPT + swave * RPI) * ROWB);
-    }
+        for (int i = 0; i < A_IT; ++i) CVHIP_GLDS16(aptr[i], sA + (i * RPT + swave * RPI) * ROWB);
+      }
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) aptr[i] += BK;
+      for (int i = 0; i < A_IT; ++i) aptr[i] += BK;
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      if (ABL != 4) CVHIP_GLDS16(bptr[i], sB + (i * RPT + swave * RPI) * ROWB);  // ABL 4: pixel tile only
-      bptr[i] += BK;
+      for (int i = 0; i < B_IT; ++i) {
+        if (ABL != 4) CVHIP_GLDS16(bptr[i], sB + (i * RPT + swave * RPI) * ROWB);  // ABL 4: pixel tile only
+        bptr[i] += BK;
+      }
     }
     f_c += BK;
     if (f_c == Cin) {
