@@ -133,6 +133,10 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const RedParams p) {
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
+            // (round 6) a row slot that is past the block's last row for EVERY lane of the wave contributes nothing: its arithmetic —
+            // the SiLU derivative is ~40 VALU instructions per element, and with 1024 blocks the mid-size layers run 1.56 / 3.125
+            // trips per lane, i.e. up to 22 % masked slots — is skipped under a wave-uniform branch. Adding +0 changed no sum before.
+            if (__builtin_amdgcn_ballot_w64(ok[q]) == 0) continue;
             if (!ok[q]) ua[q] = make_uint4(0u, 0u, 0u, 0u);  // x = 0 / dz = 0: no contribution to either sum
             if constexpr (MODE == 3) {
               // du = dz * act'(z), rounded to 16 bits (what the stand-alone apply pass stores and the reduction pass then reads)
