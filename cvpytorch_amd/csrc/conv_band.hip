@@ -75,6 +75,11 @@ struct BandArgs {
   int Nout, y_ld, OH, OW;
   int dh0, dh_step, dw0, dw_step, lo_h, lo_w;
   int TH, bands, PH, PW;
+  // stride-2 fprop (round 6): the patch holds rs = 2 input rows per output row and every patch row is stored as TWO column planes —
+  // the odd input columns 2k - 1 (k = 0 .. OW: PWo pixels) and then the even ones 2k — so that the 16 consecutive output pixels of a
+  // fragment read 16 consecutive LDS pixels for every tap (tap column 0 / 1 / 2 = odd plane k, even plane k, odd plane k + 1)
+  int rs, s2, PWo;
+  int coffp[3];        // tap column j -> pixel offset inside a patch row
   int nplw;            // patch DMA instructions per wave per chunk
   int dummy_off;       // byte offset of the 1-KB dummy DMA slot
   int buf_bytes;       // one patch buffer
@@ -216,9 +221,16 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_band_kernel(const BandArgs p)
       const int pp = ((j * kBandWaves + wave) << 4) + (lane >> 2);
       const int pr = band_div(pp, p.pw_magic);
       const int pc = pp - pr * PW;
-      const int ih = oh0 + p.lo_h + pr;
-      const int iw = p.lo_w + pc;
-      const bool ok = pp < npix && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+      const int ih = oh0 * p.rs + p.lo_h + pr;
+      int iw = p.lo_w + pc;
+      bool col_ok = true;
+      if (p.s2) {  // (block-uniform) column planes: odd input columns first, then the even ones
+        const bool odd = pc < p.PWo;
+        const int k = odd ? pc : pc - p.PWo;
+        iw = 2 * k + (odd ? p.lo_w : p.lo_w + 1);
+        col_ok = odd ? k <= p.OW : k < p.OW;
+      }
+      const bool ok = pp < npix && col_ok && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
       poff[j] = ok ? ((n_img * p.IH + ih) * p.IW + iw) * (p.x_ld >> 3) : -1;   // in 16-byte units (the planner bounds the tensor)
     }
   }
@@ -247,14 +259,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_band_kernel(const BandArgs p)
     q = q < npx ? q : (npx > 0 ? npx - 1 : 0);
     const int r = band_div(q, p.ow_magic);
     const int c = q - r * p.OW;
-    ab[b] = ((r * PW + c) << 6) + (g << 4);
+    ab[b] = ((r * p.rs * PW + c) << 6) + (g << 4);
   }
   // K steps visit the taps COLUMN-major (step ts: tap column j = ts / 3, tap row i = ts % 3): the swizzled address of a column is
   // computed once (4 VALU per fragment) and serves three steps with one add each — the inner loop is VALU-issue bound otherwise
   // (profiles/r05_band_sq.txt: 3.1 VALU per MFMA with the per-read swizzle)
   int coff[3], roff[3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) coff[j] = __builtin_amdgcn_readfirstlane((p.dw0 + j * p.dw_step - p.lo_w) * 64);
+  for (int j = 0; j < 3; ++j) coff[j] = __builtin_amdgcn_readfirstlane(p.coffp[j] * 64);
 #pragma unroll
   for (int i = 0; i < 3; ++i) roff[i] = __builtin_amdgcn_readfirstlane((p.dh0 + i * p.dh_step - p.lo_h) * PW * 64);
   int aj[MFW];
@@ -559,7 +571,7 @@ static inline int band_mfw(int per_wave) { return per_wave <= 7 ? 7 : per_wave <
 
 // One candidate form (NF weight fragments per wave, at most `cap` pixel fragments per wave): the best band height and its cost in
 // rounds of the 256 CUs x fragment units of the busiest wave. false = the geometry does not fit this form.
-static bool band_fit(const IgemmParams& p, int NF, int cap, int NW, int EH, int PW, int* th_out, int* nplw_out, int64_t* rounds_out) {
+static bool band_fit(const IgemmParams& p, int NF, int cap, int NW, int EH, int PW, int* th_out, int* nplw_out, int64_t* rounds_out, int RS = 1) {
   const int BN = band_imin(p.Nout, 128);
   if (BN % (16 * NF)) return false;
   const int WN = BN / (16 * NF);
@@ -578,7 +590,7 @@ static bool band_fit(const IgemmParams& p, int NF, int cap, int NW, int EH, int 
     const int frags = (TH * p.OW + 15) / 16;
     const int per_wave = (frags + WM - 1) / WM;
     if (per_wave > cap) break;
-    const int PH = TH - 1 + EH;
+    const int PH = (TH - 1) * RS + EH;
     if ((int64_t)PH * PW >= 65536) break;
     const int nplw = (PH * PW * 4 + threads - 1) / threads;
     if (nplw > 2 * kBandPieceSteps) break;
@@ -598,7 +610,7 @@ static bool band_fit(const IgemmParams& p, int NF, int cap, int NW, int EH, int 
     // same number of bands, evenly high: 40 rows in bands of 11 are 11 + 11 + 11 + 7 — four bands of 10 cost the same MFMA slots and stage
     // less patch (a lower band always fits where a higher one did)
     best_th = (p.OH + ((p.OH + best_th - 1) / best_th) - 1) / ((p.OH + best_th - 1) / best_th);
-    best_nplw = ((best_th - 1 + EH) * PW * 4 + threads - 1) / threads;
+    best_nplw = (((best_th - 1) * RS + EH) * PW * 4 + threads - 1) / threads;
   }
   *th_out = best_th;
   *nplw_out = best_nplw;
@@ -613,7 +625,10 @@ static bool band_plan_nw(const IgemmParams& p, int NW, BandPlan* pl, bool* polic
   const int h_a = c.dh0, h_b = c.dh0 + 2 * c.dh_step, w_a = c.dw0, w_b = c.dw0 + 2 * c.dw_step;
   const int lo_h = band_imin(h_a, h_b), hi_h = band_imax(h_a, h_b), lo_w = band_imin(w_a, w_b), hi_w = band_imax(w_a, w_b);
   const int EH = hi_h - lo_h + 1, EW = hi_w - lo_w + 1;
-  const int PW = (p.OW - 1 + EW + 7) & ~7;
+  const bool s2 = p.in_sh == 2;   // (band_plan admits stride 2 for 3x3 / pad 1 / dilation 1 forward plans only)
+  const int RS = s2 ? 2 : 1;
+  const int PWo = s2 ? ((p.OW + 1 + 7) & ~7) : 0;                       // odd input columns 2k - 1, k = 0 .. OW
+  const int PW = s2 ? PWo + ((p.OW + 7) & ~7) : ((p.OW - 1 + EW + 7) & ~7);   // + even columns 2k, k = 0 .. OW - 1
   const int NC = p.Cin / 32;
   const int n_tiles = p.Nout / BN;
   // Narrow waves (32 channels x <= 13 pixel fragments). The wide-wave form (64 channels x 7 fragments) and the hand-counted LDS read-ahead
@@ -622,7 +637,7 @@ static bool band_plan_nw(const IgemmParams& p, int NW, BandPlan* pl, bool* polic
   int th2 = 0, np2 = 0, th4 = 0, np4 = 0;
   int64_t rounds2 = 0;
   const bool fit4 = false;
-  const bool fit2 = band_fit(p, 2, 13, NW, EH, PW, &th2, &np2, &rounds2);
+  const bool fit2 = band_fit(p, 2, 13, NW, EH, PW, &th2, &np2, &rounds2, RS);
   if (!fit2 && !fit4) return false;
   const bool wide = fit4;
   const int NF = wide ? 4 : 2;
@@ -650,8 +665,12 @@ static bool band_plan_nw(const IgemmParams& p, int NW, BandPlan* pl, bool* polic
   a.lo_w = lo_w;
   a.TH = TH;
   a.bands = (p.OH + TH - 1) / TH;
-  a.PH = TH - 1 + EH;
+  a.PH = (TH - 1) * RS + EH;
   a.PW = PW;
+  a.rs = RS;
+  a.s2 = s2 ? 1 : 0;
+  a.PWo = PWo;
+  for (int j = 0; j < 3; ++j) a.coffp[j] = s2 ? (j == 0 ? 0 : j == 1 ? PWo : 1) : (c.dw0 + j * c.dw_step - lo_w);
   a.nplw = best_nplw;
   a.buf_bytes = ((a.PH * a.PW + 15) / 16) * 1024;
   a.n_tiles = n_tiles;
@@ -678,6 +697,17 @@ static bool band_plan_nw(const IgemmParams& p, int NW, BandPlan* pl, bool* polic
   // @128x256 92 vs 70) and is level on four-tile problems (512 -> 512 dilated: 149 vs 149).
   const int slots = NW == 4 ? 512 : 256;
   const int64_t rounds = (total + slots - 1) / slots;
+  if (s2) {
+    // stride-2 forward plans (round 6, second session), measured against the per-tap kernel per layer (profiles/r06_band_s2_bench.log):
+    // ahead on NARROW maps — 256 -> 256 @40 -> 20 37.4 vs 44.7 us, 256 -> 512 @40 -> 20 68.4 vs 70.8, ResNet layer4 512 -> 512 @32x64 -> 16x32
+    // 53.8 vs 56.7 — and behind on wide ones (64 -> 128 @160 -> 80 141 vs 112, 128 -> 256 @80 -> 40 100 vs 88, 256 -> 512 @64x128 122 vs 81): a
+    // stride-2 band stages 2.2 - 3 input rows per output row for every channel tile, and at one- or two-row bands the LDS-DMA, not the
+    // MFMA pipe, sets the pace (~40 B/clk/CU). Taken up to 32 output columns; CVHIP_BAND_S2=0 / CVHIP_BAND=2 for the A/B.
+    // (training forms only: with the fused inference epilogue the two kernels are level — infer 17.75 vs 17.87 k img/s)
+    const bool epi = p.bias || p.ep_scale || p.ep_act != CVHIP_ACT_NONE;
+    *policy_ok = band_env("CVHIP_BAND_S2", 1) != 0 && !epi && p.OW <= 32 && (int64_t)TH * p.OW * 10 >= (int64_t)pl->MFW * WM * 16 * 6;
+    return true;
+  }
   *policy_ok = n_tiles <= 2 && total * 10 >= rounds * slots * 9 &&                                 // >= 90 % of the block slots of every round busy
                (NC == 1 || (int64_t)TH * p.OW * 20 >= (int64_t)pl->MFW * WM * 16 * 17);          // >= 85 % of the fragment slots busy
   // Round 6: DEEP reductions (>= 8 chunks of 32 input channels: ResNet layer3 / layer4 conv2, the ASPP / reduce convolutions) are where one
@@ -698,8 +728,9 @@ static bool band_plan_nw(const IgemmParams& p, int NW, BandPlan* pl, bool* polic
 }
 
 static bool band_plan(const IgemmParams& p, BandPlan* pl) {
-  if (p.ncls != 1 || p.in_sh != 1 || p.in_sw != 1 || p.out_sh != 1 || p.out_sw != 1) return false;
+  if (p.ncls != 1 || p.in_sh != p.in_sw || (p.in_sh != 1 && p.in_sh != 2) || p.out_sh != 1 || p.out_sw != 1) return false;
   const IgemmClass& c = p.cls[0];
+  if (p.in_sh == 2 && !(c.dh0 == -1 && c.dw0 == -1 && c.dh_step == 1 && c.dw_step == 1)) return false;   // stride 2: 3x3, padding 1, dilation 1
   if (c.TR != 3 || c.TS != 3 || c.out_oh != 0 || c.out_ow != 0 || c.OHi != p.OH || c.OWi != p.OW || c.M <= 0) return false;
   if (p.pro_scale || p.z_out || p.y2 || p.x_image || p.tail_y) return false;
   if ((p.ep_scale == nullptr) != (p.ep_shift == nullptr)) return false;

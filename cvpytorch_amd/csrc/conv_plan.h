@@ -127,7 +127,13 @@ inline bool band_image_layer(const cvhip_conv_desc* d) {
   return d->R == 3 && d->S == 3 && d->stride_h == 1 && d->stride_w == 1 && (d->k_valid <= 0 || d->k_valid == d->K) &&
          (d->c_valid <= 0 || d->c_valid == d->C);
 }
-inline bool band_image_fprop(const cvhip_conv_desc* d) { return band_image_layer(d) && band_image_shape(d->K, d->C); }
+// (round 6, second session) stride-2 3x3 / padding 1 / dilation 1 layers get the forward image too: the row-band kernel runs them with a
+// patch of two column planes (conv_band.hip BandArgs::s2); their input gradient stays on the per-tap kernel's parity classes
+inline bool band_image_layer_s2(const cvhip_conv_desc* d) {
+  return d->R == 3 && d->S == 3 && d->stride_h == 2 && d->stride_w == 2 && d->pad_h == 1 && d->pad_w == 1 && d->dil_h == 1 && d->dil_w == 1 &&
+         (d->k_valid <= 0 || d->k_valid == d->K) && (d->c_valid <= 0 || d->c_valid == d->C);
+}
+inline bool band_image_fprop(const cvhip_conv_desc* d) { return (band_image_layer(d) || band_image_layer_s2(d)) && band_image_shape(d->K, d->C); }
 inline bool band_image_dgrad(const cvhip_conv_desc* d) { return band_image_layer(d) && band_image_shape(d->C, d->K); }
 // vector v of a band image -> (row n, tap, first reduction channel c0)
 __host__ __device__ __forceinline__ void band_image_decode(int64_t v, int nrows, int cin, int* n, int* tap, int* c0) {

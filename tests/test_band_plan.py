@@ -101,8 +101,18 @@ def test_band_default_policy():
             assert pl is not None and pl["NF"] == 2, (shape, dgrad)
     assert plan((64, 128, 40, 40, 128), CVHIP_BAND_NW=8)["NW"] == 8
     assert plan((64, 128, 40, 40, 128), CVHIP_BAND=0) is None
-    # stride 2, 1x1 and grouped convolutions never reach the kernel
-    d = ops.conv_desc(64, 128, 40, 40, 128, 3, 3, (2, 2), (1, 1), (1, 1), 1, 128, 128)
+    # stride 2 (round 6, second session): the FORWARD plan of a 3x3 / padding 1 / dilation 1 layer is taken — rows of two column planes,
+    # two patch rows per output row; its input gradient (stride-parity classes), other paddings, 1x1 and grouped convolutions never are
+    d = ops.conv_desc(64, 256, 40, 40, 512, 3, 3, (2, 2), (1, 1), (1, 1), 1, 256, 512)
+    buf = (C.c_int32 * L.BAND_PLAN_INTS)()
+    assert L.load().cvhip_conv2d_band_plan(C.byref(d), 0, buf) == 1
+    th, ph, pw = buf[5], buf[10], buf[11]
+    assert ph == (th - 1) * 2 + 3 and pw == 24 + 24      # odd columns 2k - 1 (k = 0 .. 20, padded to 24) + even columns (20 -> 24)
+    assert L.load().cvhip_conv2d_band_plan(C.byref(d), 1, None) == 0
+    d = ops.conv_desc(64, 256, 40, 40, 512, 3, 3, (2, 2), (0, 0), (1, 1), 1, 256, 512)
+    assert L.load().cvhip_conv2d_band_plan(C.byref(d), 0, None) == 0
+    # wide maps stay on the per-tap kernel by default (the stride-2 band is LDS-DMA-bound there: profiles/r06_band_s2_bench.log)
+    d = ops.conv_desc(64, 64, 160, 160, 128, 3, 3, (2, 2), (1, 1), (1, 1), 1, 64, 128)
     assert L.load().cvhip_conv2d_band_plan(C.byref(d), 0, None) == 0
     d = ops.conv_desc(64, 128, 40, 40, 128, 1, 1, (1, 1), (0, 0), (1, 1), 1, 128, 128)
     assert L.load().cvhip_conv2d_band_plan(C.byref(d), 0, None) == 0
@@ -127,7 +137,8 @@ def test_weight_image_sizes():
     assert sizes(64, 96) == (1, 2)
     assert sizes(8, 32) == (1, 1)           # image stem: 8 input channels
     assert sizes(128, 128, R=1) == (1, 1)   # 1x1
-    assert sizes(128, 128, stride=2)[0] == 1
+    assert sizes(128, 128, stride=2)[0] == 2        # stride-2 3x3 / padding 1: the forward image has the fragment-ordered copy (conv_band.hip s2)
+    assert sizes(96, 64, stride=2)[0] == 2 and sizes(64, 96, stride=2)[0] == 1
     assert sizes(128, 256, k_valid=255) == (1, 1)   # padded channels (the detect layers' 255 outputs)
     d = ops.conv_desc(2, 64, 24, 24, 64, 3, 3, (1, 1), (1, 1), (1, 1), 1, 64, 64)
     assert lib.cvhip_conv2d_weight_image_elems(C.byref(d), 2) == L.ERR_INVALID

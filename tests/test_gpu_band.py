@@ -76,7 +76,28 @@ BAND_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", BAND_CASES)
+# stride 2 (round 6, second session): 3x3 / padding 1 forward plans — two patch rows per output row, rows stored as two column planes
+BAND_S2_CASES = [
+    (3, 64, 160, 160, 128, 3, 3, 2, 1, 1),   # YOLOv5-s stage convolution: one-row bands of 80 pixels
+    (3, 128, 80, 80, 256, 3, 3, 2, 1, 1),    # two channel tiles
+    (2, 256, 40, 40, 512, 3, 3, 2, 1, 1),    # four channel tiles, 8 chunks
+    (2, 32, 64, 64, 64, 3, 3, 2, 1, 1),      # one chunk: single patch buffer
+    (2, 64, 21, 23, 64, 3, 3, 2, 1, 1),      # odd sizes: the last even / odd column and the last row fall outside the image
+    (3, 128, 17, 38, 128, 3, 3, 2, 1, 1),
+    (1, 96, 9, 9, 32, 3, 3, 2, 1, 1),        # three chunks, tiny map
+    (4, 128, 2, 2, 128, 3, 3, 2, 1, 1),      # 1 x 1 outputs
+]
+
+
+@pytest.mark.parametrize("case", BAND_S2_CASES)
+def test_band_s2_takes_the_kernel(case):
+    N, Cc, H, W, Kk, R, S, s, p, d = case
+    desc = ops.conv_desc(N, Cc, H, W, Kk, R, S, (s, s), (p, p), (d, d), 1, Cc, Kk)
+    assert L.load().cvhip_conv2d_band_plan(C.byref(desc), 0, None) == 1
+    assert L.load().cvhip_conv2d_band_plan(C.byref(desc), 1, None) == 0   # the input gradient stays on the stride-parity classes
+
+
+@pytest.mark.parametrize("case", BAND_CASES + BAND_S2_CASES)
 def test_band_fprop(case, force_band):
     """plain forward, no bias (ConvModule convolutions in front of a norm layer carry none, conv_module.py:112-119)"""
     _skip_unless_form_runs(case, force_band, False)
@@ -123,7 +144,7 @@ def _fused(desc, xd, wimg, y, **kw):
 
 
 @pytest.mark.parametrize("act", [L.ACT_SILU, L.ACT_RELU, L.ACT_LEAKY, L.ACT_HSWISH, L.ACT_SIGMOID, L.ACT_NONE])
-@pytest.mark.parametrize("case", [BAND_CASES[0], BAND_CASES[2], BAND_CASES[4], BAND_CASES[6], BAND_CASES[8], BAND_CASES[10]])
+@pytest.mark.parametrize("case", [BAND_CASES[0], BAND_CASES[2], BAND_CASES[4], BAND_CASES[6], BAND_CASES[8], BAND_CASES[10], BAND_S2_CASES[1], BAND_S2_CASES[4]])
 def test_band_fused_epilogue(case, act, force_band):
     """inference form (round 6): y = act((conv(x) + bias) * scale + shift) (+ residual before or after the activation) in the band
     kernel's own store pass — the eval-mode ConvModule (conv_module.py:201-214), the Darknet shortcut x + act(bn(conv)) and the ResNet
@@ -169,7 +190,7 @@ def test_band_fused_epilogue(case, act, force_band):
     close(run(bias=bd), conv + v(bias))
 
 
-@pytest.mark.parametrize("case", BAND_CASES)
+@pytest.mark.parametrize("case", BAND_CASES + BAND_S2_CASES)
 def test_band_fprop_bn_acc(case, force_band):
     """training form: raw output + BatchNorm sums folded into the layer's fp64 accumulator (cvhip_conv2d_fprop_acc)"""
     _skip_unless_form_runs(case, force_band, False)

@@ -20,6 +20,11 @@ SHAPES = [
     (64, 256, 40, 40, 512, 3, 3, 2, 1, "y5s 256->512 s2 @40"),
     (64, 128, 80, 80, 128, 3, 3, 2, 1, "y5s pan 128->128 s2 @80"),
     (64, 256, 40, 40, 256, 3, 3, 2, 1, "y5s pan 256->256 s2 @40"),
+    (16, 512, 32, 64, 512, 3, 3, 2, 1, "r50 layer4 512->512 s2 @32x64"),
+    (16, 256, 64, 128, 256, 3, 3, 2, 1, "r50 layer3 256->256 s2 @64x128"),
+    (16, 128, 128, 256, 128, 3, 3, 2, 1, "r50 layer2 128->128 s2 @128x256"),
+    (64, 512, 20, 20, 512, 3, 3, 2, 1, "y5 512->512 s2 @20"),
+    (16, 256, 64, 128, 512, 3, 3, 2, 1, "stdc 256->512 s2 @64x128"),
     (64, 256, 40, 40, 256, 1, 1, 1, 0, "y5s 256->256 k1 @40"),
     (64, 512, 20, 20, 512, 1, 1, 1, 0, "y5s 512->512 k1 @20"),
     (16, 256, 128, 256, 512, 1, 1, 2, 0, "dl 256->512 k1 s2 @128x256"),
