@@ -25,6 +25,8 @@ SHAPES = [
     (16, 128, 128, 256, 128, 3, 3, 2, 1, "r50 layer2 128->128 s2 @128x256"),
     (64, 512, 20, 20, 512, 3, 3, 2, 1, "y5 512->512 s2 @20"),
     (16, 256, 64, 128, 512, 3, 3, 2, 1, "stdc 256->512 s2 @64x128"),
+    (16, 32, 256, 512, 64, 3, 3, 1, 1, "dl stem 32->64 k3 @256x512"),
+    (64, 32, 160, 160, 32, 3, 3, 1, 1, "y5s 32->32 k3 @160 (per-tap: CVHIP_BAND=0 CVHIP_PATCH=0)"),
     (64, 256, 40, 40, 256, 1, 1, 1, 0, "y5s 256->256 k1 @40"),
     (64, 512, 20, 20, 512, 1, 1, 1, 0, "y5s 512->512 k1 @20"),
     (16, 256, 128, 256, 512, 1, 1, 2, 0, "dl 256->512 k1 s2 @128x256"),
