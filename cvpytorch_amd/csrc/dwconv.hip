@@ -441,6 +441,10 @@ struct Dw3Params {
   int N, C, IH, IW, OH, OW, ph, pw, in_ld, out_ld, dy_ld, flip, seg_len, rows_per_thread;
   int act;   // MODE 0 (fprop): fused activation
   float ap;
+  // MODE 0, LDS form only (round 6, second session): training-mode BatchNorm sums of the fp32 outputs (before the rounding to 16 bits, as
+  // the convolution epilogues take them), one partial row [2][C] per (image, row block, strip) — the reduction pass over the stored
+  // output (colreduce_kernel<0>: 587 MB per decoder layer of DeepLabv3+) is not run. NULL = none. Never with a fused activation.
+  float* stats_partial;
 };
 
 __device__ __forceinline__ f32x8 dw3_load(const h16_t* row, bool row_ok, int iw, int IW, int in_ld, int c) {
@@ -760,6 +764,10 @@ __global__ __launch_bounds__((kDwLdsCW + 1) * 64) void dw3x3_lds_kernel(const Dw
     if (MODE == 1) {
       for (int a = 0; a < 18; ++a) __syncthreads();  // the 18 barriers of the compute waves' reduction below
     }
+    if (MODE == 0 && p.stats_partial) {
+      __syncthreads();  // the 2 barriers of the compute waves' BatchNorm-sum reduction below
+      __syncthreads();
+    }
     return;
   }
 
@@ -787,6 +795,10 @@ __global__ __launch_bounds__((kDwLdsCW + 1) * 64) void dw3x3_lds_kernel(const Dw
       for (int j = 0; j < 8; ++j) acc9[a][j] = 0.f;
   }
   const int px0 = ty * PXT;  // first output pixel of this thread inside the strip
+  float bs1[MODE == 0 ? 8 : 1], bs2[MODE == 0 ? 8 : 1];  // BatchNorm sums of this thread's outputs (stats_partial)
+#pragma unroll
+  for (int jj = 0; jj < (MODE == 0 ? 8 : 1); ++jj) bs1[jj] = bs2[jj] = 0.f;
+  const bool want_stats = MODE == 0 && p.stats_partial != nullptr;
   for (int j = 0; j < nrows; ++j) {
     asm volatile("s_barrier" ::: "memory");  // the producer arrives here after rows j .. j+2 (and dy row j) have landed
     if (active) {
@@ -814,6 +826,15 @@ __global__ __launch_bounds__((kDwLdsCW + 1) * 64) void dw3x3_lds_kernel(const Dw
           }
           dw_act8(o, p.act, p.ap);
           if (ow < p.OW) *reinterpret_cast<uint4*>(p.out + ((int64_t)(n * p.OH + oh) * p.OW + ow) * p.out_ld + c) = pack8(o);
+          if constexpr (MODE == 0) {
+            if (want_stats && ow < p.OW) {
+#pragma unroll
+              for (int jj = 0; jj < 8; ++jj) {
+                bs1[jj] += o.v[jj];
+                bs2[jj] += o.v[jj] * o.v[jj];
+              }
+            }
+          }
         } else {
           // dy of pixels past the image / strip edge was staged as zeros
           const f32x8 gq = unpack8(*reinterpret_cast<const uint4*>(sD + (j % ND) * drow_bytes + ((px0 + q) * cols + tx) * 16));
@@ -824,6 +845,26 @@ __global__ __launch_bounds__((kDwLdsCW + 1) * 64) void dw3x3_lds_kernel(const Dw
 #pragma unroll
               for (int jj = 0; jj < 8; ++jj) acc9[r * 3 + s2][jj] += gq.v[jj] * win[r][q + s2].v[jj];
         }
+      }
+    }
+  }
+  if constexpr (MODE == 0) {
+    if (want_stats) {
+      __syncthreads();  // (the producer has drained its queue before it joins: the rings are dead)
+      float* const red = reinterpret_cast<float*>(dw_smem);  // NCT x 16 floats
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        red[t * 16 + jj] = active ? bs1[jj] : 0.f;
+        red[t * 16 + 8 + jj] = active ? bs2[jj] : 0.f;
+      }
+      __syncthreads();
+      const int64_t prow = ((int64_t)n * g.nrowblk + rowblk) * g.nstrip + strip;   // every row is written once by each channel chunk
+      for (int idx = t; idx < cols * 16; idx += NCT) {
+        const int x = idx >> 4, jj = idx & 15;
+        float sum = 0.f;
+        for (int yy = 0; yy < g.rpp; ++yy) sum += red[(yy * cols + x) * 16 + jj];
+        const int cc = (cvc * cols + x) * 8 + (jj & 7);
+        if (cvc * cols + x < CV) p.stats_partial[(prow * 2 + (jj >> 3)) * p.C + cc] = sum;
       }
     }
   }
@@ -848,8 +889,9 @@ __global__ __launch_bounds__((kDwLdsCW + 1) * 64) void dw3x3_lds_kernel(const Dw
 }
 
 // strip geometry + launch; false when the LDS form does not apply (then the register-window kernel runs)
+// rows_out != NULL: geometry query only — *rows_out = partial rows the stats form writes (N * row blocks * strips); nothing is launched
 template <int MODE>
-static bool dw3_lds_launch(const Dw3Params& q, hipStream_t s, int* status) {
+static bool dw3_lds_launch(const Dw3Params& q, hipStream_t s, int* status, int64_t* rows_out = nullptr) {
   static int on = -1;
   if (on < 0) {
     const char* e = getenv("CVHIP_DW3_LDS");
@@ -883,6 +925,13 @@ static bool dw3_lds_launch(const Dw3Params& q, hipStream_t s, int* status) {
   if (grid > 0x7fffffff) return false;
   const int lds = (MODE == 1 ? 5 : 6) * kx * 4096 + (MODE == 1 ? 3 * kd * 4096 : 0);
   if (lds < 256 * 8 * 4 || lds > 96 * 1024) return false;
+  if (MODE == 0 && lds < kDwLdsCW * 64 * 16 * 4) return false;   // (the stats reduction's scratch; never the case: >= 6 x 8 KB)
+  if (rows_out) {
+    const bool inst = (kx == 3 && (kd == 2 || kd == 3)) || (kx == 4 && (kd == 3 || kd == 4)) || (kx == 2 && (kd == 2 || kd == 1));
+    if (!inst) return false;
+    *rows_out = (int64_t)q.N * g.nrowblk * g.nstrip;
+    return true;
+  }
 #define CVHIP_DW3L(KXV, KDV)                                                                                                 \
   {                                                                                                                          \
     auto kern = dw3x3_lds_kernel<MODE, PXT, KXV, (MODE == 1 ? KDV : 0)>;                                                    \
@@ -984,6 +1033,52 @@ static int dw_fprop_impl(const cvhip_conv_desc* d, const void* x, const float* w
 
 int cvhip_dwconv2d_fprop(const cvhip_conv_desc* d, const void* x, const float* w, const float* bias, void* y, void* stream) {
   return dw_fprop_impl(d, x, w, bias, CVHIP_ACT_NONE, 0.f, y, stream);
+}
+
+// Forward + training-mode BatchNorm sums in one pass (3x3 / stride 1 / dilation 1 problems the LDS strip kernel runs: the decoder
+// layers of DeepLabv3+, depthwise_separable_conv_module.py:10-99 in front of their norm layer). rows = 0: not such a problem — the caller
+// runs cvhip_dwconv2d_fprop and the reduction pass. `x` / `y` only decide the alignment test of the query.
+static int dw_stats_setup(const cvhip_conv_desc* d, const void* x, const void* y, DwParams* p, Dw3Params* q) {
+  int st = fill(d, p);
+  if (st) return st;
+  p->x = (const h16_t*)x;
+  p->y = (h16_t*)y;
+  p->x_ld = d->x_ld;
+  p->y_ld = d->y_ld;
+  if (!dw3_applicable(*p, x, y, nullptr)) return CVHIP_ERR_UNSUPPORTED;
+  *q = Dw3Params{};
+  q->in = p->x; q->out = p->y;
+  q->act = CVHIP_ACT_NONE;
+  q->N = p->N; q->C = p->C; q->IH = p->H; q->IW = p->W; q->OH = p->P; q->OW = p->Q; q->ph = p->ph; q->pw = p->pw;
+  q->in_ld = p->x_ld; q->out_ld = p->y_ld; q->flip = 0;
+  return CVHIP_OK;
+}
+
+int64_t cvhip_dwconv2d_fprop_stats_rows(const cvhip_conv_desc* d, const void* x, const void* y) {
+  DwParams p;
+  Dw3Params q;
+  const int st = dw_stats_setup(d, x, y, &p, &q);
+  if (st == CVHIP_ERR_UNSUPPORTED) return 0;
+  if (st) return st;
+  int lst = CVHIP_OK;
+  int64_t rows = 0;
+  if (!dw3_lds_launch<0>(q, nullptr, &lst, &rows)) return 0;
+  return rows;
+}
+
+int cvhip_dwconv2d_fprop_stats(const cvhip_conv_desc* d, const void* x, const float* w, const float* bias, void* y, float* stats_partial,
+                               void* stream) {
+  if (!x || !w || !y || !stats_partial) return CVHIP_ERR_INVALID;
+  DwParams p;
+  Dw3Params q;
+  const int st = dw_stats_setup(d, x, y, &p, &q);
+  if (st) return st;
+  q.w = w;
+  q.bias = bias;
+  q.stats_partial = stats_partial;
+  int lst = CVHIP_OK;
+  if (dw3_lds_launch<0>(q, (hipStream_t)stream, &lst)) return lst;
+  return CVHIP_ERR_UNSUPPORTED;
 }
 
 int cvhip_dwconv2d_fprop_act(const cvhip_conv_desc* d, const void* x, const float* w, const float* bias, int32_t act, float act_param, void* y,

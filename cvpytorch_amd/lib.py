@@ -140,6 +140,8 @@ SIGNATURES = {
                                 _p, _p]),
     "cvhip_dwconv2d_fprop": (_i32, [_dp, _p, _p, _p, _p, _p]),
     "cvhip_dwconv2d_fprop_act": (_i32, [_dp, _p, _p, _p, _i32, _f32, _p, _p]),
+    "cvhip_dwconv2d_fprop_stats_rows": (_i64, [_dp, _p, _p]),
+    "cvhip_dwconv2d_fprop_stats": (_i32, [_dp, _p, _p, _p, _p, _p, _p]),
     "cvhip_dwconv2d_dgrad": (_i32, [_dp, _p, _p, _p, _p]),
     "cvhip_dwconv2d_wgrad": (_i32, [_dp, _p, _p, _p, _i32, _p]),
     "cvhip_colreduce_rows": (_i32, [_i64, _i32]),

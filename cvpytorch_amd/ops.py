@@ -59,6 +59,7 @@ _STEM_IMAGE = __import__("os").environ.get("CVHIP_STEM_IMAGE", "1") != "0"
 # CVHIP_EPI_FUSE=0 restores conv + a separate BN/activation pass (A/B switch).
 _EPI_FUSE = __import__("os").environ.get("CVHIP_EPI_FUSE", "1") != "0"
 _BN_ACC = __import__("os").environ.get("CVHIP_BN_ACC", "1") != "0"
+_DW_STATS = __import__("os").environ.get("CVHIP_DW_STATS", "1") != "0"   # depthwise 3x3 forward emits its BatchNorm sums (A/B: 0 = reduction pass)
 _BN_ACC_MAX_C = 2048
 _acc_epoch = 0
 
@@ -1293,7 +1294,18 @@ class ConvBnAct(torch.autograd.Function):
                           _ptr(bf), int(cfg.act), float(cfg.act_param), z.data_ptr(), st)
                 cfg.prod = None
                 return z
-            L.call("cvhip_dwconv2d_fprop", C.byref(desc), x.data_ptr(), wm.data_ptr(), _ptr(b), y.data_ptr(), st)
+            dw_rows = 0
+            if train_bn and _DW_STATS and Kp == K:
+                # BatchNorm sums from the strip kernel's fp32 outputs (one partial row per strip): no reduction pass over the stored output
+                dw_rows = int(lib.cvhip_dwconv2d_fprop_stats_rows(C.byref(desc), x.data_ptr(), y.data_ptr()))
+                if dw_rows < 0:
+                    L.check(dw_rows, "cvhip_dwconv2d_fprop_stats_rows")
+            if dw_rows > 0:
+                rows = dw_rows
+                partial = torch.empty((rows + L.REDUCE_SCRATCH_ROWS, 2, K), dtype=torch.float32, device=dev)
+                L.call("cvhip_dwconv2d_fprop_stats", C.byref(desc), x.data_ptr(), wm.data_ptr(), _ptr(b), y.data_ptr(), partial.data_ptr(), st)
+            else:
+                L.call("cvhip_dwconv2d_fprop", C.byref(desc), x.data_ptr(), wm.data_ptr(), _ptr(b), y.data_ptr(), st)
         else:
             desc = conv_desc(N, Cc, H, W, Kp, R, S, cfg.stride, cfg.pad, cfg.dil, 1, x_ld, Kp, kv, cv)
             # pack descriptor: contiguous pitches (the packed images do not depend on activation pitches)

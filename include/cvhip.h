@@ -116,7 +116,8 @@ int cvhip_div31_consts(int32_t d, uint32_t* mul, uint32_t* shift);
  *             (may be NULL when the layer's input needs no gradient)
  * Stride-1 3x3 layers whose channel counts the row-band kernel accepts (conv_band.hip) carry a second, FRAGMENT-ORDERED copy of the
  * same values behind each image (csrc/conv_plan.h "band image": 1 KB per MFMA weight fragment, so that a wave's fetch is contiguous):
- * the buffers must hold cvhip_conv2d_weight_image_elems(d, 0 / 1) elements — K*R*S*C, or twice that where the copy exists.
+ * the buffers must hold cvhip_conv2d_weight_image_elems(d, 0 / 1) elements — K*R*S*C, or twice that where the copy exists
+ * (stride-1 3x3 layers: both images; 3x3 / stride 2 / padding 1 layers: the forward image).
  * Replaces the implicit fp32->half weight cast autocast performs at trainer.py:179-184. */
 int64_t cvhip_conv2d_weight_image_elems(const cvhip_conv_desc* d, int which /* 0 = w_fprop, 1 = w_dgrad */);
 int cvhip_conv2d_prep_weights(const cvhip_conv_desc* d, const float* w_master_krsc,
@@ -196,6 +197,16 @@ int cvhip_dwconv2d_fprop(const cvhip_conv_desc* d, const void* x_bf16, const flo
  * DepthwiseSeparableConvModule's depthwise half is folded into w / bias — utils/fuse.py:32-54 — and only the activation remains) */
 int cvhip_dwconv2d_fprop_act(const cvhip_conv_desc* d, const void* x, const float* w_crs, const float* bias, int32_t act, float act_param,
                              void* y, void* stream);
+/* Depthwise forward + training-mode BatchNorm sums in ONE pass (round 6): the sums of the fp32 outputs (before their rounding to 16 bits,
+ * as the dense convolutions' epilogues take them) leave as partial rows [rows][2][C] in the layout cvhip_bn_finalize reads — the
+ * reduction pass over the stored output (aten::native_batch_norm's statistics half, conv_module.py:209-211 behind
+ * depthwise_separable_conv_module.py:10-99) is not run. cvhip_dwconv2d_fprop_stats_rows: the number of rows for this problem and these
+ * operand addresses, 0 when the strip kernel does not run it (then: cvhip_dwconv2d_fprop + cvhip_bn_stats_partial). The partial buffer
+ * needs rows + CVHIP_REDUCE_SCRATCH_ROWS rows like every partial buffer. */
+int64_t cvhip_dwconv2d_fprop_stats_rows(const cvhip_conv_desc* d, const void* x, const void* y);
+int cvhip_dwconv2d_fprop_stats(const cvhip_conv_desc* d, const void* x_bf16, const float* w_crs, const float* bias, void* y_bf16,
+                               float* stats_partial, void* stream);
+
 int cvhip_dwconv2d_dgrad(const cvhip_conv_desc* d, const void* dy_bf16, const float* w_crs,
                          void* dx_bf16, void* stream);
 int cvhip_dwconv2d_wgrad(const cvhip_conv_desc* d, const void* x_bf16, const void* dy_bf16,
