@@ -84,6 +84,11 @@ def main():
         def fprop(i):
             L.call("cvhip_conv2d_fprop", C.byref(pdesc), xs[i].data_ptr(), st.w_fprop.data_ptr(), None, ys[i].data_ptr(), None, stream)
 
+        acc = torch.zeros(L.BN_ACC_SHARDS, 2, K, dtype=torch.float64, device=dev)
+
+        def fprop_acc(i):
+            L.call("cvhip_conv2d_fprop_acc", C.byref(pdesc), xs[i].data_ptr(), st.w_fprop.data_ptr(), ys[i].data_ptr(), acc.data_ptr(), stream)
+
         def dgrad(i):
             L.call("cvhip_conv2d_dgrad", C.byref(pdesc), dys[i].data_ptr(), st.w_dgrad.data_ptr(), dxs[i].data_ptr(), stream)
 
@@ -95,6 +100,8 @@ def main():
             for name, env in variants:
                 os.environ.update(env)
                 res.setdefault((name, "fprop"), []).append(timed(fprop, nsets))
+                if os.environ.get("ACC"):
+                    res.setdefault((name, "fprop_acc"), []).append(timed(fprop_acc, nsets))
                 res.setdefault((name, "dgrad"), []).append(timed(dgrad, nsets))
                 res.setdefault((name, "dgrad_add"), []).append(timed(dgrad_add, nsets))
                 for k in env:
