@@ -25,6 +25,9 @@ SHAPES = [
     (16, 256, 32, 64, 256, 3, 3, 1, 1, 1, "dl 256->256 @32x64"),
     (16, 512, 32, 64, 512, 3, 3, 1, 2, 2, "dl 512->512 dil2 @32x64"),
 ]
+if os.environ.get("V7"):   # YOLOv7-l (batch 16, 1280x1280): the wide stride-1 3x3 layers of the first stages
+    SHAPES = [(16, 64, 320, 320, 64, 3, 3, 1, 1, 1, "v7 64->64 @320"), (16, 64, 640, 640, 64, 3, 3, 1, 1, 1, "v7 64->64 @640"),
+              (16, 128, 160, 160, 128, 3, 3, 1, 1, 1, "v7 128->128 @160"), (16, 256, 80, 80, 256, 3, 3, 1, 1, 1, "v7 256->256 @80")]
 if os.environ.get("STDC"):   # STDC1-Seg (batch 16, 1024x512): the 3x3 stride-1 layers of the STDC blocks, the neck and the heads
     SHAPES = [
         (16, 128, 64, 128, 64, 3, 3, 1, 1, 1, "stdc 128->64 @64x128"), (16, 64, 64, 128, 32, 3, 3, 1, 1, 1, "stdc 64->32 @64x128"),
