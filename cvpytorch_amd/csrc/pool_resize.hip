@@ -822,6 +822,57 @@ __global__ __launch_bounds__(1024) void gap_fwd_vec_kernel(const h16_t* __restri
   }
 }
 
+// ds[n][c] = sum over the pixels of dy[n][p][c] * x[n][p][c] (fp32): the gate's gradient of y = x * s[n][c] (attention-refinement / feature-
+// fusion modules, stdc_neck.py:53-58,110-114) — the torch form converted both maps to fp32, multiplied and ran a strided reduce_kernel:
+// four passes and ~110 us per module; here both maps are read once, 16 bytes per lane, in gap_fwd_vec_kernel's block shape
+__global__ __launch_bounds__(1024) void chscale_ds_kernel(const h16_t* __restrict__ dy, int ld_dy, const h16_t* __restrict__ x, int ld_x,
+                                                           float* __restrict__ ds, int N, int C, int HW) {
+  __shared__ float red[256][4][8];
+  const int n = blockIdx.y, tx = threadIdx.x & 3, ry = threadIdx.x >> 2;
+  const int c = (blockIdx.x * 4 + tx) * 8;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (c < C) {
+    const h16_t* bd = dy + (int64_t)n * HW * ld_dy + c;
+    const h16_t* bx = x + (int64_t)n * HW * ld_x + c;
+    int r = ry;
+    for (; r + 256 < HW; r += 2 * 256) {
+      uint4 ud[2], ux[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        ud[q] = *reinterpret_cast<const uint4*>(bd + (int64_t)(r + q * 256) * ld_dy);
+        ux[q] = *reinterpret_cast<const uint4*>(bx + (int64_t)(r + q * 256) * ld_x);
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f32x8 a = unpack8(ud[q]), b = unpack8(ux[q]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += a.v[j] * b.v[j];
+      }
+    }
+    for (; r < HW; r += 256) {
+      const f32x8 a = unpack8(*reinterpret_cast<const uint4*>(bd + (int64_t)r * ld_dy)), b = unpack8(*reinterpret_cast<const uint4*>(bx + (int64_t)r * ld_x));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += a.v[j] * b.v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[ry][tx][j] = acc[j];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (ry < s) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[ry][tx][j] += red[ry + s][tx][j];
+    }
+    __syncthreads();
+  }
+  if (ry == 0 && c < C) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ds[(int64_t)n * C + c + j] = red[0][tx][j];
+  }
+}
+
 __global__ __launch_bounds__(256) void gap_bwd_kernel(const h16_t* dy, h16_t* dx, int ld_dx, int N, int C, int HW) {
   const int64_t total = (int64_t)N * HW * C;
   const float inv = 1.f / (float)HW;
@@ -1200,6 +1251,14 @@ int cvhip_global_avgpool_fwd(const void* x, int32_t ld_x, void* y, int32_t N, in
   hipLaunchKernelGGL(gap_fwd_kernel, dim3(cdiv(C, 32), N), dim3(256), 0, (hipStream_t)stream, (const h16_t*)x, ld_x,
                      (h16_t*)y, N, C, HW);
   return check_launch("gap_fwd_kernel");
+}
+
+int cvhip_channel_scale_bwd_ds(const void* dy, int32_t ld_dy, const void* x, int32_t ld_x, float* ds, int32_t N, int32_t C, int32_t HW, void* stream) {
+  if (!dy || !x || !ds || N <= 0 || C <= 0 || HW <= 0) return CVHIP_ERR_INVALID;
+  if ((C & 7) || (ld_dy & 7) || (ld_x & 7) || ((((uintptr_t)dy) | ((uintptr_t)x)) & 15)) return CVHIP_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(chscale_ds_kernel, dim3(cdiv(C, 32), N), dim3(1024), 0, (hipStream_t)stream, (const h16_t*)dy, ld_dy, (const h16_t*)x, ld_x, ds, N,
+                     C, HW);
+  return check_launch("chscale_ds_kernel");
 }
 
 int cvhip_global_avgpool_bwd(const void* dy, void* dx, int32_t ld_dx, int32_t N, int32_t C, int32_t HW, void* stream) {

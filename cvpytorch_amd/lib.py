@@ -174,6 +174,7 @@ SIGNATURES = {
     "cvhip_copy2d": (_i32, [_p, _i32, _p, _i32, _i64, _i32, _p]),
     "cvhip_add2d": (_i32, [_p, _i32, _p, _i32, _p, _i32, _i64, _i32, _p]),
     "cvhip_add_act_fwd": (_i32, [_p, _i32, _p, _i32, _p, _i32, _i64, _i32, _i32, _f32, _p]),
+    "cvhip_channel_scale_bwd_ds": (_i32, [_p, _i32, _p, _i32, _p, _i32, _i32, _i32, _p]),
     "cvhip_scale_nc": (_i32, [_p, _i32, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "cvhip_seg_ce_rows": (_i32, [_i64]),
     "cvhip_seg_ce_fwd": (_i32, [_p, _i32, _p, _i64, _i32, _i32, _p, _p, _p]),

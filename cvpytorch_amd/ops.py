@@ -2347,7 +2347,13 @@ class ChannelScale(torch.autograd.Function):
             dx = empty_nhwc(N, Cc, H, W, dy.device)
             L.call("cvhip_scale_nc", dy.data_ptr(), ld, sf.data_ptr(), dx.data_ptr(), Cc, N, Cc, H * W, _stream())
         if ctx.needs_input_grad[1]:
-            ds = (dy.float() * x.float()).sum(dim=(2, 3)).reshape(ctx.s_shape).to(ctx.s_dtype)
+            x2, ldx = as_nhwc(x)
+            if Cc % 8 == 0 and ld % 8 == 0 and ldx % 8 == 0 and dy.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0:
+                dsf = torch.empty((N, Cc), dtype=torch.float32, device=dy.device)
+                L.call("cvhip_channel_scale_bwd_ds", dy.data_ptr(), ld, x2.data_ptr(), ldx, dsf.data_ptr(), N, Cc, H * W, _stream())
+                ds = dsf.reshape(ctx.s_shape).to(ctx.s_dtype)
+            else:
+                ds = (dy.float() * x.float()).sum(dim=(2, 3)).reshape(ctx.s_shape).to(ctx.s_dtype)
         return dx, ds
 
 

@@ -421,6 +421,10 @@ int cvhip_resize_bilinear_bwd_ws(const void* dy_bf16, int32_t ld_dy, void* dx_bf
 /* global average pool (AdaptiveAvgPool2d(1)) fwd/bwd: y[n][c] = mean_hw x */
 int cvhip_global_avgpool_fwd(const void* x_bf16, int32_t ld_x, void* y_bf16, int32_t N, int32_t C,
                              int32_t HW, void* stream);
+/* ds[n][c] = sum_p dy[n][p][c] * x[n][p][c] (fp32, [N][C]): the gate's gradient of the channel scaling y = x * s[n][c] of STDC's
+ * attention-refinement / feature-fusion modules (necks/seg/stdc_neck.py:53-58,110-114; aten mul + sum in the reference's backward).
+ * C % 8 == 0, pitches % 8 == 0, 16-byte-aligned bases; else CVHIP_ERR_UNSUPPORTED (the host falls back to torch). */
+int cvhip_channel_scale_bwd_ds(const void* dy, int32_t ld_dy, const void* x, int32_t ld_x, float* ds, int32_t N, int32_t C, int32_t HW, void* stream);
 int cvhip_global_avgpool_bwd(const void* dy_bf16, void* dx_bf16, int32_t ld_dx, int32_t N,
                              int32_t C, int32_t HW, void* stream);
 

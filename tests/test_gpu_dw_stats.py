@@ -99,3 +99,23 @@ def test_dw_layer_with_fused_statistics_equals_reduction_pass(monkeypatch):
         assert torch.isfinite(u).all(), n
         # the statistics differ by the rounding of the stored output only (sums of fp32 accumulators vs of 16-bit values)
         assert rel_l2(u, v) < 6e-3, (n, rel_l2(u, v))
+
+
+# ---- channel scaling y = x * s[n][c] (STDC attention-refinement / feature-fusion gates, stdc_neck.py:53-58,110-114): the gate's gradient
+# ds = sum_p dy * x through cvhip_channel_scale_bwd_ds (round 6: one pass instead of torch's convert + mul + strided reduce) -------------
+@pytest.mark.parametrize("N,Cc,H,W", [(3, 128, 16, 32), (2, 256, 32, 64), (2, 1024, 8, 8), (1, 64, 7, 5), (2, 24, 9, 9)])
+def test_channel_scale_gradients(N, Cc, H, W):
+    torch.manual_seed(3)
+    x = K.bf(torch.randn(N, Cc, H, W))
+    s = K.bf(torch.rand(N, Cc, 1, 1))
+    g = K.bf(torch.randn(N, Cc, H, W))
+    xr, sr = x.clone().requires_grad_(True), s.clone().requires_grad_(True)
+    (xr * sr).backward(g)
+    xd = x.to(dev()).to(K.BF).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    sd = s.to(dev()).to(K.BF).requires_grad_(True)
+    y = ops.channel_scale(xd, sd)
+    y.backward(g.to(dev()).to(K.BF).contiguous(memory_format=torch.channels_last))
+    torch.cuda.synchronize()
+    assert rel_l2(y.detach().float().cpu(), (x * s)) < 4e-3
+    assert rel_l2(xd.grad.float().cpu(), xr.grad) < 4e-3
+    assert rel_l2(sd.grad.float().cpu().reshape(N, Cc), sr.grad.reshape(N, Cc)) < 4e-3   # fp32 sums, one rounding to the gate's 16 bits
