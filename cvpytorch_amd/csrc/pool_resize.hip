@@ -161,10 +161,18 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolParams p) {
 // per output instead of k * k, the same answer as the row-major scan (tests/test_gpu_kernels.py compares values AND arg-max bytes
 // with max_pool2d_with_indices, ties / -inf / NaN included). Backward sums, per input pixel, the windows that selected it in the
 // gather kernel's order (bit-identical sums) from LDS copies of dy and the arg-max bytes. 24.5 / 33.6 us in the YOLOv5-s step.
-constexpr int kPoolLdsCvb = 4;        // channel vectors per block (32 channels: 512 blocks for SPPF's 64 x 256-channel maps)
-constexpr int kPoolLdsMaxPix = 1024;  // H * W limit: 1024 x 4 x 40 B = 160 KB of LDS (forward: input + row values + row arg-max)
+// Round 6 (second session): k = 9 and 13 as well (the SPP / SPPCSPC pools of YOLOX and YOLOv7, yolo_modules.py SPP / yolov7_modules.py
+// SPPCSPC: the gather kernels spent 141 - 179 us per launch on their 81 / 169 taps), and 2 or 1 channel vectors per block where 4 do not
+// fit the LDS (YOLOv7-l's 40 x 40 maps: 1600 pixels x 2 vectors x 40 B = 128 KB).
+constexpr int kPoolLdsCvbMax = 4;     // channel vectors per block (32 channels: 512 blocks for SPPF's 64 x 256-channel maps)
+constexpr int kPoolLdsMaxPix = 4096;  // H * W limit with ONE channel vector per block: 4096 x 40 B = 160 KB of LDS (forward: input + row values + row arg-max)
+static inline int pool_lds_cvb(int HW, bool bwd) {   // the widest block that fits the CU's LDS, 0 = none
+  for (int cvb = kPoolLdsCvbMax; cvb >= 1; cvb >>= 1)
+    if (HW * cvb * (bwd ? 24 : 40) <= 160 * 1024) return cvb;
+  return 0;
+}
 
-template <int K>
+template <int K, int kPoolLdsCvb>
 __global__ __launch_bounds__(256) void maxpool_s1_lds_fwd_kernel(const PoolParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char pool_smem[];
   const int CV = p.C >> 3;
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(256) void maxpool_s1_lds_fwd_kernel(const PoolParam
 
 // backward twin: dy and the arg-max bytes of one image x 4 channel vectors in the LDS, a thread per input pixel x channel vector sums the
 // windows that selected it (k * k LDS reads instead of k * k L2 gathers)
-template <int K>
+template <int K, int kPoolLdsCvb>
 __global__ __launch_bounds__(256) void maxpool_s1_lds_bwd_kernel(const PoolParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char pool_smem[];
   const int HW = p.H * p.W;
@@ -333,25 +341,26 @@ static bool pool_lds_ok(const PoolParams& p, bool bwd) {
     const char* e = getenv("CVHIP_POOL_LDS");  // 0: the gather kernels for every shape (A/B switch)
     on = (e && e[0] == '0') ? 0 : 1;
   }
-  if (!on || p.s != 1 || !(p.k & 1) || p.pad != p.k / 2 || p.OH != p.H || p.OW != p.W || (p.k != 3 && p.k != 5)) return false;   // (9 x 9 / 13 x 13: the register window would spill)
-  if ((p.C & 7) || p.H * p.W > kPoolLdsMaxPix || p.H * p.W * kPoolLdsCvb * (bwd ? 24 : 40) > 160 * 1024 || (int64_t)p.N * ((p.C / 8 + kPoolLdsCvb - 1) / kPoolLdsCvb) < 128) return false;
+  if (!on || p.s != 1 || !(p.k & 1) || p.pad != p.k / 2 || p.OH != p.H || p.OW != p.W || (p.k != 3 && p.k != 5 && p.k != 9 && p.k != 13)) return false;
+  const int cvb = pool_lds_cvb(p.H * p.W, bwd);
+  if ((p.C & 7) || p.H * p.W > kPoolLdsMaxPix || cvb == 0 || (int64_t)p.N * ((p.C / 8 + cvb - 1) / cvb) < 128) return false;
   if (bwd) return (p.ld_dy & 7) == 0 && (p.ld_dx & 7) == 0 && a16(p.dy) && a16(p.dx) && ((((uintptr_t)p.cidx) & 7) == 0);
   return (p.ld_x & 7) == 0 && (p.ld_y & 7) == 0 && a16(p.x) && a16(p.y) && (!p.idx || ((((uintptr_t)p.idx) & 7) == 0));
 }
 
-template <int K>
+template <int K, int CVB>
 static int launch_pool_lds(const PoolParams& p, bool bwd, hipStream_t s) {
+  constexpr int kPoolLdsCvb = CVB;
   const int groups = (p.C / 8 + kPoolLdsCvb - 1) / kPoolLdsCvb;
   const int lds = p.H * p.W * kPoolLdsCvb * (bwd ? 24 : 40);
-  auto kf = maxpool_s1_lds_fwd_kernel<K>;
-  auto kb = maxpool_s1_lds_bwd_kernel<K>;
+  auto kf = maxpool_s1_lds_fwd_kernel<K, CVB>;
+  auto kb = maxpool_s1_lds_bwd_kernel<K, CVB>;
   static bool attr_done[2][64] = {};
   int devid = 0;
   (void)hipGetDevice(&devid);
   bool& done = attr_done[bwd ? 1 : 0][devid & 63];
   if (!done) {
-    int cap = kPoolLdsMaxPix * kPoolLdsCvb * (bwd ? 24 : 40);
-    if (cap > 160 * 1024) cap = 160 * 1024;  // the CU's LDS (pool_lds_ok keeps every launch below it)
+    const int cap = 160 * 1024;  // the CU's LDS (pool_lds_ok keeps every launch below it)
     hipError_t e = bwd ? hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, cap)
                        : hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     if (e != hipSuccess) {
@@ -367,10 +376,18 @@ static int launch_pool_lds(const PoolParams& p, bool bwd, hipStream_t s) {
 
 static int try_pool_lds(const PoolParams& p, bool bwd, hipStream_t s) {
   if (!pool_lds_ok(p, bwd)) return -1;
+  const int cvb = pool_lds_cvb(p.H * p.W, bwd);
+#define CVHIP_POOL_K(KV)                                       \
+  if (cvb == 4) return launch_pool_lds<KV, 4>(p, bwd, s);     \
+  if (cvb == 2) return launch_pool_lds<KV, 2>(p, bwd, s);     \
+  return launch_pool_lds<KV, 1>(p, bwd, s);
   switch (p.k) {
-    case 3: return launch_pool_lds<3>(p, bwd, s);
-    default: return launch_pool_lds<5>(p, bwd, s);
+    case 3: CVHIP_POOL_K(3)
+    case 5: CVHIP_POOL_K(5)
+    case 9: CVHIP_POOL_K(9)
+    default: CVHIP_POOL_K(13)
   }
+#undef CVHIP_POOL_K
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -397,7 +397,10 @@ def test_maxpool_exact(k, s, p, Cc, H, W):
     assert torch.equal(xd.grad.float().cpu() != 0, bf(gx) != 0) or rel_l2(xd.grad.float().cpu(), gx) < 1e-3
 
 
-@pytest.mark.parametrize("k,N,Cc,H,W", [(5, 16, 512, 20, 20), (5, 8, 1024, 13, 17), (3, 32, 256, 32, 32), (5, 130, 8, 20, 20)])
+@pytest.mark.parametrize("k,N,Cc,H,W", [(5, 16, 512, 20, 20), (5, 8, 1024, 13, 17), (3, 32, 256, 32, 32), (5, 130, 8, 20, 20),
+                                         # round 6: k = 9 / 13 (SPP / SPPCSPC), and maps that fit the LDS with 2 or 1 channel vectors per block only
+                                         (9, 16, 256, 20, 20), (13, 16, 256, 20, 20), (13, 4, 512, 40, 40), (9, 4, 512, 40, 40), (5, 4, 512, 40, 40),
+                                         (13, 4, 512, 48, 64), (9, 8, 128, 11, 7)])
 def test_maxpool_lds_path_values_argmax_and_gradient(k, N, Cc, H, W):
     """stride-1 "same" pools of small maps with >= 128 (image, 64-channel) blocks run through the LDS kernels (pool_resize.hip,
     round 4): values AND arg-max bytes (tap index kh * k + kw) equal to ATen's max_pool2d_with_indices — ties (coarse values), -inf
