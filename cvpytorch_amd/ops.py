@@ -2042,6 +2042,52 @@ def sppf_chain(x0, k):
     return SppfChain.apply(x0, int(k))
 
 
+class SppParallel(torch.autograd.Function):
+    """SPP's parallel pools + concat (yolo_modules.py:165-194 with a tuple of kernel sizes: x, m5(x), m9(x), m13(x) concatenated; YOLOX's
+    backbone, yolox_csp_darknet.py) on ONE buffer, as SppfChain does for the chained form: `x0` is the [:, :c] slice of an
+    (N, (1 + len(ks)) * c, H, W) NHWC buffer that the 1x1 conv in front already wrote; every pool reads slice 0 and writes its own slice —
+    no concat copies. Backward adds every pool's gradient into slice 0 of the incoming concat gradient (cvhip_maxpool2d_bwd's accumulate
+    form): no gradient-accumulation adds, no temporaries."""
+
+    @staticmethod
+    def forward(ctx, x0, ks):
+        x0v, ld = as_nhwc(x0)
+        N, c, H, W = x0v.shape
+        nk = len(ks)
+        if ld != (1 + nk) * c:
+            raise L.CvhipError("SppParallel: x0 must be the first channel slice of an (N, (1 + len(ks)) * c, H, W) NHWC buffer")
+        st = _stream()
+        idx = torch.empty((nk, N, H, W, c), dtype=torch.uint8, device=x0v.device)
+        esz = x0v.element_size()
+        for j, k in enumerate(ks):
+            L.call("cvhip_maxpool2d_fwd", x0v.data_ptr(), ld, x0v.data_ptr() + (j + 1) * c * esz, ld, idx[j].data_ptr(), N, c, H, W, int(k), 1, int(k) // 2, st)
+        ctx.meta = (N, c, H, W, tuple(int(k) for k in ks))
+        ctx.save_for_backward(idx)
+        return x0v.as_strided((N, (1 + nk) * c, H, W), (H * W * (1 + nk) * c, 1, W * (1 + nk) * c, (1 + nk) * c))
+
+    @staticmethod
+    def backward(ctx, d):
+        (idx,) = ctx.saved_tensors
+        N, c, H, W, ks = ctx.meta
+        nk = len(ks)
+        d, ld = as_nhwc(d)
+        if ld != (1 + nk) * c or not d.is_contiguous(memory_format=torch.channels_last):
+            d = d.contiguous(memory_format=torch.channels_last).clone()
+            d, ld = as_nhwc(d)
+        elif not _OWNED_BACKWARD[0]:
+            d = d.clone(memory_format=torch.channels_last)   # (autograd's contract: see SppfChain.backward)
+            d, ld = as_nhwc(d)
+        st = _stream()
+        esz = d.element_size()
+        for j, k in enumerate(ks):   # slice 0 += maxpool_bwd_k(slice j + 1)
+            L.call("cvhip_maxpool2d_bwd", d.data_ptr() + (j + 1) * c * esz, ld, idx[j].data_ptr(), d.data_ptr(), ld, N, c, H, W, k, 1, k // 2, 1, st)
+        return d[:, :c], None
+
+
+def spp_parallel(x0, ks):
+    return SppParallel.apply(x0, tuple(ks))
+
+
 def max_pool2d(x, k, stride=None, pad=0):
     return MaxPool2d.apply(x, int(k), int(stride if stride is not None else k), int(pad))
 

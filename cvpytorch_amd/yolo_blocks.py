@@ -209,6 +209,16 @@ class SPPF(nn.Module):
             if x0.data_ptr() == buf.data_ptr():   # (the unfused fallback path of ConvModule ignores `out`)
                 return self.conv2(ops.sppf_chain(x0, self.kernel_sizes))
             x = x0
+        elif (_SPPF_CHAIN and not isinstance(self.kernel_sizes, int) and x.is_cuda and x.dim() == 4 and isinstance(self.conv1, ConvModule)
+                and self.conv1.conv.out_channels % 8 == 0 and ops.nhwc_ld(x) is not None
+                and all(isinstance(m, HipMaxPool2d) for m in self.m)):
+            # round 6: the parallel form (SPP) on one buffer too (ops.SppParallel)
+            c = self.conv1.conv.out_channels
+            buf = ops.empty_nhwc(x.shape[0], (1 + len(self.kernel_sizes)) * c, x.shape[2], x.shape[3], x.device)
+            x0 = self.conv1(x, out=buf[:, :c])
+            if x0.data_ptr() == buf.data_ptr():
+                return self.conv2(ops.spp_parallel(x0, self.kernel_sizes))
+            x = x0
         else:
             x = self.conv1(x)
         if isinstance(self.kernel_sizes, int):
